@@ -1,0 +1,264 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz from the LIVE reference (container-only; TEST INFRASTRUCTURE).
+
+Runs Sujit-O/pykg2vec (read-only at /root/reference, torch CPU fp32) on seeded inputs and freezes
+what it computes on the hot path, so that the oracle (oracle/kge_oracle.py) and the HIP path can be
+held to the reference's own numbers on the GPU box, where the reference does not exist:
+
+  * model.forward scores                      (pykg2vec/models/pairwise.py, pointwise.py)
+  * Trainer.train_step_{pairwise,pointwise} loss + autograd dense grads (utils/trainer.py:147-180)
+  * weights after 3 torch.optim steps for sgd / adam / adagrad / rms    (utils/trainer.py:112-131)
+  * Evaluator.test ranks / filtered ranks / settled metrics              (utils/evaluator.py:309-334)
+  * the same on a slice of the real FB15k TransE checkpoint examples/pretrained/TransE/model.vec.pt
+
+Usage:  python oracle/make_golden.py        (rewrites tests/golden/)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+import torch  # noqa: E402
+from pykg2vec.common import Importer  # noqa: E402
+from pykg2vec.utils.trainer import Trainer  # noqa: E402
+from pykg2vec.utils.evaluator import Evaluator  # noqa: E402
+from pykg2vec.data.kgcontroller import Triple  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+MODELS = {
+    # name -> (module.Class, hyper-parameters)
+    "transe_l1": ("pairwise.TransE", dict(hidden_size=20, l1_flag=True, margin=1.0)),
+    "transe_l2": ("pairwise.TransE", dict(hidden_size=20, l1_flag=False, margin=1.0)),
+    "transh_l1": ("pairwise.TransH", dict(hidden_size=24, l1_flag=True, margin=1.0)),
+    "transh_l2": ("pairwise.TransH", dict(hidden_size=24, l1_flag=False, margin=1.0)),
+    "transd_l1": ("pairwise.TransD", dict(ent_hidden_size=18, rel_hidden_size=18, l1_flag=True, margin=1.0)),
+    "transd_l2": ("pairwise.TransD", dict(ent_hidden_size=18, rel_hidden_size=18, l1_flag=False, margin=1.0)),
+    "rotate": ("pairwise.RotatE", dict(hidden_size=40, margin=6.0, neg_rate=4, alpha=1.0)),
+    "rescal": ("pairwise.Rescal", dict(hidden_size=12, margin=1.0)),
+    "ntn": ("pairwise.NTN", dict(ent_hidden_size=10, rel_hidden_size=6, lmbda=0.1, margin=1.0)),
+    "distmult": ("pointwise.DistMult", dict(hidden_size=22, lmbda=0.01)),
+    "complex": ("pointwise.Complex", dict(hidden_size=14, lmbda=0.01)),
+    "complexn3": ("pointwise.ComplexN3", dict(hidden_size=14, lmbda=0.01)),
+    "analogy": ("pointwise.ANALOGY", dict(hidden_size=16, lmbda=0.01)),
+}
+E, R, B = 53, 7, 32
+N_STEPS = 3
+N_TEST = 12
+
+
+class _KG:
+    """Stand-in for KnowledgeGraph.read_cache_data (data/kgcontroller.py:258-330)."""
+
+    def __init__(self, cache):
+        self.cache = cache
+        self.dataset_name = "synthetic"
+
+    def read_cache_data(self, key):
+        return self.cache[key]
+
+
+def make_graph(rng, n_train, n_valid, n_test, E_, R_):
+    tot = n_train + n_valid + n_test
+    seen, trip = set(), []
+    while len(trip) < tot:
+        x = (int(rng.integers(E_)), int(rng.integers(R_)), int(rng.integers(E_)))
+        if x not in seen:
+            seen.add(x)
+            trip.append(x)
+    trip = np.asarray(trip, dtype=np.int64)
+    return trip[:n_train], trip[n_train:n_train + n_valid], trip[n_train + n_valid:]
+
+
+def corrupt(rng, pos, train_set, E_, neg_rate):
+    nh, nr, nt = [], [], []
+    for h, r, t in pos:
+        for _ in range(neg_rate):
+            while True:
+                e = int(rng.integers(E_))
+                if rng.random() > 0.5:
+                    c = (int(h), int(r), e)
+                else:
+                    c = (e, int(r), int(t))
+                if c not in train_set:
+                    break
+            nh.append(c[0]); nr.append(c[1]); nt.append(c[2])
+    return np.asarray(nh, np.int64), np.asarray(nr, np.int64), np.asarray(nt, np.int64)
+
+
+def config_for(hp, E_, R_, train, valid, test, optimizer="sgd", lr=0.05):
+    all_t = np.concatenate([train, valid, test])
+    hr_t, tr_h = {}, {}
+    for h, r, t in all_t:
+        hr_t.setdefault((int(h), int(r)), set()).add(int(t))
+        tr_h.setdefault((int(t), int(r)), set()).add(int(h))
+    mk = lambda arr: [Triple(int(a), int(b), int(c)) for a, b, c in arr]
+    cfg = types.SimpleNamespace(
+        tot_entity=E_, tot_relation=R_, device="cpu", optimizer=optimizer, learning_rate=lr,
+        neg_rate=hp.get("neg_rate", 1), alpha=hp.get("alpha", 0.1), margin=hp.get("margin", 1.0),
+        batch_size=B, epochs=1000, test_num=N_TEST, debug=False, load_from_data=None, hits=[1, 3, 5, 10],
+        patience=3, dataset_name="synthetic", sampling="uniform",
+        knowledge_graph=_KG({"triplets_train": mk(train), "triplets_valid": mk(valid),
+                             "triplets_test": mk(test), "hr_t": hr_t, "tr_h": tr_h}))
+    for k, v in hp.items():
+        setattr(cfg, k, v)
+    cfg.summary = lambda: None
+    return cfg, hr_t, tr_h
+
+
+def build(cls_path, cfg, init_state=None):
+    mod, cls = cls_path.split(".")
+    model_def = getattr(__import__("pykg2vec.models." + mod, fromlist=[cls]), cls)
+    model = model_def(**cfg.__dict__)
+    if init_state is not None:
+        model.load_state_dict(init_state)
+    return model
+
+
+def run_eval(model, cfg, n):
+    ev = Evaluator(model, cfg)
+    model.eval()
+    with torch.no_grad():
+        ev.test(ev.test_data, n, epoch=0)
+    mc = ev.metric_calculator
+    out = {"rank_head": np.asarray(mc.rank_head, np.int64), "rank_tail": np.asarray(mc.rank_tail, np.int64),
+           "frank_head": np.asarray(mc.f_rank_head, np.int64), "frank_tail": np.asarray(mc.f_rank_tail, np.int64),
+           "mr": np.float32(mc.mr[0]), "fmr": np.float32(mc.fmr[0]), "mrr": np.float32(mc.mrr[0]),
+           "fmrr": np.float32(mc.fmrr[0])}
+    for k in cfg.hits:
+        out["hit%d" % k] = np.float32(mc.hit[(0, k)])
+        out["fhit%d" % k] = np.float32(mc.fhit[(0, k)])
+    return out
+
+
+def golden_for(name, cls_path, hp, seed):
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    train, valid, test = make_graph(rng, 400, 40, 40, E, R)
+    train_set = {tuple(map(int, x)) for x in train}
+    cfg, hr_t, tr_h = config_for(hp, E, R, train, valid, test)
+    model0 = build(cls_path, cfg)
+    init = {k: v.clone() for k, v in model0.state_dict().items()}
+    rec = {"E": E, "R": R, "B": B, "train": train, "valid": valid, "test": test}
+    for k, v in hp.items():
+        rec["hp_" + k] = np.asarray(v)
+    for k, v in init.items():
+        rec["init." + k] = v.numpy().copy()
+
+    neg_rate = hp.get("neg_rate", 1)
+    pointwise = cls_path.startswith("pointwise")
+    batches = []
+    for s in range(N_STEPS):
+        pos = train[rng.permutation(len(train))[:B]]
+        nh, nr, nt = corrupt(rng, pos, train_set, E, neg_rate)
+        if pointwise:
+            H = np.concatenate([pos[:, 0:1], nh.reshape(B, neg_rate)], 1).reshape(-1)
+            Rr = np.concatenate([pos[:, 1:2], nr.reshape(B, neg_rate)], 1).reshape(-1)
+            T = np.concatenate([pos[:, 2:3], nt.reshape(B, neg_rate)], 1).reshape(-1)
+            Y = np.tile(np.array([1] + [-1] * neg_rate, np.int64), B)
+            batches.append((H, Rr, T, Y))
+        else:
+            batches.append((pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), nh, nr, nt))
+        for i, a in enumerate(batches[-1]):
+            rec["batch%d.%d" % (s, i)] = a
+
+    # ---- forward scores + one train step's loss and autograd grads (step-0 batch, initial weights)
+    model = build(cls_path, cfg, init)
+    trainer = Trainer(model, cfg)
+    tens = [torch.LongTensor(a) for a in batches[0]]
+    model.train()
+    if pointwise:
+        rec["scores0"] = model(tens[0], tens[1], tens[2]).detach().numpy()
+        loss = trainer.train_step_pointwise(*tens)
+    else:
+        rec["scores0_pos"] = model(tens[0], tens[1], tens[2]).detach().numpy()
+        rec["scores0_neg"] = model(tens[3], tens[4], tens[5]).detach().numpy()
+        model.load_state_dict(init)  # RESCAL mutates its tables in forward; restart from init
+        loss = trainer.train_step_pairwise(*tens)
+    loss.backward()
+    rec["loss0"] = np.float32(loss.item())
+    for k, p in model.named_parameters():
+        rec["grad0." + k] = p.grad.numpy().copy()
+    for k, v in model.state_dict().items():
+        rec["after_fwd0." + k] = v.numpy().copy()  # == init except RESCAL (normalised in place)
+
+    # ---- N_STEPS optimiser steps for each optimiser
+    for opt in ("sgd", "adam", "adagrad", "rms"):
+        cfg_o, _, _ = config_for(hp, E, R, train, valid, test, optimizer=opt, lr=0.05)
+        model = build(cls_path, cfg_o, init)
+        tr = Trainer(model, cfg_o)
+        tr.build_model()
+        losses = []
+        for s in range(N_STEPS):
+            tens = [torch.LongTensor(a) for a in batches[s]]
+            model.train()
+            tr.optimizer.zero_grad()
+            loss = tr.train_step_pointwise(*tens) if pointwise else tr.train_step_pairwise(*tens)
+            loss.backward()
+            tr.optimizer.step()
+            losses.append(loss.item())
+        rec["%s.losses" % opt] = np.asarray(losses, np.float32)
+        for k, v in model.state_dict().items():
+            rec["%s.final.%s" % (opt, k)] = v.numpy().copy()
+        if opt == "adam":
+            trained = {k: v.clone() for k, v in model.state_dict().items()}
+
+    # ---- evaluation with the adam-trained weights: Evaluator.test on N_TEST test triples
+    model = build(cls_path, cfg, trained)
+    ev = run_eval(model, cfg, N_TEST)
+    for k, v in ev.items():
+        rec["eval." + k] = v
+    for k, v in model.state_dict().items():
+        rec["eval.after." + k] = v.numpy().copy()
+    # full score vectors for the first 4 test triples (tail sweep then head sweep)
+    model.eval()
+    with torch.no_grad():
+        ents = torch.arange(E)
+        sw = []
+        for h, r, t in test[:4]:
+            sw.append(model(torch.full((E,), int(h)), torch.full((E,), int(r)), ents).numpy())
+            sw.append(model(ents, torch.full((E,), int(r)), torch.full((E,), int(t))).numpy())
+    rec["eval.sweeps"] = np.stack(sw)
+    np.savez_compressed(os.path.join(OUT, "ref_%s.npz" % name), **rec)
+    print("wrote", name, "loss0=%.6f" % rec["loss0"], "fmr=%.3f" % ev["fmr"])
+
+
+def golden_pretrained():
+    """Real trained FB15k TransE weights (examples/pretrained/TransE/model.vec.pt; d=50, L1):
+    a [0:1500] entity / [0:200] relation slice keeps the fixture small."""
+    sd = torch.load(os.path.join(ref_shim.REFERENCE_ROOT, "examples/pretrained/TransE/model.vec.pt"))
+    Es, Rs = 1500, 200
+    ent = sd["ent_embeddings.weight"][:Es].clone()
+    rel = sd["rel_embeddings.weight"][:Rs].clone()
+    rng = np.random.default_rng(77)
+    hp = dict(hidden_size=50, l1_flag=True, margin=1.0)
+    train, valid, test = make_graph(rng, 6000, 200, 200, Es, Rs)
+    cfg, hr_t, tr_h = config_for(hp, Es, Rs, train, valid, test)
+    rec = {"E": Es, "R": Rs, "train": train, "valid": valid, "test": test,
+           "init.ent_embeddings.weight": ent.numpy(), "init.rel_embeddings.weight": rel.numpy(),
+           "hp_hidden_size": np.asarray(50), "hp_margin": np.asarray(1.0)}
+    ids = [rng.integers(Es, size=4096), rng.integers(Rs, size=4096), rng.integers(Es, size=4096)]
+    rec["ids.h"], rec["ids.r"], rec["ids.t"] = ids
+    for l1 in (True, False):
+        cfg.l1_flag = l1
+        model = build("pairwise.TransE", cfg, {"ent_embeddings.weight": ent, "rel_embeddings.weight": rel})
+        with torch.no_grad():
+            rec["scores_l1" if l1 else "scores_l2"] = model(*[torch.LongTensor(a) for a in ids]).numpy()
+        ev = run_eval(model, cfg, 40)
+        for k, v in ev.items():
+            rec["eval_%s.%s" % ("l1" if l1 else "l2", k)] = v
+    np.savez_compressed(os.path.join(OUT, "ref_pretrained_transe_fb15k.npz"), **rec)
+    print("wrote pretrained slice")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    for i, (name, (cls_path, hp)) in enumerate(MODELS.items()):
+        golden_for(name, cls_path, hp, seed=1000 + i)
+    golden_pretrained()

@@ -1,0 +1,124 @@
+"""Pin the CPU oracle (oracle/kge_oracle.py) to the frozen outputs of the live reference.
+
+tests/golden/ref_*.npz were produced by oracle/make_golden.py importing /root/reference
+(pykg2vec v0.0.52 on torch 2.10 CPU fp32).  No GPU needed."""
+import numpy as np
+import pytest
+
+import kge_oracle as ko
+from golden_util import CASES, Case, close
+
+OPT_TOL = dict(atol=2e-5, rtol=2e-5)  # three dense optimiser steps compound fp32 rounding
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_scores(name):
+    c = Case(name)
+    P = c.params()
+    b = c.batch(0)
+    if c.model == "rescal":
+        P = ko.rescal_normalize_tables(P)
+    if c.pointwise:
+        got = ko.score(c.model, P, b[0], b[1], b[2], **c.hp)
+        assert close(got, c.z["scores0"])
+    else:
+        assert close(ko.score(c.model, P, b[0], b[1], b[2], **c.hp), c.z["scores0_pos"])
+        assert close(ko.score(c.model, P, b[3], b[4], b[5], **c.hp), c.z["scores0_neg"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_step_loss_and_dense_grads(name):
+    c = Case(name)
+    loss, G, _, Pafter = ko.train_step_grads(c.model, c.params(), c.batch(0), **c.hp)
+    assert close(loss, c.z["loss0"]), (loss, c.z["loss0"])
+    for k, g in G.items():
+        ref = c.z["grad0.%s.weight" % k]
+        assert g.shape == ref.shape
+        assert close(g, ref, atol=2e-5), (k, np.abs(g - ref).max())
+    for k, v in Pafter.items():  # RESCAL's in-place renormalisation is part of the contract
+        assert close(v, c.z["after_fwd0.%s.weight" % k])
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam", "adagrad", "rms"])
+@pytest.mark.parametrize("name", CASES)
+def test_three_optimizer_steps(name, opt):
+    c = Case(name)
+    P = c.params()
+    st = ko.optimizer_init(opt, P)
+    losses = []
+    for s in range(3):
+        loss, G, _, Pn = ko.train_step_grads(c.model, P, c.batch(s), **c.hp)
+        for k in P:  # forward side effects (RESCAL) land in the weights before the step
+            P[k][...] = Pn[k]
+        ko.optimizer_step(opt, P, G, st, lr=0.05)
+        losses.append(loss)
+    assert close(np.asarray(losses), c.z["%s.losses" % opt], **OPT_TOL)
+    for k, v in P.items():
+        ref = c.z["%s.final.%s.weight" % (opt, k)]
+        assert close(v, ref, atol=1e-4, rtol=1e-4), (k, np.abs(v - ref).max())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_eval_sweeps_and_ranks(name):
+    c = Case(name)
+    P = c.params("adam.final.")
+    if c.model == "rescal":
+        P = ko.rescal_normalize_tables(P)
+    sw = c.z["eval.sweeps"]
+    for i, (h, r, t) in enumerate(c.test[:4]):
+        assert close(ko.sweep_scores(c.model, P, h, r, t, "tail", **c.hp), sw[2 * i])
+        assert close(ko.sweep_scores(c.model, P, h, r, t, "head", **c.hp), sw[2 * i + 1])
+    hr_t, tr_h = c.filters()
+    n = len(c.z["eval.rank_head"])
+    metrics, ranks = ko.evaluate(c.model, c.params("adam.final."), c.test[:n], hr_t, tr_h, **c.hp)
+    # integer ranks: exact unless an fp32 near-tie flips one (checked by the band test below)
+    for key, ref in (("head", "rank_head"), ("tail", "rank_tail"), ("fhead", "frank_head"), ("ftail", "frank_tail")):
+        assert np.array_equal(ranks[key], c.z["eval." + ref]), (key, ranks[key], c.z["eval." + ref])
+    for k in ("mr", "fmr", "mrr", "fmrr", "hit10", "fhit10", "hit1", "fhit3"):
+        assert np.isclose(metrics[k], c.z["eval." + k], rtol=1e-6), k
+
+
+@pytest.mark.parametrize("name", CASES[:4])
+def test_rank_logic_bit_exact_given_scores(name):
+    """The ordering scan of MetricCalculator (evaluator.py:70-123) and the sort-free count agree
+    exactly on the reference's own score vectors."""
+    c = Case(name)
+    hr_t, tr_h = c.filters()
+    sw = c.z["eval.sweeps"]
+    for i, (h, r, t) in enumerate(c.test[:4]):
+        for side, s, true, known in (("tail", sw[2 * i], int(t), hr_t[(int(h), int(r))]),
+                                     ("head", sw[2 * i + 1], int(h), tr_h[(int(t), int(r))])):
+            order_desc = np.argsort(-s, kind="stable")
+            assert ko.rank_from_ordering(order_desc, true, known) == ko.rank_from_scores(s, true, known)
+
+
+def test_pretrained_fb15k_transe_slice():
+    z = np.load(__import__("os").path.join(__import__("golden_util").GOLDEN, "ref_pretrained_transe_fb15k.npz"))
+    P = {"ent_embeddings": z["init.ent_embeddings.weight"], "rel_embeddings": z["init.rel_embeddings.weight"]}
+    for l1, key in ((True, "l1"), (False, "l2")):
+        got = ko.score("transe", P, z["ids.h"], z["ids.r"], z["ids.t"], l1_flag=l1)
+        assert close(got, z["scores_" + key])
+        allt = np.concatenate([z["train"], z["valid"], z["test"]])
+        hr_t, tr_h = ko.build_filters(allt)
+        n = len(z["eval_%s.rank_head" % key])
+        metrics, ranks = ko.evaluate("transe", P, z["test"][:n], hr_t, tr_h, l1_flag=l1)
+        same = sum(int(np.sum(ranks[a] == z["eval_%s.%s" % (key, b)])) for a, b in
+                   (("head", "rank_head"), ("tail", "rank_tail"), ("fhead", "frank_head"), ("ftail", "frank_tail")))
+        assert same >= 4 * n - 2, same  # fp32 near-ties may flip at most a couple of ranks by one
+        assert np.isclose(metrics["fmr"], z["eval_%s.fmr" % key], rtol=2e-3)
+
+
+def test_corruption_never_emits_train_triple_and_bern_prob():
+    rng = np.random.default_rng(3)
+    c = Case("transe_l1")
+    train_set = {tuple(map(int, x)) for x in c.train}
+    prob = ko.bern_probability(c.train, c.R)
+    assert np.all((prob >= 0) & (prob <= 1))
+    nh, nr, nt = ko.corrupt_batch(c.train[:64], train_set, c.E, 3, prob, rng)
+    assert len(nh) == 64 * 3
+    for i, (a, b, d) in enumerate(zip(nh, nr, nt)):
+        assert (int(a), int(b), int(d)) not in train_set
+        ph, pr, pt = c.train[i // 3]
+        assert b == pr and ((a == ph) != (d == pt) or (a == ph and d == pt) is False)
+    H, R, T, Y = ko.pointwise_layout(c.train[:64], nh, nr, nt, 3)
+    assert len(H) == 64 * 4 and set(Y.tolist()) == {1, -1} and np.array_equal(H[::4], c.train[:64, 0])
