@@ -55,7 +55,10 @@ def test_three_optimizer_steps(name, opt):
     assert close(np.asarray(losses), c.z["%s.losses" % opt], **OPT_TOL)
     for k, v in P.items():
         ref = c.z["%s.final.%s.weight" % (opt, k)]
-        assert close(v, ref, atol=1e-4, rtol=1e-4), (k, np.abs(v - ref).max())
+        # RMSprop's first steps divide by sqrt(0.01*g^2): |update| ~ 10*lr whatever |g| is, so fp32
+        # noise in near-zero gradient entries is amplified; it gets a wider absolute band.
+        tol = 2e-3 if opt == "rms" else 1e-4
+        assert close(v, ref, atol=tol, rtol=1e-4), (k, np.abs(v - ref).max())
 
 
 @pytest.mark.parametrize("name", CASES)
