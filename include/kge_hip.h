@@ -1,0 +1,147 @@
+/*
+ * kge_hip.h -- C ABI of the MI355X (gfx950) KGE scoring / training / ranking path.
+ *
+ * This is the drop-in boundary: a plain C shared library (libkge_hip.so), no torch or C++ types in
+ * any signature.  The reference (Sujit-O/pykg2vec v0.0.52) is pure Python on PyTorch and has no FFI
+ * of its own; each entry point below replaces the chain of stock ATen ops the reference issues at
+ * the cited site (paths relative to the reference tree), and INTEGRATION.md shows the ctypes stub a
+ * pykg2vec maintainer would add to call it.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory,
+ *     the library never allocates device memory (workspaces are passed in), so every call is
+ *     hipGraph-capturable;
+ *   - tables are fp32 row-major [rows, dim] exactly as nn.Embedding stores them (models/Domain.py:8-17),
+ *     ids are int64 (torch.LongTensor, utils/trainer.py:288-293), scores fp32;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and never synchronise;
+ *   - return 0 on success, negative on error; kge_last_error() gives the message (thread-local);
+ *   - stateless and re-entrant; one process per GPU for multi-GPU use.
+ */
+#ifndef KGE_HIP_H
+#define KGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGE_ABI_VERSION 1
+#define KGE_MAX_TABLES 6
+
+/* model ids; tables[] order == the reference's `parameter_list` order */
+enum kge_model {
+    KGE_TRANSE = 0,   /* pairwise.py:12-93    tables: ent_embeddings, rel_embeddings */
+    KGE_TRANSH = 1,   /* pairwise.py:96-182   + w */
+    KGE_TRANSD = 2,   /* pairwise.py:185-278  ent_embeddings, rel_embeddings, ent_mappings, rel_mappings */
+    KGE_ROTATE = 3,   /* pairwise.py:727-791  ent_embeddings(real), ent_embeddings_imag, rel_embeddings */
+    KGE_RESCAL = 4,   /* pairwise.py:794-865  ent_embeddings, rel_matrices[R, k*k] */
+    KGE_NTN = 5,      /* pairwise.py:868-963  ent, rel, mr1, mr2, br, mr */
+    KGE_DISTMULT = 6, /* pointwise.py:391-458 ent_embeddings, rel_embeddings */
+    KGE_COMPLEX = 7,  /* pointwise.py:122-238 ent_real, ent_img, rel_real, rel_img (also ComplexN3) */
+    KGE_ANALOGY = 8   /* pointwise.py:13-119  ent, rel, ent_real, ent_img, rel_real, rel_img */
+};
+
+#define KGE_FLAG_L1 1u /* l1_flag of TransE/TransH/TransD (pairwise.py:72-76) */
+
+enum kge_optimizer { KGE_OPT_SGD = 0, KGE_OPT_ADAM = 1, KGE_OPT_ADAGRAD = 2, KGE_OPT_RMSPROP = 3 };
+enum kge_reg { KGE_REG_NONE = 0, KGE_REG_F2 = 1, KGE_REG_N3 = 2, KGE_REG_N3_ABS = 3 };
+
+typedef struct kge_model_desc {
+    int32_t model;              /* enum kge_model */
+    uint32_t flags;             /* KGE_FLAG_* */
+    int64_t tot_entity;
+    int64_t tot_relation;
+    int32_t dim;                /* hidden_size / ent_hidden_size */
+    int32_t rel_dim;            /* rel_hidden_size (NTN, TransD); == dim otherwise */
+    float margin;               /* RotatE: margin in the score (pairwise.py:791) */
+    float phase_scale;          /* RotatE: pi / embedding_range, embedding_range=(margin+2)/dim (pairwise.py:747,781) */
+    const float* tables[KGE_MAX_TABLES]; /* parameter tables, parameter_list order */
+    float* grads[KGE_MAX_TABLES];        /* dense gradient buffers of the same shapes (may be NULL for forward) */
+} kge_model_desc;
+
+int kge_abi_version(void);
+const char* kge_last_error(void);
+
+/* Model.forward(h, r, t) -> energies[n]   (pairwise.py:56-76,166-174,270-278,786-791,855-860,955-960;
+ * pointwise.py:97-104,185-188,444-446).  RESCAL: call kge_rescal_normalize first (its forward does). */
+int kge_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                      int64_t n, float* scores, void* stream);
+
+/* Autograd backward of the above: grads[table] += d(sum_i dscore[i]*score_i)/d table, dense
+ * (nn.Embedding sparse=False, models/Domain.py:8-13).  Replaces loss.backward() utils/trainer.py:298. */
+int kge_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                       int64_t n, const float* dscore, void* stream);
+
+/* Rescal.embed side effect (pairwise.py:843-844,862-865): W <- W / ||W_row||_2 in place, both tables. */
+int kge_rescal_normalize(float* ent, int64_t tot_entity, float* rel, int64_t tot_relation, int32_t k,
+                         void* stream);
+
+/* Fused Trainer.train_step_pairwise (utils/trainer.py:147-157) with Criterion.pairwise_hinge
+ * (utils/criterion.py:25-29): scores both triples of each of the n pairs, adds sum(max(0, s+ + margin - s-))
+ * to *loss and the loss gradient to m->grads.  neg_rate must be 1 (the hinge adds [B] to [B*neg_rate]). */
+int kge_train_pairwise_hinge(const kge_model_desc* m,
+                             const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                             const int64_t* nh, const int64_t* nr, const int64_t* nt,
+                             int64_t n, float margin, float* loss, void* stream);
+
+/* Fused train_step_pairwise with Criterion.pariwise_logistic (utils/criterion.py:13-23; RotatE):
+ * self-adversarial weights softmax(alpha * -s-) over the neg_rate negatives of each positive (detached).
+ * Negatives of positive i are rows [i*neg_rate, (i+1)*neg_rate) (data/generator.py:71-95).
+ * workspace: at least n_pos*(1+neg_rate) floats. */
+int kge_train_pairwise_selfadv(const kge_model_desc* m,
+                               const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                               const int64_t* nh, const int64_t* nr, const int64_t* nt,
+                               int64_t n_pos, int32_t neg_rate, float alpha, float* workspace,
+                               float* loss, void* stream);
+
+/* Fused Trainer.train_step_pointwise (utils/trainer.py:176-180): Criterion.pointwise_logistic
+ * (utils/criterion.py:31-34) mean(softplus(y*s)) + lmbda*get_reg (pointwise.py:106-119,190-202,224-238,448-458). */
+int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r,
+                                 const int64_t* t, const int64_t* y, int64_t n, float lmbda,
+                                 int32_t reg_type, float* loss, void* stream);
+
+/* Dense optimiser sweep with torch.optim defaults (utils/trainer.py:112-131): SGD, Adam(0.9,0.999,1e-8),
+ * Adagrad(eps 1e-10), RMSprop(alpha .99, eps 1e-8).  state1/state2: exp_avg/exp_avg_sq (Adam),
+ * sum / square_avg in state1 (Adagrad / RMSprop).  step is 1-based.  zero_grad != 0 also clears grad
+ * (optimizer.zero_grad(), utils/trainer.py:272) in the same pass. */
+int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, float* state2,
+                       int64_t numel, float lr, int64_t step, int32_t zero_grad, void* stream);
+
+/* Filtered-rank evaluation: Evaluator.test (utils/evaluator.py:309-334) + MetricCalculator.get_tail_rank /
+ * get_head_rank (utils/evaluator.py:70-123) for n test triples, without materialising scores or orderings.
+ *   triples        int64 [n,3] (h, r, t)
+ *   tail_off/ids   CSR over queries: known tails of (h_i, r_i) = hr_t[(h,r)]  (int64 [n+1], int32 ids)
+ *   head_off/ids   CSR over queries: known heads of (t_i, r_i) = tr_h[(t,r)]
+ *   ranks          int32 [4,n]: rank_head, rank_tail, filtered_rank_head, filtered_rank_tail (0-based, as the
+ *                  reference before settle() adds 1); rank = #{e : s_e < s_true}
+ * workspace from kge_eval_workspace_bytes(). */
+size_t kge_eval_workspace_bytes(const kge_model_desc* m, int64_t n);
+int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n,
+                   const int64_t* tail_off, const int32_t* tail_ids,
+                   const int64_t* head_off, const int32_t* head_ids,
+                   void* workspace, size_t workspace_bytes, int32_t* ranks, void* stream);
+
+/* Evaluator.test_tail_rank / test_head_rank score vectors (utils/evaluator.py:249-273) through the sweep
+ * kernels: for each of the n triples, scores[2i][e] = energy of (h_i, r_i, e) and scores[2i+1][e] = energy of
+ * (e, r_i, t_i) for every entity e.  scores: float [2n, E].  Used by the predict_tail_rank / predict_head_rank
+ * hooks (n = 1) and by parity tests.  Same workspace as kge_eval_ranks. */
+int kge_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n,
+                          void* workspace, size_t workspace_bytes, float* scores, void* stream);
+
+/* Negative corruption (data/generator.py:42-97,125-156) on device.
+ *   kge_triple_set_build: open-addressing set of packed (h,r,t) train triples; slots = power of two >= 2n.
+ *   kge_corrupt: for each positive and each of neg_rate slots draw u (Philox4x32-10 keyed by seed, counter =
+ *   global slot index): u > prob[r] (bern) or 0.5 -> replace tail else head; redraw while the corrupted triple
+ *   is in the train set. */
+int kge_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, int64_t n_slots, void* stream);
+int kge_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t n_pos, int32_t neg_rate,
+                int64_t tot_entity, const float* bern_prob /* NULL = uniform 0.5 */,
+                const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset,
+                int64_t* nh, int64_t* nr, int64_t* nt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGE_HIP_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of libkge_hip.so (C ABI in include/kge_hip.h).
+
+The HIP library IS the product path: if it is missing or a call fails this module raises -- there is no
+CPU / PyTorch fallback anywhere in `pykg2vec_amd`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkge_hip.so")
+
+KGE_MAX_TABLES = 6
+ABI_VERSION = 1
+
+# enum kge_model
+TRANSE, TRANSH, TRANSD, ROTATE, RESCAL, NTN, DISTMULT, COMPLEX, ANALOGY = range(9)
+FLAG_L1 = 1
+OPT_SGD, OPT_ADAM, OPT_ADAGRAD, OPT_RMSPROP = range(4)
+REG_NONE, REG_F2, REG_N3, REG_N3_ABS = range(4)
+LOSS_SLOTS, LOSS_STRIDE = 32, 32  # loss accumulators: float[32*32], total = sum of [k*32]
+
+c_i64p = ctypes.c_void_p  # all device pointers travel as void*
+
+
+class ModelDesc(ctypes.Structure):
+    """struct kge_model_desc"""
+    _fields_ = [
+        ("model", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("tot_entity", ctypes.c_int64),
+        ("tot_relation", ctypes.c_int64),
+        ("dim", ctypes.c_int32),
+        ("rel_dim", ctypes.c_int32),
+        ("margin", ctypes.c_float),
+        ("phase_scale", ctypes.c_float),
+        ("tables", ctypes.c_void_p * KGE_MAX_TABLES),
+        ("grads", ctypes.c_void_p * KGE_MAX_TABLES),
+    ]
+
+
+_SIGNATURES = {
+    "kge_abi_version": (ctypes.c_int, []),
+    "kge_last_error": (ctypes.c_char_p, []),
+    "kge_score_forward": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_score_backward": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_rescal_normalize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
+    "kge_train_pairwise_hinge": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_train_pairwise_selfadv": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_train_pointwise_logistic": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_float, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_optimizer_step": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_float, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
+    "kge_eval_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc), ctypes.c_int64]),
+    "kge_eval_ranks": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_eval_sweep_scores": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_triple_set_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "kge_corrupt": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64] + [ctypes.c_void_p] * 3 + [ctypes.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class KgeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libkge_hip.so (once).  Raises if it has not been built: build with
+    `python -c 'import __graft_entry__ as g; g.build()'` or `make -C pykg2vec_amd/csrc`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KgeHipError("libkge_hip.so not found at %s -- the HIP extension is mandatory (no CPU fallback); "
+                          "run __graft_entry__.build()" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kge_abi_version() != ABI_VERSION:
+        raise KgeHipError("libkge_hip.so ABI %d != expected %d" % (lib.kge_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().kge_last_error()
+        raise KgeHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

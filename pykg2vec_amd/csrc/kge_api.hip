@@ -1,0 +1,214 @@
+// kge_api.hip -- the extern "C" boundary of libkge_hip.so (declared in include/kge_hip.h): argument validation,
+// error strings, dispatch to the launchers.  No device memory is allocated and no stream is synchronised here.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "kge_internal.h"
+
+namespace kge {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+bool is_vector_model(int model) {
+    switch (model) {
+        case KGE_TRANSE: case KGE_TRANSH: case KGE_TRANSD: case KGE_ROTATE:
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_ANALOGY: return true;
+        default: return false;
+    }
+}
+
+bool pick_geometry(int d, Geometry* out) {
+    if (d <= 0) return false;
+    if (d <= 32) *out = {32, 1};
+    else if (d <= 64) *out = {32, 2};
+    else if (d <= 128) *out = {32, 4};
+    else if (d <= 256) *out = {32, 8};
+    else if (d <= 512) *out = {64, 8};
+    else if (d <= 1024) *out = {64, 16};
+    else return false;
+    return true;
+}
+
+static int table_count(int model) {
+    switch (model) {
+        case KGE_TRANSE: case KGE_DISTMULT: case KGE_RESCAL: return 2;
+        case KGE_TRANSH: case KGE_ROTATE: return 3;
+        case KGE_TRANSD: case KGE_COMPLEX: return 4;
+        case KGE_NTN: case KGE_ANALOGY: return 6;
+    }
+    return -1;
+}
+
+DeviceModel to_device_model(const kge_model_desc* m) {
+    DeviceModel d;
+    for (int i = 0; i < KGE_MAX_TABLES; ++i) { d.tab[i] = m->tables[i]; d.grad[i] = m->grads[i]; }
+    d.dim = m->dim;
+    d.rel_dim = m->rel_dim;
+    d.l1 = (m->flags & KGE_FLAG_L1) ? 1 : 0;
+    d.margin = m->margin;
+    d.phase_div = m->phase_scale != 0.f ? 1.0f / m->phase_scale : 1.0f;
+    return d;
+}
+
+static int validate(const kge_model_desc* m, bool need_grads, const char* who) {
+    if (!m) { set_error("%s: null model descriptor", who); return -1; }
+    const int nt = table_count(m->model);
+    if (nt < 0) { set_error("%s: unknown model id %d", who, m->model); return -1; }
+    if (m->dim <= 0 || m->tot_entity <= 0 || m->tot_relation <= 0) {
+        set_error("%s: bad sizes (dim %d, entities %lld, relations %lld)", who, m->dim, (long long)m->tot_entity,
+                  (long long)m->tot_relation);
+        return -1;
+    }
+    if (m->model == KGE_TRANSD && m->rel_dim != m->dim) {
+        set_error("%s: TransD needs ent_hidden_size == rel_hidden_size (pairwise.py:277-278 broadcasts them)", who);
+        return -1;
+    }
+    if (m->model == KGE_ANALOGY && (m->dim & 1)) { set_error("%s: ANALOGY needs an even hidden size", who); return -1; }
+    for (int i = 0; i < nt; ++i) {
+        if (!m->tables[i]) { set_error("%s: table %d is null", who, i); return -1; }
+        if (need_grads && !m->grads[i]) { set_error("%s: gradient buffer %d is null", who, i); return -1; }
+    }
+    return 0;
+}
+
+}  // namespace kge
+
+using namespace kge;
+
+extern "C" {
+
+int kge_abi_version(void) { return KGE_ABI_VERSION; }
+const char* kge_last_error(void) { return g_err; }
+
+int kge_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+                      float* scores, void* stream) {
+    if (validate(m, false, "kge_score_forward")) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || !h || !r || !t || !scores) { set_error("kge_score_forward: bad arguments"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (m->model == KGE_RESCAL) return launch_rescal_forward(m, h, r, t, n, scores, s);
+    if (m->model == KGE_NTN) return launch_ntn_forward(m, h, r, t, n, scores, s);
+    return launch_score_forward(m, h, r, t, n, scores, s);
+}
+
+int kge_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+                       const float* dscore, void* stream) {
+    if (validate(m, true, "kge_score_backward")) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || !h || !r || !t || !dscore) { set_error("kge_score_backward: bad arguments"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (m->model == KGE_RESCAL) return launch_rescal_backward(m, h, r, t, n, dscore, s);
+    if (m->model == KGE_NTN) return launch_ntn_backward(m, h, r, t, n, dscore, s);
+    return launch_score_backward(m, h, r, t, n, dscore, s);
+}
+
+int kge_rescal_normalize(float* ent, int64_t tot_entity, float* rel, int64_t tot_relation, int32_t k, void* stream) {
+    if (!ent || !rel || k <= 0) { set_error("kge_rescal_normalize: bad arguments"); return -1; }
+    return launch_rescal_normalize(ent, tot_entity, rel, tot_relation, k, (hipStream_t)stream);
+}
+
+int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                             const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float margin,
+                             float* loss, void* stream) {
+    if (validate(m, true, "kge_train_pairwise_hinge")) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || !ph || !pr || !pt || !nh || !nr || !nt || !loss) { set_error("kge_train_pairwise_hinge: bad arguments"); return -1; }
+    if (!is_vector_model(m->model)) {
+        set_error("kge_train_pairwise_hinge: model %d trains through kge_score_forward/backward", m->model);
+        return -1;
+    }
+    return launch_pairwise_hinge(m, ph, pr, pt, nh, nr, nt, n, margin, loss, (hipStream_t)stream);
+}
+
+int kge_train_pairwise_selfadv(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                               const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n_pos,
+                               int32_t neg_rate, float alpha, float* workspace, float* loss, void* stream) {
+    if (validate(m, true, "kge_train_pairwise_selfadv")) return -1;
+    if (n_pos == 0) return 0;
+    if (n_pos < 0 || neg_rate <= 0 || !ph || !pr || !pt || !nh || !nr || !nt || !workspace || !loss) {
+        set_error("kge_train_pairwise_selfadv: bad arguments");
+        return -1;
+    }
+    if (!is_vector_model(m->model)) { set_error("kge_train_pairwise_selfadv: unsupported model %d", m->model); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    float* spos = workspace;
+    float* sneg = workspace + n_pos;
+    const int64_t n_neg = n_pos * neg_rate;
+    int rc;
+    if ((rc = launch_score_forward(m, ph, pr, pt, n_pos, spos, s))) return rc;
+    if ((rc = launch_score_forward(m, nh, nr, nt, n_neg, sneg, s))) return rc;
+    if ((rc = launch_selfadv_coeffs(spos, sneg, n_pos, neg_rate, alpha, loss, s))) return rc;
+    if ((rc = launch_score_backward(m, ph, pr, pt, n_pos, spos, s))) return rc;
+    return launch_score_backward(m, nh, nr, nt, n_neg, sneg, s);
+}
+
+int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                                 const int64_t* y, int64_t n, float lmbda, int32_t reg_type, float* loss, void* stream) {
+    if (validate(m, true, "kge_train_pointwise_logistic")) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || !h || !r || !t || !y || !loss) { set_error("kge_train_pointwise_logistic: bad arguments"); return -1; }
+    if (reg_type < KGE_REG_NONE || reg_type > KGE_REG_N3_ABS) { set_error("kge_train_pointwise_logistic: bad reg_type %d", reg_type); return -1; }
+    if (!is_vector_model(m->model)) { set_error("kge_train_pointwise_logistic: unsupported model %d", m->model); return -1; }
+    return launch_pointwise_logistic(m, h, r, t, y, n, lmbda, reg_type, loss, (hipStream_t)stream);
+}
+
+int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,
+                       int64_t step, int32_t zero_grad, void* stream) {
+    if (!param || !grad || numel < 0 || step < 1) { set_error("kge_optimizer_step: bad arguments"); return -1; }
+    if (numel == 0) return 0;
+    return launch_optimizer(kind, param, grad, state1, state2, numel, lr, step, zero_grad, (hipStream_t)stream);
+}
+
+size_t kge_eval_workspace_bytes(const kge_model_desc* m, int64_t n) {
+    if (validate(m, false, "kge_eval_workspace_bytes") || n < 0) return 0;
+    return eval_workspace_bytes(m, n);
+}
+
+int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
+                   const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* workspace,
+                   size_t workspace_bytes, int32_t* ranks, void* stream) {
+    if (validate(m, false, "kge_eval_ranks")) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || !triples || !ranks) { set_error("kge_eval_ranks: bad arguments"); return -1; }
+    if ((tail_off && !tail_ids) || (head_off && !head_ids)) { set_error("kge_eval_ranks: CSR offsets without ids"); return -1; }
+    return launch_eval_ranks(m, triples, n, tail_off, tail_ids, head_off, head_ids, workspace, workspace_bytes, ranks,
+                             (hipStream_t)stream);
+}
+
+int kge_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* workspace,
+                          size_t workspace_bytes, float* scores, void* stream) {
+    if (validate(m, false, "kge_eval_sweep_scores")) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || !triples || !scores) { set_error("kge_eval_sweep_scores: bad arguments"); return -1; }
+    return launch_eval_sweep_scores(m, triples, n, workspace, workspace_bytes, scores, (hipStream_t)stream);
+}
+
+int kge_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, int64_t n_slots, void* stream) {
+    if (!triples || !slots || n < 0 || n_slots < 2 * n || (n_slots & (n_slots - 1))) {
+        set_error("kge_triple_set_build: n_slots must be a power of two >= 2n");
+        return -1;
+    }
+    return launch_triple_set_build(triples, n, slots, n_slots, (hipStream_t)stream);
+}
+
+int kge_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t n_pos, int32_t neg_rate,
+                int64_t tot_entity, const float* bern_prob, const uint64_t* slots, int64_t n_slots, uint64_t seed,
+                uint64_t offset, int64_t* nh, int64_t* nr, int64_t* nt, void* stream) {
+    if (n_pos == 0) return 0;
+    if (!ph || !pr || !pt || !nh || !nr || !nt || n_pos < 0 || neg_rate <= 0 || tot_entity <= 1) {
+        set_error("kge_corrupt: bad arguments");
+        return -1;
+    }
+    if (slots && (n_slots & (n_slots - 1))) { set_error("kge_corrupt: n_slots must be a power of two"); return -1; }
+    return launch_corrupt(ph, pr, pt, n_pos, neg_rate, tot_entity, bern_prob, slots, n_slots, seed, offset, nh, nr, nt,
+                          (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,556 @@
+// kge_eval.hip -- filtered-rank evaluation as a tiled sweep over the entity table.
+//
+// Replaces, per test triple, Evaluator.test_tail_rank / test_head_rank (utils/evaluator.py:249-273: build [E]
+// id tensors, forward over all E candidates, torch.topk(k=E) i.e. a full sort, D2H copy of E int64) and
+// MetricCalculator.get_tail_rank / get_head_rank (utils/evaluator.py:70-123: python scan of the ordering with
+// set lookups) by
+//     rank(q)          = #{ e : s(q,e) < s(q,true) }
+//     filtered rank(q) = rank(q) - #{ e in known(q), e != true : s(q,e) < s(q,true) }
+// No score vector, no ordering, no sort ever exists in memory.
+//
+// Pipeline (all on one stream, no host sync):
+//   1. k_eval_prepare   entity table(s) -> *sweep layout* cand[tile][k][64]: candidate e = 64*tile + lane, element
+//                        k contiguous over lanes, so lane <-> candidate and every load is a coalesced 256-B line.
+//                        Model-specific candidate-side algebra that does not depend on the query is folded in here
+//                        (TransE: row normalisation; TransD: the scalar e.e_m; ComplEx/RotatE/ANALOGY: re|im
+//                        concatenation), once per evaluation instead of once per (query, candidate).
+//   2. k_eval_queries   per test triple the two query vectors: the (h,r) side pre-contracted for the tail sweep,
+//                        the (r,t) side for the head sweep, so a sweep is one of 4 pair forms
+//                        L1 / L2 / squared-L2-minus-margin distance or negated dot product.
+//   3. k_eval_target_filter   s(q,true) and the filtered count over the CSR list of known entities.
+//   4. k_eval_sweep     QT queries x 64 candidates per wave: candidate chunk in VGPRs, query elements as
+//                        wave-uniform scalar operands (s_load), QT accumulators per lane, ballot+popcount.
+//                        Each candidate tile read from L2/HBM is reused by QT queries.
+//   5. k_eval_finalize  int32 ranks [4, n].
+// Steps 3 and 4 run the SAME per-lane sequential accumulation over k, so s(q,e) is bit-identical in both and
+// the integer ranks are exact functions of the fp32 scores.
+//
+// Roofline: algorithmic bytes = candidate row bytes per scored candidate (400 B for TransE d=100); with QT-fold
+// reuse the kernel is VALU-bound (2 lane-ops per element per pair for L1), not HBM-bound.
+#include "kge_internal.h"
+
+namespace kge {
+
+constexpr int KC = 8;        // k-chunk held in VGPRs
+constexpr int QT_PLAIN = 16; // queries per wave pass, plain forms
+constexpr int QT_XF = 8;     // ... candidate-transform forms (TransH / TransD)
+
+enum Form { F_L1 = 0, F_L2 = 1, F_SQM = 2, F_NEGDOT = 3 };
+enum XForm { X_NONE = 0, X_TRANSH = 1, X_TRANSD = 2 };
+
+struct EvalPlan {
+    int64_t E, n;
+    int K, Kpad, QV, form, xform;
+    int64_t ntiles;
+    float* cand; float* aux; float* qvec; float* st; int32_t* fcount; int32_t* rcount;
+    size_t bytes;
+};
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int sweep_K(const kge_model_desc* m) {
+    switch (m->model) {
+        case KGE_COMPLEX: case KGE_ROTATE: case KGE_ANALOGY: return 2 * m->dim;
+        default: return m->dim;
+    }
+}
+
+static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p) {
+    p->E = m->tot_entity; p->n = n;
+    p->K = sweep_K(m);
+    p->Kpad = (p->K + KC - 1) / KC * KC;
+    p->xform = m->model == KGE_TRANSH ? X_TRANSH : m->model == KGE_TRANSD ? X_TRANSD : X_NONE;
+    p->QV = p->xform == X_NONE ? 1 : 2;
+    switch (m->model) {
+        case KGE_TRANSE: case KGE_TRANSH: case KGE_TRANSD: p->form = (m->flags & KGE_FLAG_L1) ? F_L1 : F_L2; break;
+        case KGE_ROTATE: p->form = F_SQM; break;
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_ANALOGY: case KGE_RESCAL: p->form = F_NEGDOT; break;
+        default: return false;
+    }
+    p->ntiles = (p->E + 63) / 64;
+    size_t off = 0;
+    char* base = (char*)ws;
+    auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += align256(bytes); return q; };
+    p->cand = (float*)take((size_t)p->ntiles * p->Kpad * 64 * sizeof(float));
+    p->aux = (float*)take((size_t)p->ntiles * 64 * sizeof(float));
+    p->qvec = (float*)take((size_t)2 * n * p->QV * p->Kpad * sizeof(float));
+    p->st = (float*)take((size_t)2 * n * sizeof(float));
+    p->fcount = (int32_t*)take((size_t)2 * n * sizeof(int32_t));
+    p->rcount = (int32_t*)take((size_t)2 * n * sizeof(int32_t));
+    p->bytes = off;
+    return true;
+}
+
+size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n) {
+    EvalPlan p;
+    if (!make_plan(m, n, nullptr, &p)) return 0;
+    return p.bytes;
+}
+
+// ------------------------------------------------------------------ 1. candidate sweep layout
+struct PrepArgs {
+    const float* seg[3]; int seg_dim[3]; int nseg;  // candidate row = concatenation of table rows
+    const float* dot_tab;                            // TransD: aux[e] = ent[e] . ent_mappings[e]
+    int normalize;                                   // TransE: divide by max(||row||, eps)
+    int64_t E; int K, Kpad;
+};
+
+__device__ __forceinline__ float prep_elem(const PrepArgs& a, int64_t e, int k) {
+    int kk = k;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s < a.nseg) {
+            if (kk < a.seg_dim[s]) return a.seg[s][e * a.seg_dim[s] + kk];
+            kk -= a.seg_dim[s];
+        }
+    }
+    return 0.f;
+}
+
+// one block = one tile of 64 candidates; 4 waves; each wave owns 16 candidates for the row reductions
+__global__ __launch_bounds__(256) void k_eval_prepare(PrepArgs a, float* __restrict__ cand, float* __restrict__ aux) {
+    __shared__ float s_scale[64];
+    __shared__ float s_tile[64][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    const int64_t e0 = tile * 64;
+    for (int j = 0; j < 16; ++j) {  // row statistics
+        const int row = wave * 16 + j;
+        const int64_t e = e0 + row;
+        float n2 = 0.f, dt = 0.f;
+        if (e < a.E && (a.normalize || a.dot_tab)) {
+            for (int k = lane; k < a.K; k += 64) {
+                const float v = prep_elem(a, e, k);
+                n2 = fmaf(v, v, n2);
+                if (a.dot_tab) dt = fmaf(v, a.dot_tab[e * a.K + k], dt);
+            }
+        }
+        n2 = wave_sum(n2);
+        dt = wave_sum(dt);
+        if (lane == 0) {
+            s_scale[row] = a.normalize ? 1.0f / fmaxf(sqrtf(n2), kEpsNormalize) : 1.0f;
+            if (a.dot_tab) aux[e0 + row] = (e < a.E) ? dt : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < a.Kpad; k0 += 64) {  // transpose 64x64 through LDS: coalesced reads AND writes
+        for (int j = 0; j < 16; ++j) {
+            const int row = wave * 16 + j;
+            const int64_t e = e0 + row;
+            const int k = k0 + lane;
+            float v = 0.f;
+            if (e < a.E && k < a.K) v = prep_elem(a, e, k) * s_scale[row];
+            s_tile[row][lane] = v;
+        }
+        __syncthreads();
+        for (int j = 0; j < 16; ++j) {
+            const int kk = wave * 16 + j;
+            if (k0 + kk < a.Kpad) cand[(tile * a.Kpad + k0 + kk) * 64 + lane] = s_tile[lane][kk];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ 2. query vectors
+// one wave per test triple; writes qvec[(2i+side)*QV*Kpad ...], side 0 = tail sweep (h,r,?), 1 = head sweep (?,r,t)
+template <int M>
+__global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64_t* __restrict__ triples, int64_t n,
+                                                      int K, int Kpad, int QV, float* __restrict__ qvec) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t h = triples[3 * i], r = triples[3 * i + 1], t = triples[3 * i + 2];
+    float* qt = qvec + (2 * i) * (int64_t)QV * Kpad;
+    float* qh = qvec + (2 * i + 1) * (int64_t)QV * Kpad;
+    const int d = m.dim;
+    for (int k = K + lane; k < Kpad; k += 64) {
+        qt[k] = 0.f; qh[k] = 0.f;
+        if (QV == 2) { qt[Kpad + k] = 0.f; qh[Kpad + k] = 0.f; }
+    }
+    if constexpr (M == KGE_TRANSE || M == KGE_TRANSH || M == KGE_TRANSD) {
+        const float* eh = m.tab[0] + h * d; const float* er = m.tab[1] + r * d; const float* et = m.tab[0] + t * d;
+        // projected head / tail  (a, c) and the relation-side vector the sweep needs
+        float ph = 0.f, pt = 0.f, iw = 1.f;
+        const float* w = nullptr; const float* rm = nullptr;
+        if constexpr (M == KGE_TRANSH) {
+            w = m.tab[2] + r * d;
+            float nw = 0.f;
+            for (int k = lane; k < d; k += 64) nw = fmaf(w[k], w[k], nw);
+            iw = 1.0f / fmaxf(sqrtf(wave_sum(nw)), kEpsNormalize);
+            for (int k = lane; k < d; k += 64) { ph = fmaf(eh[k], w[k] * iw, ph); pt = fmaf(et[k], w[k] * iw, pt); }
+            ph = wave_sum(ph); pt = wave_sum(pt);
+        } else if constexpr (M == KGE_TRANSD) {
+            const float* hm = m.tab[2] + h * d; const float* tm = m.tab[2] + t * d;
+            rm = m.tab[3] + r * d;
+            for (int k = lane; k < d; k += 64) { ph = fmaf(eh[k], hm[k], ph); pt = fmaf(et[k], tm[k], pt); }
+            ph = wave_sum(ph); pt = wave_sum(pt);
+        }
+        auto proj_h = [&](int k) -> float {
+            if constexpr (M == KGE_TRANSH) return eh[k] - ph * (w[k] * iw);
+            else if constexpr (M == KGE_TRANSD) return eh[k] + ph * rm[k];
+            else return eh[k];
+        };
+        auto proj_t = [&](int k) -> float {
+            if constexpr (M == KGE_TRANSH) return et[k] - pt * (w[k] * iw);
+            else if constexpr (M == KGE_TRANSD) return et[k] + pt * rm[k];
+            else return et[k];
+        };
+        float na = 0.f, nb = 0.f, nc = 0.f;
+        for (int k = lane; k < d; k += 64) {
+            const float a = proj_h(k), b = er[k], c = proj_t(k);
+            na = fmaf(a, a, na); nb = fmaf(b, b, nb); nc = fmaf(c, c, nc);
+        }
+        const float ia = 1.0f / fmaxf(sqrtf(wave_sum(na)), kEpsNormalize);
+        const float ib = 1.0f / fmaxf(sqrtf(wave_sum(nb)), kEpsNormalize);
+        const float ic = 1.0f / fmaxf(sqrtf(wave_sum(nc)), kEpsNormalize);
+        for (int k = lane; k < d; k += 64) {
+            qt[k] = proj_h(k) * ia + er[k] * ib;   // score = || q - c^ ||
+            qh[k] = proj_t(k) * ic - er[k] * ib;   // score = || c^ + r^ - t^ || = || c^ - q ||
+            if constexpr (M == KGE_TRANSH) { qt[Kpad + k] = w[k] * iw; qh[Kpad + k] = w[k] * iw; }
+            if constexpr (M == KGE_TRANSD) { qt[Kpad + k] = rm[k]; qh[Kpad + k] = rm[k]; }
+        }
+    } else if constexpr (M == KGE_DISTMULT) {
+        const float* eh = m.tab[0] + h * d; const float* er = m.tab[1] + r * d; const float* et = m.tab[0] + t * d;
+        for (int k = lane; k < d; k += 64) { qt[k] = eh[k] * er[k]; qh[k] = er[k] * et[k]; }
+    } else if constexpr (M == KGE_COMPLEX || M == KGE_ANALOGY) {
+        constexpr int o = (M == KGE_ANALOGY) ? 2 : 0;
+        const int dc = (M == KGE_ANALOGY) ? d / 2 : d;
+        const int base = (M == KGE_ANALOGY) ? d : 0;
+        const float* hr = m.tab[o + 0] + h * dc; const float* hi = m.tab[o + 1] + h * dc;
+        const float* rr = m.tab[o + 2] + r * dc; const float* ri = m.tab[o + 3] + r * dc;
+        const float* tr = m.tab[o + 0] + t * dc; const float* ti = m.tab[o + 1] + t * dc;
+        for (int k = lane; k < dc; k += 64) {
+            qt[base + k] = hr[k] * rr[k] - hi[k] * ri[k];
+            qt[base + dc + k] = hi[k] * rr[k] + hr[k] * ri[k];
+            qh[base + k] = tr[k] * rr[k] + ti[k] * ri[k];
+            qh[base + dc + k] = ti[k] * rr[k] - tr[k] * ri[k];
+        }
+        if constexpr (M == KGE_ANALOGY) {
+            const float* eh = m.tab[0] + h * d; const float* er = m.tab[1] + r * d; const float* et = m.tab[0] + t * d;
+            for (int k = lane; k < d; k += 64) { qt[k] = eh[k] * er[k]; qh[k] = er[k] * et[k]; }
+        }
+    } else if constexpr (M == KGE_ROTATE) {
+        const float* hr = m.tab[0] + h * d; const float* hi = m.tab[1] + h * d; const float* rl = m.tab[2] + r * d;
+        const float* tr = m.tab[0] + t * d; const float* ti = m.tab[1] + t * d;
+        for (int k = lane; k < d; k += 64) {
+            float sn, cs;
+            sincosf(rl[k] / m.phase_div, &sn, &cs);
+            qt[k] = hr[k] * cs - hi[k] * sn;       // h o r ;  score = |h o r - t|^2 - margin
+            qt[d + k] = hr[k] * sn + hi[k] * cs;
+            qh[k] = tr[k] * cs + ti[k] * sn;       // t o conj(r) ; |h o r - t| = |h - t o conj(r)| for |r| = 1
+            qh[d + k] = ti[k] * cs - tr[k] * sn;
+        }
+    } else if constexpr (M == KGE_RESCAL) {
+        const float* eh = m.tab[0] + h * d; const float* et = m.tab[0] + t * d;
+        const float* Mr = m.tab[1] + r * (int64_t)d * d;
+        for (int j = lane; j < d; j += 64) {
+            float a = 0.f, b = 0.f;
+            for (int i2 = 0; i2 < d; ++i2) {
+                a = fmaf(eh[i2], Mr[(int64_t)i2 * d + j], a);   // (h^T M)_j
+                b = fmaf(Mr[(int64_t)j * d + i2], et[i2], b);   // (M t)_j
+            }
+            qt[j] = a; qh[j] = b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pair arithmetic shared by steps 3 and 4
+template <int FORM>
+__device__ __forceinline__ float pair_step(float acc, float c, float q) {
+    if constexpr (FORM == F_L1) return acc + fabsf(c - q);
+    else if constexpr (FORM == F_NEGDOT) return fmaf(c, q, acc);
+    else { const float dlt = c - q; return fmaf(dlt, dlt, acc); }
+}
+template <int FORM>
+__device__ __forceinline__ float pair_finish(float acc, float margin) {
+    if constexpr (FORM == F_L1) return acc;
+    else if constexpr (FORM == F_L2) return sqrtf(acc);
+    else if constexpr (FORM == F_SQM) return -(margin - acc);
+    else return -acc;
+}
+
+// full sequential score of one (query, candidate) pair by ONE lane (target / filter path)
+template <int FORM, int XFORM>
+__device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand, const float* __restrict__ aux,
+                                                 const float* __restrict__ q, int64_t e, int Kpad, float margin) {
+    const float* c = cand + ((e >> 6) * Kpad) * 64 + (e & 63);
+    float acc = 0.f;
+    if constexpr (XFORM == X_NONE) {
+        for (int k = 0; k < Kpad; ++k) acc = pair_step<FORM>(acc, c[(int64_t)k * 64], q[k]);
+    } else {
+        const float* w = q + Kpad;
+        float p;
+        if constexpr (XFORM == X_TRANSH) {
+            p = 0.f;
+            for (int k = 0; k < Kpad; ++k) p = fmaf(c[(int64_t)k * 64], w[k], p);
+            p = -p;
+        } else {
+            p = aux[e];
+        }
+        float n2 = 0.f;
+        for (int k = 0; k < Kpad; ++k) { const float v = fmaf(p, w[k], c[(int64_t)k * 64]); n2 = fmaf(v, v, n2); }
+        const float inv = 1.0f / fmaxf(sqrtf(n2), kEpsNormalize);
+        for (int k = 0; k < Kpad; ++k) {
+            const float v = fmaf(p, w[k], c[(int64_t)k * 64]) * inv;
+            acc = pair_step<FORM>(acc, v, q[k]);
+        }
+    }
+    return pair_finish<FORM>(acc, margin);
+}
+
+// ------------------------------------------------------------------ 3. target score + filtered count
+template <int FORM, int XFORM>
+__global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restrict__ cand, const float* __restrict__ aux,
+                                                            const float* __restrict__ qvec, const int64_t* __restrict__ triples,
+                                                            int64_t n, int Kpad, int QV, float margin,
+                                                            const int64_t* __restrict__ tail_off, const int32_t* __restrict__ tail_ids,
+                                                            const int64_t* __restrict__ head_off, const int32_t* __restrict__ head_ids,
+                                                            float* __restrict__ st, int32_t* __restrict__ fcount) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= 2 * n) return;
+    const int64_t i = qi >> 1;
+    const int side = (int)(qi & 1);
+    const int64_t truth = side == 0 ? triples[3 * i + 2] : triples[3 * i];
+    const float* q = qvec + qi * (int64_t)QV * Kpad;
+    float s_true = 0.f;
+    if (lane == 0) s_true = pair_score_lane<FORM, XFORM>(cand, aux, q, truth, Kpad, margin);
+    s_true = __shfl(s_true, 0, 64);
+    const int64_t* off = side == 0 ? tail_off : head_off;
+    const int32_t* ids = side == 0 ? tail_ids : head_ids;
+    int cnt = 0;
+    if (off != nullptr) {
+        const int64_t b = off[i], e_ = off[i + 1];
+        for (int64_t j = b + lane; j < e_; j += 64) {
+            const int64_t e = ids[j];
+            if (e != truth) {
+                const float s = pair_score_lane<FORM, XFORM>(cand, aux, q, e, Kpad, margin);
+                cnt += (s < s_true) ? 1 : 0;
+            }
+        }
+    }
+    cnt = (int)wave_sum((float)cnt);  // < 2^24 known entities per query
+    if (lane == 0) { st[qi] = s_true; fcount[qi] = cnt; }
+}
+
+// ------------------------------------------------------------------ 4. the sweep
+// grid.x = query blocks of QT, grid.y = tile splits; each wave walks its candidate tiles.
+template <int FORM, int XFORM, int QT, bool WRITE>
+__global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ cand, const float* __restrict__ aux,
+                                                    const float* __restrict__ qvec, const float* __restrict__ st,
+                                                    int64_t nq, int64_t E, int64_t ntiles, int Kpad, int QV, float margin,
+                                                    int32_t* __restrict__ rcount, float* __restrict__ scores_out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t q0 = (int64_t)blockIdx.x * QT;
+    const int64_t qstride = (int64_t)QV * Kpad;
+    // wave-uniform query row pointers (clamped; masked at the end)
+    const float* qrow[QT];
+    float sthr[QT];
+    int cnt[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        const int64_t qi = (q0 + q < nq) ? q0 + q : nq - 1;
+        qrow[q] = qvec + qi * qstride;
+        sthr[q] = WRITE ? 0.f : st[qi];
+        cnt[q] = 0;
+    }
+    for (int64_t tile = (int64_t)blockIdx.y * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.y * 4) {
+        const float* c = cand + (tile * Kpad) * 64 + lane;
+        float acc[QT];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) acc[q] = 0.f;
+        if constexpr (XFORM == X_NONE) {
+            for (int k0 = 0; k0 < Kpad; k0 += KC) {
+                float cv[KC];
+#pragma unroll
+                for (int j = 0; j < KC; ++j) cv[j] = c[(int64_t)(k0 + j) * 64];
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) acc[q] = pair_step<FORM>(acc[q], cv[j], qrow[q][k0 + j]);
+                }
+            }
+        } else {
+            float p[QT], inv[QT];
+            if constexpr (XFORM == X_TRANSH) {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) p[q] = 0.f;
+                for (int k0 = 0; k0 < Kpad; k0 += KC) {
+                    float cv[KC];
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) cv[j] = c[(int64_t)(k0 + j) * 64];
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+#pragma unroll
+                        for (int j = 0; j < KC; ++j) p[q] = fmaf(cv[j], qrow[q][Kpad + k0 + j], p[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < QT; ++q) p[q] = -p[q];
+            } else {
+                const float a_e = aux[tile * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < QT; ++q) p[q] = a_e;
+            }
+#pragma unroll
+            for (int q = 0; q < QT; ++q) inv[q] = 0.f;
+            for (int k0 = 0; k0 < Kpad; k0 += KC) {
+                float cv[KC];
+#pragma unroll
+                for (int j = 0; j < KC; ++j) cv[j] = c[(int64_t)(k0 + j) * 64];
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) {
+                        const float v = fmaf(p[q], qrow[q][Kpad + k0 + j], cv[j]);
+                        inv[q] = fmaf(v, v, inv[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QT; ++q) inv[q] = 1.0f / fmaxf(sqrtf(inv[q]), kEpsNormalize);
+            for (int k0 = 0; k0 < Kpad; k0 += KC) {
+                float cv[KC];
+#pragma unroll
+                for (int j = 0; j < KC; ++j) cv[j] = c[(int64_t)(k0 + j) * 64];
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) {
+                        const float v = fmaf(p[q], qrow[q][Kpad + k0 + j], cv[j]) * inv[q];
+                        acc[q] = pair_step<FORM>(acc[q], v, qrow[q][k0 + j]);
+                    }
+                }
+            }
+        }
+        const int64_t e = tile * 64 + lane;
+        const bool valid = e < E;
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const float s = pair_finish<FORM>(acc[q], margin);
+            if constexpr (WRITE) {
+                if (valid && q0 + q < nq) scores_out[(q0 + q) * E + e] = s;
+            } else {
+                cnt[q] += __popcll(__ballot(valid && s < sthr[q]));
+            }
+        }
+    }
+    if constexpr (!WRITE) {
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < QT; ++q)
+                if (q0 + q < nq && cnt[q] != 0) atomicAdd(rcount + q0 + q, cnt[q]);
+        }
+    }
+}
+
+__global__ void k_eval_finalize(const int32_t* __restrict__ rcount, const int32_t* __restrict__ fcount, int64_t n,
+                                int32_t* __restrict__ ranks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t rt = rcount[2 * i], rh = rcount[2 * i + 1];
+    ranks[i] = rh;                               // rank_head
+    ranks[n + i] = rt;                           // rank_tail
+    ranks[2 * n + i] = rh - fcount[2 * i + 1];   // filtered head
+    ranks[3 * n + i] = rt - fcount[2 * i];       // filtered tail
+}
+
+// ------------------------------------------------------------------ host side
+static void fill_prep(const kge_model_desc* m, const EvalPlan& p, PrepArgs* a) {
+    a->nseg = 1; a->dot_tab = nullptr; a->normalize = 0;
+    a->E = p.E; a->K = p.K; a->Kpad = p.Kpad;
+    for (int s = 0; s < 3; ++s) { a->seg[s] = nullptr; a->seg_dim[s] = 0; }
+    a->seg[0] = m->tables[0]; a->seg_dim[0] = m->dim;
+    switch (m->model) {
+        case KGE_TRANSE: a->normalize = 1; break;
+        case KGE_TRANSD: a->dot_tab = m->tables[2]; break;
+        case KGE_COMPLEX: case KGE_ROTATE:
+            a->nseg = 2; a->seg[1] = m->tables[1]; a->seg_dim[1] = m->dim; break;
+        case KGE_ANALOGY:
+            a->nseg = 3; a->seg[1] = m->tables[2]; a->seg_dim[1] = m->dim / 2;
+            a->seg[2] = m->tables[3]; a->seg_dim[2] = m->dim / 2; break;
+        default: break;
+    }
+}
+
+template <int FORM, int XFORM>
+static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, const int64_t* triples,
+                                const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
+                                const int32_t* head_ids, float* scores_out, hipStream_t s) {
+    constexpr int QT = XFORM == X_NONE ? QT_PLAIN : QT_XF;
+    const int64_t nq = 2 * p.n;
+    const int qblocks = (int)((nq + QT - 1) / QT);
+    // enough blocks to fill 256 CUs several times over; each wave needs >= 1 tile
+    int64_t ysplit = (256 * 8 + qblocks - 1) / qblocks;
+    const int64_t max_split = (p.ntiles + 3) / 4;
+    if (ysplit > max_split) ysplit = max_split;
+    if (ysplit < 1) ysplit = 1;
+    if (ysplit > 65535) ysplit = 65535;
+    if (scores_out == nullptr) {
+        hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p.cand, p.aux,
+                           p.qvec, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids, head_off, head_ids, p.st,
+                           p.fcount);
+        hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, false>), dim3(qblocks, (unsigned)ysplit), dim3(256), 0, s, p.cand,
+                           p.aux, p.qvec, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, p.rcount, nullptr);
+    } else {
+        hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, true>), dim3(qblocks, (unsigned)ysplit), dim3(256), 0, s, p.cand,
+                           p.aux, p.qvec, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, p.rcount, scores_out);
+    }
+}
+
+static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
+                        const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
+                        size_t ws_bytes, int32_t* ranks, float* scores_out, hipStream_t s) {
+    EvalPlan p;
+    if (!make_plan(m, n, ws, &p)) { set_error("kge_eval: model %d has no sweep form", m->model); return -1; }
+    if (ws == nullptr || ws_bytes < p.bytes) {
+        set_error("kge_eval: workspace too small (%zu < %zu)", ws_bytes, p.bytes);
+        return -1;
+    }
+    if (n <= 0) return 0;
+    PrepArgs pa;
+    fill_prep(m, p, &pa);
+    hipLaunchKernelGGL(k_eval_prepare, dim3((unsigned)p.ntiles), dim3(256), 0, s, pa, p.cand, p.aux);
+    const DeviceModel dm = to_device_model(m);
+    const unsigned qb = (unsigned)((n + 3) / 4);
+#define KGE_Q(MID) case MID: hipLaunchKernelGGL((k_eval_queries<MID>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec); break;
+    switch (m->model) {
+        KGE_Q(KGE_TRANSE) KGE_Q(KGE_TRANSH) KGE_Q(KGE_TRANSD) KGE_Q(KGE_ROTATE) KGE_Q(KGE_DISTMULT)
+        KGE_Q(KGE_COMPLEX) KGE_Q(KGE_ANALOGY) KGE_Q(KGE_RESCAL)
+        default: set_error("kge_eval: unsupported model %d", m->model); return -1;
+    }
+#undef KGE_Q
+    if (scores_out == nullptr) (void)hipMemsetAsync(p.rcount, 0, (size_t)2 * n * sizeof(int32_t), s);
+#define KGE_S(F, X) launch_tf_and_sweep<F, X>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s)
+    if (p.xform == X_NONE) {
+        switch (p.form) {
+            case F_L1: KGE_S(F_L1, X_NONE); break;
+            case F_L2: KGE_S(F_L2, X_NONE); break;
+            case F_SQM: KGE_S(F_SQM, X_NONE); break;
+            default: KGE_S(F_NEGDOT, X_NONE); break;
+        }
+    } else if (p.xform == X_TRANSH) {
+        if (p.form == F_L1) KGE_S(F_L1, X_TRANSH); else KGE_S(F_L2, X_TRANSH);
+    } else {
+        if (p.form == F_L1) KGE_S(F_L1, X_TRANSD); else KGE_S(F_L2, X_TRANSD);
+    }
+#undef KGE_S
+    if (scores_out == nullptr)
+        hipLaunchKernelGGL(k_eval_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.rcount, p.fcount, n, ranks);
+    return check_launch("kge_eval pipeline");
+}
+
+int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
+                      const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
+                      size_t ws_bytes, int32_t* ranks, hipStream_t s) {
+    return run_pipeline(m, triples, n, tail_off, tail_ids, head_off, head_ids, ws, ws_bytes, ranks, nullptr, s);
+}
+
+// scores: float [2n, E]: row 2i = tail-sweep energies of triple i, row 2i+1 = head-sweep energies
+int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
+                             float* scores, hipStream_t s) {
+    return run_pipeline(m, triples, n, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, nullptr, scores, s);
+}
+
+}  // namespace kge

@@ -1,0 +1,70 @@
+// kge_internal.h -- host-side launcher prototypes shared between the translation units of libkge_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/kge_hip.h"
+#include "kge_device.h"
+
+namespace kge {
+
+void set_error(const char* fmt, ...);
+bool is_vector_model(int model);  // models handled by the gather/row kernels (everything but RESCAL, NTN)
+
+// (G, NCH) geometry for a row length; returns false when the row is too long for the register-resident kernels
+struct Geometry { int G, NCH; };
+bool pick_geometry(int max_row_dim, Geometry* out);
+DeviceModel to_device_model(const kge_model_desc* m);
+
+// kge_score.hip
+int launch_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                         int64_t n, float* scores, hipStream_t s);
+int launch_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                          int64_t n, const float* dscore, hipStream_t s);
+int launch_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                          const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float margin,
+                          float* loss, hipStream_t s);
+int launch_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                              const int64_t* y, int64_t n, float lmbda, int reg_type, float* loss, hipStream_t s);
+int launch_selfadv_coeffs(float* pos_scores, float* neg_scores, int64_t n_pos, int neg_rate, float alpha,
+                          float* loss, hipStream_t s);
+
+// kge_dense.hip (RESCAL / NTN: f32 MFMA contraction paths) + table normalisation
+int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k, hipStream_t s);
+int launch_rescal_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                          int64_t n, float* scores, hipStream_t s);
+int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                           int64_t n, const float* dscore, hipStream_t s);
+int launch_ntn_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                       int64_t n, float* scores, hipStream_t s);
+int launch_ntn_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                        int64_t n, const float* dscore, hipStream_t s);
+
+// kge_opt.hip
+int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t numel, float lr, int64_t step,
+                     int zero_grad, hipStream_t s);
+
+// kge_eval.hip
+size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n);
+int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
+                      const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
+                      size_t ws_bytes, int32_t* ranks, hipStream_t s);
+int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
+                             float* scores, hipStream_t s);
+
+// kge_sampler.hip
+int launch_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, int64_t n_slots, hipStream_t s);
+int launch_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t n_pos, int neg_rate,
+                   int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed,
+                   uint64_t offset, int64_t* nh, int64_t* nr, int64_t* nt, hipStream_t s);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+}  // namespace kge

@@ -1,0 +1,109 @@
+// kge_opt.hip -- dense optimiser sweeps with torch.optim default semantics (utils/trainer.py:112-131).
+// nn.Embedding is dense (models/Domain.py:8-13): Adam / Adagrad / RMSprop touch EVERY row every step, so the
+// sweep is a pure HBM stream: float4 per lane, grid-stride, (reads+writes) = 3 (SGD) .. 7 (Adam) floats per
+// parameter.  The gradient buffer is cleared in the same pass (optimizer.zero_grad(), utils/trainer.py:272).
+#include "kge_internal.h"
+
+namespace kge {
+
+struct OptArgs {
+    float lr;
+    float step_size;  // Adam: lr / (1 - beta1^t)
+    float bc2_sqrt;   // Adam: sqrt(1 - beta2^t)
+};
+
+template <int KIND>
+__device__ __forceinline__ void opt_update(float& p, float g, float& s1, float& s2, const OptArgs& a) {
+    if constexpr (KIND == KGE_OPT_SGD) {
+        p = p - a.lr * g;
+    } else if constexpr (KIND == KGE_OPT_ADAM) {  // torch/optim/adam.py _single_tensor_adam, defaults
+        s1 = s1 + (1.0f - 0.9f) * (g - s1);          // exp_avg.lerp_(grad, 1 - beta1)
+        s2 = s2 * 0.999f + (1.0f - 0.999f) * g * g;  // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(s2) / a.bc2_sqrt + 1e-8f;
+        p = p + (-a.step_size) * s1 / denom;         // param.addcdiv_(exp_avg, denom, value=-step_size)
+    } else if constexpr (KIND == KGE_OPT_ADAGRAD) {  // lr_decay 0, eps 1e-10
+        s1 = s1 + g * g;
+        p = p - a.lr * g / (sqrtf(s1) + 1e-10f);
+    } else {  // RMSprop alpha 0.99 eps 1e-8, momentum 0, not centered
+        s1 = s1 * 0.99f + (1.0f - 0.99f) * g * g;
+        p = p - a.lr * g / (sqrtf(s1) + 1e-8f);
+    }
+}
+
+template <int KIND, bool ZERO>
+__global__ __launch_bounds__(256) void k_opt(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
+                                             float* __restrict__ s2, int64_t numel, OptArgs a) {
+    const int64_t nvec = numel / 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        float4 gv = reinterpret_cast<float4*>(g)[i];
+        float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+        if constexpr (KIND != KGE_OPT_SGD) av = reinterpret_cast<float4*>(s1)[i];
+        if constexpr (KIND == KGE_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[i];
+        opt_update<KIND>(pv.x, gv.x, av.x, bv.x, a);
+        opt_update<KIND>(pv.y, gv.y, av.y, bv.y, a);
+        opt_update<KIND>(pv.z, gv.z, av.z, bv.z, a);
+        opt_update<KIND>(pv.w, gv.w, av.w, bv.w, a);
+        reinterpret_cast<float4*>(p)[i] = pv;
+        if constexpr (KIND != KGE_OPT_SGD) reinterpret_cast<float4*>(s1)[i] = av;
+        if constexpr (KIND == KGE_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv;
+        if constexpr (ZERO) reinterpret_cast<float4*>(g)[i] = make_float4(0, 0, 0, 0);
+    }
+    if (blockIdx.x == 0) {  // tail (numel % 4)
+        const int64_t i = nvec * 4 + threadIdx.x;
+        if (threadIdx.x < 4 && i < numel) {
+            float pv = p[i], gv = g[i], av = 0.f, bv = 0.f;
+            if constexpr (KIND != KGE_OPT_SGD) av = s1[i];
+            if constexpr (KIND == KGE_OPT_ADAM) bv = s2[i];
+            opt_update<KIND>(pv, gv, av, bv, a);
+            p[i] = pv;
+            if constexpr (KIND != KGE_OPT_SGD) s1[i] = av;
+            if constexpr (KIND == KGE_OPT_ADAM) s2[i] = bv;
+            if constexpr (ZERO) g[i] = 0.f;
+        }
+    }
+}
+
+template <int KIND>
+static int launch_kind(float* p, float* g, float* s1, float* s2, int64_t numel, OptArgs a, int zero, hipStream_t s) {
+    int64_t blocks = (numel / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (zero)
+        hipLaunchKernelGGL((k_opt<KIND, true>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a);
+    else
+        hipLaunchKernelGGL((k_opt<KIND, false>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a);
+    return check_launch("k_opt");
+}
+
+int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t numel, float lr, int64_t step,
+                     int zero_grad, hipStream_t s) {
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)s1 | (uintptr_t)s2) & 15) {
+        set_error("kge_optimizer_step: buffers must be 16-byte aligned");
+        return -1;
+    }
+    OptArgs a;
+    a.lr = lr;
+    // torch computes these scalars in double on the host, then applies them to fp32 tensors
+    const double bc1 = 1.0 - pow(0.9, (double)step);
+    const double bc2 = 1.0 - pow(0.999, (double)step);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    switch (kind) {
+        case KGE_OPT_SGD: return launch_kind<KGE_OPT_SGD>(p, g, s1, s2, numel, a, zero_grad, s);
+        case KGE_OPT_ADAM:
+            if (!s1 || !s2) { set_error("adam needs two state buffers"); return -1; }
+            return launch_kind<KGE_OPT_ADAM>(p, g, s1, s2, numel, a, zero_grad, s);
+        case KGE_OPT_ADAGRAD:
+            if (!s1) { set_error("adagrad needs a state buffer"); return -1; }
+            return launch_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, numel, a, zero_grad, s);
+        case KGE_OPT_RMSPROP:
+            if (!s1) { set_error("rmsprop needs a state buffer"); return -1; }
+            return launch_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, numel, a, zero_grad, s);
+    }
+    set_error("kge_optimizer_step: unknown optimizer %d", kind);
+    return -1;
+}
+
+}  // namespace kge

@@ -1,0 +1,131 @@
+// kge_sampler.hip -- negative corruption on the device (replaces the python worker processes of
+// pykg2vec/data/generator.py:42-97,99-158).
+//
+// Semantics kept from the reference: for every positive (h,r,t) and each of its neg_rate slots draw u ~ U[0,1);
+// u > prob -> corrupt the TAIL else the HEAD, prob = relation_property[r] (bern) or 0.5; the replacement entity is
+// drawn uniformly from [0, E) and re-drawn while the corrupted triple is a TRAIN triple; negatives of positive i
+// occupy rows [i*neg_rate, (i+1)*neg_rate).
+// What cannot be kept: the reference's RNG stream (unseeded numpy MT19937 inside worker processes).  Here the
+// stream is counter-based Philox4x32-10, key = seed, counter = (slot index, redraw round), so a batch is a pure
+// function of (seed, offset) -- reproducible and identical however the batch is split over GPUs.
+//
+// The train-triple membership test is an open-addressing hash set of packed 64-bit keys
+// (h:24 | r:16 | t:24 bits) in HBM, ~16 B per train triple at load factor <= 0.5, linear probing.
+#include "kge_internal.h"
+
+namespace kge {
+
+constexpr unsigned long long kEmpty = 0xFFFFFFFFFFFFFFFFull;
+
+__host__ __device__ __forceinline__ unsigned long long pack_triple(int64_t h, int64_t r, int64_t t) {
+    return ((unsigned long long)(h & 0xFFFFFF) << 40) | ((unsigned long long)(r & 0xFFFF) << 24) |
+           (unsigned long long)(t & 0xFFFFFF);
+}
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+__global__ void k_set_insert(const int64_t* __restrict__ triples, int64_t n, unsigned long long* __restrict__ slots,
+                             unsigned long long mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = pack_triple(triples[3 * i], triples[3 * i + 1], triples[3 * i + 2]);
+    unsigned long long s = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(slots + s, kEmpty, key);
+        if (prev == kEmpty || prev == key) return;
+        s = (s + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ bool set_contains(const unsigned long long* __restrict__ slots, unsigned long long mask,
+                                             unsigned long long key) {
+    unsigned long long s = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long v = slots[s];
+        if (v == key) return true;
+        if (v == kEmpty) return false;
+        s = (s + 1) & mask;
+    }
+}
+
+struct Philox {
+    uint32_t c[4];
+};
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+    return (uint32_t)(((unsigned long long)a * b) >> 32);
+}
+// Philox4x32-10 (Salmon et al., SC'11)
+__host__ __device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                         uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox o;
+    o.c[0] = c0; o.c[1] = c1; o.c[2] = c2; o.c[3] = c3;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void k_corrupt(const int64_t* __restrict__ ph, const int64_t* __restrict__ pr,
+                                                 const int64_t* __restrict__ pt, int64_t n_pos, int neg_rate, int64_t E,
+                                                 const float* __restrict__ bern, const unsigned long long* __restrict__ slots,
+                                                 unsigned long long mask, unsigned long long seed, unsigned long long offset,
+                                                 int64_t* __restrict__ nh, int64_t* __restrict__ nr, int64_t* __restrict__ nt) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pos * neg_rate) return;
+    const int64_t i = j / neg_rate;
+    const int64_t h = ph[i], r = pr[i], t = pt[i];
+    const unsigned long long ctr = offset + (unsigned long long)j;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    Philox x = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, k0, k1);
+    const float u = (float)(x.c[0] >> 8) * (1.0f / 16777216.0f);  // 24-bit uniform in [0,1)
+    const float prob = bern ? bern[r] : 0.5f;
+    const bool corrupt_tail = u > prob;
+    int word = 1;
+    uint32_t round = 0;
+    int64_t e;
+    for (;;) {
+        e = (int64_t)(((unsigned long long)x.c[word] * (unsigned long long)E) >> 32);  // uniform in [0,E)
+        const unsigned long long key = corrupt_tail ? pack_triple(h, r, e) : pack_triple(e, r, t);
+        if (slots == nullptr || !set_contains(slots, mask, key)) break;
+        if (++word == 4) {
+            ++round;
+            x = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), round, 0u, k0, k1);
+            word = 0;
+        }
+    }
+    nh[j] = corrupt_tail ? h : e;
+    nr[j] = r;
+    nt[j] = corrupt_tail ? e : t;
+}
+
+int launch_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, int64_t n_slots, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(slots, 0xFF, (size_t)n_slots * sizeof(uint64_t), s);
+    if (e != hipSuccess) { set_error("kge_triple_set_build: memset: %s", hipGetErrorString(e)); return -2; }
+    if (n > 0)
+        hipLaunchKernelGGL(k_set_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, triples, n,
+                           (unsigned long long*)slots, (unsigned long long)(n_slots - 1));
+    return check_launch("k_set_insert");
+}
+
+int launch_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t n_pos, int neg_rate, int64_t E,
+                   const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset,
+                   int64_t* nh, int64_t* nr, int64_t* nt, hipStream_t s) {
+    if (E >= (1 << 24)) { set_error("kge_corrupt: more than 2^24 entities not supported by the packed key"); return -1; }
+    const int64_t tot = n_pos * neg_rate;
+    hipLaunchKernelGGL(k_corrupt, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ph, pr, pt, n_pos, neg_rate, E, bern,
+                       (const unsigned long long*)slots, (unsigned long long)(slots ? n_slots - 1 : 0),
+                       (unsigned long long)seed, (unsigned long long)offset, nh, nr, nt);
+    return check_launch("k_corrupt");
+}
+
+}  // namespace kge

@@ -1,0 +1,274 @@
+// kge_score.hip -- gather-type scorers (TransE/TransH/TransD, RotatE, DistMult/ComplEx/ANALOGY):
+// forward, backward and the fused score+loss+backward training kernels.
+//
+// Reference sites replaced (paths relative to the reference tree):
+//   forward           pykg2vec/models/pairwise.py:56-76,166-174,270-278,786-791 ; pointwise.py:97-104,185-188,444-446
+//   backward          autograd of the above (utils/trainer.py:298), dense nn.Embedding grads
+//   pairwise hinge    utils/trainer.py:147-157 + utils/criterion.py:25-29
+//   pointwise         utils/trainer.py:176-180 + utils/criterion.py:31-34 + get_reg (pointwise.py:106-119,190-202,224-238,448-458)
+//   self-adversarial  utils/criterion.py:13-23
+//
+// Roofline: HBM/L2-bound gather + atomic scatter (<= 3 flop/byte).  One G-lane group per triple keeps all of
+// its rows in registers from the gather to the gradient scatter; the only HBM traffic is the row gather, the
+// 24-byte id read and the float atomics into the dense gradient tables.
+#include "kge_internal.h"
+
+namespace kge {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident 256-thread blocks; rest is grid-stride
+
+template <int M, int G, int NCH>
+__global__ __launch_bounds__(kBlock) void k_score_fwd(DeviceModel m, const int64_t* __restrict__ h,
+                                                      const int64_t* __restrict__ r, const int64_t* __restrict__ t,
+                                                      int64_t n, float* __restrict__ out) {
+    constexpr int GPB = kBlock / G;
+    const int gl = threadIdx.x % G;
+    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n; i += (int64_t)gridDim.x * GPB) {
+        const int64_t id[3] = {h[i], r[i], t[i]};
+        Rows<M, NCH> R;
+        load_rows<M, G, NCH>(R, m, id, gl);
+        Saved<M, NCH> sv;
+        const float s = model_fwd<M, G, NCH>(R, m, sv);
+        if (gl == 0) out[i] = s;
+    }
+}
+
+template <int M, int G, int NCH>
+__global__ __launch_bounds__(kBlock) void k_score_bwd(DeviceModel m, const int64_t* __restrict__ h,
+                                                      const int64_t* __restrict__ r, const int64_t* __restrict__ t,
+                                                      int64_t n, const float* __restrict__ dscore) {
+    constexpr int GPB = kBlock / G;
+    const int gl = threadIdx.x % G;
+    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n; i += (int64_t)gridDim.x * GPB) {
+        const float ds = dscore[i];
+        if (ds == 0.f) continue;  // group-uniform
+        const int64_t id[3] = {h[i], r[i], t[i]};
+        Rows<M, NCH> R;
+        load_rows<M, G, NCH>(R, m, id, gl);
+        Saved<M, NCH> sv;
+        model_fwd<M, G, NCH>(R, m, sv);  // recompute: cheaper than spilling [B,d] intermediates to HBM
+        Rows<M, NCH> Gr;
+        model_bwd<M, G, NCH>(R, m, sv, ds, Gr);
+        scatter_rows<M, G, NCH>(Gr, m, id, gl);
+    }
+}
+
+// ---- fused pairwise hinge step: score(+) , score(-), max(0, s+ + margin - s-), both backward passes.
+// A negative produced by the reference sampler shares the relation and one entity with its positive
+// (data/generator.py:71-95); rows with equal ids get ONE combined atomic scatter (4 row scatters, not 6).
+template <int M, int G, int NCH>
+__global__ __launch_bounds__(kBlock) void k_pairwise_hinge(DeviceModel m, const int64_t* __restrict__ ph,
+                                                           const int64_t* __restrict__ pr, const int64_t* __restrict__ pt,
+                                                           const int64_t* __restrict__ nh, const int64_t* __restrict__ nr,
+                                                           const int64_t* __restrict__ nt, int64_t n, float margin,
+                                                           float* __restrict__ loss) {
+    constexpr int GPB = kBlock / G;
+    constexpr int NR = role_count(M);
+    const int gl = threadIdx.x % G;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n; i += (int64_t)gridDim.x * GPB) {
+        const int64_t idp[3] = {ph[i], pr[i], pt[i]};
+        const int64_t idn[3] = {nh[i], nr[i], nt[i]};
+        Rows<M, NCH> Rp, Rn;
+        load_rows<M, G, NCH>(Rp, m, idp, gl);
+        load_rows<M, G, NCH>(Rn, m, idn, gl);
+        Saved<M, NCH> svp, svn;
+        const float sp = model_fwd<M, G, NCH>(Rp, m, svp);
+        const float sn = model_fwd<M, G, NCH>(Rn, m, svn);
+        const float v = sp + margin - sn;
+        acc += fmaxf(v, 0.f);
+        const float coef = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);  // ATen max(a, 0) backward splits ties
+        if (coef != 0.f) {
+            Rows<M, NCH> Gp, Gn;
+            model_bwd<M, G, NCH>(Rp, m, svp, coef, Gp);
+            model_bwd<M, G, NCH>(Rn, m, svn, -coef, Gn);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int sel = role_sel(M, q);
+                const int d = role_dim<M>(m, q);
+                float* gt = m.grad[role_tab(M, q)];
+                if (idp[sel] == idn[sel]) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) Gp.x[q][c] += Gn.x[q][c];
+                    atomic_add_row<G, NCH>(gt + idp[sel] * (int64_t)d, Gp.x[q], d, gl);
+                } else {
+                    atomic_add_row<G, NCH>(gt + idp[sel] * (int64_t)d, Gp.x[q], d, gl);
+                    atomic_add_row<G, NCH>(gt + idn[sel] * (int64_t)d, Gn.x[q], d, gl);
+                }
+            }
+        }
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
+
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // F.softplus, threshold 20
+__device__ __forceinline__ float sigmoid_t(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float logsigmoid_t(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+
+// ---- fused pointwise step: mean(softplus(y*s)) + lmbda * mean_i(sum of squares/cubes of the rows of row i)
+template <int M, int G, int NCH>
+__global__ __launch_bounds__(kBlock) void k_pointwise_logistic(DeviceModel m, const int64_t* __restrict__ h,
+                                                               const int64_t* __restrict__ r, const int64_t* __restrict__ t,
+                                                               const int64_t* __restrict__ y, int64_t n, float lmbda,
+                                                               int reg_type, float* __restrict__ loss) {
+    constexpr int GPB = kBlock / G;
+    constexpr int NR = role_count(M);
+    const int gl = threadIdx.x % G;
+    const float inv_n = 1.0f / (float)n;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n; i += (int64_t)gridDim.x * GPB) {
+        const int64_t id[3] = {h[i], r[i], t[i]};
+        const float yy = (float)y[i];
+        Rows<M, NCH> R;
+        load_rows<M, G, NCH>(R, m, id, gl);
+        Saved<M, NCH> sv;
+        const float s = model_fwd<M, G, NCH>(R, m, sv);
+        const float x = yy * s;
+        acc += softplus_t(x) * inv_n;
+        const float ds = yy * sigmoid_t(x) * inv_n;
+        Rows<M, NCH> Gr;
+        model_bwd<M, G, NCH>(R, m, sv, ds, Gr);
+        if (reg_type != KGE_REG_NONE) {
+            float rs = 0.f;
+            const float c2 = 2.f * lmbda * inv_n, c3 = 3.f * lmbda * inv_n;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const float v = R.x[q][c];
+                    if (reg_type == KGE_REG_F2) { rs = fmaf(v, v, rs); Gr.x[q][c] += c2 * v; }
+                    else if (reg_type == KGE_REG_N3) { rs += v * v * v; Gr.x[q][c] += c3 * v * v; }
+                    else { const float a = fabsf(v); rs += a * a * a; Gr.x[q][c] += c3 * v * a; }
+                }
+            }
+            acc += lmbda * inv_n * gsum<G>(rs);
+        }
+        scatter_rows<M, G, NCH>(Gr, m, id, gl);
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
+
+// ---- self-adversarial loss coefficients (criterion.py:13-23).  In: energies.  Out (in place): dL/d energy.
+__global__ __launch_bounds__(kBlock) void k_selfadv_coeffs(float* __restrict__ pos, float* __restrict__ neg,
+                                                           int64_t n_pos, int neg_rate, float alpha,
+                                                           float* __restrict__ loss) {
+    const float inv_b = 1.0f / (float)n_pos;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pos; i += (int64_t)gridDim.x * blockDim.x) {
+        float* ng = neg + i * neg_rate;
+        float mx = -INFINITY;
+        for (int j = 0; j < neg_rate; ++j) mx = fmaxf(mx, -ng[j] * alpha);
+        float den = 0.f;
+        for (int j = 0; j < neg_rate; ++j) den += expf(-ng[j] * alpha - mx);
+        float term = 0.f;
+        for (int j = 0; j < neg_rate; ++j) {
+            const float nj = -ng[j];
+            const float w = expf(nj * alpha - mx) / den;
+            term += w * logsigmoid_t(-nj);
+            ng[j] = -(w * sigmoid_t(nj)) * inv_b;
+        }
+        const float p = -pos[i];
+        acc += (-term - logsigmoid_t(p)) * inv_b;
+        pos[i] = sigmoid_t(-p) * inv_b;
+    }
+    block_accumulate_loss<1>(acc, 0, loss);
+}
+
+// ------------------------------------------------------------------ dispatch
+template <int M, int G, int NCH>
+struct Launch {
+    static int grid(int64_t n) {
+        int64_t b = (n + (kBlock / G) - 1) / (kBlock / G);
+        return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
+    }
+};
+
+#define KGE_FOR_GEOMETRY(MID, G_, NCH_, BODY)                   \
+    if (geo.G == G_ && geo.NCH == NCH_) {                       \
+        constexpr int M = MID;                                  \
+        constexpr int G = G_; constexpr int NCH = NCH_;         \
+        BODY;                                                   \
+        return check_launch(#MID);                              \
+    }
+#define KGE_FOR_MODEL(MID, BODY)                                \
+    case MID: {                                                 \
+        KGE_FOR_GEOMETRY(MID, 32, 1, BODY)                      \
+        KGE_FOR_GEOMETRY(MID, 32, 2, BODY)                      \
+        KGE_FOR_GEOMETRY(MID, 32, 4, BODY)                      \
+        KGE_FOR_GEOMETRY(MID, 32, 8, BODY)                      \
+        KGE_FOR_GEOMETRY(MID, 64, 8, BODY)                      \
+        KGE_FOR_GEOMETRY(MID, 64, 16, BODY)                     \
+        break;                                                  \
+    }
+#define KGE_DISPATCH(model_id, BODY)                            \
+    switch (model_id) {                                         \
+        KGE_FOR_MODEL(KGE_TRANSE, BODY)                         \
+        KGE_FOR_MODEL(KGE_TRANSH, BODY)                         \
+        KGE_FOR_MODEL(KGE_TRANSD, BODY)                         \
+        KGE_FOR_MODEL(KGE_ROTATE, BODY)                         \
+        KGE_FOR_MODEL(KGE_DISTMULT, BODY)                       \
+        KGE_FOR_MODEL(KGE_COMPLEX, BODY)                        \
+        KGE_FOR_MODEL(KGE_ANALOGY, BODY)                        \
+        default: break;                                         \
+    }
+
+static bool geometry_for(const kge_model_desc* m, Geometry* geo) {
+    if (!pick_geometry(m->dim, geo)) {
+        set_error("hidden size %d exceeds the register-resident row kernels (max 1024)", m->dim);
+        return false;
+    }
+    return true;
+}
+
+int launch_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                         int64_t n, float* scores, hipStream_t s) {
+    Geometry geo;
+    if (!geometry_for(m, &geo)) return -1;
+    const DeviceModel dm = to_device_model(m);
+    KGE_DISPATCH(m->model, (k_score_fwd<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, n, scores)))
+    set_error("kge_score_forward: unsupported model %d", m->model);
+    return -1;
+}
+
+int launch_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                          int64_t n, const float* dscore, hipStream_t s) {
+    Geometry geo;
+    if (!geometry_for(m, &geo)) return -1;
+    const DeviceModel dm = to_device_model(m);
+    KGE_DISPATCH(m->model, (k_score_bwd<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, n, dscore)))
+    set_error("kge_score_backward: unsupported model %d", m->model);
+    return -1;
+}
+
+int launch_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                          const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float margin,
+                          float* loss, hipStream_t s) {
+    Geometry geo;
+    if (!geometry_for(m, &geo)) return -1;
+    const DeviceModel dm = to_device_model(m);
+    KGE_DISPATCH(m->model, (k_pairwise_hinge<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, ph, pr, pt, nh, nr, nt, n, margin, loss)))
+    set_error("kge_train_pairwise_hinge: unsupported model %d", m->model);
+    return -1;
+}
+
+int launch_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                              const int64_t* y, int64_t n, float lmbda, int reg_type, float* loss, hipStream_t s) {
+    Geometry geo;
+    if (!geometry_for(m, &geo)) return -1;
+    const DeviceModel dm = to_device_model(m);
+    KGE_DISPATCH(m->model, (k_pointwise_logistic<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, lmbda, reg_type, loss)))
+    set_error("kge_train_pointwise_logistic: unsupported model %d", m->model);
+    return -1;
+}
+
+int launch_selfadv_coeffs(float* pos_scores, float* neg_scores, int64_t n_pos, int neg_rate, float alpha,
+                          float* loss, hipStream_t s) {
+    int64_t b = (n_pos + kBlock - 1) / kBlock;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    hipLaunchKernelGGL(k_selfadv_coeffs, dim3((int)b), dim3(kBlock), 0, s, pos_scores, neg_scores, n_pos, neg_rate,
+                       alpha, loss);
+    return check_launch("k_selfadv_coeffs");
+}
+
+}  // namespace kge

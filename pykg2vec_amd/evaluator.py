@@ -1,0 +1,182 @@
+"""Drop-in Evaluator / MetricCalculator (pykg2vec/utils/evaluator.py) on the fused rank sweep.
+
+Same constructor `(model, config, tuning=False)`, same `mini_test / full_test / test / test_tail_rank /
+test_head_rank` and `metric_calculator.{reset,settle,get_curr_scores,display_summary,save_test_summary}` surface
+and dict fields, but `test()` ranks ALL requested triples in one kge_eval_ranks call: no per-triple id tensors, no
+topk sort, no ordering copied to the host, no python rank loop.  The hr_t / tr_h dict-of-set caches are flattened
+once into per-query CSR lists on the device.
+"""
+import os
+import timeit
+
+import numpy as np
+import torch
+
+from . import kernels as K
+
+
+def _log(msg):
+    print(msg, flush=True)
+
+
+class MetricCalculator:
+    """utils/evaluator.py:15-222, fed with rank arrays instead of candidate orderings."""
+
+    def __init__(self, config):
+        self.config = config
+        self.hr_t = config.knowledge_graph.read_cache_data('hr_t')
+        self.tr_h = config.knowledge_graph.read_cache_data('tr_h')
+        self.mr, self.fmr, self.mrr, self.fmrr, self.hit, self.fhit = {}, {}, {}, {}, {}, {}
+        self.epoch = None
+        self.reset()
+
+    def reset(self):
+        self.rank_head, self.rank_tail, self.f_rank_head, self.f_rank_tail = [], [], [], []
+        self.epoch = None
+        self.start_time = timeit.default_timer()
+
+    def append_ranks(self, ranks, epoch):
+        """ranks: int array [4, n] = rank_head, rank_tail, filtered head, filtered tail (0-based)."""
+        self.epoch = epoch
+        self.rank_head = list(ranks[0])
+        self.rank_tail = list(ranks[1])
+        self.f_rank_head = list(ranks[2])
+        self.f_rank_tail = list(ranks[3])
+
+    def settle(self):  # evaluator.py:125-141
+        head_ranks = np.asarray(self.rank_head, dtype=np.float32) + 1
+        tail_ranks = np.asarray(self.rank_tail, dtype=np.float32) + 1
+        head_franks = np.asarray(self.f_rank_head, dtype=np.float32) + 1
+        tail_franks = np.asarray(self.f_rank_tail, dtype=np.float32) + 1
+        ranks = np.concatenate((head_ranks, tail_ranks))
+        franks = np.concatenate((head_franks, tail_franks))
+        self.mr[self.epoch] = np.mean(ranks)
+        self.mrr[self.epoch] = np.mean(np.reciprocal(ranks))
+        self.fmr[self.epoch] = np.mean(franks)
+        self.fmrr[self.epoch] = np.mean(np.reciprocal(franks))
+        for hit in self.config.hits:
+            self.hit[(self.epoch, hit)] = np.mean(ranks <= hit, dtype=np.float32)
+            self.fhit[(self.epoch, hit)] = np.mean(franks <= hit, dtype=np.float32)
+
+    def get_curr_scores(self):
+        return {'mr': self.mr[self.epoch], 'fmr': self.fmr[self.epoch],
+                'mrr': self.mrr[self.epoch], 'fmrr': self.fmrr[self.epoch]}
+
+    def display_summary(self):
+        dt = timeit.default_timer() - self.start_time
+        lines = ["", "------Test Results for %s: Epoch: %s --- time: %.2f------------" % (
+            getattr(self.config, "dataset_name", "?"), self.epoch, dt),
+            "--# of entities, # of relations: %d, %d" % (self.config.tot_entity, self.config.tot_relation),
+            "--mr,  filtered mr             : %.4f, %.4f" % (self.mr[self.epoch], self.fmr[self.epoch]),
+            "--mrr, filtered mrr            : %.4f, %.4f" % (self.mrr[self.epoch], self.fmrr[self.epoch])]
+        for hit in self.config.hits:
+            lines.append("--hits%d                        : %.4f " % (hit, self.hit[(self.epoch, hit)]))
+            lines.append("--filtered hits%d               : %.4f " % (hit, self.fhit[(self.epoch, hit)]))
+        lines.append("---------------------------------------------------------")
+        _log("\n".join(lines))
+
+    def save_test_summary(self, model_name):
+        """CSV of the per-epoch metrics, same columns as evaluator.py:186-206."""
+        path = getattr(self.config, "path_result", None)
+        if path is None:
+            return
+        import pandas as pd
+        columns = ['Epoch', 'Mean Rank', 'Filtered Mean Rank', 'Mean Reciprocal Rank', 'Filtered Mean Reciprocal Rank']
+        for hit in self.config.hits:
+            columns += ['Hit-%d Ratio' % hit, 'Filtered Hit-%d Ratio' % hit]
+        rows = []
+        for epoch in self.mr:
+            row = [epoch, self.mr[epoch], self.fmr[epoch], self.mrr[epoch], self.fmrr[epoch]]
+            for hit in self.config.hits:
+                row += [self.hit[(epoch, hit)], self.fhit[(epoch, hit)]]
+            rows.append(row)
+        n = len([f for f in os.listdir(str(path)) if model_name in f and 'Testing' in f])
+        pd.DataFrame(rows, columns=columns).to_csv(os.path.join(str(path), "%s_Testing_results_%d.csv" % (model_name, n)))
+
+
+def _as_array(data, n):
+    """Triple objects (`.h .r .t`, data/kgcontroller.py:26-58) or an [N,3] array -> int64 [n,3]."""
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data[:n], dtype=np.int64)
+    return np.asarray([[data[i].h, data[i].r, data[i].t] for i in range(n)], dtype=np.int64).reshape(-1, 3)
+
+
+def build_filter_csr(triples, hr_t, tr_h):
+    """Flatten hr_t[(h,r)] / tr_h[(t,r)] (dict of sets) into per-query CSR: (tail_off, tail_ids, head_off, head_ids)."""
+    n = triples.shape[0]
+    t_off = np.zeros(n + 1, dtype=np.int64)
+    h_off = np.zeros(n + 1, dtype=np.int64)
+    t_ids, h_ids = [], []
+    for i in range(n):
+        h, r, t = int(triples[i, 0]), int(triples[i, 1]), int(triples[i, 2])
+        a = hr_t.get((h, r), ())
+        b = tr_h.get((t, r), ())
+        t_ids.extend(a)
+        h_ids.extend(b)
+        t_off[i + 1] = t_off[i] + len(a)
+        h_off[i + 1] = h_off[i] + len(b)
+    return (t_off, np.asarray(t_ids, dtype=np.int32).reshape(-1), h_off, np.asarray(h_ids, dtype=np.int32).reshape(-1))
+
+
+class Evaluator:
+    """utils/evaluator.py:225-334."""
+
+    def __init__(self, model, config, tuning=False):
+        self.model = model
+        self.config = config
+        self.tuning = tuning
+        self.test_data = config.knowledge_graph.read_cache_data('triplets_test')
+        self.eval_data = config.knowledge_graph.read_cache_data('triplets_valid')
+        self.metric_calculator = MetricCalculator(config)
+        self._cache = {}
+
+    # --- single-query hooks kept for Trainer.infer_* style callers (evaluator.py:249-273)
+    def test_tail_rank(self, h, r, topk=-1):
+        dev = self.config.device
+        return self.model.predict_tail_rank(torch.as_tensor([int(h)], device=dev), torch.as_tensor([int(r)], device=dev),
+                                            topk=topk).squeeze(0)
+
+    def test_head_rank(self, r, t, topk=-1):
+        dev = self.config.device
+        return self.model.predict_head_rank(torch.as_tensor([int(t)], device=dev), torch.as_tensor([int(r)], device=dev),
+                                            topk=topk).squeeze(0)
+
+    def mini_test(self, epoch=None):
+        n = len(self.eval_data) if self.config.test_num == 0 else min(self.config.test_num, len(self.eval_data))
+        if self.config.debug:
+            n = 10
+        _log("Mini-Testing on [%d/%d] Triples in the valid set." % (n, len(self.eval_data)))
+        return self.test(self.eval_data, n, epoch=epoch)
+
+    def full_test(self, epoch=None):
+        n = 10 if self.config.debug else len(self.test_data)
+        _log("Full-Testing on [%d/%d] Triples in the test set." % (n, len(self.test_data)))
+        return self.test(self.test_data, n, epoch=epoch)
+
+    def _device_inputs(self, data, n):
+        key = (id(data), n)
+        if key not in self._cache:
+            trip = _as_array(data, n)
+            mc = self.metric_calculator
+            csr = build_filter_csr(trip, mc.hr_t, mc.tr_h)
+            dev = next(self.model.parameters()).device
+            self._cache[key] = (torch.from_numpy(trip).to(dev),) + tuple(torch.from_numpy(a).to(dev) for a in csr)
+        return self._cache[key]
+
+    def rank_all(self, data, n):
+        """int32 [4, n] device tensor of ranks for the first n triples of `data`."""
+        trip, t_off, t_ids, h_off, h_ids = self._device_inputs(data, n)
+        if getattr(self.model, "kernel_name", None) == "rescal":
+            self.model.normalize_tables()  # the reference's forward renormalises during eval too (pairwise.py:843-844)
+        return K.eval_ranks(self.model.make_desc(), trip, t_off, t_ids, h_off, h_ids)
+
+    def test(self, data, num_of_test, epoch=None):
+        mc = self.metric_calculator
+        mc.reset()
+        ranks = self.rank_all(data, num_of_test).cpu().numpy()  # the one D2H copy: 4*n int32
+        mc.append_ranks(ranks, epoch)
+        mc.settle()
+        mc.display_summary()
+        if mc.epoch is not None and mc.epoch >= self.config.epochs - 1:
+            mc.save_test_summary(self.model.model_name)
+        return mc.get_curr_scores()

@@ -1,0 +1,93 @@
+"""Device-resident batch generator (drop-in for pykg2vec/data/generator.py:244-315).
+
+The reference runs one feeder process and `num_process_gen` worker processes that corrupt triples in python loops
+and ship lists through multiprocessing queues (data/generator.py:11-158).  Here the train triples, the relation
+property (bern) table and an open-addressing hash set of the train triples live in HBM, and a batch is one
+`kge_corrupt` kernel launch.  Same iterator surface: `start_one_epoch(num_batch)`, `next()`, `stop()`; the yielded
+lists have the reference layouts (pairwise: [ph, pr, pt, nh, nr, nt]; pointwise: [h, r, t, y] with every positive
+followed by its neg_rate negatives), as int64 device tensors instead of python lists.
+
+Batch order: like the reference feeder, ONE permutation of the train set is drawn when the generator is created
+(data/generator.py:23) and every epoch walks it from the start.
+"""
+import numpy as np
+import torch
+
+from . import kernels as K
+from .common import TrainingStrategy
+
+
+def _triples_array(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.int64)
+    if torch.is_tensor(data):
+        return data.cpu().numpy().astype(np.int64)
+    return np.asarray([[x.h, x.r, x.t] for x in data], dtype=np.int64).reshape(-1, 3)
+
+
+class Generator:
+    def __init__(self, model, config, seed=None, rank=0, world_size=1):
+        self.model = model
+        self.config = config
+        self.training_strategy = model.training_strategy
+        if self.training_strategy not in (TrainingStrategy.PAIRWISE_BASED, TrainingStrategy.POINTWISE_BASED):
+            raise NotImplementedError("This strategy is not supported.")
+        self.device = torch.device(config.device if isinstance(config.device, str) else config.device)
+        train = _triples_array(config.knowledge_graph.read_cache_data('triplets_train'))
+        self.n_train = train.shape[0]
+        self.seed = int(seed if seed is not None else getattr(config, "seed", 0) or 0)
+        self.rank, self.world_size = rank, world_size
+        rng = np.random.default_rng(self.seed)
+        perm = rng.permutation(self.n_train)
+        self.triples = torch.from_numpy(train).to(self.device)
+        self.perm = torch.from_numpy(perm).to(self.device)
+        self.slots = K.triple_set_build(self.triples)
+        self.bern = None
+        if getattr(config, "sampling", "uniform") == "bern":
+            prop = config.knowledge_graph.read_cache_data('relationproperty')
+            table = np.asarray([prop[r] for r in range(config.tot_relation)], dtype=np.float32)
+            self.bern = torch.from_numpy(table).to(self.device)
+        self.neg_rate = int(config.neg_rate)
+        self.batch_size = int(config.batch_size)
+        self._pending = 0
+        self._batch_idx = 0
+        self._draws = 0  # Philox counter offset: unique per generated negative over the whole run
+
+    def __iter__(self):
+        return self
+
+    def start_one_epoch(self, num_batch):
+        self._pending = int(num_batch)
+        self._batch_idx = 0
+
+    def stop(self):
+        self._pending = 0
+
+    def __next__(self):
+        if self._pending <= 0:
+            raise StopIteration
+        b = self._batch_idx
+        self._batch_idx += 1
+        self._pending -= 1
+        B = self.batch_size
+        ids = self.perm[B * b: B * (b + 1)]
+        offset = self._draws
+        self._draws += B * self.neg_rate
+        if self.world_size > 1:  # data-parallel shard of the batch; Philox counters stay global
+            per = (ids.numel() + self.world_size - 1) // self.world_size
+            lo = self.rank * per
+            ids = ids[lo: lo + per]
+            offset += lo * self.neg_rate
+        pos = self.triples.index_select(0, ids)
+        ph, pr, pt = pos[:, 0].contiguous(), pos[:, 1].contiguous(), pos[:, 2].contiguous()
+        nh, nr, nt = K.corrupt(ph, pr, pt, self.neg_rate, self.config.tot_entity, self.bern, self.slots, self.seed, offset)
+        if self.training_strategy == TrainingStrategy.PAIRWISE_BASED:
+            return [ph, pr, pt, nh, nr, nt]
+        n = ph.numel()
+        k = self.neg_rate
+        H = torch.cat([ph.view(n, 1), nh.view(n, k)], dim=1).reshape(-1)
+        R = torch.cat([pr.view(n, 1), nr.view(n, k)], dim=1).reshape(-1)
+        T = torch.cat([pt.view(n, 1), nt.view(n, k)], dim=1).reshape(-1)
+        Y = torch.ones((n, 1 + k), dtype=torch.int64, device=self.device)
+        Y[:, 1:] = -1
+        return [H, R, T, Y.reshape(-1)]

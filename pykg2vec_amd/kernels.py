@@ -1,0 +1,192 @@
+"""Torch-tensor front end of the C ABI: argument checks, descriptor building, stream plumbing.
+
+PyTorch is used here only for device memory and the current HIP stream; all arithmetic happens in
+libkge_hip.so.  Every function raises if a tensor is not a contiguous tensor on a HIP device.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+
+MODEL_IDS = {"transe": L.TRANSE, "transh": L.TRANSH, "transd": L.TRANSD, "rotate": L.ROTATE, "rescal": L.RESCAL,
+             "ntn": L.NTN, "distmult": L.DISTMULT, "complex": L.COMPLEX, "complexn3": L.COMPLEX, "analogy": L.ANALOGY}
+OPTIMIZER_IDS = {"sgd": L.OPT_SGD, "adam": L.OPT_ADAM, "adagrad": L.OPT_ADAGRAD, "rms": L.OPT_RMSPROP}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype, what):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a tensor" % what)
+    if not t.is_cuda:
+        raise L.KgeHipError("%s must live on the HIP device (got %s); the HIP path has no CPU fallback" % (what, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s (got %s)" % (what, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % what)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _ids(t, what):
+    return _dev(t, torch.int64, what)
+
+
+def make_desc(model_name, tables, grads=None, *, tot_entity, tot_relation, dim, rel_dim=None, l1_flag=False,
+              margin=0.0):
+    """Build a kge_model_desc.  `tables` / `grads`: lists of fp32 device tensors in parameter_list order."""
+    d = L.ModelDesc()
+    d.model = MODEL_IDS[model_name]
+    d.flags = L.FLAG_L1 if l1_flag else 0
+    d.tot_entity, d.tot_relation = int(tot_entity), int(tot_relation)
+    d.dim = int(dim)
+    d.rel_dim = int(rel_dim if rel_dim is not None else dim)
+    d.margin = float(margin)
+    d.phase_scale = 0.0
+    if model_name == "rotate":
+        # embedding_range = (margin + 2) / hidden_size ; phase = r / (embedding_range / pi)   (pairwise.py:747,781)
+        d.phase_scale = 1.0 / (((float(margin) + 2.0) / dim) / 3.14159265358979323846)
+    for i, t in enumerate(tables):
+        d.tables[i] = _dev(t, torch.float32, "table %d" % i).value
+    if grads is not None:
+        for i, g in enumerate(grads):
+            if g.shape != tables[i].shape:
+                raise ValueError("grad %d shape %s != table shape %s" % (i, tuple(g.shape), tuple(tables[i].shape)))
+            d.grads[i] = _dev(g, torch.float32, "grad %d" % i).value
+    d._keepalive = (tables, grads)  # python-side references
+    return d
+
+
+def score_forward(desc, h, r, t):
+    n = h.numel()
+    if r.numel() != n or t.numel() != n:
+        raise ValueError("h, r, t must have equal lengths")
+    out = torch.empty(n, dtype=torch.float32, device=h.device)
+    L.check(L.load().kge_score_forward(ctypes.byref(desc), _ids(h, "h"), _ids(r, "r"), _ids(t, "t"), n,
+                                       _dev(out, torch.float32, "scores"), _stream()), "kge_score_forward")
+    return out
+
+
+def score_backward(desc, h, r, t, dscore):
+    n = h.numel()
+    L.check(L.load().kge_score_backward(ctypes.byref(desc), _ids(h, "h"), _ids(r, "r"), _ids(t, "t"), n,
+                                        _dev(dscore, torch.float32, "dscore"), _stream()), "kge_score_backward")
+
+
+def rescal_normalize(ent, rel, k):
+    L.check(L.load().kge_rescal_normalize(_dev(ent, torch.float32, "ent"), ent.shape[0], _dev(rel, torch.float32, "rel"),
+                                          rel.shape[0], k, _stream()), "kge_rescal_normalize")
+
+
+def new_loss_buffer(device):
+    return torch.zeros(L.LOSS_SLOTS * L.LOSS_STRIDE, dtype=torch.float32, device=device)
+
+
+def read_loss(buf):
+    """Total of the striped loss accumulators (a device tensor; no sync)."""
+    return buf.view(L.LOSS_SLOTS, L.LOSS_STRIDE)[:, 0].sum()
+
+
+def train_pairwise_hinge(desc, ph, pr, pt, nh, nr, nt, margin, loss_buf):
+    n = ph.numel()
+    if nh.numel() != n:
+        raise ValueError("pairwise_hinge needs neg_rate == 1 (criterion.py:27 adds [B] to [B*neg_rate])")
+    L.check(L.load().kge_train_pairwise_hinge(ctypes.byref(desc), _ids(ph, "ph"), _ids(pr, "pr"), _ids(pt, "pt"),
+                                              _ids(nh, "nh"), _ids(nr, "nr"), _ids(nt, "nt"), n, float(margin),
+                                              _dev(loss_buf, torch.float32, "loss"), _stream()),
+            "kge_train_pairwise_hinge")
+
+
+def train_pairwise_selfadv(desc, ph, pr, pt, nh, nr, nt, neg_rate, alpha, loss_buf, workspace=None):
+    n = ph.numel()
+    if nh.numel() != n * neg_rate:
+        raise ValueError("negatives must be [B*neg_rate]")
+    if workspace is None or workspace.numel() < n * (1 + neg_rate):
+        workspace = torch.empty(n * (1 + neg_rate), dtype=torch.float32, device=ph.device)
+    L.check(L.load().kge_train_pairwise_selfadv(ctypes.byref(desc), _ids(ph, "ph"), _ids(pr, "pr"), _ids(pt, "pt"),
+                                                _ids(nh, "nh"), _ids(nr, "nr"), _ids(nt, "nt"), n, int(neg_rate),
+                                                float(alpha), _dev(workspace, torch.float32, "workspace"),
+                                                _dev(loss_buf, torch.float32, "loss"), _stream()),
+            "kge_train_pairwise_selfadv")
+    return workspace
+
+
+def train_pointwise_logistic(desc, h, r, t, y, lmbda, reg_type, loss_buf):
+    n = h.numel()
+    L.check(L.load().kge_train_pointwise_logistic(ctypes.byref(desc), _ids(h, "h"), _ids(r, "r"), _ids(t, "t"),
+                                                  _ids(y, "y"), n, float(lmbda), int(reg_type),
+                                                  _dev(loss_buf, torch.float32, "loss"), _stream()),
+            "kge_train_pointwise_logistic")
+
+
+def optimizer_step(kind, param, grad, state1, state2, lr, step, zero_grad=True):
+    p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
+    p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
+    L.check(L.load().kge_optimizer_step(OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"),
+                                        _dev(grad, torch.float32, "grad"), p1, p2, param.numel(), float(lr), int(step),
+                                        1 if zero_grad else 0, _stream()), "kge_optimizer_step")
+
+
+def eval_workspace(desc, n, device):
+    nbytes = L.load().kge_eval_workspace_bytes(ctypes.byref(desc), int(n))
+    if nbytes == 0:
+        L.check(-1, "kge_eval_workspace_bytes")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def eval_ranks(desc, triples, tail_off, tail_ids, head_off, head_ids, workspace=None):
+    """triples int64 [n,3]; CSR filter lists (int64 offsets [n+1], int32 ids) or None.  Returns int32 [4,n]:
+    rank_head, rank_tail, filtered_rank_head, filtered_rank_tail (0-based)."""
+    n = triples.shape[0]
+    if workspace is None:
+        workspace = eval_workspace(desc, n, triples.device)
+    ranks = torch.empty((4, n), dtype=torch.int32, device=triples.device)
+    args = []
+    for off, ids in ((tail_off, tail_ids), (head_off, head_ids)):
+        if off is None:
+            args += [None, None]
+        else:
+            args += [_dev(off, torch.int64, "csr offsets"), _dev(ids, torch.int32, "csr ids")]
+    L.check(L.load().kge_eval_ranks(ctypes.byref(desc), _ids(triples, "triples"), n, *args,
+                                    _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
+                                    _dev(ranks, torch.int32, "ranks"), _stream()), "kge_eval_ranks")
+    return ranks
+
+
+def eval_sweep_scores(desc, triples, workspace=None):
+    """float32 [2n, E]: row 2i = energies of (h_i, r_i, e) for all e, row 2i+1 = energies of (e, r_i, t_i)."""
+    n = triples.shape[0]
+    if workspace is None:
+        workspace = eval_workspace(desc, n, triples.device)
+    out = torch.empty((2 * n, desc.tot_entity), dtype=torch.float32, device=triples.device)
+    L.check(L.load().kge_eval_sweep_scores(ctypes.byref(desc), _ids(triples, "triples"), n,
+                                           _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
+                                           _dev(out, torch.float32, "scores"), _stream()), "kge_eval_sweep_scores")
+    return out
+
+
+def triple_set_build(triples):
+    """Open-addressing hash set of the train triples (uint64 slots, power of two >= 2n)."""
+    n = triples.shape[0]
+    n_slots = 1 << max(4, math.ceil(math.log2(max(2 * n, 2))))
+    slots = torch.empty(n_slots, dtype=torch.int64, device=triples.device)  # uint64 payload
+    L.check(L.load().kge_triple_set_build(_ids(triples, "triples"), n, ctypes.c_void_p(slots.data_ptr()), n_slots,
+                                          _stream()), "kge_triple_set_build")
+    return slots
+
+
+def corrupt(ph, pr, pt, neg_rate, tot_entity, bern_prob, slots, seed, offset):
+    n = ph.numel()
+    nh = torch.empty(n * neg_rate, dtype=torch.int64, device=ph.device)
+    nr = torch.empty_like(nh)
+    nt = torch.empty_like(nh)
+    bp = _dev(bern_prob, torch.float32, "bern_prob") if bern_prob is not None else None
+    sp = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
+    L.check(L.load().kge_corrupt(_ids(ph, "ph"), _ids(pr, "pr"), _ids(pt, "pt"), n, int(neg_rate), int(tot_entity), bp,
+                                 sp, slots.numel() if slots is not None else 0, int(seed) & (2 ** 64 - 1),
+                                 int(offset) & (2 ** 64 - 1), _ids(nh, "nh"), _ids(nr, "nr"), _ids(nt, "nt"),
+                                 _stream()), "kge_corrupt")
+    return nh, nr, nt

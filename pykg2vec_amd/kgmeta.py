@@ -1,0 +1,104 @@
+"""Model base classes mirroring pykg2vec/models/KGMeta.py:14-80 and models/Domain.py:8-17, with `forward`
+routed to the HIP scorer through a torch.autograd.Function (dense gradients, like nn.Embedding(sparse=False))."""
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .common import TrainingStrategy
+
+
+class NamedEmbedding(nn.Embedding):
+    """nn.Embedding carrying a human-readable `.name` (models/Domain.py:8-17)."""
+
+    def __init__(self, name, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._name = name
+
+    @property
+    def name(self):
+        return self._name
+
+
+class _HipScore(torch.autograd.Function):
+    """scores = Model.forward(h, r, t) on the HIP scorer; backward scatters dense table gradients."""
+
+    @staticmethod
+    def forward(ctx, model, h, r, t, *weights):
+        h, r, t = h.contiguous(), r.contiguous(), t.contiguous()
+        desc = model.make_desc(weights)
+        ctx.model = model
+        ctx.save_for_backward(h, r, t, *weights)
+        return K.score_forward(desc, h, r, t)
+
+    @staticmethod
+    def backward(ctx, dscore):
+        h, r, t, *weights = ctx.saved_tensors
+        grads = [torch.zeros_like(w) for w in weights]
+        desc = ctx.model.make_desc(weights, grads)
+        K.score_backward(desc, h, r, t, dscore.contiguous())
+        return (None, None, None, None) + tuple(grads)
+
+
+class Model:
+    """KGMeta.Model (models/KGMeta.py:14-38)."""
+
+    kernel_name = None  # key into kernels.MODEL_IDS
+
+    def load_params(self, param_list, kwargs):
+        for param_name in param_list:
+            if param_name not in kwargs:
+                raise Exception("hyperparameter %s not found!" % param_name)
+            self.database[param_name] = kwargs[param_name]
+        return self.database
+
+    def get_reg(self, h, r, t, **kwargs):
+        return 0.0
+
+    # ---- HIP plumbing
+    def desc_kwargs(self):
+        raise NotImplementedError
+
+    def make_desc(self, weights=None, grads=None):
+        if weights is None:
+            weights = [p.weight for p in self.parameter_list]
+        return K.make_desc(self.kernel_name, list(weights), None if grads is None else list(grads),
+                           tot_entity=self.tot_entity, tot_relation=self.tot_relation, **self.desc_kwargs())
+
+    def forward(self, h, r, t):
+        return _HipScore.apply(self, h, r, t, *[p.weight for p in self.parameter_list])
+
+    # ---- the reference Evaluator's optional hooks (utils/evaluator.py:250-252,263-265): candidate ids by
+    # descending energy, shape [1, topk]; served by the sweep kernels instead of forward() over E id tensors.
+    def _sweep(self, h, r, t):
+        trip = torch.stack([h.view(-1)[0], r.view(-1)[0], t.view(-1)[0]]).view(1, 3).contiguous()
+        return K.eval_sweep_scores(self.make_desc(), trip)
+
+    def predict_tail_rank(self, h, r, topk=-1):
+        scores = self._sweep(h, r, torch.zeros_like(h))[0]
+        _, rank = torch.topk(scores, k=topk)
+        return rank.view(1, -1)
+
+    def predict_head_rank(self, t, r, topk=-1):
+        scores = self._sweep(torch.zeros_like(t), r, t)[1]
+        _, rank = torch.topk(scores, k=topk)
+        return rank.view(1, -1)
+
+
+class PairwiseModel(nn.Module, Model):
+    forward = Model.forward  # nn.Module.forward precedes Model.forward in the MRO
+
+    def __init__(self, model_name):
+        super().__init__()
+        self.model_name = model_name
+        self.training_strategy = TrainingStrategy.PAIRWISE_BASED
+        self.database = {}
+
+
+class PointwiseModel(nn.Module, Model):
+    forward = Model.forward
+
+    def __init__(self, model_name):
+        super().__init__()
+        self.model_name = model_name
+        self.training_strategy = TrainingStrategy.POINTWISE_BASED
+        self.database = {}

@@ -1,0 +1,214 @@
+"""Drop-in Trainer for the hot loop of pykg2vec/utils/trainer.py (build_model :103-144, train_step_* :147-180,
+train_model_epoch :259-307, train_model :182-239, tune_model :241-257) on the fused MI355X path.
+
+Per step the reference issues ~30 ATen kernels, two autograd graphs, a dense torch.optim sweep per table and a
+`loss.item()` sync.  Here a step is: one fused score+loss+backward kernel (gradients scattered into ONE flat dense
+buffer), at most one all-reduce of that buffer (data parallel over RCCL), one fused dense optimiser sweep over ONE
+flat parameter buffer (which also clears the gradients), and no host synchronisation until the epoch ends.
+
+Early stopping / checkpoint export / plotting are outside the hot path and stay with the
+reference; INTEGRATION.md shows how to graft `train_model_epoch` onto the reference Trainer.
+"""
+import torch
+
+from . import kernels as K
+from .common import Monitor, TrainingStrategy
+from .evaluator import Evaluator
+from .generator import Generator
+
+
+def _log(msg):
+    print(msg, flush=True)
+
+
+class FlatState:
+    """All parameter tables of a model re-homed into one flat fp32 buffer (16-byte aligned segments) with matching
+    flat gradient and optimiser-state buffers: one optimiser launch and one collective per step."""
+
+    def __init__(self, model, optimizer):
+        params = [p.weight for p in model.parameter_list]
+        dev = params[0].device
+        offs, tot = [], 0
+        for p in params:
+            offs.append(tot)
+            tot += (p.numel() + 3) // 4 * 4
+        self.numel = tot
+        self.param = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.views, self.grad_views = [], []
+        for p, o in zip(params, offs):
+            v = self.param[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v  # nn.Parameter keeps its name/shape; storage is now the flat buffer
+            self.views.append(v)
+            self.grad_views.append(self.grad[o:o + p.numel()].view_as(p))
+        self.optimizer = optimizer
+        self.state1 = torch.zeros_like(self.param) if optimizer in ("adam", "adagrad", "rms") else None
+        self.state2 = torch.zeros_like(self.param) if optimizer == "adam" else None
+        self.step = 0
+
+    def optimizer_step(self, lr):
+        self.step += 1
+        K.optimizer_step(self.optimizer, self.param, self.grad, self.state1, self.state2, lr, self.step, zero_grad=True)
+
+
+class EarlyStopper:
+    """utils/trainer.py:21-69 (patience on the monitored metric)."""
+
+    def __init__(self, patience, monitor):
+        self.patience, self.monitor = patience, monitor
+        self.previous = None
+        self.remaining = patience
+
+    def should_stop(self, metrics):
+        cur = metrics[self.monitor.value]
+        if self.previous is not None:
+            lower_is_better = self.monitor in (Monitor.MEAN_RANK, Monitor.FILTERED_MEAN_RANK)
+            worse = cur > self.previous if lower_is_better else cur < self.previous
+            if worse:
+                self.remaining -= 1
+                if self.remaining == 0:
+                    return True
+            else:
+                self.remaining = self.patience
+        self.previous = cur
+        return False
+
+
+class Trainer:
+    def __init__(self, model, config, process_group=None):
+        self.model = model
+        self.config = config
+        self.training_results = []
+        self.evaluator = None
+        self.generator = None
+        self.flat = None
+        self.early_stopper = None
+        self.monitor = None
+        self.process_group = process_group
+        self.world_size = 1
+        self.rank = 0
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world_size = torch.distributed.get_world_size(process_group)
+            self.rank = torch.distributed.get_rank(process_group)
+
+    # ------------------------------------------------------------------ build
+    def build_model(self, monitor=Monitor.FILTERED_MEAN_RANK):
+        if self.config.optimizer not in K.OPTIMIZER_IDS:
+            raise NotImplementedError("No support for %s optimizer" % self.config.optimizer)
+        self.model.to(self.config.device)
+        self.flat = FlatState(self.model, self.config.optimizer)
+        self.evaluator = Evaluator(self.model, self.config)
+        self.loss_buf = K.new_loss_buffer(self.flat.param.device)
+        self.early_stopper = EarlyStopper(getattr(self.config, "patience", 3), monitor)
+        self._desc = self.model.make_desc([v for v in self.flat.views], self.flat.grad_views)
+        self._selfadv_ws = None
+        if self.world_size > 1:  # replicas must start identical
+            torch.distributed.broadcast(self.flat.param, src=0, group=self.process_group)
+
+    # ------------------------------------------------------------------ one step (gradients into flat.grad)
+    def _accumulate_pairwise(self, ph, pr, pt, nh, nr, nt):
+        name = self.model.model_name.lower()
+        if name == "rescal":
+            self.model.normalize_tables()
+        if name == "rotate":
+            self._selfadv_ws = K.train_pairwise_selfadv(self._desc, ph, pr, pt, nh, nr, nt, self.config.neg_rate,
+                                                        self.config.alpha, self.loss_buf, self._selfadv_ws)
+        elif self.model.kernel_name in ("rescal", "ntn"):
+            self._accumulate_dense_pairwise(ph, pr, pt, nh, nr, nt)
+        else:
+            K.train_pairwise_hinge(self._desc, ph, pr, pt, nh, nr, nt, self.config.margin, self.loss_buf)
+
+    def _accumulate_dense_pairwise(self, ph, pr, pt, nh, nr, nt):
+        """RESCAL / NTN: MFMA scorer + hinge coefficients + MFMA backward (three launches)."""
+        sp = K.score_forward(self._desc, ph, pr, pt)
+        sn = K.score_forward(self._desc, nh, nr, nt)
+        v = sp + self.config.margin - sn
+        coef = (v > 0).to(torch.float32) + 0.5 * (v == 0).to(torch.float32)
+        self.loss_buf[0] += torch.clamp_min(v, 0).sum()
+        K.score_backward(self._desc, ph, pr, pt, coef)
+        K.score_backward(self._desc, nh, nr, nt, -coef)
+        if self.model.kernel_name == "ntn":  # NTN.get_reg: lmbda * sqrt(sum w^2), dense over every table
+            sq = sum((p * p).sum() for p in self.flat.views)
+            root = torch.sqrt(sq)
+            self.loss_buf[0] += self.model.lmbda * root
+            for g, p in zip(self.flat.grad_views, self.flat.views):
+                g.add_(p, alpha=1.0).sub_(p).add_(p * (self.model.lmbda / root))
+
+    def _accumulate_pointwise(self, h, r, t, y):
+        K.train_pointwise_logistic(self._desc, h, r, t, y, self.model.lmbda, self.model.kernel_reg_type(), self.loss_buf)
+
+    def _reduce_and_step(self):
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.flat.grad, group=self.process_group)
+        self.flat.optimizer_step(self.config.learning_rate)
+
+    def train_step_pairwise(self, pos_h, pos_r, pos_t, neg_h, neg_r, neg_t):
+        """Loss of one batch as a device scalar (no sync); gradients are left in the flat buffer."""
+        self.loss_buf.zero_()
+        self._accumulate_pairwise(pos_h, pos_r, pos_t, neg_h, neg_r, neg_t)
+        return K.read_loss(self.loss_buf)
+
+    def train_step_pointwise(self, h, r, t, target):
+        self.loss_buf.zero_()
+        self._accumulate_pointwise(h, r, t, target)
+        return K.read_loss(self.loss_buf)
+
+    # ------------------------------------------------------------------ epochs
+    def train_model_epoch(self, epoch_idx, tuning=False):
+        num_batch = self.config.tot_train_triples // self.config.batch_size if not self.config.debug else 10
+        self.generator.start_one_epoch(num_batch)
+        self.model.train()
+        self.loss_buf.zero_()
+        pairwise = self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED
+        for _ in range(num_batch):
+            data = next(self.generator)
+            if pairwise:
+                self._accumulate_pairwise(*data)
+            else:
+                self._accumulate_pointwise(*data)
+            self._reduce_and_step()
+        acc = K.read_loss(self.loss_buf)
+        if self.world_size > 1:
+            torch.distributed.all_reduce(acc, group=self.process_group)
+            if not pairwise or self.model.model_name.lower() == "rotate":
+                acc = acc / self.world_size  # mean-type losses: average of per-rank means
+        acc_loss = float(acc.item())  # the only host sync of the epoch
+        self.training_results.append([epoch_idx, acc_loss])
+        return acc_loss
+
+    def _new_generator(self):
+        return Generator(self.model, self.config, rank=self.rank, world_size=self.world_size)
+
+    def train_model(self):
+        self.generator = self._new_generator()
+        self.monitor = Monitor.FILTERED_MEAN_RANK
+        cur_epoch_idx = 0
+        for cur_epoch_idx in range(self.config.epochs):
+            _log("Epoch[%d/%d]" % (cur_epoch_idx, self.config.epochs))
+            loss = self.train_model_epoch(cur_epoch_idx)
+            _log("acc_loss: %f" % loss)
+            if cur_epoch_idx % self.config.test_step == 0:
+                self.model.eval()
+                with torch.no_grad():
+                    metrics = self.evaluator.mini_test(cur_epoch_idx)
+                if self.early_stopper.should_stop(metrics):
+                    break
+        self.model.eval()
+        with torch.no_grad():
+            self.evaluator.full_test(cur_epoch_idx)
+        self.generator.stop()
+        return cur_epoch_idx
+
+    def tune_model(self):
+        current_loss = float("inf")
+        self.generator = self._new_generator()
+        self.evaluator = Evaluator(self.model, self.config, tuning=True)
+        cur_epoch_idx = 0
+        for cur_epoch_idx in range(self.config.epochs):
+            current_loss = self.train_model_epoch(cur_epoch_idx, tuning=True)
+        self.model.eval()
+        with torch.no_grad():
+            self.evaluator.full_test(cur_epoch_idx)
+        self.generator.stop()
+        return current_loss

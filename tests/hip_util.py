@@ -1,0 +1,65 @@
+"""GPU-side test helpers: build drop-in models from golden cases / oracle parameter dicts."""
+import types
+
+import numpy as np
+import torch
+
+import pykg2vec_amd as pa
+from golden_util import Case
+
+CLASS_OF = {"transe": "transe", "transh": "transh", "transd": "transd", "rotate": "rotate", "rescal": "rescal",
+            "ntn": "ntn", "distmult": "distmult", "complex": "complex", "complexn3": "complexn3", "analogy": "analogy"}
+DEV = "cuda"
+
+
+class KG:
+    def __init__(self, cache):
+        self.cache = cache
+        self.dataset_name = "synthetic"
+
+    def read_cache_data(self, key):
+        return self.cache[key]
+
+
+def make_config(E, R, hp, train, valid, test, optimizer="sgd", lr=0.05, batch_size=32, device=DEV, **extra):
+    allt = np.concatenate([train, valid, test])
+    hr_t, tr_h = {}, {}
+    for h, r, t in allt:
+        hr_t.setdefault((int(h), int(r)), set()).add(int(t))
+        tr_h.setdefault((int(t), int(r)), set()).add(int(h))
+    cfg = types.SimpleNamespace(
+        tot_entity=E, tot_relation=R, device=device, optimizer=optimizer, learning_rate=lr,
+        neg_rate=hp.get("neg_rate", 1), alpha=hp.get("alpha", 0.1), margin=hp.get("margin", 1.0),
+        batch_size=batch_size, epochs=1000, test_num=0, test_step=1, debug=False, hits=[1, 3, 5, 10], patience=3,
+        dataset_name="synthetic", sampling="uniform", tot_train_triples=len(train), seed=0,
+        knowledge_graph=KG({"triplets_train": train, "triplets_valid": valid, "triplets_test": test,
+                            "hr_t": hr_t, "tr_h": tr_h}))
+    for k, v in hp.items():
+        setattr(cfg, k, v)
+    for k, v in extra.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def model_from_params(model_name, params, hp, E, R, device=DEV):
+    cls = pa.import_model(model_name)
+    kw = dict(hp)
+    kw.update(tot_entity=E, tot_relation=R)
+    m = cls(**kw)
+    with torch.no_grad():
+        for k, v in params.items():
+            getattr(m, k).weight.copy_(torch.from_numpy(np.asarray(v, dtype=np.float32)))
+    return m.to(device)
+
+
+def model_from_case(c, prefix="init.", device=DEV):
+    return model_from_params(c.model, c.params(prefix), c.hp, c.E, c.R, device)
+
+
+def dev(a, dtype=torch.int64):
+    return torch.as_tensor(np.asarray(a), dtype=dtype, device=DEV)
+
+
+def params_of(model):
+    return {p_name: getattr(model, p_name).weight.detach().cpu().numpy()
+            for p_name in [n.split(".")[0] for n, _ in model.named_parameters()]}

@@ -1,0 +1,231 @@
+"""Parity of the HIP path (through the C ABI) with (a) the frozen outputs of the live reference in tests/golden
+and (b) the CPU oracle on seeded inputs of other shapes.  fp32 tolerance: atol 1e-5 + rtol 1e-5 on energies
+(BASELINE.json north_star); integer ranks exact given equal scores."""
+import numpy as np
+import pytest
+import torch
+
+import kge_oracle as ko
+from golden_util import CASES, Case, close
+
+pytestmark = pytest.mark.gpu
+
+VECTOR_CASES = [c for c in CASES if c not in ("rescal", "ntn")]
+GRAD_TOL = dict(atol=2e-5, rtol=1e-4)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import hip_util
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return hip_util
+
+
+@pytest.mark.parametrize("name", VECTOR_CASES)
+def test_forward_matches_reference_golden(hip, name):
+    c = Case(name)
+    m = hip.model_from_case(c)
+    b = c.batch(0)
+    with torch.no_grad():
+        if c.pointwise:
+            got = m(hip.dev(b[0]), hip.dev(b[1]), hip.dev(b[2])).cpu().numpy()
+            assert close(got, c.z["scores0"]), np.abs(got - c.z["scores0"]).max()
+        else:
+            gp = m(hip.dev(b[0]), hip.dev(b[1]), hip.dev(b[2])).cpu().numpy()
+            gn = m(hip.dev(b[3]), hip.dev(b[4]), hip.dev(b[5])).cpu().numpy()
+            assert close(gp, c.z["scores0_pos"]) and close(gn, c.z["scores0_neg"])
+
+
+@pytest.mark.parametrize("name", VECTOR_CASES)
+def test_autograd_path_matches_reference_grads(hip, name):
+    """model.forward + Criterion loss + loss.backward(): the path the UNMODIFIED reference Trainer drives
+    (utils/trainer.py:147-180,298)."""
+    c = Case(name)
+    m = hip.model_from_case(c)
+    b = [hip.dev(x) for x in c.batch(0)]
+    m.train()
+    if c.pointwise:
+        preds = m(b[0], b[1], b[2])
+        loss = m.loss(preds, b[3].type(preds.type())) + m.get_reg(b[0], b[1], b[2])
+    else:
+        pos, neg = m(b[0], b[1], b[2]), m(b[3], b[4], b[5])
+        if m.model_name == "rotate":
+            loss = m.loss(pos, neg, c.hp["neg_rate"], c.hp["alpha"])
+        else:
+            loss = m.loss(pos, neg, c.hp["margin"])
+        loss = loss + m.get_reg(None, None, None)
+    loss.backward()
+    assert close(loss.item(), c.z["loss0"]), (loss.item(), c.z["loss0"])
+    for k, p in m.named_parameters():
+        ref = c.z["grad0." + k]
+        got = p.grad.cpu().numpy()
+        assert np.allclose(got, ref, **GRAD_TOL), (k, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("name", VECTOR_CASES)
+def test_fused_step_matches_reference_loss_and_grads(hip, name):
+    from pykg2vec_amd.trainer import Trainer
+    c = Case(name)
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test)
+    m = hip.model_from_case(c)
+    tr = Trainer(m, cfg)
+    tr.build_model()
+    b = [hip.dev(x) for x in c.batch(0)]
+    loss = tr.train_step_pointwise(*b) if c.pointwise else tr.train_step_pairwise(*b)
+    assert close(loss.item(), c.z["loss0"], atol=2e-5, rtol=2e-5), (loss.item(), c.z["loss0"])
+    for p, g in zip(m.parameter_list, tr.flat.grad_views):
+        name_ = [n for n, q in m.named_parameters() if q is p.weight][0]
+        ref = c.z["grad0." + name_]
+        assert np.allclose(g.cpu().numpy(), ref, **GRAD_TOL), (name_, np.abs(g.cpu().numpy() - ref).max())
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam", "adagrad", "rms"])
+@pytest.mark.parametrize("name", VECTOR_CASES)
+def test_three_fused_training_steps_match_reference_weights(hip, name, opt):
+    from pykg2vec_amd.trainer import Trainer
+    c = Case(name)
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer=opt, lr=0.05)
+    m = hip.model_from_case(c)
+    tr = Trainer(m, cfg)
+    tr.build_model()
+    losses = []
+    for s in range(3):
+        b = [hip.dev(x) for x in c.batch(s)]
+        loss = tr.train_step_pointwise(*b) if c.pointwise else tr.train_step_pairwise(*b)
+        tr._reduce_and_step()
+        losses.append(loss.item())
+    assert close(np.asarray(losses), c.z["%s.losses" % opt], atol=3e-5, rtol=3e-5)
+    tol = 2e-3 if opt == "rms" else 1e-4  # see tests/test_oracle_golden.py on RMSprop's noise amplification
+    for k, p in m.named_parameters():
+        ref = c.z["%s.final.%s" % (opt, k)]
+        got = p.detach().cpu().numpy()
+        assert np.allclose(got, ref, atol=tol, rtol=1e-4), (k, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("name", VECTOR_CASES)
+def test_eval_sweep_scores_and_ranks_match_reference(hip, name):
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.evaluator import Evaluator
+    c = Case(name)
+    m = hip.model_from_case(c, "adam.final.")
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test)
+    sw = K.eval_sweep_scores(m.make_desc(), hip.dev(c.test[:4])).cpu().numpy()
+    assert close(sw, c.z["eval.sweeps"], atol=2e-5, rtol=2e-5), np.abs(sw - c.z["eval.sweeps"]).max()
+    ev = Evaluator(m, cfg)
+    n = len(c.z["eval.rank_head"])
+    ranks = ev.rank_all(c.test, n).cpu().numpy()
+    ref = np.stack([c.z["eval.rank_head"], c.z["eval.rank_tail"], c.z["eval.frank_head"], c.z["eval.frank_tail"]])
+    # ranks are exact functions of OUR fp32 scores (checked below); against the reference they may differ only
+    # where two candidates are closer than the fp32 tolerance band
+    scores = K.eval_sweep_scores(m.make_desc(), hip.dev(c.test[:n])).cpu().numpy()
+    hr_t, tr_h = c.filters()
+    for i, (h, r, t) in enumerate(c.test[:n]):
+        rt = ko.rank_from_scores(scores[2 * i], int(t), hr_t[(int(h), int(r))])
+        rh = ko.rank_from_scores(scores[2 * i + 1], int(h), tr_h[(int(t), int(r))])
+        assert (ranks[1, i], ranks[3, i]) == rt and (ranks[0, i], ranks[2, i]) == rh
+    assert np.abs(ranks - ref).max() <= 1 and (ranks != ref).sum() <= 2, (ranks, ref)
+    metrics = ev.test(c.test, n, epoch=0)
+    assert np.isclose(metrics["fmr"], c.z["eval.fmr"], rtol=0.02)
+
+
+def test_pretrained_fb15k_transe_slice(hip):
+    import os
+    from golden_util import GOLDEN
+    from pykg2vec_amd.evaluator import Evaluator
+    z = np.load(os.path.join(GOLDEN, "ref_pretrained_transe_fb15k.npz"))
+    P = {"ent_embeddings": z["init.ent_embeddings.weight"], "rel_embeddings": z["init.rel_embeddings.weight"]}
+    for l1, key in ((True, "l1"), (False, "l2")):
+        hp = dict(hidden_size=50, l1_flag=l1, margin=1.0)
+        m = hip.model_from_params("transe", P, hp, int(z["E"]), int(z["R"]))
+        with torch.no_grad():
+            got = m(hip.dev(z["ids.h"]), hip.dev(z["ids.r"]), hip.dev(z["ids.t"])).cpu().numpy()
+        assert close(got, z["scores_" + key]), np.abs(got - z["scores_" + key]).max()
+        cfg = hip.make_config(int(z["E"]), int(z["R"]), hp, z["train"], z["valid"], z["test"])
+        n = len(z["eval_%s.rank_head" % key])
+        ranks = Evaluator(m, cfg).rank_all(z["test"], n).cpu().numpy()
+        ref = np.stack([z["eval_%s.%s" % (key, k)] for k in ("rank_head", "rank_tail", "frank_head", "frank_tail")])
+        assert (ranks != ref).sum() <= 3 and np.abs(ranks - ref).max() <= 2, (ranks != ref).sum()
+
+
+SHAPES = [("transe", dict(hidden_size=50, l1_flag=True), 1), ("transe", dict(hidden_size=100, l1_flag=False), 1),
+          ("transe", dict(hidden_size=200, l1_flag=True), 1), ("transe", dict(hidden_size=300, l1_flag=True), 1),
+          ("transh", dict(hidden_size=100, l1_flag=True), 1), ("transd", dict(ent_hidden_size=64, rel_hidden_size=64, l1_flag=False), 1),
+          ("rotate", dict(hidden_size=1000, margin=24.0, neg_rate=16, alpha=1.0), 16),
+          ("rotate", dict(hidden_size=33, margin=6.0, neg_rate=3, alpha=0.5), 3),
+          ("distmult", dict(hidden_size=100, lmbda=0.01), 2), ("complex", dict(hidden_size=200, lmbda=1e-4), 1),
+          ("complexn3", dict(hidden_size=37, lmbda=0.05), 2), ("analogy", dict(hidden_size=200, lmbda=0.01), 1)]
+
+
+@pytest.mark.parametrize("model,hp,neg_rate", SHAPES)
+def test_scores_loss_grads_vs_oracle_other_shapes(hip, model, hp, neg_rate):
+    """Every (G, NCH) register geometry of the row kernels, against the oracle on seeded inputs."""
+    from pykg2vec_amd.trainer import Trainer
+    rng = np.random.default_rng(42)
+    E, R, B = 300, 11, 160
+    shape_kw = {k: v for k, v in hp.items() if k in ("hidden_size", "ent_hidden_size", "rel_hidden_size", "margin")}
+    if model != "rotate":
+        shape_kw.pop("margin", None)
+    P = ko.init_params(model, rng, tot_entity=E, tot_relation=R, **shape_kw)
+    hp = dict(hp)
+    hp.setdefault("margin", 1.0)
+    pos = np.stack([rng.integers(E, size=B), rng.integers(R, size=B), rng.integers(E, size=B)], 1)
+    nh = np.repeat(pos[:, 0], neg_rate); nr = np.repeat(pos[:, 1], neg_rate); nt = np.repeat(pos[:, 2], neg_rate)
+    flip = rng.random(B * neg_rate) > 0.5
+    rnd = rng.integers(E, size=B * neg_rate)
+    nh = np.where(flip, nh, rnd); nt = np.where(flip, rnd, nt)
+    pointwise = model in ko.POINTWISE
+    if pointwise:
+        batch = ko.pointwise_layout(pos, nh, nr, nt, neg_rate)
+    else:
+        batch = (pos[:, 0], pos[:, 1], pos[:, 2], nh, nr, nt)
+    hp_run = dict(hp, neg_rate=neg_rate)
+    loss_ref, G_ref, scores_ref, _ = ko.train_step_grads(model, P, batch, **hp_run)
+    m = hip.model_from_params(model, P, hp, E, R)
+    cfg = hip.make_config(E, R, hp_run, pos, pos[:1], pos[:1])
+    tr = Trainer(m, cfg)
+    tr.build_model()
+    b = [hip.dev(x) for x in batch]
+    with torch.no_grad():
+        s0 = m(b[0], b[1], b[2]).cpu().numpy()
+    assert close(s0, scores_ref[0], atol=2e-5, rtol=2e-5), np.abs(s0 - scores_ref[0]).max()
+    loss = tr.train_step_pointwise(*b) if pointwise else tr.train_step_pairwise(*b)
+    assert np.isclose(loss.item(), loss_ref, rtol=5e-5, atol=5e-5), (loss.item(), loss_ref)
+    names = [n.split(".")[0] for n, _ in m.named_parameters()]
+    for nme, g in zip(names, tr.flat.grad_views):
+        got = g.cpu().numpy()
+        scale = max(1.0, np.abs(G_ref[nme]).max())
+        assert np.allclose(got, G_ref[nme], atol=5e-5 * scale, rtol=2e-4), (nme, np.abs(got - G_ref[nme]).max())
+
+
+def test_missing_gpu_tensor_fails_loudly(hip):
+    import pykg2vec_amd.pairwise as pw
+    from pykg2vec_amd._lib import KgeHipError
+    m = pw.TransE(tot_entity=10, tot_relation=3, hidden_size=8, l1_flag=True)  # left on the CPU
+    with pytest.raises(KgeHipError):
+        m(torch.tensor([1]), torch.tensor([1]), torch.tensor([1]))
+
+
+def test_sampler_invariants_and_determinism(hip):
+    from pykg2vec_amd import kernels as K
+    c = Case("transe_l1")
+    train = hip.dev(c.train)
+    slots = K.triple_set_build(train)
+    train_set = {tuple(map(int, x)) for x in c.train}
+    ph, pr, pt = train[:, 0].contiguous(), train[:, 1].contiguous(), train[:, 2].contiguous()
+    nh, nr, nt = K.corrupt(ph, pr, pt, 4, c.E, None, slots, seed=7, offset=0)
+    nh2, _, nt2 = K.corrupt(ph, pr, pt, 4, c.E, None, slots, seed=7, offset=0)
+    assert torch.equal(nh, nh2) and torch.equal(nt, nt2)
+    NH, NR, NT = nh.cpu().numpy(), nr.cpu().numpy(), nt.cpu().numpy()
+    tails = 0
+    for j in range(len(NH)):
+        h, r, t = c.train[j // 4]
+        assert NR[j] == r and (NH[j] == h or NT[j] == t)
+        assert (int(NH[j]), int(NR[j]), int(NT[j])) not in train_set
+        assert 0 <= NH[j] < c.E and 0 <= NT[j] < c.E
+        tails += int(NH[j] == h and NT[j] != t)
+    frac = tails / len(NH)
+    assert 0.42 < frac < 0.58, frac  # uniform sampling: P(corrupt tail) = 0.5
+    bern = torch.full((c.R,), 0.9, device="cuda")  # prob 0.9 -> tail corrupted when u > 0.9
+    nh3, _, nt3 = K.corrupt(ph, pr, pt, 4, c.E, bern, slots, seed=7, offset=0)
+    frac_t = float((nh3.view(-1, 4) == ph.view(-1, 1)).float().mean())
+    assert 0.05 < frac_t < 0.2, frac_t
