@@ -141,6 +141,16 @@ int kge_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t
                 const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset,
                 int64_t* nh, int64_t* nr, int64_t* nt, void* stream);
 
+/* raw_data_generator + process_function_pairwise / _pointwise (data/generator.py:11-158) as ONE launch: the batch's
+ * positives are triples[perm[start + i]], i < n_pos (triples int64 [N,3], perm int64 [N]); negatives as kge_corrupt.
+ *   layout 0 (pairwise): out = {ph, pr, pt, nh, nr, nt}; positives [n_pos], negatives [n_pos*neg_rate]
+ *   layout 1 (pointwise): out = {h, r, t, y, -, -}, each [n_pos*(1+neg_rate)]: every positive (y=+1) is followed by its
+ *                         neg_rate negatives (y=-1) */
+int kge_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start, int64_t n_pos, int32_t neg_rate,
+                     int64_t tot_entity, const float* bern_prob, const uint64_t* slots, int64_t n_slots,
+                     uint64_t seed, uint64_t offset, int32_t layout,
+                     int64_t* o0, int64_t* o1, int64_t* o2, int64_t* o3, int64_t* o4, int64_t* o5, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

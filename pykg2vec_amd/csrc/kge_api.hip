@@ -211,4 +211,20 @@ int kge_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t
                           (hipStream_t)stream);
 }
 
+int kge_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start, int64_t n_pos, int32_t neg_rate,
+                     int64_t tot_entity, const float* bern_prob, const uint64_t* slots, int64_t n_slots, uint64_t seed,
+                     uint64_t offset, int32_t layout, int64_t* o0, int64_t* o1, int64_t* o2, int64_t* o3, int64_t* o4,
+                     int64_t* o5, void* stream) {
+    if (n_pos == 0) return 0;
+    if (!triples || !perm || start < 0 || n_pos < 0 || neg_rate <= 0 || tot_entity <= 1 || (layout != 0 && layout != 1) ||
+        !o0 || !o1 || !o2 || !o3 || (layout == 0 && (!o4 || !o5))) {
+        set_error("kge_sample_batch: bad arguments");
+        return -1;
+    }
+    if (slots && (n_slots & (n_slots - 1))) { set_error("kge_sample_batch: n_slots must be a power of two"); return -1; }
+    int64_t* const out[6] = {o0, o1, o2, o3, o4, o5};
+    return launch_sample_batch(triples, perm, start, n_pos, neg_rate, tot_entity, bern_prob, slots, n_slots, seed, offset,
+                               layout, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

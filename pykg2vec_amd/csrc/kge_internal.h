@@ -58,6 +58,10 @@ int launch_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int6
                    int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed,
                    uint64_t offset, int64_t* nh, int64_t* nr, int64_t* nt, hipStream_t s);
 
+int launch_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start, int64_t n_pos, int neg_rate,
+                        int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed,
+                        uint64_t offset, int layout, int64_t* const out[6], hipStream_t s);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -75,37 +75,68 @@ __host__ __device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c
     return o;
 }
 
-__global__ __launch_bounds__(256) void k_corrupt(const int64_t* __restrict__ ph, const int64_t* __restrict__ pr,
-                                                 const int64_t* __restrict__ pt, int64_t n_pos, int neg_rate, int64_t E,
-                                                 const float* __restrict__ bern, const unsigned long long* __restrict__ slots,
-                                                 unsigned long long mask, unsigned long long seed, unsigned long long offset,
-                                                 int64_t* __restrict__ nh, int64_t* __restrict__ nr, int64_t* __restrict__ nt) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_pos * neg_rate) return;
-    const int64_t i = j / neg_rate;
-    const int64_t h = ph[i], r = pr[i], t = pt[i];
-    const unsigned long long ctr = offset + (unsigned long long)j;
+// one corrupted triple for negative slot `ctr` of positive (h, r, t): Philox block a = 0, 1, 2, ... per attempt,
+// word 0 of block 0 decides head/tail, word 1 of each block is the candidate entity
+__device__ __forceinline__ void corrupt_one(int64_t h, int64_t r, int64_t t, int64_t E, const float* __restrict__ bern,
+                                            const unsigned long long* __restrict__ slots, unsigned long long mask,
+                                            unsigned long long seed, unsigned long long ctr, int64_t& oh, int64_t& ot) {
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     Philox x = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, k0, k1);
     const float u = (float)(x.c[0] >> 8) * (1.0f / 16777216.0f);  // 24-bit uniform in [0,1)
     const float prob = bern ? bern[r] : 0.5f;
     const bool corrupt_tail = u > prob;
-    int word = 1;
-    uint32_t round = 0;
+    uint32_t attempt = 0;
     int64_t e;
     for (;;) {
-        e = (int64_t)(((unsigned long long)x.c[word] * (unsigned long long)E) >> 32);  // uniform in [0,E)
+        e = (int64_t)(((unsigned long long)x.c[1] * (unsigned long long)E) >> 32);  // uniform in [0,E)
         const unsigned long long key = corrupt_tail ? pack_triple(h, r, e) : pack_triple(e, r, t);
         if (slots == nullptr || !set_contains(slots, mask, key)) break;
-        if (++word == 4) {
-            ++round;
-            x = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), round, 0u, k0, k1);
-            word = 0;
-        }
+        ++attempt;
+        x = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), attempt, 0u, k0, k1);
     }
-    nh[j] = corrupt_tail ? h : e;
-    nr[j] = r;
-    nt[j] = corrupt_tail ? e : t;
+    oh = corrupt_tail ? h : e;
+    ot = corrupt_tail ? e : t;
+}
+
+struct SampleArgs {
+    const int64_t* triples; const int64_t* perm; int64_t start;   // positives = triples[perm[start + i]] when perm != null
+    const int64_t* ph; const int64_t* pr; const int64_t* pt;      // ... else explicit positives
+    int64_t n_pos; int neg_rate; int64_t E;
+    const float* bern; const unsigned long long* slots; unsigned long long mask;
+    unsigned long long seed, offset;
+    int layout;                                                    // 0 pairwise: (oph,opr,opt) + (nh,nr,nt); 1 pointwise rows
+    int64_t *o0, *o1, *o2, *o3, *o4, *o5;
+};
+
+__global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.n_pos * a.neg_rate) return;
+    const int64_t i = j / a.neg_rate;
+    const int k = (int)(j - i * a.neg_rate);
+    int64_t h, r, t;
+    if (a.perm) {
+        const int64_t row = a.perm[a.start + i];
+        h = a.triples[3 * row]; r = a.triples[3 * row + 1]; t = a.triples[3 * row + 2];
+    } else {
+        h = a.ph[i]; r = a.pr[i]; t = a.pt[i];
+    }
+    int64_t oh, ot;
+    corrupt_one(h, r, t, a.E, a.bern, a.slots, a.mask, a.seed, a.offset + (unsigned long long)j, oh, ot);
+    if (a.layout == 0) {
+        if (k == 0 && a.o0) { a.o0[i] = h; a.o1[i] = r; a.o2[i] = t; }
+        a.o3[j] = oh; a.o4[j] = r; a.o5[j] = ot;
+    } else {  // data/generator.py:125-156: positive row (y=+1) followed by its neg_rate negatives (y=-1)
+        const int64_t base = i * (a.neg_rate + 1);
+        if (k == 0) { a.o0[base] = h; a.o1[base] = r; a.o2[base] = t; a.o3[base] = 1; }
+        a.o0[base + 1 + k] = oh; a.o1[base + 1 + k] = r; a.o2[base + 1 + k] = ot; a.o3[base + 1 + k] = -1;
+    }
+}
+
+static int launch_sample(const SampleArgs& a, hipStream_t s) {
+    if (a.E >= (1 << 24)) { set_error("kge sampler: more than 2^24 entities not supported by the packed key"); return -1; }
+    const int64_t tot = a.n_pos * a.neg_rate;
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a);
+    return check_launch("k_sample");
 }
 
 int launch_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, int64_t n_slots, hipStream_t s) {
@@ -120,12 +151,22 @@ int launch_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, 
 int launch_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t n_pos, int neg_rate, int64_t E,
                    const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset,
                    int64_t* nh, int64_t* nr, int64_t* nt, hipStream_t s) {
-    if (E >= (1 << 24)) { set_error("kge_corrupt: more than 2^24 entities not supported by the packed key"); return -1; }
-    const int64_t tot = n_pos * neg_rate;
-    hipLaunchKernelGGL(k_corrupt, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ph, pr, pt, n_pos, neg_rate, E, bern,
-                       (const unsigned long long*)slots, (unsigned long long)(slots ? n_slots - 1 : 0),
-                       (unsigned long long)seed, (unsigned long long)offset, nh, nr, nt);
-    return check_launch("k_corrupt");
+    SampleArgs a{};
+    a.ph = ph; a.pr = pr; a.pt = pt; a.n_pos = n_pos; a.neg_rate = neg_rate; a.E = E; a.bern = bern;
+    a.slots = (const unsigned long long*)slots; a.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
+    a.seed = seed; a.offset = offset; a.layout = 0; a.o3 = nh; a.o4 = nr; a.o5 = nt;
+    return launch_sample(a, s);
+}
+
+int launch_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start, int64_t n_pos, int neg_rate,
+                        int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed,
+                        uint64_t offset, int layout, int64_t* const out[6], hipStream_t s) {
+    SampleArgs a{};
+    a.triples = triples; a.perm = perm; a.start = start; a.n_pos = n_pos; a.neg_rate = neg_rate; a.E = E; a.bern = bern;
+    a.slots = (const unsigned long long*)slots; a.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
+    a.seed = seed; a.offset = offset; a.layout = layout;
+    a.o0 = out[0]; a.o1 = out[1]; a.o2 = out[2]; a.o3 = out[3]; a.o4 = out[4]; a.o5 = out[5];
+    return launch_sample(a, s);
 }
 
 }  // namespace kge

@@ -121,7 +121,8 @@ def build_filter_csr(triples, hr_t, tr_h):
 class Evaluator:
     """utils/evaluator.py:225-334."""
 
-    def __init__(self, model, config, tuning=False):
+    def __init__(self, model, config, tuning=False, backend=K):
+        self.K = backend
         self.model = model
         self.config = config
         self.tuning = tuning
@@ -167,8 +168,10 @@ class Evaluator:
         """int32 [4, n] device tensor of ranks for the first n triples of `data`."""
         trip, t_off, t_ids, h_off, h_ids = self._device_inputs(data, n)
         if getattr(self.model, "kernel_name", None) == "rescal":
-            self.model.normalize_tables()  # the reference's forward renormalises during eval too (pairwise.py:843-844)
-        return K.eval_ranks(self.model.make_desc(), trip, t_off, t_ids, h_off, h_ids)
+            # the reference's forward renormalises both tables during eval too (pairwise.py:843-844)
+            self.K.rescal_normalize(self.model.ent_embeddings.weight.data, self.model.rel_matrices.weight.data,
+                                    self.model.hidden_size)
+        return self.K.eval_ranks(self.K.model_desc(self.model), trip, t_off, t_ids, h_off, h_ids)
 
     def test(self, data, num_of_test, epoch=None):
         mc = self.metric_calculator

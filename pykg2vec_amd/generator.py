@@ -26,7 +26,8 @@ def _triples_array(data):
 
 
 class Generator:
-    def __init__(self, model, config, seed=None, rank=0, world_size=1):
+    def __init__(self, model, config, seed=None, rank=0, world_size=1, backend=K):
+        self.K = backend
         self.model = model
         self.config = config
         self.training_strategy = model.training_strategy
@@ -41,7 +42,7 @@ class Generator:
         perm = rng.permutation(self.n_train)
         self.triples = torch.from_numpy(train).to(self.device)
         self.perm = torch.from_numpy(perm).to(self.device)
-        self.slots = K.triple_set_build(self.triples)
+        self.slots = self.K.triple_set_build(self.triples)
         self.bern = None
         if getattr(config, "sampling", "uniform") == "bern":
             prop = config.knowledge_graph.read_cache_data('relationproperty')
@@ -70,24 +71,14 @@ class Generator:
         self._batch_idx += 1
         self._pending -= 1
         B = self.batch_size
-        ids = self.perm[B * b: B * (b + 1)]
+        start, n = B * b, max(0, min(B, self.n_train - B * b))
         offset = self._draws
         self._draws += B * self.neg_rate
         if self.world_size > 1:  # data-parallel shard of the batch; Philox counters stay global
-            per = (ids.numel() + self.world_size - 1) // self.world_size
-            lo = self.rank * per
-            ids = ids[lo: lo + per]
+            per = (n + self.world_size - 1) // self.world_size
+            lo = min(n, self.rank * per)
+            start, n = start + lo, max(0, min(per, n - lo))
             offset += lo * self.neg_rate
-        pos = self.triples.index_select(0, ids)
-        ph, pr, pt = pos[:, 0].contiguous(), pos[:, 1].contiguous(), pos[:, 2].contiguous()
-        nh, nr, nt = K.corrupt(ph, pr, pt, self.neg_rate, self.config.tot_entity, self.bern, self.slots, self.seed, offset)
-        if self.training_strategy == TrainingStrategy.PAIRWISE_BASED:
-            return [ph, pr, pt, nh, nr, nt]
-        n = ph.numel()
-        k = self.neg_rate
-        H = torch.cat([ph.view(n, 1), nh.view(n, k)], dim=1).reshape(-1)
-        R = torch.cat([pr.view(n, 1), nr.view(n, k)], dim=1).reshape(-1)
-        T = torch.cat([pt.view(n, 1), nt.view(n, k)], dim=1).reshape(-1)
-        Y = torch.ones((n, 1 + k), dtype=torch.int64, device=self.device)
-        Y[:, 1:] = -1
-        return [H, R, T, Y.reshape(-1)]
+        return self.K.sample_batch(self.triples, self.perm, start, n, self.neg_rate, self.config.tot_entity, self.bern,
+                              self.slots, self.seed, offset,
+                              pointwise=self.training_strategy == TrainingStrategy.POINTWISE_BASED)

@@ -60,6 +60,11 @@ def make_desc(model_name, tables, grads=None, *, tot_entity, tot_relation, dim, 
     return d
 
 
+def model_desc(model, weights=None, grads=None):
+    """Descriptor of a drop-in model object (kgmeta.Model.make_desc)."""
+    return model.make_desc(weights, grads)
+
+
 def score_forward(desc, h, r, t):
     n = h.numel()
     if r.numel() != n or t.numel() != n:
@@ -190,3 +195,27 @@ def corrupt(ph, pr, pt, neg_rate, tot_entity, bern_prob, slots, seed, offset):
                                  int(offset) & (2 ** 64 - 1), _ids(nh, "nh"), _ids(nr, "nr"), _ids(nt, "nt"),
                                  _stream()), "kge_corrupt")
     return nh, nr, nt
+
+
+def sample_batch(triples, perm, start, n_pos, neg_rate, tot_entity, bern_prob, slots, seed, offset, pointwise=False):
+    """One launch: positives triples[perm[start:start+n_pos]] + their corrupted negatives, in the reference's batch
+    layout (pairwise: [ph, pr, pt, nh, nr, nt]; pointwise: [h, r, t, y])."""
+    dev = triples.device
+    bp = _dev(bern_prob, torch.float32, "bern_prob") if bern_prob is not None else None
+    sp = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
+    if pointwise:
+        rows = n_pos * (1 + neg_rate)
+        buf = torch.empty((4, rows), dtype=torch.int64, device=dev)
+        outs = [buf[0], buf[1], buf[2], buf[3]]
+        ptrs = [ctypes.c_void_p(o.data_ptr()) for o in outs] + [None, None]
+    else:
+        nneg = n_pos * neg_rate
+        buf = torch.empty(3 * n_pos + 3 * nneg, dtype=torch.int64, device=dev)
+        outs = [buf[0:n_pos], buf[n_pos:2 * n_pos], buf[2 * n_pos:3 * n_pos], buf[3 * n_pos:3 * n_pos + nneg],
+                buf[3 * n_pos + nneg:3 * n_pos + 2 * nneg], buf[3 * n_pos + 2 * nneg:]]
+        ptrs = [ctypes.c_void_p(o.data_ptr()) for o in outs]
+    L.check(L.load().kge_sample_batch(_ids(triples, "triples"), _ids(perm, "perm"), int(start), int(n_pos), int(neg_rate),
+                                      int(tot_entity), bp, sp, slots.numel() if slots is not None else 0,
+                                      int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), 1 if pointwise else 0,
+                                      *ptrs, _stream()), "kge_sample_batch")
+    return outs

@@ -25,7 +25,8 @@ class FlatState:
     """All parameter tables of a model re-homed into one flat fp32 buffer (16-byte aligned segments) with matching
     flat gradient and optimiser-state buffers: one optimiser launch and one collective per step."""
 
-    def __init__(self, model, optimizer):
+    def __init__(self, model, optimizer, backend=K):
+        self.K = backend
         params = [p.weight for p in model.parameter_list]
         dev = params[0].device
         offs, tot = [], 0
@@ -49,7 +50,7 @@ class FlatState:
 
     def optimizer_step(self, lr):
         self.step += 1
-        K.optimizer_step(self.optimizer, self.param, self.grad, self.state1, self.state2, lr, self.step, zero_grad=True)
+        self.K.optimizer_step(self.optimizer, self.param, self.grad, self.state1, self.state2, lr, self.step, zero_grad=True)
 
 
 class EarlyStopper:
@@ -76,7 +77,11 @@ class EarlyStopper:
 
 
 class Trainer:
-    def __init__(self, model, config, process_group=None):
+    def __init__(self, model, config, process_group=None, backend=None):
+        # `backend` exists so that the multi-process plumbing (batch sharding, gradient all-reduce, replica
+        # consistency) can be exercised on CPU/gloo with a checker injected by tests; the product default -- and the
+        # only backend this package contains -- is the HIP library, which raises without a GPU.
+        self.K = backend if backend is not None else K
         self.model = model
         self.config = config
         self.training_results = []
@@ -94,14 +99,14 @@ class Trainer:
 
     # ------------------------------------------------------------------ build
     def build_model(self, monitor=Monitor.FILTERED_MEAN_RANK):
-        if self.config.optimizer not in K.OPTIMIZER_IDS:
+        if self.config.optimizer not in K.OPTIMIZER_IDS:  # sgd / adam / adagrad / rms (utils/trainer.py:112-131)
             raise NotImplementedError("No support for %s optimizer" % self.config.optimizer)
         self.model.to(self.config.device)
-        self.flat = FlatState(self.model, self.config.optimizer)
-        self.evaluator = Evaluator(self.model, self.config)
-        self.loss_buf = K.new_loss_buffer(self.flat.param.device)
+        self.flat = FlatState(self.model, self.config.optimizer, self.K)
+        self.evaluator = Evaluator(self.model, self.config, backend=self.K)
+        self.loss_buf = self.K.new_loss_buffer(self.flat.param.device)
         self.early_stopper = EarlyStopper(getattr(self.config, "patience", 3), monitor)
-        self._desc = self.model.make_desc([v for v in self.flat.views], self.flat.grad_views)
+        self._desc = self.K.model_desc(self.model, [v for v in self.flat.views], self.flat.grad_views)
         self._selfadv_ws = None
         if self.world_size > 1:  # replicas must start identical
             torch.distributed.broadcast(self.flat.param, src=0, group=self.process_group)
@@ -110,24 +115,24 @@ class Trainer:
     def _accumulate_pairwise(self, ph, pr, pt, nh, nr, nt):
         name = self.model.model_name.lower()
         if name == "rescal":
-            self.model.normalize_tables()
+            self.K.rescal_normalize(self.flat.views[0], self.flat.views[1], self.model.hidden_size)
         if name == "rotate":
-            self._selfadv_ws = K.train_pairwise_selfadv(self._desc, ph, pr, pt, nh, nr, nt, self.config.neg_rate,
+            self._selfadv_ws = self.K.train_pairwise_selfadv(self._desc, ph, pr, pt, nh, nr, nt, self.config.neg_rate,
                                                         self.config.alpha, self.loss_buf, self._selfadv_ws)
         elif self.model.kernel_name in ("rescal", "ntn"):
             self._accumulate_dense_pairwise(ph, pr, pt, nh, nr, nt)
         else:
-            K.train_pairwise_hinge(self._desc, ph, pr, pt, nh, nr, nt, self.config.margin, self.loss_buf)
+            self.K.train_pairwise_hinge(self._desc, ph, pr, pt, nh, nr, nt, self.config.margin, self.loss_buf)
 
     def _accumulate_dense_pairwise(self, ph, pr, pt, nh, nr, nt):
         """RESCAL / NTN: MFMA scorer + hinge coefficients + MFMA backward (three launches)."""
-        sp = K.score_forward(self._desc, ph, pr, pt)
-        sn = K.score_forward(self._desc, nh, nr, nt)
+        sp = self.K.score_forward(self._desc, ph, pr, pt)
+        sn = self.K.score_forward(self._desc, nh, nr, nt)
         v = sp + self.config.margin - sn
         coef = (v > 0).to(torch.float32) + 0.5 * (v == 0).to(torch.float32)
         self.loss_buf[0] += torch.clamp_min(v, 0).sum()
-        K.score_backward(self._desc, ph, pr, pt, coef)
-        K.score_backward(self._desc, nh, nr, nt, -coef)
+        self.K.score_backward(self._desc, ph, pr, pt, coef)
+        self.K.score_backward(self._desc, nh, nr, nt, -coef)
         if self.model.kernel_name == "ntn":  # NTN.get_reg: lmbda * sqrt(sum w^2), dense over every table
             sq = sum((p * p).sum() for p in self.flat.views)
             root = torch.sqrt(sq)
@@ -136,23 +141,40 @@ class Trainer:
                 g.add_(p, alpha=1.0).sub_(p).add_(p * (self.model.lmbda / root))
 
     def _accumulate_pointwise(self, h, r, t, y):
-        K.train_pointwise_logistic(self._desc, h, r, t, y, self.model.lmbda, self.model.kernel_reg_type(), self.loss_buf)
+        self.K.train_pointwise_logistic(self._desc, h, r, t, y, self.model.lmbda, self.model.kernel_reg_type(), self.loss_buf)
+
+    def _mean_type_loss(self):
+        """pointwise_logistic and the self-adversarial loss are MEANS over the batch (criterion.py:13-23,31-34);
+        the hinge is a SUM (criterion.py:25-29)."""
+        return (self.model.training_strategy != TrainingStrategy.PAIRWISE_BASED
+                or self.model.model_name.lower() == "rotate")
 
     def _reduce_and_step(self):
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.flat.grad, group=self.process_group)
+            # ONE collective per step over the flat gradient buffer.  Sum for the hinge; for mean-type losses each
+            # rank already divided by its local row count, so the global-batch mean is the average over ranks
+            # (exact when the global batch divides evenly over ranks).
+            dist = torch.distributed
+            if self._mean_type_loss():
+                if dist.get_backend(self.process_group) == "nccl":
+                    dist.all_reduce(self.flat.grad, op=dist.ReduceOp.AVG, group=self.process_group)
+                else:
+                    dist.all_reduce(self.flat.grad, group=self.process_group)
+                    self.flat.grad.div_(self.world_size)
+            else:
+                dist.all_reduce(self.flat.grad, group=self.process_group)
         self.flat.optimizer_step(self.config.learning_rate)
 
     def train_step_pairwise(self, pos_h, pos_r, pos_t, neg_h, neg_r, neg_t):
         """Loss of one batch as a device scalar (no sync); gradients are left in the flat buffer."""
         self.loss_buf.zero_()
         self._accumulate_pairwise(pos_h, pos_r, pos_t, neg_h, neg_r, neg_t)
-        return K.read_loss(self.loss_buf)
+        return self.K.read_loss(self.loss_buf)
 
     def train_step_pointwise(self, h, r, t, target):
         self.loss_buf.zero_()
         self._accumulate_pointwise(h, r, t, target)
-        return K.read_loss(self.loss_buf)
+        return self.K.read_loss(self.loss_buf)
 
     # ------------------------------------------------------------------ epochs
     def train_model_epoch(self, epoch_idx, tuning=False):
@@ -168,17 +190,17 @@ class Trainer:
             else:
                 self._accumulate_pointwise(*data)
             self._reduce_and_step()
-        acc = K.read_loss(self.loss_buf)
+        acc = self.K.read_loss(self.loss_buf)
         if self.world_size > 1:
             torch.distributed.all_reduce(acc, group=self.process_group)
-            if not pairwise or self.model.model_name.lower() == "rotate":
-                acc = acc / self.world_size  # mean-type losses: average of per-rank means
+            if self._mean_type_loss():
+                acc = acc / self.world_size  # average of per-rank means
         acc_loss = float(acc.item())  # the only host sync of the epoch
         self.training_results.append([epoch_idx, acc_loss])
         return acc_loss
 
     def _new_generator(self):
-        return Generator(self.model, self.config, rank=self.rank, world_size=self.world_size)
+        return Generator(self.model, self.config, rank=self.rank, world_size=self.world_size, backend=self.K)
 
     def train_model(self):
         self.generator = self._new_generator()
@@ -203,7 +225,7 @@ class Trainer:
     def tune_model(self):
         current_loss = float("inf")
         self.generator = self._new_generator()
-        self.evaluator = Evaluator(self.model, self.config, tuning=True)
+        self.evaluator = Evaluator(self.model, self.config, tuning=True, backend=self.K)
         cur_epoch_idx = 0
         for cur_epoch_idx in range(self.config.epochs):
             current_loss = self.train_model_epoch(cur_epoch_idx, tuning=True)

@@ -1,0 +1,71 @@
+"""N>1 path on CPU: world_size-2 gloo run of the data-parallel Trainer (batch sharded across ranks, ONE all-reduce
+of the flat gradient buffer per step, identical dense optimiser step on every replica) must reproduce the
+single-process full-batch result.  The compute backend is the test-only oracle backend (tests/oracle_backend.py);
+what is under test is the sharding / collective / replica-consistency logic of pykg2vec_amd.trainer+generator."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, model_name, opt, out_dir):
+    for p in (os.path.dirname(HERE), HERE, os.path.join(os.path.dirname(HERE), "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_backend
+    import hip_util
+    from golden_util import Case
+    from pykg2vec_amd.trainer import Trainer
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = Case(model_name)
+    cfg = hip_util.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer=opt, lr=0.05, batch_size=64,
+                               device="cpu")
+    cfg.debug = False
+    cfg.tot_train_triples = 64 * 3  # three steps per epoch
+    m = hip_util.model_from_case(c, device="cpu")
+    tr = Trainer(m, cfg, backend=oracle_backend)
+    tr.build_model()
+    tr.generator = tr._new_generator()
+    losses = [tr.train_model_epoch(e) for e in range(2)]
+    ranks = tr.evaluator.rank_all(c.test, 8).numpy()
+    np.savez(os.path.join(out_dir, "r%d_w%d.npz" % (rank, world)), losses=np.asarray(losses), ranks=ranks,
+             **{n: p.detach().numpy() for n, p in m.named_parameters()})
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model_name,opt", [("transe_l1", "adam"), ("distmult", "adagrad"), ("rotate", "sgd")])
+def test_two_rank_data_parallel_equals_single_process(tmp_path, model_name, opt):
+    out = str(tmp_path)
+    _run(0, 1, 0, model_name, opt, out)
+    port = _free_port()
+    mp.spawn(_run, args=(2, port, model_name, opt, out), nprocs=2, join=True)
+    one = np.load(os.path.join(out, "r0_w1.npz"))
+    a = np.load(os.path.join(out, "r0_w2.npz"))
+    b = np.load(os.path.join(out, "r1_w2.npz"))
+    for k in one.files:
+        if k in ("losses", "ranks"):
+            continue
+        assert np.array_equal(a[k], b[k]), "replicas diverged on %s" % k            # bit-identical replicas
+        assert np.allclose(a[k], one[k], atol=2e-5, rtol=1e-4), (k, np.abs(a[k] - one[k]).max())
+    assert np.allclose(a["losses"], one["losses"], rtol=1e-4)
+    assert np.array_equal(a["ranks"], b["ranks"])
+    assert np.abs(a["ranks"] - one["ranks"]).max() <= 1

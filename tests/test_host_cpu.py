@@ -1,0 +1,153 @@
+"""CPU-only checks of the boundary and host logic: the C-ABI library loads and exports every symbol
+include/kge_hip.h declares (no compute calls), the drop-in classes keep the reference's construction /
+naming contract (pinned by the key names inside tests/golden, which come from the live reference), the filter
+CSR / metric code agrees with the oracle, and the product path refuses to run without the GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import kge_oracle as ko
+from golden_util import CASES, Case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pykg2vec_amd import _lib
+    header = open(os.path.join(ROOT, "include", "kge_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(kge_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().kge_abi_version() == _lib.ABI_VERSION
+
+
+def test_model_desc_struct_matches_header_layout():
+    from pykg2vec_amd import _lib
+    # int32 model, uint32 flags, 2x int64, 2x int32, 2x float, 6+6 pointers
+    assert ctypes.sizeof(_lib.ModelDesc) == 4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 * 12
+    assert _lib.ModelDesc.tables.offset == 40 and _lib.ModelDesc.grads.offset == 88
+
+
+def test_argument_validation_without_gpu():
+    from pykg2vec_amd import _lib
+    lib = _lib.load()
+    d = _lib.ModelDesc()
+    d.model = 99
+    assert lib.kge_score_forward(ctypes.byref(d), None, None, None, 4, None, None) != 0
+    assert b"unknown model" in lib.kge_last_error()
+    d.model, d.dim, d.tot_entity, d.tot_relation = _lib.TRANSE, 8, 10, 3
+    assert lib.kge_score_forward(ctypes.byref(d), None, None, None, 4, None, None) != 0
+    assert b"table 0 is null" in lib.kge_last_error()
+    assert lib.kge_optimizer_step(0, None, None, None, None, 16, 0.1, 1, 1, None) != 0
+    assert lib.kge_triple_set_build(None, 5, None, 7, None) != 0  # 7 is not a power of two
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_dropin_classes_keep_reference_contract(name):
+    import pykg2vec_amd as pa
+    from pykg2vec_amd.common import TrainingStrategy
+    c = Case(name)
+    cls = pa.import_model(c.model)
+    kw = dict(c.hp, tot_entity=c.E, tot_relation=c.R)
+    m = cls(**kw)
+    ref_keys = sorted(k[len("init."):] for k in c.z.files if k.startswith("init."))
+    assert sorted(m.state_dict().keys()) == ref_keys                       # reference checkpoint key names
+    for k in ref_keys:
+        assert tuple(m.state_dict()[k].shape) == c.z["init." + k].shape
+    assert [p.weight.shape for p in m.parameter_list] == [c.z["init.%s.weight" % n].shape for n in ko.PARAM_NAMES[c.model]]
+    assert all(hasattr(p, "name") for p in m.parameter_list)
+    assert m.model_name == c.model
+    want = TrainingStrategy.POINTWISE_BASED if c.pointwise else TrainingStrategy.PAIRWISE_BASED
+    assert m.training_strategy == want
+    assert callable(m.loss) and callable(m.get_reg) and callable(m.embed)
+    m.load_state_dict({k: torch.from_numpy(c.z["init." + k]) for k in ref_keys})  # reference weights load as-is
+    first = next(iter(kw))
+    bad = dict(kw)
+    bad.pop("tot_entity")
+    with pytest.raises(Exception, match="hyperparameter tot_entity not found!"):
+        cls(**bad)
+
+
+def test_embed_matches_reference_tuple_shapes():
+    import pykg2vec_amd.pairwise as pw
+    import pykg2vec_amd.pointwise as pt
+    h = torch.tensor([1, 2]); r = torch.tensor([0, 1]); t = torch.tensor([3, 4])
+    assert len(pw.TransE(tot_entity=9, tot_relation=3, hidden_size=8, l1_flag=True).embed(h, r, t)) == 3
+    assert len(pw.RotatE(tot_entity=9, tot_relation=3, hidden_size=8, margin=6.0).embed(h, r, t)) == 6
+    assert len(pt.Complex(tot_entity=9, tot_relation=3, hidden_size=8, lmbda=0.1).embed(h, r, t)) == 6
+    a = pw.TransH(tot_entity=9, tot_relation=3, hidden_size=8, l1_flag=True)
+    eh, er, et = a.embed(h, r, t)
+    w = torch.nn.functional.normalize(a.w(r), dim=-1)
+    assert torch.allclose((eh * w).sum(-1), torch.zeros(2), atol=1e-6)  # projected onto the hyperplane
+
+
+def test_losses_match_oracle():
+    from pykg2vec_amd.criterion import Criterion
+    rng = np.random.default_rng(0)
+    pos = rng.normal(size=12).astype(np.float32); neg = rng.normal(size=36).astype(np.float32)
+    got = Criterion.pariwise_logistic(torch.from_numpy(pos), torch.from_numpy(neg), 3, 0.7).item()
+    assert np.isclose(got, ko.pairwise_logistic_selfadv(pos, neg, 3, 0.7)[0], rtol=1e-5)
+    assert np.isclose(Criterion.pairwise_hinge(torch.from_numpy(pos), torch.from_numpy(neg[:12]), 0.8).item(),
+                      ko.pairwise_hinge(pos, neg[:12], 0.8)[0], rtol=1e-5)
+    y = np.where(rng.random(12) > 0.5, 1, -1)
+    assert np.isclose(Criterion.pointwise_logistic(torch.from_numpy(pos), torch.from_numpy(y).float()).item(),
+                      ko.pointwise_logistic(pos, y)[0], rtol=1e-5)
+
+
+def test_filter_csr_and_metrics_match_oracle():
+    import types
+    from pykg2vec_amd.evaluator import MetricCalculator, build_filter_csr
+    c = Case("transe_l1")
+    hr_t, tr_h = c.filters()
+    t_off, t_ids, h_off, h_ids = build_filter_csr(c.test, hr_t, tr_h)
+    for i, (h, r, t) in enumerate(c.test):
+        assert set(t_ids[t_off[i]:t_off[i + 1]]) == hr_t[(int(h), int(r))]
+        assert set(h_ids[h_off[i]:h_off[i + 1]]) == tr_h[(int(t), int(r))]
+    kg = types.SimpleNamespace(read_cache_data=lambda k: {"hr_t": hr_t, "tr_h": tr_h}[k])
+    cfg = types.SimpleNamespace(knowledge_graph=kg, hits=[1, 3, 5, 10], tot_entity=c.E, tot_relation=c.R)
+    mc = MetricCalculator(cfg)
+    ranks = np.stack([c.z["eval.rank_head"], c.z["eval.rank_tail"], c.z["eval.frank_head"], c.z["eval.frank_tail"]])
+    mc.append_ranks(ranks, 0)
+    mc.settle()
+    for k in ("mr", "fmr", "mrr", "fmrr"):
+        assert np.isclose(mc.get_curr_scores()[k], c.z["eval." + k], rtol=1e-6)   # reference's own settled metrics
+    for hit in (1, 3, 5, 10):
+        assert np.isclose(mc.hit[(0, hit)], c.z["eval.hit%d" % hit]) and np.isclose(mc.fhit[(0, hit)], c.z["eval.fhit%d" % hit])
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import pykg2vec_amd.pairwise as pw
+    from pykg2vec_amd._lib import KgeHipError
+    m = pw.TransE(tot_entity=10, tot_relation=3, hidden_size=8, l1_flag=True)
+    with pytest.raises(KgeHipError, match="no CPU fallback"):
+        m(torch.tensor([1]), torch.tensor([1]), torch.tensor([1]))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pykg2vec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "kge_oracle" not in text and "oracle_backend" not in text and "/root/reference" not in text, f
+
+
+def test_early_stopper():
+    from pykg2vec_amd.common import Monitor
+    from pykg2vec_amd.trainer import EarlyStopper
+    es = EarlyStopper(2, Monitor.FILTERED_MEAN_RANK)
+    assert not es.should_stop({"fmr": 10.0})
+    assert not es.should_stop({"fmr": 11.0})
+    assert es.should_stop({"fmr": 12.0})
+    es = EarlyStopper(1, Monitor.MEAN_RECIPROCAL_RANK)
+    assert not es.should_stop({"mrr": 0.2})
+    assert not es.should_stop({"mrr": 0.3})
+    assert es.should_stop({"mrr": 0.1})
