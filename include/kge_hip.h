@@ -64,15 +64,20 @@ typedef struct kge_model_desc {
 int kge_abi_version(void);
 const char* kge_last_error(void);
 
+/* Scratch bytes the score / train entry points need for a call on n rows (n pairs for the pairwise step).
+ * 0 for the gather-type models; RESCAL groups the batch by relation on the device and needs
+ * (4*(R+1) + n + 8) ints (+ 2n floats for the hinge step). */
+size_t kge_workspace_bytes(const kge_model_desc* m, int64_t n);
+
 /* Model.forward(h, r, t) -> energies[n]   (pairwise.py:56-76,166-174,270-278,786-791,855-860,955-960;
  * pointwise.py:97-104,185-188,444-446).  RESCAL: call kge_rescal_normalize first (its forward does). */
 int kge_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                      int64_t n, float* scores, void* stream);
+                      int64_t n, float* scores, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Autograd backward of the above: grads[table] += d(sum_i dscore[i]*score_i)/d table, dense
  * (nn.Embedding sparse=False, models/Domain.py:8-13).  Replaces loss.backward() utils/trainer.py:298. */
 int kge_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                       int64_t n, const float* dscore, void* stream);
+                       int64_t n, const float* dscore, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Rescal.embed side effect (pairwise.py:843-844,862-865): W <- W / ||W_row||_2 in place, both tables. */
 int kge_rescal_normalize(float* ent, int64_t tot_entity, float* rel, int64_t tot_relation, int32_t k,
@@ -80,11 +85,14 @@ int kge_rescal_normalize(float* ent, int64_t tot_entity, float* rel, int64_t tot
 
 /* Fused Trainer.train_step_pairwise (utils/trainer.py:147-157) with Criterion.pairwise_hinge
  * (utils/criterion.py:25-29): scores both triples of each of the n pairs, adds sum(max(0, s+ + margin - s-))
- * to *loss and the loss gradient to m->grads.  neg_rate must be 1 (the hinge adds [B] to [B*neg_rate]). */
+ * to the loss accumulators and the loss gradient to m->grads.  neg_rate must be 1 (the hinge adds [B] to
+ * [B*neg_rate]).  `loss`: float[32*32] striped accumulators, total = sum_k loss[32*k].  One kernel for the gather-type
+ * models; RESCAL runs normalise-free forward(+), forward(-), hinge coefficients, backward(+), backward(-). */
 int kge_train_pairwise_hinge(const kge_model_desc* m,
                              const int64_t* ph, const int64_t* pr, const int64_t* pt,
                              const int64_t* nh, const int64_t* nr, const int64_t* nt,
-                             int64_t n, float margin, float* loss, void* stream);
+                             int64_t n, float margin, void* workspace, size_t workspace_bytes,
+                             float* loss, void* stream);
 
 /* Fused train_step_pairwise with Criterion.pariwise_logistic (utils/criterion.py:13-23; RotatE):
  * self-adversarial weights softmax(alpha * -s-) over the neg_rate negatives of each positive (detached).

@@ -87,25 +87,33 @@ extern "C" {
 int kge_abi_version(void) { return KGE_ABI_VERSION; }
 const char* kge_last_error(void) { return g_err; }
 
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t kge_workspace_bytes(const kge_model_desc* m, int64_t n) {
+    if (validate(m, false, "kge_workspace_bytes") || n < 0) return 0;
+    if (is_vector_model(m->model)) return 0;
+    return align256(dense_workspace_bytes(m, n)) + align256((size_t)2 * n * sizeof(float));
+}
+
 int kge_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
-                      float* scores, void* stream) {
+                      float* scores, void* workspace, size_t workspace_bytes, void* stream) {
     if (validate(m, false, "kge_score_forward")) return -1;
     if (n == 0) return 0;
     if (n < 0 || !h || !r || !t || !scores) { set_error("kge_score_forward: bad arguments"); return -1; }
     hipStream_t s = (hipStream_t)stream;
-    if (m->model == KGE_RESCAL) return launch_rescal_forward(m, h, r, t, n, scores, s);
-    if (m->model == KGE_NTN) return launch_ntn_forward(m, h, r, t, n, scores, s);
+    if (m->model == KGE_RESCAL) return launch_rescal_forward(m, h, r, t, n, scores, workspace, workspace_bytes, s);
+    if (m->model == KGE_NTN) return launch_ntn_forward(m, h, r, t, n, scores, workspace, workspace_bytes, s);
     return launch_score_forward(m, h, r, t, n, scores, s);
 }
 
 int kge_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
-                       const float* dscore, void* stream) {
+                       const float* dscore, void* workspace, size_t workspace_bytes, void* stream) {
     if (validate(m, true, "kge_score_backward")) return -1;
     if (n == 0) return 0;
     if (n < 0 || !h || !r || !t || !dscore) { set_error("kge_score_backward: bad arguments"); return -1; }
     hipStream_t s = (hipStream_t)stream;
-    if (m->model == KGE_RESCAL) return launch_rescal_backward(m, h, r, t, n, dscore, s);
-    if (m->model == KGE_NTN) return launch_ntn_backward(m, h, r, t, n, dscore, s);
+    if (m->model == KGE_RESCAL) return launch_rescal_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, s);
+    if (m->model == KGE_NTN) return launch_ntn_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, s);
     return launch_score_backward(m, h, r, t, n, dscore, s);
 }
 
@@ -116,15 +124,26 @@ int kge_rescal_normalize(float* ent, int64_t tot_entity, float* rel, int64_t tot
 
 int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
                              const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float margin,
-                             float* loss, void* stream) {
+                             void* workspace, size_t workspace_bytes, float* loss, void* stream) {
     if (validate(m, true, "kge_train_pairwise_hinge")) return -1;
     if (n == 0) return 0;
     if (n < 0 || !ph || !pr || !pt || !nh || !nr || !nt || !loss) { set_error("kge_train_pairwise_hinge: bad arguments"); return -1; }
-    if (!is_vector_model(m->model)) {
-        set_error("kge_train_pairwise_hinge: model %d trains through kge_score_forward/backward", m->model);
+    hipStream_t s = (hipStream_t)stream;
+    if (is_vector_model(m->model)) return launch_pairwise_hinge(m, ph, pr, pt, nh, nr, nt, n, margin, loss, s);
+    // dense-contraction models: forward(+), forward(-), hinge coefficients in place, backward(+), backward(-)
+    const size_t gws = align256(dense_workspace_bytes(m, n));
+    if (!workspace || workspace_bytes < gws + align256((size_t)2 * n * sizeof(float))) {
+        set_error("kge_train_pairwise_hinge: workspace too small (need kge_workspace_bytes)");
         return -1;
     }
-    return launch_pairwise_hinge(m, ph, pr, pt, nh, nr, nt, n, margin, loss, (hipStream_t)stream);
+    float* sp = (float*)((char*)workspace + gws);
+    float* sn = sp + n;
+    int rc;
+    if ((rc = kge_score_forward(m, ph, pr, pt, n, sp, workspace, gws, stream))) return rc;
+    if ((rc = kge_score_forward(m, nh, nr, nt, n, sn, workspace, gws, stream))) return rc;
+    if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
+    if ((rc = kge_score_backward(m, ph, pr, pt, n, sp, workspace, gws, stream))) return rc;
+    return kge_score_backward(m, nh, nr, nt, n, sn, workspace, gws, stream);
 }
 
 int kge_train_pairwise_selfadv(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,

@@ -1,9 +1,308 @@
-// kge_dense.hip -- RESCAL / NTN (dense relation-matrix contraction) -- placeholder until the MFMA path lands.
+// kge_dense.hip -- RESCAL: the dense relation-matrix contraction on the f32 matrix cores.
+//
+// Reference: pykg2vec/models/pairwise.py:829-865.  energy = -h^T M_r t with M_r = rel_matrices[r].view(k,k); the
+// reference gathers a [B,k,k] tensor (B*k^2 floats: 20 MB at B=128,k=200) and runs a batched mat-vec, and its
+// autograd scatters B dense k^2 outer products back.  Here the batch is GROUPED BY RELATION on the device
+// (histogram -> scan -> scatter, three tiny kernels), and every (relation, 32-triple tile) is one workgroup that
+// runs three small GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak):
+//     U = T M_r^T   [32,k]x[k,k]   forward (score_i = -h_i . U_i) and grad_h = -ds * U
+//     V = H M_r     [32,k]x[k,k]   grad_t = -ds * V
+//     G = (ds*H)^T T   [k,32]x[32,k]   grad_M_r = -G      (one atomic per M element per 32 triples, not per triple)
+// so M_r is read once per tile from L2 instead of once per triple, and the k^2-sized gradient traffic drops 32x.
+// Also: the in-place table renormalisation Rescal.embed performs on every forward (pairwise.py:843-844,862-865).
+//
+// MFMA operand maps (cdna_hip_programming.md section 3): A: lane l holds A[i=l&31][k=l>>5]; B: lane l holds
+// B[k=l>>5][j=l&31]; C/D: col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "kge_internal.h"
+
 namespace kge {
-int launch_rescal_normalize(float*, int64_t, float*, int64_t, int, hipStream_t) { set_error("RESCAL path not built yet"); return -3; }
-int launch_rescal_forward(const kge_model_desc*, const int64_t*, const int64_t*, const int64_t*, int64_t, float*, hipStream_t) { set_error("RESCAL path not built yet"); return -3; }
-int launch_rescal_backward(const kge_model_desc*, const int64_t*, const int64_t*, const int64_t*, int64_t, const float*, hipStream_t) { set_error("RESCAL path not built yet"); return -3; }
-int launch_ntn_forward(const kge_model_desc*, const int64_t*, const int64_t*, const int64_t*, int64_t, float*, hipStream_t) { set_error("NTN path not built yet"); return -3; }
-int launch_ntn_backward(const kge_model_desc*, const int64_t*, const int64_t*, const int64_t*, int64_t, const float*, hipStream_t) { set_error("NTN path not built yet"); return -3; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TILE = 32;  // triples per workgroup tile
+
+struct GroupWs {           // carved from the caller's workspace
+    int* counts;           // [R]   triples per relation
+    int* cursor;           // [R]   scatter cursors
+    int* offsets;          // [R+1] first grouped position of each relation
+    int* tile_off;         // [R+1] first tile of each relation
+    int* perm;             // [n]   grouped position -> original row
+};
+
+static size_t group_ws_bytes(int64_t R, int64_t n) { return (size_t)(4 * (R + 1) + n + 8) * sizeof(int); }
+
+static GroupWs carve(void* ws, int64_t R, int64_t n) {
+    GroupWs g;
+    int* p = (int*)ws;
+    g.counts = p; p += R + 1;
+    g.cursor = p; p += R + 1;
+    g.offsets = p; p += R + 1;
+    g.tile_off = p; p += R + 1;
+    g.perm = p;
+    return g;
 }
+
+__global__ void k_rel_hist(const int64_t* __restrict__ r, int64_t n, int* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(counts + r[i], 1);
+}
+
+// single block: exclusive scans of counts and of ceil(counts / TILE)
+__global__ __launch_bounds__(256) void k_rel_scan(const int* __restrict__ counts, int R, int* __restrict__ offsets,
+                                                  int* __restrict__ tile_off) {
+    __shared__ int s_a[256], s_b[256];
+    int run_a = 0, run_b = 0;
+    for (int base = 0; base < R; base += 256) {
+        const int idx = base + threadIdx.x;
+        const int c = idx < R ? counts[idx] : 0;
+        const int tl = (c + TILE - 1) / TILE;
+        s_a[threadIdx.x] = c; s_b[threadIdx.x] = tl;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan
+            int va = 0, vb = 0;
+            if ((int)threadIdx.x >= d) { va = s_a[threadIdx.x - d]; vb = s_b[threadIdx.x - d]; }
+            __syncthreads();
+            s_a[threadIdx.x] += va; s_b[threadIdx.x] += vb;
+            __syncthreads();
+        }
+        if (idx < R) { offsets[idx] = run_a + s_a[threadIdx.x] - c; tile_off[idx] = run_b + s_b[threadIdx.x] - tl; }
+        run_a += s_a[255]; run_b += s_b[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { offsets[R] = run_a; tile_off[R] = run_b; }
+}
+
+__global__ void k_rel_scatter(const int64_t* __restrict__ r, int64_t n, const int* __restrict__ offsets,
+                              int* __restrict__ cursor, int* __restrict__ perm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int rel = (int)r[i];
+    perm[offsets[rel] + atomicAdd(cursor + rel, 1)] = (int)i;
+}
+
+static int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(g.counts, 0, (size_t)2 * (R + 1) * sizeof(int), s);  // counts + cursor
+    if (e != hipSuccess) { set_error("rescal grouping memset: %s", hipGetErrorString(e)); return -2; }
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_rel_hist, dim3(nb), dim3(256), 0, s, r, n, g.counts);
+    hipLaunchKernelGGL(k_rel_scan, dim3(1), dim3(256), 0, s, g.counts, (int)R, g.offsets, g.tile_off);
+    hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(256), 0, s, r, n, g.offsets, g.cursor, g.perm);
+    return check_launch("rescal grouping");
+}
+
+// which (relation, tile-in-relation) is block `b`?  binary search in tile_off[0..R]
+__device__ __forceinline__ bool locate_tile(const int* __restrict__ tile_off, int R, int b, int& rel, int& tile_in_rel) {
+    if (b >= tile_off[R]) return false;
+    int lo = 0, hi = R;  // tile_off[lo] <= b < tile_off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_off[mid] <= b) lo = mid; else hi = mid;
+    }
+    rel = lo; tile_in_rel = b - tile_off[lo];
+    return true;
+}
+
+// MODE 0: scores.  MODE 1: gradients (needs dscore).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, const float* __restrict__ relm,
+                                                float* __restrict__ g_ent, float* __restrict__ g_rel,
+                                                const int64_t* __restrict__ h, const int64_t* __restrict__ t,
+                                                const int* __restrict__ offsets, const int* __restrict__ tile_off,
+                                                const int* __restrict__ perm, int R, int k,
+                                                const float* __restrict__ dscore, float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int rel, tin;
+    if (!locate_tile(tile_off, R, blockIdx.x, rel, tin)) return;
+    const int S = (k + 1) | 1;                 // odd LDS row stride: conflict-free column reads
+    float* sT = smem;                          // [32][S]
+    float* sH = sT + TILE * S;                 // [32][S]
+    float* sDs = sH + TILE * S;                // [32]
+    float* sSc = sDs + TILE;                   // [32]
+    int* sRow = (int*)(sSc + TILE);            // [32] original row index (-1 = padding)
+    long long* sHid = (long long*)(sRow + TILE + (TILE & 1));  // [32] head ids, [32] tail ids
+    long long* sTid = sHid + TILE;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g0 = offsets[rel] + tin * TILE;
+    const int cnt = min(TILE, offsets[rel + 1] - g0);
+    if (threadIdx.x < TILE) {
+        const int row = threadIdx.x < cnt ? perm[g0 + threadIdx.x] : -1;
+        sRow[threadIdx.x] = row;
+        sHid[threadIdx.x] = row >= 0 ? h[row] : 0;
+        sTid[threadIdx.x] = row >= 0 ? t[row] : 0;
+        sDs[threadIdx.x] = (MODE == 1 && row >= 0) ? dscore[row] : 0.f;
+        sSc[threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TILE * k; idx += 256) {  // coalesced row gathers into LDS
+        const int i = idx / k, c = idx - i * k;
+        const bool ok = i < cnt;
+        sT[i * S + c] = ok ? ent[sTid[i] * k + c] : 0.f;
+        sH[i * S + c] = ok ? ent[sHid[i] * k + c] : 0.f;
+    }
+    __syncthreads();
+    const float* M = relm + (int64_t)rel * k * k;
+    const int ntile = (k + 31) / 32;
+    const int li = lane & 31, lk = lane >> 5;
+
+    // ---- U = T M^T : U[i][a] = sum_b T[i][b] M[a][b]
+    for (int at = wave; at < ntile; at += 4) {
+        const int a = at * 32 + li;
+        f32x16 acc = {0};
+        for (int kk = 0; kk < k; kk += 2) {
+            const int b = kk + lk;
+            const float av = b < k ? sT[li * S + b] : 0.f;
+            const float bv = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        if (a < k) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                if (MODE == 0) {
+                    atomicAdd(&sSc[i], sH[i * S + a] * acc[reg]);          // LDS atomic: score_i += h_i[a] U[i][a]
+                } else if (i < cnt && sDs[i] != 0.f) {
+                    unsafeAtomicAdd(g_ent + sHid[i] * k + a, -sDs[i] * acc[reg]);   // grad_h = -ds U
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        if (threadIdx.x < cnt) scores[sRow[threadIdx.x]] = -sSc[threadIdx.x];
+        return;
+    }
+    // ---- V = H M : V[i][b] = sum_a H[i][a] M[a][b] ;  grad_t = -ds V
+    for (int bt = wave; bt < ntile; bt += 4) {
+        const int b = bt * 32 + li;
+        f32x16 acc = {0};
+        for (int kk = 0; kk < k; kk += 2) {
+            const int a = kk + lk;
+            const float av = a < k ? sH[li * S + a] : 0.f;
+            const float bv = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        if (b < k) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                if (i < cnt && sDs[i] != 0.f) unsafeAtomicAdd(g_ent + sTid[i] * k + b, -sDs[i] * acc[reg]);
+            }
+        }
+    }
+    // ---- G = (ds*H)^T T : G[a][b] = sum_i ds_i H[i][a] T[i][b] ;  grad_M = -G
+    float* gM = g_rel + (int64_t)rel * k * k;
+    for (int tl = wave; tl < ntile * ntile; tl += 4) {
+        const int at = tl / ntile, bt = tl - at * ntile;
+        const int a_in = at * 32 + li, b_in = bt * 32 + li;
+        f32x16 acc = {0};
+#pragma unroll 4
+        for (int kk = 0; kk < TILE; kk += 2) {
+            const int i = kk + lk;
+            const float av = a_in < k ? sDs[i] * sH[i * S + a_in] : 0.f;
+            const float bv = b_in < k ? sT[i * S + b_in] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        if (b_in < k) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int a = at * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                if (a < k && acc[reg] != 0.f) unsafeAtomicAdd(gM + (int64_t)a * k + b_in, -acc[reg]);
+            }
+        }
+    }
+}
+
+static size_t rescal_lds_bytes(int k) {
+    const int S = (k + 1) | 1;
+    return (size_t)(2 * TILE * S + 2 * TILE) * sizeof(float) + (size_t)(TILE + (TILE & 1)) * sizeof(int) +
+           (size_t)2 * TILE * sizeof(long long);
+}
+
+size_t dense_workspace_bytes(const kge_model_desc* m, int64_t n) {
+    if (m->model == KGE_RESCAL) return group_ws_bytes(m->tot_relation, n);
+    return 0;
+}
+
+static int rescal_run(int mode, const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+                      const float* dscore, float* scores, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int k = m->dim;
+    const int64_t R = m->tot_relation;
+    if (k > 512) { set_error("RESCAL: hidden size %d exceeds the LDS-resident tile kernel (max 512)", k); return -1; }
+    if (n >= (1ll << 31)) { set_error("RESCAL: batch too large"); return -1; }
+    if (!ws || ws_bytes < group_ws_bytes(R, n)) {
+        set_error("RESCAL needs a workspace of %zu bytes (kge_workspace_bytes)", group_ws_bytes(R, n));
+        return -1;
+    }
+    const GroupWs g = carve(ws, R, n);
+    int rc = group_by_relation(r, n, R, g, s);
+    if (rc) return rc;
+    const unsigned max_tiles = (unsigned)(n / TILE + R + 1);  // upper bound on sum_r ceil(n_r / 32); surplus blocks exit
+    const size_t lds = rescal_lds_bytes(k);
+    if (mode == 0) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_rescal<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_rescal<0>, dim3(max_tiles), dim3(256), lds, s, m->tables[0], m->tables[1], nullptr, nullptr, h, t,
+                           g.offsets, g.tile_off, g.perm, (int)R, k, nullptr, scores);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_rescal<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_rescal<1>, dim3(max_tiles), dim3(256), lds, s, m->tables[0], m->tables[1], m->grads[0],
+                           m->grads[1], h, t, g.offsets, g.tile_off, g.perm, (int)R, k, dscore, nullptr);
+    }
+    return check_launch("k_rescal");
+}
+
+int launch_rescal_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+                          float* scores, void* ws, size_t ws_bytes, hipStream_t s) {
+    return rescal_run(0, m, h, r, t, n, nullptr, scores, ws, ws_bytes, s);
+}
+int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+                           const float* dscore, void* ws, size_t ws_bytes, hipStream_t s) {
+    return rescal_run(1, m, h, r, t, n, dscore, nullptr, ws, ws_bytes, s);
+}
+
+// ---- W <- W / ||W_row||_2 in place (plain division, no eps: pairwise.py:862-865)
+__global__ __launch_bounds__(256) void k_row_normalize(float* __restrict__ w, int64_t rows, int64_t dim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* p = w + row * dim;
+    float n2 = 0.f;
+    for (int64_t c = lane; c < dim; c += 64) n2 = fmaf(p[c], p[c], n2);
+    const float nrm = sqrtf(wave_sum(n2));
+    for (int64_t c = lane; c < dim; c += 64) p[c] = p[c] / nrm;
+}
+
+int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k, hipStream_t s) {
+    hipLaunchKernelGGL(k_row_normalize, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, s, ent, E, (int64_t)k);
+    hipLaunchKernelGGL(k_row_normalize, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, rel, R, (int64_t)k * k);
+    return check_launch("k_row_normalize");
+}
+
+// ---- hinge coefficients for models scored by separate forward/backward launches (RESCAL, NTN):
+// in: energies.  out (in place): pos <- dL/dpos, neg <- dL/dneg; loss += sum max(0, pos + margin - neg)
+__global__ __launch_bounds__(256) void k_hinge_coeffs(float* __restrict__ pos, float* __restrict__ neg, int64_t n,
+                                                      float margin, float* __restrict__ loss) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = pos[i] + margin - neg[i];
+        acc += fmaxf(v, 0.f);
+        const float c = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);
+        pos[i] = c; neg[i] = -c;
+    }
+    block_accumulate_loss<1>(acc, 0, loss);
+}
+
+int launch_hinge_coeffs(float* pos, float* neg, int64_t n, float margin, float* loss, hipStream_t s) {
+    int64_t b = (n + 255) / 256;
+    if (b > 1024) b = 1024;
+    hipLaunchKernelGGL(k_hinge_coeffs, dim3((unsigned)b), dim3(256), 0, s, pos, neg, n, margin, loss);
+    return check_launch("k_hinge_coeffs");
+}
+
+// NTN: not built yet
+int launch_ntn_forward(const kge_model_desc*, const int64_t*, const int64_t*, const int64_t*, int64_t, float*, void*, size_t, hipStream_t) { set_error("NTN path not built yet"); return -3; }
+int launch_ntn_backward(const kge_model_desc*, const int64_t*, const int64_t*, const int64_t*, int64_t, const float*, void*, size_t, hipStream_t) { set_error("NTN path not built yet"); return -3; }
+
+}  // namespace kge

@@ -65,20 +65,31 @@ def model_desc(model, weights=None, grads=None):
     return model.make_desc(weights, grads)
 
 
+def _workspace(desc, n, device):
+    """(ptr, nbytes, keepalive) scratch for a score/train call on n rows; (None, 0, None) for gather-type models."""
+    nbytes = L.load().kge_workspace_bytes(ctypes.byref(desc), int(n))
+    if nbytes == 0:
+        return None, 0, None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ctypes.c_void_p(ws.data_ptr()), nbytes, ws
+
+
 def score_forward(desc, h, r, t):
     n = h.numel()
     if r.numel() != n or t.numel() != n:
         raise ValueError("h, r, t must have equal lengths")
     out = torch.empty(n, dtype=torch.float32, device=h.device)
+    wp, wb, _keep = _workspace(desc, n, h.device)
     L.check(L.load().kge_score_forward(ctypes.byref(desc), _ids(h, "h"), _ids(r, "r"), _ids(t, "t"), n,
-                                       _dev(out, torch.float32, "scores"), _stream()), "kge_score_forward")
+                                       _dev(out, torch.float32, "scores"), wp, wb, _stream()), "kge_score_forward")
     return out
 
 
 def score_backward(desc, h, r, t, dscore):
     n = h.numel()
+    wp, wb, _keep = _workspace(desc, n, h.device)
     L.check(L.load().kge_score_backward(ctypes.byref(desc), _ids(h, "h"), _ids(r, "r"), _ids(t, "t"), n,
-                                        _dev(dscore, torch.float32, "dscore"), _stream()), "kge_score_backward")
+                                        _dev(dscore, torch.float32, "dscore"), wp, wb, _stream()), "kge_score_backward")
 
 
 def rescal_normalize(ent, rel, k):
@@ -99,9 +110,10 @@ def train_pairwise_hinge(desc, ph, pr, pt, nh, nr, nt, margin, loss_buf):
     n = ph.numel()
     if nh.numel() != n:
         raise ValueError("pairwise_hinge needs neg_rate == 1 (criterion.py:27 adds [B] to [B*neg_rate])")
+    wp, wb, _keep = _workspace(desc, n, ph.device)
     L.check(L.load().kge_train_pairwise_hinge(ctypes.byref(desc), _ids(ph, "ph"), _ids(pr, "pr"), _ids(pt, "pt"),
                                               _ids(nh, "nh"), _ids(nr, "nr"), _ids(nt, "nt"), n, float(margin),
-                                              _dev(loss_buf, torch.float32, "loss"), _stream()),
+                                              wp, wb, _dev(loss_buf, torch.float32, "loss"), _stream()),
             "kge_train_pairwise_hinge")
 
 

@@ -119,7 +119,7 @@ class Trainer:
         if name == "rotate":
             self._selfadv_ws = self.K.train_pairwise_selfadv(self._desc, ph, pr, pt, nh, nr, nt, self.config.neg_rate,
                                                         self.config.alpha, self.loss_buf, self._selfadv_ws)
-        elif self.model.kernel_name in ("rescal", "ntn"):
+        elif self.model.kernel_name == "ntn":
             self._accumulate_dense_pairwise(ph, pr, pt, nh, nr, nt)
         else:
             self.K.train_pairwise_hinge(self._desc, ph, pr, pt, nh, nr, nt, self.config.margin, self.loss_buf)
