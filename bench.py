@@ -112,6 +112,21 @@ def cpu_baseline_eval(P_np, test, hr_t, tr_h, budget_s=8.0):
     return n / (time.perf_counter() - t0), n
 
 
+def pmc_traffic(kernel_prefix, batch):
+    """HBM bytes per launch of the dominant train kernel from the committed rocprofv3 PMC passes
+    (profiles/*pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, separate passes, same bench command and batch size).
+    Returns (bytes or None, source)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files or batch != 32768:
+        return None, None
+    doc = json.load(open(files[-1]))
+    for name, ctr in doc["kernels"].items():
+        if name.startswith(kernel_prefix) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+            return (ctr["FETCH_SIZE"]["avg_KB"] + ctr["WRITE_SIZE"]["avg_KB"]) * 1024.0, os.path.basename(files[-1])
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +233,7 @@ def main():
     mean_rank = float(ranks[:2].float().mean().item()) + 1.0
 
     out = None
+    traffic, traffic_src = pmc_traffic("kge::k_pairwise_hinge<0, 32, 4>", per_rank_batch)
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
@@ -229,8 +245,9 @@ def main():
                        "batch_per_gpu": per_rank_batch, "global_batch": per_rank_batch * world,
                        "scored_triples_per_step": scored_per_step, "parallelism": "dp%d" % world},
             "roofline": {"kernel": "k_pairwise_hinge<TransE,G=32,NCH=4>", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms},
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": kern_ms},
             "eval": {"value": eval_value, "unit": "test triples ranked/s", "test_triples_per_gpu": n_eval,
                      "ms_per_pass": edt * 1e3, "mean_rank_check": mean_rank,
                      "roofline": {"kernel": "kge_eval_ranks pipeline (k_eval_sweep dominant)", "bound": "hbm",
