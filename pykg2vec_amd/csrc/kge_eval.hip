@@ -255,9 +255,17 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
 }
 
 // ------------------------------------------------------------------ pair arithmetic shared by steps 3 and 4
+// acc + |d| as ONE VALU op (abs is a source modifier).  Written as asm so that the SLP vectoriser cannot turn
+// pairs of them into v_and_b32 x2 + v_pk_add_f32 (3 issues per 2 elements instead of 2); same IEEE add either way.
+__device__ __forceinline__ float add_abs(float acc, float d) {
+    float r;
+    asm("v_add_f32 %0, |%1|, %2" : "=v"(r) : "v"(d), "v"(acc));
+    return r;
+}
+
 template <int FORM>
 __device__ __forceinline__ float pair_step(float acc, float c, float q) {
-    if constexpr (FORM == F_L1) return acc + fabsf(c - q);
+    if constexpr (FORM == F_L1) return add_abs(acc, c - q);
     else if constexpr (FORM == F_NEGDOT) return fmaf(c, q, acc);
     else { const float dlt = c - q; return fmaf(dlt, dlt, acc); }
 }
@@ -334,15 +342,40 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
 }
 
 // ------------------------------------------------------------------ 4. the sweep
-// grid.x = query blocks of QT, grid.y = tile splits; each wave walks its candidate tiles.
+// 1-D grid decoded as (CU slot, tile split, query block): block b runs on XCD b%8 / CU slot b%256 (observed
+// round-robin placement, used for locality only), so  slot = b % 256,  m = b / 256,  ts = m % S,  qb = (m / S)*256 + slot
+// keeps one CU on ONE block of QT queries for S consecutive workgroups: its query rows stay in the scalar cache while
+// all CUs walk the candidate tiles in step (L2-friendly).  Each wave owns tiles ts*4+wave, +4S, +8S, ...
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int FORM>
+__device__ __forceinline__ void pair_step2(float& acc, f32x2 c, f32x2 q) {
+    // two consecutive k for one (query, candidate) pair: the subtraction is one packed op, the accumulation
+    // stays sequential in k (bit-identical to pair_step applied twice)
+    if constexpr (FORM == F_NEGDOT) {
+        acc = fmaf(c.x, q.x, acc);
+        acc = fmaf(c.y, q.y, acc);
+    } else {
+        const f32x2 d = c - q;
+        if constexpr (FORM == F_L1) { acc = add_abs(acc, d.x); acc = add_abs(acc, d.y); }
+        else { acc = fmaf(d.x, d.x, acc); acc = fmaf(d.y, d.y, acc); }
+    }
+}
+
 template <int FORM, int XFORM, int QT, bool WRITE>
 __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ cand, const float* __restrict__ aux,
                                                     const float* __restrict__ qvec, const float* __restrict__ st,
                                                     int64_t nq, int64_t E, int64_t ntiles, int Kpad, int QV, float margin,
-                                                    int32_t* __restrict__ rcount, float* __restrict__ scores_out) {
+                                                    int S, int qblocks, int32_t* __restrict__ rcount,
+                                                    float* __restrict__ scores_out) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t q0 = (int64_t)blockIdx.x * QT;
+    const int slot = blockIdx.x & 255;
+    const int mm = blockIdx.x >> 8;
+    const int ts = mm % S;
+    const int qb = (mm / S) * 256 + slot;
+    if (qb >= qblocks) return;
+    const int64_t q0 = (int64_t)qb * QT;
     const int64_t qstride = (int64_t)QV * Kpad;
     // wave-uniform query row pointers (clamped; masked at the end)
     const float* qrow[QT];
@@ -355,23 +388,56 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
         sthr[q] = WRITE ? 0.f : st[qi];
         cnt[q] = 0;
     }
-    for (int64_t tile = (int64_t)blockIdx.y * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.y * 4) {
+    if constexpr (XFORM == X_NONE) {
+        // plain forms: TWO candidate tiles per wave pass -- every scalar query operand feeds two VALU streams
+        for (int64_t tile = ((int64_t)ts * 4 + wave) * 2; tile < ntiles; tile += (int64_t)S * 8) {
+            const bool has_b = tile + 1 < ntiles;
+            const float* ca = cand + (tile * Kpad) * 64 + lane;
+            const float* cb = has_b ? ca + (int64_t)Kpad * 64 : ca;
+            float acca[QT], accb[QT];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) { acca[q] = 0.f; accb[q] = 0.f; }
+            for (int k0 = 0; k0 < Kpad; k0 += KC) {
+                f32x2 va[KC / 2], vb[KC / 2];
+#pragma unroll
+                for (int j = 0; j < KC / 2; ++j) {
+                    va[j].x = ca[(int64_t)(k0 + 2 * j) * 64]; va[j].y = ca[(int64_t)(k0 + 2 * j + 1) * 64];
+                    vb[j].x = cb[(int64_t)(k0 + 2 * j) * 64]; vb[j].y = cb[(int64_t)(k0 + 2 * j + 1) * 64];
+                }
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+#pragma unroll
+                    for (int j = 0; j < KC / 2; ++j) {
+                        f32x2 qq;
+                        qq.x = qrow[q][k0 + 2 * j];
+                        qq.y = qrow[q][k0 + 2 * j + 1];
+                        pair_step2<FORM>(acca[q], va[j], qq);
+                        pair_step2<FORM>(accb[q], vb[j], qq);
+                    }
+                }
+            }
+            const int64_t ea = tile * 64 + lane, eb = ea + 64;
+            const bool valid_a = ea < E, valid_b = has_b && eb < E;
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const float sa = pair_finish<FORM>(acca[q], margin), sb = pair_finish<FORM>(accb[q], margin);
+                if constexpr (WRITE) {
+                    if (q0 + q < nq) {
+                        if (valid_a) scores_out[(q0 + q) * E + ea] = sa;
+                        if (valid_b) scores_out[(q0 + q) * E + eb] = sb;
+                    }
+                } else {
+                    cnt[q] += __popcll(__ballot(valid_a && sa < sthr[q])) + __popcll(__ballot(valid_b && sb < sthr[q]));
+                }
+            }
+        }
+    } else {
+    for (int64_t tile = (int64_t)ts * 4 + wave; tile < ntiles; tile += (int64_t)S * 4) {
         const float* c = cand + (tile * Kpad) * 64 + lane;
         float acc[QT];
 #pragma unroll
         for (int q = 0; q < QT; ++q) acc[q] = 0.f;
-        if constexpr (XFORM == X_NONE) {
-            for (int k0 = 0; k0 < Kpad; k0 += KC) {
-                float cv[KC];
-#pragma unroll
-                for (int j = 0; j < KC; ++j) cv[j] = c[(int64_t)(k0 + j) * 64];
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
-#pragma unroll
-                    for (int j = 0; j < KC; ++j) acc[q] = pair_step<FORM>(acc[q], cv[j], qrow[q][k0 + j]);
-                }
-            }
-        } else {
+        {
             float p[QT], inv[QT];
             if constexpr (XFORM == X_TRANSH) {
 #pragma unroll
@@ -436,6 +502,7 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
             }
         }
     }
+    }
     if constexpr (!WRITE) {
         if (lane == 0) {
 #pragma unroll
@@ -481,21 +548,23 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
     constexpr int QT = XFORM == X_NONE ? QT_PLAIN : QT_XF;
     const int64_t nq = 2 * p.n;
     const int qblocks = (int)((nq + QT - 1) / QT);
-    // enough blocks to fill 256 CUs several times over; each wave needs >= 1 tile
-    int64_t ysplit = (256 * 8 + qblocks - 1) / qblocks;
-    const int64_t max_split = (p.ntiles + 3) / 4;
-    if (ysplit > max_split) ysplit = max_split;
-    if (ysplit < 1) ysplit = 1;
-    if (ysplit > 65535) ysplit = 65535;
+    // tile splits S: every wave gets >= 1 tile; aim at >= ~8 waves of workgroups per CU so the last round is cheap
+    const int64_t tiles_per_wave_pass = XFORM == X_NONE ? 2 : 1;
+    const int64_t max_split = (p.ntiles + 4 * tiles_per_wave_pass - 1) / (4 * tiles_per_wave_pass);
+    const int64_t qgroups = (qblocks + 255) / 256;
+    int64_t S = (48 + qgroups - 1) / qgroups;
+    if (S > max_split) S = max_split;
+    if (S < 1) S = 1;
+    const unsigned grid = (unsigned)(qgroups * 256 * S);
     if (scores_out == nullptr) {
         hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p.cand, p.aux,
                            p.qvec, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids, head_off, head_ids, p.st,
                            p.fcount);
-        hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, false>), dim3(qblocks, (unsigned)ysplit), dim3(256), 0, s, p.cand,
-                           p.aux, p.qvec, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, p.rcount, nullptr);
+        hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, false>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec, p.st,
+                           nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, nullptr);
     } else {
-        hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, true>), dim3(qblocks, (unsigned)ysplit), dim3(256), 0, s, p.cand,
-                           p.aux, p.qvec, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, p.rcount, scores_out);
+        hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, true>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec, p.st,
+                           nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, scores_out);
     }
 }
 
