@@ -117,6 +117,11 @@ int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, cons
 int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, float* state2,
                        int64_t numel, float lr, int64_t step, int32_t zero_grad, void* stream);
 
+/* NTN.get_reg (pairwise.py:962-963): loss += lmbda * sqrt(sum_i param[i]^2), grad += lmbda * param / that root, over
+ * ONE flat buffer holding every table of the model (pad with zeros).  scratch: 1 float. */
+int kge_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, float* scratch, float* loss,
+                   void* stream);
+
 /* Filtered-rank evaluation: Evaluator.test (utils/evaluator.py:309-334) + MetricCalculator.get_tail_rank /
  * get_head_rank (utils/evaluator.py:70-123) for n test triples, without materialising scores or orderings.
  *   triples        int64 [n,3] (h, r, t)

@@ -185,6 +185,11 @@ int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, f
     return launch_optimizer(kind, param, grad, state1, state2, numel, lr, step, zero_grad, (hipStream_t)stream);
 }
 
+int kge_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, float* scratch, float* loss, void* stream) {
+    if (!param || !grad || !scratch || !loss || numel <= 0) { set_error("kge_l2norm_reg: bad arguments"); return -1; }
+    return launch_l2norm_reg(param, grad, numel, lmbda, scratch, loss, (hipStream_t)stream);
+}
+
 size_t kge_eval_workspace_bytes(const kge_model_desc* m, int64_t n) {
     if (validate(m, false, "kge_eval_workspace_bytes") || n < 0) return 0;
     return eval_workspace_bytes(m, n);

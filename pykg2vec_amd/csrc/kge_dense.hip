@@ -1,4 +1,4 @@
-// kge_dense.hip -- RESCAL: the dense relation-matrix contraction on the f32 matrix cores.
+// kge_dense.hip -- RESCAL (NTN lives in kge_ntn.hip): the dense relation-matrix contraction on the f32 matrix cores.
 //
 // Reference: pykg2vec/models/pairwise.py:829-865.  energy = -h^T M_r t with M_r = rel_matrices[r].view(k,k); the
 // reference gathers a [B,k,k] tensor (B*k^2 floats: 20 MB at B=128,k=200) and runs a batched mat-vec, and its
@@ -221,6 +221,7 @@ static size_t rescal_lds_bytes(int k) {
 
 size_t dense_workspace_bytes(const kge_model_desc* m, int64_t n) {
     if (m->model == KGE_RESCAL) return group_ws_bytes(m->tot_relation, n);
+    if (m->model == KGE_NTN) return ntn_workspace_bytes(m, n);
     return 0;
 }
 
@@ -300,9 +301,5 @@ int launch_hinge_coeffs(float* pos, float* neg, int64_t n, float margin, float* 
     hipLaunchKernelGGL(k_hinge_coeffs, dim3((unsigned)b), dim3(256), 0, s, pos, neg, n, margin, loss);
     return check_launch("k_hinge_coeffs");
 }
-
-// NTN: not built yet
-int launch_ntn_forward(const kge_model_desc*, const int64_t*, const int64_t*, const int64_t*, int64_t, float*, void*, size_t, hipStream_t) { set_error("NTN path not built yet"); return -3; }
-int launch_ntn_backward(const kge_model_desc*, const int64_t*, const int64_t*, const int64_t*, int64_t, const float*, void*, size_t, hipStream_t) { set_error("NTN path not built yet"); return -3; }
 
 }  // namespace kge

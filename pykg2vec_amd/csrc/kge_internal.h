@@ -32,6 +32,8 @@ int launch_selfadv_coeffs(float* pos_scores, float* neg_scores, int64_t n_pos, i
 // kge_dense.hip (RESCAL / NTN: f32 MFMA contraction paths) + table normalisation
 int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k, hipStream_t s);
 size_t dense_workspace_bytes(const kge_model_desc* m, int64_t n);
+size_t ntn_workspace_bytes(const kge_model_desc* m, int64_t n);
+int launch_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, float* scratch, float* loss, hipStream_t s);
 int launch_rescal_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                           int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,

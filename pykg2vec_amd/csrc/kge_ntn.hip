@@ -1,0 +1,405 @@
+// kge_ntn.hip -- NTN (pykg2vec/models/pairwise.py:868-963) on the f32 matrix cores.
+//
+//   energy = - r^ . tanh( h^T W_s t^ + h^ M1 + t^ M2 + b ),  s = 1..k_r,  x^ = F.normalize(x)
+//
+// The reference materialises h.repeat(k_r,1,1) and runs two bmm's (2*B*k_r*d^2 flop, a [k_r,B,d] temporary); its
+// autograd then produces a dense [k_r, d*d] gradient for the shared tensor W.  Here a batch is tiled 32 triples at a
+// time and the bilinear term is a chain of small GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32):
+//   forward   X_s = H^ W_s  ([32,d]x[d,d]) with the row-dot against T^ fused into the MFMA epilogue  -> bil[n][s]
+//   backward  gT^ += gz_s * (H^ W_s),  gH^ += gz_s * (T^ W_s^T),  gW_s = (gz_s * H^)^T T^   (GEMM over the batch)
+// Everything else (normalisation, the two [d,k_r] linear maps, tanh, the r^ dot) is wave-per-row VALU work.
+// Intermediates live in a caller-provided workspace of n*(4d + 3k_r + 6) floats.
+//
+// MFMA operand maps: A: lane l holds A[i=l&31][k=l>>5]; B: lane l holds B[k=l>>5][j=l&31];
+// C/D: col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include "kge_internal.h"
+
+namespace kge {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int NT = 32;       // triples per tile
+constexpr int SPW = 4;       // slices per wave in the bilinear backward
+
+struct NtnWs {
+    float *Hn, *Tn, *Rn, *inv, *flag, *Z, *GZ, *GH, *GT;
+};
+static size_t ntn_ws_floats(int64_t n, int d, int kr) { return (size_t)n * (4 * (size_t)d + 3 * (size_t)kr + 6); }
+static NtnWs ntn_carve(void* ws, int64_t n, int d, int kr) {
+    NtnWs w;
+    float* p = (float*)ws;
+    w.Hn = p; p += n * d;
+    w.Tn = p; p += n * d;
+    w.GH = p; p += n * d;
+    w.GT = p; p += n * d;
+    w.Rn = p; p += n * kr;
+    w.Z = p; p += n * kr;
+    w.GZ = p; p += n * kr;
+    w.inv = p; p += 3 * n;
+    w.flag = p;
+    return w;
+}
+size_t ntn_workspace_bytes(const kge_model_desc* m, int64_t n) { return ntn_ws_floats(n, m->dim, m->rel_dim) * sizeof(float); }
+
+// ---- 1. normalised rows: one wave per triple
+__global__ __launch_bounds__(256) void k_ntn_prep(const float* __restrict__ ent, const float* __restrict__ rel,
+                                                  const int64_t* __restrict__ h, const int64_t* __restrict__ r,
+                                                  const int64_t* __restrict__ t, int64_t n, int d, int kr, NtnWs w) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* eh = ent + h[i] * d; const float* et = ent + t[i] * d; const float* er = rel + r[i] * kr;
+    float nh = 0.f, nt = 0.f, nr = 0.f;
+    for (int c = lane; c < d; c += 64) { nh = fmaf(eh[c], eh[c], nh); nt = fmaf(et[c], et[c], nt); }
+    for (int c = lane; c < kr; c += 64) nr = fmaf(er[c], er[c], nr);
+    nh = sqrtf(wave_sum(nh)); nt = sqrtf(wave_sum(nt)); nr = sqrtf(wave_sum(nr));
+    const float ih = 1.0f / fmaxf(nh, kEpsNormalize), it = 1.0f / fmaxf(nt, kEpsNormalize), ir = 1.0f / fmaxf(nr, kEpsNormalize);
+    for (int c = lane; c < d; c += 64) { w.Hn[i * d + c] = eh[c] * ih; w.Tn[i * d + c] = et[c] * it; }
+    for (int c = lane; c < kr; c += 64) w.Rn[i * kr + c] = er[c] * ir;
+    if (lane == 0) {
+        w.inv[3 * i] = ih; w.inv[3 * i + 1] = it; w.inv[3 * i + 2] = ir;
+        w.flag[3 * i] = nh > kEpsNormalize; w.flag[3 * i + 1] = nt > kEpsNormalize; w.flag[3 * i + 2] = nr > kEpsNormalize;
+    }
+}
+
+__device__ __forceinline__ void stage_tile(float* sX, const float* __restrict__ X, int64_t row0, int cnt, int d, int S) {
+    for (int idx = threadIdx.x; idx < NT * d; idx += 256) {
+        const int i = idx / d, c = idx - i * d;
+        sX[i * S + c] = i < cnt ? X[(row0 + i) * d + c] : 0.f;
+    }
+}
+
+// ---- 2. bil[n][s] = h^_n^T W_s t^_n : block = (tile of 32 triples, 4 slices), one slice per wave
+__global__ __launch_bounds__(256) void k_ntn_bil(const float* __restrict__ W, int64_t n, int d, int kr, NtnWs w) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int S = (d + 1) | 1;
+    float* sH = smem; float* sT = sH + NT * S; float* sB = sT + NT * S;  // sB[4][32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lk = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * NT;
+    const int cnt = (int)min((int64_t)NT, n - row0);
+    const int s = blockIdx.y * 4 + wave;
+    stage_tile(sH, w.Hn, row0, cnt, d, S);
+    stage_tile(sT, w.Tn, row0, cnt, d, S);
+    if (threadIdx.x < 4 * NT) sB[threadIdx.x] = 0.f;
+    __syncthreads();
+    if (s < kr) {
+        const float* Ws = W + (int64_t)s * d * d;
+        float part[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part[q] = 0.f;
+        for (int j0 = 0; j0 < d; j0 += 32) {
+            const int j = j0 + li;
+            f32x16 acc = {0};
+            for (int kk = 0; kk < d; kk += 2) {
+                const int i2 = kk + lk;
+                const float av = i2 < d ? sH[li * S + i2] : 0.f;
+                const float bv = (i2 < d && j < d) ? Ws[(int64_t)i2 * d + j] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+            if (j < d) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = (q & 3) + 8 * (q >> 2) + 4 * lk;
+                    part[q] = fmaf(acc[q], sT[row * S + j], part[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * lk;
+            atomicAdd(&sB[wave * NT + row], part[q]);  // LDS atomic
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * NT) {
+        const int wv = threadIdx.x / NT, row = threadIdx.x - wv * NT, ss = blockIdx.y * 4 + wv;
+        if (row < cnt && ss < kr) w.Z[(row0 + row) * kr + ss] = sB[threadIdx.x];
+    }
+}
+
+// ---- 3. z = tanh(bil + h^ M1 + t^ M2 + b) ; score = - r^ . z          (one wave per triple)
+__global__ __launch_bounds__(256) void k_ntn_finish(const float* __restrict__ M1, const float* __restrict__ M2,
+                                                    const float* __restrict__ b, int64_t n, int d, int kr, NtnWs w,
+                                                    float* __restrict__ scores) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* hn = w.Hn + i * d; const float* tn = w.Tn + i * d;
+    float tot = 0.f;
+    for (int s = lane; s < kr; s += 64) {
+        float lin = b[s];
+        for (int c = 0; c < d; ++c) lin = fmaf(hn[c], M1[(int64_t)c * kr + s], fmaf(tn[c], M2[(int64_t)c * kr + s], lin));
+        const float z = tanhf(w.Z[i * kr + s] + lin);
+        w.Z[i * kr + s] = z;
+        tot = fmaf(w.Rn[i * kr + s], z, tot);
+    }
+    tot = wave_sum(tot);
+    if (lane == 0 && scores) scores[i] = -tot;
+}
+
+// ---- 4. gz, relation-row gradient, linear parts of gH^/gT^           (one wave per triple)
+__global__ __launch_bounds__(256) void k_ntn_gz(const float* __restrict__ M1, const float* __restrict__ M2,
+                                                const int64_t* __restrict__ r, const float* __restrict__ dscore,
+                                                float* __restrict__ g_rel, int64_t n, int d, int kr, NtnWs w) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    float* sgz = smem + wave * kr;
+    if (i < n) {
+        const float ds = dscore[i];
+        float dot = 0.f;
+        for (int s = lane; s < kr; s += 64) {
+            const float z = w.Z[i * kr + s], rn = w.Rn[i * kr + s];
+            const float gz = -ds * rn * (1.f - z * z);
+            w.GZ[i * kr + s] = gz;
+            sgz[s] = gz;
+            dot = fmaf(rn, -ds * z, dot);
+        }
+        dot = wave_sum(dot);
+        const float ir = w.inv[3 * i + 2];
+        const bool fr = w.flag[3 * i + 2] != 0.f;
+        if (ds != 0.f) {
+            float* gr = g_rel + r[i] * kr;
+            for (int s = lane; s < kr; s += 64) {
+                const float g = -ds * w.Z[i * kr + s];
+                unsafeAtomicAdd(gr + s, fr ? (g - w.Rn[i * kr + s] * dot) * ir : g * ir);
+            }
+        }
+    }
+    __syncthreads();
+    if (i < n) {
+        for (int c = lane; c < d; c += 64) {
+            float a = 0.f, bsum = 0.f;
+            for (int s = 0; s < kr; ++s) {
+                a = fmaf(sgz[s], M1[(int64_t)c * kr + s], a);
+                bsum = fmaf(sgz[s], M2[(int64_t)c * kr + s], bsum);
+            }
+            w.GH[i * d + c] = a;
+            w.GT[i * d + c] = bsum;
+        }
+    }
+}
+
+// ---- 5. gM1[c][s] += sum_n H^[n][c] gz[n][s] ; gM2 likewise ; gb[s] += sum_n gz[n][s]
+__global__ __launch_bounds__(256) void k_ntn_small(float* __restrict__ gM1, float* __restrict__ gM2, float* __restrict__ gb,
+                                                   int64_t n, int d, int kr, NtnWs w) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)(d + 1) * kr) return;
+    const int c = (int)(idx / kr), s = (int)(idx - (int64_t)c * kr);
+    if (c == d) {
+        float a = 0.f;
+        for (int64_t i = 0; i < n; ++i) a += w.GZ[i * kr + s];
+        gb[s] += a;
+    } else {
+        float a = 0.f, b2 = 0.f;
+        for (int64_t i = 0; i < n; ++i) {
+            const float gz = w.GZ[i * kr + s];
+            a = fmaf(w.Hn[i * d + c], gz, a);
+            b2 = fmaf(w.Tn[i * d + c], gz, b2);
+        }
+        gM1[idx] += a;
+        gM2[idx] += b2;
+    }
+}
+
+// ---- 6. bilinear backward wrt the rows: GT += sum_s gz_s (H^ W_s),  GH += sum_s gz_s (T^ W_s^T)
+// block = (tile, group of 4*SPW slices); each wave accumulates SPW slices in registers, then one atomic pass
+template <int JT>  // JT = ceil(d / 32) <= 8
+__global__ __launch_bounds__(256) void k_ntn_bil_bwd(const float* __restrict__ W, int64_t n, int d, int kr, NtnWs w) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int S = (d + 1) | 1;
+    float* sH = smem; float* sT = sH + NT * S;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lk = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * NT;
+    const int cnt = (int)min((int64_t)NT, n - row0);
+    stage_tile(sH, w.Hn, row0, cnt, d, S);
+    stage_tile(sT, w.Tn, row0, cnt, d, S);
+    __syncthreads();
+    float gt[JT][16], gh[JT][16];
+#pragma unroll
+    for (int a = 0; a < JT; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { gt[a][q] = 0.f; gh[a][q] = 0.f; }
+    const int s_base = (blockIdx.y * 4 + wave) * SPW;
+    for (int ss = 0; ss < SPW; ++ss) {
+        const int s = s_base + ss;
+        if (s >= kr) break;
+        const float* Ws = W + (int64_t)s * d * d;
+        float gzr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * lk;
+            gzr[q] = row < cnt ? w.GZ[(row0 + row) * kr + s] : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < JT; ++a) {
+            const int col = a * 32 + li;
+            f32x16 accx = {0}, accy = {0};
+            for (int kk = 0; kk < d; kk += 2) {
+                const int c = kk + lk;
+                const bool ok = c < d && col < d;
+                const float ah = c < d ? sH[li * S + c] : 0.f;
+                const float at = c < d ? sT[li * S + c] : 0.f;
+                const float bx = ok ? Ws[(int64_t)c * d + col] : 0.f;     // X = H^ W_s    : B[k=c][j=col] = W[c][col]
+                const float by = ok ? Ws[(int64_t)col * d + c] : 0.f;     // Y = T^ W_s^T  : B[k=c][j=col] = W[col][c]
+                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, bx, accx, 0, 0, 0);
+                accy = __builtin_amdgcn_mfma_f32_32x32x2f32(at, by, accy, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                gt[a][q] = fmaf(gzr[q], accx[q], gt[a][q]);
+                gh[a][q] = fmaf(gzr[q], accy[q], gh[a][q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < JT; ++a) {
+        const int col = a * 32 + li;
+        if (col < d) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * lk;
+                if (row < cnt) {
+                    if (gt[a][q] != 0.f) unsafeAtomicAdd(w.GT + (row0 + row) * d + col, gt[a][q]);
+                    if (gh[a][q] != 0.f) unsafeAtomicAdd(w.GH + (row0 + row) * d + col, gh[a][q]);
+                }
+            }
+        }
+    }
+}
+
+// ---- 7. gW[s][i][j] += sum_n gz[n][s] H^[n][i] T^[n][j] : one wave per (s, 32x32 tile), K = batch
+__global__ __launch_bounds__(256) void k_ntn_gw(float* __restrict__ gW, int64_t n, int d, int kr, NtnWs w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lk = lane >> 5;
+    const int jt = (d + 31) / 32;
+    const int tile = blockIdx.x * 4 + wave;
+    const int s = blockIdx.y;
+    if (tile >= jt * jt) return;
+    const int i0 = (tile / jt) * 32, j0 = (tile % jt) * 32;
+    const int ia = i0 + li, jb = j0 + li;
+    f32x16 acc = {0};
+    for (int64_t kk = 0; kk < n; kk += 2) {
+        const int64_t row = kk + lk;
+        const bool ok = row < n;
+        const float av = (ok && ia < d) ? w.GZ[row * kr + s] * w.Hn[row * d + ia] : 0.f;
+        const float bv = (ok && jb < d) ? w.Tn[row * d + jb] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (jb < d) {
+        float* g = gW + (int64_t)s * d * d;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = i0 + (q & 3) + 8 * (q >> 2) + 4 * lk;
+            if (i < d) g[(int64_t)i * d + jb] += acc[q];  // single writer per element in this launch
+        }
+    }
+}
+
+// ---- 8. normalisation backward + scatter of the entity-row gradients    (one wave per triple)
+__global__ __launch_bounds__(256) void k_ntn_scatter(const int64_t* __restrict__ h, const int64_t* __restrict__ t,
+                                                     const float* __restrict__ dscore, float* __restrict__ g_ent,
+                                                     int64_t n, int d, NtnWs w) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n || dscore[i] == 0.f) return;
+    float dh = 0.f, dt = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        dh = fmaf(w.Hn[i * d + c], w.GH[i * d + c], dh);
+        dt = fmaf(w.Tn[i * d + c], w.GT[i * d + c], dt);
+    }
+    dh = wave_sum(dh); dt = wave_sum(dt);
+    const float ih = w.inv[3 * i], it = w.inv[3 * i + 1];
+    const bool fh = w.flag[3 * i] != 0.f, ft = w.flag[3 * i + 1] != 0.f;
+    float* gh = g_ent + h[i] * d; float* gt = g_ent + t[i] * d;
+    for (int c = lane; c < d; c += 64) {
+        const float a = w.GH[i * d + c], b2 = w.GT[i * d + c];
+        unsafeAtomicAdd(gh + c, fh ? (a - w.Hn[i * d + c] * dh) * ih : a * ih);
+        unsafeAtomicAdd(gt + c, ft ? (b2 - w.Tn[i * d + c] * dt) * it : b2 * it);
+    }
+}
+
+// ---- host
+static int ntn_check(const kge_model_desc* m, int64_t n, void* ws, size_t ws_bytes) {
+    if (m->dim > 256 || m->rel_dim > 1024) { set_error("NTN: ent_hidden_size <= 256 and rel_hidden_size <= 1024 supported"); return -1; }
+    if (!ws || ws_bytes < ntn_workspace_bytes(m, n)) {
+        set_error("NTN needs a workspace of %zu bytes (kge_workspace_bytes)", ntn_workspace_bytes(m, n));
+        return -1;
+    }
+    return 0;
+}
+
+static int ntn_forward_core(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+                            const NtnWs& w, float* scores, hipStream_t s) {
+    const int d = m->dim, kr = m->rel_dim;
+    const unsigned rows4 = (unsigned)((n + 3) / 4), tiles = (unsigned)((n + NT - 1) / NT);
+    hipLaunchKernelGGL(k_ntn_prep, dim3(rows4), dim3(256), 0, s, m->tables[0], m->tables[1], h, r, t, n, d, kr, w);
+    const int S = (d + 1) | 1;
+    const size_t lds = (size_t)(2 * NT * S + 4 * NT) * sizeof(float);
+    hipLaunchKernelGGL(k_ntn_bil, dim3(tiles, (unsigned)((kr + 3) / 4)), dim3(256), lds, s, m->tables[5], n, d, kr, w);
+    hipLaunchKernelGGL(k_ntn_finish, dim3(rows4), dim3(256), 0, s, m->tables[2], m->tables[3], m->tables[4], n, d, kr, w,
+                       scores);
+    return check_launch("ntn forward");
+}
+
+int launch_ntn_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+                       float* scores, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (ntn_check(m, n, ws, ws_bytes)) return -1;
+    return ntn_forward_core(m, h, r, t, n, ntn_carve(ws, n, m->dim, m->rel_dim), scores, s);
+}
+
+int launch_ntn_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+                        const float* dscore, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (ntn_check(m, n, ws, ws_bytes)) return -1;
+    const int d = m->dim, kr = m->rel_dim;
+    const NtnWs w = ntn_carve(ws, n, d, kr);
+    int rc = ntn_forward_core(m, h, r, t, n, w, nullptr, s);  // recompute H^, T^, R^, z
+    if (rc) return rc;
+    const unsigned rows4 = (unsigned)((n + 3) / 4), tiles = (unsigned)((n + NT - 1) / NT);
+    hipLaunchKernelGGL(k_ntn_gz, dim3(rows4), dim3(256), (size_t)4 * kr * sizeof(float), s, m->tables[2], m->tables[3], r,
+                       dscore, m->grads[1], n, d, kr, w);
+    hipLaunchKernelGGL(k_ntn_small, dim3((unsigned)(((int64_t)(d + 1) * kr + 255) / 256)), dim3(256), 0, s, m->grads[2],
+                       m->grads[3], m->grads[4], n, d, kr, w);
+    const int S = (d + 1) | 1;
+    const size_t lds = (size_t)(2 * NT * S) * sizeof(float);
+    const dim3 gb(tiles, (unsigned)((kr + 4 * SPW - 1) / (4 * SPW)));
+    const int JT = (d + 31) / 32;
+#define KGE_NTN_BWD(J) case J: hipLaunchKernelGGL(k_ntn_bil_bwd<J>, gb, dim3(256), lds, s, m->tables[5], n, d, kr, w); break;
+    switch (JT) {
+        KGE_NTN_BWD(1) KGE_NTN_BWD(2) KGE_NTN_BWD(3) KGE_NTN_BWD(4) KGE_NTN_BWD(5) KGE_NTN_BWD(6) KGE_NTN_BWD(7) KGE_NTN_BWD(8)
+    }
+#undef KGE_NTN_BWD
+    hipLaunchKernelGGL(k_ntn_gw, dim3((unsigned)((JT * JT + 3) / 4), (unsigned)kr), dim3(256), 0, s, m->grads[5], n, d, kr, w);
+    hipLaunchKernelGGL(k_ntn_scatter, dim3(rows4), dim3(256), 0, s, h, t, dscore, m->grads[0], n, d, w);
+    return check_launch("ntn backward");
+}
+
+// ---- NTN.get_reg (pairwise.py:962-963): lmbda * sqrt(sum over ALL parameters of w^2), dense
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ p, int64_t numel, float* __restrict__ out) {
+    __shared__ float part[4];
+    float a = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+        a = fmaf(p[i], p[i], a);
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void k_l2_apply(const float* __restrict__ p, float* __restrict__ g, int64_t numel, float lmbda,
+                                                  const float* __restrict__ sumsq, float* __restrict__ loss) {
+    const float root = sqrtf(*sumsq);
+    const float c = lmbda / root;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+        g[i] = fmaf(c, p[i], g[i]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) unsafeAtomicAdd(loss, lmbda * root);
+}
+
+int launch_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, float* scratch, float* loss, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float), s);
+    if (e != hipSuccess) { set_error("kge_l2norm_reg: memset: %s", hipGetErrorString(e)); return -2; }
+    int64_t b = (numel + 255) / 256;
+    if (b > 2048) b = 2048;
+    hipLaunchKernelGGL(k_sumsq, dim3((unsigned)b), dim3(256), 0, s, param, numel, scratch);
+    hipLaunchKernelGGL(k_l2_apply, dim3((unsigned)b), dim3(256), 0, s, param, grad, numel, lmbda, scratch, loss);
+    return check_launch("kge_l2norm_reg");
+}
+
+}  // namespace kge

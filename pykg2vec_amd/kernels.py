@@ -139,6 +139,14 @@ def train_pointwise_logistic(desc, h, r, t, y, lmbda, reg_type, loss_buf):
             "kge_train_pointwise_logistic")
 
 
+def l2norm_reg(param, grad, lmbda, loss_buf):
+    """NTN.get_reg over one flat parameter buffer: loss += lmbda*||param||_2, grad += lmbda*param/||param||_2."""
+    scratch = torch.empty(1, dtype=torch.float32, device=param.device)
+    L.check(L.load().kge_l2norm_reg(_dev(param, torch.float32, "param"), _dev(grad, torch.float32, "grad"), param.numel(),
+                                    float(lmbda), _dev(scratch, torch.float32, "scratch"),
+                                    _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_l2norm_reg")
+
+
 def optimizer_step(kind, param, grad, state1, state2, lr, step, zero_grad=True):
     p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
     p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None

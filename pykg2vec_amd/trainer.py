@@ -119,26 +119,10 @@ class Trainer:
         if name == "rotate":
             self._selfadv_ws = self.K.train_pairwise_selfadv(self._desc, ph, pr, pt, nh, nr, nt, self.config.neg_rate,
                                                         self.config.alpha, self.loss_buf, self._selfadv_ws)
-        elif self.model.kernel_name == "ntn":
-            self._accumulate_dense_pairwise(ph, pr, pt, nh, nr, nt)
         else:
             self.K.train_pairwise_hinge(self._desc, ph, pr, pt, nh, nr, nt, self.config.margin, self.loss_buf)
-
-    def _accumulate_dense_pairwise(self, ph, pr, pt, nh, nr, nt):
-        """RESCAL / NTN: MFMA scorer + hinge coefficients + MFMA backward (three launches)."""
-        sp = self.K.score_forward(self._desc, ph, pr, pt)
-        sn = self.K.score_forward(self._desc, nh, nr, nt)
-        v = sp + self.config.margin - sn
-        coef = (v > 0).to(torch.float32) + 0.5 * (v == 0).to(torch.float32)
-        self.loss_buf[0] += torch.clamp_min(v, 0).sum()
-        self.K.score_backward(self._desc, ph, pr, pt, coef)
-        self.K.score_backward(self._desc, nh, nr, nt, -coef)
-        if self.model.kernel_name == "ntn":  # NTN.get_reg: lmbda * sqrt(sum w^2), dense over every table
-            sq = sum((p * p).sum() for p in self.flat.views)
-            root = torch.sqrt(sq)
-            self.loss_buf[0] += self.model.lmbda * root
-            for g, p in zip(self.flat.grad_views, self.flat.views):
-                g.add_(p, alpha=1.0).sub_(p).add_(p * (self.model.lmbda / root))
+            if self.model.kernel_name == "ntn":  # + get_reg(None, None, None) (utils/trainer.py:155): dense L2-norm
+                self.K.l2norm_reg(self.flat.param, self.flat.grad, self.model.lmbda, self.loss_buf)
 
     def _accumulate_pointwise(self, h, r, t, y):
         self.K.train_pointwise_logistic(self._desc, h, r, t, y, self.model.lmbda, self.model.kernel_reg_type(), self.loss_buf)

@@ -10,7 +10,8 @@ from golden_util import CASES, Case, close
 
 pytestmark = pytest.mark.gpu
 
-VECTOR_CASES = [c for c in CASES if c != "ntn"]  # NTN: MFMA path not built yet
+VECTOR_CASES = list(CASES)
+EVAL_CASES = [c for c in CASES if c != "ntn"]  # NTN rank sweep: not built yet
 GRAD_TOL = dict(atol=2e-5, rtol=1e-4)
 
 
@@ -102,7 +103,7 @@ def test_three_fused_training_steps_match_reference_weights(hip, name, opt):
         assert np.allclose(got, ref, atol=tol, rtol=1e-4), (k, np.abs(got - ref).max())
 
 
-@pytest.mark.parametrize("name", VECTOR_CASES)
+@pytest.mark.parametrize("name", EVAL_CASES)
 def test_eval_sweep_scores_and_ranks_match_reference(hip, name):
     from pykg2vec_amd import kernels as K
     from pykg2vec_amd.evaluator import Evaluator
@@ -156,7 +157,9 @@ SHAPES = [("transe", dict(hidden_size=50, l1_flag=True), 1), ("transe", dict(hid
           ("rotate", dict(hidden_size=33, margin=6.0, neg_rate=3, alpha=0.5), 3),
           ("distmult", dict(hidden_size=100, lmbda=0.01), 2), ("complex", dict(hidden_size=200, lmbda=1e-4), 1),
           ("complexn3", dict(hidden_size=37, lmbda=0.05), 2), ("analogy", dict(hidden_size=200, lmbda=0.01), 1),
-          ("rescal", dict(hidden_size=50), 1), ("rescal", dict(hidden_size=200), 1), ("rescal", dict(hidden_size=33), 1)]
+          ("rescal", dict(hidden_size=50), 1), ("rescal", dict(hidden_size=200), 1), ("rescal", dict(hidden_size=33), 1),
+          ("ntn", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4), 1),
+          ("ntn", dict(ent_hidden_size=40, rel_hidden_size=33, lmbda=0.1), 1)]
 
 
 @pytest.mark.parametrize("model,hp,neg_rate", SHAPES)
