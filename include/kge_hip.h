@@ -143,6 +143,12 @@ int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n,
 int kge_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n,
                           void* workspace, size_t workspace_bytes, float* scores, void* stream);
 
+/* MetricCalculator.get_tail_rank / get_head_rank (utils/evaluator.py:70-123) from materialised score rows, for models
+ * whose sweep is served by kge_score_forward over all candidates (NTN): scores float [nq, E], truth int64 [nq] (the true
+ * entity of each row), CSR of known entities per row (may be NULL) -> rank, filtered rank (int32 [nq], 0-based). */
+int kge_rank_from_scores(const float* scores, int64_t nq, int64_t tot_entity, const int64_t* truth,
+                         const int64_t* off, const int32_t* ids, int32_t* rank, int32_t* frank, void* stream);
+
 /* Negative corruption (data/generator.py:42-97,125-156) on device.
  *   kge_triple_set_build: open-addressing set of packed (h,r,t) train triples; slots = power of two >= 2n.
  *   kge_corrupt: for each positive and each of neg_rate slots draw u (Philox4x32-10 keyed by seed, counter =

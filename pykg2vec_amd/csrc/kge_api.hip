@@ -214,6 +214,16 @@ int kge_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64
     return launch_eval_sweep_scores(m, triples, n, workspace, workspace_bytes, scores, (hipStream_t)stream);
 }
 
+int kge_rank_from_scores(const float* scores, int64_t nq, int64_t tot_entity, const int64_t* truth, const int64_t* off,
+                         const int32_t* ids, int32_t* rank, int32_t* frank, void* stream) {
+    if (nq == 0) return 0;
+    if (!scores || !truth || !rank || !frank || nq < 0 || tot_entity <= 0 || (off && !ids)) {
+        set_error("kge_rank_from_scores: bad arguments");
+        return -1;
+    }
+    return launch_rank_from_scores(scores, nq, tot_entity, truth, off, ids, rank, frank, (hipStream_t)stream);
+}
+
 int kge_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, int64_t n_slots, void* stream) {
     if (!triples || !slots || n < 0 || n_slots < 2 * n || (n_slots & (n_slots - 1))) {
         set_error("kge_triple_set_build: n_slots must be a power of two >= 2n");

@@ -523,6 +523,38 @@ __global__ void k_eval_finalize(const int32_t* __restrict__ rcount, const int32_
     ranks[3 * n + i] = rt - fcount[2 * i];       // filtered tail
 }
 
+// ------------------------------------------------------------------ ranks from materialised score rows
+// (models without a pre-contracted sweep form, i.e. NTN: scores come from kge_score_forward over all candidates)
+__global__ __launch_bounds__(256) void k_rank_from_scores(const float* __restrict__ scores, int64_t nq, int64_t E,
+                                                          const int64_t* __restrict__ truth, const int64_t* __restrict__ off,
+                                                          const int32_t* __restrict__ ids, int32_t* __restrict__ rank,
+                                                          int32_t* __restrict__ frank) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float* s = scores + q * E;
+    const int64_t tr = truth[q];
+    const float st = s[tr];
+    int cnt = 0, fc = 0;
+    for (int64_t e = lane; e < E; e += 64) cnt += s[e] < st ? 1 : 0;
+    if (off) {
+        for (int64_t j = off[q] + lane; j < off[q + 1]; j += 64) {
+            const int64_t e = ids[j];
+            fc += (e != tr && s[e] < st) ? 1 : 0;
+        }
+    }
+    cnt = (int)wave_sum((float)cnt);
+    fc = (int)wave_sum((float)fc);
+    if (lane == 0) { rank[q] = cnt; frank[q] = cnt - fc; }
+}
+
+int launch_rank_from_scores(const float* scores, int64_t nq, int64_t E, const int64_t* truth, const int64_t* off,
+                            const int32_t* ids, int32_t* rank, int32_t* frank, hipStream_t s) {
+    hipLaunchKernelGGL(k_rank_from_scores, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, scores, nq, E, truth, off, ids, rank,
+                       frank);
+    return check_launch("k_rank_from_scores");
+}
+
 // ------------------------------------------------------------------ host side
 static void fill_prep(const kge_model_desc* m, const EvalPlan& p, PrepArgs* a) {
     a->nseg = 1; a->dot_tab = nullptr; a->normalize = 0;

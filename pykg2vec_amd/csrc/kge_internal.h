@@ -56,6 +56,9 @@ int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n
 int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
                              float* scores, hipStream_t s);
 
+int launch_rank_from_scores(const float* scores, int64_t nq, int64_t E, const int64_t* truth, const int64_t* off,
+                            const int32_t* ids, int32_t* rank, int32_t* frank, hipStream_t s);
+
 // kge_sampler.hip
 int launch_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, int64_t n_slots, hipStream_t s);
 int launch_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t n_pos, int neg_rate,

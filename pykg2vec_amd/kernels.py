@@ -193,6 +193,45 @@ def eval_sweep_scores(desc, triples, workspace=None):
     return out
 
 
+def rank_from_scores(scores, truth, off, ids):
+    """scores float32 [nq, E] -> (rank, filtered rank) int32 [nq] given the true entity per row and a CSR of knowns."""
+    nq, E = scores.shape
+    rank = torch.empty(nq, dtype=torch.int32, device=scores.device)
+    frank = torch.empty_like(rank)
+    po = _dev(off, torch.int64, "csr offsets") if off is not None else None
+    pi = _dev(ids, torch.int32, "csr ids") if ids is not None else None
+    L.check(L.load().kge_rank_from_scores(_dev(scores, torch.float32, "scores"), nq, E, _ids(truth, "truth"), po, pi,
+                                          _dev(rank, torch.int32, "rank"), _dev(frank, torch.int32, "frank"), _stream()),
+            "kge_rank_from_scores")
+    return rank, frank
+
+
+def eval_ranks_via_forward(desc, triples, tail_off, tail_ids, head_off, head_ids, chunk=64):
+    """kge_eval_ranks for models without a pre-contracted sweep form (NTN): like the reference
+    (utils/evaluator.py:254-272) every candidate triple goes through the batch scorer -- on the device, `chunk`
+    test triples x E candidates per kge_score_forward call -- then kge_rank_from_scores.  int32 [4, n]."""
+    n = triples.shape[0]
+    E = desc.tot_entity
+    dev = triples.device
+    ents = torch.arange(E, dtype=torch.int64, device=dev)
+    out = torch.empty((4, n), dtype=torch.int32, device=dev)
+    for lo in range(0, n, chunk):
+        tr = triples[lo:lo + chunk]
+        m = tr.shape[0]
+        h, r, t = tr[:, 0:1], tr[:, 1:2], tr[:, 2:3]
+        cand = ents.view(1, E).expand(m, E)
+        tail_scores = score_forward(desc, h.expand(m, E).reshape(-1).contiguous(), r.expand(m, E).reshape(-1).contiguous(),
+                                    cand.reshape(-1).contiguous()).view(m, E)
+        head_scores = score_forward(desc, cand.reshape(-1).contiguous(), r.expand(m, E).reshape(-1).contiguous(),
+                                    t.expand(m, E).reshape(-1).contiguous()).view(m, E)
+        to = (tail_off[lo:lo + m + 1]).contiguous() if tail_off is not None else None
+        ho = (head_off[lo:lo + m + 1]).contiguous() if head_off is not None else None
+        rt, frt = rank_from_scores(tail_scores, tr[:, 2].contiguous(), to, tail_ids)
+        rh, frh = rank_from_scores(head_scores, tr[:, 0].contiguous(), ho, head_ids)
+        out[0, lo:lo + m], out[1, lo:lo + m], out[2, lo:lo + m], out[3, lo:lo + m] = rh, rt, frh, frt
+    return out
+
+
 def triple_set_build(triples):
     """Open-addressing hash set of the train triples (uint64 slots, power of two >= 2n)."""
     n = triples.shape[0]
