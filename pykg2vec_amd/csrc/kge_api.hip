@@ -157,6 +157,10 @@ int kge_train_pairwise_selfadv(const kge_model_desc* m, const int64_t* ph, const
     }
     if (!is_vector_model(m->model)) { set_error("kge_train_pairwise_selfadv: unsupported model %d", m->model); return -1; }
     hipStream_t s = (hipStream_t)stream;
+    {   // fused bundle kernel (one launch) whenever the negatives of a positive fit one lane group
+        const int rc1 = launch_selfadv_bundle(m, ph, pr, pt, nh, nr, nt, n_pos, neg_rate, alpha, loss, s);
+        if (rc1 <= 0) return rc1;
+    }
     float* spos = workspace;
     float* sneg = workspace + n_pos;
     const int64_t n_neg = n_pos * neg_rate;

@@ -18,6 +18,10 @@ namespace kge {
 constexpr int kBlock = 256;
 constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident 256-thread blocks; rest is grid-stride
 
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // F.softplus, threshold 20
+__device__ __forceinline__ float sigmoid_t(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float logsigmoid_t(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+
 template <int M, int G, int NCH>
 __global__ __launch_bounds__(kBlock) void k_score_fwd(DeviceModel m, const int64_t* __restrict__ h,
                                                       const int64_t* __restrict__ r, const int64_t* __restrict__ t,
@@ -102,9 +106,6 @@ __global__ __launch_bounds__(kBlock) void k_pairwise_hinge(DeviceModel m, const 
     block_accumulate_loss<G>(acc, gl, loss);
 }
 
-__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // F.softplus, threshold 20
-__device__ __forceinline__ float sigmoid_t(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float logsigmoid_t(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 
 // ---- fused pointwise step: mean(softplus(y*s)) + lmbda * mean_i(sum of squares/cubes of the rows of row i)
 template <int M, int G, int NCH>
@@ -145,6 +146,90 @@ __global__ __launch_bounds__(kBlock) void k_pointwise_logistic(DeviceModel m, co
             acc += lmbda * inv_n * gsum<G>(rs);
         }
         scatter_rows<M, G, NCH>(Gr, m, id, gl);
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
+
+// ---- fused self-adversarial step (criterion.py:13-23 + trainer.py:147-157): one group owns a positive AND its
+// neg_rate negatives (rows [i*neg_rate, (i+1)*neg_rate), data/generator.py:71-95).  Pass 1 scores the 1+neg_rate
+// triples (lane j of the group keeps the energy of negative j), the group computes the detached softmax weights and
+// the loss; pass 2 re-gathers each triple (L2 hits), back-propagates, and accumulates every gradient row whose id
+// equals the positive's id for that role in REGISTERS -- a sampled negative shares its relation and one entity with
+// its positive, so 1+neg_rate triples scatter ~(NR + neg_rate*(rows of one entity)) rows instead of (1+neg_rate)*NR.
+template <int M, int G, int NCH>
+__global__ __launch_bounds__(kBlock) void k_selfadv_bundle(DeviceModel m, const int64_t* __restrict__ ph,
+                                                           const int64_t* __restrict__ pr, const int64_t* __restrict__ pt,
+                                                           const int64_t* __restrict__ nh, const int64_t* __restrict__ nr,
+                                                           const int64_t* __restrict__ nt, int64_t n_pos, int neg_rate,
+                                                           float alpha, float* __restrict__ loss) {
+    constexpr int GPB = kBlock / G;
+    constexpr int NR = role_count(M);
+    const int gl = threadIdx.x % G;
+    const float inv_b = 1.0f / (float)n_pos;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n_pos; i += (int64_t)gridDim.x * GPB) {
+        const int64_t idp[3] = {ph[i], pr[i], pt[i]};
+        // ---- pass 1: energies
+        float s_mine = 0.f;  // lane j: energy of negative j
+        float s_pos;
+        {
+            Rows<M, NCH> R;
+            Saved<M, NCH> sv;
+            load_rows<M, G, NCH>(R, m, idp, gl);
+            s_pos = model_fwd<M, G, NCH>(R, m, sv);
+            for (int j = 0; j < neg_rate; ++j) {
+                const int64_t q = i * neg_rate + j;
+                const int64_t idn[3] = {nh[q], nr[q], nt[q]};
+                load_rows<M, G, NCH>(R, m, idn, gl);
+                const float sj = model_fwd<M, G, NCH>(R, m, sv);
+                if (gl == j) s_mine = sj;
+            }
+        }
+        // ---- loss and coefficients: n_j = -s_j, w = softmax(alpha n), L_i = -sum w logsig(-n) - logsig(-s_pos)
+        const bool live = gl < neg_rate;
+        const float nj = -s_mine;
+        float mx = live ? nj * alpha : -INFINITY;
+#pragma unroll
+        for (int o = G / 2; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float ex = live ? expf(nj * alpha - mx) : 0.f;
+        const float den = gsum<G>(ex);
+        const float wj = ex / den;
+        const float term = gsum<G>(live ? wj * logsigmoid_t(-nj) : 0.f);
+        acc += (-term - logsigmoid_t(-s_pos)) * inv_b;
+        const float c_mine = live ? -(wj * sigmoid_t(nj)) * inv_b : 0.f;  // dL/d s_j
+        const float c_pos = sigmoid_t(s_pos) * inv_b;                      // dL/d s_pos
+        // ---- pass 2: backward with anchor accumulation
+        Rows<M, NCH> A;  // gradient rows of the positive's ids
+        {
+            Rows<M, NCH> R;
+            Saved<M, NCH> sv;
+            load_rows<M, G, NCH>(R, m, idp, gl);
+            model_fwd<M, G, NCH>(R, m, sv);
+            model_bwd<M, G, NCH>(R, m, sv, c_pos, A);
+        }
+        for (int j = 0; j < neg_rate; ++j) {
+            const float cj = __shfl(c_mine, (threadIdx.x / G) * G % 64 + j, 64);
+            if (cj == 0.f) continue;
+            const int64_t q = i * neg_rate + j;
+            const int64_t idn[3] = {nh[q], nr[q], nt[q]};
+            Rows<M, NCH> R, Gn;
+            Saved<M, NCH> sv;
+            load_rows<M, G, NCH>(R, m, idn, gl);
+            model_fwd<M, G, NCH>(R, m, sv);
+            model_bwd<M, G, NCH>(R, m, sv, cj, Gn);
+#pragma unroll
+            for (int q2 = 0; q2 < NR; ++q2) {
+                const int sel = role_sel(M, q2);
+                if (idn[sel] == idp[sel]) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) A.x[q2][c] += Gn.x[q2][c];
+                } else {
+                    const int d = role_dim<M>(m, q2);
+                    atomic_add_row<G, NCH>(m.grad[role_tab(M, q2)] + idn[sel] * (int64_t)d, Gn.x[q2], d, gl);
+                }
+            }
+        }
+        scatter_rows<M, G, NCH>(A, m, idp, gl);
     }
     block_accumulate_loss<G>(acc, gl, loss);
 }
@@ -259,6 +344,19 @@ int launch_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const i
     const DeviceModel dm = to_device_model(m);
     KGE_DISPATCH(m->model, (k_pointwise_logistic<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, lmbda, reg_type, loss)))
     set_error("kge_train_pointwise_logistic: unsupported model %d", m->model);
+    return -1;
+}
+
+int launch_selfadv_bundle(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                          const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n_pos, int neg_rate,
+                          float alpha, float* loss, hipStream_t s) {
+    Geometry geo;
+    if (!geometry_for(m, &geo)) return -1;
+    if (neg_rate > geo.G) return 1;  // caller falls back to the three-launch path
+    const DeviceModel dm = to_device_model(m);
+    const int64_t n = n_pos;
+    KGE_DISPATCH(m->model, (k_selfadv_bundle<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, ph, pr, pt, nh, nr, nt, n_pos, neg_rate, alpha, loss)))
+    set_error("kge_train_pairwise_selfadv: unsupported model %d", m->model);
     return -1;
 }
 

@@ -161,6 +161,7 @@ SHAPES = [("transe", dict(hidden_size=50, l1_flag=True), 1), ("transe", dict(hid
           ("transh", dict(hidden_size=100, l1_flag=True), 1), ("transd", dict(ent_hidden_size=64, rel_hidden_size=64, l1_flag=False), 1),
           ("rotate", dict(hidden_size=1000, margin=24.0, neg_rate=16, alpha=1.0), 16),
           ("rotate", dict(hidden_size=33, margin=6.0, neg_rate=3, alpha=0.5), 3),
+          ("rotate", dict(hidden_size=20, margin=6.0, neg_rate=40, alpha=1.0), 40),   # > lane group: three-launch path
           ("distmult", dict(hidden_size=100, lmbda=0.01), 2), ("complex", dict(hidden_size=200, lmbda=1e-4), 1),
           ("complexn3", dict(hidden_size=37, lmbda=0.05), 2), ("analogy", dict(hidden_size=200, lmbda=0.01), 1),
           ("rescal", dict(hidden_size=50), 1), ("rescal", dict(hidden_size=200), 1), ("rescal", dict(hidden_size=33), 1),

@@ -1,0 +1,65 @@
+"""Dev tool: step time / eval throughput of the BASELINE.json configs (synthetic dataset-shaped data) on one MI355X."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import hip_util
+from pykg2vec_amd.trainer import Trainer
+from pykg2vec_amd.evaluator import Evaluator
+
+SHAPES = {"umls": (135, 46, 5216, 661), "fb15k": (14951, 1345, 483142, 59071), "wn18rr": (40943, 11, 86835, 3134),
+          "fb15k237": (14541, 237, 272115, 20466), "yago310": (123182, 37, 1079040, 5000)}
+CONFIGS = [
+    ("C0 TransE UMLS d=50 B=128 adam", "transe", "umls", dict(hidden_size=50, l1_flag=True, margin=0.8), "adam", 128, 1, 661),
+    ("C1 TransE FB15k d=100 B=128 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 128, 1, 0),
+    ("C1 TransE FB15k d=100 B=4096 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 4096, 1, 0),
+    ("C1 TransE FB15k d=100 B=32768 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 8192),
+    ("C1 TransE-L2 FB15k d=100 B=32768 sgd", "transe", "fb15k", dict(hidden_size=100, l1_flag=False, margin=1.0), "sgd", 32768, 1, 8192),
+    ("TransH FB15k d=100 B=32768 adam", "transh", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 2048),
+    ("TransD FB15k d=100 B=32768 adam", "transd", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 2048),
+    ("DistMult FB15k d=100 B=32768 adagrad", "distmult", "fb15k", dict(hidden_size=100, lmbda=1e-4), "adagrad", 32768, 1, 8192),
+    ("C2 ComplEx WN18RR d=200 B=5000 adagrad", "complex", "wn18rr", dict(hidden_size=200, lmbda=1e-4), "adagrad", 5000, 1, 3134),
+    ("ANALOGY FB15k d=200 B=4096 adagrad", "analogy", "fb15k", dict(hidden_size=200, lmbda=1e-4), "adagrad", 4096, 1, 2048),
+    ("C3 RotatE FB15k-237 d=1000 B=1024 neg16 adam", "rotate", "fb15k237", dict(hidden_size=1000, margin=24.0, neg_rate=16, alpha=1.0), "adam", 1024, 16, 2048),
+    ("C4 RESCAL YAGO3-10 k=200 B=1024 adam", "rescal", "yago310", dict(hidden_size=200, margin=1.0), "adam", 1024, 1, 1024),
+    ("RESCAL FB15k k=50 B=128 adam (preset)", "rescal", "fb15k", dict(hidden_size=50, margin=1.0), "adam", 128, 1, 1024),
+    ("NTN FB15k d=k=100 B=128 adam (preset)", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 128, 1, 64),
+]
+only = os.environ.get("ONLY")
+rng = np.random.default_rng(1234)
+for name, model, ds, hp, opt, B, neg, n_eval in CONFIGS:
+    if only and only not in name:
+        continue
+    E, R, NTR, NTE = SHAPES[ds]
+    train = np.stack([rng.integers(E, size=NTR), rng.integers(R, size=NTR), rng.integers(E, size=NTR)], 1)
+    test = np.stack([rng.integers(E, size=max(n_eval, 16)), rng.integers(R, size=max(n_eval, 16)), rng.integers(E, size=max(n_eval, 16))], 1)
+    hp2 = dict(hp); hp2.setdefault("margin", 1.0); hp2["neg_rate"] = neg
+    cfg = hip_util.make_config(E, R, hp2, train, test[:16], test, optimizer=opt, lr=0.01, batch_size=B)
+    cfg.hr_dummy = None
+    torch.manual_seed(0)
+    m = hip_util.model_from_params(model, {}, hp, E, R)
+    tr = Trainer(m, cfg); tr.build_model()
+    gen = tr._new_generator(); tr.generator = gen
+    spe = max(1, NTR // B)
+    def step():
+        if gen._pending <= 0: gen.start_one_epoch(spe)
+        b = next(gen)
+        if model in ("distmult", "complex", "analogy"): tr._accumulate_pointwise(*b)
+        else: tr._accumulate_pairwise(*b)
+        tr._reduce_and_step()
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+    K_ = 30
+    t0 = time.perf_counter()
+    for _ in range(K_): step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K_
+    line = f"{name}: step {dt*1e6:.1f} us -> {B*(1+neg)/dt/1e6:.2f} M scored triples/s"
+    if n_eval:
+        ev = Evaluator(m, cfg)
+        ev.rank_all(test, n_eval); torch.cuda.synchronize()
+        t0 = time.perf_counter(); ev.rank_all(test, n_eval); torch.cuda.synchronize(); edt = time.perf_counter() - t0
+        line += f" | eval {n_eval} triples {edt*1e3:.2f} ms -> {n_eval/edt:.0f} test triples/s"
+    print(line, flush=True)
+    del tr, m, gen
+    torch.cuda.empty_cache()
