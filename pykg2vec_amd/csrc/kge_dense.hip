@@ -145,71 +145,74 @@ __global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, c
     const int ntile = (k + 31) / 32;
     const int li = lane & 31, lk = lane >> 5;
 
-    // ---- U = T M^T : U[i][a] = sum_b T[i][b] M[a][b]
-    for (int at = wave; at < ntile; at += 4) {
-        const int a = at * 32 + li;
-        f32x16 acc = {0};
-        for (int kk = 0; kk < k; kk += 2) {
-            const int b = kk + lk;
-            const float av = b < k ? sT[li * S + b] : 0.f;
-            const float bv = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-        if (a < k) {
+    // Work units of this tile, dealt round-robin to the 4*gridDim.y waves that share it:
+    //   [0, ntile)              U = T M^T  column tile `at`   (forward score / grad_h)
+    //   [ntile, 2 ntile)        V = H M    column tile `bt`   (grad_t)
+    //   [2 ntile, 2 ntile + ntile^2)   G = (ds*H)^T T  tile (at, bt)   (grad_M)
+    const int n_units = MODE == 0 ? ntile : 2 * ntile + ntile * ntile;
+    float* gM = MODE == 1 ? g_rel + (int64_t)rel * k * k : nullptr;
+    for (int u = blockIdx.y * 4 + wave; u < n_units; u += 4 * gridDim.y) {
+        if (u < ntile) {  // ---- U[i][a] = sum_b T[i][b] M[a][b]
+            const int a = u * 32 + li;
+            f32x16 acc = {0};
+            for (int kk = 0; kk < k; kk += 2) {
+                const int b = kk + lk;
+                const float av = b < k ? sT[li * S + b] : 0.f;
+                const float bv = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+            if (a < k) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                if (MODE == 0) {
-                    atomicAdd(&sSc[i], sH[i * S + a] * acc[reg]);          // LDS atomic: score_i += h_i[a] U[i][a]
-                } else if (i < cnt && sDs[i] != 0.f) {
-                    unsafeAtomicAdd(g_ent + sHid[i] * k + a, -sDs[i] * acc[reg]);   // grad_h = -ds U
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                    if (MODE == 0) {
+                        atomicAdd(&sSc[i], sH[i * S + a] * acc[reg]);          // LDS atomic: score_i += h_i[a] U[i][a]
+                    } else if (i < cnt && sDs[i] != 0.f) {
+                        unsafeAtomicAdd(g_ent + sHid[i] * k + a, -sDs[i] * acc[reg]);   // grad_h = -ds U
+                    }
+                }
+            }
+        } else if (u < 2 * ntile) {  // ---- V[i][b] = sum_a H[i][a] M[a][b] ;  grad_t = -ds V
+            const int b = (u - ntile) * 32 + li;
+            f32x16 acc = {0};
+            for (int kk = 0; kk < k; kk += 2) {
+                const int a = kk + lk;
+                const float av = a < k ? sH[li * S + a] : 0.f;
+                const float bv = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+            if (b < k) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                    if (i < cnt && sDs[i] != 0.f) unsafeAtomicAdd(g_ent + sTid[i] * k + b, -sDs[i] * acc[reg]);
+                }
+            }
+        } else {  // ---- G[a][b] = sum_i ds_i H[i][a] T[i][b] ;  grad_M = -G
+            const int tl = u - 2 * ntile;
+            const int at = tl / ntile, bt = tl - at * ntile;
+            const int a_in = at * 32 + li, b_in = bt * 32 + li;
+            f32x16 acc = {0};
+#pragma unroll 4
+            for (int kk = 0; kk < TILE; kk += 2) {
+                const int i = kk + lk;
+                const float av = a_in < k ? sDs[i] * sH[i * S + a_in] : 0.f;
+                const float bv = b_in < k ? sT[i * S + b_in] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+            if (b_in < k) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int a = at * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                    if (a < k && acc[reg] != 0.f) unsafeAtomicAdd(gM + (int64_t)a * k + b_in, -acc[reg]);
                 }
             }
         }
     }
     if (MODE == 0) {
         __syncthreads();
-        if (threadIdx.x < cnt) scores[sRow[threadIdx.x]] = -sSc[threadIdx.x];
-        return;
-    }
-    // ---- V = H M : V[i][b] = sum_a H[i][a] M[a][b] ;  grad_t = -ds V
-    for (int bt = wave; bt < ntile; bt += 4) {
-        const int b = bt * 32 + li;
-        f32x16 acc = {0};
-        for (int kk = 0; kk < k; kk += 2) {
-            const int a = kk + lk;
-            const float av = a < k ? sH[li * S + a] : 0.f;
-            const float bv = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-        if (b < k) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                if (i < cnt && sDs[i] != 0.f) unsafeAtomicAdd(g_ent + sTid[i] * k + b, -sDs[i] * acc[reg]);
-            }
-        }
-    }
-    // ---- G = (ds*H)^T T : G[a][b] = sum_i ds_i H[i][a] T[i][b] ;  grad_M = -G
-    float* gM = g_rel + (int64_t)rel * k * k;
-    for (int tl = wave; tl < ntile * ntile; tl += 4) {
-        const int at = tl / ntile, bt = tl - at * ntile;
-        const int a_in = at * 32 + li, b_in = bt * 32 + li;
-        f32x16 acc = {0};
-#pragma unroll 4
-        for (int kk = 0; kk < TILE; kk += 2) {
-            const int i = kk + lk;
-            const float av = a_in < k ? sDs[i] * sH[i * S + a_in] : 0.f;
-            const float bv = b_in < k ? sT[i * S + b_in] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-        if (b_in < k) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int a = at * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                if (a < k && acc[reg] != 0.f) unsafeAtomicAdd(gM + (int64_t)a * k + b_in, -acc[reg]);
-            }
-        }
+        // partial score of this block's column tiles; `scores` is zero-filled by the launcher
+        if (threadIdx.x < cnt) unsafeAtomicAdd(scores + sRow[threadIdx.x], -sSc[threadIdx.x]);
     }
 }
 
@@ -240,15 +243,20 @@ static int rescal_run(int mode, const kge_model_desc* m, const int64_t* h, const
     if (rc) return rc;
     const unsigned max_tiles = (unsigned)(n / TILE + R + 1);  // upper bound on sum_r ceil(n_r / 32); surplus blocks exit
     const size_t lds = rescal_lds_bytes(k);
+    const int ntile = (k + 31) / 32;
     if (mode == 0) {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)k_rescal<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_rescal<0>, dim3(max_tiles), dim3(256), lds, s, m->tables[0], m->tables[1], nullptr, nullptr, h, t,
+        hipError_t e = hipMemsetAsync(scores, 0, (size_t)n * sizeof(float), s);
+        if (e != hipSuccess) { set_error("rescal: memset: %s", hipGetErrorString(e)); return -2; }
+        hipLaunchKernelGGL(k_rescal<0>, dim3(max_tiles, (unsigned)((ntile + 3) / 4)), dim3(256), lds, s, m->tables[0], m->tables[1], nullptr, nullptr, h, t,
                            g.offsets, g.tile_off, g.perm, (int)R, k, nullptr, scores);
     } else {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)k_rescal<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_rescal<1>, dim3(max_tiles), dim3(256), lds, s, m->tables[0], m->tables[1], m->grads[0],
+        const int units = 2 * ntile + ntile * ntile;
+        const unsigned ysplit = (unsigned)min(8, (units + 15) / 16);  // ~4 units per wave
+        hipLaunchKernelGGL(k_rescal<1>, dim3(max_tiles, ysplit), dim3(256), lds, s, m->tables[0], m->tables[1], m->grads[0],
                            m->grads[1], h, t, g.offsets, g.tile_off, g.perm, (int)R, k, dscore, nullptr);
     }
     return check_launch("k_rescal");
@@ -275,9 +283,36 @@ __global__ __launch_bounds__(256) void k_row_normalize(float* __restrict__ w, in
     for (int64_t c = lane; c < dim; c += 64) p[c] = p[c] / nrm;
 }
 
+// long rows (the k*k relation matrices): one 1024-thread workgroup per row
+__global__ __launch_bounds__(1024) void k_row_normalize_wide(float* __restrict__ w, int64_t rows, int64_t dim) {
+    __shared__ float part[16];
+    __shared__ float s_nrm;
+    float* p = w + (int64_t)blockIdx.x * dim;
+    float n2 = 0.f;
+    for (int64_t c = threadIdx.x; c < dim; c += 1024) n2 = fmaf(p[c], p[c], n2);
+    n2 = wave_sum(n2);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += part[i];
+        s_nrm = sqrtf(t);
+    }
+    __syncthreads();
+    const float nrm = s_nrm;
+    for (int64_t c = threadIdx.x; c < dim; c += 1024) p[c] = p[c] / nrm;
+}
+
+static void normalize_rows(float* w, int64_t rows, int64_t dim, hipStream_t s) {
+    if (dim >= 2048)
+        hipLaunchKernelGGL(k_row_normalize_wide, dim3((unsigned)rows), dim3(1024), 0, s, w, rows, dim);
+    else
+        hipLaunchKernelGGL(k_row_normalize, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, w, rows, dim);
+}
+
 int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k, hipStream_t s) {
-    hipLaunchKernelGGL(k_row_normalize, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, s, ent, E, (int64_t)k);
-    hipLaunchKernelGGL(k_row_normalize, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, rel, R, (int64_t)k * k);
+    normalize_rows(ent, E, (int64_t)k, s);
+    normalize_rows(rel, R, (int64_t)k * k, s);
     return check_launch("k_row_normalize");
 }
 
