@@ -115,7 +115,9 @@ int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, cons
  * sum / square_avg in state1 (Adagrad / RMSprop).  step is 1-based.  zero_grad != 0 also clears grad
  * (optimizer.zero_grad(), utils/trainer.py:272) in the same pass. */
 int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, float* state2,
-                       int64_t numel, float lr, int64_t step, int32_t zero_grad, void* stream);
+                       int64_t numel, float lr, int64_t step, int32_t zero_grad,
+                       const float* dev_hyper /* NULL, or device {lr, step_size, bc2_sqrt} from kge_step_advance */,
+                       void* stream);
 
 /* NTN.get_reg (pairwise.py:962-963): loss += lmbda * sqrt(sum_i param[i]^2), grad += lmbda * param / that root, over
  * ONE flat buffer holding every table of the model (pad with zeros).  scratch: 1 float. */
@@ -168,7 +170,17 @@ int kge_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t
 int kge_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start, int64_t n_pos, int32_t neg_rate,
                      int64_t tot_entity, const float* bern_prob, const uint64_t* slots, int64_t n_slots,
                      uint64_t seed, uint64_t offset, int32_t layout,
-                     int64_t* o0, int64_t* o1, int64_t* o2, int64_t* o3, int64_t* o4, int64_t* o5, void* stream);
+                     int64_t* o0, int64_t* o1, int64_t* o2, int64_t* o3, int64_t* o4, int64_t* o5,
+                     const int64_t* dev_cursor /* NULL, or device {start, draw offset}: added to start / offset */,
+                     void* stream);
+
+/* Device-resident step state so that a whole training step (advance -> sample -> fused step -> optimiser) is a static
+ * launch sequence that can be captured once in a hipGraph and replayed (the launch-bound small-batch regime, default
+ * B=128 of the reference).  cursor: int64[8] = {start, draw_offset, opt_step, batch_idx, draws, ...} zero-initialised by
+ * the caller; hyper: float[4].  Each call moves to the next batch of the epoch (wrapping at n_batches, like
+ * raw_data_generator data/generator.py:28-35), advances the Philox offset and the optimiser step (Adam bias terms). */
+int kge_step_advance(int64_t* dev_cursor, float* dev_hyper, int64_t batch_stride, int64_t n_batches,
+                     int64_t draws_per_batch, float lr, void* stream);
 
 #ifdef __cplusplus
 }

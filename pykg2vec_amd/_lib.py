@@ -49,14 +49,15 @@ _SIGNATURES = {
     "kge_train_pairwise_selfadv": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_train_pointwise_logistic": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_float, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_l2norm_reg": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "kge_optimizer_step": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_float, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
+    "kge_optimizer_step": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_float, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_step_advance": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]),
     "kge_eval_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc), ctypes.c_int64]),
     "kge_eval_ranks": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_eval_sweep_scores": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_rank_from_scores": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64] + [ctypes.c_void_p] * 5 + [ctypes.c_void_p]),
     "kge_triple_set_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "kge_corrupt": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64] + [ctypes.c_void_p] * 3 + [ctypes.c_void_p]),
-    "kge_sample_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32] + [ctypes.c_void_p] * 6 + [ctypes.c_void_p]),
+    "kge_sample_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32] + [ctypes.c_void_p] * 6 + [ctypes.c_void_p, ctypes.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

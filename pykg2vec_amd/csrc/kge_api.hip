@@ -183,10 +183,11 @@ int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, cons
 }
 
 int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,
-                       int64_t step, int32_t zero_grad, void* stream) {
-    if (!param || !grad || numel < 0 || step < 1) { set_error("kge_optimizer_step: bad arguments"); return -1; }
+                       int64_t step, int32_t zero_grad, const float* dev_hyper, void* stream) {
+    if (!param || !grad || numel < 0 || (step < 1 && !dev_hyper)) { set_error("kge_optimizer_step: bad arguments"); return -1; }
     if (numel == 0) return 0;
-    return launch_optimizer(kind, param, grad, state1, state2, numel, lr, step, zero_grad, (hipStream_t)stream);
+    return launch_optimizer(kind, param, grad, state1, state2, numel, lr, step < 1 ? 1 : step, zero_grad, dev_hyper,
+                            (hipStream_t)stream);
 }
 
 int kge_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, float* scratch, float* loss, void* stream) {
@@ -252,7 +253,7 @@ int kge_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t
 int kge_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start, int64_t n_pos, int32_t neg_rate,
                      int64_t tot_entity, const float* bern_prob, const uint64_t* slots, int64_t n_slots, uint64_t seed,
                      uint64_t offset, int32_t layout, int64_t* o0, int64_t* o1, int64_t* o2, int64_t* o3, int64_t* o4,
-                     int64_t* o5, void* stream) {
+                     int64_t* o5, const int64_t* dev_cursor, void* stream) {
     if (n_pos == 0) return 0;
     if (!triples || !perm || start < 0 || n_pos < 0 || neg_rate <= 0 || tot_entity <= 1 || (layout != 0 && layout != 1) ||
         !o0 || !o1 || !o2 || !o3 || (layout == 0 && (!o4 || !o5))) {
@@ -262,7 +263,16 @@ int kge_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start,
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_sample_batch: n_slots must be a power of two"); return -1; }
     int64_t* const out[6] = {o0, o1, o2, o3, o4, o5};
     return launch_sample_batch(triples, perm, start, n_pos, neg_rate, tot_entity, bern_prob, slots, n_slots, seed, offset,
-                               layout, out, (hipStream_t)stream);
+                               layout, out, dev_cursor, (hipStream_t)stream);
+}
+
+int kge_step_advance(int64_t* dev_cursor, float* dev_hyper, int64_t batch_stride, int64_t n_batches,
+                     int64_t draws_per_batch, float lr, void* stream) {
+    if (!dev_cursor || !dev_hyper || n_batches < 1 || batch_stride < 0 || draws_per_batch < 0) {
+        set_error("kge_step_advance: bad arguments");
+        return -1;
+    }
+    return launch_step_advance(dev_cursor, dev_hyper, batch_stride, n_batches, draws_per_batch, lr, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -49,7 +49,7 @@ int launch_hinge_coeffs(float* pos, float* neg, int64_t n, float margin, float* 
 
 // kge_opt.hip
 int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t numel, float lr, int64_t step,
-                     int zero_grad, hipStream_t s);
+                     int zero_grad, const float* dev_hyper, hipStream_t s);
 
 // kge_eval.hip
 size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n);
@@ -70,7 +70,9 @@ int launch_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int6
 
 int launch_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start, int64_t n_pos, int neg_rate,
                         int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed,
-                        uint64_t offset, int layout, int64_t* const out[6], hipStream_t s);
+                        uint64_t offset, int layout, int64_t* const out[6], const int64_t* cursor, hipStream_t s);
+int launch_step_advance(int64_t* cursor, float* hyper, int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch,
+                        float lr, hipStream_t s);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -32,7 +32,9 @@ __device__ __forceinline__ void opt_update(float& p, float g, float& s1, float& 
 
 template <int KIND, bool ZERO>
 __global__ __launch_bounds__(256) void k_opt(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
-                                             float* __restrict__ s2, int64_t numel, OptArgs a) {
+                                             float* __restrict__ s2, int64_t numel, OptArgs a,
+                                             const float* __restrict__ dev_hyper) {
+    if (dev_hyper) { a.lr = dev_hyper[0]; a.step_size = dev_hyper[1]; a.bc2_sqrt = dev_hyper[2]; }  // hipGraph replays
     const int64_t nvec = numel / 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -66,19 +68,20 @@ __global__ __launch_bounds__(256) void k_opt(float* __restrict__ p, float* __res
 }
 
 template <int KIND>
-static int launch_kind(float* p, float* g, float* s1, float* s2, int64_t numel, OptArgs a, int zero, hipStream_t s) {
+static int launch_kind(float* p, float* g, float* s1, float* s2, int64_t numel, OptArgs a, int zero, const float* dh,
+                       hipStream_t s) {
     int64_t blocks = (numel / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (zero)
-        hipLaunchKernelGGL((k_opt<KIND, true>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a);
+        hipLaunchKernelGGL((k_opt<KIND, true>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh);
     else
-        hipLaunchKernelGGL((k_opt<KIND, false>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a);
+        hipLaunchKernelGGL((k_opt<KIND, false>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh);
     return check_launch("k_opt");
 }
 
 int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t numel, float lr, int64_t step,
-                     int zero_grad, hipStream_t s) {
+                     int zero_grad, const float* dev_hyper, hipStream_t s) {
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)s1 | (uintptr_t)s2) & 15) {
         set_error("kge_optimizer_step: buffers must be 16-byte aligned");
         return -1;
@@ -91,16 +94,16 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
     a.step_size = (float)((double)lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
     switch (kind) {
-        case KGE_OPT_SGD: return launch_kind<KGE_OPT_SGD>(p, g, s1, s2, numel, a, zero_grad, s);
+        case KGE_OPT_SGD: return launch_kind<KGE_OPT_SGD>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, s);
         case KGE_OPT_ADAM:
             if (!s1 || !s2) { set_error("adam needs two state buffers"); return -1; }
-            return launch_kind<KGE_OPT_ADAM>(p, g, s1, s2, numel, a, zero_grad, s);
+            return launch_kind<KGE_OPT_ADAM>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, s);
         case KGE_OPT_ADAGRAD:
             if (!s1) { set_error("adagrad needs a state buffer"); return -1; }
-            return launch_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, numel, a, zero_grad, s);
+            return launch_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, s);
         case KGE_OPT_RMSPROP:
             if (!s1) { set_error("rmsprop needs a state buffer"); return -1; }
-            return launch_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, numel, a, zero_grad, s);
+            return launch_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, s);
     }
     set_error("kge_optimizer_step: unknown optimizer %d", kind);
     return -1;

@@ -106,6 +106,7 @@ struct SampleArgs {
     unsigned long long seed, offset;
     int layout;                                                    // 0 pairwise: (oph,opr,opt) + (nh,nr,nt); 1 pointwise rows
     int64_t *o0, *o1, *o2, *o3, *o4, *o5;
+    const int64_t* cursor;                                         // optional device {start, offset}: hipGraph replays
 };
 
 __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
@@ -113,15 +114,17 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     if (j >= a.n_pos * a.neg_rate) return;
     const int64_t i = j / a.neg_rate;
     const int k = (int)(j - i * a.neg_rate);
+    const int64_t start = a.cursor ? a.start + a.cursor[0] : a.start;
+    const unsigned long long offset = a.cursor ? a.offset + (unsigned long long)a.cursor[1] : a.offset;
     int64_t h, r, t;
     if (a.perm) {
-        const int64_t row = a.perm[a.start + i];
+        const int64_t row = a.perm[start + i];
         h = a.triples[3 * row]; r = a.triples[3 * row + 1]; t = a.triples[3 * row + 2];
     } else {
         h = a.ph[i]; r = a.pr[i]; t = a.pt[i];
     }
     int64_t oh, ot;
-    corrupt_one(h, r, t, a.E, a.bern, a.slots, a.mask, a.seed, a.offset + (unsigned long long)j, oh, ot);
+    corrupt_one(h, r, t, a.E, a.bern, a.slots, a.mask, a.seed, offset + (unsigned long long)j, oh, ot);
     if (a.layout == 0) {
         if (k == 0 && a.o0) { a.o0[i] = h; a.o1[i] = r; a.o2[i] = t; }
         a.o3[j] = oh; a.o4[j] = r; a.o5[j] = ot;
@@ -160,13 +163,37 @@ int launch_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int6
 
 int launch_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start, int64_t n_pos, int neg_rate,
                         int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed,
-                        uint64_t offset, int layout, int64_t* const out[6], hipStream_t s) {
+                        uint64_t offset, int layout, int64_t* const out[6], const int64_t* cursor, hipStream_t s) {
     SampleArgs a{};
+    a.cursor = cursor;
     a.triples = triples; a.perm = perm; a.start = start; a.n_pos = n_pos; a.neg_rate = neg_rate; a.E = E; a.bern = bern;
     a.slots = (const unsigned long long*)slots; a.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
     a.seed = seed; a.offset = offset; a.layout = layout;
     a.o0 = out[0]; a.o1 = out[1]; a.o2 = out[2]; a.o3 = out[3]; a.o4 = out[4]; a.o5 = out[5];
     return launch_sample(a, s);
+}
+
+// ---- device-resident step state for hipGraph replays: cursor = {start, draws, opt_step, batch_idx}, hyper = {lr,
+// step_size, bc2_sqrt}.  One thread; runs first in the captured step.
+__global__ void k_step_advance(int64_t* cursor, float* hyper, int64_t batch_stride, int64_t n_batches,
+                               int64_t draws_per_batch, float lr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t b = cursor[3];               // batch index of THIS step
+    cursor[0] = b * batch_stride;              // start of the batch in the permutation
+    cursor[1] = cursor[4];                     // Philox counter offset of this step
+    cursor[4] += draws_per_batch;
+    cursor[3] = (b + 1) % n_batches;
+    const int64_t t = ++cursor[2];             // optimiser step, 1-based
+    const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+    hyper[0] = lr;
+    hyper[1] = (float)((double)lr / bc1);
+    hyper[2] = (float)sqrt(bc2);
+}
+
+int launch_step_advance(int64_t* cursor, float* hyper, int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch,
+                        float lr, hipStream_t s) {
+    hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, s, cursor, hyper, batch_stride, n_batches, draws_per_batch, lr);
+    return check_launch("k_step_advance");
 }
 
 }  // namespace kge

@@ -147,12 +147,20 @@ def l2norm_reg(param, grad, lmbda, loss_buf):
                                     _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_l2norm_reg")
 
 
-def optimizer_step(kind, param, grad, state1, state2, lr, step, zero_grad=True):
+def optimizer_step(kind, param, grad, state1, state2, lr, step, zero_grad=True, dev_hyper=None):
     p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
     p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
+    ph = _dev(dev_hyper, torch.float32, "dev_hyper") if dev_hyper is not None else None
     L.check(L.load().kge_optimizer_step(OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"),
                                         _dev(grad, torch.float32, "grad"), p1, p2, param.numel(), float(lr), int(step),
-                                        1 if zero_grad else 0, _stream()), "kge_optimizer_step")
+                                        1 if zero_grad else 0, ph, _stream()), "kge_optimizer_step")
+
+
+def step_advance(cursor, hyper, batch_stride, n_batches, draws_per_batch, lr):
+    """Advance the device-resident step state (int64[8] cursor, float32[4] hyper); first kernel of a captured step."""
+    L.check(L.load().kge_step_advance(_dev(cursor, torch.int64, "cursor"), _dev(hyper, torch.float32, "hyper"),
+                                      int(batch_stride), int(n_batches), int(draws_per_batch), float(lr), _stream()),
+            "kge_step_advance")
 
 
 def eval_workspace(desc, n, device):
@@ -256,25 +264,34 @@ def corrupt(ph, pr, pt, neg_rate, tot_entity, bern_prob, slots, seed, offset):
     return nh, nr, nt
 
 
-def sample_batch(triples, perm, start, n_pos, neg_rate, tot_entity, bern_prob, slots, seed, offset, pointwise=False):
+def sample_buffer(n_pos, neg_rate, pointwise, device):
+    rows = 4 * n_pos * (1 + neg_rate) if pointwise else 3 * n_pos * (1 + neg_rate)
+    return torch.empty(rows, dtype=torch.int64, device=device)
+
+
+def sample_batch(triples, perm, start, n_pos, neg_rate, tot_entity, bern_prob, slots, seed, offset, pointwise=False,
+                 out=None, cursor=None):
     """One launch: positives triples[perm[start:start+n_pos]] + their corrupted negatives, in the reference's batch
-    layout (pairwise: [ph, pr, pt, nh, nr, nt]; pointwise: [h, r, t, y])."""
+    layout (pairwise: [ph, pr, pt, nh, nr, nt]; pointwise: [h, r, t, y]).  `out`: optional preallocated
+    sample_buffer (static addresses for hipGraph capture); `cursor`: optional device {start, offset} added to the
+    host arguments."""
     dev = triples.device
     bp = _dev(bern_prob, torch.float32, "bern_prob") if bern_prob is not None else None
     sp = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
+    pc = _dev(cursor, torch.int64, "cursor") if cursor is not None else None
     if pointwise:
         rows = n_pos * (1 + neg_rate)
-        buf = torch.empty((4, rows), dtype=torch.int64, device=dev)
+        buf = (out if out is not None else torch.empty(4 * rows, dtype=torch.int64, device=dev)).view(4, rows)
         outs = [buf[0], buf[1], buf[2], buf[3]]
         ptrs = [ctypes.c_void_p(o.data_ptr()) for o in outs] + [None, None]
     else:
         nneg = n_pos * neg_rate
-        buf = torch.empty(3 * n_pos + 3 * nneg, dtype=torch.int64, device=dev)
+        buf = out if out is not None else torch.empty(3 * n_pos + 3 * nneg, dtype=torch.int64, device=dev)
         outs = [buf[0:n_pos], buf[n_pos:2 * n_pos], buf[2 * n_pos:3 * n_pos], buf[3 * n_pos:3 * n_pos + nneg],
                 buf[3 * n_pos + nneg:3 * n_pos + 2 * nneg], buf[3 * n_pos + 2 * nneg:]]
         ptrs = [ctypes.c_void_p(o.data_ptr()) for o in outs]
     L.check(L.load().kge_sample_batch(_ids(triples, "triples"), _ids(perm, "perm"), int(start), int(n_pos), int(neg_rate),
                                       int(tot_entity), bp, sp, slots.numel() if slots is not None else 0,
                                       int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), 1 if pointwise else 0,
-                                      *ptrs, _stream()), "kge_sample_batch")
+                                      *ptrs, pc, _stream()), "kge_sample_batch")
     return outs

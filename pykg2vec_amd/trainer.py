@@ -48,9 +48,10 @@ class FlatState:
         self.state2 = torch.zeros_like(self.param) if optimizer == "adam" else None
         self.step = 0
 
-    def optimizer_step(self, lr):
+    def optimizer_step(self, lr, dev_hyper=None):
         self.step += 1
-        self.K.optimizer_step(self.optimizer, self.param, self.grad, self.state1, self.state2, lr, self.step, zero_grad=True)
+        self.K.optimizer_step(self.optimizer, self.param, self.grad, self.state1, self.state2, lr, self.step,
+                              zero_grad=True, dev_hyper=dev_hyper)
 
 
 class EarlyStopper:
@@ -77,7 +78,9 @@ class EarlyStopper:
 
 
 class Trainer:
-    def __init__(self, model, config, process_group=None, backend=None):
+    GRAPH_MAX_ROWS = 16384  # steps scoring at most this many triples are launch-bound: replay them as one hipGraph
+
+    def __init__(self, model, config, process_group=None, backend=None, use_graph=None):
         # `backend` exists so that the multi-process plumbing (batch sharding, gradient all-reduce, replica
         # consistency) can be exercised on CPU/gloo with a checker injected by tests; the product default -- and the
         # only backend this package contains -- is the HIP library, which raises without a GPU.
@@ -91,6 +94,8 @@ class Trainer:
         self.early_stopper = None
         self.monitor = None
         self.process_group = process_group
+        self.use_graph = use_graph
+        self._graph = None
         self.world_size = 1
         self.rank = 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -160,20 +165,70 @@ class Trainer:
         self._accumulate_pointwise(h, r, t, target)
         return self.K.read_loss(self.loss_buf)
 
+    # ------------------------------------------------------------------ hipGraph replay of the whole step
+    def _graph_wanted(self):
+        if self.use_graph is not None:
+            return bool(self.use_graph) and self.world_size == 1 and self.K is K
+        rows = self.config.batch_size * (1 + self.config.neg_rate)
+        return self.world_size == 1 and self.K is K and rows <= self.GRAPH_MAX_ROWS
+
+    def _capture_step(self, num_batch):
+        """Capture advance -> sample -> fused step -> optimiser ONCE; per-step values that change (batch position,
+        Philox offset, Adam bias terms) live in device memory (kge_step_advance), so replays need no host arguments."""
+        gen, cfg = self.generator, self.config
+        dev = self.flat.param.device
+        pointwise = self.model.training_strategy != TrainingStrategy.PAIRWISE_BASED
+        B = int(cfg.batch_size)
+        self._cursor = torch.zeros(8, dtype=torch.int64, device=dev)
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._cursor[2] = self.flat.step
+        self._cursor[4] = gen._draws
+        self._sbuf = K.sample_buffer(B, gen.neg_rate, pointwise, dev)
+        self._graph_batches = num_batch
+
+        def body():
+            K.step_advance(self._cursor, self._hyper, B, num_batch, B * gen.neg_rate, cfg.learning_rate)
+            batch = K.sample_batch(gen.triples, gen.perm, 0, B, gen.neg_rate, cfg.tot_entity, gen.bern, gen.slots,
+                                   gen.seed, 0, pointwise=pointwise, out=self._sbuf, cursor=self._cursor)
+            if pointwise:
+                self._accumulate_pointwise(*batch)
+            else:
+                self._accumulate_pairwise(*batch)
+            self.flat.optimizer_step(cfg.learning_rate, dev_hyper=self._hyper)
+
+        body()  # the epoch's FIRST step runs eagerly (loads kernels, sizes workspaces) ...
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):  # ... then the same launch sequence is captured (capture does not execute)
+            body()
+        self._graph = graph
+        return 1  # steps already executed
+
     # ------------------------------------------------------------------ epochs
     def train_model_epoch(self, epoch_idx, tuning=False):
         num_batch = self.config.tot_train_triples // self.config.batch_size if not self.config.debug else 10
         self.generator.start_one_epoch(num_batch)
         self.model.train()
-        self.loss_buf.zero_()
         pairwise = self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED
-        for _ in range(num_batch):
-            data = next(self.generator)
-            if pairwise:
-                self._accumulate_pairwise(*data)
+        if self._graph_wanted() and num_batch > 0:
+            self.loss_buf.zero_()
+            done = 0
+            if self._graph is None or self._graph_batches != num_batch:
+                done = self._capture_step(num_batch)
             else:
-                self._accumulate_pointwise(*data)
-            self._reduce_and_step()
+                self._cursor[3] = 0  # every epoch walks the permutation from its start (data/generator.py:28-35)
+            for _ in range(num_batch - done):
+                self._graph.replay()
+            self.generator._pending = 0
+        else:
+            self.loss_buf.zero_()
+            for _ in range(num_batch):
+                data = next(self.generator)
+                if pairwise:
+                    self._accumulate_pairwise(*data)
+                else:
+                    self._accumulate_pointwise(*data)
+                self._reduce_and_step()
         acc = self.K.read_loss(self.loss_buf)
         if self.world_size > 1:
             torch.distributed.all_reduce(acc, group=self.process_group)

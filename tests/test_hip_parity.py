@@ -242,3 +242,25 @@ def test_sampler_invariants_and_determinism(hip):
     nh3, _, nt3 = K.corrupt(ph, pr, pt, 4, c.E, bern, slots, seed=7, offset=0)
     frac_t = float((nh3.view(-1, 4) == ph.view(-1, 1)).float().mean())
     assert 0.05 < frac_t < 0.2, frac_t
+
+
+@pytest.mark.parametrize("name,opt", [("transe_l1", "adam"), ("distmult", "adagrad"), ("rotate", "adam"), ("rescal", "sgd")])
+def test_graph_replayed_epochs_equal_eager_epochs(hip, name, opt):
+    """hipGraph capture/replay of the whole step (device-resident batch cursor, Philox offset, Adam bias terms) must
+    reproduce the eager loop: same batches, same negatives, same weights."""
+    from pykg2vec_amd.trainer import Trainer
+    c = Case(name)
+    out = []
+    for use_graph in (False, True):
+        cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer=opt, lr=0.02, batch_size=48)
+        m = hip.model_from_case(c)
+        tr = Trainer(m, cfg, use_graph=use_graph)
+        tr.build_model()
+        tr.generator = tr._new_generator()
+        losses = [tr.train_model_epoch(e) for e in range(3)]
+        assert (tr._graph is not None) == use_graph
+        out.append((losses, {k: p.detach().cpu().numpy() for k, p in m.named_parameters()}))
+    (l0, p0), (l1, p1) = out
+    assert np.allclose(l0, l1, rtol=2e-4), (l0, l1)
+    for k in p0:  # float atomics make the two runs differ in summation order only
+        assert np.allclose(p0[k], p1[k], atol=2e-4, rtol=1e-3), (k, np.abs(p0[k] - p1[k]).max())

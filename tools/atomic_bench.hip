@@ -25,7 +25,9 @@ __global__ __launch_bounds__(256) void k_scatter(float* __restrict__ g, const in
 #pragma unroll 4
         for (int e = gl; e < d; e += G) {
             if (MODE == 0) unsafeAtomicAdd(row + e, 1.0f);
-            else __hip_atomic_fetch_add(row + e, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (MODE == 1) __hip_atomic_fetch_add(row + e, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (MODE == 2) { if (e * 2 < d) atomicAdd((unsigned long long*)row + e, 0x0000000100000001ull); }  // 2 x int32 per op
+            else { if (e * 2 < d) unsafeAtomicAdd((double*)row + e, 1.0); }
         }
     }
 }
@@ -42,12 +44,14 @@ int main() {
         float* g; CK(hipMalloc(&g, numel * 8 * sizeof(float)));
         int* hist; CK(hipMalloc(&hist, 64)); CK(hipMemset(hist, 0, 64));
         hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-        for (int mode = 0; mode < 2; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             CK(hipMemset(g, 0, numel * 8 * sizeof(float)));
             int grid = 2048;
             for (int it = 0; it < 3; ++it) {
                 if (mode == 0) k_scatter<0><<<grid, 256>>>(g, rows, n, d, numel, it == 0 ? hist : nullptr);
-                else k_scatter<1><<<grid, 256>>>(g, rows, n, d, numel, nullptr);
+                else if (mode == 1) k_scatter<1><<<grid, 256>>>(g, rows, n, d, numel, nullptr);
+                else if (mode == 2) k_scatter<2><<<grid, 256>>>(g, rows, n, d, numel, nullptr);
+                else k_scatter<3><<<grid, 256>>>(g, rows, n, d, numel, nullptr);
             }
             CK(hipDeviceSynchronize());
             CK(hipMemset(g, 0, numel * 8 * sizeof(float)));
@@ -55,7 +59,9 @@ int main() {
             const int iters = 20;
             for (int it = 0; it < iters; ++it) {
                 if (mode == 0) k_scatter<0><<<grid, 256>>>(g, rows, n, d, numel, nullptr);
-                else k_scatter<1><<<grid, 256>>>(g, rows, n, d, numel, nullptr);
+                else if (mode == 1) k_scatter<1><<<grid, 256>>>(g, rows, n, d, numel, nullptr);
+                else if (mode == 2) k_scatter<2><<<grid, 256>>>(g, rows, n, d, numel, nullptr);
+                else k_scatter<3><<<grid, 256>>>(g, rows, n, d, numel, nullptr);
             }
             CK(hipEventRecord(b)); CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -63,7 +69,7 @@ int main() {
             CK(hipMemcpy(out.data(), g, numel * 8 * sizeof(float), hipMemcpyDeviceToHost));
             double tot = 0; for (float v : out) tot += v;
             printf("n=%d mode=%s: %.1f us/launch, %.2f TB/s payload, sum=%.0f expected=%.0f\n", n,
-                   mode == 0 ? "agent(sc1)" : "xcd-local ", ms / iters * 1e3, (double)n * d * 4 / (ms / iters * 1e-3) / 1e12, tot,
+                   mode == 0 ? "f32 agent " : mode == 1 ? "f32 wg    " : mode == 2 ? "u64 2xi32 " : "f64       ", ms / iters * 1e3, (double)n * d * 4 / (ms / iters * 1e-3) / 1e12, tot,
                    (double)n * d * iters);
         }
         int hh[16]; CK(hipMemcpy(hh, hist, 64, hipMemcpyDeviceToHost));
