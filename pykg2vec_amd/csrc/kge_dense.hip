@@ -155,11 +155,16 @@ __global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, c
         if (u < ntile) {  // ---- U[i][a] = sum_b T[i][b] M[a][b]
             const int a = u * 32 + li;
             f32x16 acc = {0};
-            for (int kk = 0; kk < k; kk += 2) {
-                const int b = kk + lk;
-                const float av = b < k ? sT[li * S + b] : 0.f;
-                const float bv = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            for (int k0 = 0; k0 < k; k0 += 16) {  // fixed-trip inner loop: 8 operand loads in flight
+                float av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = k0 + 2 * u + lk;
+                    av[u] = b < k ? sT[li * S + b] : 0.f;
+                    bv[u] = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
             }
             if (a < k) {
 #pragma unroll
@@ -175,11 +180,16 @@ __global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, c
         } else if (u < 2 * ntile) {  // ---- V[i][b] = sum_a H[i][a] M[a][b] ;  grad_t = -ds V
             const int b = (u - ntile) * 32 + li;
             f32x16 acc = {0};
-            for (int kk = 0; kk < k; kk += 2) {
-                const int a = kk + lk;
-                const float av = a < k ? sH[li * S + a] : 0.f;
-                const float bv = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            for (int k0 = 0; k0 < k; k0 += 16) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int a = k0 + 2 * u + lk;
+                    av[u] = a < k ? sH[li * S + a] : 0.f;
+                    bv[u] = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
             }
             if (b < k) {
 #pragma unroll

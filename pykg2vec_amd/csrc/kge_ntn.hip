@@ -89,11 +89,16 @@ __global__ __launch_bounds__(256) void k_ntn_bil(const float* __restrict__ W, in
         for (int j0 = 0; j0 < d; j0 += 32) {
             const int j = j0 + li;
             f32x16 acc = {0};
-            for (int kk = 0; kk < d; kk += 2) {
-                const int i2 = kk + lk;
-                const float av = i2 < d ? sH[li * S + i2] : 0.f;
-                const float bv = (i2 < d && j < d) ? Ws[(int64_t)i2 * d + j] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            for (int k0 = 0; k0 < d; k0 += 16) {  // fixed-trip inner loop: 8 operand loads in flight per MFMA chain
+                float av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i2 = k0 + 2 * u + lk;
+                    av[u] = i2 < d ? sH[li * S + i2] : 0.f;
+                    bv[u] = (i2 < d && j < d) ? Ws[(int64_t)i2 * d + j] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
             }
             if (j < d) {
 #pragma unroll
@@ -127,7 +132,17 @@ __global__ __launch_bounds__(256) void k_ntn_finish(const float* __restrict__ M1
     float tot = 0.f;
     for (int s = lane; s < kr; s += 64) {
         float lin = b[s];
-        for (int c = 0; c < d; ++c) lin = fmaf(hn[c], M1[(int64_t)c * kr + s], fmaf(tn[c], M2[(int64_t)c * kr + s], lin));
+        for (int c0 = 0; c0 < d; c0 += 8) {
+            float m1[8], m2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u < d ? c0 + u : d - 1;
+                m1[u] = M1[(int64_t)c * kr + s]; m2[u] = M2[(int64_t)c * kr + s];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < d) lin = fmaf(hn[c0 + u], m1[u], fmaf(tn[c0 + u], m2[u], lin));
+        }
         const float z = tanhf(w.Z[i * kr + s] + lin);
         w.Z[i * kr + s] = z;
         tot = fmaf(w.Rn[i * kr + s], z, tot);
@@ -169,6 +184,7 @@ __global__ __launch_bounds__(256) void k_ntn_gz(const float* __restrict__ M1, co
     if (i < n) {
         for (int c = lane; c < d; c += 64) {
             float a = 0.f, bsum = 0.f;
+#pragma unroll 8
             for (int s = 0; s < kr; ++s) {
                 a = fmaf(sgz[s], M1[(int64_t)c * kr + s], a);
                 bsum = fmaf(sgz[s], M2[(int64_t)c * kr + s], bsum);
@@ -187,10 +203,12 @@ __global__ __launch_bounds__(256) void k_ntn_small(float* __restrict__ gM1, floa
     const int c = (int)(idx / kr), s = (int)(idx - (int64_t)c * kr);
     if (c == d) {
         float a = 0.f;
+#pragma unroll 8
         for (int64_t i = 0; i < n; ++i) a += w.GZ[i * kr + s];
         gb[s] += a;
     } else {
         float a = 0.f, b2 = 0.f;
+#pragma unroll 8
         for (int64_t i = 0; i < n; ++i) {
             const float gz = w.GZ[i * kr + s];
             a = fmaf(w.Hn[i * d + c], gz, a);
@@ -234,15 +252,22 @@ __global__ __launch_bounds__(256) void k_ntn_bil_bwd(const float* __restrict__ W
         for (int a = 0; a < JT; ++a) {
             const int col = a * 32 + li;
             f32x16 accx = {0}, accy = {0};
-            for (int kk = 0; kk < d; kk += 2) {
-                const int c = kk + lk;
-                const bool ok = c < d && col < d;
-                const float ah = c < d ? sH[li * S + c] : 0.f;
-                const float at = c < d ? sT[li * S + c] : 0.f;
-                const float bx = ok ? Ws[(int64_t)c * d + col] : 0.f;     // X = H^ W_s    : B[k=c][j=col] = W[c][col]
-                const float by = ok ? Ws[(int64_t)col * d + c] : 0.f;     // Y = T^ W_s^T  : B[k=c][j=col] = W[col][c]
-                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, bx, accx, 0, 0, 0);
-                accy = __builtin_amdgcn_mfma_f32_32x32x2f32(at, by, accy, 0, 0, 0);
+            for (int k0 = 0; k0 < d; k0 += 8) {
+                float ah[4], at[4], bx[4], by[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = k0 + 2 * u + lk;
+                    const bool ok = c < d && col < d;
+                    ah[u] = c < d ? sH[li * S + c] : 0.f;
+                    at[u] = c < d ? sT[li * S + c] : 0.f;
+                    bx[u] = ok ? Ws[(int64_t)c * d + col] : 0.f;     // X = H^ W_s    : B[k=c][j=col] = W[c][col]
+                    by[u] = ok ? Ws[(int64_t)col * d + c] : 0.f;     // Y = T^ W_s^T  : B[k=c][j=col] = W[col][c]
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ah[u], bx[u], accx, 0, 0, 0);
+                    accy = __builtin_amdgcn_mfma_f32_32x32x2f32(at[u], by[u], accy, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -277,12 +302,17 @@ __global__ __launch_bounds__(256) void k_ntn_gw(float* __restrict__ gW, int64_t 
     const int i0 = (tile / jt) * 32, j0 = (tile % jt) * 32;
     const int ia = i0 + li, jb = j0 + li;
     f32x16 acc = {0};
-    for (int64_t kk = 0; kk < n; kk += 2) {
-        const int64_t row = kk + lk;
-        const bool ok = row < n;
-        const float av = (ok && ia < d) ? w.GZ[row * kr + s] * w.Hn[row * d + ia] : 0.f;
-        const float bv = (ok && jb < d) ? w.Tn[row * d + jb] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    for (int64_t k0 = 0; k0 < n; k0 += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t row = k0 + 2 * u + lk;
+            const bool ok = row < n;
+            av[u] = (ok && ia < d) ? w.GZ[row * kr + s] * w.Hn[row * d + ia] : 0.f;
+            bv[u] = (ok && jb < d) ? w.Tn[row * d + jb] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
     }
     if (jb < d) {
         float* g = gW + (int64_t)s * d * d;
@@ -397,7 +427,8 @@ int launch_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbd
     if (e != hipSuccess) { set_error("kge_l2norm_reg: memset: %s", hipGetErrorString(e)); return -2; }
     int64_t b = (numel + 255) / 256;
     if (b > 2048) b = 2048;
-    hipLaunchKernelGGL(k_sumsq, dim3((unsigned)b), dim3(256), 0, s, param, numel, scratch);
+    const int64_t br = b > 128 ? 128 : b;  // one same-address atomic per block costs ~12 ns each: keep them few
+    hipLaunchKernelGGL(k_sumsq, dim3((unsigned)br), dim3(256), 0, s, param, numel, scratch);
     hipLaunchKernelGGL(k_l2_apply, dim3((unsigned)b), dim3(256), 0, s, param, grad, numel, lmbda, scratch, loss);
     return check_launch("kge_l2norm_reg");
 }
