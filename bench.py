@@ -6,8 +6,9 @@ A *step* is one pass of the training hot path over one batch that is already res
 negative corruption (kge_corrupt) -> fused score(+)/score(-)/hinge/backward kernel (kge_train_pairwise_hinge)
 -> [N>1: RCCL all-reduce of the flat dense gradient buffer] -> fused dense Adam sweep (kge_optimizer_step).
 Nothing is skipped or cached inside the timed region.  After the timed training steps the same process times
-the filtered-rank evaluation sweep (kge_eval_ranks) and, on rank 0 at N=1, the CPU baseline (the numpy oracle --
-a *port* of the reference algorithm, oracle/kge_oracle.py -- on a bounded sample of the same workload).
+the filtered-rank evaluation sweep (kge_eval_ranks) and, on rank 0 at N=1, the CPU baseline (a multi-threaded C
+*port* of the reference algorithm, oracle/kge_oracle_c.c, pinned to the numpy oracle and the reference's golden
+vectors -- on a bounded sample of the same workload, all host cores).
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]      (N>1: via torch.distributed.run, one rank per GPU)
 Prints ONE JSON line on rank 0.
@@ -76,39 +77,46 @@ def build_filters(all_triples, queries):
     return hr_t, tr_h
 
 
-def cpu_baseline_train(train, budget_s=12.0, batch=4096):
-    """numpy oracle (port of utils/trainer.py:147-157,298-299 + criterion.py:25-29 + dense Adam), 1 thread."""
+def cpu_baseline_train(train, budget_s=12.0, batch=32768):
+    """C/OpenMP restatement of one reference train step (utils/trainer.py:147-157,298-299 + criterion.py:25-29 + dense
+    Adam) on all host cores -- oracle/kge_oracle_c.c, a *port* held to the numpy oracle by tests/test_oracle_c.py."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import kge_oracle as ko
+    import kge_oracle_c as kc
     rng = np.random.default_rng(0)
     P = ko.init_params("transe", rng, tot_entity=E, tot_relation=R, hidden_size=DIM)
-    st = ko.optimizer_init("adam", P)
-    pos = train[:batch]
-    neg = pos.copy()
-    flip = rng.random(batch) > 0.5
-    rnd = rng.integers(E, size=batch)
-    neg[:, 2] = np.where(flip, rnd, neg[:, 2])
-    neg[:, 0] = np.where(flip, neg[:, 0], rnd)
-    b = (pos[:, 0], pos[:, 1], pos[:, 2], neg[:, 0], neg[:, 1], neg[:, 2])
-    for _ in range(2):  # warm
-        _, G, _, _ = ko.train_step_grads("transe", P, b, l1_flag=True, margin=1.0)
-        ko.optimizer_step("adam", P, G, st, 0.01)
+    st = kc.TransEAdam(P["ent_embeddings"], P["rel_embeddings"], True, 1.0, 0.01)
+    batches = []
+    for k in range(N_TRAIN // batch):  # one epoch of distinct batches, like the GPU leg walks the permutation
+        pos = train[k * batch:(k + 1) * batch]
+        neg = pos.copy()
+        flip = rng.random(batch) > 0.5
+        rnd = rng.integers(E, size=batch)
+        neg[:, 2] = np.where(flip, rnd, neg[:, 2])
+        neg[:, 0] = np.where(flip, neg[:, 0], rnd)
+        batches.append([np.ascontiguousarray(a) for a in (pos[:, 0], pos[:, 1], pos[:, 2], neg[:, 0], neg[:, 1], neg[:, 2])])
+    st.train_step(*batches[0])  # warm
     t0, n = time.perf_counter(), 0
     while time.perf_counter() - t0 < budget_s:
-        _, G, _, _ = ko.train_step_grads("transe", P, b, l1_flag=True, margin=1.0)
-        ko.optimizer_step("adam", P, G, st, 0.01)
+        st.train_step(*batches[n % len(batches)])
         n += 1
     dt = time.perf_counter() - t0
-    return 2 * batch * n / dt, "%d Adam steps of B=%d positives + %d negatives (FB15k-shape TransE d=100 L1), numpy fp32" % (n, batch, batch)
+    return (2 * batch * n / dt, kc.threads(),
+            "%d dense-Adam steps of B=%d positives + %d negatives (FB15k-shape TransE d=100 L1), C/OpenMP fp32" % (n, batch, batch))
 
 
-def cpu_baseline_eval(P_np, test, hr_t, tr_h, budget_s=8.0):
+def cpu_baseline_eval(P_np, test, csr, budget_s=8.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import kge_oracle as ko
-    t0, n = time.perf_counter(), 0
+    import kge_oracle_c as kc
+    t_off, t_ids, h_off, h_ids = csr
+    t0, n, chunk = time.perf_counter(), 0, 4 * kc.threads()
     while time.perf_counter() - t0 < budget_s and n < len(test):
-        ko.evaluate("transe", P_np, test[n:n + 4], hr_t, tr_h, l1_flag=True)
-        n += 4
+        m = min(chunk, len(test) - n)
+        to = t_off[n:n + m + 1] - t_off[n]
+        ho = h_off[n:n + m + 1] - h_off[n]
+        kc.transe_eval(P_np["ent_embeddings"], P_np["rel_embeddings"], True, test[n:n + m], to,
+                       t_ids[t_off[n]:t_off[n + m]], ho, h_ids[h_off[n]:h_off[n + m]])
+        n += m
     return n / (time.perf_counter() - t0), n
 
 
@@ -258,15 +266,14 @@ def main():
                                           "algorithmic rate may exceed the HBM peak"}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = 1
-            v, sample = cpu_baseline_train(train)
+            v, cores, sample = cpu_baseline_train(train)
             P_np = {"ent_embeddings": model.ent_embeddings.weight.detach().cpu().numpy(),
                     "rel_embeddings": model.rel_embeddings.weight.detach().cpu().numpy()}
-            ve, ne = cpu_baseline_eval(P_np, my_test, hr_t, tr_h)
+            ve, ne = cpu_baseline_eval(P_np, my_test, build_filter_csr(my_test, hr_t, tr_h))
             out["cpu_baseline"] = {"value": v, "unit": "scored triples/s", "cores": cores, "kind": "port",
                                    "sample": sample,
                                    "eval": {"value": ve, "unit": "test triples ranked/s",
-                                            "sample": "%d test triples, two full-entity sweeps each, numpy fp32" % ne}}
+                                            "sample": "%d test triples, two full-entity sweeps each, C/OpenMP fp32" % ne}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
