@@ -67,7 +67,7 @@ def train_pointwise_logistic(desc, h, r, t, y, lmbda, reg_type, loss_buf):
     loss_buf[0] += float(loss)
 
 
-def optimizer_step(kind, param, grad, state1, state2, lr, step, zero_grad=True):
+def optimizer_step(kind, param, grad, state1, state2, lr, step, zero_grad=True, dev_hyper=None):
     P = {"p": param.numpy()}
     st = {"step": step - 1}
     if kind == "adam":
@@ -88,7 +88,8 @@ def triple_set_build(triples):
     return {tuple(map(int, x)) for x in triples.numpy()}
 
 
-def sample_batch(triples, perm, start, n_pos, neg_rate, tot_entity, bern_prob, slots, seed, offset, pointwise=False):
+def sample_batch(triples, perm, start, n_pos, neg_rate, tot_entity, bern_prob, slots, seed, offset, pointwise=False,
+                 out=None, cursor=None):
     """Deterministic function of (seed, offset + slot index) like the device sampler (different stream)."""
     pos = triples[perm[start:start + n_pos]].numpy()
     nh, nr, nt = [], [], []

@@ -46,7 +46,7 @@ def test_argument_validation_without_gpu():
     d.model, d.dim, d.tot_entity, d.tot_relation = _lib.TRANSE, 8, 10, 3
     assert lib.kge_score_forward(ctypes.byref(d), None, None, None, 4, None, None, 0, None) != 0
     assert b"table 0 is null" in lib.kge_last_error()
-    assert lib.kge_optimizer_step(0, None, None, None, None, 16, 0.1, 1, 1, None) != 0
+    assert lib.kge_optimizer_step(0, None, None, None, None, 16, 0.1, 1, 1, None, None) != 0
     assert lib.kge_triple_set_build(None, 5, None, 7, None) != 0  # 7 is not a power of two
 
 
