@@ -19,6 +19,12 @@
 
 #define EPS_NORMALIZE 1e-12f
 
+void kgec_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#endif
+}
+
 int kgec_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -72,7 +78,8 @@ float kgec_transe_adam_step(float* ent, float* rel, int64_t E, int64_t R, int d,
                             const int64_t* pr, const int64_t* pt, const int64_t* nh, const int64_t* nr, const int64_t* nt,
                             int64_t n, float lr, int64_t step, float* g_ent, float* g_rel, float* m_ent, float* v_ent,
                             float* m_rel, float* v_rel) {
-    memset(g_ent, 0, (size_t)E * d * sizeof(float));
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < E * d; ++i) g_ent[i] = 0.f;
     memset(g_rel, 0, (size_t)R * d * sizeof(float));
     double loss = 0.0;
     /* pairs are independent given the tables; gradient rows collide, so each thread owns a slice of ROWS:

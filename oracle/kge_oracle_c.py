@@ -22,10 +22,10 @@ def build(force=False):
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            build()
+        build()  # no-op when the library is newer than the source
         lib = ctypes.CDLL(LIB)
         lib.kgec_threads.restype = ctypes.c_int
+        lib.kgec_set_threads.argtypes = [ctypes.c_int]
         lib.kgec_transe_adam_step.restype = ctypes.c_float
         lib.kgec_transe_adam_step.argtypes = ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 6 +
@@ -39,6 +39,10 @@ def load():
 
 def threads():
     return load().kgec_threads()
+
+
+def set_threads(n):
+    load().kgec_set_threads(int(n))
 
 
 def _p(a):
