@@ -94,6 +94,15 @@ int kge_train_pairwise_hinge(const kge_model_desc* m,
                              int64_t n, float margin, void* workspace, size_t workspace_bytes,
                              float* loss, void* stream);
 
+/* The same step with the negative sampler FUSED IN FRONT (data/generator.py:42-97 + utils/trainer.py:147-157 +
+ * utils/criterion.py:25-29 in one kernel, neg_rate 1): pair i is triples[perm[start+i]] and its corruption drawn with
+ * Philox counter offset+i -- the very batch kge_sample_batch(start, n, 1, ..., seed, offset) would emit.  Gather-type
+ * models only.  dev_cursor as in kge_sample_batch. */
+int kge_train_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm,
+                                     int64_t start, int64_t n, const float* bern_prob, const uint64_t* slots,
+                                     int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor,
+                                     float margin, float* loss, void* stream);
+
 /* Fused train_step_pairwise with Criterion.pariwise_logistic (utils/criterion.py:13-23; RotatE):
  * self-adversarial weights softmax(alpha * -s-) over the neg_rate negatives of each positive (detached).
  * Negatives of positive i are rows [i*neg_rate, (i+1)*neg_rate) (data/generator.py:71-95).

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkge_hip.so")
+LIB_PATH = os.environ.get("KGE_HIP_LIB", os.path.join(_HERE, "libkge_hip.so"))  # env override: A/B builds in dev tools
 
 KGE_MAX_TABLES = 6
 ABI_VERSION = 1
@@ -46,6 +46,7 @@ _SIGNATURES = {
     "kge_score_backward": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "kge_rescal_normalize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
     "kge_train_pairwise_hinge": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_train_pairwise_hinge_sampled": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_train_pairwise_selfadv": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_train_pointwise_logistic": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_float, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_l2norm_reg": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

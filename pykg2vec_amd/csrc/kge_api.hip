@@ -146,6 +146,22 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
     return kge_score_backward(m, nh, nr, nt, n, sn, workspace, gws, stream);
 }
 
+int kge_train_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
+                                     int64_t n, const float* bern_prob, const uint64_t* slots, int64_t n_slots,
+                                     uint64_t seed, uint64_t offset, const int64_t* dev_cursor, float margin, float* loss,
+                                     void* stream) {
+    if (validate(m, true, "kge_train_pairwise_hinge_sampled")) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || start < 0 || !triples || !perm || !loss) { set_error("kge_train_pairwise_hinge_sampled: bad arguments"); return -1; }
+    if (slots && (n_slots & (n_slots - 1))) { set_error("kge_train_pairwise_hinge_sampled: n_slots must be a power of two"); return -1; }
+    if (!is_vector_model(m->model)) {
+        set_error("kge_train_pairwise_hinge_sampled: model %d needs kge_sample_batch + kge_train_pairwise_hinge", m->model);
+        return -1;
+    }
+    return launch_pairwise_hinge_sampled(m, triples, perm, start, n, bern_prob, slots, n_slots, seed, offset, dev_cursor,
+                                         margin, loss, (hipStream_t)stream);
+}
+
 int kge_train_pairwise_selfadv(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
                                const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n_pos,
                                int32_t neg_rate, float alpha, float* workspace, float* loss, void* stream) {

@@ -12,6 +12,7 @@
 // its rows in registers from the gather to the gradient scatter; the only HBM traffic is the row gather, the
 // 24-byte id read and the float atomics into the dense gradient tables.
 #include "kge_internal.h"
+#include "kge_sampler_device.h"
 
 namespace kge {
 
@@ -61,19 +62,44 @@ __global__ __launch_bounds__(kBlock) void k_score_bwd(DeviceModel m, const int64
 // ---- fused pairwise hinge step: score(+) , score(-), max(0, s+ + margin - s-), both backward passes.
 // A negative produced by the reference sampler shares the relation and one entity with its positive
 // (data/generator.py:71-95); rows with equal ids get ONE combined atomic scatter (4 row scatters, not 6).
-template <int M, int G, int NCH>
+// SAMPLED = true fuses the negative sampler in front (north_star: corruption + both scores + margin ranking + backward
+// in ONE kernel): the positive is triples[perm[start+i]] and its negative is drawn here by corrupt_one() with the same
+// Philox counters as the stand-alone sampler, so kge_sample_batch + kge_train_pairwise_hinge and this kernel see
+// identical batches.  Every lane of a group runs the (scalar) draw redundantly: no shuffle, no divergence.
+struct FusedSampler {
+    const int64_t* triples; const int64_t* perm; int64_t start; int64_t E;
+    const float* bern; const unsigned long long* slots; unsigned long long mask; unsigned long long seed, offset;
+    const int64_t* cursor;
+};
+
+template <int M, int G, int NCH, bool SAMPLED>
 __global__ __launch_bounds__(kBlock) void k_pairwise_hinge(DeviceModel m, const int64_t* __restrict__ ph,
                                                            const int64_t* __restrict__ pr, const int64_t* __restrict__ pt,
                                                            const int64_t* __restrict__ nh, const int64_t* __restrict__ nr,
                                                            const int64_t* __restrict__ nt, int64_t n, float margin,
-                                                           float* __restrict__ loss) {
+                                                           float* __restrict__ loss, FusedSampler fs) {
     constexpr int GPB = kBlock / G;
     constexpr int NR = role_count(M);
     const int gl = threadIdx.x % G;
     float acc = 0.f;
+    int64_t s_start = 0;
+    unsigned long long s_off = 0;
+    if constexpr (SAMPLED) {
+        s_start = fs.cursor ? fs.start + fs.cursor[0] : fs.start;
+        s_off = fs.cursor ? fs.offset + (unsigned long long)fs.cursor[1] : fs.offset;
+    }
     for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n; i += (int64_t)gridDim.x * GPB) {
-        const int64_t idp[3] = {ph[i], pr[i], pt[i]};
-        const int64_t idn[3] = {nh[i], nr[i], nt[i]};
+        int64_t idp[3], idn[3];
+        if constexpr (SAMPLED) {
+            const int64_t row = fs.perm[s_start + i];
+            idp[0] = fs.triples[3 * row]; idp[1] = fs.triples[3 * row + 1]; idp[2] = fs.triples[3 * row + 2];
+            idn[1] = idp[1];
+            corrupt_one(idp[0], idp[1], idp[2], fs.E, fs.bern, fs.slots, fs.mask, fs.seed, s_off + (unsigned long long)i,
+                        idn[0], idn[2]);
+        } else {
+            idp[0] = ph[i]; idp[1] = pr[i]; idp[2] = pt[i];
+            idn[0] = nh[i]; idn[1] = nr[i]; idn[2] = nt[i];
+        }
         Rows<M, NCH> Rp, Rn;
         load_rows<M, G, NCH>(Rp, m, idp, gl);
         load_rows<M, G, NCH>(Rn, m, idn, gl);
@@ -106,6 +132,135 @@ __global__ __launch_bounds__(kBlock) void k_pairwise_hinge(DeviceModel m, const 
     block_accumulate_loss<G>(acc, gl, loss);
 }
 
+
+// ---- TransE, sampler fused, shared rows loaded ONCE.  A sampled negative is the positive with its head OR its tail
+// replaced (data/generator.py:77-95), so a pair touches 4 distinct rows: H, R, T and the corrupting entity C -- not 6.
+// 4 row gathers, 4 norms, 2 energies, 4 normalisation dot products (three batched butterflies), 4 scatters; the
+// gradients wrt the normalised vectors add linearly before the normalisation backward, which is exactly the sum of
+// the two per-triple backward passes the reference's autograd performs.
+template <int G>
+__device__ __forceinline__ void gsum4(float& a, float& b, float& c, float& d) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64);
+        c += __shfl_xor(c, m, 64); d += __shfl_xor(d, m, 64);
+    }
+}
+
+// Batches arrive SORTED BY RELATION (generator: each batch slice of the permutation is sorted once at start-up -- a
+// batch is a set, its order changes nothing but fp summation order), and a group walks CH consecutive pairs: the
+// relation row, its norm and its gradient stay in registers across pairs of the same relation and are scattered once
+// per run instead of once per pair.
+template <int G, int NCH, int CH>
+__global__ __launch_bounds__(kBlock) void k_transe_pair_sampled(DeviceModel m, int64_t n, float margin,
+                                                                float* __restrict__ loss, FusedSampler fs) {
+    constexpr int GPB = kBlock / G;
+    const int gl = threadIdx.x % G;
+    const int d = m.dim;
+    const bool l1 = m.l1;
+    float acc = 0.f;
+    const int64_t s_start = fs.cursor ? fs.start + fs.cursor[0] : fs.start;
+    const unsigned long long s_off = fs.cursor ? fs.offset + (unsigned long long)fs.cursor[1] : fs.offset;
+    const int64_t nchunks = (n + CH - 1) / CH;
+    for (int64_t ck = (int64_t)blockIdx.x * GPB + threadIdx.x / G; ck < nchunks; ck += (int64_t)gridDim.x * GPB) {
+        int64_t r_cur = -1;
+        float R[NCH], gRh[NCH];  // relation row and the running gradient wrt its NORMALISED form
+        float iR = 0.f;
+        bool fR = false, r_dirty = false;
+        auto flush_r = [&]() {
+            if (!r_dirty) return;
+            float dR = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) dR = fmaf(R[k], gRh[k], dR);
+            dR = gsum<G>(dR) * iR;
+            float gR[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) gR[k] = fR ? (gRh[k] - (R[k] * iR) * dR) * iR : gRh[k] * iR;
+            atomic_add_row<G, NCH>(m.grad[1] + r_cur * (int64_t)d, gR, d, gl);
+            r_dirty = false;
+        };
+        const int64_t i_end = min(n, (ck + 1) * CH);
+        for (int64_t i = ck * CH; i < i_end; ++i) {
+            const int64_t row = fs.perm[s_start + i];
+            const int64_t h = fs.triples[3 * row], r = fs.triples[3 * row + 1], t = fs.triples[3 * row + 2];
+            int64_t nh, nt;
+            corrupt_one(h, r, t, fs.E, fs.bern, fs.slots, fs.mask, fs.seed, s_off + (unsigned long long)i, nh, nt);
+            const bool tail = nh == h;              // tail corrupted (else head corrupted)
+            const int64_t c = tail ? nt : nh;
+            float H[NCH], T[NCH], C[NCH];
+            load_row<G, NCH>(H, m.tab[0] + h * (int64_t)d, d, gl);
+            load_row<G, NCH>(T, m.tab[0] + t * (int64_t)d, d, gl);
+            load_row<G, NCH>(C, m.tab[0] + c * (int64_t)d, d, gl);
+            float nH = 0.f, nR = 0.f, nT = 0.f, nC = 0.f;
+            const bool new_r = r != r_cur;  // group-uniform
+            if (new_r) {
+                flush_r();
+                r_cur = r;
+                load_row<G, NCH>(R, m.tab[1] + r * (int64_t)d, d, gl);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) { nR = fmaf(R[k], R[k], nR); gRh[k] = 0.f; }
+            }
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                nH = fmaf(H[k], H[k], nH); nT = fmaf(T[k], T[k], nT); nC = fmaf(C[k], C[k], nC);
+            }
+            gsum4<G>(nH, nR, nT, nC);
+            if (new_r) {
+                nR = sqrtf(nR);
+                fR = nR > kEpsNormalize;
+                iR = 1.0f / fmaxf(nR, kEpsNormalize);
+            }
+            nH = sqrtf(nH); nT = sqrtf(nT); nC = sqrtf(nC);
+            const bool fH = nH > kEpsNormalize, fT = nT > kEpsNormalize, fC = nC > kEpsNormalize;
+            const float iH = 1.0f / fmaxf(nH, kEpsNormalize), iT = 1.0f / fmaxf(nT, kEpsNormalize);
+            const float iC = 1.0f / fmaxf(nC, kEpsNormalize);
+            float up[NCH], un[NCH];
+            float sp = 0.f, sn = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const float hh = H[k] * iH, rr = R[k] * iR, tt = T[k] * iT, cc = C[k] * iC;
+                up[k] = hh + rr - tt;
+                un[k] = tail ? (hh + rr - cc) : (cc + rr - tt);
+                sp = l1 ? sp + fabsf(up[k]) : fmaf(up[k], up[k], sp);
+                sn = l1 ? sn + fabsf(un[k]) : fmaf(un[k], un[k], sn);
+            }
+            gsum2<G>(sp, sn);
+            if (!l1) { sp = sqrtf(sp); sn = sqrtf(sn); }
+            const float v = sp + margin - sn;
+            acc += fmaxf(v, 0.f);
+            const float coef = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);
+            if (coef == 0.f) continue;
+            const float ip = (!l1 && sp > 0.f) ? coef / sp : 0.f, in = (!l1 && sn > 0.f) ? -coef / sn : 0.f;
+            // gradients wrt the normalised vectors (gp: positive with ds=+coef, gn: negative with ds=-coef)
+            float gH[NCH], gT[NCH], gC[NCH];
+            float dH = 0.f, dT = 0.f, dC = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const float gp = l1 ? (up[k] > 0.f ? coef : (up[k] < 0.f ? -coef : 0.f)) : up[k] * ip;
+                const float gn = l1 ? (un[k] > 0.f ? -coef : (un[k] < 0.f ? coef : 0.f)) : un[k] * in;
+                gRh[k] += gp + gn;
+                gH[k] = tail ? gp + gn : gp;
+                gT[k] = tail ? -gp : -(gp + gn);
+                gC[k] = tail ? -gn : gn;
+                dH = fmaf(H[k], gH[k], dH); dT = fmaf(T[k], gT[k], dT); dC = fmaf(C[k], gC[k], dC);
+            }
+            r_dirty = true;
+            gsum3<G>(dH, dT, dC);
+            dH *= iH; dT *= iT; dC *= iC;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                gH[k] = fH ? (gH[k] - (H[k] * iH) * dH) * iH : gH[k] * iH;
+                gT[k] = fT ? (gT[k] - (T[k] * iT) * dT) * iT : gT[k] * iT;
+                gC[k] = fC ? (gC[k] - (C[k] * iC) * dC) * iC : gC[k] * iC;
+            }
+            atomic_add_row<G, NCH>(m.grad[0] + h * (int64_t)d, gH, d, gl);
+            atomic_add_row<G, NCH>(m.grad[0] + t * (int64_t)d, gT, d, gl);
+            atomic_add_row<G, NCH>(m.grad[0] + c * (int64_t)d, gC, d, gl);
+        }
+        flush_r();
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
 
 // ---- fused pointwise step: mean(softplus(y*s)) + lmbda * mean_i(sum of squares/cubes of the rows of row i)
 template <int M, int G, int NCH>
@@ -332,8 +487,35 @@ int launch_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const int6
     Geometry geo;
     if (!geometry_for(m, &geo)) return -1;
     const DeviceModel dm = to_device_model(m);
-    KGE_DISPATCH(m->model, (k_pairwise_hinge<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, ph, pr, pt, nh, nr, nt, n, margin, loss)))
+    const FusedSampler fs{};
+    KGE_DISPATCH(m->model, (k_pairwise_hinge<M, G, NCH, false><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, ph, pr, pt, nh, nr, nt, n, margin, loss, fs)))
     set_error("kge_train_pairwise_hinge: unsupported model %d", m->model);
+    return -1;
+}
+
+int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
+                                  int64_t n, const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed,
+                                  uint64_t offset, const int64_t* cursor, float margin, float* loss, hipStream_t s) {
+    Geometry geo;
+    if (!geometry_for(m, &geo)) return -1;
+    if (m->tot_entity >= (1 << 24)) { set_error("fused sampler: more than 2^24 entities not supported by the packed key"); return -1; }
+    const DeviceModel dm = to_device_model(m);
+    FusedSampler fs;
+    fs.triples = triples; fs.perm = perm; fs.start = start; fs.E = m->tot_entity; fs.bern = bern;
+    fs.slots = (const unsigned long long*)slots; fs.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
+    fs.seed = seed; fs.offset = offset; fs.cursor = cursor;
+    if (m->model == KGE_TRANSE) {  // shared-row specialisation: 4 row gathers / scatters per pair instead of 6
+#define KGE_TE(G_, NCH_)                                                                                                   \
+    if (geo.G == G_ && geo.NCH == NCH_) {                                                                                   \
+        k_transe_pair_sampled<G_, NCH_, 4><<<dim3(Launch<KGE_TRANSE, G_, NCH_>::grid((n + 3) / 4)), dim3(kBlock), 0, s>>>(dm, n, margin, loss, fs); \
+        return check_launch("k_transe_pair_sampled");                                                                       \
+    }
+        KGE_TE(32, 1) KGE_TE(32, 2) KGE_TE(32, 4) KGE_TE(32, 8) KGE_TE(64, 8) KGE_TE(64, 16)
+#undef KGE_TE
+    }
+    const int64_t* z = nullptr;
+    KGE_DISPATCH(m->model, (k_pairwise_hinge<M, G, NCH, true><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, z, z, z, z, z, z, n, margin, loss, fs)))
+    set_error("kge_train_pairwise_hinge_sampled: unsupported model %d", m->model);
     return -1;
 }
 

@@ -40,6 +40,13 @@ class Generator:
         self.rank, self.world_size = rank, world_size
         rng = np.random.default_rng(self.seed)
         perm = rng.permutation(self.n_train)
+        # A batch is a SET of triples: inside each batch slice of the permutation the rows are ordered by relation id
+        # (once, here), so that the fused kernel can keep a relation row and its gradient in registers across
+        # consecutive pairs.  Which triples form which batch is unchanged.
+        bsz = int(config.batch_size)
+        for lo in range(0, self.n_train, bsz):
+            sl = perm[lo:lo + bsz]
+            perm[lo:lo + bsz] = sl[np.argsort(train[sl, 1], kind="stable")]
         self.triples = torch.from_numpy(train).to(self.device)
         self.perm = torch.from_numpy(perm).to(self.device)
         self.slots = self.K.triple_set_build(self.triples)
@@ -64,7 +71,8 @@ class Generator:
     def stop(self):
         self._pending = 0
 
-    def __next__(self):
+    def _next_range(self):
+        """(start, n, offset) of the next batch in the permutation / Philox stream; advances the counters."""
         if self._pending <= 0:
             raise StopIteration
         b = self._batch_idx
@@ -79,6 +87,10 @@ class Generator:
             lo = min(n, self.rank * per)
             start, n = start + lo, max(0, min(per, n - lo))
             offset += lo * self.neg_rate
+        return start, n, offset
+
+    def __next__(self):
+        start, n, offset = self._next_range()
         return self.K.sample_batch(self.triples, self.perm, start, n, self.neg_rate, self.config.tot_entity, self.bern,
-                              self.slots, self.seed, offset,
-                              pointwise=self.training_strategy == TrainingStrategy.POINTWISE_BASED)
+                                   self.slots, self.seed, offset,
+                                   pointwise=self.training_strategy == TrainingStrategy.POINTWISE_BASED)

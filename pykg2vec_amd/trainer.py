@@ -129,6 +129,32 @@ class Trainer:
             if self.model.kernel_name == "ntn":  # + get_reg(None, None, None) (utils/trainer.py:155): dense L2-norm
                 self.K.l2norm_reg(self.flat.param, self.flat.grad, self.model.lmbda, self.loss_buf)
 
+    def _fused_sampler_ok(self):
+        """Sampler + scoring + hinge + backward in one kernel: gather-type pairwise-hinge models with neg_rate 1."""
+        return (self.K is K and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED
+                and self.model.kernel_name not in ("rescal", "ntn") and self.model.model_name.lower() != "rotate"
+                and int(self.config.neg_rate) == 1)
+
+    def _accumulate_next_batch(self, cursor=None, fixed_range=None):
+        """One batch from the generator's stream into the gradient / loss buffers."""
+        gen = self.generator
+        if self._fused_sampler_ok():
+            start, n, offset = fixed_range if fixed_range is not None else gen._next_range()
+            K.train_pairwise_hinge_sampled(self._desc, gen.triples, gen.perm, start, n, gen.bern, gen.slots, gen.seed,
+                                           offset, self.config.margin, self.loss_buf, cursor=cursor)
+            return
+        if fixed_range is not None:
+            pointwise = self.model.training_strategy != TrainingStrategy.PAIRWISE_BASED
+            data = K.sample_batch(gen.triples, gen.perm, fixed_range[0], fixed_range[1], gen.neg_rate, self.config.tot_entity,
+                                  gen.bern, gen.slots, gen.seed, fixed_range[2], pointwise=pointwise, out=self._sbuf,
+                                  cursor=cursor)
+        else:
+            data = next(gen)
+        if self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED:
+            self._accumulate_pairwise(*data)
+        else:
+            self._accumulate_pointwise(*data)
+
     def _accumulate_pointwise(self, h, r, t, y):
         self.K.train_pointwise_logistic(self._desc, h, r, t, y, self.model.lmbda, self.model.kernel_reg_type(), self.loss_buf)
 
@@ -188,12 +214,7 @@ class Trainer:
 
         def body():
             K.step_advance(self._cursor, self._hyper, B, num_batch, B * gen.neg_rate, cfg.learning_rate)
-            batch = K.sample_batch(gen.triples, gen.perm, 0, B, gen.neg_rate, cfg.tot_entity, gen.bern, gen.slots,
-                                   gen.seed, 0, pointwise=pointwise, out=self._sbuf, cursor=self._cursor)
-            if pointwise:
-                self._accumulate_pointwise(*batch)
-            else:
-                self._accumulate_pairwise(*batch)
+            self._accumulate_next_batch(cursor=self._cursor, fixed_range=(0, B, 0))
             self.flat.optimizer_step(cfg.learning_rate, dev_hyper=self._hyper)
 
         body()  # the epoch's FIRST step runs eagerly (loads kernels, sizes workspaces) ...
@@ -223,11 +244,7 @@ class Trainer:
         else:
             self.loss_buf.zero_()
             for _ in range(num_batch):
-                data = next(self.generator)
-                if pairwise:
-                    self._accumulate_pairwise(*data)
-                else:
-                    self._accumulate_pointwise(*data)
+                self._accumulate_next_batch()
                 self._reduce_and_step()
         acc = self.K.read_loss(self.loss_buf)
         if self.world_size > 1:

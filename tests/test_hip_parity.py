@@ -264,3 +264,30 @@ def test_graph_replayed_epochs_equal_eager_epochs(hip, name, opt):
     assert np.allclose(l0, l1, rtol=2e-4), (l0, l1)
     for k in p0:  # float atomics make the two runs differ in summation order only
         assert np.allclose(p0[k], p1[k], atol=2e-4, rtol=1e-3), (k, np.abs(p0[k] - p1[k]).max())
+
+
+@pytest.mark.parametrize("name", ["transe_l1", "transe_l2", "transh_l1", "transd_l2"])
+def test_fused_sampler_step_equals_sample_then_step(hip, name):
+    """kge_train_pairwise_hinge_sampled (corruption fused into the scoring kernel) must see exactly the batch
+    kge_sample_batch emits for the same (start, n, seed, offset): same loss, same gradients."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.trainer import Trainer
+    c = Case(name)
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, batch_size=64)
+    res = []
+    for fused in (False, True):
+        m = hip.model_from_case(c)
+        tr = Trainer(m, cfg)
+        tr.build_model()
+        gen = tr._new_generator()
+        tr.generator = gen
+        tr.loss_buf.zero_()
+        if fused:
+            K.train_pairwise_hinge_sampled(tr._desc, gen.triples, gen.perm, 128, 64, None, gen.slots, 11, 999, 1.0, tr.loss_buf)
+        else:
+            b = K.sample_batch(gen.triples, gen.perm, 128, 64, 1, c.E, None, gen.slots, 11, 999)
+            K.train_pairwise_hinge(tr._desc, *b, 1.0, tr.loss_buf)
+        res.append((K.read_loss(tr.loss_buf).item(), [g.cpu().numpy().copy() for g in tr.flat.grad_views]))
+    assert np.isclose(res[0][0], res[1][0], rtol=1e-5)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.allclose(a, b, atol=1e-5, rtol=1e-4)
