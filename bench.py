@@ -253,7 +253,7 @@ def main():
     mean_rank = float(ranks[:2].float().mean().item()) + 1.0
 
     out = None
-    traffic, traffic_src = pmc_traffic("kge::k_pairwise_hinge<0, 32, 4", per_rank_batch)
+    traffic, traffic_src = pmc_traffic("kge::k_transe_pair_sampled<32, 4, 4>", per_rank_batch)
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
@@ -264,7 +264,7 @@ def main():
                                    "on-device uniform corruption; E=14951 R=1345 train=483142",
                        "batch_per_gpu": per_rank_batch, "global_batch": per_rank_batch * world,
                        "scored_triples_per_step": scored_per_step, "parallelism": "dp%d" % world},
-            "roofline": {"kernel": "k_pairwise_hinge<TransE,G=32,NCH=4,SAMPLED>", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_ms},
