@@ -116,8 +116,9 @@ int kge_train_pairwise_selfadv(const kge_model_desc* m,
 /* Fused Trainer.train_step_pointwise (utils/trainer.py:176-180): Criterion.pointwise_logistic
  * (utils/criterion.py:31-34) mean(softplus(y*s)) + lmbda*get_reg (pointwise.py:106-119,190-202,224-238,448-458). */
 int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r,
-                                 const int64_t* t, const int64_t* y, int64_t n, float lmbda,
-                                 int32_t reg_type, float* loss, void* stream);
+                                 const int64_t* t, const int64_t* y, int64_t n,
+                                 int32_t bundle /* rows per sampler bundle = 1+neg_rate (data/generator.py:125-156); <=1: none */,
+                                 float lmbda, int32_t reg_type, float* loss, void* stream);
 
 /* Dense optimiser sweep with torch.optim defaults (utils/trainer.py:112-131): SGD, Adam(0.9,0.999,1e-8),
  * Adagrad(eps 1e-10), RMSprop(alpha .99, eps 1e-8).  state1/state2: exp_avg/exp_avg_sq (Adam),

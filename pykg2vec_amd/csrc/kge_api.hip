@@ -189,13 +189,14 @@ int kge_train_pairwise_selfadv(const kge_model_desc* m, const int64_t* ph, const
 }
 
 int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                                 const int64_t* y, int64_t n, float lmbda, int32_t reg_type, float* loss, void* stream) {
+                                 const int64_t* y, int64_t n, int32_t bundle, float lmbda, int32_t reg_type, float* loss,
+                                 void* stream) {
     if (validate(m, true, "kge_train_pointwise_logistic")) return -1;
     if (n == 0) return 0;
     if (n < 0 || !h || !r || !t || !y || !loss) { set_error("kge_train_pointwise_logistic: bad arguments"); return -1; }
     if (reg_type < KGE_REG_NONE || reg_type > KGE_REG_N3_ABS) { set_error("kge_train_pointwise_logistic: bad reg_type %d", reg_type); return -1; }
     if (!is_vector_model(m->model)) { set_error("kge_train_pointwise_logistic: unsupported model %d", m->model); return -1; }
-    return launch_pointwise_logistic(m, h, r, t, y, n, lmbda, reg_type, loss, (hipStream_t)stream);
+    return launch_pointwise_logistic(m, h, r, t, y, n, bundle, lmbda, reg_type, loss, (hipStream_t)stream);
 }
 
 int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,

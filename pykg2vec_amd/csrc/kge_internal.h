@@ -28,7 +28,7 @@ int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triple
                                   int64_t n, const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed,
                                   uint64_t offset, const int64_t* cursor, float margin, float* loss, hipStream_t s);
 int launch_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                              const int64_t* y, int64_t n, float lmbda, int reg_type, float* loss, hipStream_t s);
+                              const int64_t* y, int64_t n, int bundle, float lmbda, int reg_type, float* loss, hipStream_t s);
 int launch_selfadv_bundle(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
                           const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n_pos, int neg_rate,
                           float alpha, float* loss, hipStream_t s);  // returns 1 when neg_rate exceeds the group width

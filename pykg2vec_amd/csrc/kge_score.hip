@@ -305,6 +305,100 @@ __global__ __launch_bounds__(kBlock) void k_pointwise_logistic(DeviceModel m, co
     block_accumulate_loss<G>(acc, gl, loss);
 }
 
+// ---- pointwise step over BUNDLES: the reference sampler emits each positive followed by its neg_rate corruptions
+// (data/generator.py:125-156), which share the relation row(s) and one entity's row(s) with it.  One group walks the
+// `bundle` consecutive rows, accumulating in registers every gradient row whose id equals the bundle's first row's id
+// for that role, and scatters those once: 1+neg_rate rows cost NR + neg_rate*(rows of one entity) scatters instead of
+// (1+neg_rate)*NR.  Pure id-equality test, so it is exact for arbitrary input rows too.
+// Batches are sorted by relation (generator), so a group also walks CHB consecutive bundles and carries the RELATION
+// rows' gradients across them while the relation id does not change (few-relation graphs such as WN18RR otherwise
+// funnel thousands of atomic row-adds per step into a dozen rows, i.e. into a handful of memory channels).
+constexpr int kMaxChunkBundles = 8;
+static int chunk_bundles(int64_t nb) {  // enough groups to fill the chip first, then amortise relation scatters
+    int64_t c = nb / 2048;
+    return (int)(c < 1 ? 1 : (c > kMaxChunkBundles ? kMaxChunkBundles : c));
+}
+
+template <int M, int G, int NCH>
+__global__ __launch_bounds__(kBlock) void k_pointwise_bundle(DeviceModel m, const int64_t* __restrict__ h,
+                                                             const int64_t* __restrict__ r, const int64_t* __restrict__ t,
+                                                             const int64_t* __restrict__ y, int64_t n, int bundle, int CHB,
+                                                             float lmbda, int reg_type, float* __restrict__ loss) {
+    constexpr int GPB = kBlock / G;
+    constexpr int NR = role_count(M);
+    const int gl = threadIdx.x % G;
+    const float inv_n = 1.0f / (float)n;
+    const float c2 = 2.f * lmbda * inv_n, c3 = 3.f * lmbda * inv_n;
+    const int64_t nb = (n + bundle - 1) / bundle;
+    const int64_t nchunks = (nb + CHB - 1) / CHB;
+    float acc = 0.f;
+    for (int64_t ck = (int64_t)blockIdx.x * GPB + threadIdx.x / G; ck < nchunks; ck += (int64_t)gridDim.x * GPB) {
+        Rows<M, NCH> A;  // anchors: entity roles are reset per bundle, relation roles persist while the relation id holds
+        int64_t ida[3] = {-1, -1, -1};
+        auto flush_role = [&](int q) {
+            const int sel = role_sel(M, q);
+            if (ida[sel] < 0) return;
+            const int d = role_dim<M>(m, q);
+            atomic_add_row<G, NCH>(m.grad[role_tab(M, q)] + ida[sel] * (int64_t)d, A.x[q], d, gl);
+        };
+        const int64_t b1 = min(nb, (ck + 1) * CHB);
+        for (int64_t b = ck * CHB; b < b1; ++b) {
+            const int64_t i0 = b * bundle;
+            const int64_t idb[3] = {h[i0], r[i0], t[i0]};
+            const bool same_rel = idb[1] == ida[1];  // group-uniform
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int sel = role_sel(M, q);
+                if (sel == 1 && same_rel) continue;  // keep accumulating this relation's rows
+                flush_role(q);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) A.x[q][c] = 0.f;
+            }
+            ida[0] = idb[0]; ida[1] = idb[1]; ida[2] = idb[2];
+            const int64_t i1 = min(n, i0 + bundle);
+            for (int64_t i = i0; i < i1; ++i) {
+                const int64_t id[3] = {h[i], r[i], t[i]};
+                const float yy = (float)y[i];
+                Rows<M, NCH> R, Gr;
+                Saved<M, NCH> sv;
+                load_rows<M, G, NCH>(R, m, id, gl);
+                const float s = model_fwd<M, G, NCH>(R, m, sv);
+                const float x = yy * s;
+                acc += softplus_t(x) * inv_n;
+                model_bwd<M, G, NCH>(R, m, sv, yy * sigmoid_t(x) * inv_n, Gr);
+                if (reg_type != KGE_REG_NONE) {
+                    float rs = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            const float v = R.x[q][c];
+                            if (reg_type == KGE_REG_F2) { rs = fmaf(v, v, rs); Gr.x[q][c] += c2 * v; }
+                            else if (reg_type == KGE_REG_N3) { rs += v * v * v; Gr.x[q][c] += c3 * v * v; }
+                            else { const float a = fabsf(v); rs += a * a * a; Gr.x[q][c] += c3 * v * a; }
+                        }
+                    }
+                    acc += lmbda * inv_n * gsum<G>(rs);
+                }
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const int sel = role_sel(M, q);
+                    if (id[sel] == ida[sel]) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) A.x[q][c] += Gr.x[q][c];
+                    } else {
+                        const int d = role_dim<M>(m, q);
+                        atomic_add_row<G, NCH>(m.grad[role_tab(M, q)] + id[sel] * (int64_t)d, Gr.x[q], d, gl);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) flush_role(q);
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
+
 // ---- fused self-adversarial step (criterion.py:13-23 + trainer.py:147-157): one group owns a positive AND its
 // neg_rate negatives (rows [i*neg_rate, (i+1)*neg_rate), data/generator.py:71-95).  Pass 1 scores the 1+neg_rate
 // triples (lane j of the group keeps the energy of negative j), the group computes the detached softmax weights and
@@ -520,10 +614,17 @@ int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triple
 }
 
 int launch_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                              const int64_t* y, int64_t n, float lmbda, int reg_type, float* loss, hipStream_t s) {
+                              const int64_t* y, int64_t n, int bundle, float lmbda, int reg_type, float* loss, hipStream_t s) {
     Geometry geo;
     if (!geometry_for(m, &geo)) return -1;
     const DeviceModel dm = to_device_model(m);
+    if (bundle > 1) {
+        const int chb = chunk_bundles((n + bundle - 1) / bundle);
+        const int64_t nb = ((n + bundle - 1) / bundle + chb - 1) / chb;
+        KGE_DISPATCH(m->model, (k_pointwise_bundle<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(nb)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, bundle, chb, lmbda, reg_type, loss)))
+        set_error("kge_train_pointwise_logistic: unsupported model %d", m->model);
+        return -1;
+    }
     KGE_DISPATCH(m->model, (k_pointwise_logistic<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, lmbda, reg_type, loss)))
     set_error("kge_train_pointwise_logistic: unsupported model %d", m->model);
     return -1;

@@ -145,10 +145,10 @@ def train_pairwise_selfadv(desc, ph, pr, pt, nh, nr, nt, neg_rate, alpha, loss_b
     return workspace
 
 
-def train_pointwise_logistic(desc, h, r, t, y, lmbda, reg_type, loss_buf):
+def train_pointwise_logistic(desc, h, r, t, y, lmbda, reg_type, loss_buf, bundle=1):
     n = h.numel()
     L.check(L.load().kge_train_pointwise_logistic(ctypes.byref(desc), _ids(h, "h"), _ids(r, "r"), _ids(t, "t"),
-                                                  _ids(y, "y"), n, float(lmbda), int(reg_type),
+                                                  _ids(y, "y"), n, int(bundle), float(lmbda), int(reg_type),
                                                   _dev(loss_buf, torch.float32, "loss"), _stream()),
             "kge_train_pointwise_logistic")
 

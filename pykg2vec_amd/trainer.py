@@ -156,7 +156,9 @@ class Trainer:
             self._accumulate_pointwise(*data)
 
     def _accumulate_pointwise(self, h, r, t, y):
-        self.K.train_pointwise_logistic(self._desc, h, r, t, y, self.model.lmbda, self.model.kernel_reg_type(), self.loss_buf)
+        # rows arrive as bundles [positive, its neg_rate negatives] (generator / data/generator.py:125-156)
+        self.K.train_pointwise_logistic(self._desc, h, r, t, y, self.model.lmbda, self.model.kernel_reg_type(),
+                                        self.loss_buf, bundle=1 + int(self.config.neg_rate))
 
     def _mean_type_loss(self):
         """pointwise_logistic and the self-adversarial loss are MEANS over the batch (criterion.py:13-23,31-34);

@@ -60,7 +60,7 @@ def train_pairwise_selfadv(desc, ph, pr, pt, nh, nr, nt, neg_rate, alpha, loss_b
     return workspace
 
 
-def train_pointwise_logistic(desc, h, r, t, y, lmbda, reg_type, loss_buf):
+def train_pointwise_logistic(desc, h, r, t, y, lmbda, reg_type, loss_buf, bundle=1):
     hp = dict(desc.hp, lmbda=lmbda)
     loss, G, _, _ = ko.train_step_grads(desc.name, desc.params(), tuple(map(_np, (h, r, t, y))), **hp)
     _add_grads(desc, G)

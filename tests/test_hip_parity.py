@@ -291,3 +291,24 @@ def test_fused_sampler_step_equals_sample_then_step(hip, name):
     assert np.isclose(res[0][0], res[1][0], rtol=1e-5)
     for a, b in zip(res[0][1], res[1][1]):
         assert np.allclose(a, b, atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["distmult", "complex", "analogy"])
+def test_pointwise_bundle_kernel_equals_row_kernel(hip, name):
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.trainer import Trainer
+    c = Case(name)
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test)
+    res = []
+    for bundle in (1, 2, 5):
+        m = hip.model_from_case(c)
+        tr = Trainer(m, cfg)
+        tr.build_model()
+        b = [hip.dev(x) for x in c.batch(0)]
+        tr.loss_buf.zero_()
+        K.train_pointwise_logistic(tr._desc, *b, m.lmbda, m.kernel_reg_type(), tr.loss_buf, bundle=bundle)
+        res.append((K.read_loss(tr.loss_buf).item(), [g.cpu().numpy().copy() for g in tr.flat.grad_views]))
+    for other in res[1:]:
+        assert np.isclose(res[0][0], other[0], rtol=1e-5)
+        for a, b2 in zip(res[0][1], other[1]):
+            assert np.allclose(a, b2, atol=1e-6, rtol=1e-4)
