@@ -28,28 +28,37 @@ struct DeviceModel {  // by-value kernel argument
 };
 
 // ------------------------------------------------------------------ group reductions
+// All-reduce (sum) over the G lanes of a group, every lane gets the total.  Steps inside a 16-lane row are DPP
+// modifiers folded into the v_add_f32 (quad_perm xor-1, xor-2, then row_half_mirror / row_mirror, valid because the
+// lanes being mirrored already hold equal partial sums): no LDS traffic, no address VGPR, one VALU op per step.  Only
+// the cross-row steps (lane ^ 16, lane ^ 32) go through the LDS crossbar (ds_swizzle / ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float swz_xor16(float v) {  // BitMode swizzle: and 0x1F, or 0, xor 0x10
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+}
 template <int G>
 __device__ __forceinline__ float gsum(float v) {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    static_assert(G == 1 || G == 16 || G == 32 || G == 64, "group width");
+    if constexpr (G >= 16) {
+        v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+        v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+        v += dpp_mov<0x141>(v);  // row_half_mirror
+        v += dpp_mov<0x140>(v);  // row_mirror
+    }
+    if constexpr (G >= 32) v += swz_xor16(v);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 template <int G>
 __device__ __forceinline__ void gsum3(float& a, float& b, float& c) {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) {
-        a += __shfl_xor(a, m, 64);
-        b += __shfl_xor(b, m, 64);
-        c += __shfl_xor(c, m, 64);
-    }
+    a = gsum<G>(a); b = gsum<G>(b); c = gsum<G>(c);  // independent chains; the scheduler interleaves them
 }
 template <int G>
 __device__ __forceinline__ void gsum2(float& a, float& b) {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) {
-        a += __shfl_xor(a, m, 64);
-        b += __shfl_xor(b, m, 64);
-    }
+    a = gsum<G>(a); b = gsum<G>(b);
 }
 __device__ __forceinline__ float wave_sum(float v) { return gsum<64>(v); }
 

@@ -140,11 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_pairwise_hinge(DeviceModel m, const 
 // the two per-triple backward passes the reference's autograd performs.
 template <int G>
 __device__ __forceinline__ void gsum4(float& a, float& b, float& c, float& d) {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) {
-        a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64);
-        c += __shfl_xor(c, m, 64); d += __shfl_xor(d, m, 64);
-    }
+    a = gsum<G>(a); b = gsum<G>(b); c = gsum<G>(c); d = gsum<G>(d);
 }
 
 // Batches arrive SORTED BY RELATION (generator: each batch slice of the permutation is sorted once at start-up -- a
@@ -439,7 +435,7 @@ __global__ __launch_bounds__(kBlock) void k_selfadv_bundle(DeviceModel m, const 
         const float nj = -s_mine;
         float mx = live ? nj * alpha : -INFINITY;
 #pragma unroll
-        for (int o = G / 2; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        for (int o = G / 2; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));  // max: rare, keep the shuffle form
         const float ex = live ? expf(nj * alpha - mx) : 0.f;
         const float den = gsum<G>(ex);
         const float wj = ex / den;
