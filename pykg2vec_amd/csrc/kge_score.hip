@@ -175,14 +175,27 @@ __global__ __launch_bounds__(kBlock) void k_transe_pair_sampled(DeviceModel m, i
             atomic_add_row<G, NCH>(m.grad[1] + r_cur * (int64_t)d, gR, d, gl);
             r_dirty = false;
         };
-        const int64_t i_end = min(n, (ck + 1) * CH);
-        for (int64_t i = ck * CH; i < i_end; ++i) {
-            const int64_t row = fs.perm[s_start + i];
-            const int64_t h = fs.triples[3 * row], r = fs.triples[3 * row + 1], t = fs.triples[3 * row + 2];
+        // sampling, lane-parallel: lane j of the group draws pair j of the chunk (perm -> triple -> Philox -> hash-set
+        // probe: four dependent memory round trips and ~250 scalar-style instructions, done once for the CH pairs
+        // side by side instead of redundantly in every lane, pair after pair); ids travel by shuffle
+        const int64_t i0 = ck * CH;
+        const int64_t i_end = min(n, i0 + CH);
+        int my_h = 0, my_r = 0, my_t = 0, my_c = 0, my_tail = 0;
+        if (gl < CH && i0 + gl < n) {
+            const int64_t row = fs.perm[s_start + i0 + gl];
+            const int64_t sh = fs.triples[3 * row], sr = fs.triples[3 * row + 1], st = fs.triples[3 * row + 2];
             int64_t nh, nt;
-            corrupt_one(h, r, t, fs.E, fs.bern, fs.slots, fs.mask, fs.seed, s_off + (unsigned long long)i, nh, nt);
-            const bool tail = nh == h;              // tail corrupted (else head corrupted)
-            const int64_t c = tail ? nt : nh;
+            corrupt_one(sh, sr, st, fs.E, fs.bern, fs.slots, fs.mask, fs.seed, s_off + (unsigned long long)(i0 + gl), nh, nt);
+            my_h = (int)sh; my_r = (int)sr; my_t = (int)st;
+            my_tail = nh == sh;
+            my_c = (int)(my_tail ? nt : nh);
+        }
+        const int gbase = (threadIdx.x & 63) / G * G;  // first lane of this group inside its wave
+        for (int64_t i = i0; i < i_end; ++i) {
+            const int src = gbase + (int)(i - i0);
+            const int64_t h = __shfl(my_h, src, 64), r = __shfl(my_r, src, 64), t = __shfl(my_t, src, 64);
+            const int64_t c = __shfl(my_c, src, 64);
+            const bool tail = __shfl(my_tail, src, 64) != 0;   // tail corrupted (else head corrupted)
             float H[NCH], T[NCH], C[NCH];
             load_row<G, NCH>(H, m.tab[0] + h * (int64_t)d, d, gl);
             load_row<G, NCH>(T, m.tab[0] + t * (int64_t)d, d, gl);
