@@ -291,7 +291,16 @@ __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand,
                                                  const float* __restrict__ q, int64_t e, int Kpad, float margin) {
     const float* c = cand + ((e >> 6) * Kpad) * 64 + (e & 63);
     float acc = 0.f;
-    if constexpr (XFORM == X_NONE) {
+    if constexpr (XFORM == X_NONE && FORM == F_NEGDOT) {
+        // the sweep accumulates even and odd k in the two halves of one packed register (v_pk_fma_f32) and adds the
+        // halves at the end; the same order here keeps scores bit-identical between the two kernels
+        float a0 = 0.f, a1 = 0.f;
+        for (int k = 0; k < Kpad; k += 2) {
+            a0 = fmaf(c[(int64_t)k * 64], q[k], a0);
+            a1 = fmaf(c[(int64_t)(k + 1) * 64], q[k + 1], a1);
+        }
+        acc = a0 + a1;
+    } else if constexpr (XFORM == X_NONE) {
         for (int k = 0; k < Kpad; ++k) acc = pair_step<FORM>(acc, c[(int64_t)k * 64], q[k]);
     } else {
         const float* w = q + Kpad;
@@ -403,8 +412,9 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
             const float* ca = cand + (tile * Kpad) * 64 + lane;
             const float* cb = has_b ? ca + (int64_t)Kpad * 64 : ca;
             float acca[QT], accb[QT];
+            f32x2 pa[QT], pb[QT];  // NEGDOT: packed even/odd-k accumulators
 #pragma unroll
-            for (int q = 0; q < QT; ++q) { acca[q] = 0.f; accb[q] = 0.f; }
+            for (int q = 0; q < QT; ++q) { acca[q] = 0.f; accb[q] = 0.f; pa[q] = f32x2{0.f, 0.f}; pb[q] = f32x2{0.f, 0.f}; }
             for (int k0 = 0; k0 < Kpad; k0 += KC) {
                 f32x2 va[KC / 2], vb[KC / 2];
 #pragma unroll
@@ -419,10 +429,19 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                         f32x2 qq;
                         qq.x = qrow[q][k0 + 2 * j];
                         qq.y = qrow[q][k0 + 2 * j + 1];
-                        pair_step2<FORM>(acca[q], va[j], qq);
-                        pair_step2<FORM>(accb[q], vb[j], qq);
+                        if constexpr (FORM == F_NEGDOT) {  // one v_pk_fma_f32 per k-pair: SGPR pair x VGPR pair
+                            pa[q] = __builtin_elementwise_fma(va[j], qq, pa[q]);
+                            pb[q] = __builtin_elementwise_fma(vb[j], qq, pb[q]);
+                        } else {
+                            pair_step2<FORM>(acca[q], va[j], qq);
+                            pair_step2<FORM>(accb[q], vb[j], qq);
+                        }
                     }
                 }
+            }
+            if constexpr (FORM == F_NEGDOT) {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) { acca[q] = pa[q].x + pa[q].y; accb[q] = pb[q].x + pb[q].y; }
             }
             const int64_t ea = tile * 64 + lane, eb = ea + 64;
             const bool valid_a = ea < E, valid_b = has_b && eb < E;
