@@ -291,13 +291,20 @@ __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand,
                                                  const float* __restrict__ q, int64_t e, int Kpad, float margin) {
     const float* c = cand + ((e >> 6) * Kpad) * 64 + (e & 63);
     float acc = 0.f;
-    if constexpr (XFORM == X_NONE && FORM == F_NEGDOT) {
+    if constexpr (XFORM == X_NONE && FORM != F_L1) {
         // the sweep accumulates even and odd k in the two halves of one packed register (v_pk_fma_f32) and adds the
         // halves at the end; the same order here keeps scores bit-identical between the two kernels
         float a0 = 0.f, a1 = 0.f;
         for (int k = 0; k < Kpad; k += 2) {
-            a0 = fmaf(c[(int64_t)k * 64], q[k], a0);
-            a1 = fmaf(c[(int64_t)(k + 1) * 64], q[k + 1], a1);
+            const float c0 = c[(int64_t)k * 64], c1 = c[(int64_t)(k + 1) * 64];
+            if constexpr (FORM == F_NEGDOT) {
+                a0 = fmaf(c0, q[k], a0);
+                a1 = fmaf(c1, q[k + 1], a1);
+            } else {
+                const float d0 = c0 - q[k], d1 = c1 - q[k + 1];
+                a0 = fmaf(d0, d0, a0);
+                a1 = fmaf(d1, d1, a1);
+            }
         }
         acc = a0 + a1;
     } else if constexpr (XFORM == X_NONE) {
@@ -432,6 +439,10 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                         if constexpr (FORM == F_NEGDOT) {  // one v_pk_fma_f32 per k-pair: SGPR pair x VGPR pair
                             pa[q] = __builtin_elementwise_fma(va[j], qq, pa[q]);
                             pb[q] = __builtin_elementwise_fma(vb[j], qq, pb[q]);
+                        } else if constexpr (FORM == F_L2 || FORM == F_SQM) {  // v_pk_add (sub) + v_pk_fma per k-pair
+                            const f32x2 da = va[j] - qq, db = vb[j] - qq;
+                            pa[q] = __builtin_elementwise_fma(da, da, pa[q]);
+                            pb[q] = __builtin_elementwise_fma(db, db, pb[q]);
                         } else {
                             pair_step2<FORM>(acca[q], va[j], qq);
                             pair_step2<FORM>(accb[q], vb[j], qq);
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                     }
                 }
             }
-            if constexpr (FORM == F_NEGDOT) {
+            if constexpr (FORM != F_L1) {
 #pragma unroll
                 for (int q = 0; q < QT; ++q) { acca[q] = pa[q].x + pa[q].y; accb[q] = pb[q].x + pb[q].y; }
             }
