@@ -1,0 +1,62 @@
+"""CPU restatement of the DEVICE negative sampler (pykg2vec_amd/csrc/kge_sampler_device.h) -- TEST INFRASTRUCTURE.
+
+The reference's corruption rule (data/generator.py:71-95: u > prob -> replace tail else head, redraw while the corrupted
+triple is a train triple) is kept, but its random stream (unseeded numpy MT19937 inside worker processes) cannot be:
+the device draws from Philox4x32-10 (Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11;
+the Random123 library).  This file restates that documented algorithm so that the integer outputs of `kge_corrupt` /
+`kge_sample_batch` can be checked BIT-EXACTLY: Philox is pinned by the Random123 known-answer vectors below, the rest
+(24-bit uniform, Lemire multiply-shift entity draw, packed-key set membership, redraw counter) by construction.
+"""
+import numpy as np
+
+M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+MASK32 = 0xFFFFFFFF
+
+# Random123 kat_vectors, philox4x32 with 10 rounds: (counter[4], key[2]) -> output[4]
+PHILOX_KAT = [
+    ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000),
+     (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff),
+     (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+def philox4x32_10(c, k):
+    c0, c1, c2, c3 = c
+    k0, k1 = k
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & MASK32, p1 & MASK32, ((p0 >> 32) ^ c3 ^ k1) & MASK32, p0 & MASK32
+        k0, k1 = (k0 + W0) & MASK32, (k1 + W1) & MASK32
+    return c0, c1, c2, c3
+
+
+def corrupt_one(h, r, t, E, prob, train_set, seed, ctr):
+    """One negative for slot `ctr`: Philox block `attempt` = 0, 1, ...; word 0 of block 0 picks the side
+    (u = top 24 bits / 2^24, u > prob -> tail), word 1 of each block is the candidate entity ((w * E) >> 32)."""
+    key = (seed & MASK32, (seed >> 32) & MASK32)
+    base = (ctr & MASK32, (ctr >> 32) & MASK32)
+    x = philox4x32_10(base + (0, 0), key)
+    u = np.float32(x[0] >> 8) * np.float32(1.0 / 16777216.0)
+    tail = bool(u > np.float32(prob))
+    attempt = 0
+    while True:
+        e = (x[1] * E) >> 32
+        cand = (h, r, e) if tail else (e, r, t)
+        if train_set is None or cand not in train_set:
+            return cand
+        attempt += 1
+        x = philox4x32_10(base + (attempt, 0), key)
+
+
+def corrupt(ph, pr, pt, neg_rate, E, bern_prob, train_set, seed, offset):
+    """kge_corrupt: negatives of positive i occupy slots [i*neg_rate, (i+1)*neg_rate); counter = offset + slot."""
+    nh, nr, nt = [], [], []
+    for i in range(len(ph)):
+        for k in range(neg_rate):
+            prob = 0.5 if bern_prob is None else float(bern_prob[pr[i]])
+            c = corrupt_one(int(ph[i]), int(pr[i]), int(pt[i]), E, prob, train_set, seed, offset + i * neg_rate + k)
+            nh.append(c[0]); nr.append(c[1]); nt.append(c[2])
+    return np.asarray(nh, np.int64), np.asarray(nr, np.int64), np.asarray(nt, np.int64)
