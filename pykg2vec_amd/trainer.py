@@ -232,9 +232,10 @@ class Trainer:
         num_batch = self.config.tot_train_triples // self.config.batch_size if not self.config.debug else 10
         self.generator.start_one_epoch(num_batch)
         self.model.train()
-        pairwise = self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED
         if self._graph_wanted() and num_batch > 0:
             self.loss_buf.zero_()
+            gen = self.generator
+            step0, draws0 = self.flat.step, gen._draws  # host mirrors of the device-resident counters
             done = 0
             if self._graph is None or self._graph_batches != num_batch:
                 done = self._capture_step(num_batch)
@@ -242,7 +243,9 @@ class Trainer:
                 self._cursor[3] = 0  # every epoch walks the permutation from its start (data/generator.py:28-35)
             for _ in range(num_batch - done):
                 self._graph.replay()
-            self.generator._pending = 0
+            self.flat.step = step0 + num_batch
+            gen._draws = draws0 + num_batch * gen.batch_size * gen.neg_rate
+            gen._pending = 0
         else:
             self.loss_buf.zero_()
             for _ in range(num_batch):
