@@ -113,6 +113,17 @@ int kge_train_pairwise_selfadv(const kge_model_desc* m,
                                int64_t n_pos, int32_t neg_rate, float alpha, float* workspace,
                                float* loss, void* stream);
 
+/* RotatE self-adversarial step with the negative sampler FUSED IN FRONT (one launch): positive i is
+ * triples[perm[start+i]], its neg_rate negatives are drawn with Philox counters offset + i*neg_rate + j -- the batch
+ * kge_sample_batch(start, n_pos, neg_rate, ..., seed, offset) would emit.  The positive's five rows and the relation's
+ * sin/cos stay in registers across the bundle; only the corrupting entity's two rows are gathered per negative.
+ * neg_rate <= lane-group width (32 for hidden_size <= 256, else 64). */
+int kge_train_pairwise_selfadv_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm,
+                                       int64_t start, int64_t n_pos, int32_t neg_rate, float alpha,
+                                       const float* bern_prob, const uint64_t* slots, int64_t n_slots,
+                                       uint64_t seed, uint64_t offset, const int64_t* dev_cursor,
+                                       float* loss, void* stream);
+
 /* Fused Trainer.train_step_pointwise (utils/trainer.py:176-180): Criterion.pointwise_logistic
  * (utils/criterion.py:31-34) mean(softplus(y*s)) + lmbda*get_reg (pointwise.py:106-119,190-202,224-238,448-458). */
 int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r,

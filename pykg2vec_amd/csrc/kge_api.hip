@@ -188,6 +188,21 @@ int kge_train_pairwise_selfadv(const kge_model_desc* m, const int64_t* ph, const
     return launch_score_backward(m, nh, nr, nt, n_neg, sneg, s);
 }
 
+int kge_train_pairwise_selfadv_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
+                                       int64_t n_pos, int32_t neg_rate, float alpha, const float* bern_prob,
+                                       const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset,
+                                       const int64_t* dev_cursor, float* loss, void* stream) {
+    if (validate(m, true, "kge_train_pairwise_selfadv_sampled")) return -1;
+    if (n_pos == 0) return 0;
+    if (n_pos < 0 || start < 0 || neg_rate <= 0 || !triples || !perm || !loss) {
+        set_error("kge_train_pairwise_selfadv_sampled: bad arguments");
+        return -1;
+    }
+    if (slots && (n_slots & (n_slots - 1))) { set_error("kge_train_pairwise_selfadv_sampled: n_slots must be a power of two"); return -1; }
+    return launch_rotate_bundle_sampled(m, triples, perm, start, n_pos, neg_rate, alpha, bern_prob, slots, n_slots, seed,
+                                        offset, dev_cursor, loss, (hipStream_t)stream);
+}
+
 int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                                  const int64_t* y, int64_t n, int32_t bundle, float lmbda, int32_t reg_type, float* loss,
                                  void* stream) {

@@ -32,6 +32,10 @@ int launch_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const i
 int launch_selfadv_bundle(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
                           const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n_pos, int neg_rate,
                           float alpha, float* loss, hipStream_t s);  // returns 1 when neg_rate exceeds the group width
+int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
+                                 int64_t n_pos, int neg_rate, float alpha, const float* bern, const uint64_t* slots,
+                                 int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor, float* loss,
+                                 hipStream_t s);
 int launch_selfadv_coeffs(float* pos_scores, float* neg_scores, int64_t n_pos, int neg_rate, float alpha,
                           float* loss, hipStream_t s);
 

@@ -492,6 +492,132 @@ __global__ __launch_bounds__(kBlock) void k_selfadv_bundle(DeviceModel m, const 
     block_accumulate_loss<G>(acc, gl, loss);
 }
 
+// ---- RotatE, sampler fused, shared rows loaded ONCE per bundle (config C3: d=1000, neg_rate 16).
+// A bundle = a positive (h,r,t) and its neg_rate corruptions; every negative differs from the positive in ONE entity,
+// so the five rows of the positive (h_re, h_im, rel, t_re, t_im), the sin/cos of the relation phases and the rotated
+// head h o r are computed once and stay in registers; per negative only the corrupting entity's two rows are gathered
+// (2 rows instead of 5, no sincos).  Lane j of the group draws negative j (Philox, hash-set probe) in parallel.
+// Pass 1 scores, group softmax gives the detached self-adversarial weights (criterion.py:13-23), pass 2 re-gathers the
+// two rows per negative and back-propagates; gradients of the positive's five rows accumulate in registers and are
+// scattered once per bundle.
+template <int G, int NCH>
+__global__ __launch_bounds__(kBlock) void k_rotate_bundle_sampled(DeviceModel m, int64_t n_pos, int neg_rate, float alpha,
+                                                                  float* __restrict__ loss, FusedSampler fs) {
+    constexpr int GPB = kBlock / G;
+    const int gl = threadIdx.x % G;
+    const int d = m.dim;
+    const float inv_b = 1.0f / (float)n_pos;
+    const int64_t s_start = fs.cursor ? fs.start + fs.cursor[0] : fs.start;
+    const unsigned long long s_off = fs.cursor ? fs.offset + (unsigned long long)fs.cursor[1] : fs.offset;
+    const int gbase = (threadIdx.x & 63) / G * G;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n_pos; i += (int64_t)gridDim.x * GPB) {
+        const int64_t row = fs.perm[s_start + i];
+        const int64_t h = fs.triples[3 * row], r = fs.triples[3 * row + 1], t = fs.triples[3 * row + 2];
+        int my_c = 0, my_tail = 0;  // lane j: corrupting entity and side of negative j
+        if (gl < neg_rate) {
+            int64_t nh, nt;
+            corrupt_one(h, r, t, fs.E, fs.bern, fs.slots, fs.mask, fs.seed, s_off + (unsigned long long)(i * neg_rate + gl), nh, nt);
+            my_tail = nh == h;
+            my_c = (int)(my_tail ? nt : nh);
+        }
+        float HR[NCH], HI[NCH], TR[NCH], TI[NCH], CS[NCH], SN[NCH];
+        {
+            float RL[NCH];
+            load_row<G, NCH>(HR, m.tab[0] + h * (int64_t)d, d, gl);
+            load_row<G, NCH>(HI, m.tab[1] + h * (int64_t)d, d, gl);
+            load_row<G, NCH>(RL, m.tab[2] + r * (int64_t)d, d, gl);
+            load_row<G, NCH>(TR, m.tab[0] + t * (int64_t)d, d, gl);
+            load_row<G, NCH>(TI, m.tab[1] + t * (int64_t)d, d, gl);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) sincosf(RL[k] / m.phase_div, &SN[k], &CS[k]);
+        }
+        // energy of (head rows A, tail rows B):  sum |A o r - B|^2 - margin
+        auto energy = [&](const float (&AR)[NCH], const float (&AI)[NCH], const float (&BR)[NCH], const float (&BI)[NCH]) {
+            float p = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const float re = AR[k] * CS[k] - AI[k] * SN[k] - BR[k];
+                const float im = AR[k] * SN[k] + AI[k] * CS[k] - BI[k];
+                p += re * re + im * im;
+            }
+            return -(m.margin - gsum<G>(p));
+        };
+        const float s_pos = energy(HR, HI, TR, TI);
+        float s_mine = 0.f;
+        for (int j = 0; j < neg_rate; ++j) {
+            const int64_t c = __shfl(my_c, gbase + j, 64);
+            const bool tail = __shfl(my_tail, gbase + j, 64) != 0;
+            float CR[NCH], CI[NCH];
+            load_row<G, NCH>(CR, m.tab[0] + c * (int64_t)d, d, gl);
+            load_row<G, NCH>(CI, m.tab[1] + c * (int64_t)d, d, gl);
+            const float sj = tail ? energy(HR, HI, CR, CI) : energy(CR, CI, TR, TI);
+            if (gl == j) s_mine = sj;
+        }
+        // loss and coefficients (as k_selfadv_bundle)
+        const bool live = gl < neg_rate;
+        const float nj = -s_mine;
+        float mx = live ? nj * alpha : -INFINITY;
+#pragma unroll
+        for (int o = G / 2; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float ex = live ? expf(nj * alpha - mx) : 0.f;
+        const float den = gsum<G>(ex);
+        const float wj = ex / den;
+        const float term = gsum<G>(live ? wj * logsigmoid_t(-nj) : 0.f);
+        acc += (-term - logsigmoid_t(-s_pos)) * inv_b;
+        const float c_mine = live ? -(wj * sigmoid_t(nj)) * inv_b : 0.f;
+        const float c_pos = sigmoid_t(s_pos) * inv_b;
+        // pass 2: gradient accumulators of the positive's rows; GP = gradient wrt the phase
+        float gHR[NCH], gHI[NCH], gTR[NCH], gTI[NCH], GP[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const float re = HR[k] * CS[k] - HI[k] * SN[k] - TR[k], im = HR[k] * SN[k] + HI[k] * CS[k] - TI[k];
+            const float Rr = 2.f * c_pos * re, Ii = 2.f * c_pos * im;
+            gHR[k] = Rr * CS[k] + Ii * SN[k];
+            gHI[k] = -Rr * SN[k] + Ii * CS[k];
+            gTR[k] = -Rr; gTI[k] = -Ii;
+            GP[k] = Rr * (-HR[k] * SN[k] - HI[k] * CS[k]) + Ii * (HR[k] * CS[k] - HI[k] * SN[k]);
+        }
+        for (int j = 0; j < neg_rate; ++j) {
+            const float cj = __shfl(c_mine, gbase + j, 64);
+            if (cj == 0.f) continue;
+            const int64_t c = __shfl(my_c, gbase + j, 64);
+            const bool tail = __shfl(my_tail, gbase + j, 64) != 0;
+            float CR[NCH], CI[NCH], gCR[NCH], gCI[NCH];
+            load_row<G, NCH>(CR, m.tab[0] + c * (int64_t)d, d, gl);
+            load_row<G, NCH>(CI, m.tab[1] + c * (int64_t)d, d, gl);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if (tail) {  // (h, r, c): head rows are the positive's, tail rows are C
+                    const float re = HR[k] * CS[k] - HI[k] * SN[k] - CR[k], im = HR[k] * SN[k] + HI[k] * CS[k] - CI[k];
+                    const float Rr = 2.f * cj * re, Ii = 2.f * cj * im;
+                    gCR[k] = -Rr; gCI[k] = -Ii;
+                    gHR[k] += Rr * CS[k] + Ii * SN[k];
+                    gHI[k] += -Rr * SN[k] + Ii * CS[k];
+                    GP[k] += Rr * (-HR[k] * SN[k] - HI[k] * CS[k]) + Ii * (HR[k] * CS[k] - HI[k] * SN[k]);
+                } else {     // (c, r, t): head rows are C, tail rows are the positive's
+                    const float re = CR[k] * CS[k] - CI[k] * SN[k] - TR[k], im = CR[k] * SN[k] + CI[k] * CS[k] - TI[k];
+                    const float Rr = 2.f * cj * re, Ii = 2.f * cj * im;
+                    gCR[k] = Rr * CS[k] + Ii * SN[k];
+                    gCI[k] = -Rr * SN[k] + Ii * CS[k];
+                    gTR[k] -= Rr; gTI[k] -= Ii;
+                    GP[k] += Rr * (-CR[k] * SN[k] - CI[k] * CS[k]) + Ii * (CR[k] * CS[k] - CI[k] * SN[k]);
+                }
+            }
+            atomic_add_row<G, NCH>(m.grad[0] + c * (int64_t)d, gCR, d, gl);
+            atomic_add_row<G, NCH>(m.grad[1] + c * (int64_t)d, gCI, d, gl);
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) GP[k] = GP[k] / m.phase_div;
+        atomic_add_row<G, NCH>(m.grad[0] + h * (int64_t)d, gHR, d, gl);
+        atomic_add_row<G, NCH>(m.grad[1] + h * (int64_t)d, gHI, d, gl);
+        atomic_add_row<G, NCH>(m.grad[2] + r * (int64_t)d, GP, d, gl);
+        atomic_add_row<G, NCH>(m.grad[0] + t * (int64_t)d, gTR, d, gl);
+        atomic_add_row<G, NCH>(m.grad[1] + t * (int64_t)d, gTI, d, gl);
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
+
 // ---- self-adversarial loss coefficients (criterion.py:13-23).  In: energies.  Out (in place): dL/d energy.
 __global__ __launch_bounds__(kBlock) void k_selfadv_coeffs(float* __restrict__ pos, float* __restrict__ neg,
                                                            int64_t n_pos, int neg_rate, float alpha,
@@ -649,6 +775,30 @@ int launch_selfadv_bundle(const kge_model_desc* m, const int64_t* ph, const int6
     const int64_t n = n_pos;
     KGE_DISPATCH(m->model, (k_selfadv_bundle<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, ph, pr, pt, nh, nr, nt, n_pos, neg_rate, alpha, loss)))
     set_error("kge_train_pairwise_selfadv: unsupported model %d", m->model);
+    return -1;
+}
+
+int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
+                                 int64_t n_pos, int neg_rate, float alpha, const float* bern, const uint64_t* slots,
+                                 int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor, float* loss,
+                                 hipStream_t s) {
+    Geometry geo;
+    if (!geometry_for(m, &geo)) return -1;
+    if (m->model != KGE_ROTATE) { set_error("kge_train_pairwise_selfadv_sampled: RotatE only"); return -1; }
+    if (neg_rate > geo.G) { set_error("kge_train_pairwise_selfadv_sampled: neg_rate %d exceeds the lane group (%d)", neg_rate, geo.G); return -1; }
+    if (m->tot_entity >= (1 << 24)) { set_error("fused sampler: more than 2^24 entities not supported by the packed key"); return -1; }
+    const DeviceModel dm = to_device_model(m);
+    FusedSampler fs;
+    fs.triples = triples; fs.perm = perm; fs.start = start; fs.E = m->tot_entity; fs.bern = bern;
+    fs.slots = (const unsigned long long*)slots; fs.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
+    fs.seed = seed; fs.offset = offset; fs.cursor = cursor;
+#define KGE_RB(G_, NCH_)                                                                                                      \
+    if (geo.G == G_ && geo.NCH == NCH_) {                                                                                      \
+        k_rotate_bundle_sampled<G_, NCH_><<<dim3(Launch<KGE_ROTATE, G_, NCH_>::grid(n_pos)), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs); \
+        return check_launch("k_rotate_bundle_sampled");                                                                        \
+    }
+    KGE_RB(32, 1) KGE_RB(32, 2) KGE_RB(32, 4) KGE_RB(32, 8) KGE_RB(64, 8) KGE_RB(64, 16)
+#undef KGE_RB
     return -1;
 }
 

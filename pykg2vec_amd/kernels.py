@@ -131,6 +131,20 @@ def train_pairwise_hinge_sampled(desc, triples, perm, start, n, bern_prob, slots
             "kge_train_pairwise_hinge_sampled")
 
 
+def train_pairwise_selfadv_sampled(desc, triples, perm, start, n_pos, neg_rate, alpha, bern_prob, slots, seed, offset,
+                                   loss_buf, cursor=None):
+    """RotatE: sampler + scores + self-adversarial loss + backward in ONE launch (batch == sample_batch(...))."""
+    bp = _dev(bern_prob, torch.float32, "bern_prob") if bern_prob is not None else None
+    sp = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
+    pc = _dev(cursor, torch.int64, "cursor") if cursor is not None else None
+    L.check(L.load().kge_train_pairwise_selfadv_sampled(ctypes.byref(desc), _ids(triples, "triples"), _ids(perm, "perm"),
+                                                        int(start), int(n_pos), int(neg_rate), float(alpha), bp, sp,
+                                                        slots.numel() if slots is not None else 0,
+                                                        int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), pc,
+                                                        _dev(loss_buf, torch.float32, "loss"), _stream()),
+            "kge_train_pairwise_selfadv_sampled")
+
+
 def train_pairwise_selfadv(desc, ph, pr, pt, nh, nr, nt, neg_rate, alpha, loss_buf, workspace=None):
     n = ph.numel()
     if nh.numel() != n * neg_rate:

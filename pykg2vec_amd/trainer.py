@@ -135,9 +135,20 @@ class Trainer:
                 and self.model.kernel_name not in ("rescal", "ntn") and self.model.model_name.lower() != "rotate"
                 and int(self.config.neg_rate) == 1)
 
+    def _fused_rotate_ok(self):
+        """RotatE self-adversarial step with the sampler fused in (negatives of a positive must fit one lane group)."""
+        group = 32 if self.model.hidden_size <= 256 else 64
+        return (self.K is K and self.model.model_name.lower() == "rotate" and self.model.kernel_name == "rotate"
+                and int(self.config.neg_rate) <= group)
+
     def _accumulate_next_batch(self, cursor=None, fixed_range=None):
         """One batch from the generator's stream into the gradient / loss buffers."""
         gen = self.generator
+        if self._fused_rotate_ok():
+            start, n, offset = fixed_range if fixed_range is not None else gen._next_range()
+            K.train_pairwise_selfadv_sampled(self._desc, gen.triples, gen.perm, start, n, gen.neg_rate, self.config.alpha,
+                                             gen.bern, gen.slots, gen.seed, offset, self.loss_buf, cursor=cursor)
+            return
         if self._fused_sampler_ok():
             start, n, offset = fixed_range if fixed_range is not None else gen._next_range()
             K.train_pairwise_hinge_sampled(self._desc, gen.triples, gen.perm, start, n, gen.bern, gen.slots, gen.seed,

@@ -312,3 +312,34 @@ def test_pointwise_bundle_kernel_equals_row_kernel(hip, name):
         assert np.isclose(res[0][0], other[0], rtol=1e-5)
         for a, b2 in zip(res[0][1], other[1]):
             assert np.allclose(a, b2, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("d,neg", [(40, 4), (100, 16), (1000, 16), (300, 7)])
+def test_rotate_fused_sampler_bundle_equals_sample_then_step(hip, d, neg):
+    """kge_train_pairwise_selfadv_sampled (RotatE: sampler fused, positive's rows and sin/cos kept in registers across
+    the bundle) against kge_sample_batch + kge_train_pairwise_selfadv on the same Philox stream."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.trainer import Trainer
+    rng = np.random.default_rng(d)
+    E, R, B = 400, 9, 96
+    hp = dict(hidden_size=d, margin=6.0, neg_rate=neg, alpha=0.8)
+    P = ko.init_params("rotate", rng, tot_entity=E, tot_relation=R, hidden_size=d, margin=6.0)
+    train = np.stack([rng.integers(E, size=1000), rng.integers(R, size=1000), rng.integers(E, size=1000)], 1)
+    cfg = hip.make_config(E, R, hp, train, train[:4], train[:4], batch_size=B)
+    res = []
+    for fused in (False, True):
+        m = hip.model_from_params("rotate", P, hp, E, R)
+        tr = Trainer(m, cfg, use_graph=False)
+        tr.build_model()
+        gen = tr._new_generator()
+        tr.generator = gen
+        tr.loss_buf.zero_()
+        if fused:
+            K.train_pairwise_selfadv_sampled(tr._desc, gen.triples, gen.perm, 192, B, neg, 0.8, None, gen.slots, 3, 777, tr.loss_buf)
+        else:
+            b = K.sample_batch(gen.triples, gen.perm, 192, B, neg, E, None, gen.slots, 3, 777)
+            K.train_pairwise_selfadv(tr._desc, *b, neg, 0.8, tr.loss_buf)
+        res.append((K.read_loss(tr.loss_buf).item(), [g.cpu().numpy().copy() for g in tr.flat.grad_views]))
+    assert np.isclose(res[0][0], res[1][0], rtol=2e-5), (res[0][0], res[1][0])
+    for a, b2 in zip(res[0][1], res[1][1]):
+        assert np.allclose(a, b2, atol=2e-6, rtol=2e-4), np.abs(a - b2).max()
