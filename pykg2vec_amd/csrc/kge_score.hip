@@ -271,6 +271,188 @@ __global__ __launch_bounds__(kBlock) void k_transe_pair_sampled(DeviceModel m, i
     block_accumulate_loss<G>(acc, gl, loss);
 }
 
+// ---- TransH / TransD, sampler fused, shared rows loaded once (the TransE pair kernel plus the entity projections).
+//   TransH (pairwise.py:143-182): a_X = X - (X.w^) w^          w^ = F.normalize(w_r)
+//   TransD (pairwise.py:229-278): a_X = X + (X.X_m) r_m
+// for X in {H, T, C}; the pair is then TransE on (a_H, r, a_T) / (a_H, r, a_C) or (a_C, r, a_T).  The relation-side rows
+// (r, and w_r or r_m) and their gradients are carried across the pairs of a relation run and scattered once per run;
+// each pair gathers 3 entity rows (TransD: + their 3 mapping rows) instead of 8 (12).
+template <int M, int G, int NCH, int CH>
+__global__ __launch_bounds__(kBlock) void k_transx_pair_sampled(DeviceModel m, int64_t n, float margin,
+                                                                float* __restrict__ loss, FusedSampler fs) {
+    static_assert(M == KGE_TRANSH || M == KGE_TRANSD, "TransH / TransD");
+    constexpr int GPB = kBlock / G;
+    const int gl = threadIdx.x % G;
+    const int d = m.dim;
+    const bool l1 = m.l1;
+    float acc = 0.f;
+    const int64_t s_start = fs.cursor ? fs.start + fs.cursor[0] : fs.start;
+    const unsigned long long s_off = fs.cursor ? fs.offset + (unsigned long long)fs.cursor[1] : fs.offset;
+    const int64_t nchunks = (n + CH - 1) / CH;
+    const int gbase = (threadIdx.x & 63) / G * G;
+    const float* entmap = M == KGE_TRANSD ? m.tab[2] : nullptr;
+    float* g_entmap = M == KGE_TRANSD ? m.grad[2] : nullptr;
+    for (int64_t ck = (int64_t)blockIdx.x * GPB + threadIdx.x / G; ck < nchunks; ck += (int64_t)gridDim.x * GPB) {
+        int64_t r_cur = -1;
+        float R[NCH], gRh[NCH];   // relation row, gradient wrt its normalised form
+        float P[NCH], gP[NCH];    // TransH: w^ and gradient wrt w^ ; TransD: r_m and its gradient
+        float iR = 0.f, iW = 0.f;
+        bool fR = false, fW = false, r_dirty = false;
+        auto flush_r = [&]() {
+            if (!r_dirty) return;
+            float dR = 0.f, dW = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { dR = fmaf(R[k], gRh[k], dR); dW = fmaf(P[k], gP[k], dW); }
+            gsum2<G>(dR, dW);
+            dR *= iR;
+            float gR[NCH], gW[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                gR[k] = fR ? (gRh[k] - (R[k] * iR) * dR) * iR : gRh[k] * iR;
+                if constexpr (M == KGE_TRANSH) gW[k] = fW ? (gP[k] - P[k] * dW) * iW : gP[k] * iW;  // through F.normalize(w)
+                else gW[k] = gP[k];
+            }
+            atomic_add_row<G, NCH>(m.grad[1] + r_cur * (int64_t)d, gR, d, gl);
+            atomic_add_row<G, NCH>(m.grad[M == KGE_TRANSH ? 2 : 3] + r_cur * (int64_t)d, gW, d, gl);
+            r_dirty = false;
+        };
+        const int64_t i0 = ck * CH;
+        const int64_t i_end = min(n, i0 + CH);
+        int my_h = 0, my_r = 0, my_t = 0, my_c = 0, my_tail = 0;
+        if (gl < CH && i0 + gl < n) {  // lane-parallel sampling of the chunk's pairs
+            const int64_t row = fs.perm[s_start + i0 + gl];
+            const int64_t sh = fs.triples[3 * row], sr = fs.triples[3 * row + 1], st = fs.triples[3 * row + 2];
+            int64_t nh, nt;
+            corrupt_one(sh, sr, st, fs.E, fs.bern, fs.slots, fs.mask, fs.seed, s_off + (unsigned long long)(i0 + gl), nh, nt);
+            my_h = (int)sh; my_r = (int)sr; my_t = (int)st;
+            my_tail = nh == sh;
+            my_c = (int)(my_tail ? nt : nh);
+        }
+        for (int64_t i = i0; i < i_end; ++i) {
+            const int src = gbase + (int)(i - i0);
+            const int64_t h = __shfl(my_h, src, 64), r = __shfl(my_r, src, 64), t = __shfl(my_t, src, 64);
+            const int64_t c = __shfl(my_c, src, 64);
+            const bool tail = __shfl(my_tail, src, 64) != 0;
+            float H[NCH], T[NCH], C[NCH], HM[NCH], TM[NCH], CM[NCH];
+            load_row<G, NCH>(H, m.tab[0] + h * (int64_t)d, d, gl);
+            load_row<G, NCH>(T, m.tab[0] + t * (int64_t)d, d, gl);
+            load_row<G, NCH>(C, m.tab[0] + c * (int64_t)d, d, gl);
+            if constexpr (M == KGE_TRANSD) {
+                load_row<G, NCH>(HM, entmap + h * (int64_t)d, d, gl);
+                load_row<G, NCH>(TM, entmap + t * (int64_t)d, d, gl);
+                load_row<G, NCH>(CM, entmap + c * (int64_t)d, d, gl);
+            }
+            const bool new_r = r != r_cur;  // group-uniform
+            float nR = 0.f;
+            if (new_r) {
+                flush_r();
+                r_cur = r;
+                load_row<G, NCH>(R, m.tab[1] + r * (int64_t)d, d, gl);
+                load_row<G, NCH>(P, m.tab[M == KGE_TRANSH ? 2 : 3] + r * (int64_t)d, d, gl);
+                float nW = 0.f;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) { nR = fmaf(R[k], R[k], nR); nW = fmaf(P[k], P[k], nW); gRh[k] = 0.f; gP[k] = 0.f; }
+                gsum2<G>(nR, nW);
+                nR = sqrtf(nR);
+                fR = nR > kEpsNormalize;
+                iR = 1.0f / fmaxf(nR, kEpsNormalize);
+                if constexpr (M == KGE_TRANSH) {
+                    nW = sqrtf(nW);
+                    fW = nW > kEpsNormalize;
+                    iW = 1.0f / fmaxf(nW, kEpsNormalize);
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) P[k] *= iW;  // P = w^
+                }
+            }
+            // projections
+            float pH = 0.f, pT = 0.f, pC = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if constexpr (M == KGE_TRANSH) { pH = fmaf(H[k], P[k], pH); pT = fmaf(T[k], P[k], pT); pC = fmaf(C[k], P[k], pC); }
+                else { pH = fmaf(H[k], HM[k], pH); pT = fmaf(T[k], TM[k], pT); pC = fmaf(C[k], CM[k], pC); }
+            }
+            gsum3<G>(pH, pT, pC);
+            float aH[NCH], aT[NCH], aC[NCH];
+            float nH = 0.f, nT = 0.f, nC = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if constexpr (M == KGE_TRANSH) { aH[k] = H[k] - pH * P[k]; aT[k] = T[k] - pT * P[k]; aC[k] = C[k] - pC * P[k]; }
+                else { aH[k] = H[k] + pH * P[k]; aT[k] = T[k] + pT * P[k]; aC[k] = C[k] + pC * P[k]; }
+                nH = fmaf(aH[k], aH[k], nH); nT = fmaf(aT[k], aT[k], nT); nC = fmaf(aC[k], aC[k], nC);
+            }
+            gsum3<G>(nH, nT, nC);
+            nH = sqrtf(nH); nT = sqrtf(nT); nC = sqrtf(nC);
+            const bool fH = nH > kEpsNormalize, fT = nT > kEpsNormalize, fC = nC > kEpsNormalize;
+            const float iH = 1.0f / fmaxf(nH, kEpsNormalize), iT = 1.0f / fmaxf(nT, kEpsNormalize);
+            const float iC = 1.0f / fmaxf(nC, kEpsNormalize);
+            float up[NCH], un[NCH];
+            float sp = 0.f, sn = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const float hh = aH[k] * iH, rr = R[k] * iR, tt = aT[k] * iT, cc = aC[k] * iC;
+                up[k] = hh + rr - tt;
+                un[k] = tail ? (hh + rr - cc) : (cc + rr - tt);
+                sp = l1 ? sp + fabsf(up[k]) : fmaf(up[k], up[k], sp);
+                sn = l1 ? sn + fabsf(un[k]) : fmaf(un[k], un[k], sn);
+            }
+            gsum2<G>(sp, sn);
+            if (!l1) { sp = sqrtf(sp); sn = sqrtf(sn); }
+            const float v = sp + margin - sn;
+            acc += fmaxf(v, 0.f);
+            const float coef = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);
+            if (coef == 0.f) continue;
+            const float ip = (!l1 && sp > 0.f) ? coef / sp : 0.f, in = (!l1 && sn > 0.f) ? -coef / sn : 0.f;
+            float gH[NCH], gT[NCH], gC[NCH];  // first: wrt the normalised projections; then wrt a_X; then wrt X
+            float dH = 0.f, dT = 0.f, dC = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const float gp = l1 ? (up[k] > 0.f ? coef : (up[k] < 0.f ? -coef : 0.f)) : up[k] * ip;
+                const float gn = l1 ? (un[k] > 0.f ? -coef : (un[k] < 0.f ? coef : 0.f)) : un[k] * in;
+                gRh[k] += gp + gn;
+                gH[k] = tail ? gp + gn : gp;
+                gT[k] = tail ? -gp : -(gp + gn);
+                gC[k] = tail ? -gn : gn;
+                dH = fmaf(aH[k], gH[k], dH); dT = fmaf(aT[k], gT[k], dT); dC = fmaf(aC[k], gC[k], dC);
+            }
+            r_dirty = true;
+            gsum3<G>(dH, dT, dC);
+            dH *= iH; dT *= iT; dC *= iC;
+            float qH = 0.f, qT = 0.f, qC = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {  // gradient wrt a_X, and its dot with the projection direction
+                gH[k] = fH ? (gH[k] - (aH[k] * iH) * dH) * iH : gH[k] * iH;
+                gT[k] = fT ? (gT[k] - (aT[k] * iT) * dT) * iT : gT[k] * iT;
+                gC[k] = fC ? (gC[k] - (aC[k] * iC) * dC) * iC : gC[k] * iC;
+                qH = fmaf(gH[k], P[k], qH); qT = fmaf(gT[k], P[k], qT); qC = fmaf(gC[k], P[k], qC);
+            }
+            gsum3<G>(qH, qT, qC);
+            if constexpr (M == KGE_TRANSH) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    gP[k] -= pH * gH[k] + qH * H[k] + pT * gT[k] + qT * T[k] + pC * gC[k] + qC * C[k];
+                    gH[k] -= qH * P[k]; gT[k] -= qT * P[k]; gC[k] -= qC * P[k];
+                }
+            } else {
+                float gHM[NCH], gTM[NCH], gCM[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    gP[k] += pH * gH[k] + pT * gT[k] + pC * gC[k];
+                    gHM[k] = qH * H[k]; gTM[k] = qT * T[k]; gCM[k] = qC * C[k];
+                    gH[k] += qH * HM[k]; gT[k] += qT * TM[k]; gC[k] += qC * CM[k];
+                }
+                atomic_add_row<G, NCH>(g_entmap + h * (int64_t)d, gHM, d, gl);
+                atomic_add_row<G, NCH>(g_entmap + t * (int64_t)d, gTM, d, gl);
+                atomic_add_row<G, NCH>(g_entmap + c * (int64_t)d, gCM, d, gl);
+            }
+            atomic_add_row<G, NCH>(m.grad[0] + h * (int64_t)d, gH, d, gl);
+            atomic_add_row<G, NCH>(m.grad[0] + t * (int64_t)d, gT, d, gl);
+            atomic_add_row<G, NCH>(m.grad[0] + c * (int64_t)d, gC, d, gl);
+        }
+        flush_r();
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
+
 // ---- fused pointwise step: mean(softplus(y*s)) + lmbda * mean_i(sum of squares/cubes of the rows of row i)
 template <int M, int G, int NCH>
 __global__ __launch_bounds__(kBlock) void k_pointwise_logistic(DeviceModel m, const int64_t* __restrict__ h,
@@ -741,6 +923,17 @@ int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triple
     }
         KGE_TE(32, 1) KGE_TE(32, 2) KGE_TE(32, 4) KGE_TE(32, 8) KGE_TE(64, 8) KGE_TE(64, 16)
 #undef KGE_TE
+    }
+    if (m->model == KGE_TRANSH || m->model == KGE_TRANSD) {  // shared-row specialisations with the projections
+#define KGE_TX(MID, G_, NCH_)                                                                                               \
+    if (m->model == MID && geo.G == G_ && geo.NCH == NCH_) {                                                                 \
+        k_transx_pair_sampled<MID, G_, NCH_, 4><<<dim3(Launch<MID, G_, NCH_>::grid((n + 3) / 4)), dim3(kBlock), 0, s>>>(dm, n, margin, loss, fs); \
+        return check_launch("k_transx_pair_sampled");                                                                        \
+    }
+#define KGE_TX_ALL(MID) KGE_TX(MID, 32, 1) KGE_TX(MID, 32, 2) KGE_TX(MID, 32, 4) KGE_TX(MID, 32, 8) KGE_TX(MID, 64, 8) KGE_TX(MID, 64, 16)
+        KGE_TX_ALL(KGE_TRANSH) KGE_TX_ALL(KGE_TRANSD)
+#undef KGE_TX_ALL
+#undef KGE_TX
     }
     const int64_t* z = nullptr;
     KGE_DISPATCH(m->model, (k_pairwise_hinge<M, G, NCH, true><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, z, z, z, z, z, z, n, margin, loss, fs)))

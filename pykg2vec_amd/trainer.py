@@ -137,9 +137,10 @@ class Trainer:
 
     def _fused_rotate_ok(self):
         """RotatE self-adversarial step with the sampler fused in (negatives of a positive must fit one lane group)."""
+        if not (self.K is K and self.model.model_name.lower() == "rotate" and self.model.kernel_name == "rotate"):
+            return False
         group = 32 if self.model.hidden_size <= 256 else 64
-        return (self.K is K and self.model.model_name.lower() == "rotate" and self.model.kernel_name == "rotate"
-                and int(self.config.neg_rate) <= group)
+        return int(self.config.neg_rate) <= group
 
     def _accumulate_next_batch(self, cursor=None, fixed_range=None):
         """One batch from the generator's stream into the gradient / loss buffers."""

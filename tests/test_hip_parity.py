@@ -266,7 +266,7 @@ def test_graph_replayed_epochs_equal_eager_epochs(hip, name, opt):
         assert np.allclose(p0[k], p1[k], atol=2e-4, rtol=1e-3), (k, np.abs(p0[k] - p1[k]).max())
 
 
-@pytest.mark.parametrize("name", ["transe_l1", "transe_l2", "transh_l1", "transd_l2"])
+@pytest.mark.parametrize("name", ["transe_l1", "transe_l2", "transh_l1", "transh_l2", "transd_l1", "transd_l2"])
 def test_fused_sampler_step_equals_sample_then_step(hip, name):
     """kge_train_pairwise_hinge_sampled (corruption fused into the scoring kernel) must see exactly the batch
     kge_sample_batch emits for the same (start, n, seed, offset): same loss, same gradients."""
