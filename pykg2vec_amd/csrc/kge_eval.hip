@@ -82,6 +82,7 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p)
 }
 
 size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n) {
+    if (m->model == KGE_NTN) return ntn_eval_workspace_bytes(m, n);
     EvalPlan p;
     if (!make_plan(m, n, nullptr, &p)) return 0;
     return p.bytes;
@@ -683,12 +684,15 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
 int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
                       const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
                       size_t ws_bytes, int32_t* ranks, hipStream_t s) {
+    if (m->model == KGE_NTN)
+        return launch_ntn_eval_ranks(m, triples, n, tail_off, tail_ids, head_off, head_ids, ws, ws_bytes, ranks, s);
     return run_pipeline(m, triples, n, tail_off, tail_ids, head_off, head_ids, ws, ws_bytes, ranks, nullptr, s);
 }
 
 // scores: float [2n, E]: row 2i = tail-sweep energies of triple i, row 2i+1 = head-sweep energies
 int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
                              float* scores, hipStream_t s) {
+    if (m->model == KGE_NTN) return launch_ntn_eval_scores(m, triples, n, ws, ws_bytes, scores, s);
     return run_pipeline(m, triples, n, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, nullptr, scores, s);
 }
 

@@ -69,6 +69,14 @@ int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, in
 int launch_rank_from_scores(const float* scores, int64_t nq, int64_t E, const int64_t* truth, const int64_t* off,
                             const int32_t* ids, int32_t* rank, int32_t* frank, hipStream_t s);
 
+// kge_ntn_eval.hip
+size_t ntn_eval_workspace_bytes(const kge_model_desc* m, int64_t n);
+int launch_ntn_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
+                          const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
+                          size_t ws_bytes, int32_t* ranks, hipStream_t s);
+int launch_ntn_eval_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
+                           float* scores, hipStream_t s);
+
 // kge_sampler.hip
 int launch_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, int64_t n_slots, hipStream_t s);
 int launch_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t n_pos, int neg_rate,

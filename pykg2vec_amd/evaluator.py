@@ -171,8 +171,6 @@ class Evaluator:
             # the reference's forward renormalises both tables during eval too (pairwise.py:843-844)
             self.K.rescal_normalize(self.model.ent_embeddings.weight.data, self.model.rel_matrices.weight.data,
                                     self.model.hidden_size)
-        if getattr(self.model, "kernel_name", None) == "ntn":  # no pre-contracted sweep form yet: batch scorer over E
-            return self.K.eval_ranks_via_forward(self.K.model_desc(self.model), trip, t_off, t_ids, h_off, h_ids)
         return self.K.eval_ranks(self.K.model_desc(self.model), trip, t_off, t_ids, h_off, h_ids)
 
     def test(self, data, num_of_test, epoch=None):

@@ -72,12 +72,6 @@ class Model:
     def _sweep(self, h, r, t):
         """float32 [2, E]: energies of (h, r, e) and of (e, r, t) for every entity e."""
         h0, r0, t0 = h.view(-1)[0], r.view(-1)[0], t.view(-1)[0]
-        if self.kernel_name == "ntn":  # no pre-contracted sweep form: every candidate triple through the batch scorer
-            E = self.tot_entity
-            ents = torch.arange(E, dtype=torch.int64, device=h.device)
-            desc = self.make_desc()
-            return torch.stack([K.score_forward(desc, h0.expand(E).contiguous(), r0.expand(E).contiguous(), ents),
-                                K.score_forward(desc, ents, r0.expand(E).contiguous(), t0.expand(E).contiguous())])
         trip = torch.stack([h0, r0, t0]).view(1, 3).contiguous()
         return K.eval_sweep_scores(self.make_desc(), trip)
 

@@ -113,9 +113,6 @@ def test_eval_sweep_scores_and_ranks_match_reference(hip, name):
     if c.model == "rescal":
         m.normalize_tables()  # the reference's forward renormalises the tables before every sweep (pairwise.py:843-844)
     def sweep_scores(trips):
-        if c.model == "ntn":  # served by the batch scorer over all candidates (no pre-contracted sweep form yet)
-            rows = [m._sweep(*[hip.dev([int(v)]) for v in tr]) for tr in trips]
-            return torch.cat(rows).cpu().numpy()
         return K.eval_sweep_scores(m.make_desc(), hip.dev(trips)).cpu().numpy()
 
     sw = sweep_scores(c.test[:4])
@@ -343,3 +340,30 @@ def test_rotate_fused_sampler_bundle_equals_sample_then_step(hip, d, neg):
     assert np.isclose(res[0][0], res[1][0], rtol=2e-5), (res[0][0], res[1][0])
     for a, b2 in zip(res[0][1], res[1][1]):
         assert np.allclose(a, b2, atol=2e-6, rtol=2e-4), np.abs(a - b2).max()
+
+
+@pytest.mark.parametrize("d,kr,E", [(40, 33, 300), (100, 100, 517), (8, 4, 65)])
+def test_ntn_mfma_sweep_equals_batch_scorer_sweep(hip, d, kr, E):
+    """The pre-contracted NTN sweep (one [E,d]x[d,k_r] f32-MFMA GEMM per query) against ranking every candidate triple
+    through the batch scorer as the reference does (utils/evaluator.py:254-272)."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.evaluator import build_filter_csr
+    rng = np.random.default_rng(E)
+    R = 7
+    hp = dict(ent_hidden_size=d, rel_hidden_size=kr, lmbda=0.1, margin=1.0)
+    P = ko.init_params("ntn", rng, tot_entity=E, tot_relation=R, ent_hidden_size=d, rel_hidden_size=kr)
+    m = hip.model_from_params("ntn", P, hp, E, R)
+    n = 300  # > one chunk of 256 triples
+    test = np.stack([rng.integers(E, size=n), rng.integers(R, size=n), rng.integers(E, size=n)], 1)
+    hr_t, tr_h = ko.build_filters(test)
+    csr = [hip.dev(a, torch.int64 if i % 2 == 0 else torch.int32) for i, a in enumerate(build_filter_csr(test, hr_t, tr_h))]
+    trip = hip.dev(test)
+    desc = m.make_desc()
+    fast = K.eval_ranks(desc, trip, *csr).cpu().numpy()
+    slow = K.eval_ranks_via_forward(desc, trip, *csr).cpu().numpy()
+    assert (fast != slow).sum() <= 4 and np.abs(fast - slow).max() <= 1, (fast != slow).sum()
+    sw = K.eval_sweep_scores(desc, trip[:3].contiguous()).cpu().numpy()
+    for i in range(3):
+        h, r, t = map(int, test[i])
+        assert np.allclose(sw[2 * i], ko.sweep_scores("ntn", P, h, r, t, "tail"), atol=2e-5, rtol=2e-5)
+        assert np.allclose(sw[2 * i + 1], ko.sweep_scores("ntn", P, h, r, t, "head"), atol=2e-5, rtol=2e-5)
