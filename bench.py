@@ -252,6 +252,26 @@ def main():
     eval_ach = eval_alg / (eval_kern_ms * 1e-3) / 1e9
     mean_rank = float(ranks[:2].float().mean().item()) + 1.0
 
+    # ---- the reference's DEFAULT batch (B=128, common.py:48) through Trainer.train_model_epoch: the launch-bound
+    # regime, replayed as a hipGraph (N=1 only; informational, not `value`)
+    small = None
+    if world == 1:
+        cfg_s = make_config(train, valid, test, 128, device, 0)
+        cfg_s.knowledge_graph = cfg.knowledge_graph
+        cfg_s.tot_train_triples = 128 * 400
+        torch.manual_seed(0)
+        tr_s = Trainer(pw.TransE(**cfg_s.__dict__), cfg_s)
+        tr_s.build_model()
+        tr_s.generator = tr_s._new_generator()
+        tr_s.train_model_epoch(0)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        tr_s.train_model_epoch(1)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - ts) / 400
+        small = {"batch": 128, "value": 256 / dts, "unit": "scored triples/s", "ms_per_step": dts * 1e3,
+                 "mode": "hipGraph replay of advance+fused step+Adam" if tr_s._graph is not None else "eager"}
+
     out = None
     traffic, traffic_src = pmc_traffic("kge::k_transe_pair_sampled<32, 4, 4>", per_rank_batch)
     if rank == 0:
@@ -277,6 +297,8 @@ def main():
                                           "reused by 16 queries from registers, so the sweep is VALU-bound and the "
                                           "algorithmic rate may exceed the HBM peak"}},
         }
+        if small is not None:
+            out["train_reference_default_batch"] = small
         if world == 1 and not args.no_cpu_baseline:
             v, cores, sample = cpu_baseline_train(train)
             P_np = {"ent_embeddings": model.ent_embeddings.weight.detach().cpu().numpy(),
