@@ -918,7 +918,10 @@ int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triple
     if (m->model == KGE_TRANSE) {  // shared-row specialisation: 4 row gathers / scatters per pair instead of 6
 #define KGE_TE(G_, NCH_)                                                                                                   \
     if (geo.G == G_ && geo.NCH == NCH_) {                                                                                   \
-        k_transe_pair_sampled<G_, NCH_, 4><<<dim3(Launch<KGE_TRANSE, G_, NCH_>::grid((n + 3) / 4)), dim3(kBlock), 0, s>>>(dm, n, margin, loss, fs); \
+        if (n >= 16384)  /* big batch: 4 pairs per group share the relation row; small batch: one pair per group */ \
+            k_transe_pair_sampled<G_, NCH_, 4><<<dim3(Launch<KGE_TRANSE, G_, NCH_>::grid((n + 3) / 4)), dim3(kBlock), 0, s>>>(dm, n, margin, loss, fs); \
+        else                                                                                                                \
+            k_transe_pair_sampled<G_, NCH_, 1><<<dim3(Launch<KGE_TRANSE, G_, NCH_>::grid(n)), dim3(kBlock), 0, s>>>(dm, n, margin, loss, fs); \
         return check_launch("k_transe_pair_sampled");                                                                       \
     }
         KGE_TE(32, 1) KGE_TE(32, 2) KGE_TE(32, 4) KGE_TE(32, 8) KGE_TE(64, 8) KGE_TE(64, 16)
