@@ -243,9 +243,10 @@ def rank_from_scores(scores, truth, off, ids):
 
 
 def eval_ranks_via_forward(desc, triples, tail_off, tail_ids, head_off, head_ids, chunk=64):
-    """kge_eval_ranks for models without a pre-contracted sweep form (NTN): like the reference
-    (utils/evaluator.py:254-272) every candidate triple goes through the batch scorer -- on the device, `chunk`
-    test triples x E candidates per kge_score_forward call -- then kge_rank_from_scores.  int32 [4, n]."""
+    """The reference's own evaluation algorithm (utils/evaluator.py:254-272) on the device: every candidate triple
+    goes through the batch scorer, `chunk` test triples x E candidates per kge_score_forward call, then
+    kge_rank_from_scores.  Works for every model; kept as an independent cross-check of the sweep kernels (it is what
+    tests compare the NTN MFMA sweep with).  int32 [4, n]."""
     n = triples.shape[0]
     E = desc.tot_entity
     dev = triples.device
