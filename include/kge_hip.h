@@ -65,8 +65,8 @@ int kge_abi_version(void);
 const char* kge_last_error(void);
 
 /* Scratch bytes the score / train entry points need for a call on n rows (n pairs for the pairwise step).
- * 0 for the gather-type models; RESCAL groups the batch by relation on the device and needs
- * (4*(R+1) + n + 8) ints (+ 2n floats for the hinge step). */
+ * 0 for the gather-type models; RESCAL groups the batch by relation on the device ((4*(R+1) + n + 8) ints per side),
+ * NTN keeps n*(4d + 3k_r + 6) floats of intermediates per side; the hinge step adds 2n floats. */
 size_t kge_workspace_bytes(const kge_model_desc* m, int64_t n);
 
 /* Model.forward(h, r, t) -> energies[n]   (pairwise.py:56-76,166-174,270-278,786-791,855-860,955-960;

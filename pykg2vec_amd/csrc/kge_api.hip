@@ -92,7 +92,8 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t kge_workspace_bytes(const kge_model_desc* m, int64_t n) {
     if (validate(m, false, "kge_workspace_bytes") || n < 0) return 0;
     if (is_vector_model(m->model)) return 0;
-    return align256(dense_workspace_bytes(m, n)) + align256((size_t)2 * n * sizeof(float));
+    // the pairwise step keeps one scorer workspace per side (positive / negative) plus the two score vectors
+    return 2 * align256(dense_workspace_bytes(m, n)) + align256((size_t)2 * n * sizeof(float));
 }
 
 int kge_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
@@ -113,7 +114,7 @@ int kge_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t*
     if (n < 0 || !h || !r || !t || !dscore) { set_error("kge_score_backward: bad arguments"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     if (m->model == KGE_RESCAL) return launch_rescal_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, s);
-    if (m->model == KGE_NTN) return launch_ntn_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, s);
+    if (m->model == KGE_NTN) return launch_ntn_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, false, s);
     return launch_score_backward(m, h, r, t, n, dscore, s);
 }
 
@@ -132,18 +133,24 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
     if (is_vector_model(m->model)) return launch_pairwise_hinge(m, ph, pr, pt, nh, nr, nt, n, margin, loss, s);
     // dense-contraction models: forward(+), forward(-), hinge coefficients in place, backward(+), backward(-)
     const size_t gws = align256(dense_workspace_bytes(m, n));
-    if (!workspace || workspace_bytes < gws + align256((size_t)2 * n * sizeof(float))) {
+    if (!workspace || workspace_bytes < 2 * gws + align256((size_t)2 * n * sizeof(float))) {
         set_error("kge_train_pairwise_hinge: workspace too small (need kge_workspace_bytes)");
         return -1;
     }
-    float* sp = (float*)((char*)workspace + gws);
+    void* wsp = workspace;                       // scorer workspace of the positives ...
+    void* wsn = (char*)workspace + gws;          // ... and of the negatives (NTN: the forward's intermediates stay here)
+    float* sp = (float*)((char*)workspace + 2 * gws);
     float* sn = sp + n;
     int rc;
-    if ((rc = kge_score_forward(m, ph, pr, pt, n, sp, workspace, gws, stream))) return rc;
-    if ((rc = kge_score_forward(m, nh, nr, nt, n, sn, workspace, gws, stream))) return rc;
+    if ((rc = kge_score_forward(m, ph, pr, pt, n, sp, wsp, gws, stream))) return rc;
+    if ((rc = kge_score_forward(m, nh, nr, nt, n, sn, wsn, gws, stream))) return rc;
     if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
-    if ((rc = kge_score_backward(m, ph, pr, pt, n, sp, workspace, gws, stream))) return rc;
-    return kge_score_backward(m, nh, nr, nt, n, sn, workspace, gws, stream);
+    if (m->model == KGE_NTN) {
+        if ((rc = launch_ntn_backward(m, ph, pr, pt, n, sp, wsp, gws, true, s))) return rc;
+        return launch_ntn_backward(m, nh, nr, nt, n, sn, wsn, gws, true, s);
+    }
+    if ((rc = kge_score_backward(m, ph, pr, pt, n, sp, wsp, gws, stream))) return rc;
+    return kge_score_backward(m, nh, nr, nt, n, sn, wsn, gws, stream);
 }
 
 int kge_train_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,

@@ -51,7 +51,7 @@ int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int6
 int launch_ntn_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                        int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_ntn_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                        int64_t n, const float* dscore, void* ws, size_t ws_bytes, hipStream_t s);
+                        int64_t n, const float* dscore, void* ws, size_t ws_bytes, bool forward_in_ws, hipStream_t s);
 int launch_hinge_coeffs(float* pos, float* neg, int64_t n, float margin, float* loss, hipStream_t s);
 
 // kge_opt.hip

@@ -18,7 +18,7 @@ namespace kge {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int NT = 32;       // triples per tile
-constexpr int SPW = 4;       // slices per wave in the bilinear backward
+constexpr int SPW = 1;       // slices per wave in the bilinear backward (1: most parallelism; the batch is small)
 
 struct NtnWs {
     float *Hn, *Tn, *Rn, *inv, *flag, *Z, *GZ, *GH, *GT;
@@ -377,12 +377,14 @@ int launch_ntn_forward(const kge_model_desc* m, const int64_t* h, const int64_t*
 }
 
 int launch_ntn_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
-                        const float* dscore, void* ws, size_t ws_bytes, hipStream_t s) {
+                        const float* dscore, void* ws, size_t ws_bytes, bool forward_in_ws, hipStream_t s) {
     if (ntn_check(m, n, ws, ws_bytes)) return -1;
     const int d = m->dim, kr = m->rel_dim;
     const NtnWs w = ntn_carve(ws, n, d, kr);
-    int rc = ntn_forward_core(m, h, r, t, n, w, nullptr, s);  // recompute H^, T^, R^, z
-    if (rc) return rc;
+    if (!forward_in_ws) {  // recompute H^, T^, R^, z  (the fused train step keeps the forward's workspace instead)
+        int rc = ntn_forward_core(m, h, r, t, n, w, nullptr, s);
+        if (rc) return rc;
+    }
     const unsigned rows4 = (unsigned)((n + 3) / 4), tiles = (unsigned)((n + NT - 1) / NT);
     hipLaunchKernelGGL(k_ntn_gz, dim3(rows4), dim3(256), (size_t)4 * kr * sizeof(float), s, m->tables[2], m->tables[3], r,
                        dscore, m->grads[1], n, d, kr, w);
