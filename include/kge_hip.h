@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 1
-#define KGE_MAX_TABLES 6
+#define KGE_ABI_VERSION 2
+#define KGE_MAX_TABLES 12
 
 /* model ids; tables[] order == the reference's `parameter_list` order */
 enum kge_model {
@@ -40,13 +40,21 @@ enum kge_model {
     KGE_NTN = 5,      /* pairwise.py:868-963  ent, rel, mr1, mr2, br, mr */
     KGE_DISTMULT = 6, /* pointwise.py:391-458 ent_embeddings, rel_embeddings */
     KGE_COMPLEX = 7,  /* pointwise.py:122-238 ent_real, ent_img, rel_real, rel_img (also ComplexN3) */
-    KGE_ANALOGY = 8   /* pointwise.py:13-119  ent, rel, ent_real, ent_img, rel_real, rel_img */
+    KGE_ANALOGY = 8,  /* pointwise.py:13-119  ent, rel, ent_real, ent_img, rel_real, rel_img */
+    KGE_TRANSM = 9,   /* pairwise.py:281-365  ent_embeddings, rel_embeddings, theta[R] (fixed per-relation weight, no grad) */
+    KGE_CP = 10,      /* pointwise.py:320-387 sub_embeddings, rel_embeddings, obj_embeddings */
+    KGE_SIMPLE = 11,  /* pointwise.py:461-546 ent_head, ent_tail, rel, rel_inv; energy = -clamp(<h,r,t> + <t,r_inv,h>/2, +-20) */
+    KGE_SIMPLE_IGNR = 12, /* pointwise.py:549-592 same tables; energy = -clamp(<h,r,t> + <t,r_inv,h>, +-20) */
+    KGE_QUATE = 13    /* pointwise.py:595-768 ent_s, ent_x, ent_y, ent_z, rel_s, rel_x, rel_y, rel_z (rel_w is unused by forward) */
 };
 
 #define KGE_FLAG_L1 1u /* l1_flag of TransE/TransH/TransD (pairwise.py:72-76) */
 
 enum kge_optimizer { KGE_OPT_SGD = 0, KGE_OPT_ADAM = 1, KGE_OPT_ADAGRAD = 2, KGE_OPT_RMSPROP = 3 };
-enum kge_reg { KGE_REG_NONE = 0, KGE_REG_F2 = 1, KGE_REG_N3 = 2, KGE_REG_N3_ABS = 3 };
+/* F2 / N3 / N3_ABS: lmbda * mean_i(sum x^2 | x^3 | |x|^3 over the rows gathered for row i) (pointwise.py get_reg's).
+ * ID_F2 / ID_N3: SimplE.get_reg as the reference executes it (pointwise.py:528-536) -- it is handed the ID tensors, so
+ * the term is the constant lmbda * sum_i(h_i^p + r_i^p + t_i^p) in float32: added to the loss, no gradient. */
+enum kge_reg { KGE_REG_NONE = 0, KGE_REG_F2 = 1, KGE_REG_N3 = 2, KGE_REG_N3_ABS = 3, KGE_REG_ID_F2 = 4, KGE_REG_ID_N3 = 5 };
 
 typedef struct kge_model_desc {
     int32_t model;              /* enum kge_model */

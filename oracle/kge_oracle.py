@@ -41,17 +41,36 @@ PARAM_NAMES = {
     "complexn3": ["ent_embeddings_real", "ent_embeddings_img", "rel_embeddings_real", "rel_embeddings_img"],
     "analogy": ["ent_embeddings", "rel_embeddings", "ent_embeddings_real", "ent_embeddings_img",
                 "rel_embeddings_real", "rel_embeddings_img"],
+    # pairwise.py:299-320 ; pointwise.py:339-356,481-500,620-676
+    "transm": ["ent_embeddings", "rel_embeddings"],
+    "cp": ["sub_embeddings", "rel_embeddings", "obj_embeddings"],
+    "simple": ["ent_head_embeddings", "ent_tail_embeddings", "rel_embeddings", "rel_inv_embeddings"],
+    "simple_ignr": ["ent_head_embeddings", "ent_tail_embeddings", "rel_embeddings", "rel_inv_embeddings"],
+    "quate": ["ent_s_embedding", "ent_x_embedding", "ent_y_embedding", "ent_z_embedding",
+              "rel_s_embedding", "rel_x_embedding", "rel_y_embedding", "rel_z_embedding", "rel_w_embedding"],
 }
-PAIRWISE = ("transe", "transh", "transd", "rotate", "rescal", "ntn")
-POINTWISE = ("distmult", "complex", "complexn3", "analogy")
+PAIRWISE = ("transe", "transh", "transd", "rotate", "rescal", "ntn", "transm")
+POINTWISE = ("distmult", "complex", "complexn3", "analogy", "cp", "simple", "simple_ignr", "quate")
 
 
 def param_shapes(model, tot_entity, tot_relation, hidden_size=None, ent_hidden_size=None,
                  rel_hidden_size=None):
     """Table shapes as the reference constructors allocate them."""
     E, R, k = tot_entity, tot_relation, hidden_size
-    if model in ("transe", "distmult"):
+    if model in ("transe", "distmult", "transm"):
         return {"ent_embeddings": (E, k), "rel_embeddings": (R, k)}
+    if model == "cp":
+        return {"sub_embeddings": (E, k), "rel_embeddings": (R, k), "obj_embeddings": (E, k)}
+    if model in ("simple", "simple_ignr"):
+        return {"ent_head_embeddings": (E, k), "ent_tail_embeddings": (E, k), "rel_embeddings": (R, k),
+                "rel_inv_embeddings": (R, k)}
+    if model == "quate":
+        # the reference re-assigns the four rel_{s,x,y,z} tables from _quaternion_init(tot_entity, k), so they
+        # carry tot_entity rows (pointwise.py:653-657); rel_w keeps [R, k] and is not used by forward
+        out = {"ent_%s_embedding" % c: (E, k) for c in "sxyz"}
+        out.update({"rel_%s_embedding" % c: (E, k) for c in "sxyz"})
+        out["rel_w_embedding"] = (R, k)
+        return out
     if model == "transh":
         return {"ent_embeddings": (E, k), "rel_embeddings": (R, k), "w": (R, k)}
     if model == "transd":
@@ -203,7 +222,49 @@ def score(model, params, h, r, t, dtype=np.float32, **hp):
                             P["ent_embeddings_real"][t], P["ent_embeddings_img"][t])
         dm = -np.sum(P["ent_embeddings"][h] * P["rel_embeddings"][r] * P["ent_embeddings"][t], axis=-1)
         return cs + dm
+    if model == "transm":  # pairwise.py:325-347: theta_r * TransE distance; hp["theta"] = transm_theta(train, R)
+        s, _ = _trans_tail(P["ent_embeddings"][h], P["rel_embeddings"][r], P["ent_embeddings"][t], hp["l1_flag"])
+        return np.asarray(hp["theta"], dtype=dtype)[r] * s
+    if model == "cp":  # pointwise.py:374-376
+        return -np.sum(P["sub_embeddings"][h] * P["rel_embeddings"][r] * P["obj_embeddings"][t], axis=-1)
+    if model in ("simple", "simple_ignr"):  # pointwise.py:522-526, 581-585
+        return -np.clip(_simple_init(model, P, h, r, t, dtype), dtype(-20), dtype(20))
+    if model == "quate":  # pointwise.py:683-700
+        H, T, Rn = _quate_rows(P, h, r, t)
+        a, b, c, d = _hamilton(H, Rn)
+        return -np.sum(a * T[0] + b * T[1] + c * T[2] + d * T[3], axis=-1)
     raise KeyError(model)
+
+
+def transm_theta(train_triples, tot_relation):
+    """TransM's fixed per-relation weight (pairwise.py:303-315).  rel_head / rel_tail are LISTS there (one entry per
+    train triple, duplicates kept), so both lengths equal the relation's triple count c:
+    theta_r = 1 / log(2 + c/(1+c) + c/(1+c)), computed in float64 then cast to float32."""
+    cnt = np.bincount(np.asarray(train_triples)[:, 1], minlength=tot_relation).astype(np.float64)
+    return (1.0 / np.log(2.0 + cnt / (1.0 + cnt) + cnt / (1.0 + cnt))).astype(np.float32)
+
+
+def _simple_init(model, P, h, r, t, dtype):
+    a = np.sum(P["ent_head_embeddings"][h] * P["rel_embeddings"][r] * P["ent_tail_embeddings"][t], axis=-1)
+    b = np.sum(P["ent_head_embeddings"][t] * P["rel_inv_embeddings"][r] * P["ent_tail_embeddings"][h], axis=-1)
+    # SimplE: operator precedence halves only the inverse term (pointwise.py:525); SimplE_ignr sums the
+    # concatenated [k | k] vectors, i.e. no halving (pointwise.py:584)
+    return a + b / dtype(2.0) if model == "simple" else a + b
+
+
+def _quate_rows(P, h, r, t):
+    H = [P["ent_%s_embedding" % c][h] for c in "sxyz"]
+    T = [P["ent_%s_embedding" % c][t] for c in "sxyz"]
+    Rr = [P["rel_%s_embedding" % c][r] for c in "sxyz"]
+    den = np.sqrt(Rr[0] ** 2 + Rr[1] ** 2 + Rr[2] ** 2 + Rr[3] ** 2)
+    return H, T, [x / den for x in Rr]
+
+
+def _hamilton(H, Rn):
+    hs, hx, hy, hz = H
+    ps, px, py, pz = Rn
+    return (hs * ps - hx * px - hy * py - hz * pz, hs * px + ps * hx + hy * pz - py * hz,
+            hs * py + ps * hy + hz * px - pz * hx, hs * pz + ps * hz + hx * py - px * hy)
 
 
 def _complex_score(hr_, hi_, rr, ri, tr_, ti_):
@@ -334,6 +395,47 @@ def score_grad(model, params, h, r, t, ds, dtype=np.float32, **hp):
             eh, er, et = P["ent_embeddings"][h], P["rel_embeddings"][r], P["ent_embeddings"][t]
             add("ent_embeddings", h, er * et * nds); add("rel_embeddings", r, eh * et * nds)
             add("ent_embeddings", t, eh * er * nds)
+    elif model == "transm":
+        a, b, c = P["ent_embeddings"][h], P["rel_embeddings"][r], P["ent_embeddings"][t]
+        s, saved = _trans_tail(a, b, c, hp["l1_flag"])
+        ga, gb, gc = _trans_tail_bwd(a, b, c, saved, s, ds * np.asarray(hp["theta"], dtype=dtype)[r], hp["l1_flag"])
+        add("ent_embeddings", h, ga); add("rel_embeddings", r, gb); add("ent_embeddings", t, gc)
+    elif model == "cp":
+        eh, er, et = P["sub_embeddings"][h], P["rel_embeddings"][r], P["obj_embeddings"][t]
+        nds = -ds[:, None]
+        add("sub_embeddings", h, er * et * nds); add("rel_embeddings", r, eh * et * nds)
+        add("obj_embeddings", t, eh * er * nds)
+    elif model in ("simple", "simple_ignr"):
+        init = _simple_init(model, P, h, r, t, dtype)
+        inside = (init >= -20) & (init <= 20)  # torch.clamp passes the gradient on the closed interval
+        g1 = np.where(inside, -ds, 0).astype(dtype)[:, None]
+        g2 = g1 / dtype(2.0) if model == "simple" else g1
+        h1, h2 = P["ent_head_embeddings"][h], P["ent_head_embeddings"][t]
+        r1, r2 = P["rel_embeddings"][r], P["rel_inv_embeddings"][r]
+        t1, t2 = P["ent_tail_embeddings"][t], P["ent_tail_embeddings"][h]
+        add("ent_head_embeddings", h, r1 * t1 * g1); add("rel_embeddings", r, h1 * t1 * g1)
+        add("ent_tail_embeddings", t, h1 * r1 * g1)
+        add("ent_head_embeddings", t, r2 * t2 * g2); add("rel_inv_embeddings", r, h2 * t2 * g2)
+        add("ent_tail_embeddings", h, h2 * r2 * g2)
+    elif model == "quate":
+        H, T, Rn = _quate_rows(P, h, r, t)
+        hs, hx, hy, hz = H
+        ts, tx, ty, tz = T
+        ps, px, py, pz = Rn
+        g = -ds[:, None]
+        for c, v in zip("sxyz", _hamilton(H, Rn)):
+            add("ent_%s_embedding" % c, t, v * g)
+        add("ent_s_embedding", h, (ps * ts + px * tx + py * ty + pz * tz) * g)
+        add("ent_x_embedding", h, (-px * ts + ps * tx - pz * ty + py * tz) * g)
+        add("ent_y_embedding", h, (-py * ts + pz * tx + ps * ty - px * tz) * g)
+        add("ent_z_embedding", h, (-pz * ts - py * tx + px * ty + ps * tz) * g)
+        gp = [(hs * ts + hx * tx + hy * ty + hz * tz) * g, (-hx * ts + hs * tx + hz * ty - hy * tz) * g,
+              (-hy * ts - hz * tx + hs * ty + hx * tz) * g, (-hz * ts + hy * tx - hx * ty + hs * tz) * g]
+        raw = [P["rel_%s_embedding" % c][r] for c in "sxyz"]
+        den = np.sqrt(raw[0] ** 2 + raw[1] ** 2 + raw[2] ** 2 + raw[3] ** 2)
+        dot = ps * gp[0] + px * gp[1] + py * gp[2] + pz * gp[3]
+        for c, pc, gc_ in zip("sxyz", Rn, gp):
+            add("rel_%s_embedding" % c, r, (gc_ - pc * dot) / den)
     else:
         raise KeyError(model)
     return G
@@ -392,13 +494,33 @@ def pointwise_reg(model, params, h, r, t, lmbda, reg_type=None, dtype=np.float32
     P = _cast(params, dtype)
     h, r, t = _idx(h), _idx(r), _idx(t)
     if reg_type is None:
-        reg_type = "N3" if model == "complexn3" else "F2"
+        reg_type = "N3" if model in ("complexn3", "cp", "quate") else "F2"
     reg_type = reg_type.lower()
-    use_abs = model == "complexn3"
+    use_abs = model in ("complexn3", "quate")
     N = dtype(h.shape[0])
     G = {k: np.zeros_like(v) for k, v in P.items()}
     total = np.zeros(h.shape[0], dtype=dtype)
-    if model == "distmult":
+    if model in ("simple", "simple_ignr"):
+        # SimplE.get_reg (pointwise.py:528-536) is handed the ID tensors and regularises THEM:
+        # lmbda * (sum(h^2) + sum(r^2) + sum(t^2)) in float32 ("mean" of a 0-d tensor) -- a constant, no gradient
+        p = 2 if reg_type == "f2" else 3
+        tot = sum(np.sum(np.asarray(x, dtype=np.float32) ** p, dtype=np.float32) for x in (h, r, t))
+        return dtype(dtype(lmbda) * dtype(tot)), G
+    if model == "quate":
+        # QuatE.get_reg (pointwise.py:702-736): lmbda * sum over the 12 gathered rows-sets of mean over ALL B*k
+        # elements of |x|^p
+        p = 2 if reg_type == "f2" else 3
+        lam, cnt, reg = dtype(lmbda), dtype(h.shape[0] * P["ent_s_embedding"].shape[1]), dtype(0)
+        for names, idx in (((("ent_%s_embedding" % c) for c in "sxyz"), h), ((("ent_%s_embedding" % c) for c in "sxyz"), t),
+                           ((("rel_%s_embedding" % c) for c in "sxyz"), r)):
+            for name in names:
+                x = P[name][idx]
+                reg += np.mean(np.abs(x) ** p, dtype=dtype)
+                np.add.at(G[name], idx, (p * lam / cnt) * np.sign(x) * np.abs(x) ** (p - 1))
+        return dtype(lam * reg), G
+    if model == "cp":
+        rows = [("sub_embeddings", h), ("rel_embeddings", r), ("obj_embeddings", t)]
+    elif model == "distmult":
         rows = [("ent_embeddings", h), ("rel_embeddings", r), ("ent_embeddings", t)]
     elif model in ("complex", "complexn3"):
         rows = [("ent_embeddings_real", h), ("ent_embeddings_img", h), ("rel_embeddings_real", r),

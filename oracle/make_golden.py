@@ -47,6 +47,13 @@ MODELS = {
     "complex": ("pointwise.Complex", dict(hidden_size=14, lmbda=0.01)),
     "complexn3": ("pointwise.ComplexN3", dict(hidden_size=14, lmbda=0.01)),
     "analogy": ("pointwise.ANALOGY", dict(hidden_size=16, lmbda=0.01)),
+    # second group: the remaining gather-type models
+    "transm_l1": ("pairwise.TransM", dict(hidden_size=20, l1_flag=True, margin=1.0)),
+    "transm_l2": ("pairwise.TransM", dict(hidden_size=20, l1_flag=False, margin=1.0)),
+    "cp": ("pointwise.CP", dict(hidden_size=22, lmbda=0.01)),
+    "simple": ("pointwise.SimplE", dict(hidden_size=18, lmbda=0.01)),
+    "simple_ignr": ("pointwise.SimplE_ignr", dict(hidden_size=18, lmbda=0.01)),
+    "quate": ("pointwise.QuatE", dict(hidden_size=12, lmbda=0.01)),
 }
 E, R, B = 53, 7, 32
 N_STEPS = 3
@@ -102,7 +109,7 @@ def config_for(hp, E_, R_, train, valid, test, optimizer="sgd", lr=0.05):
     cfg = types.SimpleNamespace(
         tot_entity=E_, tot_relation=R_, device="cpu", optimizer=optimizer, learning_rate=lr,
         neg_rate=hp.get("neg_rate", 1), alpha=hp.get("alpha", 0.1), margin=hp.get("margin", 1.0),
-        batch_size=B, epochs=1000, test_num=N_TEST, debug=False, load_from_data=None, hits=[1, 3, 5, 10],
+        batch_size=B, tot_train_triples=len(train), epochs=1000, test_num=N_TEST, debug=False, load_from_data=None, hits=[1, 3, 5, 10],
         patience=3, dataset_name="synthetic", sampling="uniform",
         knowledge_graph=_KG({"triplets_train": mk(train), "triplets_valid": mk(valid),
                              "triplets_test": mk(test), "hr_t": hr_t, "tr_h": tr_h}))
@@ -150,6 +157,8 @@ def golden_for(name, cls_path, hp, seed):
         rec["hp_" + k] = np.asarray(v)
     for k, v in init.items():
         rec["init." + k] = v.numpy().copy()
+    if hasattr(model0, "theta"):  # TransM: fixed per-relation weights derived from the train split (pairwise.py:305-315)
+        rec["theta"] = model0.theta.numpy().copy()
 
     neg_rate = hp.get("neg_rate", 1)
     pointwise = cls_path.startswith("pointwise")
@@ -184,7 +193,8 @@ def golden_for(name, cls_path, hp, seed):
     loss.backward()
     rec["loss0"] = np.float32(loss.item())
     for k, p in model.named_parameters():
-        rec["grad0." + k] = p.grad.numpy().copy()
+        if p.grad is not None:  # QuatE carries unused fc / bn parameters (pointwise.py:625-628)
+            rec["grad0." + k] = p.grad.numpy().copy()
     for k, v in model.state_dict().items():
         rec["after_fwd0." + k] = v.numpy().copy()  # == init except RESCAL (normalised in place)
 
@@ -259,6 +269,9 @@ def golden_pretrained():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])  # optional: regenerate just the named cases
     for i, (name, (cls_path, hp)) in enumerate(MODELS.items()):
-        golden_for(name, cls_path, hp, seed=1000 + i)
-    golden_pretrained()
+        if not only or name in only:
+            golden_for(name, cls_path, hp, seed=1000 + i)
+    if not only or "pretrained" in only:
+        golden_pretrained()

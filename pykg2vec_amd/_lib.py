@@ -9,14 +9,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KGE_HIP_LIB", os.path.join(_HERE, "libkge_hip.so"))  # env override: A/B builds in dev tools
 
-KGE_MAX_TABLES = 6
-ABI_VERSION = 1
+KGE_MAX_TABLES = 12
+ABI_VERSION = 2
 
 # enum kge_model
-TRANSE, TRANSH, TRANSD, ROTATE, RESCAL, NTN, DISTMULT, COMPLEX, ANALOGY = range(9)
+(TRANSE, TRANSH, TRANSD, ROTATE, RESCAL, NTN, DISTMULT, COMPLEX, ANALOGY, TRANSM, CP, SIMPLE, SIMPLE_IGNR,
+ QUATE) = range(14)
 FLAG_L1 = 1
 OPT_SGD, OPT_ADAM, OPT_ADAGRAD, OPT_RMSPROP = range(4)
-REG_NONE, REG_F2, REG_N3, REG_N3_ABS = range(4)
+REG_NONE, REG_F2, REG_N3, REG_N3_ABS, REG_ID_F2, REG_ID_N3 = range(6)
 LOSS_SLOTS, LOSS_STRIDE = 32, 32  # loss accumulators: float[32*32], total = sum of [k*32]
 
 c_i64p = ctypes.c_void_p  # all device pointers travel as void*

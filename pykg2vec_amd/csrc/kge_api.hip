@@ -19,7 +19,8 @@ void set_error(const char* fmt, ...) {
 bool is_vector_model(int model) {
     switch (model) {
         case KGE_TRANSE: case KGE_TRANSH: case KGE_TRANSD: case KGE_ROTATE:
-        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_ANALOGY: return true;
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_ANALOGY:
+        case KGE_TRANSM: case KGE_CP: case KGE_SIMPLE: case KGE_SIMPLE_IGNR: case KGE_QUATE: return true;
         default: return false;
     }
 }
@@ -42,9 +43,13 @@ static int table_count(int model) {
         case KGE_TRANSH: case KGE_ROTATE: return 3;
         case KGE_TRANSD: case KGE_COMPLEX: return 4;
         case KGE_NTN: case KGE_ANALOGY: return 6;
+        case KGE_TRANSM: case KGE_CP: return 3;
+        case KGE_SIMPLE: case KGE_SIMPLE_IGNR: return 4;
+        case KGE_QUATE: return 8;
     }
     return -1;
 }
+static int grad_count(int model) { return model == KGE_TRANSM ? 2 : table_count(model); }  // TransM's theta is a fixed input
 
 DeviceModel to_device_model(const kge_model_desc* m) {
     DeviceModel d;
@@ -73,7 +78,7 @@ static int validate(const kge_model_desc* m, bool need_grads, const char* who) {
     if (m->model == KGE_ANALOGY && (m->dim & 1)) { set_error("%s: ANALOGY needs an even hidden size", who); return -1; }
     for (int i = 0; i < nt; ++i) {
         if (!m->tables[i]) { set_error("%s: table %d is null", who, i); return -1; }
-        if (need_grads && !m->grads[i]) { set_error("%s: gradient buffer %d is null", who, i); return -1; }
+        if (need_grads && i < grad_count(m->model) && !m->grads[i]) { set_error("%s: gradient buffer %d is null", who, i); return -1; }
     }
     return 0;
 }
@@ -216,7 +221,7 @@ int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, cons
     if (validate(m, true, "kge_train_pointwise_logistic")) return -1;
     if (n == 0) return 0;
     if (n < 0 || !h || !r || !t || !y || !loss) { set_error("kge_train_pointwise_logistic: bad arguments"); return -1; }
-    if (reg_type < KGE_REG_NONE || reg_type > KGE_REG_N3_ABS) { set_error("kge_train_pointwise_logistic: bad reg_type %d", reg_type); return -1; }
+    if (reg_type < KGE_REG_NONE || reg_type > KGE_REG_ID_N3) { set_error("kge_train_pointwise_logistic: bad reg_type %d", reg_type); return -1; }
     if (!is_vector_model(m->model)) { set_error("kge_train_pointwise_logistic: unsupported model %d", m->model); return -1; }
     return launch_pointwise_logistic(m, h, r, t, y, n, bundle, lmbda, reg_type, loss, (hipStream_t)stream);
 }

@@ -84,7 +84,8 @@ __device__ __forceinline__ void atomic_add_row(float* __restrict__ row, const fl
 // role r of model M is row  tab[role_tab(M,r)][ id[role_sel(M,r)] ],  id = {h, r, t}
 __host__ __device__ constexpr int role_count(int M) {
     return M == KGE_TRANSE ? 3 : M == KGE_TRANSH ? 4 : M == KGE_TRANSD ? 6 : M == KGE_ROTATE ? 5
-         : M == KGE_DISTMULT ? 3 : M == KGE_COMPLEX ? 6 : M == KGE_ANALOGY ? 9 : 0;
+         : M == KGE_DISTMULT ? 3 : M == KGE_COMPLEX ? 6 : M == KGE_ANALOGY ? 9
+         : M == KGE_TRANSM ? 4 : M == KGE_CP ? 3 : (M == KGE_SIMPLE || M == KGE_SIMPLE_IGNR) ? 6 : M == KGE_QUATE ? 12 : 0;
 }
 __host__ __device__ constexpr int role_tab(int M, int r) {
     switch (M) {
@@ -94,6 +95,10 @@ __host__ __device__ constexpr int role_tab(int M, int r) {
         case KGE_ROTATE: { constexpr int t[5] = {0, 1, 2, 0, 1}; return t[r]; }         // hr, hi, rel, tr, ti
         case KGE_COMPLEX: { constexpr int t[6] = {0, 1, 2, 3, 0, 1}; return t[r]; }     // hr, hi, rr, ri, tr, ti
         case KGE_ANALOGY: { constexpr int t[9] = {0, 1, 0, 2, 3, 4, 5, 2, 3}; return t[r]; }  // eh, er, et | hr,hi,rr,ri,tr,ti
+        case KGE_TRANSM: { constexpr int t[4] = {0, 1, 0, 2}; return t[r]; }            // eh, er, et, theta[r] (1 float)
+        case KGE_CP: { constexpr int t[3] = {0, 1, 2}; return t[r]; }                   // sub[h], rel[r], obj[t]
+        case KGE_SIMPLE: case KGE_SIMPLE_IGNR: { constexpr int t[6] = {0, 0, 2, 3, 1, 1}; return t[r]; }  // h1,h2,r1,r2,t1,t2
+        case KGE_QUATE: { constexpr int t[12] = {0, 1, 2, 3, 0, 1, 2, 3, 4, 5, 6, 7}; return t[r]; }      // h sxyz, t sxyz, r sxyz
     }
     return 0;
 }
@@ -105,12 +110,19 @@ __host__ __device__ constexpr int role_sel(int M, int r) {
         case KGE_ROTATE: { constexpr int s[5] = {0, 0, 1, 2, 2}; return s[r]; }
         case KGE_COMPLEX: { constexpr int s[6] = {0, 0, 1, 1, 2, 2}; return s[r]; }
         case KGE_ANALOGY: { constexpr int s[9] = {0, 1, 2, 0, 0, 1, 1, 2, 2}; return s[r]; }
+        case KGE_TRANSM: { constexpr int s[4] = {0, 1, 2, 1}; return s[r]; }
+        case KGE_CP: { constexpr int s[3] = {0, 1, 2}; return s[r]; }
+        case KGE_SIMPLE: case KGE_SIMPLE_IGNR: { constexpr int s[6] = {0, 2, 1, 1, 2, 0}; return s[r]; }  // h2 = head[t], t2 = tail[h]
+        case KGE_QUATE: { constexpr int s[12] = {0, 0, 0, 0, 2, 2, 2, 2, 1, 1, 1, 1}; return s[r]; }
     }
     return 0;
 }
+// roles whose table is a fixed input (no gradient buffer, never scattered)
+__host__ __device__ constexpr bool role_trainable(int M, int r) { return !(M == KGE_TRANSM && r == 3); }
 template <int M>
 __device__ __forceinline__ int role_dim(const DeviceModel& m, int r) {
     if (M == KGE_ANALOGY && r >= 3) return m.dim / 2;
+    if (M == KGE_TRANSM && r == 3) return 1;
     return m.dim;
 }
 
@@ -131,6 +143,7 @@ template <int M, int G, int NCH>
 __device__ __forceinline__ void scatter_rows(const Rows<M, NCH>& Gr, const DeviceModel& m, const int64_t (&id)[3], int gl) {
 #pragma unroll
     for (int r = 0; r < role_count(M); ++r) {
+        if (!role_trainable(M, r)) continue;
         const int d = role_dim<M>(m, r);
         atomic_add_row<G, NCH>(m.grad[role_tab(M, r)] + id[role_sel(M, r)] * (int64_t)d, Gr.x[r], d, gl);
     }
@@ -207,8 +220,8 @@ struct Saved {
     float a[NCH], c[NCH];  // projected head / tail (TransH, TransD)
     float wh[NCH];         // TransH: normalised hyperplane normal; RotatE: cos(phase)
     float aux[NCH];        // RotatE: sin(phase)
-    float ph, pt, iw;      // projections h.w^ / t.w^ (TransH), h.hm / t.tm (TransD); 1/max(|w|,eps)
-    bool fw;
+    float ph, pt, iw;      // projections h.w^ / t.w^ (TransH), h.hm / t.tm (TransD); 1/max(|w|,eps); TransM: theta_r
+    bool fw;               // TransH: |w| > eps; SimplE: the clamp passes the gradient
 };
 
 template <int M, int G, int NCH>
@@ -289,6 +302,44 @@ __device__ __forceinline__ float model_fwd(const Rows<M, NCH>& R, const DeviceMo
         }
         gsum2<G>(p, q);
         return (-p) + (-q);
+    } else if constexpr (M == KGE_TRANSM) {  // pairwise.py:325-347: theta_r * TransE distance
+        sv.ph = gsum<G>(R.x[3][0]);          // theta_r sits in lane 0 of the group, zeros elsewhere
+        return sv.ph * tail_fwd<G, NCH>(R.x[0], R.x[1], R.x[2], m.l1, sv.tail);
+    } else if constexpr (M == KGE_CP) {      // pointwise.py:374-376
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) p += R.x[0][i] * R.x[1][i] * R.x[2][i];
+        return -gsum<G>(p);
+    } else if constexpr (M == KGE_SIMPLE || M == KGE_SIMPLE_IGNR) {  // pointwise.py:522-526, 581-585
+        float p = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            p += R.x[0][i] * R.x[2][i] * R.x[4][i];   // <head[h], rel[r], tail[t]>
+            q += R.x[1][i] * R.x[3][i] * R.x[5][i];   // <head[t], rel_inv[r], tail[h]>
+        }
+        gsum2<G>(p, q);
+        const float init = (M == KGE_SIMPLE) ? p + q / 2.0f : p + q;
+        sv.fw = init >= -20.f && init <= 20.f;        // torch.clamp backward: gradient inside the closed interval
+        return -fminf(fmaxf(init, -20.f), 20.f);
+    } else if constexpr (M == KGE_QUATE) {  // pointwise.py:683-700: (h (x) r/|r|) . t with elementwise quaternions
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const float hs = R.x[0][i], hx = R.x[1][i], hy = R.x[2][i], hz = R.x[3][i];
+            const float ts = R.x[4][i], tx = R.x[5][i], ty = R.x[6][i], tz = R.x[7][i];
+            const float rs = R.x[8][i], rx = R.x[9][i], ry = R.x[10][i], rz = R.x[11][i];
+            const float den = sqrtf(rs * rs + rx * rx + ry * ry + rz * rz);
+            // padding lanes (all-zero rows) would give 0/0: they contribute nothing, keep them at zero
+            const float inv = den > 0.f ? 1.0f / den : 0.f;
+            const float ps = rs * inv, px = rx * inv, py = ry * inv, pz = rz * inv;
+            sv.a[i] = ps; sv.c[i] = px; sv.wh[i] = py; sv.aux[i] = pz;
+            const float a = hs * ps - hx * px - hy * py - hz * pz;
+            const float b = hs * px + ps * hx + hy * pz - py * hz;
+            const float c = hs * py + ps * hy + hz * px - pz * hx;
+            const float d = hs * pz + ps * hz + hx * py - px * hy;
+            p += a * ts + b * tx + c * ty + d * tz;
+        }
+        return -gsum<G>(p);
     }
     return 0.f;
 }
@@ -378,6 +429,61 @@ __device__ __forceinline__ void model_bwd(const Rows<M, NCH>& R, const DeviceMod
                 Gr.x[1][i] = R.x[0][i] * R.x[2][i] * nds;
                 Gr.x[2][i] = R.x[0][i] * R.x[1][i] * nds;
             }
+        }
+    } else if constexpr (M == KGE_TRANSM) {
+        tail_bwd<G, NCH>(R.x[0], R.x[1], R.x[2], m.l1, sv.tail, ds * sv.ph, Gr.x[0], Gr.x[1], Gr.x[2]);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) Gr.x[3][i] = 0.f;  // theta is a fixed input
+    } else if constexpr (M == KGE_CP) {
+        const float nds = -ds;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            Gr.x[0][i] = R.x[1][i] * R.x[2][i] * nds;
+            Gr.x[1][i] = R.x[0][i] * R.x[2][i] * nds;
+            Gr.x[2][i] = R.x[0][i] * R.x[1][i] * nds;
+        }
+    } else if constexpr (M == KGE_SIMPLE || M == KGE_SIMPLE_IGNR) {
+        const float g1 = sv.fw ? -ds : 0.f;
+        const float g2 = (M == KGE_SIMPLE) ? g1 / 2.0f : g1;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            Gr.x[0][i] = R.x[2][i] * R.x[4][i] * g1;
+            Gr.x[2][i] = R.x[0][i] * R.x[4][i] * g1;
+            Gr.x[4][i] = R.x[0][i] * R.x[2][i] * g1;
+            Gr.x[1][i] = R.x[3][i] * R.x[5][i] * g2;
+            Gr.x[3][i] = R.x[1][i] * R.x[5][i] * g2;
+            Gr.x[5][i] = R.x[1][i] * R.x[3][i] * g2;
+        }
+    } else if constexpr (M == KGE_QUATE) {
+        const float g = -ds;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const float hs = R.x[0][i], hx = R.x[1][i], hy = R.x[2][i], hz = R.x[3][i];
+            const float ts = R.x[4][i], tx = R.x[5][i], ty = R.x[6][i], tz = R.x[7][i];
+            const float rs = R.x[8][i], rx = R.x[9][i], ry = R.x[10][i], rz = R.x[11][i];
+            const float ps = sv.a[i], px = sv.c[i], py = sv.wh[i], pz = sv.aux[i];
+            // d/d t = Hamilton product h (x) r^
+            Gr.x[4][i] = (hs * ps - hx * px - hy * py - hz * pz) * g;
+            Gr.x[5][i] = (hs * px + ps * hx + hy * pz - py * hz) * g;
+            Gr.x[6][i] = (hs * py + ps * hy + hz * px - pz * hx) * g;
+            Gr.x[7][i] = (hs * pz + ps * hz + hx * py - px * hy) * g;
+            // d/d h
+            Gr.x[0][i] = (ps * ts + px * tx + py * ty + pz * tz) * g;
+            Gr.x[1][i] = (-px * ts + ps * tx - pz * ty + py * tz) * g;
+            Gr.x[2][i] = (-py * ts + pz * tx + ps * ty - px * tz) * g;
+            Gr.x[3][i] = (-pz * ts - py * tx + px * ty + ps * tz) * g;
+            // d/d r^ , then through the per-element normalisation r^ = r / |r|
+            const float gs = (hs * ts + hx * tx + hy * ty + hz * tz) * g;
+            const float gx = (-hx * ts + hs * tx + hz * ty - hy * tz) * g;
+            const float gy = (-hy * ts - hz * tx + hs * ty + hx * tz) * g;
+            const float gz = (-hz * ts + hy * tx - hx * ty + hs * tz) * g;
+            const float den = sqrtf(rs * rs + rx * rx + ry * ry + rz * rz);
+            const float inv = den > 0.f ? 1.0f / den : 0.f;
+            const float dot = ps * gs + px * gx + py * gy + pz * gz;
+            Gr.x[8][i] = (gs - ps * dot) * inv;
+            Gr.x[9][i] = (gx - px * dot) * inv;
+            Gr.x[10][i] = (gy - py * dot) * inv;
+            Gr.x[11][i] = (gz - pz * dot) * inv;
         }
     }
 }

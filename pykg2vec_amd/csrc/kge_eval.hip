@@ -37,12 +37,15 @@ constexpr int QT_XF = 8;     // ... candidate-transform forms (TransH / TransD)
 
 enum Form { F_L1 = 0, F_L2 = 1, F_SQM = 2, F_NEGDOT = 3 };
 enum XForm { X_NONE = 0, X_TRANSH = 1, X_TRANSD = 2 };
+// per-query post-op on the finished energy: TransM multiplies by theta_r (pairwise.py:341-347), SimplE clamps to
+// [-20, 20] (pointwise.py:525-526)
+enum Post { P_NONE = 0, P_SCALE = 1, P_CLAMP = 2 };
 
 struct EvalPlan {
     int64_t E, n;
-    int K, Kpad, QV, form, xform;
+    int K, Kpad, QV, form, xform, post;
     int64_t ntiles;
-    float* cand; float* aux; float* qvec; float* st; int32_t* fcount; int32_t* rcount;
+    float* cand; float* aux; float* qvec; float* qscale; float* st; int32_t* fcount; int32_t* rcount;
     size_t bytes;
 };
 
@@ -51,6 +54,8 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static int sweep_K(const kge_model_desc* m) {
     switch (m->model) {
         case KGE_COMPLEX: case KGE_ROTATE: case KGE_ANALOGY: return 2 * m->dim;
+        case KGE_CP: case KGE_SIMPLE: case KGE_SIMPLE_IGNR: return 2 * m->dim;  // both entity tables side by side
+        case KGE_QUATE: return 4 * m->dim;
         default: return m->dim;
     }
 }
@@ -62,11 +67,14 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p)
     p->xform = m->model == KGE_TRANSH ? X_TRANSH : m->model == KGE_TRANSD ? X_TRANSD : X_NONE;
     p->QV = p->xform == X_NONE ? 1 : 2;
     switch (m->model) {
-        case KGE_TRANSE: case KGE_TRANSH: case KGE_TRANSD: p->form = (m->flags & KGE_FLAG_L1) ? F_L1 : F_L2; break;
+        case KGE_TRANSE: case KGE_TRANSH: case KGE_TRANSD: case KGE_TRANSM:
+            p->form = (m->flags & KGE_FLAG_L1) ? F_L1 : F_L2; break;
         case KGE_ROTATE: p->form = F_SQM; break;
-        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_ANALOGY: case KGE_RESCAL: p->form = F_NEGDOT; break;
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_ANALOGY: case KGE_RESCAL:
+        case KGE_CP: case KGE_SIMPLE: case KGE_SIMPLE_IGNR: case KGE_QUATE: p->form = F_NEGDOT; break;
         default: return false;
     }
+    p->post = m->model == KGE_TRANSM ? P_SCALE : (m->model == KGE_SIMPLE || m->model == KGE_SIMPLE_IGNR) ? P_CLAMP : P_NONE;
     p->ntiles = (p->E + 63) / 64;
     size_t off = 0;
     char* base = (char*)ws;
@@ -74,6 +82,7 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p)
     p->cand = (float*)take((size_t)p->ntiles * p->Kpad * 64 * sizeof(float));
     p->aux = (float*)take((size_t)p->ntiles * 64 * sizeof(float));
     p->qvec = (float*)take((size_t)2 * n * p->QV * p->Kpad * sizeof(float));
+    p->qscale = (float*)take((size_t)2 * n * sizeof(float));
     p->st = (float*)take((size_t)2 * n * sizeof(float));
     p->fcount = (int32_t*)take((size_t)2 * n * sizeof(int32_t));
     p->rcount = (int32_t*)take((size_t)2 * n * sizeof(int32_t));
@@ -90,7 +99,7 @@ size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n) {
 
 // ------------------------------------------------------------------ 1. candidate sweep layout
 struct PrepArgs {
-    const float* seg[3]; int seg_dim[3]; int nseg;  // candidate row = concatenation of table rows
+    const float* seg[4]; int seg_dim[4]; int nseg;  // candidate row = concatenation of table rows
     const float* dot_tab;                            // TransD: aux[e] = ent[e] . ent_mappings[e]
     int normalize;                                   // TransE: divide by max(||row||, eps)
     int64_t E; int K, Kpad;
@@ -99,7 +108,7 @@ struct PrepArgs {
 __device__ __forceinline__ float prep_elem(const PrepArgs& a, int64_t e, int k) {
     int kk = k;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 4; ++s) {
         if (s < a.nseg) {
             if (kk < a.seg_dim[s]) return a.seg[s][e * a.seg_dim[s] + kk];
             kk -= a.seg_dim[s];
@@ -156,11 +165,16 @@ __global__ __launch_bounds__(256) void k_eval_prepare(PrepArgs a, float* __restr
 // one wave per test triple; writes qvec[(2i+side)*QV*Kpad ...], side 0 = tail sweep (h,r,?), 1 = head sweep (?,r,t)
 template <int M>
 __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64_t* __restrict__ triples, int64_t n,
-                                                      int K, int Kpad, int QV, float* __restrict__ qvec) {
+                                                      int K, int Kpad, int QV, float* __restrict__ qvec,
+                                                      float* __restrict__ qscale) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const int64_t h = triples[3 * i], r = triples[3 * i + 1], t = triples[3 * i + 2];
+    if (lane == 0) {
+        const float sc = (M == KGE_TRANSM) ? m.tab[2][r] : 1.0f;
+        qscale[2 * i] = sc; qscale[2 * i + 1] = sc;
+    }
     float* qt = qvec + (2 * i) * (int64_t)QV * Kpad;
     float* qh = qvec + (2 * i + 1) * (int64_t)QV * Kpad;
     const int d = m.dim;
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
         qt[k] = 0.f; qh[k] = 0.f;
         if (QV == 2) { qt[Kpad + k] = 0.f; qh[Kpad + k] = 0.f; }
     }
-    if constexpr (M == KGE_TRANSE || M == KGE_TRANSH || M == KGE_TRANSD) {
+    if constexpr (M == KGE_TRANSE || M == KGE_TRANSH || M == KGE_TRANSD || M == KGE_TRANSM) {
         const float* eh = m.tab[0] + h * d; const float* er = m.tab[1] + r * d; const float* et = m.tab[0] + t * d;
         // projected head / tail  (a, c) and the relation-side vector the sweep needs
         float ph = 0.f, pt = 0.f, iw = 1.f;
@@ -241,6 +255,42 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
             qh[k] = tr[k] * cs + ti[k] * sn;       // t o conj(r) ; |h o r - t| = |h - t o conj(r)| for |r| = 1
             qh[d + k] = ti[k] * cs - tr[k] * sn;
         }
+    } else if constexpr (M == KGE_CP) {  // candidate row [sub[e] | obj[e]]
+        const float* sh = m.tab[0] + h * d; const float* er = m.tab[1] + r * d; const float* ot = m.tab[2] + t * d;
+        for (int k = lane; k < d; k += 64) {
+            qt[k] = 0.f; qt[d + k] = sh[k] * er[k];     // tail sweep: <sub[h] o rel[r], obj[e]>
+            qh[k] = er[k] * ot[k]; qh[d + k] = 0.f;     // head sweep: <sub[e], rel[r] o obj[t]>
+        }
+    } else if constexpr (M == KGE_SIMPLE || M == KGE_SIMPLE_IGNR) {  // candidate row [tail[e] | head[e]]
+        const float w2 = (M == KGE_SIMPLE) ? 0.5f : 1.0f;  // pointwise.py:525: only the inverse term is halved
+        const float* hh = m.tab[0] + h * d; const float* ht = m.tab[0] + t * d;   // head-role rows of h and t
+        const float* th = m.tab[1] + h * d; const float* tt = m.tab[1] + t * d;   // tail-role rows of h and t
+        const float* r1 = m.tab[2] + r * d; const float* r2 = m.tab[3] + r * d;
+        for (int k = lane; k < d; k += 64) {
+            qt[k] = hh[k] * r1[k];              // <head[h], rel, tail[e]>
+            qt[d + k] = w2 * (r2[k] * th[k]);   // <head[e], rel_inv, tail[h]>
+            qh[k] = w2 * (ht[k] * r2[k]);       // <head[t], rel_inv, tail[e]>
+            qh[d + k] = r1[k] * tt[k];          // <head[e], rel, tail[t]>
+        }
+    } else if constexpr (M == KGE_QUATE) {  // candidate row [s | x | y | z][e]
+        const float* H[4]; const float* T[4]; const float* Rq[4];
+        for (int c = 0; c < 4; ++c) { H[c] = m.tab[c] + h * d; T[c] = m.tab[c] + t * d; Rq[c] = m.tab[4 + c] + r * d; }
+        for (int k = lane; k < d; k += 64) {
+            const float rs = Rq[0][k], rx = Rq[1][k], ry = Rq[2][k], rz = Rq[3][k];
+            const float den = sqrtf(rs * rs + rx * rx + ry * ry + rz * rz);
+            const float inv = den > 0.f ? 1.0f / den : 0.f;
+            const float ps = rs * inv, px = rx * inv, py = ry * inv, pz = rz * inv;
+            const float hs = H[0][k], hx = H[1][k], hy = H[2][k], hz = H[3][k];
+            const float ts = T[0][k], tx = T[1][k], ty = T[2][k], tz = T[3][k];
+            qt[k] = hs * ps - hx * px - hy * py - hz * pz;          // h (x) r^, dotted with the candidate tail
+            qt[d + k] = hs * px + ps * hx + hy * pz - py * hz;
+            qt[2 * d + k] = hs * py + ps * hy + hz * px - pz * hx;
+            qt[3 * d + k] = hs * pz + ps * hz + hx * py - px * hy;
+            qh[k] = ps * ts + px * tx + py * ty + pz * tz;          // coefficients of the candidate head's s, x, y, z
+            qh[d + k] = -px * ts + ps * tx - pz * ty + py * tz;
+            qh[2 * d + k] = -py * ts + pz * tx + ps * ty - px * tz;
+            qh[3 * d + k] = -pz * ts - py * tx + px * ty + ps * tz;
+        }
     } else if constexpr (M == KGE_RESCAL) {
         const float* eh = m.tab[0] + h * d; const float* et = m.tab[0] + t * d;
         const float* Mr = m.tab[1] + r * (int64_t)d * d;
@@ -286,10 +336,18 @@ __device__ __forceinline__ float pair_finish(float acc, float margin) {
     else return -acc;
 }
 
+template <int POST>
+__device__ __forceinline__ float pair_post(float s, float scale) {
+    if constexpr (POST == P_SCALE) return scale * s;
+    else if constexpr (POST == P_CLAMP) return fminf(fmaxf(s, -20.f), 20.f);
+    else return s;
+}
+
 // full sequential score of one (query, candidate) pair by ONE lane (target / filter path)
-template <int FORM, int XFORM>
+template <int FORM, int XFORM, int POST>
 __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand, const float* __restrict__ aux,
-                                                 const float* __restrict__ q, int64_t e, int Kpad, float margin) {
+                                                 const float* __restrict__ q, int64_t e, int Kpad, float margin,
+                                                 float scale) {
     const float* c = cand + ((e >> 6) * Kpad) * 64 + (e & 63);
     float acc = 0.f;
     if constexpr (XFORM == X_NONE && FORM != F_L1) {
@@ -328,13 +386,14 @@ __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand,
             acc = pair_step<FORM>(acc, v, q[k]);
         }
     }
-    return pair_finish<FORM>(acc, margin);
+    return pair_post<POST>(pair_finish<FORM>(acc, margin), scale);
 }
 
 // ------------------------------------------------------------------ 3. target score + filtered count
-template <int FORM, int XFORM>
+template <int FORM, int XFORM, int POST>
 __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restrict__ cand, const float* __restrict__ aux,
-                                                            const float* __restrict__ qvec, const int64_t* __restrict__ triples,
+                                                            const float* __restrict__ qvec, const float* __restrict__ qscale,
+                                                            const int64_t* __restrict__ triples,
                                                             int64_t n, int Kpad, int QV, float margin,
                                                             const int64_t* __restrict__ tail_off, const int32_t* __restrict__ tail_ids,
                                                             const int64_t* __restrict__ head_off, const int32_t* __restrict__ head_ids,
@@ -346,8 +405,9 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
     const int side = (int)(qi & 1);
     const int64_t truth = side == 0 ? triples[3 * i + 2] : triples[3 * i];
     const float* q = qvec + qi * (int64_t)QV * Kpad;
+    const float scale = POST == P_SCALE ? qscale[qi] : 1.0f;
     float s_true = 0.f;
-    if (lane == 0) s_true = pair_score_lane<FORM, XFORM>(cand, aux, q, truth, Kpad, margin);
+    if (lane == 0) s_true = pair_score_lane<FORM, XFORM, POST>(cand, aux, q, truth, Kpad, margin, scale);
     s_true = __shfl(s_true, 0, 64);
     const int64_t* off = side == 0 ? tail_off : head_off;
     const int32_t* ids = side == 0 ? tail_ids : head_ids;
@@ -357,7 +417,7 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
         for (int64_t j = b + lane; j < e_; j += 64) {
             const int64_t e = ids[j];
             if (e != truth) {
-                const float s = pair_score_lane<FORM, XFORM>(cand, aux, q, e, Kpad, margin);
+                const float s = pair_score_lane<FORM, XFORM, POST>(cand, aux, q, e, Kpad, margin, scale);
                 cnt += (s < s_true) ? 1 : 0;
             }
         }
@@ -387,9 +447,10 @@ __device__ __forceinline__ void pair_step2(float& acc, f32x2 c, f32x2 q) {
     }
 }
 
-template <int FORM, int XFORM, int QT, bool WRITE>
+template <int FORM, int XFORM, int QT, bool WRITE, int POST>
 __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ cand, const float* __restrict__ aux,
-                                                    const float* __restrict__ qvec, const float* __restrict__ st,
+                                                    const float* __restrict__ qvec, const float* __restrict__ qscale,
+                                                    const float* __restrict__ st,
                                                     int64_t nq, int64_t E, int64_t ntiles, int Kpad, int QV, float margin,
                                                     int S, int qblocks, int32_t* __restrict__ rcount,
                                                     float* __restrict__ scores_out) {
@@ -405,12 +466,14 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
     // wave-uniform query row pointers (clamped; masked at the end)
     const float* qrow[QT];
     float sthr[QT];
+    float qsc[QT];
     int cnt[QT];
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
         const int64_t qi = (q0 + q < nq) ? q0 + q : nq - 1;
         qrow[q] = qvec + qi * qstride;
         sthr[q] = WRITE ? 0.f : st[qi];
+        qsc[q] = POST == P_SCALE ? qscale[qi] : 1.0f;
         cnt[q] = 0;
     }
     if constexpr (XFORM == X_NONE) {
@@ -459,7 +522,8 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
             const bool valid_a = ea < E, valid_b = has_b && eb < E;
 #pragma unroll
             for (int q = 0; q < QT; ++q) {
-                const float sa = pair_finish<FORM>(acca[q], margin), sb = pair_finish<FORM>(accb[q], margin);
+                const float sa = pair_post<POST>(pair_finish<FORM>(acca[q], margin), qsc[q]);
+                const float sb = pair_post<POST>(pair_finish<FORM>(accb[q], margin), qsc[q]);
                 if constexpr (WRITE) {
                     if (q0 + q < nq) {
                         if (valid_a) scores_out[(q0 + q) * E + ea] = sa;
@@ -533,7 +597,7 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
         const bool valid = e < E;
 #pragma unroll
         for (int q = 0; q < QT; ++q) {
-            const float s = pair_finish<FORM>(acc[q], margin);
+            const float s = pair_post<POST>(pair_finish<FORM>(acc[q], margin), qsc[q]);
             if constexpr (WRITE) {
                 if (valid && q0 + q < nq) scores_out[(q0 + q) * E + e] = s;
             } else {
@@ -598,10 +662,18 @@ int launch_rank_from_scores(const float* scores, int64_t nq, int64_t E, const in
 static void fill_prep(const kge_model_desc* m, const EvalPlan& p, PrepArgs* a) {
     a->nseg = 1; a->dot_tab = nullptr; a->normalize = 0;
     a->E = p.E; a->K = p.K; a->Kpad = p.Kpad;
-    for (int s = 0; s < 3; ++s) { a->seg[s] = nullptr; a->seg_dim[s] = 0; }
+    for (int s = 0; s < 4; ++s) { a->seg[s] = nullptr; a->seg_dim[s] = 0; }
     a->seg[0] = m->tables[0]; a->seg_dim[0] = m->dim;
     switch (m->model) {
-        case KGE_TRANSE: a->normalize = 1; break;
+        case KGE_TRANSE: case KGE_TRANSM: a->normalize = 1; break;
+        case KGE_CP:  // [sub | obj]: the head sweep reads the first half, the tail sweep the second (zero query halves)
+            a->nseg = 2; a->seg[1] = m->tables[2]; a->seg_dim[1] = m->dim; break;
+        case KGE_SIMPLE: case KGE_SIMPLE_IGNR:  // [tail-role row | head-role row] of entity e
+            a->nseg = 2; a->seg[0] = m->tables[1]; a->seg[1] = m->tables[0]; a->seg_dim[1] = m->dim; break;
+        case KGE_QUATE:
+            a->nseg = 4;
+            for (int q = 1; q < 4; ++q) { a->seg[q] = m->tables[q]; a->seg_dim[q] = m->dim; }
+            break;
         case KGE_TRANSD: a->dot_tab = m->tables[2]; break;
         case KGE_COMPLEX: case KGE_ROTATE:
             a->nseg = 2; a->seg[1] = m->tables[1]; a->seg_dim[1] = m->dim; break;
@@ -612,7 +684,7 @@ static void fill_prep(const kge_model_desc* m, const EvalPlan& p, PrepArgs* a) {
     }
 }
 
-template <int FORM, int XFORM>
+template <int FORM, int XFORM, int POST = P_NONE>
 static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, const int64_t* triples,
                                 const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
                                 const int32_t* head_ids, float* scores_out, hipStream_t s) {
@@ -628,14 +700,14 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
     if (S < 1) S = 1;
     const unsigned grid = (unsigned)(qgroups * 256 * S);
     if (scores_out == nullptr) {
-        hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p.cand, p.aux,
-                           p.qvec, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids, head_off, head_ids, p.st,
-                           p.fcount);
-        hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, false>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec, p.st,
-                           nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, nullptr);
+        hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM, POST>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p.cand,
+                           p.aux, p.qvec, p.qscale, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids, head_off, head_ids,
+                           p.st, p.fcount);
+        hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, false, POST>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec,
+                           p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, nullptr);
     } else {
-        hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, true>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec, p.st,
-                           nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, scores_out);
+        hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, true, POST>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec,
+                           p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, scores_out);
     }
 }
 
@@ -654,16 +726,22 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     hipLaunchKernelGGL(k_eval_prepare, dim3((unsigned)p.ntiles), dim3(256), 0, s, pa, p.cand, p.aux);
     const DeviceModel dm = to_device_model(m);
     const unsigned qb = (unsigned)((n + 3) / 4);
-#define KGE_Q(MID) case MID: hipLaunchKernelGGL((k_eval_queries<MID>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec); break;
+#define KGE_Q(MID) case MID: hipLaunchKernelGGL((k_eval_queries<MID>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale); break;
     switch (m->model) {
         KGE_Q(KGE_TRANSE) KGE_Q(KGE_TRANSH) KGE_Q(KGE_TRANSD) KGE_Q(KGE_ROTATE) KGE_Q(KGE_DISTMULT)
         KGE_Q(KGE_COMPLEX) KGE_Q(KGE_ANALOGY) KGE_Q(KGE_RESCAL)
+        KGE_Q(KGE_TRANSM) KGE_Q(KGE_CP) KGE_Q(KGE_SIMPLE) KGE_Q(KGE_SIMPLE_IGNR) KGE_Q(KGE_QUATE)
         default: set_error("kge_eval: unsupported model %d", m->model); return -1;
     }
 #undef KGE_Q
     if (scores_out == nullptr) (void)hipMemsetAsync(p.rcount, 0, (size_t)2 * n * sizeof(int32_t), s);
 #define KGE_S(F, X) launch_tf_and_sweep<F, X>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s)
-    if (p.xform == X_NONE) {
+    if (p.post == P_SCALE) {
+        if (p.form == F_L1) launch_tf_and_sweep<F_L1, X_NONE, P_SCALE>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s);
+        else launch_tf_and_sweep<F_L2, X_NONE, P_SCALE>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s);
+    } else if (p.post == P_CLAMP) {
+        launch_tf_and_sweep<F_NEGDOT, X_NONE, P_CLAMP>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s);
+    } else if (p.xform == X_NONE) {
         switch (p.form) {
             case F_L1: KGE_S(F_L1, X_NONE); break;
             case F_L2: KGE_S(F_L2, X_NONE); break;

@@ -36,6 +36,18 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
                                  int64_t n_pos, int neg_rate, float alpha, const float* bern, const uint64_t* slots,
                                  int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor, float* loss,
                                  hipStream_t s);
+// kge_score_ext.hip: the same generic kernels instantiated for TransM / CP / SimplE / SimplE_ignr / QuatE
+struct FusedSampler;
+int launch_score_forward_ext(const kge_model_desc* m, Geometry geo, const int64_t* h, const int64_t* r, const int64_t* t,
+                             int64_t n, float* scores, hipStream_t s);
+int launch_score_backward_ext(const kge_model_desc* m, Geometry geo, const int64_t* h, const int64_t* r, const int64_t* t,
+                              int64_t n, const float* dscore, hipStream_t s);
+int launch_pairwise_hinge_ext(const kge_model_desc* m, Geometry geo, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                              const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float margin,
+                              float* loss, const FusedSampler* fs, bool sampled, hipStream_t s);
+int launch_pointwise_logistic_ext(const kge_model_desc* m, Geometry geo, const int64_t* h, const int64_t* r, const int64_t* t,
+                                  const int64_t* y, int64_t n, int bundle, float lmbda, int reg_type, float* loss,
+                                  hipStream_t s);
 int launch_selfadv_coeffs(float* pos_scores, float* neg_scores, int64_t n_pos, int neg_rate, float alpha,
                           float* loss, hipStream_t s);
 

@@ -11,127 +11,9 @@
 // Roofline: HBM/L2-bound gather + atomic scatter (<= 3 flop/byte).  One G-lane group per triple keeps all of
 // its rows in registers from the gather to the gradient scatter; the only HBM traffic is the row gather, the
 // 24-byte id read and the float atomics into the dense gradient tables.
-#include "kge_internal.h"
-#include "kge_sampler_device.h"
+#include "kge_row_kernels.h"
 
 namespace kge {
-
-constexpr int kBlock = 256;
-constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident 256-thread blocks; rest is grid-stride
-
-__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // F.softplus, threshold 20
-__device__ __forceinline__ float sigmoid_t(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float logsigmoid_t(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
-
-template <int M, int G, int NCH>
-__global__ __launch_bounds__(kBlock) void k_score_fwd(DeviceModel m, const int64_t* __restrict__ h,
-                                                      const int64_t* __restrict__ r, const int64_t* __restrict__ t,
-                                                      int64_t n, float* __restrict__ out) {
-    constexpr int GPB = kBlock / G;
-    const int gl = threadIdx.x % G;
-    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n; i += (int64_t)gridDim.x * GPB) {
-        const int64_t id[3] = {h[i], r[i], t[i]};
-        Rows<M, NCH> R;
-        load_rows<M, G, NCH>(R, m, id, gl);
-        Saved<M, NCH> sv;
-        const float s = model_fwd<M, G, NCH>(R, m, sv);
-        if (gl == 0) out[i] = s;
-    }
-}
-
-template <int M, int G, int NCH>
-__global__ __launch_bounds__(kBlock) void k_score_bwd(DeviceModel m, const int64_t* __restrict__ h,
-                                                      const int64_t* __restrict__ r, const int64_t* __restrict__ t,
-                                                      int64_t n, const float* __restrict__ dscore) {
-    constexpr int GPB = kBlock / G;
-    const int gl = threadIdx.x % G;
-    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n; i += (int64_t)gridDim.x * GPB) {
-        const float ds = dscore[i];
-        if (ds == 0.f) continue;  // group-uniform
-        const int64_t id[3] = {h[i], r[i], t[i]};
-        Rows<M, NCH> R;
-        load_rows<M, G, NCH>(R, m, id, gl);
-        Saved<M, NCH> sv;
-        model_fwd<M, G, NCH>(R, m, sv);  // recompute: cheaper than spilling [B,d] intermediates to HBM
-        Rows<M, NCH> Gr;
-        model_bwd<M, G, NCH>(R, m, sv, ds, Gr);
-        scatter_rows<M, G, NCH>(Gr, m, id, gl);
-    }
-}
-
-// ---- fused pairwise hinge step: score(+) , score(-), max(0, s+ + margin - s-), both backward passes.
-// A negative produced by the reference sampler shares the relation and one entity with its positive
-// (data/generator.py:71-95); rows with equal ids get ONE combined atomic scatter (4 row scatters, not 6).
-// SAMPLED = true fuses the negative sampler in front (north_star: corruption + both scores + margin ranking + backward
-// in ONE kernel): the positive is triples[perm[start+i]] and its negative is drawn here by corrupt_one() with the same
-// Philox counters as the stand-alone sampler, so kge_sample_batch + kge_train_pairwise_hinge and this kernel see
-// identical batches.  Every lane of a group runs the (scalar) draw redundantly: no shuffle, no divergence.
-struct FusedSampler {
-    const int64_t* triples; const int64_t* perm; int64_t start; int64_t E;
-    const float* bern; const unsigned long long* slots; unsigned long long mask; unsigned long long seed, offset;
-    const int64_t* cursor;
-};
-
-template <int M, int G, int NCH, bool SAMPLED>
-__global__ __launch_bounds__(kBlock) void k_pairwise_hinge(DeviceModel m, const int64_t* __restrict__ ph,
-                                                           const int64_t* __restrict__ pr, const int64_t* __restrict__ pt,
-                                                           const int64_t* __restrict__ nh, const int64_t* __restrict__ nr,
-                                                           const int64_t* __restrict__ nt, int64_t n, float margin,
-                                                           float* __restrict__ loss, FusedSampler fs) {
-    constexpr int GPB = kBlock / G;
-    constexpr int NR = role_count(M);
-    const int gl = threadIdx.x % G;
-    float acc = 0.f;
-    int64_t s_start = 0;
-    unsigned long long s_off = 0;
-    if constexpr (SAMPLED) {
-        s_start = fs.cursor ? fs.start + fs.cursor[0] : fs.start;
-        s_off = fs.cursor ? fs.offset + (unsigned long long)fs.cursor[1] : fs.offset;
-    }
-    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n; i += (int64_t)gridDim.x * GPB) {
-        int64_t idp[3], idn[3];
-        if constexpr (SAMPLED) {
-            const int64_t row = fs.perm[s_start + i];
-            idp[0] = fs.triples[3 * row]; idp[1] = fs.triples[3 * row + 1]; idp[2] = fs.triples[3 * row + 2];
-            idn[1] = idp[1];
-            corrupt_one(idp[0], idp[1], idp[2], fs.E, fs.bern, fs.slots, fs.mask, fs.seed, s_off + (unsigned long long)i,
-                        idn[0], idn[2]);
-        } else {
-            idp[0] = ph[i]; idp[1] = pr[i]; idp[2] = pt[i];
-            idn[0] = nh[i]; idn[1] = nr[i]; idn[2] = nt[i];
-        }
-        Rows<M, NCH> Rp, Rn;
-        load_rows<M, G, NCH>(Rp, m, idp, gl);
-        load_rows<M, G, NCH>(Rn, m, idn, gl);
-        Saved<M, NCH> svp, svn;
-        const float sp = model_fwd<M, G, NCH>(Rp, m, svp);
-        const float sn = model_fwd<M, G, NCH>(Rn, m, svn);
-        const float v = sp + margin - sn;
-        acc += fmaxf(v, 0.f);
-        const float coef = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);  // ATen max(a, 0) backward splits ties
-        if (coef != 0.f) {
-            Rows<M, NCH> Gp, Gn;
-            model_bwd<M, G, NCH>(Rp, m, svp, coef, Gp);
-            model_bwd<M, G, NCH>(Rn, m, svn, -coef, Gn);
-#pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                const int sel = role_sel(M, q);
-                const int d = role_dim<M>(m, q);
-                float* gt = m.grad[role_tab(M, q)];
-                if (idp[sel] == idn[sel]) {
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) Gp.x[q][c] += Gn.x[q][c];
-                    atomic_add_row<G, NCH>(gt + idp[sel] * (int64_t)d, Gp.x[q], d, gl);
-                } else {
-                    atomic_add_row<G, NCH>(gt + idp[sel] * (int64_t)d, Gp.x[q], d, gl);
-                    atomic_add_row<G, NCH>(gt + idn[sel] * (int64_t)d, Gn.x[q], d, gl);
-                }
-            }
-        }
-    }
-    block_accumulate_loss<G>(acc, gl, loss);
-}
-
 
 // ---- TransE, sampler fused, shared rows loaded ONCE.  A sampled negative is the positive with its head OR its tail
 // replaced (data/generator.py:77-95), so a pair touches 4 distinct rows: H, R, T and the corrupting entity C -- not 6.
@@ -453,227 +335,6 @@ __global__ __launch_bounds__(kBlock) void k_transx_pair_sampled(DeviceModel m, i
     block_accumulate_loss<G>(acc, gl, loss);
 }
 
-// ---- fused pointwise step: mean(softplus(y*s)) + lmbda * mean_i(sum of squares/cubes of the rows of row i)
-template <int M, int G, int NCH>
-__global__ __launch_bounds__(kBlock) void k_pointwise_logistic(DeviceModel m, const int64_t* __restrict__ h,
-                                                               const int64_t* __restrict__ r, const int64_t* __restrict__ t,
-                                                               const int64_t* __restrict__ y, int64_t n, float lmbda,
-                                                               int reg_type, float* __restrict__ loss) {
-    constexpr int GPB = kBlock / G;
-    constexpr int NR = role_count(M);
-    const int gl = threadIdx.x % G;
-    const float inv_n = 1.0f / (float)n;
-    float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n; i += (int64_t)gridDim.x * GPB) {
-        const int64_t id[3] = {h[i], r[i], t[i]};
-        const float yy = (float)y[i];
-        Rows<M, NCH> R;
-        load_rows<M, G, NCH>(R, m, id, gl);
-        Saved<M, NCH> sv;
-        const float s = model_fwd<M, G, NCH>(R, m, sv);
-        const float x = yy * s;
-        acc += softplus_t(x) * inv_n;
-        const float ds = yy * sigmoid_t(x) * inv_n;
-        Rows<M, NCH> Gr;
-        model_bwd<M, G, NCH>(R, m, sv, ds, Gr);
-        if (reg_type != KGE_REG_NONE) {
-            float rs = 0.f;
-            const float c2 = 2.f * lmbda * inv_n, c3 = 3.f * lmbda * inv_n;
-#pragma unroll
-            for (int q = 0; q < NR; ++q) {
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const float v = R.x[q][c];
-                    if (reg_type == KGE_REG_F2) { rs = fmaf(v, v, rs); Gr.x[q][c] += c2 * v; }
-                    else if (reg_type == KGE_REG_N3) { rs += v * v * v; Gr.x[q][c] += c3 * v * v; }
-                    else { const float a = fabsf(v); rs += a * a * a; Gr.x[q][c] += c3 * v * a; }
-                }
-            }
-            acc += lmbda * inv_n * gsum<G>(rs);
-        }
-        scatter_rows<M, G, NCH>(Gr, m, id, gl);
-    }
-    block_accumulate_loss<G>(acc, gl, loss);
-}
-
-// ---- pointwise step over BUNDLES: the reference sampler emits each positive followed by its neg_rate corruptions
-// (data/generator.py:125-156), which share the relation row(s) and one entity's row(s) with it.  One group walks the
-// `bundle` consecutive rows, accumulating in registers every gradient row whose id equals the bundle's first row's id
-// for that role, and scatters those once: 1+neg_rate rows cost NR + neg_rate*(rows of one entity) scatters instead of
-// (1+neg_rate)*NR.  Pure id-equality test, so it is exact for arbitrary input rows too.
-// Batches are sorted by relation (generator), so a group also walks CHB consecutive bundles and carries the RELATION
-// rows' gradients across them while the relation id does not change (few-relation graphs such as WN18RR otherwise
-// funnel thousands of atomic row-adds per step into a dozen rows, i.e. into a handful of memory channels).
-constexpr int kMaxChunkBundles = 8;
-static int chunk_bundles(int64_t nb) {  // enough groups to fill the chip first, then amortise relation scatters
-    int64_t c = nb / 2048;
-    return (int)(c < 1 ? 1 : (c > kMaxChunkBundles ? kMaxChunkBundles : c));
-}
-
-template <int M, int G, int NCH>
-__global__ __launch_bounds__(kBlock) void k_pointwise_bundle(DeviceModel m, const int64_t* __restrict__ h,
-                                                             const int64_t* __restrict__ r, const int64_t* __restrict__ t,
-                                                             const int64_t* __restrict__ y, int64_t n, int bundle, int CHB,
-                                                             float lmbda, int reg_type, float* __restrict__ loss) {
-    constexpr int GPB = kBlock / G;
-    constexpr int NR = role_count(M);
-    const int gl = threadIdx.x % G;
-    const float inv_n = 1.0f / (float)n;
-    const float c2 = 2.f * lmbda * inv_n, c3 = 3.f * lmbda * inv_n;
-    const int64_t nb = (n + bundle - 1) / bundle;
-    const int64_t nchunks = (nb + CHB - 1) / CHB;
-    float acc = 0.f;
-    for (int64_t ck = (int64_t)blockIdx.x * GPB + threadIdx.x / G; ck < nchunks; ck += (int64_t)gridDim.x * GPB) {
-        Rows<M, NCH> A;  // anchors: entity roles are reset per bundle, relation roles persist while the relation id holds
-        int64_t ida[3] = {-1, -1, -1};
-        auto flush_role = [&](int q) {
-            const int sel = role_sel(M, q);
-            if (ida[sel] < 0) return;
-            const int d = role_dim<M>(m, q);
-            atomic_add_row<G, NCH>(m.grad[role_tab(M, q)] + ida[sel] * (int64_t)d, A.x[q], d, gl);
-        };
-        const int64_t b1 = min(nb, (ck + 1) * CHB);
-        for (int64_t b = ck * CHB; b < b1; ++b) {
-            const int64_t i0 = b * bundle;
-            const int64_t idb[3] = {h[i0], r[i0], t[i0]};
-            const bool same_rel = idb[1] == ida[1];  // group-uniform
-#pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                const int sel = role_sel(M, q);
-                if (sel == 1 && same_rel) continue;  // keep accumulating this relation's rows
-                flush_role(q);
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) A.x[q][c] = 0.f;
-            }
-            ida[0] = idb[0]; ida[1] = idb[1]; ida[2] = idb[2];
-            const int64_t i1 = min(n, i0 + bundle);
-            for (int64_t i = i0; i < i1; ++i) {
-                const int64_t id[3] = {h[i], r[i], t[i]};
-                const float yy = (float)y[i];
-                Rows<M, NCH> R, Gr;
-                Saved<M, NCH> sv;
-                load_rows<M, G, NCH>(R, m, id, gl);
-                const float s = model_fwd<M, G, NCH>(R, m, sv);
-                const float x = yy * s;
-                acc += softplus_t(x) * inv_n;
-                model_bwd<M, G, NCH>(R, m, sv, yy * sigmoid_t(x) * inv_n, Gr);
-                if (reg_type != KGE_REG_NONE) {
-                    float rs = 0.f;
-#pragma unroll
-                    for (int q = 0; q < NR; ++q) {
-#pragma unroll
-                        for (int c = 0; c < NCH; ++c) {
-                            const float v = R.x[q][c];
-                            if (reg_type == KGE_REG_F2) { rs = fmaf(v, v, rs); Gr.x[q][c] += c2 * v; }
-                            else if (reg_type == KGE_REG_N3) { rs += v * v * v; Gr.x[q][c] += c3 * v * v; }
-                            else { const float a = fabsf(v); rs += a * a * a; Gr.x[q][c] += c3 * v * a; }
-                        }
-                    }
-                    acc += lmbda * inv_n * gsum<G>(rs);
-                }
-#pragma unroll
-                for (int q = 0; q < NR; ++q) {
-                    const int sel = role_sel(M, q);
-                    if (id[sel] == ida[sel]) {
-#pragma unroll
-                        for (int c = 0; c < NCH; ++c) A.x[q][c] += Gr.x[q][c];
-                    } else {
-                        const int d = role_dim<M>(m, q);
-                        atomic_add_row<G, NCH>(m.grad[role_tab(M, q)] + id[sel] * (int64_t)d, Gr.x[q], d, gl);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NR; ++q) flush_role(q);
-    }
-    block_accumulate_loss<G>(acc, gl, loss);
-}
-
-// ---- fused self-adversarial step (criterion.py:13-23 + trainer.py:147-157): one group owns a positive AND its
-// neg_rate negatives (rows [i*neg_rate, (i+1)*neg_rate), data/generator.py:71-95).  Pass 1 scores the 1+neg_rate
-// triples (lane j of the group keeps the energy of negative j), the group computes the detached softmax weights and
-// the loss; pass 2 re-gathers each triple (L2 hits), back-propagates, and accumulates every gradient row whose id
-// equals the positive's id for that role in REGISTERS -- a sampled negative shares its relation and one entity with
-// its positive, so 1+neg_rate triples scatter ~(NR + neg_rate*(rows of one entity)) rows instead of (1+neg_rate)*NR.
-template <int M, int G, int NCH>
-__global__ __launch_bounds__(kBlock) void k_selfadv_bundle(DeviceModel m, const int64_t* __restrict__ ph,
-                                                           const int64_t* __restrict__ pr, const int64_t* __restrict__ pt,
-                                                           const int64_t* __restrict__ nh, const int64_t* __restrict__ nr,
-                                                           const int64_t* __restrict__ nt, int64_t n_pos, int neg_rate,
-                                                           float alpha, float* __restrict__ loss) {
-    constexpr int GPB = kBlock / G;
-    constexpr int NR = role_count(M);
-    const int gl = threadIdx.x % G;
-    const float inv_b = 1.0f / (float)n_pos;
-    float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n_pos; i += (int64_t)gridDim.x * GPB) {
-        const int64_t idp[3] = {ph[i], pr[i], pt[i]};
-        // ---- pass 1: energies
-        float s_mine = 0.f;  // lane j: energy of negative j
-        float s_pos;
-        {
-            Rows<M, NCH> R;
-            Saved<M, NCH> sv;
-            load_rows<M, G, NCH>(R, m, idp, gl);
-            s_pos = model_fwd<M, G, NCH>(R, m, sv);
-            for (int j = 0; j < neg_rate; ++j) {
-                const int64_t q = i * neg_rate + j;
-                const int64_t idn[3] = {nh[q], nr[q], nt[q]};
-                load_rows<M, G, NCH>(R, m, idn, gl);
-                const float sj = model_fwd<M, G, NCH>(R, m, sv);
-                if (gl == j) s_mine = sj;
-            }
-        }
-        // ---- loss and coefficients: n_j = -s_j, w = softmax(alpha n), L_i = -sum w logsig(-n) - logsig(-s_pos)
-        const bool live = gl < neg_rate;
-        const float nj = -s_mine;
-        float mx = live ? nj * alpha : -INFINITY;
-#pragma unroll
-        for (int o = G / 2; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));  // max: rare, keep the shuffle form
-        const float ex = live ? expf(nj * alpha - mx) : 0.f;
-        const float den = gsum<G>(ex);
-        const float wj = ex / den;
-        const float term = gsum<G>(live ? wj * logsigmoid_t(-nj) : 0.f);
-        acc += (-term - logsigmoid_t(-s_pos)) * inv_b;
-        const float c_mine = live ? -(wj * sigmoid_t(nj)) * inv_b : 0.f;  // dL/d s_j
-        const float c_pos = sigmoid_t(s_pos) * inv_b;                      // dL/d s_pos
-        // ---- pass 2: backward with anchor accumulation
-        Rows<M, NCH> A;  // gradient rows of the positive's ids
-        {
-            Rows<M, NCH> R;
-            Saved<M, NCH> sv;
-            load_rows<M, G, NCH>(R, m, idp, gl);
-            model_fwd<M, G, NCH>(R, m, sv);
-            model_bwd<M, G, NCH>(R, m, sv, c_pos, A);
-        }
-        for (int j = 0; j < neg_rate; ++j) {
-            const float cj = __shfl(c_mine, (threadIdx.x / G) * G % 64 + j, 64);
-            if (cj == 0.f) continue;
-            const int64_t q = i * neg_rate + j;
-            const int64_t idn[3] = {nh[q], nr[q], nt[q]};
-            Rows<M, NCH> R, Gn;
-            Saved<M, NCH> sv;
-            load_rows<M, G, NCH>(R, m, idn, gl);
-            model_fwd<M, G, NCH>(R, m, sv);
-            model_bwd<M, G, NCH>(R, m, sv, cj, Gn);
-#pragma unroll
-            for (int q2 = 0; q2 < NR; ++q2) {
-                const int sel = role_sel(M, q2);
-                if (idn[sel] == idp[sel]) {
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) A.x[q2][c] += Gn.x[q2][c];
-                } else {
-                    const int d = role_dim<M>(m, q2);
-                    atomic_add_row<G, NCH>(m.grad[role_tab(M, q2)] + idn[sel] * (int64_t)d, Gn.x[q2], d, gl);
-                }
-            }
-        }
-        scatter_rows<M, G, NCH>(A, m, idp, gl);
-    }
-    block_accumulate_loss<G>(acc, gl, loss);
-}
-
 // ---- RotatE, sampler fused, shared rows loaded ONCE per bundle (config C3: d=1000, neg_rate 16).
 // A bundle = a positive (h,r,t) and its neg_rate corruptions; every negative differs from the positive in ONE entity,
 // so the five rows of the positive (h_re, h_im, rel, t_re, t_im), the sin/cos of the relation phases and the rotated
@@ -826,32 +487,6 @@ __global__ __launch_bounds__(kBlock) void k_selfadv_coeffs(float* __restrict__ p
     block_accumulate_loss<1>(acc, 0, loss);
 }
 
-// ------------------------------------------------------------------ dispatch
-template <int M, int G, int NCH>
-struct Launch {
-    static int grid(int64_t n) {
-        int64_t b = (n + (kBlock / G) - 1) / (kBlock / G);
-        return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
-    }
-};
-
-#define KGE_FOR_GEOMETRY(MID, G_, NCH_, BODY)                   \
-    if (geo.G == G_ && geo.NCH == NCH_) {                       \
-        constexpr int M = MID;                                  \
-        constexpr int G = G_; constexpr int NCH = NCH_;         \
-        BODY;                                                   \
-        return check_launch(#MID);                              \
-    }
-#define KGE_FOR_MODEL(MID, BODY)                                \
-    case MID: {                                                 \
-        KGE_FOR_GEOMETRY(MID, 32, 1, BODY)                      \
-        KGE_FOR_GEOMETRY(MID, 32, 2, BODY)                      \
-        KGE_FOR_GEOMETRY(MID, 32, 4, BODY)                      \
-        KGE_FOR_GEOMETRY(MID, 32, 8, BODY)                      \
-        KGE_FOR_GEOMETRY(MID, 64, 8, BODY)                      \
-        KGE_FOR_GEOMETRY(MID, 64, 16, BODY)                     \
-        break;                                                  \
-    }
 #define KGE_DISPATCH(model_id, BODY)                            \
     switch (model_id) {                                         \
         KGE_FOR_MODEL(KGE_TRANSE, BODY)                         \
@@ -878,8 +513,7 @@ int launch_score_forward(const kge_model_desc* m, const int64_t* h, const int64_
     if (!geometry_for(m, &geo)) return -1;
     const DeviceModel dm = to_device_model(m);
     KGE_DISPATCH(m->model, (k_score_fwd<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, n, scores)))
-    set_error("kge_score_forward: unsupported model %d", m->model);
-    return -1;
+    return launch_score_forward_ext(m, geo, h, r, t, n, scores, s);
 }
 
 int launch_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
@@ -888,8 +522,7 @@ int launch_score_backward(const kge_model_desc* m, const int64_t* h, const int64
     if (!geometry_for(m, &geo)) return -1;
     const DeviceModel dm = to_device_model(m);
     KGE_DISPATCH(m->model, (k_score_bwd<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, n, dscore)))
-    set_error("kge_score_backward: unsupported model %d", m->model);
-    return -1;
+    return launch_score_backward_ext(m, geo, h, r, t, n, dscore, s);
 }
 
 int launch_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
@@ -900,8 +533,7 @@ int launch_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const int6
     const DeviceModel dm = to_device_model(m);
     const FusedSampler fs{};
     KGE_DISPATCH(m->model, (k_pairwise_hinge<M, G, NCH, false><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, ph, pr, pt, nh, nr, nt, n, margin, loss, fs)))
-    set_error("kge_train_pairwise_hinge: unsupported model %d", m->model);
-    return -1;
+    return launch_pairwise_hinge_ext(m, geo, ph, pr, pt, nh, nr, nt, n, margin, loss, &fs, false, s);
 }
 
 int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
@@ -940,8 +572,7 @@ int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triple
     }
     const int64_t* z = nullptr;
     KGE_DISPATCH(m->model, (k_pairwise_hinge<M, G, NCH, true><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, z, z, z, z, z, z, n, margin, loss, fs)))
-    set_error("kge_train_pairwise_hinge_sampled: unsupported model %d", m->model);
-    return -1;
+    return launch_pairwise_hinge_ext(m, geo, z, z, z, z, z, z, n, margin, loss, &fs, true, s);
 }
 
 int launch_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
@@ -953,12 +584,10 @@ int launch_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const i
         const int chb = chunk_bundles((n + bundle - 1) / bundle);
         const int64_t nb = ((n + bundle - 1) / bundle + chb - 1) / chb;
         KGE_DISPATCH(m->model, (k_pointwise_bundle<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(nb)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, bundle, chb, lmbda, reg_type, loss)))
-        set_error("kge_train_pointwise_logistic: unsupported model %d", m->model);
-        return -1;
+        return launch_pointwise_logistic_ext(m, geo, h, r, t, y, n, bundle, lmbda, reg_type, loss, s);
     }
     KGE_DISPATCH(m->model, (k_pointwise_logistic<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, lmbda, reg_type, loss)))
-    set_error("kge_train_pointwise_logistic: unsupported model %d", m->model);
-    return -1;
+    return launch_pointwise_logistic_ext(m, geo, h, r, t, y, n, bundle, lmbda, reg_type, loss, s);
 }
 
 int launch_selfadv_bundle(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,

@@ -36,6 +36,36 @@ class TransE(PairwiseModel):
         return self.ent_embeddings(h), self.rel_embeddings(r), self.ent_embeddings(t)
 
 
+class TransM(TransE):
+    """pairwise.py:281-365.  TransE distance weighted by a fixed per-relation theta_r computed from the train split."""
+    kernel_name = "transm"
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        train = kwargs["knowledge_graph"].read_cache_data("triplets_train")
+        self.theta = torch.from_numpy(self._theta(train, self.tot_relation)).to(kwargs["device"])
+
+    @staticmethod
+    def _theta(train, tot_relation):
+        """pairwise.py:303-315.  rel_head / rel_tail there are per-triple LISTS, so both lengths equal the relation's
+        triple count c:  theta_r = 1 / log(2 + c/(1+c) + c/(1+c))  (float64, stored as float32)."""
+        import numpy as np
+        if len(train) and hasattr(train[0], "r"):
+            rel = np.fromiter((t.r for t in train), dtype=np.int64, count=len(train))
+        else:
+            rel = np.asarray(train, dtype=np.int64).reshape(-1, 3)[:, 1]
+        c = np.bincount(rel, minlength=tot_relation).astype(np.float64)
+        return (1.0 / np.log(2.0 + c / (1.0 + c) + c / (1.0 + c))).astype(np.float32)
+
+    def make_desc(self, weights=None, grads=None):
+        if weights is None:
+            weights = [p.weight for p in self.parameter_list]
+        theta = self.theta if self.theta.device == weights[0].device else self.theta.to(weights[0].device)
+        self.theta = theta.contiguous()
+        return K.make_desc(self.kernel_name, list(weights) + [self.theta], None if grads is None else list(grads),
+                           tot_entity=self.tot_entity, tot_relation=self.tot_relation, **self.desc_kwargs())
+
+
 class TransH(PairwiseModel):
     """pairwise.py:96-182.  Entities projected onto the relation hyperplane (normal w_r) first."""
     kernel_name = "transh"

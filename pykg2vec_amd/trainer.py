@@ -169,7 +169,7 @@ class Trainer:
 
     def _accumulate_pointwise(self, h, r, t, y):
         # rows arrive as bundles [positive, its neg_rate negatives] (generator / data/generator.py:125-156)
-        self.K.train_pointwise_logistic(self._desc, h, r, t, y, self.model.lmbda, self.model.kernel_reg_type(),
+        self.K.train_pointwise_logistic(self._desc, h, r, t, y, self.model.kernel_lmbda(), self.model.kernel_reg_type(),
                                         self.loss_buf, bundle=1 + int(self.config.neg_rate))
 
     def _mean_type_loss(self):

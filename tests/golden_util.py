@@ -6,10 +6,14 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 CASES = ["transe_l1", "transe_l2", "transh_l1", "transh_l2", "transd_l1", "transd_l2", "rotate",
-         "rescal", "ntn", "distmult", "complex", "complexn3", "analogy"]
+         "rescal", "ntn", "distmult", "complex", "complexn3", "analogy",
+         "transm_l1", "transm_l2", "cp", "simple", "simple_ignr", "quate"]
 ORACLE_NAME = {"transe_l1": "transe", "transe_l2": "transe", "transh_l1": "transh", "transh_l2": "transh",
-               "transd_l1": "transd", "transd_l2": "transd"}
-POINTWISE = ("distmult", "complex", "complexn3", "analogy")
+               "transd_l1": "transd", "transd_l2": "transd", "transm_l1": "transm", "transm_l2": "transm"}
+POINTWISE = ("distmult", "complex", "complexn3", "analogy", "cp", "simple", "simple_ignr", "quate")
+# state_dict entries that are parameter tables of the scoring path (QuatE also carries unused fc / bn modules)
+TABLES = {"cp": ("sub_embeddings", "rel_embeddings", "obj_embeddings"),
+          "quate": tuple("%s_%s_embedding" % (a, c) for a in ("ent", "rel") for c in "sxyz") + ("rel_w_embedding",)}
 
 # fp32 tolerance of BASELINE.json north_star ("within 1e-5 fp32"); SURVEY.md section 7 explains why an
 # absolute 1e-5 alone is below fp32 rounding for L1 energies ~14, hence atol + rtol.
@@ -25,6 +29,8 @@ class Case:
         z = self.z
         self.E, self.R, self.B = int(z["E"]), int(z["R"]), int(z["B"])
         self.hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp_")}
+        if "theta" in z.files:  # TransM's fixed per-relation weights (a function of the train split)
+            self.hp["theta"] = z["theta"]
         self.pointwise = self.model in POINTWISE
         self.train, self.valid, self.test = z["train"], z["valid"], z["test"]
 
@@ -32,7 +38,9 @@ class Case:
         out = {}
         for k in self.z.files:
             if k.startswith(prefix) and k.endswith(".weight"):
-                out[k[len(prefix):-len(".weight")]] = self.z[k].copy()
+                name = k[len(prefix):-len(".weight")]
+                if self.model not in TABLES or name in TABLES[self.model]:
+                    out[name] = self.z[k].copy()
         return out
 
     def batch(self, s):

@@ -41,10 +41,17 @@ def make_config(E, R, hp, train, valid, test, optimizer="sgd", lr=0.05, batch_si
     return cfg
 
 
-def model_from_params(model_name, params, hp, E, R, device=DEV):
+def model_from_params(model_name, params, hp, E, R, device=DEV, train=None):
     cls = pa.import_model(model_name)
     kw = dict(hp)
     kw.update(tot_entity=E, tot_relation=R)
+    # constructor inputs some models read besides their hyper-parameters (TransM: train split + device,
+    # pairwise.py:299-315; SimplE: pointwise.py:478-479)
+    kw.setdefault("device", device)
+    kw.setdefault("batch_size", 32)
+    kw.setdefault("tot_train_triples", 0 if train is None else len(train))
+    if train is not None:
+        kw.setdefault("knowledge_graph", KG({"triplets_train": train}))
     m = cls(**kw)
     with torch.no_grad():
         for k, v in params.items():
@@ -53,7 +60,14 @@ def model_from_params(model_name, params, hp, E, R, device=DEV):
 
 
 def model_from_case(c, prefix="init.", device=DEV):
-    return model_from_params(c.model, c.params(prefix), c.hp, c.E, c.R, device)
+    return model_from_params(c.model, c.params(prefix), c.hp, c.E, c.R, device, train=c.train)
+
+
+def table_parameters(model):
+    """(state_dict name, parameter) of the model's embedding tables, parameter_list order (QuatE also registers
+    fc / bn modules its forward never uses)."""
+    named = {id(q): n for n, q in model.named_parameters()}
+    return [(named[id(p.weight)], p.weight) for p in model.parameter_list]
 
 
 def dev(a, dtype=torch.int64):

@@ -3,6 +3,7 @@ include/kge_hip.h declares (no compute calls), the drop-in classes keep the refe
 naming contract (pinned by the key names inside tests/golden, which come from the live reference), the filter
 CSR / metric code agrees with the oracle, and the product path refuses to run without the GPU."""
 import ctypes
+import types
 import os
 import re
 
@@ -31,9 +32,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_model_desc_struct_matches_header_layout():
     from pykg2vec_amd import _lib
-    # int32 model, uint32 flags, 2x int64, 2x int32, 2x float, 6+6 pointers
-    assert ctypes.sizeof(_lib.ModelDesc) == 4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 * 12
-    assert _lib.ModelDesc.tables.offset == 40 and _lib.ModelDesc.grads.offset == 88
+    # int32 model, uint32 flags, 2x int64, 2x int32, 2x float, 12+12 pointers (KGE_MAX_TABLES)
+    assert _lib.KGE_MAX_TABLES == 12
+    assert ctypes.sizeof(_lib.ModelDesc) == 4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 * 24
+    assert _lib.ModelDesc.tables.offset == 40 and _lib.ModelDesc.grads.offset == 40 + 8 * 12
 
 
 def test_argument_validation_without_gpu():
@@ -56,8 +58,11 @@ def test_dropin_classes_keep_reference_contract(name):
     from pykg2vec_amd.common import TrainingStrategy
     c = Case(name)
     cls = pa.import_model(c.model)
-    kw = dict(c.hp, tot_entity=c.E, tot_relation=c.R)
+    kw = dict(c.hp, tot_entity=c.E, tot_relation=c.R, device="cpu", batch_size=c.B, tot_train_triples=len(c.train),
+              knowledge_graph=types.SimpleNamespace(read_cache_data=lambda key: c.train))
     m = cls(**kw)
+    if c.model == "transm":  # the fixed per-relation weights are derived from the train split exactly as the reference does
+        assert np.array_equal(m.theta.numpy(), c.z["theta"])
     ref_keys = sorted(k[len("init."):] for k in c.z.files if k.startswith("init."))
     assert sorted(m.state_dict().keys()) == ref_keys                       # reference checkpoint key names
     for k in ref_keys:

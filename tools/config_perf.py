@@ -23,6 +23,16 @@ CONFIGS = [
     ("C3 RotatE FB15k-237 d=1000 B=1024 neg16 adam", "rotate", "fb15k237", dict(hidden_size=1000, margin=24.0, neg_rate=16, alpha=1.0), "adam", 1024, 16, 2048),
     ("C4 RESCAL YAGO3-10 k=200 B=1024 adam", "rescal", "yago310", dict(hidden_size=200, margin=1.0), "adam", 1024, 1, 1024),
     ("RESCAL FB15k k=50 B=128 adam (preset)", "rescal", "fb15k", dict(hidden_size=50, margin=1.0), "adam", 128, 1, 1024),
+    ("TransM FB15k d=50 B=1200 sgd (preset)", "transm", "fb15k", dict(hidden_size=50, l1_flag=False, margin=0.5), "sgd", 1200, 1, 8192),
+    ("TransM FB15k d=100 B=32768 adam", "transm", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 8192),
+    ("CP FB15k d=50 B=128 adagrad (preset)", "cp", "fb15k", dict(hidden_size=50, lmbda=1e-4), "adagrad", 128, 1, 8192),
+    ("CP FB15k d=100 B=32768 adagrad", "cp", "fb15k", dict(hidden_size=100, lmbda=1e-4), "adagrad", 32768, 1, 0),
+    ("SimplE FB15k d=100 B=128 adagrad (preset)", "simple", "fb15k", dict(hidden_size=100, lmbda=0.1), "adagrad", 128, 1, 8192),
+    ("SimplE FB15k d=100 B=32768 adagrad", "simple", "fb15k", dict(hidden_size=100, lmbda=0.1), "adagrad", 32768, 1, 0),
+    ("SimplE_ignr FB15k d=100 B=32768 adagrad", "simple_ignr", "fb15k", dict(hidden_size=100, lmbda=0.1), "adagrad", 32768, 1, 2048),
+    ("QuatE FB15k d=200 B=100 adagrad (preset)", "quate", "fb15k", dict(hidden_size=200, lmbda=0.1), "adagrad", 100, 1, 2048),
+    ("QuatE FB15k d=100 B=32768 adagrad", "quate", "fb15k", dict(hidden_size=100, lmbda=0.1), "adagrad", 32768, 1, 0),
+    ("QuatE WN18 d=300 B=4096 adagrad", "quate", "wn18rr", dict(hidden_size=300, lmbda=0.05), "adagrad", 4096, 1, 0),
     ("NTN FB15k d=k=100 B=128 adam (preset)", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 128, 1, 64),
 ]
 only = os.environ.get("ONLY")
@@ -37,7 +47,7 @@ for name, model, ds, hp, opt, B, neg, n_eval in CONFIGS:
     cfg = hip_util.make_config(E, R, hp2, train, test[:16], test, optimizer=opt, lr=0.01, batch_size=B)
     cfg.hr_dummy = None
     torch.manual_seed(0)
-    m = hip_util.model_from_params(model, {}, hp, E, R)
+    m = hip_util.model_from_params(model, {}, hp, E, R, train=train)
     tr = Trainer(m, cfg); tr.build_model()
     tr.generator = tr._new_generator()
     K_ = min(200, max(1, NTR // B))
