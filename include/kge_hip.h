@@ -45,7 +45,8 @@ enum kge_model {
     KGE_CP = 10,      /* pointwise.py:320-387 sub_embeddings, rel_embeddings, obj_embeddings */
     KGE_SIMPLE = 11,  /* pointwise.py:461-546 ent_head, ent_tail, rel, rel_inv; energy = -clamp(<h,r,t> + <t,r_inv,h>/2, +-20) */
     KGE_SIMPLE_IGNR = 12, /* pointwise.py:549-592 same tables; energy = -clamp(<h,r,t> + <t,r_inv,h>, +-20) */
-    KGE_QUATE = 13    /* pointwise.py:595-768 ent_s, ent_x, ent_y, ent_z, rel_s, rel_x, rel_y, rel_z (rel_w is unused by forward) */
+    KGE_QUATE = 13,   /* pointwise.py:595-768 ent_s, ent_x, ent_y, ent_z, rel_s, rel_x, rel_y, rel_z (rel_w is unused by forward) */
+    KGE_TRANSR = 14   /* pairwise.py:367-470  ent_embeddings[E,dim], rel_embeddings[R,rel_dim], rel_matrix[R, dim*rel_dim] */
 };
 
 #define KGE_FLAG_L1 1u /* l1_flag of TransE/TransH/TransD (pairwise.py:72-76) */
@@ -73,7 +74,7 @@ int kge_abi_version(void);
 const char* kge_last_error(void);
 
 /* Scratch bytes the score / train entry points need for a call on n rows (n pairs for the pairwise step).
- * 0 for the gather-type models; RESCAL groups the batch by relation on the device ((4*(R+1) + n + 8) ints per side),
+ * 0 for the gather-type models; RESCAL and TransR group the batch by relation on the device (about 5R + n + n/32 ints per side),
  * NTN keeps n*(4d + 3k_r + 6) floats of intermediates per side; the hinge step adds 2n floats. */
 size_t kge_workspace_bytes(const kge_model_desc* m, int64_t n);
 
@@ -160,7 +161,9 @@ int kge_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, 
  *   head_off/ids   CSR over queries: known heads of (t_i, r_i) = tr_h[(t,r)]
  *   ranks          int32 [4,n]: rank_head, rank_tail, filtered_rank_head, filtered_rank_tail (0-based, as the
  *                  reference before settle() adds 1); rank = #{e : s_e < s_true}
- * workspace from kge_eval_workspace_bytes(). */
+ * workspace from kge_eval_workspace_bytes().
+ * TransR: candidates are scored in the relation space, so the sweep table is projected by M_r once per call and ALL n
+ * triples of a call must carry the same relation id (triples[1] is used); the host groups test triples by relation. */
 size_t kge_eval_workspace_bytes(const kge_model_desc* m, int64_t n);
 int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n,
                    const int64_t* tail_off, const int32_t* tail_ids,

@@ -43,13 +43,14 @@ PARAM_NAMES = {
                 "rel_embeddings_real", "rel_embeddings_img"],
     # pairwise.py:299-320 ; pointwise.py:339-356,481-500,620-676
     "transm": ["ent_embeddings", "rel_embeddings"],
+    "transr": ["ent_embeddings", "rel_embeddings", "rel_matrix"],  # pairwise.py:389-402
     "cp": ["sub_embeddings", "rel_embeddings", "obj_embeddings"],
     "simple": ["ent_head_embeddings", "ent_tail_embeddings", "rel_embeddings", "rel_inv_embeddings"],
     "simple_ignr": ["ent_head_embeddings", "ent_tail_embeddings", "rel_embeddings", "rel_inv_embeddings"],
     "quate": ["ent_s_embedding", "ent_x_embedding", "ent_y_embedding", "ent_z_embedding",
               "rel_s_embedding", "rel_x_embedding", "rel_y_embedding", "rel_z_embedding", "rel_w_embedding"],
 }
-PAIRWISE = ("transe", "transh", "transd", "rotate", "rescal", "ntn", "transm")
+PAIRWISE = ("transe", "transh", "transd", "rotate", "rescal", "ntn", "transm", "transr")
 POINTWISE = ("distmult", "complex", "complexn3", "analogy", "cp", "simple", "simple_ignr", "quate")
 
 
@@ -59,6 +60,9 @@ def param_shapes(model, tot_entity, tot_relation, hidden_size=None, ent_hidden_s
     E, R, k = tot_entity, tot_relation, hidden_size
     if model in ("transe", "distmult", "transm"):
         return {"ent_embeddings": (E, k), "rel_embeddings": (R, k)}
+    if model == "transr":
+        return {"ent_embeddings": (E, ent_hidden_size), "rel_embeddings": (R, rel_hidden_size),
+                "rel_matrix": (R, ent_hidden_size * rel_hidden_size)}
     if model == "cp":
         return {"sub_embeddings": (E, k), "rel_embeddings": (R, k), "obj_embeddings": (E, k)}
     if model in ("simple", "simple_ignr"):
@@ -225,6 +229,13 @@ def score(model, params, h, r, t, dtype=np.float32, **hp):
     if model == "transm":  # pairwise.py:325-347: theta_r * TransE distance; hp["theta"] = transm_theta(train, R)
         s, _ = _trans_tail(P["ent_embeddings"][h], P["rel_embeddings"][r], P["ent_embeddings"][t], hp["l1_flag"])
         return np.asarray(hp["theta"], dtype=dtype)[r] * s
+    if model == "transr":  # pairwise.py:404-470: normalise, project by M_r = rel_matrix[r].view(d_e, d_r), TransE tail
+        hh, _ = _normalize(P["ent_embeddings"][h])
+        rh, _ = _normalize(P["rel_embeddings"][r])
+        th, _ = _normalize(P["ent_embeddings"][t])
+        M = P["rel_matrix"][r].reshape(len(r), hh.shape[1], rh.shape[1])
+        s, _ = _trans_tail(np.einsum("na,nab->nb", hh, M), rh, np.einsum("na,nab->nb", th, M), hp["l1_flag"])
+        return s
     if model == "cp":  # pointwise.py:374-376
         return -np.sum(P["sub_embeddings"][h] * P["rel_embeddings"][r] * P["obj_embeddings"][t], axis=-1)
     if model in ("simple", "simple_ignr"):  # pointwise.py:522-526, 581-585
@@ -400,6 +411,20 @@ def score_grad(model, params, h, r, t, ds, dtype=np.float32, **hp):
         s, saved = _trans_tail(a, b, c, hp["l1_flag"])
         ga, gb, gc = _trans_tail_bwd(a, b, c, saved, s, ds * np.asarray(hp["theta"], dtype=dtype)[r], hp["l1_flag"])
         add("ent_embeddings", h, ga); add("rel_embeddings", r, gb); add("ent_embeddings", t, gc)
+    elif model == "transr":
+        eh, er, et = P["ent_embeddings"][h], P["rel_embeddings"][r], P["ent_embeddings"][t]
+        hh, nh = _normalize(eh); rh, nr = _normalize(er); th, nt = _normalize(et)
+        de, dr = hh.shape[1], rh.shape[1]
+        M = P["rel_matrix"][r].reshape(len(r), de, dr)
+        a, c = np.einsum("na,nab->nb", hh, M), np.einsum("na,nab->nb", th, M)
+        s, saved = _trans_tail(a, rh, c, hp["l1_flag"])
+        ga, gb, gc = _trans_tail_bwd(a, rh, c, saved, s, ds, hp["l1_flag"])
+        gM = np.einsum("na,nb->nab", hh, ga) + np.einsum("na,nb->nab", th, gc)
+        add("rel_matrix", r, gM.reshape(len(r), de * dr))
+        eps = dtype(EPS_NORMALIZE)
+        add("ent_embeddings", h, _normalize_bwd(hh, nh, _norm_rows(eh) > eps, np.einsum("nab,nb->na", M, ga)))
+        add("ent_embeddings", t, _normalize_bwd(th, nt, _norm_rows(et) > eps, np.einsum("nab,nb->na", M, gc)))
+        add("rel_embeddings", r, _normalize_bwd(rh, nr, _norm_rows(er) > eps, gb))
     elif model == "cp":
         eh, er, et = P["sub_embeddings"][h], P["rel_embeddings"][r], P["obj_embeddings"][t]
         nds = -ds[:, None]

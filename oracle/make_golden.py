@@ -54,6 +54,8 @@ MODELS = {
     "simple": ("pointwise.SimplE", dict(hidden_size=18, lmbda=0.01)),
     "simple_ignr": ("pointwise.SimplE_ignr", dict(hidden_size=18, lmbda=0.01)),
     "quate": ("pointwise.QuatE", dict(hidden_size=12, lmbda=0.01)),
+    "transr_l1": ("pairwise.TransR", dict(ent_hidden_size=14, rel_hidden_size=10, l1_flag=True, margin=1.0)),
+    "transr_l2": ("pairwise.TransR", dict(ent_hidden_size=14, rel_hidden_size=10, l1_flag=False, margin=1.0)),
 }
 E, R, B = 53, 7, 32
 N_STEPS = 3

@@ -12,7 +12,7 @@ MODEL_MAP = {  # lower-case name -> "module.Class", same keys as Importer.modelM
     "transe": "pairwise.TransE", "transh": "pairwise.TransH", "transd": "pairwise.TransD", "rotate": "pairwise.RotatE",
     "rescal": "pairwise.Rescal", "ntn": "pairwise.NTN", "distmult": "pointwise.DistMult", "complex": "pointwise.Complex",
     "complexn3": "pointwise.ComplexN3", "analogy": "pointwise.ANALOGY",
-    "transm": "pairwise.TransM", "cp": "pointwise.CP", "simple": "pointwise.SimplE",
+    "transm": "pairwise.TransM", "transr": "pairwise.TransR", "cp": "pointwise.CP", "simple": "pointwise.SimplE",
     "simple_ignr": "pointwise.SimplE_ignr", "quate": "pointwise.QuatE",
 }
 

@@ -14,7 +14,7 @@ ABI_VERSION = 2
 
 # enum kge_model
 (TRANSE, TRANSH, TRANSD, ROTATE, RESCAL, NTN, DISTMULT, COMPLEX, ANALOGY, TRANSM, CP, SIMPLE, SIMPLE_IGNR,
- QUATE) = range(14)
+ QUATE, TRANSR) = range(15)
 FLAG_L1 = 1
 OPT_SGD, OPT_ADAM, OPT_ADAGRAD, OPT_RMSPROP = range(4)
 REG_NONE, REG_F2, REG_N3, REG_N3_ABS, REG_ID_F2, REG_ID_N3 = range(6)

@@ -43,7 +43,7 @@ static int table_count(int model) {
         case KGE_TRANSH: case KGE_ROTATE: return 3;
         case KGE_TRANSD: case KGE_COMPLEX: return 4;
         case KGE_NTN: case KGE_ANALOGY: return 6;
-        case KGE_TRANSM: case KGE_CP: return 3;
+        case KGE_TRANSM: case KGE_CP: case KGE_TRANSR: return 3;
         case KGE_SIMPLE: case KGE_SIMPLE_IGNR: return 4;
         case KGE_QUATE: return 8;
     }
@@ -109,6 +109,7 @@ int kge_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* 
     hipStream_t s = (hipStream_t)stream;
     if (m->model == KGE_RESCAL) return launch_rescal_forward(m, h, r, t, n, scores, workspace, workspace_bytes, s);
     if (m->model == KGE_NTN) return launch_ntn_forward(m, h, r, t, n, scores, workspace, workspace_bytes, s);
+    if (m->model == KGE_TRANSR) return launch_transr_forward(m, h, r, t, n, scores, workspace, workspace_bytes, s);
     return launch_score_forward(m, h, r, t, n, scores, s);
 }
 
@@ -118,8 +119,9 @@ int kge_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t*
     if (n == 0) return 0;
     if (n < 0 || !h || !r || !t || !dscore) { set_error("kge_score_backward: bad arguments"); return -1; }
     hipStream_t s = (hipStream_t)stream;
-    if (m->model == KGE_RESCAL) return launch_rescal_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, s);
+    if (m->model == KGE_RESCAL) return launch_rescal_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, false, s);
     if (m->model == KGE_NTN) return launch_ntn_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, false, s);
+    if (m->model == KGE_TRANSR) return launch_transr_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, false, s);
     return launch_score_backward(m, h, r, t, n, dscore, s);
 }
 
@@ -154,8 +156,13 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
         if ((rc = launch_ntn_backward(m, ph, pr, pt, n, sp, wsp, gws, true, s))) return rc;
         return launch_ntn_backward(m, nh, nr, nt, n, sn, wsn, gws, true, s);
     }
-    if ((rc = kge_score_backward(m, ph, pr, pt, n, sp, wsp, gws, stream))) return rc;
-    return kge_score_backward(m, nh, nr, nt, n, sn, wsn, gws, stream);
+    // RESCAL / TransR: each side's forward left its relation grouping in that side's workspace
+    if (m->model == KGE_RESCAL) {
+        if ((rc = launch_rescal_backward(m, ph, pr, pt, n, sp, wsp, gws, true, s))) return rc;
+        return launch_rescal_backward(m, nh, nr, nt, n, sn, wsn, gws, true, s);
+    }
+    if ((rc = launch_transr_backward(m, ph, pr, pt, n, sp, wsp, gws, true, s))) return rc;
+    return launch_transr_backward(m, nh, nr, nt, n, sn, wsn, gws, true, s);
 }
 
 int kge_train_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,

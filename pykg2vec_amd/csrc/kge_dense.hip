@@ -14,33 +14,11 @@
 // MFMA operand maps (cdna_hip_programming.md section 3): A: lane l holds A[i=l&31][k=l>>5]; B: lane l holds
 // B[k=l>>5][j=l&31]; C/D: col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "kge_internal.h"
+#include "kge_relgroup.h"
 
 namespace kge {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int TILE = 32;  // triples per workgroup tile
-
-struct GroupWs {           // carved from the caller's workspace
-    int* counts;           // [R]   triples per relation
-    int* cursor;           // [R]   scatter cursors
-    int* offsets;          // [R+1] first grouped position of each relation
-    int* tile_off;         // [R+1] first tile of each relation
-    int* perm;             // [n]   grouped position -> original row
-};
-
-static size_t group_ws_bytes(int64_t R, int64_t n) { return (size_t)(4 * (R + 1) + n + 8) * sizeof(int); }
-
-static GroupWs carve(void* ws, int64_t R, int64_t n) {
-    GroupWs g;
-    int* p = (int*)ws;
-    g.counts = p; p += R + 1;
-    g.cursor = p; p += R + 1;
-    g.offsets = p; p += R + 1;
-    g.tile_off = p; p += R + 1;
-    g.perm = p;
-    return g;
-}
 
 __global__ void k_rel_hist(const int64_t* __restrict__ r, int64_t n, int* __restrict__ counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,33 +51,24 @@ __global__ __launch_bounds__(256) void k_rel_scan(const int* __restrict__ counts
 }
 
 __global__ void k_rel_scatter(const int64_t* __restrict__ r, int64_t n, const int* __restrict__ offsets,
-                              int* __restrict__ cursor, int* __restrict__ perm) {
+                              const int* __restrict__ tile_off, int* __restrict__ cursor, int* __restrict__ perm,
+                              int* __restrict__ tile_rel) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int rel = (int)r[i];
-    perm[offsets[rel] + atomicAdd(cursor + rel, 1)] = (int)i;
+    const int local = atomicAdd(cursor + rel, 1);
+    perm[offsets[rel] + local] = (int)i;
+    if (local % TILE == 0) tile_rel[tile_off[rel] + local / TILE] = rel;  // the first row of a tile names its relation
 }
 
-static int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s) {
+int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s) {
     hipError_t e = hipMemsetAsync(g.counts, 0, (size_t)2 * (R + 1) * sizeof(int), s);  // counts + cursor
     if (e != hipSuccess) { set_error("rescal grouping memset: %s", hipGetErrorString(e)); return -2; }
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_rel_hist, dim3(nb), dim3(256), 0, s, r, n, g.counts);
     hipLaunchKernelGGL(k_rel_scan, dim3(1), dim3(256), 0, s, g.counts, (int)R, g.offsets, g.tile_off);
-    hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(256), 0, s, r, n, g.offsets, g.cursor, g.perm);
+    hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(256), 0, s, r, n, g.offsets, g.tile_off, g.cursor, g.perm, g.tile_rel);
     return check_launch("rescal grouping");
-}
-
-// which (relation, tile-in-relation) is block `b`?  binary search in tile_off[0..R]
-__device__ __forceinline__ bool locate_tile(const int* __restrict__ tile_off, int R, int b, int& rel, int& tile_in_rel) {
-    if (b >= tile_off[R]) return false;
-    int lo = 0, hi = R;  // tile_off[lo] <= b < tile_off[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (tile_off[mid] <= b) lo = mid; else hi = mid;
-    }
-    rel = lo; tile_in_rel = b - tile_off[lo];
-    return true;
 }
 
 // MODE 0: scores.  MODE 1: gradients (needs dscore).
@@ -108,11 +77,11 @@ __global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, c
                                                 float* __restrict__ g_ent, float* __restrict__ g_rel,
                                                 const int64_t* __restrict__ h, const int64_t* __restrict__ t,
                                                 const int* __restrict__ offsets, const int* __restrict__ tile_off,
-                                                const int* __restrict__ perm, int R, int k,
+                                                const int* __restrict__ tile_rel, const int* __restrict__ perm, int R, int k,
                                                 const float* __restrict__ dscore, float* __restrict__ scores) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rel, tin;
-    if (!locate_tile(tile_off, R, blockIdx.x, rel, tin)) return;
+    if (!locate_tile(tile_off, tile_rel, R, blockIdx.x, rel, tin)) return;
     const int S = (k + 1) | 1;                 // odd LDS row stride: conflict-free column reads
     float* sT = smem;                          // [32][S]
     float* sH = sT + TILE * S;                 // [32][S]
@@ -235,11 +204,12 @@ static size_t rescal_lds_bytes(int k) {
 size_t dense_workspace_bytes(const kge_model_desc* m, int64_t n) {
     if (m->model == KGE_RESCAL) return group_ws_bytes(m->tot_relation, n);
     if (m->model == KGE_NTN) return ntn_workspace_bytes(m, n);
+    if (m->model == KGE_TRANSR) return transr_workspace_bytes(m, n);
     return 0;
 }
 
 static int rescal_run(int mode, const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
-                      const float* dscore, float* scores, void* ws, size_t ws_bytes, hipStream_t s) {
+                      const float* dscore, float* scores, void* ws, size_t ws_bytes, bool grouped, hipStream_t s) {
     const int k = m->dim;
     const int64_t R = m->tot_relation;
     if (k > 512) { set_error("RESCAL: hidden size %d exceeds the LDS-resident tile kernel (max 512)", k); return -1; }
@@ -248,10 +218,12 @@ static int rescal_run(int mode, const kge_model_desc* m, const int64_t* h, const
         set_error("RESCAL needs a workspace of %zu bytes (kge_workspace_bytes)", group_ws_bytes(R, n));
         return -1;
     }
-    const GroupWs g = carve(ws, R, n);
-    int rc = group_by_relation(r, n, R, g, s);
-    if (rc) return rc;
-    const unsigned max_tiles = (unsigned)(n / TILE + R + 1);  // upper bound on sum_r ceil(n_r / 32); surplus blocks exit
+    const GroupWs g = carve_group_ws(ws, R, n);
+    if (!grouped) {  // the fused train step's backward reuses the grouping its forward left in this workspace
+        int rc = group_by_relation(r, n, R, g, s);
+        if (rc) return rc;
+    }
+    const unsigned max_tiles = (unsigned)group_max_tiles(R, n);  // surplus blocks exit
     const size_t lds = rescal_lds_bytes(k);
     const int ntile = (k + 31) / 32;
     if (mode == 0) {
@@ -260,25 +232,25 @@ static int rescal_run(int mode, const kge_model_desc* m, const int64_t* h, const
         hipError_t e = hipMemsetAsync(scores, 0, (size_t)n * sizeof(float), s);
         if (e != hipSuccess) { set_error("rescal: memset: %s", hipGetErrorString(e)); return -2; }
         hipLaunchKernelGGL(k_rescal<0>, dim3(max_tiles, (unsigned)((ntile + 3) / 4)), dim3(256), lds, s, m->tables[0], m->tables[1], nullptr, nullptr, h, t,
-                           g.offsets, g.tile_off, g.perm, (int)R, k, nullptr, scores);
+                           g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, nullptr, scores);
     } else {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)k_rescal<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const int units = 2 * ntile + ntile * ntile;
         const unsigned ysplit = (unsigned)min(8, (units + 15) / 16);  // ~4 units per wave
         hipLaunchKernelGGL(k_rescal<1>, dim3(max_tiles, ysplit), dim3(256), lds, s, m->tables[0], m->tables[1], m->grads[0],
-                           m->grads[1], h, t, g.offsets, g.tile_off, g.perm, (int)R, k, dscore, nullptr);
+                           m->grads[1], h, t, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, dscore, nullptr);
     }
     return check_launch("k_rescal");
 }
 
 int launch_rescal_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
                           float* scores, void* ws, size_t ws_bytes, hipStream_t s) {
-    return rescal_run(0, m, h, r, t, n, nullptr, scores, ws, ws_bytes, s);
+    return rescal_run(0, m, h, r, t, n, nullptr, scores, ws, ws_bytes, false, s);
 }
 int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
-                           const float* dscore, void* ws, size_t ws_bytes, hipStream_t s) {
-    return rescal_run(1, m, h, r, t, n, dscore, nullptr, ws, ws_bytes, s);
+                           const float* dscore, void* ws, size_t ws_bytes, bool grouped, hipStream_t s) {
+    return rescal_run(1, m, h, r, t, n, dscore, nullptr, ws, ws_bytes, grouped, s);
 }
 
 // ---- W <- W / ||W_row||_2 in place (plain division, no eps: pairwise.py:862-865)

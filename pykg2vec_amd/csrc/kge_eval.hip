@@ -56,6 +56,7 @@ static int sweep_K(const kge_model_desc* m) {
         case KGE_COMPLEX: case KGE_ROTATE: case KGE_ANALOGY: return 2 * m->dim;
         case KGE_CP: case KGE_SIMPLE: case KGE_SIMPLE_IGNR: return 2 * m->dim;  // both entity tables side by side
         case KGE_QUATE: return 4 * m->dim;
+        case KGE_TRANSR: return m->rel_dim;  // candidates live in the relation space of the call's relation
         default: return m->dim;
     }
 }
@@ -67,7 +68,7 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p)
     p->xform = m->model == KGE_TRANSH ? X_TRANSH : m->model == KGE_TRANSD ? X_TRANSD : X_NONE;
     p->QV = p->xform == X_NONE ? 1 : 2;
     switch (m->model) {
-        case KGE_TRANSE: case KGE_TRANSH: case KGE_TRANSD: case KGE_TRANSM:
+        case KGE_TRANSE: case KGE_TRANSH: case KGE_TRANSD: case KGE_TRANSM: case KGE_TRANSR:
             p->form = (m->flags & KGE_FLAG_L1) ? F_L1 : F_L2; break;
         case KGE_ROTATE: p->form = F_SQM; break;
         case KGE_DISTMULT: case KGE_COMPLEX: case KGE_ANALOGY: case KGE_RESCAL:
@@ -721,6 +722,10 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
         return -1;
     }
     if (n <= 0) return 0;
+    if (m->model == KGE_TRANSR) {  // candidates projected by the call's relation matrix (all triples share it)
+        int rc = launch_transr_eval_prepare(m, triples, n, p.Kpad, p.ntiles, p.cand, p.qvec, p.qscale, s);
+        if (rc) return rc;
+    } else {
     PrepArgs pa;
     fill_prep(m, p, &pa);
     hipLaunchKernelGGL(k_eval_prepare, dim3((unsigned)p.ntiles), dim3(256), 0, s, pa, p.cand, p.aux);
@@ -734,6 +739,7 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
         default: set_error("kge_eval: unsupported model %d", m->model); return -1;
     }
 #undef KGE_Q
+    }
     if (scores_out == nullptr) (void)hipMemsetAsync(p.rcount, 0, (size_t)2 * n * sizeof(int32_t), s);
 #define KGE_S(F, X) launch_tf_and_sweep<F, X>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s)
     if (p.post == P_SCALE) {

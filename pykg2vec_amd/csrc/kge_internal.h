@@ -59,11 +59,19 @@ int launch_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbd
 int launch_rescal_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                           int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                           int64_t n, const float* dscore, void* ws, size_t ws_bytes, hipStream_t s);
+                           int64_t n, const float* dscore, void* ws, size_t ws_bytes, bool grouped, hipStream_t s);
 int launch_ntn_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                        int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_ntn_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                         int64_t n, const float* dscore, void* ws, size_t ws_bytes, bool forward_in_ws, hipStream_t s);
+// kge_transr.hip
+size_t transr_workspace_bytes(const kge_model_desc* m, int64_t n);
+int launch_transr_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                          int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_transr_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
+                           int64_t n, const float* dscore, void* ws, size_t ws_bytes, bool grouped, hipStream_t s);
+int launch_transr_eval_prepare(const kge_model_desc* m, const int64_t* triples, int64_t n, int Kpad, int64_t ntiles,
+                               float* cand, float* qvec, float* qscale, hipStream_t s);
 int launch_hinge_coeffs(float* pos, float* neg, int64_t n, float margin, float* loss, hipStream_t s);
 
 // kge_opt.hip

@@ -1,0 +1,48 @@
+// kge_relgroup.h -- device-side grouping of a batch by relation id (histogram -> scan -> scatter), shared by the
+// relation-matrix models (RESCAL: kge_dense.hip, TransR: kge_transr.hip).  A workgroup then owns one
+// (relation, 32-triple tile) and reads that relation's matrix once per tile instead of once per triple.
+#pragma once
+#include "kge_internal.h"
+
+namespace kge {
+
+constexpr int TILE = 32;  // triples per workgroup tile
+
+struct GroupWs {           // carved from the caller's workspace
+    int* counts;           // [R]   triples per relation
+    int* cursor;           // [R]   scatter cursors
+    int* offsets;          // [R+1] first grouped position of each relation
+    int* tile_off;         // [R+1] first tile of each relation
+    int* perm;             // [n]   grouped position -> original row
+    int* tile_rel;         // [n/TILE + R + 1] relation of each tile (filled for the tiles that exist)
+};
+
+inline int64_t group_max_tiles(int64_t R, int64_t n) { return n / TILE + R + 1; }  // >= sum_r ceil(n_r / TILE)
+inline size_t group_ws_bytes(int64_t R, int64_t n) {
+    return (size_t)(4 * (R + 1) + n + group_max_tiles(R, n) + 8) * sizeof(int);
+}
+
+inline GroupWs carve_group_ws(void* ws, int64_t R, int64_t n) {
+    GroupWs g;
+    int* p = (int*)ws;
+    g.counts = p; p += R + 1;
+    g.cursor = p; p += R + 1;
+    g.offsets = p; p += R + 1;
+    g.tile_off = p; p += R + 1;
+    g.perm = p; p += n;
+    g.tile_rel = p;
+    return g;
+}
+
+int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s);  // kge_dense.hip
+
+// which (relation, tile-in-relation) is block `b`?  (tile_rel is written by the grouping's scatter pass)
+__device__ __forceinline__ bool locate_tile(const int* __restrict__ tile_off, const int* __restrict__ tile_rel, int R, int b,
+                                            int& rel, int& tile_in_rel) {
+    if (b >= tile_off[R]) return false;
+    rel = tile_rel[b];
+    tile_in_rel = b - tile_off[rel];
+    return true;
+}
+
+}  // namespace kge

@@ -130,6 +130,7 @@ class Evaluator:
         self.eval_data = config.knowledge_graph.read_cache_data('triplets_valid')
         self.metric_calculator = MetricCalculator(config)
         self._cache = {}
+        self._groups = {}
 
     # --- single-query hooks kept for Trainer.infer_* style callers (evaluator.py:249-273)
     def test_tail_rank(self, h, r, topk=-1):
@@ -154,10 +155,19 @@ class Evaluator:
         _log("Full-Testing on [%d/%d] Triples in the test set." % (n, len(self.test_data)))
         return self.test(self.test_data, n, epoch=epoch)
 
+    def _by_relation(self):
+        """TransR sweeps a candidate table projected by ONE relation matrix per kge_eval_ranks call."""
+        return getattr(self.model, "kernel_name", None) == "transr"
+
     def _device_inputs(self, data, n):
         key = (id(data), n)
         if key not in self._cache:
             trip = _as_array(data, n)
+            if self._by_relation():  # test triples grouped by relation; ranks are scattered back to the input order
+                order = np.argsort(trip[:, 1], kind="stable")
+                trip = np.ascontiguousarray(trip[order])
+                cuts = np.flatnonzero(np.diff(trip[:, 1])) + 1
+                self._groups[key] = (order, np.concatenate([[0], cuts, [len(trip)]]).astype(np.int64))
             mc = self.metric_calculator
             csr = build_filter_csr(trip, mc.hr_t, mc.tr_h)
             dev = next(self.model.parameters()).device
@@ -171,7 +181,16 @@ class Evaluator:
             # the reference's forward renormalises both tables during eval too (pairwise.py:843-844)
             self.K.rescal_normalize(self.model.ent_embeddings.weight.data, self.model.rel_matrices.weight.data,
                                     self.model.hidden_size)
-        return self.K.eval_ranks(self.K.model_desc(self.model), trip, t_off, t_ids, h_off, h_ids)
+        desc = self.K.model_desc(self.model)
+        if self._by_relation():
+            order, cuts = self._groups[(id(data), n)]
+            out = torch.empty((4, len(order)), dtype=torch.int32, device=trip.device)
+            dst = torch.from_numpy(order).to(trip.device)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                a, b = int(a), int(b)
+                out[:, dst[a:b]] = self.K.eval_ranks(desc, trip[a:b], t_off[a:b + 1], t_ids, h_off[a:b + 1], h_ids)
+            return out
+        return self.K.eval_ranks(desc, trip, t_off, t_ids, h_off, h_ids)
 
     def test(self, data, num_of_test, epoch=None):
         mc = self.metric_calculator

@@ -12,7 +12,8 @@ from . import _lib as L
 
 MODEL_IDS = {"transe": L.TRANSE, "transh": L.TRANSH, "transd": L.TRANSD, "rotate": L.ROTATE, "rescal": L.RESCAL,
              "ntn": L.NTN, "distmult": L.DISTMULT, "complex": L.COMPLEX, "complexn3": L.COMPLEX, "analogy": L.ANALOGY,
-             "transm": L.TRANSM, "cp": L.CP, "simple": L.SIMPLE, "simple_ignr": L.SIMPLE_IGNR, "quate": L.QUATE}
+             "transm": L.TRANSM, "cp": L.CP, "simple": L.SIMPLE, "simple_ignr": L.SIMPLE_IGNR, "quate": L.QUATE,
+             "transr": L.TRANSR}
 OPTIMIZER_IDS = {"sgd": L.OPT_SGD, "adam": L.OPT_ADAM, "adagrad": L.OPT_ADAGRAD, "rms": L.OPT_RMSPROP}
 
 

@@ -66,6 +66,30 @@ class TransM(TransE):
                            tot_entity=self.tot_entity, tot_relation=self.tot_relation, **self.desc_kwargs())
 
 
+class TransR(PairwiseModel):
+    """pairwise.py:367-470.  Normalised entities projected by the relation's [d_e, d_r] matrix, then the TransE tail."""
+    kernel_name = "transr"
+
+    def __init__(self, **kwargs):
+        super().__init__(self.__class__.__name__.lower())
+        self.__dict__.update(self.load_params(
+            ["tot_entity", "tot_relation", "rel_hidden_size", "ent_hidden_size", "l1_flag"], kwargs))
+        self.ent_embeddings = NamedEmbedding("ent_embedding", self.tot_entity, self.ent_hidden_size)
+        self.rel_embeddings = NamedEmbedding("rel_embedding", self.tot_relation, self.rel_hidden_size)
+        self.rel_matrix = NamedEmbedding("rel_matrix", self.tot_relation, self.ent_hidden_size * self.rel_hidden_size)
+        _xavier(self.ent_embeddings, self.rel_embeddings, self.rel_matrix)
+        self.parameter_list = [self.ent_embeddings, self.rel_embeddings, self.rel_matrix]
+        self.loss = Criterion.pairwise_hinge
+
+    def desc_kwargs(self):
+        return dict(dim=self.ent_hidden_size, rel_dim=self.rel_hidden_size, l1_flag=bool(self.l1_flag))
+
+    def embed(self, h, r, t):
+        m = self.rel_matrix(r).view(-1, self.ent_hidden_size, self.rel_hidden_size)
+        proj = lambda e: torch.bmm(F.normalize(self.ent_embeddings(e), p=2, dim=-1).unsqueeze(1), m).squeeze(1)
+        return proj(h), F.normalize(self.rel_embeddings(r), p=2, dim=-1), proj(t)
+
+
 class TransH(PairwiseModel):
     """pairwise.py:96-182.  Entities projected onto the relation hyperplane (normal w_r) first."""
     kernel_name = "transh"

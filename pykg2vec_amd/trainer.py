@@ -132,7 +132,7 @@ class Trainer:
     def _fused_sampler_ok(self):
         """Sampler + scoring + hinge + backward in one kernel: gather-type pairwise-hinge models with neg_rate 1."""
         return (self.K is K and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED
-                and self.model.kernel_name not in ("rescal", "ntn") and self.model.model_name.lower() != "rotate"
+                and self.model.kernel_name not in ("rescal", "ntn", "transr") and self.model.model_name.lower() != "rotate"
                 and int(self.config.neg_rate) == 1)
 
     def _fused_rotate_ok(self):

@@ -119,6 +119,9 @@ def test_eval_sweep_scores_and_ranks_match_reference(hip, name):
     if c.model == "rescal":
         m.normalize_tables()  # the reference's forward renormalises the tables before every sweep (pairwise.py:843-844)
     def sweep_scores(trips):
+        if c.model == "transr":  # one relation per sweep call (the candidate table is projected by M_r)
+            return np.concatenate([K.eval_sweep_scores(m.make_desc(), hip.dev(trips[i:i + 1])).cpu().numpy()
+                                   for i in range(len(trips))])
         return K.eval_sweep_scores(m.make_desc(), hip.dev(trips)).cpu().numpy()
 
     sw = sweep_scores(c.test[:4])
@@ -171,6 +174,9 @@ SHAPES = [("transe", dict(hidden_size=50, l1_flag=True), 1), ("transe", dict(hid
           ("ntn", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4), 1),
           ("ntn", dict(ent_hidden_size=40, rel_hidden_size=33, lmbda=0.1), 1),
           ("transm", dict(hidden_size=50, l1_flag=False), 1), ("transm", dict(hidden_size=300, l1_flag=True), 1),
+          ("transr", dict(ent_hidden_size=50, rel_hidden_size=50, l1_flag=True), 1),
+          ("transr", dict(ent_hidden_size=128, rel_hidden_size=100, l1_flag=False), 1),
+          ("transr", dict(ent_hidden_size=33, rel_hidden_size=70, l1_flag=True), 1),
           ("cp", dict(hidden_size=50, lmbda=1e-4), 1), ("cp", dict(hidden_size=600, lmbda=1e-4), 2),
           ("simple", dict(hidden_size=100, lmbda=0.1), 1), ("simple_ignr", dict(hidden_size=100, lmbda=0.1), 3),
           ("quate", dict(hidden_size=100, lmbda=0.2), 1), ("quate", dict(hidden_size=200, lmbda=0.1), 2),
@@ -258,7 +264,7 @@ def test_sampler_invariants_and_determinism(hip):
 
 
 @pytest.mark.parametrize("name,opt", [("transe_l1", "adam"), ("distmult", "adagrad"), ("rotate", "adam"), ("rescal", "sgd"),
-                                      ("transm_l2", "sgd"), ("simple", "adagrad"), ("quate", "adagrad")])
+                                      ("transm_l2", "sgd"), ("simple", "adagrad"), ("quate", "adagrad"), ("transr_l1", "sgd")])
 def test_graph_replayed_epochs_equal_eager_epochs(hip, name, opt):
     """hipGraph capture/replay of the whole step (device-resident batch cursor, Philox offset, Adam bias terms) must
     reproduce the eager loop: same batches, same negatives, same weights."""

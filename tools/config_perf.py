@@ -25,6 +25,8 @@ CONFIGS = [
     ("RESCAL FB15k k=50 B=128 adam (preset)", "rescal", "fb15k", dict(hidden_size=50, margin=1.0), "adam", 128, 1, 1024),
     ("TransM FB15k d=50 B=1200 sgd (preset)", "transm", "fb15k", dict(hidden_size=50, l1_flag=False, margin=0.5), "sgd", 1200, 1, 8192),
     ("TransM FB15k d=100 B=32768 adam", "transm", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 8192),
+    ("TransR FB15k 50/50 B=4800 sgd (preset)", "transr", "fb15k", dict(ent_hidden_size=50, rel_hidden_size=50, l1_flag=True, margin=1.0), "sgd", 4800, 1, 2048),
+    ("TransR WN18RR 100/100 B=4096 adam", "transr", "wn18rr", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=False, margin=1.0), "adam", 4096, 1, 1024),
     ("CP FB15k d=50 B=128 adagrad (preset)", "cp", "fb15k", dict(hidden_size=50, lmbda=1e-4), "adagrad", 128, 1, 8192),
     ("CP FB15k d=100 B=32768 adagrad", "cp", "fb15k", dict(hidden_size=100, lmbda=1e-4), "adagrad", 32768, 1, 0),
     ("SimplE FB15k d=100 B=128 adagrad (preset)", "simple", "fb15k", dict(hidden_size=100, lmbda=0.1), "adagrad", 128, 1, 8192),
