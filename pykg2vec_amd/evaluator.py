@@ -143,6 +143,20 @@ class Evaluator:
         return self.model.predict_head_rank(torch.as_tensor([int(t)], device=dev), torch.as_tensor([int(r)], device=dev),
                                             topk=topk).squeeze(0)
 
+    def test_rel_rank(self, h, t, topk=-1):
+        """evaluator.py:275-287: energies of (h, r, t) for every relation r through the batch scorer, then topk."""
+        dev = self.config.device
+        if hasattr(self.model, "predict_rel_rank"):
+            return self.model.predict_rel_rank(torch.as_tensor([int(h)], device=dev), torch.as_tensor([int(t)], device=dev),
+                                               topk=topk).squeeze(0)
+        R = int(self.config.tot_relation)
+        rel = torch.arange(R, dtype=torch.int64, device=dev)
+        with torch.no_grad():
+            preds = self.model.forward(torch.full((R,), int(h), dtype=torch.int64, device=dev), rel,
+                                       torch.full((R,), int(t), dtype=torch.int64, device=dev))
+        _, rank = torch.topk(preds, k=topk)
+        return rank
+
     def mini_test(self, epoch=None):
         n = len(self.eval_data) if self.config.test_num == 0 else min(self.config.test_num, len(self.eval_data))
         if self.config.debug:

@@ -78,6 +78,9 @@ class EarlyStopper:
 
 
 class Trainer:
+    TRAINED_MODEL_FILE_NAME = "model.vec.pt"      # utils/trainer.py:86-87
+    TRAINED_MODEL_CONFIG_NAME = "config.npy"
+
     GRAPH_MAX_ROWS = 16384  # steps scoring at most this many triples are launch-bound: replay them as one hipGraph
 
     def __init__(self, model, config, process_group=None, backend=None, use_graph=None):
@@ -294,6 +297,47 @@ class Trainer:
             self.evaluator.full_test(cur_epoch_idx)
         self.generator.stop()
         return cur_epoch_idx
+
+    # ------------------------------------------------------------------ inference / persistence (utils/trainer.py:330-419)
+    def _infer(self, ids, id2name):
+        ids = ids.detach().cpu().numpy()
+        return {int(i): id2name[int(i)] for i in ids}
+
+    def infer_tails(self, h, r, topk=5):
+        idx2ent = self.config.knowledge_graph.read_cache_data('idx2entity')
+        return self._infer(self.evaluator.test_tail_rank(h, r, topk), idx2ent)
+
+    def infer_heads(self, r, t, topk=5):
+        idx2ent = self.config.knowledge_graph.read_cache_data('idx2entity')
+        return self._infer(self.evaluator.test_head_rank(r, t, topk), idx2ent)
+
+    def infer_rels(self, h, t, topk=5):
+        idx2rel = self.config.knowledge_graph.read_cache_data('idx2relation')
+        return self._infer(self.evaluator.test_rel_rank(h, t, topk), idx2rel)
+
+    def save_model(self):
+        """state_dict (reference key names) + pickled config next to it, as utils/trainer.py:389-397."""
+        import numpy as np
+        saved_path = self.config.path_tmp / self.model.model_name
+        saved_path.mkdir(parents=True, exist_ok=True)
+        torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                   str(saved_path / self.TRAINED_MODEL_FILE_NAME))
+        np.save(saved_path / self.TRAINED_MODEL_CONFIG_NAME, self.config)
+
+    def load_model(self, model_path=None):
+        """Load weights saved by this class or by the reference Trainer (same file names, same state_dict keys) into
+        the current model; the flat parameter buffer keeps backing the tables."""
+        from pathlib import Path
+        base = Path(model_path) if model_path is not None else self.config.path_tmp / self.model.model_name
+        f = base / self.TRAINED_MODEL_FILE_NAME
+        if not f.exists():
+            raise ValueError("Cannot load model from %s" % f)
+        state = torch.load(str(f), map_location="cpu")
+        with torch.no_grad():
+            own = self.model.state_dict()
+            for k, v in state.items():
+                own[k].copy_(v)
+        self.model.eval()
 
     def tune_model(self):
         current_loss = float("inf")
