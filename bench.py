@@ -273,7 +273,7 @@ def main():
                  "mode": "hipGraph replay of advance+fused step+Adam" if tr_s._graph is not None else "eager"}
 
     out = None
-    traffic, traffic_src = pmc_traffic("kge::k_transe_pair_sampled<32, 4, 4>", per_rank_batch)
+    traffic, traffic_src = pmc_traffic("kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch)
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",

@@ -29,7 +29,9 @@ __device__ __forceinline__ void gsum4(float& a, float& b, float& c, float& d) {
 // batch is a set, its order changes nothing but fp summation order), and a group walks CH consecutive pairs: the
 // relation row, its norm and its gradient stay in registers across pairs of the same relation and are scattered once
 // per run instead of once per pair.
-template <int G, int NCH, int CH>
+// SCALED = TransM (pairwise.py:341-347): both energies are multiplied by the fixed per-relation weight theta_r, which
+// travels with the relation row.
+template <int G, int NCH, int CH, bool SCALED>
 __global__ __launch_bounds__(kBlock) void k_transe_pair_sampled(DeviceModel m, int64_t n, float margin,
                                                                 float* __restrict__ loss, FusedSampler fs) {
     constexpr int GPB = kBlock / G;
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(kBlock) void k_transe_pair_sampled(DeviceModel m, i
     for (int64_t ck = (int64_t)blockIdx.x * GPB + threadIdx.x / G; ck < nchunks; ck += (int64_t)gridDim.x * GPB) {
         int64_t r_cur = -1;
         float R[NCH], gRh[NCH];  // relation row and the running gradient wrt its NORMALISED form
-        float iR = 0.f;
+        float iR = 0.f, theta = 1.f;
         bool fR = false, r_dirty = false;
         auto flush_r = [&]() {
             if (!r_dirty) return;
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(kBlock) void k_transe_pair_sampled(DeviceModel m, i
                 flush_r();
                 r_cur = r;
                 load_row<G, NCH>(R, m.tab[1] + r * (int64_t)d, d, gl);
+                if constexpr (SCALED) theta = m.tab[2][r];
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) { nR = fmaf(R[k], R[k], nR); gRh[k] = 0.f; }
             }
@@ -117,10 +120,11 @@ __global__ __launch_bounds__(kBlock) void k_transe_pair_sampled(DeviceModel m, i
             }
             gsum2<G>(sp, sn);
             if (!l1) { sp = sqrtf(sp); sn = sqrtf(sn); }
-            const float v = sp + margin - sn;
+            const float v = SCALED ? theta * sp + margin - theta * sn : sp + margin - sn;
             acc += fmaxf(v, 0.f);
-            const float coef = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);
-            if (coef == 0.f) continue;
+            const float c01 = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);
+            if (c01 == 0.f) continue;
+            const float coef = SCALED ? c01 * theta : c01;  // d loss / d (unscaled distance)
             const float ip = (!l1 && sp > 0.f) ? coef / sp : 0.f, in = (!l1 && sn > 0.f) ? -coef / sn : 0.f;
             // gradients wrt the normalised vectors (gp: positive with ds=+coef, gn: negative with ds=-coef)
             float gH[NCH], gT[NCH], gC[NCH];
@@ -547,16 +551,18 @@ int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triple
     fs.triples = triples; fs.perm = perm; fs.start = start; fs.E = m->tot_entity; fs.bern = bern;
     fs.slots = (const unsigned long long*)slots; fs.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
     fs.seed = seed; fs.offset = offset; fs.cursor = cursor;
-    if (m->model == KGE_TRANSE) {  // shared-row specialisation: 4 row gathers / scatters per pair instead of 6
-#define KGE_TE(G_, NCH_)                                                                                                   \
-    if (geo.G == G_ && geo.NCH == NCH_) {                                                                                   \
+    if (m->model == KGE_TRANSE || m->model == KGE_TRANSM) {  // shared-row specialisation: 4 row gathers / scatters per pair, not 6
+#define KGE_TE(G_, NCH_, SC)                                                                                               \
+    if (geo.G == G_ && geo.NCH == NCH_ && (m->model == KGE_TRANSM) == SC) {                                                 \
         if (n >= 16384)  /* big batch: 4 pairs per group share the relation row; small batch: one pair per group */ \
-            k_transe_pair_sampled<G_, NCH_, 4><<<dim3(Launch<KGE_TRANSE, G_, NCH_>::grid((n + 3) / 4)), dim3(kBlock), 0, s>>>(dm, n, margin, loss, fs); \
+            k_transe_pair_sampled<G_, NCH_, 4, SC><<<dim3(Launch<KGE_TRANSE, G_, NCH_>::grid((n + 3) / 4)), dim3(kBlock), 0, s>>>(dm, n, margin, loss, fs); \
         else                                                                                                                \
-            k_transe_pair_sampled<G_, NCH_, 1><<<dim3(Launch<KGE_TRANSE, G_, NCH_>::grid(n)), dim3(kBlock), 0, s>>>(dm, n, margin, loss, fs); \
+            k_transe_pair_sampled<G_, NCH_, 1, SC><<<dim3(Launch<KGE_TRANSE, G_, NCH_>::grid(n)), dim3(kBlock), 0, s>>>(dm, n, margin, loss, fs); \
         return check_launch("k_transe_pair_sampled");                                                                       \
     }
-        KGE_TE(32, 1) KGE_TE(32, 2) KGE_TE(32, 4) KGE_TE(32, 8) KGE_TE(64, 8) KGE_TE(64, 16)
+#define KGE_TE_ALL(SC) KGE_TE(32, 1, SC) KGE_TE(32, 2, SC) KGE_TE(32, 4, SC) KGE_TE(32, 8, SC) KGE_TE(64, 8, SC) KGE_TE(64, 16, SC)
+        KGE_TE_ALL(false) KGE_TE_ALL(true)
+#undef KGE_TE_ALL
 #undef KGE_TE
     }
     if (m->model == KGE_TRANSH || m->model == KGE_TRANSD) {  // shared-row specialisations with the projections
