@@ -163,12 +163,26 @@ int kge_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, 
  *                  reference before settle() adds 1); rank = #{e : s_e < s_true}
  * workspace from kge_eval_workspace_bytes().
  * TransR: candidates are scored in the relation space, so the sweep table is projected by M_r once per call and ALL n
- * triples of a call must carry the same relation id (triples[1] is used); the host groups test triples by relation. */
+ * triples of a call must carry the same relation id (triples[1] is used); kge_eval_ranks_grouped below takes many
+ * relation groups per call. */
 size_t kge_eval_workspace_bytes(const kge_model_desc* m, int64_t n);
 int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n,
                    const int64_t* tail_off, const int32_t* tail_ids,
                    const int64_t* head_off, const int32_t* head_ids,
                    void* workspace, size_t workspace_bytes, int32_t* ranks, void* stream);
+
+/* TransR, several relations per call.  `triples` are sorted by relation; group g = the run of triples with relation
+ * group_rel[g] (device int64 [n_groups]); group_of_triple (device int32 [n]) names each triple's group; qblocks
+ * (device int32 [n_qblocks,4]) = {group, first query, query count <= 16, 0} partitions every group's query range
+ * [2a, 2b) (query 2i = tail sweep of triple i, 2i+1 = head sweep) into sweep workgroups.  One candidate table per group
+ * lives in the workspace (kge_eval_grouped_workspace_bytes); ranks as in kge_eval_ranks. */
+size_t kge_eval_grouped_workspace_bytes(const kge_model_desc* m, int64_t n, int64_t n_groups);
+int kge_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int64_t n,
+                           const int32_t* group_of_triple, const int64_t* group_rel, int64_t n_groups,
+                           const int32_t* qblocks, int64_t n_qblocks,
+                           const int64_t* tail_off, const int32_t* tail_ids,
+                           const int64_t* head_off, const int32_t* head_ids,
+                           void* workspace, size_t workspace_bytes, int32_t* ranks, void* stream);
 
 /* Evaluator.test_tail_rank / test_head_rank score vectors (utils/evaluator.py:249-273) through the sweep
  * kernels: for each of the n triples, scores[2i][e] = energy of (h_i, r_i, e) and scores[2i+1][e] = energy of

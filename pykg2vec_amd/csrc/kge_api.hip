@@ -262,6 +262,26 @@ int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, c
                              (hipStream_t)stream);
 }
 
+size_t kge_eval_grouped_workspace_bytes(const kge_model_desc* m, int64_t n, int64_t n_groups) {
+    if (validate(m, false, "kge_eval_grouped_workspace_bytes") || n < 0 || n_groups < 1) return 0;
+    return eval_workspace_bytes(m, n, n_groups);
+}
+
+int kge_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,
+                           const int64_t* group_rel, int64_t n_groups, const int32_t* qblocks, int64_t n_qblocks,
+                           const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
+                           const int32_t* head_ids, void* workspace, size_t workspace_bytes, int32_t* ranks, void* stream) {
+    if (validate(m, false, "kge_eval_ranks_grouped")) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || !triples || !ranks || !group_of_triple || !group_rel || !qblocks || n_groups < 1 || n_qblocks < 1) {
+        set_error("kge_eval_ranks_grouped: bad arguments");
+        return -1;
+    }
+    if ((tail_off && !tail_ids) || (head_off && !head_ids)) { set_error("kge_eval_ranks_grouped: CSR offsets without ids"); return -1; }
+    return launch_eval_ranks_grouped(m, triples, n, group_of_triple, group_rel, n_groups, qblocks, n_qblocks, tail_off, tail_ids,
+                                     head_off, head_ids, workspace, workspace_bytes, ranks, (hipStream_t)stream);
+}
+
 int kge_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* workspace,
                           size_t workspace_bytes, float* scores, void* stream) {
     if (validate(m, false, "kge_eval_sweep_scores")) return -1;

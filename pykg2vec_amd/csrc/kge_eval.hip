@@ -42,7 +42,7 @@ enum XForm { X_NONE = 0, X_TRANSH = 1, X_TRANSD = 2 };
 enum Post { P_NONE = 0, P_SCALE = 1, P_CLAMP = 2 };
 
 struct EvalPlan {
-    int64_t E, n;
+    int64_t E, n, tables, table_stride;  // tables > 1: one projected candidate table per relation group (TransR)
     int K, Kpad, QV, form, xform, post;
     int64_t ntiles;
     float* cand; float* aux; float* qvec; float* qscale; float* st; int32_t* fcount; int32_t* rcount;
@@ -61,8 +61,8 @@ static int sweep_K(const kge_model_desc* m) {
     }
 }
 
-static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p) {
-    p->E = m->tot_entity; p->n = n;
+static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p, int64_t tables = 1) {
+    p->E = m->tot_entity; p->n = n; p->tables = tables;
     p->K = sweep_K(m);
     p->Kpad = (p->K + KC - 1) / KC * KC;
     p->xform = m->model == KGE_TRANSH ? X_TRANSH : m->model == KGE_TRANSD ? X_TRANSD : X_NONE;
@@ -80,7 +80,8 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p)
     size_t off = 0;
     char* base = (char*)ws;
     auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += align256(bytes); return q; };
-    p->cand = (float*)take((size_t)p->ntiles * p->Kpad * 64 * sizeof(float));
+    p->table_stride = p->ntiles * p->Kpad * 64;
+    p->cand = (float*)take((size_t)tables * p->table_stride * sizeof(float));
     p->aux = (float*)take((size_t)p->ntiles * 64 * sizeof(float));
     p->qvec = (float*)take((size_t)2 * n * p->QV * p->Kpad * sizeof(float));
     p->qscale = (float*)take((size_t)2 * n * sizeof(float));
@@ -91,10 +92,10 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p)
     return true;
 }
 
-size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n) {
+size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n, int64_t tables) {
     if (m->model == KGE_NTN) return ntn_eval_workspace_bytes(m, n);
     EvalPlan p;
-    if (!make_plan(m, n, nullptr, &p)) return 0;
+    if (!make_plan(m, n, nullptr, &p, tables)) return 0;
     return p.bytes;
 }
 
@@ -398,11 +399,13 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
                                                             int64_t n, int Kpad, int QV, float margin,
                                                             const int64_t* __restrict__ tail_off, const int32_t* __restrict__ tail_ids,
                                                             const int64_t* __restrict__ head_off, const int32_t* __restrict__ head_ids,
-                                                            float* __restrict__ st, int32_t* __restrict__ fcount) {
+                                                            float* __restrict__ st, int32_t* __restrict__ fcount,
+                                                            const int32_t* __restrict__ group_of_triple, int64_t table_stride) {
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= 2 * n) return;
     const int64_t i = qi >> 1;
+    if (group_of_triple) cand += group_of_triple[i] * table_stride;  // grouped evaluation: this query's candidate table
     const int side = (int)(qi & 1);
     const int64_t truth = side == 0 ? triples[3 * i + 2] : triples[3 * i];
     const float* q = qvec + qi * (int64_t)QV * Kpad;
@@ -454,7 +457,8 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                                                     const float* __restrict__ st,
                                                     int64_t nq, int64_t E, int64_t ntiles, int Kpad, int QV, float margin,
                                                     int S, int qblocks, int32_t* __restrict__ rcount,
-                                                    float* __restrict__ scores_out) {
+                                                    float* __restrict__ scores_out,
+                                                    const int32_t* __restrict__ qdesc, int64_t table_stride) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int slot = blockIdx.x & 255;
@@ -462,7 +466,12 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
     const int ts = mm % S;
     const int qb = (mm / S) * 256 + slot;
     if (qb >= qblocks) return;
-    const int64_t q0 = (int64_t)qb * QT;
+    int64_t q0 = (int64_t)qb * QT;
+    if (qdesc) {  // grouped evaluation: block -> {candidate table, first query, query count <= QT}
+        cand += qdesc[4 * qb] * table_stride;
+        q0 = qdesc[4 * qb + 1];
+        nq = q0 + qdesc[4 * qb + 2];
+    }
     const int64_t qstride = (int64_t)QV * Kpad;
     // wave-uniform query row pointers (clamped; masked at the end)
     const float* qrow[QT];
@@ -688,10 +697,12 @@ static void fill_prep(const kge_model_desc* m, const EvalPlan& p, PrepArgs* a) {
 template <int FORM, int XFORM, int POST = P_NONE>
 static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, const int64_t* triples,
                                 const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
-                                const int32_t* head_ids, float* scores_out, hipStream_t s) {
+                                const int32_t* head_ids, float* scores_out, hipStream_t s,
+                                const int32_t* group_of_triple = nullptr, const int32_t* qdesc = nullptr,
+                                int64_t n_qblocks = 0) {
     constexpr int QT = XFORM == X_NONE ? QT_PLAIN : QT_XF;
     const int64_t nq = 2 * p.n;
-    const int qblocks = (int)((nq + QT - 1) / QT);
+    const int qblocks = qdesc ? (int)n_qblocks : (int)((nq + QT - 1) / QT);
     // tile splits S: every wave gets >= 1 tile; aim at >= ~8 waves of workgroups per CU so the last round is cheap
     const int64_t tiles_per_wave_pass = XFORM == X_NONE ? 2 : 1;
     const int64_t max_split = (p.ntiles + 4 * tiles_per_wave_pass - 1) / (4 * tiles_per_wave_pass);
@@ -703,12 +714,14 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
     if (scores_out == nullptr) {
         hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM, POST>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p.cand,
                            p.aux, p.qvec, p.qscale, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids, head_off, head_ids,
-                           p.st, p.fcount);
+                           p.st, p.fcount, group_of_triple, p.table_stride);
         hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, false, POST>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec,
-                           p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, nullptr);
+                           p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, nullptr,
+                           qdesc, p.table_stride);
     } else {
         hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, true, POST>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec,
-                           p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, scores_out);
+                           p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, scores_out,
+                           qdesc, p.table_stride);
     }
 }
 
@@ -723,7 +736,7 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     }
     if (n <= 0) return 0;
     if (m->model == KGE_TRANSR) {  // candidates projected by the call's relation matrix (all triples share it)
-        int rc = launch_transr_eval_prepare(m, triples, n, p.Kpad, p.ntiles, p.cand, p.qvec, p.qscale, s);
+        int rc = launch_transr_eval_prepare(m, triples, n, nullptr, 1, p.Kpad, p.ntiles, p.cand, p.qvec, p.qscale, s);
         if (rc) return rc;
     } else {
     PrepArgs pa;
@@ -771,6 +784,32 @@ int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n
     if (m->model == KGE_NTN)
         return launch_ntn_eval_ranks(m, triples, n, tail_off, tail_ids, head_off, head_ids, ws, ws_bytes, ranks, s);
     return run_pipeline(m, triples, n, tail_off, tail_ids, head_off, head_ids, ws, ws_bytes, ranks, nullptr, s);
+}
+
+// TransR over several relation groups in one pass: one projected candidate table per group, every sweep workgroup
+// bound to one group's queries by its descriptor {group, first query, query count}.
+int launch_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,
+                              const int64_t* group_rel, int64_t n_groups, const int32_t* qblocks, int64_t n_qblocks,
+                              const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
+                              const int32_t* head_ids, void* ws, size_t ws_bytes, int32_t* ranks, hipStream_t s) {
+    if (m->model != KGE_TRANSR) { set_error("kge_eval_ranks_grouped: TransR only (other models need no grouping)"); return -1; }
+    EvalPlan p;
+    if (!make_plan(m, n, ws, &p, n_groups)) { set_error("kge_eval: model %d has no sweep form", m->model); return -1; }
+    if (ws == nullptr || ws_bytes < p.bytes) {
+        set_error("kge_eval_ranks_grouped: workspace too small (%zu < %zu)", ws_bytes, p.bytes);
+        return -1;
+    }
+    int rc = launch_transr_eval_prepare(m, triples, n, group_rel, n_groups, p.Kpad, p.ntiles, p.cand, p.qvec, p.qscale, s);
+    if (rc) return rc;
+    (void)hipMemsetAsync(p.rcount, 0, (size_t)2 * n * sizeof(int32_t), s);
+    if (p.form == F_L1)
+        launch_tf_and_sweep<F_L1, X_NONE>(p, m, triples, tail_off, tail_ids, head_off, head_ids, nullptr, s, group_of_triple,
+                                          qblocks, n_qblocks);
+    else
+        launch_tf_and_sweep<F_L2, X_NONE>(p, m, triples, tail_off, tail_ids, head_off, head_ids, nullptr, s, group_of_triple,
+                                          qblocks, n_qblocks);
+    hipLaunchKernelGGL(k_eval_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.rcount, p.fcount, n, ranks);
+    return check_launch("kge_eval grouped pipeline");
 }
 
 // scores: float [2n, E]: row 2i = tail-sweep energies of triple i, row 2i+1 = head-sweep energies

@@ -70,8 +70,9 @@ int launch_transr_forward(const kge_model_desc* m, const int64_t* h, const int64
                           int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_transr_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                            int64_t n, const float* dscore, void* ws, size_t ws_bytes, bool grouped, hipStream_t s);
-int launch_transr_eval_prepare(const kge_model_desc* m, const int64_t* triples, int64_t n, int Kpad, int64_t ntiles,
-                               float* cand, float* qvec, float* qscale, hipStream_t s);
+int launch_transr_eval_prepare(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* group_rel,
+                               int64_t n_groups, int Kpad, int64_t ntiles, float* cand, float* qvec, float* qscale,
+                               hipStream_t s);
 int launch_hinge_coeffs(float* pos, float* neg, int64_t n, float margin, float* loss, hipStream_t s);
 
 // kge_opt.hip
@@ -79,7 +80,11 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
                      int zero_grad, const float* dev_hyper, hipStream_t s);
 
 // kge_eval.hip
-size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n);
+size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n, int64_t tables = 1);
+int launch_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,
+                              const int64_t* group_rel, int64_t n_groups, const int32_t* qblocks, int64_t n_qblocks,
+                              const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
+                              const int32_t* head_ids, void* ws, size_t ws_bytes, int32_t* ranks, hipStream_t s);
 int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
                       const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
                       size_t ws_bytes, int32_t* ranks, hipStream_t s);

@@ -317,15 +317,17 @@ int launch_transr_backward(const kge_model_desc* m, const int64_t* h, const int6
 // ------------------------------------------------------------------ evaluation helpers (one relation per call)
 // candidate tile -> sweep layout cand[tile][k][64] with cand[e][:] = n(n(ent[e]) M_r), r = triples[1]
 __global__ __launch_bounds__(256) void k_transr_project(const float* __restrict__ ent, const float* __restrict__ mat,
-                                                        const int64_t* __restrict__ triples, int64_t E, int de, int dr,
-                                                        int Kpad, float* __restrict__ cand) {
+                                                        const int64_t* __restrict__ triples,
+                                                        const int64_t* __restrict__ group_rel, int64_t table_stride,
+                                                        int64_t E, int de, int dr, int Kpad, float* __restrict__ cand) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Se = (de + 1) | 1, Sr = (dr + 1) | 1;
     float* sE = smem;            // [64][Se] normalised entity rows
     float* sP = sE + 64 * Se;    // [64][Sr] projected rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x, e0 = tile * 64;
-    const int64_t rel = triples[1];
+    const int64_t rel = group_rel ? group_rel[blockIdx.y] : triples[1];  // blockIdx.y = relation group = candidate table
+    cand += blockIdx.y * table_stride;
     const float* M = mat + rel * (int64_t)de * dr;
     const int c0 = lane, c1 = lane + 64;
     for (int j = 0; j < 16; ++j) {
@@ -397,14 +399,16 @@ __global__ __launch_bounds__(256) void k_transr_queries(const float* __restrict_
     if (lane == 0) { qscale[2 * i] = 1.0f; qscale[2 * i + 1] = 1.0f; }
 }
 
-int launch_transr_eval_prepare(const kge_model_desc* m, const int64_t* triples, int64_t n, int Kpad, int64_t ntiles,
-                               float* cand, float* qvec, float* qscale, hipStream_t s) {
+int launch_transr_eval_prepare(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* group_rel,
+                               int64_t n_groups, int Kpad, int64_t ntiles, float* cand, float* qvec, float* qscale,
+                               hipStream_t s) {
     if (transr_check(m, n)) return -1;
     const int de = m->dim, dr = m->rel_dim;
     const size_t lds = (size_t)64 * (((de + 1) | 1) + ((dr + 1) | 1)) * sizeof(float);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_transr_project, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_transr_project, dim3((unsigned)ntiles), dim3(256), lds, s, m->tables[0], m->tables[2], triples,
-                       m->tot_entity, de, dr, Kpad, cand);
+    if (n_groups < 1 || n_groups > 65535) { set_error("TransR evaluation: %lld relation groups per call (1..65535)", (long long)n_groups); return -1; }
+    hipLaunchKernelGGL(k_transr_project, dim3((unsigned)ntiles, (unsigned)n_groups), dim3(256), lds, s, m->tables[0],
+                       m->tables[2], triples, group_rel, ntiles * (int64_t)Kpad * 64, m->tot_entity, de, dr, Kpad, cand);
     hipLaunchKernelGGL(k_transr_queries, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, m->tables[0], m->tables[1],
                        m->tables[2], triples, n, de, dr, Kpad, qvec, qscale);
     return check_launch("k_transr_project / k_transr_queries");

@@ -173,6 +173,34 @@ class Evaluator:
         """TransR sweeps a candidate table projected by ONE relation matrix per kge_eval_ranks call."""
         return getattr(self.model, "kernel_name", None) == "transr"
 
+    TABLE_BUDGET_BYTES = 1 << 30  # projected candidate tables held at once by a grouped TransR evaluation call
+
+    def _group_chunks(self, trip, cuts):
+        """Split the relation groups (runs of `trip`, boundaries `cuts`) into chunks whose candidate tables fit the
+        budget; per chunk the device arrays kge_eval_ranks_grouped takes."""
+        dev = next(self.model.parameters()).device
+        dr = int(self.model.rel_hidden_size)
+        table = ((int(self.config.tot_entity) + 63) // 64) * 64 * ((dr + 7) // 8 * 8) * 4
+        per = int(max(1, min(4096, self.TABLE_BUDGET_BYTES // table)))
+        chunks = []
+        G = len(cuts) - 1
+        for g0 in range(0, G, per):
+            g1 = min(G, g0 + per)
+            a, b = int(cuts[g0]), int(cuts[g1])
+            cnt = np.diff(cuts[g0:g1 + 1])
+            group_of_triple = np.repeat(np.arange(g1 - g0, dtype=np.int32), cnt)
+            group_rel = trip[cuts[g0:g1], 1].astype(np.int64)
+            nb = (2 * cnt + 15) // 16                       # sweep workgroups (16 queries each) per group
+            blk_group = np.repeat(np.arange(g1 - g0, dtype=np.int64), nb)
+            first_blk = np.concatenate([[0], np.cumsum(nb)[:-1]])
+            within = np.arange(int(nb.sum()), dtype=np.int64) - np.repeat(first_blk, nb)
+            q_first = 2 * (cuts[g0:g1] - a)[blk_group] + 16 * within
+            q_count = np.minimum(16, 2 * (cuts[g0 + 1:g1 + 1] - a)[blk_group] - q_first)
+            qblocks = np.stack([blk_group, q_first, q_count, np.zeros_like(q_first)], 1).astype(np.int32)
+            chunks.append((a, b, torch.from_numpy(group_of_triple).to(dev), torch.from_numpy(group_rel).to(dev),
+                           torch.from_numpy(np.ascontiguousarray(qblocks)).to(dev)))
+        return chunks
+
     def _device_inputs(self, data, n):
         key = (id(data), n)
         if key not in self._cache:
@@ -180,8 +208,8 @@ class Evaluator:
             if self._by_relation():  # test triples grouped by relation; ranks are scattered back to the input order
                 order = np.argsort(trip[:, 1], kind="stable")
                 trip = np.ascontiguousarray(trip[order])
-                cuts = np.flatnonzero(np.diff(trip[:, 1])) + 1
-                self._groups[key] = (order, np.concatenate([[0], cuts, [len(trip)]]).astype(np.int64))
+                cuts = np.concatenate([[0], np.flatnonzero(np.diff(trip[:, 1])) + 1, [len(trip)]]).astype(np.int64)
+                self._groups[key] = (order, self._group_chunks(trip, cuts))
             mc = self.metric_calculator
             csr = build_filter_csr(trip, mc.hr_t, mc.tr_h)
             dev = next(self.model.parameters()).device
@@ -197,12 +225,12 @@ class Evaluator:
                                     self.model.hidden_size)
         desc = self.K.model_desc(self.model)
         if self._by_relation():
-            order, cuts = self._groups[(id(data), n)]
+            order, chunks = self._groups[(id(data), n)]
             out = torch.empty((4, len(order)), dtype=torch.int32, device=trip.device)
             dst = torch.from_numpy(order).to(trip.device)
-            for a, b in zip(cuts[:-1], cuts[1:]):
-                a, b = int(a), int(b)
-                out[:, dst[a:b]] = self.K.eval_ranks(desc, trip[a:b], t_off[a:b + 1], t_ids, h_off[a:b + 1], h_ids)
+            for a, b, got, grel, qb in chunks:  # many relation groups per launch, bounded by candidate-table memory
+                out[:, dst[a:b]] = self.K.eval_ranks_grouped(desc, trip[a:b], got, grel, qb, t_off[a:b + 1], t_ids,
+                                                             h_off[a:b + 1], h_ids)
             return out
         return self.K.eval_ranks(desc, trip, t_off, t_ids, h_off, h_ids)
 

@@ -219,6 +219,29 @@ def eval_ranks(desc, triples, tail_off, tail_ids, head_off, head_ids, workspace=
     return ranks
 
 
+def eval_ranks_grouped(desc, triples, group_of_triple, group_rel, qblocks, tail_off, tail_ids, head_off, head_ids):
+    """TransR: triples sorted by relation, several relation groups per call (kge_eval_ranks_grouped).  int32 [4,n]."""
+    n, G = triples.shape[0], group_rel.shape[0]
+    lib = L.load()
+    nbytes = lib.kge_eval_grouped_workspace_bytes(ctypes.byref(desc), int(n), int(G))
+    if nbytes == 0:
+        L.check(-1, "kge_eval_grouped_workspace_bytes")
+    workspace = torch.empty(nbytes, dtype=torch.uint8, device=triples.device)
+    ranks = torch.empty((4, n), dtype=torch.int32, device=triples.device)
+    args = []
+    for off, ids in ((tail_off, tail_ids), (head_off, head_ids)):
+        if off is None:
+            args += [None, None]
+        else:
+            args += [_dev(off, torch.int64, "csr offsets"), _dev(ids, torch.int32, "csr ids")]
+    L.check(lib.kge_eval_ranks_grouped(ctypes.byref(desc), _ids(triples, "triples"), n,
+                                       _dev(group_of_triple, torch.int32, "group_of_triple"), _ids(group_rel, "group_rel"), G,
+                                       _dev(qblocks, torch.int32, "qblocks"), qblocks.shape[0], *args,
+                                       _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
+                                       _dev(ranks, torch.int32, "ranks"), _stream()), "kge_eval_ranks_grouped")
+    return ranks
+
+
 def eval_sweep_scores(desc, triples, workspace=None):
     """float32 [2n, E]: row 2i = energies of (h_i, r_i, e) for all e, row 2i+1 = energies of (e, r_i, t_i)."""
     n = triples.shape[0]
