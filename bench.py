@@ -167,11 +167,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = "cuda:%d" % local_rank
+    # one rank per GPU; KGE_BENCH_SHARE_GPU=1 (tests only) lets the ranks of a 1-GPU box share device 0 over gloo, which
+    # exercises the whole N>1 path (sharded sampler stream, gradient all-reduce, replica consistency) on real kernels
+    share = os.environ.get("KGE_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = "cuda:%d" % dev_index
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
 
     import pykg2vec_amd.pairwise as pw
     from pykg2vec_amd import kernels as K
@@ -310,6 +317,13 @@ def main():
                                             "sample": "%d test triples, two full-entity sweeps each, C/OpenMP fp32" % ne}}
         print(json.dumps(out), flush=True)
     if world > 1:
+        if os.environ.get("KGE_BENCH_CHECK_REPLICAS") == "1":  # tests: replicas must hold identical tables after the run
+            ref = tr.flat.param.clone()
+            dist.broadcast(ref, src=0)
+            same = torch.tensor([float(torch.equal(ref, tr.flat.param))], device=device)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            if rank == 0:
+                print("REPLICAS_IDENTICAL %d" % int(same.item()), flush=True)
         dist.destroy_process_group()
 
 
