@@ -148,3 +148,39 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8192
     assert d["value"] > 0 and d["eval"]["value"] > 0 and "cpu_baseline" not in d
     assert "REPLICAS_IDENTICAL 1" in out.stdout
+
+
+@pytest.mark.parametrize("model,hp,opt,lr,fmr_drop,mrr_gain", [
+    ("transe", dict(hidden_size=32, l1_flag=True, margin=1.0), "adam", 0.01, 0.5, 3.0),
+    # a symmetric bilinear model can only partly fit a translation graph: it must still clearly beat chance
+    ("distmult", dict(hidden_size=32, lmbda=1e-5), "adagrad", 0.1, 0.8, 1.5),
+    # the per-relation matrices fit the small training set long before they generalise: a milder bar
+    ("transr", dict(ent_hidden_size=32, rel_hidden_size=32, l1_flag=False, margin=1.0), "adam", 0.01, 0.75, 3.0)])
+def test_train_model_learns_a_planted_graph(hip, model, hp, opt, lr, fmr_drop, mrr_gain):
+    """Trainer.train_model end to end (epoch loop, hipGraph replay, mini_test + early stopper, full_test): on a graph
+    generated by a planted translation model the filtered ranks must move far away from chance."""
+    from pykg2vec_amd.trainer import Trainer
+    rng = np.random.default_rng(7)
+    E, R, dp = 400, 6, 8
+    ent = rng.normal(size=(E, dp)); rel = rng.normal(size=(R, dp)) * 1.5
+    trip = set()
+    for h in range(E):
+        for r in range(R):
+            t = int(np.argmin(np.abs(ent[h] + rel[r] - ent).sum(1) + 1e9 * (np.arange(E) == h)))
+            trip.add((h, r, t))
+    trip = np.asarray(sorted(trip), dtype=np.int64)
+    trip = trip[rng.permutation(len(trip))]
+    n_test = 200
+    train, valid, test = trip[2 * n_test:], trip[:n_test], trip[n_test:2 * n_test]
+    cfg = hip.make_config(E, R, dict(hp, neg_rate=1), train, valid, test, optimizer=opt, lr=lr, batch_size=256)
+    cfg.epochs, cfg.test_step, cfg.test_num, cfg.patience = 60, 20, 100, 10
+    torch.manual_seed(0)
+    m = hip.model_from_params(model, {}, hp, E, R, train=train)
+    tr = Trainer(m, cfg)
+    tr.build_model()
+    before = tr.evaluator.test(test, n_test, epoch=0)
+    tr.train_model()
+    after = tr.evaluator.test(test, n_test, epoch=0)
+    assert before["fmr"] > 0.3 * E                      # chance level at initialisation
+    assert after["fmr"] < fmr_drop * before["fmr"], (before, after)
+    assert after["fmrr"] > mrr_gain * before["fmrr"], (before, after)
