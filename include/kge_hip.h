@@ -228,6 +228,16 @@ int kge_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start,
 int kge_step_advance(int64_t* dev_cursor, float* dev_hyper, int64_t batch_stride, int64_t n_batches,
                      int64_t draws_per_batch, float lr, void* stream);
 
+/* kge_optimizer_step for hipGraph-replayed steps, with kge_step_advance for the FOLLOWING step folded into the same
+ * launch: the sweep reads its scalars from dev_hyper (this step's set) and thread 0 derives the next step's state
+ * next_cursor / next_hyper from dev_cursor.  The two sets must be distinct buffers (the replayed graphs alternate
+ * between them), which removes the one-thread advance launch from every step. */
+int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* state1, float* state2,
+                               int64_t numel, float lr, int32_t zero_grad,
+                               const float* dev_hyper, const int64_t* dev_cursor,
+                               int64_t* next_cursor, float* next_hyper,
+                               int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -238,7 +238,20 @@ int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, f
     if (!param || !grad || numel < 0 || (step < 1 && !dev_hyper)) { set_error("kge_optimizer_step: bad arguments"); return -1; }
     if (numel == 0) return 0;
     return launch_optimizer(kind, param, grad, state1, state2, numel, lr, step < 1 ? 1 : step, zero_grad, dev_hyper,
-                            (hipStream_t)stream);
+                            nullptr, nullptr, nullptr, 0, 1, 0, (hipStream_t)stream);
+}
+
+int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,
+                               int32_t zero_grad, const float* dev_hyper, const int64_t* dev_cursor, int64_t* next_cursor,
+                               float* next_hyper, int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch,
+                               void* stream) {
+    if (!param || !grad || numel <= 0 || !dev_hyper || !dev_cursor || !next_cursor || !next_hyper || n_batches < 1 ||
+        dev_cursor == next_cursor || dev_hyper == next_hyper) {
+        set_error("kge_optimizer_step_advance: bad arguments (the next-step state must be a different set)");
+        return -1;
+    }
+    return launch_optimizer(kind, param, grad, state1, state2, numel, lr, 1, zero_grad, dev_hyper, dev_cursor, next_cursor,
+                            next_hyper, batch_stride, n_batches, draws_per_batch, (hipStream_t)stream);
 }
 
 int kge_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, float* scratch, float* loss, void* stream) {

@@ -77,7 +77,8 @@ int launch_hinge_coeffs(float* pos, float* neg, int64_t n, float margin, float* 
 
 // kge_opt.hip
 int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t numel, float lr, int64_t step,
-                     int zero_grad, const float* dev_hyper, hipStream_t s);
+                     int zero_grad, const float* dev_hyper, const int64_t* cursor_in, int64_t* cursor_out, float* hyper_out,
+                     int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, hipStream_t s);
 
 // kge_eval.hip
 size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n, int64_t tables = 1);

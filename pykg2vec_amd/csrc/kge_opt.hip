@@ -12,6 +12,32 @@ struct OptArgs {
     float bc2_sqrt;   // Adam: sqrt(1 - beta2^t)
 };
 
+// Optional tail duty of the optimiser launch in hipGraph-replayed steps: thread 0 of block 0 derives the NEXT step's
+// device-resident state (batch cursor, Philox offset, optimiser step, Adam bias terms) from the current one.  It writes
+// a different state set than the one this step's kernels read (two sets, alternating), so there is no ordering hazard
+// and no separate one-thread launch per step.
+struct AdvanceArgs {
+    const int64_t* cin;   // {start, philox offset, opt step, next batch index, next draws offset} of THIS step (NULL: off)
+    int64_t* cout;        // the same five fields for the next step
+    float* hout;          // {lr, step_size, bc2_sqrt} of the next step
+    int64_t batch_stride, n_batches, draws_per_batch;
+    float lr;
+};
+
+__device__ __forceinline__ void advance_state(const AdvanceArgs& v) {
+    const int64_t b = v.cin[3];
+    v.cout[0] = b * v.batch_stride;
+    v.cout[1] = v.cin[4];
+    v.cout[4] = v.cin[4] + v.draws_per_batch;
+    v.cout[3] = (b + 1) % v.n_batches;
+    const int64_t t = v.cin[2] + 1;
+    v.cout[2] = t;
+    const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+    v.hout[0] = v.lr;
+    v.hout[1] = (float)((double)v.lr / bc1);
+    v.hout[2] = (float)sqrt(bc2);
+}
+
 template <int KIND>
 __device__ __forceinline__ void opt_update(float& p, float g, float& s1, float& s2, const OptArgs& a) {
     if constexpr (KIND == KGE_OPT_SGD) {
@@ -33,8 +59,9 @@ __device__ __forceinline__ void opt_update(float& p, float g, float& s1, float& 
 template <int KIND, bool ZERO>
 __global__ __launch_bounds__(256) void k_opt(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                              float* __restrict__ s2, int64_t numel, OptArgs a,
-                                             const float* __restrict__ dev_hyper) {
+                                             const float* __restrict__ dev_hyper, AdvanceArgs adv) {
     if (dev_hyper) { a.lr = dev_hyper[0]; a.step_size = dev_hyper[1]; a.bc2_sqrt = dev_hyper[2]; }  // hipGraph replays
+    if (adv.cin != nullptr && blockIdx.x == 0 && threadIdx.x == 0) advance_state(adv);
     const int64_t nvec = numel / 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -69,23 +96,28 @@ __global__ __launch_bounds__(256) void k_opt(float* __restrict__ p, float* __res
 
 template <int KIND>
 static int launch_kind(float* p, float* g, float* s1, float* s2, int64_t numel, OptArgs a, int zero, const float* dh,
-                       hipStream_t s) {
+                       const AdvanceArgs& adv, hipStream_t s) {
     int64_t blocks = (numel / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (zero)
-        hipLaunchKernelGGL((k_opt<KIND, true>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh);
+        hipLaunchKernelGGL((k_opt<KIND, true>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh, adv);
     else
-        hipLaunchKernelGGL((k_opt<KIND, false>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh);
+        hipLaunchKernelGGL((k_opt<KIND, false>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh, adv);
     return check_launch("k_opt");
 }
 
 int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t numel, float lr, int64_t step,
-                     int zero_grad, const float* dev_hyper, hipStream_t s) {
+                     int zero_grad, const float* dev_hyper, const int64_t* cursor_in, int64_t* cursor_out, float* hyper_out,
+                     int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, hipStream_t s) {
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)s1 | (uintptr_t)s2) & 15) {
         set_error("kge_optimizer_step: buffers must be 16-byte aligned");
         return -1;
     }
+    AdvanceArgs adv;
+    adv.cin = cursor_in; adv.cout = cursor_out; adv.hout = hyper_out;
+    adv.batch_stride = batch_stride; adv.n_batches = n_batches > 0 ? n_batches : 1; adv.draws_per_batch = draws_per_batch;
+    adv.lr = lr;
     OptArgs a;
     a.lr = lr;
     // torch computes these scalars in double on the host, then applies them to fp32 tensors
@@ -94,16 +126,16 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
     a.step_size = (float)((double)lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
     switch (kind) {
-        case KGE_OPT_SGD: return launch_kind<KGE_OPT_SGD>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, s);
+        case KGE_OPT_SGD: return launch_kind<KGE_OPT_SGD>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, adv, s);
         case KGE_OPT_ADAM:
             if (!s1 || !s2) { set_error("adam needs two state buffers"); return -1; }
-            return launch_kind<KGE_OPT_ADAM>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, s);
+            return launch_kind<KGE_OPT_ADAM>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, adv, s);
         case KGE_OPT_ADAGRAD:
             if (!s1) { set_error("adagrad needs a state buffer"); return -1; }
-            return launch_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, s);
+            return launch_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, adv, s);
         case KGE_OPT_RMSPROP:
             if (!s1) { set_error("rmsprop needs a state buffer"); return -1; }
-            return launch_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, s);
+            return launch_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, adv, s);
     }
     set_error("kge_optimizer_step: unknown optimizer %d", kind);
     return -1;

@@ -186,6 +186,18 @@ def optimizer_step(kind, param, grad, state1, state2, lr, step, zero_grad=True, 
                                         1 if zero_grad else 0, ph, _stream()), "kge_optimizer_step")
 
 
+def optimizer_step_advance(kind, param, grad, state1, state2, lr, hyper, cursor, next_cursor, next_hyper, batch_stride,
+                           n_batches, draws_per_batch, zero_grad=True):
+    """Dense optimiser sweep of a graph-replayed step + the next step's device-resident state (kge_optimizer_step_advance)."""
+    p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
+    p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
+    L.check(L.load().kge_optimizer_step_advance(
+        OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"), _dev(grad, torch.float32, "grad"), p1, p2, param.numel(),
+        float(lr), 1 if zero_grad else 0, _dev(hyper, torch.float32, "hyper"), _dev(cursor, torch.int64, "cursor"),
+        _dev(next_cursor, torch.int64, "next_cursor"), _dev(next_hyper, torch.float32, "next_hyper"), int(batch_stride),
+        int(n_batches), int(draws_per_batch), _stream()), "kge_optimizer_step_advance")
+
+
 def step_advance(cursor, hyper, batch_stride, n_batches, draws_per_batch, lr):
     """Advance the device-resident step state (int64[8] cursor, float32[4] hyper); first kernel of a captured step."""
     L.check(L.load().kge_step_advance(_dev(cursor, torch.int64, "cursor"), _dev(hyper, torch.float32, "hyper"),

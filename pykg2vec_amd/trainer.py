@@ -48,6 +48,11 @@ class FlatState:
         self.state2 = torch.zeros_like(self.param) if optimizer == "adam" else None
         self.step = 0
 
+    def optimizer_step_advance(self, lr, hyper, cursor, next_cursor, next_hyper, batch_stride, n_batches, draws):
+        self.step += 1
+        self.K.optimizer_step_advance(self.optimizer, self.param, self.grad, self.state1, self.state2, lr, hyper, cursor,
+                                      next_cursor, next_hyper, batch_stride, n_batches, draws, zero_grad=True)
+
     def optimizer_step(self, lr, dev_hyper=None):
         self.step += 1
         self.K.optimizer_step(self.optimizer, self.param, self.grad, self.state1, self.state2, lr, self.step,
@@ -216,30 +221,41 @@ class Trainer:
         return self.world_size == 1 and self.K is K and rows <= self.GRAPH_MAX_ROWS
 
     def _capture_step(self, num_batch):
-        """Capture advance -> sample -> fused step -> optimiser ONCE; per-step values that change (batch position,
-        Philox offset, Adam bias terms) live in device memory (kge_step_advance), so replays need no host arguments."""
+        """Capture [sample ->] fused step -> optimiser (+ next step's state) once per state parity; per-step values
+        that change (batch position, Philox offset, Adam bias terms) live in device memory, so replays need no host
+        arguments."""
         gen, cfg = self.generator, self.config
         dev = self.flat.param.device
         pointwise = self.model.training_strategy != TrainingStrategy.PAIRWISE_BASED
         B = int(cfg.batch_size)
-        self._cursor = torch.zeros(8, dtype=torch.int64, device=dev)
-        self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
-        self._cursor[2] = self.flat.step
-        self._cursor[4] = gen._draws
+        # two sets of device-resident step state {cursor[8], hyper[4]}: the step that reads set p leaves the state of the
+        # following step in set 1-p (written by its optimiser launch), so a step is [sample +] fused step + optimiser
+        # with no separate advance launch; two graphs, one per parity, are replayed alternately
+        self._cursor = torch.zeros(16, dtype=torch.int64, device=dev)
+        self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        cur = [self._cursor[0:8], self._cursor[8:16]]
+        hyp = [self._hyper[0:4], self._hyper[4:8]]
+        cur[0][2] = self.flat.step
+        cur[0][4] = gen._draws
         self._sbuf = K.sample_buffer(B, gen.neg_rate, pointwise, dev)
         self._graph_batches = num_batch
+        K.step_advance(cur[0], hyp[0], B, num_batch, B * gen.neg_rate, cfg.learning_rate)  # state of the first step
 
-        def body():
-            K.step_advance(self._cursor, self._hyper, B, num_batch, B * gen.neg_rate, cfg.learning_rate)
-            self._accumulate_next_batch(cursor=self._cursor, fixed_range=(0, B, 0))
-            self.flat.optimizer_step(cfg.learning_rate, dev_hyper=self._hyper)
+        def body(p):
+            self._accumulate_next_batch(cursor=cur[p], fixed_range=(0, B, 0))
+            self.flat.optimizer_step_advance(cfg.learning_rate, hyp[p], cur[p], cur[1 - p], hyp[1 - p], B, num_batch,
+                                             B * gen.neg_rate)
 
-        body()  # the epoch's FIRST step runs eagerly (loads kernels, sizes workspaces) ...
+        body(0)  # the epoch's FIRST step runs eagerly (loads kernels, sizes workspaces) ...
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):  # ... then the same launch sequence is captured (capture does not execute)
-            body()
-        self._graph = graph
+        self._graphs = []
+        for p in (0, 1):  # ... then the launch sequence of each parity is captured (capture does not execute)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body(p)
+            self._graphs.append(graph)
+        self._graph = self._graphs[0]
+        self._parity = 1  # the eager step consumed set 0; the next step's state is in set 1
         return 1  # steps already executed
 
     # ------------------------------------------------------------------ epochs
@@ -254,10 +270,11 @@ class Trainer:
             done = 0
             if self._graph is None or self._graph_batches != num_batch:
                 done = self._capture_step(num_batch)
-            else:
-                self._cursor[3] = 0  # every epoch walks the permutation from its start (data/generator.py:28-35)
+            # (an epoch is exactly num_batch steps, so the device-side batch index has wrapped to 0 by itself: every
+            # epoch walks the permutation from its start, data/generator.py:28-35)
             for _ in range(num_batch - done):
-                self._graph.replay()
+                self._graphs[self._parity].replay()
+                self._parity ^= 1
             self.flat.step = step0 + num_batch
             gen._draws = draws0 + num_batch * gen.batch_size * gen.neg_rate
             gen._pending = 0
