@@ -185,7 +185,10 @@ SHAPES = [("transe", dict(hidden_size=50, l1_flag=True), 1), ("transe", dict(hid
           ("cp", dict(hidden_size=50, lmbda=1e-4), 1), ("cp", dict(hidden_size=600, lmbda=1e-4), 2),
           ("simple", dict(hidden_size=100, lmbda=0.1), 1), ("simple_ignr", dict(hidden_size=100, lmbda=0.1), 3),
           ("quate", dict(hidden_size=100, lmbda=0.2), 1), ("quate", dict(hidden_size=200, lmbda=0.1), 2),
-          ("quate", dict(hidden_size=300, lmbda=0.05), 1)]
+          ("quate", dict(hidden_size=300, lmbda=0.05), 1),
+          # widest register geometry (64 lanes x 16 chunks) for the second model group
+          ("quate", dict(hidden_size=520, lmbda=0.05), 1), ("simple", dict(hidden_size=700, lmbda=0.1), 1),
+          ("transm", dict(hidden_size=1000, l1_flag=False), 1)]
 
 
 @pytest.mark.parametrize("model,hp,neg_rate", SHAPES)
