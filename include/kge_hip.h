@@ -238,6 +238,29 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
                                int64_t* next_cursor, float* next_hyper,
                                int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, void* stream);
 
+/* ---- 1-N scoring head of the projection models (ConvE / TuckER / InteractE / HypER / AcrE:
+ * projection.py:100-102, 335-336, 444-447, 606-609, 734-737):  preds[B,E] = sigmoid(x[B,dim] @ ent[E,dim]^T + bias[E]).
+ * bias may be NULL (TuckER).  fp32 on the matrix cores. */
+int kge_head_1n_forward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity,
+                        const float* bias, float* preds, void* stream);
+
+/* Autograd backward of the head given d loss / d preds: dx[B,dim] is overwritten, g_ent[E,dim] and g_bias[E] are
+ * accumulated into (any of the three may be NULL). */
+int kge_head_1n_backward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity,
+                         const float* preds, const float* dpreds, float* dx, float* g_ent, float* g_bias, void* stream);
+
+/* One direction of Criterion.multi_class_bce (utils/criterion.py:41-49) fused with the head and its backward:
+ * loss += mean_{B*E} BCEWithLogits(preds, y)  -- the reference applies the logits loss to the SIGMOID OUTPUTS, kept --
+ * with y the multi-hot rows given as CSR (label_off int64 [B+1], label_ids int32 [n_pos]: hr_t / tr_h of the batch,
+ * data/generator.py:160-213) and, when label_smoothing >= 0, y <- y (1 - ls) + 1/E.  The [B,E] predictions never reach
+ * HBM; the [B,E] logit gradient lives in the workspace (kge_head_1n_bce_workspace_bytes).  dx overwritten, g_ent /
+ * g_bias accumulated, loss in the striped accumulators used by the other train entry points. */
+size_t kge_head_1n_bce_workspace_bytes(int64_t batch, int64_t tot_entity, int64_t n_pos);
+int kge_head_1n_bce(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
+                    const int64_t* label_off, const int32_t* label_ids, int64_t n_pos, float label_smoothing,
+                    void* workspace, size_t workspace_bytes, float* loss, float* dx, float* g_ent, float* g_bias,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

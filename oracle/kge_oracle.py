@@ -587,6 +587,35 @@ def ntn_reg(params, lmbda, dtype=np.float32):
     return dtype(lmbda) * root, {k: (dtype(lmbda) * v / root).astype(dtype) for k, v in P.items()}
 
 
+# --------------------------------------------------------------------------- 1-N scoring head (projection models)
+def head_1n_forward(x, ent, bias=None, dtype=np.float32):
+    """Last lines of ConvE / TuckER / InteractE / HypER / AcrE forward (projection.py:100-102, 335-336, 444-447, 606-609,
+    734-737): sigmoid(x @ ent.T + bias), [B, E]."""
+    z = np.asarray(x, dtype) @ np.asarray(ent, dtype).T
+    if bias is not None:
+        z = z + np.asarray(bias, dtype).reshape(1, -1)
+    return _sigmoid(z)
+
+
+def multi_class_bce_dir(preds, labels, label_smoothing, tot_entity, dtype=np.float32):
+    """One direction of Criterion.multi_class_bce (criterion.py:41-49): optional label smoothing
+    y <- y (1 - ls) + 1/E, then torch.nn.BCEWithLogitsLoss (mean over all B*E elements) applied to the sigmoid OUTPUTS
+    as if they were logits.  Returns (loss, d loss / d preds)."""
+    p = np.asarray(preds, dtype)
+    y = np.asarray(labels, dtype)
+    if label_smoothing is not None and tot_entity is not None:
+        y = y * dtype(1.0 - label_smoothing) + dtype(1.0 / tot_entity)
+    elem = np.maximum(p, 0) - p * y + np.log1p(np.exp(-np.abs(p)))
+    return dtype(np.mean(elem, dtype=dtype)), ((_sigmoid(p) - y) / dtype(p.size)).astype(dtype)
+
+
+def head_1n_backward(x, ent, preds, dpreds, dtype=np.float32):
+    """(dx, d ent, d bias) of head_1n_forward given d loss / d preds."""
+    p = np.asarray(preds, dtype)
+    dz = np.asarray(dpreds, dtype) * p * (1 - p)
+    return dz @ np.asarray(ent, dtype), dz.T @ np.asarray(x, dtype), dz.sum(axis=0)
+
+
 # --------------------------------------------------------------------------- one training step
 def train_step_grads(model, params, batch, dtype=np.float32, **hp):
     """Loss and dense gradients of one reference train step.

@@ -269,6 +269,40 @@ def golden_pretrained():
     print("wrote pretrained slice")
 
 
+def golden_head_1n():
+    """The 1-N scoring head + Criterion.multi_class_bce exactly as the projection models chain them
+    (projection.py:100-102 + utils/trainer.py:159-170 + utils/criterion.py:41-49), on random activations."""
+    from pykg2vec.utils.criterion import Criterion
+    torch.manual_seed(321)
+    rng = np.random.default_rng(321)
+    Bh, Eh, dh = 37, 203, 45
+    rec = {"B": Bh, "E": Eh, "d": dh}
+    ent = torch.nn.Parameter(torch.randn(Eh, dh) * 0.3)
+    bias = torch.nn.Parameter(torch.randn(1, Eh) * 0.1)
+    xs = [torch.nn.Parameter(torch.randn(Bh, dh)) for _ in range(2)]           # tail-direction / head-direction activations
+    labels = [(rng.random((Bh, Eh)) < 0.03).astype(np.float32) for _ in range(2)]  # hr_t, tr_h multi-hot rows
+    labels[0][3] = 0.0                                                          # a row without any positive
+    for ls_name, ls in (("smooth", 0.1), ("plain", None)):
+        for q in [ent, bias] + xs:
+            q.grad = None
+        pred_t = torch.sigmoid(torch.matmul(xs[0], ent.T) + bias)
+        pred_h = torch.sigmoid(torch.matmul(xs[1], ent.T) + bias)
+        loss = Criterion.multi_class_bce(pred_h, pred_t, torch.from_numpy(labels[1]), torch.from_numpy(labels[0]), ls,
+                                         Eh if ls is not None else None)
+        loss.backward()
+        rec[ls_name + ".loss"] = np.float32(loss.item())
+        rec[ls_name + ".pred_t"] = pred_t.detach().numpy()
+        rec[ls_name + ".pred_h"] = pred_h.detach().numpy()
+        rec[ls_name + ".g_ent"] = ent.grad.numpy().copy()
+        rec[ls_name + ".g_bias"] = bias.grad.numpy().copy()
+        rec[ls_name + ".g_x_t"] = xs[0].grad.numpy().copy()
+        rec[ls_name + ".g_x_h"] = xs[1].grad.numpy().copy()
+    rec.update(ent=ent.detach().numpy(), bias=bias.detach().numpy(), x_t=xs[0].detach().numpy(), x_h=xs[1].detach().numpy(),
+               hr_t=labels[0], tr_h=labels[1])
+    np.savez_compressed(os.path.join(OUT, "ref_head_1n.npz"), **rec)
+    print("wrote head_1n", rec["smooth.loss"], rec["plain.loss"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])  # optional: regenerate just the named cases
@@ -277,3 +311,5 @@ if __name__ == "__main__":
             golden_for(name, cls_path, hp, seed=1000 + i)
     if not only or "pretrained" in only:
         golden_pretrained()
+    if not only or "head_1n" in only:
+        golden_head_1n()

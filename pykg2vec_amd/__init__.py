@@ -6,7 +6,7 @@ libkge_hip.so (C ABI: include/kge_hip.h).  Importing the package does not need a
 from . import _lib  # noqa: F401
 from .common import Monitor, TrainingStrategy  # noqa: F401
 
-__all__ = ["pairwise", "pointwise", "criterion", "evaluator", "trainer", "generator", "kernels"]
+__all__ = ["pairwise", "pointwise", "criterion", "evaluator", "trainer", "generator", "kernels", "head"]
 
 MODEL_MAP = {  # lower-case name -> "module.Class", same keys as Importer.modelMap (pykg2vec/common.py:266-298) for this path
     "transe": "pairwise.TransE", "transh": "pairwise.TransH", "transd": "pairwise.TransD", "rotate": "pairwise.RotatE",

@@ -24,3 +24,11 @@ class Criterion:
     @staticmethod
     def pointwise_logistic(preds, target):  # criterion.py:31-34
         return F.softplus(target * preds).mean()
+
+    @staticmethod
+    def multi_class_bce(pred_heads, pred_tails, tr_h, hr_t, label_smoothing, tot_entity):  # criterion.py:41-49
+        if label_smoothing is not None and tot_entity is not None:
+            hr_t = hr_t * (1.0 - label_smoothing) + 1.0 / tot_entity
+            tr_h = tr_h * (1.0 - label_smoothing) + 1.0 / tot_entity
+        bce = torch.nn.BCEWithLogitsLoss()  # (sic) applied to sigmoid outputs, as the reference does
+        return torch.mean(bce(pred_heads, tr_h)) + torch.mean(bce(pred_tails, hr_t))

@@ -254,6 +254,29 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
                             next_hyper, batch_stride, n_batches, draws_per_batch, (hipStream_t)stream);
 }
 
+int kge_head_1n_forward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
+                        float* preds, void* stream) {
+    return launch_head_forward(x, batch, dim, ent, tot_entity, bias, preds, (hipStream_t)stream);
+}
+
+int kge_head_1n_backward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* preds,
+                         const float* dpreds, float* dx, float* g_ent, float* g_bias, void* stream) {
+    return launch_head_backward(x, batch, dim, ent, tot_entity, preds, dpreds, dx, g_ent, g_bias, (hipStream_t)stream);
+}
+
+size_t kge_head_1n_bce_workspace_bytes(int64_t batch, int64_t tot_entity, int64_t n_pos) {
+    if (batch <= 0 || tot_entity <= 0 || n_pos < 0) return 0;
+    return head_bce_workspace_bytes(batch, tot_entity, n_pos);
+}
+
+int kge_head_1n_bce(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
+                    const int64_t* label_off, const int32_t* label_ids, int64_t n_pos, float label_smoothing,
+                    void* workspace, size_t workspace_bytes, float* loss, float* dx, float* g_ent, float* g_bias,
+                    void* stream) {
+    return launch_head_bce(x, batch, dim, ent, tot_entity, bias, label_off, label_ids, n_pos, label_smoothing, workspace,
+                           workspace_bytes, loss, dx, g_ent, g_bias, (hipStream_t)stream);
+}
+
 int kge_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, float* scratch, float* loss, void* stream) {
     if (!param || !grad || !scratch || !loss || numel <= 0) { set_error("kge_l2norm_reg: bad arguments"); return -1; }
     return launch_l2norm_reg(param, grad, numel, lmbda, scratch, loss, (hipStream_t)stream);

@@ -1,0 +1,308 @@
+// kge_head.hip -- the 1-N scoring head of the projection models:
+//     preds[B, E] = sigmoid(x[B, d] @ ent[E, d]^T + bias[E])
+// ConvE / TuckER / InteractE / HypER / AcrE end their forward with exactly these lines
+// (pykg2vec/models/projection.py:100-102, 335-336, 444-447, 606-609, 734-737) and train it with
+// Criterion.multi_class_bce (utils/criterion.py:41-49): BCEWithLogitsLoss applied to the SIGMOID OUTPUTS against the
+// (label-smoothed) multi-hot rows hr_t / tr_h, mean over B*E.
+//
+// GEMM-shaped, so it runs on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak), 64x64 output tile per
+// workgroup (4 waves x one 32x32 tile), K staged through LDS in 32-wide slabs.  Operand maps as in kge_dense.hip.
+//   k_head_fwd        Z = X Ent^T (+bias) -> sigmoid            [B,d]x[d,E]
+//   k_head_bce        the same GEMM with the loss fused into the epilogue: every element is first treated as a negative
+//                     (label y0); loss += sum softplus(p) - p*y0 and dz = (sigmoid(p) - y0) p (1-p) / (B*E) is written
+//   k_head_bce_pos    one 32-lane group per positive (b, e) of the CSR label lists: recomputes p and applies the
+//                     (y1 - y0) correction to the loss and to dz[b, e]  (a positive is touched by exactly one group)
+//   k_head_dx         dX = dZ Ent            [B,E]x[E,d]   split over E, atomics into dX
+//   k_head_dent       g_ent += dZ^T X        [E,B]x[B,d] ;  g_bias += column sums of dZ
+// For the autograd form dZ = dpreds * p * (1 - p) is formed while the operand tile is staged.
+#include "kge_internal.h"
+
+namespace kge {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HT = 64;   // output tile edge per workgroup
+constexpr int HK = 32;   // K slab staged in LDS
+constexpr int HS = HK + 1;
+
+__device__ __forceinline__ int head_row(int reg, int lk) { return (reg & 3) + 8 * (reg >> 2) + 4 * lk; }
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+__device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+// one 32-wide K slab: acc += A[32 x 32] B[32 x 32] with A rows / B columns taken from LDS tiles stored [row][k]
+__device__ __forceinline__ void slab_mfma(const float* __restrict__ sa, const float* __restrict__ sb, int li, int lk, f32x16& acc) {
+#pragma unroll
+    for (int kk = 0; kk < HK; kk += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[li * HS + kk + lk], sb[li * HS + kk + lk], acc, 0, 0, 0);
+}
+
+// Pipelined K loop shared by the three GEMMs: every thread stages HT*HK/256 = 8 elements of each operand tile per slab;
+// the NEXT slab's global loads are issued into registers before the current slab's MFMAs, so their latency overlaps the
+// matrix work.  fa / fb(slab, j, pos) return the j-th element this thread stages and its LDS position.
+constexpr int HPT = HT * HK / 256;
+
+struct NoSlabHook { __device__ __forceinline__ void operator()() const {} };
+
+template <class FA, class FB, class FH = NoSlabHook>
+__device__ __forceinline__ void gemm_pipeline(int nslabs, FA fa, FB fb, float* __restrict__ sA, float* __restrict__ sB,
+                                              int wr, int wc, int li, int lk, f32x16& acc, FH hook = FH()) {
+    float ra[HPT], rb[HPT];
+    int pa[HPT], pb[HPT];
+#pragma unroll
+    for (int j = 0; j < HPT; ++j) { ra[j] = fa(0, j, pa[j]); rb[j] = fb(0, j, pb[j]); }
+    for (int sl = 0; sl < nslabs; ++sl) {
+#pragma unroll
+        for (int j = 0; j < HPT; ++j) { sA[pa[j]] = ra[j]; sB[pb[j]] = rb[j]; }
+        __syncthreads();
+        if (sl + 1 < nslabs) {
+#pragma unroll
+            for (int j = 0; j < HPT; ++j) { ra[j] = fa(sl + 1, j, pa[j]); rb[j] = fb(sl + 1, j, pb[j]); }
+        }
+        hook();  // sees the staged slab (k_head_dent: bias-gradient column sums)
+        slab_mfma(sA + wr * 32 * HS, sB + wc * 32 * HS, li, lk, acc);
+        __syncthreads();
+    }
+}
+
+struct HeadArgs {
+    const float* x; const float* ent; const float* bias;
+    int64_t B, E; int d;
+    float* preds;                 // fwd: sigmoid outputs [B,E]
+    float* dz;                    // bce: gradient wrt the logits [B,E]
+    float y0, inv_count;          // bce: negative label, 1/(B*E)
+    float* loss;                  // striped accumulators
+};
+
+// MODE 0: preds.  MODE 1: fused multi_class_bce with every label = y0 (positives are corrected by k_head_bce_pos).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_head_gemm(HeadArgs a) {
+    __shared__ float sA[HT * HS], sB[HT * HS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t e0 = (int64_t)blockIdx.x * HT, b0 = (int64_t)blockIdx.y * HT;
+    const int wr = wave >> 1, wc = wave & 1;  // wave's 32x32 sub-tile: rows (batch) wr, columns (entities) wc
+    f32x16 acc = {0};
+    auto fa = [&](int sl, int j, int& pos) -> float {  // x tile [b][k], coalesced along k
+        const int idx = threadIdx.x + 256 * j, r = idx / HK, k = idx - r * HK, kg = sl * HK + k;
+        pos = r * HS + k;
+        return (kg < a.d && b0 + r < a.B) ? a.x[(b0 + r) * a.d + kg] : 0.f;
+    };
+    auto fb = [&](int sl, int j, int& pos) -> float {  // entity tile [e][k]
+        const int idx = threadIdx.x + 256 * j, r = idx / HK, k = idx - r * HK, kg = sl * HK + k;
+        pos = r * HS + k;
+        return (kg < a.d && e0 + r < a.E) ? a.ent[(e0 + r) * a.d + kg] : 0.f;
+    };
+    gemm_pipeline((a.d + HK - 1) / HK, fa, fb, sA, sB, wr, wc, li, lk, acc);
+    const int64_t e = e0 + wc * 32 + li;
+    const float bias = (a.bias && e < a.E) ? a.bias[e] : 0.f;
+    float lsum = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t b = b0 + wr * 32 + head_row(reg, lk);
+        if (b < a.B && e < a.E) {
+            const float p = sigmoidf_(acc[reg] + bias);
+            if constexpr (MODE == 0) {
+                a.preds[b * a.E + e] = p;
+            } else {
+                lsum += softplusf_(p) - p * a.y0;                                   // BCEWithLogits(p, y0)
+                a.dz[b * a.E + e] = (sigmoidf_(p) - a.y0) * p * (1.f - p) * a.inv_count;
+            }
+        }
+    }
+    if constexpr (MODE == 1) block_accumulate_loss<1>(lsum * a.inv_count, 0, a.loss);
+}
+
+// positives: group of 32 lanes per (b, e) entry of the CSR label lists
+__global__ __launch_bounds__(256) void k_head_bce_pos(HeadArgs a, const int64_t* __restrict__ lab_off, const int32_t* __restrict__ lab_ids,
+                                                      const int32_t* __restrict__ row_of, int64_t n_pos, float dy) {
+    const int gl = threadIdx.x & 31;
+    float acc = 0.f;
+    for (int64_t j = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); j < n_pos; j += (int64_t)gridDim.x * 8) {
+        const int64_t b = row_of[j], e = lab_ids[j];
+        float z = 0.f;
+        for (int k = gl; k < a.d; k += 32) z = fmaf(a.x[b * a.d + k], a.ent[e * a.d + k], z);
+        z = gsum<32>(z) + (a.bias ? a.bias[e] : 0.f);
+        const float p = sigmoidf_(z);
+        if (gl == 0) a.dz[b * a.E + e] -= dy * p * (1.f - p) * a.inv_count;  // label y1 instead of y0: d(-p*y)/dp
+        acc -= p * dy * a.inv_count;
+    }
+    (void)lab_off;
+    block_accumulate_loss<32>(acc, gl, a.loss);
+}
+
+// per-element gradient wrt the logits: dz[b,e] (fused form) or dpreds[b,e] * p (1 - p) (autograd form)
+struct DzSrc {
+    const float* dz; const float* dpreds; const float* preds;
+    __device__ __forceinline__ float at(int64_t i) const {
+        if (dz) return dz[i];
+        const float p = preds[i];
+        return dpreds[i] * p * (1.f - p);
+    }
+};
+
+// dX[b, k] += sum_{e in this split} dz[b, e] ent[e, k]     grid: (d tiles, B tiles, E splits)
+__global__ __launch_bounds__(256) void k_head_dx(DzSrc g, const float* __restrict__ ent, int64_t B, int64_t E, int d,
+                                                 int64_t e_per_split, float* __restrict__ dx) {
+    __shared__ float sA[HT * HS], sB[HT * HS];  // sA[b][e-slab], sB[k][e-slab]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t k0 = (int64_t)blockIdx.x * HT, b0 = (int64_t)blockIdx.y * HT;
+    const int64_t es = (int64_t)blockIdx.z * e_per_split, ee = min(E, es + e_per_split);
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x16 acc = {0};
+    auto fa = [&](int sl, int j, int& pos) -> float {  // dz tile [b][e-slab], coalesced along e
+        const int idx = threadIdx.x + 256 * j, r = idx / HK, c = idx - r * HK;
+        const int64_t e = es + (int64_t)sl * HK + c;
+        pos = r * HS + c;
+        return (e < ee && b0 + r < B) ? g.at((b0 + r) * E + e) : 0.f;
+    };
+    auto fb = [&](int sl, int j, int& pos) -> float {  // entity tile stored [k][e-slab], read coalesced along k
+        const int idx = threadIdx.x + 256 * j, c = idx / HT, r = idx - c * HT;
+        const int64_t e = es + (int64_t)sl * HK + c;
+        pos = r * HS + c;
+        return (e < ee && k0 + r < d) ? ent[e * d + k0 + r] : 0.f;
+    };
+    gemm_pipeline((int)((ee - es + HK - 1) / HK), fa, fb, sA, sB, wr, wc, li, lk, acc);
+    const int64_t k = k0 + wc * 32 + li;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t b = b0 + wr * 32 + head_row(reg, lk);
+        if (b < B && k < d && acc[reg] != 0.f) unsafeAtomicAdd(dx + b * d + k, acc[reg]);
+    }
+}
+
+// g_ent[e, k] += sum_{b in this split} dz[b, e] x[b, k] ;  g_bias[e] += sum_b dz[b, e]    grid: (d tiles, E tiles, B splits)
+__global__ __launch_bounds__(256) void k_head_dent(DzSrc g, const float* __restrict__ x, int64_t B, int64_t E, int d,
+                                                   int64_t b_per_split, float* __restrict__ g_ent, float* __restrict__ g_bias) {
+    __shared__ float sA[HT * HS], sB[HT * HS];  // sA[e][b-slab], sB[k][b-slab]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t k0 = (int64_t)blockIdx.x * HT, e0 = (int64_t)blockIdx.y * HT;
+    const int64_t bs = (int64_t)blockIdx.z * b_per_split, be = min(B, bs + b_per_split);
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x16 acc = {0};
+    float colsum = 0.f;  // threads 0..63 of the k-tile-0 workgroups: bias gradient of entity e0 + threadIdx.x
+    const bool do_bias = g_bias != nullptr && blockIdx.x == 0 && threadIdx.x < HT;
+    auto fa = [&](int sl, int j, int& pos) -> float {  // dz tile stored [e][b-slab], read coalesced along e
+        const int idx = threadIdx.x + 256 * j, c = idx / HT, r = idx - c * HT;
+        const int64_t b = bs + (int64_t)sl * HK + c;
+        pos = r * HS + c;
+        return (b < be && e0 + r < E) ? g.at(b * E + e0 + r) : 0.f;
+    };
+    auto fb = [&](int sl, int j, int& pos) -> float {  // x tile stored [k][b-slab], read coalesced along k
+        const int idx = threadIdx.x + 256 * j, c = idx / HT, r = idx - c * HT;
+        const int64_t b = bs + (int64_t)sl * HK + c;
+        pos = r * HS + c;
+        return (b < be && k0 + r < d) ? x[b * d + k0 + r] : 0.f;
+    };
+    auto hook = [&]() {
+        if (do_bias) {
+#pragma unroll 8
+            for (int c = 0; c < HK; ++c) colsum += sA[threadIdx.x * HS + c];
+        }
+    };
+    gemm_pipeline((int)((be - bs + HK - 1) / HK), fa, fb, sA, sB, wr, wc, li, lk, acc, hook);
+    const int64_t k = k0 + wc * 32 + li;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t e = e0 + wr * 32 + head_row(reg, lk);
+        if (e < E && k < d && acc[reg] != 0.f) unsafeAtomicAdd(g_ent + e * d + k, acc[reg]);
+    }
+    if (do_bias && e0 + threadIdx.x < E && colsum != 0.f) unsafeAtomicAdd(g_bias + e0 + threadIdx.x, colsum);
+}
+
+__global__ void k_head_rows_of(const int64_t* __restrict__ lab_off, int64_t B, int32_t* __restrict__ row_of) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int64_t j = lab_off[b]; j < lab_off[b + 1]; ++j) row_of[j] = (int32_t)b;
+}
+
+static int head_check(const char* who, const float* x, const float* ent, int64_t B, int64_t E, int d) {
+    if (!x || !ent || B <= 0 || E <= 0 || d <= 0) { set_error("%s: bad arguments", who); return -1; }
+    if (B > (int64_t)65535 * HT) { set_error("%s: batch too large", who); return -1; }
+    return 0;
+}
+
+static dim3 head_grid(int64_t E, int64_t B) { return dim3((unsigned)((E + HT - 1) / HT), (unsigned)((B + HT - 1) / HT)); }
+
+int launch_head_forward(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* bias, float* preds,
+                        hipStream_t s) {
+    if (head_check("kge_head_1n_forward", x, ent, B, E, d) || !preds) { if (!preds) set_error("kge_head_1n_forward: null output"); return -1; }
+    HeadArgs a{};
+    a.x = x; a.ent = ent; a.bias = bias; a.B = B; a.E = E; a.d = d; a.preds = preds;
+    hipLaunchKernelGGL(k_head_gemm<0>, head_grid(E, B), dim3(256), 0, s, a);
+    return check_launch("k_head_gemm<0>");
+}
+
+static int head_backward_gemms(const DzSrc& g, const float* x, int64_t B, int d, const float* ent, int64_t E, float* dx,
+                               float* g_ent, float* g_bias, hipStream_t s) {
+    if (dx) {
+        hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * d * sizeof(float), s);
+        if (e != hipSuccess) { set_error("kge_head: memset: %s", hipGetErrorString(e)); return -2; }
+        // split the long E reduction so that ~8 workgroups per CU exist; every split a multiple of the slab
+        const int64_t tiles = ((B + HT - 1) / HT) * ((d + HT - 1) / HT);
+        int64_t splits = (2048 + tiles - 1) / tiles;
+        const int64_t max_splits = (E + HK - 1) / HK;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        int64_t per = ((E + splits - 1) / splits + HK - 1) / HK * HK;
+        splits = (E + per - 1) / per;
+        hipLaunchKernelGGL(k_head_dx, dim3((unsigned)((d + HT - 1) / HT), (unsigned)((B + HT - 1) / HT), (unsigned)splits),
+                           dim3(256), 0, s, g, ent, B, E, d, per, dx);
+    }
+    if (g_ent) {
+        const int64_t tiles = ((E + HT - 1) / HT) * ((d + HT - 1) / HT);
+        int64_t splits = (2048 + tiles - 1) / tiles;
+        const int64_t max_splits = (B + HK - 1) / HK;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        int64_t per = ((B + splits - 1) / splits + HK - 1) / HK * HK;
+        splits = (B + per - 1) / per;
+        hipLaunchKernelGGL(k_head_dent, dim3((unsigned)((d + HT - 1) / HT), (unsigned)((E + HT - 1) / HT), (unsigned)splits),
+                           dim3(256), 0, s, g, x, B, E, d, per, g_ent, g_bias);
+    }
+    return check_launch("k_head_dx / k_head_dent");
+}
+
+int launch_head_backward(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* preds,
+                         const float* dpreds, float* dx, float* g_ent, float* g_bias, hipStream_t s) {
+    if (head_check("kge_head_1n_backward", x, ent, B, E, d)) return -1;
+    if (!preds || !dpreds) { set_error("kge_head_1n_backward: preds / dpreds are null"); return -1; }
+    DzSrc g{nullptr, dpreds, preds};
+    return head_backward_gemms(g, x, B, d, ent, E, dx, g_ent, g_bias, s);
+}
+
+size_t head_bce_workspace_bytes(int64_t B, int64_t E, int64_t n_pos) {
+    return ((size_t)B * E * sizeof(float) + 255) / 256 * 256 + ((size_t)n_pos * sizeof(int32_t) + 255) / 256 * 256;
+}
+
+int launch_head_bce(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* bias,
+                    const int64_t* lab_off, const int32_t* lab_ids, int64_t n_pos, float label_smoothing, void* ws,
+                    size_t ws_bytes, float* loss, float* dx, float* g_ent, float* g_bias, hipStream_t s) {
+    if (head_check("kge_head_1n_bce", x, ent, B, E, d)) return -1;
+    if (!lab_off || (n_pos > 0 && !lab_ids) || !loss || n_pos < 0) { set_error("kge_head_1n_bce: bad arguments"); return -1; }
+    if (!ws || ws_bytes < head_bce_workspace_bytes(B, E, n_pos)) {
+        set_error("kge_head_1n_bce: workspace too small (need kge_head_1n_bce_workspace_bytes)");
+        return -1;
+    }
+    float* dz = (float*)ws;
+    int32_t* row_of = (int32_t*)((char*)ws + ((size_t)B * E * sizeof(float) + 255) / 256 * 256);
+    // Criterion.multi_class_bce (utils/criterion.py:42-45): y <- y (1 - ls) + 1/E when label smoothing is given
+    const bool smooth = label_smoothing >= 0.f;
+    const float y0 = smooth ? 1.0f / (float)E : 0.f;
+    const float y1 = smooth ? (1.0f - label_smoothing) + 1.0f / (float)E : 1.f;
+    HeadArgs a{};
+    a.x = x; a.ent = ent; a.bias = bias; a.B = B; a.E = E; a.d = d; a.dz = dz; a.loss = loss;
+    a.y0 = y0; a.inv_count = 1.0f / ((float)B * (float)E);
+    hipLaunchKernelGGL(k_head_gemm<1>, head_grid(E, B), dim3(256), 0, s, a);
+    if (n_pos > 0) {
+        hipLaunchKernelGGL(k_head_rows_of, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, lab_off, B, row_of);
+        int64_t blocks = (n_pos + 7) / 8;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_head_bce_pos, dim3((unsigned)blocks), dim3(256), 0, s, a, lab_off, lab_ids, row_of, n_pos, y1 - y0);
+    }
+    DzSrc g{dz, nullptr, nullptr};
+    return head_backward_gemms(g, x, B, d, ent, E, dx, g_ent, g_bias, s);
+}
+
+}  // namespace kge

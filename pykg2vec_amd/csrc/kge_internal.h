@@ -103,6 +103,16 @@ int launch_ntn_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64
 int launch_ntn_eval_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
                            float* scores, hipStream_t s);
 
+// kge_head.hip (1-N scoring head of the projection models)
+int launch_head_forward(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* bias, float* preds,
+                        hipStream_t s);
+int launch_head_backward(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* preds,
+                         const float* dpreds, float* dx, float* g_ent, float* g_bias, hipStream_t s);
+size_t head_bce_workspace_bytes(int64_t B, int64_t E, int64_t n_pos);
+int launch_head_bce(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* bias,
+                    const int64_t* lab_off, const int32_t* lab_ids, int64_t n_pos, float label_smoothing, void* ws,
+                    size_t ws_bytes, float* loss, float* dx, float* g_ent, float* g_bias, hipStream_t s);
+
 // kge_sampler.hip
 int launch_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, int64_t n_slots, hipStream_t s);
 int launch_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t n_pos, int neg_rate,

@@ -1,0 +1,40 @@
+"""The 1-N scoring head the projection models end their forward with (pykg2vec/models/projection.py:100-102,
+335-336, 444-447, 606-609, 734-737): `sigmoid(x @ ent_embeddings.weight.T + b)`, on the MI355X matrix cores.
+
+`one_to_n_scores` is a differentiable drop-in for those three lines (x comes from the model's own torch layers; the
+entity table and the bias receive dense gradients like nn.Embedding(sparse=False)); `multi_class_bce_step` is the fused
+training form: head + one direction of Criterion.multi_class_bce + backward without a [B, E] prediction tensor."""
+import torch
+
+from . import kernels as K
+
+
+class _OneToN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ent, bias):
+        x, ent = x.contiguous(), ent.contiguous()
+        b = None if bias is None else bias.contiguous().view(-1)
+        preds = K.head_1n_forward(x, ent, b)
+        ctx.save_for_backward(x, ent, preds)
+        ctx.has_bias = bias is not None
+        ctx.bias_shape = None if bias is None else bias.shape
+        return preds
+
+    @staticmethod
+    def backward(ctx, dpreds):
+        x, ent, preds = ctx.saved_tensors
+        dx, g_ent, g_bias = K.head_1n_backward(x, ent, preds, dpreds.contiguous(), need_bias=ctx.has_bias)
+        return dx, g_ent, (g_bias.view(ctx.bias_shape) if ctx.has_bias else None)
+
+
+def one_to_n_scores(x, ent_weight, bias=None):
+    """sigmoid(x @ ent_weight.T + bias) -> [B, E]; bias: [E] or [1, E] (ConvE's `b.weight`) or None (TuckER)."""
+    return _OneToN.apply(x, ent_weight, bias)
+
+
+def multi_class_bce_step(x, ent_weight, bias, label_off, label_ids, label_smoothing, loss_buf, g_ent, g_bias=None):
+    """Fused head + one direction of Criterion.multi_class_bce (utils/criterion.py:41-49) + backward.
+    Labels are the batch's hr_t (tail direction) or tr_h (head direction) rows as CSR.  Returns d loss / d x."""
+    b = None if bias is None else bias.contiguous().view(-1)
+    gb = None if g_bias is None else g_bias.view(-1)
+    return K.head_1n_bce(x.contiguous(), ent_weight.contiguous(), b, label_off, label_ids, label_smoothing, loss_buf, g_ent, gb)

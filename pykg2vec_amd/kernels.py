@@ -361,3 +361,52 @@ def sample_batch(triples, perm, start, n_pos, neg_rate, tot_entity, bern_prob, s
                                       int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), 1 if pointwise else 0,
                                       *ptrs, pc, _stream()), "kge_sample_batch")
     return outs
+
+
+# ---------------------------------------------------------------------------- 1-N scoring head (projection models)
+def _f32(t, what):
+    return _dev(t, torch.float32, what)
+
+
+def head_1n_forward(x, ent, bias=None):
+    """sigmoid(x @ ent.T + bias): float32 [B, E]  (kge_head_1n_forward)."""
+    B, d = x.shape
+    E = ent.shape[0]
+    preds = torch.empty((B, E), dtype=torch.float32, device=x.device)
+    L.check(L.load().kge_head_1n_forward(_f32(x, "x"), B, d, _f32(ent, "ent"), E,
+                                         _f32(bias, "bias") if bias is not None else None, _f32(preds, "preds"), _stream()),
+            "kge_head_1n_forward")
+    return preds
+
+
+def head_1n_backward(x, ent, preds, dpreds, need_bias=True):
+    """(dx, g_ent, g_bias) of the head given d loss / d preds (kge_head_1n_backward)."""
+    B, d = x.shape
+    E = ent.shape[0]
+    dx = torch.empty_like(x)
+    g_ent = torch.zeros_like(ent)
+    g_bias = torch.zeros(E, dtype=torch.float32, device=x.device) if need_bias else None
+    L.check(L.load().kge_head_1n_backward(_f32(x, "x"), B, d, _f32(ent, "ent"), E, _f32(preds, "preds"),
+                                          _f32(dpreds, "dpreds"), _f32(dx, "dx"), _f32(g_ent, "g_ent"),
+                                          _f32(g_bias, "g_bias") if need_bias else None, _stream()), "kge_head_1n_backward")
+    return dx, g_ent, g_bias
+
+
+def head_1n_bce(x, ent, bias, label_off, label_ids, label_smoothing, loss_buf, g_ent, g_bias=None):
+    """One direction of Criterion.multi_class_bce fused with the head and its backward (kge_head_1n_bce).
+    label_off int64 [B+1], label_ids int32 [n_pos]; label_smoothing None = off.  Adds to loss_buf / g_ent / g_bias,
+    returns dx [B, d]."""
+    B, d = x.shape
+    E = ent.shape[0]
+    n_pos = int(label_ids.numel())
+    lib = L.load()
+    ws = torch.empty(lib.kge_head_1n_bce_workspace_bytes(B, E, n_pos), dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x)
+    L.check(lib.kge_head_1n_bce(_f32(x, "x"), B, d, _f32(ent, "ent"), E, _f32(bias, "bias") if bias is not None else None,
+                                _dev(label_off, torch.int64, "label_off"),
+                                _dev(label_ids, torch.int32, "label_ids") if n_pos else None, n_pos,
+                                -1.0 if label_smoothing is None else float(label_smoothing),
+                                _dev(ws, torch.uint8, "workspace"), ws.numel(), _f32(loss_buf, "loss"), _f32(dx, "dx"),
+                                _f32(g_ent, "g_ent"), _f32(g_bias, "g_bias") if g_bias is not None else None, _stream()),
+            "kge_head_1n_bce")
+    return dx

@@ -433,3 +433,76 @@ def test_inference_hooks_and_checkpoint_roundtrip(hip, tmp_path):
     for k, v in m.state_dict().items():
         assert torch.equal(v.cpu(), before[k])
     assert m.ent_embeddings.weight.data_ptr() == tr.flat.views[0].data_ptr()  # still backed by the flat buffer
+
+
+def _csr_of(dense):
+    off = np.concatenate([[0], np.cumsum(dense.sum(1).astype(np.int64))])
+    ids = np.concatenate([np.flatnonzero(r) for r in dense]).astype(np.int32)
+    return off, ids
+
+
+@pytest.mark.parametrize("mode,ls", [("smooth", 0.1), ("plain", None)])
+def test_head_1n_matches_reference_golden(hip, mode, ls):
+    """1-N scoring head (MFMA GEMM + sigmoid) through autograd with Criterion.multi_class_bce, and the fused
+    head + loss + backward entry point, against the live reference's numbers (tests/golden/ref_head_1n.npz)."""
+    import os
+    from golden_util import GOLDEN
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.criterion import Criterion
+    from pykg2vec_amd.head import multi_class_bce_step, one_to_n_scores
+    z = np.load(os.path.join(GOLDEN, "ref_head_1n.npz"))
+    E = int(z["E"])
+    f = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+    ent, bias = f(z["ent"]).requires_grad_(), f(z["bias"]).requires_grad_()
+    xt, xh = f(z["x_t"]).requires_grad_(), f(z["x_h"]).requires_grad_()
+    pt, ph = one_to_n_scores(xt, ent, bias), one_to_n_scores(xh, ent, bias)
+    assert close(pt.detach().cpu().numpy(), z[mode + ".pred_t"]) and close(ph.detach().cpu().numpy(), z[mode + ".pred_h"])
+    loss = Criterion.multi_class_bce(ph, pt, f(z["tr_h"]), f(z["hr_t"]), ls, E if ls is not None else None)
+    loss.backward()
+    assert close(loss.item(), z[mode + ".loss"])
+    tol = dict(atol=2e-8, rtol=2e-4)  # gradients are O(1e-5): 1/(B*E) scaled
+    for got, key in ((ent.grad, "g_ent"), (bias.grad, "g_bias"), (xt.grad, "g_x_t"), (xh.grad, "g_x_h")):
+        assert np.allclose(got.cpu().numpy(), z[mode + "." + key], **tol), (key, np.abs(got.cpu().numpy() - z[mode + "." + key]).max())
+    # fused form: two directions accumulate into the same loss / entity / bias gradient buffers
+    loss_buf = K.new_loss_buffer("cuda")
+    g_ent, g_bias = torch.zeros_like(ent), torch.zeros(E, device="cuda")
+    dxs = []
+    for x, lab in ((xt, z["hr_t"]), (xh, z["tr_h"])):
+        off, ids = _csr_of(lab)
+        dxs.append(multi_class_bce_step(x.detach(), ent.detach(), bias.detach(), torch.from_numpy(off).cuda(),
+                                        torch.from_numpy(ids).cuda(), ls, loss_buf, g_ent, g_bias))
+    assert close(K.read_loss(loss_buf).item(), z[mode + ".loss"])
+    assert np.allclose(g_ent.cpu().numpy(), z[mode + ".g_ent"], **tol)
+    assert np.allclose(g_bias.cpu().numpy().reshape(1, -1), z[mode + ".g_bias"], **tol)
+    assert np.allclose(dxs[0].cpu().numpy(), z[mode + ".g_x_t"], **tol) and np.allclose(dxs[1].cpu().numpy(), z[mode + ".g_x_h"], **tol)
+
+
+@pytest.mark.parametrize("B,E,d,with_bias", [(128, 14951, 200, True), (1, 65, 1, False), (1000, 4099, 33, True), (64, 64, 64, False)])
+def test_head_1n_vs_oracle_other_shapes(hip, B, E, d, with_bias):
+    from pykg2vec_amd import kernels as K
+    rng = np.random.default_rng(B + E + d)
+    x = rng.normal(size=(B, d)).astype(np.float32)
+    ent = (rng.normal(size=(E, d)) * 0.2).astype(np.float32)
+    bias = (rng.normal(size=E) * 0.1).astype(np.float32) if with_bias else None
+    lab = (rng.random((B, E)) < 0.01).astype(np.float32)
+    p_ref = ko.head_1n_forward(x, ent, bias)
+    loss_ref, dp = ko.multi_class_bce_dir(p_ref, lab, 0.1, E)
+    dx_ref, ge_ref, gb_ref = ko.head_1n_backward(x, ent, p_ref, dp)
+    xd, ed = torch.from_numpy(x).cuda(), torch.from_numpy(ent).cuda()
+    bd = torch.from_numpy(bias).cuda() if with_bias else None
+    p = K.head_1n_forward(xd, ed, bd)
+    assert close(p.cpu().numpy(), p_ref, atol=2e-6)
+    dx, ge, gb = K.head_1n_backward(xd, ed, p, torch.from_numpy(dp).cuda(), need_bias=with_bias)
+    scale = 1.0 / (B * E)
+    assert np.allclose(dx.cpu().numpy(), dx_ref, atol=1e-3 * scale, rtol=1e-3)
+    assert np.allclose(ge.cpu().numpy(), ge_ref, atol=1e-3 * scale, rtol=1e-3)
+    if with_bias:
+        assert np.allclose(gb.cpu().numpy(), gb_ref, atol=1e-3 * scale, rtol=1e-3)
+    off, ids = _csr_of(lab)
+    loss_buf = K.new_loss_buffer("cuda")
+    g_ent = torch.zeros_like(ed)
+    g_bias = torch.zeros(E, device="cuda") if with_bias else None
+    dx2 = K.head_1n_bce(xd, ed, bd, torch.from_numpy(off).cuda(), torch.from_numpy(ids).cuda(), 0.1, loss_buf, g_ent, g_bias)
+    assert np.isclose(K.read_loss(loss_buf).item(), loss_ref, rtol=2e-5)
+    assert np.allclose(dx2.cpu().numpy(), dx_ref, atol=1e-3 * scale, rtol=1e-3)
+    assert np.allclose(g_ent.cpu().numpy(), ge_ref, atol=1e-3 * scale, rtol=1e-3)

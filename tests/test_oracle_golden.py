@@ -133,3 +133,24 @@ def test_corruption_never_emits_train_triple_and_bern_prob():
         assert b == pr and ((a == ph) != (d == pt) or (a == ph and d == pt) is False)
     H, R, T, Y = ko.pointwise_layout(c.train[:64], nh, nr, nt, 3)
     assert len(H) == 64 * 4 and set(Y.tolist()) == {1, -1} and np.array_equal(H[::4], c.train[:64, 0])
+
+
+@pytest.mark.parametrize("mode,ls", [("smooth", 0.1), ("plain", None)])
+def test_head_1n_and_multi_class_bce(mode, ls):
+    """1-N scoring head + Criterion.multi_class_bce (both directions) against the live reference's autograd."""
+    import os
+    from golden_util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "ref_head_1n.npz"))
+    E = int(z["E"])
+    tot = E if ls is not None else None
+    pt = ko.head_1n_forward(z["x_t"], z["ent"], z["bias"])
+    ph = ko.head_1n_forward(z["x_h"], z["ent"], z["bias"])
+    assert close(pt, z[mode + ".pred_t"]) and close(ph, z[mode + ".pred_h"])
+    lt, dpt = ko.multi_class_bce_dir(pt, z["hr_t"], ls, tot)
+    lh, dph = ko.multi_class_bce_dir(ph, z["tr_h"], ls, tot)
+    assert close(lt + lh, z[mode + ".loss"])
+    gxt, get_, gbt = ko.head_1n_backward(z["x_t"], z["ent"], pt, dpt)
+    gxh, geh, gbh = ko.head_1n_backward(z["x_h"], z["ent"], ph, dph)
+    assert close(gxt, z[mode + ".g_x_t"], atol=1e-7) and close(gxh, z[mode + ".g_x_h"], atol=1e-7)
+    assert close(get_ + geh, z[mode + ".g_ent"], atol=1e-7)
+    assert close((gbt + gbh).reshape(1, -1), z[mode + ".g_bias"], atol=1e-7)

@@ -1,0 +1,43 @@
+"""Dev tool: 1-N scoring head (kge_head_1n_*) vs the stock ATen chain the reference issues
+(matmul + add + sigmoid, BCEWithLogitsLoss on dense multi-hot labels, autograd backward) on one MI355X."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from pykg2vec_amd import kernels as K
+
+
+def bench(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+for B, E, d in ((128, 14951, 200), (1000, 14951, 200), (128, 40943, 200), (4096, 14951, 200)):
+    rng = np.random.default_rng(0)
+    x = torch.randn(B, d, device="cuda"); ent = torch.randn(E, d, device="cuda") * 0.2; bias = torch.randn(E, device="cuda") * 0.1
+    lab = (torch.rand(B, E, device="cuda") < 0.002).float()
+    off = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), lab.sum(1).long().cumsum(0)])
+    ids = lab.nonzero()[:, 1].int().contiguous()
+    loss_buf = K.new_loss_buffer("cuda"); g_ent = torch.zeros_like(ent); g_bias = torch.zeros(E, device="cuda")
+    t_fwd = bench(lambda: K.head_1n_forward(x, ent, bias))
+    t_fused = bench(lambda: K.head_1n_bce(x, ent, bias, off, ids, 0.1, loss_buf, g_ent, g_bias))
+    xr, er, br = x.clone().requires_grad_(), ent.clone().requires_grad_(), bias.clone().requires_grad_()
+    bce = torch.nn.BCEWithLogitsLoss()
+
+    def aten():
+        p = torch.sigmoid(torch.matmul(xr, er.T) + br)
+        y = lab * 0.9 + 1.0 / E
+        loss = bce(p, y)
+        loss.backward()
+        xr.grad = er.grad = br.grad = None
+    t_aten = bench(aten)
+    t_aten_fwd = bench(lambda: torch.sigmoid(torch.matmul(x, ent.T) + bias))
+    flops = 2.0 * B * E * d
+    print(f"B={B} E={E} d={d}: forward {t_fwd:.1f} us ({flops/t_fwd/1e6:.1f} TFLOP/s; ATen {t_aten_fwd:.1f} us) | "
+          f"fused head+bce+backward {t_fused:.1f} us ({3*flops/t_fused/1e6:.1f} TFLOP/s; ATen chain {t_aten:.1f} us)", flush=True)
