@@ -50,7 +50,7 @@ for name, model, ds, hp, opt, B, neg, n_eval in CONFIGS:
     cfg.hr_dummy = None
     torch.manual_seed(0)
     m = hip_util.model_from_params(model, {}, hp, E, R, train=train)
-    tr = Trainer(m, cfg); tr.build_model()
+    tr = Trainer(m, cfg, use_graph=(True if os.environ.get('FORCE_GRAPH') == '1' else None)); tr.build_model()
     tr.generator = tr._new_generator()
     K_ = min(200, max(1, NTR // B))
     cfg.tot_train_triples = B * K_            # one "epoch" = K_ steps through Trainer.train_model_epoch
