@@ -121,33 +121,32 @@ __global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, c
     const int n_units = MODE == 0 ? ntile : 2 * ntile + ntile * ntile;
     float* gM = MODE == 1 ? g_rel + (int64_t)rel * k * k : nullptr;
     for (int u = blockIdx.y * 4 + wave; u < n_units; u += 4 * gridDim.y) {
-        if (u < ntile) {  // ---- U[i][a] = sum_b T[i][b] M[a][b]
+        if (MODE == 1 && u < ntile) {  // ---- U[i][a] = sum_b T[i][b] M[a][b] ;  grad_h = -ds U
             const int a = u * 32 + li;
             f32x16 acc = {0};
+            // (lane a reads M[a][b]: a 4-byte gather over 32 rows.  Staging the rows through LDS and a transposed copy of M
+            // were both measured and did not pay: the unit is bound by the dependent-load latency, not by the sectors)
             for (int k0 = 0; k0 < k; k0 += 16) {  // fixed-trip inner loop: 8 operand loads in flight
                 float av[8], bv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int b = k0 + 2 * u + lk;
-                    av[u] = b < k ? sT[li * S + b] : 0.f;
-                    bv[u] = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
+                for (int q = 0; q < 8; ++q) {
+                    const int b = k0 + 2 * q + lk;
+                    av[q] = b < k ? sT[li * S + b] : 0.f;
+                    bv[q] = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+                for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
             }
             if (a < k) {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                    if (MODE == 0) {
-                        atomicAdd(&sSc[i], sH[i * S + a] * acc[reg]);          // LDS atomic: score_i += h_i[a] U[i][a]
-                    } else if (i < cnt && sDs[i] != 0.f) {
-                        unsafeAtomicAdd(g_ent + sHid[i] * k + a, -sDs[i] * acc[reg]);   // grad_h = -ds U
-                    }
+                    if (i < cnt && sDs[i] != 0.f) unsafeAtomicAdd(g_ent + sHid[i] * k + a, -sDs[i] * acc[reg]);   // grad_h = -ds U
                 }
             }
-        } else if (u < 2 * ntile) {  // ---- V[i][b] = sum_a H[i][a] M[a][b] ;  grad_t = -ds V
-            const int b = (u - ntile) * 32 + li;
+        } else if (MODE == 0 || u < 2 * ntile) {  // ---- V[i][b] = sum_a H[i][a] M[a][b]  (M rows read coalesced)
+            // MODE 0: score_i = -V_i . t_i ;  MODE 1: grad_t = -ds V
+            const int b = (MODE == 0 ? u : u - ntile) * 32 + li;
             f32x16 acc = {0};
             for (int k0 = 0; k0 < k; k0 += 16) {
                 float av[8], bv[8];
@@ -164,7 +163,11 @@ __global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, c
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                    if (i < cnt && sDs[i] != 0.f) unsafeAtomicAdd(g_ent + sTid[i] * k + b, -sDs[i] * acc[reg]);
+                    if (MODE == 0) {
+                        atomicAdd(&sSc[i], sT[i * S + b] * acc[reg]);          // LDS atomic: score_i += V[i][b] t_i[b]
+                    } else if (i < cnt && sDs[i] != 0.f) {
+                        unsafeAtomicAdd(g_ent + sTid[i] * k + b, -sDs[i] * acc[reg]);
+                    }
                 }
             }
         } else {  // ---- G[a][b] = sum_i ds_i H[i][a] T[i][b] ;  grad_M = -G
@@ -200,6 +203,8 @@ static size_t rescal_lds_bytes(int k) {
     return (size_t)(2 * TILE * S + 2 * TILE) * sizeof(float) + (size_t)(TILE + (TILE & 1)) * sizeof(int) +
            (size_t)2 * TILE * sizeof(long long);
 }
+
+
 
 size_t dense_workspace_bytes(const kge_model_desc* m, int64_t n) {
     if (m->model == KGE_RESCAL) return group_ws_bytes(m->tot_relation, n);
