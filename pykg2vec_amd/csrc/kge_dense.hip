@@ -261,13 +261,39 @@ int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int6
 // ---- W <- W / ||W_row||_2 in place (plain division, no eps: pairwise.py:862-865)
 __global__ __launch_bounds__(256) void k_row_normalize(float* __restrict__ w, int64_t rows, int64_t dim) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    float* p = w + row * dim;
-    float n2 = 0.f;
-    for (int64_t c = lane; c < dim; c += 64) n2 = fmaf(p[c], p[c], n2);
-    const float nrm = sqrtf(wave_sum(n2));
-    for (int64_t c = lane; c < dim; c += 64) p[c] = p[c] / nrm;
+    // two rows per wave pass: both rows' loads are in flight before the first reduction; rows up to 256 floats stay in
+    // registers between the norm and the scaling (one HBM read, one write)
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2; row < rows; row += (int64_t)gridDim.x * 8) {
+        float* p0 = w + row * dim;
+        float* p1 = p0 + dim;
+        const bool has1 = row + 1 < rows;
+        if (dim <= 256) {
+            float a[4], b[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t e = lane + 64 * c;
+                a[c] = e < dim ? p0[e] : 0.f;
+                b[c] = (has1 && e < dim) ? p1[e] : 0.f;
+            }
+            float na = 0.f, nb = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { na = fmaf(a[c], a[c], na); nb = fmaf(b[c], b[c], nb); }
+            na = sqrtf(wave_sum(na)); nb = sqrtf(wave_sum(nb));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t e = lane + 64 * c;
+                if (e < dim) { p0[e] = a[c] / na; if (has1) p1[e] = b[c] / nb; }
+            }
+        } else {
+            for (int rr = 0; rr < (has1 ? 2 : 1); ++rr) {
+                float* p = rr ? p1 : p0;
+                float n2 = 0.f;
+                for (int64_t c = lane; c < dim; c += 64) n2 = fmaf(p[c], p[c], n2);
+                const float nrm = sqrtf(wave_sum(n2));
+                for (int64_t c = lane; c < dim; c += 64) p[c] = p[c] / nrm;
+            }
+        }
+    }
 }
 
 // long rows (the k*k relation matrices): one 1024-thread workgroup per row
@@ -294,7 +320,7 @@ static void normalize_rows(float* w, int64_t rows, int64_t dim, hipStream_t s) {
     if (dim >= 2048)
         hipLaunchKernelGGL(k_row_normalize_wide, dim3((unsigned)rows), dim3(1024), 0, s, w, rows, dim);
     else
-        hipLaunchKernelGGL(k_row_normalize, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, w, rows, dim);
+        hipLaunchKernelGGL(k_row_normalize, dim3((unsigned)min((int64_t)16384, (rows + 7) / 8)), dim3(256), 0, s, w, rows, dim);
 }
 
 int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k, hipStream_t s) {
