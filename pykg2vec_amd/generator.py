@@ -25,6 +25,17 @@ def _triples_array(data):
     return np.asarray([[x.h, x.r, x.t] for x in data], dtype=np.int64).reshape(-1, 3)
 
 
+def relation_property(train, tot_relation):
+    """KnowledgeGraph.read_relation_property (data/kgcontroller.py:466-492) on the flat train array:
+    prob[r] = |unique tails of r| / (|unique heads of r| + |unique tails of r|), 0 for unseen relations."""
+    train = np.asarray(train, dtype=np.int64).reshape(-1, 3)
+    E = int(train[:, [0, 2]].max()) + 1 if len(train) else 1
+    nh = np.bincount(np.unique(train[:, 1] * E + train[:, 0]) // E, minlength=tot_relation)
+    nt = np.bincount(np.unique(train[:, 1] * E + train[:, 2]) // E, minlength=tot_relation)
+    tot = nh + nt
+    return np.where(tot > 0, nt / np.maximum(tot, 1), 0.0)
+
+
 class Generator:
     def __init__(self, model, config, seed=None, rank=0, world_size=1, backend=K):
         self.K = backend
@@ -52,8 +63,11 @@ class Generator:
         self.slots = self.K.triple_set_build(self.triples)
         self.bern = None
         if getattr(config, "sampling", "uniform") == "bern":
-            prop = config.knowledge_graph.read_cache_data('relationproperty')
-            table = np.asarray([prop[r] for r in range(config.tot_relation)], dtype=np.float32)
+            try:
+                prop = config.knowledge_graph.read_cache_data('relationproperty')
+                table = np.asarray([prop[r] for r in range(config.tot_relation)], dtype=np.float32)
+            except (KeyError, FileNotFoundError, AttributeError):  # cache without the pickle: derive it from the split
+                table = relation_property(train, config.tot_relation).astype(np.float32)
             self.bern = torch.from_numpy(table).to(self.device)
         self.neg_rate = int(config.neg_rate)
         self.batch_size = int(config.batch_size)

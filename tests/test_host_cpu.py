@@ -156,3 +156,12 @@ def test_early_stopper():
     assert not es.should_stop({"mrr": 0.2})
     assert not es.should_stop({"mrr": 0.3})
     assert es.should_stop({"mrr": 0.1})
+
+
+def test_relation_property_matches_reference_rule():
+    from pykg2vec_amd.generator import relation_property
+    c = Case("transe_l1")
+    assert np.allclose(relation_property(c.train, c.R), ko.bern_probability(c.train, c.R))
+    sparse = c.train[c.train[:, 1] != 3]
+    got = relation_property(sparse, c.R)
+    assert got[3] == 0.0 and np.allclose(got, ko.bern_probability(sparse, c.R))
