@@ -24,8 +24,11 @@ class MetricCalculator:
 
     def __init__(self, config):
         self.config = config
-        self.hr_t = config.knowledge_graph.read_cache_data('hr_t')
-        self.tr_h = config.knowledge_graph.read_cache_data('tr_h')
+        try:  # the reference's dict-of-sets filters when the cache carries them ...
+            self.hr_t = config.knowledge_graph.read_cache_data('hr_t')
+            self.tr_h = config.knowledge_graph.read_cache_data('tr_h')
+        except (KeyError, FileNotFoundError, AttributeError):  # ... else the flat splits are grouped on demand
+            self.hr_t = self.tr_h = None
         self.mr, self.fmr, self.mrr, self.fmrr, self.hit, self.fhit = {}, {}, {}, {}, {}, {}
         self.epoch = None
         self.reset()
@@ -96,6 +99,8 @@ class MetricCalculator:
 
 def _as_array(data, n):
     """Triple objects (`.h .r .t`, data/kgcontroller.py:26-58) or an [N,3] array -> int64 [n,3]."""
+    if n is None:
+        n = len(data)
     if isinstance(data, np.ndarray):
         return np.ascontiguousarray(data[:n], dtype=np.int64)
     return np.asarray([[data[i].h, data[i].r, data[i].t] for i in range(n)], dtype=np.int64).reshape(-1, 3)
@@ -116,6 +121,31 @@ def build_filter_csr(triples, hr_t, tr_h):
         t_off[i + 1] = t_off[i] + len(a)
         h_off[i + 1] = h_off[i] + len(b)
     return (t_off, np.asarray(t_ids, dtype=np.int32).reshape(-1), h_off, np.asarray(h_ids, dtype=np.int32).reshape(-1))
+
+
+def _csr_side(queries_key, all_key, all_val):
+    """Per query the unique values whose key equals the query's key: (offsets int64 [n+1], ids int32)."""
+    pairs = np.unique(np.stack([all_key, all_val], 1), axis=0)          # sorted by key, then value; duplicates dropped
+    ukeys, starts, counts = np.unique(pairs[:, 0], return_index=True, return_counts=True)
+    pos = np.minimum(np.searchsorted(ukeys, queries_key), len(ukeys) - 1)
+    found = ukeys[pos] == queries_key
+    cnt = np.where(found, counts[pos], 0).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    # ids of query i = pairs[starts[pos[i]] : +cnt[i], 1]
+    within = np.arange(int(off[-1]), dtype=np.int64) - np.repeat(off[:-1], cnt)
+    ids = pairs[np.repeat(starts[pos], cnt) + within, 1].astype(np.int32)
+    return off, ids
+
+
+def build_filter_csr_from_triples(queries, known_triples, tot_relation):
+    """The same CSR as build_filter_csr, straight from the flat splits: hr_t / tr_h are the tails / heads of
+    train + valid + test grouped by (h, r) / (t, r) (data/kgcontroller.py:410-428); no dict of sets is materialised."""
+    q = np.asarray(queries, dtype=np.int64).reshape(-1, 3)
+    a = np.asarray(known_triples, dtype=np.int64).reshape(-1, 3)
+    R = int(tot_relation)
+    t_off, t_ids = _csr_side(q[:, 0] * R + q[:, 1], a[:, 0] * R + a[:, 1], a[:, 2])
+    h_off, h_ids = _csr_side(q[:, 2] * R + q[:, 1], a[:, 2] * R + a[:, 1], a[:, 0])
+    return t_off, t_ids, h_off, h_ids
 
 
 class Evaluator:
@@ -211,7 +241,13 @@ class Evaluator:
                 cuts = np.concatenate([[0], np.flatnonzero(np.diff(trip[:, 1])) + 1, [len(trip)]]).astype(np.int64)
                 self._groups[key] = (order, self._group_chunks(trip, cuts))
             mc = self.metric_calculator
-            csr = build_filter_csr(trip, mc.hr_t, mc.tr_h)
+            if mc.hr_t is not None:
+                csr = build_filter_csr(trip, mc.hr_t, mc.tr_h)
+            else:  # hr_t / tr_h = train + valid + test grouped by (h,r) / (t,r)  (data/kgcontroller.py:410-428)
+                kg = self.config.knowledge_graph
+                known = np.concatenate([_as_array(kg.read_cache_data(k), None) for k in
+                                        ('triplets_train', 'triplets_valid', 'triplets_test')])
+                csr = build_filter_csr_from_triples(trip, known, self.config.tot_relation)
             dev = next(self.model.parameters()).device
             self._cache[key] = (torch.from_numpy(trip).to(dev),) + tuple(torch.from_numpy(a).to(dev) for a in csr)
         return self._cache[key]

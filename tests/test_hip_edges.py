@@ -184,3 +184,17 @@ def test_train_model_learns_a_planted_graph(hip, model, hp, opt, lr, fmr_drop, m
     assert before["fmr"] > 0.3 * E                      # chance level at initialisation
     assert after["fmr"] < fmr_drop * before["fmr"], (before, after)
     assert after["fmrr"] > mrr_gain * before["fmrr"], (before, after)
+
+
+def test_evaluator_without_cached_filter_dicts_groups_the_flat_splits(hip):
+    """A KG cache carrying only the three splits: filters are built from them (vectorised CSR) -- same ranks."""
+    from golden_util import Case
+    from pykg2vec_amd.evaluator import Evaluator
+    c = Case("transe_l1")
+    m = hip.model_from_case(c, "adam.final.")
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test)
+    want = Evaluator(m, cfg).rank_all(c.test, len(c.test)).cpu().numpy()
+    for k in ("hr_t", "tr_h"):
+        del cfg.knowledge_graph.cache[k]
+    got = Evaluator(m, cfg).rank_all(c.test, len(c.test)).cpu().numpy()
+    assert np.array_equal(got, want)

@@ -165,3 +165,17 @@ def test_relation_property_matches_reference_rule():
     sparse = c.train[c.train[:, 1] != 3]
     got = relation_property(sparse, c.R)
     assert got[3] == 0.0 and np.allclose(got, ko.bern_probability(sparse, c.R))
+
+
+def test_vectorised_filter_csr_equals_dict_of_sets_form():
+    from pykg2vec_amd.evaluator import build_filter_csr, build_filter_csr_from_triples
+    c = Case("transe_l1")
+    hr_t, tr_h = c.filters()
+    allt = np.concatenate([c.train, c.valid, c.test, c.train[:50]])  # duplicates must not matter
+    q = np.concatenate([c.test, np.asarray([[c.E - 1, c.R - 1, 0]])])  # last query may have no known entity at all
+    a = build_filter_csr(q, hr_t, tr_h)
+    b = build_filter_csr_from_triples(q, allt, c.R)
+    for side in (0, 2):
+        assert np.array_equal(a[side], b[side])
+        for i in range(len(q)):
+            assert set(a[side + 1][a[side][i]:a[side][i + 1]]) == set(b[side + 1][b[side][i]:b[side][i + 1]])
