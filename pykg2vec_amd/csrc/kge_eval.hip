@@ -352,40 +352,71 @@ __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand,
                                                  float scale) {
     const float* c = cand + ((e >> 6) * Kpad) * 64 + (e & 63);
     float acc = 0.f;
+    // candidate / query elements are fetched KC at a time BEFORE the dependent accumulation chain (one memory round trip
+    // per KC elements instead of one per element); the accumulation order is unchanged
     if constexpr (XFORM == X_NONE && FORM != F_L1) {
         // the sweep accumulates even and odd k in the two halves of one packed register (v_pk_fma_f32) and adds the
         // halves at the end; the same order here keeps scores bit-identical between the two kernels
         float a0 = 0.f, a1 = 0.f;
-        for (int k = 0; k < Kpad; k += 2) {
-            const float c0 = c[(int64_t)k * 64], c1 = c[(int64_t)(k + 1) * 64];
-            if constexpr (FORM == F_NEGDOT) {
-                a0 = fmaf(c0, q[k], a0);
-                a1 = fmaf(c1, q[k + 1], a1);
-            } else {
-                const float d0 = c0 - q[k], d1 = c1 - q[k + 1];
-                a0 = fmaf(d0, d0, a0);
-                a1 = fmaf(d1, d1, a1);
+        for (int k0 = 0; k0 < Kpad; k0 += KC) {
+            float cv[KC], qv[KC];
+#pragma unroll
+            for (int j = 0; j < KC; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; qv[j] = q[k0 + j]; }
+#pragma unroll
+            for (int j = 0; j < KC; j += 2) {
+                if constexpr (FORM == F_NEGDOT) {
+                    a0 = fmaf(cv[j], qv[j], a0);
+                    a1 = fmaf(cv[j + 1], qv[j + 1], a1);
+                } else {
+                    const float d0 = cv[j] - qv[j], d1 = cv[j + 1] - qv[j + 1];
+                    a0 = fmaf(d0, d0, a0);
+                    a1 = fmaf(d1, d1, a1);
+                }
             }
         }
         acc = a0 + a1;
     } else if constexpr (XFORM == X_NONE) {
-        for (int k = 0; k < Kpad; ++k) acc = pair_step<FORM>(acc, c[(int64_t)k * 64], q[k]);
+        for (int k0 = 0; k0 < Kpad; k0 += KC) {
+            float cv[KC], qv[KC];
+#pragma unroll
+            for (int j = 0; j < KC; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; qv[j] = q[k0 + j]; }
+#pragma unroll
+            for (int j = 0; j < KC; ++j) acc = pair_step<FORM>(acc, cv[j], qv[j]);
+        }
     } else {
         const float* w = q + Kpad;
         float p;
         if constexpr (XFORM == X_TRANSH) {
             p = 0.f;
-            for (int k = 0; k < Kpad; ++k) p = fmaf(c[(int64_t)k * 64], w[k], p);
+            for (int k0 = 0; k0 < Kpad; k0 += KC) {
+                float cv[KC], wv[KC];
+#pragma unroll
+                for (int j = 0; j < KC; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; wv[j] = w[k0 + j]; }
+#pragma unroll
+                for (int j = 0; j < KC; ++j) p = fmaf(cv[j], wv[j], p);
+            }
             p = -p;
         } else {
             p = aux[e];
         }
         float n2 = 0.f;
-        for (int k = 0; k < Kpad; ++k) { const float v = fmaf(p, w[k], c[(int64_t)k * 64]); n2 = fmaf(v, v, n2); }
+        for (int k0 = 0; k0 < Kpad; k0 += KC) {
+            float cv[KC], wv[KC];
+#pragma unroll
+            for (int j = 0; j < KC; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; wv[j] = w[k0 + j]; }
+#pragma unroll
+            for (int j = 0; j < KC; ++j) { const float v = fmaf(p, wv[j], cv[j]); n2 = fmaf(v, v, n2); }
+        }
         const float inv = 1.0f / fmaxf(sqrtf(n2), kEpsNormalize);
-        for (int k = 0; k < Kpad; ++k) {
-            const float v = fmaf(p, w[k], c[(int64_t)k * 64]) * inv;
-            acc = pair_step<FORM>(acc, v, q[k]);
+        for (int k0 = 0; k0 < Kpad; k0 += KC) {
+            float cv[KC], wv[KC], qv[KC];
+#pragma unroll
+            for (int j = 0; j < KC; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; wv[j] = w[k0 + j]; qv[j] = q[k0 + j]; }
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                const float v = fmaf(p, wv[j], cv[j]) * inv;
+                acc = pair_step<FORM>(acc, v, qv[j]);
+            }
         }
     }
     return pair_post<POST>(pair_finish<FORM>(acc, margin), scale);
