@@ -8,7 +8,7 @@ d = json.loads([l for l in open(log) if l.startswith('{')][0])
 b = json.load(open(os.path.join(ROOT, 'gpurun_out', 'r01_bench_line.json')))
 json.dump(b, open(os.path.join(ROOT, 'profiles', 'r01_bench_line.json'), 'w'))
 table = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rocpd_summary.py'), stats_db], capture_output=True, text=True).stdout
-kavg = [l for l in table.splitlines() if 'k_transe_pair_sampled<32, 4, 4, false>' in l][0].split('|')[5].strip()
+kavg = [l for l in table.splitlines() if 'k_transe_pair_sampled<32, 4, 4, false>' in l][0].split('|')[4].strip()
 hdr = f"""# rocprofv3 --kernel-trace --stats, round 1, final build
 
 Command (MI355X box): `rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline`
