@@ -298,7 +298,18 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
         const float* Mr = m.tab[1] + r * (int64_t)d * d;
         for (int j = lane; j < d; j += 64) {
             float a = 0.f, b = 0.f;
-            for (int i2 = 0; i2 < d; ++i2) {
+            int i2 = 0;
+            for (; i2 + KC <= d; i2 += KC) {  // operands of KC steps in flight before the dependent fma chains
+                float m1[KC], m2[KC], hv[KC], tv[KC];
+#pragma unroll
+                for (int u = 0; u < KC; ++u) {
+                    m1[u] = Mr[(int64_t)(i2 + u) * d + j]; m2[u] = Mr[(int64_t)j * d + i2 + u];
+                    hv[u] = eh[i2 + u]; tv[u] = et[i2 + u];
+                }
+#pragma unroll
+                for (int u = 0; u < KC; ++u) { a = fmaf(hv[u], m1[u], a); b = fmaf(m2[u], tv[u], b); }
+            }
+            for (; i2 < d; ++i2) {
                 a = fmaf(eh[i2], Mr[(int64_t)i2 * d + j], a);   // (h^T M)_j
                 b = fmaf(Mr[(int64_t)j * d + i2], et[i2], b);   // (M t)_j
             }
