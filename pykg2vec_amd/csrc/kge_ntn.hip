@@ -407,10 +407,20 @@ int launch_ntn_backward(const kge_model_desc* m, const int64_t* h, const int64_t
 // ---- NTN.get_reg (pairwise.py:962-963): lmbda * sqrt(sum over ALL parameters of w^2), dense
 __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ p, int64_t numel, float* __restrict__ out) {
     __shared__ float part[4];
-    float a = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
-        a = fmaf(p[i], p[i], a);
-    a = wave_sum(a);
+    float a = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four independent chains over 16-byte loads
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)p) & 15) == 0) {
+        const int64_t nvec = numel / 4;
+        for (int64_t i = tid; i < nvec; i += stride) {
+            const float4 v = reinterpret_cast<const float4*>(p)[i];
+            a = fmaf(v.x, v.x, a); a1 = fmaf(v.y, v.y, a1); a2 = fmaf(v.z, v.z, a2); a3 = fmaf(v.w, v.w, a3);
+        }
+        for (int64_t i = nvec * 4 + tid; i < numel; i += stride) a = fmaf(p[i], p[i], a);
+    } else {
+        for (int64_t i = tid; i < numel; i += stride) a = fmaf(p[i], p[i], a);
+    }
+    a = wave_sum((a + a1) + (a2 + a3));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
     __syncthreads();
     if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
@@ -429,7 +439,7 @@ int launch_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbd
     if (e != hipSuccess) { set_error("kge_l2norm_reg: memset: %s", hipGetErrorString(e)); return -2; }
     int64_t b = (numel + 255) / 256;
     if (b > 2048) b = 2048;
-    const int64_t br = b > 128 ? 128 : b;  // one same-address atomic per block costs ~12 ns each: keep them few
+    const int64_t br = b > 256 ? 256 : b;  // one same-address atomic per block costs ~12 ns each: keep them few
     hipLaunchKernelGGL(k_sumsq, dim3((unsigned)br), dim3(256), 0, s, param, numel, scratch);
     hipLaunchKernelGGL(k_l2_apply, dim3((unsigned)b), dim3(256), 0, s, param, grad, numel, lmbda, scratch, loss);
     return check_launch("kge_l2norm_reg");
