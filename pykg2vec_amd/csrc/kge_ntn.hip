@@ -130,22 +130,37 @@ __global__ __launch_bounds__(256) void k_ntn_finish(const float* __restrict__ M1
     if (i >= n) return;
     const float* hn = w.Hn + i * d; const float* tn = w.Tn + i * d;
     float tot = 0.f;
-    for (int s = lane; s < kr; s += 64) {
-        float lin = b[s];
+    for (int sb = 0; sb < kr; sb += 128) {  // two slices per lane per pass: twice the loads in flight per round trip
+        const int s0 = sb + lane, s1 = sb + 64 + lane;
+        const bool v0 = s0 < kr, v1 = s1 < kr;
+        const int q0 = v0 ? s0 : kr - 1, q1 = v1 ? s1 : kr - 1;
+        float lin0 = b[q0], lin1 = b[q1];
         for (int c0 = 0; c0 < d; c0 += 8) {
-            float m1[8], m2[8];
+            float m1a[8], m2a[8], m1b[8], m2b[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = c0 + u < d ? c0 + u : d - 1;
-                m1[u] = M1[(int64_t)c * kr + s]; m2[u] = M2[(int64_t)c * kr + s];
+                m1a[u] = M1[(int64_t)c * kr + q0]; m2a[u] = M2[(int64_t)c * kr + q0];
+                m1b[u] = M1[(int64_t)c * kr + q1]; m2b[u] = M2[(int64_t)c * kr + q1];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (c0 + u < d) lin = fmaf(hn[c0 + u], m1[u], fmaf(tn[c0 + u], m2[u], lin));
+                if (c0 + u < d) {
+                    const float hv = hn[c0 + u], tv = tn[c0 + u];
+                    lin0 = fmaf(hv, m1a[u], fmaf(tv, m2a[u], lin0));
+                    lin1 = fmaf(hv, m1b[u], fmaf(tv, m2b[u], lin1));
+                }
         }
-        const float z = tanhf(w.Z[i * kr + s] + lin);
-        w.Z[i * kr + s] = z;
-        tot = fmaf(w.Rn[i * kr + s], z, tot);
+        if (v0) {
+            const float z = tanhf(w.Z[i * kr + s0] + lin0);
+            w.Z[i * kr + s0] = z;
+            tot = fmaf(w.Rn[i * kr + s0], z, tot);
+        }
+        if (v1) {
+            const float z = tanhf(w.Z[i * kr + s1] + lin1);
+            w.Z[i * kr + s1] = z;
+            tot = fmaf(w.Rn[i * kr + s1], z, tot);
+        }
     }
     tot = wave_sum(tot);
     if (lane == 0 && scores) scores[i] = -tot;
