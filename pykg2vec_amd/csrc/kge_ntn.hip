@@ -68,7 +68,8 @@ __device__ __forceinline__ void stage_tile(float* sX, const float* __restrict__ 
     }
 }
 
-// ---- 2. bil[n][s] = h^_n^T W_s t^_n : block = (tile of 32 triples, 4 slices), one slice per wave
+// ---- 2. bil[n][s] = h^_n^T W_s t^_n : block = (tile of 32 triples, one slice); the 32-wide column tiles of W_s are dealt
+// to the four waves (a wave's chain of dependent operand round trips is d/16 long instead of 4 d/16)
 __global__ __launch_bounds__(256) void k_ntn_bil(const float* __restrict__ W, int64_t n, int d, int kr, NtnWs w) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int S = (d + 1) | 1;
@@ -76,17 +77,17 @@ __global__ __launch_bounds__(256) void k_ntn_bil(const float* __restrict__ W, in
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lk = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * NT;
     const int cnt = (int)min((int64_t)NT, n - row0);
-    const int s = blockIdx.y * 4 + wave;
+    const int s = blockIdx.y;
     stage_tile(sH, w.Hn, row0, cnt, d, S);
     stage_tile(sT, w.Tn, row0, cnt, d, S);
-    if (threadIdx.x < 4 * NT) sB[threadIdx.x] = 0.f;
+    if (threadIdx.x < NT) sB[threadIdx.x] = 0.f;
     __syncthreads();
-    if (s < kr) {
+    {
         const float* Ws = W + (int64_t)s * d * d;
         float part[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) part[q] = 0.f;
-        for (int j0 = 0; j0 < d; j0 += 32) {
+        for (int j0 = wave * 32; j0 < d; j0 += 128) {
             const int j = j0 + li;
             f32x16 acc = {0};
             for (int k0 = 0; k0 < d; k0 += 16) {  // fixed-trip inner loop: 8 operand loads in flight per MFMA chain
@@ -111,14 +112,11 @@ __global__ __launch_bounds__(256) void k_ntn_bil(const float* __restrict__ W, in
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = (q & 3) + 8 * (q >> 2) + 4 * lk;
-            atomicAdd(&sB[wave * NT + row], part[q]);  // LDS atomic
+            atomicAdd(&sB[row], part[q]);  // LDS atomic: the four waves' column tiles add up
         }
     }
     __syncthreads();
-    if (threadIdx.x < 4 * NT) {
-        const int wv = threadIdx.x / NT, row = threadIdx.x - wv * NT, ss = blockIdx.y * 4 + wv;
-        if (row < cnt && ss < kr) w.Z[(row0 + row) * kr + ss] = sB[threadIdx.x];
-    }
+    if (threadIdx.x < cnt) w.Z[(row0 + threadIdx.x) * kr + s] = sB[threadIdx.x];
 }
 
 // ---- 3. z = tanh(bil + h^ M1 + t^ M2 + b) ; score = - r^ . z          (one wave per triple)
@@ -379,7 +377,7 @@ static int ntn_forward_core(const kge_model_desc* m, const int64_t* h, const int
     hipLaunchKernelGGL(k_ntn_prep, dim3(rows4), dim3(256), 0, s, m->tables[0], m->tables[1], h, r, t, n, d, kr, w);
     const int S = (d + 1) | 1;
     const size_t lds = (size_t)(2 * NT * S + 4 * NT) * sizeof(float);
-    hipLaunchKernelGGL(k_ntn_bil, dim3(tiles, (unsigned)((kr + 3) / 4)), dim3(256), lds, s, m->tables[5], n, d, kr, w);
+    hipLaunchKernelGGL(k_ntn_bil, dim3(tiles, (unsigned)kr), dim3(256), lds, s, m->tables[5], n, d, kr, w);
     hipLaunchKernelGGL(k_ntn_finish, dim3(rows4), dim3(256), 0, s, m->tables[2], m->tables[3], m->tables[4], n, d, kr, w,
                        scores);
     return check_launch("ntn forward");
