@@ -36,6 +36,10 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
                                  int64_t n_pos, int neg_rate, float alpha, const float* bern, const uint64_t* slots,
                                  int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor, float* loss,
                                  hipStream_t s);
+// kge_score_generic.hip: generic (roles-table) tail of the sampler-fused hinge step, after the shared-row specialisations
+struct FusedSampler;
+int launch_pairwise_hinge_sampled_generic(const kge_model_desc* m, Geometry geo, const FusedSampler& fs, int64_t n,
+                                          float margin, float* loss, hipStream_t s);
 // kge_score_ext.hip: the same generic kernels instantiated for TransM / CP / SimplE / SimplE_ignr / QuatE
 struct FusedSampler;
 int launch_score_forward_ext(const kge_model_desc* m, Geometry geo, const int64_t* h, const int64_t* r, const int64_t* t,

@@ -1,5 +1,6 @@
-// kge_score.hip -- gather-type scorers (TransE/TransH/TransD, RotatE, DistMult/ComplEx/ANALOGY):
-// forward, backward and the fused score+loss+backward training kernels.
+// kge_score.hip -- the shared-row, sampler-fused training kernels of the gather-type scorers (TransE / TransM,
+// TransH / TransD, RotatE); the model-generic forward / backward / fused steps are in kge_row_kernels.h, instantiated
+// in kge_score_generic.hip and kge_score_ext.hip.
 //
 // Reference sites replaced (paths relative to the reference tree):
 //   forward           pykg2vec/models/pairwise.py:56-76,166-174,270-278,786-791 ; pointwise.py:97-104,185-188,444-446
@@ -491,53 +492,12 @@ __global__ __launch_bounds__(kBlock) void k_selfadv_coeffs(float* __restrict__ p
     block_accumulate_loss<1>(acc, 0, loss);
 }
 
-#define KGE_DISPATCH(model_id, BODY)                            \
-    switch (model_id) {                                         \
-        KGE_FOR_MODEL(KGE_TRANSE, BODY)                         \
-        KGE_FOR_MODEL(KGE_TRANSH, BODY)                         \
-        KGE_FOR_MODEL(KGE_TRANSD, BODY)                         \
-        KGE_FOR_MODEL(KGE_ROTATE, BODY)                         \
-        KGE_FOR_MODEL(KGE_DISTMULT, BODY)                       \
-        KGE_FOR_MODEL(KGE_COMPLEX, BODY)                        \
-        KGE_FOR_MODEL(KGE_ANALOGY, BODY)                        \
-        default: break;                                         \
-    }
-
 static bool geometry_for(const kge_model_desc* m, Geometry* geo) {
     if (!pick_geometry(m->dim, geo)) {
         set_error("hidden size %d exceeds the register-resident row kernels (max 1024)", m->dim);
         return false;
     }
     return true;
-}
-
-int launch_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                         int64_t n, float* scores, hipStream_t s) {
-    Geometry geo;
-    if (!geometry_for(m, &geo)) return -1;
-    const DeviceModel dm = to_device_model(m);
-    KGE_DISPATCH(m->model, (k_score_fwd<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, n, scores)))
-    return launch_score_forward_ext(m, geo, h, r, t, n, scores, s);
-}
-
-int launch_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                          int64_t n, const float* dscore, hipStream_t s) {
-    Geometry geo;
-    if (!geometry_for(m, &geo)) return -1;
-    const DeviceModel dm = to_device_model(m);
-    KGE_DISPATCH(m->model, (k_score_bwd<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, n, dscore)))
-    return launch_score_backward_ext(m, geo, h, r, t, n, dscore, s);
-}
-
-int launch_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
-                          const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float margin,
-                          float* loss, hipStream_t s) {
-    Geometry geo;
-    if (!geometry_for(m, &geo)) return -1;
-    const DeviceModel dm = to_device_model(m);
-    const FusedSampler fs{};
-    KGE_DISPATCH(m->model, (k_pairwise_hinge<M, G, NCH, false><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, ph, pr, pt, nh, nr, nt, n, margin, loss, fs)))
-    return launch_pairwise_hinge_ext(m, geo, ph, pr, pt, nh, nr, nt, n, margin, loss, &fs, false, s);
 }
 
 int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
@@ -576,43 +536,7 @@ int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triple
 #undef KGE_TX_ALL
 #undef KGE_TX
     }
-    const int64_t* z = nullptr;
-    KGE_DISPATCH(m->model, (k_pairwise_hinge<M, G, NCH, true><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, z, z, z, z, z, z, n, margin, loss, fs)))
-    return launch_pairwise_hinge_ext(m, geo, z, z, z, z, z, z, n, margin, loss, &fs, true, s);
-}
-
-int launch_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                              const int64_t* y, int64_t n, int bundle, float lmbda, int reg_type, float* loss, hipStream_t s) {
-    Geometry geo;
-    if (!geometry_for(m, &geo)) return -1;
-    const DeviceModel dm = to_device_model(m);
-    if (bundle > 1) {
-        const int chb = chunk_bundles((n + bundle - 1) / bundle);
-        const int64_t nb = ((n + bundle - 1) / bundle + chb - 1) / chb;
-        // few relations: relation-row gradients accumulate in LDS (one flush per workgroup), every bundle its own group
-        const size_t rel_lds = (size_t)m->tot_relation * (size_t)rel_span_host(m->model, m->dim) * sizeof(float);
-        if (rel_lds <= 32 * 1024) {  // larger tables cost more in LDS atomics and occupancy than they save
-            const int64_t nbl = (n + bundle - 1) / bundle;
-            KGE_DISPATCH(m->model, (k_pointwise_bundle<M, G, NCH, true><<<dim3(Launch<M, G, NCH>::grid(nbl)), dim3(kBlock), rel_lds, s>>>(dm, h, r, t, y, n, bundle, 1, lmbda, reg_type, loss, m->tot_relation)))
-        }
-        KGE_DISPATCH(m->model, (k_pointwise_bundle<M, G, NCH, false><<<dim3(Launch<M, G, NCH>::grid(nb)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, bundle, chb, lmbda, reg_type, loss, m->tot_relation)))
-        return launch_pointwise_logistic_ext(m, geo, h, r, t, y, n, bundle, lmbda, reg_type, loss, s);
-    }
-    KGE_DISPATCH(m->model, (k_pointwise_logistic<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, lmbda, reg_type, loss)))
-    return launch_pointwise_logistic_ext(m, geo, h, r, t, y, n, bundle, lmbda, reg_type, loss, s);
-}
-
-int launch_selfadv_bundle(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
-                          const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n_pos, int neg_rate,
-                          float alpha, float* loss, hipStream_t s) {
-    Geometry geo;
-    if (!geometry_for(m, &geo)) return -1;
-    if (neg_rate > geo.G) return 1;  // caller falls back to the three-launch path
-    const DeviceModel dm = to_device_model(m);
-    const int64_t n = n_pos;
-    KGE_DISPATCH(m->model, (k_selfadv_bundle<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, ph, pr, pt, nh, nr, nt, n_pos, neg_rate, alpha, loss)))
-    set_error("kge_train_pairwise_selfadv: unsupported model %d", m->model);
-    return -1;
+    return launch_pairwise_hinge_sampled_generic(m, geo, fs, n, margin, loss, s);
 }
 
 int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
