@@ -137,8 +137,19 @@ int kge_train_pairwise_selfadv_sampled(const kge_model_desc* m, const int64_t* t
  * (utils/criterion.py:31-34) mean(softplus(y*s)) + lmbda*get_reg (pointwise.py:106-119,190-202,224-238,448-458). */
 int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r,
                                  const int64_t* t, const int64_t* y, int64_t n,
-                                 int32_t bundle /* rows per sampler bundle = 1+neg_rate (data/generator.py:125-156); <=1: none */,
+                                 int32_t bundle /* rows per sampler bundle = 1+neg_rate (data/generator.py:125-156);
+ <=1: none */,
                                  float lmbda, int32_t reg_type, float* loss, void* stream);
+
+/* The same step with the negative sampler FUSED IN FRONT (data/generator.py:99-158 + utils/trainer.py:176-180 +
+ * utils/criterion.py:31-34 in one kernel): bundle i = triples[perm[start+i]] with y=+1 followed by its neg_rate
+ * corruptions with y=-1, drawn with the Philox counters kge_sample_batch(layout 1) uses -- both paths see identical
+ * rows.  neg_rate must not exceed the lane group of the model's row length (32, or 64 above 256 floats). */
+int kge_train_pointwise_logistic_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm,
+                                         int64_t start, int64_t n_pos, int32_t neg_rate, const float* bern_prob,
+                                         const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset,
+                                         const int64_t* dev_cursor, float lmbda, int32_t reg_type, float* loss,
+                                         void* stream);
 
 /* Dense optimiser sweep with torch.optim defaults (utils/trainer.py:112-131): SGD, Adam(0.9,0.999,1e-8),
  * Adagrad(eps 1e-10), RMSprop(alpha .99, eps 1e-8).  state1/state2: exp_avg/exp_avg_sq (Adam),

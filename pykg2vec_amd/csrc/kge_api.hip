@@ -230,7 +230,21 @@ int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, cons
     if (n < 0 || !h || !r || !t || !y || !loss) { set_error("kge_train_pointwise_logistic: bad arguments"); return -1; }
     if (reg_type < KGE_REG_NONE || reg_type > KGE_REG_ID_N3) { set_error("kge_train_pointwise_logistic: bad reg_type %d", reg_type); return -1; }
     if (!is_vector_model(m->model)) { set_error("kge_train_pointwise_logistic: unsupported model %d", m->model); return -1; }
-    return launch_pointwise_logistic(m, h, r, t, y, n, bundle, lmbda, reg_type, loss, (hipStream_t)stream);
+    return launch_pointwise_logistic(m, h, r, t, y, n, bundle, lmbda, reg_type, loss, nullptr, (hipStream_t)stream);
+}
+
+int kge_train_pointwise_logistic_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
+                                         int64_t n_pos, int32_t neg_rate, const float* bern_prob, const uint64_t* slots,
+                                         int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor,
+                                         float lmbda, int32_t reg_type, float* loss, void* stream) {
+    if (validate(m, true, "kge_train_pointwise_logistic_sampled")) return -1;
+    if (n_pos == 0) return 0;
+    if (n_pos < 0 || neg_rate < 1 || start < 0 || !triples || !perm || !loss) { set_error("kge_train_pointwise_logistic_sampled: bad arguments"); return -1; }
+    if (slots && (n_slots & (n_slots - 1))) { set_error("kge_train_pointwise_logistic_sampled: n_slots must be a power of two"); return -1; }
+    if (reg_type < KGE_REG_NONE || reg_type > KGE_REG_ID_N3) { set_error("kge_train_pointwise_logistic_sampled: bad reg_type %d", reg_type); return -1; }
+    if (!is_vector_model(m->model)) { set_error("kge_train_pointwise_logistic_sampled: unsupported model %d", m->model); return -1; }
+    return launch_pointwise_logistic_sampled(m, triples, perm, start, n_pos, neg_rate, bern_prob, slots, n_slots, seed, offset,
+                                             dev_cursor, lmbda, reg_type, loss, (hipStream_t)stream);
 }
 
 int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,

@@ -27,8 +27,14 @@ int launch_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const int6
 int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
                                   int64_t n, const float* bern, const uint64_t* slots, int64_t n_slots, uint64_t seed,
                                   uint64_t offset, const int64_t* cursor, float margin, float* loss, hipStream_t s);
+struct FusedSampler;
 int launch_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
-                              const int64_t* y, int64_t n, int bundle, float lmbda, int reg_type, float* loss, hipStream_t s);
+                              const int64_t* y, int64_t n, int bundle, float lmbda, int reg_type, float* loss,
+                              const FusedSampler* sampler /* NULL: explicit rows */, hipStream_t s);
+int launch_pointwise_logistic_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
+                                      int64_t n_pos, int neg_rate, const float* bern, const uint64_t* slots, int64_t n_slots,
+                                      uint64_t seed, uint64_t offset, const int64_t* cursor, float lmbda, int reg_type,
+                                      float* loss, hipStream_t s);
 int launch_selfadv_bundle(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
                           const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n_pos, int neg_rate,
                           float alpha, float* loss, hipStream_t s);  // returns 1 when neg_rate exceeds the group width
@@ -51,7 +57,7 @@ int launch_pairwise_hinge_ext(const kge_model_desc* m, Geometry geo, const int64
                               float* loss, const FusedSampler* fs, bool sampled, hipStream_t s);
 int launch_pointwise_logistic_ext(const kge_model_desc* m, Geometry geo, const int64_t* h, const int64_t* r, const int64_t* t,
                                   const int64_t* y, int64_t n, int bundle, float lmbda, int reg_type, float* loss,
-                                  hipStream_t s);
+                                  const FusedSampler* sampler, hipStream_t s);
 int launch_selfadv_coeffs(float* pos_scores, float* neg_scores, int64_t n_pos, int neg_rate, float alpha,
                           float* loss, hipStream_t s);
 

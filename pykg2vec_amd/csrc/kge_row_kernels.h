@@ -227,10 +227,17 @@ __global__ __launch_bounds__(kBlock) void k_pointwise_bundle(DeviceModel m, cons
                                                              const int64_t* __restrict__ r, const int64_t* __restrict__ t,
                                                              const int64_t* __restrict__ y, int64_t n, int bundle, int CHB,
                                                              float lmbda, int reg_type, float* __restrict__ loss,
-                                                             int64_t tot_relation) {
+                                                             int64_t tot_relation, FusedSampler fs) {
     constexpr int GPB = kBlock / G;
     constexpr int NR = role_count(M);
     const int gl = threadIdx.x % G;
+    // fs.triples != NULL: the sampler is fused in front (kge_train_pointwise_logistic_sampled): bundle b is the positive
+    // triples[perm[start + b]] (y = +1) followed by bundle-1 corruptions (y = -1), negative j drawn by lane j of the group
+    // with the Philox counter kge_sample_batch uses for it, so both paths see identical rows
+    const bool sampled = fs.triples != nullptr;
+    const int64_t s_start = (sampled && fs.cursor) ? fs.start + fs.cursor[0] : fs.start;
+    const unsigned long long s_off = (sampled && fs.cursor) ? fs.offset + (unsigned long long)fs.cursor[1] : fs.offset;
+    const int gbase = (threadIdx.x & 63) / G * G;
     extern __shared__ float s_rel[];  // LDSREL: [tot_relation][rel_span]
     const int span = LDSREL ? rel_span<M>(m.dim) : 0;
     if constexpr (LDSREL) {
@@ -254,7 +261,20 @@ __global__ __launch_bounds__(kBlock) void k_pointwise_bundle(DeviceModel m, cons
         const int64_t b1 = min(nb, (ck + 1) * CHB);
         for (int64_t b = ck * CHB; b < b1; ++b) {
             const int64_t i0 = b * bundle;
-            const int64_t idb[3] = {h[i0], r[i0], t[i0]};
+            int64_t idb[3];
+            int my_nh = 0, my_nt = 0;
+            if (sampled) {
+                const int64_t row = fs.perm[s_start + b];
+                idb[0] = fs.triples[3 * row]; idb[1] = fs.triples[3 * row + 1]; idb[2] = fs.triples[3 * row + 2];
+                if (gl < bundle - 1) {
+                    int64_t nh, nt;
+                    corrupt_one(idb[0], idb[1], idb[2], fs.E, fs.bern, fs.slots, fs.mask, fs.seed,
+                                s_off + (unsigned long long)(b * (bundle - 1) + gl), nh, nt);
+                    my_nh = (int)nh; my_nt = (int)nt;
+                }
+            } else {
+                idb[0] = h[i0]; idb[1] = r[i0]; idb[2] = t[i0];
+            }
             const bool same_rel = idb[1] == ida[1];  // group-uniform
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
@@ -267,8 +287,18 @@ __global__ __launch_bounds__(kBlock) void k_pointwise_bundle(DeviceModel m, cons
             ida[0] = idb[0]; ida[1] = idb[1]; ida[2] = idb[2];
             const int64_t i1 = min(n, i0 + bundle);
             for (int64_t i = i0; i < i1; ++i) {
-                const int64_t id[3] = {h[i], r[i], t[i]};
-                const float yy = (float)y[i];
+                int64_t id[3];
+                float yy;
+                if (sampled) {
+                    const int k = (int)(i - i0);
+                    const int src = gbase + (k > 0 ? k - 1 : 0);
+                    const int64_t nh = __shfl(my_nh, src, 64), nt = __shfl(my_nt, src, 64);
+                    id[0] = k == 0 ? idb[0] : nh; id[1] = idb[1]; id[2] = k == 0 ? idb[2] : nt;
+                    yy = k == 0 ? 1.f : -1.f;
+                } else {
+                    id[0] = h[i]; id[1] = r[i]; id[2] = t[i];
+                    yy = (float)y[i];
+                }
                 Rows<M, NCH> R, Gr;
                 Saved<M, NCH> sv;
                 load_rows<M, G, NCH>(R, m, id, gl);

@@ -62,8 +62,9 @@ int launch_pairwise_hinge_ext(const kge_model_desc* m, Geometry geo, const int64
 
 int launch_pointwise_logistic_ext(const kge_model_desc* m, Geometry geo, const int64_t* h, const int64_t* r, const int64_t* t,
                                   const int64_t* y, int64_t n, int bundle, float lmbda, int reg_type, float* loss,
-                                  hipStream_t s) {
+                                  const FusedSampler* fsp, hipStream_t s) {
     const DeviceModel dm = to_device_model(m);
+    const FusedSampler fs = fsp ? *fsp : FusedSampler{};
     if (bundle > 1) {
         const int chb = chunk_bundles((n + bundle - 1) / bundle);
         const int64_t nb = ((n + bundle - 1) / bundle + chb - 1) / chb;
@@ -71,9 +72,9 @@ int launch_pointwise_logistic_ext(const kge_model_desc* m, Geometry geo, const i
         const size_t rel_lds = (size_t)m->tot_relation * (size_t)rel_span_host(m->model, m->dim) * sizeof(float);
         if (rel_lds <= 32 * 1024) {  // larger tables cost more in LDS atomics and occupancy than they save
             const int64_t nbl = (n + bundle - 1) / bundle;
-            KGE_DISPATCH_POINTWISE(m->model, (k_pointwise_bundle<M, G, NCH, true><<<dim3(Launch<M, G, NCH>::grid(nbl)), dim3(kBlock), rel_lds, s>>>(dm, h, r, t, y, n, bundle, 1, lmbda, reg_type, loss, m->tot_relation)))
+            KGE_DISPATCH_POINTWISE(m->model, (k_pointwise_bundle<M, G, NCH, true><<<dim3(Launch<M, G, NCH>::grid(nbl)), dim3(kBlock), rel_lds, s>>>(dm, h, r, t, y, n, bundle, 1, lmbda, reg_type, loss, m->tot_relation, fs)))
         }
-        KGE_DISPATCH_POINTWISE(m->model, (k_pointwise_bundle<M, G, NCH, false><<<dim3(Launch<M, G, NCH>::grid(nb)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, bundle, chb, lmbda, reg_type, loss, m->tot_relation)))
+        KGE_DISPATCH_POINTWISE(m->model, (k_pointwise_bundle<M, G, NCH, false><<<dim3(Launch<M, G, NCH>::grid(nb)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, bundle, chb, lmbda, reg_type, loss, m->tot_relation, fs)))
     } else {
         KGE_DISPATCH_POINTWISE(m->model, (k_pointwise_logistic<M, G, NCH><<<dim3(Launch<M, G, NCH>::grid(n)), dim3(kBlock), 0, s>>>(dm, h, r, t, y, n, lmbda, reg_type, loss)))
     }

@@ -133,6 +133,21 @@ def train_pairwise_hinge_sampled(desc, triples, perm, start, n, bern_prob, slots
             "kge_train_pairwise_hinge_sampled")
 
 
+def train_pointwise_logistic_sampled(desc, triples, perm, start, n_pos, neg_rate, bern_prob, slots, seed, offset, lmbda,
+                                     reg_type, loss_buf, cursor=None):
+    """Sampler + scoring + pointwise logistic loss + regulariser + backward in ONE launch; the rows equal
+    sample_batch(start, n_pos, neg_rate, pointwise=True)."""
+    bp = _dev(bern_prob, torch.float32, "bern_prob") if bern_prob is not None else None
+    sp = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
+    pc = _dev(cursor, torch.int64, "cursor") if cursor is not None else None
+    L.check(L.load().kge_train_pointwise_logistic_sampled(ctypes.byref(desc), _ids(triples, "triples"), _ids(perm, "perm"),
+                                                          int(start), int(n_pos), int(neg_rate), bp, sp,
+                                                          slots.numel() if slots is not None else 0,
+                                                          int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), pc,
+                                                          float(lmbda), int(reg_type), _dev(loss_buf, torch.float32, "loss"),
+                                                          _stream()), "kge_train_pointwise_logistic_sampled")
+
+
 def train_pairwise_selfadv_sampled(desc, triples, perm, start, n_pos, neg_rate, alpha, bern_prob, slots, seed, offset,
                                    loss_buf, cursor=None):
     """RotatE: sampler + scores + self-adversarial loss + backward in ONE launch (batch == sample_batch(...))."""

@@ -143,6 +143,14 @@ class Trainer:
                 and self.model.kernel_name not in ("rescal", "ntn", "transr") and self.model.model_name.lower() != "rotate"
                 and int(self.config.neg_rate) == 1)
 
+    def _fused_pointwise_ok(self):
+        """Sampler + scoring + logistic loss + backward in one kernel for the pointwise models (a bundle's negatives
+        must fit one lane group)."""
+        if not (self.K is K and self.model.training_strategy == TrainingStrategy.POINTWISE_BASED):
+            return False
+        group = 32 if self.model.hidden_size <= 256 else 64
+        return 1 <= int(self.config.neg_rate) <= group
+
     def _fused_rotate_ok(self):
         """RotatE self-adversarial step with the sampler fused in (negatives of a positive must fit one lane group)."""
         if not (self.K is K and self.model.model_name.lower() == "rotate" and self.model.kernel_name == "rotate"):
@@ -157,6 +165,12 @@ class Trainer:
             start, n, offset = fixed_range if fixed_range is not None else gen._next_range()
             K.train_pairwise_selfadv_sampled(self._desc, gen.triples, gen.perm, start, n, gen.neg_rate, self.config.alpha,
                                              gen.bern, gen.slots, gen.seed, offset, self.loss_buf, cursor=cursor)
+            return
+        if self._fused_pointwise_ok():
+            start, n, offset = fixed_range if fixed_range is not None else gen._next_range()
+            K.train_pointwise_logistic_sampled(self._desc, gen.triples, gen.perm, start, n, gen.neg_rate, gen.bern, gen.slots,
+                                               gen.seed, offset, self.model.kernel_lmbda(), self.model.kernel_reg_type(),
+                                               self.loss_buf, cursor=cursor)
             return
         if self._fused_sampler_ok():
             start, n, offset = fixed_range if fixed_range is not None else gen._next_range()

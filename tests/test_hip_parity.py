@@ -513,3 +513,31 @@ def test_head_1n_vs_oracle_other_shapes(hip, B, E, d, with_bias):
     assert np.isclose(K.read_loss(loss_buf).item(), loss_ref, rtol=2e-5)
     assert np.allclose(dx2.cpu().numpy(), dx_ref, atol=1e-3 * scale, rtol=1e-3)
     assert np.allclose(g_ent.cpu().numpy(), ge_ref, atol=1e-3 * scale, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name,neg", [("distmult", 1), ("complex", 3), ("analogy", 1), ("cp", 2), ("simple", 1), ("quate", 4)])
+def test_fused_pointwise_sampler_step_equals_sample_then_step(hip, name, neg):
+    """kge_train_pointwise_logistic_sampled (corruption fused into the pointwise kernel) must see exactly the rows
+    kge_sample_batch(layout pointwise) emits for the same (start, n, neg_rate, seed, offset): same loss, same gradients."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.trainer import Trainer
+    c = Case(name)
+    cfg = hip.make_config(c.E, c.R, dict(c.hp, neg_rate=neg), c.train, c.valid, c.test, batch_size=64)
+    res = []
+    for fused in (False, True):
+        m = hip.model_from_case(c)
+        tr = Trainer(m, cfg)
+        tr.build_model()
+        gen = tr._new_generator()
+        tr.generator = gen
+        tr.loss_buf.zero_()
+        if fused:
+            K.train_pointwise_logistic_sampled(tr._desc, gen.triples, gen.perm, 128, 64, neg, None, gen.slots, 11, 999,
+                                               m.kernel_lmbda(), m.kernel_reg_type(), tr.loss_buf)
+        else:
+            b = K.sample_batch(gen.triples, gen.perm, 128, 64, neg, c.E, None, gen.slots, 11, 999, pointwise=True)
+            K.train_pointwise_logistic(tr._desc, *b, m.kernel_lmbda(), m.kernel_reg_type(), tr.loss_buf, bundle=1 + neg)
+        res.append((K.read_loss(tr.loss_buf).item(), [g.cpu().numpy().copy() for g in tr.flat.grad_views]))
+    assert np.isclose(res[0][0], res[1][0], rtol=1e-5)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.allclose(a, b, atol=1e-6, rtol=1e-4)
