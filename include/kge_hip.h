@@ -182,7 +182,10 @@ int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n,
                    const int64_t* head_off, const int32_t* head_ids,
                    void* workspace, size_t workspace_bytes, int32_t* ranks, void* stream);
 
-/* TransR, several relations per call.  `triples` are sorted by relation; group g = the run of triples with relation
+/* Models whose candidate-side transform depends on the relation (TransR: projection by M_r; TransH: hyperplane of w_r;
+ * TransD: mapping r_m), several relations per call: one transformed + normalised candidate table per relation group,
+ * then the plain L1 / L2 sweep.  For TransH / TransD this is an alternative to kge_eval_ranks (which transforms inside
+ * the sweep, per query) that pays off once a relation has a few test triples.  `triples` are sorted by relation; group g = the run of triples with relation
  * group_rel[g] (device int64 [n_groups]); group_of_triple (device int32 [n]) names each triple's group; qblocks
  * (device int32 [n_qblocks,4]) = {group, first query, query count <= 16, 0} partitions every group's query range
  * [2a, 2b) (query 2i = tail sweep of triple i, 2i+1 = head sweep) into sweep workgroups.  One candidate table per group

@@ -314,7 +314,7 @@ int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, c
 
 size_t kge_eval_grouped_workspace_bytes(const kge_model_desc* m, int64_t n, int64_t n_groups) {
     if (validate(m, false, "kge_eval_grouped_workspace_bytes") || n < 0 || n_groups < 1) return 0;
-    return eval_workspace_bytes(m, n, n_groups);
+    return eval_workspace_bytes(m, n, n_groups == 1 ? 2 : n_groups);
 }
 
 int kge_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,

@@ -63,9 +63,10 @@ static int sweep_K(const kge_model_desc* m) {
 
 static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p, int64_t tables = 1) {
     p->E = m->tot_entity; p->n = n; p->tables = tables;
+    const bool per_group_tables = tables > 1 || m->model == KGE_TRANSR;  // candidates already transformed per relation group
     p->K = sweep_K(m);
     p->Kpad = (p->K + KC - 1) / KC * KC;
-    p->xform = m->model == KGE_TRANSH ? X_TRANSH : m->model == KGE_TRANSD ? X_TRANSD : X_NONE;
+    p->xform = per_group_tables ? X_NONE : m->model == KGE_TRANSH ? X_TRANSH : m->model == KGE_TRANSD ? X_TRANSD : X_NONE;
     p->QV = p->xform == X_NONE ? 1 : 2;
     switch (m->model) {
         case KGE_TRANSE: case KGE_TRANSH: case KGE_TRANSD: case KGE_TRANSM: case KGE_TRANSR:
@@ -163,6 +164,115 @@ __global__ __launch_bounds__(256) void k_eval_prepare(PrepArgs a, float* __restr
     }
 }
 
+// ---- per-relation candidate tables for TransH / TransD (grouped evaluation): the candidate-side transform depends on the
+// query only through its relation (hyperplane normal w_r / mapping r_m), so for a group of queries sharing r it is applied
+// ONCE per candidate -- project, normalise, write the sweep layout -- and the queries then run the plain L1 / L2 sweep
+// (1.5 VALU issues per element pair instead of ~7 with the in-sweep transform).  grid: (tiles, groups).
+struct XfPrepArgs {
+    const float* ent; const float* vec_tab; const float* ent_map; const int64_t* group_rel;
+    int xform; int64_t E; int K, Kpad; int64_t table_stride;
+};
+
+__global__ __launch_bounds__(256) void k_eval_prepare_xf(XfPrepArgs a, float* __restrict__ cand) {
+    __shared__ float s_p[64], s_scale[64];
+    __shared__ float s_tile[64][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x, e0 = tile * 64;
+    const float* vec = a.vec_tab + a.group_rel[blockIdx.y] * (int64_t)a.K;
+    cand += blockIdx.y * a.table_stride;
+    float iw = 1.f;
+    if (a.xform == X_TRANSH) {  // w^ = w / max(|w|, eps)   (pairwise.py:176-180)
+        float nw = 0.f;
+        for (int k = lane; k < a.K; k += 64) nw = fmaf(vec[k], vec[k], nw);
+        iw = 1.0f / fmaxf(sqrtf(wave_sum(nw)), kEpsNormalize);
+    }
+    if (a.K <= 256) {
+        // rows of up to 256 floats: the wave's 16 rows live in registers (4 floats per lane each) from the gather to the
+        // transposed store -- one read of the entity table per relation group
+        float vh[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int k = lane + 64 * c; vh[c] = k < a.K ? vec[k] * iw : 0.f; }
+        float v[16][4];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t e = e0 + wave * 16 + j;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int k = lane + 64 * c; v[j][c] = (e < a.E && k < a.K) ? a.ent[e * a.K + k] : 0.f; }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t e = e0 + wave * 16 + j;
+            float dt = 0.f;
+            if (a.xform == X_TRANSH) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dt = fmaf(v[j][c], vh[c], dt);
+                dt = -wave_sum(dt);                                  // e - (e . w^) w^
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const int k = lane + 64 * c; dt = fmaf(v[j][c], (e < a.E && k < a.K) ? a.ent_map[e * a.K + k] : 0.f, dt); }
+                dt = wave_sum(dt);                                   // e + (e . e_m) r_m   (pairwise.py:229-251)
+            }
+            float n2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[j][c] = fmaf(dt, vh[c], v[j][c]); n2 = fmaf(v[j][c], v[j][c], n2); }
+            const float sc = 1.0f / fmaxf(sqrtf(wave_sum(n2)), kEpsNormalize);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[j][c] *= sc;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k0 = 64 * c;
+            if (k0 >= a.Kpad) break;  // block-uniform
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s_tile[wave * 16 + j][lane] = v[j][c];
+            __syncthreads();
+            for (int j = 0; j < 16; ++j) {
+                const int kk = wave * 16 + j;
+                if (k0 + kk < a.Kpad) cand[(tile * a.Kpad + k0 + kk) * 64 + lane] = s_tile[lane][kk];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    for (int j = 0; j < 16; ++j) {  // long rows: statistics first (projection coefficient, norm of the transformed row) ...
+        const int row = wave * 16 + j;
+        const int64_t e = e0 + row;
+        float p = 0.f, n2 = 0.f;
+        if (e < a.E) {
+            const float* er = a.ent + e * a.K;
+            float dt = 0.f;
+            if (a.xform == X_TRANSH) {
+                for (int k = lane; k < a.K; k += 64) dt = fmaf(er[k], vec[k] * iw, dt);
+                p = -wave_sum(dt);
+            } else {
+                const float* em = a.ent_map + e * a.K;
+                for (int k = lane; k < a.K; k += 64) dt = fmaf(er[k], em[k], dt);
+                p = wave_sum(dt);
+            }
+            for (int k = lane; k < a.K; k += 64) { const float v = fmaf(p, vec[k] * iw, er[k]); n2 = fmaf(v, v, n2); }
+            n2 = wave_sum(n2);
+        }
+        if (lane == 0) { s_p[row] = p; s_scale[row] = 1.0f / fmaxf(sqrtf(n2), kEpsNormalize); }
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < a.Kpad; k0 += 64) {  // ... then transpose 64x64 through LDS: coalesced reads AND writes
+        for (int j = 0; j < 16; ++j) {
+            const int row = wave * 16 + j;
+            const int64_t e = e0 + row;
+            const int k = k0 + lane;
+            float v = 0.f;
+            if (e < a.E && k < a.K) v = fmaf(s_p[row], vec[k] * iw, a.ent[e * a.K + k]) * s_scale[row];
+            s_tile[row][lane] = v;
+        }
+        __syncthreads();
+        for (int j = 0; j < 16; ++j) {
+            const int kk = wave * 16 + j;
+            if (k0 + kk < a.Kpad) cand[(tile * a.Kpad + k0 + kk) * 64 + lane] = s_tile[lane][kk];
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ 2. query vectors
 // one wave per test triple; writes qvec[(2i+side)*QV*Kpad ...], side 0 = tail sweep (h,r,?), 1 = head sweep (?,r,t)
 template <int M>
@@ -223,8 +333,10 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
         for (int k = lane; k < d; k += 64) {
             qt[k] = proj_h(k) * ia + er[k] * ib;   // score = || q - c^ ||
             qh[k] = proj_t(k) * ic - er[k] * ib;   // score = || c^ + r^ - t^ || = || c^ - q ||
-            if constexpr (M == KGE_TRANSH) { qt[Kpad + k] = w[k] * iw; qh[Kpad + k] = w[k] * iw; }
-            if constexpr (M == KGE_TRANSD) { qt[Kpad + k] = rm[k]; qh[Kpad + k] = rm[k]; }
+            if (QV == 2) {  // the in-sweep candidate transform needs the relation-side vector next to the query
+                if constexpr (M == KGE_TRANSH) { qt[Kpad + k] = w[k] * iw; qh[Kpad + k] = w[k] * iw; }
+                if constexpr (M == KGE_TRANSD) { qt[Kpad + k] = rm[k]; qh[Kpad + k] = rm[k]; }
+            }
         }
     } else if constexpr (M == KGE_DISTMULT) {
         const float* eh = m.tab[0] + h * d; const float* er = m.tab[1] + r * d; const float* et = m.tab[0] + t * d;
@@ -834,15 +946,35 @@ int launch_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, i
                               const int64_t* group_rel, int64_t n_groups, const int32_t* qblocks, int64_t n_qblocks,
                               const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
                               const int32_t* head_ids, void* ws, size_t ws_bytes, int32_t* ranks, hipStream_t s) {
-    if (m->model != KGE_TRANSR) { set_error("kge_eval_ranks_grouped: TransR only (other models need no grouping)"); return -1; }
+    if (m->model != KGE_TRANSR && m->model != KGE_TRANSH && m->model != KGE_TRANSD) {
+        set_error("kge_eval_ranks_grouped: TransR / TransH / TransD only (the other models' candidates do not depend on the relation)");
+        return -1;
+    }
+    if (n_groups < 1 || n_groups > 65535) { set_error("kge_eval_ranks_grouped: %lld relation groups per call (1..65535)", (long long)n_groups); return -1; }
     EvalPlan p;
-    if (!make_plan(m, n, ws, &p, n_groups)) { set_error("kge_eval: model %d has no sweep form", m->model); return -1; }
+    // tables = n_groups + (n_groups == 1): a single group must still plan per-group (already transformed) candidates
+    if (!make_plan(m, n, ws, &p, n_groups == 1 ? 2 : n_groups)) { set_error("kge_eval: model %d has no sweep form", m->model); return -1; }
     if (ws == nullptr || ws_bytes < p.bytes) {
         set_error("kge_eval_ranks_grouped: workspace too small (%zu < %zu)", ws_bytes, p.bytes);
         return -1;
     }
-    int rc = launch_transr_eval_prepare(m, triples, n, group_rel, n_groups, p.Kpad, p.ntiles, p.cand, p.qvec, p.qscale, s);
-    if (rc) return rc;
+    if (m->model == KGE_TRANSR) {
+        int rc = launch_transr_eval_prepare(m, triples, n, group_rel, n_groups, p.Kpad, p.ntiles, p.cand, p.qvec, p.qscale, s);
+        if (rc) return rc;
+    } else {
+        XfPrepArgs xa;
+        xa.ent = m->tables[0]; xa.group_rel = group_rel; xa.E = p.E; xa.K = p.K; xa.Kpad = p.Kpad; xa.table_stride = p.table_stride;
+        xa.xform = m->model == KGE_TRANSH ? X_TRANSH : X_TRANSD;
+        xa.vec_tab = m->model == KGE_TRANSH ? m->tables[2] : m->tables[3];   // w  /  rel_mappings
+        xa.ent_map = m->model == KGE_TRANSD ? m->tables[2] : nullptr;       // ent_mappings
+        hipLaunchKernelGGL(k_eval_prepare_xf, dim3((unsigned)p.ntiles, (unsigned)n_groups), dim3(256), 0, s, xa, p.cand);
+        const DeviceModel dm = to_device_model(m);
+        const unsigned qb = (unsigned)((n + 3) / 4);
+        if (m->model == KGE_TRANSH)
+            hipLaunchKernelGGL((k_eval_queries<KGE_TRANSH>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale);
+        else
+            hipLaunchKernelGGL((k_eval_queries<KGE_TRANSD>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale);
+    }
     (void)hipMemsetAsync(p.rcount, 0, (size_t)2 * n * sizeof(int32_t), s);
     if (p.form == F_L1)
         launch_tf_and_sweep<F_L1, X_NONE>(p, m, triples, tail_off, tail_ids, head_off, head_ids, nullptr, s, group_of_triple,

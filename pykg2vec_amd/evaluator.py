@@ -199,9 +199,22 @@ class Evaluator:
         _log("Full-Testing on [%d/%d] Triples in the test set." % (n, len(self.test_data)))
         return self.test(self.test_data, n, epoch=epoch)
 
-    def _by_relation(self):
-        """TransR sweeps a candidate table projected by ONE relation matrix per kge_eval_ranks call."""
-        return getattr(self.model, "kernel_name", None) == "transr"
+    GROUPED_MIN_TRIPLES_PER_RELATION = 8  # measured crossover (Zipf-distributed test relations, FB15k shape): 8 beats 4 at 2k..32k triples
+
+    def _dense_relations(self, trip):
+        """Which test triples go through the per-relation candidate tables (kge_eval_ranks_grouped)?  TransR: all of them
+        (its candidates only exist in a relation's space).  TransH / TransD: the triples of relations that have at least
+        GROUPED_MIN_TRIPLES_PER_RELATION test triples -- there one transform of the candidate table per relation plus the
+        plain sweep beats transforming every candidate for every query inside the sweep; rare relations keep the
+        in-sweep transform.  Returns a bool mask over `trip`, or None when nothing is grouped."""
+        name = getattr(self.model, "kernel_name", None)
+        if name == "transr":
+            return np.ones(len(trip), bool)
+        if name in ("transh", "transd") and self.K is K and len(trip):
+            counts = np.bincount(trip[:, 1], minlength=int(self.config.tot_relation))
+            dense = counts[trip[:, 1]] >= self.GROUPED_MIN_TRIPLES_PER_RELATION
+            return dense if dense.any() else None
+        return None
 
     TABLE_BUDGET_BYTES = 1 << 30  # projected candidate tables held at once by a grouped TransR evaluation call
 
@@ -209,7 +222,7 @@ class Evaluator:
         """Split the relation groups (runs of `trip`, boundaries `cuts`) into chunks whose candidate tables fit the
         budget; per chunk the device arrays kge_eval_ranks_grouped takes."""
         dev = next(self.model.parameters()).device
-        dr = int(self.model.rel_hidden_size)
+        dr = int(self.model.rel_hidden_size if self.model.kernel_name == "transr" else self.model.desc_kwargs()["dim"])
         table = ((int(self.config.tot_entity) + 63) // 64) * 64 * ((dr + 7) // 8 * 8) * 4
         per = int(max(1, min(4096, self.TABLE_BUDGET_BYTES // table)))
         chunks = []
@@ -235,11 +248,13 @@ class Evaluator:
         key = (id(data), n)
         if key not in self._cache:
             trip = _as_array(data, n)
-            if self._by_relation():  # test triples grouped by relation; ranks are scattered back to the input order
-                order = np.argsort(trip[:, 1], kind="stable")
+            dense = self._dense_relations(trip)
+            if dense is not None:  # grouped triples first, sorted by relation; ranks are scattered back to the input order
+                order = np.lexsort((trip[:, 1], ~dense))
                 trip = np.ascontiguousarray(trip[order])
-                cuts = np.concatenate([[0], np.flatnonzero(np.diff(trip[:, 1])) + 1, [len(trip)]]).astype(np.int64)
-                self._groups[key] = (order, self._group_chunks(trip, cuts))
+                nd = int(dense.sum())
+                cuts = np.concatenate([[0], np.flatnonzero(np.diff(trip[:nd, 1])) + 1, [nd]]).astype(np.int64)
+                self._groups[key] = (order, self._group_chunks(trip, cuts), nd)
             mc = self.metric_calculator
             if mc.hr_t is not None:
                 csr = build_filter_csr(trip, mc.hr_t, mc.tr_h)
@@ -260,10 +275,12 @@ class Evaluator:
             self.K.rescal_normalize(self.model.ent_embeddings.weight.data, self.model.rel_matrices.weight.data,
                                     self.model.hidden_size)
         desc = self.K.model_desc(self.model)
-        if self._by_relation():
-            order, chunks = self._groups[(id(data), n)]
+        if (id(data), n) in self._groups:
+            order, chunks, nd = self._groups[(id(data), n)]
             out = torch.empty((4, len(order)), dtype=torch.int32, device=trip.device)
             dst = torch.from_numpy(order).to(trip.device)
+            if nd < len(order):  # rare relations: candidate transform inside the sweep
+                out[:, dst[nd:]] = self.K.eval_ranks(desc, trip[nd:], t_off[nd:], t_ids, h_off[nd:], h_ids)
             for a, b, got, grel, qb in chunks:  # many relation groups per launch, bounded by candidate-table memory
                 out[:, dst[a:b]] = self.K.eval_ranks_grouped(desc, trip[a:b], got, grel, qb, t_off[a:b + 1], t_ids,
                                                              h_off[a:b + 1], h_ids)

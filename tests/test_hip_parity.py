@@ -148,6 +148,25 @@ def test_eval_sweep_scores_and_ranks_match_reference(hip, name):
     assert np.abs(ranks - ref).max() <= 1 and (ranks != ref).sum() <= 2, (ranks, ref)
     metrics = ev.test(c.test, n, epoch=0)
     assert np.isclose(metrics["fmr"], c.z["eval.fmr"], rtol=0.02)
+    if c.model in ("transh", "transd"):
+        # grouped evaluation (candidates transformed once per relation, then the plain sweep) against the in-sweep transform
+        # and the reference: different rounding, so only fp32 near-ties may move
+        ev3 = Evaluator(m, cfg)
+        ev3.GROUPED_MIN_TRIPLES_PER_RELATION = 0
+        r3 = ev3.rank_all(c.test, n).cpu().numpy()
+        assert (id(c.test), n) in ev3._groups
+        assert np.abs(r3 - ranks).max() <= 1 and (r3 != ranks).sum() <= 2, (r3, ranks)
+        assert np.abs(r3 - ref).max() <= 1 and (r3 != ref).sum() <= 2, (r3, ref)
+        ev3.TABLE_BUDGET_BYTES = 1  # one relation group per call
+        ev4 = Evaluator(m, cfg)
+        ev4.GROUPED_MIN_TRIPLES_PER_RELATION, ev4.TABLE_BUDGET_BYTES = 0, 1
+        assert np.array_equal(ev4.rank_all(c.test, n).cpu().numpy(), r3)
+        ev5 = Evaluator(m, cfg)  # mixed: relations with >= 2 test triples grouped, the rest through the in-sweep transform
+        ev5.GROUPED_MIN_TRIPLES_PER_RELATION = 2
+        r5 = ev5.rank_all(c.test, n).cpu().numpy()
+        nd5 = ev5._groups[(id(c.test), n)][2]
+        assert 0 < nd5 < n
+        assert np.abs(r5 - ranks).max() <= 1 and (r5 != ranks).sum() <= 2
     if c.model == "transr":  # relation groups split over several grouped calls (tiny table budget) give the same ranks
         ev2 = Evaluator(m, cfg)
         ev2.TABLE_BUDGET_BYTES = 1

@@ -38,13 +38,18 @@ CONFIGS = [
     ("NTN FB15k d=k=100 B=128 adam (preset)", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 128, 1, 64),
 ]
 only = os.environ.get("ONLY")
+ZIPF = os.environ.get("ZIPF_REL") == "1"   # relation ids of the TEST triples Zipf(1)-skewed, as in real test splits
 rng = np.random.default_rng(1234)
 for name, model, ds, hp, opt, B, neg, n_eval in CONFIGS:
     if only and only not in name:
         continue
     E, R, NTR, NTE = SHAPES[ds]
     train = np.stack([rng.integers(E, size=NTR), rng.integers(R, size=NTR), rng.integers(E, size=NTR)], 1)
-    test = np.stack([rng.integers(E, size=max(n_eval, 16)), rng.integers(R, size=max(n_eval, 16)), rng.integers(E, size=max(n_eval, 16))], 1)
+    nt_ = max(int(os.environ.get("N_EVAL", n_eval)) if n_eval else 0, 16)
+    rel_t = rng.integers(R, size=nt_)
+    if ZIPF:
+        w = 1.0 / np.arange(1, R + 1); rel_t = rng.choice(R, size=nt_, p=w / w.sum())
+    test = np.stack([rng.integers(E, size=nt_), rel_t, rng.integers(E, size=nt_)], 1)
     hp2 = dict(hp); hp2.setdefault("margin", 1.0); hp2["neg_rate"] = neg
     cfg = hip_util.make_config(E, R, hp2, train, test[:16], test, optimizer=opt, lr=0.01, batch_size=B)
     cfg.hr_dummy = None
@@ -61,8 +66,12 @@ for name, model, ds, hp, opt, B, neg, n_eval in CONFIGS:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K_
     line = f"{name}: {'graph' if tr._graph is not None else 'eager'} step {dt*1e6:.1f} us -> {B*(1+neg)/dt/1e6:.2f} M scored triples/s"
+    if os.environ.get("N_EVAL") and n_eval:
+        n_eval = int(os.environ["N_EVAL"])
     if n_eval:
         ev = Evaluator(m, cfg)
+        if os.environ.get("GROUPED_MIN"):
+            ev.GROUPED_MIN_TRIPLES_PER_RELATION = float(os.environ["GROUPED_MIN"])
         ev.rank_all(test, n_eval); torch.cuda.synchronize()
         t0 = time.perf_counter(); ev.rank_all(test, n_eval); torch.cuda.synchronize(); edt = time.perf_counter() - t0
         line += f" | eval {n_eval} triples {edt*1e3:.2f} ms -> {n_eval/edt:.0f} test triples/s"
