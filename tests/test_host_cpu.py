@@ -179,3 +179,24 @@ def test_vectorised_filter_csr_equals_dict_of_sets_form():
         assert np.array_equal(a[side], b[side])
         for i in range(len(q)):
             assert set(a[side + 1][a[side][i]:a[side][i + 1]]) == set(b[side + 1][b[side][i]:b[side][i + 1]])
+
+
+def test_new_entry_points_validate_arguments_without_gpu():
+    from pykg2vec_amd import _lib
+    lib = _lib.load()
+    d = _lib.ModelDesc()
+    d.model, d.dim, d.rel_dim, d.tot_entity, d.tot_relation = _lib.TRANSE, 8, 8, 10, 3
+    fake = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    for i in range(2):
+        d.tables[i] = 16
+    assert lib.kge_eval_ranks_grouped(ctypes.byref(d), fake, 4, fake, fake, 1, fake, 1, None, None, None, None, fake, 1 << 20,
+                                      fake, None) != 0
+    assert b"TransR / TransH / TransD only" in lib.kge_last_error()
+    assert lib.kge_head_1n_forward(None, 4, 8, None, 10, None, None, None) != 0
+    assert lib.kge_head_1n_bce_workspace_bytes(0, 10, 0) == 0
+    assert lib.kge_optimizer_step_advance(1, fake, fake, fake, fake, 16, 0.1, 1, fake, fake, fake, fake, 4, 2, 4, None) != 0
+    assert b"different set" in lib.kge_last_error()  # next-step state must not alias the current one
+    d.model, d.dim, d.rel_dim = _lib.TRANSR, 200, 50
+    d.tables[2] = 16
+    assert lib.kge_score_forward(ctypes.byref(d), fake, fake, fake, 4, fake, fake, 1 << 20, None) != 0
+    assert b"exceed the LDS-resident tile kernel" in lib.kge_last_error()
