@@ -560,3 +560,46 @@ def test_fused_pointwise_sampler_step_equals_sample_then_step(hip, name, neg):
     assert np.isclose(res[0][0], res[1][0], rtol=1e-5)
     for a, b in zip(res[0][1], res[1][1]):
         assert np.allclose(a, b, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["transe_l1", "transh_l2", "transd_l1", "transm_l1", "distmult", "complex", "rotate"])
+def test_fused_sampler_steps_with_bern_probabilities(hip, name):
+    """The sampler-fused kernels with per-relation bern head/tail probabilities (data/generator.py:77-83) must see the batch
+    kge_sample_batch emits with the same probabilities."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.trainer import Trainer
+    c = Case(name)
+    neg = int(c.hp.get("neg_rate", 1)) if c.model == "rotate" else (2 if c.pointwise else 1)
+    cfg = hip.make_config(c.E, c.R, dict(c.hp, neg_rate=neg), c.train, c.valid, c.test, batch_size=64)
+    bern = torch.tensor(np.random.default_rng(5).uniform(0.05, 0.95, size=c.R), dtype=torch.float32, device="cuda")
+    res = []
+    for fused in (False, True):
+        m = hip.model_from_case(c)
+        tr = Trainer(m, cfg)
+        tr.build_model()
+        gen = tr._new_generator()
+        tr.loss_buf.zero_()
+        args = (gen.triples, gen.perm, 64, 64)
+        if c.pointwise:
+            if fused:
+                K.train_pointwise_logistic_sampled(tr._desc, *args, neg, bern, gen.slots, 3, 77, m.kernel_lmbda(),
+                                                   m.kernel_reg_type(), tr.loss_buf)
+            else:
+                b = K.sample_batch(*args, neg, c.E, bern, gen.slots, 3, 77, pointwise=True)
+                K.train_pointwise_logistic(tr._desc, *b, m.kernel_lmbda(), m.kernel_reg_type(), tr.loss_buf, bundle=1 + neg)
+        elif c.model == "rotate":
+            if fused:
+                K.train_pairwise_selfadv_sampled(tr._desc, *args, neg, c.hp["alpha"], bern, gen.slots, 3, 77, tr.loss_buf)
+            else:
+                b = K.sample_batch(*args, neg, c.E, bern, gen.slots, 3, 77)
+                K.train_pairwise_selfadv(tr._desc, *b, neg, c.hp["alpha"], tr.loss_buf)
+        else:
+            if fused:
+                K.train_pairwise_hinge_sampled(tr._desc, *args, bern, gen.slots, 3, 77, 1.0, tr.loss_buf)
+            else:
+                b = K.sample_batch(*args, 1, c.E, bern, gen.slots, 3, 77)
+                K.train_pairwise_hinge(tr._desc, *b, 1.0, tr.loss_buf)
+        res.append((K.read_loss(tr.loss_buf).item(), [g.cpu().numpy().copy() for g in tr.flat.grad_views]))
+    assert np.isclose(res[0][0], res[1][0], rtol=1e-5)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.allclose(a, b, atol=1e-5, rtol=1e-4)
