@@ -339,10 +339,30 @@ __global__ __launch_bounds__(256) void k_transr_project(const float* __restrict_
         if (c1 < de) sE[row * Se + c1] = v1 * inv;
     }
     __syncthreads();
-    for (int j = wave; j < dr; j += 4) {  // lane = candidate; M[a][j] is wave-uniform
-        float p = 0.f;
-        for (int a = 0; a < de; ++a) p = fmaf(sE[lane * Se + a], M[(int64_t)a * dr + j], p);
-        sP[lane * Sr + j] = p;
+    // P[64, dr] = E^[64, de] M_r on the matrix cores: 32x32 output tiles dealt to the four waves
+    {
+        const int li = lane & 31, lk = lane >> 5;
+        const int nct = (dr + 31) / 32;
+        for (int u = wave; u < 2 * nct; u += 4) {
+            const int rt = u / nct, ct = u - rt * nct;
+            const int j = ct * 32 + li;
+            f32x16 acc = {0};
+            for (int k0 = 0; k0 < de; k0 += 16) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = k0 + 2 * q + lk;
+                    av[q] = k < de ? sE[(rt * 32 + li) * Se + k] : 0.f;
+                    bv[q] = (k < de && j < dr) ? M[(int64_t)k * dr + j] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+            }
+            if (j < dr) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) sP[(rt * 32 + mfma_row(reg, lk)) * Sr + j] = acc[reg];
+            }
+        }
     }
     __syncthreads();
     float n2 = 0.f;
