@@ -330,13 +330,21 @@ __global__ __launch_bounds__(256) void k_transr_project(const float* __restrict_
     cand += blockIdx.y * table_stride;
     const float* M = mat + rel * (int64_t)de * dr;
     const int c0 = lane, c1 = lane + 64;
-    for (int j = 0; j < 16; ++j) {
-        const int row = wave * 16 + j;
-        const int64_t e = e0 + row;
-        const float v0 = (e < E && c0 < de) ? ent[e * de + c0] : 0.f, v1 = (e < E && c1 < de) ? ent[e * de + c1] : 0.f;
-        const float inv = 1.0f / fmaxf(sqrtf(wave_sum(fmaf(v1, v1, v0 * v0))), kEpsNormalize);
-        if (c0 < de) sE[row * Se + c0] = v0 * inv;
-        if (c1 < de) sE[row * Se + c1] = v1 * inv;
+    {   // the wave's 16 rows are gathered before the first reduction (one memory round trip, not sixteen)
+        float v0[16], v1[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t e = e0 + wave * 16 + j;
+            v0[j] = (e < E && c0 < de) ? ent[e * de + c0] : 0.f;
+            v1[j] = (e < E && c1 < de) ? ent[e * de + c1] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = wave * 16 + j;
+            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(fmaf(v1[j], v1[j], v0[j] * v0[j]))), kEpsNormalize);
+            if (c0 < de) sE[row * Se + c0] = v0[j] * inv;
+            if (c1 < de) sE[row * Se + c1] = v1[j] * inv;
+        }
     }
     __syncthreads();
     // P[64, dr] = E^[64, de] M_r on the matrix cores: 32x32 output tiles dealt to the four waves
