@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_ntn_sweep(int64_t nq, int64_t E, int d,
     const float* elin = side == 0 ? w.EM2 : w.EM1;   // tail candidates: t^_e M2 ; head candidates: h^_e M1
     const int64_t ntile32 = (E + 31) / 32;
     float* out = scores + (row0 + q) * E;
-    for (int64_t tl = wave; tl < ntile32; tl += 4) {
+    for (int64_t tl = (int64_t)blockIdx.y * 4 + wave; tl < ntile32; tl += 4 * (int64_t)gridDim.y) {  // tiles dealt over gridDim.y workgroups
         const int64_t e0 = tl * 32;
         const float* cbase = w.cand + ((e0 >> 6) * w.Kpad) * 64 + (e0 & 63) + li;   // + k*64
         float tot[16];
@@ -293,7 +293,13 @@ static int ntn_eval_common(const kge_model_desc* m, const int64_t* triples, int6
         hipLaunchKernelGGL(k_ntn_q_contract, dim3((unsigned)((c + NQT - 1) / NQT), (unsigned)((kr + 3) / 4)), dim3(256), lds_c,
                            s, m->tables[5], c, d, kr, w);
         float* sc = scores_out ? scores_out + 2 * lo * E : w.scores;
-        hipLaunchKernelGGL(k_ntn_sweep, dim3((unsigned)(2 * c)), dim3(256), lds_s, s, 2 * c, E, d, kr, w, (int64_t)0, sc);
+        // few queries (one workgroup each) would leave most CUs idle and every SIMD with a single wave: split each
+        // query's candidate tiles over several workgroups (~3 per CU: the transposed query matrix takes ~50 KB of LDS)
+        int64_t split = (768 + 2 * c - 1) / (2 * c);
+        if (split > 16) split = 16;
+        if (split < 1) split = 1;
+        hipLaunchKernelGGL(k_ntn_sweep, dim3((unsigned)(2 * c), (unsigned)split), dim3(256), lds_s, s, 2 * c, E, d, kr, w,
+                           (int64_t)0, sc);
         if (ranks)
             hipLaunchKernelGGL(k_ntn_rank_rows, dim3((unsigned)((2 * c + 3) / 4)), dim3(256), 0, s, sc, c, E, w.truth, tail_off,
                                tail_ids, head_off, head_ids, lo, n, ranks);
