@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void k_ntn_small(float* __restrict__ gM1, floa
 }
 
 // ---- 6. bilinear backward wrt the rows: GT += sum_s gz_s (H^ W_s),  GH += sum_s gz_s (T^ W_s^T)
-// block = (tile, group of 4*SPW slices); each wave accumulates SPW slices in registers, then one atomic pass
+// block = (tile, SPW slices); the 32-wide column tiles are dealt to the four waves (a wave's chain of dependent operand
+// round trips is d/8 per slice instead of JT*d/8); each wave accumulates its column tiles over the slices, one atomic pass
 template <int JT>  // JT = ceil(d / 32) <= 8
 __global__ __launch_bounds__(256) void k_ntn_bil_bwd(const float* __restrict__ W, int64_t n, int d, int kr, NtnWs w) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -245,12 +246,13 @@ __global__ __launch_bounds__(256) void k_ntn_bil_bwd(const float* __restrict__ W
     stage_tile(sH, w.Hn, row0, cnt, d, S);
     stage_tile(sT, w.Tn, row0, cnt, d, S);
     __syncthreads();
-    float gt[JT][16], gh[JT][16];
+    constexpr int JW = (JT + 3) / 4;  // column tiles per wave
+    float gt[JW][16], gh[JW][16];
 #pragma unroll
-    for (int a = 0; a < JT; ++a)
+    for (int a = 0; a < JW; ++a)
 #pragma unroll
         for (int q = 0; q < 16; ++q) { gt[a][q] = 0.f; gh[a][q] = 0.f; }
-    const int s_base = (blockIdx.y * 4 + wave) * SPW;
+    const int s_base = blockIdx.y * SPW;
     for (int ss = 0; ss < SPW; ++ss) {
         const int s = s_base + ss;
         if (s >= kr) break;
@@ -262,8 +264,9 @@ __global__ __launch_bounds__(256) void k_ntn_bil_bwd(const float* __restrict__ W
             gzr[q] = row < cnt ? w.GZ[(row0 + row) * kr + s] : 0.f;
         }
 #pragma unroll
-        for (int a = 0; a < JT; ++a) {
-            const int col = a * 32 + li;
+        for (int a = 0; a < JW; ++a) {
+            if (wave + 4 * a >= JT) break;  // wave-uniform
+            const int col = (wave + 4 * a) * 32 + li;
             f32x16 accx = {0}, accy = {0};
             for (int k0 = 0; k0 < d; k0 += 8) {
                 float ah[4], at[4], bx[4], by[4];
@@ -290,9 +293,9 @@ __global__ __launch_bounds__(256) void k_ntn_bil_bwd(const float* __restrict__ W
         }
     }
 #pragma unroll
-    for (int a = 0; a < JT; ++a) {
-        const int col = a * 32 + li;
-        if (col < d) {
+    for (int a = 0; a < JW; ++a) {
+        const int col = (wave + 4 * a) * 32 + li;
+        if (wave + 4 * a < JT && col < d) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * lk;
@@ -405,7 +408,7 @@ int launch_ntn_backward(const kge_model_desc* m, const int64_t* h, const int64_t
                        m->grads[3], m->grads[4], n, d, kr, w);
     const int S = (d + 1) | 1;
     const size_t lds = (size_t)(2 * NT * S) * sizeof(float);
-    const dim3 gb(tiles, (unsigned)((kr + 4 * SPW - 1) / (4 * SPW)));
+    const dim3 gb(tiles, (unsigned)((kr + SPW - 1) / SPW));
     const int JT = (d + 31) / 32;
 #define KGE_NTN_BWD(J) case J: hipLaunchKernelGGL(k_ntn_bil_bwd<J>, gb, dim3(256), lds, s, m->tables[5], n, d, kr, w); break;
     switch (JT) {
