@@ -119,49 +119,63 @@ __global__ __launch_bounds__(256) void k_ntn_bil(const float* __restrict__ W, in
     if (threadIdx.x < cnt) w.Z[(row0 + threadIdx.x) * kr + s] = sB[threadIdx.x];
 }
 
-// ---- 3. z = tanh(bil + h^ M1 + t^ M2 + b) ; score = - r^ . z          (one wave per triple)
+// ---- 3. z = tanh(bil + h^ M1 + t^ M2 + b) ; score = - r^ . z
+// one workgroup per triple: the d-long contraction is split over the four waves (each a quarter of c, partial sums meet
+// in LDS) -- at the reference's B=128 a wave per triple would leave 7/8 of the SIMDs without a wave
 __global__ __launch_bounds__(256) void k_ntn_finish(const float* __restrict__ M1, const float* __restrict__ M2,
                                                     const float* __restrict__ b, int64_t n, int d, int kr, NtnWs w,
                                                     float* __restrict__ scores) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float s_part[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x;
     if (i >= n) return;
     const float* hn = w.Hn + i * d; const float* tn = w.Tn + i * d;
+    const int dq = ((d + 3) / 4 + 7) / 8 * 8;           // c-range of a wave, a multiple of the unroll
+    const int c_lo = wave * dq, c_hi = min(d, c_lo + dq);
     float tot = 0.f;
-    for (int sb = 0; sb < kr; sb += 128) {  // two slices per lane per pass: twice the loads in flight per round trip
+    for (int sb = 0; sb < kr; sb += 128) {  // two slices per lane per pass
         const int s0 = sb + lane, s1 = sb + 64 + lane;
         const bool v0 = s0 < kr, v1 = s1 < kr;
         const int q0 = v0 ? s0 : kr - 1, q1 = v1 ? s1 : kr - 1;
-        float lin0 = b[q0], lin1 = b[q1];
-        for (int c0 = 0; c0 < d; c0 += 8) {
+        float lin0 = 0.f, lin1 = 0.f;
+        for (int c0 = c_lo; c0 < c_hi; c0 += 8) {
             float m1a[8], m2a[8], m1b[8], m2b[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int c = c0 + u < d ? c0 + u : d - 1;
+                const int c = c0 + u < c_hi ? c0 + u : d - 1;
                 m1a[u] = M1[(int64_t)c * kr + q0]; m2a[u] = M2[(int64_t)c * kr + q0];
                 m1b[u] = M1[(int64_t)c * kr + q1]; m2b[u] = M2[(int64_t)c * kr + q1];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (c0 + u < d) {
+                if (c0 + u < c_hi) {
                     const float hv = hn[c0 + u], tv = tn[c0 + u];
                     lin0 = fmaf(hv, m1a[u], fmaf(tv, m2a[u], lin0));
                     lin1 = fmaf(hv, m1b[u], fmaf(tv, m2b[u], lin1));
                 }
         }
-        if (v0) {
-            const float z = tanhf(w.Z[i * kr + s0] + lin0);
-            w.Z[i * kr + s0] = z;
-            tot = fmaf(w.Rn[i * kr + s0], z, tot);
+        s_part[wave][lane] = lin0; s_part[wave][64 + lane] = lin1;
+        __syncthreads();
+        if (wave == 0) {
+            if (v0) {
+                const float lin = b[s0] + ((s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]));
+                const float z = tanhf(w.Z[i * kr + s0] + lin);
+                w.Z[i * kr + s0] = z;
+                tot = fmaf(w.Rn[i * kr + s0], z, tot);
+            }
+            if (v1) {
+                const float lin = b[s1] + ((s_part[0][64 + lane] + s_part[1][64 + lane]) + (s_part[2][64 + lane] + s_part[3][64 + lane]));
+                const float z = tanhf(w.Z[i * kr + s1] + lin);
+                w.Z[i * kr + s1] = z;
+                tot = fmaf(w.Rn[i * kr + s1], z, tot);
+            }
         }
-        if (v1) {
-            const float z = tanhf(w.Z[i * kr + s1] + lin1);
-            w.Z[i * kr + s1] = z;
-            tot = fmaf(w.Rn[i * kr + s1], z, tot);
-        }
+        __syncthreads();
     }
-    tot = wave_sum(tot);
-    if (lane == 0 && scores) scores[i] = -tot;
+    if (wave == 0) {
+        tot = wave_sum(tot);
+        if (lane == 0 && scores) scores[i] = -tot;
+    }
 }
 
 // ---- 4. gz, relation-row gradient, linear parts of gH^/gT^           (one wave per triple)
@@ -381,7 +395,7 @@ static int ntn_forward_core(const kge_model_desc* m, const int64_t* h, const int
     const int S = (d + 1) | 1;
     const size_t lds = (size_t)(2 * NT * S + 4 * NT) * sizeof(float);
     hipLaunchKernelGGL(k_ntn_bil, dim3(tiles, (unsigned)kr), dim3(256), lds, s, m->tables[5], n, d, kr, w);
-    hipLaunchKernelGGL(k_ntn_finish, dim3(rows4), dim3(256), 0, s, m->tables[2], m->tables[3], m->tables[4], n, d, kr, w,
+    hipLaunchKernelGGL(k_ntn_finish, dim3((unsigned)n), dim3(256), 0, s, m->tables[2], m->tables[3], m->tables[4], n, d, kr, w,
                        scores);
     return check_launch("ntn forward");
 }
