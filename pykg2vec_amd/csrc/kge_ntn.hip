@@ -62,9 +62,20 @@ __global__ __launch_bounds__(256) void k_ntn_prep(const float* __restrict__ ent,
 }
 
 __device__ __forceinline__ void stage_tile(float* sX, const float* __restrict__ X, int64_t row0, int cnt, int d, int S) {
-    for (int idx = threadIdx.x; idx < NT * d; idx += 256) {
-        const int i = idx / d, c = idx - i * d;
-        sX[i * S + c] = i < cnt ? X[(row0 + i) * d + c] : 0.f;
+    // four loads per thread in flight before the LDS stores (a load-store-load-store chain pays the global latency per element)
+    for (int base = 0; base < NT * d; base += 4 * 256) {
+        float v[4];
+        int pos[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            const int i = idx / d, c = idx - i * d;
+            pos[u] = idx < NT * d ? i * S + c : -1;
+            v[u] = (idx < NT * d && i < cnt) ? X[(row0 + i) * d + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pos[u] >= 0) sX[pos[u]] = v[u];
     }
 }
 
