@@ -242,7 +242,7 @@ static int rescal_run(int mode, const kge_model_desc* m, const int64_t* h, const
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)k_rescal<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const int units = 2 * ntile + ntile * ntile;
-        const unsigned ysplit = (unsigned)min(8, (units + 15) / 16);  // ~4 units per wave
+        const unsigned ysplit = (unsigned)min(16, (units + 3) / 4);  // ~1 unit per wave
         hipLaunchKernelGGL(k_rescal<1>, dim3(max_tiles, ysplit), dim3(256), lds, s, m->tables[0], m->tables[1], m->grads[0],
                            m->grads[1], h, t, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, dscore, nullptr);
     }
