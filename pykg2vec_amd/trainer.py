@@ -87,6 +87,7 @@ class Trainer:
     TRAINED_MODEL_CONFIG_NAME = "config.npy"
 
     GRAPH_MAX_ROWS = 16384  # steps scoring at most this many triples are launch-bound: replay them as one hipGraph
+    GRAPH_UNROLL = 8        # steps per replayed multi-step graph (even; 0 = single-step graphs only)
 
     def __init__(self, model, config, process_group=None, backend=None, use_graph=None):
         # `backend` exists so that the multi-process plumbing (batch sharding, gradient all-reduce, replica
@@ -270,6 +271,15 @@ class Trainer:
             self._graphs.append(graph)
         self._graph = self._graphs[0]
         self._parity = 1  # the eager step consumed set 0; the next step's state is in set 1
+        # launch-bound steps: one graph launch per step still costs the host ~10 us; a third graph replays GRAPH_UNROLL
+        # (even) steps back to back starting from parity 1
+        self._graph_multi = None
+        if self.GRAPH_UNROLL >= 2 and num_batch >= 2 * self.GRAPH_UNROLL:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for u in range(self.GRAPH_UNROLL):
+                    body((1 + u) & 1)
+            self._graph_multi = graph
         return 1  # steps already executed
 
     # ------------------------------------------------------------------ epochs
@@ -286,9 +296,15 @@ class Trainer:
                 done = self._capture_step(num_batch)
             # (an epoch is exactly num_batch steps, so the device-side batch index has wrapped to 0 by itself: every
             # epoch walks the permutation from its start, data/generator.py:28-35)
-            for _ in range(num_batch - done):
-                self._graphs[self._parity].replay()
-                self._parity ^= 1
+            remaining = num_batch - done
+            while remaining > 0:
+                if self._graph_multi is not None and self._parity == 1 and remaining >= self.GRAPH_UNROLL:
+                    self._graph_multi.replay()  # an even number of steps: parity unchanged
+                    remaining -= self.GRAPH_UNROLL
+                else:
+                    self._graphs[self._parity].replay()
+                    self._parity ^= 1
+                    remaining -= 1
             self.flat.step = step0 + num_batch
             gen._draws = draws0 + num_batch * gen.batch_size * gen.neg_rate
             gen._pending = 0

@@ -37,6 +37,8 @@ CONFIGS = [
     ("QuatE WN18 d=300 B=4096 adagrad", "quate", "wn18rr", dict(hidden_size=300, lmbda=0.05), "adagrad", 4096, 1, 0),
     ("NTN FB15k d=k=100 B=128 adam (preset)", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 128, 1, 64),
 ]
+if os.environ.get("GRAPH_UNROLL"):
+    Trainer.GRAPH_UNROLL = int(os.environ["GRAPH_UNROLL"])
 only = os.environ.get("ONLY")
 ZIPF = os.environ.get("ZIPF_REL") == "1"   # relation ids of the TEST triples Zipf(1)-skewed, as in real test splits
 rng = np.random.default_rng(1234)
