@@ -306,13 +306,17 @@ def test_graph_replayed_epochs_equal_eager_epochs(hip, name, opt):
     c = Case(name)
     out = []
     for use_graph in (False, True):
-        cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer=opt, lr=0.02, batch_size=48)
+        # 400 train triples / 16 = 25 steps per epoch: one eager step, then multi-step graphs (GRAPH_UNROLL) and single-step
+        # graphs of both parities all get replayed
+        cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer=opt, lr=0.02, batch_size=16)
         m = hip.model_from_case(c)
         tr = Trainer(m, cfg, use_graph=use_graph)
         tr.build_model()
         tr.generator = tr._new_generator()
         losses = [tr.train_model_epoch(e) for e in range(3)]
         assert (tr._graph is not None) == use_graph
+        if use_graph:
+            assert tr._graph_multi is not None
         out.append((losses, {k: p.detach().cpu().numpy() for k, p in hip.table_parameters(m)}))
     (l0, p0), (l1, p1) = out
     assert np.allclose(l0, l1, rtol=2e-4), (l0, l1)
