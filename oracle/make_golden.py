@@ -303,6 +303,68 @@ def golden_head_1n():
     print("wrote head_1n", rec["smooth.loss"], rec["plain.loss"])
 
 
+class _ListQueue:
+    """multiprocessing.Queue stand-in for running the reference's worker bodies in-process."""
+
+    def __init__(self, items=()):
+        self.items = list(items)
+
+    def get(self):
+        return self.items.pop(0)
+
+    def put(self, x):
+        self.items.append(x)
+
+
+def golden_sampler():
+    """Rows a16 / a17 / a19 of SURVEY.md section 8: the reference's OWN process_function_pairwise / _pointwise
+    (data/generator.py:42-158) and KnowledgeGraph.read_relation_property (data/kgcontroller.py:466-492), executed
+    unchanged.  Their randomness (`np.random.random`, `np.random.randint`) is patched to replay the Philox stream of
+    the device sampler in the reference's consumption order (sampler_oracle.ReferenceStream), so the frozen outputs
+    are what the device sampler must reproduce bit for bit."""
+    import pykg2vec.data.generator as ref_gen
+    from pykg2vec.data.kgcontroller import KnowledgeGraph
+    import sampler_oracle as so
+    rec = {}
+    Bs = 48
+    for gname, (E_, R_, n_train, gseed) in {"sparse": (53, 7, 400, 4101), "dense": (20, 3, 600, 4102)}.items():
+        rng = np.random.default_rng(gseed)
+        train, _, _ = make_graph(rng, n_train, 0, 0, E_, R_)
+        triples = [Triple(int(a), int(b), int(c)) for a, b, c in train]
+        fake_kg = types.SimpleNamespace(relations=list(range(R_)), triplets={"train": triples})
+        prop = KnowledgeGraph.read_relation_property(fake_kg)          # dict relation -> python float
+        rec["%s.E" % gname], rec["%s.R" % gname], rec["%s.train" % gname] = E_, R_, train
+        rec["%s.relation_property" % gname] = np.asarray([prop[r] for r in range(R_)], dtype=np.float64)
+        case = 0
+        for sampling in ("uniform", "bern"):
+            for neg_rate in (1, 3):
+                for kind in ("pairwise", "pointwise"):
+                    cfg = types.SimpleNamespace(
+                        knowledge_graph=_KG({"triplets_train": triples, "relationproperty": prop}),
+                        neg_rate=neg_rate, sampling=sampling, tot_entity=E_)
+                    pos = train[rng.permutation(n_train)[:Bs]]
+                    seed, offset = 0x1234ABCD5678 + case, 1000 * case + 17
+                    stream = so.ReferenceStream(seed, offset)
+                    raw_q, out_q = _ListQueue([(0, pos), None]), _ListQueue()
+                    saved = np.random.random, np.random.randint
+                    np.random.random, np.random.randint = stream.random, stream.randint
+                    try:
+                        getattr(ref_gen, "process_function_" + kind)(raw_q, out_q, cfg)
+                    finally:
+                        np.random.random, np.random.randint = saved
+                    out = [np.asarray(a, dtype=np.int64) for a in out_q.items[0]]
+                    assert stream.n_random == Bs * neg_rate
+                    key = "%s.%s.%s.n%d" % (gname, kind, sampling, neg_rate)
+                    rec[key + ".pos"], rec[key + ".seed"], rec[key + ".offset"] = pos, np.uint64(seed), np.int64(offset)
+                    rec[key + ".redraws"] = np.int64(stream.n_randint - stream.n_random)
+                    for i, a in enumerate(out):
+                        rec[key + ".out%d" % i] = a
+                    print("sampler", key, "redraws", stream.n_randint - stream.n_random)
+                    case += 1
+    np.savez_compressed(os.path.join(OUT, "ref_sampler.npz"), **rec)
+    print("wrote sampler")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])  # optional: regenerate just the named cases
@@ -313,3 +375,5 @@ if __name__ == "__main__":
         golden_pretrained()
     if not only or "head_1n" in only:
         golden_head_1n()
+    if not only or "sampler" in only:
+        golden_sampler()

@@ -60,3 +60,45 @@ def corrupt(ph, pr, pt, neg_rate, E, bern_prob, train_set, seed, offset):
             c = corrupt_one(int(ph[i]), int(pr[i]), int(pt[i]), E, prob, train_set, seed, offset + i * neg_rate + k)
             nh.append(c[0]); nr.append(c[1]); nt.append(c[2])
     return np.asarray(nh, np.int64), np.asarray(nr, np.int64), np.asarray(nt, np.int64)
+
+
+def bern_table_f32(prob64):
+    """The float32 table the device compares its 24-bit uniform against: each double probability rounded toward
+    zero, so that `u > table[r]` equals the reference's double-precision `u > prob` for every u = k / 2^24."""
+    out = np.empty(len(prob64), dtype=np.float32)
+    for i, p in enumerate(np.asarray(prob64, dtype=np.float64)):
+        q = np.float32(p)
+        out[i] = q if float(q) <= p else np.nextafter(q, np.float32(-1.0))
+    return out
+
+
+class ReferenceStream:
+    """`np.random.random` / `np.random.randint` stand-ins that replay the device sampler's Philox stream in the order the
+    REFERENCE consumes randomness (data/generator.py:77-91 and :133-154): one `random()` per negative slot (the
+    head/tail decision), then one `randint(tot_entity)` per attempt until the corrupted triple is not a train triple.
+    `oracle/make_golden.py` patches numpy with an instance of this class and runs the reference's
+    process_function_pairwise / _pointwise bodies unchanged; their outputs are frozen in tests/golden/ref_sampler.npz.
+    Equality of those outputs with `corrupt()` above (and with the device sampler) pins the corruption RULE -- which
+    side is replaced for a given u, that only the entity is redrawn, the train-set rejection, the slot order and the
+    pairwise / pointwise layouts -- to the reference; only the bit source differs (Philox instead of MT19937)."""
+
+    def __init__(self, seed, offset):
+        self.key = (seed & MASK32, (seed >> 32) & MASK32)
+        self.ctr = offset - 1
+        self.attempt = 0
+        self.n_random = self.n_randint = 0
+
+    def _block(self, attempt):
+        return philox4x32_10((self.ctr & MASK32, (self.ctr >> 32) & MASK32, attempt, 0), self.key)
+
+    def random(self):
+        self.ctr += 1
+        self.attempt = 0
+        self.n_random += 1
+        return (self._block(0)[0] >> 8) / 16777216.0   # exact in float32 and float64
+
+    def randint(self, n):
+        x = self._block(self.attempt)
+        self.attempt += 1
+        self.n_randint += 1
+        return (x[1] * int(n)) >> 32

@@ -36,6 +36,19 @@ def relation_property(train, tot_relation):
     return np.where(tot > 0, nt / np.maximum(tot, 1), 0.0)
 
 
+def bern_table(prob):
+    """float32 device table of the bern probabilities with the reference's comparison preserved exactly: the
+    reference tests `np.random.random() > prob` in double precision (data/generator.py:73,77); the device tests a
+    24-bit uniform u (a multiple of 2^-24, exact in float32) against table[r].  Rounding each probability TOWARD ZERO
+    to float32 keeps every such comparison identical (round-to-nearest could move a probability up past a
+    representable u)."""
+    p64 = np.asarray(prob, dtype=np.float64)
+    p32 = p64.astype(np.float32)
+    up = p32.astype(np.float64) > p64
+    p32[up] = np.nextafter(p32[up], np.float32(-1.0))
+    return p32
+
+
 class Generator:
     def __init__(self, model, config, seed=None, rank=0, world_size=1, backend=K):
         self.K = backend
@@ -65,10 +78,10 @@ class Generator:
         if getattr(config, "sampling", "uniform") == "bern":
             try:
                 prop = config.knowledge_graph.read_cache_data('relationproperty')
-                table = np.asarray([prop[r] for r in range(config.tot_relation)], dtype=np.float32)
+                table = np.asarray([prop[r] for r in range(config.tot_relation)], dtype=np.float64)
             except (KeyError, FileNotFoundError, AttributeError):  # cache without the pickle: derive it from the split
-                table = relation_property(train, config.tot_relation).astype(np.float32)
-            self.bern = torch.from_numpy(table).to(self.device)
+                table = relation_property(train, config.tot_relation)
+            self.bern = torch.from_numpy(bern_table(table)).to(self.device)
         self.neg_rate = int(config.neg_rate)
         self.batch_size = int(config.batch_size)
         self._pending = 0
