@@ -1,0 +1,121 @@
+#!/usr/bin/env python
+"""BASELINE.json configs C1-C4 at FULL table size through the LIVE reference (container-only; TEST INFRASTRUCTURE).
+
+oracle/make_golden.py pins every model at toy sizes; this script runs the reference itself (read-only at
+/root/reference, torch CPU fp32) at the sizes BASELINE.json quotes -- FB15k TransE d=100 (L1, L2), WN18RR ComplEx
+d=200, FB15k-237 RotatE d=1000 neg 16, YAGO3-10 RESCAL k=200 -- on tables built from a numpy seed
+(tests/golden_util.fullsize_inputs) and freezes ONLY the outputs into tests/golden/ref_full_<case>.npz:
+
+  * model.forward energies of n_scores random triples                       (models/pairwise.py, pointwise.py)
+  * one Trainer.train_step_* + loss.backward(): loss, dense-gradient digests  (utils/trainer.py:147-180,298)
+  * Evaluator.test ranks / filtered ranks of n_rank test triples              (utils/evaluator.py:309-334)
+    (none for RESCAL at YAGO3-10 size: the reference's sweep would gather E*k*k floats = 19.7 GB)
+
+Usage: python oracle/make_golden_fullsize.py [case ...]
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+import torch  # noqa: E402
+from pykg2vec.utils.trainer import Trainer  # noqa: E402
+from pykg2vec.utils.evaluator import Evaluator  # noqa: E402
+from pykg2vec.data.kgcontroller import Triple  # noqa: E402
+import golden_util as gu  # noqa: E402
+import kge_oracle as ko  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+CLASS = {"transe": "pairwise.TransE", "complex": "pointwise.Complex", "rotate": "pairwise.RotatE",
+         "rescal": "pairwise.Rescal"}
+
+
+class _KG:
+    def __init__(self, cache):
+        self.cache = cache
+        self.dataset_name = "synthetic"
+
+    def read_cache_data(self, key):
+        return self.cache[key]
+
+
+def run(name):
+    spec, P, train, valid, test, ids, batch = gu.fullsize_inputs(name)
+    E, R, hp, model_name = spec["E"], spec["R"], spec["hp"], spec["model"]
+    n_rank = spec["n_rank"]
+    queries = test[:n_rank]
+    hr_t, tr_h = gu.query_filters(np.concatenate([train, valid, test]), queries, R) if n_rank else ({}, {})
+    mk = lambda arr: [Triple(int(a), int(b), int(c)) for a, b, c in arr]
+    cfg = types.SimpleNamespace(
+        tot_entity=E, tot_relation=R, device="cpu", optimizer="sgd", learning_rate=0.01, neg_rate=hp.get("neg_rate", 1),
+        alpha=hp.get("alpha", 0.1), margin=hp.get("margin", 1.0), batch_size=spec["step_B"], tot_train_triples=len(train),
+        epochs=1000, test_num=n_rank, debug=False, load_from_data=None, hits=[1, 3, 5, 10], patience=3,
+        dataset_name="synthetic", sampling="uniform",
+        knowledge_graph=_KG({"triplets_train": [], "triplets_valid": mk(valid[:4]), "triplets_test": mk(queries),
+                             "hr_t": hr_t, "tr_h": tr_h}))
+    for k, v in hp.items():
+        setattr(cfg, k, v)
+    cfg.summary = lambda: None
+    mod, cls = CLASS[model_name].split(".")
+    model_def = getattr(__import__("pykg2vec.models." + mod, fromlist=[cls]), cls)
+    model = model_def(**cfg.__dict__)
+    init = {k + ".weight": torch.from_numpy(v.copy()) for k, v in P.items()}
+    model.load_state_dict(init)
+    rec = {"name": name}
+
+    # ---- forward energies
+    model.eval()
+    with torch.no_grad():
+        rec["scores"] = model(*[torch.LongTensor(ids[:, i].copy()) for i in range(3)]).numpy()
+    model.load_state_dict(init)  # RESCAL renormalises its tables inside forward (pairwise.py:843-844)
+
+    # ---- one training step: loss + dense-gradient digests
+    trainer = Trainer(model, cfg)
+    tens = [torch.LongTensor(a) for a in batch]
+    model.train()
+    loss = trainer.train_step_pointwise(*tens) if model_name in gu.POINTWISE else trainer.train_step_pairwise(*tens)
+    loss.backward()
+    rec["loss"] = np.float32(loss.item())
+    touched = np.unique(np.concatenate([batch[0], batch[2]]))[:64]
+    for k, p in model.named_parameters():
+        g = p.grad.numpy()
+        rows = touched if g.shape[0] == E else np.unique(batch[1])[:64]
+        s, a, full = gu.grad_digest(g, rows)
+        rec["grad.%s.rowsum" % k], rec["grad.%s.rowabs" % k] = s, a
+        rec["grad.%s.rows" % k], rec["grad.%s.full" % k] = rows, full[:, :gu.DIGEST_COLS]
+    if model_name == "rescal":  # the in-place renormalisation is part of the step's observable result
+        for k, v in model.state_dict().items():
+            rec["after_fwd.%s.rows" % k] = v.numpy()[:64, :gu.DIGEST_COLS].copy()
+
+    # ---- Evaluator.test on the first n_rank test triples
+    if n_rank:
+        model.load_state_dict(init)
+        ev = Evaluator(model, cfg)
+        model.eval()
+        with torch.no_grad():
+            ev.test(ev.test_data, n_rank, epoch=0)
+        mc = ev.metric_calculator
+        rec["ranks"] = np.stack([np.asarray(x, np.int64) for x in (mc.rank_head, mc.rank_tail, mc.f_rank_head, mc.f_rank_tail)])
+        # the reference's own energy of the true candidate and how many candidates sit inside the fp32 band around it
+        with torch.no_grad():
+            ents = torch.arange(E)
+            st = []
+            for h, r, t in queries:
+                sh = model(ents, torch.full((E,), int(r)), torch.full((E,), int(t))).numpy()
+                stl = model(torch.full((E,), int(h)), torch.full((E,), int(r)), ents).numpy()
+                st.append((sh[int(h)], stl[int(t)]))
+        rec["true_scores"] = np.asarray(st, np.float32)   # [n_rank, 2] = (head sweep, tail sweep)
+    np.savez_compressed(os.path.join(OUT, "ref_full_%s.npz" % name), **rec)
+    print("wrote", name, "loss=%.6f" % rec["loss"], "ranks" if n_rank else "", rec.get("ranks", np.zeros(0))[:, :4] if n_rank else "")
+
+
+if __name__ == "__main__":
+    for name in (sys.argv[1:] or list(gu.FULLSIZE)):
+        run(name)

@@ -59,3 +59,86 @@ class Case:
 
 def close(a, b, atol=ATOL, rtol=RTOL):
     return np.allclose(a, b, atol=atol, rtol=rtol)
+
+
+# ---- BASELINE.json configs at FULL table size, frozen from the live reference (oracle/make_golden_fullsize.py).
+# Only seeds and outputs are stored: tables and triples are re-created from the seed on either box (numpy Generator
+# streams of the same numpy build), so the fixtures stay small.
+FULLSIZE = {
+    "c1_transe_l1": dict(model="transe", E=14951, R=1345, splits=(483142, 50000, 59071), seed=9101,
+                         hp=dict(hidden_size=100, l1_flag=True, margin=1.0), n_scores=256, step_B=4096, n_rank=32),
+    "c1_transe_l2": dict(model="transe", E=14951, R=1345, splits=(483142, 50000, 59071), seed=9102,
+                         hp=dict(hidden_size=100, l1_flag=False, margin=1.0), n_scores=256, step_B=4096, n_rank=32),
+    "c2_complex": dict(model="complex", E=40943, R=11, splits=(86835, 3034, 3134), seed=9103,
+                       hp=dict(hidden_size=200, lmbda=1e-4), n_scores=256, step_B=1000, n_rank=8),
+    "c3_rotate": dict(model="rotate", E=14541, R=237, splits=(272115, 17535, 20466), seed=9104,
+                      hp=dict(hidden_size=1000, margin=24.0, neg_rate=16, alpha=1.0), n_scores=64, step_B=32, n_rank=4),
+    "c4_rescal": dict(model="rescal", E=123182, R=37, splits=(1079040, 5000, 5000), seed=9105,
+                      hp=dict(hidden_size=200, margin=1.0), n_scores=64, step_B=64, n_rank=0),
+}
+
+
+def fullsize_inputs(name):
+    """Deterministic inputs of a FULLSIZE case: (spec, params, train, valid, test, score_ids, step_batch)."""
+    import kge_oracle as ko
+    spec = FULLSIZE[name]
+    rng = np.random.default_rng(spec["seed"])
+    E, R = spec["E"], spec["R"]
+
+    def draw(n):
+        return np.stack([rng.integers(E, size=n), rng.integers(R, size=n), rng.integers(E, size=n)], 1).astype(np.int64)
+
+    train, valid, test = (draw(n) for n in spec["splits"])
+    shape_kw = dict(tot_entity=E, tot_relation=R, hidden_size=spec["hp"]["hidden_size"])
+    if spec["model"] == "rotate":
+        shape_kw["margin"] = spec["hp"]["margin"]
+    P = ko.init_params(spec["model"], rng, **shape_kw)
+    ids = draw(spec["n_scores"])
+    B, neg = spec["step_B"], spec["hp"].get("neg_rate", 1)
+    pos = train[rng.permutation(len(train))[:B]]
+    flip = rng.random(B * neg) > 0.5
+    ent = rng.integers(E, size=B * neg)
+    nh = np.where(flip, np.repeat(pos[:, 0], neg), ent)
+    nt = np.where(flip, ent, np.repeat(pos[:, 2], neg))
+    nr = np.repeat(pos[:, 1], neg)
+    if spec["model"] in POINTWISE:
+        batch = ko.pointwise_layout(pos, nh, nr, nt, neg)
+    else:
+        batch = (pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), nh, nr, nt)
+    return spec, P, train, valid, test, ids, tuple(np.ascontiguousarray(a) for a in batch)
+
+
+def query_filters(all_triples, queries, R):
+    """hr_t / tr_h (train+valid+test, kgcontroller.py:410-428) restricted to the keys the evaluated queries look up."""
+    want_hr = {(int(h), int(r)) for h, r, t in queries}
+    want_tr = {(int(t), int(r)) for h, r, t in queries}
+    hr_t, tr_h = {k: set() for k in want_hr}, {k: set() for k in want_tr}
+    key_hr = all_triples[:, 0] * R + all_triples[:, 1]
+    key_tr = all_triples[:, 2] * R + all_triples[:, 1]
+    q_hr = np.fromiter((h * R + r for h, r in want_hr), dtype=np.int64)
+    q_tr = np.fromiter((t * R + r for t, r in want_tr), dtype=np.int64)
+    for row in all_triples[np.isin(key_hr, q_hr)]:
+        hr_t[(int(row[0]), int(row[1]))].add(int(row[2]))
+    for row in all_triples[np.isin(key_tr, q_tr)]:
+        tr_h[(int(row[2]), int(row[1]))].add(int(row[0]))
+    return hr_t, tr_h
+
+
+DIGEST_COLS = 256  # columns kept of the full rows of very wide tables (RESCAL's k*k relation matrices)
+
+
+def grad_digest(g, rows):
+    """What the fixture keeps of a dense [rows, d] gradient: per-row sums, per-row absolute sums (float64
+    accumulation) and the full rows listed in `rows`."""
+    g64 = np.asarray(g, dtype=np.float64)
+    return g64.sum(1).astype(np.float32), np.abs(g64).sum(1).astype(np.float32), np.asarray(g)[rows].copy()
+
+
+def rank_band_ok(scores_row, true_id, got, ref, atol=ATOL, rtol=RTOL):
+    """A rank that differs from the reference's by k needs at least k candidates whose order against the true
+    candidate can flip inside the fp32 tolerance band: |s(e) - s(true)| <= 2 * (atol + rtol * |s|) (both energies may
+    move by one band).  Returns (ok, near_ties)."""
+    st = float(scores_row[true_id])
+    band = 2.0 * (atol + rtol * abs(st))
+    near = int(np.sum(np.abs(scores_row.astype(np.float64) - st) <= band)) - 1   # the true candidate itself excluded
+    return abs(int(got) - int(ref)) <= near, near

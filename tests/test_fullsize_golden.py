@@ -1,0 +1,164 @@
+"""BASELINE.json configs C1-C4 at FULL table size against outputs of the LIVE reference
+(tests/golden/ref_full_*.npz, frozen by oracle/make_golden_fullsize.py; inputs re-created from the seed by
+golden_util.fullsize_inputs).  CPU half: the numpy oracle is held to the reference at these sizes.  GPU half: the HIP
+path (forward, one fused training step, filtered ranks) is held to the same files; every rank that differs from the
+reference's must be explained by candidates inside the fp32 tolerance band, and the observed agreement is written to
+gpurun_out/rank_agreement_fullsize.json (copied to profiles/ by the builder)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import kge_oracle as ko
+import golden_util as gu
+from golden_util import FULLSIZE, GOLDEN, close
+
+CASES = list(FULLSIZE)
+_INPUTS = {}
+
+
+def _inputs(name):
+    if name not in _INPUTS:
+        _INPUTS.clear()  # one case resident at a time (C4 tables are ~130 MB)
+        _INPUTS[name] = gu.fullsize_inputs(name)
+    return _INPUTS[name]
+
+
+def _golden(name):
+    return np.load(os.path.join(GOLDEN, "ref_full_%s.npz" % name))
+
+
+def _hp(spec):
+    hp = dict(spec["hp"])
+    hp.setdefault("margin", 1.0)
+    return hp
+
+
+def _check_grad_digest(z, key, g, scale_floor=1e-3):
+    rows = z["grad.%s.rows" % key]
+    s, a, full = gu.grad_digest(g, rows)
+    ref_s, ref_a, ref_full = z["grad.%s.rowsum" % key], z["grad.%s.rowabs" % key], z["grad.%s.full" % key]
+    scale = max(scale_floor, float(np.abs(ref_full).max()))
+    assert np.allclose(full[:, :gu.DIGEST_COLS], ref_full, atol=2e-5 * max(1.0, scale), rtol=1e-3), \
+        (key, np.abs(full[:, :gu.DIGEST_COLS] - ref_full).max())
+    # per-row digests over ALL rows: untouched rows are exactly zero in both, touched rows agree to fp32 noise
+    assert np.array_equal(ref_a == 0, a == 0), key
+    d = g.shape[1]
+    assert np.allclose(a, ref_a, atol=1e-5 * d * max(1.0, scale), rtol=1e-3), (key, np.abs(a - ref_a).max())
+    assert np.allclose(s, ref_s, atol=1e-5 * d * max(1.0, scale), rtol=1e-3), (key, np.abs(s - ref_s).max())
+
+
+# ------------------------------------------------------------------ CPU: oracle vs the live reference at full size
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_forward_and_step_match_reference_at_full_size(name):
+    spec, P, train, valid, test, ids, batch = _inputs(name)
+    z = _golden(name)
+    model, hp = spec["model"], _hp(spec)
+    Pn = ko.rescal_normalize_tables(P) if model == "rescal" else P
+    got = ko.score(model, Pn, ids[:, 0], ids[:, 1], ids[:, 2], **hp)
+    assert close(got, z["scores"]), np.abs(got - z["scores"]).max()
+    loss, G, _, Pafter = ko.train_step_grads(model, {k: v.copy() for k, v in P.items()}, batch, **hp)
+    assert np.isclose(loss, z["loss"], rtol=2e-5, atol=2e-5), (loss, z["loss"])
+    for k, g in G.items():
+        _check_grad_digest(z, k + ".weight", g)
+    if model == "rescal":
+        for k, v in Pafter.items():
+            assert close(v[:64, :gu.DIGEST_COLS], z["after_fwd.%s.weight.rows" % k])
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if FULLSIZE[n]["n_rank"]])
+def test_oracle_ranks_match_reference_at_full_size(name):
+    spec, P, train, valid, test, ids, batch = _inputs(name)
+    z = _golden(name)
+    n = spec["n_rank"] if spec["model"] != "rotate" else 2   # d=1000 numpy sweeps: keep the CPU suite short
+    q = test[:n]
+    hr_t, tr_h = gu.query_filters(np.concatenate([train, valid, test]), test[:spec["n_rank"]], spec["R"])
+    ref = z["ranks"][:, :n]
+    hp = _hp(spec)
+    for i, (h, r, t) in enumerate(q):
+        h, r, t = int(h), int(r), int(t)
+        sh = ko.sweep_scores(spec["model"], P, h, r, t, "head", **hp)
+        st = ko.sweep_scores(spec["model"], P, h, r, t, "tail", **hp)
+        assert close(sh[h], z["true_scores"][i, 0]) and close(st[t], z["true_scores"][i, 1])
+        for s, true, known, raw, filt in ((sh, h, tr_h[(t, r)], ref[0, i], ref[2, i]), (st, t, hr_t[(h, r)], ref[1, i], ref[3, i])):
+            rk, frk = ko.rank_from_scores(s, true, known)
+            ok_r, _ = gu.rank_band_ok(s, true, rk, raw)
+            ok_f, _ = gu.rank_band_ok(s, true, frk, filt)
+            assert ok_r and ok_f, (name, i, rk, raw, frk, filt)
+
+
+# ------------------------------------------------------------------ GPU: the HIP path vs the live reference at full size
+def _gpu_setup(name, batch_size=None):
+    import hip_util
+    from pykg2vec_amd.trainer import Trainer
+    spec, P, train, valid, test, ids, batch = _inputs(name)
+    hp = _hp(spec)
+    n_rank = spec["n_rank"]
+    hr_t, tr_h = gu.query_filters(np.concatenate([train, valid, test]), test[:n_rank], spec["R"]) if n_rank else ({}, {})
+    cfg = hip_util.make_config(spec["E"], spec["R"], hp, train[:1], valid[:4], test[:max(n_rank, 1)], optimizer="sgd", lr=0.01,
+                               batch_size=batch_size or spec["step_B"])
+    cfg.knowledge_graph.cache.update(triplets_train=train, hr_t=hr_t, tr_h=tr_h)
+    cfg.tot_train_triples = len(train)
+    m = hip_util.model_from_params(spec["model"], P, spec["hp"], spec["E"], spec["R"], train=train)
+    return hip_util, spec, hp, cfg, m, Trainer
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_forward_and_fused_step_match_reference_at_full_size(name):
+    import torch
+    hip, spec, hp, cfg, m, Trainer = _gpu_setup(name)
+    _, P, train, valid, test, ids, batch = _inputs(name)
+    z = _golden(name)
+    with torch.no_grad():
+        got = m(hip.dev(ids[:, 0]), hip.dev(ids[:, 1]), hip.dev(ids[:, 2])).cpu().numpy()
+    if spec["model"] == "rescal":   # forward renormalised the tables in place (pairwise.py:843-844): restore
+        m = hip.model_from_params(spec["model"], P, spec["hp"], spec["E"], spec["R"], train=train)
+    assert close(got, z["scores"]), np.abs(got - z["scores"]).max()
+    tr = Trainer(m, cfg, use_graph=False)
+    tr.build_model()
+    b = [hip.dev(x) for x in batch]
+    loss = tr.train_step_pointwise(*b) if spec["model"] in gu.POINTWISE else tr.train_step_pairwise(*b)
+    assert np.isclose(loss.item(), z["loss"], rtol=3e-5, atol=3e-5), (loss.item(), z["loss"])
+    for (pname, _), g in zip(hip.table_parameters(m), tr.flat.grad_views):
+        _check_grad_digest(z, pname, g.cpu().numpy())
+    if spec["model"] == "rescal":
+        for pname, p in hip.table_parameters(m):
+            assert close(p.detach().cpu().numpy()[:64, :gu.DIGEST_COLS], z["after_fwd.%s.rows" % pname])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in CASES if FULLSIZE[n]["n_rank"]])
+def test_hip_ranks_match_reference_at_full_size_inside_the_score_band(name):
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.evaluator import Evaluator
+    hip, spec, hp, cfg, m, _ = _gpu_setup(name)
+    _, P, train, valid, test, ids, batch = _inputs(name)
+    z = _golden(name)
+    n = spec["n_rank"]
+    q = test[:n]
+    ranks = Evaluator(m, cfg).rank_all(q, n).cpu().numpy()
+    ref = z["ranks"]
+    scores = K.eval_sweep_scores(m.make_desc(), hip.dev(q)).cpu().numpy()   # [2n, E]: tail sweep, head sweep per triple
+    report = {"case": name, "queries": 2 * n, "raw_equal": 0, "filtered_equal": 0, "max_abs_rank_diff": 0, "flips": []}
+    for i, (h, r, t) in enumerate(q):
+        for side, row, true, raw_g, filt_g, raw_r, filt_r in (
+                ("tail", scores[2 * i], int(t), ranks[1, i], ranks[3, i], ref[1, i], ref[3, i]),
+                ("head", scores[2 * i + 1], int(h), ranks[0, i], ranks[2, i], ref[0, i], ref[2, i])):
+            assert close(row[true], z["true_scores"][i, 0 if side == "head" else 1], atol=2e-5, rtol=2e-5)
+            ok_r, near = gu.rank_band_ok(row, true, raw_g, raw_r)
+            ok_f, _ = gu.rank_band_ok(row, true, filt_g, filt_r)
+            assert ok_r and ok_f, (name, i, side, int(raw_g), int(raw_r), int(filt_g), int(filt_r), near)
+            report["raw_equal"] += int(raw_g == raw_r)
+            report["filtered_equal"] += int(filt_g == filt_r)
+            report["max_abs_rank_diff"] = max(report["max_abs_rank_diff"], abs(int(raw_g) - int(raw_r)))
+            if raw_g != raw_r or filt_g != filt_r:
+                report["flips"].append({"triple": i, "side": side, "gpu": [int(raw_g), int(filt_g)],
+                                        "reference": [int(raw_r), int(filt_r)], "candidates_inside_band": near})
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "rank_agreement_fullsize.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc[name] = report
+    json.dump(doc, open(path, "w"), indent=1)

@@ -74,6 +74,16 @@ def test_fused_sampler_kernel_equals_unfused_at_full_size(world):
     assert np.isclose(out[0][0], out[1][0], rtol=2e-5)
     diff = (out[0][1] - out[1][1]).abs().max().item()
     assert diff < 5e-4 * max(1.0, out[0][1].abs().max().item()), diff
+    # ... and the bench's dominant kernel DIRECTLY against the oracle on the batch its in-kernel sampler draws
+    # (same Philox counters as kge_sample_batch): loss and both dense gradient tables
+    nb = tuple(a.cpu().numpy() for a in b)
+    loss_ref, G_ref, _, _ = ko.train_step_grads("transe", P, nb, l1_flag=True, margin=1.0)
+    assert np.isclose(out[1][0], loss_ref, rtol=2e-5), (out[1][0], loss_ref)
+    flat = out[1][1].cpu().numpy()
+    g_ent, g_rel = flat[:E * D].reshape(E, D), flat[E * D:E * D + R * D].reshape(R, D)
+    for got, name in ((g_ent, "ent_embeddings"), (g_rel, "rel_embeddings")):
+        scale = np.abs(G_ref[name]).max()
+        assert np.allclose(got, G_ref[name], atol=2e-5 * max(1.0, scale), rtol=1e-3), (name, np.abs(got - G_ref[name]).max())
 
 
 def test_hinge_loss_and_gradients_are_additive_over_batch_splits(world):

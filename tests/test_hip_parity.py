@@ -6,13 +6,40 @@ import pytest
 import torch
 
 import kge_oracle as ko
-from golden_util import CASES, Case, close
+from golden_util import CASES, Case, close, rank_band_ok
 
 pytestmark = pytest.mark.gpu
 
 VECTOR_CASES = list(CASES)
 EVAL_CASES = list(CASES)
 GRAD_TOL = dict(atol=2e-5, rtol=1e-4)
+
+
+def assert_ranks_inside_band(case, ranks, ref, scores, trips):
+    """Every rank that differs from the reference's must be explained by candidates inside the fp32 tolerance band
+    around the true candidate's energy (golden_util.rank_band_ok); the observed agreement is appended to
+    gpurun_out/rank_agreement.json (kept under profiles/ per round)."""
+    import json
+    import os
+    rep = {"queries": 2 * len(trips), "raw_equal": 0, "filtered_equal": 0, "max_abs_rank_diff": 0, "flips": []}
+    for i, (h, r, t) in enumerate(trips):
+        for side, row, true, a, b in (("tail", scores[2 * i], int(t), 1, 3), ("head", scores[2 * i + 1], int(h), 0, 2)):
+            ok_r, near = rank_band_ok(row, true, ranks[a, i], ref[a, i])
+            ok_f, _ = rank_band_ok(row, true, ranks[b, i], ref[b, i])
+            assert ok_r and ok_f, (case, i, side, ranks[:, i], ref[:, i], near)
+            rep["raw_equal"] += int(ranks[a, i] == ref[a, i])
+            rep["filtered_equal"] += int(ranks[b, i] == ref[b, i])
+            rep["max_abs_rank_diff"] = max(rep["max_abs_rank_diff"], abs(int(ranks[a, i]) - int(ref[a, i])))
+            if ranks[a, i] != ref[a, i] or ranks[b, i] != ref[b, i]:
+                rep["flips"].append({"triple": i, "side": side, "gpu": [int(ranks[a, i]), int(ranks[b, i])],
+                                     "reference": [int(ref[a, i]), int(ref[b, i])], "candidates_inside_band": near})
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "rank_agreement.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc[case] = rep
+    json.dump(doc, open(path, "w"), indent=1)
+    return rep
 
 
 @pytest.fixture(scope="module")
@@ -145,7 +172,8 @@ def test_eval_sweep_scores_and_ranks_match_reference(hip, name):
         rt = ko.rank_from_scores(scores[2 * i], int(t), hr_t[(int(h), int(r))])
         rh = ko.rank_from_scores(scores[2 * i + 1], int(h), tr_h[(int(t), int(r))])
         assert (ranks[1, i], ranks[3, i]) == rt and (ranks[0, i], ranks[2, i]) == rh
-    assert np.abs(ranks - ref).max() <= 1 and (ranks != ref).sum() <= 2, (ranks, ref)
+    rep = assert_ranks_inside_band(name, ranks, ref, scores, c.test[:n])
+    assert rep["raw_equal"] + rep["filtered_equal"] >= 4 * n - 2, rep   # and near-ties are rare
     metrics = ev.test(c.test, n, epoch=0)
     assert np.isclose(metrics["fmr"], c.z["eval.fmr"], rtol=0.02)
     if c.model in ("transh", "transd"):
@@ -190,7 +218,10 @@ def test_pretrained_fb15k_transe_slice(hip):
         n = len(z["eval_%s.rank_head" % key])
         ranks = Evaluator(m, cfg).rank_all(z["test"], n).cpu().numpy()
         ref = np.stack([z["eval_%s.%s" % (key, k)] for k in ("rank_head", "rank_tail", "frank_head", "frank_tail")])
-        assert (ranks != ref).sum() <= 3 and np.abs(ranks - ref).max() <= 2, (ranks != ref).sum()
+        from pykg2vec_amd import kernels as K
+        scores = K.eval_sweep_scores(m.make_desc(), hip.dev(z["test"][:n])).cpu().numpy()
+        rep = assert_ranks_inside_band("pretrained_fb15k_transe_" + key, ranks, ref, scores, z["test"][:n])
+        assert rep["raw_equal"] + rep["filtered_equal"] >= 4 * n - 3, rep
 
 
 SHAPES = [("transe", dict(hidden_size=50, l1_flag=True), 1), ("transe", dict(hidden_size=100, l1_flag=False), 1),
