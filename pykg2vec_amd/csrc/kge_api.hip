@@ -83,6 +83,17 @@ static int validate(const kge_model_desc* m, bool need_grads, const char* who) {
     return 0;
 }
 
+// The train-triple hash set packs a triple into one 64-bit key h:24 | r:16 | t:24 (kge_sampler_device.h): beyond these
+// ranges keys alias and valid negatives would be rejected silently, so every entry point that probes the set refuses.
+static int validate_packed_key(const kge_model_desc* m, const char* who) {
+    if (m->tot_entity > (1 << 24) || m->tot_relation > (1 << 16)) {
+        set_error("%s: the packed train-triple key holds 2^24 entities and 2^16 relations (got %lld / %lld)", who,
+                  (long long)m->tot_entity, (long long)m->tot_relation);
+        return -1;
+    }
+    return 0;
+}
+
 }  // namespace kge
 
 using namespace kge;
@@ -170,6 +181,7 @@ int kge_train_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* tri
                                      uint64_t seed, uint64_t offset, const int64_t* dev_cursor, float margin, float* loss,
                                      void* stream) {
     if (validate(m, true, "kge_train_pairwise_hinge_sampled")) return -1;
+    if (validate_packed_key(m, "kge_train_pairwise_hinge_sampled")) return -1;
     if (n == 0) return 0;
     if (n < 0 || start < 0 || !triples || !perm || !loss) { set_error("kge_train_pairwise_hinge_sampled: bad arguments"); return -1; }
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_train_pairwise_hinge_sampled: n_slots must be a power of two"); return -1; }
@@ -212,6 +224,7 @@ int kge_train_pairwise_selfadv_sampled(const kge_model_desc* m, const int64_t* t
                                        const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset,
                                        const int64_t* dev_cursor, float* loss, void* stream) {
     if (validate(m, true, "kge_train_pairwise_selfadv_sampled")) return -1;
+    if (validate_packed_key(m, "kge_train_pairwise_selfadv_sampled")) return -1;
     if (n_pos == 0) return 0;
     if (n_pos < 0 || start < 0 || neg_rate <= 0 || !triples || !perm || !loss) {
         set_error("kge_train_pairwise_selfadv_sampled: bad arguments");
@@ -238,6 +251,7 @@ int kge_train_pointwise_logistic_sampled(const kge_model_desc* m, const int64_t*
                                          int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor,
                                          float lmbda, int32_t reg_type, float* loss, void* stream) {
     if (validate(m, true, "kge_train_pointwise_logistic_sampled")) return -1;
+    if (validate_packed_key(m, "kge_train_pointwise_logistic_sampled")) return -1;
     if (n_pos == 0) return 0;
     if (n_pos < 0 || neg_rate < 1 || start < 0 || !triples || !perm || !loss) { set_error("kge_train_pointwise_logistic_sampled: bad arguments"); return -1; }
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_train_pointwise_logistic_sampled: n_slots must be a power of two"); return -1; }

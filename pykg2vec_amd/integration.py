@@ -1,0 +1,76 @@
+"""Drop-in wiring into an importable reference tree, without editing it.
+
+`install_models()` puts this package's model classes where `Importer().import_model_config` looks them up
+(pykg2vec/common.py:300-328 -> `pykg2vec.models.pairwise` / `.pointwise`).  `reference_trainer()` returns a subclass
+of the reference's own `pykg2vec.utils.trainer.Trainer` whose hot loop (`build_model`, `train_model_epoch`, the
+`train_step_*` methods and their private helpers) is this package's fused path, while everything outside the hot
+path -- `train_model`'s epoch / early-stopping / best-checkpoint logic, `tune_model`, `save_model`, `load_model`,
+`infer_*`, `export_embeddings`, `save_training_result`, `display` -- stays the reference's code, running over the
+drop-in models, generator and evaluator.
+"""
+import types
+
+PAIRWISE = ("TransE", "TransH", "TransD", "TransM", "TransR", "RotatE", "Rescal", "NTN")
+POINTWISE = ("DistMult", "Complex", "ComplexN3", "ANALOGY", "CP", "SimplE", "SimplE_ignr", "QuatE")
+
+
+def install_models():
+    import pykg2vec.models.pairwise as ref_pw
+    import pykg2vec.models.pointwise as ref_pt
+    from . import pairwise as pw, pointwise as pt
+    for name in PAIRWISE:
+        setattr(ref_pw, name, getattr(pw, name))
+    for name in POINTWISE:
+        setattr(ref_pt, name, getattr(pt, name))
+
+
+def reference_trainer(backend=None, process_group=None, use_graph=None):
+    """The reference Trainer class with the MI355X hot loop grafted in.  `backend` / `process_group` / `use_graph` are
+    forwarded to the hot path (see pykg2vec_amd.trainer.Trainer)."""
+    import pykg2vec.utils.trainer as ref_tr
+    from .common import Monitor
+    from .evaluator import Evaluator as HipEvaluator
+    from .generator import Generator as HipGenerator
+    from .trainer import Trainer as Hip
+
+    class Trainer(ref_tr.Trainer):
+        GRAPH_MAX_ROWS, GRAPH_UNROLL = Hip.GRAPH_MAX_ROWS, Hip.GRAPH_UNROLL
+
+        def __init__(self, model, config):
+            super().__init__(model, config)
+            self._init_hot_path(process_group, backend, use_graph)
+
+        def build_model(self, monitor=Monitor.FILTERED_MEAN_RANK):
+            if getattr(self.config, "load_from_data", None) is not None:   # utils/trainer.py:105-106
+                self.load_model(self.config.load_from_data)
+            Hip.build_model(self, monitor)
+            self.early_stopper = ref_tr.EarlyStopper(self.config.patience, monitor)   # the reference's own
+            if hasattr(self.config, "summary"):
+                self.config.summary()
+
+        # the reference's train_model / tune_model construct `Generator(model, config)` and `Evaluator(model, config,
+        # tuning=True)` from their module globals (utils/trainer.py:191,245-246): swap in the device-resident ones for
+        # the duration of the call
+        def _with_hip_collaborators(self, fn):
+            saved = ref_tr.Generator, ref_tr.Evaluator
+            ref_tr.Generator = lambda model, config: HipGenerator(model, config, rank=self.rank, world_size=self.world_size,
+                                                                  backend=self.K)
+            ref_tr.Evaluator = lambda model, config, tuning=False: HipEvaluator(model, config, tuning=tuning, backend=self.K)
+            try:
+                return fn()
+            finally:
+                ref_tr.Generator, ref_tr.Evaluator = saved
+
+        def train_model(self):
+            return self._with_hip_collaborators(lambda: ref_tr.Trainer.train_model(self))
+
+        def tune_model(self):
+            return self._with_hip_collaborators(lambda: ref_tr.Trainer.tune_model(self))
+
+    # the hot loop and its private helpers, taken from the class that owns them (no name list to keep in sync)
+    for name, fn in vars(Hip).items():
+        if isinstance(fn, types.FunctionType) and name not in vars(Trainer) and \
+                (name.startswith("_") and not name.startswith("__") or name in ("train_model_epoch", "train_step_pairwise",
+                                                                                 "train_step_pointwise")):
+            setattr(Trainer, name, fn)
+    return Trainer

@@ -324,6 +324,12 @@ def eval_ranks_via_forward(desc, triples, tail_off, tail_ids, head_off, head_ids
 def triple_set_build(triples):
     """Open-addressing hash set of the train triples (uint64 slots, power of two >= 2n)."""
     n = triples.shape[0]
+    if n:  # packed key h:24 | r:16 | t:24 (csrc/kge_sampler_device.h): out-of-range ids would alias silently
+        _ids(triples, "triples")
+        hi = triples.max(dim=0).values.tolist()
+        if triples.min().item() < 0 or max(hi[0], hi[2]) >= 1 << 24 or hi[1] >= 1 << 16:
+            raise L.KgeHipError("kge_triple_set_build: ids exceed the packed key (entities < 2^24, relations < 2^16): "
+                                "max h/r/t = %s" % hi)
     n_slots = 1 << max(4, math.ceil(math.log2(max(2 * n, 2))))
     slots = torch.empty(n_slots, dtype=torch.int64, device=triples.device)  # uint64 payload
     L.check(L.load().kge_triple_set_build(_ids(triples, "triples"), n, ctypes.c_void_p(slots.data_ptr()), n_slots,

@@ -6,8 +6,9 @@ Per step the reference issues ~30 ATen kernels, two autograd graphs, a dense tor
 buffer), at most one all-reduce of that buffer (data parallel over RCCL), one fused dense optimiser sweep over ONE
 flat parameter buffer (which also clears the gradients), and no host synchronisation until the epoch ends.
 
-Early stopping / checkpoint export / plotting are outside the hot path and stay with the
-reference; INTEGRATION.md shows how to graft `train_model_epoch` onto the reference Trainer.
+Checkpoint save/load, inference helpers, hyper-parameter tuning, export and plotting are outside the hot path
+ and stay with the reference: `pykg2vec_amd.integration.reference_trainer()` grafts this
+module's hot loop onto the reference's own Trainer class, which keeps all of those (tests/test_integration_graft.py).
 """
 import torch
 
@@ -60,26 +61,31 @@ class FlatState:
 
 
 class EarlyStopper:
-    """utils/trainer.py:21-69 (patience on the monitored metric)."""
+    """utils/trainer.py:21-69.  `patience_left` is decremented on a worse metric while it is positive; the trainer
+    stops on the next worse metric once it is 0 (so patience=3 stops on the 4th consecutive worse evaluation, and
+    patience=0 on the first); any non-worse evaluation resets it."""
 
     def __init__(self, patience, monitor):
         self.patience, self.monitor = patience, monitor
-        self.previous = None
-        self.remaining = patience
+        self.previous_metrics = None
+        self.patience_left = patience
 
-    def should_stop(self, metrics):
-        cur = metrics[self.monitor.value]
-        if self.previous is not None:
-            lower_is_better = self.monitor in (Monitor.MEAN_RANK, Monitor.FILTERED_MEAN_RANK)
-            worse = cur > self.previous if lower_is_better else cur < self.previous
-            if worse:
-                self.remaining -= 1
-                if self.remaining == 0:
-                    return True
+    def should_stop(self, curr_metrics):
+        should_stop = False
+        key = self.monitor.value
+        if self.previous_metrics is not None:
+            if self.monitor in (Monitor.MEAN_RANK, Monitor.FILTERED_MEAN_RANK):
+                is_worse = self.previous_metrics[key] < curr_metrics[key]
             else:
-                self.remaining = self.patience
-        self.previous = cur
-        return False
+                is_worse = self.previous_metrics[key] > curr_metrics[key]
+            if self.patience_left > 0 and is_worse:
+                self.patience_left -= 1
+            elif self.patience_left == 0 and is_worse:
+                should_stop = True
+            else:
+                self.patience_left = self.patience
+        self.previous_metrics = curr_metrics
+        return should_stop
 
 
 class Trainer:
@@ -90,18 +96,21 @@ class Trainer:
     GRAPH_UNROLL = 8        # steps per replayed multi-step graph (even; 0 = single-step graphs only)
 
     def __init__(self, model, config, process_group=None, backend=None, use_graph=None):
-        # `backend` exists so that the multi-process plumbing (batch sharding, gradient all-reduce, replica
-        # consistency) can be exercised on CPU/gloo with a checker injected by tests; the product default -- and the
-        # only backend this package contains -- is the HIP library, which raises without a GPU.
-        self.K = backend if backend is not None else K
         self.model = model
         self.config = config
         self.training_results = []
         self.evaluator = None
         self.generator = None
-        self.flat = None
         self.early_stopper = None
         self.monitor = None
+        self._init_hot_path(process_group, backend, use_graph)
+
+    def _init_hot_path(self, process_group=None, backend=None, use_graph=None):
+        # `backend` exists so that the multi-process plumbing (batch sharding, gradient collectives, replica
+        # consistency) can be exercised on CPU/gloo with a checker injected by tests; the product default -- and the
+        # only backend this package contains -- is the HIP library, which raises without a GPU.
+        self.K = backend if backend is not None else K
+        self.flat = None
         self.process_group = process_group
         self.use_graph = use_graph
         self._graph = None
@@ -229,7 +238,11 @@ class Trainer:
         return self.K.read_loss(self.loss_buf)
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
-    def _graph_wanted(self):
+    def _graph_wanted(self, num_batch=None):
+        # captured steps read perm[batch_idx * B + i] for all i < B with no per-step clamp (the eager path clamps in
+        # Generator._next_range): every batch of the epoch must lie inside the train permutation
+        if num_batch is not None and num_batch * int(self.config.batch_size) > self.generator.n_train:
+            return False
         if self.use_graph is not None:
             return bool(self.use_graph) and self.world_size == 1 and self.K is K
         rows = self.config.batch_size * (1 + self.config.neg_rate)
@@ -287,7 +300,7 @@ class Trainer:
         num_batch = self.config.tot_train_triples // self.config.batch_size if not self.config.debug else 10
         self.generator.start_one_epoch(num_batch)
         self.model.train()
-        if self._graph_wanted() and num_batch > 0:
+        if num_batch > 0 and self._graph_wanted(num_batch):
             self.loss_buf.zero_()
             gen = self.generator
             step0, draws0 = self.flat.step, gen._draws  # host mirrors of the device-resident counters
@@ -344,57 +357,3 @@ class Trainer:
             self.evaluator.full_test(cur_epoch_idx)
         self.generator.stop()
         return cur_epoch_idx
-
-    # ------------------------------------------------------------------ inference / persistence (utils/trainer.py:330-419)
-    def _infer(self, ids, id2name):
-        ids = ids.detach().cpu().numpy()
-        return {int(i): id2name[int(i)] for i in ids}
-
-    def infer_tails(self, h, r, topk=5):
-        idx2ent = self.config.knowledge_graph.read_cache_data('idx2entity')
-        return self._infer(self.evaluator.test_tail_rank(h, r, topk), idx2ent)
-
-    def infer_heads(self, r, t, topk=5):
-        idx2ent = self.config.knowledge_graph.read_cache_data('idx2entity')
-        return self._infer(self.evaluator.test_head_rank(r, t, topk), idx2ent)
-
-    def infer_rels(self, h, t, topk=5):
-        idx2rel = self.config.knowledge_graph.read_cache_data('idx2relation')
-        return self._infer(self.evaluator.test_rel_rank(h, t, topk), idx2rel)
-
-    def save_model(self):
-        """state_dict (reference key names) + pickled config next to it, as utils/trainer.py:389-397."""
-        import numpy as np
-        saved_path = self.config.path_tmp / self.model.model_name
-        saved_path.mkdir(parents=True, exist_ok=True)
-        torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()},
-                   str(saved_path / self.TRAINED_MODEL_FILE_NAME))
-        np.save(saved_path / self.TRAINED_MODEL_CONFIG_NAME, self.config)
-
-    def load_model(self, model_path=None):
-        """Load weights saved by this class or by the reference Trainer (same file names, same state_dict keys) into
-        the current model; the flat parameter buffer keeps backing the tables."""
-        from pathlib import Path
-        base = Path(model_path) if model_path is not None else self.config.path_tmp / self.model.model_name
-        f = base / self.TRAINED_MODEL_FILE_NAME
-        if not f.exists():
-            raise ValueError("Cannot load model from %s" % f)
-        state = torch.load(str(f), map_location="cpu")
-        with torch.no_grad():
-            own = self.model.state_dict()
-            for k, v in state.items():
-                own[k].copy_(v)
-        self.model.eval()
-
-    def tune_model(self):
-        current_loss = float("inf")
-        self.generator = self._new_generator()
-        self.evaluator = Evaluator(self.model, self.config, tuning=True, backend=self.K)
-        cur_epoch_idx = 0
-        for cur_epoch_idx in range(self.config.epochs):
-            current_loss = self.train_model_epoch(cur_epoch_idx, tuning=True)
-        self.model.eval()
-        with torch.no_grad():
-            self.evaluator.full_test(cur_epoch_idx)
-        self.generator.stop()
-        return current_loss

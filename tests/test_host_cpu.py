@@ -146,15 +146,19 @@ def test_product_never_imports_the_oracle():
 
 
 def test_early_stopper():
+    """utils/trainer.py:43-67: patience p stops on the (p+1)-th consecutive worse evaluation; p=0 on the first."""
     from pykg2vec_amd.common import Monitor
     from pykg2vec_amd.trainer import EarlyStopper
-    es = EarlyStopper(2, Monitor.FILTERED_MEAN_RANK)
-    assert not es.should_stop({"fmr": 10.0})
-    assert not es.should_stop({"fmr": 11.0})
-    assert es.should_stop({"fmr": 12.0})
+    for patience in (0, 1, 3):
+        es = EarlyStopper(patience, Monitor.FILTERED_MEAN_RANK)
+        assert not es.should_stop({"fmr": 10.0})
+        seq = [es.should_stop({"fmr": 10.0 + k}) for k in range(1, patience + 2)]
+        assert seq == [False] * patience + [True], (patience, seq)
     es = EarlyStopper(1, Monitor.MEAN_RECIPROCAL_RANK)
     assert not es.should_stop({"mrr": 0.2})
-    assert not es.should_stop({"mrr": 0.3})
+    assert not es.should_stop({"mrr": 0.1})     # worse: one chance left -> 0
+    assert not es.should_stop({"mrr": 0.3})     # better: patience restored
+    assert not es.should_stop({"mrr": 0.2})
     assert es.should_stop({"mrr": 0.1})
 
 
