@@ -44,7 +44,9 @@ def reference_trainer(backend=None, process_group=None, use_graph=None):
             if getattr(self.config, "load_from_data", None) is not None:   # utils/trainer.py:105-106
                 self.load_model(self.config.load_from_data)
             Hip.build_model(self, monitor)
-            self.early_stopper = ref_tr.EarlyStopper(self.config.patience, monitor)   # the reference's own
+            # the reference's own stopper, keyed by the reference's own enum (this package defines stand-in enums when
+            # it was imported before the reference became importable)
+            self.early_stopper = ref_tr.EarlyStopper(self.config.patience, ref_tr.Monitor(monitor.value))
             if hasattr(self.config, "summary"):
                 self.config.summary()
 

@@ -114,7 +114,7 @@ def test_early_stopper_equals_the_reference_one():
     for monitor in (Monitor.FILTERED_MEAN_RANK, Monitor.MEAN_RECIPROCAL_RANK):
         for patience in (0, 1, 3):
             for _ in range(20):
-                a, b = EarlyStopper(patience, monitor), ref_tr.EarlyStopper(patience, monitor)
+                a, b = EarlyStopper(patience, monitor), ref_tr.EarlyStopper(patience, ref_tr.Monitor(monitor.value))
                 for v in rng.integers(0, 4, size=12):
                     m = {monitor.value: float(v)}
                     assert a.should_stop(m) == b.should_stop(m)
