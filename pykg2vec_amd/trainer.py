@@ -24,9 +24,15 @@ def _log(msg):
 
 class FlatState:
     """All parameter tables of a model re-homed into one flat fp32 buffer (16-byte aligned segments) with matching
-    flat gradient and optimiser-state buffers: one optimiser launch and one collective per step."""
+    flat gradient and optimiser-state buffers: one optimiser launch per step and one pair of collectives.
 
-    def __init__(self, model, optimizer, backend=K):
+    Data parallel (world_size N > 1): the flat buffers are padded to a multiple of 4*N floats and cut into N equal
+    shards.  Every rank keeps the full parameters and its full local gradient, but the optimiser STATE (Adam moments,
+    Adagrad / RMSprop accumulators) only for its own shard, and runs the dense optimiser sweep only over that shard:
+    reduce-scatter(grad) -> optimiser on 1/N of the tables -> all-gather(param).  Same bytes on the wire as an
+    all-reduce, 1/N of the optimiser sweep (the B-independent part of the step) and of its state memory."""
+
+    def __init__(self, model, optimizer, backend=K, world_size=1, rank=0):
         self.K = backend
         params = [p.weight for p in model.parameter_list]
         dev = params[0].device
@@ -34,7 +40,12 @@ class FlatState:
         for p in params:
             offs.append(tot)
             tot += (p.numel() + 3) // 4 * 4
+        quantum = 4 * world_size
+        tot = (tot + quantum - 1) // quantum * quantum
         self.numel = tot
+        self.world_size, self.rank = world_size, rank
+        self.shard_numel = tot // world_size
+        self.shard_lo = rank * self.shard_numel
         self.param = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.views, self.grad_views = [], []
@@ -45,18 +56,23 @@ class FlatState:
             self.views.append(v)
             self.grad_views.append(self.grad[o:o + p.numel()].view_as(p))
         self.optimizer = optimizer
-        self.state1 = torch.zeros_like(self.param) if optimizer in ("adam", "adagrad", "rms") else None
-        self.state2 = torch.zeros_like(self.param) if optimizer == "adam" else None
+        self.param_shard = self.param[self.shard_lo:self.shard_lo + self.shard_numel]
+        # reduced gradient of this rank's shard: the full buffer itself when there is nothing to reduce
+        self.grad_shard = self.grad if world_size == 1 else torch.zeros(self.shard_numel, dtype=torch.float32, device=dev)
+        self.state1 = torch.zeros_like(self.param_shard) if optimizer in ("adam", "adagrad", "rms") else None
+        self.state2 = torch.zeros_like(self.param_shard) if optimizer == "adam" else None
         self.step = 0
 
     def optimizer_step_advance(self, lr, hyper, cursor, next_cursor, next_hyper, batch_stride, n_batches, draws):
         self.step += 1
-        self.K.optimizer_step_advance(self.optimizer, self.param, self.grad, self.state1, self.state2, lr, hyper, cursor,
-                                      next_cursor, next_hyper, batch_stride, n_batches, draws, zero_grad=True)
+        self.K.optimizer_step_advance(self.optimizer, self.param_shard, self.grad_shard, self.state1, self.state2, lr, hyper,
+                                      cursor, next_cursor, next_hyper, batch_stride, n_batches, draws, zero_grad=True)
 
     def optimizer_step(self, lr, dev_hyper=None):
+        """Dense optimiser sweep over this rank's shard (the whole buffer when world_size == 1); clears the reduced
+        gradient it consumed."""
         self.step += 1
-        self.K.optimizer_step(self.optimizer, self.param, self.grad, self.state1, self.state2, lr, self.step,
+        self.K.optimizer_step(self.optimizer, self.param_shard, self.grad_shard, self.state1, self.state2, lr, self.step,
                               zero_grad=True, dev_hyper=dev_hyper)
 
 
@@ -125,7 +141,7 @@ class Trainer:
         if self.config.optimizer not in K.OPTIMIZER_IDS:  # sgd / adam / adagrad / rms (utils/trainer.py:112-131)
             raise NotImplementedError("No support for %s optimizer" % self.config.optimizer)
         self.model.to(self.config.device)
-        self.flat = FlatState(self.model, self.config.optimizer, self.K)
+        self.flat = FlatState(self.model, self.config.optimizer, self.K, self.world_size, self.rank)
         self.evaluator = Evaluator(self.model, self.config, backend=self.K)
         self.loss_buf = self.K.new_loss_buffer(self.flat.param.device)
         self.early_stopper = EarlyStopper(getattr(self.config, "patience", 3), monitor)
@@ -145,7 +161,8 @@ class Trainer:
         else:
             self.K.train_pairwise_hinge(self._desc, ph, pr, pt, nh, nr, nt, self.config.margin, self.loss_buf)
             if self.model.kernel_name == "ntn":  # + get_reg(None, None, None) (utils/trainer.py:155): dense L2-norm
-                self.K.l2norm_reg(self.flat.param, self.flat.grad, self.model.lmbda, self.loss_buf)
+                # (one regulariser per GLOBAL step: the hinge gradients are summed over ranks)
+                self.K.l2norm_reg(self.flat.param, self.flat.grad, self.model.lmbda / self.world_size, self.loss_buf)
 
     def _fused_sampler_ok(self):
         """Sampler + scoring + hinge + backward in one kernel: gather-type pairwise-hinge models with neg_rate 1."""
@@ -210,21 +227,44 @@ class Trainer:
         return (self.model.training_strategy != TrainingStrategy.PAIRWISE_BASED
                 or self.model.model_name.lower() == "rotate")
 
-    def _reduce_and_step(self):
-        if self.world_size > 1:
-            # ONE collective per step over the flat gradient buffer.  Sum for the hinge; for mean-type losses each
-            # rank already divided by its local row count, so the global-batch mean is the average over ranks
-            # (exact when the global batch divides evenly over ranks).
-            dist = torch.distributed
-            if self._mean_type_loss():
-                if dist.get_backend(self.process_group) == "nccl":
-                    dist.all_reduce(self.flat.grad, op=dist.ReduceOp.AVG, group=self.process_group)
-                else:
-                    dist.all_reduce(self.flat.grad, group=self.process_group)
-                    self.flat.grad.div_(self.world_size)
+    def _collectives(self):
+        """(reduce_scatter_ok, backend name) of the process group: RCCL ("nccl") has the fused primitives; gloo (CPU
+        tests, ranks sharing one GPU) gets the same result from all_reduce + slice."""
+        name = torch.distributed.get_backend(self.process_group)
+        return name == "nccl", name
+
+    def _reduce_and_step(self, advance=None):
+        """Gradient exchange (N > 1) + dense optimiser.  `advance`: the device-resident step-state arguments of
+        FlatState.optimizer_step_advance when the step is being captured into a hipGraph."""
+        flat = self.flat
+
+        def optimise():
+            if advance is not None:
+                flat.optimizer_step_advance(self.config.learning_rate, *advance)
             else:
-                dist.all_reduce(self.flat.grad, group=self.process_group)
-        self.flat.optimizer_step(self.config.learning_rate)
+                flat.optimizer_step(self.config.learning_rate)
+
+        if self.world_size == 1:
+            optimise()
+            return
+        # Sharded data-parallel step: reduce-scatter the flat gradient (each rank receives the SUM -- or, for the
+        # mean-type losses, the AVERAGE, since each rank already divided by its local row count -- of its 1/N shard),
+        # run the dense optimiser on that shard only, all-gather the updated parameters in place.  Replicas hold
+        # byte-identical tables afterwards by construction (everyone receives the same shards).
+        dist = torch.distributed
+        mean = self._mean_type_loss()
+        fused, _ = self._collectives()
+        if fused:
+            dist.reduce_scatter_tensor(flat.grad_shard, flat.grad, op=dist.ReduceOp.AVG if mean else dist.ReduceOp.SUM,
+                                       group=self.process_group)
+        else:
+            dist.all_reduce(flat.grad, group=self.process_group)
+            flat.grad_shard.copy_(flat.grad[flat.shard_lo:flat.shard_lo + flat.shard_numel])
+            if mean:
+                flat.grad_shard.div_(self.world_size)
+        flat.grad.zero_()          # the local accumulation buffer of the next step (the optimiser clears only grad_shard)
+        optimise()
+        dist.all_gather_into_tensor(flat.param, flat.param_shard, group=self.process_group)
 
     def train_step_pairwise(self, pos_h, pos_r, pos_t, neg_h, neg_r, neg_t):
         """Loss of one batch as a device scalar (no sync); gradients are left in the flat buffer."""
@@ -243,10 +283,18 @@ class Trainer:
         # Generator._next_range): every batch of the epoch must lie inside the train permutation
         if num_batch is not None and num_batch * int(self.config.batch_size) > self.generator.n_train:
             return False
+        if self.K is not K:
+            return False
+        if self.world_size > 1:
+            # RCCL collectives are capturable (gloo is not); multi-rank capture is opt-in (use_graph=True or
+            # KGE_GRAPH_MULTI=1) because it cannot be exercised on the single-GPU boxes this repo is tested on
+            import os
+            asked = bool(self.use_graph) or (self.use_graph is None and os.environ.get("KGE_GRAPH_MULTI") == "1")
+            return asked and self._collectives()[0] and self.config.batch_size % self.world_size == 0
         if self.use_graph is not None:
-            return bool(self.use_graph) and self.world_size == 1 and self.K is K
+            return bool(self.use_graph)
         rows = self.config.batch_size * (1 + self.config.neg_rate)
-        return self.world_size == 1 and self.K is K and rows <= self.GRAPH_MAX_ROWS
+        return rows <= self.GRAPH_MAX_ROWS
 
     def _capture_step(self, num_batch):
         """Capture [sample ->] fused step -> optimiser (+ next step's state) once per state parity; per-step values
@@ -265,14 +313,16 @@ class Trainer:
         hyp = [self._hyper[0:4], self._hyper[4:8]]
         cur[0][2] = self.flat.step
         cur[0][4] = gen._draws
-        self._sbuf = K.sample_buffer(B, gen.neg_rate, pointwise, dev)
+        self._sbuf = K.sample_buffer(B // self.world_size, gen.neg_rate, pointwise, dev)
         self._graph_batches = num_batch
         K.step_advance(cur[0], hyp[0], B, num_batch, B * gen.neg_rate, cfg.learning_rate)  # state of the first step
 
+        per = B // self.world_size           # this rank's slice of every batch (Philox counters stay global)
+        shard = (self.rank * per, per, self.rank * per * gen.neg_rate)
+
         def body(p):
-            self._accumulate_next_batch(cursor=cur[p], fixed_range=(0, B, 0))
-            self.flat.optimizer_step_advance(cfg.learning_rate, hyp[p], cur[p], cur[1 - p], hyp[1 - p], B, num_batch,
-                                             B * gen.neg_rate)
+            self._accumulate_next_batch(cursor=cur[p], fixed_range=shard)
+            self._reduce_and_step(advance=(hyp[p], cur[p], cur[1 - p], hyp[1 - p], B, num_batch, B * gen.neg_rate))
 
         body(0)  # the epoch's FIRST step runs eagerly (loads kernels, sizes workspaces) ...
         torch.cuda.synchronize()
