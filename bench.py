@@ -4,18 +4,23 @@ FB15k-shape TransE d=100 (configs[1]).
 
 A *step* is one pass of the training hot path over one batch of the HBM-resident train set: ONE kernel does the
 negative corruption, score(+), score(-), hinge and the backward scatter (kge_train_pairwise_hinge_sampled)
--> [N>1: RCCL all-reduce of the flat dense gradient buffer] -> fused dense Adam sweep (kge_optimizer_step).
-Nothing is skipped or cached inside the timed region.  After the timed training steps the same process times
-the filtered-rank evaluation sweep (kge_eval_ranks) and, on rank 0 at N=1, the CPU baseline (a multi-threaded C
-*port* of the reference algorithm, oracle/kge_oracle_c.c, pinned to the numpy oracle and the reference's golden
-vectors -- on a bounded sample of the same workload, all host cores).
+-> [N>1: RCCL reduce-scatter of the flat dense gradient] -> fused dense Adam sweep over the rank's 1/N shard
+(kge_optimizer_step) -> [N>1: RCCL all-gather of the updated tables].  Nothing is skipped or cached inside the timed
+region.  After the timed training steps the same process times the filtered-rank evaluation sweep (kge_eval_ranks),
+the other BASELINE configs (C2 ComplEx-WN18RR, C3 RotatE-FB15k-237, C4 RESCAL-YAGO3-10; N=1 only, `extra`) and, on
+rank 0 at N=1, the CPU baseline (a multi-threaded C *port* of the reference algorithm, oracle/kge_oracle_c.c, pinned
+to the numpy oracle and the reference's golden vectors -- on a bounded sample of the same workload, all host cores).
 
-Launch:  python bench.py [--gpus N --steps K --warmup W]      (N>1: via torch.distributed.run, one rank per GPU)
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+         N>1 without a torch.distributed environment: bench.py re-executes itself under torch.distributed.run
+         (one rank per GPU); an existing RANK/WORLD_SIZE environment (torchrun) is used as is.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -31,45 +36,56 @@ DIM = 100
 TRAIN_BYTES_PER_SCORED_TRIPLE = 3 * DIM * 4 * 3 + 28   # 3 628 B: fwd gather + grad read-modify-write + ids
 EVAL_BYTES_PER_CANDIDATE = DIM * 4                      # 400 B: one candidate row read once
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
+# VALU issue roof of the L1 rank sweep (k_eval_sweep<L1>): per (query, candidate) ELEMENT the kernel issues 1.5 VALU
+# instructions (half a v_pk_add_f32 for the subtraction + one v_add_f32 |d|); tools/valu_bench.hip measures what that
+# instruction mix sustains with operands in registers (profiles/r02_valu_bench.txt): the roof below is in elements/s
+# for the whole chip at the 2.4 GHz peak clock.
+VALU_SIMDS = 256 * 4
+VALU_PEAK_CLOCK_HZ = 2.4e9
+L1_SWEEP_CYCLES_PER_ELEMENT_PER_WAVE = 4.0              # 1 v_pk_add_f32 (2 elements) + 2 v_add_f32 |x| per 2 elements
+L1_SWEEP_ISSUES_PER_ELEMENT = 1.5
+MIN_WARM_SECONDS = 0.05                                 # warm until >= 50 ms of GPU work has run, whatever --warmup says
 
 
 class _KG:
-    def __init__(self, cache):
+    def __init__(self, cache, name="fb15k-shape-synthetic"):
         self.cache = cache
-        self.dataset_name = "fb15k-shape-synthetic"
+        self.dataset_name = name
 
     def read_cache_data(self, key):
         return self.cache[key]
 
 
-def synthetic_fb15k(seed=1234):
+def synthetic_split(E_, R_, sizes, seed=1234):
     rng = np.random.default_rng(seed)
 
     def draw(n):
-        return np.stack([rng.integers(E, size=n), rng.integers(R, size=n), rng.integers(E, size=n)], 1).astype(np.int64)
+        return np.stack([rng.integers(E_, size=n), rng.integers(R_, size=n), rng.integers(E_, size=n)], 1).astype(np.int64)
 
-    return draw(N_TRAIN), draw(N_VALID), draw(N_TEST)
+    return tuple(draw(n) for n in sizes)
 
 
-def make_config(train, valid, test, batch_size, device, n_filter_triples):
-    # hr_t / tr_h filter sets over train+valid+test (kgcontroller.py:410-428); built only for the evaluated triples
+def make_config(E_, R_, n_train, batch_size, device, **hp):
     cfg = types.SimpleNamespace(
-        tot_entity=E, tot_relation=R, device=device, optimizer="adam", learning_rate=0.01, neg_rate=1, alpha=0.1,
+        tot_entity=E_, tot_relation=R_, device=device, optimizer="adam", learning_rate=0.01, neg_rate=1, alpha=0.1,
         margin=1.0, batch_size=batch_size, epochs=1, test_num=0, test_step=1, debug=False, hits=[1, 3, 5, 10],
-        patience=3, dataset_name="fb15k-shape-synthetic", sampling="uniform", tot_train_triples=N_TRAIN, seed=0,
-        hidden_size=DIM, l1_flag=True, knowledge_graph=None)
+        patience=3, dataset_name="synthetic", sampling="uniform", tot_train_triples=n_train, seed=0,
+        knowledge_graph=None)
+    for k, v in hp.items():
+        setattr(cfg, k, v)
     return cfg
 
 
-def build_filters(all_triples, queries):
+def build_filters(all_triples, queries, R_):
     """hr_t / tr_h restricted to the keys the evaluated queries use (same sets the reference would look up)."""
     want_hr = {(int(h), int(r)) for h, r, t in queries}
     want_tr = {(int(t), int(r)) for h, r, t in queries}
     hr_t, tr_h = {k: set() for k in want_hr}, {k: set() for k in want_tr}
-    key_hr = all_triples[:, 0] * R + all_triples[:, 1]
-    key_tr = all_triples[:, 2] * R + all_triples[:, 1]
-    q_hr = np.fromiter((h * R + r for h, r in want_hr), dtype=np.int64)
-    q_tr = np.fromiter((t * R + r for t, r in want_tr), dtype=np.int64)
+    key_hr = all_triples[:, 0] * R_ + all_triples[:, 1]
+    key_tr = all_triples[:, 2] * R_ + all_triples[:, 1]
+    q_hr = np.fromiter((h * R_ + r for h, r in want_hr), dtype=np.int64)
+    q_tr = np.fromiter((t * R_ + r for t, r in want_tr), dtype=np.int64)
     for row in all_triples[np.isin(key_hr, q_hr)]:
         hr_t[(int(row[0]), int(row[1]))].add(int(row[2]))
     for row in all_triples[np.isin(key_tr, q_tr)]:
@@ -133,6 +149,18 @@ def cpu_baseline_eval(P_np, test, csr, budget_s=8.0):
     return n / (time.perf_counter() - t0), n
 
 
+def reference_cpu_numbers():
+    """The UNMODIFIED reference's CPU-PyTorch throughput on this workload, measured in the build container (the
+    reference tree cannot travel to the GPU box): profiles/r02_reference_cpu_baseline.json, written by
+    tools/ref_cpu_baseline.py.  Reported next to the in-run port; never used as `value`."""
+    path = os.path.join(ROOT, "profiles", "r02_reference_cpu_baseline.json")
+    if not os.path.exists(path):
+        return None
+    doc = json.load(open(path))
+    return {"train_scored_triples_per_s": doc["train"]["value"], "eval_test_triples_per_s": doc["eval"]["value"],
+            "cores": doc["cores"], "host": doc["host"], "source": "profiles/r02_reference_cpu_baseline.json"}
+
+
 def pmc_traffic(kernel_prefix, batch):
     """HBM bytes per launch of the dominant train kernel from the committed rocprofv3 PMC passes
     (profiles/*pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, separate passes, same bench command and batch size).
@@ -148,6 +176,94 @@ def pmc_traffic(kernel_prefix, batch):
     return None, None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no torch.distributed environment: re-execute under torch.distributed.run, one
+    rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def timed_epochs(tr, steps_per_epoch, n_epochs=1):
+    """One warm-up epoch (captures the hipGraph when the step is launch-bound), then n_epochs timed ones."""
+    import torch
+    tr.train_model_epoch(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e in range(n_epochs):
+        tr.train_model_epoch(1 + e)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (n_epochs * steps_per_epoch)
+
+
+# the other BASELINE.json configs (SURVEY.md 8d): shapes, presets, algorithmic bytes / flops per unit
+EXTRA_CONFIGS = {
+    "C2": dict(name="ComplEx WN18RR-shape d=200, pointwise logistic + F2 reg, Adagrad, B=5000 (+5000 negatives)",
+               model="complex", E=40943, R=11, splits=(86835, 3034, 3134), hp=dict(hidden_size=200, lmbda=1e-4),
+               optimizer="adagrad", batch=5000, neg=1, n_eval=3134, train_bytes=14428, eval_bytes=1600),
+    "C3": dict(name="RotatE FB15k-237-shape d=1000, self-adversarial neg 16, Adam, B=1024",
+               model="rotate", E=14541, R=237, splits=(272115, 17535, 20466),
+               hp=dict(hidden_size=1000, margin=24.0, alpha=1.0), optimizer="adam", batch=1024, neg=16, n_eval=2048,
+               train_bytes=60028, eval_bytes=8000),
+    "C4": dict(name="RESCAL YAGO3-10-shape k=200, hinge, Adam, B=1024 (f32 MFMA path)",
+               model="rescal", E=123182, R=37, splits=(1079040, 5000, 5000), hp=dict(hidden_size=200, margin=1.0),
+               optimizer="adam", batch=1024, neg=1, n_eval=1024, train_bytes=4828, eval_bytes=800, train_flops=80400),
+}
+
+
+def run_extra_config(key, device):
+    import torch
+    import pykg2vec_amd as pa
+    from pykg2vec_amd.evaluator import Evaluator
+    from pykg2vec_amd.trainer import Trainer
+    c = EXTRA_CONFIGS[key]
+    E_, R_ = c["E"], c["R"]
+    train, valid, test = synthetic_split(E_, R_, c["splits"], seed=1234)
+    q = test[:c["n_eval"]]
+    hr_t, tr_h = build_filters(np.concatenate([train, valid, test]), q, R_)
+    hp = dict(c["hp"])
+    cfg = make_config(E_, R_, len(train), c["batch"], device, optimizer=c["optimizer"], neg_rate=c["neg"], **hp)
+    cfg.knowledge_graph = _KG({"triplets_train": train, "triplets_valid": valid[:16], "triplets_test": q, "hr_t": hr_t,
+                               "tr_h": tr_h}, key)
+    torch.manual_seed(0)
+    model = pa.import_model(c["model"])(**cfg.__dict__)
+    tr = Trainer(model, cfg)
+    tr.build_model()
+    tr.generator = tr._new_generator()
+    steps = min(200, len(train) // c["batch"])
+    cfg.tot_train_triples = steps * c["batch"]
+    dt = timed_epochs(tr, steps)
+    rows = c["batch"] * (1 + c["neg"])
+    ev = Evaluator(model, cfg)
+    ev.rank_all(q, len(q))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        ev.rank_all(q, len(q))
+    torch.cuda.synchronize()
+    edt = (time.perf_counter() - t0) / reps
+    out = {"workload": c["name"], "mode": "hipGraph replay" if tr._graph is not None else "eager",
+           "step_us": dt * 1e6, "scored_triples_per_s": rows / dt,
+           "train_algorithmic_GBps_whole_step": rows * c["train_bytes"] / dt / 1e9,
+           "train_hbm_frac_whole_step": rows * c["train_bytes"] / dt / 1e9 / HBM_PEAK_GBS,
+           "eval_test_triples_per_s": len(q) / edt, "eval_ms_per_pass": edt * 1e3, "eval_test_triples": len(q),
+           "eval_algorithmic_GBps": 2.0 * len(q) * E_ * c["eval_bytes"] / edt / 1e9}
+    if "train_flops" in c:
+        out["train_TFLOPs_whole_step"] = rows * c["train_flops"] / dt / 1e12
+        out["train_mfma_frac_whole_step"] = out["train_TFLOPs_whole_step"] / MFMA_F32_PEAK_TFLOPS
+    del tr, ev, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,7 +272,11 @@ def main():
     ap.add_argument("--batch", type=int, default=32768, help="positives per GPU per step (weak scaling)")
     ap.add_argument("--eval-triples", type=int, default=8192, help="test triples ranked per GPU in the eval leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the C2 / C3 / C4 `extra` records (N=1 only)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -164,11 +284,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     # one rank per GPU; KGE_BENCH_SHARE_GPU=1 (tests only) lets the ranks of a 1-GPU box share device 0 over gloo, which
-    # exercises the whole N>1 path (sharded sampler stream, gradient all-reduce, replica consistency) on real kernels
+    # exercises the whole N>1 path (sharded sampler stream, gradient exchange, sharded optimiser, replica consistency)
     share = os.environ.get("KGE_BENCH_SHARE_GPU") == "1"
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
@@ -185,11 +303,11 @@ def main():
     from pykg2vec_amd.evaluator import Evaluator, build_filter_csr
     from pykg2vec_amd.trainer import Trainer
 
-    train, valid, test = synthetic_fb15k()
+    train, valid, test = synthetic_split(E, R, (N_TRAIN, N_VALID, N_TEST))
     n_eval = min(args.eval_triples, N_TEST // world)
     my_test = test[rank * n_eval:(rank + 1) * n_eval]  # queries sharded over ranks, tables replicated: no collective
-    hr_t, tr_h = build_filters(np.concatenate([train, valid, test]), my_test)
-    cfg = make_config(train, valid, test, args.batch * world, device, n_eval)
+    hr_t, tr_h = build_filters(np.concatenate([train, valid, test]), my_test, R)
+    cfg = make_config(E, R, N_TRAIN, args.batch * world, device, hidden_size=DIM, l1_flag=True)
     cfg.knowledge_graph = _KG({"triplets_train": train, "triplets_valid": valid[:16], "triplets_test": my_test,
                                "hr_t": hr_t, "tr_h": tr_h})
     torch.manual_seed(0)
@@ -216,8 +334,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- warm-up: the W steps asked for, then more until >= MIN_WARM_SECONDS of GPU work has run (clocks, caches,
+    # code objects, RCCL channels), so that a short timed region measures the steady state
     for _ in range(args.warmup):
         one_step()
+    torch.cuda.synchronize()
+    warm_extra, t_warm = 0, time.perf_counter()
+    while True:
+        flag = torch.tensor([float(time.perf_counter() - t_warm < MIN_WARM_SECONDS)], device=device)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)   # every rank runs the same number of collective steps
+        if flag.item() == 0.0:
+            break
+        for _ in range(16):
+            one_step()
+        warm_extra += 16
+        torch.cuda.synchronize()
+
+    # ---- the timed region: EXACTLY --steps steps between barrier + synchronize on both sides
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
@@ -229,10 +363,27 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    per_rank_batch = next(iter([args.batch]))
+    per_rank_batch = args.batch
     scored_per_step = 2 * per_rank_batch * world
     value = scored_per_step * args.steps / dt
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    # HIP events around each launch of the timed region: they bracket [dispatch gap after the previous kernel + the
+    # kernel], i.e. an upper bound of the kernel's duration ...
+    event_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    # ... the kernel's own duration (what rocprofv3 --kernel-trace reports, profiles/) is measured right after the
+    # timed region by a burst of back-to-back launches of the SAME kernel on the same stream between two events: no
+    # host gap, no optimiser in between (gradients just keep accumulating; they are cleared afterwards)
+    burst = 32
+    if gen._pending < burst:
+        gen.start_one_epoch(steps_per_epoch)
+    eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    eb0.record()
+    for _ in range(burst):
+        tr._accumulate_next_batch()
+    eb1.record()
+    torch.cuda.synchronize()
+    kern_ms = eb0.elapsed_time(eb1) / burst
+    tr.flat.grad.zero_()
     alg_bytes = 2 * per_rank_batch * TRAIN_BYTES_PER_SCORED_TRIPLE
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
@@ -243,7 +394,7 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    reps = 3
+    reps = 5
     for _ in range(reps):
         ranks = ev.rank_all(my_test, n_eval)
     e1.record()
@@ -255,29 +406,26 @@ def main():
     edt = float(te.item())
     eval_value = n_eval * world / edt
     eval_kern_ms = e0.elapsed_time(e1) / reps
+    eval_elements = 2.0 * n_eval * E * DIM                       # (query, candidate, k) elements per pass
+    eval_elem_rate = eval_elements / (eval_kern_ms * 1e-3)
+    valu_peak_elems = VALU_SIMDS * 64.0 / L1_SWEEP_CYCLES_PER_ELEMENT_PER_WAVE * VALU_PEAK_CLOCK_HZ
     eval_alg = 2.0 * n_eval * E * EVAL_BYTES_PER_CANDIDATE
-    eval_ach = eval_alg / (eval_kern_ms * 1e-3) / 1e9
     mean_rank = float(ranks[:2].float().mean().item()) + 1.0
 
     # ---- the reference's DEFAULT batch (B=128, common.py:48) through Trainer.train_model_epoch: the launch-bound
     # regime, replayed as a hipGraph (N=1 only; informational, not `value`)
     small = None
     if world == 1:
-        cfg_s = make_config(train, valid, test, 128, device, 0)
+        cfg_s = make_config(E, R, 128 * 400, 128, device, hidden_size=DIM, l1_flag=True)
         cfg_s.knowledge_graph = cfg.knowledge_graph
-        cfg_s.tot_train_triples = 128 * 400
         torch.manual_seed(0)
         tr_s = Trainer(pw.TransE(**cfg_s.__dict__), cfg_s)
         tr_s.build_model()
         tr_s.generator = tr_s._new_generator()
-        tr_s.train_model_epoch(0)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        tr_s.train_model_epoch(1)
-        torch.cuda.synchronize()
-        dts = (time.perf_counter() - ts) / 400
+        dts = timed_epochs(tr_s, 400)
         small = {"batch": 128, "value": 256 / dts, "unit": "scored triples/s", "ms_per_step": dts * 1e3,
                  "mode": "hipGraph replay, 8 steps per graph, of fused step + Adam (next step's state derived inside the Adam launch)" if tr_s._graph is not None else "eager"}
+        del tr_s
 
     out = None
     traffic, traffic_src = pmc_traffic("kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch)
@@ -290,22 +438,44 @@ def main():
             "config": {"workload": "FB15k-shape TransE d=100 L1 margin=1.0 hinge, neg_rate=1, dense Adam lr=0.01, "
                                    "on-device uniform corruption; E=14951 R=1345 train=483142",
                        "batch_per_gpu": per_rank_batch, "global_batch": per_rank_batch * world,
-                       "scored_triples_per_step": scored_per_step, "parallelism": "dp%d" % world},
+                       "scored_triples_per_step": scored_per_step, "parallelism": "dp%d" % world,
+                       "warmup_steps_run": args.warmup + warm_extra},
             "roofline": {"kernel": "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": kern_ms},
+                         "avg_launch_ms": kern_ms,
+                         "avg_launch_ms_method": "HIP events around a burst of %d back-to-back launches of the kernel "
+                                                 "right after the timed region (= rocprofv3 kernel duration)" % burst,
+                         "timed_region_event_ms": event_ms,
+                         "timed_region_event_ms_note": "HIP events around each launch inside the timed region: includes "
+                                                       "the dispatch gap in front of the kernel"},
             "eval": {"value": eval_value, "unit": "test triples ranked/s", "test_triples_per_gpu": n_eval,
                      "ms_per_pass": edt * 1e3, "mean_rank_check": mean_rank,
-                     "roofline": {"kernel": "kge_eval_ranks pipeline (k_eval_sweep dominant)", "bound": "hbm",
-                                  "achieved": eval_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": eval_ach / HBM_PEAK_GBS, "traffic": None,
-                                  "note": "algorithmic bytes = 400 B per scored candidate; each candidate tile is "
-                                          "reused by 16 queries from registers, so the sweep is VALU-bound and the "
-                                          "algorithmic rate may exceed the HBM peak"}},
+                     "roofline": {"kernel": "kge_eval_ranks pipeline (k_eval_sweep<L1,QT=16> dominant)", "bound": "valu",
+                                  "achieved": eval_elem_rate / 1e12, "peak": valu_peak_elems / 1e12,
+                                  "unit": "T (query,candidate,k) elements/s", "frac": eval_elem_rate / valu_peak_elems,
+                                  "valu_issues_per_element": L1_SWEEP_ISSUES_PER_ELEMENT,
+                                  "achieved_lane_issues_per_s": eval_elem_rate * L1_SWEEP_ISSUES_PER_ELEMENT,
+                                  "peak_note": "1024 SIMDs x 64 lanes / 4 cycles per element per wave (1 v_pk_add_f32 + "
+                                               "2 v_add_f32 |x| per 2 elements; tools/valu_bench.hip, "
+                                               "profiles/r02_valu_bench.txt) x 2.4 GHz",
+                                  "algorithmic_GBps": eval_alg / (eval_kern_ms * 1e-3) / 1e9,
+                                  "algorithmic_note": "400 B per scored candidate (SURVEY 8d); each candidate tile is "
+                                                      "reused by 16 queries from registers, so this exceeds the HBM "
+                                                      "peak and is not the bound",
+                                  "traffic": None}},
         }
         if small is not None:
             out["train_reference_default_batch"] = small
+    if world == 1 and not args.no_extra_configs:
+        extra = {}
+        for key in EXTRA_CONFIGS:
+            try:
+                extra[key] = run_extra_config(key, device)
+            except Exception as e:  # an `extra` record must never take the headline line down
+                extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["extra"] = extra
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             v, cores, sample = cpu_baseline_train(train)
             P_np = {"ent_embeddings": model.ent_embeddings.weight.detach().cpu().numpy(),
@@ -315,6 +485,14 @@ def main():
                                    "sample": sample,
                                    "eval": {"value": ve, "unit": "test triples ranked/s",
                                             "sample": "%d test triples, two full-entity sweeps each, C/OpenMP fp32" % ne}}
+            ref = reference_cpu_numbers()
+            if ref is not None:
+                out["cpu_baseline"]["reference_in_build_container"] = ref
+        if world > 1:
+            out["collectives"] = {"backend": dist.get_backend(), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "(unset: RCCL picks)"),
+                                  "NCCL_PROTO": os.environ.get("NCCL_PROTO", "(unset)"),
+                                  "per_step": "reduce_scatter(flat grad, %d B) + all_gather(flat param)" % (tr.flat.numel * 4),
+                                  "optimizer_shard_floats": tr.flat.shard_numel}
         print(json.dumps(out), flush=True)
     if world > 1:
         if os.environ.get("KGE_BENCH_CHECK_REPLICAS") == "1":  # tests: replicas must hold identical tables after the run
