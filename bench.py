@@ -37,14 +37,16 @@ TRAIN_BYTES_PER_SCORED_TRIPLE = 3 * DIM * 4 * 3 + 28   # 3 628 B: fwd gather + g
 EVAL_BYTES_PER_CANDIDATE = DIM * 4                      # 400 B: one candidate row read once
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
-# VALU issue roof of the L1 rank sweep (k_eval_sweep<L1>): per (query, candidate) ELEMENT the kernel issues 1.5 VALU
-# instructions (half a v_pk_add_f32 for the subtraction + one v_add_f32 |d|); tools/valu_bench.hip measures what that
-# instruction mix sustains with operands in registers (profiles/r02_valu_bench.txt): the roof below is in elements/s
-# for the whole chip at the 2.4 GHz peak clock.
+# VALU issue roof of the L1 rank sweep (k_eval_sweep<L1>): per (query, candidate, k) ELEMENT the kernel issues two plain
+# VALU instructions (v_subrev_f32 with the query element as SGPR operand + v_add_f32 |d|).  A wave64 VALU instruction
+# occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md), so the roof is 1024 SIMDs x 64 lanes / 4 cycles x 2.4 GHz =
+# 39.3 T elements/s; tools/valu_bench.hip measures 32.9 T elements/s for exactly this instruction mix with all operands
+# in registers (profiles/r02_valu_bench.txt: the chip does not hold 2.4 GHz under full VALU load).
 VALU_SIMDS = 256 * 4
 VALU_PEAK_CLOCK_HZ = 2.4e9
-L1_SWEEP_CYCLES_PER_ELEMENT_PER_WAVE = 4.0              # 1 v_pk_add_f32 (2 elements) + 2 v_add_f32 |x| per 2 elements
-L1_SWEEP_ISSUES_PER_ELEMENT = 1.5
+L1_SWEEP_CYCLES_PER_ELEMENT_PER_WAVE = 4.0              # 2 plain VALU issues x 2 cycles each per element per wave64
+L1_SWEEP_ISSUES_PER_ELEMENT = 2.0
+L1_SWEEP_MICROBENCH_TELEMS = 32.9                       # register-resident ceiling of the same mix (tools/valu_bench.hip)
 MIN_WARM_SECONDS = 0.05                                 # warm until >= 50 ms of GPU work has run, whatever --warmup says
 
 
@@ -317,6 +319,18 @@ def main():
     gen = tr._new_generator()
     tr.generator = gen
     steps_per_epoch = N_TRAIN // cfg.batch_size
+    init_param = tr.flat.param.clone()
+
+    def reset_model():
+        """Back to the freshly initialised tables and optimiser state.  The hinge kernel skips the backward of pairs whose
+        margin is already satisfied, so a step gets cheaper as training progresses: every measurement below starts
+        from the same (initial, all-margins-violated) state, whatever the warm-up length."""
+        tr.flat.param.copy_(init_param)
+        tr.flat.grad.zero_()
+        for st in (tr.flat.state1, tr.flat.state2):
+            if st is not None:
+                st.zero_()
+        tr.flat.step = 0
 
     def one_step(ev_pair=None):
         if gen._pending <= 0:
@@ -352,6 +366,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- the timed region: EXACTLY --steps steps between barrier + synchronize on both sides
+    reset_model()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
@@ -373,12 +388,13 @@ def main():
     # timed region by a burst of back-to-back launches of the SAME kernel on the same stream between two events: no
     # host gap, no optimiser in between (gradients just keep accumulating; they are cleared afterwards)
     burst = 32
-    if gen._pending < burst:
-        gen.start_one_epoch(steps_per_epoch)
+    reset_model()
     eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     eb0.record()
     for _ in range(burst):
+        if gen._pending <= 0:
+            gen.start_one_epoch(steps_per_epoch)
         tr._accumulate_next_batch()
     eb1.record()
     torch.cuda.synchronize()
@@ -439,7 +455,8 @@ def main():
                                    "on-device uniform corruption; E=14951 R=1345 train=483142",
                        "batch_per_gpu": per_rank_batch, "global_batch": per_rank_batch * world,
                        "scored_triples_per_step": scored_per_step, "parallelism": "dp%d" % world,
-                       "warmup_steps_run": args.warmup + warm_extra},
+                       "warmup_steps_run": args.warmup + warm_extra,
+                       "model_state": "timed steps start from the freshly initialised tables (reset after warm-up)"},
             "roofline": {"kernel": "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
@@ -456,9 +473,11 @@ def main():
                                   "unit": "T (query,candidate,k) elements/s", "frac": eval_elem_rate / valu_peak_elems,
                                   "valu_issues_per_element": L1_SWEEP_ISSUES_PER_ELEMENT,
                                   "achieved_lane_issues_per_s": eval_elem_rate * L1_SWEEP_ISSUES_PER_ELEMENT,
-                                  "peak_note": "1024 SIMDs x 64 lanes / 4 cycles per element per wave (1 v_pk_add_f32 + "
-                                               "2 v_add_f32 |x| per 2 elements; tools/valu_bench.hip, "
-                                               "profiles/r02_valu_bench.txt) x 2.4 GHz",
+                                  "peak_note": "1024 SIMDs x 64 lanes / (2 plain VALU issues x 2 cycles) per element x 2.4 GHz; "
+                                               "the same instruction mix with operands in registers sustains "
+                                               "%.1f T elements/s (tools/valu_bench.hip, profiles/r02_valu_bench.txt)"
+                                               % L1_SWEEP_MICROBENCH_TELEMS,
+                                  "frac_of_microbench_ceiling": eval_elem_rate / 1e12 / L1_SWEEP_MICROBENCH_TELEMS,
                                   "algorithmic_GBps": eval_alg / (eval_kern_ms * 1e-3) / 1e9,
                                   "algorithmic_note": "400 B per scored candidate (SURVEY 8d); each candidate tile is "
                                                       "reused by 16 queries from registers, so this exceeds the HBM "

@@ -431,13 +431,14 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
 }
 
 // ------------------------------------------------------------------ pair arithmetic shared by steps 3 and 4
-// acc + |d| as ONE VALU op (abs is a source modifier).  Written as asm so that the SLP vectoriser cannot turn
-// pairs of them into v_and_b32 x2 + v_pk_add_f32 (3 issues per 2 elements instead of 2); same IEEE add either way.
-__device__ __forceinline__ float add_abs(float acc, float d) {
-    float r;
-    asm("v_add_f32 %0, |%1|, %2" : "=v"(r) : "v"(d), "v"(acc));
-    return r;
-}
+// L1 step: d = c - q, acc + |d| -- two plain (non-packed) VALU ops per element, abs folded in as a source modifier.
+// tools/valu_bench.hip (profiles/r02_valu_bench.txt): a plain VOP2/VOP3 f32 op issues every ~2.4 cycles per SIMD,
+// v_pk_add_f32 every ~4.3, and [v_sub, v_sub, v_add |x|, v_add |x|] per two elements sustains 32.9 T elements/s on the
+// chip against 24.7 T for [v_pk_add, v_add |x|, v_add |x|]: fewer instructions is not faster here.  This translation
+// unit is compiled with -fno-slp-vectorize (Makefile) so that the compiler neither re-packs the subtractions into
+// v_pk_add_f32 nor turns pairs of |x| adds into v_and_b32 x2 + v_pk_add_f32, and is free to interleave the queries'
+// independent chains (inline asm would pin the order and cost an s_nop per dependent pair).
+__device__ __forceinline__ float add_abs(float acc, float d) { return acc + fabsf(d); }
 
 // acc + d*d as ONE v_fma_f32, hidden from the SLP vectoriser for the same reason (it otherwise pairs the two tiles'
 // accumulators into v_pk_fma_f32 and pays ~1.2 v_mov per element to shuffle operands); same IEEE fma either way.
@@ -598,10 +599,12 @@ __device__ __forceinline__ void pair_step2(float& acc, f32x2 c, f32x2 q) {
     if constexpr (FORM == F_NEGDOT) {
         acc = fmaf(c.x, q.x, acc);
         acc = fmaf(c.y, q.y, acc);
+    } else if constexpr (FORM == F_L1) {
+        acc = add_abs(acc, c.x - q.x);
+        acc = add_abs(acc, c.y - q.y);
     } else {
         const f32x2 d = c - q;
-        if constexpr (FORM == F_L1) { acc = add_abs(acc, d.x); acc = add_abs(acc, d.y); }
-        else { acc = fma_sq(acc, d.x); acc = fma_sq(acc, d.y); }
+        acc = fma_sq(acc, d.x); acc = fma_sq(acc, d.y);
     }
 }
 
