@@ -252,6 +252,37 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
                                int64_t* next_cursor, float* next_hyper,
                                int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, void* stream);
 
+/* ---- Owner-computes ("pull") training step for TransE: Generator (data/generator.py:42-97) +
+ * Trainer.train_step_pairwise (utils/trainer.py:147-157) + Criterion.pairwise_hinge (utils/criterion.py:25-29) +
+ * loss.backward() + optimizer.step() (utils/trainer.py:298-299), neg_rate 1, with no atomics on parameters or gradients,
+ * no gradient buffer and bit-reproducible results.  Every parameter row has one owner per step that re-evaluates the
+ * pairs the row occurs in and keeps only its own gradient (see csrc/kge_pull.hip).  Host-built, per batch (int32):
+ *   pairs  [n, 4]        (h, r, t, 0) of the batch's positives, in batch order (Philox counter of pair i = offset + i)
+ *   inc    [3n]          static incidences sorted by (row, pair, role): pair << 2 | role, role 0 = head, 1 = tail,
+ *                        2 = relation; rows are numbered entities first, then tot_entity + relation
+ *   items  [n_items, 4]  (row, first incidence, end incidence, kind | slot << 2): kind 0 = the row's only item (finishes the
+ *                        row), 1 = first item of a row cut into several (also walks the row's corrupting-entity list),
+ *                        2 = a later item; kinds 1 / 2 write a partial sum to partials[slot]
+ *   multi  [n_multi, 4]  (row, first slot, number of slots, 0) of the rows cut into several items
+ * Per step (device): pc[n] corrupting entity | tail << 24, head[tot_entity] (-1 when idle; the step resets it when
+ * reset_lists != 0) and next[n]: per-entity linked lists of the pairs that drew the entity, written by kge_pull_sample
+ * (same draws as kge_sample_batch with the same seed / offset) or kge_pull_lists_explicit (given negatives).
+ * m->tables = the tables read; tables_out = the other half of the double buffer; norm_in / norm_out [E + R]: L2 row norms
+ * of the tables read / written (kge_row_norms before the first step); state1 / state2: optimiser state per table.
+ * partials: kge_pull_partial_stride(dim) floats per slot. */
+int kge_pull_partial_stride(int32_t dim);
+int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, void* stream);
+int kge_pull_sample(const int32_t* pairs, int64_t n, int64_t tot_entity, const float* bern_prob, const uint64_t* slots,
+                    int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor, int32_t* pc, int32_t* head,
+                    int32_t* next, void* stream);
+int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n, int32_t* pc, int32_t* head,
+                            int32_t* next, void* stream);
+int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* norm_in, float* norm_out,
+                  float* const state1[2], float* const state2[2], const int32_t* pairs, const int32_t* pc, int32_t* head,
+                  const int32_t* next, const int32_t* items, int64_t n_items, const int32_t* inc, float* partials,
+                  const int32_t* multi, int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step,
+                  const float* dev_hyper, int32_t reset_lists, float* loss, void* stream);
+
 /* ---- 1-N scoring head of the projection models (ConvE / TuckER / InteractE / HypER / AcrE:
  * projection.py:100-102, 335-336, 444-447, 606-609, 734-737):  preds[B,E] = sigmoid(x[B,dim] @ ent[E,dim]^T + bias[E]).
  * bias may be NULL (TuckER).  fp32 on the matrix cores. */

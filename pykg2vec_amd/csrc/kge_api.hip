@@ -282,6 +282,55 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
                             next_hyper, batch_stride, n_batches, draws_per_batch, (hipStream_t)stream);
 }
 
+/* ---- owner-computes ("pull") training step, kge_pull.hip */
+int kge_pull_partial_stride(int32_t dim) { return pull_partial_stride(dim); }
+
+int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, void* stream) {
+    if (!table || !norms || rows < 0 || dim <= 0) { set_error("kge_row_norms: bad arguments"); return -1; }
+    return launch_row_norms(table, rows, dim, norms, (hipStream_t)stream);
+}
+
+int kge_pull_sample(const int32_t* pairs, int64_t n, int64_t tot_entity, const float* bern_prob, const uint64_t* slots,
+                    int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor, int32_t* pc, int32_t* head,
+                    int32_t* next, void* stream) {
+    if (n == 0) return 0;
+    if (n < 0 || !pairs || !pc || !head || !next || tot_entity <= 0) { set_error("kge_pull_sample: bad arguments"); return -1; }
+    if (tot_entity > (1 << 24)) { set_error("kge_pull_sample: more than 2^24 entities not supported by the packed key"); return -1; }
+    if (slots && (n_slots & (n_slots - 1))) { set_error("kge_pull_sample: n_slots must be a power of two"); return -1; }
+    return launch_pull_sample(pairs, n, tot_entity, bern_prob, slots, n_slots, seed, offset, dev_cursor, pc, head, next,
+                              (hipStream_t)stream);
+}
+
+int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n, int32_t* pc, int32_t* head,
+                            int32_t* next, void* stream) {
+    if (n == 0) return 0;
+    if (n < 0 || !pairs || !nh || !nt || !pc || !head || !next) { set_error("kge_pull_lists_explicit: bad arguments"); return -1; }
+    return launch_pull_lists_explicit(pairs, nh, nt, n, pc, head, next, (hipStream_t)stream);
+}
+
+int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* norm_in, float* norm_out,
+                  float* const state1[2], float* const state2[2], const int32_t* pairs, const int32_t* pc, int32_t* head,
+                  const int32_t* next, const int32_t* items, int64_t n_items, const int32_t* inc, float* partials,
+                  const int32_t* multi, int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step,
+                  const float* dev_hyper, int32_t reset_lists, float* loss, void* stream) {
+    if (validate(m, false, "kge_pull_step")) return -1;
+    if (m->model != KGE_TRANSE) { set_error("kge_pull_step: TransE only (model %d)", m->model); return -1; }
+    if (n_items <= 0 || n_multi < 0 || !tables_out || !tables_out[0] || !tables_out[1] || !norm_in || !norm_out || !pairs ||
+        !pc || !head || !next || !items || !inc || !loss || (n_multi > 0 && (!partials || !multi))) {
+        set_error("kge_pull_step: bad arguments");
+        return -1;
+    }
+    if (tables_out[0] == m->tables[0] || tables_out[1] == m->tables[1]) {
+        set_error("kge_pull_step: the output tables must be the other half of the double buffer (rows are read by other owners)");
+        return -1;
+    }
+    if (optimizer != KGE_OPT_SGD && (!state1 || !state1[0] || !state1[1])) { set_error("kge_pull_step: optimizer state missing"); return -1; }
+    if (optimizer == KGE_OPT_ADAM && (!state2 || !state2[0] || !state2[1])) { set_error("kge_pull_step: adam needs two state buffers"); return -1; }
+    return launch_pull_step(m, tables_out, norm_in, norm_out, state1, state2, pairs, pc, head, next, items, n_items, inc,
+                            partials, multi, n_multi, margin, optimizer, lr, step, dev_hyper, reset_lists, loss,
+                            (hipStream_t)stream);
+}
+
 int kge_head_1n_forward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
                         float* preds, void* stream) {
     return launch_head_forward(x, batch, dim, ent, tot_entity, bias, preds, (hipStream_t)stream);

@@ -3,14 +3,9 @@
 // sweep is a pure HBM stream: float4 per lane, grid-stride, (reads+writes) = 3 (SGD) .. 7 (Adam) floats per
 // parameter.  The gradient buffer is cleared in the same pass (optimizer.zero_grad(), utils/trainer.py:272).
 #include "kge_internal.h"
+#include "kge_opt_device.h"
 
 namespace kge {
-
-struct OptArgs {
-    float lr;
-    float step_size;  // Adam: lr / (1 - beta1^t)
-    float bc2_sqrt;   // Adam: sqrt(1 - beta2^t)
-};
 
 // Optional tail duty of the optimiser launch in hipGraph-replayed steps: thread 0 of block 0 derives the NEXT step's
 // device-resident state (batch cursor, Philox offset, optimiser step, Adam bias terms) from the current one.  It writes
@@ -36,24 +31,6 @@ __device__ __forceinline__ void advance_state(const AdvanceArgs& v) {
     v.hout[0] = v.lr;
     v.hout[1] = (float)((double)v.lr / bc1);
     v.hout[2] = (float)sqrt(bc2);
-}
-
-template <int KIND>
-__device__ __forceinline__ void opt_update(float& p, float g, float& s1, float& s2, const OptArgs& a) {
-    if constexpr (KIND == KGE_OPT_SGD) {
-        p = p - a.lr * g;
-    } else if constexpr (KIND == KGE_OPT_ADAM) {  // torch/optim/adam.py _single_tensor_adam, defaults
-        s1 = s1 + (1.0f - 0.9f) * (g - s1);          // exp_avg.lerp_(grad, 1 - beta1)
-        s2 = s2 * 0.999f + (1.0f - 0.999f) * g * g;  // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-        const float denom = sqrtf(s2) / a.bc2_sqrt + 1e-8f;
-        p = p + (-a.step_size) * s1 / denom;         // param.addcdiv_(exp_avg, denom, value=-step_size)
-    } else if constexpr (KIND == KGE_OPT_ADAGRAD) {  // lr_decay 0, eps 1e-10
-        s1 = s1 + g * g;
-        p = p - a.lr * g / (sqrtf(s1) + 1e-10f);
-    } else {  // RMSprop alpha 0.99 eps 1e-8, momentum 0, not centered
-        s1 = s1 * 0.99f + (1.0f - 0.99f) * g * g;
-        p = p - a.lr * g / (sqrtf(s1) + 1e-8f);
-    }
 }
 
 template <int KIND, bool ZERO>
@@ -118,13 +95,7 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
     adv.cin = cursor_in; adv.cout = cursor_out; adv.hout = hyper_out;
     adv.batch_stride = batch_stride; adv.n_batches = n_batches > 0 ? n_batches : 1; adv.draws_per_batch = draws_per_batch;
     adv.lr = lr;
-    OptArgs a;
-    a.lr = lr;
-    // torch computes these scalars in double on the host, then applies them to fp32 tensors
-    const double bc1 = 1.0 - pow(0.9, (double)step);
-    const double bc2 = 1.0 - pow(0.999, (double)step);
-    a.step_size = (float)((double)lr / bc1);
-    a.bc2_sqrt = (float)sqrt(bc2);
+    const OptArgs a = make_opt_args(lr, step);
     switch (kind) {
         case KGE_OPT_SGD: return launch_kind<KGE_OPT_SGD>(p, g, s1, s2, numel, a, zero_grad, dev_hyper, adv, s);
         case KGE_OPT_ADAM:

@@ -1,0 +1,43 @@
+// kge_opt_device.h -- per-element dense optimiser updates with torch.optim default semantics (utils/trainer.py:112-131),
+// shared by the flat-buffer sweep (kge_opt.hip) and the owner-computes training step (kge_pull.hip).
+#pragma once
+#include "kge_device.h"
+
+namespace kge {
+
+struct OptArgs {
+    float lr;
+    float step_size;  // Adam: lr / (1 - beta1^t)
+    float bc2_sqrt;   // Adam: sqrt(1 - beta2^t)
+};
+
+template <int KIND>
+__device__ __forceinline__ void opt_update(float& p, float g, float& s1, float& s2, const OptArgs& a) {
+    if constexpr (KIND == KGE_OPT_SGD) {
+        p = p - a.lr * g;
+    } else if constexpr (KIND == KGE_OPT_ADAM) {  // torch/optim/adam.py _single_tensor_adam, defaults
+        s1 = s1 + (1.0f - 0.9f) * (g - s1);          // exp_avg.lerp_(grad, 1 - beta1)
+        s2 = s2 * 0.999f + (1.0f - 0.999f) * g * g;  // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(s2) / a.bc2_sqrt + 1e-8f;
+        p = p + (-a.step_size) * s1 / denom;         // param.addcdiv_(exp_avg, denom, value=-step_size)
+    } else if constexpr (KIND == KGE_OPT_ADAGRAD) {  // lr_decay 0, eps 1e-10
+        s1 = s1 + g * g;
+        p = p - a.lr * g / (sqrtf(s1) + 1e-10f);
+    } else {  // RMSprop alpha 0.99 eps 1e-8, momentum 0, not centered
+        s1 = s1 * 0.99f + (1.0f - 0.99f) * g * g;
+        p = p - a.lr * g / (sqrtf(s1) + 1e-8f);
+    }
+}
+
+// torch computes Adam's bias-correction scalars in double on the host, then applies them to fp32 tensors
+inline OptArgs make_opt_args(float lr, int64_t step) {
+    OptArgs a;
+    a.lr = lr;
+    const double bc1 = 1.0 - pow(0.9, (double)step);
+    const double bc2 = 1.0 - pow(0.999, (double)step);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    return a;
+}
+
+}  // namespace kge

@@ -49,6 +49,68 @@ def bern_table(prob):
     return p32
 
 
+def build_pull_batch(pos, tot_entity, tot_relation, segment):
+    """Incidence index of ONE batch for the owner-computes step (csrc/kge_pull.hip): every parameter row (entities first,
+    then tot_entity + relation) gets the sorted list of the (pair, role) slots it occupies in the batch -- role 0 = head,
+    1 = tail, 2 = relation -- cut into work items of at most `segment` incidences.  Pure numpy, vectorised.
+    Returns int32 arrays (pairs [B,4], inc [3B], items [n_items,4], multi [n_multi,4]) and the number of partial slots."""
+    pos = np.asarray(pos, dtype=np.int64).reshape(-1, 3)
+    B, E, nrows = len(pos), int(tot_entity), int(tot_entity) + int(tot_relation)
+    i = np.arange(B, dtype=np.int64)
+    rows = np.concatenate([pos[:, 0], pos[:, 2], E + pos[:, 1]])
+    vals = np.concatenate([4 * i, 4 * i + 1, 4 * i + 2])
+    order = np.lexsort((vals, rows))
+    inc = vals[order].astype(np.int32)
+    counts = np.bincount(rows, minlength=nrows)
+    row_off = np.cumsum(counts) - counts
+    nseg = np.maximum(1, (counts + segment - 1) // segment)
+    first = np.cumsum(nseg) - nseg
+    tot = int(nseg.sum())
+    item_row = np.repeat(np.arange(nrows, dtype=np.int64), nseg)
+    seg_idx = np.arange(tot, dtype=np.int64) - np.repeat(first, nseg)
+    beg = row_off[item_row] + seg_idx * segment
+    end = np.minimum(beg + segment, row_off[item_row] + counts[item_row])
+    is_multi = nseg[item_row] > 1
+    slot = np.cumsum(is_multi) - 1                      # consecutive per row, in segment order
+    kind = np.where(~is_multi, 0, np.where(seg_idx == 0, 1, 2))
+    info = kind | (np.where(is_multi, slot, 0) << 2)
+    items = np.stack([item_row, beg, end, info], 1)
+    # heaviest items first (entity owners also walk their corrupting-entity list, ~B/E pairs)
+    weight = (end - beg) + np.where((item_row < E) & (kind != 2), max(1, B // max(E, 1)), 0)
+    items = items[np.argsort(-weight, kind="stable")].astype(np.int32)
+    mrows = np.flatnonzero(nseg > 1)
+    multi = np.stack([mrows, slot[first[mrows]], nseg[mrows], np.zeros_like(mrows)], 1).astype(np.int32).reshape(-1, 4)
+    pairs = np.concatenate([pos, np.zeros((B, 1), np.int64)], 1).astype(np.int32)
+    return pairs, inc, np.ascontiguousarray(items), np.ascontiguousarray(multi), int(is_multi.sum())
+
+
+class PullIndex:
+    """Device-resident incidence index of every batch of the epoch (a batch is a fixed slice of the generator's
+    permutation, data/generator.py:23-35, so the index is built once)."""
+
+    SEGMENT = 8  # incidences per work item: rows with longer lists are cut up and finished by a second small kernel
+
+    def __init__(self, batches, tot_entity, tot_relation, device, segment=None):
+        seg = int(segment or self.SEGMENT)
+        built = [build_pull_batch(b, tot_entity, tot_relation, seg) for b in batches]
+        self.n_batches = len(built)
+        self.batch_size = len(batches[0]) if built else 0
+        self.max_slots = max([x[4] for x in built] + [1])
+
+        def cat(k):
+            return torch.from_numpy(np.concatenate([x[k] for x in built])).to(device) if built else None
+
+        self.pairs, self.inc, self.items, self.multi = cat(0), cat(1), cat(2), cat(3)
+        self.item_off = np.concatenate([[0], np.cumsum([len(x[2]) for x in built])]).astype(np.int64)
+        self.multi_off = np.concatenate([[0], np.cumsum([len(x[3]) for x in built])]).astype(np.int64)
+
+    def batch(self, b):
+        """(pairs, inc, items, multi) views of batch b; incidence / pair indices inside are relative to the batch."""
+        B = self.batch_size
+        return (self.pairs[b * B:(b + 1) * B], self.inc[3 * b * B:3 * (b + 1) * B],
+                self.items[self.item_off[b]:self.item_off[b + 1]], self.multi[self.multi_off[b]:self.multi_off[b + 1]])
+
+
 class Generator:
     def __init__(self, model, config, seed=None, rank=0, world_size=1, backend=K):
         self.K = backend
@@ -84,9 +146,20 @@ class Generator:
             self.bern = torch.from_numpy(bern_table(table)).to(self.device)
         self.neg_rate = int(config.neg_rate)
         self.batch_size = int(config.batch_size)
+        self._train_np, self._perm_np = train, perm
+        self._pull_index = None
         self._pending = 0
         self._batch_idx = 0
         self._draws = 0  # Philox counter offset: unique per generated negative over the whole run
+
+    def pull_index(self):
+        """Incidence index of every FULL batch of the permutation (built on first use)."""
+        if self._pull_index is None:
+            B = self.batch_size
+            nb = self.n_train // B
+            pos = self._train_np[self._perm_np[:nb * B]].reshape(nb, B, 3)
+            self._pull_index = PullIndex(list(pos), self.config.tot_entity, self.config.tot_relation, self.device)
+        return self._pull_index
 
     def __iter__(self):
         return self

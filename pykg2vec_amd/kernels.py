@@ -384,6 +384,64 @@ def sample_batch(triples, perm, start, n_pos, neg_rate, tot_entity, bern_prob, s
     return outs
 
 
+# ---------------------------------------------------------------------------- owner-computes ("pull") training step
+def _i32(t, what):
+    return _dev(t, torch.int32, what)
+
+
+def _ptr_pair(tensors):
+    """float* const x[2] argument: a 2-slot pointer array (kept alive by the caller for the duration of the call)."""
+    arr = (ctypes.c_void_p * 2)()
+    for i in range(2):
+        arr[i] = tensors[i].data_ptr() if tensors is not None and tensors[i] is not None else None
+    return arr
+
+
+def row_norms(table, out):
+    """out[r] = ||table[r]||_2 in the lane layout / operation order the pull step uses for the rows it writes."""
+    L.check(L.load().kge_row_norms(_dev(table, torch.float32, "table"), table.shape[0], table.shape[1],
+                                   _dev(out, torch.float32, "norms"), _stream()), "kge_row_norms")
+
+
+def pull_partial_stride(dim):
+    return int(L.load().kge_pull_partial_stride(int(dim)))
+
+
+def pull_sample(pairs, tot_entity, bern_prob, slots, seed, offset, pc, head, nxt, cursor=None):
+    """Draw the corruption of every pair of a batch (the draws kge_sample_batch makes for the same seed / offset) and
+    thread the pairs into per-entity lists of `drawn as corrupting entity`."""
+    bp = _dev(bern_prob, torch.float32, "bern_prob") if bern_prob is not None else None
+    sp = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
+    pcur = _dev(cursor, torch.int64, "cursor") if cursor is not None else None
+    L.check(L.load().kge_pull_sample(_i32(pairs, "pairs"), pairs.shape[0], int(tot_entity), bp, sp,
+                                     slots.numel() if slots is not None else 0, int(seed) & (2 ** 64 - 1),
+                                     int(offset) & (2 ** 64 - 1), pcur, _i32(pc, "pc"), _i32(head, "head"), _i32(nxt, "next"),
+                                     _stream()), "kge_pull_sample")
+
+
+def pull_lists_explicit(pairs, nh, nt, pc, head, nxt):
+    L.check(L.load().kge_pull_lists_explicit(_i32(pairs, "pairs"), _ids(nh, "nh"), _ids(nt, "nt"), pairs.shape[0],
+                                             _i32(pc, "pc"), _i32(head, "head"), _i32(nxt, "next"), _stream()),
+            "kge_pull_lists_explicit")
+
+
+def pull_step(desc_in, tables_out, norm_in, norm_out, state1, state2, pairs, pc, head, nxt, items, inc, partials, multi,
+              margin, optimizer, lr, step, loss_buf, reset_lists=True, dev_hyper=None):
+    """One whole training step (scoring, hinge, backward, dense optimiser) without atomics: see csrc/kge_pull.hip.
+    desc_in: descriptor over the tables READ; tables_out: [ent, rel] of the other half of the double buffer."""
+    to, s1, s2 = _ptr_pair(tables_out), _ptr_pair(state1), _ptr_pair(state2)
+    n_multi = 0 if multi is None else multi.shape[0]
+    L.check(L.load().kge_pull_step(
+        ctypes.byref(desc_in), ctypes.addressof(to), _dev(norm_in, torch.float32, "norm_in"),
+        _dev(norm_out, torch.float32, "norm_out"), ctypes.addressof(s1) if state1 is not None else None,
+        ctypes.addressof(s2) if state2 is not None else None, _i32(pairs, "pairs"), _i32(pc, "pc"), _i32(head, "head"),
+        _i32(nxt, "next"), _i32(items, "items"), items.shape[0], _i32(inc, "inc"),
+        _dev(partials, torch.float32, "partials") if n_multi else None, _i32(multi, "multi") if n_multi else None, n_multi,
+        float(margin), OPTIMIZER_IDS[optimizer], float(lr), int(step),
+        _dev(dev_hyper, torch.float32, "dev_hyper") if dev_hyper is not None else None, 1 if reset_lists else 0,
+        _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_pull_step")
+
+
 # ---------------------------------------------------------------------------- 1-N scoring head (projection models)
 def _f32(t, what):
     return _dev(t, torch.float32, what)

@@ -76,6 +76,44 @@ class FlatState:
                               zero_grad=True, dev_hyper=dev_hyper)
 
 
+class PullState:
+    """Device state of the owner-computes training step (csrc/kge_pull.hip): the second half of the double-buffered
+    tables, the row norms of both halves and the per-step sampler lists.  `cur` = which half holds the current tables
+    (0 = FlatState.param, i.e. the storage behind the model's nn.Parameters)."""
+
+    def __init__(self, flat, model, batch_size, max_slots):
+        dev = flat.param.device
+        self.flat = flat
+        self.alt = torch.empty_like(flat.param)
+        shapes = [tuple(v.shape) for v in flat.views[:2]]
+        offs = [v.data_ptr() - flat.param.data_ptr() for v in flat.views[:2]]
+        view = lambda buf: [buf[o // 4:o // 4 + r * d].view(r, d) for o, (r, d) in zip(offs, shapes)]
+        self.tables = [view(flat.param), view(self.alt)]
+        self.state1 = view(flat.state1) if flat.state1 is not None else None
+        self.state2 = view(flat.state2) if flat.state2 is not None else None
+        E, R, d = shapes[0][0], shapes[1][0], shapes[0][1]
+        self.E, self.R = E, R
+        self.norms = [torch.empty(E + R, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.pc = torch.empty(batch_size, dtype=torch.int32, device=dev)
+        self.next = torch.empty(batch_size, dtype=torch.int32, device=dev)
+        self.head = torch.full((E,), -1, dtype=torch.int32, device=dev)
+        self.partials = torch.empty(max(1, max_slots) * K.pull_partial_stride(d), dtype=torch.float32, device=dev)
+        self.cur = 0
+
+    def sync_in(self):
+        """(Re)derive the row norms from the tables the model currently holds (they may have been set from outside)."""
+        self.sync_out()
+        K.row_norms(self.tables[0][0], self.norms[0][:self.E])
+        K.row_norms(self.tables[0][1], self.norms[0][self.E:])
+
+    def sync_out(self):
+        """Make FlatState.param (the storage behind the model's parameters) hold the current tables."""
+        if self.cur == 1:
+            self.flat.param.copy_(self.alt)
+            self.norms[0].copy_(self.norms[1])
+            self.cur = 0
+
+
 class EarlyStopper:
     """utils/trainer.py:21-69.  `patience_left` is decremented on a worse metric while it is positive; the trainer
     stops on the next worse metric once it is 0 (so patience=3 stops on the 4th consecutive worse evaluation, and
@@ -220,6 +258,84 @@ class Trainer:
         # rows arrive as bundles [positive, its neg_rate negatives] (generator / data/generator.py:125-156)
         self.K.train_pointwise_logistic(self._desc, h, r, t, y, self.model.kernel_lmbda(), self.model.kernel_reg_type(),
                                         self.loss_buf, bundle=1 + int(self.config.neg_rate))
+
+    # ------------------------------------------------------------------ owner-computes ("pull") step: big TransE batches
+    def _pull_ok(self):
+        """TransE + pairwise hinge with neg_rate 1, single GPU, full batches too large for the launch-bound graph path:
+        the whole step (sampling, scoring, hinge, backward, dense optimiser) runs without atomics or a gradient buffer
+        and is bit-reproducible (csrc/kge_pull.hip).  KGE_PULL=0 / 1 overrides the batch-size rule."""
+        import os
+        if not (self.K is K and self.world_size == 1 and self.model.kernel_name == "transe"
+                and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1
+                and self.generator is not None and self.generator.n_train >= self.config.batch_size):
+            return False
+        env = os.environ.get("KGE_PULL")
+        if env is not None:
+            return env == "1"
+        return self.config.batch_size * 2 > self.GRAPH_MAX_ROWS
+
+    def _pull_state(self):
+        idx = self.generator.pull_index()
+        if getattr(self, "_pull", None) is None or self._pull.pc.numel() != idx.batch_size:
+            self._pull = PullState(self.flat, self.model, idx.batch_size, idx.max_slots)
+            self._pull.sync_in()
+        return self._pull, idx
+
+    def _pull_step(self, batch_idx, offset, lists_ready=False):
+        """One full training step on batch `batch_idx` of the permutation (Philox counters offset .. offset + B)."""
+        ps, idx = self._pull_state()
+        gen = self.generator
+        pairs, inc, items, multi = idx.batch(batch_idx)
+        if not lists_ready:
+            K.pull_sample(pairs, self.config.tot_entity, gen.bern, gen.slots, gen.seed, offset, ps.pc, ps.head, ps.next)
+        src, dst = ps.cur, 1 - ps.cur
+        self.flat.step += 1
+        desc = K.make_desc("transe", ps.tables[src], None, tot_entity=self.config.tot_entity,
+                           tot_relation=self.config.tot_relation, **self.model.desc_kwargs())
+        K.pull_step(desc, ps.tables[dst], ps.norms[src], ps.norms[dst], ps.state1, ps.state2, pairs, ps.pc, ps.head, ps.next,
+                    items, inc, ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate,
+                    self.flat.step, self.loss_buf)
+        ps.cur = dst
+
+    def pull_step_explicit(self, ph, pr, pt, nh, nr, nt, segment=None):
+        """The owner-computes step on an explicit batch (positives + given negatives, neg_rate 1): the incidence index
+        of this one batch is built on the host first, so this is for parity tests and one-off batches, not the hot loop."""
+        import numpy as np
+        from .generator import PullIndex
+        pos = np.stack([x.detach().cpu().numpy() for x in (ph, pr, pt)], 1)
+        idx = PullIndex([pos], self.config.tot_entity, self.config.tot_relation, self.flat.param.device, segment)
+        ps = PullState(self.flat, self.model, len(pos), idx.max_slots)
+        ps.sync_in()
+        pairs, inc, items, multi = idx.batch(0)
+        K.pull_lists_explicit(pairs, nh.contiguous(), nt.contiguous(), ps.pc, ps.head, ps.next)
+        self.flat.step += 1
+        desc = K.make_desc("transe", ps.tables[0], None, tot_entity=self.config.tot_entity,
+                           tot_relation=self.config.tot_relation, **self.model.desc_kwargs())
+        K.pull_step(desc, ps.tables[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs, ps.pc, ps.head, ps.next,
+                    items, inc, ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate,
+                    self.flat.step, self.loss_buf)
+        ps.cur = 1
+        ps.sync_out()
+
+    def sync_model(self):
+        """After stepping: make the model's parameters (FlatState.param) hold the current tables."""
+        if getattr(self, "_pull", None) is not None:
+            self._pull.sync_out()
+
+    def step_next_batch(self):
+        """One whole training step on the generator's next batch, whichever path serves it."""
+        if self._pull_ok():
+            start, n, offset = self.generator._next_range()
+            if n == self.config.batch_size and start % n == 0:
+                self._pull_step(start // n, offset)
+                return
+            self.sync_model()   # a short last batch: the push path handles it
+            self._pull = None
+            self._accumulate_next_batch(fixed_range=(start, n, offset))
+            self._reduce_and_step()
+            return
+        self._accumulate_next_batch()
+        self._reduce_and_step()
 
     def _mean_type_loss(self):
         """pointwise_logistic and the self-adversarial loss are MEANS over the batch (criterion.py:13-23,31-34);
@@ -373,9 +489,11 @@ class Trainer:
             gen._pending = 0
         else:
             self.loss_buf.zero_()
+            if self._pull_ok():
+                self._pull_state()[0].sync_in()   # the tables may have been changed from outside since the last epoch
             for _ in range(num_batch):
-                self._accumulate_next_batch()
-                self._reduce_and_step()
+                self.step_next_batch()
+            self.sync_model()
         acc = self.K.read_loss(self.loss_buf)
         if self.world_size > 1:
             torch.distributed.all_reduce(acc, group=self.process_group)

@@ -1,0 +1,152 @@
+"""The owner-computes ("pull") training step (csrc/kge_pull.hip): no atomics, optimiser fused, bit-reproducible.
+Held to (a) the live reference's golden post-optimiser weights on its golden batches, (b) the push path (atomic
+scatter + dense optimiser sweep) on the batch the fused sampler draws at BASELINE size, (c) itself, bit for bit,
+across runs."""
+import numpy as np
+import pytest
+import torch
+
+import kge_oracle as ko
+from golden_util import Case, close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import hip_util
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return hip_util
+
+
+@pytest.mark.parametrize("segment", [None, 2])
+@pytest.mark.parametrize("opt", ["sgd", "adam", "adagrad", "rms"])
+@pytest.mark.parametrize("name", ["transe_l1", "transe_l2"])
+def test_three_pull_steps_match_reference_weights(hip, name, opt, segment):
+    """Golden batches of the live reference, three steps: losses and post-optimiser tables (tests/golden/ref_transe_*).
+    segment=2 cuts almost every row's incidence list into several work items (partial sums + finishing kernel)."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.trainer import Trainer
+    c = Case(name)
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer=opt, lr=0.05)
+    m = hip.model_from_case(c)
+    tr = Trainer(m, cfg)
+    tr.build_model()
+    losses = []
+    for s in range(3):
+        b = [hip.dev(x) for x in c.batch(s)]
+        tr.loss_buf.zero_()
+        tr.pull_step_explicit(*b, segment=segment)
+        losses.append(K.read_loss(tr.loss_buf).item())
+    assert close(np.asarray(losses), c.z["%s.losses" % opt], atol=3e-5, rtol=3e-5), (losses, c.z["%s.losses" % opt])
+    for k, p in hip.table_parameters(m):
+        ref = c.z["%s.final.%s" % (opt, k)]
+        got = p.detach().cpu().numpy()
+        # no atomics: the RMSprop caveat of the push path (order-dependent rounding residues) does not apply here
+        assert np.allclose(got, ref, atol=1e-4, rtol=1e-4), (k, np.abs(got - ref).max())
+
+
+E, R, D, B = 14951, 1345, 100, 32768
+
+
+@pytest.fixture(scope="module")
+def world():
+    rng = np.random.default_rng(1234)
+    n_train = 4 * B + 100
+    train = np.stack([rng.integers(E, size=n_train), rng.integers(R, size=n_train), rng.integers(E, size=n_train)], 1)
+    test = np.stack([rng.integers(E, size=64), rng.integers(R, size=64), rng.integers(E, size=64)], 1)
+    P = ko.init_params("transe", rng, tot_entity=E, tot_relation=R, hidden_size=D)
+    return train, test, P
+
+
+def _trainer(hip, world, l1=True, opt="adam", pull=True, monkeypatch=None):
+    from pykg2vec_amd.trainer import Trainer
+    train, test, P = world
+    hp = dict(hidden_size=D, l1_flag=l1, margin=1.0)
+    cfg = hip.make_config(E, R, hp, train[:1], test[:16], test, optimizer=opt, lr=0.01, batch_size=B)
+    cfg.knowledge_graph.cache["triplets_train"] = train
+    cfg.tot_train_triples = len(train)
+    m = hip.model_from_params("transe", P, hp, E, R)
+    monkeypatch.setenv("KGE_PULL", "1" if pull else "0")
+    tr = Trainer(m, cfg, use_graph=False)
+    tr.build_model()
+    tr.generator = tr._new_generator()
+    return tr, m, cfg
+
+
+@pytest.mark.parametrize("l1,opt", [(True, "adam"), (False, "sgd"), (True, "adagrad")])
+def test_pull_epoch_equals_push_epoch_at_baseline_size(hip, world, l1, opt, monkeypatch):
+    """Same generator seed => same batches and the same Philox draws on both paths: after an epoch of 4 steps at
+    B = 32768 the tables must agree to fp32 summation-order noise, and the epoch losses too."""
+    out = []
+    for pull in (False, True):
+        tr, m, cfg = _trainer(hip, world, l1, opt, pull, monkeypatch)
+        assert tr._pull_ok() == pull
+        loss = tr.train_model_epoch(0)
+        out.append((loss, [p.detach().clone() for _, p in hip.table_parameters(m)]))
+    assert np.isclose(out[0][0], out[1][0], rtol=2e-5), (out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.allclose(a, b, atol=2e-5, rtol=1e-4), (a - b).abs().max().item()
+
+
+def test_pull_step_matches_oracle_on_its_sampled_batch(hip, world, monkeypatch):
+    """One pull step at full size against the numpy oracle's gradients + Adam on the batch the sampler drew."""
+    from pykg2vec_amd import kernels as K
+    tr, m, cfg = _trainer(hip, world, True, "adam", True, monkeypatch)
+    train, test, P = world
+    gen = tr.generator
+    cfg.tot_train_triples = B   # one step
+    loss = tr.train_model_epoch(0)
+    batch = K.sample_batch(gen.triples, gen.perm, 0, B, 1, E, None, gen.slots, gen.seed, 0)
+    nb = tuple(a.cpu().numpy() for a in batch)
+    loss_ref, G_ref, _, _ = ko.train_step_grads("transe", P, nb, l1_flag=True, margin=1.0)
+    assert np.isclose(loss, loss_ref, rtol=2e-5), (loss, loss_ref)
+    Pn = {k: v.copy() for k, v in P.items()}
+    st = ko.optimizer_init("adam", Pn)
+    ko.optimizer_step("adam", Pn, G_ref, st, 0.01)
+    for k, p in hip.table_parameters(m):
+        got, ref = p.detach().cpu().numpy(), Pn[k.split(".")[0]]
+        # Adam's first step moves every touched weight by ~lr * sign(g): only entries whose gradient is a rounding
+        # residue of cancelling contributions may land elsewhere -- they are isolated
+        bad = np.abs(got - ref) > 1e-5 + 1e-4 * np.abs(ref)
+        assert bad.mean() < 2e-3, (k, bad.sum(), np.abs(got - ref).max())
+
+
+def test_training_is_bit_reproducible(hip, world, monkeypatch):
+    """SURVEY.md section 5 (race detection): no atomics on parameters or gradients, fixed summation orders -- two runs
+    from the same state produce byte-identical tables, optimiser state and row norms."""
+    res = []
+    for _ in range(2):
+        tr, m, cfg = _trainer(hip, world, True, "adam", True, monkeypatch)
+        for e in range(2):
+            tr.train_model_epoch(e)
+        res.append((tr.flat.param.clone(), tr.flat.state1.clone(), tr.flat.state2.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_pull_untouched_rows_follow_dense_optimizer_semantics(hip, monkeypatch):
+    """nn.Embedding is dense (models/Domain.py:8-13): Adam moves rows with momentum even when the batch does not touch
+    them; a row nobody touches in step 1 must still equal torch's dense update (zero gradient: unchanged for a fresh
+    state) and in step 2 keep decaying its moments."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.trainer import Trainer
+    c = Case("transe_l1")
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer="adam", lr=0.05)
+    m = hip.model_from_case(c)
+    tr = Trainer(m, cfg)
+    tr.build_model()
+    b0 = [hip.dev(x) for x in c.batch(0)]
+    # second batch: one pair only -> almost every row is untouched but carries momentum from the first step
+    b1 = [x[:1].contiguous() for x in [hip.dev(y) for y in c.batch(1)]]
+    tr.pull_step_explicit(*b0)
+    before = m.ent_embeddings.weight.detach().clone()
+    m1 = tr.flat.state1.clone()
+    tr.pull_step_explicit(*b1)
+    after = m.ent_embeddings.weight.detach()
+    touched = set(int(x) for t in (b1[0], b1[2], b1[3], b1[5]) for x in t.cpu().numpy())
+    moved = (after != before).any(1).cpu().numpy()
+    had_momentum = (m1[:c.E * c.hp["hidden_size"]].view(c.E, -1) != 0).any(1).cpu().numpy()
+    for e in range(c.E):
+        if e not in touched:
+            assert moved[e] == had_momentum[e], e
