@@ -171,10 +171,11 @@ def pmc_traffic(kernel_prefix, batch):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files or batch != 32768:
         return None, None
-    doc = json.load(open(files[-1]))
-    for name, ctr in doc["kernels"].items():
-        if name.startswith(kernel_prefix) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-            return (ctr["FETCH_SIZE"]["avg_KB"] + ctr["WRITE_SIZE"]["avg_KB"]) * 1024.0, os.path.basename(files[-1])
+    for f in reversed(files):   # newest round first
+        doc = json.load(open(f))
+        for name, ctr in doc["kernels"].items():
+            if name.startswith(kernel_prefix) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+                return (ctr["FETCH_SIZE"]["avg_KB"] + ctr["WRITE_SIZE"]["avg_KB"]) * 1024.0, os.path.basename(f)
     return None, None
 
 
@@ -320,21 +321,34 @@ def main():
     tr.generator = gen
     steps_per_epoch = N_TRAIN // cfg.batch_size
     init_param = tr.flat.param.clone()
+    pull = tr._pull_ok()   # single GPU, big batch: the atomic-free owner-computes step (csrc/kge_pull.hip)
 
     def reset_model():
         """Back to the freshly initialised tables and optimiser state.  The hinge kernel skips the backward of pairs whose
         margin is already satisfied, so a step gets cheaper as training progresses: every measurement below starts
         from the same (initial, all-margins-violated) state, whatever the warm-up length."""
+        ps = getattr(tr, "_pull", None)
+        if ps is not None:
+            ps.cur = 0
         tr.flat.param.copy_(init_param)
         tr.flat.grad.zero_()
         for st in (tr.flat.state1, tr.flat.state2):
             if st is not None:
                 st.zero_()
         tr.flat.step = 0
+        if ps is not None:
+            ps.sync_in()   # row norms of the restored tables
 
     def one_step(ev_pair=None):
         if gen._pending <= 0:
             gen.start_one_epoch(steps_per_epoch)
+        if pull:   # sampler lists -> owner-computes step (scores, hinge, backward, dense Adam; no atomics) [-> finish]
+            if ev_pair is not None:
+                ev_pair[0].record()
+            tr.step_next_batch()
+            if ev_pair is not None:
+                ev_pair[1].record()
+            return
         if ev_pair is not None:
             ev_pair[0].record()
         tr._accumulate_next_batch()  # ONE launch: corruption + score(+) + score(-) + hinge + backward scatter
@@ -390,19 +404,36 @@ def main():
     burst = 32
     reset_model()
     eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    eb0.record()
-    for _ in range(burst):
-        if gen._pending <= 0:
-            gen.start_one_epoch(steps_per_epoch)
-        tr._accumulate_next_batch()
-    eb1.record()
-    torch.cuda.synchronize()
+    if pull:
+        ps, idx = tr._pull_state()
+        pairs_b, inc_b, items_b, multi_b = idx.batch(0)
+        K.pull_sample(pairs_b, E, gen.bern, gen.slots, gen.seed, 0, ps.pc, ps.head, ps.next)
+        desc_b = K.make_desc("transe", ps.tables[0], None, tot_entity=E, tot_relation=R, **model.desc_kwargs())
+        none_multi = multi_b[:0]   # the finishing kernel of multi-segment rows is a separate (small) launch: not in the burst
+        torch.cuda.synchronize()
+        eb0.record()
+        for _ in range(burst):   # same inputs every time (lists kept, no buffer swap): the kernel's own duration
+            K.pull_step(desc_b, ps.tables[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs_b, ps.pc, ps.head, ps.next,
+                        items_b, inc_b, ps.partials, none_multi, cfg.margin, cfg.optimizer, cfg.learning_rate, 1, tr.loss_buf,
+                        reset_lists=False)
+        eb1.record()
+        torch.cuda.synchronize()
+        ps.head.fill_(-1)
+    else:
+        torch.cuda.synchronize()
+        eb0.record()
+        for _ in range(burst):
+            if gen._pending <= 0:
+                gen.start_one_epoch(steps_per_epoch)
+            tr._accumulate_next_batch()
+        eb1.record()
+        torch.cuda.synchronize()
     kern_ms = eb0.elapsed_time(eb1) / burst
-    tr.flat.grad.zero_()
+    reset_model()
     alg_bytes = 2 * per_rank_batch * TRAIN_BYTES_PER_SCORED_TRIPLE
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
+    tr.sync_model()
     # ---- eval leg: filtered ranks of n_eval test triples per rank
     ev = Evaluator(model, cfg)
     ev.rank_all(my_test, n_eval)  # warm-up (also builds the device CSR once)
@@ -444,7 +475,10 @@ def main():
         del tr_s
 
     out = None
-    traffic, traffic_src = pmc_traffic("kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch)
+    kernel_label = ("k_pull_step<Adam,G=32,NCH=4> (owner-computes step: per-row re-evaluation of incident pairs, hinge, backward, "
+                    "normalisation backward, dense Adam; no atomics)" if pull else
+                    "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)")
+    traffic, traffic_src = pmc_traffic("kge::k_pull_step<1, 32, 4" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch)
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
@@ -456,8 +490,10 @@ def main():
                        "batch_per_gpu": per_rank_batch, "global_batch": per_rank_batch * world,
                        "scored_triples_per_step": scored_per_step, "parallelism": "dp%d" % world,
                        "warmup_steps_run": args.warmup + warm_extra,
-                       "model_state": "timed steps start from the freshly initialised tables (reset after warm-up)"},
-            "roofline": {"kernel": "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)", "bound": "hbm", "achieved": achieved,
+                       "model_state": "timed steps start from the freshly initialised tables (reset after warm-up)",
+                       "step_path": "owner-computes (pull): kge_pull_sample + kge_pull_step [+ finish]" if pull else
+                                    "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step"},
+            "roofline": {"kernel": kernel_label, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_ms,
