@@ -316,7 +316,7 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
     if (validate(m, false, "kge_pull_step")) return -1;
     if (m->model != KGE_TRANSE) { set_error("kge_pull_step: TransE only (model %d)", m->model); return -1; }
     if (n_items <= 0 || n_multi < 0 || !tables_out || !tables_out[0] || !tables_out[1] || !norm_in || !norm_out || !pairs ||
-        !pc || !head || !next || !items || !inc || !loss || (n_multi > 0 && (!partials || !multi))) {
+        !pc || !head || !next || !items || !inc || !loss || !partials || (n_multi > 0 && !multi)) {
         set_error("kge_pull_step: bad arguments");
         return -1;
     }

@@ -426,17 +426,18 @@ def pull_lists_explicit(pairs, nh, nt, pc, head, nxt):
 
 
 def pull_step(desc_in, tables_out, norm_in, norm_out, state1, state2, pairs, pc, head, nxt, items, inc, partials, multi,
-              margin, optimizer, lr, step, loss_buf, reset_lists=True, dev_hyper=None):
+              margin, optimizer, lr, step, loss_buf, reset_lists=True, dev_hyper=None, run_finish=True):
     """One whole training step (scoring, hinge, backward, dense optimiser) without atomics: see csrc/kge_pull.hip.
     desc_in: descriptor over the tables READ; tables_out: [ent, rel] of the other half of the double buffer."""
     to, s1, s2 = _ptr_pair(tables_out), _ptr_pair(state1), _ptr_pair(state2)
-    n_multi = 0 if multi is None else multi.shape[0]
+    # run_finish=False (timing only): the owners still write their partial sums, the finishing launch is skipped
+    n_multi = multi.shape[0] if (multi is not None and run_finish) else 0
     L.check(L.load().kge_pull_step(
         ctypes.byref(desc_in), ctypes.addressof(to), _dev(norm_in, torch.float32, "norm_in"),
         _dev(norm_out, torch.float32, "norm_out"), ctypes.addressof(s1) if state1 is not None else None,
         ctypes.addressof(s2) if state2 is not None else None, _i32(pairs, "pairs"), _i32(pc, "pc"), _i32(head, "head"),
         _i32(nxt, "next"), _i32(items, "items"), items.shape[0], _i32(inc, "inc"),
-        _dev(partials, torch.float32, "partials") if n_multi else None, _i32(multi, "multi") if n_multi else None, n_multi,
+        _dev(partials, torch.float32, "partials"), _i32(multi, "multi") if n_multi else None, n_multi,
         float(margin), OPTIMIZER_IDS[optimizer], float(lr), int(step),
         _dev(dev_hyper, torch.float32, "dev_hyper") if dev_hyper is not None else None, 1 if reset_lists else 0,
         _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_pull_step")
