@@ -407,17 +407,20 @@ def main():
     if pull:
         ps, idx = tr._pull_state()
         pairs_b, inc_b, items_b, multi_b = idx.batch(0)
-        K.pull_sample(pairs_b, E, gen.bern, gen.slots, gen.seed, 0, ps.pc, ps.head, ps.next)
+        for ls in ps.lists:   # a sampler riding in the last timed step may have filled a set for a batch that never ran
+            ls.clear()
+        ps.ready, ps.cur_list = None, 0
+        K.pull_sample(pairs_b, E, gen.bern, gen.slots, gen.seed, 0, ps.lists[0])
         desc_b = K.make_desc("transe", ps.tables[0], None, tot_entity=E, tot_relation=R, **model.desc_kwargs())
         torch.cuda.synchronize()
         eb0.record()
         for _ in range(burst):   # same inputs every time (lists kept, no buffer swap): the kernel's own duration
-            K.pull_step(desc_b, ps.tables[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs_b, ps.pc, ps.head, ps.next,
+            K.pull_step(desc_b, ps.tables[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs_b, ps.lists[0],
                         items_b, inc_b, ps.partials, multi_b, cfg.margin, cfg.optimizer, cfg.learning_rate, 1, tr.loss_buf,
                         reset_lists=False, run_finish=False)   # the small finishing launch of multi-segment rows is not in the burst
         eb1.record()
         torch.cuda.synchronize()
-        ps.head.fill_(-1)
+        ps.lists[0].clear()
     else:
         torch.cuda.synchronize()
         eb0.record()

@@ -264,24 +264,35 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
  *                        row), 1 = first item of a row cut into several (also walks the row's corrupting-entity list),
  *                        2 = a later item; kinds 1 / 2 write a partial sum to partials[slot]
  *   multi  [n_multi, 4]  (row, first slot, number of slots, 0) of the rows cut into several items
- * Per step (device): pc[n] corrupting entity | tail << 24, head[tot_entity] (-1 when idle; the step resets it when
- * reset_lists != 0) and next[n]: per-entity linked lists of the pairs that drew the entity, written by kge_pull_sample
- * (same draws as kge_sample_batch with the same seed / offset) or kge_pull_lists_explicit (given negatives).
+ * Per step (device): a kge_pull_lists set, written by kge_pull_sample (same draws as kge_sample_batch with the same
+ * seed / offset) or kge_pull_lists_explicit (given negatives) and consumed -- and reset when reset_lists != 0 -- by the
+ * step.  next_pairs != NULL: the sampler of the NEXT batch rides in this step's launch and fills next_lists (a second
+ * set), so a steady-state step is one launch (+ a small finishing launch when rows are cut into several items).
  * m->tables = the tables read; tables_out = the other half of the double buffer; norm_in / norm_out [E + R]: L2 row norms
  * of the tables read / written (kge_row_norms before the first step); state1 / state2: optimiser state per table.
  * partials: kge_pull_partial_stride(dim) floats per slot. */
+#define KGE_PULL_BUCKET 16
+typedef struct kge_pull_lists {
+    int32_t* pc;      /* [n]  per pair: corrupting entity | (tail corrupted) << 24 */
+    int32_t* count;   /* [tot_entity]  pairs that drew the entity this step; all 0 between steps */
+    int32_t* bucket;  /* [tot_entity * KGE_PULL_BUCKET]  the first KGE_PULL_BUCKET of them */
+    int32_t* head;    /* [tot_entity]  overflow list head, all -1 between steps */
+    int32_t* next;    /* [n]  overflow list links */
+} kge_pull_lists;
 int kge_pull_partial_stride(int32_t dim);
 int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, void* stream);
 int kge_pull_sample(const int32_t* pairs, int64_t n, int64_t tot_entity, const float* bern_prob, const uint64_t* slots,
-                    int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor, int32_t* pc, int32_t* head,
-                    int32_t* next, void* stream);
-int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n, int32_t* pc, int32_t* head,
-                            int32_t* next, void* stream);
+                    int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor, const kge_pull_lists* out,
+                    void* stream);
+int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n, const kge_pull_lists* out,
+                            void* stream);
 int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* norm_in, float* norm_out,
-                  float* const state1[2], float* const state2[2], const int32_t* pairs, const int32_t* pc, int32_t* head,
-                  const int32_t* next, const int32_t* items, int64_t n_items, const int32_t* inc, float* partials,
-                  const int32_t* multi, int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step,
-                  const float* dev_hyper, int32_t reset_lists, float* loss, void* stream);
+                  float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
+                  const int32_t* items, int64_t n_items, const int32_t* inc, float* partials, const int32_t* multi,
+                  int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step, const float* dev_hyper,
+                  int32_t reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern_prob, const uint64_t* slots,
+                  int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
+                  void* stream);
 
 /* ---- 1-N scoring head of the projection models (ConvE / TuckER / InteractE / HypER / AcrE:
  * projection.py:100-102, 335-336, 444-447, 606-609, 734-737):  preds[B,E] = sigmoid(x[B,dim] @ ent[E,dim]^T + bias[E]).

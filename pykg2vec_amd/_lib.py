@@ -39,6 +39,14 @@ class ModelDesc(ctypes.Structure):
     ]
 
 
+class PullLists(ctypes.Structure):
+    """struct kge_pull_lists"""
+    _fields_ = [("pc", ctypes.c_void_p), ("count", ctypes.c_void_p), ("bucket", ctypes.c_void_p), ("head", ctypes.c_void_p),
+                ("next", ctypes.c_void_p)]
+
+
+PULL_BUCKET = 16
+
 _SIGNATURES = {
     "kge_abi_version": (ctypes.c_int, []),
     "kge_last_error": (ctypes.c_char_p, []),
@@ -82,11 +90,13 @@ _SIGNATURES = {
     "kge_pull_partial_stride": (ctypes.c_int, [ctypes.c_int32]),
     "kge_row_norms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_pull_sample": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
-                                       ctypes.c_uint64, ctypes.c_uint64] + [ctypes.c_void_p] * 5),
-    "kge_pull_lists_explicit": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int64] + [ctypes.c_void_p] * 4),
-    "kge_pull_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 10 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int32, ctypes.c_float, ctypes.c_int64,
-                                     ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+                                       ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(PullLists), ctypes.c_void_p]),
+    "kge_pull_lists_explicit": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.POINTER(PullLists), ctypes.c_void_p]),
+    "kge_pull_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 6 + [ctypes.POINTER(PullLists), ctypes.c_void_p,
+                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
+                                     ctypes.c_int32, ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
+                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -290,33 +290,36 @@ int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, v
     return launch_row_norms(table, rows, dim, norms, (hipStream_t)stream);
 }
 
+static int lists_ok(const kge_pull_lists* l) { return l && l->pc && l->count && l->bucket && l->head && l->next; }
+
 int kge_pull_sample(const int32_t* pairs, int64_t n, int64_t tot_entity, const float* bern_prob, const uint64_t* slots,
-                    int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor, int32_t* pc, int32_t* head,
-                    int32_t* next, void* stream) {
+                    int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor, const kge_pull_lists* out,
+                    void* stream) {
     if (n == 0) return 0;
-    if (n < 0 || !pairs || !pc || !head || !next || tot_entity <= 0) { set_error("kge_pull_sample: bad arguments"); return -1; }
+    if (n < 0 || !pairs || !lists_ok(out) || tot_entity <= 0) { set_error("kge_pull_sample: bad arguments"); return -1; }
     if (tot_entity > (1 << 24)) { set_error("kge_pull_sample: more than 2^24 entities not supported by the packed key"); return -1; }
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_pull_sample: n_slots must be a power of two"); return -1; }
-    return launch_pull_sample(pairs, n, tot_entity, bern_prob, slots, n_slots, seed, offset, dev_cursor, pc, head, next,
-                              (hipStream_t)stream);
+    return launch_pull_sample(pairs, n, tot_entity, bern_prob, slots, n_slots, seed, offset, dev_cursor, out, (hipStream_t)stream);
 }
 
-int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n, int32_t* pc, int32_t* head,
-                            int32_t* next, void* stream) {
+int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n, const kge_pull_lists* out,
+                            void* stream) {
     if (n == 0) return 0;
-    if (n < 0 || !pairs || !nh || !nt || !pc || !head || !next) { set_error("kge_pull_lists_explicit: bad arguments"); return -1; }
-    return launch_pull_lists_explicit(pairs, nh, nt, n, pc, head, next, (hipStream_t)stream);
+    if (n < 0 || !pairs || !nh || !nt || !lists_ok(out)) { set_error("kge_pull_lists_explicit: bad arguments"); return -1; }
+    return launch_pull_lists_explicit(pairs, nh, nt, n, out, (hipStream_t)stream);
 }
 
 int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* norm_in, float* norm_out,
-                  float* const state1[2], float* const state2[2], const int32_t* pairs, const int32_t* pc, int32_t* head,
-                  const int32_t* next, const int32_t* items, int64_t n_items, const int32_t* inc, float* partials,
-                  const int32_t* multi, int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step,
-                  const float* dev_hyper, int32_t reset_lists, float* loss, void* stream) {
+                  float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
+                  const int32_t* items, int64_t n_items, const int32_t* inc, float* partials, const int32_t* multi,
+                  int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step, const float* dev_hyper,
+                  int32_t reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern_prob, const uint64_t* slots,
+                  int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
+                  void* stream) {
     if (validate(m, false, "kge_pull_step")) return -1;
     if (m->model != KGE_TRANSE) { set_error("kge_pull_step: TransE only (model %d)", m->model); return -1; }
     if (n_items <= 0 || n_multi < 0 || !tables_out || !tables_out[0] || !tables_out[1] || !norm_in || !norm_out || !pairs ||
-        !pc || !head || !next || !items || !inc || !loss || !partials || (n_multi > 0 && !multi)) {
+        !lists_ok(lists) || !items || !inc || !loss || !partials || (n_multi > 0 && !multi)) {
         set_error("kge_pull_step: bad arguments");
         return -1;
     }
@@ -326,9 +329,16 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
     }
     if (optimizer != KGE_OPT_SGD && (!state1 || !state1[0] || !state1[1])) { set_error("kge_pull_step: optimizer state missing"); return -1; }
     if (optimizer == KGE_OPT_ADAM && (!state2 || !state2[0] || !state2[1])) { set_error("kge_pull_step: adam needs two state buffers"); return -1; }
-    return launch_pull_step(m, tables_out, norm_in, norm_out, state1, state2, pairs, pc, head, next, items, n_items, inc,
-                            partials, multi, n_multi, margin, optimizer, lr, step, dev_hyper, reset_lists, loss,
-                            (hipStream_t)stream);
+    if (next_pairs) {
+        if (next_n < 0 || !lists_ok(next_lists) || next_lists->count == lists->count || (slots && (n_slots & (n_slots - 1)))) {
+            set_error("kge_pull_step: the next batch's sampler needs its own list set");
+            return -1;
+        }
+        if (validate_packed_key(m, "kge_pull_step")) return -1;
+    }
+    return launch_pull_step(m, tables_out, norm_in, norm_out, state1, state2, pairs, lists, items, n_items, inc, partials, multi,
+                            n_multi, margin, optimizer, lr, step, dev_hyper, reset_lists, next_pairs, next_n, bern_prob, slots,
+                            n_slots, seed, next_offset, next_lists, loss, (hipStream_t)stream);
 }
 
 int kge_head_1n_forward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,

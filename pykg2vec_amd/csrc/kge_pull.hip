@@ -10,8 +10,8 @@
 // resource for the idle ones: every parameter ROW has one owner group per step which
 //   * walks the row's incidence list -- the (pair, role) occurrences of the row in this batch: as head, as tail, as
 //     relation (static per batch, indexed once when the generator is built: a batch is a fixed slice of the permutation,
-//     data/generator.py:23-35) and as corrupting entity (per step: the sampler threads its draws into per-entity linked
-//     lists, consumed in pair order),
+//     data/generator.py:23-35) and as corrupting entity (per step: the sampler registers each draw in the drawn entity's
+//     bucket, consumed in pair order; the sampler of step k+1 rides in the launch of step k),
 //   * RE-computes each incident pair's forward (three L2-resident row gathers + pre-computed row norms: one butterfly
 //     reduction per incidence) and keeps only the gradient of ITS OWN row, summed in registers in a fixed order,
 //   * applies the normalisation backward once, then the dense optimiser update of that row (torch.optim semantics, every
@@ -19,7 +19,7 @@
 //     for the next step.
 // Each pair is evaluated ~3.25 times instead of once (cheap: VALU + L2 reads), nothing is scattered, the optimiser pass
 // and the gradient zeroing pass disappear.  Rows with long lists (frequent relations, hub entities) are cut into
-// segments of at most kPullSegment incidences: each segment's owner writes a partial sum, a small second kernel adds the
+// segments of at most PullIndex.SEGMENT (host) incidences: each segment's owner writes a partial sum, a small second kernel adds the
 // partials in segment order and finishes the row -- still deterministic.
 #include "kge_row_kernels.h"
 #include "kge_opt_device.h"
@@ -28,6 +28,26 @@
 namespace kge {
 
 constexpr int kRoleH = 0, kRoleT = 1, kRoleR = 2, kRoleC = 3;
+constexpr int kPullCap = 16;   // per-entity bucket of "drawn as corrupting entity" pairs; overflow goes to a linked list
+
+// per-step sampler output: which pairs drew entity e as their corrupting entity
+struct PullLists {
+    int32_t* pc;       // [B]  per pair: corrupting entity | (tail corrupted) << 24
+    int32_t* count;    // [E]  number of pairs that drew e this step (reset to 0 by e's owner)
+    int32_t* bucket;   // [E * kPullCap] the first kPullCap of them, in arrival (i.e. arbitrary) order
+    int32_t* head;     // [E]  overflow list head (-1: none; reset by e's owner)
+    int32_t* next;     // [B]  overflow list links
+};
+
+struct PullSampleArgs {
+    const int4* pairs;         // batch to sample: (h, r, t, -)
+    int64_t n, E;
+    const float* bern;
+    const unsigned long long* slots;
+    unsigned long long mask, seed, offset;
+    const int64_t* cursor;
+    PullLists out;
+};
 
 struct PullArgs {
     const float* tab_in[2];    // entity / relation table read by this step
@@ -37,19 +57,33 @@ struct PullArgs {
     float* s1[2];              // optimiser state, same row layout as the tables (NULL where the optimiser has none)
     float* s2[2];
     const int4* pairs;         // this batch: (h, r, t, -)
-    const int32_t* pc;         // per pair: corrupting entity | (tail corrupted) << 24
-    int32_t* head;             // per entity: most recent pair that drew it as corrupting entity, -1 = none
-    const int32_t* next;       // per pair: the previous pair that drew the same entity, -1 = none
+    PullLists lists;           // this batch's sampler output
     const int4* items;         // work items: (row g, first incidence, end incidence, kind | slot << 2)
     const int32_t* inc;        // static incidences of the batch sorted by (row, pair, role): pair << 2 | role
     float* partials;           // [slots][G * NCH] partial gradient sums of multi-segment rows
     const int4* multi;         // rows with several segments: (row g, first slot, number of slots, -)
     int64_t n_items, n_multi;
+    int item_blocks;           // blocks [0, item_blocks) own work items; later blocks sample the NEXT batch
     int E, d, l1, reset_lists;
     float margin;
     OptArgs opt;
     const float* dev_hyper;    // optional device-resident {lr, step_size, bc2_sqrt}
 };
+
+// one pair of the sampled batch: draw the corruption (same Philox counters as kge_sample_batch / the fused push kernels:
+// offset + pair index) and register the pair with the corrupting entity
+__device__ __forceinline__ void pull_sample_one(const PullSampleArgs& sa, int64_t i) {
+    const unsigned long long off = sa.cursor ? sa.offset + (unsigned long long)sa.cursor[1] : sa.offset;
+    const int4 p = sa.pairs[i];
+    int64_t nh, nt;
+    corrupt_one(p.x, p.y, p.z, sa.E, sa.bern, sa.slots, sa.mask, sa.seed, off + (unsigned long long)i, nh, nt);
+    const bool tail = nh == p.x;
+    const int c = (int)(tail ? nt : nh);
+    sa.out.pc[i] = c | ((int)tail << 24);
+    const int pos = atomicAdd(sa.out.count + c, 1);
+    if (pos < kPullCap) sa.out.bucket[(int64_t)c * kPullCap + pos] = (int)i;
+    else sa.out.next[i] = atomicExch(sa.out.head + c, (int)i);
+}
 
 // gradient wrt the NORMALISED own row, summed over incidences -> normalisation backward -> optimiser -> new row + norm
 template <int OPT, int G, int NCH>
@@ -57,7 +91,10 @@ __device__ __forceinline__ void pull_finish_row(const PullArgs& a, int g, const 
                                                 int gl) {
     const int d = a.d;
     const bool is_rel = g >= a.E;
-    const int tb = is_rel ? 1 : 0;
+    // (pointer selects, not a[tb]: a runtime index into a kernel-argument array would put the array in scratch)
+    float* const t_out = is_rel ? a.tab_out[1] : a.tab_out[0];
+    float* const st1 = is_rel ? a.s1[1] : a.s1[0];
+    float* const st2 = is_rel ? a.s2[1] : a.s2[0];
     const int64_t off = (int64_t)(is_rel ? g - a.E : g) * d;
     const bool fX = nX > kEpsNormalize;
     const float iX = 1.0f / fmaxf(nX, kEpsNormalize);
@@ -75,12 +112,12 @@ __device__ __forceinline__ void pull_finish_row(const PullArgs& a, int g, const 
         const float graw = fX ? (gs[k] - (X[k] * iX) * dX) * iX : gs[k] * iX;
         float p = X[k], m1 = 0.f, m2 = 0.f;
         if (live) {
-            if constexpr (OPT != KGE_OPT_SGD) m1 = a.s1[tb][off + e];
-            if constexpr (OPT == KGE_OPT_ADAM) m2 = a.s2[tb][off + e];
+            if constexpr (OPT != KGE_OPT_SGD) m1 = st1[off + e];
+            if constexpr (OPT == KGE_OPT_ADAM) m2 = st2[off + e];
             opt_update<OPT>(p, graw, m1, m2, o);
-            a.tab_out[tb][off + e] = p;
-            if constexpr (OPT != KGE_OPT_SGD) a.s1[tb][off + e] = m1;
-            if constexpr (OPT == KGE_OPT_ADAM) a.s2[tb][off + e] = m2;
+            t_out[off + e] = p;
+            if constexpr (OPT != KGE_OPT_SGD) st1[off + e] = m1;
+            if constexpr (OPT == KGE_OPT_ADAM) st2[off + e] = m2;
             n2 = fmaf(p, p, n2);
         }
     }
@@ -88,10 +125,25 @@ __device__ __forceinline__ void pull_finish_row(const PullArgs& a, int g, const 
     if (gl == 0) a.norm_out[g] = sqrtf(n2);
 }
 
+// the four rows of one incident pair (raw table values) and their norms, as gathered for one owner
+template <int NCH>
+struct PullRows {
+    float hh[NCH], rr[NCH], tt[NCH], cc[NCH];
+    float nh, nr, nt, nc;
+    int role;
+    bool tail;
+};
+
 template <int OPT, int G, int NCH>
-__global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, float* __restrict__ loss) {
+__global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs sa, float* __restrict__ loss) {
     constexpr int GPB = kBlock / G;
+    if ((int)blockIdx.x >= a.item_blocks) {   // tail blocks: the sampler of the NEXT batch rides along (writes the other list set)
+        const int64_t i = (int64_t)((int)blockIdx.x - a.item_blocks) * kBlock + threadIdx.x;
+        if (i < sa.n) pull_sample_one(sa, i);
+        return;
+    }
     const int gl = threadIdx.x % G;
+    const int gbase = (threadIdx.x & 63) / G * G;   // first lane of this group inside its wave
     const int d = a.d;
     const bool l1 = a.l1 != 0;
     const int64_t item = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
@@ -101,64 +153,66 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, float* __restr
         const int g = it.x;
         const int kind = it.w & 3;
         const bool is_rel = g >= a.E;
-        float X[NCH], Xh[NCH], gs[NCH];
-        load_row<G, NCH>(X, a.tab_in[is_rel ? 1 : 0] + (int64_t)(is_rel ? g - a.E : g) * d, d, gl);
-        const float nX = a.norm_in[g];
-        {
-            const float iX = 1.0f / fmaxf(nX, kEpsNormalize);
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) { Xh[k] = X[k] * iX; gs[k] = 0.f; }
+        const int n_static = it.z - it.y;
+        // ---- the owner's visit list, one descriptor per lane: static incidences first, then the pairs that drew this
+        // entity as their corrupting entity (bucket entries, visited in pair order)
+        int vi = -1, vrole = 0, ord = gbase + gl;
+        if (gl < n_static) { const int e = a.inc[it.y + gl]; vi = e >> 2; vrole = e & 3; }
+        int cnt = 0;
+        if (!is_rel && kind != 2) cnt = a.lists.count[g];
+        const bool fast_c = cnt <= kPullCap && n_static + cnt <= G;
+        int nvis = n_static;
+        if (cnt > 0 && fast_c) {
+            const int q = gl - n_static;
+            if (q >= 0 && q < cnt) { vi = a.lists.bucket[(int64_t)g * kPullCap + q]; vrole = kRoleC; }
+            if (cnt > 1) {   // arrival order is arbitrary: rank the entries by pair index, visit by rank
+                int rank = 0;
+                for (int m = 0; m < cnt; ++m) rank += __shfl(vi, gbase + n_static + m, 64) < vi ? 1 : 0;
+                for (int m = 0; m < cnt; ++m)
+                    if (__shfl(rank, gbase + n_static + m, 64) == q) ord = gbase + n_static + m;
+            }
+            nvis += cnt;
         }
-        // one incidence: pair i seen from role `role` (group-uniform)
-        auto visit = [&](int i, int role) {
-            const int4 pr = a.pairs[i];
-            const int pcv = a.pc[i];
-            const int c = pcv & 0xFFFFFF;
-            const bool tail = (pcv >> 24) != 0;
-            float hh[NCH], rr[NCH], tt[NCH], cc[NCH];
-            // the three rows that are not the owner's: gather + scale by the stored norm (own row: registers)
-            if (role != kRoleH) {
-                load_row<G, NCH>(hh, a.tab_in[0] + (int64_t)pr.x * d, d, gl);
-                const float s = 1.0f / fmaxf(a.norm_in[pr.x], kEpsNormalize);
+        int4 pr = make_int4(0, 0, 0, 0);
+        int pcv = 0;
+        if (vi >= 0) { pr = a.pairs[vi]; pcv = a.lists.pc[vi]; }
+        float X[NCH], gs[NCH];
+        load_row<G, NCH>(X, (is_rel ? a.tab_in[1] : a.tab_in[0]) + (int64_t)(is_rel ? g - a.E : g) * d, d, gl);
+        const float nX = a.norm_in[g];
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) hh[k] *= s;
-            } else {
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) hh[k] = Xh[k];
-            }
-            if (role != kRoleR) {
-                load_row<G, NCH>(rr, a.tab_in[1] + (int64_t)pr.y * d, d, gl);
-                const float s = 1.0f / fmaxf(a.norm_in[a.E + pr.y], kEpsNormalize);
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) rr[k] *= s;
-            } else {
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) rr[k] = Xh[k];
-            }
-            if (role != kRoleT) {
-                load_row<G, NCH>(tt, a.tab_in[0] + (int64_t)pr.z * d, d, gl);
-                const float s = 1.0f / fmaxf(a.norm_in[pr.z], kEpsNormalize);
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) tt[k] *= s;
-            } else {
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) tt[k] = Xh[k];
-            }
-            if (role != kRoleC) {
-                load_row<G, NCH>(cc, a.tab_in[0] + (int64_t)c * d, d, gl);
-                const float s = 1.0f / fmaxf(a.norm_in[c], kEpsNormalize);
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) cc[k] *= s;
-            } else {
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) cc[k] = Xh[k];
-            }
+        for (int k = 0; k < NCH; ++k) gs[k] = 0.f;
+
+        // gather the rows of one incident pair: the owner's own row comes from registers, the other three from L2
+        auto fetch = [&](int h, int r, int t, int c, bool tail, int role, PullRows<NCH>& b) {
+            b.role = role; b.tail = tail;
+            if (role != kRoleH) { load_row<G, NCH>(b.hh, a.tab_in[0] + (int64_t)h * d, d, gl); b.nh = a.norm_in[h]; }
+            if (role != kRoleR) { load_row<G, NCH>(b.rr, a.tab_in[1] + (int64_t)r * d, d, gl); b.nr = a.norm_in[a.E + r]; }
+            if (role != kRoleT) { load_row<G, NCH>(b.tt, a.tab_in[0] + (int64_t)t * d, d, gl); b.nt = a.norm_in[t]; }
+            if (role != kRoleC) { load_row<G, NCH>(b.cc, a.tab_in[0] + (int64_t)c * d, d, gl); b.nc = a.norm_in[c]; }
+        };
+        auto fetch_visit = [&](int v, PullRows<NCH>& b) {
+            const int src = __shfl(ord, gbase + v, 64);
+            const int pv = __shfl(pcv, src, 64);
+            fetch(__shfl(pr.x, src, 64), __shfl(pr.y, src, 64), __shfl(pr.z, src, 64), pv & 0xFFFFFF, (pv >> 24) != 0,
+                  __shfl(vrole, src, 64), b);
+        };
+        // forward of the pair (identical arithmetic whichever of its four rows the owner holds), hinge, and the owner's
+        // share of the backward: gradient wrt its NORMALISED row
+        auto compute = [&](const PullRows<NCH>& b) {
+            const int role = b.role;
+            // (selects, not stores into b: a role-indexed store would push the four norms into scratch)
+            const float iH = 1.0f / fmaxf(role == kRoleH ? nX : b.nh, kEpsNormalize);
+            const float iR = 1.0f / fmaxf(role == kRoleR ? nX : b.nr, kEpsNormalize);
+            const float iT = 1.0f / fmaxf(role == kRoleT ? nX : b.nt, kEpsNormalize);
+            const float iC = 1.0f / fmaxf(role == kRoleC ? nX : b.nc, kEpsNormalize);
             float up[NCH], un[NCH];
             float sp = 0.f, sn = 0.f;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                up[k] = hh[k] + rr[k] - tt[k];
-                un[k] = tail ? (hh[k] + rr[k] - cc[k]) : (cc[k] + rr[k] - tt[k]);
+                const float hh = (role == kRoleH ? X[k] : b.hh[k]) * iH, rr = (role == kRoleR ? X[k] : b.rr[k]) * iR;
+                const float tt = (role == kRoleT ? X[k] : b.tt[k]) * iT, cc = (role == kRoleC ? X[k] : b.cc[k]) * iC;
+                up[k] = hh + rr - tt;
+                un[k] = b.tail ? (hh + rr - cc) : (cc + rr - tt);
                 sp = l1 ? sp + fabsf(up[k]) : fmaf(up[k], up[k], sp);
                 sn = l1 ? sn + fabsf(un[k]) : fmaf(un[k], un[k], sn);
             }
@@ -169,34 +223,52 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, float* __restr
             const float coef = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);   // torch.max splits the subgradient at equality
             if (coef == 0.f) return;
             const float ip = (!l1 && sp > 0.f) ? coef / sp : 0.f, in = (!l1 && sn > 0.f) ? -coef / sn : 0.f;
+            // own row's coefficient in up / un:  H: +1 / (tail ? +1 : 0)   T: -1 / (tail ? 0 : -1)   R: +1 / +1   C: 0 / (tail ? -1 : +1)
+            const float su = role == kRoleH ? 1.f : role == kRoleT ? -1.f : role == kRoleR ? 1.f : 0.f;
+            const float sv = role == kRoleH ? (b.tail ? 1.f : 0.f) : role == kRoleT ? (b.tail ? 0.f : -1.f)
+                           : role == kRoleR ? 1.f : (b.tail ? -1.f : 1.f);
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 const float gp = l1 ? (up[k] > 0.f ? coef : (up[k] < 0.f ? -coef : 0.f)) : up[k] * ip;
                 const float gn = l1 ? (un[k] > 0.f ? -coef : (un[k] < 0.f ? coef : 0.f)) : un[k] * in;
-                float gx;
-                if (role == kRoleH) gx = tail ? gp + gn : gp;
-                else if (role == kRoleT) gx = tail ? -gp : -(gp + gn);
-                else if (role == kRoleR) gx = gp + gn;
-                else gx = tail ? -gn : gn;
-                gs[k] += gx;
+                gs[k] = fmaf(sv, gn, fmaf(su, gp, gs[k]));
             }
         };
-        for (int p = it.y; p < it.z; ++p) {
-            const int e = a.inc[p];
-            visit(e >> 2, e & 3);
+        // software pipeline: the gathers of visit v+1 are in flight while visit v is evaluated (two buffers, no copies)
+        if (nvis > 0) {
+            PullRows<NCH> ba, bb;
+            fetch_visit(0, ba);
+            for (int v = 0; v < nvis; v += 2) {
+                const bool more = v + 1 < nvis;
+                if (more) fetch_visit(v + 1, bb);
+                compute(ba);
+                if (more) {
+                    if (v + 2 < nvis) fetch_visit(v + 2, ba);
+                    compute(bb);
+                }
+            }
         }
-        if (!is_rel && kind != 2) {
-            // pairs whose sampler drew this entity: a linked list in arrival (i.e. arbitrary) order; visit in pair order
+        if (cnt > 0 && !fast_c) {
+            // more drawers than the lane group or the bucket holds (tiny entity sets only): pair-ordered selection over
+            // the bucket and the overflow list, one unpipelined visit at a time
+            const int nb = cnt < kPullCap ? cnt : kPullCap;
             int last = -1;
             for (;;) {
                 int best = 0x7FFFFFFF;
-                for (int j = a.head[g]; j >= 0; j = a.next[j])
-                    if (j > last && j < best) best = j;
+                for (int m = 0; m < nb; ++m) { const int j = a.lists.bucket[(int64_t)g * kPullCap + m]; if (j > last && j < best) best = j; }
+                for (int j = a.lists.head[g]; j >= 0; j = a.lists.next[j]) if (j > last && j < best) best = j;
                 if (best == 0x7FFFFFFF) break;
-                visit(best, kRoleC);
+                const int4 p2 = a.pairs[best];
+                const int pv = a.lists.pc[best];
+                PullRows<NCH> b;
+                fetch(p2.x, p2.y, p2.z, pv & 0xFFFFFF, (pv >> 24) != 0, kRoleC, b);
+                compute(b);
                 last = best;
             }
-            if (a.reset_lists && gl == 0) a.head[g] = -1;
+        }
+        if (cnt > 0 && a.reset_lists && gl == 0) {
+            a.lists.count[g] = 0;
+            if (cnt > kPullCap) a.lists.head[g] = -1;
         }
         if (kind == 0) {
             pull_finish_row<OPT, G, NCH>(a, g, X, nX, gs, gl);
@@ -220,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_finish(PullArgs a) {
     const int g = row.x;
     const bool is_rel = g >= a.E;
     float X[NCH], gs[NCH];
-    load_row<G, NCH>(X, a.tab_in[is_rel ? 1 : 0] + (int64_t)(is_rel ? g - a.E : g) * a.d, a.d, gl);
+    load_row<G, NCH>(X, (is_rel ? a.tab_in[1] : a.tab_in[0]) + (int64_t)(is_rel ? g - a.E : g) * a.d, a.d, gl);
 #pragma unroll
     for (int k = 0; k < NCH; ++k) gs[k] = 0.f;
     for (int s = 0; s < row.z; ++s) {
@@ -247,42 +319,38 @@ __global__ __launch_bounds__(kBlock) void k_row_norms(const float* __restrict__ 
     if (gl == 0) out[r] = sqrtf(n2);
 }
 
-// per pair: draw the corruption (same Philox counters as kge_sample_batch / the fused push kernels: offset + pair index)
-// and thread the pair into the corrupting entity's list
-__global__ __launch_bounds__(256) void k_pull_sample(const int4* __restrict__ pairs, int64_t n, int64_t E,
-                                                     const float* __restrict__ bern, const unsigned long long* __restrict__ slots,
-                                                     unsigned long long mask, unsigned long long seed, unsigned long long offset,
-                                                     const int64_t* __restrict__ cursor, int32_t* __restrict__ pc,
-                                                     int32_t* __restrict__ head, int32_t* __restrict__ next) {
+// stand-alone sampler launch (first step of an epoch; later steps' sampling rides in the previous step's launch)
+__global__ __launch_bounds__(256) void k_pull_sample(PullSampleArgs sa) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long off = cursor ? offset + (unsigned long long)cursor[1] : offset;
-    const int4 p = pairs[i];
-    int64_t nh, nt;
-    corrupt_one(p.x, p.y, p.z, E, bern, slots, mask, seed, off + (unsigned long long)i, nh, nt);
-    const bool tail = nh == p.x;
-    const int c = (int)(tail ? nt : nh);
-    pc[i] = c | ((int)tail << 24);
-    next[i] = atomicExch(head + c, (int)i);
+    if (i < sa.n) pull_sample_one(sa, i);
 }
 
-// the same lists from explicit negatives (parity tests drive the step with the reference's golden batches)
+// the same registration from explicit negatives (parity tests drive the step with the reference's golden batches)
 __global__ __launch_bounds__(256) void k_pull_lists_explicit(const int4* __restrict__ pairs, const int64_t* __restrict__ nh,
-                                                             const int64_t* __restrict__ nt, int64_t n, int32_t* __restrict__ pc,
-                                                             int32_t* __restrict__ head, int32_t* __restrict__ next) {
+                                                             const int64_t* __restrict__ nt, int64_t n, PullLists out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bool tail = nh[i] == pairs[i].x;   // the sampler's own rule (kge_score.hip: my_tail = nh == sh)
     const int c = (int)(tail ? nt[i] : nh[i]);
-    pc[i] = c | ((int)tail << 24);
-    next[i] = atomicExch(head + c, (int)i);
+    out.pc[i] = c | ((int)tail << 24);
+    const int pos = atomicAdd(out.count + c, 1);
+    if (pos < kPullCap) out.bucket[(int64_t)c * kPullCap + pos] = (int)i;
+    else out.next[i] = atomicExch(out.head + c, (int)i);
 }
 
 // ------------------------------------------------------------------ host side
+static PullLists to_lists(const kge_pull_lists* l) {
+    PullLists o;
+    o.pc = l->pc; o.count = l->count; o.bucket = l->bucket; o.head = l->head; o.next = l->next;
+    return o;
+}
+
 template <int OPT, int G, int NCH>
-static int launch_pull_geo(const PullArgs& a, float* loss, hipStream_t s) {
+static int launch_pull_geo(PullArgs& a, const PullSampleArgs& sa, float* loss, hipStream_t s) {
     constexpr int GPB = kBlock / G;
-    hipLaunchKernelGGL((k_pull_step<OPT, G, NCH>), dim3((unsigned)((a.n_items + GPB - 1) / GPB)), dim3(kBlock), 0, s, a, loss);
+    a.item_blocks = (int)((a.n_items + GPB - 1) / GPB);
+    const int sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
+    hipLaunchKernelGGL((k_pull_step<OPT, G, NCH>), dim3((unsigned)(a.item_blocks + sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
     int rc = check_launch("k_pull_step");
     if (rc || a.n_multi == 0) return rc;
     hipLaunchKernelGGL((k_pull_finish<OPT, G, NCH>), dim3((unsigned)((a.n_multi + GPB - 1) / GPB)), dim3(kBlock), 0, s, a);
@@ -290,8 +358,8 @@ static int launch_pull_geo(const PullArgs& a, float* loss, hipStream_t s) {
 }
 
 template <int OPT>
-static int launch_pull_opt(const PullArgs& a, Geometry geo, float* loss, hipStream_t s) {
-#define KGE_PULL(G_, NCH_) if (geo.G == G_ && geo.NCH == NCH_) return launch_pull_geo<OPT, G_, NCH_>(a, loss, s);
+static int launch_pull_opt(PullArgs& a, const PullSampleArgs& sa, Geometry geo, float* loss, hipStream_t s) {
+#define KGE_PULL(G_, NCH_) if (geo.G == G_ && geo.NCH == NCH_) return launch_pull_geo<OPT, G_, NCH_>(a, sa, loss, s);
     KGE_PULL(32, 1) KGE_PULL(32, 2) KGE_PULL(32, 4) KGE_PULL(32, 8) KGE_PULL(64, 8) KGE_PULL(64, 16)
 #undef KGE_PULL
     return -1;
@@ -303,11 +371,25 @@ int pull_partial_stride(int dim) {
     return geo.G * geo.NCH;
 }
 
+static PullSampleArgs make_sample_args(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots,
+                                       int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor,
+                                       const kge_pull_lists* out) {
+    PullSampleArgs sa;
+    sa.pairs = (const int4*)pairs; sa.n = n; sa.E = E; sa.bern = bern;
+    sa.slots = (const unsigned long long*)slots; sa.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
+    sa.seed = seed; sa.offset = offset; sa.cursor = cursor;
+    if (out) sa.out = to_lists(out);
+    else { sa.out.pc = sa.out.count = sa.out.bucket = sa.out.head = sa.out.next = nullptr; }
+    return sa;
+}
+
 int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* norm_in, float* norm_out,
-                     float* const state1[2], float* const state2[2], const int32_t* pairs, const int32_t* pc, int32_t* head,
-                     const int32_t* next, const int32_t* items, int64_t n_items, const int32_t* inc, float* partials,
-                     const int32_t* multi, int64_t n_multi, float margin, int optimizer, float lr, int64_t step,
-                     const float* dev_hyper, int reset_lists, float* loss, hipStream_t s) {
+                     float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
+                     const int32_t* items, int64_t n_items, const int32_t* inc, float* partials, const int32_t* multi,
+                     int64_t n_multi, float margin, int optimizer, float lr, int64_t step, const float* dev_hyper,
+                     int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern, const uint64_t* slots,
+                     int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
+                     hipStream_t s) {
     Geometry geo;
     if (!pick_geometry(m->dim, &geo)) { set_error("kge_pull_step: hidden size %d exceeds the register-resident rows", m->dim); return -1; }
     PullArgs a;
@@ -316,18 +398,20 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
         a.s1[i] = state1 ? state1[i] : nullptr; a.s2[i] = state2 ? state2[i] : nullptr;
     }
     a.norm_in = norm_in; a.norm_out = norm_out;
-    a.pairs = (const int4*)pairs; a.pc = pc; a.head = head; a.next = next;
+    a.pairs = (const int4*)pairs; a.lists = to_lists(lists);
     a.items = (const int4*)items; a.inc = inc; a.partials = partials; a.multi = (const int4*)multi;
-    a.n_items = n_items; a.n_multi = n_multi;
+    a.n_items = n_items; a.n_multi = n_multi; a.item_blocks = 0;
     a.E = (int)m->tot_entity; a.d = m->dim; a.l1 = (m->flags & KGE_FLAG_L1) ? 1 : 0; a.reset_lists = reset_lists;
     a.margin = margin;
     a.opt = make_opt_args(lr, step < 1 ? 1 : step);
     a.dev_hyper = dev_hyper;
+    const PullSampleArgs sa = make_sample_args(next_pairs, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
+                                               n_slots, seed, next_offset, nullptr, next_lists);
     switch (optimizer) {
-        case KGE_OPT_SGD: return launch_pull_opt<KGE_OPT_SGD>(a, geo, loss, s);
-        case KGE_OPT_ADAM: return launch_pull_opt<KGE_OPT_ADAM>(a, geo, loss, s);
-        case KGE_OPT_ADAGRAD: return launch_pull_opt<KGE_OPT_ADAGRAD>(a, geo, loss, s);
-        case KGE_OPT_RMSPROP: return launch_pull_opt<KGE_OPT_RMSPROP>(a, geo, loss, s);
+        case KGE_OPT_SGD: return launch_pull_opt<KGE_OPT_SGD>(a, sa, geo, loss, s);
+        case KGE_OPT_ADAM: return launch_pull_opt<KGE_OPT_ADAM>(a, sa, geo, loss, s);
+        case KGE_OPT_ADAGRAD: return launch_pull_opt<KGE_OPT_ADAGRAD>(a, sa, geo, loss, s);
+        case KGE_OPT_RMSPROP: return launch_pull_opt<KGE_OPT_RMSPROP>(a, sa, geo, loss, s);
     }
     set_error("kge_pull_step: unknown optimizer %d", optimizer);
     return -1;
@@ -349,18 +433,16 @@ int launch_row_norms(const float* table, int64_t rows, int dim, float* out, hipS
 }
 
 int launch_pull_sample(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots,
-                       uint64_t seed, uint64_t offset, const int64_t* cursor, int32_t* pc, int32_t* head, int32_t* next,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(k_pull_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int4*)pairs, n, E, bern,
-                       (const unsigned long long*)slots, (unsigned long long)(slots ? n_slots - 1 : 0), seed, offset, cursor, pc,
-                       head, next);
+                       uint64_t seed, uint64_t offset, const int64_t* cursor, const kge_pull_lists* out, hipStream_t s) {
+    const PullSampleArgs sa = make_sample_args(pairs, n, E, bern, slots, n_slots, seed, offset, cursor, out);
+    hipLaunchKernelGGL(k_pull_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sa);
     return check_launch("k_pull_sample");
 }
 
-int launch_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n, int32_t* pc,
-                               int32_t* head, int32_t* next, hipStream_t s) {
+int launch_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n,
+                               const kge_pull_lists* out, hipStream_t s) {
     hipLaunchKernelGGL(k_pull_lists_explicit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int4*)pairs, nh, nt, n,
-                       pc, head, next);
+                       to_lists(out));
     return check_launch("k_pull_lists_explicit");
 }
 

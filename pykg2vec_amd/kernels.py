@@ -407,40 +407,63 @@ def pull_partial_stride(dim):
     return int(L.load().kge_pull_partial_stride(int(dim)))
 
 
-def pull_sample(pairs, tot_entity, bern_prob, slots, seed, offset, pc, head, nxt, cursor=None):
+class PullListSet:
+    """One kge_pull_lists set: per-step sampler output of the owner-computes step (count all 0 / head all -1 between steps)."""
+
+    def __init__(self, batch_size, tot_entity, device):
+        self.pc = torch.empty(batch_size, dtype=torch.int32, device=device)
+        self.next = torch.empty(batch_size, dtype=torch.int32, device=device)
+        self.count = torch.zeros(tot_entity, dtype=torch.int32, device=device)
+        self.bucket = torch.empty(tot_entity * L.PULL_BUCKET, dtype=torch.int32, device=device)
+        self.head = torch.full((tot_entity,), -1, dtype=torch.int32, device=device)
+        self.c = L.PullLists(self.pc.data_ptr(), self.count.data_ptr(), self.bucket.data_ptr(), self.head.data_ptr(),
+                             self.next.data_ptr())
+
+    def clear(self):
+        self.count.zero_()
+        self.head.fill_(-1)
+
+
+def pull_sample(pairs, tot_entity, bern_prob, slots, seed, offset, lists, cursor=None):
     """Draw the corruption of every pair of a batch (the draws kge_sample_batch makes for the same seed / offset) and
-    thread the pairs into per-entity lists of `drawn as corrupting entity`."""
+    register each pair with the entity it drew (`lists`: a cleared PullListSet)."""
     bp = _dev(bern_prob, torch.float32, "bern_prob") if bern_prob is not None else None
     sp = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
     pcur = _dev(cursor, torch.int64, "cursor") if cursor is not None else None
     L.check(L.load().kge_pull_sample(_i32(pairs, "pairs"), pairs.shape[0], int(tot_entity), bp, sp,
                                      slots.numel() if slots is not None else 0, int(seed) & (2 ** 64 - 1),
-                                     int(offset) & (2 ** 64 - 1), pcur, _i32(pc, "pc"), _i32(head, "head"), _i32(nxt, "next"),
-                                     _stream()), "kge_pull_sample")
+                                     int(offset) & (2 ** 64 - 1), pcur, ctypes.byref(lists.c), _stream()), "kge_pull_sample")
 
 
-def pull_lists_explicit(pairs, nh, nt, pc, head, nxt):
+def pull_lists_explicit(pairs, nh, nt, lists):
     L.check(L.load().kge_pull_lists_explicit(_i32(pairs, "pairs"), _ids(nh, "nh"), _ids(nt, "nt"), pairs.shape[0],
-                                             _i32(pc, "pc"), _i32(head, "head"), _i32(nxt, "next"), _stream()),
-            "kge_pull_lists_explicit")
+                                             ctypes.byref(lists.c), _stream()), "kge_pull_lists_explicit")
 
 
-def pull_step(desc_in, tables_out, norm_in, norm_out, state1, state2, pairs, pc, head, nxt, items, inc, partials, multi,
-              margin, optimizer, lr, step, loss_buf, reset_lists=True, dev_hyper=None, run_finish=True):
+def pull_step(desc_in, tables_out, norm_in, norm_out, state1, state2, pairs, lists, items, inc, partials, multi,
+              margin, optimizer, lr, step, loss_buf, reset_lists=True, dev_hyper=None, run_finish=True, sample_next=None):
     """One whole training step (scoring, hinge, backward, dense optimiser) without atomics: see csrc/kge_pull.hip.
-    desc_in: descriptor over the tables READ; tables_out: [ent, rel] of the other half of the double buffer."""
+    desc_in: descriptor over the tables READ; tables_out: [ent, rel] of the other half of the double buffer.
+    sample_next = (next_pairs, bern_prob, slots, seed, next_offset, next_lists): the sampler of the next batch rides
+    in this launch and fills `next_lists` (a cleared second PullListSet)."""
     to, s1, s2 = _ptr_pair(tables_out), _ptr_pair(state1), _ptr_pair(state2)
     # run_finish=False (timing only): the owners still write their partial sums, the finishing launch is skipped
     n_multi = multi.shape[0] if (multi is not None and run_finish) else 0
+    if sample_next is not None:
+        npairs, bern, slots, seed, noff, nlists = sample_next
+        nx = (_i32(npairs, "next_pairs"), npairs.shape[0], _dev(bern, torch.float32, "bern_prob") if bern is not None else None,
+              ctypes.c_void_p(slots.data_ptr()) if slots is not None else None, slots.numel() if slots is not None else 0,
+              int(seed) & (2 ** 64 - 1), int(noff) & (2 ** 64 - 1), ctypes.byref(nlists.c))
+    else:
+        nx = (None, 0, None, None, 0, 0, 0, None)
     L.check(L.load().kge_pull_step(
         ctypes.byref(desc_in), ctypes.addressof(to), _dev(norm_in, torch.float32, "norm_in"),
         _dev(norm_out, torch.float32, "norm_out"), ctypes.addressof(s1) if state1 is not None else None,
-        ctypes.addressof(s2) if state2 is not None else None, _i32(pairs, "pairs"), _i32(pc, "pc"), _i32(head, "head"),
-        _i32(nxt, "next"), _i32(items, "items"), items.shape[0], _i32(inc, "inc"),
-        _dev(partials, torch.float32, "partials"), _i32(multi, "multi") if n_multi else None, n_multi,
-        float(margin), OPTIMIZER_IDS[optimizer], float(lr), int(step),
+        ctypes.addressof(s2) if state2 is not None else None, _i32(pairs, "pairs"), ctypes.byref(lists.c),
+        _i32(items, "items"), items.shape[0], _i32(inc, "inc"), _dev(partials, torch.float32, "partials"),
+        _i32(multi, "multi") if n_multi else None, n_multi, float(margin), OPTIMIZER_IDS[optimizer], float(lr), int(step),
         _dev(dev_hyper, torch.float32, "dev_hyper") if dev_hyper is not None else None, 1 if reset_lists else 0,
-        _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_pull_step")
+        *nx, _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_pull_step")
 
 
 # ---------------------------------------------------------------------------- 1-N scoring head (projection models)

@@ -94,9 +94,12 @@ class PullState:
         E, R, d = shapes[0][0], shapes[1][0], shapes[0][1]
         self.E, self.R = E, R
         self.norms = [torch.empty(E + R, dtype=torch.float32, device=dev) for _ in range(2)]
-        self.pc = torch.empty(batch_size, dtype=torch.int32, device=dev)
-        self.next = torch.empty(batch_size, dtype=torch.int32, device=dev)
-        self.head = torch.full((E,), -1, dtype=torch.int32, device=dev)
+        self.batch_size = batch_size
+        # two sampler list sets: the step on batch k consumes one while the sampler of batch k+1, riding in the same
+        # launch, fills the other.  `ready` = (batch index, Philox offset) the current set was sampled for.
+        self.lists = [K.PullListSet(batch_size, E, dev) for _ in range(2)]
+        self.cur_list = 0
+        self.ready = None
         self.partials = torch.empty(max(1, max_slots) * K.pull_partial_stride(d), dtype=torch.float32, device=dev)
         self.cur = 0
 
@@ -276,26 +279,38 @@ class Trainer:
 
     def _pull_state(self):
         idx = self.generator.pull_index()
-        if getattr(self, "_pull", None) is None or self._pull.pc.numel() != idx.batch_size:
+        if getattr(self, "_pull", None) is None or self._pull.batch_size != idx.batch_size:
             self._pull = PullState(self.flat, self.model, idx.batch_size, idx.max_slots)
             self._pull.sync_in()
         return self._pull, idx
 
-    def _pull_step(self, batch_idx, offset, lists_ready=False):
+    def _pull_step(self, batch_idx, offset):
         """One full training step on batch `batch_idx` of the permutation (Philox counters offset .. offset + B)."""
         ps, idx = self._pull_state()
         gen = self.generator
         pairs, inc, items, multi = idx.batch(batch_idx)
-        if not lists_ready:
-            K.pull_sample(pairs, self.config.tot_entity, gen.bern, gen.slots, gen.seed, offset, ps.pc, ps.head, ps.next)
+        lists = ps.lists[ps.cur_list]
+        if ps.ready != (batch_idx, offset):   # first step of an epoch (or a restart): stand-alone sampler launch
+            if ps.ready is not None:
+                lists.clear()
+            K.pull_sample(pairs, self.config.tot_entity, gen.bern, gen.slots, gen.seed, offset, lists)
+        # the sampler of the NEXT batch of this epoch rides in this step's launch and fills the other list set
+        nxt = None
+        if gen._pending > 0 and batch_idx + 1 < idx.n_batches:
+            nxt = (batch_idx + 1, offset + idx.batch_size * gen.neg_rate)
+        sample_next = None if nxt is None else (idx.batch(nxt[0])[0], gen.bern, gen.slots, gen.seed, nxt[1],
+                                                ps.lists[1 - ps.cur_list])
         src, dst = ps.cur, 1 - ps.cur
         self.flat.step += 1
         desc = K.make_desc("transe", ps.tables[src], None, tot_entity=self.config.tot_entity,
                            tot_relation=self.config.tot_relation, **self.model.desc_kwargs())
-        K.pull_step(desc, ps.tables[dst], ps.norms[src], ps.norms[dst], ps.state1, ps.state2, pairs, ps.pc, ps.head, ps.next,
-                    items, inc, ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate,
-                    self.flat.step, self.loss_buf)
+        K.pull_step(desc, ps.tables[dst], ps.norms[src], ps.norms[dst], ps.state1, ps.state2, pairs, lists, items, inc,
+                    ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate, self.flat.step,
+                    self.loss_buf, sample_next=sample_next)
         ps.cur = dst
+        ps.ready = nxt
+        if nxt is not None:
+            ps.cur_list = 1 - ps.cur_list
 
     def pull_step_explicit(self, ph, pr, pt, nh, nr, nt, segment=None):
         """The owner-computes step on an explicit batch (positives + given negatives, neg_rate 1): the incidence index
@@ -307,12 +322,12 @@ class Trainer:
         ps = PullState(self.flat, self.model, len(pos), idx.max_slots)
         ps.sync_in()
         pairs, inc, items, multi = idx.batch(0)
-        K.pull_lists_explicit(pairs, nh.contiguous(), nt.contiguous(), ps.pc, ps.head, ps.next)
+        K.pull_lists_explicit(pairs, nh.contiguous(), nt.contiguous(), ps.lists[0])
         self.flat.step += 1
         desc = K.make_desc("transe", ps.tables[0], None, tot_entity=self.config.tot_entity,
                            tot_relation=self.config.tot_relation, **self.model.desc_kwargs())
-        K.pull_step(desc, ps.tables[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs, ps.pc, ps.head, ps.next,
-                    items, inc, ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate,
+        K.pull_step(desc, ps.tables[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs, ps.lists[0], items, inc,
+                    ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate,
                     self.flat.step, self.loss_buf)
         ps.cur = 1
         ps.sync_out()
