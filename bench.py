@@ -415,7 +415,7 @@ def main():
         torch.cuda.synchronize()
         eb0.record()
         for _ in range(burst):   # same inputs every time (lists kept, no buffer swap): the kernel's own duration
-            K.pull_step(desc_b, ps.tables[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs_b, ps.lists[0],
+            K.pull_step(desc_b, ps.tables[1], ps.hats[0], ps.hats[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs_b, ps.lists[0],
                         items_b, inc_b, ps.partials, multi_b, cfg.margin, cfg.optimizer, cfg.learning_rate, 1, tr.loss_buf,
                         reset_lists=False, run_finish=False)   # the small finishing launch of multi-segment rows is not in the burst
         eb1.record()

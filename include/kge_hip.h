@@ -268,8 +268,10 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
  * seed / offset) or kge_pull_lists_explicit (given negatives) and consumed -- and reset when reset_lists != 0 -- by the
  * step.  next_pairs != NULL: the sampler of the NEXT batch rides in this step's launch and fills next_lists (a second
  * set), so a steady-state step is one launch (+ a small finishing launch when rows are cut into several items).
- * m->tables = the tables read; tables_out = the other half of the double buffer; norm_in / norm_out [E + R]: L2 row norms
- * of the tables read / written (kge_row_norms before the first step); state1 / state2: optimiser state per table.
+ * m->tables = the tables read; tables_out = the other half of the double buffer; hat_in / hat_out: the row-normalised
+ * copies x / max(||x||, 1e-12) of the tables read / written (what other owners gather); norm_in / norm_out [E + R]: their
+ * L2 row norms (kge_row_norms fills both before the first step); state1 / state2: optimiser state per table.
+ * dim must be a multiple of 4 (rows move as float4).
  * partials: kge_pull_partial_stride(dim) floats per slot. */
 #define KGE_PULL_BUCKET 16
 typedef struct kge_pull_lists {
@@ -280,13 +282,14 @@ typedef struct kge_pull_lists {
     int32_t* next;    /* [n]  overflow list links */
 } kge_pull_lists;
 int kge_pull_partial_stride(int32_t dim);
-int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, void* stream);
+int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, float* normalised, void* stream);
 int kge_pull_sample(const int32_t* pairs, int64_t n, int64_t tot_entity, const float* bern_prob, const uint64_t* slots,
                     int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor, const kge_pull_lists* out,
                     void* stream);
 int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n, const kge_pull_lists* out,
                             void* stream);
-int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* norm_in, float* norm_out,
+int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
+                  const float* norm_in, float* norm_out,
                   float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
                   const int32_t* items, int64_t n_items, const int32_t* inc, float* partials, const int32_t* multi,
                   int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step, const float* dev_hyper,

@@ -285,9 +285,9 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
 /* ---- owner-computes ("pull") training step, kge_pull.hip */
 int kge_pull_partial_stride(int32_t dim) { return pull_partial_stride(dim); }
 
-int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, void* stream) {
+int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, float* normalised, void* stream) {
     if (!table || !norms || rows < 0 || dim <= 0) { set_error("kge_row_norms: bad arguments"); return -1; }
-    return launch_row_norms(table, rows, dim, norms, (hipStream_t)stream);
+    return launch_row_norms(table, rows, dim, norms, normalised, (hipStream_t)stream);
 }
 
 static int lists_ok(const kge_pull_lists* l) { return l && l->pc && l->count && l->bucket && l->head && l->next; }
@@ -309,7 +309,8 @@ int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64
     return launch_pull_lists_explicit(pairs, nh, nt, n, out, (hipStream_t)stream);
 }
 
-int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* norm_in, float* norm_out,
+int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
+                  const float* norm_in, float* norm_out,
                   float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
                   const int32_t* items, int64_t n_items, const int32_t* inc, float* partials, const int32_t* multi,
                   int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step, const float* dev_hyper,
@@ -318,7 +319,8 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
                   void* stream) {
     if (validate(m, false, "kge_pull_step")) return -1;
     if (m->model != KGE_TRANSE) { set_error("kge_pull_step: TransE only (model %d)", m->model); return -1; }
-    if (n_items <= 0 || n_multi < 0 || !tables_out || !tables_out[0] || !tables_out[1] || !norm_in || !norm_out || !pairs ||
+    if (n_items <= 0 || n_multi < 0 || !tables_out || !tables_out[0] || !tables_out[1] || !hat_in || !hat_in[0] || !hat_in[1] ||
+        !hat_out || !hat_out[0] || !hat_out[1] || hat_in[0] == hat_out[0] || !norm_in || !norm_out || !pairs ||
         !lists_ok(lists) || !items || !inc || !loss || !partials || (n_multi > 0 && !multi)) {
         set_error("kge_pull_step: bad arguments");
         return -1;
@@ -336,7 +338,7 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
         }
         if (validate_packed_key(m, "kge_pull_step")) return -1;
     }
-    return launch_pull_step(m, tables_out, norm_in, norm_out, state1, state2, pairs, lists, items, n_items, inc, partials, multi,
+    return launch_pull_step(m, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, n_items, inc, partials, multi,
                             n_multi, margin, optimizer, lr, step, dev_hyper, reset_lists, next_pairs, next_n, bern_prob, slots,
                             n_slots, seed, next_offset, next_lists, loss, (hipStream_t)stream);
 }

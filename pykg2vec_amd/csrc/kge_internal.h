@@ -92,14 +92,14 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
 
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);
-int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* norm_in, float* norm_out,
-                     float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
-                     const int32_t* items, int64_t n_items, const int32_t* inc, float* partials, const int32_t* multi,
-                     int64_t n_multi, float margin, int optimizer, float lr, int64_t step, const float* dev_hyper,
-                     int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern, const uint64_t* slots,
-                     int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
-                     hipStream_t s);
-int launch_row_norms(const float* table, int64_t rows, int dim, float* out, hipStream_t s);
+int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
+                     const float* norm_in, float* norm_out, float* const state1[2], float* const state2[2], const int32_t* pairs,
+                     const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const int32_t* inc, float* partials,
+                     const int32_t* multi, int64_t n_multi, float margin, int optimizer, float lr, int64_t step,
+                     const float* dev_hyper, int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern,
+                     const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
+                     const kge_pull_lists* next_lists, float* loss, hipStream_t s);
+int launch_row_norms(const float* table, int64_t rows, int dim, float* out, float* hat, hipStream_t s);
 int launch_pull_sample(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots,
                        uint64_t seed, uint64_t offset, const int64_t* cursor, const kge_pull_lists* out, hipStream_t s);
 int launch_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n,

@@ -52,6 +52,8 @@ struct PullSampleArgs {
 struct PullArgs {
     const float* tab_in[2];    // entity / relation table read by this step
     float* tab_out[2];         // the tables the step writes (other half of the double buffer)
+    const float* hat_in[2];    // row-normalised copies x / max(||x||, eps) of tab_in: what the other owners gather
+    float* hat_out[2];         // the same for tab_out, written by each row's owner
     const float* norm_in;      // [E + R] L2 norms of the rows of tab_in (entities first)
     float* norm_out;           // norms of the rows of tab_out
     float* s1[2];              // optimiser state, same row layout as the tables (NULL where the optimiser has none)
@@ -60,10 +62,10 @@ struct PullArgs {
     PullLists lists;           // this batch's sampler output
     const int4* items;         // work items: (row g, first incidence, end incidence, kind | slot << 2)
     const int32_t* inc;        // static incidences of the batch sorted by (row, pair, role): pair << 2 | role
-    float* partials;           // [slots][G * NCH] partial gradient sums of multi-segment rows
+    float* partials;           // [slots][4 * G * NV] partial gradient sums of multi-segment rows
     const int4* multi;         // rows with several segments: (row g, first slot, number of slots, -)
     int64_t n_items, n_multi;
-    int item_blocks;           // blocks [0, item_blocks) own work items; later blocks sample the NEXT batch
+    int sample_blocks;         // blocks [0, sample_blocks) sample the NEXT batch; the others own work items
     int E, d, l1, reset_lists;
     float margin;
     OptArgs opt;
@@ -85,68 +87,103 @@ __device__ __forceinline__ void pull_sample_one(const PullSampleArgs& sa, int64_
     else sa.out.next[i] = atomicExch(sa.out.head + c, (int)i);
 }
 
-// gradient wrt the NORMALISED own row, summed over incidences -> normalisation backward -> optimiser -> new row + norm
-template <int OPT, int G, int NCH>
-__device__ __forceinline__ void pull_finish_row(const PullArgs& a, int g, const float (&X)[NCH], float nX, const float (&gs)[NCH],
+// Rows as float4 per lane: lane gl of a G-lane group holds elements 4*(v*G + gl) .. +3 for v < NV (d % 4 == 0): one
+// 16-byte load / store instruction per lane moves a whole 100-float row with 25 lanes.
+template <int G, int NV>
+__device__ __forceinline__ void load_row4(float4 (&x)[NV], const float* __restrict__ row, int nvec, int gl) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int i = v * G + gl;
+        x[v] = i < nvec ? reinterpret_cast<const float4*>(row)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int G, int NV>
+__device__ __forceinline__ void store_row4(float* __restrict__ row, const float4 (&x)[NV], int nvec, int gl) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int i = v * G + gl;
+        if (i < nvec) reinterpret_cast<float4*>(row)[i] = x[v];
+    }
+}
+#define KGE_F4_EACH(expr_x, expr_y, expr_z, expr_w) expr_x; expr_y; expr_z; expr_w;
+
+// gradient wrt the NORMALISED own row, summed over incidences -> normalisation backward -> optimiser -> new row, its
+// normalised copy and its norm
+template <int OPT, int G, int NV>
+__device__ __forceinline__ void pull_finish_row(const PullArgs& a, int g, const float4 (&X)[NV], float nX, const float4 (&gs)[NV],
                                                 int gl) {
-    const int d = a.d;
+    const int nvec = a.d >> 2;
     const bool is_rel = g >= a.E;
     // (pointer selects, not a[tb]: a runtime index into a kernel-argument array would put the array in scratch)
     float* const t_out = is_rel ? a.tab_out[1] : a.tab_out[0];
+    float* const h_out = is_rel ? a.hat_out[1] : a.hat_out[0];
     float* const st1 = is_rel ? a.s1[1] : a.s1[0];
     float* const st2 = is_rel ? a.s2[1] : a.s2[0];
-    const int64_t off = (int64_t)(is_rel ? g - a.E : g) * d;
+    const int64_t off = (int64_t)(is_rel ? g - a.E : g) * a.d;
     const bool fX = nX > kEpsNormalize;
     const float iX = 1.0f / fmaxf(nX, kEpsNormalize);
     float dX = 0.f;
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) dX = fmaf(X[k], gs[k], dX);
+    for (int v = 0; v < NV; ++v) {
+        dX = fmaf(X[v].x, gs[v].x, dX); dX = fmaf(X[v].y, gs[v].y, dX);
+        dX = fmaf(X[v].z, gs[v].z, dX); dX = fmaf(X[v].w, gs[v].w, dX);
+    }
     dX = gsum<G>(dX) * iX;
     OptArgs o = a.opt;
     if (a.dev_hyper) { o.lr = a.dev_hyper[0]; o.step_size = a.dev_hyper[1]; o.bc2_sqrt = a.dev_hyper[2]; }
+    float4 P[NV], M1[NV], M2[NV];
+    if constexpr (OPT != KGE_OPT_SGD) load_row4<G, NV>(M1, st1 + off, nvec, gl);
+    if constexpr (OPT == KGE_OPT_ADAM) load_row4<G, NV>(M2, st2 + off, nvec, gl);
     float n2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int e = k * G + gl;
-        const bool live = e < d;
-        const float graw = fX ? (gs[k] - (X[k] * iX) * dX) * iX : gs[k] * iX;
-        float p = X[k], m1 = 0.f, m2 = 0.f;
-        if (live) {
-            if constexpr (OPT != KGE_OPT_SGD) m1 = st1[off + e];
-            if constexpr (OPT == KGE_OPT_ADAM) m2 = st2[off + e];
-            opt_update<OPT>(p, graw, m1, m2, o);
-            t_out[off + e] = p;
-            if constexpr (OPT != KGE_OPT_SGD) st1[off + e] = m1;
-            if constexpr (OPT == KGE_OPT_ADAM) st2[off + e] = m2;
-            n2 = fmaf(p, p, n2);
+    for (int v = 0; v < NV; ++v) {
+        P[v] = X[v];
+#define KGE_UPD(c)                                                                                           \
+        {                                                                                                    \
+            const float graw = fX ? (gs[v].c - (X[v].c * iX) * dX) * iX : gs[v].c * iX;                      \
+            float m1 = 0.f, m2 = 0.f;                                                                        \
+            if constexpr (OPT != KGE_OPT_SGD) m1 = M1[v].c;                                                  \
+            if constexpr (OPT == KGE_OPT_ADAM) m2 = M2[v].c;                                                 \
+            opt_update<OPT>(P[v].c, graw, m1, m2, o);                                                        \
+            if constexpr (OPT != KGE_OPT_SGD) M1[v].c = m1;                                                  \
+            if constexpr (OPT == KGE_OPT_ADAM) M2[v].c = m2;                                                 \
+            n2 = fmaf(P[v].c, P[v].c, n2);                                                                   \
         }
+        KGE_UPD(x) KGE_UPD(y) KGE_UPD(z) KGE_UPD(w)
+#undef KGE_UPD
     }
+    // (lanes beyond the row hold zeros: X = 0, gs = 0, state loaded as 0 -> every optimiser leaves p = 0, n2 unchanged)
     n2 = gsum<G>(n2);
-    if (gl == 0) a.norm_out[g] = sqrtf(n2);
+    const float nn = sqrtf(n2);
+    const float inn = 1.0f / fmaxf(nn, kEpsNormalize);
+    store_row4<G, NV>(t_out + off, P, nvec, gl);
+    if constexpr (OPT != KGE_OPT_SGD) store_row4<G, NV>(st1 + off, M1, nvec, gl);
+    if constexpr (OPT == KGE_OPT_ADAM) store_row4<G, NV>(st2 + off, M2, nvec, gl);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { P[v].x *= inn; P[v].y *= inn; P[v].z *= inn; P[v].w *= inn; }
+    store_row4<G, NV>(h_out + off, P, nvec, gl);
+    if (gl == 0) a.norm_out[g] = nn;
 }
 
-// the four rows of one incident pair (raw table values) and their norms, as gathered for one owner
-template <int NCH>
+// the four NORMALISED rows of one incident pair as gathered for one owner
+template <int NV>
 struct PullRows {
-    float hh[NCH], rr[NCH], tt[NCH], cc[NCH];
-    float nh, nr, nt, nc;
-    int role;
-    bool tail;
+    float4 hh[NV], rr[NV], tt[NV], cc[NV];
+    int w;   // corrupting entity | tail << 24 | role << 25
 };
 
-template <int OPT, int G, int NCH>
+template <int OPT, bool L1, int G, int NV>
 __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs sa, float* __restrict__ loss) {
     constexpr int GPB = kBlock / G;
-    if ((int)blockIdx.x >= a.item_blocks) {   // tail blocks: the sampler of the NEXT batch rides along (writes the other list set)
-        const int64_t i = (int64_t)((int)blockIdx.x - a.item_blocks) * kBlock + threadIdx.x;
+    if ((int)blockIdx.x < a.sample_blocks) {   // leading blocks: the sampler of the NEXT batch rides along (writes the other list set)
+        const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
         if (i < sa.n) pull_sample_one(sa, i);
         return;
     }
     const int gl = threadIdx.x % G;
     const int gbase = (threadIdx.x & 63) / G * G;   // first lane of this group inside its wave
-    const int d = a.d;
-    const bool l1 = a.l1 != 0;
-    const int64_t item = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
+    const int d = a.d, nvec = a.d >> 2;
+    const int64_t item = (int64_t)((int)blockIdx.x - a.sample_blocks) * GPB + threadIdx.x / G;
     float acc = 0.f;
     if (item < a.n_items) {
         const int4 it = a.items[item];
@@ -173,70 +210,76 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
             }
             nvis += cnt;
         }
+        // per lane: the ids of ITS visit (h, r, t, c | tail << 24 | role << 25)
         int4 pr = make_int4(0, 0, 0, 0);
-        int pcv = 0;
-        if (vi >= 0) { pr = a.pairs[vi]; pcv = a.lists.pc[vi]; }
-        float X[NCH], gs[NCH];
-        load_row<G, NCH>(X, (is_rel ? a.tab_in[1] : a.tab_in[0]) + (int64_t)(is_rel ? g - a.E : g) * d, d, gl);
+        if (vi >= 0) { pr = a.pairs[vi]; pr.w = a.lists.pc[vi] | (vrole << 25); }
+        float4 X[NV], gs[NV];
+        load_row4<G, NV>(X, (is_rel ? a.tab_in[1] : a.tab_in[0]) + (int64_t)(is_rel ? g - a.E : g) * d, nvec, gl);
         const float nX = a.norm_in[g];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) gs[k] = 0.f;
+        for (int v = 0; v < NV; ++v) gs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-        // gather the rows of one incident pair: the owner's own row comes from registers, the other three from L2
-        auto fetch = [&](int h, int r, int t, int c, bool tail, int role, PullRows<NCH>& b) {
-            b.role = role; b.tail = tail;
-            if (role != kRoleH) { load_row<G, NCH>(b.hh, a.tab_in[0] + (int64_t)h * d, d, gl); b.nh = a.norm_in[h]; }
-            if (role != kRoleR) { load_row<G, NCH>(b.rr, a.tab_in[1] + (int64_t)r * d, d, gl); b.nr = a.norm_in[a.E + r]; }
-            if (role != kRoleT) { load_row<G, NCH>(b.tt, a.tab_in[0] + (int64_t)t * d, d, gl); b.nt = a.norm_in[t]; }
-            if (role != kRoleC) { load_row<G, NCH>(b.cc, a.tab_in[0] + (int64_t)c * d, d, gl); b.nc = a.norm_in[c]; }
+        // gather the four normalised rows of one incident pair (the owner's own row among them: it is L1 / L2 hot, and
+        // loading it like the others keeps the gather branch-free and the arithmetic identical for all four owners)
+        auto fetch = [&](int h, int r, int t, int w, PullRows<NV>& b) {
+            b.w = w;
+            load_row4<G, NV>(b.hh, a.hat_in[0] + (int64_t)h * d, nvec, gl);
+            load_row4<G, NV>(b.rr, a.hat_in[1] + (int64_t)r * d, nvec, gl);
+            load_row4<G, NV>(b.tt, a.hat_in[0] + (int64_t)t * d, nvec, gl);
+            load_row4<G, NV>(b.cc, a.hat_in[0] + (int64_t)(w & 0xFFFFFF) * d, nvec, gl);
         };
-        auto fetch_visit = [&](int v, PullRows<NCH>& b) {
+        auto fetch_visit = [&](int v, PullRows<NV>& b) {
             const int src = __shfl(ord, gbase + v, 64);
-            const int pv = __shfl(pcv, src, 64);
-            fetch(__shfl(pr.x, src, 64), __shfl(pr.y, src, 64), __shfl(pr.z, src, 64), pv & 0xFFFFFF, (pv >> 24) != 0,
-                  __shfl(vrole, src, 64), b);
+            fetch(__shfl(pr.x, src, 64), __shfl(pr.y, src, 64), __shfl(pr.z, src, 64), __shfl(pr.w, src, 64), b);
         };
         // forward of the pair (identical arithmetic whichever of its four rows the owner holds), hinge, and the owner's
         // share of the backward: gradient wrt its NORMALISED row
-        auto compute = [&](const PullRows<NCH>& b) {
-            const int role = b.role;
-            // (selects, not stores into b: a role-indexed store would push the four norms into scratch)
-            const float iH = 1.0f / fmaxf(role == kRoleH ? nX : b.nh, kEpsNormalize);
-            const float iR = 1.0f / fmaxf(role == kRoleR ? nX : b.nr, kEpsNormalize);
-            const float iT = 1.0f / fmaxf(role == kRoleT ? nX : b.nt, kEpsNormalize);
-            const float iC = 1.0f / fmaxf(role == kRoleC ? nX : b.nc, kEpsNormalize);
-            float up[NCH], un[NCH];
+        auto compute = [&](const PullRows<NV>& b) {
+            const int role = (b.w >> 25) & 3;
+            const bool tail = ((b.w >> 24) & 1) != 0;
+            float4 up[NV], un[NV];
             float sp = 0.f, sn = 0.f;
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                const float hh = (role == kRoleH ? X[k] : b.hh[k]) * iH, rr = (role == kRoleR ? X[k] : b.rr[k]) * iR;
-                const float tt = (role == kRoleT ? X[k] : b.tt[k]) * iT, cc = (role == kRoleC ? X[k] : b.cc[k]) * iC;
-                up[k] = hh + rr - tt;
-                un[k] = b.tail ? (hh + rr - cc) : (cc + rr - tt);
-                sp = l1 ? sp + fabsf(up[k]) : fmaf(up[k], up[k], sp);
-                sn = l1 ? sn + fabsf(un[k]) : fmaf(un[k], un[k], sn);
+            for (int v = 0; v < NV; ++v) {
+#define KGE_FWD(c)                                                                                            \
+                up[v].c = b.hh[v].c + b.rr[v].c - b.tt[v].c;                                                  \
+                un[v].c = (tail ? b.hh[v].c : b.cc[v].c) + b.rr[v].c - (tail ? b.cc[v].c : b.tt[v].c);        \
+                sp = L1 ? sp + fabsf(up[v].c) : fmaf(up[v].c, up[v].c, sp);                                   \
+                sn = L1 ? sn + fabsf(un[v].c) : fmaf(un[v].c, un[v].c, sn);
+                KGE_FWD(x) KGE_FWD(y) KGE_FWD(z) KGE_FWD(w)
+#undef KGE_FWD
             }
             gsum2<G>(sp, sn);
-            if (!l1) { sp = sqrtf(sp); sn = sqrtf(sn); }
+            if constexpr (!L1) { sp = sqrtf(sp); sn = sqrtf(sn); }
             const float v = sp + a.margin - sn;
             if (role == kRoleH) acc += fmaxf(v, 0.f);   // every pair has exactly one head incidence: the loss is counted there
             const float coef = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);   // torch.max splits the subgradient at equality
             if (coef == 0.f) return;
-            const float ip = (!l1 && sp > 0.f) ? coef / sp : 0.f, in = (!l1 && sn > 0.f) ? -coef / sn : 0.f;
-            // own row's coefficient in up / un:  H: +1 / (tail ? +1 : 0)   T: -1 / (tail ? 0 : -1)   R: +1 / +1   C: 0 / (tail ? -1 : +1)
-            const float su = role == kRoleH ? 1.f : role == kRoleT ? -1.f : role == kRoleR ? 1.f : 0.f;
-            const float sv = role == kRoleH ? (b.tail ? 1.f : 0.f) : role == kRoleT ? (b.tail ? 0.f : -1.f)
-                           : role == kRoleR ? 1.f : (b.tail ? -1.f : 1.f);
+            // own row's coefficient in up / un:  H: +1 / (tail ? +1 : 0)   T: -1 / (tail ? 0 : -1)   R: +1 / +1   C: 0 / (tail ? -1 : +1);
+            // d loss / d up = +coef * g(up), d loss / d un = -coef * g(un): the signs are folded into su / sv
+            float su = role == kRoleT ? -coef : (role == kRoleC ? 0.f : coef);
+            float sv = role == kRoleR ? -coef : (role == kRoleH ? (tail ? -coef : 0.f) : role == kRoleT ? (tail ? 0.f : coef) : (tail ? coef : -coef));
+            if constexpr (L1) {
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                const float gp = l1 ? (up[k] > 0.f ? coef : (up[k] < 0.f ? -coef : 0.f)) : up[k] * ip;
-                const float gn = l1 ? (un[k] > 0.f ? -coef : (un[k] < 0.f ? coef : 0.f)) : un[k] * in;
-                gs[k] = fmaf(sv, gn, fmaf(su, gp, gs[k]));
+                for (int v2 = 0; v2 < NV; ++v2) {
+#define KGE_BWD(c)                                                                                            \
+                    gs[v2].c += (up[v2].c > 0.f ? su : (up[v2].c < 0.f ? -su : 0.f)) + (un[v2].c > 0.f ? sv : (un[v2].c < 0.f ? -sv : 0.f));
+                    KGE_BWD(x) KGE_BWD(y) KGE_BWD(z) KGE_BWD(w)
+#undef KGE_BWD
+                }
+            } else {
+                su = sp > 0.f ? su / sp : 0.f;
+                sv = sn > 0.f ? sv / sn : 0.f;
+#pragma unroll
+                for (int v2 = 0; v2 < NV; ++v2) {
+                    gs[v2].x = fmaf(sv, un[v2].x, fmaf(su, up[v2].x, gs[v2].x)); gs[v2].y = fmaf(sv, un[v2].y, fmaf(su, up[v2].y, gs[v2].y));
+                    gs[v2].z = fmaf(sv, un[v2].z, fmaf(su, up[v2].z, gs[v2].z)); gs[v2].w = fmaf(sv, un[v2].w, fmaf(su, up[v2].w, gs[v2].w));
+                }
             }
         };
         // software pipeline: the gathers of visit v+1 are in flight while visit v is evaluated (two buffers, no copies)
         if (nvis > 0) {
-            PullRows<NCH> ba, bb;
+            PullRows<NV> ba, bb;
             fetch_visit(0, ba);
             for (int v = 0; v < nvis; v += 2) {
                 const bool more = v + 1 < nvis;
@@ -259,9 +302,8 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                 for (int j = a.lists.head[g]; j >= 0; j = a.lists.next[j]) if (j > last && j < best) best = j;
                 if (best == 0x7FFFFFFF) break;
                 const int4 p2 = a.pairs[best];
-                const int pv = a.lists.pc[best];
-                PullRows<NCH> b;
-                fetch(p2.x, p2.y, p2.z, pv & 0xFFFFFF, (pv >> 24) != 0, kRoleC, b);
+                PullRows<NV> b;
+                fetch(p2.x, p2.y, p2.z, a.lists.pc[best] | (kRoleC << 25), b);
                 compute(b);
                 last = best;
             }
@@ -271,18 +313,18 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
             if (cnt > kPullCap) a.lists.head[g] = -1;
         }
         if (kind == 0) {
-            pull_finish_row<OPT, G, NCH>(a, g, X, nX, gs, gl);
+            pull_finish_row<OPT, G, NV>(a, g, X, nX, gs, gl);
         } else {
-            float* out = a.partials + (int64_t)(it.w >> 2) * (G * NCH);
+            float4* out = reinterpret_cast<float4*>(a.partials) + (int64_t)(it.w >> 2) * (G * NV);
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) out[k * G + gl] = gs[k];
+            for (int v = 0; v < NV; ++v) out[v * G + gl] = gs[v];
         }
     }
     block_accumulate_loss<G>(acc, gl, loss);
 }
 
 // rows cut into several segments: add the segments' partial sums in segment order, then finish the row
-template <int OPT, int G, int NCH>
+template <int OPT, int G, int NV>
 __global__ __launch_bounds__(kBlock) void k_pull_finish(PullArgs a) {
     constexpr int GPB = kBlock / G;
     const int gl = threadIdx.x % G;
@@ -291,32 +333,43 @@ __global__ __launch_bounds__(kBlock) void k_pull_finish(PullArgs a) {
     const int4 row = a.multi[m];
     const int g = row.x;
     const bool is_rel = g >= a.E;
-    float X[NCH], gs[NCH];
-    load_row<G, NCH>(X, (is_rel ? a.tab_in[1] : a.tab_in[0]) + (int64_t)(is_rel ? g - a.E : g) * a.d, a.d, gl);
+    float4 X[NV], gs[NV];
+    load_row4<G, NV>(X, (is_rel ? a.tab_in[1] : a.tab_in[0]) + (int64_t)(is_rel ? g - a.E : g) * a.d, a.d >> 2, gl);
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) gs[k] = 0.f;
+    for (int v = 0; v < NV; ++v) gs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < row.z; ++s) {
-        const float* in = a.partials + (int64_t)(row.y + s) * (G * NCH);
+        const float4* in = reinterpret_cast<const float4*>(a.partials) + (int64_t)(row.y + s) * (G * NV);
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) gs[k] += in[k * G + gl];
+        for (int v = 0; v < NV; ++v) {
+            const float4 p = in[v * G + gl];
+            gs[v].x += p.x; gs[v].y += p.y; gs[v].z += p.z; gs[v].w += p.w;
+        }
     }
-    pull_finish_row<OPT, G, NCH>(a, g, X, a.norm_in[g], gs, gl);
+    pull_finish_row<OPT, G, NV>(a, g, X, a.norm_in[g], gs, gl);
 }
 
-// L2 norms of the rows of a table, in the lane layout / operation order pull_finish_row uses
-template <int G, int NCH>
-__global__ __launch_bounds__(kBlock) void k_row_norms(const float* __restrict__ tab, int64_t rows, int d, float* __restrict__ out) {
+// L2 norms and normalised copies of the rows of a table, in the lane layout / operation order pull_finish_row uses
+template <int G, int NV>
+__global__ __launch_bounds__(kBlock) void k_row_norms(const float* __restrict__ tab, int64_t rows, int d, float* __restrict__ out,
+                                                      float* __restrict__ hat) {
     constexpr int GPB = kBlock / G;
     const int gl = threadIdx.x % G;
     const int64_t r = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
     if (r >= rows) return;
-    float X[NCH];
-    load_row<G, NCH>(X, tab + r * d, d, gl);
+    float4 X[NV];
+    load_row4<G, NV>(X, tab + r * d, d >> 2, gl);
     float n2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) n2 = fmaf(X[k], X[k], n2);
+    for (int v = 0; v < NV; ++v) { n2 = fmaf(X[v].x, X[v].x, n2); n2 = fmaf(X[v].y, X[v].y, n2); n2 = fmaf(X[v].z, X[v].z, n2); n2 = fmaf(X[v].w, X[v].w, n2); }
     n2 = gsum<G>(n2);
-    if (gl == 0) out[r] = sqrtf(n2);
+    const float nn = sqrtf(n2);
+    if (gl == 0) out[r] = nn;
+    if (hat) {
+        const float inn = 1.0f / fmaxf(nn, kEpsNormalize);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { X[v].x *= inn; X[v].y *= inn; X[v].z *= inn; X[v].w *= inn; }
+        store_row4<G, NV>(hat + r * d, X, d >> 2, gl);
+    }
 }
 
 // stand-alone sampler launch (first step of an epoch; later steps' sampling rides in the previous step's launch)
@@ -345,31 +398,42 @@ static PullLists to_lists(const kge_pull_lists* l) {
     return o;
 }
 
-template <int OPT, int G, int NCH>
+// float4-per-lane geometry: 32-lane groups, NV = float4s per lane (row length d, d % 4 == 0, d <= 1024)
+static int pull_nv(int dim) {
+    if (dim <= 0 || (dim & 3) || dim > 1024) return 0;
+    const int nvec = dim >> 2;
+    for (int nv = 1; nv <= 8; nv <<= 1)
+        if (nvec <= 32 * nv) return nv;
+    return 0;
+}
+
+template <int OPT, int NV>
 static int launch_pull_geo(PullArgs& a, const PullSampleArgs& sa, float* loss, hipStream_t s) {
-    constexpr int GPB = kBlock / G;
-    a.item_blocks = (int)((a.n_items + GPB - 1) / GPB);
-    const int sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
-    hipLaunchKernelGGL((k_pull_step<OPT, G, NCH>), dim3((unsigned)(a.item_blocks + sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
+    constexpr int G = 32, GPB = kBlock / G;
+    const int item_blocks = (int)((a.n_items + GPB - 1) / GPB);
+    a.sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
+    if (a.l1)
+        hipLaunchKernelGGL((k_pull_step<OPT, true, G, NV>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
+    else
+        hipLaunchKernelGGL((k_pull_step<OPT, false, G, NV>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
     int rc = check_launch("k_pull_step");
     if (rc || a.n_multi == 0) return rc;
-    hipLaunchKernelGGL((k_pull_finish<OPT, G, NCH>), dim3((unsigned)((a.n_multi + GPB - 1) / GPB)), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((k_pull_finish<OPT, G, NV>), dim3((unsigned)((a.n_multi + GPB - 1) / GPB)), dim3(kBlock), 0, s, a);
     return check_launch("k_pull_finish");
 }
 
 template <int OPT>
-static int launch_pull_opt(PullArgs& a, const PullSampleArgs& sa, Geometry geo, float* loss, hipStream_t s) {
-#define KGE_PULL(G_, NCH_) if (geo.G == G_ && geo.NCH == NCH_) return launch_pull_geo<OPT, G_, NCH_>(a, sa, loss, s);
-    KGE_PULL(32, 1) KGE_PULL(32, 2) KGE_PULL(32, 4) KGE_PULL(32, 8) KGE_PULL(64, 8) KGE_PULL(64, 16)
-#undef KGE_PULL
+static int launch_pull_opt(PullArgs& a, const PullSampleArgs& sa, int nv, float* loss, hipStream_t s) {
+    switch (nv) {
+        case 1: return launch_pull_geo<OPT, 1>(a, sa, loss, s);
+        case 2: return launch_pull_geo<OPT, 2>(a, sa, loss, s);
+        case 4: return launch_pull_geo<OPT, 4>(a, sa, loss, s);
+        case 8: return launch_pull_geo<OPT, 8>(a, sa, loss, s);
+    }
     return -1;
 }
 
-int pull_partial_stride(int dim) {
-    Geometry geo;
-    if (!pick_geometry(dim, &geo)) return 0;
-    return geo.G * geo.NCH;
-}
+int pull_partial_stride(int dim) { return 4 * 32 * pull_nv(dim); }
 
 static PullSampleArgs make_sample_args(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots,
                                        int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor,
@@ -383,24 +447,25 @@ static PullSampleArgs make_sample_args(const int32_t* pairs, int64_t n, int64_t 
     return sa;
 }
 
-int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* norm_in, float* norm_out,
-                     float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
-                     const int32_t* items, int64_t n_items, const int32_t* inc, float* partials, const int32_t* multi,
-                     int64_t n_multi, float margin, int optimizer, float lr, int64_t step, const float* dev_hyper,
-                     int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern, const uint64_t* slots,
-                     int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
-                     hipStream_t s) {
-    Geometry geo;
-    if (!pick_geometry(m->dim, &geo)) { set_error("kge_pull_step: hidden size %d exceeds the register-resident rows", m->dim); return -1; }
+int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
+                     const float* norm_in, float* norm_out, float* const state1[2], float* const state2[2], const int32_t* pairs,
+                     const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const int32_t* inc, float* partials,
+                     const int32_t* multi, int64_t n_multi, float margin, int optimizer, float lr, int64_t step,
+                     const float* dev_hyper, int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern,
+                     const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
+                     const kge_pull_lists* next_lists, float* loss, hipStream_t s) {
+    const int nv = pull_nv(m->dim);
+    if (!nv) { set_error("kge_pull_step: hidden size %d must be a multiple of 4 and at most 1024", m->dim); return -1; }
     PullArgs a;
     for (int i = 0; i < 2; ++i) {
         a.tab_in[i] = m->tables[i]; a.tab_out[i] = tables_out[i];
+        a.hat_in[i] = hat_in[i]; a.hat_out[i] = hat_out[i];
         a.s1[i] = state1 ? state1[i] : nullptr; a.s2[i] = state2 ? state2[i] : nullptr;
     }
     a.norm_in = norm_in; a.norm_out = norm_out;
     a.pairs = (const int4*)pairs; a.lists = to_lists(lists);
     a.items = (const int4*)items; a.inc = inc; a.partials = partials; a.multi = (const int4*)multi;
-    a.n_items = n_items; a.n_multi = n_multi; a.item_blocks = 0;
+    a.n_items = n_items; a.n_multi = n_multi; a.sample_blocks = 0;
     a.E = (int)m->tot_entity; a.d = m->dim; a.l1 = (m->flags & KGE_FLAG_L1) ? 1 : 0; a.reset_lists = reset_lists;
     a.margin = margin;
     a.opt = make_opt_args(lr, step < 1 ? 1 : step);
@@ -408,28 +473,27 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
     const PullSampleArgs sa = make_sample_args(next_pairs, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
                                                n_slots, seed, next_offset, nullptr, next_lists);
     switch (optimizer) {
-        case KGE_OPT_SGD: return launch_pull_opt<KGE_OPT_SGD>(a, sa, geo, loss, s);
-        case KGE_OPT_ADAM: return launch_pull_opt<KGE_OPT_ADAM>(a, sa, geo, loss, s);
-        case KGE_OPT_ADAGRAD: return launch_pull_opt<KGE_OPT_ADAGRAD>(a, sa, geo, loss, s);
-        case KGE_OPT_RMSPROP: return launch_pull_opt<KGE_OPT_RMSPROP>(a, sa, geo, loss, s);
+        case KGE_OPT_SGD: return launch_pull_opt<KGE_OPT_SGD>(a, sa, nv, loss, s);
+        case KGE_OPT_ADAM: return launch_pull_opt<KGE_OPT_ADAM>(a, sa, nv, loss, s);
+        case KGE_OPT_ADAGRAD: return launch_pull_opt<KGE_OPT_ADAGRAD>(a, sa, nv, loss, s);
+        case KGE_OPT_RMSPROP: return launch_pull_opt<KGE_OPT_RMSPROP>(a, sa, nv, loss, s);
     }
     set_error("kge_pull_step: unknown optimizer %d", optimizer);
     return -1;
 }
 
-int launch_row_norms(const float* table, int64_t rows, int dim, float* out, hipStream_t s) {
-    Geometry geo;
-    if (!pick_geometry(dim, &geo)) { set_error("kge_row_norms: row length %d too long", dim); return -1; }
+int launch_row_norms(const float* table, int64_t rows, int dim, float* out, float* hat, hipStream_t s) {
+    const int nv = pull_nv(dim);
+    if (!nv) { set_error("kge_row_norms: row length %d must be a multiple of 4 and at most 1024", dim); return -1; }
     if (rows == 0) return 0;
-#define KGE_RN(G_, NCH_)                                                                                                   \
-    if (geo.G == G_ && geo.NCH == NCH_) {                                                                                   \
-        hipLaunchKernelGGL((k_row_norms<G_, NCH_>), dim3((unsigned)((rows + kBlock / G_ - 1) / (kBlock / G_))), dim3(kBlock), 0, s, \
-                           table, rows, dim, out);                                                                          \
-        return check_launch("k_row_norms");                                                                                 \
+    const dim3 grid((unsigned)((rows + kBlock / 32 - 1) / (kBlock / 32)));
+    switch (nv) {
+        case 1: hipLaunchKernelGGL((k_row_norms<32, 1>), grid, dim3(kBlock), 0, s, table, rows, dim, out, hat); break;
+        case 2: hipLaunchKernelGGL((k_row_norms<32, 2>), grid, dim3(kBlock), 0, s, table, rows, dim, out, hat); break;
+        case 4: hipLaunchKernelGGL((k_row_norms<32, 4>), grid, dim3(kBlock), 0, s, table, rows, dim, out, hat); break;
+        default: hipLaunchKernelGGL((k_row_norms<32, 8>), grid, dim3(kBlock), 0, s, table, rows, dim, out, hat); break;
     }
-    KGE_RN(32, 1) KGE_RN(32, 2) KGE_RN(32, 4) KGE_RN(32, 8) KGE_RN(64, 8) KGE_RN(64, 16)
-#undef KGE_RN
-    return -1;
+    return check_launch("k_row_norms");
 }
 
 int launch_pull_sample(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots,

@@ -397,10 +397,13 @@ def _ptr_pair(tensors):
     return arr
 
 
-def row_norms(table, out):
-    """out[r] = ||table[r]||_2 in the lane layout / operation order the pull step uses for the rows it writes."""
+def row_norms(table, out, hat=None):
+    """out[r] = ||table[r]||_2 and hat[r] = table[r] / max(norm, 1e-12), in the lane layout / operation order the pull
+    step uses for the rows it writes."""
     L.check(L.load().kge_row_norms(_dev(table, torch.float32, "table"), table.shape[0], table.shape[1],
-                                   _dev(out, torch.float32, "norms"), _stream()), "kge_row_norms")
+                                   _dev(out, torch.float32, "norms"),
+                                   _dev(hat, torch.float32, "normalised") if hat is not None else None, _stream()),
+            "kge_row_norms")
 
 
 def pull_partial_stride(dim):
@@ -440,13 +443,14 @@ def pull_lists_explicit(pairs, nh, nt, lists):
                                              ctypes.byref(lists.c), _stream()), "kge_pull_lists_explicit")
 
 
-def pull_step(desc_in, tables_out, norm_in, norm_out, state1, state2, pairs, lists, items, inc, partials, multi,
+def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, inc, partials, multi,
               margin, optimizer, lr, step, loss_buf, reset_lists=True, dev_hyper=None, run_finish=True, sample_next=None):
     """One whole training step (scoring, hinge, backward, dense optimiser) without atomics: see csrc/kge_pull.hip.
-    desc_in: descriptor over the tables READ; tables_out: [ent, rel] of the other half of the double buffer.
+    desc_in: descriptor over the tables READ; tables_out: [ent, rel] of the other half of the double buffer; hat_in /
+    hat_out: the row-normalised copies of both halves.
     sample_next = (next_pairs, bern_prob, slots, seed, next_offset, next_lists): the sampler of the next batch rides
     in this launch and fills `next_lists` (a cleared second PullListSet)."""
-    to, s1, s2 = _ptr_pair(tables_out), _ptr_pair(state1), _ptr_pair(state2)
+    to, s1, s2, hi, ho = _ptr_pair(tables_out), _ptr_pair(state1), _ptr_pair(state2), _ptr_pair(hat_in), _ptr_pair(hat_out)
     # run_finish=False (timing only): the owners still write their partial sums, the finishing launch is skipped
     n_multi = multi.shape[0] if (multi is not None and run_finish) else 0
     if sample_next is not None:
@@ -457,7 +461,7 @@ def pull_step(desc_in, tables_out, norm_in, norm_out, state1, state2, pairs, lis
     else:
         nx = (None, 0, None, None, 0, 0, 0, None)
     L.check(L.load().kge_pull_step(
-        ctypes.byref(desc_in), ctypes.addressof(to), _dev(norm_in, torch.float32, "norm_in"),
+        ctypes.byref(desc_in), ctypes.addressof(to), ctypes.addressof(hi), ctypes.addressof(ho), _dev(norm_in, torch.float32, "norm_in"),
         _dev(norm_out, torch.float32, "norm_out"), ctypes.addressof(s1) if state1 is not None else None,
         ctypes.addressof(s2) if state2 is not None else None, _i32(pairs, "pairs"), ctypes.byref(lists.c),
         _i32(items, "items"), items.shape[0], _i32(inc, "inc"), _dev(partials, torch.float32, "partials"),

@@ -85,10 +85,12 @@ class PullState:
         dev = flat.param.device
         self.flat = flat
         self.alt = torch.empty_like(flat.param)
+        self.hat_buf = [torch.zeros_like(flat.param), torch.zeros_like(flat.param)]   # row-normalised copies of both halves
         shapes = [tuple(v.shape) for v in flat.views[:2]]
         offs = [v.data_ptr() - flat.param.data_ptr() for v in flat.views[:2]]
         view = lambda buf: [buf[o // 4:o // 4 + r * d].view(r, d) for o, (r, d) in zip(offs, shapes)]
         self.tables = [view(flat.param), view(self.alt)]
+        self.hats = [view(self.hat_buf[0]), view(self.hat_buf[1])]
         self.state1 = view(flat.state1) if flat.state1 is not None else None
         self.state2 = view(flat.state2) if flat.state2 is not None else None
         E, R, d = shapes[0][0], shapes[1][0], shapes[0][1]
@@ -106,14 +108,15 @@ class PullState:
     def sync_in(self):
         """(Re)derive the row norms from the tables the model currently holds (they may have been set from outside)."""
         self.sync_out()
-        K.row_norms(self.tables[0][0], self.norms[0][:self.E])
-        K.row_norms(self.tables[0][1], self.norms[0][self.E:])
+        K.row_norms(self.tables[0][0], self.norms[0][:self.E], self.hats[0][0])
+        K.row_norms(self.tables[0][1], self.norms[0][self.E:], self.hats[0][1])
 
     def sync_out(self):
         """Make FlatState.param (the storage behind the model's parameters) hold the current tables."""
         if self.cur == 1:
             self.flat.param.copy_(self.alt)
             self.norms[0].copy_(self.norms[1])
+            self.hat_buf[0].copy_(self.hat_buf[1])
             self.cur = 0
 
 
@@ -268,7 +271,7 @@ class Trainer:
         the whole step (sampling, scoring, hinge, backward, dense optimiser) runs without atomics or a gradient buffer
         and is bit-reproducible (csrc/kge_pull.hip).  KGE_PULL=0 / 1 overrides the batch-size rule."""
         import os
-        if not (self.K is K and self.world_size == 1 and self.model.kernel_name == "transe"
+        if not (self.K is K and self.world_size == 1 and self.model.kernel_name == "transe" and self.model.hidden_size % 4 == 0
                 and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1
                 and self.generator is not None and self.generator.n_train >= self.config.batch_size):
             return False
@@ -304,7 +307,8 @@ class Trainer:
         self.flat.step += 1
         desc = K.make_desc("transe", ps.tables[src], None, tot_entity=self.config.tot_entity,
                            tot_relation=self.config.tot_relation, **self.model.desc_kwargs())
-        K.pull_step(desc, ps.tables[dst], ps.norms[src], ps.norms[dst], ps.state1, ps.state2, pairs, lists, items, inc,
+        K.pull_step(desc, ps.tables[dst], ps.hats[src], ps.hats[dst], ps.norms[src], ps.norms[dst], ps.state1, ps.state2, pairs,
+                    lists, items, inc,
                     ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate, self.flat.step,
                     self.loss_buf, sample_next=sample_next)
         ps.cur = dst
@@ -326,7 +330,8 @@ class Trainer:
         self.flat.step += 1
         desc = K.make_desc("transe", ps.tables[0], None, tot_entity=self.config.tot_entity,
                            tot_relation=self.config.tot_relation, **self.model.desc_kwargs())
-        K.pull_step(desc, ps.tables[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs, ps.lists[0], items, inc,
+        K.pull_step(desc, ps.tables[1], ps.hats[0], ps.hats[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs,
+                    ps.lists[0], items, inc,
                     ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate,
                     self.flat.step, self.loss_buf)
         ps.cur = 1
