@@ -184,19 +184,26 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
     const int gbase = (threadIdx.x & 63) / G * G;   // first lane of this group inside its wave
     const int d = a.d, nvec = a.d >> 2;
     const int64_t item = (int64_t)((int)blockIdx.x - a.sample_blocks) * GPB + threadIdx.x / G;
+    // partial sums of rows cut into 2..GPB items: their owners sit in consecutive groups of this workgroup
+    __shared__ float4 s_part[GPB][NV * G];
     float acc = 0.f;
-    if (item < a.n_items) {
-        const int4 it = a.items[item];
-        const int g = it.x;
-        const int kind = it.w & 3;
+    int4 it = make_int4(-1, 0, 0, 0);
+    if (item < a.n_items) it = a.items[item];
+    const int g = it.x;
+    const int kind = it.w & 3;
+    float4 X[NV], gs[NV];
+    float nX = 0.f;
+    if (g >= 0) {
         const bool is_rel = g >= a.E;
         const int n_static = it.z - it.y;
         // ---- the owner's visit list, one descriptor per lane: static incidences first, then the pairs that drew this
         // entity as their corrupting entity (bucket entries, visited in pair order)
         int vi = -1, vrole = 0, ord = gbase + gl;
         if (gl < n_static) { const int e = a.inc[it.y + gl]; vi = e >> 2; vrole = e & 3; }
+        // the row's corrupting-entity draws are walked by its first (or only) item
+        const bool walks_c = !is_rel && (kind == 0 || kind == 1 || (kind == 3 && ((it.w >> 2) & 15) == 0));
         int cnt = 0;
-        if (!is_rel && kind != 2) cnt = a.lists.count[g];
+        if (walks_c) cnt = a.lists.count[g];
         const bool fast_c = cnt <= kPullCap && n_static + cnt <= G;
         int nvis = n_static;
         if (cnt > 0 && fast_c) {
@@ -213,9 +220,8 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
         // per lane: the ids of ITS visit (h, r, t, c | tail << 24 | role << 25)
         int4 pr = make_int4(0, 0, 0, 0);
         if (vi >= 0) { pr = a.pairs[vi]; pr.w = a.lists.pc[vi] | (vrole << 25); }
-        float4 X[NV], gs[NV];
         load_row4<G, NV>(X, (is_rel ? a.tab_in[1] : a.tab_in[0]) + (int64_t)(is_rel ? g - a.E : g) * d, nvec, gl);
-        const float nX = a.norm_in[g];
+        nX = a.norm_in[g];
 #pragma unroll
         for (int v = 0; v < NV; ++v) gs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -314,11 +320,26 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
         }
         if (kind == 0) {
             pull_finish_row<OPT, G, NV>(a, g, X, nX, gs, gl);
+        } else if (kind == 3) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s_part[threadIdx.x / G][v * G + gl] = gs[v];
         } else {
             float4* out = reinterpret_cast<float4*>(a.partials) + (int64_t)(it.w >> 2) * (G * NV);
 #pragma unroll
             for (int v = 0; v < NV; ++v) out[v * G + gl] = gs[v];
         }
+    }
+    __syncthreads();
+    if (g >= 0 && kind == 3 && ((it.w >> 2) & 15) == 0) {   // first item of a workgroup-local row: add the others' sums in segment order
+        const int nseg = it.w >> 6, me = threadIdx.x / G;
+        for (int m = 1; m < nseg; ++m) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float4 p = s_part[me + m][v * G + gl];
+                gs[v].x += p.x; gs[v].y += p.y; gs[v].z += p.z; gs[v].w += p.w;
+            }
+        }
+        pull_finish_row<OPT, G, NV>(a, g, X, nX, gs, gl);
     }
     block_accumulate_loss<G>(acc, gl, loss);
 }

@@ -49,13 +49,22 @@ def bern_table(prob):
     return p32
 
 
+PULL_GROUPS_PER_BLOCK = 8   # 256-thread workgroups of 32-lane owner groups (csrc/kge_pull.hip)
+
+
 def build_pull_batch(pos, tot_entity, tot_relation, segment):
     """Incidence index of ONE batch for the owner-computes step (csrc/kge_pull.hip): every parameter row (entities first,
     then tot_entity + relation) gets the sorted list of the (pair, role) slots it occupies in the batch -- role 0 = head,
-    1 = tail, 2 = relation -- cut into work items of at most `segment` incidences.  Pure numpy, vectorised.
-    Returns int32 arrays (pairs [B,4], inc [3B], items [n_items,4], multi [n_multi,4]) and the number of partial slots."""
+    1 = tail, 2 = relation -- cut into work items of at most `segment` incidences.
+
+    Item kinds: 0 = the row's only item; 3 = one of 2..8 items of a row, all placed in consecutive owner groups of ONE
+    workgroup (they combine their partial sums through LDS, in segment order); 1 / 2 = first / later item of a row with
+    more than 8 items (partial sums through global memory + the finishing kernel).  Items are laid out in workgroup slots
+    (8 per workgroup, padding items have row -1), heaviest workgroups first.
+    Returns int32 arrays (pairs [B,4], inc [3B], items [n_slots,4], multi [n_multi,4]) and the number of partial slots."""
     pos = np.asarray(pos, dtype=np.int64).reshape(-1, 3)
     B, E, nrows = len(pos), int(tot_entity), int(tot_entity) + int(tot_relation)
+    GPB = PULL_GROUPS_PER_BLOCK
     i = np.arange(B, dtype=np.int64)
     rows = np.concatenate([pos[:, 0], pos[:, 2], E + pos[:, 1]])
     vals = np.concatenate([4 * i, 4 * i + 1, 4 * i + 2])
@@ -70,18 +79,53 @@ def build_pull_batch(pos, tot_entity, tot_relation, segment):
     seg_idx = np.arange(tot, dtype=np.int64) - np.repeat(first, nseg)
     beg = row_off[item_row] + seg_idx * segment
     end = np.minimum(beg + segment, row_off[item_row] + counts[item_row])
-    is_multi = nseg[item_row] > 1
-    slot = np.cumsum(is_multi) - 1                      # consecutive per row, in segment order
-    kind = np.where(~is_multi, 0, np.where(seg_idx == 0, 1, 2))
-    info = kind | (np.where(is_multi, slot, 0) << 2)
+    nseg_i = nseg[item_row]
+    is_global = nseg_i > GPB                                # partial sums through global memory
+    is_local = (nseg_i > 1) & ~is_global                    # partial sums through LDS inside one workgroup
+    slot = np.cumsum(is_global) - 1                         # consecutive per row, in segment order
+    kind = np.where(is_global, np.where(seg_idx == 0, 1, 2), np.where(is_local, 3, 0))
+    info = np.where(is_global, kind | (slot << 2), np.where(is_local, 3 | (seg_idx << 2) | (nseg_i << 6), 0))
     items = np.stack([item_row, beg, end, info], 1)
-    # heaviest items first (entity owners also walk their corrupting-entity list, ~B/E pairs)
-    weight = (end - beg) + np.where((item_row < E) & (kind != 2), max(1, B // max(E, 1)), 0)
-    items = items[np.argsort(-weight, kind="stable")].astype(np.int32)
-    mrows = np.flatnonzero(nseg > 1)
-    multi = np.stack([mrows, slot[first[mrows]], nseg[mrows], np.zeros_like(mrows)], 1).astype(np.int32).reshape(-1, 4)
+    # ---- placement into workgroup slots: the items of a "local" row must sit in consecutive groups of one workgroup
+    c_extra = max(1, B // max(E, 1))                        # entity owners also walk ~B/E corrupting-entity draws
+    weight = (end - beg) + np.where((item_row < E) & (seg_idx == 0), c_extra, 0)
+    local_rows = np.flatnonzero((nseg > 1) & (nseg <= GPB))
+    blocks = []                                             # lists of item indices, at most GPB each
+    open_by_free = {}                                       # free slots -> indices of blocks with that much room
+    for r in local_rows[np.argsort(-nseg[local_rows], kind="stable")]:
+        need = int(nseg[r])
+        members = list(range(int(first[r]), int(first[r]) + need))
+        fit = next((f for f in range(need, GPB) if open_by_free.get(f)), None)
+        if fit is None:
+            blocks.append(members)
+            bi, free = len(blocks) - 1, GPB - need
+        else:
+            bi = open_by_free[fit].pop()
+            blocks[bi].extend(members)
+            free = fit - need
+        if free > 0:
+            open_by_free.setdefault(free, []).append(bi)
+    rest = np.flatnonzero(~is_local)
+    rest = rest[np.argsort(-weight[rest], kind="stable")].tolist()   # singles and global-multi items, heaviest first
+    pos_r = 0
+    for bi in range(len(blocks)):                           # top up the workgroups that hold local rows
+        room = GPB - len(blocks[bi])
+        if room and pos_r < len(rest):
+            blocks[bi].extend(rest[pos_r:pos_r + room])
+            pos_r += room
+    while pos_r < len(rest):
+        blocks.append(rest[pos_r:pos_r + GPB])
+        pos_r += GPB
+    bw = np.asarray([weight[b].max() if len(b) else 0 for b in blocks])
+    out = np.full((len(blocks) * GPB, 4), 0, dtype=np.int64)
+    out[:, 0] = -1
+    for k, bi in enumerate(np.argsort(-bw, kind="stable")):
+        b = blocks[bi]
+        out[k * GPB:k * GPB + len(b)] = items[b]
+    grows = np.flatnonzero(nseg > GPB)
+    multi = np.stack([grows, slot[first[grows]], nseg[grows], np.zeros_like(grows)], 1).astype(np.int32).reshape(-1, 4)
     pairs = np.concatenate([pos, np.zeros((B, 1), np.int64)], 1).astype(np.int32)
-    return pairs, inc, np.ascontiguousarray(items), np.ascontiguousarray(multi), int(is_multi.sum())
+    return pairs, inc, np.ascontiguousarray(out.astype(np.int32)), np.ascontiguousarray(multi), int(is_global.sum())
 
 
 class PullIndex:

@@ -283,35 +283,30 @@ class Trainer:
     def _pull_state(self):
         idx = self.generator.pull_index()
         if getattr(self, "_pull", None) is None or self._pull.batch_size != idx.batch_size:
-            self._pull = PullState(self.flat, self.model, idx.batch_size, idx.max_slots)
-            self._pull.sync_in()
+            ps = self._pull = PullState(self.flat, self.model, idx.batch_size, idx.max_slots)
+            ps.sync_in()
+            gen, cfg = self.generator, self.config
+            ps.plan = K.PullPlan("transe", self.model.desc_kwargs(), cfg.tot_entity, cfg.tot_relation, ps.tables, ps.hats,
+                                 ps.norms, ps.state1, ps.state2, ps.lists, idx, ps.partials, cfg.margin, cfg.optimizer,
+                                 cfg.learning_rate, self.loss_buf, gen.bern, gen.slots, gen.seed)
         return self._pull, idx
 
     def _pull_step(self, batch_idx, offset):
         """One full training step on batch `batch_idx` of the permutation (Philox counters offset .. offset + B)."""
         ps, idx = self._pull_state()
         gen = self.generator
-        pairs, inc, items, multi = idx.batch(batch_idx)
         lists = ps.lists[ps.cur_list]
         if ps.ready != (batch_idx, offset):   # first step of an epoch (or a restart): stand-alone sampler launch
             if ps.ready is not None:
                 lists.clear()
-            K.pull_sample(pairs, self.config.tot_entity, gen.bern, gen.slots, gen.seed, offset, lists)
+            K.pull_sample(idx.batch(batch_idx)[0], self.config.tot_entity, gen.bern, gen.slots, gen.seed, offset, lists)
         # the sampler of the NEXT batch of this epoch rides in this step's launch and fills the other list set
         nxt = None
         if gen._pending > 0 and batch_idx + 1 < idx.n_batches:
             nxt = (batch_idx + 1, offset + idx.batch_size * gen.neg_rate)
-        sample_next = None if nxt is None else (idx.batch(nxt[0])[0], gen.bern, gen.slots, gen.seed, nxt[1],
-                                                ps.lists[1 - ps.cur_list])
-        src, dst = ps.cur, 1 - ps.cur
         self.flat.step += 1
-        desc = K.make_desc("transe", ps.tables[src], None, tot_entity=self.config.tot_entity,
-                           tot_relation=self.config.tot_relation, **self.model.desc_kwargs())
-        K.pull_step(desc, ps.tables[dst], ps.hats[src], ps.hats[dst], ps.norms[src], ps.norms[dst], ps.state1, ps.state2, pairs,
-                    lists, items, inc,
-                    ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate, self.flat.step,
-                    self.loss_buf, sample_next=sample_next)
-        ps.cur = dst
+        ps.plan.step(batch_idx, ps.cur, ps.cur_list, self.flat.step, None if nxt is None else nxt[0], 0 if nxt is None else nxt[1])
+        ps.cur = 1 - ps.cur
         ps.ready = nxt
         if nxt is not None:
             ps.cur_list = 1 - ps.cur_list

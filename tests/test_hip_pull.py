@@ -19,12 +19,14 @@ def hip():
     return hip_util
 
 
-@pytest.mark.parametrize("segment", [None, 2])
+@pytest.mark.parametrize("segment", [None, 2, 1])
 @pytest.mark.parametrize("opt", ["sgd", "adam", "adagrad", "rms"])
 @pytest.mark.parametrize("name", ["transe_l1", "transe_l2"])
 def test_three_pull_steps_match_reference_weights(hip, name, opt, segment):
     """Golden batches of the live reference, three steps: losses and post-optimiser tables (tests/golden/ref_transe_*).
-    segment=2 cuts almost every row's incidence list into several work items (partial sums + finishing kernel)."""
+    segment=2 cuts almost every row's incidence list into several work items that combine through LDS inside one
+    workgroup; segment=1 additionally pushes the relation rows (> 8 incidences) through global partial sums + the
+    finishing kernel."""
     from pykg2vec_amd import kernels as K
     from pykg2vec_amd.trainer import Trainer
     c = Case(name)
