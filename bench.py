@@ -342,19 +342,27 @@ def main():
     def one_step(ev_pair=None):
         if gen._pending <= 0:
             gen.start_one_epoch(steps_per_epoch)
-        if pull:   # sampler lists -> owner-computes step (scores, hinge, backward, dense Adam; no atomics) [-> finish]
-            if ev_pair is not None:
-                ev_pair[0].record()
-            tr.step_next_batch()
-            if ev_pair is not None:
-                ev_pair[1].record()
-            return
         if ev_pair is not None:
             ev_pair[0].record()
         tr._accumulate_next_batch()  # ONE launch: corruption + score(+) + score(-) + hinge + backward scatter
         if ev_pair is not None:
             ev_pair[1].record()
         tr._reduce_and_step()
+
+    def run_steps(n, events=None):
+        """n training steps through the product's step path.  Owner-computes path: each step is ONE launch (next batch's
+        sampler + per-row re-evaluation, hinge, backward, dense Adam; no atomics) and the steps of an epoch are enqueued
+        by one native call (kge_pull_run), so there are no per-step events."""
+        if not pull:
+            for k in range(n):
+                one_step(None if events is None else events[k])
+            return
+        while n > 0:
+            if gen._pending <= 0:
+                gen.start_one_epoch(steps_per_epoch)
+            k = min(n, gen._pending)
+            tr.step_next_batches(k)
+            n -= k
 
     def barrier():
         torch.cuda.synchronize()
@@ -364,8 +372,7 @@ def main():
 
     # ---- warm-up: the W steps asked for, then more until >= MIN_WARM_SECONDS of GPU work has run (clocks, caches,
     # code objects, RCCL channels), so that a short timed region measures the steady state
-    for _ in range(args.warmup):
-        one_step()
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     warm_extra, t_warm = 0, time.perf_counter()
     while True:
@@ -374,8 +381,7 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)   # every rank runs the same number of collective steps
         if flag.item() == 0.0:
             break
-        for _ in range(16):
-            one_step()
+        run_steps(16)
         warm_extra += 16
         torch.cuda.synchronize()
 
@@ -384,8 +390,7 @@ def main():
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(events[k])
+    run_steps(args.steps, events)
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -397,7 +402,7 @@ def main():
     value = scored_per_step * args.steps / dt
     # HIP events around each launch of the timed region: they bracket [dispatch gap after the previous kernel + the
     # kernel], i.e. an upper bound of the kernel's duration ...
-    event_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    event_ms = None if pull else float(np.mean([a.elapsed_time(b) for a, b in events]))
     # ... the kernel's own duration (what rocprofv3 --kernel-trace reports, profiles/) is measured right after the
     # timed region by a burst of back-to-back launches of the SAME kernel on the same stream between two events: no
     # host gap, no optimiser in between (gradients just keep accumulating; they are cleared afterwards)

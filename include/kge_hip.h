@@ -297,6 +297,45 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
                   int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
                   void* stream);
 
+/* A whole run of consecutive owner-computes steps enqueued by ONE native call (the per-step work is ~35 us of GPU time: a
+ * Python-level loop cannot keep the queue full).  The plan holds everything that does not change between steps. */
+typedef struct kge_pull_batch {
+    const int32_t* pairs;   /* [n_pairs, 4] */
+    const int32_t* items;   /* [n_items, 4] */
+    int64_t n_items;
+    const int32_t* inc;     /* [3 * n_pairs] */
+    const int32_t* multi;   /* [n_multi, 4] or NULL */
+    int64_t n_multi;
+    int64_t n_pairs;
+} kge_pull_batch;
+typedef struct kge_pull_plan {
+    kge_model_desc model[2];      /* descriptor over table half 0 / half 1 (tables[0..1]; grads unused) */
+    float* hat[2][2];             /* [half][table] row-normalised copies */
+    float* norm[2];               /* [half] row norms, E + R */
+    float* state1[2];             /* [table] optimiser state (NULL where unused) */
+    float* state2[2];
+    kge_pull_lists lists[2];      /* the two sampler list sets */
+    const kge_pull_batch* batches;  /* HOST array of n_batches entries */
+    int64_t n_batches;
+    float* partials;
+    float margin;
+    int32_t optimizer;
+    float lr;
+    const float* bern_prob;
+    const uint64_t* slots;
+    int64_t n_slots;
+    uint64_t seed;
+    int64_t draws_per_batch;      /* Philox counters consumed per batch (= n_pairs * neg_rate) */
+    float* loss;
+} kge_pull_plan;
+/* Steps on batches first_batch .. first_batch + n_steps - 1.  src_half: the table half the first step reads (halves
+ * alternate); cur_list: the list set the first step consumes; lists_ready == 0: a stand-alone sampler launch fills it first
+ * (it must be cleared).  first_opt_step: optimiser step number of the first step (1-based); first_offset: its Philox
+ * offset.  sample_after_last != 0: the last step also carries the sampler of batch first_batch + n_steps. */
+size_t kge_pull_plan_bytes(void);   /* sizeof(kge_pull_plan): lets a binding check its struct layout */
+int kge_pull_run(const kge_pull_plan* plan, int64_t first_batch, int64_t n_steps, int32_t src_half, int32_t cur_list,
+                 int32_t lists_ready, int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream);
+
 /* ---- 1-N scoring head of the projection models (ConvE / TuckER / InteractE / HypER / AcrE:
  * projection.py:100-102, 335-336, 444-447, 606-609, 734-737):  preds[B,E] = sigmoid(x[B,dim] @ ent[E,dim]^T + bias[E]).
  * bias may be NULL (TuckER).  fp32 on the matrix cores. */

@@ -47,6 +47,22 @@ class PullLists(ctypes.Structure):
 
 PULL_BUCKET = 16
 
+
+class PullBatch(ctypes.Structure):
+    """struct kge_pull_batch"""
+    _fields_ = [("pairs", ctypes.c_void_p), ("items", ctypes.c_void_p), ("n_items", ctypes.c_int64), ("inc", ctypes.c_void_p),
+                ("multi", ctypes.c_void_p), ("n_multi", ctypes.c_int64), ("n_pairs", ctypes.c_int64)]
+
+
+class PullPlanC(ctypes.Structure):
+    """struct kge_pull_plan"""
+    _fields_ = [("model", ModelDesc * 2), ("hat", (ctypes.c_void_p * 2) * 2), ("norm", ctypes.c_void_p * 2),
+                ("state1", ctypes.c_void_p * 2), ("state2", ctypes.c_void_p * 2), ("lists", PullLists * 2),
+                ("batches", ctypes.POINTER(PullBatch)), ("n_batches", ctypes.c_int64), ("partials", ctypes.c_void_p),
+                ("margin", ctypes.c_float), ("optimizer", ctypes.c_int32), ("lr", ctypes.c_float),
+                ("bern_prob", ctypes.c_void_p), ("slots", ctypes.c_void_p), ("n_slots", ctypes.c_int64),
+                ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p)]
+
 _SIGNATURES = {
     "kge_abi_version": (ctypes.c_int, []),
     "kge_last_error": (ctypes.c_char_p, []),
@@ -97,6 +113,9 @@ _SIGNATURES = {
                                      ctypes.c_int32, ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
                                      ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                      ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_pull_plan_bytes": (ctypes.c_size_t, []),
+    "kge_pull_run": (ctypes.c_int, [ctypes.POINTER(PullPlanC), ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                    ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

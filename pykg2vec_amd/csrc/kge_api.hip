@@ -343,6 +343,43 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
                             n_slots, seed, next_offset, next_lists, loss, (hipStream_t)stream);
 }
 
+size_t kge_pull_plan_bytes(void) { return sizeof(kge_pull_plan); }
+
+int kge_pull_run(const kge_pull_plan* p, int64_t first_batch, int64_t n_steps, int32_t src_half, int32_t cur_list,
+                 int32_t lists_ready, int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream) {
+    if (!p || !p->batches || n_steps < 0 || first_batch < 0 || first_batch + n_steps > p->n_batches || (src_half & ~1) ||
+        (cur_list & ~1) || first_opt_step < 1) {
+        set_error("kge_pull_run: bad arguments");
+        return -1;
+    }
+    int src = src_half, cl = cur_list;
+    uint64_t offset = first_offset;
+    for (int64_t k = 0; k < n_steps; ++k) {
+        const kge_pull_batch* b = p->batches + first_batch + k;
+        int rc;
+        if (k == 0 && !lists_ready) {
+            rc = kge_pull_sample(b->pairs, b->n_pairs, p->model[0].tot_entity, p->bern_prob, p->slots, p->n_slots, p->seed, offset,
+                                 nullptr, &p->lists[cl], stream);
+            if (rc) return rc;
+        }
+        const bool has_next = (k + 1 < n_steps || sample_after_last) && first_batch + k + 1 < p->n_batches;
+        const kge_pull_batch* nb = has_next ? b + 1 : nullptr;
+        float* const tables_out[2] = {const_cast<float*>(p->model[1 - src].tables[0]), const_cast<float*>(p->model[1 - src].tables[1])};
+        const float* const hat_in[2] = {p->hat[src][0], p->hat[src][1]};
+        float* const hat_out[2] = {p->hat[1 - src][0], p->hat[1 - src][1]};
+        rc = kge_pull_step(&p->model[src], tables_out, hat_in, hat_out, p->norm[src], p->norm[1 - src], p->state1, p->state2,
+                           b->pairs, &p->lists[cl], b->items, b->n_items, b->inc, p->partials, b->multi, b->n_multi, p->margin,
+                           p->optimizer, p->lr, first_opt_step + k, nullptr, 1, nb ? nb->pairs : nullptr, nb ? nb->n_pairs : 0,
+                           p->bern_prob, p->slots, p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch,
+                           nb ? &p->lists[1 - cl] : nullptr, p->loss, stream);
+        if (rc) return rc;
+        src ^= 1;
+        if (has_next) cl ^= 1;
+        offset += (uint64_t)p->draws_per_batch;
+    }
+    return 0;
+}
+
 int kge_head_1n_forward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
                         float* preds, void* stream) {
     return launch_head_forward(x, batch, dim, ent, tot_entity, bias, preds, (hipStream_t)stream);

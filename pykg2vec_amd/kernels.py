@@ -471,54 +471,46 @@ def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, s
 
 
 class PullPlan:
-    """Pre-marshalled kge_pull_step calls for a (model, index, state) triple: everything that does not change from step
-    to step is converted to ctypes once, so the hot loop pays one foreign call per step instead of ~40 tensor / ctypes
-    conversions (the step is ~35 us of GPU work: the host must not be the bottleneck)."""
+    """struct kge_pull_plan for a (model, index, state) triple: everything that does not change from step to step,
+    marshalled once.  `run` enqueues a whole sequence of steps with ONE foreign call (the per-step work is ~35 us of GPU
+    time: a Python-level loop could not keep the queue full)."""
 
     def __init__(self, model_name, desc_kwargs, tot_entity, tot_relation, tables, hats, norms, state1, state2, lists, index,
-                 partials, margin, optimizer, lr, loss_buf, bern, slots, seed):
-        self.fn = L.load().kge_pull_step
+                 partials, margin, optimizer, lr, loss_buf, bern, slots, seed, draws_per_batch):
         self.keep = (tables, hats, norms, state1, state2, lists, index, partials, loss_buf, bern, slots)   # keep storage alive
-        self.desc = [make_desc(model_name, tables[src], None, tot_entity=tot_entity, tot_relation=tot_relation, **desc_kwargs)
-                     for src in (0, 1)]
-        self.tab = [_ptr_pair(tables[h]) for h in (0, 1)]
-        self.hat = [_ptr_pair(hats[h]) for h in (0, 1)]
-        self.norm = [ctypes.c_void_p(n.data_ptr()) for n in norms]
-        self.s1, self.s2 = _ptr_pair(state1), _ptr_pair(state2)
-        self.has1, self.has2 = state1 is not None, state2 is not None
-        self.lists = lists
-        self.batches = []
+        c = L.PullPlanC()
+        for half in (0, 1):
+            c.model[half] = make_desc(model_name, tables[half], None, tot_entity=tot_entity, tot_relation=tot_relation, **desc_kwargs)
+            c.norm[half] = norms[half].data_ptr()
+            c.lists[half] = lists[half].c
+            for t in (0, 1):
+                c.hat[half][t] = hats[half][t].data_ptr()
+        for t in (0, 1):
+            c.state1[t] = state1[t].data_ptr() if state1 is not None else None
+            c.state2[t] = state2[t].data_ptr() if state2 is not None else None
+        self.batches = (L.PullBatch * index.n_batches)()
         for b in range(index.n_batches):
             pairs, inc, items, multi = index.batch(b)
-            self.batches.append((ctypes.c_void_p(pairs.data_ptr()), ctypes.c_void_p(items.data_ptr()), items.shape[0],
-                                 ctypes.c_void_p(inc.data_ptr()), ctypes.c_void_p(multi.data_ptr()) if multi.shape[0] else None,
-                                 multi.shape[0], pairs.shape[0]))
-        self.partials = ctypes.c_void_p(partials.data_ptr())
-        self.margin, self.opt, self.lr = float(margin), OPTIMIZER_IDS[optimizer], float(lr)
-        self.loss = ctypes.c_void_p(loss_buf.data_ptr())
-        self.bern = ctypes.c_void_p(bern.data_ptr()) if bern is not None else None
-        self.slots = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
-        self.n_slots = slots.numel() if slots is not None else 0
-        self.seed = int(seed) & (2 ** 64 - 1)
+            self.batches[b] = L.PullBatch(pairs.data_ptr(), items.data_ptr(), items.shape[0], inc.data_ptr(),
+                                          multi.data_ptr() if multi.shape[0] else None, multi.shape[0], pairs.shape[0])
+        c.batches = ctypes.cast(self.batches, ctypes.POINTER(L.PullBatch))
+        c.n_batches = index.n_batches
+        c.partials = partials.data_ptr()
+        c.margin, c.optimizer, c.lr = float(margin), OPTIMIZER_IDS[optimizer], float(lr)
+        c.bern_prob = bern.data_ptr() if bern is not None else None
+        c.slots = slots.data_ptr() if slots is not None else None
+        c.n_slots = slots.numel() if slots is not None else 0
+        c.seed = int(seed) & (2 ** 64 - 1)
+        c.draws_per_batch = int(draws_per_batch)
+        c.loss = loss_buf.data_ptr()
+        self.c = c
+        self.fn = L.load().kge_pull_run
 
-    def step(self, b, src, cur_list, step, next_batch, next_offset):
-        """Step on batch b reading table half `src`, consuming list set `cur_list`; next_batch (or None): the batch whose
-        sampler rides along and fills the other list set with Philox offset next_offset."""
-        pairs, items, n_items, inc, multi, n_multi, _ = self.batches[b]
-        if next_batch is None:
-            npairs, nn, nlists = None, 0, None
-        else:
-            nb = self.batches[next_batch]
-            npairs, nn, nlists = nb[0], nb[6], ctypes.byref(self.lists[1 - cur_list].c)
-        dst = 1 - src
-        rc = self.fn(ctypes.byref(self.desc[src]), ctypes.addressof(self.tab[dst]), ctypes.addressof(self.hat[src]),
-                     ctypes.addressof(self.hat[dst]), self.norm[src], self.norm[dst],
-                     ctypes.addressof(self.s1) if self.has1 else None, ctypes.addressof(self.s2) if self.has2 else None,
-                     pairs, ctypes.byref(self.lists[cur_list].c), items, n_items, inc, self.partials, multi, n_multi,
-                     self.margin, self.opt, self.lr, int(step), None, 1, npairs, nn, self.bern, self.slots, self.n_slots,
-                     self.seed, int(next_offset) & (2 ** 64 - 1), nlists, self.loss, _stream())
+    def run(self, first_batch, n_steps, src_half, cur_list, lists_ready, first_opt_step, first_offset, sample_after_last):
+        rc = self.fn(ctypes.byref(self.c), int(first_batch), int(n_steps), int(src_half), int(cur_list), 1 if lists_ready else 0,
+                     int(first_opt_step), int(first_offset) & (2 ** 64 - 1), 1 if sample_after_last else 0, _stream())
         if rc:
-            L.check(rc, "kge_pull_step")
+            L.check(rc, "kge_pull_run")
 
 
 # ---------------------------------------------------------------------------- 1-N scoring head (projection models)

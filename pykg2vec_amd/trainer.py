@@ -288,28 +288,35 @@ class Trainer:
             gen, cfg = self.generator, self.config
             ps.plan = K.PullPlan("transe", self.model.desc_kwargs(), cfg.tot_entity, cfg.tot_relation, ps.tables, ps.hats,
                                  ps.norms, ps.state1, ps.state2, ps.lists, idx, ps.partials, cfg.margin, cfg.optimizer,
-                                 cfg.learning_rate, self.loss_buf, gen.bern, gen.slots, gen.seed)
+                                 cfg.learning_rate, self.loss_buf, gen.bern, gen.slots, gen.seed,
+                                 idx.batch_size * gen.neg_rate)
         return self._pull, idx
 
-    def _pull_step(self, batch_idx, offset):
-        """One full training step on batch `batch_idx` of the permutation (Philox counters offset .. offset + B)."""
+    def _pull_steps(self, n_steps):
+        """The next n_steps steps of the current epoch, enqueued by one native call (kge_pull_run)."""
         ps, idx = self._pull_state()
         gen = self.generator
-        lists = ps.lists[ps.cur_list]
-        if ps.ready != (batch_idx, offset):   # first step of an epoch (or a restart): stand-alone sampler launch
-            if ps.ready is not None:
-                lists.clear()
-            K.pull_sample(idx.batch(batch_idx)[0], self.config.tot_entity, gen.bern, gen.slots, gen.seed, offset, lists)
-        # the sampler of the NEXT batch of this epoch rides in this step's launch and fills the other list set
-        nxt = None
-        if gen._pending > 0 and batch_idx + 1 < idx.n_batches:
-            nxt = (batch_idx + 1, offset + idx.batch_size * gen.neg_rate)
-        self.flat.step += 1
-        ps.plan.step(batch_idx, ps.cur, ps.cur_list, self.flat.step, None if nxt is None else nxt[0], 0 if nxt is None else nxt[1])
-        ps.cur = 1 - ps.cur
-        ps.ready = nxt
-        if nxt is not None:
-            ps.cur_list = 1 - ps.cur_list
+        B = idx.batch_size
+        if n_steps <= 0:
+            return
+        first = gen._batch_idx
+        if gen._pending < n_steps or first + n_steps > idx.n_batches:
+            raise StopIteration
+        offset = gen._draws
+        gen._batch_idx += n_steps
+        gen._pending -= n_steps
+        gen._draws += n_steps * B * gen.neg_rate
+        ready = ps.ready == (first, offset)
+        if not ready and ps.ready is not None:   # a sampler rode along for a batch that is not the next one: discard
+            ps.lists[ps.cur_list].clear()
+        # the last step carries the sampler of the following batch when this epoch still has one
+        after = gen._pending > 0 and first + n_steps < idx.n_batches
+        ps.plan.run(first, n_steps, ps.cur, ps.cur_list, ready, self.flat.step + 1, offset, after)
+        self.flat.step += n_steps
+        carried = n_steps - 1 + (1 if after else 0)            # number of ride-along samplers = list-set flips
+        ps.cur ^= n_steps & 1
+        ps.cur_list ^= carried & 1
+        ps.ready = (first + n_steps, offset + n_steps * B * gen.neg_rate) if after else None
 
     def pull_step_explicit(self, ph, pr, pt, nh, nr, nt, segment=None):
         """The owner-computes step on an explicit batch (positives + given negatives, neg_rate 1): the incidence index
@@ -339,18 +346,19 @@ class Trainer:
 
     def step_next_batch(self):
         """One whole training step on the generator's next batch, whichever path serves it."""
-        if self._pull_ok():
-            start, n, offset = self.generator._next_range()
-            if n == self.config.batch_size and start % n == 0:
-                self._pull_step(start // n, offset)
-                return
-            self.sync_model()   # a short last batch: the push path handles it
-            self._pull = None
-            self._accumulate_next_batch(fixed_range=(start, n, offset))
-            self._reduce_and_step()
+        self.step_next_batches(1)
+
+    def step_next_batches(self, n):
+        """n consecutive steps of the current epoch.  On the owner-computes path they are enqueued by one native call."""
+        if n > 0 and self._pull_ok() and self.generator._batch_idx + n <= self.generator.n_train // self.config.batch_size:
+            self._pull_steps(n)
             return
-        self._accumulate_next_batch()
-        self._reduce_and_step()
+        if getattr(self, "_pull", None) is not None:   # leaving the pull path (a short last batch): hand the tables back
+            self.sync_model()
+            self._pull = None
+        for _ in range(n):
+            self._accumulate_next_batch()
+            self._reduce_and_step()
 
     def _mean_type_loss(self):
         """pointwise_logistic and the self-adversarial loss are MEANS over the batch (criterion.py:13-23,31-34);
@@ -506,8 +514,7 @@ class Trainer:
             self.loss_buf.zero_()
             if self._pull_ok():
                 self._pull_state()[0].sync_in()   # the tables may have been changed from outside since the last epoch
-            for _ in range(num_batch):
-                self.step_next_batch()
+            self.step_next_batches(num_batch)
             self.sync_model()
         acc = self.K.read_loss(self.loss_buf)
         if self.world_size > 1:

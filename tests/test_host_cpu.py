@@ -204,3 +204,13 @@ def test_new_entry_points_validate_arguments_without_gpu():
     d.tables[2] = 16
     assert lib.kge_score_forward(ctypes.byref(d), fake, fake, fake, 4, fake, fake, 1 << 20, None) != 0
     assert b"exceed the LDS-resident tile kernel" in lib.kge_last_error()
+
+
+def test_pull_plan_struct_layout_matches_the_library():
+    """struct kge_pull_plan is filled by the Python binding and read by kge_pull_run: the layouts must agree."""
+    from pykg2vec_amd import _lib
+    lib = _lib.load()
+    assert lib.kge_pull_plan_bytes() == ctypes.sizeof(_lib.PullPlanC)
+    assert ctypes.sizeof(_lib.PullBatch) == 56 and ctypes.sizeof(_lib.PullLists) == 40
+    assert lib.kge_pull_partial_stride(100) == 128 and lib.kge_pull_partial_stride(102) == 0   # rows move as float4
+    assert lib.kge_pull_run(None, 0, 1, 0, 0, 0, 1, 0, 0, None) != 0 and b"kge_pull_run" in lib.kge_last_error()
