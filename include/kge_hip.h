@@ -269,7 +269,8 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
  * step.  next_pairs != NULL: the sampler of the NEXT batch rides in this step's launch and fills next_lists (a second
  * set), so a steady-state step is one launch (+ a small finishing launch when rows are cut into several items).
  * m->tables = the tables read; tables_out = the other half of the double buffer; hat_in / hat_out: the row-normalised
- * copies x / max(||x||, 1e-12) of the tables read / written (what other owners gather); norm_in / norm_out [E + R]: their
+ * copies x / max(||x||, 1e-12) of the tables read / written (what other owners gather), rows padded with zeros to
+ * kge_pull_partial_stride(dim) floats; norm_in / norm_out [E + R]: their
  * L2 row norms (kge_row_norms fills both before the first step); state1 / state2: optimiser state per table.
  * dim must be a multiple of 4 (rows move as float4).
  * partials: kge_pull_partial_stride(dim) floats per slot. */

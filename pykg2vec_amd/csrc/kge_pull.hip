@@ -52,7 +52,8 @@ struct PullSampleArgs {
 struct PullArgs {
     const float* tab_in[2];    // entity / relation table read by this step
     float* tab_out[2];         // the tables the step writes (other half of the double buffer)
-    const float* hat_in[2];    // row-normalised copies x / max(||x||, eps) of tab_in: what the other owners gather
+    const float* hat_in[2];    // row-normalised copies x / max(||x||, eps) of tab_in: what the other owners gather.  Rows
+                               // are padded with zeros to 4 * G * NV floats, so a gather is one unconditional 16-byte load
     float* hat_out[2];         // the same for tab_out, written by each row's owner
     const float* norm_in;      // [E + R] L2 norms of the rows of tab_in (entities first)
     float* norm_out;           // norms of the rows of tab_out
@@ -159,9 +160,12 @@ __device__ __forceinline__ void pull_finish_row(const PullArgs& a, int g, const 
     store_row4<G, NV>(t_out + off, P, nvec, gl);
     if constexpr (OPT != KGE_OPT_SGD) store_row4<G, NV>(st1 + off, M1, nvec, gl);
     if constexpr (OPT == KGE_OPT_ADAM) store_row4<G, NV>(st2 + off, M2, nvec, gl);
+    float4* const hrow = reinterpret_cast<float4*>(h_out) + (int64_t)(is_rel ? g - a.E : g) * (G * NV);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { P[v].x *= inn; P[v].y *= inn; P[v].z *= inn; P[v].w *= inn; }
-    store_row4<G, NV>(h_out + off, P, nvec, gl);
+    for (int v = 0; v < NV; ++v) {   // padded row: lanes beyond the row store their zeros
+        P[v].x *= inn; P[v].y *= inn; P[v].z *= inn; P[v].w *= inn;
+        hrow[v * G + gl] = P[v];
+    }
     if (gl == 0) a.norm_out[g] = nn;
 }
 
@@ -227,12 +231,18 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
 
         // gather the four normalised rows of one incident pair (the owner's own row among them: it is L1 / L2 hot, and
         // loading it like the others keeps the gather branch-free and the arithmetic identical for all four owners)
+        const float4* __restrict__ hat_e = reinterpret_cast<const float4*>(a.hat_in[0]) + gl;
+        const float4* __restrict__ hat_r = reinterpret_cast<const float4*>(a.hat_in[1]) + gl;
         auto fetch = [&](int h, int r, int t, int w, PullRows<NV>& b) {
             b.w = w;
-            load_row4<G, NV>(b.hh, a.hat_in[0] + (int64_t)h * d, nvec, gl);
-            load_row4<G, NV>(b.rr, a.hat_in[1] + (int64_t)r * d, nvec, gl);
-            load_row4<G, NV>(b.tt, a.hat_in[0] + (int64_t)t * d, nvec, gl);
-            load_row4<G, NV>(b.cc, a.hat_in[0] + (int64_t)(w & 0xFFFFFF) * d, nvec, gl);
+            const int c = w & 0xFFFFFF;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {   // padded rows: no bounds checks
+                b.hh[v] = hat_e[(int64_t)h * (G * NV) + v * G];
+                b.rr[v] = hat_r[(int64_t)r * (G * NV) + v * G];
+                b.tt[v] = hat_e[(int64_t)t * (G * NV) + v * G];
+                b.cc[v] = hat_e[(int64_t)c * (G * NV) + v * G];
+            }
         };
         auto fetch_visit = [&](int v, PullRows<NV>& b) {
             const int src = __shfl(ord, gbase + v, 64);
@@ -385,11 +395,14 @@ __global__ __launch_bounds__(kBlock) void k_row_norms(const float* __restrict__ 
     n2 = gsum<G>(n2);
     const float nn = sqrtf(n2);
     if (gl == 0) out[r] = nn;
-    if (hat) {
+    if (hat) {   // padded rows of 4 * G * NV floats
         const float inn = 1.0f / fmaxf(nn, kEpsNormalize);
+        float4* const hrow = reinterpret_cast<float4*>(hat) + r * (G * NV);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) { X[v].x *= inn; X[v].y *= inn; X[v].z *= inn; X[v].w *= inn; }
-        store_row4<G, NV>(hat + r * d, X, d >> 2, gl);
+        for (int v = 0; v < NV; ++v) {
+            X[v].x *= inn; X[v].y *= inn; X[v].z *= inn; X[v].w *= inn;
+            hrow[v * G + gl] = X[v];
+        }
     }
 }
 

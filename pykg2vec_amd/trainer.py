@@ -85,12 +85,13 @@ class PullState:
         dev = flat.param.device
         self.flat = flat
         self.alt = torch.empty_like(flat.param)
-        self.hat_buf = [torch.zeros_like(flat.param), torch.zeros_like(flat.param)]   # row-normalised copies of both halves
         shapes = [tuple(v.shape) for v in flat.views[:2]]
         offs = [v.data_ptr() - flat.param.data_ptr() for v in flat.views[:2]]
         view = lambda buf: [buf[o // 4:o // 4 + r * d].view(r, d) for o, (r, d) in zip(offs, shapes)]
         self.tables = [view(flat.param), view(self.alt)]
-        self.hats = [view(self.hat_buf[0]), view(self.hat_buf[1])]
+        # row-normalised copies of both halves, rows padded to the kernels' float4 lane layout (kge_pull_partial_stride)
+        stride = K.pull_partial_stride(shapes[0][1])
+        self.hats = [[torch.zeros(r, stride, dtype=torch.float32, device=dev) for r, _ in shapes] for _ in range(2)]
         self.state1 = view(flat.state1) if flat.state1 is not None else None
         self.state2 = view(flat.state2) if flat.state2 is not None else None
         E, R, d = shapes[0][0], shapes[1][0], shapes[0][1]
@@ -116,7 +117,8 @@ class PullState:
         if self.cur == 1:
             self.flat.param.copy_(self.alt)
             self.norms[0].copy_(self.norms[1])
-            self.hat_buf[0].copy_(self.hat_buf[1])
+            for t in (0, 1):
+                self.hats[0][t].copy_(self.hats[1][t])
             self.cur = 0
 
 
