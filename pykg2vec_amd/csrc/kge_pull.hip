@@ -190,6 +190,9 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
     const int64_t item = (int64_t)((int)blockIdx.x - a.sample_blocks) * GPB + threadIdx.x / G;
     // partial sums of rows cut into 2..GPB items: their owners sit in consecutive groups of this workgroup
     __shared__ float4 s_part[GPB][NV * G];
+    // visit descriptors (h, r, t, c | tail << 24 | role << 25) of each owner group, in visit order: one broadcast
+    // ds_read_b128 per visit instead of four cross-lane shuffles
+    __shared__ int4 s_desc[GPB][G];
     float acc = 0.f;
     int4 it = make_int4(-1, 0, 0, 0);
     if (item < a.n_items) it = a.items[item];
@@ -200,30 +203,32 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
     if (g >= 0) {
         const bool is_rel = g >= a.E;
         const int n_static = it.z - it.y;
+        int cnt = 0, nvis = 0;
+        bool fast_c = true;
         // ---- the owner's visit list, one descriptor per lane: static incidences first, then the pairs that drew this
         // entity as their corrupting entity (bucket entries, visited in pair order)
-        int vi = -1, vrole = 0, ord = gbase + gl;
+        int vi = -1, vrole = 0, slot = gl;   // slot: this lane's position in the visit order
         if (gl < n_static) { const int e = a.inc[it.y + gl]; vi = e >> 2; vrole = e & 3; }
         // the row's corrupting-entity draws are walked by its first (or only) item
         const bool walks_c = !is_rel && (kind == 0 || kind == 1 || (kind == 3 && ((it.w >> 2) & 15) == 0));
-        int cnt = 0;
         if (walks_c) cnt = a.lists.count[g];
-        const bool fast_c = cnt <= kPullCap && n_static + cnt <= G;
-        int nvis = n_static;
+        fast_c = cnt <= kPullCap && n_static + cnt <= G;
+        nvis = n_static;
         if (cnt > 0 && fast_c) {
             const int q = gl - n_static;
             if (q >= 0 && q < cnt) { vi = a.lists.bucket[(int64_t)g * kPullCap + q]; vrole = kRoleC; }
             if (cnt > 1) {   // arrival order is arbitrary: rank the entries by pair index, visit by rank
                 int rank = 0;
                 for (int m = 0; m < cnt; ++m) rank += __shfl(vi, gbase + n_static + m, 64) < vi ? 1 : 0;
-                for (int m = 0; m < cnt; ++m)
-                    if (__shfl(rank, gbase + n_static + m, 64) == q) ord = gbase + n_static + m;
+                if (q >= 0 && q < cnt) slot = n_static + rank;
             }
             nvis += cnt;
         }
-        // per lane: the ids of ITS visit (h, r, t, c | tail << 24 | role << 25)
-        int4 pr = make_int4(0, 0, 0, 0);
-        if (vi >= 0) { pr = a.pairs[vi]; pr.w = a.lists.pc[vi] | (vrole << 25); }
+        if (vi >= 0) {
+            int4 pr = a.pairs[vi];
+            pr.w = a.lists.pc[vi] | (vrole << 25);
+            s_desc[threadIdx.x / G][slot] = pr;
+        }
         load_row4<G, NV>(X, (is_rel ? a.tab_in[1] : a.tab_in[0]) + (int64_t)(is_rel ? g - a.E : g) * d, nvec, gl);
         nX = a.norm_in[g];
 #pragma unroll
@@ -231,22 +236,26 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
 
         // gather the four normalised rows of one incident pair (the owner's own row among them: it is L1 / L2 hot, and
         // loading it like the others keeps the gather branch-free and the arithmetic identical for all four owners)
-        const float4* __restrict__ hat_e = reinterpret_cast<const float4*>(a.hat_in[0]) + gl;
-        const float4* __restrict__ hat_r = reinterpret_cast<const float4*>(a.hat_in[1]) + gl;
+        // (32-bit byte offsets from the uniform table bases: one shift-or per row instead of 64-bit address arithmetic)
+        const char* __restrict__ hat_e = reinterpret_cast<const char*>(a.hat_in[0]);
+        const char* __restrict__ hat_r = reinterpret_cast<const char*>(a.hat_in[1]);
+        constexpr unsigned kRowBytes = 16u * G * NV;
+        const unsigned lane_off = 16u * gl;
         auto fetch = [&](int h, int r, int t, int w, PullRows<NV>& b) {
             b.w = w;
-            const int c = w & 0xFFFFFF;
+            const unsigned oh = (unsigned)h * kRowBytes + lane_off, orr = (unsigned)r * kRowBytes + lane_off;
+            const unsigned ot = (unsigned)t * kRowBytes + lane_off, oc = (unsigned)(w & 0xFFFFFF) * kRowBytes + lane_off;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {   // padded rows: no bounds checks
-                b.hh[v] = hat_e[(int64_t)h * (G * NV) + v * G];
-                b.rr[v] = hat_r[(int64_t)r * (G * NV) + v * G];
-                b.tt[v] = hat_e[(int64_t)t * (G * NV) + v * G];
-                b.cc[v] = hat_e[(int64_t)c * (G * NV) + v * G];
+                b.hh[v] = *reinterpret_cast<const float4*>(hat_e + (oh + 16u * G * v));
+                b.rr[v] = *reinterpret_cast<const float4*>(hat_r + (orr + 16u * G * v));
+                b.tt[v] = *reinterpret_cast<const float4*>(hat_e + (ot + 16u * G * v));
+                b.cc[v] = *reinterpret_cast<const float4*>(hat_e + (oc + 16u * G * v));
             }
         };
         auto fetch_visit = [&](int v, PullRows<NV>& b) {
-            const int src = __shfl(ord, gbase + v, 64);
-            fetch(__shfl(pr.x, src, 64), __shfl(pr.y, src, 64), __shfl(pr.z, src, 64), __shfl(pr.w, src, 64), b);
+            const int4 ds = s_desc[threadIdx.x / G][v];   // same address for the whole group: a broadcast read
+            fetch(ds.x, ds.y, ds.z, ds.w, b);
         };
         // forward of the pair (identical arithmetic whichever of its four rows the owner holds), hinge, and the owner's
         // share of the backward: gradient wrt its NORMALISED row
@@ -278,8 +287,11 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
             if constexpr (L1) {
 #pragma unroll
                 for (int v2 = 0; v2 < NV; ++v2) {
+                    // sign(x) as clamp(x * 2^100, -1, 1): +-1 for every |x| >= 2^-100, 0 for 0 (sums of normalised components
+                    // are either exactly 0 -- padding lanes -- or ~1e-2..1): two plain VALU ops, no VOPC -> SGPR round trip
 #define KGE_BWD(c)                                                                                            \
-                    gs[v2].c += (up[v2].c > 0.f ? su : (up[v2].c < 0.f ? -su : 0.f)) + (un[v2].c > 0.f ? sv : (un[v2].c < 0.f ? -sv : 0.f));
+                    gs[v2].c = fmaf(sv, __builtin_amdgcn_fmed3f(un[v2].c * 0x1p100f, -1.f, 1.f),              \
+                                    fmaf(su, __builtin_amdgcn_fmed3f(up[v2].c * 0x1p100f, -1.f, 1.f), gs[v2].c));
                     KGE_BWD(x) KGE_BWD(y) KGE_BWD(z) KGE_BWD(w)
 #undef KGE_BWD
                 }
