@@ -260,10 +260,13 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
  *   pairs  [n, 4]        (h, r, t, 0) of the batch's positives, in batch order (Philox counter of pair i = offset + i)
  *   inc    [3n]          static incidences sorted by (row, pair, role): pair << 2 | role, role 0 = head, 1 = tail,
  *                        2 = relation; rows are numbered entities first, then tot_entity + relation
- *   items  [n_items, 4]  (row, first incidence, end incidence, kind | slot << 2): kind 0 = the row's only item (finishes the
- *                        row), 1 = first item of a row cut into several (also walks the row's corrupting-entity list),
- *                        2 = a later item; kinds 1 / 2 write a partial sum to partials[slot]
- *   multi  [n_multi, 4]  (row, first slot, number of slots, 0) of the rows cut into several items
+ *   items  [n_items, 4]  (row, first incidence, end incidence, info), laid out in workgroup slots of
+ *                        kge_pull_groups_per_block(dim) items (row -1 = padding).  info & 3 = kind: 0 = the row's only item;
+ *                        3 = one of 2..groups-per-block items of a row, all in consecutive slots of ONE workgroup (info =
+ *                        3 | segment << 2 | segments << 6; they combine through LDS); 1 / 2 = first / later item of a row
+ *                        with more items than that (info = kind | slot << 2: partial sums go to partials[slot] and the
+ *                        finishing kernel).  The row's first item also walks the row's corrupting-entity draws.
+ *   multi  [n_multi, 4]  (row, first slot, number of slots, 0) of the rows finished by the finishing kernel
  * Per step (device): a kge_pull_lists set, written by kge_pull_sample (same draws as kge_sample_batch with the same
  * seed / offset) or kge_pull_lists_explicit (given negatives) and consumed -- and reset when reset_lists != 0 -- by the
  * step.  next_pairs != NULL: the sampler of the NEXT batch rides in this step's launch and fills next_lists (a second
@@ -283,6 +286,7 @@ typedef struct kge_pull_lists {
     int32_t* next;    /* [n]  overflow list links */
 } kge_pull_lists;
 int kge_pull_partial_stride(int32_t dim);
+int kge_pull_groups_per_block(int32_t dim);   /* owner groups per 256-thread workgroup: items are laid out in workgroup slots */
 int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, float* normalised, void* stream);
 int kge_pull_sample(const int32_t* pairs, int64_t n, int64_t tot_entity, const float* bern_prob, const uint64_t* slots,
                     int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor, const kge_pull_lists* out,

@@ -92,6 +92,7 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
 
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);
+int pull_groups_per_block(int dim);
 int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
                      const float* norm_in, float* norm_out, float* const state1[2], float* const state2[2], const int32_t* pairs,
                      const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const int32_t* inc, float* partials,

@@ -24,6 +24,7 @@
 #include "kge_row_kernels.h"
 #include "kge_opt_device.h"
 #include "kge_sampler_device.h"
+#include <stdlib.h>
 
 namespace kge {
 
@@ -444,18 +445,29 @@ static PullLists to_lists(const kge_pull_lists* l) {
     return o;
 }
 
-// float4-per-lane geometry: 32-lane groups, NV = float4s per lane (row length d, d % 4 == 0, d <= 1024)
-static int pull_nv(int dim) {
-    if (dim <= 0 || (dim & 3) || dim > 1024) return 0;
+// float4-per-lane geometry (row length d, d % 4 == 0, d <= 1024): G-lane owner groups, NV float4s per lane, padded row =
+// 4 * G * NV floats.  Rows of up to 128 floats use 16-lane groups (four owners per wave share the per-visit fixed work:
+// descriptor read, address arithmetic, reduction steps, hinge logic); KGE_PULL_G=32 forces 32-lane groups (A/B runs).
+struct PullGeo { int G, NV; };
+static PullGeo pull_geo(int dim) {
+    PullGeo g{0, 0};
+    if (dim <= 0 || (dim & 3) || dim > 1024) return g;
     const int nvec = dim >> 2;
+    const char* force = getenv("KGE_PULL_G");
+    if (nvec <= 32 && !(force && force[0] == '3')) {
+        g.G = 16; g.NV = nvec <= 16 ? 1 : 2;
+        return g;
+    }
+    g.G = 32;
     for (int nv = 1; nv <= 8; nv <<= 1)
-        if (nvec <= 32 * nv) return nv;
-    return 0;
+        if (nvec <= 32 * nv) { g.NV = nv; return g; }
+    g.G = 0;
+    return g;
 }
 
-template <int OPT, int NV>
+template <int OPT, int G, int NV>
 static int launch_pull_geo(PullArgs& a, const PullSampleArgs& sa, float* loss, hipStream_t s) {
-    constexpr int G = 32, GPB = kBlock / G;
+    constexpr int GPB = kBlock / G;
     const int item_blocks = (int)((a.n_items + GPB - 1) / GPB);
     a.sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
     if (a.l1)
@@ -469,17 +481,15 @@ static int launch_pull_geo(PullArgs& a, const PullSampleArgs& sa, float* loss, h
 }
 
 template <int OPT>
-static int launch_pull_opt(PullArgs& a, const PullSampleArgs& sa, int nv, float* loss, hipStream_t s) {
-    switch (nv) {
-        case 1: return launch_pull_geo<OPT, 1>(a, sa, loss, s);
-        case 2: return launch_pull_geo<OPT, 2>(a, sa, loss, s);
-        case 4: return launch_pull_geo<OPT, 4>(a, sa, loss, s);
-        case 8: return launch_pull_geo<OPT, 8>(a, sa, loss, s);
-    }
+static int launch_pull_opt(PullArgs& a, const PullSampleArgs& sa, PullGeo g, float* loss, hipStream_t s) {
+#define KGE_PG(G_, NV_) if (g.G == G_ && g.NV == NV_) return launch_pull_geo<OPT, G_, NV_>(a, sa, loss, s);
+    KGE_PG(16, 1) KGE_PG(16, 2) KGE_PG(32, 1) KGE_PG(32, 2) KGE_PG(32, 4) KGE_PG(32, 8)
+#undef KGE_PG
     return -1;
 }
 
-int pull_partial_stride(int dim) { return 4 * 32 * pull_nv(dim); }
+int pull_partial_stride(int dim) { const PullGeo g = pull_geo(dim); return 4 * g.G * g.NV; }
+int pull_groups_per_block(int dim) { const PullGeo g = pull_geo(dim); return g.G ? kBlock / g.G : 0; }
 
 static PullSampleArgs make_sample_args(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots,
                                        int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor,
@@ -500,8 +510,8 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
                      const float* dev_hyper, int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern,
                      const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
                      const kge_pull_lists* next_lists, float* loss, hipStream_t s) {
-    const int nv = pull_nv(m->dim);
-    if (!nv) { set_error("kge_pull_step: hidden size %d must be a multiple of 4 and at most 1024", m->dim); return -1; }
+    const PullGeo geo = pull_geo(m->dim);
+    if (!geo.G) { set_error("kge_pull_step: hidden size %d must be a multiple of 4 and at most 1024", m->dim); return -1; }
     PullArgs a;
     for (int i = 0; i < 2; ++i) {
         a.tab_in[i] = m->tables[i]; a.tab_out[i] = tables_out[i];
@@ -519,27 +529,28 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
     const PullSampleArgs sa = make_sample_args(next_pairs, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
                                                n_slots, seed, next_offset, nullptr, next_lists);
     switch (optimizer) {
-        case KGE_OPT_SGD: return launch_pull_opt<KGE_OPT_SGD>(a, sa, nv, loss, s);
-        case KGE_OPT_ADAM: return launch_pull_opt<KGE_OPT_ADAM>(a, sa, nv, loss, s);
-        case KGE_OPT_ADAGRAD: return launch_pull_opt<KGE_OPT_ADAGRAD>(a, sa, nv, loss, s);
-        case KGE_OPT_RMSPROP: return launch_pull_opt<KGE_OPT_RMSPROP>(a, sa, nv, loss, s);
+        case KGE_OPT_SGD: return launch_pull_opt<KGE_OPT_SGD>(a, sa, geo, loss, s);
+        case KGE_OPT_ADAM: return launch_pull_opt<KGE_OPT_ADAM>(a, sa, geo, loss, s);
+        case KGE_OPT_ADAGRAD: return launch_pull_opt<KGE_OPT_ADAGRAD>(a, sa, geo, loss, s);
+        case KGE_OPT_RMSPROP: return launch_pull_opt<KGE_OPT_RMSPROP>(a, sa, geo, loss, s);
     }
     set_error("kge_pull_step: unknown optimizer %d", optimizer);
     return -1;
 }
 
 int launch_row_norms(const float* table, int64_t rows, int dim, float* out, float* hat, hipStream_t s) {
-    const int nv = pull_nv(dim);
-    if (!nv) { set_error("kge_row_norms: row length %d must be a multiple of 4 and at most 1024", dim); return -1; }
+    const PullGeo g = pull_geo(dim);
+    if (!g.G) { set_error("kge_row_norms: row length %d must be a multiple of 4 and at most 1024", dim); return -1; }
     if (rows == 0) return 0;
-    const dim3 grid((unsigned)((rows + kBlock / 32 - 1) / (kBlock / 32)));
-    switch (nv) {
-        case 1: hipLaunchKernelGGL((k_row_norms<32, 1>), grid, dim3(kBlock), 0, s, table, rows, dim, out, hat); break;
-        case 2: hipLaunchKernelGGL((k_row_norms<32, 2>), grid, dim3(kBlock), 0, s, table, rows, dim, out, hat); break;
-        case 4: hipLaunchKernelGGL((k_row_norms<32, 4>), grid, dim3(kBlock), 0, s, table, rows, dim, out, hat); break;
-        default: hipLaunchKernelGGL((k_row_norms<32, 8>), grid, dim3(kBlock), 0, s, table, rows, dim, out, hat); break;
+#define KGE_RN(G_, NV_)                                                                                               \
+    if (g.G == G_ && g.NV == NV_) {                                                                                    \
+        hipLaunchKernelGGL((k_row_norms<G_, NV_>), dim3((unsigned)((rows + kBlock / G_ - 1) / (kBlock / G_))), dim3(kBlock), 0, s, \
+                           table, rows, dim, out, hat);                                                                \
+        return check_launch("k_row_norms");                                                                            \
     }
-    return check_launch("k_row_norms");
+    KGE_RN(16, 1) KGE_RN(16, 2) KGE_RN(32, 1) KGE_RN(32, 2) KGE_RN(32, 4) KGE_RN(32, 8)
+#undef KGE_RN
+    return -1;
 }
 
 int launch_pull_sample(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots,

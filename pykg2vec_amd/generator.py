@@ -49,22 +49,20 @@ def bern_table(prob):
     return p32
 
 
-PULL_GROUPS_PER_BLOCK = 8   # 256-thread workgroups of 32-lane owner groups (csrc/kge_pull.hip)
-
-
-def build_pull_batch(pos, tot_entity, tot_relation, segment):
+def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8):
     """Incidence index of ONE batch for the owner-computes step (csrc/kge_pull.hip): every parameter row (entities first,
     then tot_entity + relation) gets the sorted list of the (pair, role) slots it occupies in the batch -- role 0 = head,
     1 = tail, 2 = relation -- cut into work items of at most `segment` incidences.
 
-    Item kinds: 0 = the row's only item; 3 = one of 2..8 items of a row, all placed in consecutive owner groups of ONE
-    workgroup (they combine their partial sums through LDS, in segment order); 1 / 2 = first / later item of a row with
-    more than 8 items (partial sums through global memory + the finishing kernel).  Items are laid out in workgroup slots
-    (8 per workgroup, padding items have row -1), heaviest workgroups first.
+    Item kinds: 0 = the row's only item; 3 = one of 2..groups_per_block items of a row, all placed in consecutive owner
+    groups of ONE workgroup (they combine their partial sums through LDS, in segment order); 1 / 2 = first / later item
+    of a row with more items than that (partial sums through global memory + the finishing kernel).  Items are laid out
+    in workgroup slots (groups_per_block per workgroup = kge_pull_groups_per_block(dim); padding items have row -1),
+    heaviest workgroups first.
     Returns int32 arrays (pairs [B,4], inc [3B], items [n_slots,4], multi [n_multi,4]) and the number of partial slots."""
     pos = np.asarray(pos, dtype=np.int64).reshape(-1, 3)
     B, E, nrows = len(pos), int(tot_entity), int(tot_entity) + int(tot_relation)
-    GPB = PULL_GROUPS_PER_BLOCK
+    GPB = int(groups_per_block)
     i = np.arange(B, dtype=np.int64)
     rows = np.concatenate([pos[:, 0], pos[:, 2], E + pos[:, 1]])
     vals = np.concatenate([4 * i, 4 * i + 1, 4 * i + 2])
@@ -134,9 +132,9 @@ class PullIndex:
 
     SEGMENT = 8  # incidences per work item: rows with longer lists are cut up and finished by a second small kernel
 
-    def __init__(self, batches, tot_entity, tot_relation, device, segment=None):
+    def __init__(self, batches, tot_entity, tot_relation, device, segment=None, groups_per_block=8):
         seg = int(segment or self.SEGMENT)
-        built = [build_pull_batch(b, tot_entity, tot_relation, seg) for b in batches]
+        built = [build_pull_batch(b, tot_entity, tot_relation, seg, groups_per_block) for b in batches]
         self.n_batches = len(built)
         self.batch_size = len(batches[0]) if built else 0
         self.max_slots = max([x[4] for x in built] + [1])
@@ -202,7 +200,8 @@ class Generator:
             B = self.batch_size
             nb = self.n_train // B
             pos = self._train_np[self._perm_np[:nb * B]].reshape(nb, B, 3)
-            self._pull_index = PullIndex(list(pos), self.config.tot_entity, self.config.tot_relation, self.device)
+            self._pull_index = PullIndex(list(pos), self.config.tot_entity, self.config.tot_relation, self.device,
+                                         groups_per_block=self.K.pull_groups_per_block(self.model.hidden_size))
         return self._pull_index
 
     def __iter__(self):

@@ -410,6 +410,10 @@ def pull_partial_stride(dim):
     return int(L.load().kge_pull_partial_stride(int(dim)))
 
 
+def pull_groups_per_block(dim):
+    return int(L.load().kge_pull_groups_per_block(int(dim)))
+
+
 class PullListSet:
     """One kge_pull_lists set: per-step sampler output of the owner-computes step (count all 0 / head all -1 between steps)."""
 

@@ -326,7 +326,8 @@ class Trainer:
         import numpy as np
         from .generator import PullIndex
         pos = np.stack([x.detach().cpu().numpy() for x in (ph, pr, pt)], 1)
-        idx = PullIndex([pos], self.config.tot_entity, self.config.tot_relation, self.flat.param.device, segment)
+        idx = PullIndex([pos], self.config.tot_entity, self.config.tot_relation, self.flat.param.device, segment,
+                        K.pull_groups_per_block(self.model.hidden_size))
         ps = PullState(self.flat, self.model, len(pos), idx.max_slots)
         ps.sync_in()
         pairs, inc, items, multi = idx.batch(0)

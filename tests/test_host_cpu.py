@@ -213,4 +213,5 @@ def test_pull_plan_struct_layout_matches_the_library():
     assert lib.kge_pull_plan_bytes() == ctypes.sizeof(_lib.PullPlanC)
     assert ctypes.sizeof(_lib.PullBatch) == 56 and ctypes.sizeof(_lib.PullLists) == 40
     assert lib.kge_pull_partial_stride(100) == 128 and lib.kge_pull_partial_stride(102) == 0   # rows move as float4
+    assert lib.kge_pull_groups_per_block(100) in (8, 16) and lib.kge_pull_groups_per_block(1000) == 8
     assert lib.kge_pull_run(None, 0, 1, 0, 0, 0, 1, 0, 0, None) != 0 and b"kge_pull_run" in lib.kge_last_error()
