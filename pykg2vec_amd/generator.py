@@ -133,7 +133,8 @@ class PullIndex:
     SEGMENT = 8  # incidences per work item: rows with longer lists are cut up and finished by a second small kernel
 
     def __init__(self, batches, tot_entity, tot_relation, device, segment=None, groups_per_block=8):
-        seg = int(segment or self.SEGMENT)
+        import os
+        seg = int(segment or os.environ.get("KGE_PULL_SEGMENT") or self.SEGMENT)   # env: tuning sweeps only
         built = [build_pull_batch(b, tot_entity, tot_relation, seg, groups_per_block) for b in batches]
         self.n_batches = len(built)
         self.batch_size = len(batches[0]) if built else 0
