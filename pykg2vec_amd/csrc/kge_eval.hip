@@ -788,10 +788,12 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
 // candidate table sits in the L2s (FB15k TransE: 6 MB), but ComplEx-WN18RR (65 MB), RotatE-FB15k-237 (116 MB) or
 // RESCAL-YAGO3-10 (98 MB) stream from the Infinity Cache / HBM at 5-10 TB/s and the VALUs wait (0.58 of their roof,
 // profiles/r02).  Here the four waves of a workgroup share every candidate chunk through LDS: the workgroup copies a
-// chunk of 2 tiles x KC k x 64 candidates (4 KB) from memory ONCE (one 16-byte load per thread, issued a chunk ahead,
-// double-buffered in LDS, one barrier per chunk) and each wave scores it against ITS OWN 16 queries -- 64 queries per
+// stage of 2 tiles x 32 k x 64 candidates (16 KB) from memory ONCE (four 16-byte loads per thread, issued a whole stage
+// ahead, double-buffered in LDS, one barrier per stage) and each wave scores it against ITS OWN 16 queries -- 64 queries per
 // candidate byte fetched, a quarter of the memory traffic, same VALU work.  The per-(query, candidate) arithmetic is the
 // plain sweep's, operation for operation, so energies stay bit-identical to k_eval_target_filter's.
+constexpr int LDS_SUB = 4;   // k-chunks (of KC) per LDS stage: 2 tiles x 32 k x 64 candidates = 16 KB per stage, 32 KB double-buffered
+
 template <int FORM, bool WRITE, int POST>
 __global__ __launch_bounds__(256) void k_eval_sweep_lds(const float* __restrict__ cand, const float* __restrict__ qvec,
                                                         const float* __restrict__ qscale, const float* __restrict__ st,
@@ -799,9 +801,12 @@ __global__ __launch_bounds__(256) void k_eval_sweep_lds(const float* __restrict_
                                                         int qblocks, int32_t* __restrict__ rcount,
                                                         float* __restrict__ scores_out) {
     constexpr int QT = QT_PLAIN;
-    __shared__ float s_c[2][2][KC][64];   // [buffer][tile of the pair][k][candidate]
+    constexpr int KS = LDS_SUB * KC;            // k per stage
+    __shared__ float s_c[2][LDS_SUB][2][KC][64];   // [buffer][k-chunk][tile of the pair][k][candidate]
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // wave-uniform by construction; readfirstlane tells the compiler, so the query pointers / thresholds / counters stay
+    // in SGPRs and the query elements arrive by s_load as SGPR operands of the VALU ops (as in the plain sweep)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = blockIdx.x & 255;
     const int mm = blockIdx.x >> 8;
     const int ts = mm % S;
@@ -820,7 +825,9 @@ __global__ __launch_bounds__(256) void k_eval_sweep_lds(const float* __restrict_
         qsc[q] = POST == P_SCALE ? qscale[qi] : 1.0f;
         cnt[q] = 0;
     }
-    // staging role of this thread: float4 number threadIdx.x of the chunk = tile (t / 128), k row ((t % 128) / 16), 4 candidates
+    // staging role of this thread inside every k-chunk: float4 number threadIdx.x = tile (t / 128), k row ((t % 128) / 16),
+    // 4 candidates; a stage is LDS_SUB such chunks: LDS_SUB independent 16-byte loads in flight per thread, issued a whole
+    // stage ahead of their use (the memory system needs tens of KB in flight per CU to stream at TB/s)
     const int st_tile = threadIdx.x >> 7, st_k = (threadIdx.x & 127) >> 4, st_c4 = threadIdx.x & 15;
     for (int64_t tile = (int64_t)ts * 2; tile < ntiles; tile += (int64_t)S * 2) {   // the whole workgroup walks the same tile pairs
         const bool has_b = tile + 1 < ntiles;
@@ -829,41 +836,52 @@ __global__ __launch_bounds__(256) void k_eval_sweep_lds(const float* __restrict_
         f32x2 pa[QT], pb[QT];
 #pragma unroll
         for (int q = 0; q < QT; ++q) { acca[q] = 0.f; accb[q] = 0.f; pa[q] = f32x2{0.f, 0.f}; pb[q] = f32x2{0.f, 0.f}; }
-        float4 stage = *reinterpret_cast<const float4*>(src);
+        float4 stage[LDS_SUB];
+#pragma unroll
+        for (int u = 0; u < LDS_SUB; ++u)
+            stage[u] = u * KC < Kpad ? *reinterpret_cast<const float4*>(src + (int64_t)(u * KC) * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
         int buf = 0;
-        for (int k0 = 0; k0 < Kpad; k0 += KC) {
-            *reinterpret_cast<float4*>(&s_c[buf][st_tile][st_k][st_c4 * 4]) = stage;
-            __syncthreads();   // chunk k0 is in LDS; everybody is done reading the buffer written next (two chunks ago)
-            if (k0 + KC < Kpad) stage = *reinterpret_cast<const float4*>(src + (int64_t)(k0 + KC) * 64);
-            f32x2 va[KC / 2], vb[KC / 2];
+        for (int k0 = 0; k0 < Kpad; k0 += KS) {
 #pragma unroll
-            for (int j = 0; j < KC / 2; ++j) {
-                va[j].x = s_c[buf][0][2 * j][lane]; va[j].y = s_c[buf][0][2 * j + 1][lane];
-                vb[j].x = s_c[buf][1][2 * j][lane]; vb[j].y = s_c[buf][1][2 * j + 1][lane];
-            }
+            for (int u = 0; u < LDS_SUB; ++u) *reinterpret_cast<float4*>(&s_c[buf][u][st_tile][st_k][st_c4 * 4]) = stage[u];
+            __syncthreads();   // stage k0 is in LDS; everybody is done reading the buffer written next (two stages ago)
 #pragma unroll
-            for (int q = 0; q < QT; ++q) {
+            for (int u = 0; u < LDS_SUB; ++u)
+                if (k0 + KS + u * KC < Kpad) stage[u] = *reinterpret_cast<const float4*>(src + (int64_t)(k0 + KS + u * KC) * 64);
+#pragma unroll 1
+            for (int u = 0; u < LDS_SUB; ++u) {
+                const int kk = k0 + u * KC;
+                if (kk >= Kpad) break;
+                f32x2 va[KC / 2], vb[KC / 2];
 #pragma unroll
                 for (int j = 0; j < KC / 2; ++j) {
-                    f32x2 qq;
-                    qq.x = qrow[q][k0 + 2 * j];
-                    qq.y = qrow[q][k0 + 2 * j + 1];
-                    if constexpr (FORM == F_NEGDOT) {
-                        pa[q] = __builtin_elementwise_fma(va[j], qq, pa[q]);
-                        pb[q] = __builtin_elementwise_fma(vb[j], qq, pb[q]);
-                    } else if constexpr (FORM == F_L2 || FORM == F_SQM) {
-                        const f32x2 da = va[j] - qq, db = vb[j] - qq;
-                        pa[q] = __builtin_elementwise_fma(da, da, pa[q]);
-                        pb[q] = __builtin_elementwise_fma(db, db, pb[q]);
-                    } else {
-                        pair_step2<FORM>(acca[q], va[j], qq);
-                        pair_step2<FORM>(accb[q], vb[j], qq);
+                    va[j].x = s_c[buf][u][0][2 * j][lane]; va[j].y = s_c[buf][u][0][2 * j + 1][lane];
+                    vb[j].x = s_c[buf][u][1][2 * j][lane]; vb[j].y = s_c[buf][u][1][2 * j + 1][lane];
+                }
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+#pragma unroll
+                    for (int j = 0; j < KC / 2; ++j) {
+                        f32x2 qq;
+                        qq.x = qrow[q][kk + 2 * j];
+                        qq.y = qrow[q][kk + 2 * j + 1];
+                        if constexpr (FORM == F_NEGDOT) {
+                            pa[q] = __builtin_elementwise_fma(va[j], qq, pa[q]);
+                            pb[q] = __builtin_elementwise_fma(vb[j], qq, pb[q]);
+                        } else if constexpr (FORM == F_L2 || FORM == F_SQM) {
+                            const f32x2 da = va[j] - qq, db = vb[j] - qq;
+                            pa[q] = __builtin_elementwise_fma(da, da, pa[q]);
+                            pb[q] = __builtin_elementwise_fma(db, db, pb[q]);
+                        } else {
+                            pair_step2<FORM>(acca[q], va[j], qq);
+                            pair_step2<FORM>(accb[q], vb[j], qq);
+                        }
                     }
                 }
             }
             buf ^= 1;
         }
-        __syncthreads();   // before the next tile pair's first chunk reuses buffer 0
+        __syncthreads();   // before the next tile pair's first stage reuses buffer 0
         if constexpr (FORM != F_L1) {
 #pragma unroll
             for (int q = 0; q < QT; ++q) { acca[q] = pa[q].x + pa[q].y; accb[q] = pb[q].x + pb[q].y; }
