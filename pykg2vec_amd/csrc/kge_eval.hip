@@ -35,6 +35,10 @@ namespace kge {
 constexpr int KC = 8;        // k-chunk held in VGPRs
 constexpr int QT_PLAIN = 16; // queries per wave pass, plain forms
 constexpr int QT_XF = 8;     // ... candidate-transform forms (TransH / TransD)
+#ifndef KGE_QGRP
+#define KGE_QGRP 4
+#endif
+constexpr int QGRP = KGE_QGRP;      // queries whose scalar operands are live together in the packed-FMA forms
 
 enum Form { F_L1 = 0, F_L2 = 1, F_SQM = 2, F_NEGDOT = 3 };
 enum XForm { X_NONE = 0, X_TRANSH = 1, X_TRANSD = 2 };
@@ -654,13 +658,17 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
             f32x2 pa[QT], pb[QT];  // NEGDOT: packed even/odd-k accumulators
 #pragma unroll
             for (int q = 0; q < QT; ++q) { acca[q] = 0.f; accb[q] = 0.f; pa[q] = f32x2{0.f, 0.f}; pb[q] = f32x2{0.f, 0.f}; }
-            for (int k0 = 0; k0 < Kpad; k0 += KC) {
-                f32x2 va[KC / 2], vb[KC / 2];
+            // candidate chunk k0 + KC is requested before chunk k0 is evaluated (two register buffers, loop unrolled by
+            // two): with the table in the Infinity Cache / HBM a load takes far longer than the ~600 cycles of arithmetic on
+            // one chunk, and the compiler does not pipeline this loop by itself
+            auto load_chunk = [&](int k0, f32x2 (&va)[KC / 2], f32x2 (&vb)[KC / 2]) {
 #pragma unroll
                 for (int j = 0; j < KC / 2; ++j) {
                     va[j].x = ca[(int64_t)(k0 + 2 * j) * 64]; va[j].y = ca[(int64_t)(k0 + 2 * j + 1) * 64];
                     vb[j].x = cb[(int64_t)(k0 + 2 * j) * 64]; vb[j].y = cb[(int64_t)(k0 + 2 * j + 1) * 64];
                 }
+            };
+            auto eval_chunk = [&](int k0, const f32x2 (&va)[KC / 2], const f32x2 (&vb)[KC / 2]) {
 #pragma unroll
                 for (int q = 0; q < QT; ++q) {
 #pragma unroll
@@ -679,6 +687,19 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                             pair_step2<FORM>(acca[q], va[j], qq);
                             pair_step2<FORM>(accb[q], vb[j], qq);
                         }
+                    }
+                }
+            };
+            {
+                f32x2 va0[KC / 2], vb0[KC / 2], va1[KC / 2], vb1[KC / 2];
+                load_chunk(0, va0, vb0);
+                for (int k0 = 0; k0 < Kpad; k0 += 2 * KC) {
+                    const bool more = k0 + KC < Kpad;
+                    if (more) load_chunk(k0 + KC, va1, vb1);
+                    eval_chunk(k0, va0, vb0);
+                    if (more) {
+                        if (k0 + 2 * KC < Kpad) load_chunk(k0 + 2 * KC, va0, vb0);
+                        eval_chunk(k0 + KC, va1, vb1);
                     }
                 }
             }
