@@ -28,17 +28,12 @@
 // Roofline: algorithmic bytes = candidate row bytes per scored candidate (400 B for TransE d=100); with QT-fold
 // reuse the kernel is VALU-bound (2 lane-ops per element per pair for L1), not HBM-bound.
 #include "kge_internal.h"
-#include <stdlib.h>
 
 namespace kge {
 
 constexpr int KC = 8;        // k-chunk held in VGPRs
 constexpr int QT_PLAIN = 16; // queries per wave pass, plain forms
 constexpr int QT_XF = 8;     // ... candidate-transform forms (TransH / TransD)
-#ifndef KGE_QGRP
-#define KGE_QGRP 4
-#endif
-constexpr int QGRP = KGE_QGRP;      // queries whose scalar operands are live together in the packed-FMA forms
 
 enum Form { F_L1 = 0, F_L2 = 1, F_SQM = 2, F_NEGDOT = 3 };
 enum XForm { X_NONE = 0, X_TRANSH = 1, X_TRANSD = 2 };
@@ -658,17 +653,13 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
             f32x2 pa[QT], pb[QT];  // NEGDOT: packed even/odd-k accumulators
 #pragma unroll
             for (int q = 0; q < QT; ++q) { acca[q] = 0.f; accb[q] = 0.f; pa[q] = f32x2{0.f, 0.f}; pb[q] = f32x2{0.f, 0.f}; }
-            // candidate chunk k0 + KC is requested before chunk k0 is evaluated (two register buffers, loop unrolled by
-            // two): with the table in the Infinity Cache / HBM a load takes far longer than the ~600 cycles of arithmetic on
-            // one chunk, and the compiler does not pipeline this loop by itself
-            auto load_chunk = [&](int k0, f32x2 (&va)[KC / 2], f32x2 (&vb)[KC / 2]) {
+            for (int k0 = 0; k0 < Kpad; k0 += KC) {
+                f32x2 va[KC / 2], vb[KC / 2];
 #pragma unroll
                 for (int j = 0; j < KC / 2; ++j) {
                     va[j].x = ca[(int64_t)(k0 + 2 * j) * 64]; va[j].y = ca[(int64_t)(k0 + 2 * j + 1) * 64];
                     vb[j].x = cb[(int64_t)(k0 + 2 * j) * 64]; vb[j].y = cb[(int64_t)(k0 + 2 * j + 1) * 64];
                 }
-            };
-            auto eval_chunk = [&](int k0, const f32x2 (&va)[KC / 2], const f32x2 (&vb)[KC / 2]) {
 #pragma unroll
                 for (int q = 0; q < QT; ++q) {
 #pragma unroll
@@ -687,19 +678,6 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                             pair_step2<FORM>(acca[q], va[j], qq);
                             pair_step2<FORM>(accb[q], vb[j], qq);
                         }
-                    }
-                }
-            };
-            {
-                f32x2 va0[KC / 2], vb0[KC / 2], va1[KC / 2], vb1[KC / 2];
-                load_chunk(0, va0, vb0);
-                for (int k0 = 0; k0 < Kpad; k0 += 2 * KC) {
-                    const bool more = k0 + KC < Kpad;
-                    if (more) load_chunk(k0 + KC, va1, vb1);
-                    eval_chunk(k0, va0, vb0);
-                    if (more) {
-                        if (k0 + 2 * KC < Kpad) load_chunk(k0 + 2 * KC, va0, vb0);
-                        eval_chunk(k0 + KC, va1, vb1);
                     }
                 }
             }
@@ -804,134 +782,6 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
     }
 }
 
-// ------------------------------------------------------------------ 4b. the sweep for LONG candidate tables (LDS-staged)
-// With 16 queries per candidate load the plain sweep needs 1/16 of its operand stream from memory: fine while the
-// candidate table sits in the L2s (FB15k TransE: 6 MB), but ComplEx-WN18RR (65 MB), RotatE-FB15k-237 (116 MB) or
-// RESCAL-YAGO3-10 (98 MB) stream from the Infinity Cache / HBM at 5-10 TB/s and the VALUs wait (0.58 of their roof,
-// profiles/r02).  Here the four waves of a workgroup share every candidate chunk through LDS: the workgroup copies a
-// stage of 2 tiles x 32 k x 64 candidates (16 KB) from memory ONCE (four 16-byte loads per thread, issued a whole stage
-// ahead, double-buffered in LDS, one barrier per stage) and each wave scores it against ITS OWN 16 queries -- 64 queries per
-// candidate byte fetched, a quarter of the memory traffic, same VALU work.  The per-(query, candidate) arithmetic is the
-// plain sweep's, operation for operation, so energies stay bit-identical to k_eval_target_filter's.
-constexpr int LDS_SUB = 4;   // k-chunks (of KC) per LDS stage: 2 tiles x 32 k x 64 candidates = 16 KB per stage, 32 KB double-buffered
-
-template <int FORM, bool WRITE, int POST>
-__global__ __launch_bounds__(256) void k_eval_sweep_lds(const float* __restrict__ cand, const float* __restrict__ qvec,
-                                                        const float* __restrict__ qscale, const float* __restrict__ st,
-                                                        int64_t nq, int64_t E, int64_t ntiles, int Kpad, float margin, int S,
-                                                        int qblocks, int32_t* __restrict__ rcount,
-                                                        float* __restrict__ scores_out) {
-    constexpr int QT = QT_PLAIN;
-    constexpr int KS = LDS_SUB * KC;            // k per stage
-    __shared__ float s_c[2][LDS_SUB][2][KC][64];   // [buffer][k-chunk][tile of the pair][k][candidate]
-    const int lane = threadIdx.x & 63;
-    // wave-uniform by construction; readfirstlane tells the compiler, so the query pointers / thresholds / counters stay
-    // in SGPRs and the query elements arrive by s_load as SGPR operands of the VALU ops (as in the plain sweep)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x & 255;
-    const int mm = blockIdx.x >> 8;
-    const int ts = mm % S;
-    const int qb = (mm / S) * 256 + slot;   // block of 4 x QT queries
-    if (qb >= qblocks) return;
-    const int64_t q0 = (int64_t)qb * (4 * QT) + wave * QT;
-    const float* qrow[QT];
-    float sthr[QT];
-    float qsc[QT];
-    int cnt[QT];
-#pragma unroll
-    for (int q = 0; q < QT; ++q) {
-        const int64_t qi = (q0 + q < nq) ? q0 + q : nq - 1;
-        qrow[q] = qvec + qi * (int64_t)Kpad;
-        sthr[q] = WRITE ? 0.f : st[qi];
-        qsc[q] = POST == P_SCALE ? qscale[qi] : 1.0f;
-        cnt[q] = 0;
-    }
-    // staging role of this thread inside every k-chunk: float4 number threadIdx.x = tile (t / 128), k row ((t % 128) / 16),
-    // 4 candidates; a stage is LDS_SUB such chunks: LDS_SUB independent 16-byte loads in flight per thread, issued a whole
-    // stage ahead of their use (the memory system needs tens of KB in flight per CU to stream at TB/s)
-    const int st_tile = threadIdx.x >> 7, st_k = (threadIdx.x & 127) >> 4, st_c4 = threadIdx.x & 15;
-    for (int64_t tile = (int64_t)ts * 2; tile < ntiles; tile += (int64_t)S * 2) {   // the whole workgroup walks the same tile pairs
-        const bool has_b = tile + 1 < ntiles;
-        const float* src = cand + ((tile + ((st_tile && has_b) ? 1 : 0)) * Kpad + st_k) * 64 + st_c4 * 4;
-        float acca[QT], accb[QT];
-        f32x2 pa[QT], pb[QT];
-#pragma unroll
-        for (int q = 0; q < QT; ++q) { acca[q] = 0.f; accb[q] = 0.f; pa[q] = f32x2{0.f, 0.f}; pb[q] = f32x2{0.f, 0.f}; }
-        float4 stage[LDS_SUB];
-#pragma unroll
-        for (int u = 0; u < LDS_SUB; ++u)
-            stage[u] = u * KC < Kpad ? *reinterpret_cast<const float4*>(src + (int64_t)(u * KC) * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
-        int buf = 0;
-        for (int k0 = 0; k0 < Kpad; k0 += KS) {
-#pragma unroll
-            for (int u = 0; u < LDS_SUB; ++u) *reinterpret_cast<float4*>(&s_c[buf][u][st_tile][st_k][st_c4 * 4]) = stage[u];
-            __syncthreads();   // stage k0 is in LDS; everybody is done reading the buffer written next (two stages ago)
-#pragma unroll
-            for (int u = 0; u < LDS_SUB; ++u)
-                if (k0 + KS + u * KC < Kpad) stage[u] = *reinterpret_cast<const float4*>(src + (int64_t)(k0 + KS + u * KC) * 64);
-#pragma unroll 1
-            for (int u = 0; u < LDS_SUB; ++u) {
-                const int kk = k0 + u * KC;
-                if (kk >= Kpad) break;
-                f32x2 va[KC / 2], vb[KC / 2];
-#pragma unroll
-                for (int j = 0; j < KC / 2; ++j) {
-                    va[j].x = s_c[buf][u][0][2 * j][lane]; va[j].y = s_c[buf][u][0][2 * j + 1][lane];
-                    vb[j].x = s_c[buf][u][1][2 * j][lane]; vb[j].y = s_c[buf][u][1][2 * j + 1][lane];
-                }
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
-#pragma unroll
-                    for (int j = 0; j < KC / 2; ++j) {
-                        f32x2 qq;
-                        qq.x = qrow[q][kk + 2 * j];
-                        qq.y = qrow[q][kk + 2 * j + 1];
-                        if constexpr (FORM == F_NEGDOT) {
-                            pa[q] = __builtin_elementwise_fma(va[j], qq, pa[q]);
-                            pb[q] = __builtin_elementwise_fma(vb[j], qq, pb[q]);
-                        } else if constexpr (FORM == F_L2 || FORM == F_SQM) {
-                            const f32x2 da = va[j] - qq, db = vb[j] - qq;
-                            pa[q] = __builtin_elementwise_fma(da, da, pa[q]);
-                            pb[q] = __builtin_elementwise_fma(db, db, pb[q]);
-                        } else {
-                            pair_step2<FORM>(acca[q], va[j], qq);
-                            pair_step2<FORM>(accb[q], vb[j], qq);
-                        }
-                    }
-                }
-            }
-            buf ^= 1;
-        }
-        __syncthreads();   // before the next tile pair's first stage reuses buffer 0
-        if constexpr (FORM != F_L1) {
-#pragma unroll
-            for (int q = 0; q < QT; ++q) { acca[q] = pa[q].x + pa[q].y; accb[q] = pb[q].x + pb[q].y; }
-        }
-        const int64_t ea = tile * 64 + lane, eb = ea + 64;
-        const bool valid_a = ea < E, valid_b = has_b && eb < E;
-#pragma unroll
-        for (int q = 0; q < QT; ++q) {
-            const float sa = pair_post<POST>(pair_finish<FORM>(acca[q], margin), qsc[q]);
-            const float sb = pair_post<POST>(pair_finish<FORM>(accb[q], margin), qsc[q]);
-            if constexpr (WRITE) {
-                if (q0 + q < nq) {
-                    if (valid_a) scores_out[(q0 + q) * E + ea] = sa;
-                    if (valid_b) scores_out[(q0 + q) * E + eb] = sb;
-                }
-            } else {
-                cnt[q] += __popcll(__ballot(valid_a && sa < sthr[q])) + __popcll(__ballot(valid_b && sb < sthr[q]));
-            }
-        }
-    }
-    if constexpr (!WRITE) {
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < QT; ++q)
-                if (q0 + q < nq && cnt[q] != 0) atomicAdd(rcount + q0 + q, cnt[q]);
-        }
-    }
-}
-
 __global__ void k_eval_finalize(const int32_t* __restrict__ rcount, const int32_t* __restrict__ fcount, int64_t n,
                                 int32_t* __restrict__ ranks) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1001,15 +851,6 @@ static void fill_prep(const kge_model_desc* m, const EvalPlan& p, PrepArgs* a) {
     }
 }
 
-// The LDS-staged sweep pays when the candidate table does not fit the L2s (4 MB per XCD, 32 MB aggregate) and there are
-// enough queries to fill 64-query workgroups; KGE_EVAL_LDS=0 / 1 forces the choice (A/B runs).
-static bool use_lds_sweep(const EvalPlan& p, int64_t nq) {
-    const char* force = getenv("KGE_EVAL_LDS");
-    if (force) return force[0] == '1';
-    const size_t table_bytes = (size_t)p.ntiles * p.Kpad * 64 * sizeof(float);
-    return table_bytes > ((size_t)24 << 20) && nq >= 256;
-}
-
 template <int FORM, int XFORM, int POST = P_NONE>
 static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, const int64_t* triples,
                                 const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
@@ -1031,25 +872,6 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
         hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM, POST>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p.cand,
                            p.aux, p.qvec, p.qscale, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids, head_off, head_ids,
                            p.st, p.fcount, group_of_triple, p.table_stride);
-    if constexpr (XFORM == X_NONE) {
-        // candidate tables beyond what the L2s hold: the LDS-staged sweep (64 queries per candidate byte fetched)
-        if (qdesc == nullptr && use_lds_sweep(p, nq)) {
-            const int qblocks64 = (int)((nq + 4 * QT - 1) / (4 * QT));
-            const int64_t qg = (qblocks64 + 255) / 256;
-            int64_t S2 = (8 * 256 + qblocks64 - 1) / qblocks64;   // aim at >= 8 workgroups per CU in flight
-            const int64_t max_split2 = (p.ntiles + 1) / 2;
-            if (S2 > max_split2) S2 = max_split2;
-            if (S2 < 1) S2 = 1;
-            const unsigned grid2 = (unsigned)(qg * 256 * S2);
-            if (scores_out == nullptr)
-                hipLaunchKernelGGL((k_eval_sweep_lds<FORM, false, POST>), dim3(grid2), dim3(256), 0, s, p.cand, p.qvec, p.qscale,
-                                   p.st, nq, p.E, p.ntiles, p.Kpad, m->margin, (int)S2, qblocks64, p.rcount, nullptr);
-            else
-                hipLaunchKernelGGL((k_eval_sweep_lds<FORM, true, POST>), dim3(grid2), dim3(256), 0, s, p.cand, p.qvec, p.qscale,
-                                   p.st, nq, p.E, p.ntiles, p.Kpad, m->margin, (int)S2, qblocks64, p.rcount, scores_out);
-            return;
-        }
-    }
     if (scores_out == nullptr) {
         hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, false, POST>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec,
                            p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, nullptr,

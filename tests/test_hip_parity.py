@@ -636,32 +636,3 @@ def test_fused_sampler_steps_with_bern_probabilities(hip, name):
     assert np.isclose(res[0][0], res[1][0], rtol=1e-5)
     for a, b in zip(res[0][1], res[1][1]):
         assert np.allclose(a, b, atol=1e-5, rtol=1e-4)
-
-
-@pytest.mark.parametrize("name", ["transe_l1", "transe_l2", "rotate", "complex", "distmult", "rescal", "analogy", "cp", "simple",
-                                  "quate", "transm_l1"])
-def test_lds_staged_sweep_is_bit_identical_to_the_plain_sweep(hip, name, monkeypatch):
-    """k_eval_sweep_lds (long candidate tables: four waves share each candidate chunk through LDS) runs the plain sweep's
-    arithmetic operation for operation: forced on for the small golden tables, it must reproduce the plain sweep's
-    energies bit for bit and therefore its integer ranks exactly."""
-    from pykg2vec_amd import kernels as K
-    from pykg2vec_amd.evaluator import Evaluator
-    c = Case(name)
-    m = hip.model_from_case(c, "adam.final.")
-    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test)
-    if c.model == "rescal":
-        m.normalize_tables()
-    # enough queries for several 64-query workgroups: the test triples, tiled
-    trips = np.concatenate([c.test] * 6)[:200]
-    out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("KGE_EVAL_LDS", flag)
-        scores = K.eval_sweep_scores(m.make_desc(), hip.dev(trips)).cpu().numpy()
-        cfg2 = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, trips)
-        ranks = Evaluator(m, cfg2).rank_all(trips, len(trips)).cpu().numpy()
-        out[flag] = (scores, ranks)
-    if c.model == "rescal":   # its evaluation renormalises the tables in place on every call (pairwise.py:843-844)
-        assert np.allclose(out["0"][0], out["1"][0], atol=1e-6, rtol=1e-5)
-        return
-    assert np.array_equal(out["0"][0], out["1"][0])
-    assert np.array_equal(out["0"][1], out["1"][1])
