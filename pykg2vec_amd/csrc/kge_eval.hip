@@ -28,6 +28,7 @@
 // Roofline: algorithmic bytes = candidate row bytes per scored candidate (400 B for TransE d=100); with QT-fold
 // reuse the kernel is VALU-bound (2 lane-ops per element per pair for L1), not HBM-bound.
 #include "kge_internal.h"
+#include <stdlib.h>
 
 namespace kge {
 
@@ -46,6 +47,7 @@ struct EvalPlan {
     int K, Kpad, QV, form, xform, post;
     int64_t ntiles;
     float* cand; float* aux; float* qvec; float* qscale; float* st; int32_t* fcount; int32_t* rcount;
+    float* qT;   // dot-product forms: the queries as k-major 128-wide tiles (matrix-core sweep)
     size_t bytes;
 };
 
@@ -89,6 +91,9 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p,
     p->st = (float*)take((size_t)2 * n * sizeof(float));
     p->fcount = (int32_t*)take((size_t)2 * n * sizeof(int32_t));
     p->rcount = (int32_t*)take((size_t)2 * n * sizeof(int32_t));
+    p->qT = nullptr;
+    if (p->form == F_NEGDOT && p->xform == X_NONE)
+        p->qT = (float*)take((size_t)((2 * n + 127) / 128) * p->Kpad * 128 * sizeof(float));
     p->bytes = off;
     return true;
 }
@@ -469,13 +474,26 @@ __device__ __forceinline__ float pair_post(float s, float scale) {
     else return s;
 }
 
-// full sequential score of one (query, candidate) pair by ONE lane (target / filter path)
-template <int FORM, int XFORM, int POST>
+// full sequential score of one (query, candidate) pair by ONE lane (target / filter path).  CHAIN: the dot product as
+// ONE fmaf chain over k -- the order v_mfma_f32_32x32x2_f32 accumulates in (k_eval_gemm) -- instead of the packed sweep's
+// even / odd split.
+template <int FORM, int XFORM, int POST, bool CHAIN = false>
 __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand, const float* __restrict__ aux,
                                                  const float* __restrict__ q, int64_t e, int Kpad, float margin,
                                                  float scale) {
     const float* c = cand + ((e >> 6) * Kpad) * 64 + (e & 63);
     float acc = 0.f;
+    if constexpr (CHAIN) {
+        static_assert(!CHAIN || (FORM == F_NEGDOT && XFORM == X_NONE), "chain order: plain dot-product form only");
+        for (int k0 = 0; k0 < Kpad; k0 += KC) {
+            float cv[KC], qv[KC];
+#pragma unroll
+            for (int j = 0; j < KC; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; qv[j] = q[k0 + j]; }
+#pragma unroll
+            for (int j = 0; j < KC; ++j) acc = fmaf(cv[j], qv[j], acc);
+        }
+        return pair_post<POST>(pair_finish<FORM>(acc, margin), scale);
+    }
     // candidate / query elements are fetched KC at a time BEFORE the dependent accumulation chain (one memory round trip
     // per KC elements instead of one per element); the accumulation order is unchanged
     if constexpr (XFORM == X_NONE && FORM != F_L1) {
@@ -547,7 +565,7 @@ __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand,
 }
 
 // ------------------------------------------------------------------ 3. target score + filtered count
-template <int FORM, int XFORM, int POST>
+template <int FORM, int XFORM, int POST, bool CHAIN = false>
 __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restrict__ cand, const float* __restrict__ aux,
                                                             const float* __restrict__ qvec, const float* __restrict__ qscale,
                                                             const int64_t* __restrict__ triples,
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
     const float* q = qvec + qi * (int64_t)QV * Kpad;
     const float scale = POST == P_SCALE ? qscale[qi] : 1.0f;
     float s_true = 0.f;
-    if (lane == 0) s_true = pair_score_lane<FORM, XFORM, POST>(cand, aux, q, truth, Kpad, margin, scale);
+    if (lane == 0) s_true = pair_score_lane<FORM, XFORM, POST, CHAIN>(cand, aux, q, truth, Kpad, margin, scale);
     s_true = __shfl(s_true, 0, 64);
     const int64_t* off = side == 0 ? tail_off : head_off;
     const int32_t* ids = side == 0 ? tail_ids : head_ids;
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
         for (int64_t j = b + lane; j < e_; j += 64) {
             const int64_t e = ids[j];
             if (e != truth) {
-                const float s = pair_score_lane<FORM, XFORM, POST>(cand, aux, q, e, Kpad, margin, scale);
+                const float s = pair_score_lane<FORM, XFORM, POST, CHAIN>(cand, aux, q, e, Kpad, margin, scale);
                 cnt += (s < s_true) ? 1 : 0;
             }
         }
@@ -782,6 +800,141 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
     }
 }
 
+// ------------------------------------------------------------------ 4b. the dot-product sweep on the matrix cores
+// DistMult / ComplEx / ANALOGY / RESCAL / CP / SimplE / QuatE rank by s(q, e) = -<q, c_e>: a [candidates x K] x [K x queries]
+// GEMM.  The VALU sweep feeds every packed FMA one scalar operand pair and re-reads each candidate chunk once per 16
+// queries; with K = 400 .. 2000 its operand streams (candidates AND queries) come from the Infinity Cache and it stalls at
+// ~0.58 of its issue roof (profiles/r02_experiments.md).  Here a workgroup holds a 128-query x 128-candidate tile of
+// accumulators on the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 157 TF peak), both operands staged through
+// LDS in 16-deep K slabs (one 16-byte load per operand float4, issued a slab ahead, double-buffered, one barrier per
+// slab): 64 FMAs per operand float fetched instead of 16.  Candidates are the M side, so every lane owns ONE query column
+// and the count epilogue needs one threshold and one counter per lane and column block.  The fp32 result of an MFMA chain
+// is bit-identical to one fmaf chain over k, which is the order k_eval_target_filter<CHAIN> uses for s(q, true): integer
+// ranks stay exact functions of the fp32 energies.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int GT = 128;      // tile edge (queries and candidates) per workgroup
+constexpr int GKS = 16;      // K slab
+constexpr int GLD = GT + 4;  // LDS row length (k-major tiles: [k][GT + pad])
+
+// queries [nq][Kpad] -> k-major tiles qT[tile][k][GT] (zero rows beyond nq): the layout the candidate table already has
+__global__ __launch_bounds__(256) void k_eval_qt(const float* __restrict__ qvec, int64_t nq, int Kpad, float* __restrict__ qT) {
+    __shared__ float s_t[64][65];
+    const int64_t q0 = (int64_t)blockIdx.x * 64;   // 64 queries x 64 k per block
+    const int k0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t q = q0 + r;
+        s_t[r][tx] = (q < nq && k0 + tx < Kpad) ? qvec[q * Kpad + k0 + tx] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int k = k0 + r;
+        const int64_t q = q0 + tx;
+        if (k < Kpad) qT[((q / GT) * Kpad + k) * GT + (q % GT)] = s_t[tx][r];
+    }
+}
+
+template <bool WRITE, int POST>
+__global__ __launch_bounds__(256) void k_eval_gemm(const float* __restrict__ cand, const float* __restrict__ qT,
+                                                   const float* __restrict__ st, int64_t nq, int64_t E, int64_t ntiles64,
+                                                   int Kpad, int qtiles, int S, int32_t* __restrict__ rcount,
+                                                   float* __restrict__ scores_out) {
+    __shared__ float sA[2][GKS][GLD], sB[2][GKS][GLD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;   // wave's 64 x 64 sub-tile: candidate rows wr, query columns wc
+    const int qt = blockIdx.x % qtiles, sp = blockIdx.x / qtiles;
+    const int64_t ctiles = (ntiles64 + 1) / 2;   // 128-candidate tiles
+    // staging role: float4 number t + 256 j of a slab = (k = idx / 32, 4 columns at 4 * (idx % 32))
+    int sk[2], sc4[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int idx = threadIdx.x + 256 * j; sk[j] = idx >> 5; sc4[j] = idx & 31; }
+    const float* qsrc = qT + (int64_t)qt * Kpad * GT;
+    float thr[2];
+    int cnt[2] = {0, 0};
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 32 + li;
+        thr[ni] = (!WRITE && q < nq) ? st[q] : 0.f;
+    }
+    const int nslab = Kpad / GKS + ((Kpad % GKS) ? 1 : 0);
+    for (int64_t ct = sp; ct < ctiles; ct += S) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x16{0};
+        // candidate slab source: two 64-candidate tiles of the sweep layout side by side
+        const float* asrc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int64_t t64 = ct * 2 + (sc4[j] >> 4);
+            if (t64 >= ntiles64) t64 = ntiles64 - 1;   // odd tile count: the duplicate rows are masked in the epilogue
+            asrc[j] = cand + (t64 * Kpad + sk[j]) * 64 + (sc4[j] & 15) * 4;
+        }
+        float4 ra[2], rb[2];
+        auto load_slab = [&](int sl) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = sl * GKS + sk[j];
+                const bool live = k < Kpad;
+                ra[j] = live ? *reinterpret_cast<const float4*>(asrc[j] + (int64_t)(sl * GKS) * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[j] = live ? *reinterpret_cast<const float4*>(qsrc + (int64_t)k * GT + sc4[j] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        load_slab(0);
+        int buf = 0;
+        for (int sl = 0; sl < nslab; ++sl) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                *reinterpret_cast<float4*>(&sA[buf][sk[j]][sc4[j] * 4]) = ra[j];
+                *reinterpret_cast<float4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
+            }
+            __syncthreads();   // slab sl is in LDS; everybody finished reading the buffer that is written next
+            if (sl + 1 < nslab) load_slab(sl + 1);
+#pragma unroll
+            for (int kk = 0; kk < GKS; kk += 2) {
+                const float a0 = sA[buf][kk + lk][wr * 64 + li], a1 = sA[buf][kk + lk][wr * 64 + 32 + li];
+                const float b0 = sB[buf][kk + lk][wc * 64 + li], b1 = sB[buf][kk + lk][wc * 64 + 32 + li];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+        __syncthreads();   // before the next candidate tile's first slab reuses buffer 0
+        // epilogue: energy = -dot (+ post-op); lane owns query column (ni, li), its 16 registers are candidate rows
+        const int64_t e_base = ct * GT + wr * 64;
+        const bool full = ct * GT + GT <= E && (ct * 2 + 1 < ntiles64);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 32 + li;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int64_t e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                    const float sc = pair_post<POST>(-acc[mi][ni][reg], 1.0f);
+                    if constexpr (WRITE) {
+                        if (q < nq && e < E && (full || (e >> 6) < ntiles64)) scores_out[q * E + e] = sc;
+                    } else {
+                        const bool hit = sc < thr[ni];
+                        cnt[ni] += full ? (hit ? 1 : 0) : ((hit && e < E) ? 1 : 0);
+                    }
+                }
+            }
+    }
+    if constexpr (!WRITE) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int c2 = cnt[ni] + __shfl_xor(cnt[ni], 32, 64);   // the two lanes that own the same query column
+            const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 32 + li;
+            if (lk == 0 && q < nq && c2 != 0) atomicAdd(rcount + q, c2);
+        }
+    }
+}
+
 __global__ void k_eval_finalize(const int32_t* __restrict__ rcount, const int32_t* __restrict__ fcount, int64_t n,
                                 int32_t* __restrict__ ranks) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -851,6 +1004,14 @@ static void fill_prep(const kge_model_desc* m, const EvalPlan& p, PrepArgs* a) {
     }
 }
 
+// Dot-product forms go to the matrix cores when there are enough queries to fill 128-wide tiles; KGE_EVAL_GEMM=0 / 1 forces
+// the choice (A/B runs).
+static bool use_gemm_sweep(const EvalPlan& p, int64_t nq) {
+    const char* force = getenv("KGE_EVAL_GEMM");
+    if (force) return force[0] == '1';
+    return nq >= 512 && p.Kpad >= 32;
+}
+
 template <int FORM, int XFORM, int POST = P_NONE>
 static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, const int64_t* triples,
                                 const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
@@ -868,6 +1029,28 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
     if (S > max_split) S = max_split;
     if (S < 1) S = 1;
     const unsigned grid = (unsigned)(qgroups * 256 * S);
+    if constexpr (FORM == F_NEGDOT && XFORM == X_NONE && POST != P_SCALE) {
+        if (qdesc == nullptr && p.qT != nullptr && use_gemm_sweep(p, nq)) {   // the dot-product sweep on the matrix cores
+            const int qtiles = (int)((nq + GT - 1) / GT);
+            const int64_t ctiles = (p.ntiles + 1) / 2;
+            int64_t S2 = (4 * 256 + qtiles - 1) / qtiles;   // >= 4 workgroups per CU in flight
+            if (S2 > ctiles) S2 = ctiles;
+            if (S2 < 1) S2 = 1;
+            hipLaunchKernelGGL(k_eval_qt, dim3((unsigned)(qtiles * 2), (unsigned)((p.Kpad + 63) / 64)), dim3(256), 0, s, p.qvec, nq,
+                               p.Kpad, p.qT);
+            if (scores_out == nullptr) {
+                hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM, POST, true>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s,
+                                   p.cand, p.aux, p.qvec, p.qscale, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids,
+                                   head_off, head_ids, p.st, p.fcount, group_of_triple, p.table_stride);
+                hipLaunchKernelGGL((k_eval_gemm<false, POST>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
+                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, nullptr);
+            } else {
+                hipLaunchKernelGGL((k_eval_gemm<true, POST>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
+                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, scores_out);
+            }
+            return;
+        }
+    }
     if (scores_out == nullptr)
         hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM, POST>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p.cand,
                            p.aux, p.qvec, p.qscale, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids, head_off, head_ids,

@@ -636,3 +636,61 @@ def test_fused_sampler_steps_with_bern_probabilities(hip, name):
     assert np.isclose(res[0][0], res[1][0], rtol=1e-5)
     for a, b in zip(res[0][1], res[1][1]):
         assert np.allclose(a, b, atol=1e-5, rtol=1e-4)
+
+
+GEMM_CASES = ["distmult", "complex", "complexn3", "analogy", "rescal", "cp", "simple", "simple_ignr", "quate"]
+
+
+@pytest.mark.parametrize("name", GEMM_CASES)
+def test_matrix_core_sweep_scores_and_ranks(hip, name, monkeypatch):
+    """k_eval_gemm (the dot-product sweep on the f32 matrix cores), forced on for the small golden tables: energies within
+    the fp32 tolerance of the live reference's, integer ranks EXACT functions of the kernel's own energies (the target
+    energy comes from k_eval_target_filter<CHAIN>, which must round like the MFMA chain), and ranks against the
+    reference inside the score band."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.evaluator import Evaluator
+    monkeypatch.setenv("KGE_EVAL_GEMM", "1")
+    c = Case(name)
+    m = hip.model_from_case(c, "adam.final.")
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test)
+    if c.model == "rescal":
+        m.normalize_tables()
+    sw = K.eval_sweep_scores(m.make_desc(), hip.dev(c.test[:4])).cpu().numpy()
+    assert close(sw, c.z["eval.sweeps"], atol=2e-5, rtol=2e-5), np.abs(sw - c.z["eval.sweeps"]).max()
+    n = len(c.z["eval.rank_head"])
+    ranks = Evaluator(m, cfg).rank_all(c.test, n).cpu().numpy()
+    scores = K.eval_sweep_scores(m.make_desc(), hip.dev(c.test[:n])).cpu().numpy()
+    hr_t, tr_h = c.filters()
+    for i, (h, r, t) in enumerate(c.test[:n]):
+        rt = ko.rank_from_scores(scores[2 * i], int(t), hr_t[(int(h), int(r))])
+        rh = ko.rank_from_scores(scores[2 * i + 1], int(h), tr_h[(int(t), int(r))])
+        assert (ranks[1, i], ranks[3, i]) == rt and (ranks[0, i], ranks[2, i]) == rh, (i, ranks[:, i], rt, rh)
+    ref = np.stack([c.z["eval.rank_head"], c.z["eval.rank_tail"], c.z["eval.frank_head"], c.z["eval.frank_tail"]])
+    assert_ranks_inside_band(name + "_gemm", ranks, ref, scores, c.test[:n])
+
+
+@pytest.mark.parametrize("model,E,d", [("distmult", 333, 100), ("complex", 1000, 36), ("distmult", 129, 8)])
+def test_matrix_core_sweep_equals_vector_sweep_ranks_on_ragged_shapes(hip, model, E, d, monkeypatch):
+    """Odd numbers of 64-candidate tiles, partial last tiles, query counts that are not multiples of 128: ranks from the
+    matrix-core sweep are exact functions of its energies, and agree with the VALU sweep's up to fp32 near-ties."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.evaluator import Evaluator
+    rng = np.random.default_rng(11)
+    R, n = 5, 333
+    P = ko.init_params(model, rng, tot_entity=E, tot_relation=R, hidden_size=d)
+    trip = np.stack([rng.integers(E, size=n + 600), rng.integers(R, size=n + 600), rng.integers(E, size=n + 600)], 1)
+    hp = dict(hidden_size=d, lmbda=0.01)
+    cfg = hip.make_config(E, R, hp, trip[n:], trip[:8], trip[:n])
+    m = hip.model_from_params(model, P, hp, E, R)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("KGE_EVAL_GEMM", flag)
+        out[flag] = (Evaluator(m, cfg).rank_all(trip[:n], n).cpu().numpy(),
+                     K.eval_sweep_scores(m.make_desc(), hip.dev(trip[:n])).cpu().numpy())
+    r1, s1 = out["1"]
+    hr_t, tr_h = cfg.knowledge_graph.cache["hr_t"], cfg.knowledge_graph.cache["tr_h"]
+    for i, (h, r, t) in enumerate(trip[:n]):
+        assert (r1[1, i], r1[3, i]) == ko.rank_from_scores(s1[2 * i], int(t), hr_t[(int(h), int(r))])
+        assert (r1[0, i], r1[2, i]) == ko.rank_from_scores(s1[2 * i + 1], int(h), tr_h[(int(t), int(r))])
+    assert np.allclose(out["0"][1], s1, atol=1e-6, rtol=1e-5)
+    assert (out["0"][0] != r1).mean() < 0.01 and np.abs(out["0"][0] - r1).max() <= 2
