@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void k_eval_qt(const float* __restrict__ qvec,
 }
 
 template <bool WRITE, int POST>
-__global__ __launch_bounds__(256) void k_eval_gemm(const float* __restrict__ cand, const float* __restrict__ qT,
+__global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ cand, const float* __restrict__ qT,
                                                    const float* __restrict__ st, int64_t nq, int64_t E, int64_t ntiles64,
                                                    int Kpad, int qtiles, int S, int32_t* __restrict__ rcount,
                                                    float* __restrict__ scores_out) {
@@ -905,25 +905,42 @@ __global__ __launch_bounds__(256) void k_eval_gemm(const float* __restrict__ can
         }
         __syncthreads();   // before the next candidate tile's first slab reuses buffer 0
         // epilogue: energy = -dot (+ post-op); lane owns query column (ni, li), its 16 registers are candidate rows
-        const int64_t e_base = ct * GT + wr * 64;
+        const int e_base = (int)(ct * GT) + wr * 64 + 4 * lk;   // candidate ids fit 31 bits (packed keys: < 2^24)
+        const int e_lim = (int)E;
         const bool full = ct * GT + GT <= E && (ct * 2 + 1 < ntiles64);
+        if constexpr (!WRITE) {
+            if (full) {   // whole tile inside the table: compare and count, nothing else
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 32 + li;
+                    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int64_t e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                    const float sc = pair_post<POST>(-acc[mi][ni][reg], 1.0f);
-                    if constexpr (WRITE) {
-                        if (q < nq && e < E && (full || (e >> 6) < ntiles64)) scores_out[q * E + e] = sc;
-                    } else {
-                        const bool hit = sc < thr[ni];
-                        cnt[ni] += full ? (hit ? 1 : 0) : ((hit && e < E) ? 1 : 0);
+                        for (int reg = 0; reg < 16; ++reg)
+                            cnt[ni] += pair_post<POST>(-acc[mi][ni][reg], 1.0f) < thr[ni] ? 1 : 0;
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2);
+                            cnt[ni] += (pair_post<POST>(-acc[mi][ni][reg], 1.0f) < thr[ni] && e < e_lim) ? 1 : 0;
+                        }
+            }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 32 + li;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2);
+                        if (q < nq && e < e_lim) scores_out[q * E + e] = pair_post<POST>(-acc[mi][ni][reg], 1.0f);
                     }
                 }
-            }
+        }
     }
     if constexpr (!WRITE) {
 #pragma unroll
