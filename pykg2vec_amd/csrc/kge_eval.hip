@@ -858,53 +858,54 @@ __global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ 
         thr[ni] = (!WRITE && q < nq) ? st[q] : 0.f;
     }
     const int nslab = Kpad / GKS + ((Kpad % GKS) ? 1 : 0);
-    for (int64_t ct = sp; ct < ctiles; ct += S) {
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x16{0};
-        // candidate slab source: two 64-candidate tiles of the sweep layout side by side
-        const float* asrc[2];
+    // ONE software pipeline over all (candidate tile, K slab) steps of this workgroup: the loads of step g + 1 -- which may
+    // be the first slab of the NEXT candidate tile -- are in flight while step g runs on the matrix cores, so there is no
+    // fill / drain bubble at tile boundaries; LDS buffers alternate across the whole sequence (one barrier per step)
+    const int64_t my_tiles = sp < ctiles ? (ctiles - sp + S - 1) / S : 0;
+    const int64_t nsteps = my_tiles * nslab;
+    float4 ra[2], rb[2];
+    auto load_step = [&](int64_t g) {
+        const int64_t ct = sp + (g / nslab) * S;
+        const int sl = (int)(g % nslab);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            int64_t t64 = ct * 2 + (sc4[j] >> 4);
+            int64_t t64 = ct * 2 + (sc4[j] >> 4);   // two 64-candidate tiles of the sweep layout side by side
             if (t64 >= ntiles64) t64 = ntiles64 - 1;   // odd tile count: the duplicate rows are masked in the epilogue
-            asrc[j] = cand + (t64 * Kpad + sk[j]) * 64 + (sc4[j] & 15) * 4;
+            const int k = sl * GKS + sk[j];
+            const bool live = k < Kpad;
+            ra[j] = live ? *reinterpret_cast<const float4*>(cand + (t64 * Kpad + k) * 64 + (sc4[j] & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = live ? *reinterpret_cast<const float4*>(qsrc + (int64_t)k * GT + sc4[j] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        float4 ra[2], rb[2];
-        auto load_slab = [&](int sl) {
+    };
+    f32x16 acc[2][2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int k = sl * GKS + sk[j];
-                const bool live = k < Kpad;
-                ra[j] = live ? *reinterpret_cast<const float4*>(asrc[j] + (int64_t)(sl * GKS) * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[j] = live ? *reinterpret_cast<const float4*>(qsrc + (int64_t)k * GT + sc4[j] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        };
-        load_slab(0);
-        int buf = 0;
-        for (int sl = 0; sl < nslab; ++sl) {
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                *reinterpret_cast<float4*>(&sA[buf][sk[j]][sc4[j] * 4]) = ra[j];
-                *reinterpret_cast<float4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
-            }
-            __syncthreads();   // slab sl is in LDS; everybody finished reading the buffer that is written next
-            if (sl + 1 < nslab) load_slab(sl + 1);
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x16{0};
+    if (nsteps > 0) load_step(0);
+    int buf = 0;
+    for (int64_t g = 0; g < nsteps; ++g) {
 #pragma unroll
-            for (int kk = 0; kk < GKS; kk += 2) {
-                const float a0 = sA[buf][kk + lk][wr * 64 + li], a1 = sA[buf][kk + lk][wr * 64 + 32 + li];
-                const float b0 = sB[buf][kk + lk][wc * 64 + li], b1 = sB[buf][kk + lk][wc * 64 + 32 + li];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
-            buf ^= 1;
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<float4*>(&sA[buf][sk[j]][sc4[j] * 4]) = ra[j];
+            *reinterpret_cast<float4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
         }
-        __syncthreads();   // before the next candidate tile's first slab reuses buffer 0
-        // epilogue: energy = -dot (+ post-op); lane owns query column (ni, li), its 16 registers are candidate rows
+        __syncthreads();   // step g is in LDS; everybody finished reading the buffer that is written next
+        if (g + 1 < nsteps) load_step(g + 1);
+#pragma unroll
+        for (int kk = 0; kk < GKS; kk += 2) {
+            const float a0 = sA[buf][kk + lk][wr * 64 + li], a1 = sA[buf][kk + lk][wr * 64 + 32 + li];
+            const float b0 = sB[buf][kk + lk][wc * 64 + li], b1 = sB[buf][kk + lk][wc * 64 + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        buf ^= 1;
+        if ((int)(g % nslab) != nslab - 1) continue;
+        // ---- last slab of a candidate tile: epilogue.  energy = -dot (+ post-op); the lane owns query column (ni, li),
+        // its 16 registers per block are candidate rows
+        const int64_t ct = sp + (g / nslab) * S;
         const int e_base = (int)(ct * GT) + wr * 64 + 4 * lk;   // candidate ids fit 31 bits (packed keys: < 2^24)
         const int e_lim = (int)E;
         const bool full = ct * GT + GT <= E && (ct * 2 + 1 < ntiles64);
@@ -941,6 +942,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ 
                     }
                 }
         }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x16{0};
     }
     if constexpr (!WRITE) {
 #pragma unroll
@@ -1050,7 +1055,9 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
         if (qdesc == nullptr && p.qT != nullptr && use_gemm_sweep(p, nq)) {   // the dot-product sweep on the matrix cores
             const int qtiles = (int)((nq + GT - 1) / GT);
             const int64_t ctiles = (p.ntiles + 1) / 2;
-            int64_t S2 = (4 * 256 + qtiles - 1) / qtiles;   // >= 4 workgroups per CU in flight
+            // candidate-tile splits: fill the 4 x 256 resident workgroup slots WITHOUT spilling into a second, mostly empty
+            // generation (1029 workgroups on 1024 slots cost 25 % more than 980)
+            int64_t S2 = (4 * 256) / qtiles;
             if (S2 > ctiles) S2 = ctiles;
             if (S2 < 1) S2 = 1;
             hipLaunchKernelGGL(k_eval_qt, dim3((unsigned)(qtiles * 2), (unsigned)((p.Kpad + 63) / 64)), dim3(256), 0, s, p.qvec, nq,
