@@ -92,7 +92,7 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p,
     p->fcount = (int32_t*)take((size_t)2 * n * sizeof(int32_t));
     p->rcount = (int32_t*)take((size_t)2 * n * sizeof(int32_t));
     p->qT = nullptr;
-    if (p->form == F_NEGDOT && p->xform == X_NONE)
+    if ((p->form == F_NEGDOT || p->form == F_SQM) && p->xform == X_NONE)
         p->qT = (float*)take((size_t)((2 * n + 127) / 128) * p->Kpad * 128 * sizeof(float));
     p->bytes = off;
     return true;
@@ -110,6 +110,7 @@ struct PrepArgs {
     const float* seg[4]; int seg_dim[4]; int nseg;  // candidate row = concatenation of table rows
     const float* dot_tab;                            // TransD: aux[e] = ent[e] . ent_mappings[e]
     int normalize;                                   // TransE: divide by max(||row||, eps)
+    int want_n2;                                     // matrix-core squared-distance sweep: aux[e] = sum_k c_k^2
     int64_t E; int K, Kpad;
 };
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void k_eval_prepare(PrepArgs a, float* __restr
         const int row = wave * 16 + j;
         const int64_t e = e0 + row;
         float n2 = 0.f, dt = 0.f;
-        if (e < a.E && (a.normalize || a.dot_tab)) {
+        if (e < a.E && (a.normalize || a.dot_tab || a.want_n2)) {
             for (int k = lane; k < a.K; k += 64) {
                 const float v = prep_elem(a, e, k);
                 n2 = fmaf(v, v, n2);
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void k_eval_prepare(PrepArgs a, float* __restr
         if (lane == 0) {
             s_scale[row] = a.normalize ? 1.0f / fmaxf(sqrtf(n2), kEpsNormalize) : 1.0f;
             if (a.dot_tab) aux[e0 + row] = (e < a.E) ? dt : 0.f;
+            if (a.want_n2) aux[e0 + row] = (e < a.E) ? n2 : 0.f;
         }
     }
     __syncthreads();
@@ -474,6 +476,9 @@ __device__ __forceinline__ float pair_post(float s, float scale) {
     else return s;
 }
 
+// squared L2 distance from the dot product and the two squared norms (matrix-core sweep and its target / filter twin)
+__device__ __forceinline__ float sqm_from_dot(float dot, float qn, float cn) { return fmaf(-2.0f, dot, qn + cn); }
+
 // full sequential score of one (query, candidate) pair by ONE lane (target / filter path).  CHAIN: the dot product as
 // ONE fmaf chain over k -- the order v_mfma_f32_32x32x2_f32 accumulates in (k_eval_gemm) -- instead of the packed sweep's
 // even / odd split.
@@ -484,7 +489,7 @@ __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand,
     const float* c = cand + ((e >> 6) * Kpad) * 64 + (e & 63);
     float acc = 0.f;
     if constexpr (CHAIN) {
-        static_assert(!CHAIN || (FORM == F_NEGDOT && XFORM == X_NONE), "chain order: plain dot-product form only");
+        static_assert(!CHAIN || ((FORM == F_NEGDOT || FORM == F_SQM) && XFORM == X_NONE), "chain order: plain dot-product based forms");
         for (int k0 = 0; k0 < Kpad; k0 += KC) {
             float cv[KC], qv[KC];
 #pragma unroll
@@ -492,7 +497,10 @@ __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand,
 #pragma unroll
             for (int j = 0; j < KC; ++j) acc = fmaf(cv[j], qv[j], acc);
         }
-        return pair_post<POST>(pair_finish<FORM>(acc, margin), scale);
+        // squared distance through the expansion |q|^2 + |c|^2 - 2 <q, c> the matrix-core sweep uses (`scale` = |q|^2,
+        // aux[e] = |c|^2): same stored norms, same operation order => same bits as k_eval_gemm
+        if constexpr (FORM == F_SQM) acc = sqm_from_dot(acc, scale, aux[e]);
+        return pair_post<POST>(pair_finish<FORM>(acc, margin), 1.0f);
     }
     // candidate / query elements are fetched KC at a time BEFORE the dependent accumulation chain (one memory round trip
     // per KC elements instead of one per element); the accumulation order is unchanged
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
     const int side = (int)(qi & 1);
     const int64_t truth = side == 0 ? triples[3 * i + 2] : triples[3 * i];
     const float* q = qvec + qi * (int64_t)QV * Kpad;
-    const float scale = POST == P_SCALE ? qscale[qi] : 1.0f;
+    const float scale = (POST == P_SCALE || (CHAIN && FORM == F_SQM)) ? qscale[qi] : 1.0f;   // CHAIN SQM: |q|^2
     float s_true = 0.f;
     if (lane == 0) s_true = pair_score_lane<FORM, XFORM, POST, CHAIN>(cand, aux, q, truth, Kpad, margin, scale);
     s_true = __shfl(s_true, 0, 64);
@@ -834,11 +842,23 @@ __global__ __launch_bounds__(256) void k_eval_qt(const float* __restrict__ qvec,
     }
 }
 
-template <bool WRITE, int POST>
+// |q|^2 per query row (squared-distance form), one wave per query
+__global__ __launch_bounds__(256) void k_eval_qnorm(const float* __restrict__ qvec, int64_t nq, int Kpad, float* __restrict__ qn) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    float n2 = 0.f;
+    for (int k = lane; k < Kpad; k += 64) { const float v = qvec[q * Kpad + k]; n2 = fmaf(v, v, n2); }
+    n2 = wave_sum(n2);
+    if (lane == 0) qn[q] = n2;
+}
+
+template <bool WRITE, int POST, bool SQM>
 __global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ cand, const float* __restrict__ qT,
                                                    const float* __restrict__ st, int64_t nq, int64_t E, int64_t ntiles64,
                                                    int Kpad, int qtiles, int S, int32_t* __restrict__ rcount,
-                                                   float* __restrict__ scores_out) {
+                                                   float* __restrict__ scores_out, const float* __restrict__ qn,
+                                                   const float* __restrict__ cn, float margin) {
     __shared__ float sA[2][GKS][GLD], sB[2][GKS][GLD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lk = lane >> 5;
@@ -850,13 +870,19 @@ __global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 2; ++j) { const int idx = threadIdx.x + 256 * j; sk[j] = idx >> 5; sc4[j] = idx & 31; }
     const float* qsrc = qT + (int64_t)qt * Kpad * GT;
-    float thr[2];
+    float thr[2], qn2[2];
     int cnt[2] = {0, 0};
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 32 + li;
         thr[ni] = (!WRITE && q < nq) ? st[q] : 0.f;
+        qn2[ni] = (SQM && q < nq) ? qn[q] : 0.f;
     }
+    // energy of one accumulator element: -dot, or the squared distance -(margin - (|q|^2 + |c|^2 - 2 dot))
+    auto energy = [&](float dot, int ni, float cn2) {
+        if constexpr (SQM) return pair_post<POST>(pair_finish<F_SQM>(sqm_from_dot(dot, qn2[ni], cn2), margin), 1.0f);
+        else return pair_post<POST>(-dot, 1.0f);
+    };
     const int nslab = Kpad / GKS + ((Kpad % GKS) ? 1 : 0);
     // ONE software pipeline over all (candidate tile, K slab) steps of this workgroup: the loads of step g + 1 -- which may
     // be the first slab of the NEXT candidate tile -- are in flight while step g runs on the matrix cores, so there is no
@@ -909,6 +935,16 @@ __global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ 
         const int e_base = (int)(ct * GT) + wr * 64 + 4 * lk;   // candidate ids fit 31 bits (packed keys: < 2^24)
         const int e_lim = (int)E;
         const bool full = ct * GT + GT <= E && (ct * 2 + 1 < ntiles64);
+        float cn2[2][16];   // squared norms of this lane's candidate rows (squared-distance form only)
+        if constexpr (SQM) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2);
+                    cn2[mi][reg] = e < (int)(ntiles64 * 64) ? cn[e] : 0.f;
+                }
+        }
         if constexpr (!WRITE) {
             if (full) {   // whole tile inside the table: compare and count, nothing else
 #pragma unroll
@@ -917,7 +953,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ 
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg)
-                            cnt[ni] += pair_post<POST>(-acc[mi][ni][reg], 1.0f) < thr[ni] ? 1 : 0;
+                            cnt[ni] += energy(acc[mi][ni][reg], ni, SQM ? cn2[mi][reg] : 0.f) < thr[ni] ? 1 : 0;
             } else {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
@@ -926,7 +962,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ 
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
                             const int e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2);
-                            cnt[ni] += (pair_post<POST>(-acc[mi][ni][reg], 1.0f) < thr[ni] && e < e_lim) ? 1 : 0;
+                            cnt[ni] += (energy(acc[mi][ni][reg], ni, SQM ? cn2[mi][reg] : 0.f) < thr[ni] && e < e_lim) ? 1 : 0;
                         }
             }
         } else {
@@ -938,7 +974,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ 
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2);
-                        if (q < nq && e < e_lim) scores_out[q * E + e] = pair_post<POST>(-acc[mi][ni][reg], 1.0f);
+                        if (q < nq && e < e_lim) scores_out[q * E + e] = energy(acc[mi][ni][reg], ni, SQM ? cn2[mi][reg] : 0.f);
                     }
                 }
         }
@@ -1002,7 +1038,7 @@ int launch_rank_from_scores(const float* scores, int64_t nq, int64_t E, const in
 
 // ------------------------------------------------------------------ host side
 static void fill_prep(const kge_model_desc* m, const EvalPlan& p, PrepArgs* a) {
-    a->nseg = 1; a->dot_tab = nullptr; a->normalize = 0;
+    a->nseg = 1; a->dot_tab = nullptr; a->normalize = 0; a->want_n2 = 0;
     a->E = p.E; a->K = p.K; a->Kpad = p.Kpad;
     for (int s = 0; s < 4; ++s) { a->seg[s] = nullptr; a->seg_dim[s] = 0; }
     a->seg[0] = m->tables[0]; a->seg_dim[0] = m->dim;
@@ -1051,8 +1087,9 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
     if (S > max_split) S = max_split;
     if (S < 1) S = 1;
     const unsigned grid = (unsigned)(qgroups * 256 * S);
-    if constexpr (FORM == F_NEGDOT && XFORM == X_NONE && POST != P_SCALE) {
-        if (qdesc == nullptr && p.qT != nullptr && use_gemm_sweep(p, nq)) {   // the dot-product sweep on the matrix cores
+    if constexpr ((FORM == F_NEGDOT || FORM == F_SQM) && XFORM == X_NONE && POST != P_SCALE) {
+        if (qdesc == nullptr && p.qT != nullptr && use_gemm_sweep(p, nq)) {   // the dot-product based sweeps on the matrix cores
+            constexpr bool SQM = FORM == F_SQM;
             const int qtiles = (int)((nq + GT - 1) / GT);
             const int64_t ctiles = (p.ntiles + 1) / 2;
             // candidate-tile splits: fill the 4 x 256 resident workgroup slots WITHOUT spilling into a second, mostly empty
@@ -1062,15 +1099,17 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
             if (S2 < 1) S2 = 1;
             hipLaunchKernelGGL(k_eval_qt, dim3((unsigned)(qtiles * 2), (unsigned)((p.Kpad + 63) / 64)), dim3(256), 0, s, p.qvec, nq,
                                p.Kpad, p.qT);
+            if (SQM)   // |q|^2 per query (p.qscale is free in this form); |c|^2 per candidate was left in p.aux by k_eval_prepare
+                hipLaunchKernelGGL(k_eval_qnorm, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p.qvec, nq, p.Kpad, p.qscale);
             if (scores_out == nullptr) {
                 hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM, POST, true>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s,
                                    p.cand, p.aux, p.qvec, p.qscale, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids,
                                    head_off, head_ids, p.st, p.fcount, group_of_triple, p.table_stride);
-                hipLaunchKernelGGL((k_eval_gemm<false, POST>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
-                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, nullptr);
+                hipLaunchKernelGGL((k_eval_gemm<false, POST, SQM>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
+                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, nullptr, p.qscale, p.aux, m->margin);
             } else {
-                hipLaunchKernelGGL((k_eval_gemm<true, POST>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
-                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, scores_out);
+                hipLaunchKernelGGL((k_eval_gemm<true, POST, SQM>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
+                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, scores_out, p.qscale, p.aux, m->margin);
             }
             return;
         }
@@ -1106,6 +1145,7 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     } else {
     PrepArgs pa;
     fill_prep(m, p, &pa);
+    pa.want_n2 = (p.form == F_SQM && p.xform == X_NONE && p.qT != nullptr && use_gemm_sweep(p, 2 * n)) ? 1 : 0;
     hipLaunchKernelGGL(k_eval_prepare, dim3((unsigned)p.ntiles), dim3(256), 0, s, pa, p.cand, p.aux);
     const DeviceModel dm = to_device_model(m);
     const unsigned qb = (unsigned)((n + 3) / 4);

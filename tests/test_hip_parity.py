@@ -638,7 +638,7 @@ def test_fused_sampler_steps_with_bern_probabilities(hip, name):
         assert np.allclose(a, b, atol=1e-5, rtol=1e-4)
 
 
-GEMM_CASES = ["distmult", "complex", "complexn3", "analogy", "rescal", "cp", "simple", "simple_ignr", "quate"]
+GEMM_CASES = ["distmult", "complex", "complexn3", "analogy", "rescal", "cp", "simple", "simple_ignr", "quate", "rotate"]
 
 
 @pytest.mark.parametrize("name", GEMM_CASES)

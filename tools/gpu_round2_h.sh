@@ -14,5 +14,6 @@ for flag in 0 1; do
   KGE_EVAL_GEMM=$flag ONLY="C4 " timeout 200 python tools/config_perf.py > gpurun_out/h_c4_gemm$flag.log 2>&1
   KGE_EVAL_GEMM=$flag ONLY="DistMult" timeout 200 python tools/config_perf.py > gpurun_out/h_dm_gemm$flag.log 2>&1
   KGE_EVAL_GEMM=$flag ONLY="ANALOGY" timeout 200 python tools/config_perf.py > gpurun_out/h_an_gemm$flag.log 2>&1
+  KGE_EVAL_GEMM=$flag ONLY="C3 " timeout 200 python tools/config_perf.py > gpurun_out/h_c3_gemm$flag.log 2>&1
 done
 grep -h "eval" gpurun_out/h_*_gemm*.log
