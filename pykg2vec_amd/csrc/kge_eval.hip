@@ -935,49 +935,27 @@ __global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ 
         const int e_base = (int)(ct * GT) + wr * 64 + 4 * lk;   // candidate ids fit 31 bits (packed keys: < 2^24)
         const int e_lim = (int)E;
         const bool full = ct * GT + GT <= E && (ct * 2 + 1 < ntiles64);
-        float cn2[2][16];   // squared norms of this lane's candidate rows (squared-distance form only)
-        if constexpr (SQM) {
+        // (candidate rows outermost: in the squared-distance form |c|^2 of a row is fetched once and used for both query
+        // column blocks, without holding 32 of them in registers)
+        const int e_pad = (int)(ntiles64 * 64);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2);
-                    cn2[mi][reg] = e < (int)(ntiles64 * 64) ? cn[e] : 0.f;
-                }
-        }
-        if constexpr (!WRITE) {
-            if (full) {   // whole tile inside the table: compare and count, nothing else
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg)
-                            cnt[ni] += energy(acc[mi][ni][reg], ni, SQM ? cn2[mi][reg] : 0.f) < thr[ni] ? 1 : 0;
-            } else {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const int e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2);
-                            cnt[ni] += (energy(acc[mi][ni][reg], ni, SQM ? cn2[mi][reg] : 0.f) < thr[ni] && e < e_lim) ? 1 : 0;
-                        }
-            }
-        } else {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int reg = 0; reg < 16; ++reg) {
+                const int e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2);
+                float cn2 = 0.f;
+                if constexpr (SQM) cn2 = e < e_pad ? cn[e] : 0.f;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 32 + li;
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int e = e_base + mi * 32 + (reg & 3) + 8 * (reg >> 2);
-                        if (q < nq && e < e_lim) scores_out[q * E + e] = energy(acc[mi][ni][reg], ni, SQM ? cn2[mi][reg] : 0.f);
+                    const float sc = energy(acc[mi][ni][reg], ni, cn2);
+                    if constexpr (WRITE) {
+                        const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 32 + li;
+                        if (q < nq && e < e_lim) scores_out[q * E + e] = sc;
+                    } else {
+                        cnt[ni] += (sc < thr[ni] && (full || e < e_lim)) ? 1 : 0;
                     }
                 }
-        }
+            }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
