@@ -133,33 +133,39 @@ __global__ __launch_bounds__(256) void k_eval_prepare(PrepArgs a, float* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x;
     const int64_t e0 = tile * 64;
-    for (int j = 0; j < 16; ++j) {  // row statistics
-        const int row = wave * 16 + j;
-        const int64_t e = e0 + row;
-        float n2 = 0.f, dt = 0.f;
-        if (e < a.E && (a.normalize || a.dot_tab || a.want_n2)) {
-            for (int k = lane; k < a.K; k += 64) {
-                const float v = prep_elem(a, e, k);
-                n2 = fmaf(v, v, n2);
-                if (a.dot_tab) dt = fmaf(v, a.dot_tab[e * a.K + k], dt);
-            }
+    // Row statistics.  Only the TransE normalisation must be known BEFORE the rows are written (it scales them): that
+    // case takes a pass of its own over the (short) rows.  Squared norms / the TransD dot product are by-products: they
+    // accumulate per lane during the transposing pass below -- one read of the table, not two (RotatE d=1000: 116 MB).
+    if (a.normalize) {
+        for (int j = 0; j < 16; ++j) {
+            const int row = wave * 16 + j;
+            const int64_t e = e0 + row;
+            float n2 = 0.f;
+            if (e < a.E)
+                for (int k = lane; k < a.K; k += 64) { const float v = prep_elem(a, e, k); n2 = fmaf(v, v, n2); }
+            n2 = wave_sum(n2);
+            if (lane == 0) s_scale[row] = 1.0f / fmaxf(sqrtf(n2), kEpsNormalize);
         }
-        n2 = wave_sum(n2);
-        dt = wave_sum(dt);
-        if (lane == 0) {
-            s_scale[row] = a.normalize ? 1.0f / fmaxf(sqrtf(n2), kEpsNormalize) : 1.0f;
-            if (a.dot_tab) aux[e0 + row] = (e < a.E) ? dt : 0.f;
-            if (a.want_n2) aux[e0 + row] = (e < a.E) ? n2 : 0.f;
-        }
+    } else if (threadIdx.x < 64) {
+        s_scale[threadIdx.x] = 1.0f;
     }
     __syncthreads();
+    float n2acc[16], dtacc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { n2acc[j] = 0.f; dtacc[j] = 0.f; }
     for (int k0 = 0; k0 < a.Kpad; k0 += 64) {  // transpose 64x64 through LDS: coalesced reads AND writes
+#pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int row = wave * 16 + j;
             const int64_t e = e0 + row;
             const int k = k0 + lane;
             float v = 0.f;
-            if (e < a.E && k < a.K) v = prep_elem(a, e, k) * s_scale[row];
+            if (e < a.E && k < a.K) {
+                const float raw = prep_elem(a, e, k);
+                if (a.want_n2) n2acc[j] = fmaf(raw, raw, n2acc[j]);
+                if (a.dot_tab) dtacc[j] = fmaf(raw, a.dot_tab[e * a.K + k], dtacc[j]);
+                v = raw * s_scale[row];
+            }
             s_tile[row][lane] = v;
         }
         __syncthreads();
@@ -168,6 +174,13 @@ __global__ __launch_bounds__(256) void k_eval_prepare(PrepArgs a, float* __restr
             if (k0 + kk < a.Kpad) cand[(tile * a.Kpad + k0 + kk) * 64 + lane] = s_tile[lane][kk];
         }
         __syncthreads();
+    }
+    if (a.want_n2 || a.dot_tab) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float tot = wave_sum(a.dot_tab ? dtacc[j] : n2acc[j]);
+            if (lane == 0) aux[e0 + wave * 16 + j] = (e0 + wave * 16 + j < a.E) ? tot : 0.f;
+        }
     }
 }
 
@@ -853,8 +866,9 @@ __global__ __launch_bounds__(256) void k_eval_qnorm(const float* __restrict__ qv
     if (lane == 0) qn[q] = n2;
 }
 
+// (four workgroups per CU for the dot form; the squared-distance epilogue needs ~20 more registers: three per CU, no spills)
 template <bool WRITE, int POST, bool SQM>
-__global__ __launch_bounds__(256, 4) void k_eval_gemm(const float* __restrict__ cand, const float* __restrict__ qT,
+__global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __restrict__ cand, const float* __restrict__ qT,
                                                    const float* __restrict__ st, int64_t nq, int64_t E, int64_t ntiles64,
                                                    int Kpad, int qtiles, int S, int32_t* __restrict__ rcount,
                                                    float* __restrict__ scores_out, const float* __restrict__ qn,
@@ -1072,7 +1086,7 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
             const int64_t ctiles = (p.ntiles + 1) / 2;
             // candidate-tile splits: fill the 4 x 256 resident workgroup slots WITHOUT spilling into a second, mostly empty
             // generation (1029 workgroups on 1024 slots cost 25 % more than 980)
-            int64_t S2 = (4 * 256) / qtiles;
+            int64_t S2 = ((SQM ? 3 : 4) * 256) / qtiles;
             if (S2 > ctiles) S2 = ctiles;
             if (S2 < 1) S2 = 1;
             hipLaunchKernelGGL(k_eval_qt, dim3((unsigned)(qtiles * 2), (unsigned)((p.Kpad + 63) / 64)), dim3(256), 0, s, p.qvec, nq,
