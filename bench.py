@@ -258,7 +258,10 @@ def run_extra_config(key, device):
            "train_algorithmic_GBps_whole_step": rows * c["train_bytes"] / dt / 1e9,
            "train_hbm_frac_whole_step": rows * c["train_bytes"] / dt / 1e9 / HBM_PEAK_GBS,
            "eval_test_triples_per_s": len(q) / edt, "eval_ms_per_pass": edt * 1e3, "eval_test_triples": len(q),
-           "eval_algorithmic_GBps": 2.0 * len(q) * E_ * c["eval_bytes"] / edt / 1e9}
+           "eval_algorithmic_GBps": 2.0 * len(q) * E_ * c["eval_bytes"] / edt / 1e9,
+           "eval_sweep": ("matrix cores (k_eval_gemm, f32 MFMA)" if c["model"] in ("complex", "rotate", "rescal") and 2 * len(q) >= 512
+                          else "VALU (k_eval_sweep)"),
+           "eval_TFLOPs": 2.0 * 2 * len(q) * E_ * (c["eval_bytes"] / 4) / edt / 1e12}
     if "train_flops" in c:
         out["train_TFLOPs_whole_step"] = rows * c["train_flops"] / dt / 1e12
         out["train_mfma_frac_whole_step"] = out["train_TFLOPs_whole_step"] / MFMA_F32_PEAK_TFLOPS
