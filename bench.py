@@ -488,7 +488,7 @@ def main():
     kernel_label = ("k_pull_step<Adam,G=32,NCH=4> (owner-computes step: per-row re-evaluation of incident pairs, hinge, backward, "
                     "normalisation backward, dense Adam; no atomics)" if pull else
                     "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)")
-    traffic, traffic_src = pmc_traffic("kge::k_pull_step<1, 32, 4" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch)
+    traffic, traffic_src = pmc_traffic("kge::k_pull_step<1, true, 32" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch)
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
@@ -501,7 +501,7 @@ def main():
                        "scored_triples_per_step": scored_per_step, "parallelism": "dp%d" % world,
                        "warmup_steps_run": args.warmup + warm_extra,
                        "model_state": "timed steps start from the freshly initialised tables (reset after warm-up)",
-                       "step_path": "owner-computes (pull): kge_pull_sample + kge_pull_step [+ finish]" if pull else
+                       "step_path": "owner-computes (pull): kge_pull_run, one k_pull_step launch per step (the next batch's sampler rides in its leading blocks)" if pull else
                                     "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step"},
             "roofline": {"kernel": kernel_label, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
