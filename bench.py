@@ -163,10 +163,12 @@ def reference_cpu_numbers():
             "cores": doc["cores"], "host": doc["host"], "source": "profiles/r02_reference_cpu_baseline.json"}
 
 
-def pmc_traffic(kernel_prefix, batch):
+def pmc_traffic(kernel_prefix, batch, fetch_scale=1.0):
     """HBM bytes per launch of the dominant train kernel from the committed rocprofv3 PMC passes
     (profiles/*pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, separate passes, same bench command and batch size).
-    Returns (bytes or None, source)."""
+    fetch_scale: the gfx950 correction of MI355X_MICROARCH.md (HBM section) -- FETCH_SIZE reports half the bytes of wide
+    (16 B per lane) coalesced reads, which is how the owner-computes kernel fetches every row; the round-1 push kernel
+    reads one dword per lane (uncalibrated width: left raw).  Returns (bytes or None, source)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files or batch != 32768:
@@ -175,7 +177,7 @@ def pmc_traffic(kernel_prefix, batch):
         doc = json.load(open(f))
         for name, ctr in doc["kernels"].items():
             if name.startswith(kernel_prefix) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-                return (ctr["FETCH_SIZE"]["avg_KB"] + ctr["WRITE_SIZE"]["avg_KB"]) * 1024.0, os.path.basename(f)
+                return (fetch_scale * ctr["FETCH_SIZE"]["avg_KB"] + ctr["WRITE_SIZE"]["avg_KB"]) * 1024.0, os.path.basename(f)
     return None, None
 
 
@@ -488,7 +490,8 @@ def main():
     kernel_label = ("k_pull_step<Adam,G=32,NCH=4> (owner-computes step: per-row re-evaluation of incident pairs, hinge, backward, "
                     "normalisation backward, dense Adam; no atomics)" if pull else
                     "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)")
-    traffic, traffic_src = pmc_traffic("kge::k_pull_step<1, true, 32" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch)
+    traffic, traffic_src = pmc_traffic("kge::k_pull_step<1, true, 32" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch,
+                                       fetch_scale=2.0 if pull else 1.0)
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
@@ -505,7 +508,7 @@ def main():
                                     "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step"},
             "roofline": {"kernel": kernel_label, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic_source": traffic_src, "traffic_note": ("2 x FETCH_SIZE (gfx950: 16-byte-per-lane reads are tallied at half) + WRITE_SIZE" if pull else "FETCH_SIZE + WRITE_SIZE, raw"), "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_ms,
                          "avg_launch_ms_method": "HIP events around a burst of %d back-to-back launches of the kernel "
                                                  "right after the timed region (= rocprofv3 kernel duration)" % burst,

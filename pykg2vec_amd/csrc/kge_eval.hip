@@ -932,10 +932,18 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
         }
         __syncthreads();   // step g is in LDS; everybody finished reading the buffer that is written next
         if (g + 1 < nsteps) load_step(g + 1);
+        // operands of step kk + 2 are read from LDS before the MFMAs of step kk are issued (register double buffer; the
+        // scheduling barrier keeps the compiler from sinking the reads back in front of their use)
+        float na0 = sA[buf][lk][wr * 64 + li], na1 = sA[buf][lk][wr * 64 + 32 + li];
+        float nb0 = sB[buf][lk][wc * 64 + li], nb1 = sB[buf][lk][wc * 64 + 32 + li];
 #pragma unroll
         for (int kk = 0; kk < GKS; kk += 2) {
-            const float a0 = sA[buf][kk + lk][wr * 64 + li], a1 = sA[buf][kk + lk][wr * 64 + 32 + li];
-            const float b0 = sB[buf][kk + lk][wc * 64 + li], b1 = sB[buf][kk + lk][wc * 64 + 32 + li];
+            const float a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;
+            if (kk + 2 < GKS) {
+                na0 = sA[buf][kk + 2 + lk][wr * 64 + li]; na1 = sA[buf][kk + 2 + lk][wr * 64 + 32 + li];
+                nb0 = sB[buf][kk + 2 + lk][wc * 64 + li]; nb1 = sB[buf][kk + 2 + lk][wc * 64 + 32 + li];
+            }
+            KGE_KEEP_READS_AHEAD();
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);

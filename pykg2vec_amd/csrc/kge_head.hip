@@ -112,6 +112,109 @@ __global__ __launch_bounds__(256) void k_head_gemm(HeadArgs a) {
     if constexpr (MODE == 1) block_accumulate_loss<1>(lsum * a.inv_count, 0, a.loss);
 }
 
+// ---- the same GEMM at a 128 x 128 macro-tile (large batches): 4 waves x (2 x 2) accumulators of 32 x 32, i.e. 64 FMAs per
+// operand float fetched from LDS instead of 16; both operand tiles are row-major in memory (k contiguous), fetched with one
+// 16-byte load per thread and 16-deep K slab and written k-major into LDS ([k][128 + pad]: conflict-free MFMA operand reads);
+// slabs double-buffered in LDS with the next slab's global loads in flight during the current slab's 32 MFMAs per wave (one
+// barrier per slab).  The accumulation order over k is the old kernel's (one MFMA chain), so the logits are bit-identical.
+constexpr int HT2 = 128, HK2 = 16, HLD2 = HT2 + 4;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void k_head_gemm128(HeadArgs a) {
+    __shared__ float sA[2][HK2][HLD2], sB[2][HK2][HLD2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t e0 = (int64_t)blockIdx.x * HT2, b0 = (int64_t)blockIdx.y * HT2;
+    const int wr = wave >> 1, wc = wave & 1;   // wave's 64 x 64 sub-tile: batch rows wr, entity columns wc
+    // staging role: float4 number t + 256 j of a slab = (row = idx / 4, k = 4 * (idx % 4) .. + 3)
+    const int srow = threadIdx.x >> 2, sk4 = (threadIdx.x & 3) * 4;
+    const int nslab = (a.d + HK2 - 1) / HK2;
+    float4 ra[2], rb[2];
+    auto load_slab = [&](int sl) {
+        const int k = sl * HK2 + sk4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t b = b0 + srow + 64 * j, e = e0 + srow + 64 * j;
+            const bool live = k < a.d;   // d % 4 == 0: a float4 is inside the row or past its end
+            ra[j] = (live && b < a.B) ? *reinterpret_cast<const float4*>(a.x + b * a.d + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = (live && e < a.E) ? *reinterpret_cast<const float4*>(a.ent + e * a.d + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x16{0};
+    load_slab(0);
+    int buf = 0;
+    for (int sl = 0; sl < nslab; ++sl) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = srow + 64 * j;
+            sA[buf][sk4 + 0][r] = ra[j].x; sA[buf][sk4 + 1][r] = ra[j].y; sA[buf][sk4 + 2][r] = ra[j].z; sA[buf][sk4 + 3][r] = ra[j].w;
+            sB[buf][sk4 + 0][r] = rb[j].x; sB[buf][sk4 + 1][r] = rb[j].y; sB[buf][sk4 + 2][r] = rb[j].z; sB[buf][sk4 + 3][r] = rb[j].w;
+        }
+        __syncthreads();   // slab sl is in LDS; everybody finished reading the buffer that is written next
+        if (sl + 1 < nslab) load_slab(sl + 1);
+        // operands of step kk + 2 are read from LDS before the MFMAs of step kk are issued (register double buffer): the LDS
+        // latency hides under 4 x 64 cycles of matrix work instead of stalling the wave in front of every quadruple
+        float na0 = sA[buf][lk][wr * 64 + li], na1 = sA[buf][lk][wr * 64 + 32 + li];
+        float nc0 = sB[buf][lk][wc * 64 + li], nc1 = sB[buf][lk][wc * 64 + 32 + li];
+#pragma unroll
+        for (int kk = 0; kk < HK2; kk += 2) {
+            const float a0 = na0, a1 = na1, c0 = nc0, c1 = nc1;
+            if (kk + 2 < HK2) {
+                na0 = sA[buf][kk + 2 + lk][wr * 64 + li]; na1 = sA[buf][kk + 2 + lk][wr * 64 + 32 + li];
+                nc0 = sB[buf][kk + 2 + lk][wc * 64 + li]; nc1 = sB[buf][kk + 2 + lk][wc * 64 + 32 + li];
+            }
+            KGE_KEEP_READS_AHEAD();
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c1, acc[1][1], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    float lsum = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int64_t e = e0 + wc * 64 + ni * 32 + li;
+        const float bias = (a.bias && e < a.E) ? a.bias[e] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t b = b0 + wr * 64 + mi * 32 + head_row(reg, lk);
+                if (b < a.B && e < a.E) {
+                    const float p = sigmoidf_(acc[mi][ni][reg] + bias);
+                    if constexpr (MODE == 0) {
+                        a.preds[b * a.E + e] = p;
+                    } else {
+                        lsum += softplusf_(p) - p * a.y0;
+                        a.dz[b * a.E + e] = (sigmoidf_(p) - a.y0) * p * (1.f - p) * a.inv_count;
+                    }
+                }
+            }
+    }
+    if constexpr (MODE == 1) block_accumulate_loss<1>(lsum * a.inv_count, 0, a.loss);
+}
+
+// the large tile pays once the grid fills the chip with it and the rows can be fetched 16 bytes at a time
+static bool head_use_128(const HeadArgs& a) {
+    const char* force = getenv("KGE_HEAD_TILE");
+    if (force) return force[0] == '1' && a.d % 4 == 0;
+    const int64_t tiles = ((a.E + HT2 - 1) / HT2) * ((a.B + HT2 - 1) / HT2);
+    return a.d % 4 == 0 && (((uintptr_t)a.x | (uintptr_t)a.ent) & 15) == 0 && tiles >= 512;
+}
+
+template <int MODE>
+static void launch_head_gemm(const HeadArgs& a, hipStream_t s) {
+    if (head_use_128(a))
+        hipLaunchKernelGGL(k_head_gemm128<MODE>, dim3((unsigned)((a.E + HT2 - 1) / HT2), (unsigned)((a.B + HT2 - 1) / HT2)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_head_gemm<MODE>, dim3((unsigned)((a.E + HT - 1) / HT), (unsigned)((a.B + HT - 1) / HT)), dim3(256), 0, s, a);
+}
+
 // positives: group of 32 lanes per (b, e) entry of the CSR label lists
 __global__ __launch_bounds__(256) void k_head_bce_pos(HeadArgs a, const int64_t* __restrict__ lab_off, const int32_t* __restrict__ lab_ids,
                                                       const int32_t* __restrict__ row_of, int64_t n_pos, float dy) {
@@ -223,14 +326,13 @@ static int head_check(const char* who, const float* x, const float* ent, int64_t
     return 0;
 }
 
-static dim3 head_grid(int64_t E, int64_t B) { return dim3((unsigned)((E + HT - 1) / HT), (unsigned)((B + HT - 1) / HT)); }
 
 int launch_head_forward(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* bias, float* preds,
                         hipStream_t s) {
     if (head_check("kge_head_1n_forward", x, ent, B, E, d) || !preds) { if (!preds) set_error("kge_head_1n_forward: null output"); return -1; }
     HeadArgs a{};
     a.x = x; a.ent = ent; a.bias = bias; a.B = B; a.E = E; a.d = d; a.preds = preds;
-    hipLaunchKernelGGL(k_head_gemm<0>, head_grid(E, B), dim3(256), 0, s, a);
+    launch_head_gemm<0>(a, s);
     return check_launch("k_head_gemm<0>");
 }
 
@@ -294,7 +396,7 @@ int launch_head_bce(const float* x, int64_t B, int d, const float* ent, int64_t 
     HeadArgs a{};
     a.x = x; a.ent = ent; a.bias = bias; a.B = B; a.E = E; a.d = d; a.dz = dz; a.loss = loss;
     a.y0 = y0; a.inv_count = 1.0f / ((float)B * (float)E);
-    hipLaunchKernelGGL(k_head_gemm<1>, head_grid(E, B), dim3(256), 0, s, a);
+    launch_head_gemm<1>(a, s);
     if (n_pos > 0) {
         hipLaunchKernelGGL(k_head_rows_of, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, lab_off, B, row_of);
         int64_t blocks = (n_pos + 7) / 8;

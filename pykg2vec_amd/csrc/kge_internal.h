@@ -6,6 +6,14 @@
 #include "../../include/kge_hip.h"
 #include "kge_device.h"
 
+// GEMM inner loops read the LDS operands of step k + 2 before issuing the MFMAs of step k; the scheduling barrier keeps the
+// compiler from sinking those reads back in front of their use (-DKGE_NO_LDS_PREFETCH: A/B builds without it)
+#ifdef KGE_NO_LDS_PREFETCH
+#define KGE_KEEP_READS_AHEAD() ((void)0)
+#else
+#define KGE_KEEP_READS_AHEAD() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace kge {
 
 void set_error(const char* fmt, ...);

@@ -1,7 +1,7 @@
 // kge_opt.hip -- dense optimiser sweeps with torch.optim default semantics (utils/trainer.py:112-131).
 // nn.Embedding is dense (models/Domain.py:8-13): Adam / Adagrad / RMSprop touch EVERY row every step, so the
 // sweep is a pure HBM stream: float4 per lane, grid-stride, (reads+writes) = 3 (SGD) .. 7 (Adam) floats per
-// parameter.  The gradient buffer is cleared in the same pass (optimizer.zero_grad(), utils/trainer.py:272).
+// parameter -- less where the gradient is zero: no clearing write, and for SGD / Adagrad nothing but the gradient read.  The gradient buffer is cleared in the same pass (optimizer.zero_grad(), utils/trainer.py:272).
 #include "kge_internal.h"
 #include "kge_opt_device.h"
 
@@ -42,8 +42,13 @@ __global__ __launch_bounds__(256) void k_opt(float* __restrict__ p, float* __res
     const int64_t nvec = numel / 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const float4 gv = reinterpret_cast<float4*>(g)[i];
+        const bool gzero = gv.x == 0.f && gv.y == 0.f && gv.z == 0.f && gv.w == 0.f;
+        // SGD / Adagrad with g == 0 leave parameter and state unchanged (p - lr*0/.. and s + 0*0): rows the batch did not
+        // touch -- almost all of a large table -- cost one gradient read instead of six streams.  Adam / RMSprop decay
+        // their moments for every row every step (dense nn.Embedding gradients, models/Domain.py:8-13) and take the full path.
+        if constexpr (KIND == KGE_OPT_SGD || KIND == KGE_OPT_ADAGRAD) { if (gzero) continue; }
         float4 pv = reinterpret_cast<float4*>(p)[i];
-        float4 gv = reinterpret_cast<float4*>(g)[i];
         float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
         if constexpr (KIND != KGE_OPT_SGD) av = reinterpret_cast<float4*>(s1)[i];
         if constexpr (KIND == KGE_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[i];
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256) void k_opt(float* __restrict__ p, float* __res
         reinterpret_cast<float4*>(p)[i] = pv;
         if constexpr (KIND != KGE_OPT_SGD) reinterpret_cast<float4*>(s1)[i] = av;
         if constexpr (KIND == KGE_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv;
-        if constexpr (ZERO) reinterpret_cast<float4*>(g)[i] = make_float4(0, 0, 0, 0);
+        if constexpr (ZERO) { if (!gzero) reinterpret_cast<float4*>(g)[i] = make_float4(0, 0, 0, 0); }   // already clear: no write
     }
     if (blockIdx.x == 0) {  // tail (numel % 4)
         const int64_t i = nvec * 4 + threadIdx.x;

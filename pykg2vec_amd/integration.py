@@ -73,6 +73,8 @@ def reference_trainer(backend=None, process_group=None, use_graph=None):
     for name, fn in vars(Hip).items():
         if isinstance(fn, types.FunctionType) and name not in vars(Trainer) and \
                 (name.startswith("_") and not name.startswith("__") or name in ("train_model_epoch", "train_step_pairwise",
-                                                                                 "train_step_pointwise")):
+                                                                                 "train_step_pointwise", "step_next_batch",
+                                                                                 "step_next_batches", "pull_step_explicit",
+                                                                                 "sync_model")):
             setattr(Trainer, name, fn)
     return Trainer

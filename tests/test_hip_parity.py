@@ -567,6 +567,36 @@ def test_head_1n_vs_oracle_other_shapes(hip, B, E, d, with_bias):
     assert np.allclose(g_ent.cpu().numpy(), ge_ref, atol=1e-3 * scale, rtol=1e-3)
 
 
+@pytest.mark.parametrize("B,E,d", [(300, 1000, 40), (129, 257, 4), (2048, 14951, 200)])
+def test_head_1n_large_tile_equals_small_tile(hip, monkeypatch, B, E, d):
+    """The 128 x 128 macro-tile GEMM (large batches) keeps the k order of the 64 x 64 one: identical predictions, and the
+    fused head + BCE entry point built on it agrees with the oracle."""
+    from pykg2vec_amd import kernels as K
+    rng = np.random.default_rng(B + E + d)
+    x = rng.normal(size=(B, d)).astype(np.float32)
+    ent = (rng.normal(size=(E, d)) * 0.2).astype(np.float32)
+    bias = (rng.normal(size=E) * 0.1).astype(np.float32)
+    xd, ed, bd = torch.from_numpy(x).cuda(), torch.from_numpy(ent).cuda(), torch.from_numpy(bias).cuda()
+    out = {}
+    for tile in ("0", "1"):
+        monkeypatch.setenv("KGE_HEAD_TILE", tile)
+        out[tile] = K.head_1n_forward(xd, ed, bd)
+    assert torch.equal(out["0"], out["1"])
+    p_ref = ko.head_1n_forward(x, ent, bias)
+    assert close(out["1"].cpu().numpy(), p_ref, atol=2e-6)
+    lab = (rng.random((B, E)) < 0.01).astype(np.float32)
+    loss_ref, dp = ko.multi_class_bce_dir(p_ref, lab, 0.1, E)
+    dx_ref, ge_ref, _ = ko.head_1n_backward(x, ent, p_ref, dp)
+    off, ids = _csr_of(lab)
+    loss_buf = K.new_loss_buffer("cuda")
+    g_ent = torch.zeros_like(ed)
+    dx = K.head_1n_bce(xd, ed, bd, torch.from_numpy(off).cuda(), torch.from_numpy(ids).cuda(), 0.1, loss_buf, g_ent, torch.zeros(E, device="cuda"))
+    scale = 1.0 / (B * E)
+    assert np.isclose(K.read_loss(loss_buf).item(), loss_ref, rtol=2e-5)
+    assert np.allclose(dx.cpu().numpy(), dx_ref, atol=1e-3 * scale, rtol=1e-3)
+    assert np.allclose(g_ent.cpu().numpy(), ge_ref, atol=1e-3 * scale, rtol=1e-3)
+
+
 @pytest.mark.parametrize("name,neg", [("distmult", 1), ("complex", 3), ("analogy", 1), ("cp", 2), ("simple", 1), ("quate", 4)])
 def test_fused_pointwise_sampler_step_equals_sample_then_step(hip, name, neg):
     """kge_train_pointwise_logistic_sampled (corruption fused into the pointwise kernel) must see exactly the rows

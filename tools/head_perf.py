@@ -18,7 +18,7 @@ def bench(fn, n=50):
     return (time.perf_counter() - t0) / n * 1e6
 
 
-for B, E, d in ((128, 14951, 200), (1000, 14951, 200), (128, 40943, 200), (4096, 14951, 200)):
+for B, E, d in ((128, 14951, 200), (1000, 14951, 200), (128, 40943, 200), (4096, 14951, 200), (16384, 14951, 200)):
     rng = np.random.default_rng(0)
     x = torch.randn(B, d, device="cuda"); ent = torch.randn(E, d, device="cuda") * 0.2; bias = torch.randn(E, device="cuda") * 0.1
     lab = (torch.rand(B, E, device="cuda") < 0.002).float()

@@ -65,5 +65,17 @@ int main() {
     timeit("mfma_f32_32x32x2f32, 4 acc", [&](int g) { k_mfma32<4><<<g, 256>>>(out, in); }, (double)ITERS * 4 * 4096);
     timeit("mfma_f32_16x16x4f32, 4 acc", [&](int g) { k_mfma16<4><<<g, 256>>>(out, in); }, (double)ITERS * 4 * 2048);
     timeit("mfma_f32_16x16x4f32, 8 acc", [&](int g) { k_mfma16<8><<<g, 256>>>(out, in); }, (double)ITERS * 8 * 2048);
+    // sustained rate: the same 4-accumulator kernel back to back for ~0.2 s (clock / power management settles), reported per
+    // block of 50 launches -- what a long GEMM sweep can actually count on
+    printf("sustained, mfma_f32_32x32x2f32 4 acc, 4 waves/SIMD, blocks of 50 launches:");
+    for (int blk = 0; blk < 8; ++blk) {
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        CK(hipEventRecord(a));
+        for (int r = 0; r < 50; ++r) k_mfma32<4><<<1024, 256>>>(out, in);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        printf(" %.1f", (double)ITERS * 4 * 4096 * 4.0 * 1024 * 50 / (ms * 1e-3) / 1e12);
+    }
+    printf(" TFLOP/s\n");
     return 0;
 }
