@@ -341,6 +341,52 @@ size_t kge_pull_plan_bytes(void);   /* sizeof(kge_pull_plan): lets a binding che
 int kge_pull_run(const kge_pull_plan* plan, int64_t first_batch, int64_t n_steps, int32_t src_half, int32_t cur_list,
                  int32_t lists_ready, int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream);
 
+/* ---- Atomic-free ("staged") training step for the long-row bundle kernels (RotatE self-adversarial; replaces the dense
+ * gradient buffer + atomics of kge_train_pairwise_selfadv_sampled followed by kge_optimizer_step; same reference lines:
+ * data/generator.py:42-97, utils/trainer.py:147-157,298-299, utils/criterion.py:20-23, utils/trainer.py:112-131).
+ * The bundle kernel writes every gradient row it produces to its own slot of `stage` with plain stores:
+ *   positive i      -> static slots  i*static_slots + site          (RotatE: h_re, h_im, r, t_re, t_im)
+ *   negative pair p -> dynamic slots n_pos*static_slots + p*dynamic_slots + site   (RotatE: c_re, c_im), p = i*neg_rate + j,
+ * and registers pair p with the entity it drew (dyn_count / dyn_bucket[E][dyn_cap] / overflow chain dyn_head, dyn_next[p]).
+ * kge_optimizer_step_staged then owns one parameter row per wave: it sums the row's slots in ascending slot order --
+ * static incidences from the per-batch CSR (ent_off/ent_inc: positive << 1 | side, side 0 head / 1 tail; rel_off/rel_inc:
+ * positive), dynamic ones from the entity's bucket sorted by pair -- and applies the dense optimiser in place.  No gradient
+ * buffer, no atomics on floats, bit-reproducible.  Rows with no slot get g = 0 (Adam / RMSprop still update them; SGD /
+ * Adagrad leave them untouched, as torch.optim does for a zero dense gradient). */
+typedef struct kge_staged_table {
+    int32_t cls;            /* 0: entity table, 1: relation table */
+    int32_t site_a, site_b; /* static slot sites: entity tables head / tail incidence, relation tables site_a */
+    int32_t dsite;          /* dynamic slot site of an entity table (-1: the negatives never touch it) */
+    int64_t flat_off;       /* float offset of the table in the flat parameter / state buffers */
+    int64_t rows;
+} kge_staged_table;
+
+typedef struct kge_staged_step {
+    float* param; float* state1; float* state2;        /* flat fp32 buffers (state: as kge_optimizer_step) */
+    kge_staged_table tables[8];
+    int32_t n_tables, dim;                              /* all tables share the row length */
+    const int32_t* ent_off; const int32_t* ent_inc;     /* [E+1], [2 n_pos] */
+    const int32_t* rel_off; const int32_t* rel_inc;     /* [R+1], [n_pos] */
+    int32_t* dyn_count; int32_t* dyn_bucket; int32_t* dyn_head; int32_t* dyn_next; int32_t dyn_cap;
+    int32_t* dyn_count_next; int32_t* dyn_head_next;    /* the set the NEXT step registers into: cleared by the optimiser
+                                                           sweep of this step (NULL: the train entry point memsets its own) */
+    float* stage; int64_t stage_stride;                 /* floats between slots (>= dim, multiple of 4) */
+    int32_t static_slots, dynamic_slots;
+    int64_t n_pos, n_neg;                               /* positives / negative pairs of the batch */
+    int64_t tot_entity, tot_relation;
+} kge_staged_step;
+size_t kge_staged_step_bytes(void);
+
+/* kge_train_pairwise_selfadv_sampled with staged output (st->stage, st->dyn_*).  dyn_count / dyn_head must be clear on
+ * entry: either the previous kge_optimizer_step_staged cleared them (dyn_count_next / dyn_head_next of ITS plan pointed at
+ * them: two alternating sets) or, when st->dyn_count_next is NULL, this entry point memsets them itself. */
+int kge_train_pairwise_selfadv_sampled_staged(const kge_model_desc* m, const int64_t* triples, const int64_t* perm,
+                                              int64_t start, int64_t n_pos, int32_t neg_rate, float alpha,
+                                              const float* bern_prob, const uint64_t* slots, int64_t n_slots,
+                                              uint64_t seed, uint64_t offset, const kge_staged_step* st, float* loss,
+                                              void* stream);
+int kge_optimizer_step_staged(int32_t optimizer, const kge_staged_step* st, float lr, int64_t step, void* stream);
+
 /* ---- 1-N scoring head of the projection models (ConvE / TuckER / InteractE / HypER / AcrE:
  * projection.py:100-102, 335-336, 444-447, 606-609, 734-737):  preds[B,E] = sigmoid(x[B,dim] @ ent[E,dim]^T + bias[E]).
  * bias may be NULL (TuckER).  fp32 on the matrix cores. */

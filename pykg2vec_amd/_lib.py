@@ -63,7 +63,33 @@ class PullPlanC(ctypes.Structure):
                 ("bern_prob", ctypes.c_void_p), ("slots", ctypes.c_void_p), ("n_slots", ctypes.c_int64),
                 ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p)]
 
+class StagedTable(ctypes.Structure):
+    """struct kge_staged_table"""
+    _fields_ = [("cls", ctypes.c_int32), ("site_a", ctypes.c_int32), ("site_b", ctypes.c_int32), ("dsite", ctypes.c_int32),
+                ("flat_off", ctypes.c_int64), ("rows", ctypes.c_int64)]
+
+
+class StagedStep(ctypes.Structure):
+    """struct kge_staged_step"""
+    _fields_ = [("param", ctypes.c_void_p), ("state1", ctypes.c_void_p), ("state2", ctypes.c_void_p),
+                ("tables", StagedTable * 8), ("n_tables", ctypes.c_int32), ("dim", ctypes.c_int32),
+                ("ent_off", ctypes.c_void_p), ("ent_inc", ctypes.c_void_p), ("rel_off", ctypes.c_void_p), ("rel_inc", ctypes.c_void_p),
+                ("dyn_count", ctypes.c_void_p), ("dyn_bucket", ctypes.c_void_p), ("dyn_head", ctypes.c_void_p),
+                ("dyn_next", ctypes.c_void_p), ("dyn_cap", ctypes.c_int32),
+                ("dyn_count_next", ctypes.c_void_p), ("dyn_head_next", ctypes.c_void_p),
+                ("stage", ctypes.c_void_p), ("stage_stride", ctypes.c_int64),
+                ("static_slots", ctypes.c_int32), ("dynamic_slots", ctypes.c_int32),
+                ("n_pos", ctypes.c_int64), ("n_neg", ctypes.c_int64),
+                ("tot_entity", ctypes.c_int64), ("tot_relation", ctypes.c_int64)]
+
+
 _SIGNATURES = {
+    "kge_staged_step_bytes": (ctypes.c_size_t, []),
+    "kge_train_pairwise_selfadv_sampled_staged": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                                  ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p,
+                                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64,
+                                                                  ctypes.POINTER(StagedStep), ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_optimizer_step_staged": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(StagedStep), ctypes.c_float, ctypes.c_int64, ctypes.c_void_p]),
     "kge_abi_version": (ctypes.c_int, []),
     "kge_last_error": (ctypes.c_char_p, []),
     "kge_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc), ctypes.c_int64]),

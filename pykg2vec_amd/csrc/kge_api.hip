@@ -232,7 +232,45 @@ int kge_train_pairwise_selfadv_sampled(const kge_model_desc* m, const int64_t* t
     }
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_train_pairwise_selfadv_sampled: n_slots must be a power of two"); return -1; }
     return launch_rotate_bundle_sampled(m, triples, perm, start, n_pos, neg_rate, alpha, bern_prob, slots, n_slots, seed,
-                                        offset, dev_cursor, loss, (hipStream_t)stream);
+                                        offset, dev_cursor, loss, nullptr, (hipStream_t)stream);
+}
+
+size_t kge_staged_step_bytes(void) { return sizeof(kge_staged_step); }
+
+int kge_train_pairwise_selfadv_sampled_staged(const kge_model_desc* m, const int64_t* triples, const int64_t* perm,
+                                              int64_t start, int64_t n_pos, int32_t neg_rate, float alpha,
+                                              const float* bern_prob, const uint64_t* slots, int64_t n_slots, uint64_t seed,
+                                              uint64_t offset, const kge_staged_step* st, float* loss, void* stream) {
+    const char* who = "kge_train_pairwise_selfadv_sampled_staged";
+    if (validate(m, false, who)) return -1;
+    if (validate_packed_key(m, who)) return -1;
+    if (n_pos == 0) return 0;
+    if (n_pos < 0 || start < 0 || neg_rate <= 0 || !triples || !perm || !loss || !st) { set_error("%s: bad arguments", who); return -1; }
+    if (slots && (n_slots & (n_slots - 1))) { set_error("%s: n_slots must be a power of two", who); return -1; }
+    if (m->model != KGE_ROTATE) { set_error("%s: RotatE only", who); return -1; }
+    if (!st->stage || !st->dyn_count || !st->dyn_bucket || !st->dyn_head || !st->dyn_next || st->dyn_cap <= 0 ||
+        st->static_slots != 5 || st->dynamic_slots != 2 || st->stage_stride < m->dim || st->n_pos != n_pos ||
+        st->n_neg != n_pos * neg_rate || st->tot_entity != m->tot_entity) {
+        set_error("%s: staging plan does not match the batch (RotatE: 5 static + 2 dynamic slots)", who);
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (!st->dyn_count_next) {   // single registration set: clear it here (otherwise the previous optimiser sweep did)
+        hipError_t e = hipMemsetAsync(st->dyn_count, 0, (size_t)m->tot_entity * sizeof(int32_t), s);
+        if (e == hipSuccess) e = hipMemsetAsync(st->dyn_head, 0xFF, (size_t)m->tot_entity * sizeof(int32_t), s);
+        if (e != hipSuccess) { set_error("%s: memset: %s", who, hipGetErrorString(e)); return -2; }
+    }
+    StageSink sink;
+    sink.stage = st->stage; sink.stride = st->stage_stride;
+    sink.count = st->dyn_count; sink.bucket = st->dyn_bucket; sink.head = st->dyn_head; sink.next = st->dyn_next; sink.cap = st->dyn_cap;
+    sink.ns = st->static_slots; sink.nd = st->dynamic_slots;
+    return launch_rotate_bundle_sampled(m, triples, perm, start, n_pos, neg_rate, alpha, bern_prob, slots, n_slots, seed,
+                                        offset, nullptr, loss, &sink, s);
+}
+
+int kge_optimizer_step_staged(int32_t optimizer, const kge_staged_step* st, float lr, int64_t step, void* stream) {
+    if (step < 1) { set_error("kge_optimizer_step_staged: step counts from 1"); return -1; }
+    return launch_optimizer_staged(optimizer, st, lr, step, (hipStream_t)stream);
 }
 
 int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,

@@ -80,6 +80,15 @@ __device__ __forceinline__ void atomic_add_row(float* __restrict__ row, const fl
     }
 }
 
+template <int G, int NCH>
+__device__ __forceinline__ void store_row(float* __restrict__ row, const float (&g)[NCH], int dim, int gl) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        int e = c * G + gl;
+        if (e < dim) row[e] = g[c];
+    }
+}
+
 // ------------------------------------------------------------------ roles: which table / which id a row comes from
 // role r of model M is row  tab[role_tab(M,r)][ id[role_sel(M,r)] ],  id = {h, r, t}
 __host__ __device__ constexpr int role_count(int M) {

@@ -46,10 +46,25 @@ int launch_pointwise_logistic_sampled(const kge_model_desc* m, const int64_t* tr
 int launch_selfadv_bundle(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
                           const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n_pos, int neg_rate,
                           float alpha, float* loss, hipStream_t s);  // returns 1 when neg_rate exceeds the group width
+// Staged (atomic-free) gradient output of the bundle kernels: every gradient row a bundle produces goes to its own slot of
+// a staging buffer with plain stores; kge_optimizer_step_staged (kge_staged.hip) sums the slots of each parameter row in a
+// fixed order inside the optimiser sweep.  Slots: positive i owns static slots [i*ns, (i+1)*ns); negative pair p owns
+// dynamic slots n_pos*ns + [p*nd, (p+1)*nd) and registers itself with the entity it drew (count / bucket / overflow chain).
+struct StageSink {
+    float* stage; int64_t stride;
+    int32_t* count; int32_t* bucket; int32_t* head; int32_t* next; int32_t cap;
+    int32_t ns, nd;
+};
+__device__ __forceinline__ void stage_register(const StageSink& k, int c, int pair) {
+    const int pos = atomicAdd(k.count + c, 1);
+    if (pos < k.cap) k.bucket[(int64_t)c * k.cap + pos] = pair;
+    else k.next[pair] = atomicExch(k.head + c, pair);
+}
 int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
                                  int64_t n_pos, int neg_rate, float alpha, const float* bern, const uint64_t* slots,
                                  int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor, float* loss,
-                                 hipStream_t s);
+                                 const StageSink* sink /* NULL: atomic scatter into m->grads */, hipStream_t s);
+int launch_optimizer_staged(int kind, const kge_staged_step* st, float lr, int64_t step, hipStream_t s);
 // kge_score_generic.hip: generic (roles-table) tail of the sampler-fused hinge step, after the shared-row specialisations
 struct FusedSampler;
 int launch_pairwise_hinge_sampled_generic(const kge_model_desc* m, Geometry geo, const FusedSampler& fs, int64_t n,

@@ -33,7 +33,7 @@ __device__ __forceinline__ void advance_state(const AdvanceArgs& v) {
     v.hout[2] = (float)sqrt(bc2);
 }
 
-template <int KIND, bool ZERO>
+template <int KIND, bool ZERO, bool NT>
 __global__ __launch_bounds__(256) void k_opt(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                              float* __restrict__ s2, int64_t numel, OptArgs a,
                                              const float* __restrict__ dev_hyper, AdvanceArgs adv) {
@@ -42,23 +42,23 @@ __global__ __launch_bounds__(256) void k_opt(float* __restrict__ p, float* __res
     const int64_t nvec = numel / 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-        const float4 gv = reinterpret_cast<float4*>(g)[i];
+        const float4 gv = stream_load<NT>(reinterpret_cast<const float4*>(g) + i);
         const bool gzero = gv.x == 0.f && gv.y == 0.f && gv.z == 0.f && gv.w == 0.f;
         // SGD / Adagrad with g == 0 leave parameter and state unchanged (p - lr*0/.. and s + 0*0): rows the batch did not
         // touch -- almost all of a large table -- cost one gradient read instead of six streams.  Adam / RMSprop decay
         // their moments for every row every step (dense nn.Embedding gradients, models/Domain.py:8-13) and take the full path.
         if constexpr (KIND == KGE_OPT_SGD || KIND == KGE_OPT_ADAGRAD) { if (gzero) continue; }
-        float4 pv = reinterpret_cast<float4*>(p)[i];
+        float4 pv = stream_load<NT>(reinterpret_cast<const float4*>(p) + i);
         float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
-        if constexpr (KIND != KGE_OPT_SGD) av = reinterpret_cast<float4*>(s1)[i];
-        if constexpr (KIND == KGE_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[i];
+        if constexpr (KIND != KGE_OPT_SGD) av = stream_load<NT>(reinterpret_cast<const float4*>(s1) + i);
+        if constexpr (KIND == KGE_OPT_ADAM) bv = stream_load<NT>(reinterpret_cast<const float4*>(s2) + i);
         opt_update<KIND>(pv.x, gv.x, av.x, bv.x, a);
         opt_update<KIND>(pv.y, gv.y, av.y, bv.y, a);
         opt_update<KIND>(pv.z, gv.z, av.z, bv.z, a);
         opt_update<KIND>(pv.w, gv.w, av.w, bv.w, a);
-        reinterpret_cast<float4*>(p)[i] = pv;
-        if constexpr (KIND != KGE_OPT_SGD) reinterpret_cast<float4*>(s1)[i] = av;
-        if constexpr (KIND == KGE_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv;
+        reinterpret_cast<float4*>(p)[i] = pv;   // (the next step gathers parameter rows: plain store)
+        if constexpr (KIND != KGE_OPT_SGD) stream_store<NT>(reinterpret_cast<float4*>(s1) + i, av);
+        if constexpr (KIND == KGE_OPT_ADAM) stream_store<NT>(reinterpret_cast<float4*>(s2) + i, bv);
         if constexpr (ZERO) { if (!gzero) reinterpret_cast<float4*>(g)[i] = make_float4(0, 0, 0, 0); }   // already clear: no write
     }
     if (blockIdx.x == 0) {  // tail (numel % 4)
@@ -82,10 +82,18 @@ static int launch_kind(float* p, float* g, float* s1, float* s2, int64_t numel, 
     int64_t blocks = (numel / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (zero)
-        hipLaunchKernelGGL((k_opt<KIND, true>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh, adv);
+    // parameters + gradient + state beyond the 256 MB Infinity Cache: stream them non-temporally (kge_opt_device.h)
+    const int streams = KIND == KGE_OPT_SGD ? 2 : KIND == KGE_OPT_ADAM ? 4 : 3;
+    const char* force = getenv("KGE_OPT_NT");
+    const bool nt = force ? force[0] == '1' : (int64_t)streams * numel * 4 > ((int64_t)256 << 20);
+    if (zero && nt)
+        hipLaunchKernelGGL((k_opt<KIND, true, true>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh, adv);
+    else if (zero)
+        hipLaunchKernelGGL((k_opt<KIND, true, false>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh, adv);
+    else if (nt)
+        hipLaunchKernelGGL((k_opt<KIND, false, true>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh, adv);
     else
-        hipLaunchKernelGGL((k_opt<KIND, false>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh, adv);
+        hipLaunchKernelGGL((k_opt<KIND, false, false>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh, adv);
     return check_launch("k_opt");
 }
 

@@ -29,6 +29,29 @@ __device__ __forceinline__ void opt_update(float& p, float g, float& s1, float& 
     }
 }
 
+// Streams that are read once and written once per step and do not fit any cache (optimiser state of tables beyond the
+// 256 MB Infinity Cache): non-temporal accesses.  Measured on the RotatE FB15k-237 d=1000 step (117 MB tables, Adam):
+// 264 -> 234 us per step (profiles/r02_experiments.md).
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 stream_load(const float4* ptr) {
+    if constexpr (NT) {
+        const nt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(ptr));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *ptr;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void stream_store(float4* ptr, const float4& v) {
+    if constexpr (NT) {
+        nt_f32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+        __builtin_nontemporal_store(w, reinterpret_cast<nt_f32x4*>(ptr));
+    } else {
+        *ptr = v;
+    }
+}
+
 // torch computes Adam's bias-correction scalars in double on the host, then applies them to fp32 tensors
 inline OptArgs make_opt_args(float lr, int64_t step) {
     OptArgs a;

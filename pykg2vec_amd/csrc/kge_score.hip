@@ -348,9 +348,9 @@ __global__ __launch_bounds__(kBlock) void k_transx_pair_sampled(DeviceModel m, i
 // Pass 1 scores, group softmax gives the detached self-adversarial weights (criterion.py:13-23), pass 2 re-gathers the
 // two rows per negative and back-propagates; gradients of the positive's five rows accumulate in registers and are
 // scattered once per bundle.
-template <int G, int NCH>
+template <int G, int NCH, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_rotate_bundle_sampled(DeviceModel m, int64_t n_pos, int neg_rate, float alpha,
-                                                                  float* __restrict__ loss, FusedSampler fs) {
+                                                                  float* __restrict__ loss, FusedSampler fs, StageSink sink) {
     constexpr int GPB = kBlock / G;
     const int gl = threadIdx.x % G;
     const int d = m.dim;
@@ -452,16 +452,35 @@ __global__ __launch_bounds__(kBlock) void k_rotate_bundle_sampled(DeviceModel m,
                     GP[k] += Rr * (-CR[k] * SN[k] - CI[k] * CS[k]) + Ii * (CR[k] * CS[k] - CI[k] * SN[k]);
                 }
             }
-            atomic_add_row<G, NCH>(m.grad[0] + c * (int64_t)d, gCR, d, gl);
-            atomic_add_row<G, NCH>(m.grad[1] + c * (int64_t)d, gCI, d, gl);
+            if constexpr (STAGED) {
+                // atomic-free form: the two gradient rows go to this negative's own staging slots with plain stores, and the
+                // pair is registered with entity c (whose owner sums its slots in kge_optimizer_step_staged)
+                const int64_t pair = i * neg_rate + j;
+                float* slot = sink.stage + (n_pos * sink.ns + pair * sink.nd) * sink.stride;
+                store_row<G, NCH>(slot, gCR, d, gl);
+                store_row<G, NCH>(slot + sink.stride, gCI, d, gl);
+                if (gl == 0) stage_register(sink, (int)c, (int)pair);
+            } else {
+                atomic_add_row<G, NCH>(m.grad[0] + c * (int64_t)d, gCR, d, gl);
+                atomic_add_row<G, NCH>(m.grad[1] + c * (int64_t)d, gCI, d, gl);
+            }
         }
 #pragma unroll
         for (int k = 0; k < NCH; ++k) GP[k] = GP[k] / m.phase_div;
-        atomic_add_row<G, NCH>(m.grad[0] + h * (int64_t)d, gHR, d, gl);
-        atomic_add_row<G, NCH>(m.grad[1] + h * (int64_t)d, gHI, d, gl);
-        atomic_add_row<G, NCH>(m.grad[2] + r * (int64_t)d, GP, d, gl);
-        atomic_add_row<G, NCH>(m.grad[0] + t * (int64_t)d, gTR, d, gl);
-        atomic_add_row<G, NCH>(m.grad[1] + t * (int64_t)d, gTI, d, gl);
+        if constexpr (STAGED) {   // static slots of positive i: h_re, h_im, r, t_re, t_im
+            float* slot = sink.stage + i * sink.ns * sink.stride;
+            store_row<G, NCH>(slot, gHR, d, gl);
+            store_row<G, NCH>(slot + sink.stride, gHI, d, gl);
+            store_row<G, NCH>(slot + 2 * sink.stride, GP, d, gl);
+            store_row<G, NCH>(slot + 3 * sink.stride, gTR, d, gl);
+            store_row<G, NCH>(slot + 4 * sink.stride, gTI, d, gl);
+        } else {
+            atomic_add_row<G, NCH>(m.grad[0] + h * (int64_t)d, gHR, d, gl);
+            atomic_add_row<G, NCH>(m.grad[1] + h * (int64_t)d, gHI, d, gl);
+            atomic_add_row<G, NCH>(m.grad[2] + r * (int64_t)d, GP, d, gl);
+            atomic_add_row<G, NCH>(m.grad[0] + t * (int64_t)d, gTR, d, gl);
+            atomic_add_row<G, NCH>(m.grad[1] + t * (int64_t)d, gTI, d, gl);
+        }
     }
     block_accumulate_loss<G>(acc, gl, loss);
 }
@@ -542,7 +561,7 @@ int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triple
 int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
                                  int64_t n_pos, int neg_rate, float alpha, const float* bern, const uint64_t* slots,
                                  int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor, float* loss,
-                                 hipStream_t s) {
+                                 const StageSink* sink, hipStream_t s) {
     Geometry geo;
     if (!geometry_for(m, &geo)) return -1;
     if (m->model != KGE_ROTATE) { set_error("kge_train_pairwise_selfadv_sampled: RotatE only"); return -1; }
@@ -555,7 +574,10 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
     fs.seed = seed; fs.offset = offset; fs.cursor = cursor;
 #define KGE_RB(G_, NCH_)                                                                                                      \
     if (geo.G == G_ && geo.NCH == NCH_) {                                                                                      \
-        k_rotate_bundle_sampled<G_, NCH_><<<dim3(Launch<KGE_ROTATE, G_, NCH_>::grid(n_pos)), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs); \
+        if (sink)                                                                                                              \
+            k_rotate_bundle_sampled<G_, NCH_, true><<<dim3(Launch<KGE_ROTATE, G_, NCH_>::grid(n_pos)), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs, *sink); \
+        else                                                                                                                   \
+            k_rotate_bundle_sampled<G_, NCH_, false><<<dim3(Launch<KGE_ROTATE, G_, NCH_>::grid(n_pos)), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs, StageSink{}); \
         return check_launch("k_rotate_bundle_sampled");                                                                        \
     }
     KGE_RB(32, 1) KGE_RB(32, 2) KGE_RB(32, 4) KGE_RB(32, 8) KGE_RB(64, 8) KGE_RB(64, 16)

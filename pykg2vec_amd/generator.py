@@ -154,6 +154,45 @@ class PullIndex:
                 self.items[self.item_off[b]:self.item_off[b + 1]], self.multi[self.multi_off[b]:self.multi_off[b + 1]])
 
 
+class StagedIndex:
+    """Static incidence CSR of every batch for the staged (atomic-free) bundle step (kge_optimizer_step_staged): per batch,
+    for every entity the positives it heads / tails (entries positive << 1 | side, ascending) and for every relation the
+    positives it labels.  Batches are fixed slices of the generator's permutation, so this is built once."""
+
+    MAX_BYTES = 1 << 30
+
+    def __init__(self, batches, tot_entity, tot_relation, device):
+        E, R = int(tot_entity), int(tot_relation)
+        ent_off, ent_inc, rel_off, rel_inc = [], [], [], []
+        for b in batches:
+            n = len(b)
+            i = np.arange(n, dtype=np.int64)
+            ent = np.concatenate([b[:, 0], b[:, 2]])
+            x = np.concatenate([i * 2, i * 2 + 1])
+            order = np.lexsort((x, ent))
+            ent_inc.append(x[order].astype(np.int32))
+            ent_off.append(np.concatenate([[0], np.cumsum(np.bincount(ent, minlength=E))]).astype(np.int32))
+            rel_inc.append(np.argsort(b[:, 1], kind="stable").astype(np.int32))
+            rel_off.append(np.concatenate([[0], np.cumsum(np.bincount(b[:, 1], minlength=R))]).astype(np.int32))
+        self.sizes = [len(b) for b in batches]
+        self.pos_off = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        self.E, self.R = E, R
+
+        def cat(xs):
+            return torch.from_numpy(np.concatenate(xs)).to(device)
+
+        self.ent_off, self.ent_inc, self.rel_off, self.rel_inc = cat(ent_off), cat(ent_inc), cat(rel_off), cat(rel_inc)
+
+    @classmethod
+    def fits(cls, n_batches, tot_entity, tot_relation):
+        return n_batches * (tot_entity + tot_relation + 2) * 4 <= cls.MAX_BYTES
+
+    def batch(self, b):
+        E, R, p = self.E, self.R, self.pos_off
+        return (self.ent_off[b * (E + 1):(b + 1) * (E + 1)], self.ent_inc[2 * p[b]:2 * p[b + 1]],
+                self.rel_off[b * (R + 1):(b + 1) * (R + 1)], self.rel_inc[p[b]:p[b + 1]], self.sizes[b])
+
+
 class Generator:
     def __init__(self, model, config, seed=None, rank=0, world_size=1, backend=K):
         self.K = backend
@@ -204,6 +243,15 @@ class Generator:
             self._pull_index = PullIndex(list(pos), self.config.tot_entity, self.config.tot_relation, self.device,
                                          groups_per_block=self.K.pull_groups_per_block(self.model.hidden_size))
         return self._pull_index
+
+    def staged_index(self):
+        """Static incidence CSR of every batch of the permutation, the short last one included (built on first use)."""
+        if getattr(self, "_staged_index", None) is None:
+            B = self.batch_size
+            pos = self._train_np[self._perm_np]
+            batches = [pos[lo:lo + B] for lo in range(0, self.n_train, B)]
+            self._staged_index = StagedIndex(batches, self.config.tot_entity, self.config.tot_relation, self.device)
+        return self._staged_index
 
     def __iter__(self):
         return self

@@ -162,6 +162,79 @@ def train_pairwise_selfadv_sampled(desc, triples, perm, start, n_pos, neg_rate, 
             "kge_train_pairwise_selfadv_sampled")
 
 
+STAGED_CAP = 16   # bucket entries per corrupting entity before the overflow chain
+
+
+class StagedPlan:
+    """struct kge_staged_step for one model: flat parameter / state buffers, the table list with its slot sites, the
+    staging buffer and the per-entity registration lists.  `bind(batch_index_views, n_pos)` points it at one batch."""
+
+    LAYOUTS = {   # model -> (static slots per positive, dynamic slots per negative, [(cls, site_a, site_b, dsite)] per table)
+        "rotate": (5, 2, [(0, 0, 3, 0), (0, 1, 4, 1), (1, 2, 0, -1)]),
+    }
+
+    def __init__(self, kernel_name, flat_param, state1, state2, table_offsets, table_rows, dim, tot_entity, tot_relation,
+                 max_pos, neg_rate):
+        ns, nd, sites = self.LAYOUTS[kernel_name]
+        if len(sites) != len(table_offsets):
+            raise KgeHipError("staged plan: table list does not match the model")
+        dev = flat_param.device
+        self.ns, self.nd, self.neg_rate, self.max_pos = ns, nd, int(neg_rate), int(max_pos)
+        self.stride = (int(dim) + 3) // 4 * 4
+        n_slots = self.max_pos * (ns + nd * self.neg_rate)
+        self.stage = torch.empty(n_slots * self.stride, dtype=torch.float32, device=dev)
+        # two registration sets (count, head) alternate between steps: the optimiser sweep of a step clears the other one
+        self.counts = [torch.zeros(tot_entity, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.heads = [torch.full((tot_entity,), -1, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.parity = 0
+        self.bucket = torch.zeros(tot_entity * STAGED_CAP, dtype=torch.int32, device=dev)
+        self.next = torch.zeros(self.max_pos * self.neg_rate, dtype=torch.int32, device=dev)
+        self._keep = (flat_param, state1, state2)
+        c = self.c = L.StagedStep()
+        c.param = _dev(flat_param, torch.float32, "param")
+        c.state1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
+        c.state2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
+        for k, ((cls, sa, sb, ds), off, rows) in enumerate(zip(sites, table_offsets, table_rows)):
+            c.tables[k].cls, c.tables[k].site_a, c.tables[k].site_b, c.tables[k].dsite = cls, sa, sb, ds
+            c.tables[k].flat_off, c.tables[k].rows = int(off), int(rows)
+        c.n_tables, c.dim = len(sites), int(dim)
+        c.dyn_bucket, c.dyn_next, c.dyn_cap = self.bucket.data_ptr(), self.next.data_ptr(), STAGED_CAP
+        c.stage, c.stage_stride = self.stage.data_ptr(), self.stride
+        c.static_slots, c.dynamic_slots = ns, nd
+        c.tot_entity, c.tot_relation = int(tot_entity), int(tot_relation)
+
+    def bind(self, ent_off, ent_inc, rel_off, rel_inc, n_pos):
+        if n_pos > self.max_pos:
+            raise KgeHipError("staged plan: batch larger than the plan")
+        self._batch = (ent_off, ent_inc, rel_off, rel_inc)
+        c = self.c
+        c.ent_off, c.ent_inc = _dev(ent_off, torch.int32, "ent_off"), _dev(ent_inc, torch.int32, "ent_inc")
+        c.rel_off, c.rel_inc = _dev(rel_off, torch.int32, "rel_off"), _dev(rel_inc, torch.int32, "rel_inc")
+        c.n_pos, c.n_neg = int(n_pos), int(n_pos) * self.neg_rate
+        # this step registers into set `parity`; its optimiser sweep clears the other set for the next step
+        q = self.parity
+        c.dyn_count, c.dyn_head = self.counts[q].data_ptr(), self.heads[q].data_ptr()
+        c.dyn_count_next, c.dyn_head_next = self.counts[q ^ 1].data_ptr(), self.heads[q ^ 1].data_ptr()
+        self.parity ^= 1
+        return self
+
+
+def train_pairwise_selfadv_sampled_staged(desc, triples, perm, start, n_pos, neg_rate, alpha, bern_prob, slots, seed, offset,
+                                          plan, loss_buf):
+    """RotatE bundle step with staged (atomic-free) gradient output; follow with optimizer_step_staged(plan)."""
+    bp = _dev(bern_prob, torch.float32, "bern_prob") if bern_prob is not None else None
+    sp = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
+    L.check(L.load().kge_train_pairwise_selfadv_sampled_staged(
+        ctypes.byref(desc), _ids(triples, "triples"), _ids(perm, "perm"), int(start), int(n_pos), int(neg_rate), float(alpha),
+        bp, sp, slots.numel() if slots is not None else 0, int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+        ctypes.byref(plan.c), _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_train_pairwise_selfadv_sampled_staged")
+
+
+def optimizer_step_staged(kind, plan, lr, step):
+    L.check(L.load().kge_optimizer_step_staged(OPTIMIZER_IDS[kind], ctypes.byref(plan.c), float(lr), int(step), _stream()),
+            "kge_optimizer_step_staged")
+
+
 def train_pairwise_selfadv(desc, ph, pr, pt, nh, nr, nt, neg_rate, alpha, loss_buf, workspace=None):
     n = ph.numel()
     if nh.numel() != n * neg_rate:

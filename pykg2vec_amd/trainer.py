@@ -40,6 +40,7 @@ class FlatState:
         for p in params:
             offs.append(tot)
             tot += (p.numel() + 3) // 4 * 4
+        self.offsets = offs   # float offset of every table in the flat buffers
         quantum = 4 * world_size
         tot = (tot + quantum - 1) // quantum * quantum
         self.numel = tot
@@ -342,6 +343,49 @@ class Trainer:
         ps.cur = 1
         ps.sync_out()
 
+    # ------------------------------------------------------------------ staged (atomic-free) step of the long-row bundle kernels
+    def _staged_ok(self):
+        """RotatE self-adversarial step without a gradient buffer: the bundle kernel stages its gradient rows with plain
+        stores and the optimiser sweep sums them per parameter row in a fixed order (csrc/kge_staged.hip) -- no fp32
+        atomics, bit-reproducible.  Single GPU, batches beyond the launch-bound graph regime; KGE_STAGED=0 / 1 overrides."""
+        import os
+        from .generator import StagedIndex
+        if not (self.K is K and self.world_size == 1 and self.generator is not None and self._fused_rotate_ok()):
+            return False
+        dims = {p.weight.shape[1] for p in self.model.parameter_list}
+        if len(dims) != 1 or self.model.hidden_size % 4 or self.model.hidden_size > 2048:
+            return False
+        nb = (self.generator.n_train + self.generator.batch_size - 1) // self.generator.batch_size
+        if not StagedIndex.fits(nb, self.config.tot_entity, self.config.tot_relation):
+            return False
+        env = os.environ.get("KGE_STAGED")
+        if env is not None:
+            return env == "1"
+        return self.config.batch_size * (1 + int(self.config.neg_rate)) > self.GRAPH_MAX_ROWS
+
+    def _staged_plan(self):
+        if getattr(self, "_staged", None) is None:
+            cfg, flat = self.config, self.flat
+            rows = [p.weight.shape[0] for p in self.model.parameter_list]
+            self._staged = K.StagedPlan(self.model.kernel_name, flat.param, flat.state1, flat.state2, flat.offsets, rows,
+                                        self.model.hidden_size, cfg.tot_entity, cfg.tot_relation, cfg.batch_size,
+                                        int(cfg.neg_rate))
+        return self._staged
+
+    def _staged_step(self):
+        gen, cfg = self.generator, self.config
+        b = gen._batch_idx
+        start, n, offset = gen._next_range()
+        if n <= 0:
+            return
+        ent_off, ent_inc, rel_off, rel_inc, n_idx = gen.staged_index().batch(b)
+        assert n_idx == n
+        plan = self._staged_plan().bind(ent_off, ent_inc, rel_off, rel_inc, n)
+        K.train_pairwise_selfadv_sampled_staged(self._desc, gen.triples, gen.perm, start, n, gen.neg_rate, cfg.alpha, gen.bern,
+                                                gen.slots, gen.seed, offset, plan, self.loss_buf)
+        self.flat.step += 1
+        K.optimizer_step_staged(cfg.optimizer, plan, cfg.learning_rate, self.flat.step)
+
     def sync_model(self):
         """After stepping: make the model's parameters (FlatState.param) hold the current tables."""
         if getattr(self, "_pull", None) is not None:
@@ -359,6 +403,10 @@ class Trainer:
         if getattr(self, "_pull", None) is not None:   # leaving the pull path (a short last batch): hand the tables back
             self.sync_model()
             self._pull = None
+        if self._staged_ok():
+            for _ in range(n):
+                self._staged_step()
+            return
         for _ in range(n):
             self._accumulate_next_batch()
             self._reduce_and_step()

@@ -1,0 +1,102 @@
+"""The staged (atomic-free) RotatE training step (csrc/kge_staged.hip + the STAGED form of k_rotate_bundle_sampled):
+gradient rows are stored once per bundle slot and summed per parameter row inside the optimiser sweep.  Held to (a) the
+push path (atomic scatter + dense sweep) on the batches the fused sampler draws, (b) the numpy oracle's dense gradient
+of the same sampled batch (through an SGD step with lr = 1), (c) itself, bit for bit, across runs."""
+import numpy as np
+import pytest
+import torch
+
+import kge_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import hip_util
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return hip_util
+
+
+def _world(E, R, D, n_train, seed=7):
+    rng = np.random.default_rng(seed)
+    train = np.stack([rng.integers(E, size=n_train), rng.integers(R, size=n_train), rng.integers(E, size=n_train)], 1)
+    test = np.stack([rng.integers(E, size=8), rng.integers(R, size=8), rng.integers(E, size=8)], 1)
+    P = ko.init_params("rotate", rng, tot_entity=E, tot_relation=R, hidden_size=D, margin=6.0)
+    return train, test, P
+
+
+def _trainer(hip, world, E, R, D, B, neg, opt, staged, monkeypatch, lr=0.01):
+    from pykg2vec_amd.trainer import Trainer
+    train, test, P = world
+    hp = dict(hidden_size=D, margin=6.0, neg_rate=neg, alpha=0.5)
+    cfg = hip.make_config(E, R, hp, train, test, test, optimizer=opt, lr=lr, batch_size=B)
+    m = hip.model_from_params("rotate", P, hp, E, R)
+    monkeypatch.setenv("KGE_STAGED", "1" if staged else "0")
+    tr = Trainer(m, cfg, use_graph=False)
+    tr.build_model()
+    tr.generator = tr._new_generator()
+    assert tr._staged_ok() == staged
+    return tr, m
+
+
+def _run(tr, m, hip, n_steps):
+    from pykg2vec_amd import kernels as K
+    tr.generator.start_one_epoch(n_steps)
+    tr.loss_buf.zero_()
+    tr.step_next_batches(n_steps)
+    tr.sync_model()
+    return K.read_loss(tr.loss_buf).item(), {k: p.detach().clone() for k, p in hip.table_parameters(m)}
+
+
+@pytest.mark.parametrize("E,R,D,B,neg,steps", [(53, 7, 40, 32, 4, 3),        # toy: short last batch included (n_train 80)
+                                               (12, 2, 8, 32, 8, 2),         # every entity drawn > 16 times: overflow chains (E large enough for the
+                                                                             # train-set rejection to find negatives)
+                                               (2000, 37, 1000, 256, 16, 2)])  # C3 row length and negative rate
+@pytest.mark.parametrize("opt", ["sgd", "adam", "adagrad", "rms"])
+def test_staged_steps_equal_push_steps(hip, monkeypatch, E, R, D, B, neg, steps, opt):
+    world = _world(E, R, D, (80 if E > 12 else 40) if B == 32 else 3 * B)
+    res = {}
+    for staged in (False, True):
+        tr, m = _trainer(hip, world, E, R, D, B, neg, opt, staged, monkeypatch)
+        res[staged] = _run(tr, m, hip, steps)
+    assert np.isclose(res[True][0], res[False][0], rtol=2e-5), (res[True][0], res[False][0])
+    for k in res[True][1]:
+        a, b = res[True][1][k].cpu().numpy(), res[False][1][k].cpu().numpy()
+        bad = ~np.isclose(a, b, atol=2e-5, rtol=1e-4)
+        # Adam / Adagrad / RMSprop divide by sqrt(accumulated g^2): a gradient entry that is pure rounding residue (sums that
+        # cancel in one order and not in the other) moves the parameter by O(lr) either way; such entries are rare
+        lim = 0.0 if opt == "sgd" else 2e-3
+        assert bad.mean() <= lim, (opt, k, bad.mean(), np.abs(a - b).max())
+
+
+def test_staged_training_is_bit_reproducible(hip, monkeypatch):
+    E, R, D, B, neg = 2000, 37, 1000, 256, 16
+    world = _world(E, R, D, 3 * B)
+    out = []
+    for _ in range(2):
+        tr, m = _trainer(hip, world, E, R, D, B, neg, "adam", True, monkeypatch)
+        out.append(_run(tr, m, hip, 3))
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
+def test_staged_gradient_matches_oracle(hip, monkeypatch):
+    """One SGD step with lr = 1 turns the staged path into its own gradient: p_before - p_after must be the oracle's dense
+    gradient of the batch the sampler drew (kge_sample_batch with the same counters)."""
+    from pykg2vec_amd import kernels as K
+    E, R, D, B, neg = 300, 11, 64, 128, 8
+    world = _world(E, R, D, B)
+    tr, m = _trainer(hip, world, E, R, D, B, neg, "sgd", True, monkeypatch, lr=1.0)
+    before = {k[:-len(".weight")]: p.detach().cpu().numpy().copy() for k, p in hip.table_parameters(m)}
+    gen = tr.generator
+    ph, pr, pt, nh, nr, nt = [x.cpu().numpy() for x in
+                              K.sample_batch(gen.triples, gen.perm, 0, B, neg, E, gen.bern, gen.slots, gen.seed, 0)]
+    loss, after = _run(tr, m, hip, 1)
+    want_loss, grads, _, _ = ko.train_step_grads("rotate", before, (ph, pr, pt, nh, nr, nt), hidden_size=D, margin=6.0,
+                                                 neg_rate=neg, alpha=0.5)
+    assert np.isclose(loss, want_loss, rtol=2e-5)
+    for k in before:
+        got = before[k] - after[k + ".weight"].cpu().numpy()
+        assert np.allclose(got, grads[k], atol=2e-6, rtol=2e-4), (k, np.abs(got - grads[k]).max())
