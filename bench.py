@@ -255,7 +255,9 @@ def run_extra_config(key, device):
         ev.rank_all(q, len(q))
     torch.cuda.synchronize()
     edt = (time.perf_counter() - t0) / reps
-    out = {"workload": c["name"], "mode": "hipGraph replay" if tr._graph is not None else "eager",
+    out = {"workload": c["name"],
+           "mode": ("hipGraph replay" if tr._graph is not None else
+                    "eager, staged gradients (no atomics, kge_optimizer_step_staged)" if getattr(tr, "_staged", None) is not None else "eager"),
            "step_us": dt * 1e6, "scored_triples_per_s": rows / dt,
            "train_algorithmic_GBps_whole_step": rows * c["train_bytes"] / dt / 1e9,
            "train_hbm_frac_whole_step": rows * c["train_bytes"] / dt / 1e9 / HBM_PEAK_GBS,

@@ -367,6 +367,12 @@ typedef struct kge_staged_step {
     int32_t n_tables, dim;                              /* all tables share the row length */
     const int32_t* ent_off; const int32_t* ent_inc;     /* [E+1], [2 n_pos] */
     const int32_t* rel_off; const int32_t* rel_inc;     /* [R+1], [n_pos] */
+    /* optional pre-reduction of long relation lists (a graph with a handful of relations funnels thousands of slots into
+     * one row): relation r's list is cut into chunks of 32 slots, chunk ids [rel_chunk_off[r], rel_chunk_off[r+1]);
+     * chunk_rel[c] = the relation of chunk c; one wave per (chunk, relation table) sums its slots into rel_partials
+     * [n_chunks][#relation tables][stage_stride] and the optimiser sums a relation row's partials in chunk order.
+     * rel_chunk_off == NULL: relation rows are summed slot by slot like entity rows. */
+    const int32_t* rel_chunk_off; const int32_t* chunk_rel; float* rel_partials; int32_t n_chunks;
     int32_t* dyn_count; int32_t* dyn_bucket; int32_t* dyn_head; int32_t* dyn_next; int32_t dyn_cap;
     int32_t* dyn_count_next; int32_t* dyn_head_next;    /* the set the NEXT step registers into: cleared by the optimiser
                                                            sweep of this step (NULL: the train entry point memsets its own) */
@@ -385,6 +391,13 @@ int kge_train_pairwise_selfadv_sampled_staged(const kge_model_desc* m, const int
                                               const float* bern_prob, const uint64_t* slots, int64_t n_slots,
                                               uint64_t seed, uint64_t offset, const kge_staged_step* st, float* loss,
                                               void* stream);
+/* kge_train_pointwise_logistic_sampled with staged output, DistMult (3 static + 1 dynamic slots: h, r, t | c) and ComplEx /
+ * ComplexN3 (6 + 2: h_re, h_im, r_re, r_im, t_re, t_im | c_re, c_im).  Same clearing contract as above. */
+int kge_train_pointwise_logistic_sampled_staged(const kge_model_desc* m, const int64_t* triples, const int64_t* perm,
+                                                int64_t start, int64_t n_pos, int32_t neg_rate, const float* bern_prob,
+                                                const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset,
+                                                float lmbda, int32_t reg_type, const kge_staged_step* st, float* loss,
+                                                void* stream);
 int kge_optimizer_step_staged(int32_t optimizer, const kge_staged_step* st, float lr, int64_t step, void* stream);
 
 /* ---- 1-N scoring head of the projection models (ConvE / TuckER / InteractE / HypER / AcrE:

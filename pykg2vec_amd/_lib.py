@@ -74,6 +74,8 @@ class StagedStep(ctypes.Structure):
     _fields_ = [("param", ctypes.c_void_p), ("state1", ctypes.c_void_p), ("state2", ctypes.c_void_p),
                 ("tables", StagedTable * 8), ("n_tables", ctypes.c_int32), ("dim", ctypes.c_int32),
                 ("ent_off", ctypes.c_void_p), ("ent_inc", ctypes.c_void_p), ("rel_off", ctypes.c_void_p), ("rel_inc", ctypes.c_void_p),
+                ("rel_chunk_off", ctypes.c_void_p), ("chunk_rel", ctypes.c_void_p), ("rel_partials", ctypes.c_void_p),
+                ("n_chunks", ctypes.c_int32),
                 ("dyn_count", ctypes.c_void_p), ("dyn_bucket", ctypes.c_void_p), ("dyn_head", ctypes.c_void_p),
                 ("dyn_next", ctypes.c_void_p), ("dyn_cap", ctypes.c_int32),
                 ("dyn_count_next", ctypes.c_void_p), ("dyn_head_next", ctypes.c_void_p),
@@ -89,6 +91,11 @@ _SIGNATURES = {
                                                                   ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p,
                                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64,
                                                                   ctypes.POINTER(StagedStep), ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_train_pointwise_logistic_sampled_staged": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                                    ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                                                    ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_float,
+                                                                    ctypes.c_int32, ctypes.POINTER(StagedStep), ctypes.c_void_p,
+                                                                    ctypes.c_void_p]),
     "kge_optimizer_step_staged": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(StagedStep), ctypes.c_float, ctypes.c_int64, ctypes.c_void_p]),
     "kge_abi_version": (ctypes.c_int, []),
     "kge_last_error": (ctypes.c_char_p, []),

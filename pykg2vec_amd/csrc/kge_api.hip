@@ -235,6 +235,25 @@ int kge_train_pairwise_selfadv_sampled(const kge_model_desc* m, const int64_t* t
                                         offset, dev_cursor, loss, nullptr, (hipStream_t)stream);
 }
 
+static int staged_sink(const kge_model_desc* m, const kge_staged_step* st, int64_t n_pos, int32_t neg_rate, int ns, int nd,
+                       const char* who, hipStream_t s, StageSink* sink) {
+    if (!st->stage || !st->dyn_count || !st->dyn_bucket || !st->dyn_head || !st->dyn_next || st->dyn_cap <= 0 ||
+        st->static_slots != ns || st->dynamic_slots != nd || st->stage_stride < m->dim || st->n_pos != n_pos ||
+        st->n_neg != n_pos * neg_rate || st->tot_entity != m->tot_entity) {
+        set_error("%s: staging plan does not match the batch (%d static + %d dynamic slots)", who, ns, nd);
+        return -1;
+    }
+    if (!st->dyn_count_next) {   // single registration set: clear it here (otherwise the previous optimiser sweep did)
+        hipError_t e = hipMemsetAsync(st->dyn_count, 0, (size_t)m->tot_entity * sizeof(int32_t), s);
+        if (e == hipSuccess) e = hipMemsetAsync(st->dyn_head, 0xFF, (size_t)m->tot_entity * sizeof(int32_t), s);
+        if (e != hipSuccess) { set_error("%s: memset: %s", who, hipGetErrorString(e)); return -2; }
+    }
+    sink->stage = st->stage; sink->stride = st->stage_stride;
+    sink->count = st->dyn_count; sink->bucket = st->dyn_bucket; sink->head = st->dyn_head; sink->next = st->dyn_next;
+    sink->cap = st->dyn_cap; sink->ns = st->static_slots; sink->nd = st->dynamic_slots;
+    return 0;
+}
+
 size_t kge_staged_step_bytes(void) { return sizeof(kge_staged_step); }
 
 int kge_train_pairwise_selfadv_sampled_staged(const kge_model_desc* m, const int64_t* triples, const int64_t* perm,
@@ -248,24 +267,33 @@ int kge_train_pairwise_selfadv_sampled_staged(const kge_model_desc* m, const int
     if (n_pos < 0 || start < 0 || neg_rate <= 0 || !triples || !perm || !loss || !st) { set_error("%s: bad arguments", who); return -1; }
     if (slots && (n_slots & (n_slots - 1))) { set_error("%s: n_slots must be a power of two", who); return -1; }
     if (m->model != KGE_ROTATE) { set_error("%s: RotatE only", who); return -1; }
-    if (!st->stage || !st->dyn_count || !st->dyn_bucket || !st->dyn_head || !st->dyn_next || st->dyn_cap <= 0 ||
-        st->static_slots != 5 || st->dynamic_slots != 2 || st->stage_stride < m->dim || st->n_pos != n_pos ||
-        st->n_neg != n_pos * neg_rate || st->tot_entity != m->tot_entity) {
-        set_error("%s: staging plan does not match the batch (RotatE: 5 static + 2 dynamic slots)", who);
-        return -1;
-    }
     hipStream_t s = (hipStream_t)stream;
-    if (!st->dyn_count_next) {   // single registration set: clear it here (otherwise the previous optimiser sweep did)
-        hipError_t e = hipMemsetAsync(st->dyn_count, 0, (size_t)m->tot_entity * sizeof(int32_t), s);
-        if (e == hipSuccess) e = hipMemsetAsync(st->dyn_head, 0xFF, (size_t)m->tot_entity * sizeof(int32_t), s);
-        if (e != hipSuccess) { set_error("%s: memset: %s", who, hipGetErrorString(e)); return -2; }
-    }
     StageSink sink;
-    sink.stage = st->stage; sink.stride = st->stage_stride;
-    sink.count = st->dyn_count; sink.bucket = st->dyn_bucket; sink.head = st->dyn_head; sink.next = st->dyn_next; sink.cap = st->dyn_cap;
-    sink.ns = st->static_slots; sink.nd = st->dynamic_slots;
+    const int rc = staged_sink(m, st, n_pos, neg_rate, 5, 2, who, s, &sink);
+    if (rc) return rc;
     return launch_rotate_bundle_sampled(m, triples, perm, start, n_pos, neg_rate, alpha, bern_prob, slots, n_slots, seed,
                                         offset, nullptr, loss, &sink, s);
+}
+
+int kge_train_pointwise_logistic_sampled_staged(const kge_model_desc* m, const int64_t* triples, const int64_t* perm,
+                                                int64_t start, int64_t n_pos, int32_t neg_rate, const float* bern_prob,
+                                                const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset,
+                                                float lmbda, int32_t reg_type, const kge_staged_step* st, float* loss,
+                                                void* stream) {
+    const char* who = "kge_train_pointwise_logistic_sampled_staged";
+    if (validate(m, false, who)) return -1;
+    if (validate_packed_key(m, who)) return -1;
+    if (n_pos == 0) return 0;
+    if (n_pos < 0 || neg_rate < 1 || start < 0 || !triples || !perm || !loss || !st) { set_error("%s: bad arguments", who); return -1; }
+    if (slots && (n_slots & (n_slots - 1))) { set_error("%s: n_slots must be a power of two", who); return -1; }
+    if (reg_type < KGE_REG_NONE || reg_type > KGE_REG_ID_N3) { set_error("%s: bad reg_type %d", who, reg_type); return -1; }
+    if (m->model != KGE_DISTMULT && m->model != KGE_COMPLEX) { set_error("%s: DistMult / ComplEx only", who); return -1; }
+    StageSink sink;
+    const int rc = staged_sink(m, st, n_pos, neg_rate, m->model == KGE_COMPLEX ? 6 : 3, m->model == KGE_COMPLEX ? 2 : 1, who,
+                               (hipStream_t)stream, &sink);
+    if (rc) return rc;
+    return launch_pointwise_logistic_sampled_staged(m, triples, perm, start, n_pos, neg_rate, bern_prob, slots, n_slots, seed,
+                                                    offset, lmbda, reg_type, loss, sink, (hipStream_t)stream);
 }
 
 int kge_optimizer_step_staged(int32_t optimizer, const kge_staged_step* st, float lr, int64_t step, void* stream) {

@@ -65,6 +65,10 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
                                  int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor, float* loss,
                                  const StageSink* sink /* NULL: atomic scatter into m->grads */, hipStream_t s);
 int launch_optimizer_staged(int kind, const kge_staged_step* st, float lr, int64_t step, hipStream_t s);
+int launch_pointwise_logistic_sampled_staged(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
+                                             int64_t n_pos, int neg_rate, const float* bern, const uint64_t* slots,
+                                             int64_t n_slots, uint64_t seed, uint64_t offset, float lmbda, int reg_type,
+                                             float* loss, const StageSink& sink, hipStream_t s);
 // kge_score_generic.hip: generic (roles-table) tail of the sampler-fused hinge step, after the shared-row specialisations
 struct FusedSampler;
 int launch_pairwise_hinge_sampled_generic(const kge_model_desc* m, Geometry geo, const FusedSampler& fs, int64_t n,

@@ -222,12 +222,24 @@ static inline int rel_span_host(int model, int dim) {
 // the same few rows -- thousands of same-address float atomics that the memory side serialises.  When R * rel_span floats
 // fit in LDS the workgroup accumulates all relation rows there (ds_add_f32) and flushes the non-zero entries once at
 // the end: each global relation-gradient address then receives one atomic per workgroup instead of one per bundle.
-template <int M, int G, int NCH, bool LDSREL>
+// position of role q among the roles that take their id from the same triple slot (h / r / t): the dynamic staging site
+__host__ __device__ constexpr int role_rank_in_sel(int M, int q) {
+    int k = 0;
+    for (int j = 0; j < q; ++j) k += role_sel(M, j) == role_sel(M, q) ? 1 : 0;
+    return k;
+}
+
+// STAGED (sampler-fused, one bundle per lane group, no LDS relation accumulation): instead of atomics into dense gradient
+// tables every gradient row goes to its own staging slot with plain stores (kge_internal.h: StageSink) -- the bundle's
+// anchor rows (all roles of the positive, with the negatives' contributions to shared rows merged in registers) to static
+// slots b * NR + role, the rows of a negative's corrupted entity to dynamic slots, registered with that entity.
+template <int M, int G, int NCH, bool LDSREL, bool STAGED = false>
 __global__ __launch_bounds__(kBlock) void k_pointwise_bundle(DeviceModel m, const int64_t* __restrict__ h,
                                                              const int64_t* __restrict__ r, const int64_t* __restrict__ t,
                                                              const int64_t* __restrict__ y, int64_t n, int bundle, int CHB,
                                                              float lmbda, int reg_type, float* __restrict__ loss,
-                                                             int64_t tot_relation, FusedSampler fs) {
+                                                             int64_t tot_relation, FusedSampler fs, StageSink sink = StageSink{}) {
+    static_assert(!(STAGED && LDSREL), "staged output keeps relation rows per bundle");
     constexpr int GPB = kBlock / G;
     constexpr int NR = role_count(M);
     const int gl = threadIdx.x % G;
@@ -256,7 +268,8 @@ __global__ __launch_bounds__(kBlock) void k_pointwise_bundle(DeviceModel m, cons
             const int sel = role_sel(M, q);
             if (ida[sel] < 0 || !role_trainable(M, q) || (LDSREL && sel == 1)) return;
             const int d = role_dim<M>(m, q);
-            atomic_add_row<G, NCH>(m.grad[role_tab(M, q)] + ida[sel] * (int64_t)d, A.x[q], d, gl);
+            if constexpr (STAGED) store_row<G, NCH>(sink.stage + (ck * NR + q) * sink.stride, A.x[q], d, gl);   // CHB == 1: bundle ck
+            else atomic_add_row<G, NCH>(m.grad[role_tab(M, q)] + ida[sel] * (int64_t)d, A.x[q], d, gl);
         };
         const int64_t b1 = min(nb, (ck + 1) * CHB);
         for (int64_t b = ck * CHB; b < b1; ++b) {
@@ -340,7 +353,14 @@ __global__ __launch_bounds__(kBlock) void k_pointwise_bundle(DeviceModel m, cons
                         for (int c = 0; c < NCH; ++c) A.x[q][c] += Gr.x[q][c];
                     } else if (role_trainable(M, q)) {
                         const int d = role_dim<M>(m, q);
-                        atomic_add_row<G, NCH>(m.grad[role_tab(M, q)] + id[sel] * (int64_t)d, Gr.x[q], d, gl);
+                        if constexpr (STAGED) {   // a negative's corrupted entity (sampled bundles: row k > 0 of bundle b)
+                            const int64_t pair = b * (bundle - 1) + (i - i0 - 1);
+                            constexpr int NRc = role_count(M);
+                            store_row<G, NCH>(sink.stage + (nb * NRc + pair * sink.nd + role_rank_in_sel(M, q)) * sink.stride, Gr.x[q], d, gl);
+                            if (role_rank_in_sel(M, q) == 0 && gl == 0) stage_register(sink, (int)id[sel], (int)pair);
+                        } else {
+                            atomic_add_row<G, NCH>(m.grad[role_tab(M, q)] + id[sel] * (int64_t)d, Gr.x[q], d, gl);
+                        }
                     }
                 }
             }

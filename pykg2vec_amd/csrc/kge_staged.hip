@@ -23,6 +23,7 @@ struct StagedKArgs {
     OptArgs opt;
     int64_t rows_total;
     int32_t* clear_count; int32_t* clear_head;   // registration set of the next step (NULL: the caller clears)
+    int n_rel_tables;
 };
 
 template <int NV>
@@ -34,6 +35,54 @@ __device__ __forceinline__ void add_slot(float4 (&g)[NV], const float* __restric
             const float4 x = *reinterpret_cast<const float4*>(slot + 4 * i);
             g[v].x += x.x; g[v].y += x.y; g[v].z += x.z; g[v].w += x.w;
         }
+    }
+}
+
+constexpr int kRelChunk = 32;   // slots per pre-reduced chunk of a relation's list
+
+// one wave per (chunk, relation table): partial[chunk][j] = sum of the chunk's slots in list order
+template <int NV>
+__global__ __launch_bounds__(256) void k_stage_rel_chunks(StagedKArgs a, int n_rel_tables) {
+    const kge_staged_step& st = a.st;
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (int64_t)st.n_chunks * n_rel_tables) return;
+    const int c = (int)(w / n_rel_tables), j = (int)(w - (int64_t)c * n_rel_tables);
+    // the j-th relation-class table's static site
+    int site = 0, seen = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < st.n_tables && st.tables[k].cls == 1) { if (seen == j) site = st.tables[k].site_a; ++seen; }
+    const int r = st.chunk_rel[c];
+    const int lo = st.rel_off[r] + kRelChunk * (c - st.rel_chunk_off[r]);
+    const int hi = min(st.rel_off[r + 1], lo + kRelChunk);
+    const int nvec = st.dim >> 2;
+    float4 g[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) g[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = lo;
+    for (; k + 8 <= hi; k += 8) {   // eight slot rows in flight; additions in list order
+        float4 x8[8][NV];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* slot = st.stage + ((int64_t)st.rel_inc[k + u] * st.static_slots + site) * st.stage_stride;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int i = lane + 64 * v;
+                x8[u][v] = i < nvec ? *reinterpret_cast<const float4*>(slot + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { g[v].x += x8[u][v].x; g[v].y += x8[u][v].y; g[v].z += x8[u][v].z; g[v].w += x8[u][v].w; }
+    }
+    for (; k < hi; ++k) add_slot<NV>(g, st.stage + ((int64_t)st.rel_inc[k] * st.static_slots + site) * st.stage_stride, nvec, lane);
+    float* out = st.rel_partials + ((int64_t)c * n_rel_tables + j) * st.stage_stride;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int i = lane + 64 * v;
+        if (i < nvec) reinterpret_cast<float4*>(out)[i] = g[v];
     }
 }
 
@@ -62,6 +111,16 @@ __global__ __launch_bounds__(256) void k_opt_staged(StagedKArgs a) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) g[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     bool any = false;
+    // ---- relation rows with pre-reduced chunks: sum the partial rows in chunk order
+    if (cls == 1 && st.rel_chunk_off != nullptr) {
+        int jrel = 0;   // index of this table among the relation-class tables
+#pragma unroll
+        for (int k = 0; k < 8; ++k) jrel += (k < tb && st.tables[k].cls == 1) ? 1 : 0;
+        const int c0 = st.rel_chunk_off[id], c1 = st.rel_chunk_off[id + 1];
+        any = c1 > c0;
+        for (int c = c0; c < c1; ++c)
+            add_slot<NV>(g, st.rel_partials + ((int64_t)c * a.n_rel_tables + jrel) * stride, nvec, lane);
+    } else
     // ---- static incidences (ascending positive index => ascending slot)
     {
         const int32_t* off = cls == 0 ? st.ent_off : st.rel_off;
@@ -154,6 +213,13 @@ __global__ __launch_bounds__(256) void k_opt_staged(StagedKArgs a) {
 template <int KIND>
 static int launch_staged_kind(const StagedKArgs& a, hipStream_t s) {
     const int nvec = a.st.dim >> 2;
+    if (a.st.rel_chunk_off != nullptr && a.st.n_chunks > 0) {
+        const dim3 cg((unsigned)(((int64_t)a.st.n_chunks * a.n_rel_tables + 3) / 4));
+        if (nvec <= 64) hipLaunchKernelGGL((k_stage_rel_chunks<1>), cg, dim3(256), 0, s, a, a.n_rel_tables);
+        else if (nvec <= 128) hipLaunchKernelGGL((k_stage_rel_chunks<2>), cg, dim3(256), 0, s, a, a.n_rel_tables);
+        else if (nvec <= 256) hipLaunchKernelGGL((k_stage_rel_chunks<4>), cg, dim3(256), 0, s, a, a.n_rel_tables);
+        else hipLaunchKernelGGL((k_stage_rel_chunks<8>), cg, dim3(256), 0, s, a, a.n_rel_tables);
+    }
     const dim3 grid((unsigned)((a.rows_total + 3) / 4));
     if (nvec <= 64) hipLaunchKernelGGL((k_opt_staged<KIND, 1>), grid, dim3(256), 0, s, a);
     else if (nvec <= 128) hipLaunchKernelGGL((k_opt_staged<KIND, 2>), grid, dim3(256), 0, s, a);
@@ -179,6 +245,12 @@ int launch_optimizer_staged(int kind, const kge_staged_step* st, float lr, int64
     a.clear_count = st->dyn_count_next;
     a.clear_head = st->dyn_head_next;
     a.rows_total = 0;
+    a.n_rel_tables = 0;
+    for (int k = 0; k < st->n_tables; ++k) a.n_rel_tables += st->tables[k].cls == 1 ? 1 : 0;
+    if (st->rel_chunk_off && (!st->chunk_rel || !st->rel_partials || st->n_chunks < 0)) {
+        set_error("kge_optimizer_step_staged: relation chunking needs chunk_rel, rel_partials and n_chunks");
+        return -1;
+    }
     for (int k = 0; k < st->n_tables; ++k) {
         if (st->tables[k].flat_off % 4) { set_error("kge_optimizer_step_staged: table offsets must be multiples of 4 floats"); return -1; }
         a.rows_total += st->tables[k].rows;

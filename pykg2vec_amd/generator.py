@@ -160,10 +160,13 @@ class StagedIndex:
     positives it labels.  Batches are fixed slices of the generator's permutation, so this is built once."""
 
     MAX_BYTES = 1 << 30
+    REL_CHUNK = 32      # csrc/kge_staged.hip kRelChunk
+    LONG_LIST = 64      # relation lists beyond this are pre-reduced in chunks by many waves
 
     def __init__(self, batches, tot_entity, tot_relation, device):
         E, R = int(tot_entity), int(tot_relation)
-        ent_off, ent_inc, rel_off, rel_inc = [], [], [], []
+        ent_off, ent_inc, rel_off, rel_inc, chunk_off, chunk_rel = [], [], [], [], [], []
+        self.max_rel_list = 0
         for b in batches:
             n = len(b)
             i = np.arange(n, dtype=np.int64)
@@ -173,8 +176,15 @@ class StagedIndex:
             ent_inc.append(x[order].astype(np.int32))
             ent_off.append(np.concatenate([[0], np.cumsum(np.bincount(ent, minlength=E))]).astype(np.int32))
             rel_inc.append(np.argsort(b[:, 1], kind="stable").astype(np.int32))
-            rel_off.append(np.concatenate([[0], np.cumsum(np.bincount(b[:, 1], minlength=R))]).astype(np.int32))
+            cnt = np.bincount(b[:, 1], minlength=R)
+            rel_off.append(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32))
+            nch = (cnt + self.REL_CHUNK - 1) // self.REL_CHUNK
+            chunk_off.append(np.concatenate([[0], np.cumsum(nch)]).astype(np.int32))
+            chunk_rel.append(np.repeat(np.arange(R, dtype=np.int32), nch))
+            self.max_rel_list = max(self.max_rel_list, int(cnt.max()) if n else 0)
         self.sizes = [len(b) for b in batches]
+        self.n_chunks = [len(x) for x in chunk_rel]
+        self.chunk_pos = np.concatenate([[0], np.cumsum(self.n_chunks)]).astype(np.int64)
         self.pos_off = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
         self.E, self.R = E, R
 
@@ -182,6 +192,7 @@ class StagedIndex:
             return torch.from_numpy(np.concatenate(xs)).to(device)
 
         self.ent_off, self.ent_inc, self.rel_off, self.rel_inc = cat(ent_off), cat(ent_inc), cat(rel_off), cat(rel_inc)
+        self.chunk_off, self.chunk_rel = cat(chunk_off), cat(chunk_rel + [np.zeros(1, np.int32)])
 
     @classmethod
     def fits(cls, n_batches, tot_entity, tot_relation):
@@ -191,6 +202,13 @@ class StagedIndex:
         E, R, p = self.E, self.R, self.pos_off
         return (self.ent_off[b * (E + 1):(b + 1) * (E + 1)], self.ent_inc[2 * p[b]:2 * p[b + 1]],
                 self.rel_off[b * (R + 1):(b + 1) * (R + 1)], self.rel_inc[p[b]:p[b + 1]], self.sizes[b])
+
+    def chunks(self, b):
+        """(rel_chunk_off, chunk_rel, n_chunks) of batch b, or None when no relation list is long enough to pay."""
+        if self.max_rel_list <= self.LONG_LIST:
+            return None
+        R, c = self.R, self.chunk_pos
+        return self.chunk_off[b * (R + 1):(b + 1) * (R + 1)], self.chunk_rel[c[b]:max(c[b + 1], c[b] + 1)], self.n_chunks[b]
 
 
 class Generator:

@@ -170,7 +170,9 @@ class StagedPlan:
     staging buffer and the per-entity registration lists.  `bind(batch_index_views, n_pos)` points it at one batch."""
 
     LAYOUTS = {   # model -> (static slots per positive, dynamic slots per negative, [(cls, site_a, site_b, dsite)] per table)
-        "rotate": (5, 2, [(0, 0, 3, 0), (0, 1, 4, 1), (1, 2, 0, -1)]),
+        "rotate": (5, 2, [(0, 0, 3, 0), (0, 1, 4, 1), (1, 2, 0, -1)]),                      # h_re h_im r t_re t_im | c_re c_im
+        "distmult": (3, 1, [(0, 0, 2, 0), (1, 1, 0, -1)]),                                   # h r t | c
+        "complex": (6, 2, [(0, 0, 4, 0), (0, 1, 5, 1), (1, 2, 0, -1), (1, 3, 0, -1)]),      # h_re h_im r_re r_im t_re t_im | c_re c_im
     }
 
     def __init__(self, kernel_name, flat_param, state1, state2, table_offsets, table_rows, dim, tot_entity, tot_relation,
@@ -190,6 +192,8 @@ class StagedPlan:
         self.bucket = torch.zeros(tot_entity * STAGED_CAP, dtype=torch.int32, device=dev)
         self.next = torch.zeros(self.max_pos * self.neg_rate, dtype=torch.int32, device=dev)
         self._keep = (flat_param, state1, state2)
+        self.n_rel_tables = sum(1 for x in sites if x[0] == 1)
+        self.rel_partials = None
         c = self.c = L.StagedStep()
         c.param = _dev(flat_param, torch.float32, "param")
         c.state1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
@@ -203,11 +207,20 @@ class StagedPlan:
         c.static_slots, c.dynamic_slots = ns, nd
         c.tot_entity, c.tot_relation = int(tot_entity), int(tot_relation)
 
-    def bind(self, ent_off, ent_inc, rel_off, rel_inc, n_pos):
+    def bind(self, ent_off, ent_inc, rel_off, rel_inc, n_pos, chunks=None):
         if n_pos > self.max_pos:
             raise KgeHipError("staged plan: batch larger than the plan")
-        self._batch = (ent_off, ent_inc, rel_off, rel_inc)
+        self._batch = (ent_off, ent_inc, rel_off, rel_inc, chunks)
         c = self.c
+        if chunks is not None:
+            chunk_off, chunk_rel, n_chunks = chunks
+            need = max(1, n_chunks) * self.n_rel_tables * self.stride
+            if self.rel_partials is None or self.rel_partials.numel() < need:
+                self.rel_partials = torch.empty(need, dtype=torch.float32, device=self.stage.device)
+            c.rel_chunk_off, c.chunk_rel = _dev(chunk_off, torch.int32, "rel_chunk_off"), _dev(chunk_rel, torch.int32, "chunk_rel")
+            c.rel_partials, c.n_chunks = self.rel_partials.data_ptr(), int(n_chunks)
+        else:
+            c.rel_chunk_off, c.chunk_rel, c.rel_partials, c.n_chunks = None, None, None, 0
         c.ent_off, c.ent_inc = _dev(ent_off, torch.int32, "ent_off"), _dev(ent_inc, torch.int32, "ent_inc")
         c.rel_off, c.rel_inc = _dev(rel_off, torch.int32, "rel_off"), _dev(rel_inc, torch.int32, "rel_inc")
         c.n_pos, c.n_neg = int(n_pos), int(n_pos) * self.neg_rate
@@ -228,6 +241,18 @@ def train_pairwise_selfadv_sampled_staged(desc, triples, perm, start, n_pos, neg
         ctypes.byref(desc), _ids(triples, "triples"), _ids(perm, "perm"), int(start), int(n_pos), int(neg_rate), float(alpha),
         bp, sp, slots.numel() if slots is not None else 0, int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
         ctypes.byref(plan.c), _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_train_pairwise_selfadv_sampled_staged")
+
+
+def train_pointwise_logistic_sampled_staged(desc, triples, perm, start, n_pos, neg_rate, bern_prob, slots, seed, offset, lmbda,
+                                            reg_type, plan, loss_buf):
+    """DistMult / ComplEx bundle step with staged (atomic-free) gradient output; follow with optimizer_step_staged(plan)."""
+    bp = _dev(bern_prob, torch.float32, "bern_prob") if bern_prob is not None else None
+    sp = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
+    L.check(L.load().kge_train_pointwise_logistic_sampled_staged(
+        ctypes.byref(desc), _ids(triples, "triples"), _ids(perm, "perm"), int(start), int(n_pos), int(neg_rate), bp, sp,
+        slots.numel() if slots is not None else 0, int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), float(lmbda),
+        int(reg_type), ctypes.byref(plan.c), _dev(loss_buf, torch.float32, "loss"), _stream()),
+        "kge_train_pointwise_logistic_sampled_staged")
 
 
 def optimizer_step_staged(kind, plan, lr, step):

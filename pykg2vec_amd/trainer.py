@@ -345,12 +345,14 @@ class Trainer:
 
     # ------------------------------------------------------------------ staged (atomic-free) step of the long-row bundle kernels
     def _staged_ok(self):
-        """RotatE self-adversarial step without a gradient buffer: the bundle kernel stages its gradient rows with plain
-        stores and the optimiser sweep sums them per parameter row in a fixed order (csrc/kge_staged.hip) -- no fp32
+        """RotatE self-adversarial / DistMult / ComplEx logistic step without a gradient buffer: the bundle kernel stages its
+        gradient rows with plain stores and the optimiser sweep sums them per parameter row in a fixed order (csrc/kge_staged.hip) -- no fp32
         atomics, bit-reproducible.  Single GPU, batches beyond the launch-bound graph regime; KGE_STAGED=0 / 1 overrides."""
         import os
         from .generator import StagedIndex
-        if not (self.K is K and self.world_size == 1 and self.generator is not None and self._fused_rotate_ok()):
+        if not (self.K is K and self.world_size == 1 and self.generator is not None):
+            return False
+        if not (self._fused_rotate_ok() or (self._fused_pointwise_ok() and self.model.kernel_name in ("distmult", "complex"))):
             return False
         dims = {p.weight.shape[1] for p in self.model.parameter_list}
         if len(dims) != 1 or self.model.hidden_size % 4 or self.model.hidden_size > 2048:
@@ -361,7 +363,10 @@ class Trainer:
         env = os.environ.get("KGE_STAGED")
         if env is not None:
             return env == "1"
-        return self.config.batch_size * (1 + int(self.config.neg_rate)) > self.GRAPH_MAX_ROWS
+        # default: the long-row RotatE bundles beyond the graph regime (C3: 320 -> 230 us per step).  For the pointwise models
+        # the staged step is correct and deterministic but not faster than atomics + hipGraph replay at the measured shapes
+        # (profiles/r02_experiments.md), so it stays opt-in (KGE_STAGED=1).
+        return self.model.kernel_name == "rotate" and self.config.batch_size * (1 + int(self.config.neg_rate)) > self.GRAPH_MAX_ROWS
 
     def _staged_plan(self):
         if getattr(self, "_staged", None) is None:
@@ -378,11 +383,17 @@ class Trainer:
         start, n, offset = gen._next_range()
         if n <= 0:
             return
-        ent_off, ent_inc, rel_off, rel_inc, n_idx = gen.staged_index().batch(b)
+        idx = gen.staged_index()
+        ent_off, ent_inc, rel_off, rel_inc, n_idx = idx.batch(b)
         assert n_idx == n
-        plan = self._staged_plan().bind(ent_off, ent_inc, rel_off, rel_inc, n)
-        K.train_pairwise_selfadv_sampled_staged(self._desc, gen.triples, gen.perm, start, n, gen.neg_rate, cfg.alpha, gen.bern,
-                                                gen.slots, gen.seed, offset, plan, self.loss_buf)
+        plan = self._staged_plan().bind(ent_off, ent_inc, rel_off, rel_inc, n, idx.chunks(b))
+        if self.model.kernel_name == "rotate":
+            K.train_pairwise_selfadv_sampled_staged(self._desc, gen.triples, gen.perm, start, n, gen.neg_rate, cfg.alpha,
+                                                    gen.bern, gen.slots, gen.seed, offset, plan, self.loss_buf)
+        else:
+            K.train_pointwise_logistic_sampled_staged(self._desc, gen.triples, gen.perm, start, n, gen.neg_rate, gen.bern,
+                                                      gen.slots, gen.seed, offset, self.model.kernel_lmbda(),
+                                                      self.model.kernel_reg_type(), plan, self.loss_buf)
         self.flat.step += 1
         K.optimizer_step_staged(cfg.optimizer, plan, cfg.learning_rate, self.flat.step)
 
@@ -474,6 +485,9 @@ class Trainer:
         if num_batch is not None and num_batch * int(self.config.batch_size) > self.generator.n_train:
             return False
         if self.K is not K:
+            return False
+        import os
+        if os.environ.get("KGE_STAGED") == "1" and self._staged_ok():   # the staged step is an eager two-launch step
             return False
         if self.world_size > 1:
             # RCCL collectives are capturable (gloo is not); multi-rank capture is opt-in (use_graph=True or

@@ -100,3 +100,42 @@ def test_staged_gradient_matches_oracle(hip, monkeypatch):
     for k in before:
         got = before[k] - after[k + ".weight"].cpu().numpy()
         assert np.allclose(got, grads[k], atol=2e-6, rtol=2e-4), (k, np.abs(got - grads[k]).max())
+
+
+def _pw_trainer(hip, model, world, E, R, D, B, neg, opt, staged, monkeypatch, lr=0.01):
+    from pykg2vec_amd.trainer import Trainer
+    train, test, P = world
+    hp = dict(hidden_size=D, lmbda=1e-3, neg_rate=neg)
+    cfg = hip.make_config(E, R, hp, train, test, test, optimizer=opt, lr=lr, batch_size=B)
+    m = hip.model_from_params(model, P, hp, E, R)
+    monkeypatch.setenv("KGE_STAGED", "1" if staged else "0")
+    tr = Trainer(m, cfg, use_graph=False)
+    tr.build_model()
+    tr.generator = tr._new_generator()
+    assert tr._staged_ok() == staged
+    return tr, m
+
+
+@pytest.mark.parametrize("model,E,R,D,B,neg,steps", [("distmult", 53, 7, 40, 32, 3, 3), ("complex", 53, 7, 40, 32, 2, 3),
+                                                     ("complexn3", 53, 7, 40, 32, 1, 3),
+                                                     ("complex", 12, 2, 8, 32, 8, 2),          # overflow chains
+                                                     ("complex", 4000, 11, 200, 512, 1, 2),    # C2 row length, few relations
+                                                     ("complex", 4000, 3, 200, 512, 1, 2),     # relation lists of ~170 slots: chunked pre-reduction
+                                                     ("distmult", 3000, 400, 100, 1024, 1, 2)])
+@pytest.mark.parametrize("opt", ["sgd", "adagrad", "adam"])
+def test_staged_pointwise_steps_equal_push_steps(hip, monkeypatch, model, E, R, D, B, neg, steps, opt):
+    rng = np.random.default_rng(11)
+    n_train = (80 if E > 12 else 40) if B == 32 else 2 * B + 17
+    train = np.stack([rng.integers(E, size=n_train), rng.integers(R, size=n_train), rng.integers(E, size=n_train)], 1)
+    test = train[:8]
+    P = ko.init_params("complex" if model.startswith("complex") else model, rng, tot_entity=E, tot_relation=R, hidden_size=D)
+    res = {}
+    for staged in (False, True):
+        tr, m = _pw_trainer(hip, model, (train, test, P), E, R, D, B, neg, opt, staged, monkeypatch)
+        res[staged] = _run(tr, m, hip, steps)
+    assert np.isclose(res[True][0], res[False][0], rtol=2e-5), (res[True][0], res[False][0])
+    for k in res[True][1]:
+        a, b = res[True][1][k].cpu().numpy(), res[False][1][k].cpu().numpy()
+        bad = ~np.isclose(a, b, atol=2e-5, rtol=1e-4)
+        lim = 0.0 if opt == "sgd" else 2e-3
+        assert bad.mean() <= lim, (opt, k, bad.mean(), np.abs(a - b).max())
