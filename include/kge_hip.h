@@ -91,6 +91,11 @@ int kge_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t*
 /* Rescal.embed side effect (pairwise.py:843-844,862-865): W <- W / ||W_row||_2 in place, both tables. */
 int kge_rescal_normalize(float* ent, int64_t tot_entity, float* rel, int64_t tot_relation, int32_t k,
                          void* stream);
+/* The same with a caller-owned scratch (kge_rescal_normalize_scratch_bytes): long relation-matrix rows are then normalised
+ * by many workgroups per row (partial sums of squares per 4096-float chunk, added in chunk order) instead of one. */
+size_t kge_rescal_normalize_scratch_bytes(int64_t tot_relation, int32_t k);
+int kge_rescal_normalize_ws(float* ent, int64_t tot_entity, float* rel, int64_t tot_relation, int32_t k, void* scratch,
+                            size_t scratch_bytes, void* stream);
 
 /* Fused Trainer.train_step_pairwise (utils/trainer.py:147-157) with Criterion.pairwise_hinge
  * (utils/criterion.py:25-29): scores both triples of each of the n pairs, adds sum(max(0, s+ + margin - s-))

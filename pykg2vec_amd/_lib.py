@@ -103,6 +103,8 @@ _SIGNATURES = {
     "kge_score_forward": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "kge_score_backward": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "kge_rescal_normalize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
+    "kge_rescal_normalize_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int32]),
+    "kge_rescal_normalize_ws": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "kge_train_pairwise_hinge": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_train_pairwise_hinge_sampled": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_train_pairwise_selfadv": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -138,7 +138,18 @@ int kge_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t*
 
 int kge_rescal_normalize(float* ent, int64_t tot_entity, float* rel, int64_t tot_relation, int32_t k, void* stream) {
     if (!ent || !rel || k <= 0) { set_error("kge_rescal_normalize: bad arguments"); return -1; }
-    return launch_rescal_normalize(ent, tot_entity, rel, tot_relation, k, (hipStream_t)stream);
+    return launch_rescal_normalize(ent, tot_entity, rel, tot_relation, k, nullptr, 0, (hipStream_t)stream);
+}
+
+size_t kge_rescal_normalize_scratch_bytes(int64_t tot_relation, int32_t k) {
+    return (size_t)tot_relation * (size_t)(((int64_t)k * k + 4095) / 4096) * sizeof(float);
+}
+
+int kge_rescal_normalize_ws(float* ent, int64_t tot_entity, float* rel, int64_t tot_relation, int32_t k, void* scratch,
+                            size_t scratch_bytes, void* stream) {
+    if (!ent || !rel || k <= 0) { set_error("kge_rescal_normalize_ws: bad arguments"); return -1; }
+    return launch_rescal_normalize(ent, tot_entity, rel, tot_relation, k, (float*)scratch, scratch_bytes / sizeof(float),
+                                   (hipStream_t)stream);
 }
 
 int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
@@ -160,6 +171,13 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
     float* sp = (float*)((char*)workspace + 2 * gws);
     float* sn = sp + n;
     int rc;
+    if (m->model == KGE_RESCAL) {
+        // positives and negatives as ONE grouped batch of 2n triples (scores / coefficients contiguous: sp | sn); the
+        // region of the two per-side workspaces holds the grouping of 2n triples (group_ws_bytes(R, 2n) <= 2 gws)
+        if ((rc = launch_rescal_pair_forward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s))) return rc;
+        if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
+        return launch_rescal_pair_backward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s);
+    }
     if ((rc = kge_score_forward(m, ph, pr, pt, n, sp, wsp, gws, stream))) return rc;
     if ((rc = kge_score_forward(m, nh, nr, nt, n, sn, wsn, gws, stream))) return rc;
     if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
@@ -167,11 +185,7 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
         if ((rc = launch_ntn_backward(m, ph, pr, pt, n, sp, wsp, gws, true, s))) return rc;
         return launch_ntn_backward(m, nh, nr, nt, n, sn, wsn, gws, true, s);
     }
-    // RESCAL / TransR: each side's forward left its relation grouping in that side's workspace
-    if (m->model == KGE_RESCAL) {
-        if ((rc = launch_rescal_backward(m, ph, pr, pt, n, sp, wsp, gws, true, s))) return rc;
-        return launch_rescal_backward(m, nh, nr, nt, n, sn, wsn, gws, true, s);
-    }
+    // TransR: each side's forward left its relation grouping in that side's workspace
     if ((rc = launch_transr_backward(m, ph, pr, pt, n, sp, wsp, gws, true, s))) return rc;
     return launch_transr_backward(m, nh, nr, nt, n, sn, wsn, gws, true, s);
 }

@@ -20,9 +20,9 @@ namespace kge {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ void k_rel_hist(const int64_t* __restrict__ r, int64_t n, int* __restrict__ counts) {
+__global__ void k_rel_hist(IdSplit r, int64_t n, int* __restrict__ counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(counts + r[i], 1);
+    if (i < n) atomicAdd(counts + r.at(i), 1);
 }
 
 // single block: exclusive scans of counts and of ceil(counts / TILE)
@@ -50,18 +50,22 @@ __global__ __launch_bounds__(256) void k_rel_scan(const int* __restrict__ counts
     if (threadIdx.x == 0) { offsets[R] = run_a; tile_off[R] = run_b; }
 }
 
-__global__ void k_rel_scatter(const int64_t* __restrict__ r, int64_t n, const int* __restrict__ offsets,
+__global__ void k_rel_scatter(IdSplit r, int64_t n, const int* __restrict__ offsets,
                               const int* __restrict__ tile_off, int* __restrict__ cursor, int* __restrict__ perm,
                               int* __restrict__ tile_rel) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int rel = (int)r[i];
+    const int rel = (int)r.at(i);
     const int local = atomicAdd(cursor + rel, 1);
     perm[offsets[rel] + local] = (int)i;
     if (local % TILE == 0) tile_rel[tile_off[rel] + local / TILE] = rel;  // the first row of a tile names its relation
 }
 
 int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s) {
+    return group_by_relation_split(id_whole(r, n), n, R, g, s);
+}
+
+int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s) {
     hipError_t e = hipMemsetAsync(g.counts, 0, (size_t)2 * (R + 1) * sizeof(int), s);  // counts + cursor
     if (e != hipSuccess) { set_error("rescal grouping memset: %s", hipGetErrorString(e)); return -2; }
     const unsigned nb = (unsigned)((n + 255) / 256);
@@ -75,7 +79,7 @@ int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, const float* __restrict__ relm,
                                                 float* __restrict__ g_ent, float* __restrict__ g_rel,
-                                                const int64_t* __restrict__ h, const int64_t* __restrict__ t,
+                                                IdSplit h, IdSplit t,
                                                 const int* __restrict__ offsets, const int* __restrict__ tile_off,
                                                 const int* __restrict__ tile_rel, const int* __restrict__ perm, int R, int k,
                                                 const float* __restrict__ dscore, float* __restrict__ scores) {
@@ -97,8 +101,8 @@ __global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, c
     if (threadIdx.x < TILE) {
         const int row = threadIdx.x < cnt ? perm[g0 + threadIdx.x] : -1;
         sRow[threadIdx.x] = row;
-        sHid[threadIdx.x] = row >= 0 ? h[row] : 0;
-        sTid[threadIdx.x] = row >= 0 ? t[row] : 0;
+        sHid[threadIdx.x] = row >= 0 ? h.at(row) : 0;
+        sTid[threadIdx.x] = row >= 0 ? t.at(row) : 0;
         sDs[threadIdx.x] = (MODE == 1 && row >= 0) ? dscore[row] : 0.f;
         sSc[threadIdx.x] = 0.f;
     }
@@ -213,7 +217,7 @@ size_t dense_workspace_bytes(const kge_model_desc* m, int64_t n) {
     return 0;
 }
 
-static int rescal_run(int mode, const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+static int rescal_run(int mode, const kge_model_desc* m, IdSplit h, IdSplit r, IdSplit t, int64_t n,
                       const float* dscore, float* scores, void* ws, size_t ws_bytes, bool grouped, hipStream_t s) {
     const int k = m->dim;
     const int64_t R = m->tot_relation;
@@ -225,7 +229,7 @@ static int rescal_run(int mode, const kge_model_desc* m, const int64_t* h, const
     }
     const GroupWs g = carve_group_ws(ws, R, n);
     if (!grouped) {  // the fused train step's backward reuses the grouping its forward left in this workspace
-        int rc = group_by_relation(r, n, R, g, s);
+        int rc = group_by_relation_split(r, n, R, g, s);
         if (rc) return rc;
     }
     const unsigned max_tiles = (unsigned)group_max_tiles(R, n);  // surplus blocks exit
@@ -251,11 +255,25 @@ static int rescal_run(int mode, const kge_model_desc* m, const int64_t* h, const
 
 int launch_rescal_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
                           float* scores, void* ws, size_t ws_bytes, hipStream_t s) {
-    return rescal_run(0, m, h, r, t, n, nullptr, scores, ws, ws_bytes, false, s);
+    return rescal_run(0, m, id_whole(h, n), id_whole(r, n), id_whole(t, n), n, nullptr, scores, ws, ws_bytes, false, s);
 }
 int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
                            const float* dscore, void* ws, size_t ws_bytes, bool grouped, hipStream_t s) {
-    return rescal_run(1, m, h, r, t, n, dscore, nullptr, ws, ws_bytes, grouped, s);
+    return rescal_run(1, m, id_whole(h, n), id_whole(r, n), id_whole(t, n), n, dscore, nullptr, ws, ws_bytes, grouped, s);
+}
+
+// The fused pairwise step scores / back-propagates positives and negatives as ONE batch of 2n triples: one grouping pass and
+// one launch per direction instead of two (the kernels are latency-sized at the reference's batch sizes, so a launch costs
+// the same with twice the tiles).  scores / dscore: [2n], positives first.
+int launch_rescal_pair_forward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                               const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float* scores2, void* ws,
+                               size_t ws_bytes, hipStream_t s) {
+    return rescal_run(0, m, IdSplit{ph, nh, n}, IdSplit{pr, nr, n}, IdSplit{pt, nt, n}, 2 * n, nullptr, scores2, ws, ws_bytes, false, s);
+}
+int launch_rescal_pair_backward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                                const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, const float* dscore2,
+                                void* ws, size_t ws_bytes, hipStream_t s) {
+    return rescal_run(1, m, IdSplit{ph, nh, n}, IdSplit{pr, nr, n}, IdSplit{pt, nt, n}, 2 * n, dscore2, nullptr, ws, ws_bytes, true, s);
 }
 
 // ---- W <- W / ||W_row||_2 in place (plain division, no eps: pairwise.py:862-865)
@@ -316,16 +334,51 @@ __global__ __launch_bounds__(1024) void k_row_normalize_wide(float* __restrict__
     for (int64_t c = threadIdx.x; c < dim; c += 1024) p[c] = p[c] / nrm;
 }
 
-static void normalize_rows(float* w, int64_t rows, int64_t dim, hipStream_t s) {
+// very long rows, few of them (the relation matrices of a graph with a handful of relations: 37 rows of 40 000 floats):
+// one workgroup per row leaves the chip idle, so a row is cut into 4096-float chunks -- pass 1 writes each chunk's sum of
+// squares, pass 2 adds a row's partials in chunk order (deterministic) and scales its chunk.  `part`: [rows][nchunk].
+constexpr int kNormChunk = 4096;
+__global__ __launch_bounds__(256) void k_row_sumsq_chunks(const float* __restrict__ w, int64_t dim, int nchunk, float* __restrict__ part) {
+    __shared__ float sw[4];
+    const int64_t row = blockIdx.x / nchunk;
+    const int ch = blockIdx.x % nchunk;
+    const float* p = w + row * dim;
+    const int64_t lo = (int64_t)ch * kNormChunk, hi = min(dim, lo + kNormChunk);
+    float n2 = 0.f;
+    for (int64_t c = lo + threadIdx.x; c < hi; c += 256) n2 = fmaf(p[c], p[c], n2);
+    n2 = wave_sum(n2);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = n2;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ __launch_bounds__(256) void k_row_scale_chunks(float* __restrict__ w, int64_t dim, int nchunk, const float* __restrict__ part) {
+    const int64_t row = blockIdx.x / nchunk;
+    const int ch = blockIdx.x % nchunk;
+    float t = 0.f;
+    for (int i = 0; i < nchunk; ++i) t += part[row * nchunk + i];
+    const float nrm = sqrtf(t);
+    float* p = w + row * dim;
+    const int64_t lo = (int64_t)ch * kNormChunk, hi = min(dim, lo + kNormChunk);
+    for (int64_t c = lo + threadIdx.x; c < hi; c += 256) p[c] = p[c] / nrm;
+}
+
+static void normalize_rows(float* w, int64_t rows, int64_t dim, hipStream_t s, float* scratch = nullptr, size_t scratch_floats = 0) {
+    const int nchunk = (int)((dim + kNormChunk - 1) / kNormChunk);
+    if (dim >= 4 * kNormChunk && rows < 1024 && scratch && scratch_floats >= (size_t)rows * nchunk) {
+        hipLaunchKernelGGL(k_row_sumsq_chunks, dim3((unsigned)(rows * nchunk)), dim3(256), 0, s, w, dim, nchunk, scratch);
+        hipLaunchKernelGGL(k_row_scale_chunks, dim3((unsigned)(rows * nchunk)), dim3(256), 0, s, w, dim, nchunk, scratch);
+        return;
+    }
     if (dim >= 2048)
         hipLaunchKernelGGL(k_row_normalize_wide, dim3((unsigned)rows), dim3(1024), 0, s, w, rows, dim);
     else
         hipLaunchKernelGGL(k_row_normalize, dim3((unsigned)min((int64_t)16384, (rows + 7) / 8)), dim3(256), 0, s, w, rows, dim);
 }
 
-int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k, hipStream_t s) {
+int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k, float* scratch, size_t scratch_floats,
+                            hipStream_t s) {
     normalize_rows(ent, E, (int64_t)k, s);
-    normalize_rows(rel, R, (int64_t)k * k, s);
+    normalize_rows(rel, R, (int64_t)k * k, s, scratch, scratch_floats);
     return check_launch("k_row_normalize");
 }
 

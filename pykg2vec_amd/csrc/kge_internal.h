@@ -89,7 +89,8 @@ int launch_selfadv_coeffs(float* pos_scores, float* neg_scores, int64_t n_pos, i
                           float* loss, hipStream_t s);
 
 // kge_dense.hip (RESCAL / NTN: f32 MFMA contraction paths) + table normalisation
-int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k, hipStream_t s);
+int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k, float* scratch, size_t scratch_floats,
+                            hipStream_t s);
 size_t dense_workspace_bytes(const kge_model_desc* m, int64_t n);
 size_t ntn_workspace_bytes(const kge_model_desc* m, int64_t n);
 int launch_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, float* scratch, float* loss, hipStream_t s);
@@ -97,6 +98,12 @@ int launch_rescal_forward(const kge_model_desc* m, const int64_t* h, const int64
                           int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                            int64_t n, const float* dscore, void* ws, size_t ws_bytes, bool grouped, hipStream_t s);
+int launch_rescal_pair_forward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                               const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float* scores2, void* ws,
+                               size_t ws_bytes, hipStream_t s);
+int launch_rescal_pair_backward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                                const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, const float* dscore2,
+                                void* ws, size_t ws_bytes, hipStream_t s);
 int launch_ntn_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                        int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_ntn_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,

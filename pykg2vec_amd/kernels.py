@@ -94,9 +94,18 @@ def score_backward(desc, h, r, t, dscore):
                                         _dev(dscore, torch.float32, "dscore"), wp, wb, _stream()), "kge_score_backward")
 
 
+_rescal_scratch = {}
+
+
 def rescal_normalize(ent, rel, k):
-    L.check(L.load().kge_rescal_normalize(_dev(ent, torch.float32, "ent"), ent.shape[0], _dev(rel, torch.float32, "rel"),
-                                          rel.shape[0], k, _stream()), "kge_rescal_normalize")
+    lib = L.load()
+    need = lib.kge_rescal_normalize_scratch_bytes(rel.shape[0], int(k))
+    key = (ent.device, need)
+    if key not in _rescal_scratch:   # a few hundred floats, kept per (device, size): the call stays allocation-free and capturable
+        _rescal_scratch[key] = torch.empty(max(1, need // 4), dtype=torch.float32, device=ent.device)
+    sc = _rescal_scratch[key]
+    L.check(lib.kge_rescal_normalize_ws(_dev(ent, torch.float32, "ent"), ent.shape[0], _dev(rel, torch.float32, "rel"),
+                                        rel.shape[0], k, sc.data_ptr(), sc.numel() * 4, _stream()), "kge_rescal_normalize_ws")
 
 
 def new_loss_buffer(device):
