@@ -178,6 +178,11 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
         if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
         return launch_rescal_pair_backward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s);
     }
+    if (m->model == KGE_TRANSR) {
+        if ((rc = launch_transr_pair_forward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s))) return rc;
+        if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
+        return launch_transr_pair_backward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s);
+    }
     if ((rc = kge_score_forward(m, ph, pr, pt, n, sp, wsp, gws, stream))) return rc;
     if ((rc = kge_score_forward(m, nh, nr, nt, n, sn, wsn, gws, stream))) return rc;
     if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
@@ -185,9 +190,8 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
         if ((rc = launch_ntn_backward(m, ph, pr, pt, n, sp, wsp, gws, true, s))) return rc;
         return launch_ntn_backward(m, nh, nr, nt, n, sn, wsn, gws, true, s);
     }
-    // TransR: each side's forward left its relation grouping in that side's workspace
-    if ((rc = launch_transr_backward(m, ph, pr, pt, n, sp, wsp, gws, true, s))) return rc;
-    return launch_transr_backward(m, nh, nr, nt, n, sn, wsn, gws, true, s);
+    set_error("kge_train_pairwise_hinge: unsupported model %d", m->model);
+    return -1;
 }
 
 int kge_train_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,

@@ -98,6 +98,12 @@ int launch_rescal_forward(const kge_model_desc* m, const int64_t* h, const int64
                           int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                            int64_t n, const float* dscore, void* ws, size_t ws_bytes, bool grouped, hipStream_t s);
+int launch_transr_pair_forward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                               const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float* scores2, void* ws,
+                               size_t ws_bytes, hipStream_t s);
+int launch_transr_pair_backward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                                const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, const float* dscore2,
+                                void* ws, size_t ws_bytes, hipStream_t s);
 int launch_rescal_pair_forward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
                                const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float* scores2, void* ws,
                                size_t ws_bytes, hipStream_t s);

@@ -26,7 +26,7 @@ constexpr int TR_MAXD = 128;  // rows are held two elements per lane in the per-
 struct TransRArgs {
     const float* ent; const float* rel; const float* mat;
     float* g_ent; float* g_rel; float* g_mat;
-    const int64_t* h; const int64_t* t;
+    IdSplit h, t;
     const int* offsets; const int* tile_off; const int* tile_rel; const int* perm;
     int R, de, dr, l1;
     const float* dscore; float* scores;
@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void k_transr(TransRArgs A) {
     if (threadIdx.x < TILE) {
         const int row = threadIdx.x < cnt ? A.perm[g0 + threadIdx.x] : -1;
         sRow[threadIdx.x] = row;
-        sHid[threadIdx.x] = row >= 0 ? A.h[row] : 0;
-        sTid[threadIdx.x] = row >= 0 ? A.t[row] : 0;
+        sHid[threadIdx.x] = row >= 0 ? A.h.at(row) : 0;
+        sTid[threadIdx.x] = row >= 0 ? A.t.at(row) : 0;
         sDs[threadIdx.x] = (MODE == 1 && row >= 0) ? A.dscore[row] : 0.f;
     }
     if (threadIdx.x < TR_MAXD) sGR[threadIdx.x] = 0.f;
@@ -274,7 +274,7 @@ static int transr_check(const kge_model_desc* m, int64_t n) {
     return 0;
 }
 
-static int transr_run(int mode, const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+static int transr_run(int mode, const kge_model_desc* m, IdSplit h, IdSplit r, IdSplit t, int64_t n,
                       const float* dscore, float* scores, void* ws, size_t ws_bytes, bool grouped, hipStream_t s) {
     if (transr_check(m, n)) return -1;
     const int64_t R = m->tot_relation;
@@ -284,7 +284,7 @@ static int transr_run(int mode, const kge_model_desc* m, const int64_t* h, const
     }
     const GroupWs g = carve_group_ws(ws, R, n);
     if (!grouped) {  // the fused train step's backward reuses the grouping its forward left in this workspace
-        int rc = group_by_relation(r, n, R, g, s);
+        int rc = group_by_relation_split(r, n, R, g, s);
         if (rc) return rc;
     }
     TransRArgs a;
@@ -307,11 +307,23 @@ static int transr_run(int mode, const kge_model_desc* m, const int64_t* h, const
 
 int launch_transr_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
                           float* scores, void* ws, size_t ws_bytes, hipStream_t s) {
-    return transr_run(0, m, h, r, t, n, nullptr, scores, ws, ws_bytes, false, s);
+    return transr_run(0, m, id_whole(h, n), id_whole(r, n), id_whole(t, n), n, nullptr, scores, ws, ws_bytes, false, s);
 }
 int launch_transr_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
                            const float* dscore, void* ws, size_t ws_bytes, bool grouped, hipStream_t s) {
-    return transr_run(1, m, h, r, t, n, dscore, nullptr, ws, ws_bytes, grouped, s);
+    return transr_run(1, m, id_whole(h, n), id_whole(r, n), id_whole(t, n), n, dscore, nullptr, ws, ws_bytes, grouped, s);
+}
+
+// positives and negatives of the fused pairwise step as ONE grouped batch of 2n triples (see launch_rescal_pair_forward)
+int launch_transr_pair_forward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                               const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float* scores2, void* ws,
+                               size_t ws_bytes, hipStream_t s) {
+    return transr_run(0, m, IdSplit{ph, nh, n}, IdSplit{pr, nr, n}, IdSplit{pt, nt, n}, 2 * n, nullptr, scores2, ws, ws_bytes, false, s);
+}
+int launch_transr_pair_backward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
+                                const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, const float* dscore2,
+                                void* ws, size_t ws_bytes, hipStream_t s) {
+    return transr_run(1, m, IdSplit{ph, nh, n}, IdSplit{pr, nr, n}, IdSplit{pt, nt, n}, 2 * n, dscore2, nullptr, ws, ws_bytes, true, s);
 }
 
 // ------------------------------------------------------------------ evaluation helpers (one relation per call)
