@@ -101,7 +101,8 @@ int kge_rescal_normalize_ws(float* ent, int64_t tot_entity, float* rel, int64_t 
  * (utils/criterion.py:25-29): scores both triples of each of the n pairs, adds sum(max(0, s+ + margin - s-))
  * to the loss accumulators and the loss gradient to m->grads.  neg_rate must be 1 (the hinge adds [B] to
  * [B*neg_rate]).  `loss`: float[32*32] striped accumulators, total = sum_k loss[32*k].  One kernel for the gather-type
- * models; RESCAL runs normalise-free forward(+), forward(-), hinge coefficients, backward(+), backward(-). */
+ * models; RESCAL / TransR / NTN run forward over [positives | negatives] as one batch of 2n triples, the hinge
+ * coefficients in place, and one backward over the same 2n (RESCAL: normalise-free, call kge_rescal_normalize first). */
 int kge_train_pairwise_hinge(const kge_model_desc* m,
                              const int64_t* ph, const int64_t* pr, const int64_t* pt,
                              const int64_t* nh, const int64_t* nr, const int64_t* nt,

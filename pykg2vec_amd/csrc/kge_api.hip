@@ -160,14 +160,13 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
     if (n < 0 || !ph || !pr || !pt || !nh || !nr || !nt || !loss) { set_error("kge_train_pairwise_hinge: bad arguments"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     if (is_vector_model(m->model)) return launch_pairwise_hinge(m, ph, pr, pt, nh, nr, nt, n, margin, loss, s);
-    // dense-contraction models: forward(+), forward(-), hinge coefficients in place, backward(+), backward(-)
+    // dense-contraction models: forward over [positives | negatives], hinge coefficients in place, backward over the same 2n
     const size_t gws = align256(dense_workspace_bytes(m, n));
     if (!workspace || workspace_bytes < 2 * gws + align256((size_t)2 * n * sizeof(float))) {
         set_error("kge_train_pairwise_hinge: workspace too small (need kge_workspace_bytes)");
         return -1;
     }
-    void* wsp = workspace;                       // scorer workspace of the positives ...
-    void* wsn = (char*)workspace + gws;          // ... and of the negatives (NTN: the forward's intermediates stay here)
+    void* wsp = workspace;                       // scorer workspace: both sides as one batch of 2n triples (2 gws bytes)
     float* sp = (float*)((char*)workspace + 2 * gws);
     float* sn = sp + n;
     int rc;
@@ -178,17 +177,15 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
         if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
         return launch_rescal_pair_backward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s);
     }
+    if (m->model == KGE_NTN) {
+        if ((rc = launch_ntn_pair_forward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s))) return rc;
+        if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
+        return launch_ntn_pair_backward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s);
+    }
     if (m->model == KGE_TRANSR) {
         if ((rc = launch_transr_pair_forward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s))) return rc;
         if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
         return launch_transr_pair_backward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s);
-    }
-    if ((rc = kge_score_forward(m, ph, pr, pt, n, sp, wsp, gws, stream))) return rc;
-    if ((rc = kge_score_forward(m, nh, nr, nt, n, sn, wsn, gws, stream))) return rc;
-    if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;
-    if (m->model == KGE_NTN) {
-        if ((rc = launch_ntn_backward(m, ph, pr, pt, n, sp, wsp, gws, true, s))) return rc;
-        return launch_ntn_backward(m, nh, nr, nt, n, sn, wsn, gws, true, s);
     }
     set_error("kge_train_pairwise_hinge: unsupported model %d", m->model);
     return -1;

@@ -46,6 +46,14 @@ int launch_pointwise_logistic_sampled(const kge_model_desc* m, const int64_t* tr
 int launch_selfadv_bundle(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
                           const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n_pos, int neg_rate,
                           float alpha, float* loss, hipStream_t s);  // returns 1 when neg_rate exceeds the group width
+// id array that may come in two pieces (the positives followed by the negatives of a pair batch): element i of [a | b].
+// The relation-matrix models score / back-propagate both sides of the fused pairwise step as ONE batch of 2n triples.
+struct IdSplit {
+    const int64_t* a; const int64_t* b; int64_t na;
+    __device__ __forceinline__ int64_t at(int64_t i) const { return i < na ? a[i] : b[i - na]; }
+};
+inline IdSplit id_whole(const int64_t* a, int64_t n) { return IdSplit{a, nullptr, n}; }
+
 // Staged (atomic-free) gradient output of the bundle kernels: every gradient row a bundle produces goes to its own slot of
 // a staging buffer with plain stores; kge_optimizer_step_staged (kge_staged.hip) sums the slots of each parameter row in a
 // fixed order inside the optimiser sweep.  Slots: positive i owns static slots [i*ns, (i+1)*ns); negative pair p owns
@@ -98,6 +106,12 @@ int launch_rescal_forward(const kge_model_desc* m, const int64_t* h, const int64
                           int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_rescal_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                            int64_t n, const float* dscore, void* ws, size_t ws_bytes, bool grouped, hipStream_t s);
+int launch_ntn_pair_forward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
+                            const int64_t* nr, const int64_t* nt, int64_t n, float* scores2, void* ws, size_t ws_bytes,
+                            hipStream_t s);
+int launch_ntn_pair_backward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
+                             const int64_t* nr, const int64_t* nt, int64_t n, const float* dscore2, void* ws, size_t ws_bytes,
+                             hipStream_t s);
 int launch_transr_pair_forward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt,
                                const int64_t* nh, const int64_t* nr, const int64_t* nt, int64_t n, float* scores2, void* ws,
                                size_t ws_bytes, hipStream_t s);

@@ -42,12 +42,11 @@ size_t ntn_workspace_bytes(const kge_model_desc* m, int64_t n) { return ntn_ws_f
 
 // ---- 1. normalised rows: one wave per triple
 __global__ __launch_bounds__(256) void k_ntn_prep(const float* __restrict__ ent, const float* __restrict__ rel,
-                                                  const int64_t* __restrict__ h, const int64_t* __restrict__ r,
-                                                  const int64_t* __restrict__ t, int64_t n, int d, int kr, NtnWs w) {
+                                                  IdSplit h, IdSplit r, IdSplit t, int64_t n, int d, int kr, NtnWs w) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
-    const float* eh = ent + h[i] * d; const float* et = ent + t[i] * d; const float* er = rel + r[i] * kr;
+    const float* eh = ent + h.at(i) * d; const float* et = ent + t.at(i) * d; const float* er = rel + r.at(i) * kr;
     float nh = 0.f, nt = 0.f, nr = 0.f;
     for (int c = lane; c < d; c += 64) { nh = fmaf(eh[c], eh[c], nh); nt = fmaf(et[c], et[c], nt); }
     for (int c = lane; c < kr; c += 64) nr = fmaf(er[c], er[c], nr);
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(256) void k_ntn_finish(const float* __restrict__ M1
 
 // ---- 4. gz, relation-row gradient, linear parts of gH^/gT^           (one wave per triple)
 __global__ __launch_bounds__(256) void k_ntn_gz(const float* __restrict__ M1, const float* __restrict__ M2,
-                                                const int64_t* __restrict__ r, const float* __restrict__ dscore,
+                                                IdSplit r, const float* __restrict__ dscore,
                                                 float* __restrict__ g_rel, int64_t n, int d, int kr, NtnWs w) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -211,7 +210,7 @@ __global__ __launch_bounds__(256) void k_ntn_gz(const float* __restrict__ M1, co
         const float ir = w.inv[3 * i + 2];
         const bool fr = w.flag[3 * i + 2] != 0.f;
         if (ds != 0.f) {
-            float* gr = g_rel + r[i] * kr;
+            float* gr = g_rel + r.at(i) * kr;
             for (int s = lane; s < kr; s += 64) {
                 const float g = -ds * w.Z[i * kr + s];
                 unsafeAtomicAdd(gr + s, fr ? (g - w.Rn[i * kr + s] * dot) * ir : g * ir);
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(256) void k_ntn_gw(float* __restrict__ gW, int64_t 
 }
 
 // ---- 8. normalisation backward + scatter of the entity-row gradients    (one wave per triple)
-__global__ __launch_bounds__(256) void k_ntn_scatter(const int64_t* __restrict__ h, const int64_t* __restrict__ t,
+__global__ __launch_bounds__(256) void k_ntn_scatter(IdSplit h, IdSplit t,
                                                      const float* __restrict__ dscore, float* __restrict__ g_ent,
                                                      int64_t n, int d, NtnWs w) {
     const int lane = threadIdx.x & 63;
@@ -380,7 +379,7 @@ __global__ __launch_bounds__(256) void k_ntn_scatter(const int64_t* __restrict__
     dh = wave_sum(dh); dt = wave_sum(dt);
     const float ih = w.inv[3 * i], it = w.inv[3 * i + 1];
     const bool fh = w.flag[3 * i] != 0.f, ft = w.flag[3 * i + 1] != 0.f;
-    float* gh = g_ent + h[i] * d; float* gt = g_ent + t[i] * d;
+    float* gh = g_ent + h.at(i) * d; float* gt = g_ent + t.at(i) * d;
     for (int c = lane; c < d; c += 64) {
         const float a = w.GH[i * d + c], b2 = w.GT[i * d + c];
         unsafeAtomicAdd(gh + c, fh ? (a - w.Hn[i * d + c] * dh) * ih : a * ih);
@@ -398,7 +397,7 @@ static int ntn_check(const kge_model_desc* m, int64_t n, void* ws, size_t ws_byt
     return 0;
 }
 
-static int ntn_forward_core(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
+static int ntn_forward_core(const kge_model_desc* m, IdSplit h, IdSplit r, IdSplit t, int64_t n,
                             const NtnWs& w, float* scores, hipStream_t s) {
     const int d = m->dim, kr = m->rel_dim;
     const unsigned rows4 = (unsigned)((n + 3) / 4), tiles = (unsigned)((n + NT - 1) / NT);
@@ -414,11 +413,34 @@ static int ntn_forward_core(const kge_model_desc* m, const int64_t* h, const int
 int launch_ntn_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
                        float* scores, void* ws, size_t ws_bytes, hipStream_t s) {
     if (ntn_check(m, n, ws, ws_bytes)) return -1;
-    return ntn_forward_core(m, h, r, t, n, ntn_carve(ws, n, m->dim, m->rel_dim), scores, s);
+    return ntn_forward_core(m, id_whole(h, n), id_whole(r, n), id_whole(t, n), n, ntn_carve(ws, n, m->dim, m->rel_dim), scores, s);
 }
+
+// positives and negatives of the fused pairwise step as ONE batch of 2n triples: 3 + 5 launches per step instead of 6 + 10
+// (the workspace is linear in n, so the two per-side workspaces of the fused step hold it)
+int launch_ntn_pair_forward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
+                            const int64_t* nr, const int64_t* nt, int64_t n, float* scores2, void* ws, size_t ws_bytes,
+                            hipStream_t s) {
+    if (ntn_check(m, 2 * n, ws, ws_bytes)) return -1;
+    return ntn_forward_core(m, IdSplit{ph, nh, n}, IdSplit{pr, nr, n}, IdSplit{pt, nt, n}, 2 * n,
+                            ntn_carve(ws, 2 * n, m->dim, m->rel_dim), scores2, s);
+}
+
+static int ntn_backward_core(const kge_model_desc* m, IdSplit h, IdSplit r, IdSplit t, int64_t n, const float* dscore, void* ws,
+                             size_t ws_bytes, bool forward_in_ws, hipStream_t s);
 
 int launch_ntn_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
                         const float* dscore, void* ws, size_t ws_bytes, bool forward_in_ws, hipStream_t s) {
+    return ntn_backward_core(m, id_whole(h, n), id_whole(r, n), id_whole(t, n), n, dscore, ws, ws_bytes, forward_in_ws, s);
+}
+int launch_ntn_pair_backward(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
+                             const int64_t* nr, const int64_t* nt, int64_t n, const float* dscore2, void* ws, size_t ws_bytes,
+                             hipStream_t s) {
+    return ntn_backward_core(m, IdSplit{ph, nh, n}, IdSplit{pr, nr, n}, IdSplit{pt, nt, n}, 2 * n, dscore2, ws, ws_bytes, true, s);
+}
+
+static int ntn_backward_core(const kge_model_desc* m, IdSplit h, IdSplit r, IdSplit t, int64_t n, const float* dscore, void* ws,
+                             size_t ws_bytes, bool forward_in_ws, hipStream_t s) {
     if (ntn_check(m, n, ws, ws_bytes)) return -1;
     const int d = m->dim, kr = m->rel_dim;
     const NtnWs w = ntn_carve(ws, n, d, kr);

@@ -34,13 +34,6 @@ inline GroupWs carve_group_ws(void* ws, int64_t R, int64_t n) {
     return g;
 }
 
-// id array that may come in two pieces (the positives followed by the negatives of a pair batch): element i of [a | b]
-struct IdSplit {
-    const int64_t* a; const int64_t* b; int64_t na;
-    __device__ __forceinline__ int64_t at(int64_t i) const { return i < na ? a[i] : b[i - na]; }
-};
-inline IdSplit id_whole(const int64_t* a, int64_t n) { return IdSplit{a, nullptr, n}; }
-
 int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s);  // kge_dense.hip
 int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s);   // n = total length
 
