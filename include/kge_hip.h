@@ -353,7 +353,8 @@ int kge_pull_run(const kge_pull_plan* plan, int64_t first_batch, int64_t n_steps
  * The bundle kernel writes every gradient row it produces to its own slot of `stage` with plain stores:
  *   positive i      -> static slots  i*static_slots + site          (RotatE: h_re, h_im, r, t_re, t_im)
  *   negative pair p -> dynamic slots n_pos*static_slots + p*dynamic_slots + site   (RotatE: c_re, c_im), p = i*neg_rate + j,
- * and registers pair p with the entity it drew (dyn_count / dyn_bucket[E][dyn_cap] / overflow chain dyn_head, dyn_next[p]).
+ * and registers pair p with the entity it drew (dyn_count / dyn_bucket[E][dyn_cap] / overflow chain dyn_head (pair + 1; 0 = empty),
+ * dyn_next[p]).
  * kge_optimizer_step_staged then owns one parameter row per wave: it sums the row's slots in ascending slot order --
  * static incidences from the per-batch CSR (ent_off/ent_inc: positive << 1 | side, side 0 head / 1 tail; rel_off/rel_inc:
  * positive), dynamic ones from the entity's bucket sorted by pair -- and applies the dense optimiser in place.  No gradient
@@ -374,7 +375,7 @@ typedef struct kge_staged_step {
     const int32_t* ent_off; const int32_t* ent_inc;     /* [E+1], [2 n_pos] */
     const int32_t* rel_off; const int32_t* rel_inc;     /* [R+1], [n_pos] */
     /* optional pre-reduction of long relation lists (a graph with a handful of relations funnels thousands of slots into
-     * one row): relation r's list is cut into chunks of 32 slots, chunk ids [rel_chunk_off[r], rel_chunk_off[r+1]);
+     * one row): relation r's list is cut into chunks of 16 slots, chunk ids [rel_chunk_off[r], rel_chunk_off[r+1]);
      * chunk_rel[c] = the relation of chunk c; one wave per (chunk, relation table) sums its slots into rel_partials
      * [n_chunks][#relation tables][stage_stride] and the optimiser sums a relation row's partials in chunk order.
      * rel_chunk_off == NULL: relation rows are summed slot by slot like entity rows. */
@@ -382,6 +383,14 @@ typedef struct kge_staged_step {
     int32_t* dyn_count; int32_t* dyn_bucket; int32_t* dyn_head; int32_t* dyn_next; int32_t dyn_cap;
     int32_t* dyn_count_next; int32_t* dyn_head_next;    /* the set the NEXT step registers into: cleared by the optimiser
                                                            sweep of this step (NULL: the train entry point memsets its own) */
+    /* optional touched-row lists (SGD / Adagrad leave untouched rows alone, so their sweep only needs the rows with a slot):
+     * touched_ent / touched_rel = the entities / relations of the batch's positives (sorted, unique; static per batch);
+     * dyn_list[p] = the entity negative pair p drew if p was the first pair to register with it this step, else -1 (written
+     * by the train entry point; needs the single-set form, dyn_count_next == NULL, which that entry point clears itself --
+     * with one memset when dyn_count | dyn_head are laid out back to back).  touched_ent == NULL: every row of every table
+     * is visited (always the case for Adam / RMSprop, which move every row every step). */
+    const int32_t* touched_ent; int32_t n_touched_ent; const int32_t* touched_rel; int32_t n_touched_rel;
+    int32_t* dyn_list;
     float* stage; int64_t stage_stride;                 /* floats between slots (>= dim, multiple of 4) */
     int32_t static_slots, dynamic_slots;
     int64_t n_pos, n_neg;                               /* positives / negative pairs of the batch */

@@ -258,14 +258,26 @@ static int staged_sink(const kge_model_desc* m, const kge_staged_step* st, int64
         set_error("%s: staging plan does not match the batch (%d static + %d dynamic slots)", who, ns, nd);
         return -1;
     }
-    if (!st->dyn_count_next) {   // single registration set: clear it here (otherwise the previous optimiser sweep did)
-        hipError_t e = hipMemsetAsync(st->dyn_count, 0, (size_t)m->tot_entity * sizeof(int32_t), s);
-        if (e == hipSuccess) e = hipMemsetAsync(st->dyn_head, 0xFF, (size_t)m->tot_entity * sizeof(int32_t), s);
+    if (!st->dyn_count_next) {
+        // single registration set: clear it here (otherwise the previous optimiser sweep did).  An empty set is all zeros
+        // (head holds pair + 1), so count | head laid out back to back clear with one memset.
+        const size_t E = (size_t)m->tot_entity;
+        hipError_t e;
+        if (st->dyn_head == st->dyn_count + E) {
+            e = hipMemsetAsync(st->dyn_count, 0, 2 * E * sizeof(int32_t), s);
+        } else {
+            e = hipMemsetAsync(st->dyn_count, 0, E * sizeof(int32_t), s);
+            if (e == hipSuccess) e = hipMemsetAsync(st->dyn_head, 0, E * sizeof(int32_t), s);
+        }
         if (e != hipSuccess) { set_error("%s: memset: %s", who, hipGetErrorString(e)); return -2; }
+    } else if (st->dyn_list) {
+        set_error("%s: touched-row lists need a single registration set (dyn_count_next == NULL)", who);
+        return -1;
     }
     sink->stage = st->stage; sink->stride = st->stage_stride;
     sink->count = st->dyn_count; sink->bucket = st->dyn_bucket; sink->head = st->dyn_head; sink->next = st->dyn_next;
     sink->cap = st->dyn_cap; sink->ns = st->static_slots; sink->nd = st->dynamic_slots;
+    sink->dyn_list = st->dyn_list;
     return 0;
 }
 

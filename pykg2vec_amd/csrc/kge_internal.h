@@ -62,11 +62,13 @@ struct StageSink {
     float* stage; int64_t stride;
     int32_t* count; int32_t* bucket; int32_t* head; int32_t* next; int32_t cap;
     int32_t ns, nd;
+    int32_t* dyn_list;   // optional [n_neg]: entry p = the entity pair p drew if p was that entity's FIRST registrant, else -1
 };
 __device__ __forceinline__ void stage_register(const StageSink& k, int c, int pair) {
     const int pos = atomicAdd(k.count + c, 1);
     if (pos < k.cap) k.bucket[(int64_t)c * k.cap + pos] = pair;
-    else k.next[pair] = atomicExch(k.head + c, pair);
+    else k.next[pair] = atomicExch(k.head + c, pair + 1) - 1;   // head holds pair + 1: an all-zero buffer is an empty set
+    if (k.dyn_list) k.dyn_list[pair] = pos == 0 ? c : -1;   // (a plain store per pair: no shared counter to serialise on)
 }
 int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
                                  int64_t n_pos, int neg_rate, float alpha, const float* bern, const uint64_t* slots,

@@ -24,6 +24,7 @@ struct StagedKArgs {
     int64_t rows_total;
     int32_t* clear_count; int32_t* clear_head;   // registration set of the next step (NULL: the caller clears)
     int n_rel_tables;
+    int n_tables_cls[2];                         // number of entity-class / relation-class tables
 };
 
 template <int NV>
@@ -38,7 +39,7 @@ __device__ __forceinline__ void add_slot(float4 (&g)[NV], const float* __restric
     }
 }
 
-constexpr int kRelChunk = 32;   // slots per pre-reduced chunk of a relation's list
+constexpr int kRelChunk = 16;   // slots per pre-reduced chunk of a relation's list
 
 // one wave per (chunk, relation table): partial[chunk][j] = sum of the chunk's slots in list order
 template <int NV>
@@ -91,11 +92,32 @@ __global__ __launch_bounds__(256) void k_opt_staged(StagedKArgs a) {
     const kge_staged_step& st = a.st;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows_total) return;
-    // which table
     int tb = 0;
     int64_t id = row;
-    while (tb + 1 < st.n_tables && id >= st.tables[tb].rows) { id -= st.tables[tb].rows; ++tb; }
+    constexpr bool SPARSE = KIND == KGE_OPT_SGD || KIND == KGE_OPT_ADAGRAD;
+    if (SPARSE && st.touched_ent != nullptr) {
+        // work list instead of every row: [entities of the positives | entities drawn this step | relations of the positives],
+        // each crossed with the tables of its class; a drawn entity that also has static incidences is served by the first part
+        const int net = a.n_tables_cls[0], nrt = a.n_tables_cls[1];
+        const int64_t nA = (int64_t)st.n_touched_ent * net, nB = st.n_neg * net, nC = (int64_t)st.n_touched_rel * nrt;
+        int cls_w, j;
+        // (relation rows first: theirs are the long slot lists, so they should start with the first workgroups)
+        if (row < nC) { id = st.touched_rel[row / nrt]; j = (int)(row % nrt); cls_w = 1; }
+        else if (row < nC + nA) { id = st.touched_ent[(row - nC) / net]; j = (int)((row - nC) % net); cls_w = 0; }
+        else if (row < nC + nA + nB) {
+            const int64_t k = (row - nC - nA) / net;   // pair k: its entity, if the pair was the entity's first registrant
+            id = st.dyn_list[k]; j = (int)((row - nC - nA) % net); cls_w = 0;
+            if (id < 0 || st.ent_off[id + 1] > st.ent_off[id]) return;
+        } else return;
+        int seen = 0;
+        tb = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < st.n_tables && st.tables[k].cls == cls_w) { if (seen == j) tb = k; ++seen; }
+    } else {
+        if (row >= a.rows_total) return;
+        while (tb + 1 < st.n_tables && id >= st.tables[tb].rows) { id -= st.tables[tb].rows; ++tb; }
+    }
     int cls = 0, site_a = 0, site_b = 0, dsite = -1;
     int64_t flat_off = 0;
 #pragma unroll
@@ -107,6 +129,14 @@ __global__ __launch_bounds__(256) void k_opt_staged(StagedKArgs a) {
     float* s1 = st.state1 ? st.state1 + flat_off + id * d : nullptr;
     float* s2 = st.state2 ? st.state2 + flat_off + id * d : nullptr;
     constexpr bool DENSE = KIND == KGE_OPT_ADAM || KIND == KGE_OPT_RMSPROP;   // every row moves every step
+    // work-list mode with short rows (NV == 1): nearly every visited row has a slot, and a wave's life is a chain of dependent
+    // round trips (offsets -> incidences -> slot rows -> bucket -> ...): start the row's own parameter / state loads now
+    const bool early = !DENSE && NV == 1 && st.touched_ent != nullptr;
+    float4 pe = make_float4(0, 0, 0, 0), ae = make_float4(0, 0, 0, 0);
+    if (early && lane < (d >> 2)) {
+        pe = KGE_STREAM_LOAD(reinterpret_cast<const float4*>(p) + lane);
+        if constexpr (KIND != KGE_OPT_SGD) ae = KGE_STREAM_LOAD(reinterpret_cast<const float4*>(s1) + lane);
+    }
     float4 g[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) g[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -118,7 +148,24 @@ __global__ __launch_bounds__(256) void k_opt_staged(StagedKArgs a) {
         for (int k = 0; k < 8; ++k) jrel += (k < tb && st.tables[k].cls == 1) ? 1 : 0;
         const int c0 = st.rel_chunk_off[id], c1 = st.rel_chunk_off[id + 1];
         any = c1 > c0;
-        for (int c = c0; c < c1; ++c)
+        int c = c0;
+        constexpr int UP = NV == 1 ? 8 : 4;   // partial rows in flight (no more live registers than the slot walk below needs)
+        for (; c + UP <= c1; c += UP) {   // additions stay in chunk order
+            float4 x8[UP][NV];
+#pragma unroll
+            for (int u = 0; u < UP; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int i = lane + 64 * v;
+                    x8[u][v] = i < nvec ? *reinterpret_cast<const float4*>(st.rel_partials + ((int64_t)(c + u) * a.n_rel_tables + jrel) * stride + 4 * i)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int u = 0; u < UP; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) { g[v].x += x8[u][v].x; g[v].y += x8[u][v].y; g[v].z += x8[u][v].z; g[v].w += x8[u][v].w; }
+        }
+        for (; c < c1; ++c)
             add_slot<NV>(g, st.rel_partials + ((int64_t)c * a.n_rel_tables + jrel) * stride, nvec, lane);
     } else
     // ---- static incidences (ascending positive index => ascending slot)
@@ -159,7 +206,7 @@ __global__ __launch_bounds__(256) void k_opt_staged(StagedKArgs a) {
         const int cnt = st.dyn_count[id];
         // the OTHER registration set (used by the previous step, fully consumed) is cleared here for the next step: no
         // memset launches between steps.  One owner per entity does it (the table whose dynamic site is 0).
-        if (dsite == 0 && lane == 0 && a.clear_count) { a.clear_count[id] = 0; a.clear_head[id] = -1; }
+        if (dsite == 0 && lane == 0 && a.clear_count) { a.clear_count[id] = 0; a.clear_head[id] = 0; }
         if (cnt > 0) {
             any = true;
             const int64_t dyn_base = st.n_pos * st.static_slots;
@@ -179,7 +226,7 @@ __global__ __launch_bounds__(256) void k_opt_staged(StagedKArgs a) {
                 for (;;) {
                     int best = 0x7FFFFFFF;
                     for (int m = 0; m < nb; ++m) { const int j = st.dyn_bucket[id * st.dyn_cap + m]; if (j > last && j < best) best = j; }
-                    for (int j = st.dyn_head[id]; j >= 0; j = st.dyn_next[j]) if (j > last && j < best) best = j;
+                    for (int j = st.dyn_head[id] - 1; j >= 0; j = st.dyn_next[j]) if (j > last && j < best) best = j;
                     if (best == 0x7FFFFFFF) break;
                     add_slot<NV>(g, st.stage + (dyn_base + (int64_t)best * st.dynamic_slots + dsite) * stride, nvec, lane);
                     last = best;
@@ -195,9 +242,12 @@ __global__ __launch_bounds__(256) void k_opt_staged(StagedKArgs a) {
     for (int v = 0; v < NV; ++v) {
         const int i = lane + 64 * v;
         if (i < nvec) {
-            float4 pv = KGE_STREAM_LOAD(reinterpret_cast<const float4*>(p) + i);
-            float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
-            if constexpr (KIND != KGE_OPT_SGD) av = KGE_STREAM_LOAD(reinterpret_cast<const float4*>(s1) + i);
+            float4 pv, av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+            if (early) { pv = pe; av = ae; }
+            else {
+                pv = KGE_STREAM_LOAD(reinterpret_cast<const float4*>(p) + i);
+                if constexpr (KIND != KGE_OPT_SGD) av = KGE_STREAM_LOAD(reinterpret_cast<const float4*>(s1) + i);
+            }
             if constexpr (KIND == KGE_OPT_ADAM) bv = KGE_STREAM_LOAD(reinterpret_cast<const float4*>(s2) + i);
             opt_update<KIND>(pv.x, g[v].x, av.x, bv.x, a.opt);
             opt_update<KIND>(pv.y, g[v].y, av.y, bv.y, a.opt);
@@ -244,6 +294,16 @@ int launch_optimizer_staged(int kind, const kge_staged_step* st, float lr, int64
     a.opt = make_opt_args(lr, step);
     a.clear_count = st->dyn_count_next;
     a.clear_head = st->dyn_head_next;
+    a.n_tables_cls[0] = a.n_tables_cls[1] = 0;
+    for (int k = 0; k < st->n_tables; ++k) a.n_tables_cls[st->tables[k].cls == 1 ? 1 : 0] += 1;
+    const bool sparse_kind = kind == KGE_OPT_SGD || kind == KGE_OPT_ADAGRAD;
+    if (st->touched_ent && sparse_kind) {
+        if (!st->touched_rel || !st->dyn_list || st->dyn_count_next) {
+            set_error("kge_optimizer_step_staged: touched-row lists need touched_rel, dyn_list and a single registration set "
+                      "(dyn_count_next == NULL: the sweep no longer visits every entity, so it cannot clear the other set)");
+            return -1;
+        }
+    }
     a.rows_total = 0;
     a.n_rel_tables = 0;
     for (int k = 0; k < st->n_tables; ++k) a.n_rel_tables += st->tables[k].cls == 1 ? 1 : 0;
@@ -255,6 +315,8 @@ int launch_optimizer_staged(int kind, const kge_staged_step* st, float lr, int64
         if (st->tables[k].flat_off % 4) { set_error("kge_optimizer_step_staged: table offsets must be multiples of 4 floats"); return -1; }
         a.rows_total += st->tables[k].rows;
     }
+    if (st->touched_ent && sparse_kind)   // work list: [touched entities | drawn entities (upper bound n_neg) | touched relations]
+        a.rows_total = ((int64_t)st->n_touched_ent + st->n_neg) * a.n_tables_cls[0] + (int64_t)st->n_touched_rel * a.n_tables_cls[1];
     switch (kind) {
         case KGE_OPT_SGD: return launch_staged_kind<KGE_OPT_SGD>(a, s);
         case KGE_OPT_ADAM:

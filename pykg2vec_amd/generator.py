@@ -160,12 +160,12 @@ class StagedIndex:
     positives it labels.  Batches are fixed slices of the generator's permutation, so this is built once."""
 
     MAX_BYTES = 1 << 30
-    REL_CHUNK = 32      # csrc/kge_staged.hip kRelChunk
+    REL_CHUNK = 16      # csrc/kge_staged.hip kRelChunk
     LONG_LIST = 64      # relation lists beyond this are pre-reduced in chunks by many waves
 
     def __init__(self, batches, tot_entity, tot_relation, device):
         E, R = int(tot_entity), int(tot_relation)
-        ent_off, ent_inc, rel_off, rel_inc, chunk_off, chunk_rel = [], [], [], [], [], []
+        ent_off, ent_inc, rel_off, rel_inc, chunk_off, chunk_rel, t_ent, t_rel = [], [], [], [], [], [], [], []
         self.max_rel_list = 0
         for b in batches:
             n = len(b)
@@ -182,6 +182,8 @@ class StagedIndex:
             chunk_off.append(np.concatenate([[0], np.cumsum(nch)]).astype(np.int32))
             chunk_rel.append(np.repeat(np.arange(R, dtype=np.int32), nch))
             self.max_rel_list = max(self.max_rel_list, int(cnt.max()) if n else 0)
+            t_ent.append(np.unique(ent).astype(np.int32))
+            t_rel.append(np.flatnonzero(cnt).astype(np.int32))
         self.sizes = [len(b) for b in batches]
         self.n_chunks = [len(x) for x in chunk_rel]
         self.chunk_pos = np.concatenate([[0], np.cumsum(self.n_chunks)]).astype(np.int64)
@@ -193,6 +195,9 @@ class StagedIndex:
 
         self.ent_off, self.ent_inc, self.rel_off, self.rel_inc = cat(ent_off), cat(ent_inc), cat(rel_off), cat(rel_inc)
         self.chunk_off, self.chunk_rel = cat(chunk_off), cat(chunk_rel + [np.zeros(1, np.int32)])
+        self.t_ent, self.t_rel = cat(t_ent + [np.zeros(1, np.int32)]), cat(t_rel + [np.zeros(1, np.int32)])
+        self.t_ent_pos = np.concatenate([[0], np.cumsum([len(x) for x in t_ent])]).astype(np.int64)
+        self.t_rel_pos = np.concatenate([[0], np.cumsum([len(x) for x in t_rel])]).astype(np.int64)
 
     @classmethod
     def fits(cls, n_batches, tot_entity, tot_relation):
@@ -202,6 +207,12 @@ class StagedIndex:
         E, R, p = self.E, self.R, self.pos_off
         return (self.ent_off[b * (E + 1):(b + 1) * (E + 1)], self.ent_inc[2 * p[b]:2 * p[b + 1]],
                 self.rel_off[b * (R + 1):(b + 1) * (R + 1)], self.rel_inc[p[b]:p[b + 1]], self.sizes[b])
+
+    def touched(self, b):
+        """(entities, n, relations, n) taking part in batch b's positives: the static part of the sparse sweep's work list."""
+        a, r = self.t_ent_pos, self.t_rel_pos
+        return (self.t_ent[a[b]:max(a[b + 1], a[b] + 1)], int(a[b + 1] - a[b]),
+                self.t_rel[r[b]:max(r[b + 1], r[b] + 1)], int(r[b + 1] - r[b]))
 
     def chunks(self, b):
         """(rel_chunk_off, chunk_rel, n_chunks) of batch b, or None when no relation list is long enough to pay."""

@@ -185,7 +185,7 @@ class StagedPlan:
     }
 
     def __init__(self, kernel_name, flat_param, state1, state2, table_offsets, table_rows, dim, tot_entity, tot_relation,
-                 max_pos, neg_rate):
+                 max_pos, neg_rate, sparse=False):
         ns, nd, sites = self.LAYOUTS[kernel_name]
         if len(sites) != len(table_offsets):
             raise KgeHipError("staged plan: table list does not match the model")
@@ -194,16 +194,23 @@ class StagedPlan:
         self.stride = (int(dim) + 3) // 4 * 4
         n_slots = self.max_pos * (ns + nd * self.neg_rate)
         self.stage = torch.empty(n_slots * self.stride, dtype=torch.float32, device=dev)
-        # two registration sets (count, head) alternate between steps: the optimiser sweep of a step clears the other one
-        self.counts = [torch.zeros(tot_entity, dtype=torch.int32, device=dev) for _ in range(2)]
-        self.heads = [torch.full((tot_entity,), -1, dtype=torch.int32, device=dev) for _ in range(2)]
+        # sparse (SGD / Adagrad with touched-row lists): ONE registration set, count | head back to back so that
+        # the train entry point clears it with one memset; the sweep then visits only rows that have a slot.
+        # dense: two sets (count, head) alternate between steps and the sweep of a step clears the other one (no memset).
+        self.sparse = bool(sparse)
+        E = int(tot_entity)
+        self.sets = [torch.zeros(2 * E, dtype=torch.int32, device=dev) for _ in range(1 if self.sparse else 2)]
+        self.counts = [x[:E] for x in self.sets]
+        self.heads = [x[E:2 * E] for x in self.sets]          # overflow chain heads hold pair + 1: zero = empty
+        self.dyn_list = torch.zeros(self.max_pos * self.neg_rate, dtype=torch.int32, device=dev) if self.sparse else None
         self.parity = 0
         self.bucket = torch.zeros(tot_entity * STAGED_CAP, dtype=torch.int32, device=dev)
         self.next = torch.zeros(self.max_pos * self.neg_rate, dtype=torch.int32, device=dev)
         self._keep = (flat_param, state1, state2)
+        self._cache = {}
         self.n_rel_tables = sum(1 for x in sites if x[0] == 1)
         self.rel_partials = None
-        c = self.c = L.StagedStep()
+        c = self.c = self.cur = L.StagedStep()
         c.param = _dev(flat_param, torch.float32, "param")
         c.state1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
         c.state2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
@@ -216,7 +223,23 @@ class StagedPlan:
         c.static_slots, c.dynamic_slots = ns, nd
         c.tot_entity, c.tot_relation = int(tot_entity), int(tot_relation)
 
-    def bind(self, ent_off, ent_inc, rel_off, rel_inc, n_pos, chunks=None):
+    def bind_batch(self, b, index):
+        """Point the plan at batch b of a generator.StagedIndex.  The filled descriptor is cached per (batch, parity): the
+        eager step is two native calls plus a dictionary lookup, not a dozen pointer validations."""
+        key = (b, 0 if self.sparse else self.parity)
+        hit = self._cache.get(key)
+        if hit is None:
+            ent_off, ent_inc, rel_off, rel_inc, n = index.batch(b)
+            self.bind(ent_off, ent_inc, rel_off, rel_inc, n, index.chunks(b), index.touched(b) if self.sparse else None)
+            snap = L.StagedStep()
+            ctypes.memmove(ctypes.byref(snap), ctypes.byref(self.c), ctypes.sizeof(L.StagedStep))
+            hit = self._cache[key] = (snap, self._batch, n)
+        elif not self.sparse:
+            self.parity ^= 1
+        self.cur = hit[0]
+        return hit[2]
+
+    def bind(self, ent_off, ent_inc, rel_off, rel_inc, n_pos, chunks=None, touched=None):
         if n_pos > self.max_pos:
             raise KgeHipError("staged plan: batch larger than the plan")
         self._batch = (ent_off, ent_inc, rel_off, rel_inc, chunks)
@@ -233,11 +256,24 @@ class StagedPlan:
         c.ent_off, c.ent_inc = _dev(ent_off, torch.int32, "ent_off"), _dev(ent_inc, torch.int32, "ent_inc")
         c.rel_off, c.rel_inc = _dev(rel_off, torch.int32, "rel_off"), _dev(rel_inc, torch.int32, "rel_inc")
         c.n_pos, c.n_neg = int(n_pos), int(n_pos) * self.neg_rate
+        if self.sparse:
+            if touched is None:
+                raise KgeHipError("staged plan: the sparse sweep needs the batch's touched-row lists")
+            t_ent, n_ent, t_rel, n_rel = touched
+            self._batch += (t_ent, t_rel)
+            c.touched_ent, c.n_touched_ent = _dev(t_ent, torch.int32, "touched_ent"), int(n_ent)
+            c.touched_rel, c.n_touched_rel = _dev(t_rel, torch.int32, "touched_rel"), int(n_rel)
+            c.dyn_list = self.dyn_list.data_ptr()
+            c.dyn_count, c.dyn_head = self.counts[0].data_ptr(), self.heads[0].data_ptr()
+            c.dyn_count_next, c.dyn_head_next = None, None
+            self.cur = c
+            return self
         # this step registers into set `parity`; its optimiser sweep clears the other set for the next step
         q = self.parity
         c.dyn_count, c.dyn_head = self.counts[q].data_ptr(), self.heads[q].data_ptr()
         c.dyn_count_next, c.dyn_head_next = self.counts[q ^ 1].data_ptr(), self.heads[q ^ 1].data_ptr()
         self.parity ^= 1
+        self.cur = c
         return self
 
 
@@ -249,7 +285,7 @@ def train_pairwise_selfadv_sampled_staged(desc, triples, perm, start, n_pos, neg
     L.check(L.load().kge_train_pairwise_selfadv_sampled_staged(
         ctypes.byref(desc), _ids(triples, "triples"), _ids(perm, "perm"), int(start), int(n_pos), int(neg_rate), float(alpha),
         bp, sp, slots.numel() if slots is not None else 0, int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
-        ctypes.byref(plan.c), _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_train_pairwise_selfadv_sampled_staged")
+        ctypes.byref(plan.cur), _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_train_pairwise_selfadv_sampled_staged")
 
 
 def train_pointwise_logistic_sampled_staged(desc, triples, perm, start, n_pos, neg_rate, bern_prob, slots, seed, offset, lmbda,
@@ -260,12 +296,12 @@ def train_pointwise_logistic_sampled_staged(desc, triples, perm, start, n_pos, n
     L.check(L.load().kge_train_pointwise_logistic_sampled_staged(
         ctypes.byref(desc), _ids(triples, "triples"), _ids(perm, "perm"), int(start), int(n_pos), int(neg_rate), bp, sp,
         slots.numel() if slots is not None else 0, int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), float(lmbda),
-        int(reg_type), ctypes.byref(plan.c), _dev(loss_buf, torch.float32, "loss"), _stream()),
+        int(reg_type), ctypes.byref(plan.cur), _dev(loss_buf, torch.float32, "loss"), _stream()),
         "kge_train_pointwise_logistic_sampled_staged")
 
 
 def optimizer_step_staged(kind, plan, lr, step):
-    L.check(L.load().kge_optimizer_step_staged(OPTIMIZER_IDS[kind], ctypes.byref(plan.c), float(lr), int(step), _stream()),
+    L.check(L.load().kge_optimizer_step_staged(OPTIMIZER_IDS[kind], ctypes.byref(plan.cur), float(lr), int(step), _stream()),
             "kge_optimizer_step_staged")
 
 

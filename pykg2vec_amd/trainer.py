@@ -374,7 +374,7 @@ class Trainer:
             rows = [p.weight.shape[0] for p in self.model.parameter_list]
             self._staged = K.StagedPlan(self.model.kernel_name, flat.param, flat.state1, flat.state2, flat.offsets, rows,
                                         self.model.hidden_size, cfg.tot_entity, cfg.tot_relation, cfg.batch_size,
-                                        int(cfg.neg_rate))
+                                        int(cfg.neg_rate), sparse=cfg.optimizer in ("sgd", "adagrad"))
         return self._staged
 
     def _staged_step(self):
@@ -383,10 +383,9 @@ class Trainer:
         start, n, offset = gen._next_range()
         if n <= 0:
             return
-        idx = gen.staged_index()
-        ent_off, ent_inc, rel_off, rel_inc, n_idx = idx.batch(b)
+        plan = self._staged_plan()
+        n_idx = plan.bind_batch(b, gen.staged_index())
         assert n_idx == n
-        plan = self._staged_plan().bind(ent_off, ent_inc, rel_off, rel_inc, n, idx.chunks(b))
         if self.model.kernel_name == "rotate":
             K.train_pairwise_selfadv_sampled_staged(self._desc, gen.triples, gen.perm, start, n, gen.neg_rate, cfg.alpha,
                                                     gen.bern, gen.slots, gen.seed, offset, plan, self.loss_buf)
