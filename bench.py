@@ -329,6 +329,7 @@ def main():
     steps_per_epoch = N_TRAIN // cfg.batch_size
     init_param = tr.flat.param.clone()
     pull = tr._pull_ok()   # single GPU, big batch: the atomic-free owner-computes step (csrc/kge_pull.hip)
+    pull_dp = tr._pull_dp_ok()   # N > 1: the same kernel writes the rank's dense gradient (no atomics), then the sharded step
 
     def reset_model():
         """Back to the freshly initialised tables and optimiser state.  The hinge kernel skips the backward of pairs whose
@@ -360,7 +361,7 @@ def main():
         """n training steps through the product's step path.  Owner-computes path: each step is ONE launch (next batch's
         sampler + per-row re-evaluation, hinge, backward, dense Adam; no atomics) and the steps of an epoch are enqueued
         by one native call (kge_pull_run), so there are no per-step events."""
-        if not pull:
+        if not (pull or pull_dp):
             for k in range(n):
                 one_step(None if events is None else events[k])
             return
@@ -409,14 +410,31 @@ def main():
     value = scored_per_step * args.steps / dt
     # HIP events around each launch of the timed region: they bracket [dispatch gap after the previous kernel + the
     # kernel], i.e. an upper bound of the kernel's duration ...
-    event_ms = None if pull else float(np.mean([a.elapsed_time(b) for a, b in events]))
+    event_ms = None if (pull or pull_dp) else float(np.mean([a.elapsed_time(b) for a, b in events]))
     # ... the kernel's own duration (what rocprofv3 --kernel-trace reports, profiles/) is measured right after the
     # timed region by a burst of back-to-back launches of the SAME kernel on the same stream between two events: no
     # host gap, no optimiser in between (gradients just keep accumulating; they are cleared afterwards)
     burst = 32
     reset_model()
     eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if pull:
+    if pull_dp:
+        tr.generator.start_one_epoch(steps_per_epoch)
+        tr.step_next_batches(1)   # (allocates the gradient-mode state if the timed loop did not)
+        ps, idx = tr._pull, gen.pull_index()
+        pairs_b, inc_b, items_b, multi_b = idx.batch(0)
+        for ls in ps.lists:
+            ls.clear()
+        ps.ready, ps.cur_list = None, 0
+        K.pull_sample(pairs_b, E, gen.bern, gen.slots, gen.seed, 0, ps.lists[0])
+        torch.cuda.synchronize()
+        eb0.record()
+        for _ in range(burst):
+            K.pull_step(tr._desc, ps.tables[1], ps.hats[0], None, ps.norms[0], None, None, None, pairs_b, ps.lists[0], items_b, inc_b,
+                        ps.partials, multi_b, cfg.margin, "gradient", 0.0, 1, tr.loss_buf, reset_lists=False, run_finish=False)
+        eb1.record()
+        torch.cuda.synchronize()
+        ps.lists[0].clear()
+    elif pull:
         ps, idx = tr._pull_state()
         pairs_b, inc_b, items_b, multi_b = idx.batch(0)
         for ls in ps.lists:   # a sampler riding in the last timed step may have filled a set for a batch that never ran
@@ -491,9 +509,11 @@ def main():
     out = None
     kernel_label = ("k_pull_step<Adam,G=32,NCH=4> (owner-computes step: per-row re-evaluation of incident pairs, hinge, backward, "
                     "normalisation backward, dense Adam; no atomics)" if pull else
+                    "k_pull_step<gradient,G=32,NCH=4> (owner-computes gradient of the rank's share of the batch: per-row re-evaluation of "
+                    "incident pairs, hinge, backward, normalisation backward; dense gradient rows written once, no atomics)" if pull_dp else
                     "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)")
-    traffic, traffic_src = pmc_traffic("kge::k_pull_step<1, true, 32" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch,
-                                       fetch_scale=2.0 if pull else 1.0)
+    traffic, traffic_src = (None, None) if pull_dp else pmc_traffic(
+        "kge::k_pull_step<1, true, 32" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch, fetch_scale=2.0 if pull else 1.0)
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
@@ -507,6 +527,7 @@ def main():
                        "warmup_steps_run": args.warmup + warm_extra,
                        "model_state": "timed steps start from the freshly initialised tables (reset after warm-up)",
                        "step_path": "owner-computes (pull): kge_pull_run, one k_pull_step launch per step (the next batch's sampler rides in its leading blocks)" if pull else
+                                    "owner-computes gradient (k_pull_step, KGE_OPT_GRADIENT: no atomics) + reduce-scatter + sharded kge_optimizer_step + all-gather + kge_row_norms" if pull_dp else
                                     "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step"},
             "roofline": {"kernel": kernel_label, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

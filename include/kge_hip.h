@@ -51,7 +51,9 @@ enum kge_model {
 
 #define KGE_FLAG_L1 1u /* l1_flag of TransE/TransH/TransD (pairwise.py:72-76) */
 
-enum kge_optimizer { KGE_OPT_SGD = 0, KGE_OPT_ADAM = 1, KGE_OPT_ADAGRAD = 2, KGE_OPT_RMSPROP = 3 };
+enum kge_optimizer { KGE_OPT_SGD = 0, KGE_OPT_ADAM = 1, KGE_OPT_ADAGRAD = 2, KGE_OPT_RMSPROP = 3,
+                     KGE_OPT_GRADIENT = 4 /* kge_pull_step only: no update -- the row's dense gradient is WRITTEN to tables_out
+                                            (every row, zeros included; data-parallel ranks reduce it afterwards) */ };
 /* F2 / N3 / N3_ABS: lmbda * mean_i(sum x^2 | x^3 | |x|^3 over the rows gathered for row i) (pointwise.py get_reg's).
  * ID_F2 / ID_N3: SimplE.get_reg as the reference executes it (pointwise.py:528-536) -- it is handed the ID tensors, so
  * the term is the constant lmbda * sum_i(h_i^p + r_i^p + t_i^p) in float32: added to the loss, no gradient. */

@@ -413,17 +413,20 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
                   void* stream) {
     if (validate(m, false, "kge_pull_step")) return -1;
     if (m->model != KGE_TRANSE) { set_error("kge_pull_step: TransE only (model %d)", m->model); return -1; }
+    const bool grad_only = optimizer == KGE_OPT_GRADIENT;   // writes gradient rows: no normalised copies / norms / state out
     if (n_items <= 0 || n_multi < 0 || !tables_out || !tables_out[0] || !tables_out[1] || !hat_in || !hat_in[0] || !hat_in[1] ||
-        !hat_out || !hat_out[0] || !hat_out[1] || hat_in[0] == hat_out[0] || !norm_in || !norm_out || !pairs ||
-        !lists_ok(lists) || !items || !inc || !loss || !partials || (n_multi > 0 && !multi)) {
+        !norm_in || !pairs || !lists_ok(lists) || !items || !inc || !loss || !partials || (n_multi > 0 && !multi) ||
+        (!grad_only && (!hat_out || !hat_out[0] || !hat_out[1] || hat_in[0] == hat_out[0] || !norm_out))) {
         set_error("kge_pull_step: bad arguments");
         return -1;
     }
+    float* const no_hat[2] = {nullptr, nullptr};
+    if (grad_only) { hat_out = no_hat; }
     if (tables_out[0] == m->tables[0] || tables_out[1] == m->tables[1]) {
         set_error("kge_pull_step: the output tables must be the other half of the double buffer (rows are read by other owners)");
         return -1;
     }
-    if (optimizer != KGE_OPT_SGD && (!state1 || !state1[0] || !state1[1])) { set_error("kge_pull_step: optimizer state missing"); return -1; }
+    if (optimizer != KGE_OPT_SGD && !grad_only && (!state1 || !state1[0] || !state1[1])) { set_error("kge_pull_step: optimizer state missing"); return -1; }
     if (optimizer == KGE_OPT_ADAM && (!state2 || !state2[0] || !state2[1])) { set_error("kge_pull_step: adam needs two state buffers"); return -1; }
     if (next_pairs) {
         if (next_n < 0 || !lists_ok(next_lists) || next_lists->count == lists->count || (slots && (n_slots & (n_slots - 1)))) {

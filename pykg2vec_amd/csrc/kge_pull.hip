@@ -131,10 +131,22 @@ __device__ __forceinline__ void pull_finish_row(const PullArgs& a, int g, const 
         dX = fmaf(X[v].z, gs[v].z, dX); dX = fmaf(X[v].w, gs[v].w, dX);
     }
     dX = gsum<G>(dX) * iX;
+    if constexpr (OPT == KGE_OPT_GRADIENT) {   // data-parallel ranks: the dense gradient row itself (reduced across ranks later)
+        float4 Gw[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            Gw[v].x = fX ? (gs[v].x - (X[v].x * iX) * dX) * iX : gs[v].x * iX;
+            Gw[v].y = fX ? (gs[v].y - (X[v].y * iX) * dX) * iX : gs[v].y * iX;
+            Gw[v].z = fX ? (gs[v].z - (X[v].z * iX) * dX) * iX : gs[v].z * iX;
+            Gw[v].w = fX ? (gs[v].w - (X[v].w * iX) * dX) * iX : gs[v].w * iX;
+        }
+        store_row4<G, NV>(t_out + off, Gw, nvec, gl);
+        return;
+    }
     OptArgs o = a.opt;
     if (a.dev_hyper) { o.lr = a.dev_hyper[0]; o.step_size = a.dev_hyper[1]; o.bc2_sqrt = a.dev_hyper[2]; }
     float4 P[NV], M1[NV], M2[NV];
-    if constexpr (OPT != KGE_OPT_SGD) load_row4<G, NV>(M1, st1 + off, nvec, gl);
+    if constexpr (OPT != KGE_OPT_SGD && OPT != KGE_OPT_GRADIENT) load_row4<G, NV>(M1, st1 + off, nvec, gl);
     if constexpr (OPT == KGE_OPT_ADAM) load_row4<G, NV>(M2, st2 + off, nvec, gl);
     float n2 = 0.f;
 #pragma unroll
@@ -533,6 +545,7 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
         case KGE_OPT_ADAM: return launch_pull_opt<KGE_OPT_ADAM>(a, sa, geo, loss, s);
         case KGE_OPT_ADAGRAD: return launch_pull_opt<KGE_OPT_ADAGRAD>(a, sa, geo, loss, s);
         case KGE_OPT_RMSPROP: return launch_pull_opt<KGE_OPT_RMSPROP>(a, sa, geo, loss, s);
+        case KGE_OPT_GRADIENT: return launch_pull_opt<KGE_OPT_GRADIENT>(a, sa, geo, loss, s);
     }
     set_error("kge_pull_step: unknown optimizer %d", optimizer);
     return -1;

@@ -269,6 +269,9 @@ class Generator:
             B = self.batch_size
             nb = self.n_train // B
             pos = self._train_np[self._perm_np[:nb * B]].reshape(nb, B, 3)
+            if self.world_size > 1:   # data-parallel rank: its slice of every batch (the rule of _next_range; B % world == 0)
+                per = (B + self.world_size - 1) // self.world_size
+                pos = pos[:, self.rank * per:(self.rank + 1) * per]
             self._pull_index = PullIndex(list(pos), self.config.tot_entity, self.config.tot_relation, self.device,
                                          groups_per_block=self.K.pull_groups_per_block(self.model.hidden_size))
         return self._pull_index

@@ -14,7 +14,8 @@ MODEL_IDS = {"transe": L.TRANSE, "transh": L.TRANSH, "transd": L.TRANSD, "rotate
              "ntn": L.NTN, "distmult": L.DISTMULT, "complex": L.COMPLEX, "complexn3": L.COMPLEX, "analogy": L.ANALOGY,
              "transm": L.TRANSM, "cp": L.CP, "simple": L.SIMPLE, "simple_ignr": L.SIMPLE_IGNR, "quate": L.QUATE,
              "transr": L.TRANSR}
-OPTIMIZER_IDS = {"sgd": L.OPT_SGD, "adam": L.OPT_ADAM, "adagrad": L.OPT_ADAGRAD, "rms": L.OPT_RMSPROP}
+OPTIMIZER_IDS = {"sgd": L.OPT_SGD, "adam": L.OPT_ADAM, "adagrad": L.OPT_ADAGRAD, "rms": L.OPT_RMSPROP,
+                 "gradient": 4}   # KGE_OPT_GRADIENT: kge_pull_step writes the dense gradient instead of updating
 
 
 def _stream():
@@ -608,8 +609,10 @@ def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, s
     else:
         nx = (None, 0, None, None, 0, 0, 0, None)
     L.check(L.load().kge_pull_step(
-        ctypes.byref(desc_in), ctypes.addressof(to), ctypes.addressof(hi), ctypes.addressof(ho), _dev(norm_in, torch.float32, "norm_in"),
-        _dev(norm_out, torch.float32, "norm_out"), ctypes.addressof(s1) if state1 is not None else None,
+        ctypes.byref(desc_in), ctypes.addressof(to), ctypes.addressof(hi), ctypes.addressof(ho) if hat_out is not None else None,
+        _dev(norm_in, torch.float32, "norm_in"),
+        _dev(norm_out, torch.float32, "norm_out") if norm_out is not None else None,
+        ctypes.addressof(s1) if state1 is not None else None,
         ctypes.addressof(s2) if state2 is not None else None, _i32(pairs, "pairs"), ctypes.byref(lists.c),
         _i32(items, "items"), items.shape[0], _i32(inc, "inc"), _dev(partials, torch.float32, "partials"),
         _i32(multi, "multi") if n_multi else None, n_multi, float(margin), OPTIMIZER_IDS[optimizer], float(lr), int(step),

@@ -82,10 +82,13 @@ class PullState:
     tables, the row norms of both halves and the per-step sampler lists.  `cur` = which half holds the current tables
     (0 = FlatState.param, i.e. the storage behind the model's nn.Parameters)."""
 
-    def __init__(self, flat, model, batch_size, max_slots):
+    def __init__(self, flat, model, batch_size, max_slots, grad_only=False):
         dev = flat.param.device
         self.flat = flat
-        self.alt = torch.empty_like(flat.param)
+        # grad_only (data-parallel ranks): the step writes gradient rows into FlatState.grad instead of updated tables, so
+        # there is no second half -- `tables[1]` are the gradient views and only hats[0] / norms[0] are used
+        self.grad_only = grad_only
+        self.alt = flat.grad if grad_only else torch.empty_like(flat.param)
         shapes = [tuple(v.shape) for v in flat.views[:2]]
         offs = [v.data_ptr() - flat.param.data_ptr() for v in flat.views[:2]]
         view = lambda buf: [buf[o // 4:o // 4 + r * d].view(r, d) for o, (r, d) in zip(offs, shapes)]
@@ -93,8 +96,8 @@ class PullState:
         # row-normalised copies of both halves, rows padded to the kernels' float4 lane layout (kge_pull_partial_stride)
         stride = K.pull_partial_stride(shapes[0][1])
         self.hats = [[torch.zeros(r, stride, dtype=torch.float32, device=dev) for r, _ in shapes] for _ in range(2)]
-        self.state1 = view(flat.state1) if flat.state1 is not None else None
-        self.state2 = view(flat.state2) if flat.state2 is not None else None
+        self.state1 = view(flat.state1) if flat.state1 is not None and not grad_only else None
+        self.state2 = view(flat.state2) if flat.state2 is not None and not grad_only else None
         E, R, d = shapes[0][0], shapes[1][0], shapes[0][1]
         self.E, self.R = E, R
         self.norms = [torch.empty(E + R, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -109,13 +112,22 @@ class PullState:
 
     def sync_in(self):
         """(Re)derive the row norms from the tables the model currently holds (they may have been set from outside)."""
+        if self.grad_only:
+            self.ready = None
+            self.refresh_norms()
+            return
         self.sync_out()
+        K.row_norms(self.tables[0][0], self.norms[0][:self.E], self.hats[0][0])
+        K.row_norms(self.tables[0][1], self.norms[0][self.E:], self.hats[0][1])
+
+    def refresh_norms(self):
+        """Row norms / normalised copies of the current parameter tables (after the all-gather of a data-parallel step)."""
         K.row_norms(self.tables[0][0], self.norms[0][:self.E], self.hats[0][0])
         K.row_norms(self.tables[0][1], self.norms[0][self.E:], self.hats[0][1])
 
     def sync_out(self):
         """Make FlatState.param (the storage behind the model's parameters) hold the current tables."""
-        if self.cur == 1:
+        if self.cur == 1 and not self.grad_only:
             self.flat.param.copy_(self.alt)
             self.norms[0].copy_(self.norms[1])
             for t in (0, 1):
@@ -283,6 +295,56 @@ class Trainer:
             return env == "1"
         return self.config.batch_size * 2 > self.GRAPH_MAX_ROWS
 
+    def _pull_dp_ok(self):
+        """Data-parallel ranks: the local gradient by owner-computes (kge_pull_step in KGE_OPT_GRADIENT mode: every row of the
+        flat gradient written once, no atomics, no clearing pass), then the sharded reduce-scatter / optimiser / all-gather
+        step.  Same conditions as the single-GPU pull step, on the rank's share of the batch."""
+        import os
+        B, N = int(self.config.batch_size), self.world_size
+        if not (self.K is K and N > 1 and self.model.kernel_name == "transe" and self.model.hidden_size % 4 == 0
+                and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1
+                and self.generator is not None and B % N == 0 and self.generator.n_train >= B):
+            return False
+        env = os.environ.get("KGE_PULL")
+        if env is not None:
+            return env == "1"
+        return (B // N) * 2 > self.GRAPH_MAX_ROWS
+
+    def _pull_dp_step(self):
+        gen, cfg = self.generator, self.config
+        idx = gen.pull_index()
+        if getattr(self, "_pull", None) is None or not self._pull.grad_only:
+            self._pull = PullState(self.flat, self.model, idx.batch_size, idx.max_slots, grad_only=True)
+            self._pull.refresh_norms()
+        ps = self._pull
+        b = gen._batch_idx
+        start, n, offset = gen._next_range()
+        if b >= idx.n_batches or n != idx.batch_size:     # the short last batch: atomic-scatter kernels on this one
+            ps.ready = None
+            self._accumulate_next_batch(fixed_range=(start, n, offset))
+            self._reduce_and_step()
+            ps.refresh_norms()
+            return
+        pairs, inc, items, multi = idx.batch(b)
+        cur = ps.cur_list
+        if ps.ready != (b, offset):
+            ps.lists[cur].clear()
+            K.pull_sample(pairs, cfg.tot_entity, gen.bern, gen.slots, gen.seed, offset, ps.lists[cur])
+        nxt = None
+        if gen._pending > 0 and b + 1 < idx.n_batches:   # the next batch's sampler rides in this launch
+            per = idx.batch_size
+            off_next = gen._draws + self.rank * per * gen.neg_rate
+            nxt = (idx.batch(b + 1)[0], gen.bern, gen.slots, gen.seed, off_next, ps.lists[cur ^ 1])
+        K.pull_step(self._desc, ps.tables[1], ps.hats[0], None, ps.norms[0], None, None, None, pairs, ps.lists[cur], items, inc,
+                    ps.partials, multi, cfg.margin, "gradient", 0.0, 1, self.loss_buf, sample_next=nxt)
+        if nxt is not None:
+            ps.cur_list ^= 1
+            ps.ready = (b + 1, nxt[4])
+        else:
+            ps.ready = None
+        self._reduce_and_step(clear_local_grad=False)   # every row of the local gradient is rewritten by the next step
+        ps.refresh_norms()
+
     def _pull_state(self):
         idx = self.generator.pull_index()
         if getattr(self, "_pull", None) is None or self._pull.batch_size != idx.batch_size:
@@ -417,6 +479,10 @@ class Trainer:
             for _ in range(n):
                 self._staged_step()
             return
+        if self._pull_dp_ok():
+            for _ in range(n):
+                self._pull_dp_step()
+            return
         for _ in range(n):
             self._accumulate_next_batch()
             self._reduce_and_step()
@@ -433,7 +499,7 @@ class Trainer:
         name = torch.distributed.get_backend(self.process_group)
         return name == "nccl", name
 
-    def _reduce_and_step(self, advance=None):
+    def _reduce_and_step(self, advance=None, clear_local_grad=True):
         """Gradient exchange (N > 1) + dense optimiser.  `advance`: the device-resident step-state arguments of
         FlatState.optimizer_step_advance when the step is being captured into a hipGraph."""
         flat = self.flat
@@ -462,7 +528,8 @@ class Trainer:
             flat.grad_shard.copy_(flat.grad[flat.shard_lo:flat.shard_lo + flat.shard_numel])
             if mean:
                 flat.grad_shard.div_(self.world_size)
-        flat.grad.zero_()          # the local accumulation buffer of the next step (the optimiser clears only grad_shard)
+        if clear_local_grad:
+            flat.grad.zero_()      # the local accumulation buffer of the next step (the optimiser clears only grad_shard)
         optimise()
         dist.all_gather_into_tensor(flat.param, flat.param_shard, group=self.process_group)
 

@@ -131,6 +131,24 @@ def test_zero_rows_take_the_eps_branch_of_normalize(hip):
     assert np.all(np.isfinite(got))
 
 
+def test_bench_two_ranks_owner_computes_gradient():
+    """The same with the data-parallel owner-computes gradient step forced on (KGE_PULL=1: kge_pull_step in gradient mode, no
+    atomics, then reduce-scatter / sharded optimiser / all-gather / row norms): replicas identical, one JSON line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KGE_BENCH_SHARE_GPU="1", KGE_BENCH_CHECK_REPLICAS="1", KGE_PULL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--batch", "4096", "--eval-triples", "256"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "owner-computes gradient" in d["config"]["step_path"]
+    assert d["value"] > 0 and "REPLICAS_IDENTICAL 1" in out.stdout
+
+
 def test_bench_two_ranks_share_one_gpu():
     """bench.py's N>1 path end to end on real kernels: two ranks (gloo, both on device 0) shard the batch and the Philox
     stream, all-reduce the flat gradient and must end with bit-identical tables; rank 0 prints the one JSON line."""

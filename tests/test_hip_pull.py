@@ -159,3 +159,31 @@ def test_pull_untouched_rows_follow_dense_optimizer_semantics(hip, monkeypatch):
     for e in range(c.E):
         if e not in touched:
             assert moved[e] == had_momentum[e], e
+
+
+@pytest.mark.parametrize("l1", [True, False])
+def test_gradient_mode_equals_the_atomic_gradient(hip, world, l1, monkeypatch):
+    """kge_pull_step in KGE_OPT_GRADIENT mode (what data-parallel ranks run) writes, for every row, the dense gradient the
+    atomic-scatter kernel accumulates for the same sampled batch."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.trainer import PullState
+    tr, m, cfg = _trainer(hip, world, l1=l1, opt="sgd", pull=False, monkeypatch=monkeypatch)
+    gen = tr.generator
+    gen.start_one_epoch(1)
+    tr.flat.grad.zero_()
+    tr._accumulate_next_batch()                      # push kernel: batch 0, Philox offset 0
+    want = tr.flat.grad.clone()
+    loss_push = K.read_loss(tr.loss_buf).item()
+    idx = gen.pull_index()
+    ps = PullState(tr.flat, m, idx.batch_size, idx.max_slots, grad_only=True)
+    ps.refresh_norms()
+    pairs, inc, items, multi = idx.batch(0)
+    K.pull_sample(pairs, E, gen.bern, gen.slots, gen.seed, 0, ps.lists[0])
+    tr.flat.grad.fill_(7.0)                          # every row must be overwritten
+    tr.loss_buf.zero_()
+    K.pull_step(tr._desc, ps.tables[1], ps.hats[0], None, ps.norms[0], None, None, None, pairs, ps.lists[0], items, inc,
+                ps.partials, multi, cfg.margin, "gradient", 0.0, 1, tr.loss_buf)
+    got = tr.flat.grad
+    assert np.isclose(K.read_loss(tr.loss_buf).item(), loss_push, rtol=2e-5)
+    n = E * D + R * D
+    assert torch.allclose(got[:n], want[:n], atol=2e-5, rtol=1e-4), (got[:n] - want[:n]).abs().max().item()
