@@ -215,3 +215,58 @@ def test_pull_plan_struct_layout_matches_the_library():
     assert lib.kge_pull_partial_stride(100) == 128 and lib.kge_pull_partial_stride(102) == 0   # rows move as float4
     assert lib.kge_pull_groups_per_block(100) in (8, 16) and lib.kge_pull_groups_per_block(1000) == 8
     assert lib.kge_pull_run(None, 0, 1, 0, 0, 0, 1, 0, 0, None) != 0 and b"kge_pull_run" in lib.kge_last_error()
+
+
+def test_staged_index_is_the_incidence_csr_of_every_batch():
+    """generator.StagedIndex (the static half of the staged optimiser sweep's inverse index): per batch, entity e lists the
+    positives it heads / tails as positive << 1 | side in ascending order, relation r the positives it labels; chunk offsets
+    cut a relation's list into REL_CHUNK-slot pieces; touched lists are the sorted unique ids."""
+    from pykg2vec_amd.generator import StagedIndex
+    rng = np.random.default_rng(3)
+    E, R = 17, 3
+    batches = [np.stack([rng.integers(E, size=n), rng.integers(R, size=n), rng.integers(E, size=n)], 1) for n in (40, 40, 9)]
+    ix = StagedIndex(batches, E, R, "cpu")
+    for b, pos in enumerate(batches):
+        ent_off, ent_inc, rel_off, rel_inc, n = ix.batch(b)
+        assert n == len(pos) and int(ent_off[-1]) == 2 * n and int(rel_off[-1]) == n
+        for e in range(E):
+            want = sorted([2 * i for i in range(n) if pos[i, 0] == e] + [2 * i + 1 for i in range(n) if pos[i, 2] == e])
+            assert ent_inc[int(ent_off[e]):int(ent_off[e + 1])].tolist() == want
+        for r in range(R):
+            assert rel_inc[int(rel_off[r]):int(rel_off[r + 1])].tolist() == [i for i in range(n) if pos[i, 1] == r]
+        t_ent, n_ent, t_rel, n_rel = ix.touched(b)
+        assert t_ent[:n_ent].tolist() == sorted(set(pos[:, 0]) | set(pos[:, 2])) and t_rel[:n_rel].tolist() == sorted(set(pos[:, 1]))
+    assert ix.max_rel_list < StagedIndex.LONG_LIST and ix.chunks(0) is None
+    big = [np.stack([rng.integers(E, size=300), np.zeros(300, np.int64), rng.integers(E, size=300)], 1)]
+    ix2 = StagedIndex(big, E, R, "cpu")
+    chunk_off, chunk_rel, n_chunks = ix2.chunks(0)
+    c = StagedIndex.REL_CHUNK
+    assert n_chunks == (300 + c - 1) // c and chunk_off.tolist() == [0, n_chunks, n_chunks, n_chunks]
+    assert chunk_rel[:n_chunks].tolist() == [0] * n_chunks
+
+
+def test_pull_index_of_a_data_parallel_rank_covers_its_slice_of_every_batch():
+    """At world_size N the owner-computes gradient step of rank r works on pairs [r B/N, (r+1) B/N) of every batch -- the
+    slice Generator._next_range hands that rank."""
+    import hip_util
+    import oracle_backend
+    from pykg2vec_amd.generator import Generator
+    rng = np.random.default_rng(5)
+    E, R, n_train, B = 30, 4, 100, 32
+    train = np.stack([rng.integers(E, size=n_train), rng.integers(R, size=n_train), rng.integers(E, size=n_train)], 1)
+    hp = dict(hidden_size=8, l1_flag=True, margin=1.0)
+    cfg = hip_util.make_config(E, R, hp, train, train[:2], train[:2], batch_size=B, device="cpu")
+    m = hip_util.model_from_params("transe", {}, hp, E, R, device="cpu")
+    for rank in (0, 1):
+        gen = Generator(m, cfg, rank=rank, world_size=2, backend=oracle_backend)
+        gen.K = types.SimpleNamespace(pull_groups_per_block=lambda d: 8)   # (the geometry query is the library's)
+        idx = gen.pull_index()
+        assert idx.batch_size == B // 2 and idx.n_batches == n_train // B
+        gen.start_one_epoch(idx.n_batches)
+        perm = gen._perm_np
+        for b in range(idx.n_batches):
+            gen.K = oracle_backend
+            start, n, _ = gen._next_range()
+            assert n == B // 2 and start == b * B + rank * (B // 2)
+            pairs = idx.batch(b)[0].numpy()
+            assert np.array_equal(pairs[:, :3], train[perm[start:start + n]])
