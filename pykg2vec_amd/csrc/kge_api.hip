@@ -412,7 +412,7 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
                   int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
                   void* stream) {
     if (validate(m, false, "kge_pull_step")) return -1;
-    if (m->model != KGE_TRANSE) { set_error("kge_pull_step: TransE only (model %d)", m->model); return -1; }
+    if (m->model != KGE_TRANSE && m->model != KGE_TRANSM) { set_error("kge_pull_step: TransE / TransM only (model %d)", m->model); return -1; }
     const bool grad_only = optimizer == KGE_OPT_GRADIENT;   // writes gradient rows: no normalised copies / norms / state out
     if (n_items <= 0 || n_multi < 0 || !tables_out || !tables_out[0] || !tables_out[1] || !hat_in || !hat_in[0] || !hat_in[1] ||
         !norm_in || !pairs || !lists_ok(lists) || !items || !inc || !loss || !partials || (n_multi > 0 && !multi) ||

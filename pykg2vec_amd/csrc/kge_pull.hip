@@ -72,6 +72,7 @@ struct PullArgs {
     float margin;
     OptArgs opt;
     const float* dev_hyper;    // optional device-resident {lr, step_size, bc2_sqrt}
+    const float* theta;        // TransM (pairwise.py:341-347): fixed per-relation weight of both energies; NULL = TransE
 };
 
 // one pair of the sampled batch: draw the corruption (same Philox counters as kge_sample_batch / the fused push kernels:
@@ -187,6 +188,7 @@ template <int NV>
 struct PullRows {
     float4 hh[NV], rr[NV], tt[NV], cc[NV];
     int w;   // corrupting entity | tail << 24 | role << 25
+    float th;   // TransM weight of the pair's relation (1 for TransE)
 };
 
 template <int OPT, bool L1, int G, int NV>
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
         const unsigned lane_off = 16u * gl;
         auto fetch = [&](int h, int r, int t, int w, PullRows<NV>& b) {
             b.w = w;
+            b.th = a.theta ? a.theta[r] : 1.0f;
             const unsigned oh = (unsigned)h * kRowBytes + lane_off, orr = (unsigned)r * kRowBytes + lane_off;
             const unsigned ot = (unsigned)t * kRowBytes + lane_off, oc = (unsigned)(w & 0xFFFFFF) * kRowBytes + lane_off;
 #pragma unroll
@@ -289,9 +292,9 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
             }
             gsum2<G>(sp, sn);
             if constexpr (!L1) { sp = sqrtf(sp); sn = sqrtf(sn); }
-            const float v = sp + a.margin - sn;
+            const float v = b.th * sp + a.margin - b.th * sn;   // (TransE: th = 1, the products are exact)
             if (role == kRoleH) acc += fmaxf(v, 0.f);   // every pair has exactly one head incidence: the loss is counted there
-            const float coef = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);   // torch.max splits the subgradient at equality
+            const float coef = (v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f)) * b.th;   // torch.max splits the subgradient at equality
             if (coef == 0.f) return;
             // own row's coefficient in up / un:  H: +1 / (tail ? +1 : 0)   T: -1 / (tail ? 0 : -1)   R: +1 / +1   C: 0 / (tail ? -1 : +1);
             // d loss / d up = +coef * g(up), d loss / d un = -coef * g(un): the signs are folded into su / sv
@@ -536,6 +539,7 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
     a.n_items = n_items; a.n_multi = n_multi; a.sample_blocks = 0;
     a.E = (int)m->tot_entity; a.d = m->dim; a.l1 = (m->flags & KGE_FLAG_L1) ? 1 : 0; a.reset_lists = reset_lists;
     a.margin = margin;
+    a.theta = m->model == KGE_TRANSM ? m->tables[2] : nullptr;
     a.opt = make_opt_args(lr, step < 1 ? 1 : step);
     a.dev_hyper = dev_hyper;
     const PullSampleArgs sa = make_sample_args(next_pairs, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,

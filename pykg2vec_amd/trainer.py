@@ -282,11 +282,11 @@ class Trainer:
 
     # ------------------------------------------------------------------ owner-computes ("pull") step: big TransE batches
     def _pull_ok(self):
-        """TransE + pairwise hinge with neg_rate 1, single GPU, full batches too large for the launch-bound graph path:
+        """TransE / TransM + pairwise hinge with neg_rate 1, single GPU, full batches too large for the launch-bound graph path:
         the whole step (sampling, scoring, hinge, backward, dense optimiser) runs without atomics or a gradient buffer
         and is bit-reproducible (csrc/kge_pull.hip).  KGE_PULL=0 / 1 overrides the batch-size rule."""
         import os
-        if not (self.K is K and self.world_size == 1 and self.model.kernel_name == "transe" and self.model.hidden_size % 4 == 0
+        if not (self.K is K and self.world_size == 1 and self.model.kernel_name in ("transe", "transm") and self.model.hidden_size % 4 == 0
                 and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1
                 and self.generator is not None and self.generator.n_train >= self.config.batch_size):
             return False
@@ -301,7 +301,7 @@ class Trainer:
         step.  Same conditions as the single-GPU pull step, on the rank's share of the batch."""
         import os
         B, N = int(self.config.batch_size), self.world_size
-        if not (self.K is K and N > 1 and self.model.kernel_name == "transe" and self.model.hidden_size % 4 == 0
+        if not (self.K is K and N > 1 and self.model.kernel_name in ("transe", "transm") and self.model.hidden_size % 4 == 0
                 and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1
                 and self.generator is not None and B % N == 0 and self.generator.n_train >= B):
             return False
@@ -345,13 +345,18 @@ class Trainer:
         self._reduce_and_step(clear_local_grad=False)   # every row of the local gradient is rewritten by the next step
         ps.refresh_norms()
 
+    def _pull_fixed_tables(self):
+        """Non-trainable descriptor tables after the two embedding tables (TransM: the per-relation weights theta)."""
+        return [self.model.theta.to(self.flat.param.device).contiguous()] if self.model.kernel_name == "transm" else []
+
     def _pull_state(self):
         idx = self.generator.pull_index()
         if getattr(self, "_pull", None) is None or self._pull.batch_size != idx.batch_size:
             ps = self._pull = PullState(self.flat, self.model, idx.batch_size, idx.max_slots)
             ps.sync_in()
             gen, cfg = self.generator, self.config
-            ps.plan = K.PullPlan("transe", self.model.desc_kwargs(), cfg.tot_entity, cfg.tot_relation, ps.tables, ps.hats,
+            ps.plan = K.PullPlan(self.model.kernel_name, self.model.desc_kwargs(), cfg.tot_entity, cfg.tot_relation,
+                                 [t + self._pull_fixed_tables() for t in ps.tables], ps.hats,
                                  ps.norms, ps.state1, ps.state2, ps.lists, idx, ps.partials, cfg.margin, cfg.optimizer,
                                  cfg.learning_rate, self.loss_buf, gen.bern, gen.slots, gen.seed,
                                  idx.batch_size * gen.neg_rate)
@@ -396,7 +401,7 @@ class Trainer:
         pairs, inc, items, multi = idx.batch(0)
         K.pull_lists_explicit(pairs, nh.contiguous(), nt.contiguous(), ps.lists[0])
         self.flat.step += 1
-        desc = K.make_desc("transe", ps.tables[0], None, tot_entity=self.config.tot_entity,
+        desc = K.make_desc(self.model.kernel_name, ps.tables[0] + self._pull_fixed_tables(), None, tot_entity=self.config.tot_entity,
                            tot_relation=self.config.tot_relation, **self.model.desc_kwargs())
         K.pull_step(desc, ps.tables[1], ps.hats[0], ps.hats[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs,
                     ps.lists[0], items, inc,

@@ -21,7 +21,7 @@ def hip():
 
 @pytest.mark.parametrize("segment", [None, 2, 1])
 @pytest.mark.parametrize("opt", ["sgd", "adam", "adagrad", "rms"])
-@pytest.mark.parametrize("name", ["transe_l1", "transe_l2"])
+@pytest.mark.parametrize("name", ["transe_l1", "transe_l2", "transm_l1", "transm_l2"])
 def test_three_pull_steps_match_reference_weights(hip, name, opt, segment):
     """Golden batches of the live reference, three steps: losses and post-optimiser tables (tests/golden/ref_transe_*).
     segment=2 cuts almost every row's incidence list into several work items that combine through LDS inside one
