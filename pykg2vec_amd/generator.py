@@ -104,22 +104,31 @@ def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8)
         if free > 0:
             open_by_free.setdefault(free, []).append(bi)
     rest = np.flatnonzero(~is_local)
-    rest = rest[np.argsort(-weight[rest], kind="stable")].tolist()   # singles and global-multi items, heaviest first
+    rest = rest[np.argsort(-weight[rest], kind="stable")]             # singles and global-multi items, heaviest first
     pos_r = 0
     for bi in range(len(blocks)):                           # top up the workgroups that hold local rows
         room = GPB - len(blocks[bi])
         if room and pos_r < len(rest):
-            blocks[bi].extend(rest[pos_r:pos_r + room])
+            blocks[bi].extend(rest[pos_r:pos_r + room].tolist())
             pos_r += room
-    while pos_r < len(rest):
-        blocks.append(rest[pos_r:pos_r + GPB])
-        pos_r += GPB
-    bw = np.asarray([weight[b].max() if len(b) else 0 for b in blocks])
-    out = np.full((len(blocks) * GPB, 4), 0, dtype=np.int64)
+    # the bulk: the remaining items, GPB per workgroup in weight order (vectorised -- tens of thousands of workgroups per batch)
+    tail = rest[pos_r:]
+    n_tail_blocks = (len(tail) + GPB - 1) // GPB
+    tail_idx = np.full(n_tail_blocks * GPB, -1, dtype=np.int64)
+    tail_idx[:len(tail)] = tail
+    tail_idx = tail_idx.reshape(n_tail_blocks, GPB)
+    head_idx = np.full((len(blocks), GPB), -1, dtype=np.int64)
+    for bi, b in enumerate(blocks):
+        head_idx[bi, :len(b)] = b
+    all_idx = np.concatenate([head_idx, tail_idx]) if len(blocks) else tail_idx
+    wpad = np.concatenate([weight, [0]])                    # index -1 -> weight 0
+    bw = wpad[all_idx].max(axis=1) if len(all_idx) else np.zeros(0, dtype=np.int64)
+    all_idx = all_idx[np.argsort(-bw, kind="stable")]
+    out = np.full((len(all_idx) * GPB, 4), 0, dtype=np.int64)
     out[:, 0] = -1
-    for k, bi in enumerate(np.argsort(-bw, kind="stable")):
-        b = blocks[bi]
-        out[k * GPB:k * GPB + len(b)] = items[b]
+    flat = all_idx.reshape(-1)
+    live = flat >= 0
+    out[live] = items[flat[live]]
     grows = np.flatnonzero(nseg > GPB)
     multi = np.stack([grows, slot[first[grows]], nseg[grows], np.zeros_like(grows)], 1).astype(np.int32).reshape(-1, 4)
     pairs = np.concatenate([pos, np.zeros((B, 1), np.int64)], 1).astype(np.int32)

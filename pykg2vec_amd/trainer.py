@@ -168,6 +168,7 @@ class Trainer:
     TRAINED_MODEL_CONFIG_NAME = "config.npy"
 
     GRAPH_MAX_ROWS = 16384  # steps scoring at most this many triples are launch-bound: replay them as one hipGraph
+    PULL_INDEX_BUDGET = 256 << 20   # bytes of per-batch incidence index the owner-computes path may build (see _pull_ok)
     GRAPH_UNROLL = 8        # steps per replayed multi-step graph (even; 0 = single-step graphs only)
 
     def __init__(self, model, config, process_group=None, backend=None, use_graph=None):
@@ -293,7 +294,13 @@ class Trainer:
         env = os.environ.get("KGE_PULL")
         if env is not None:
             return env == "1"
-        return self.config.batch_size * 2 > self.GRAPH_MAX_ROWS
+        # one launch per step, enqueued by a native loop: faster than the hipGraph-replayed atomic step at every batch size
+        # measured (FB15k shape: B=128 13.1 vs 16.5 us, B=4096 17.2 vs 24.6 us, B=32768 34.5 vs 60 us).  The limit is the
+        # per-batch incidence index (16 B per parameter row and batch, built once on the host): small batches of a big graph
+        # would need gigabytes of it, and those stay on the graph-replayed path.
+        n_batches = self.generator.n_train // int(self.config.batch_size)
+        index_bytes = n_batches * (int(self.config.tot_entity) + int(self.config.tot_relation)) * 16
+        return index_bytes <= self.PULL_INDEX_BUDGET or self.config.batch_size * 2 > self.GRAPH_MAX_ROWS
 
     def _pull_dp_ok(self):
         """Data-parallel ranks: the local gradient by owner-computes (kge_pull_step in KGE_OPT_GRADIENT mode: every row of the
@@ -559,6 +566,8 @@ class Trainer:
             return False
         import os
         if os.environ.get("KGE_STAGED") == "1" and self._staged_ok():   # the staged step is an eager two-launch step
+            return False
+        if self.use_graph is None and self.generator is not None and self._pull_ok():   # one native call per epoch beats a replay per step
             return False
         if self.world_size > 1:
             # RCCL collectives are capturable (gloo is not); multi-rank capture is opt-in (use_graph=True or
