@@ -430,7 +430,8 @@ def main():
         eb0.record()
         for _ in range(burst):
             K.pull_step(tr._desc, ps.tables[1], ps.hats[0], None, ps.norms[0], None, None, None, pairs_b, ps.lists[0], items_b, inc_b,
-                        ps.partials, multi_b, cfg.margin, "gradient", 0.0, 1, tr.loss_buf, reset_lists=False, run_finish=False)
+                        ps.partials, multi_b, cfg.margin, "gradient", 0.0, 1, tr.loss_buf, reset_lists=False, run_finish=False,
+                        dense_skip=idx.skip(0))
         eb1.record()
         torch.cuda.synchronize()
         ps.lists[0].clear()
@@ -447,7 +448,7 @@ def main():
         for _ in range(burst):   # same inputs every time (lists kept, no buffer swap): the kernel's own duration
             K.pull_step(desc_b, ps.tables[1], ps.hats[0], ps.hats[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs_b, ps.lists[0],
                         items_b, inc_b, ps.partials, multi_b, cfg.margin, cfg.optimizer, cfg.learning_rate, 1, tr.loss_buf,
-                        reset_lists=False, run_finish=False)   # the small finishing launch of multi-segment rows is not in the burst
+                        reset_lists=False, run_finish=False, dense_skip=idx.skip(0))   # the small finishing launch of multi-segment rows is not in the burst
         eb1.record()
         torch.cuda.synchronize()
         ps.lists[0].clear()
@@ -503,7 +504,9 @@ def main():
         tr_s.generator = tr_s._new_generator()
         dts = timed_epochs(tr_s, 400)
         small = {"batch": 128, "value": 256 / dts, "unit": "scored triples/s", "ms_per_step": dts * 1e3,
-                 "mode": "hipGraph replay, 8 steps per graph, of fused step + Adam (next step's state derived inside the Adam launch)" if tr_s._graph is not None else "eager"}
+                 "mode": ("hipGraph replay, 8 steps per graph, of fused step + Adam (next step's state derived inside the Adam launch)" if tr_s._graph is not None
+                          else "owner-computes step, one launch per step, the epoch enqueued by one native call (kge_pull_run); compact incidence index" if getattr(tr_s, "_pull", None) is not None
+                          else "eager")}
         del tr_s
 
     out = None

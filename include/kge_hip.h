@@ -304,7 +304,7 @@ int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64
 int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
                   const float* norm_in, float* norm_out,
                   float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
-                  const int32_t* items, int64_t n_items, const int32_t* inc, float* partials, const int32_t* multi,
+                  const int32_t* items, int64_t n_items, const uint32_t* dense_skip, const int32_t* inc, float* partials, const int32_t* multi,
                   int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step, const float* dev_hyper,
                   int32_t reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern_prob, const uint64_t* slots,
                   int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
@@ -316,6 +316,9 @@ typedef struct kge_pull_batch {
     const int32_t* pairs;   /* [n_pairs, 4] */
     const int32_t* items;   /* [n_items, 4] */
     int64_t n_items;
+    const uint32_t* dense_skip;   /* NULL: `items` covers every parameter row.  Else a bitmap over the E + R rows: `items` lists
+                                   only rows with a static incidence (bit set) and every other row is visited implicitly
+                                   (dense optimisers move every row every step; its corrupting-entity draws are walked too) */
     const int32_t* inc;     /* [3 * n_pairs] */
     const int32_t* multi;   /* [n_multi, 4] or NULL */
     int64_t n_multi;

@@ -50,7 +50,8 @@ PULL_BUCKET = 16
 
 class PullBatch(ctypes.Structure):
     """struct kge_pull_batch"""
-    _fields_ = [("pairs", ctypes.c_void_p), ("items", ctypes.c_void_p), ("n_items", ctypes.c_int64), ("inc", ctypes.c_void_p),
+    _fields_ = [("pairs", ctypes.c_void_p), ("items", ctypes.c_void_p), ("n_items", ctypes.c_int64), ("dense_skip", ctypes.c_void_p),
+                ("inc", ctypes.c_void_p),
                 ("multi", ctypes.c_void_p), ("n_multi", ctypes.c_int64), ("n_pairs", ctypes.c_int64)]
 
 
@@ -147,7 +148,7 @@ _SIGNATURES = {
                                        ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(PullLists), ctypes.c_void_p]),
     "kge_pull_lists_explicit": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.POINTER(PullLists), ctypes.c_void_p]),
     "kge_pull_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 8 + [ctypes.POINTER(PullLists), ctypes.c_void_p,
-                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
+                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
                                      ctypes.c_int32, ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
                                      ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                      ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_void_p]),

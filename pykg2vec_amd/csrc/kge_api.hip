@@ -406,7 +406,7 @@ int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64
 int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
                   const float* norm_in, float* norm_out,
                   float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
-                  const int32_t* items, int64_t n_items, const int32_t* inc, float* partials, const int32_t* multi,
+                  const int32_t* items, int64_t n_items, const uint32_t* dense_skip, const int32_t* inc, float* partials, const int32_t* multi,
                   int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step, const float* dev_hyper,
                   int32_t reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern_prob, const uint64_t* slots,
                   int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
@@ -435,7 +435,7 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
         }
         if (validate_packed_key(m, "kge_pull_step")) return -1;
     }
-    return launch_pull_step(m, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, n_items, inc, partials, multi,
+    return launch_pull_step(m, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, n_items, dense_skip, inc, partials, multi,
                             n_multi, margin, optimizer, lr, step, dev_hyper, reset_lists, next_pairs, next_n, bern_prob, slots,
                             n_slots, seed, next_offset, next_lists, loss, (hipStream_t)stream);
 }
@@ -465,7 +465,7 @@ int kge_pull_run(const kge_pull_plan* p, int64_t first_batch, int64_t n_steps, i
         const float* const hat_in[2] = {p->hat[src][0], p->hat[src][1]};
         float* const hat_out[2] = {p->hat[1 - src][0], p->hat[1 - src][1]};
         rc = kge_pull_step(&p->model[src], tables_out, hat_in, hat_out, p->norm[src], p->norm[1 - src], p->state1, p->state2,
-                           b->pairs, &p->lists[cl], b->items, b->n_items, b->inc, p->partials, b->multi, b->n_multi, p->margin,
+                           b->pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip, b->inc, p->partials, b->multi, b->n_multi, p->margin,
                            p->optimizer, p->lr, first_opt_step + k, nullptr, 1, nb ? nb->pairs : nullptr, nb ? nb->n_pairs : 0,
                            p->bern_prob, p->slots, p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch,
                            nb ? &p->lists[1 - cl] : nullptr, p->loss, stream);

@@ -151,7 +151,7 @@ int pull_partial_stride(int dim);
 int pull_groups_per_block(int dim);
 int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
                      const float* norm_in, float* norm_out, float* const state1[2], float* const state2[2], const int32_t* pairs,
-                     const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const int32_t* inc, float* partials,
+                     const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* dense_skip, const int32_t* inc, float* partials,
                      const int32_t* multi, int64_t n_multi, float margin, int optimizer, float lr, int64_t step,
                      const float* dev_hyper, int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern,
                      const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,

@@ -67,6 +67,8 @@ struct PullArgs {
     float* partials;           // [slots][4 * G * NV] partial gradient sums of multi-segment rows
     const int4* multi;         // rows with several segments: (row g, first slot, number of slots, -)
     int64_t n_items, n_multi;
+    const uint32_t* dense_skip;   // optional bitmap: rows with explicit items; all other rows are visited implicitly after them
+    int n_rows;                   // E + R
     int sample_blocks;         // blocks [0, sample_blocks) sample the NEXT batch; the others own work items
     int E, d, l1, reset_lists;
     float margin;
@@ -211,6 +213,10 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
     float acc = 0.f;
     int4 it = make_int4(-1, 0, 0, 0);
     if (item < a.n_items) it = a.items[item];
+    else if (a.dense_skip != nullptr && item - a.n_items < a.n_rows) {   // implicit part: a row without static incidences
+        const int row = (int)(item - a.n_items);
+        if (!((a.dense_skip[row >> 5] >> (row & 31)) & 1u)) it = make_int4(row, 0, 0, 0);
+    }
     const int g = it.x;
     const int kind = it.w & 3;
     float4 X[NV], gs[NV];
@@ -483,7 +489,7 @@ static PullGeo pull_geo(int dim) {
 template <int OPT, int G, int NV>
 static int launch_pull_geo(PullArgs& a, const PullSampleArgs& sa, float* loss, hipStream_t s) {
     constexpr int GPB = kBlock / G;
-    const int item_blocks = (int)((a.n_items + GPB - 1) / GPB);
+    const int item_blocks = (int)((a.n_items + (a.dense_skip ? a.n_rows : 0) + GPB - 1) / GPB);
     a.sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
     if (a.l1)
         hipLaunchKernelGGL((k_pull_step<OPT, true, G, NV>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
@@ -520,7 +526,7 @@ static PullSampleArgs make_sample_args(const int32_t* pairs, int64_t n, int64_t 
 
 int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
                      const float* norm_in, float* norm_out, float* const state1[2], float* const state2[2], const int32_t* pairs,
-                     const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const int32_t* inc, float* partials,
+                     const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* dense_skip, const int32_t* inc, float* partials,
                      const int32_t* multi, int64_t n_multi, float margin, int optimizer, float lr, int64_t step,
                      const float* dev_hyper, int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern,
                      const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
@@ -537,6 +543,7 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
     a.pairs = (const int4*)pairs; a.lists = to_lists(lists);
     a.items = (const int4*)items; a.inc = inc; a.partials = partials; a.multi = (const int4*)multi;
     a.n_items = n_items; a.n_multi = n_multi; a.sample_blocks = 0;
+    a.dense_skip = dense_skip; a.n_rows = (int)(m->tot_entity + m->tot_relation);
     a.E = (int)m->tot_entity; a.d = m->dim; a.l1 = (m->flags & KGE_FLAG_L1) ? 1 : 0; a.reset_lists = reset_lists;
     a.margin = margin;
     a.theta = m->model == KGE_TRANSM ? m->tables[2] : nullptr;

@@ -49,7 +49,7 @@ def bern_table(prob):
     return p32
 
 
-def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8):
+def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8, compact=False):
     """Incidence index of ONE batch for the owner-computes step (csrc/kge_pull.hip): every parameter row (entities first,
     then tot_entity + relation) gets the sorted list of the (pair, role) slots it occupies in the batch -- role 0 = head,
     1 = tail, 2 = relation -- cut into work items of at most `segment` incidences.
@@ -59,6 +59,9 @@ def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8)
     of a row with more items than that (partial sums through global memory + the finishing kernel).  Items are laid out
     in workgroup slots (groups_per_block per workgroup = kge_pull_groups_per_block(dim); padding items have row -1),
     heaviest workgroups first.
+    compact=True lists only the rows that have an incidence and returns, as a sixth value, the bitmap of those rows (int32
+    words): the kernel visits every other row implicitly after the listed items (small batches of a big graph touch a small
+    part of the tables, and an explicit item per untouched row and batch would dominate the index).
     Returns int32 arrays (pairs [B,4], inc [3B], items [n_slots,4], multi [n_multi,4]) and the number of partial slots."""
     pos = np.asarray(pos, dtype=np.int64).reshape(-1, 3)
     B, E, nrows = len(pos), int(tot_entity), int(tot_entity) + int(tot_relation)
@@ -70,7 +73,7 @@ def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8)
     inc = vals[order].astype(np.int32)
     counts = np.bincount(rows, minlength=nrows)
     row_off = np.cumsum(counts) - counts
-    nseg = np.maximum(1, (counts + segment - 1) // segment)
+    nseg = np.maximum(0 if compact else 1, (counts + segment - 1) // segment)   # compact: untouched rows get no item
     first = np.cumsum(nseg) - nseg
     tot = int(nseg.sum())
     item_row = np.repeat(np.arange(nrows, dtype=np.int64), nseg)
@@ -132,7 +135,13 @@ def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8)
     grows = np.flatnonzero(nseg > GPB)
     multi = np.stack([grows, slot[first[grows]], nseg[grows], np.zeros_like(grows)], 1).astype(np.int32).reshape(-1, 4)
     pairs = np.concatenate([pos, np.zeros((B, 1), np.int64)], 1).astype(np.int32)
-    return pairs, inc, np.ascontiguousarray(out.astype(np.int32)), np.ascontiguousarray(multi), int(is_global.sum())
+    res = (pairs, inc, np.ascontiguousarray(out.astype(np.int32)), np.ascontiguousarray(multi), int(is_global.sum()))
+    if compact:
+        bits = np.zeros((nrows + 31) // 32 * 32, dtype=np.uint8)
+        bits[:nrows] = counts > 0
+        words = np.packbits(bits.reshape(-1, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1)
+        res += (words.view(np.int32),)
+    return res
 
 
 class PullIndex:
@@ -141,10 +150,16 @@ class PullIndex:
 
     SEGMENT = 8  # incidences per work item: rows with longer lists are cut up and finished by a second small kernel
 
-    def __init__(self, batches, tot_entity, tot_relation, device, segment=None, groups_per_block=8):
+    def __init__(self, batches, tot_entity, tot_relation, device, segment=None, groups_per_block=8, compact=None):
         import os
         seg = int(segment or os.environ.get("KGE_PULL_SEGMENT") or self.SEGMENT)   # env: tuning sweeps only
-        built = [build_pull_batch(b, tot_entity, tot_relation, seg, groups_per_block) for b in batches]
+        nrows = int(tot_entity) + int(tot_relation)
+        if compact is None:   # a batch touches at most 3 B rows: list only those when that is the smaller index
+            compact = bool(batches) and 3 * len(batches[0]) * 2 <= nrows
+        self.compact = bool(compact)
+        built = [build_pull_batch(b, tot_entity, tot_relation, seg, groups_per_block, compact=self.compact) for b in batches]
+        self.words = (nrows + 31) // 32
+        self._skip = torch.from_numpy(np.concatenate([x[5] for x in built])).to(device) if (self.compact and built) else None
         self.n_batches = len(built)
         self.batch_size = len(batches[0]) if built else 0
         self.max_slots = max([x[4] for x in built] + [1])
@@ -155,6 +170,16 @@ class PullIndex:
         self.pairs, self.inc, self.items, self.multi = cat(0), cat(1), cat(2), cat(3)
         self.item_off = np.concatenate([[0], np.cumsum([len(x[2]) for x in built])]).astype(np.int64)
         self.multi_off = np.concatenate([[0], np.cumsum([len(x[3]) for x in built])]).astype(np.int64)
+
+    def skip(self, b):
+        """Bitmap (int32 words) of the rows batch b lists explicitly, or None when its items cover every row."""
+        return self._skip[b * self.words:(b + 1) * self.words] if self._skip is not None else None
+
+    @staticmethod
+    def bytes_estimate(n_batches, batch_size, tot_entity, tot_relation):
+        nrows = int(tot_entity) + int(tot_relation)
+        listed = min(3 * batch_size, nrows) if 3 * batch_size * 2 <= nrows else nrows
+        return n_batches * (listed * 16 + 3 * batch_size * 4 + batch_size * 16 + nrows // 8)
 
     def batch(self, b):
         """(pairs, inc, items, multi) views of batch b; incidence / pair indices inside are relative to the batch."""

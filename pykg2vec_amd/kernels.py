@@ -592,7 +592,8 @@ def pull_lists_explicit(pairs, nh, nt, lists):
 
 
 def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, inc, partials, multi,
-              margin, optimizer, lr, step, loss_buf, reset_lists=True, dev_hyper=None, run_finish=True, sample_next=None):
+              margin, optimizer, lr, step, loss_buf, reset_lists=True, dev_hyper=None, run_finish=True, sample_next=None,
+              dense_skip=None):
     """One whole training step (scoring, hinge, backward, dense optimiser) without atomics: see csrc/kge_pull.hip.
     desc_in: descriptor over the tables READ; tables_out: [ent, rel] of the other half of the double buffer; hat_in /
     hat_out: the row-normalised copies of both halves.
@@ -614,7 +615,8 @@ def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, s
         _dev(norm_out, torch.float32, "norm_out") if norm_out is not None else None,
         ctypes.addressof(s1) if state1 is not None else None,
         ctypes.addressof(s2) if state2 is not None else None, _i32(pairs, "pairs"), ctypes.byref(lists.c),
-        _i32(items, "items"), items.shape[0], _i32(inc, "inc"), _dev(partials, torch.float32, "partials"),
+        _i32(items, "items"), items.shape[0], _i32(dense_skip, "dense_skip") if dense_skip is not None else None,
+        _i32(inc, "inc"), _dev(partials, torch.float32, "partials"),
         _i32(multi, "multi") if n_multi else None, n_multi, float(margin), OPTIMIZER_IDS[optimizer], float(lr), int(step),
         _dev(dev_hyper, torch.float32, "dev_hyper") if dev_hyper is not None else None, 1 if reset_lists else 0,
         *nx, _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_pull_step")
@@ -641,7 +643,9 @@ class PullPlan:
         self.batches = (L.PullBatch * index.n_batches)()
         for b in range(index.n_batches):
             pairs, inc, items, multi = index.batch(b)
-            self.batches[b] = L.PullBatch(pairs.data_ptr(), items.data_ptr(), items.shape[0], inc.data_ptr(),
+            skip = index.skip(b)
+            self.batches[b] = L.PullBatch(pairs.data_ptr(), items.data_ptr(), items.shape[0],
+                                          skip.data_ptr() if skip is not None else None, inc.data_ptr(),
                                           multi.data_ptr() if multi.shape[0] else None, multi.shape[0], pairs.shape[0])
         c.batches = ctypes.cast(self.batches, ctypes.POINTER(L.PullBatch))
         c.n_batches = index.n_batches

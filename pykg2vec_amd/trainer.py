@@ -296,10 +296,11 @@ class Trainer:
             return env == "1"
         # one launch per step, enqueued by a native loop: faster than the hipGraph-replayed atomic step at every batch size
         # measured (FB15k shape: B=128 13.1 vs 16.5 us, B=4096 17.2 vs 24.6 us, B=32768 34.5 vs 60 us).  The limit is the
-        # per-batch incidence index (16 B per parameter row and batch, built once on the host): small batches of a big graph
-        # would need gigabytes of it, and those stay on the graph-replayed path.
+        # per-batch incidence index built once on the host (16 B per listed row; batches that touch a small part of the tables
+        # list only those rows and the kernel visits the rest implicitly).
+        from .generator import PullIndex
         n_batches = self.generator.n_train // int(self.config.batch_size)
-        index_bytes = n_batches * (int(self.config.tot_entity) + int(self.config.tot_relation)) * 16
+        index_bytes = PullIndex.bytes_estimate(n_batches, int(self.config.batch_size), self.config.tot_entity, self.config.tot_relation)
         return index_bytes <= self.PULL_INDEX_BUDGET or self.config.batch_size * 2 > self.GRAPH_MAX_ROWS
 
     def _pull_dp_ok(self):
@@ -343,7 +344,7 @@ class Trainer:
             off_next = gen._draws + self.rank * per * gen.neg_rate
             nxt = (idx.batch(b + 1)[0], gen.bern, gen.slots, gen.seed, off_next, ps.lists[cur ^ 1])
         K.pull_step(self._desc, ps.tables[1], ps.hats[0], None, ps.norms[0], None, None, None, pairs, ps.lists[cur], items, inc,
-                    ps.partials, multi, cfg.margin, "gradient", 0.0, 1, self.loss_buf, sample_next=nxt)
+                    ps.partials, multi, cfg.margin, "gradient", 0.0, 1, self.loss_buf, sample_next=nxt, dense_skip=idx.skip(b))
         if nxt is not None:
             ps.cur_list ^= 1
             ps.ready = (b + 1, nxt[4])
@@ -395,17 +396,18 @@ class Trainer:
         ps.cur_list ^= carried & 1
         ps.ready = (first + n_steps, offset + n_steps * B * gen.neg_rate) if after else None
 
-    def pull_step_explicit(self, ph, pr, pt, nh, nr, nt, segment=None):
+    def pull_step_explicit(self, ph, pr, pt, nh, nr, nt, segment=None, compact=None):
         """The owner-computes step on an explicit batch (positives + given negatives, neg_rate 1): the incidence index
         of this one batch is built on the host first, so this is for parity tests and one-off batches, not the hot loop."""
         import numpy as np
         from .generator import PullIndex
         pos = np.stack([x.detach().cpu().numpy() for x in (ph, pr, pt)], 1)
         idx = PullIndex([pos], self.config.tot_entity, self.config.tot_relation, self.flat.param.device, segment,
-                        K.pull_groups_per_block(self.model.hidden_size))
+                        K.pull_groups_per_block(self.model.hidden_size), compact=compact)
         ps = PullState(self.flat, self.model, len(pos), idx.max_slots)
         ps.sync_in()
         pairs, inc, items, multi = idx.batch(0)
+        skip = idx.skip(0)
         K.pull_lists_explicit(pairs, nh.contiguous(), nt.contiguous(), ps.lists[0])
         self.flat.step += 1
         desc = K.make_desc(self.model.kernel_name, ps.tables[0] + self._pull_fixed_tables(), None, tot_entity=self.config.tot_entity,
@@ -413,7 +415,7 @@ class Trainer:
         K.pull_step(desc, ps.tables[1], ps.hats[0], ps.hats[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs,
                     ps.lists[0], items, inc,
                     ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate,
-                    self.flat.step, self.loss_buf)
+                    self.flat.step, self.loss_buf, dense_skip=skip)
         ps.cur = 1
         ps.sync_out()
 

@@ -120,7 +120,15 @@ def test_full_entity_sweep_ranks_vs_oracle_and_properties(world):
     _, ref = ko.evaluate("transe", P, test[:k], hr_t, tr_h, l1_flag=True)
     ref = np.stack([ref["head"], ref["tail"], ref["fhead"], ref["ftail"]])
     got = r1[:, :k]
-    assert (got != ref).sum() <= 3 and np.abs(got - ref).max() <= 2, (got != ref).sum()   # fp32 near-ties only
+    # every rank that differs from the oracle's must be explained by candidates inside the fp32 tolerance band around the
+    # true candidate's energy (the same criterion as against the live reference's ranks, golden_util.rank_band_ok)
+    from golden_util import rank_band_ok
+    for i, (h, r, t) in enumerate(test[:k]):
+        for side, true, a, b in (("tail", int(t), 1, 3), ("head", int(h), 0, 2)):
+            row = ko.sweep_scores("transe", P, h, r, t, side, l1_flag=True)
+            ok_r, near = rank_band_ok(row, true, got[a, i], ref[a, i])
+            ok_f, _ = rank_band_ok(row, true, got[b, i], ref[b, i])
+            assert ok_r and ok_f, (i, side, got[:, i], ref[:, i], near)
     # random-init model: mean raw rank ~ E/2
     assert abs(r1[:2].mean() - E / 2) < 0.05 * E
 

@@ -19,10 +19,10 @@ def hip():
     return hip_util
 
 
-@pytest.mark.parametrize("segment", [None, 2, 1])
+@pytest.mark.parametrize("segment,compact", [(None, False), (2, False), (1, False), (None, True), (1, True)])
 @pytest.mark.parametrize("opt", ["sgd", "adam", "adagrad", "rms"])
 @pytest.mark.parametrize("name", ["transe_l1", "transe_l2", "transm_l1", "transm_l2"])
-def test_three_pull_steps_match_reference_weights(hip, name, opt, segment):
+def test_three_pull_steps_match_reference_weights(hip, name, opt, segment, compact):
     """Golden batches of the live reference, three steps: losses and post-optimiser tables (tests/golden/ref_transe_*).
     segment=2 cuts almost every row's incidence list into several work items that combine through LDS inside one
     workgroup; segment=1 additionally pushes the relation rows (> 8 incidences) through global partial sums + the
@@ -38,7 +38,7 @@ def test_three_pull_steps_match_reference_weights(hip, name, opt, segment):
     for s in range(3):
         b = [hip.dev(x) for x in c.batch(s)]
         tr.loss_buf.zero_()
-        tr.pull_step_explicit(*b, segment=segment)
+        tr.pull_step_explicit(*b, segment=segment, compact=compact)   # compact: only touched rows listed, the rest implicit
         losses.append(K.read_loss(tr.loss_buf).item())
     assert close(np.asarray(losses), c.z["%s.losses" % opt], atol=3e-5, rtol=3e-5), (losses, c.z["%s.losses" % opt])
     for k, p in hip.table_parameters(m):
@@ -182,7 +182,7 @@ def test_gradient_mode_equals_the_atomic_gradient(hip, world, l1, monkeypatch):
     tr.flat.grad.fill_(7.0)                          # every row must be overwritten
     tr.loss_buf.zero_()
     K.pull_step(tr._desc, ps.tables[1], ps.hats[0], None, ps.norms[0], None, None, None, pairs, ps.lists[0], items, inc,
-                ps.partials, multi, cfg.margin, "gradient", 0.0, 1, tr.loss_buf)
+                ps.partials, multi, cfg.margin, "gradient", 0.0, 1, tr.loss_buf, dense_skip=idx.skip(0))
     got = tr.flat.grad
     assert np.isclose(K.read_loss(tr.loss_buf).item(), loss_push, rtol=2e-5)
     n = E * D + R * D

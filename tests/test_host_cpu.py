@@ -211,7 +211,8 @@ def test_pull_plan_struct_layout_matches_the_library():
     from pykg2vec_amd import _lib
     lib = _lib.load()
     assert lib.kge_pull_plan_bytes() == ctypes.sizeof(_lib.PullPlanC)
-    assert ctypes.sizeof(_lib.PullBatch) == 56 and ctypes.sizeof(_lib.PullLists) == 40
+    assert ctypes.sizeof(_lib.PullBatch) == 64 and ctypes.sizeof(_lib.PullLists) == 40
+    assert lib.kge_staged_step_bytes() == ctypes.sizeof(_lib.StagedStep)
     assert lib.kge_pull_partial_stride(100) == 128 and lib.kge_pull_partial_stride(102) == 0   # rows move as float4
     assert lib.kge_pull_groups_per_block(100) in (8, 16) and lib.kge_pull_groups_per_block(1000) == 8
     assert lib.kge_pull_run(None, 0, 1, 0, 0, 0, 1, 0, 0, None) != 0 and b"kge_pull_run" in lib.kge_last_error()
@@ -270,3 +271,30 @@ def test_pull_index_of_a_data_parallel_rank_covers_its_slice_of_every_batch():
             assert n == B // 2 and start == b * B + rank * (B // 2)
             pairs = idx.batch(b)[0].numpy()
             assert np.array_equal(pairs[:, :3], train[perm[start:start + n]])
+
+
+@pytest.mark.parametrize("E,R,B,seg", [(53, 7, 32, 8), (53, 7, 32, 1), (500, 20, 40, 8), (14951, 1345, 128, 8)])
+def test_compact_pull_index_visits_every_row_exactly_once(E, R, B, seg):
+    """generator.build_pull_batch(compact=True): explicit items for the rows with an incidence, a bitmap of those rows, and the
+    kernel's implicit enumeration (every row whose bit is clear, after the explicit items) together cover each parameter row
+    once; the explicit part is the full index restricted to the touched rows."""
+    from pykg2vec_amd.generator import build_pull_batch
+    rng = np.random.default_rng(E + B)
+    pos = np.stack([rng.integers(E, size=B), rng.integers(R, size=B), rng.integers(E, size=B)], 1)
+    full = build_pull_batch(pos, E, R, seg, 8)
+    pairs, inc, items, multi, nglob, words = build_pull_batch(pos, E, R, seg, 8, compact=True)
+    assert np.array_equal(pairs, full[0]) and np.array_equal(inc, full[1]) and np.array_equal(multi, full[3]) and nglob == full[4]
+    nrows = E + R
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:nrows].astype(bool)
+    touched = np.zeros(nrows, bool)
+    touched[pos[:, 0]] = True; touched[pos[:, 2]] = True; touched[E + pos[:, 1]] = True
+    assert np.array_equal(bits, touched)
+    live = items[items[:, 0] >= 0]
+    assert set(live[:, 0]) == set(np.flatnonzero(touched)) and len(items) % 8 == 0
+    # the same (row, first, end, info) items as the full index has for those rows
+    f_live = full[2][full[2][:, 0] >= 0]
+    want = {tuple(x) for x in f_live if touched[x[0]]}
+    assert {tuple(x) for x in live} == want
+    implicit = [g for g in range(nrows) if not bits[g]]
+    rows_once = sorted(set(live[:, 0])) + implicit
+    assert sorted(rows_once) == list(range(nrows))
