@@ -1,4 +1,7 @@
 #!/bin/bash
+# Same-box A/B of k_eval_gemm builds (profiles/r02_experiments.md).  The variant libraries are built by compiling kge_eval.hip
+# with -D switches (e.g. -DKGE_NO_LDS_PREFETCH) and linking it with the other objects of pykg2vec_amd/csrc/build into
+# tools/_libs/libkge_<name>.so; KGE_HIP_LIB selects the library inside ONE gpurun call (boxes differ by up to +-8 %).
 ulimit -c 0
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT

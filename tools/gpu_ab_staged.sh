@@ -1,4 +1,6 @@
 #!/bin/bash
+# Same-box A/B of the staged (atomic-free) step against the atomic-scatter step (KGE_STAGED=0/1) through bench.py's C2/C3/C4
+# records, plus a rocprofv3 kernel table of the staged run (profiles/r02_experiments.md).
 ulimit -c 0
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+# GPU test suite + __graft_entry__.smoke(), as the driver runs them at round end (run through gpurun).
 ulimit -c 0
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
