@@ -283,8 +283,13 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
  * copies x / max(||x||, 1e-12) of the tables read / written (what other owners gather), rows padded with zeros to
  * kge_pull_partial_stride(dim) floats; norm_in / norm_out [E + R]: their
  * L2 row norms (kge_row_norms fills both before the first step); state1 / state2: optimiser state per table.
- * dim must be a multiple of 4 (rows move as float4).
- * partials: kge_pull_partial_stride(dim) floats per slot. */
+ * dim must be a multiple of 4 (rows move as float4) and at most 1024.  TransM: m->tables[2] = the per-relation weights.
+ * partials: kge_pull_partial_stride(dim) floats per slot.
+ * dense_skip (optional): bitmap over the E + R rows of the rows `items` lists; every other row is visited implicitly after the
+ * listed items (a batch that touches a small part of the tables needs no explicit item per untouched row).  NULL: `items`
+ * covers every row.
+ * optimizer == KGE_OPT_GRADIENT: no update -- tables_out receive the dense gradient rows (every row, zeros included);
+ * hat_out / norm_out / state may be NULL.  This is what data-parallel ranks run before their reduce-scatter. */
 #define KGE_PULL_BUCKET 16
 typedef struct kge_pull_lists {
     int32_t* pc;      /* [n]  per pair: corrupting entity | (tail corrupted) << 24 */

@@ -287,7 +287,7 @@ class Trainer:
         the whole step (sampling, scoring, hinge, backward, dense optimiser) runs without atomics or a gradient buffer
         and is bit-reproducible (csrc/kge_pull.hip).  KGE_PULL=0 / 1 overrides the batch-size rule."""
         import os
-        if not (self.K is K and self.world_size == 1 and self.model.kernel_name in ("transe", "transm") and self.model.hidden_size % 4 == 0
+        if not (self.K is K and self.world_size == 1 and self.model.kernel_name in ("transe", "transm") and self.model.hidden_size % 4 == 0 and self.model.hidden_size <= 1024
                 and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1
                 and self.generator is not None and self.generator.n_train >= self.config.batch_size):
             return False
@@ -309,7 +309,7 @@ class Trainer:
         step.  Same conditions as the single-GPU pull step, on the rank's share of the batch."""
         import os
         B, N = int(self.config.batch_size), self.world_size
-        if not (self.K is K and N > 1 and self.model.kernel_name in ("transe", "transm") and self.model.hidden_size % 4 == 0
+        if not (self.K is K and N > 1 and self.model.kernel_name in ("transe", "transm") and self.model.hidden_size % 4 == 0 and self.model.hidden_size <= 1024
                 and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1
                 and self.generator is not None and B % N == 0 and self.generator.n_train >= B):
             return False
