@@ -401,6 +401,9 @@ typedef struct kge_staged_step {
      * is visited (always the case for Adam / RMSprop, which move every row every step). */
     const int32_t* touched_ent; int32_t n_touched_ent; const int32_t* touched_rel; int32_t n_touched_rel;
     int32_t* dyn_list;
+    float* dyn_scale;                                   /* optional [n_neg]: factor applied to the dynamic slots of pair p when they are
+                                                           summed (RotatE: the single-pass bundle kernel stages them relative to a running
+                                                           softmax maximum and writes the normalisation here); NULL = 1 */
     float* stage; int64_t stage_stride;                 /* floats between slots (>= dim, multiple of 4) */
     int32_t static_slots, dynamic_slots;
     int64_t n_pos, n_neg;                               /* positives / negative pairs of the batch */

@@ -82,6 +82,7 @@ class StagedStep(ctypes.Structure):
                 ("dyn_count_next", ctypes.c_void_p), ("dyn_head_next", ctypes.c_void_p),
                 ("touched_ent", ctypes.c_void_p), ("n_touched_ent", ctypes.c_int32), ("touched_rel", ctypes.c_void_p),
                 ("n_touched_rel", ctypes.c_int32), ("dyn_list", ctypes.c_void_p),
+                ("dyn_scale", ctypes.c_void_p),
                 ("stage", ctypes.c_void_p), ("stage_stride", ctypes.c_int64),
                 ("static_slots", ctypes.c_int32), ("dynamic_slots", ctypes.c_int32),
                 ("n_pos", ctypes.c_int64), ("n_neg", ctypes.c_int64),

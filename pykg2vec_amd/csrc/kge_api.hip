@@ -247,7 +247,7 @@ int kge_train_pairwise_selfadv_sampled(const kge_model_desc* m, const int64_t* t
     }
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_train_pairwise_selfadv_sampled: n_slots must be a power of two"); return -1; }
     return launch_rotate_bundle_sampled(m, triples, perm, start, n_pos, neg_rate, alpha, bern_prob, slots, n_slots, seed,
-                                        offset, dev_cursor, loss, nullptr, (hipStream_t)stream);
+                                        offset, dev_cursor, loss, nullptr, nullptr, (hipStream_t)stream);
 }
 
 static int staged_sink(const kge_model_desc* m, const kge_staged_step* st, int64_t n_pos, int32_t neg_rate, int ns, int nd,
@@ -298,8 +298,9 @@ int kge_train_pairwise_selfadv_sampled_staged(const kge_model_desc* m, const int
     StageSink sink;
     const int rc = staged_sink(m, st, n_pos, neg_rate, 5, 2, who, s, &sink);
     if (rc) return rc;
+    if (!st->dyn_scale) { set_error("%s: the single-pass kernel needs dyn_scale (one float per negative pair)", who); return -1; }
     return launch_rotate_bundle_sampled(m, triples, perm, start, n_pos, neg_rate, alpha, bern_prob, slots, n_slots, seed,
-                                        offset, nullptr, loss, &sink, s);
+                                        offset, nullptr, loss, &sink, st->dyn_scale, s);
 }
 
 int kge_train_pointwise_logistic_sampled_staged(const kge_model_desc* m, const int64_t* triples, const int64_t* perm,

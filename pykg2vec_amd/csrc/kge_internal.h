@@ -73,7 +73,9 @@ __device__ __forceinline__ void stage_register(const StageSink& k, int c, int pa
 int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
                                  int64_t n_pos, int neg_rate, float alpha, const float* bern, const uint64_t* slots,
                                  int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor, float* loss,
-                                 const StageSink* sink /* NULL: atomic scatter into m->grads */, hipStream_t s);
+                                 const StageSink* sink /* NULL: atomic scatter into m->grads */,
+                                 float* pair_scale /* staged: per-negative factor the optimiser applies to the dynamic slots */,
+                                 hipStream_t s);
 int launch_optimizer_staged(int kind, const kge_staged_step* st, float lr, int64_t step, hipStream_t s);
 int launch_pointwise_logistic_sampled_staged(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
                                              int64_t n_pos, int neg_rate, const float* bern, const uint64_t* slots,

@@ -348,9 +348,9 @@ __global__ __launch_bounds__(kBlock) void k_transx_pair_sampled(DeviceModel m, i
 // Pass 1 scores, group softmax gives the detached self-adversarial weights (criterion.py:13-23), pass 2 re-gathers the
 // two rows per negative and back-propagates; gradients of the positive's five rows accumulate in registers and are
 // scattered once per bundle.
-template <int G, int NCH, bool STAGED>
+template <int G, int NCH>
 __global__ __launch_bounds__(kBlock) void k_rotate_bundle_sampled(DeviceModel m, int64_t n_pos, int neg_rate, float alpha,
-                                                                  float* __restrict__ loss, FusedSampler fs, StageSink sink) {
+                                                                  float* __restrict__ loss, FusedSampler fs) {
     constexpr int GPB = kBlock / G;
     const int gl = threadIdx.x % G;
     const int d = m.dim;
@@ -452,35 +452,158 @@ __global__ __launch_bounds__(kBlock) void k_rotate_bundle_sampled(DeviceModel m,
                     GP[k] += Rr * (-CR[k] * SN[k] - CI[k] * CS[k]) + Ii * (CR[k] * CS[k] - CI[k] * SN[k]);
                 }
             }
-            if constexpr (STAGED) {
-                // atomic-free form: the two gradient rows go to this negative's own staging slots with plain stores, and the
-                // pair is registered with entity c (whose owner sums its slots in kge_optimizer_step_staged)
-                const int64_t pair = i * neg_rate + j;
-                float* slot = sink.stage + (n_pos * sink.ns + pair * sink.nd) * sink.stride;
-                store_row<G, NCH>(slot, gCR, d, gl);
-                store_row<G, NCH>(slot + sink.stride, gCI, d, gl);
-                if (gl == 0) stage_register(sink, (int)c, (int)pair);
-            } else {
-                atomic_add_row<G, NCH>(m.grad[0] + c * (int64_t)d, gCR, d, gl);
-                atomic_add_row<G, NCH>(m.grad[1] + c * (int64_t)d, gCI, d, gl);
-            }
+            atomic_add_row<G, NCH>(m.grad[0] + c * (int64_t)d, gCR, d, gl);
+            atomic_add_row<G, NCH>(m.grad[1] + c * (int64_t)d, gCI, d, gl);
         }
 #pragma unroll
         for (int k = 0; k < NCH; ++k) GP[k] = GP[k] / m.phase_div;
-        if constexpr (STAGED) {   // static slots of positive i: h_re, h_im, r, t_re, t_im
-            float* slot = sink.stage + i * sink.ns * sink.stride;
-            store_row<G, NCH>(slot, gHR, d, gl);
-            store_row<G, NCH>(slot + sink.stride, gHI, d, gl);
-            store_row<G, NCH>(slot + 2 * sink.stride, GP, d, gl);
-            store_row<G, NCH>(slot + 3 * sink.stride, gTR, d, gl);
-            store_row<G, NCH>(slot + 4 * sink.stride, gTI, d, gl);
-        } else {
-            atomic_add_row<G, NCH>(m.grad[0] + h * (int64_t)d, gHR, d, gl);
-            atomic_add_row<G, NCH>(m.grad[1] + h * (int64_t)d, gHI, d, gl);
-            atomic_add_row<G, NCH>(m.grad[2] + r * (int64_t)d, GP, d, gl);
-            atomic_add_row<G, NCH>(m.grad[0] + t * (int64_t)d, gTR, d, gl);
-            atomic_add_row<G, NCH>(m.grad[1] + t * (int64_t)d, gTI, d, gl);
+        atomic_add_row<G, NCH>(m.grad[0] + h * (int64_t)d, gHR, d, gl);
+        atomic_add_row<G, NCH>(m.grad[1] + h * (int64_t)d, gHI, d, gl);
+        atomic_add_row<G, NCH>(m.grad[2] + r * (int64_t)d, GP, d, gl);
+        atomic_add_row<G, NCH>(m.grad[0] + t * (int64_t)d, gTR, d, gl);
+        atomic_add_row<G, NCH>(m.grad[1] + t * (int64_t)d, gTI, d, gl);
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
+
+// ---- the staged (atomic-free) form of the same step, SINGLE PASS over the negatives.  The two-pass kernel gathers every
+// negative's two rows twice (energies first, gradients once the softmax weights are known); at d = 1000 those 4 KB rows come
+// from the Infinity Cache / HBM and the gathers ARE the kernel (283 MB per C3 step at ~3.1 TB/s).  Here the self-adversarial
+// softmax is accumulated online (running maximum M, running sums rescaled by exp(M_old - M_new) whenever the maximum moves):
+// negative j contributes with the unnormalised weight e_j = exp(alpha n_j - M_j) the moment its rows are in registers --
+// its own two gradient rows are staged scaled by e_j sigmoid(n_j) together with the per-pair factor
+// exp(M_j - M_final) * (-1 / (B * sum_j e_j)), which kge_optimizer_step_staged applies when it sums the slot; the positive's
+// five rows accumulate in registers and are scaled once at the end.  Same mathematics, one gather per row.
+template <int G, int NCH>
+__global__ __launch_bounds__(kBlock) void k_rotate_bundle_staged(DeviceModel m, int64_t n_pos, int neg_rate, float alpha,
+                                                                 float* __restrict__ loss, FusedSampler fs, StageSink sink,
+                                                                 float* __restrict__ pair_scale) {
+    constexpr int GPB = kBlock / G;
+    const int gl = threadIdx.x % G;
+    const int d = m.dim;
+    const float inv_b = 1.0f / (float)n_pos;
+    const int gbase = (threadIdx.x & 63) / G * G;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G; i < n_pos; i += (int64_t)gridDim.x * GPB) {
+        const int64_t row = fs.perm[fs.start + i];
+        const int64_t h = fs.triples[3 * row], r = fs.triples[3 * row + 1], t = fs.triples[3 * row + 2];
+        int my_c = 0, my_tail = 0;  // lane j: corrupting entity and side of negative j
+        if (gl < neg_rate) {
+            int64_t nh, nt;
+            corrupt_one(h, r, t, fs.E, fs.bern, fs.slots, fs.mask, fs.seed, fs.offset + (unsigned long long)(i * neg_rate + gl), nh, nt);
+            my_tail = nh == h;
+            my_c = (int)(my_tail ? nt : nh);
         }
+        float HR[NCH], HI[NCH], TR[NCH], TI[NCH], CS[NCH], SN[NCH];
+        {
+            float RL[NCH];
+            load_row<G, NCH>(HR, m.tab[0] + h * (int64_t)d, d, gl);
+            load_row<G, NCH>(HI, m.tab[1] + h * (int64_t)d, d, gl);
+            load_row<G, NCH>(RL, m.tab[2] + r * (int64_t)d, d, gl);
+            load_row<G, NCH>(TR, m.tab[0] + t * (int64_t)d, d, gl);
+            load_row<G, NCH>(TI, m.tab[1] + t * (int64_t)d, d, gl);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) sincosf(RL[k] / m.phase_div, &SN[k], &CS[k]);
+        }
+        // unnormalised, running-maximum-relative sums over the negatives seen so far
+        float aHR[NCH], aHI[NCH], aTR[NCH], aTI[NCH], aP[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) { aHR[k] = aHI[k] = aTR[k] = aTI[k] = aP[k] = 0.f; }
+        float M = -INFINITY, D = 0.f, Lw = 0.f;
+        float m_mine = 0.f;   // lane j: the running maximum at the time negative j was staged
+        // the rows of negative j + 1 are requested before negative j is evaluated (one wave per SIMD: nothing else would
+        // cover the round trip to the Infinity Cache / HBM)
+        float NR[NCH], NI[NCH];
+        {
+            const int64_t c0 = __shfl(my_c, gbase, 64);
+            load_row<G, NCH>(NR, m.tab[0] + c0 * (int64_t)d, d, gl);
+            load_row<G, NCH>(NI, m.tab[1] + c0 * (int64_t)d, d, gl);
+        }
+        for (int j = 0; j < neg_rate; ++j) {
+            const int64_t c = __shfl(my_c, gbase + j, 64);
+            const bool tail = __shfl(my_tail, gbase + j, 64) != 0;
+            float CR[NCH], CI[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { CR[k] = NR[k]; CI[k] = NI[k]; }
+            if (j + 1 < neg_rate) {
+                const int64_t cn1 = __shfl(my_c, gbase + j + 1, 64);
+                load_row<G, NCH>(NR, m.tab[0] + cn1 * (int64_t)d, d, gl);
+                load_row<G, NCH>(NI, m.tab[1] + cn1 * (int64_t)d, d, gl);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of this negative's arithmetic
+            // residual of the negative triple: (h, r, c) when the tail was corrupted, (c, r, t) otherwise
+            float re[NCH], im[NCH], p = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const float ar = tail ? HR[k] : CR[k], ai = tail ? HI[k] : CI[k];
+                const float br = tail ? CR[k] : TR[k], bi = tail ? CI[k] : TI[k];
+                re[k] = ar * CS[k] - ai * SN[k] - br;
+                im[k] = ar * SN[k] + ai * CS[k] - bi;
+                p += re[k] * re[k] + im[k] * im[k];
+            }
+            const float nj = m.margin - gsum<G>(p);          // = -(energy of negative j)
+            const float a = nj * alpha;
+            const float Mn = fmaxf(M, a);
+            const float f = expf(M - Mn);                     // 0 for the first negative (M = -inf)
+            const float e = expf(a - Mn);
+            const float wt = e * sigmoid_t(nj);               // unnormalised coefficient weight
+            D = D * f + e;
+            Lw = Lw * f + e * logsigmoid_t(-nj);
+            M = Mn;
+            if (gl == j) m_mine = Mn;
+            float gCR[NCH], gCI[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const float Rr = 2.f * wt * re[k], Ii = 2.f * wt * im[k];
+                aHR[k] *= f; aHI[k] *= f; aTR[k] *= f; aTI[k] *= f; aP[k] *= f;
+                if (tail) {
+                    gCR[k] = -Rr; gCI[k] = -Ii;
+                    aHR[k] += Rr * CS[k] + Ii * SN[k];
+                    aHI[k] += -Rr * SN[k] + Ii * CS[k];
+                    aP[k] += Rr * (-HR[k] * SN[k] - HI[k] * CS[k]) + Ii * (HR[k] * CS[k] - HI[k] * SN[k]);
+                } else {
+                    gCR[k] = Rr * CS[k] + Ii * SN[k];
+                    gCI[k] = -Rr * SN[k] + Ii * CS[k];
+                    aTR[k] -= Rr; aTI[k] -= Ii;
+                    aP[k] += Rr * (-CR[k] * SN[k] - CI[k] * CS[k]) + Ii * (CR[k] * CS[k] - CI[k] * SN[k]);
+                }
+            }
+            const int64_t pair = i * neg_rate + j;
+            float* slot = sink.stage + (n_pos * sink.ns + pair * sink.nd) * sink.stride;
+            store_row<G, NCH>(slot, gCR, d, gl);
+            store_row<G, NCH>(slot + sink.stride, gCI, d, gl);
+            if (gl == 0) stage_register(sink, (int)c, (int)pair);
+        }
+        // normalisation: coefficient of negative j = -(e_j sigmoid(n_j) / D) / B with e_j relative to the FINAL maximum
+        const float cn = -inv_b / D;
+        if (gl < neg_rate) pair_scale[i * neg_rate + gl] = expf(m_mine - M) * cn;
+        // the positive triple itself
+        float p0 = 0.f, re0[NCH], im0[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            re0[k] = HR[k] * CS[k] - HI[k] * SN[k] - TR[k];
+            im0[k] = HR[k] * SN[k] + HI[k] * CS[k] - TI[k];
+            p0 += re0[k] * re0[k] + im0[k] * im0[k];
+        }
+        const float s_pos = -(m.margin - gsum<G>(p0));
+        acc += (-(Lw / D) - logsigmoid_t(-s_pos)) * inv_b;
+        const float c_pos = sigmoid_t(s_pos) * inv_b;
+        float gHR[NCH], gHI[NCH], gTR[NCH], gTI[NCH], GP[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const float Rr = 2.f * c_pos * re0[k], Ii = 2.f * c_pos * im0[k];
+            gHR[k] = Rr * CS[k] + Ii * SN[k] + cn * aHR[k];
+            gHI[k] = -Rr * SN[k] + Ii * CS[k] + cn * aHI[k];
+            gTR[k] = -Rr + cn * aTR[k];
+            gTI[k] = -Ii + cn * aTI[k];
+            GP[k] = (Rr * (-HR[k] * SN[k] - HI[k] * CS[k]) + Ii * (HR[k] * CS[k] - HI[k] * SN[k]) + cn * aP[k]) / m.phase_div;
+        }
+        float* slot = sink.stage + i * sink.ns * sink.stride;   // static slots of positive i: h_re, h_im, r, t_re, t_im
+        store_row<G, NCH>(slot, gHR, d, gl);
+        store_row<G, NCH>(slot + sink.stride, gHI, d, gl);
+        store_row<G, NCH>(slot + 2 * sink.stride, GP, d, gl);
+        store_row<G, NCH>(slot + 3 * sink.stride, gTR, d, gl);
+        store_row<G, NCH>(slot + 4 * sink.stride, gTI, d, gl);
     }
     block_accumulate_loss<G>(acc, gl, loss);
 }
@@ -561,7 +684,7 @@ int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triple
 int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples, const int64_t* perm, int64_t start,
                                  int64_t n_pos, int neg_rate, float alpha, const float* bern, const uint64_t* slots,
                                  int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor, float* loss,
-                                 const StageSink* sink, hipStream_t s) {
+                                 const StageSink* sink, float* pair_scale, hipStream_t s) {
     Geometry geo;
     if (!geometry_for(m, &geo)) return -1;
     if (m->model != KGE_ROTATE) { set_error("kge_train_pairwise_selfadv_sampled: RotatE only"); return -1; }
@@ -575,9 +698,9 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
 #define KGE_RB(G_, NCH_)                                                                                                      \
     if (geo.G == G_ && geo.NCH == NCH_) {                                                                                      \
         if (sink)                                                                                                              \
-            k_rotate_bundle_sampled<G_, NCH_, true><<<dim3(Launch<KGE_ROTATE, G_, NCH_>::grid(n_pos)), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs, *sink); \
+            k_rotate_bundle_staged<G_, NCH_><<<dim3(Launch<KGE_ROTATE, G_, NCH_>::grid(n_pos)), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs, *sink, pair_scale); \
         else                                                                                                                   \
-            k_rotate_bundle_sampled<G_, NCH_, false><<<dim3(Launch<KGE_ROTATE, G_, NCH_>::grid(n_pos)), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs, StageSink{}); \
+            k_rotate_bundle_sampled<G_, NCH_><<<dim3(Launch<KGE_ROTATE, G_, NCH_>::grid(n_pos)), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs); \
         return check_launch("k_rotate_bundle_sampled");                                                                        \
     }
     KGE_RB(32, 1) KGE_RB(32, 2) KGE_RB(32, 4) KGE_RB(32, 8) KGE_RB(64, 8) KGE_RB(64, 16)

@@ -28,6 +28,18 @@ struct StagedKArgs {
 };
 
 template <int NV>
+__device__ __forceinline__ void add_slot_scaled(float4 (&g)[NV], const float* __restrict__ slot, float sc, int nvec, int lane) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int i = lane + 64 * v;
+        if (i < nvec) {
+            const float4 x = *reinterpret_cast<const float4*>(slot + 4 * i);
+            g[v].x = fmaf(sc, x.x, g[v].x); g[v].y = fmaf(sc, x.y, g[v].y); g[v].z = fmaf(sc, x.z, g[v].z); g[v].w = fmaf(sc, x.w, g[v].w);
+        }
+    }
+}
+
+template <int NV>
 __device__ __forceinline__ void add_slot(float4 (&g)[NV], const float* __restrict__ slot, int nvec, int lane) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -218,7 +230,9 @@ __global__ __launch_bounds__(256) void k_opt_staged(StagedKArgs a) {
                     const unsigned long long who = __ballot(lane < cnt && rank == r);
                     const int src = __ffsll((long long)who) - 1;
                     const int pair = __shfl(mine, src, 64);
-                    add_slot<NV>(g, st.stage + (dyn_base + (int64_t)pair * st.dynamic_slots + dsite) * stride, nvec, lane);
+                    const float* sl = st.stage + (dyn_base + (int64_t)pair * st.dynamic_slots + dsite) * stride;
+                    if (st.dyn_scale) add_slot_scaled<NV>(g, sl, st.dyn_scale[pair], nvec, lane);
+                    else add_slot<NV>(g, sl, nvec, lane);
                 }
             } else {   // overflowed bucket: selection by ascending pair over bucket + chain
                 const int nb = cnt < st.dyn_cap ? cnt : st.dyn_cap;
@@ -228,7 +242,9 @@ __global__ __launch_bounds__(256) void k_opt_staged(StagedKArgs a) {
                     for (int m = 0; m < nb; ++m) { const int j = st.dyn_bucket[id * st.dyn_cap + m]; if (j > last && j < best) best = j; }
                     for (int j = st.dyn_head[id] - 1; j >= 0; j = st.dyn_next[j]) if (j > last && j < best) best = j;
                     if (best == 0x7FFFFFFF) break;
-                    add_slot<NV>(g, st.stage + (dyn_base + (int64_t)best * st.dynamic_slots + dsite) * stride, nvec, lane);
+                    const float* sl = st.stage + (dyn_base + (int64_t)best * st.dynamic_slots + dsite) * stride;
+                    if (st.dyn_scale) add_slot_scaled<NV>(g, sl, st.dyn_scale[best], nvec, lane);
+                    else add_slot<NV>(g, sl, nvec, lane);
                     last = best;
                 }
             }

@@ -221,6 +221,8 @@ class StagedPlan:
         c.n_tables, c.dim = len(sites), int(dim)
         c.dyn_bucket, c.dyn_next, c.dyn_cap = self.bucket.data_ptr(), self.next.data_ptr(), STAGED_CAP
         c.stage, c.stage_stride = self.stage.data_ptr(), self.stride
+        self.dyn_scale = torch.ones(self.max_pos * self.neg_rate, dtype=torch.float32, device=dev) if kernel_name == "rotate" else None
+        c.dyn_scale = self.dyn_scale.data_ptr() if self.dyn_scale is not None else None
         c.static_slots, c.dynamic_slots = ns, nd
         c.tot_entity, c.tot_relation = int(tot_entity), int(tot_relation)
 
