@@ -1,0 +1,57 @@
+"""Dev tool: randomised check that the staged (atomic-free) step of RotatE / DistMult / ComplEx reproduces the atomic-scatter
+step: same batches, same negatives, same weights up to fp32 summation order, over random graph / batch / row sizes and
+negative rates (bucket overflow on tiny entity sets, long relation lists, short last batches).  One MI355X."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import hip_util, kge_oracle as ko
+from pykg2vec_amd.trainer import Trainer
+
+rng = np.random.default_rng(int(os.environ.get("SEED", "21")))
+N = int(os.environ.get("ITERS", "45"))
+bad = chunked = 0
+for it in range(N):
+    model = ["rotate", "distmult", "complex", "complexn3"][it % 4]
+    tiny = it % 5 == 0
+    E = int(rng.integers(10, 40)) if tiny else int(rng.integers(100, 3000))
+    R = int(rng.integers(1, 4)) if it % 3 == 0 else int(rng.integers(4, 60))      # few relations: long lists, chunked pre-reduction
+    B = int(rng.integers(8, 400))
+    neg = int(rng.integers(1, 9))
+    d = 4 * int(rng.integers(1, 64))
+    nb = int(rng.integers(2, 5))
+    n_train = nb * B + int(rng.integers(0, B))
+    opt = ["sgd", "adam", "adagrad", "rms"][int(rng.integers(4))]
+    train = np.stack([rng.integers(E, size=n_train), rng.integers(R, size=n_train), rng.integers(E, size=n_train)], 1)
+    if len({tuple(x) for x in train}) > 0.4 * E * E * R:
+        continue
+    hp = dict(hidden_size=d, margin=float(rng.uniform(2, 12)), neg_rate=neg, alpha=float(rng.uniform(0.2, 2)), lmbda=float(rng.uniform(0, 0.05)))
+    P = ko.init_params("complex" if model.startswith("complex") else model, rng, tot_entity=E, tot_relation=R, hidden_size=d,
+                       **({"margin": hp["margin"]} if model == "rotate" else {}))
+    res = {}
+    for staged in ("0", "1"):
+        os.environ["KGE_STAGED"] = staged
+        # (RMSprop's first steps are lr * g / (0.1 |g|) = 10 lr per entry whatever the gradient's size: at lr = 0.01 that is
+        # several times RotatE's initial embedding range and two mathematically equal paths diverge chaotically)
+        cfg = hip_util.make_config(E, R, hp, train, train[:2], train[:2], optimizer=opt, lr=2e-4 if opt == "rms" else 0.01, batch_size=B)
+        cfg.tot_train_triples = n_train + (B - n_train % B) % B      # include the short last batch in the epoch
+        m = hip_util.model_from_params(model, P, hp, E, R, train=train)
+        tr = Trainer(m, cfg, use_graph=False)
+        tr.build_model()
+        tr.generator = tr._new_generator()
+        losses = [tr.train_model_epoch(e) for e in range(2)]
+        if staged == "1":
+            assert getattr(tr, "_staged", None) is not None
+            chunked += int(tr.generator.staged_index().chunks(0) is not None)
+        res[staged] = (losses, [p.detach().cpu().numpy().copy() for _, p in hip_util.table_parameters(m)])
+        del tr, m
+    ok = np.allclose(res["0"][0], res["1"][0], rtol=1e-4)
+    for a, b in zip(res["0"][1], res["1"][1]):
+        frac = (~np.isclose(a, b, atol=3e-5, rtol=2e-4)).mean()
+        ok = ok and frac <= (0.0 if opt == "sgd" else 5e-3)
+    if not ok:
+        bad += 1
+        print("MISMATCH", model, dict(E=E, R=R, B=B, d=d, neg=neg, n_train=n_train, opt=opt), res["0"][0], res["1"][0], flush=True)
+print(f"staged fuzz done: {N} cases, {bad} bad; chunked relation lists in {chunked}")
+sys.exit(1 if bad else 0)
