@@ -439,11 +439,10 @@ class Trainer:
         env = os.environ.get("KGE_STAGED")
         if env is not None:
             return env == "1"
-        # default beyond the hipGraph regime: RotatE (C3: 320 -> 224 us per step) and DistMult / ComplEx (as fast as the atomic
-        # step there -- 122 vs 118 us at DistMult FB15k B=32768 -- and bit-reproducible).  Inside the graph regime the replayed
-        # atomic step stays (C2: 111 us replayed vs 108 us staged + eager launches, profiles/r02_experiments.md); KGE_STAGED=1
-        # forces the staged step there too.
-        return self.config.batch_size * (1 + int(self.config.neg_rate)) > self.GRAPH_MAX_ROWS
+        # default: the long-row RotatE bundles beyond the graph regime (C3: 320 -> 230 us per step).  For the pointwise models
+        # the staged step is correct and deterministic but not faster than atomics + hipGraph replay at the measured shapes
+        # (profiles/r02_experiments.md), so it stays opt-in (KGE_STAGED=1).
+        return self.model.kernel_name == "rotate" and self.config.batch_size * (1 + int(self.config.neg_rate)) > self.GRAPH_MAX_ROWS
 
     def _staged_plan(self):
         if getattr(self, "_staged", None) is None:
