@@ -503,7 +503,17 @@ __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand,
     float acc = 0.f;
     if constexpr (CHAIN) {
         static_assert(!CHAIN || ((FORM == F_NEGDOT || FORM == F_SQM) && XFORM == X_NONE), "chain order: plain dot-product based forms");
-        for (int k0 = 0; k0 < Kpad; k0 += KC) {
+        // (long rows: 32 operands per dependent round trip -- Kpad is a multiple of 8, the tail runs 8 at a time)
+        constexpr int KL = 32;
+        int k0 = 0;
+        for (; k0 + KL <= Kpad; k0 += KL) {
+            float cv[KL], qv[KL];
+#pragma unroll
+            for (int j = 0; j < KL; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; qv[j] = q[k0 + j]; }
+#pragma unroll
+            for (int j = 0; j < KL; ++j) acc = fmaf(cv[j], qv[j], acc);
+        }
+        for (; k0 < Kpad; k0 += KC) {
             float cv[KC], qv[KC];
 #pragma unroll
             for (int j = 0; j < KC; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; qv[j] = q[k0 + j]; }
@@ -605,7 +615,31 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
     const float* q = qvec + qi * (int64_t)QV * Kpad;
     const float scale = (POST == P_SCALE || (CHAIN && FORM == F_SQM)) ? qscale[qi] : 1.0f;   // CHAIN SQM: |q|^2
     float s_true = 0.f;
-    if (lane == 0) s_true = pair_score_lane<FORM, XFORM, POST, CHAIN>(cand, aux, q, truth, Kpad, margin, scale);
+    if constexpr (CHAIN) {
+        // the true candidate's energy is ONE fmaf chain over k (the order the matrix-core sweep accumulates in), but its
+        // operands sit 256 bytes apart in the sweep layout: the wave fetches 64 of them per round trip into LDS (instead of a
+        // few per dependent round trip of one lane), then lane 0 runs the chain out of LDS -- same operands, same order
+        constexpr int CHUNK = 512;
+        __shared__ float s_c[4][CHUNK], s_q[4][CHUNK];
+        const int wv = threadIdx.x >> 6;
+        const float* c = cand + ((truth >> 6) * Kpad) * 64 + (truth & 63);
+        float acc = 0.f;
+        for (int k0 = 0; k0 < Kpad; k0 += CHUNK) {
+            const int nk = min(CHUNK, Kpad - k0);
+            for (int k = lane; k < nk; k += 64) { s_c[wv][k] = c[(int64_t)(k0 + k) * 64]; s_q[wv][k] = q[k0 + k]; }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0);   // (LDS writes of this wave are visible to its lane 0 below)
+            if (lane == 0)
+                for (int k = 0; k < nk; ++k) acc = fmaf(s_c[wv][k], s_q[wv][k], acc);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) {
+            if constexpr (FORM == F_SQM) acc = sqm_from_dot(acc, scale, aux[truth]);
+            s_true = pair_post<POST>(pair_finish<FORM>(acc, margin), 1.0f);
+        }
+    } else {
+        if (lane == 0) s_true = pair_score_lane<FORM, XFORM, POST, CHAIN>(cand, aux, q, truth, Kpad, margin, scale);
+    }
     s_true = __shfl(s_true, 0, 64);
     const int64_t* off = side == 0 ? tail_off : head_off;
     const int32_t* ids = side == 0 ? tail_ids : head_ids;
