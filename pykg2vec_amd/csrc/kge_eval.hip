@@ -112,6 +112,7 @@ struct PrepArgs {
     int normalize;                                   // TransE: divide by max(||row||, eps)
     int want_n2;                                     // matrix-core squared-distance sweep: aux[e] = sum_k c_k^2
     int64_t E; int K, Kpad;
+    int kper;                                        // K range of one workgroup (multiple of 64; gridDim.y of them per tile)
 };
 
 __device__ __forceinline__ float prep_elem(const PrepArgs& a, int64_t e, int k) {
@@ -153,7 +154,10 @@ __global__ __launch_bounds__(256) void k_eval_prepare(PrepArgs a, float* __restr
     float n2acc[16], dtacc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) { n2acc[j] = 0.f; dtacc[j] = 0.f; }
-    for (int k0 = 0; k0 < a.Kpad; k0 += 64) {  // transpose 64x64 through LDS: coalesced reads AND writes
+    // long rows, few tiles (RotatE d=1000 on 14 541 entities: 228 tiles x 32 chunks each): the K range is split over
+    // gridDim.y workgroups so that the chip is full; the row statistics then come from k_eval_cnorm (fixed summation order)
+    const int k_lo = blockIdx.y * a.kper, k_hi = min(a.Kpad, k_lo + a.kper);
+    for (int k0 = k_lo; k0 < k_hi; k0 += 64) {  // transpose 64x64 through LDS: coalesced reads AND writes
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int row = wave * 16 + j;
@@ -175,13 +179,24 @@ __global__ __launch_bounds__(256) void k_eval_prepare(PrepArgs a, float* __restr
         }
         __syncthreads();
     }
-    if (a.want_n2 || a.dot_tab) {
+    if ((a.want_n2 || a.dot_tab) && gridDim.y == 1) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float tot = wave_sum(a.dot_tab ? dtacc[j] : n2acc[j]);
             if (lane == 0) aux[e0 + wave * 16 + j] = (e0 + wave * 16 + j < a.E) ? tot : 0.f;
         }
     }
+}
+
+// |c|^2 of every candidate row when the transposing pass is split over K: one wave per candidate, lanes stride k
+__global__ __launch_bounds__(256) void k_eval_cnorm(PrepArgs a, float* __restrict__ aux) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // grid covers the padded rows of the last tile too
+    if (e >= a.E) { if (lane == 0) aux[e] = 0.f; return; }
+    float n2 = 0.f;
+    for (int k = lane; k < a.K; k += 64) { const float v = prep_elem(a, e, k); n2 = fmaf(v, v, n2); }
+    n2 = wave_sum(n2);
+    if (lane == 0) aux[e] = n2;
 }
 
 // ---- per-relation candidate tables for TransH / TransD (grouped evaluation): the candidate-side transform depends on the
@@ -1180,7 +1195,18 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     PrepArgs pa;
     fill_prep(m, p, &pa);
     pa.want_n2 = (p.form == F_SQM && p.xform == X_NONE && p.qT != nullptr && use_gemm_sweep(p, 2 * n)) ? 1 : 0;
-    hipLaunchKernelGGL(k_eval_prepare, dim3((unsigned)p.ntiles), dim3(256), 0, s, pa, p.cand, p.aux);
+    // K split: only where nothing but the re-layout happens per element (no normalisation, no TransD dot product)
+    int ksplit = 1;
+    if (!pa.normalize && !pa.dot_tab && p.Kpad >= 512 && p.ntiles < 1024) {
+        ksplit = (int)min((int64_t)(p.Kpad / 128), (1024 + p.ntiles - 1) / p.ntiles);
+        if (ksplit < 1) ksplit = 1;
+    }
+    pa.kper = ((p.Kpad + ksplit - 1) / ksplit + 63) / 64 * 64;
+    ksplit = (p.Kpad + pa.kper - 1) / pa.kper;
+    hipLaunchKernelGGL(k_eval_prepare, dim3((unsigned)p.ntiles, (unsigned)ksplit), dim3(256), 0, s, pa, p.cand, p.aux);
+    if (ksplit > 1 && pa.want_n2) {
+        hipLaunchKernelGGL(k_eval_cnorm, dim3((unsigned)(p.ntiles * 16)), dim3(256), 0, s, pa, p.aux);   // 64 rows per tile, 4 per block
+    }
     const DeviceModel dm = to_device_model(m);
     const unsigned qb = (unsigned)((n + 3) / 4);
 #define KGE_Q(MID) case MID: hipLaunchKernelGGL((k_eval_queries<MID>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale); break;
