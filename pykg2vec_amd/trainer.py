@@ -95,7 +95,10 @@ class PullState:
         self.tables = [view(flat.param), view(self.alt)]
         # row-normalised copies of both halves, rows padded to the kernels' float4 lane layout (kge_pull_partial_stride)
         stride = K.pull_partial_stride(shapes[0][1])
-        self.hats = [[torch.zeros(r, stride, dtype=torch.float32, device=dev) for r, _ in shapes] for _ in range(2)]
+        # (entity rows, then relation rows, in ONE buffer per half: a single kge_row_norms call refreshes both tables when they
+        # are adjacent in the flat parameter buffer)
+        self.hat_all = [torch.zeros(sum(r for r, _ in shapes), stride, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.hats = [[h[:shapes[0][0]], h[shapes[0][0]:]] for h in self.hat_all]
         self.state1 = view(flat.state1) if flat.state1 is not None and not grad_only else None
         self.state2 = view(flat.state2) if flat.state2 is not None and not grad_only else None
         E, R, d = shapes[0][0], shapes[1][0], shapes[0][1]
@@ -122,8 +125,13 @@ class PullState:
 
     def refresh_norms(self):
         """Row norms / normalised copies of the current parameter tables (after the all-gather of a data-parallel step)."""
-        K.row_norms(self.tables[0][0], self.norms[0][:self.E], self.hats[0][0])
-        K.row_norms(self.tables[0][1], self.norms[0][self.E:], self.hats[0][1])
+        ent, rel = self.tables[0]
+        if rel.data_ptr() == ent.data_ptr() + ent.numel() * 4 and ent.shape[1] == rel.shape[1]:   # adjacent: one launch
+            both = self.flat.param[(ent.data_ptr() - self.flat.param.data_ptr()) // 4:][:ent.numel() + rel.numel()]
+            K.row_norms(both.view(self.E + self.R, ent.shape[1]), self.norms[0], self.hat_all[0])
+            return
+        K.row_norms(ent, self.norms[0][:self.E], self.hats[0][0])
+        K.row_norms(rel, self.norms[0][self.E:], self.hats[0][1])
 
     def sync_out(self):
         """Make FlatState.param (the storage behind the model's parameters) hold the current tables."""
