@@ -595,7 +595,7 @@ def pull_lists_explicit(pairs, nh, nt, lists):
 
 def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, inc, partials, multi,
               margin, optimizer, lr, step, loss_buf, reset_lists=True, dev_hyper=None, run_finish=True, sample_next=None,
-              dense_skip=None):
+              dense_skip=None, prepare_only=False):
     """One whole training step (scoring, hinge, backward, dense optimiser) without atomics: see csrc/kge_pull.hip.
     desc_in: descriptor over the tables READ; tables_out: [ent, rel] of the other half of the double buffer; hat_in /
     hat_out: the row-normalised copies of both halves.
@@ -611,7 +611,7 @@ def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, s
               int(seed) & (2 ** 64 - 1), int(noff) & (2 ** 64 - 1), ctypes.byref(nlists.c))
     else:
         nx = (None, 0, None, None, 0, 0, 0, None)
-    L.check(L.load().kge_pull_step(
+    args = (
         ctypes.byref(desc_in), ctypes.addressof(to), ctypes.addressof(hi), ctypes.addressof(ho) if hat_out is not None else None,
         _dev(norm_in, torch.float32, "norm_in"),
         _dev(norm_out, torch.float32, "norm_out") if norm_out is not None else None,
@@ -621,7 +621,21 @@ def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, s
         _i32(inc, "inc"), _dev(partials, torch.float32, "partials"),
         _i32(multi, "multi") if n_multi else None, n_multi, float(margin), OPTIMIZER_IDS[optimizer], float(lr), int(step),
         _dev(dev_hyper, torch.float32, "dev_hyper") if dev_hyper is not None else None, 1 if reset_lists else 0,
-        *nx, _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_pull_step")
+        *nx, _dev(loss_buf, torch.float32, "loss"))
+    keep = (desc_in, to, hi, ho, s1, s2, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, inc,
+            partials, multi, loss_buf, dense_skip, sample_next)
+    if prepare_only:   # marshal once, call many times (a data-parallel step runs this launch between two collectives:
+        fn = L.load().kge_pull_step                                   # host time per step matters there)
+        argl = list(args)
+        off_idx = len(argl) - 3      # next_offset: the one argument that differs from epoch to epoch (Philox counters advance)
+
+        def call(next_offset=None):
+            if next_offset is not None:
+                argl[off_idx] = int(next_offset) & (2 ** 64 - 1)
+            L.check(fn(*argl, _stream()), "kge_pull_step")
+        call.keep = keep
+        return call
+    L.check(L.load().kge_pull_step(*args, _stream()), "kge_pull_step")
 
 
 class PullPlan:

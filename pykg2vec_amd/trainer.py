@@ -110,6 +110,7 @@ class PullState:
         self.lists = [K.PullListSet(batch_size, E, dev) for _ in range(2)]
         self.cur_list = 0
         self.ready = None
+        self.calls = {}   # prepared kge_pull_step calls of the data-parallel gradient step
         self.partials = torch.empty(max(1, max_slots) * K.pull_partial_stride(d), dtype=torch.float32, device=dev)
         self.cur = 0
 
@@ -351,8 +352,13 @@ class Trainer:
             per = idx.batch_size
             off_next = gen._draws + self.rank * per * gen.neg_rate
             nxt = (idx.batch(b + 1)[0], gen.bern, gen.slots, gen.seed, off_next, ps.lists[cur ^ 1])
-        K.pull_step(self._desc, ps.tables[1], ps.hats[0], None, ps.norms[0], None, None, None, pairs, ps.lists[cur], items, inc,
-                    ps.partials, multi, cfg.margin, "gradient", 0.0, 1, self.loss_buf, sample_next=nxt, dense_skip=idx.skip(b))
+        key = (b, cur, nxt is not None)
+        call = ps.calls.get(key)
+        if call is None:   # arguments marshalled once per (batch, list set); only the ride-along Philox offset changes per epoch
+            call = ps.calls[key] = K.pull_step(self._desc, ps.tables[1], ps.hats[0], None, ps.norms[0], None, None, None, pairs,
+                                               ps.lists[cur], items, inc, ps.partials, multi, cfg.margin, "gradient", 0.0, 1,
+                                               self.loss_buf, sample_next=nxt, dense_skip=idx.skip(b), prepare_only=True)
+        call(nxt[4] if nxt is not None else None)
         if nxt is not None:
             ps.cur_list ^= 1
             ps.ready = (b + 1, nxt[4])
