@@ -564,7 +564,17 @@ __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand,
         }
         acc = a0 + a1;
     } else if constexpr (XFORM == X_NONE) {
-        for (int k0 = 0; k0 < Kpad; k0 += KC) {
+        // (32 operands per dependent round trip, then the tail 8 at a time: Kpad is a multiple of 8; order unchanged)
+        constexpr int KL = 32;
+        int k0 = 0;
+        for (; k0 + KL <= Kpad; k0 += KL) {
+            float cv[KL], qv[KL];
+#pragma unroll
+            for (int j = 0; j < KL; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; qv[j] = q[k0 + j]; }
+#pragma unroll
+            for (int j = 0; j < KL; ++j) acc = pair_step<FORM>(acc, cv[j], qv[j]);
+        }
+        for (; k0 < Kpad; k0 += KC) {
             float cv[KC], qv[KC];
 #pragma unroll
             for (int j = 0; j < KC; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; qv[j] = q[k0 + j]; }
