@@ -298,3 +298,54 @@ def test_compact_pull_index_visits_every_row_exactly_once(E, R, B, seg):
     implicit = [g for g in range(nrows) if not bits[g]]
     rows_once = sorted(set(live[:, 0])) + implicit
     assert sorted(rows_once) == list(range(nrows))
+
+
+@pytest.mark.parametrize("E,R,B,seg,gpb", [(53, 7, 32, 8, 8), (53, 7, 64, 2, 8), (40, 3, 200, 1, 8), (300, 5, 1000, 8, 4),
+                                            (14951, 1345, 4096, 8, 8)])
+def test_pull_index_structure(E, R, B, seg, gpb):
+    """generator.build_pull_batch invariants the kernel relies on: every parameter row is covered by work items whose
+    incidence ranges tile its sorted (pair, role) list exactly; items of at most `seg` incidences; rows of 2..gpb items sit in
+    consecutive slots of ONE workgroup in segment order (kind 3); longer rows are kind 1 (first) / 2 (rest) with consecutive
+    partial slots listed in `multi`; slots are padded per workgroup with row -1."""
+    from pykg2vec_amd.generator import build_pull_batch
+    rng = np.random.default_rng(E * 7 + B)
+    pos = np.stack([rng.integers(E, size=B), rng.integers(R, size=B), rng.integers(E, size=B)], 1)
+    pairs, inc, items, multi, nglob = build_pull_batch(pos, E, R, seg, gpb)
+    assert np.array_equal(pairs[:, :3], pos) and len(inc) == 3 * B and len(items) % gpb == 0
+    nrows = E + R
+    # the incidence list: sorted by (row, pair, role); role 0 = head, 1 = tail, 2 = relation
+    rows_of = np.where((inc & 3) == 0, pos[inc >> 2, 0], np.where((inc & 3) == 1, pos[inc >> 2, 2], E + pos[inc >> 2, 1]))
+    assert np.all(np.diff(rows_of) >= 0)
+    for g in np.unique(rows_of):
+        seg_vals = inc[rows_of == g]
+        assert np.all(np.diff(seg_vals) > 0)
+    counts = np.bincount(rows_of, minlength=nrows)
+    start = np.cumsum(counts) - counts
+    covered = {}
+    for slot, (g, lo, hi, info) in enumerate(items):
+        if g < 0:
+            continue
+        assert 0 <= hi - lo <= seg and (hi > lo or counts[g] == 0)
+        covered.setdefault(int(g), []).append((int(lo), int(hi), int(info), slot))
+    assert sorted(covered) == list(range(nrows))
+    n_partial = 0
+    for g, its in covered.items():
+        its.sort()
+        assert its[0][0] == start[g] and its[-1][1] == start[g] + counts[g]
+        assert all(a[1] == b[0] for a, b in zip(its, its[1:]))
+        kinds = [x[2] & 3 for x in its]
+        if len(its) == 1:
+            assert kinds == [0]
+        elif len(its) <= gpb:
+            assert kinds == [3] * len(its)
+            slots = [x[3] for x in its]
+            assert slots == list(range(slots[0], slots[0] + len(its))) and slots[0] // gpb == slots[-1] // gpb
+            assert [(x[2] >> 2) & 15 for x in its] == list(range(len(its))) and all((x[2] >> 6) == len(its) for x in its)
+        else:
+            assert kinds == [1] + [2] * (len(its) - 1)
+            ps = [x[2] >> 2 for x in its]
+            assert ps == list(range(ps[0], ps[0] + len(its)))
+            row = multi[multi[:, 0] == g]
+            assert len(row) == 1 and row[0, 1] == ps[0] and row[0, 2] == len(its)
+            n_partial += len(its)
+    assert n_partial == nglob
