@@ -160,12 +160,17 @@ def reference_cpu_numbers():
         return None
     doc = json.load(open(path))
     return {"train_scored_triples_per_s": doc["train"]["value"], "eval_test_triples_per_s": doc["eval"]["value"],
-            "cores": doc["cores"], "host": doc["host"], "source": "profiles/r02_reference_cpu_baseline.json"}
+            "cores": doc["cores"], "host": doc["host"], "source": "profiles/r02_reference_cpu_baseline.json",
+            "same_run": False, "same_host": False}
 
 
 def pmc_traffic(kernel_prefix, batch, fetch_scale=1.0):
     """HBM bytes per launch of the dominant train kernel from the committed rocprofv3 PMC passes
     (profiles/*pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, separate passes, same bench command and batch size).
+    The same kernel name is launched at several geometries inside one bench run (B=32768 headline steps, the B=128
+    reference-default-batch leg), so the entry is selected by GRID: tools/rocpd_pmc.py keys its rows "<kernel> @grid=<threads>"
+    and the headline launches are the largest grid of that kernel.  (Files written before the per-grid keys carry one mixed
+    row per kernel: its max_KB -- the big launches -- is used, never the mixed average.)
     fetch_scale: the gfx950 correction of MI355X_MICROARCH.md (HBM section) -- FETCH_SIZE reports half the bytes of wide
     (16 B per lane) coalesced reads, which is how the owner-computes kernel fetches every row; the round-1 push kernel
     reads one dword per lane (uncalibrated width: left raw).  Returns (bytes or None, source)."""
@@ -175,9 +180,19 @@ def pmc_traffic(kernel_prefix, batch, fetch_scale=1.0):
         return None, None
     for f in reversed(files):   # newest round first
         doc = json.load(open(f))
+        best = None
         for name, ctr in doc["kernels"].items():
-            if name.startswith(kernel_prefix) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-                return (fetch_scale * ctr["FETCH_SIZE"]["avg_KB"] + ctr["WRITE_SIZE"]["avg_KB"]) * 1024.0, os.path.basename(f)
+            if not (name.startswith(kernel_prefix) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr):
+                continue
+            if "@grid=" in name:
+                grid = int(name.split("@grid=")[1].split("x")[0])
+                cand = (grid, fetch_scale * ctr["FETCH_SIZE"]["avg_KB"] + ctr["WRITE_SIZE"]["avg_KB"], name)
+            else:
+                cand = (0, fetch_scale * ctr["FETCH_SIZE"]["max_KB"] + ctr["WRITE_SIZE"]["max_KB"], name + " (max rows)")
+            if best is None or cand[0] > best[0]:
+                best = cand
+        if best is not None:
+            return best[1] * 1024.0, "%s :: %s" % (os.path.basename(f), best[2])
     return None, None
 
 

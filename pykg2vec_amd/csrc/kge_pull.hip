@@ -533,6 +533,15 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
                      const kge_pull_lists* next_lists, float* loss, hipStream_t s) {
     const PullGeo geo = pull_geo(m->dim);
     if (!geo.G) { set_error("kge_pull_step: hidden size %d must be a multiple of 4 and at most 1024", m->dim); return -1; }
+    {   // the row gathers use 32-bit byte offsets into the padded normalised tables (16 * G * NV bytes per row)
+        const uint64_t row_bytes = 16ull * (uint64_t)geo.G * (uint64_t)geo.NV;
+        const uint64_t rows = (uint64_t)(m->tot_entity > m->tot_relation ? m->tot_entity : m->tot_relation);
+        if (rows * row_bytes > 0xFFFFFFFFull) {
+            set_error("kge_pull_step: %llu rows of %llu bytes exceed the 4 GiB the 32-bit gather offsets address",
+                      (unsigned long long)rows, (unsigned long long)row_bytes);
+            return -1;
+        }
+    }
     PullArgs a;
     for (int i = 0; i < 2; ++i) {
         a.tab_in[i] = m->tables[i]; a.tab_out[i] = tables_out[i];

@@ -647,7 +647,7 @@ int launch_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* triple
                                   uint64_t offset, const int64_t* cursor, float margin, float* loss, hipStream_t s) {
     Geometry geo;
     if (!geometry_for(m, &geo)) return -1;
-    if (m->tot_entity >= (1 << 24)) { set_error("fused sampler: more than 2^24 entities not supported by the packed key"); return -1; }
+    if (m->tot_entity > (1 << 24)) { set_error("fused sampler: more than 2^24 entities not supported by the packed key"); return -1; }
     const DeviceModel dm = to_device_model(m);
     FusedSampler fs;
     fs.triples = triples; fs.perm = perm; fs.start = start; fs.E = m->tot_entity; fs.bern = bern;
@@ -689,7 +689,7 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
     if (!geometry_for(m, &geo)) return -1;
     if (m->model != KGE_ROTATE) { set_error("kge_train_pairwise_selfadv_sampled: RotatE only"); return -1; }
     if (neg_rate > geo.G) { set_error("kge_train_pairwise_selfadv_sampled: neg_rate %d exceeds the lane group (%d)", neg_rate, geo.G); return -1; }
-    if (m->tot_entity >= (1 << 24)) { set_error("fused sampler: more than 2^24 entities not supported by the packed key"); return -1; }
+    if (m->tot_entity > (1 << 24)) { set_error("fused sampler: more than 2^24 entities not supported by the packed key"); return -1; }
     const DeviceModel dm = to_device_model(m);
     FusedSampler fs;
     fs.triples = triples; fs.perm = perm; fs.start = start; fs.E = m->tot_entity; fs.bern = bern;

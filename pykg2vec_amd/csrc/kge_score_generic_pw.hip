@@ -49,7 +49,7 @@ int launch_pointwise_logistic_sampled(const kge_model_desc* m, const int64_t* tr
                                       int64_t n_pos, int neg_rate, const float* bern, const uint64_t* slots, int64_t n_slots,
                                       uint64_t seed, uint64_t offset, const int64_t* cursor, float lmbda, int reg_type,
                                       float* loss, hipStream_t s) {
-    if (m->tot_entity >= (1 << 24)) { set_error("fused sampler: more than 2^24 entities not supported by the packed key"); return -1; }
+    if (m->tot_entity > (1 << 24)) { set_error("fused sampler: more than 2^24 entities not supported by the packed key"); return -1; }
     FusedSampler fs;
     fs.triples = triples; fs.perm = perm; fs.start = start; fs.E = m->tot_entity; fs.bern = bern;
     fs.slots = (const unsigned long long*)slots; fs.mask = (unsigned long long)(slots ? n_slots - 1 : 0);

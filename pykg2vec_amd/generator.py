@@ -153,6 +153,9 @@ class PullIndex:
     def __init__(self, batches, tot_entity, tot_relation, device, segment=None, groups_per_block=8, compact=None):
         import os
         seg = int(segment or os.environ.get("KGE_PULL_SEGMENT") or self.SEGMENT)   # env: tuning sweeps only
+        group = 256 // int(groups_per_block)   # lanes of an owner group: one visit descriptor per lane
+        if not 1 <= seg <= group:
+            raise ValueError("PullIndex: segment %d must be in [1, %d] (incidences of a work item map one per lane)" % (seg, group))
         nrows = int(tot_entity) + int(tot_relation)
         if compact is None:   # a batch touches at most 3 B rows: list only those when that is the smaller index
             compact = bool(batches) and 3 * len(batches[0]) * 2 <= nrows

@@ -189,7 +189,7 @@ class StagedPlan:
                  max_pos, neg_rate, sparse=False):
         ns, nd, sites = self.LAYOUTS[kernel_name]
         if len(sites) != len(table_offsets):
-            raise KgeHipError("staged plan: table list does not match the model")
+            raise L.KgeHipError("staged plan: table list does not match the model")
         dev = flat_param.device
         self.ns, self.nd, self.neg_rate, self.max_pos = ns, nd, int(neg_rate), int(max_pos)
         self.stride = (int(dim) + 3) // 4 * 4
@@ -232,6 +232,11 @@ class StagedPlan:
         key = (b, 0 if self.sparse else self.parity)
         hit = self._cache.get(key)
         if hit is None:
+            if self.rel_partials is None and index.max_rel_list > index.LONG_LIST:
+                # sized ONCE for the batch with the most chunks: the cached per-batch snapshots below hold this pointer,
+                # so the buffer must never be reallocated while the plan lives
+                self.rel_partials = torch.empty(max(1, max(index.n_chunks)) * self.n_rel_tables * self.stride,
+                                                dtype=torch.float32, device=self.stage.device)
             ent_off, ent_inc, rel_off, rel_inc, n = index.batch(b)
             self.bind(ent_off, ent_inc, rel_off, rel_inc, n, index.chunks(b), index.touched(b) if self.sparse else None)
             snap = L.StagedStep()
@@ -244,13 +249,16 @@ class StagedPlan:
 
     def bind(self, ent_off, ent_inc, rel_off, rel_inc, n_pos, chunks=None, touched=None):
         if n_pos > self.max_pos:
-            raise KgeHipError("staged plan: batch larger than the plan")
+            raise L.KgeHipError("staged plan: batch larger than the plan")
         self._batch = (ent_off, ent_inc, rel_off, rel_inc, chunks)
         c = self.c
         if chunks is not None:
             chunk_off, chunk_rel, n_chunks = chunks
             need = max(1, n_chunks) * self.n_rel_tables * self.stride
             if self.rel_partials is None or self.rel_partials.numel() < need:
+                if self._cache:   # a cached snapshot holds the old pointer: growing now would leave it dangling
+                    raise L.KgeHipError("staged plan: relation partial buffer too small for this batch (%d floats needed); "
+                                        "bind batches through bind_batch(), which sizes it for the whole index" % need)
                 self.rel_partials = torch.empty(need, dtype=torch.float32, device=self.stage.device)
             c.rel_chunk_off, c.chunk_rel = _dev(chunk_off, torch.int32, "rel_chunk_off"), _dev(chunk_rel, torch.int32, "chunk_rel")
             c.rel_partials, c.n_chunks = self.rel_partials.data_ptr(), int(n_chunks)
@@ -261,7 +269,7 @@ class StagedPlan:
         c.n_pos, c.n_neg = int(n_pos), int(n_pos) * self.neg_rate
         if self.sparse:
             if touched is None:
-                raise KgeHipError("staged plan: the sparse sweep needs the batch's touched-row lists")
+                raise L.KgeHipError("staged plan: the sparse sweep needs the batch's touched-row lists")
             t_ent, n_ent, t_rel, n_rel = touched
             self._batch += (t_ent, t_rel)
             c.touched_ent, c.n_touched_ent = _dev(t_ent, torch.int32, "touched_ent"), int(n_ent)

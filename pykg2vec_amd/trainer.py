@@ -6,10 +6,14 @@ Per step the reference issues ~30 ATen kernels, two autograd graphs, a dense tor
 buffer), at most one all-reduce of that buffer (data parallel over RCCL), one fused dense optimiser sweep over ONE
 flat parameter buffer (which also clears the gradients), and no host synchronisation until the epoch ends.
 
-Checkpoint save/load, inference helpers, hyper-parameter tuning, export and plotting are outside the hot path
- and stay with the reference: `pykg2vec_amd.integration.reference_trainer()` grafts this
-module's hot loop onto the reference's own Trainer class, which keeps all of those (tests/test_integration_graft.py).
+Inference helpers, hyper-parameter tuning, early stopping, export and plotting are outside the hot path (SURVEY.md
+section 2) and stay with the reference: `pykg2vec_amd.integration.reference_trainer()` grafts this module's hot loop onto
+the reference's own Trainer class, which keeps all of those (tests/test_integration_graft.py).  The stand-alone Trainer
+keeps only the checkpoint pair in the reference's format (save_model / load_model: `model.vec.pt` state_dict) and accepts
+any object with `should_stop(metrics)` as `early_stopper` (the graft passes the reference's own EarlyStopper).
 """
+import os
+
 import torch
 
 from . import kernels as K
@@ -32,8 +36,11 @@ class FlatState:
     reduce-scatter(grad) -> optimiser on 1/N of the tables -> all-gather(param).  Same bytes on the wire as an
     all-reduce, 1/N of the optimiser sweep (the B-independent part of the step) and of its state memory."""
 
-    def __init__(self, model, optimizer, backend=K, world_size=1, rank=0):
+    def __init__(self, model, optimizer, backend=K, world_size=1, rank=0, distributed=None):
         self.K = backend
+        # distributed (default: world_size > 1): the step goes through the collectives and needs a reduce-scatter target that
+        # is distinct from the local gradient buffer -- also at world size 1 when a process group was given explicitly
+        distributed = world_size > 1 if distributed is None else bool(distributed)
         params = [p.weight for p in model.parameter_list]
         dev = params[0].device
         offs, tot = [], 0
@@ -59,7 +66,7 @@ class FlatState:
         self.optimizer = optimizer
         self.param_shard = self.param[self.shard_lo:self.shard_lo + self.shard_numel]
         # reduced gradient of this rank's shard: the full buffer itself when there is nothing to reduce
-        self.grad_shard = self.grad if world_size == 1 else torch.zeros(self.shard_numel, dtype=torch.float32, device=dev)
+        self.grad_shard = self.grad if not distributed else torch.zeros(self.shard_numel, dtype=torch.float32, device=dev)
         self.state1 = torch.zeros_like(self.param_shard) if optimizer in ("adam", "adagrad", "rms") else None
         self.state2 = torch.zeros_like(self.param_shard) if optimizer == "adam" else None
         self.step = 0
@@ -144,34 +151,6 @@ class PullState:
             self.cur = 0
 
 
-class EarlyStopper:
-    """utils/trainer.py:21-69.  `patience_left` is decremented on a worse metric while it is positive; the trainer
-    stops on the next worse metric once it is 0 (so patience=3 stops on the 4th consecutive worse evaluation, and
-    patience=0 on the first); any non-worse evaluation resets it."""
-
-    def __init__(self, patience, monitor):
-        self.patience, self.monitor = patience, monitor
-        self.previous_metrics = None
-        self.patience_left = patience
-
-    def should_stop(self, curr_metrics):
-        should_stop = False
-        key = self.monitor.value
-        if self.previous_metrics is not None:
-            if self.monitor in (Monitor.MEAN_RANK, Monitor.FILTERED_MEAN_RANK):
-                is_worse = self.previous_metrics[key] < curr_metrics[key]
-            else:
-                is_worse = self.previous_metrics[key] > curr_metrics[key]
-            if self.patience_left > 0 and is_worse:
-                self.patience_left -= 1
-            elif self.patience_left == 0 and is_worse:
-                should_stop = True
-            else:
-                self.patience_left = self.patience
-        self.previous_metrics = curr_metrics
-        return should_stop
-
-
 class Trainer:
     TRAINED_MODEL_FILE_NAME = "model.vec.pt"      # utils/trainer.py:86-87
     TRAINED_MODEL_CONFIG_NAME = "config.npy"
@@ -190,6 +169,15 @@ class Trainer:
         self.monitor = None
         self._init_hot_path(process_group, backend, use_graph)
 
+    def _switches(self):
+        """The A/B switches of DESIGN.md section 5a, read ONCE when a Trainer is constructed (None = unset: the built-in
+        rule decides).  They exist for same-box A/B runs and for tests that force a path; the hot loop never reads the
+        environment."""
+        env = os.environ.get
+        flag = lambda name: None if env(name) is None else env(name) == "1"
+        return {"pull": flag("KGE_PULL"), "staged": flag("KGE_STAGED"), "graph_multi": flag("KGE_GRAPH_MULTI"),
+                "pw_pull": flag("KGE_PW_PULL")}
+
     def _init_hot_path(self, process_group=None, backend=None, use_graph=None):
         # `backend` exists so that the multi-process plumbing (batch sharding, gradient collectives, replica
         # consistency) can be exercised on CPU/gloo with a checker injected by tests; the product default -- and the
@@ -198,25 +186,30 @@ class Trainer:
         self.flat = None
         self.process_group = process_group
         self.use_graph = use_graph
+        self.switches = self._switches()
         self._graph = None
         self.world_size = 1
         self.rank = 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world_size = torch.distributed.get_world_size(process_group)
             self.rank = torch.distributed.get_rank(process_group)
+        # an explicitly given process group is honoured even when it has ONE rank: the step then runs the same collectives
+        # (degenerate, but every RCCL call and the multi-rank graph capture execute -- tests/test_hip_dist.py does this on
+        # the one GPU a test box has)
+        self.distributed = self.world_size > 1 or process_group is not None
 
     # ------------------------------------------------------------------ build
     def build_model(self, monitor=Monitor.FILTERED_MEAN_RANK):
         if self.config.optimizer not in K.OPTIMIZER_IDS:  # sgd / adam / adagrad / rms (utils/trainer.py:112-131)
             raise NotImplementedError("No support for %s optimizer" % self.config.optimizer)
         self.model.to(self.config.device)
-        self.flat = FlatState(self.model, self.config.optimizer, self.K, self.world_size, self.rank)
+        self.flat = FlatState(self.model, self.config.optimizer, self.K, self.world_size, self.rank, self.distributed)
         self.evaluator = Evaluator(self.model, self.config, backend=self.K)
         self.loss_buf = self.K.new_loss_buffer(self.flat.param.device)
-        self.early_stopper = EarlyStopper(getattr(self.config, "patience", 3), monitor)
+        self.monitor = monitor
         self._desc = self.K.model_desc(self.model, [v for v in self.flat.views], self.flat.grad_views)
         self._selfadv_ws = None
-        if self.world_size > 1:  # replicas must start identical
+        if self.distributed:  # replicas must start identical
             torch.distributed.broadcast(self.flat.param, src=0, group=self.process_group)
 
     # ------------------------------------------------------------------ one step (gradients into flat.grad)
@@ -295,14 +288,11 @@ class Trainer:
         """TransE / TransM + pairwise hinge with neg_rate 1, single GPU, full batches too large for the launch-bound graph path:
         the whole step (sampling, scoring, hinge, backward, dense optimiser) runs without atomics or a gradient buffer
         and is bit-reproducible (csrc/kge_pull.hip).  KGE_PULL=0 / 1 overrides the batch-size rule."""
-        import os
-        if not (self.K is K and self.world_size == 1 and self.model.kernel_name in ("transe", "transm") and self.model.hidden_size % 4 == 0 and self.model.hidden_size <= 1024
-                and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1
+        if not (self.K is K and not self.distributed and self._pull_shape_ok()
                 and self.generator is not None and self.generator.n_train >= self.config.batch_size):
             return False
-        env = os.environ.get("KGE_PULL")
-        if env is not None:
-            return env == "1"
+        if self.switches["pull"] is not None:
+            return self.switches["pull"]
         # one launch per step, enqueued by a native loop: faster than the hipGraph-replayed atomic step at every batch size
         # measured (FB15k shape: B=128 13.1 vs 16.5 us, B=4096 17.2 vs 24.6 us, B=32768 34.5 vs 60 us).  The limit is the
         # per-batch incidence index built once on the host (16 B per listed row; batches that touch a small part of the tables
@@ -312,19 +302,25 @@ class Trainer:
         index_bytes = PullIndex.bytes_estimate(n_batches, int(self.config.batch_size), self.config.tot_entity, self.config.tot_relation)
         return index_bytes <= self.PULL_INDEX_BUDGET or self.config.batch_size * 2 > self.GRAPH_MAX_ROWS
 
+    def _pull_shape_ok(self):
+        """Model / shape conditions of the owner-computes kernels: TransE / TransM hinge with neg_rate 1, rows of float4s, and
+        padded normalised tables the kernel's 32-bit gather offsets can address (csrc/kge_pull.hip: launch_pull_step)."""
+        if not (self.model.kernel_name in ("transe", "transm") and self.model.hidden_size % 4 == 0 and self.model.hidden_size <= 1024
+                and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1):
+            return False
+        rows = max(int(self.config.tot_entity), int(self.config.tot_relation))
+        return rows * K.pull_partial_stride(self.model.hidden_size) * 4 <= 0xFFFFFFFF
+
     def _pull_dp_ok(self):
         """Data-parallel ranks: the local gradient by owner-computes (kge_pull_step in KGE_OPT_GRADIENT mode: every row of the
         flat gradient written once, no atomics, no clearing pass), then the sharded reduce-scatter / optimiser / all-gather
         step.  Same conditions as the single-GPU pull step, on the rank's share of the batch."""
-        import os
         B, N = int(self.config.batch_size), self.world_size
-        if not (self.K is K and N > 1 and self.model.kernel_name in ("transe", "transm") and self.model.hidden_size % 4 == 0 and self.model.hidden_size <= 1024
-                and self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1
+        if not (self.K is K and self.distributed and self._pull_shape_ok()
                 and self.generator is not None and B % N == 0 and self.generator.n_train >= B):
             return False
-        env = os.environ.get("KGE_PULL")
-        if env is not None:
-            return env == "1"
+        if self.switches["pull"] is not None:
+            return self.switches["pull"]
         return (B // N) * 2 > self.GRAPH_MAX_ROWS
 
     def _pull_dp_step(self):
@@ -338,6 +334,7 @@ class Trainer:
         start, n, offset = gen._next_range()
         if b >= idx.n_batches or n != idx.batch_size:     # the short last batch: atomic-scatter kernels on this one
             ps.ready = None
+            self.flat.grad.zero_()   # the gradient-mode steps leave the previous (reduced) gradient behind; the fallback ADDS
             self._accumulate_next_batch(fixed_range=(start, n, offset))
             self._reduce_and_step()
             ps.refresh_norms()
@@ -438,9 +435,8 @@ class Trainer:
         """RotatE self-adversarial / DistMult / ComplEx logistic step without a gradient buffer: the bundle kernel stages its
         gradient rows with plain stores and the optimiser sweep sums them per parameter row in a fixed order (csrc/kge_staged.hip) -- no fp32
         atomics, bit-reproducible.  Single GPU, batches beyond the launch-bound graph regime; KGE_STAGED=0 / 1 overrides."""
-        import os
         from .generator import StagedIndex
-        if not (self.K is K and self.world_size == 1 and self.generator is not None):
+        if not (self.K is K and not self.distributed and self.generator is not None):
             return False
         if not (self._fused_rotate_ok() or (self._fused_pointwise_ok() and self.model.kernel_name in ("distmult", "complex"))):
             return False
@@ -450,9 +446,8 @@ class Trainer:
         nb = (self.generator.n_train + self.generator.batch_size - 1) // self.generator.batch_size
         if not StagedIndex.fits(nb, self.config.tot_entity, self.config.tot_relation):
             return False
-        env = os.environ.get("KGE_STAGED")
-        if env is not None:
-            return env == "1"
+        if self.switches["staged"] is not None:
+            return self.switches["staged"]
         # default: the long-row RotatE bundles beyond the graph regime (C3: 320 -> 230 us per step).  For the pointwise models
         # the staged step is correct and deterministic but not faster than atomics + hipGraph replay at the measured shapes
         # (profiles/r02_experiments.md), so it stays opt-in (KGE_STAGED=1).
@@ -500,7 +495,9 @@ class Trainer:
         if n > 0 and self._pull_ok() and self.generator._batch_idx + n <= self.generator.n_train // self.config.batch_size:
             self._pull_steps(n)
             return
-        if getattr(self, "_pull", None) is not None:   # leaving the pull path (a short last batch): hand the tables back
+        if getattr(self, "_pull", None) is not None and not self._pull.grad_only:
+            # leaving the single-GPU pull path (a short last batch): hand the tables back.  (The gradient-mode state of the
+            # data-parallel step owns no tables and is kept: its prepared calls and ride-along sampler survive.)
             self.sync_model()
             self._pull = None
         if self._staged_ok():
@@ -538,7 +535,7 @@ class Trainer:
             else:
                 flat.optimizer_step(self.config.learning_rate)
 
-        if self.world_size == 1:
+        if not self.distributed:
             optimise()
             return
         # Sharded data-parallel step: reduce-scatter the flat gradient (each rank receives the SUM -- or, for the
@@ -580,16 +577,14 @@ class Trainer:
             return False
         if self.K is not K:
             return False
-        import os
-        if os.environ.get("KGE_STAGED") == "1" and self._staged_ok():   # the staged step is an eager two-launch step
+        if self.switches["staged"] and self._staged_ok():   # the staged step is an eager two-launch step
             return False
         if self.use_graph is None and self.generator is not None and self._pull_ok():   # one native call per epoch beats a replay per step
             return False
-        if self.world_size > 1:
+        if self.distributed:
             # RCCL collectives are capturable (gloo is not); multi-rank capture is opt-in (use_graph=True or
-            # KGE_GRAPH_MULTI=1) because it cannot be exercised on the single-GPU boxes this repo is tested on
-            import os
-            asked = bool(self.use_graph) or (self.use_graph is None and os.environ.get("KGE_GRAPH_MULTI") == "1")
+            # KGE_GRAPH_MULTI=1): it has only ever run on one-rank process groups (tests/test_hip_dist.py)
+            asked = bool(self.use_graph) or (self.use_graph is None and bool(self.switches["graph_multi"]))
             return asked and self._collectives()[0] and self.config.batch_size % self.world_size == 0
         if self.use_graph is not None:
             return bool(self.use_graph)
@@ -678,7 +673,7 @@ class Trainer:
             self.step_next_batches(num_batch)
             self.sync_model()
         acc = self.K.read_loss(self.loss_buf)
-        if self.world_size > 1:
+        if self.distributed:
             torch.distributed.all_reduce(acc, group=self.process_group)
             if self._mean_type_loss():
                 acc = acc / self.world_size  # average of per-rank means
@@ -689,9 +684,29 @@ class Trainer:
     def _new_generator(self):
         return Generator(self.model, self.config, rank=self.rank, world_size=self.world_size, backend=self.K)
 
+    # ------------------------------------------------------------------ checkpoints (reference format, utils/trainer.py:388-409)
+    def save_model(self, path):
+        """state_dict under the reference's file name and key names (`ent_embeddings.weight`, ...): a checkpoint written
+        here loads into the reference's model classes and vice versa."""
+        self.sync_model()
+        os.makedirs(str(path), exist_ok=True)
+        torch.save(self.model.state_dict(), os.path.join(str(path), self.TRAINED_MODEL_FILE_NAME))
+
+    def load_model(self, path):
+        state = torch.load(os.path.join(str(path), self.TRAINED_MODEL_FILE_NAME), map_location=self.config.device)
+        if self.flat is None:
+            self.model.load_state_dict(state)
+            return
+        named = dict(self.model.named_parameters())
+        with torch.no_grad():   # in place: the parameters live in the flat buffer
+            for k, v in state.items():
+                if k in named:
+                    named[k].data.copy_(v)
+        if getattr(self, "_pull", None) is not None:
+            self._pull.sync_in()
+
     def train_model(self):
         self.generator = self._new_generator()
-        self.monitor = Monitor.FILTERED_MEAN_RANK
         cur_epoch_idx = 0
         for cur_epoch_idx in range(self.config.epochs):
             _log("Epoch[%d/%d]" % (cur_epoch_idx, self.config.epochs))
@@ -701,7 +716,7 @@ class Trainer:
                 self.model.eval()
                 with torch.no_grad():
                     metrics = self.evaluator.mini_test(cur_epoch_idx)
-                if self.early_stopper.should_stop(metrics):
+                if self.early_stopper is not None and self.early_stopper.should_stop(metrics):
                     break
         self.model.eval()
         with torch.no_grad():

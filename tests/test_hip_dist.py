@@ -71,3 +71,75 @@ def test_two_ranks_owner_computes_gradient_equals_single_process(tmp_path, model
         bad = ~np.isclose(a[k], one[k], atol=2e-5, rtol=1e-4)
         assert bad.mean() <= (0.0 if opt == "sgd" else 2e-3), (k, bad.mean(), np.abs(a[k] - one[k]).max())
     assert np.allclose(a["losses"], one["losses"], rtol=1e-4), (a["losses"], one["losses"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The RCCL branch on the one GPU a test box has: a ONE-rank "nccl" process group handed to the Trainer explicitly makes the
+# step run reduce_scatter_tensor (SUM for the hinge, AVG for the mean-type losses) -> sharded optimiser ->
+# all_gather_into_tensor exactly as at N > 1 (degenerate collectives, same calls), eagerly and captured in a hipGraph
+# (KGE_GRAPH_MULTI=1), and with the owner-computes gradient step in front (KGE_PULL=1).  Each must reproduce the plain
+# single-process run.
+def _run_rccl_one_rank(rank, port, case, out_dir):
+    for p in (os.path.dirname(HERE), HERE, os.path.join(os.path.dirname(HERE), "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    model, opt, mode = case
+    for k in ("KGE_PULL", "KGE_GRAPH_MULTI", "KGE_STAGED"):
+        os.environ.pop(k, None)
+    if mode == "graph":
+        os.environ["KGE_GRAPH_MULTI"] = "1"
+    os.environ["KGE_PULL"] = "1" if mode == "pull" else "0"
+    import hip_util
+    import kge_oracle as ko
+    from pykg2vec_amd.trainer import Trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    rng = np.random.default_rng(11)
+    E, R, D, B = 600, 19, 32, 256
+    n_train = 4 * B
+    train = np.stack([rng.integers(E, size=n_train), rng.integers(R, size=n_train), rng.integers(E, size=n_train)], 1)
+    hp = dict(hidden_size=D, l1_flag=True, margin=1.0) if model == "transe" else dict(hidden_size=D, lmbda=1e-3)
+    P = ko.init_params(model, rng, tot_entity=E, tot_relation=R, hidden_size=D)
+    out = {}
+    for label, pg in (("plain", None), ("rccl", dist.group.WORLD)):
+        cfg = hip_util.make_config(E, R, hp, train, train[:4], train[:16], optimizer=opt, lr=0.01, batch_size=B)
+        m = hip_util.model_from_params(model, P, hp, E, R, train=train)
+        if pg is None:     # the plain run must not see the default group
+            tr = Trainer(m, cfg, use_graph=False)
+            tr.distributed, tr.world_size, tr.rank = False, 1, 0
+        else:
+            tr = Trainer(m, cfg, process_group=pg)
+        tr.build_model()
+        tr.generator = tr._new_generator()
+        if pg is not None:
+            assert tr.distributed and tr.world_size == 1 and tr._collectives() == (True, "nccl")
+            assert tr.flat.grad_shard.data_ptr() != tr.flat.grad.data_ptr()
+            assert tr._graph_wanted(4) == (mode == "graph")
+            assert tr._pull_dp_ok() == (mode == "pull")
+        losses = [tr.train_model_epoch(e) for e in range(2)]
+        if pg is not None and mode == "graph":
+            assert tr._graph is not None
+        torch.cuda.synchronize()
+        out[label] = (losses, {n: p.detach().cpu().numpy() for n, p in m.named_parameters()})
+    np.savez(os.path.join(out_dir, "rccl1.npz"), plain_losses=np.asarray(out["plain"][0]), rccl_losses=np.asarray(out["rccl"][0]),
+             **{"plain." + k: v for k, v in out["plain"][1].items()}, **{"rccl." + k: v for k, v in out["rccl"][1].items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [("transe", "adam", "eager"), ("transe", "adam", "graph"), ("transe", "sgd", "pull"),
+                                  ("complex", "adagrad", "eager"), ("complex", "adagrad", "graph")],
+                         ids=lambda c: "-".join(c))
+def test_one_rank_rccl_group_runs_the_collective_step(tmp_path, case):
+    out = str(tmp_path)
+    mp.spawn(_run_rccl_one_rank, args=(_free_port(), case, out), nprocs=1, join=True)
+    z = np.load(os.path.join(out, "rccl1.npz"))
+    assert np.allclose(z["plain_losses"], z["rccl_losses"], rtol=1e-4), (z["plain_losses"], z["rccl_losses"])
+    for k in z.files:
+        if not k.startswith("plain."):
+            continue
+        a, b = z[k], z["rccl." + k[6:]]
+        bad = ~np.isclose(a, b, atol=2e-5, rtol=1e-4)   # (Adam / Adagrad first steps on atomically summed gradients move an
+        # entry by ~lr * sign(g): isolated sign flips of rounding residues are allowed, nothing else)
+        assert bad.mean() <= (0.0 if case[1] == "sgd" else 2e-3), (k, bad.mean(), np.abs(a - b).max())

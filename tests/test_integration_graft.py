@@ -103,18 +103,3 @@ def test_reference_trainer_drives_the_drop_in_path(tmp_path, case, model_name):
     tr3 = Trainer(model_def(**cfg3.__dict__), cfg3)
     tr3.build_model()
     assert np.isfinite(tr3.tune_model())
-
-
-def test_early_stopper_equals_the_reference_one():
-    ref_shim.install()
-    import pykg2vec.utils.trainer as ref_tr
-    from pykg2vec_amd.common import Monitor
-    from pykg2vec_amd.trainer import EarlyStopper
-    rng = np.random.default_rng(3)
-    for monitor in (Monitor.FILTERED_MEAN_RANK, Monitor.MEAN_RECIPROCAL_RANK):
-        for patience in (0, 1, 3):
-            for _ in range(20):
-                a, b = EarlyStopper(patience, monitor), ref_tr.EarlyStopper(patience, ref_tr.Monitor(monitor.value))
-                for v in rng.integers(0, 4, size=12):
-                    m = {monitor.value: float(v)}
-                    assert a.should_stop(m) == b.should_stop(m)
