@@ -70,11 +70,15 @@ FULLSIZE = {
     "c1_transe_l2": dict(model="transe", E=14951, R=1345, splits=(483142, 50000, 59071), seed=9102,
                          hp=dict(hidden_size=100, l1_flag=False, margin=1.0), n_scores=256, step_B=4096, n_rank=32),
     "c2_complex": dict(model="complex", E=40943, R=11, splits=(86835, 3034, 3134), seed=9103,
-                       hp=dict(hidden_size=200, lmbda=1e-4), n_scores=256, step_B=1000, n_rank=8),
+                       hp=dict(hidden_size=200, lmbda=1e-4), n_scores=256, step_B=1000, n_rank=32),
     "c3_rotate": dict(model="rotate", E=14541, R=237, splits=(272115, 17535, 20466), seed=9104,
-                      hp=dict(hidden_size=1000, margin=24.0, neg_rate=16, alpha=1.0), n_scores=64, step_B=32, n_rank=4),
+                      hp=dict(hidden_size=1000, margin=24.0, neg_rate=16, alpha=1.0), n_scores=64, step_B=32, n_rank=32),
     "c4_rescal": dict(model="rescal", E=123182, R=37, splits=(1079040, 5000, 5000), seed=9105,
                       hp=dict(hidden_size=200, margin=1.0), n_scores=64, step_B=64, n_rank=0),
+    # the C4 relation-matrix width with an entity set small enough for the reference's own sweep (it gathers E*k*k floats
+    # per query, pairwise.py:829-865: 320 MB here, 19.7 GB at YAGO3-10 size): the rank fixture C4 itself cannot have
+    "c4_rescal_smallE": dict(model="rescal", E=2000, R=37, splits=(40000, 500, 500), seed=9106,
+                             hp=dict(hidden_size=200, margin=1.0), n_scores=64, step_B=64, n_rank=16),
 }
 
 
