@@ -146,3 +146,18 @@ def rank_band_ok(scores_row, true_id, got, ref, atol=ATOL, rtol=RTOL):
     band = 2.0 * (atol + rtol * abs(st))
     near = int(np.sum(np.abs(scores_row.astype(np.float64) - st) <= band)) - 1   # the true candidate itself excluded
     return abs(int(got) - int(ref)) <= near, near
+
+
+def tie_bracket(scores_row, true_id, known=()):
+    """(less, ties, fless, fties) of one sweep: candidates strictly below the true one's energy / exactly tied with it
+    (true one excluded), all candidates and known-filtered.  The reference's scan of the topk ordering
+    (utils/evaluator.py:70-123) finds the true candidate after every strictly lower one and after an ATen-dependent subset of
+    its tie group, so   less <= rank_ref <= less + ties   and   fless <= frank_ref <= fless + fties."""
+    st = scores_row[true_id]
+    lower, tied = scores_row < st, scores_row == st
+    tied[true_id] = False
+    keep = np.ones(len(scores_row), dtype=bool)
+    kn = np.fromiter((e for e in known if e != true_id), dtype=np.int64)
+    if kn.size:
+        keep[kn] = False
+    return int(lower.sum()), int(tied.sum()), int((lower & keep).sum()), int((tied & keep).sum())

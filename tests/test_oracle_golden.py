@@ -154,3 +154,34 @@ def test_head_1n_and_multi_class_bce(mode, ls):
     assert close(gxt, z[mode + ".g_x_t"], atol=1e-7) and close(gxh, z[mode + ".g_x_h"], atol=1e-7)
     assert close(get_ + geh, z[mode + ".g_ent"], atol=1e-7)
     assert close((gbt + gbh).reshape(1, -1), z[mode + ".g_bias"], atol=1e-7)
+
+
+def test_tie_policy_brackets_the_reference_on_clamp_saturated_simple():
+    """Exact ties (SimplE's +-20 clamp with large embeddings, tests/golden/ref_simple_ties.npz from the live reference):
+    the count-based rank (#strictly lower) is the optimistic end of the tie group; the reference's topk scan lands
+    somewhere inside it.  INTEGRATION.md "behavioural differences" (c)."""
+    from golden_util import tie_bracket
+    c = Case("simple_ties")
+    P = c.params()
+    hr_t, tr_h = c.filters()
+    n = len(c.z["eval.rank_head"])
+    sw = c.z["eval.sweeps"]
+    inside, ties_total = 0, 0
+    for i, (h, r, t) in enumerate(c.test[:n]):
+        h, r, t = int(h), int(r), int(t)
+        for row_ref, side, true, known, raw, filt in (
+                (sw[2 * i], "tail", t, hr_t[(h, r)], c.z["eval.rank_tail"][i], c.z["eval.frank_tail"][i]),
+                (sw[2 * i + 1], "head", h, tr_h[(t, r)], c.z["eval.rank_head"][i], c.z["eval.frank_head"][i])):
+            got = ko.sweep_scores("simple", P, h, r, t, side, **c.hp)
+            sat = np.abs(row_ref) == 20.0
+            # saturated energies are exact; the others are sums of cancelling products of magnitude ~1e2: absolute noise ~1e-4
+            assert np.array_equal(got[sat], row_ref[sat]) and close(got, row_ref, atol=3e-4)
+            less, ties, fless, fties = tie_bracket(got, true, known)
+            rk, frk = ko.rank_from_scores(got, true, known)
+            assert (rk, frk) == (less, fless)
+            near = int(np.sum((np.abs(got - got[true]) <= 6e-4) & (got != got[true])))   # unsaturated neighbours that may flip
+            assert less - near <= raw <= less + ties + near and fless - near <= filt <= fless + fties + near, \
+                (i, side, less, ties, raw, fless, fties, filt, near)
+            inside += int(raw > less)
+            ties_total += ties
+    assert ties_total > 100 and inside > 0   # the fixture really exercises ties, and the reference does not pick the optimistic end
