@@ -346,6 +346,29 @@ def main():
     pull = tr._pull_ok()   # single GPU, big batch: the atomic-free owner-computes step (csrc/kge_pull.hip)
     pull_dp = tr._pull_dp_ok()   # N > 1: the same kernel writes the rank's dense gradient (no atomics), then the sharded step
 
+    # ---- per-run set-up of the owner-computes path: the incidence index of every batch of the epoch order, built on the device
+    # (csrc/kge_index.hip).  Timed twice: cold (first call: includes loading the code objects) and warm (a rebuild), host wall
+    # clock around the call incl. its one device->host read; plus HIP events around the warm build.
+    setup = None
+    if pull or pull_dp:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gen.pull_index()
+        torch.cuda.synchronize()
+        cold_ms = (time.perf_counter() - t0) * 1e3
+        gen._pull_index = None
+        es0, es1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        es0.record()
+        idx0 = gen.pull_index()
+        es1.record()
+        torch.cuda.synchronize()
+        warm_ms = (time.perf_counter() - t0) * 1e3
+        setup = {"what": "incidence index of %d batches of %d pairs (kge_pull_index_build: key build, three batched bitonic sorts, "
+                         "row list, placement)" % (idx0.n_batches, idx0.batch_size), "built_on": idx0.built_on,
+                 "host_wall_ms_cold": cold_ms, "host_wall_ms_warm": warm_ms, "device_ms_warm": es0.elapsed_time(es1),
+                 "gpu_step_equivalents": None}
+
     def reset_model():
         """Back to the freshly initialised tables and optimiser state.  The hinge kernel skips the backward of pairs whose
         margin is already satisfied, so a step gets cheaper as training progresses: every measurement below starts
@@ -574,6 +597,10 @@ def main():
                                                       "peak and is not the bound",
                                   "traffic": None}},
         }
+        if setup is not None:
+            setup["gpu_step_equivalents"] = setup["host_wall_ms_warm"] / (dt / args.steps * 1e3)
+            out["setup_ms"] = setup["host_wall_ms_warm"]
+            out["setup"] = setup
         if small is not None:
             out["train_reference_default_batch"] = small
     if world == 1 and not args.no_extra_configs:

@@ -292,7 +292,8 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
  * hat_out / norm_out / state may be NULL.  This is what data-parallel ranks run before their reduce-scatter. */
 #define KGE_PULL_BUCKET 16
 typedef struct kge_pull_lists {
-    int32_t* pc;      /* [n]  per pair: corrupting entity | (tail corrupted) << 24 */
+    int32_t* pc;      /* [n]  per pair: corrupting entity | (tail corrupted) << 24 | (first pair to register with that entity
+                         this step) << 27 */
     int32_t* count;   /* [tot_entity]  pairs that drew the entity this step; all 0 between steps */
     int32_t* bucket;  /* [tot_entity * KGE_PULL_BUCKET]  the first KGE_PULL_BUCKET of them */
     int32_t* head;    /* [tot_entity]  overflow list head, all -1 between steps */
@@ -356,6 +357,28 @@ typedef struct kge_pull_plan {
 size_t kge_pull_plan_bytes(void);   /* sizeof(kge_pull_plan): lets a binding check its struct layout */
 int kge_pull_run(const kge_pull_plan* plan, int64_t first_batch, int64_t n_steps, int32_t src_half, int32_t cur_list,
                  int32_t lists_ready, int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream);
+
+/* ---- The incidence index of kge_pull_step / kge_own_step, built ON THE DEVICE for n_batches batches at once (csrc/kge_index.hip).
+ * The reference's per-run set-up of the batch feed is one permutation (data/generator.py:19-35: a batch is a fixed slice of it);
+ * the index is this path's own per-run structure over those slices.  Batch b covers the pairs
+ * triples[perm[b * batch_stride + slice_lo + i]], i < n_pairs (data-parallel ranks pass their slice of every batch).
+ * Outputs, per batch b at fixed strides (device, int32):
+ *   pairs  + b * n_pairs * 4          [n_pairs, 4]
+ *   inc    + b * n_pairs * 3          [3 n_pairs]
+ *   items  + b * item_cap * 4         [item_cap, 4], the first counts[4 b] slots are live (the rest is padding, row -1)
+ *   multi  + b * multi_cap * 4        [multi_cap, 4], the first counts[4 b + 1] rows are live
+ *   skip   + b * words                bitmap of the listed rows (compact != 0 only: kge_pull_batch.dense_skip)
+ *   counts + 4 b                      {item slots, multi rows, partial slots, listed rows}
+ * item_cap / multi_cap / words / workspace bytes from kge_pull_index_geometry.  compact != 0 lists only rows with an incidence.
+ * The layout rule is the one stated at pykg2vec_amd/generator.py::build_pull_batch (a numpy restatement used by tests and for
+ * one-off explicit batches): both produce identical arrays.  Integer work only. */
+int kge_pull_index_geometry(int64_t n_batches, int64_t n_pairs, int64_t tot_entity, int64_t tot_relation, int32_t segment,
+                            int32_t groups_per_block, int32_t compact, int64_t* item_cap, int64_t* multi_cap, int64_t* words,
+                            size_t* workspace_bytes);
+int kge_pull_index_build(const int64_t* triples, const int64_t* perm, int64_t batch_stride, int64_t slice_lo, int64_t n_pairs,
+                         int64_t n_batches, int64_t tot_entity, int64_t tot_relation, int32_t segment, int32_t groups_per_block,
+                         int32_t compact, int32_t* pairs, int32_t* inc, int32_t* items, int32_t* multi, uint32_t* skip,
+                         int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- Atomic-free ("staged") training step for the long-row bundle kernels (RotatE self-adversarial; replaces the dense
  * gradient buffer + atomics of kge_train_pairwise_selfadv_sampled followed by kge_optimizer_step; same reference lines:

@@ -153,6 +153,10 @@ _SIGNATURES = {
                                      ctypes.c_int32, ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
                                      ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                      ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_pull_index_geometry": (ctypes.c_int, [ctypes.c_int64] * 4 + [ctypes.c_int32] * 3 + [ctypes.POINTER(ctypes.c_int64)] * 3
+                                + [ctypes.POINTER(ctypes.c_size_t)]),
+    "kge_pull_index_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int64] * 6 + [ctypes.c_int32] * 3
+                             + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]),
     "kge_pull_plan_bytes": (ctypes.c_size_t, []),
     "kge_pull_run": (ctypes.c_int, [ctypes.POINTER(PullPlanC), ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                     ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]),

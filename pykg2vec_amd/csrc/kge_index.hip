@@ -1,0 +1,381 @@
+// kge_index.hip -- the incidence index of the owner-computes training step (kge_pull.hip), built ON THE DEVICE for every batch
+// of the epoch order at once (include/kge_hip.h: kge_pull_index_build).
+//
+// What it replaces: nothing in the reference -- its per-run set-up is one permutation (data/generator.py:19-35); the index is
+// this path's own per-run structure ("device-resident dataset structures ... built once per run").  Round 2 built
+// it with numpy sorts on the host (0.43 s at the FB15k shape, B = 32768; 2.0 s at B = 128); here it is a handful of launches:
+//   k_ix_keys    one 64-bit key per incidence: row << 32 | pair << 2 | role                      (+ the batch's pair list)
+//   bitonic sort of the keys of every batch side by side (LDS tiles of 2048 keys; global steps above that)
+//   k_ix_rows    run boundaries -> the row list (row, first incidence, count), work items per row, the three item classes
+//                (single / workgroup-local / global partials), sort keys for the two placement orders
+//   two more batched sorts (local rows by size class, the other items by weight)
+//   k_ix_place   the placement rule of generator.build_pull_batch (its docstring is the specification: the numpy function and
+//                this file produce IDENTICAL arrays, tests/test_hip_pull.py::test_device_built_index_equals_the_numpy_one)
+// Everything is integer work: bit-exact by construction, no float anywhere.
+#include "kge_internal.h"
+
+namespace kge {
+
+typedef unsigned long long u64;
+constexpr int kIxBlock = 1024;
+constexpr u64 kKeyPad = ~0ull;
+
+// ---------------------------------------------------------------- batched bitonic sort (ascending) of [n_arrays][P] u64 keys
+// element i of an array and its partner i ^ j are put in ascending order when (i & k) == 0, descending otherwise
+__device__ __forceinline__ void cmpx(u64& a, u64& b, bool asc) {
+    if ((a > b) == asc) { const u64 t = a; a = b; b = t; }
+}
+
+// all stages k = 2 .. tile of one LDS tile (first pass), or the steps j = tile/2 .. 1 of stage k (k > tile: merge pass)
+__global__ __launch_bounds__(256) void k_bitonic_tile(u64* __restrict__ keys, int P, int tile, int k_only) {
+    extern __shared__ u64 s_keys[];
+    const long base = (long)blockIdx.x * tile;
+    const int i0 = (int)(base % P);                 // position of the tile inside its array
+    for (int t = threadIdx.x; t < tile; t += 256) s_keys[t] = keys[base + t];
+    __syncthreads();
+    const int half = tile >> 1;
+    for (int k = k_only ? k_only : 2; k <= (k_only ? k_only : tile); k <<= 1) {
+        for (int j = (k_only ? half : k >> 1); j >= 1; j >>= 1) {
+            for (int t = threadIdx.x; t < half; t += 256) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool asc = ((i0 + lo) & k) == 0;
+                u64 a = s_keys[lo], b = s_keys[hi];
+                if ((a > b) == asc) { s_keys[lo] = b; s_keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = threadIdx.x; t < tile; t += 256) keys[base + t] = s_keys[t];
+}
+
+// one step (k, j) with j >= tile: partners live in different tiles
+__global__ __launch_bounds__(256) void k_bitonic_step(u64* __restrict__ keys, int P, long n_pairs, int k, int j) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_pairs) return;
+    const long arr = t / (P >> 1);
+    const int tt = (int)(t - arr * (P >> 1));
+    const int lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
+    const int hi = lo | j;
+    u64* a = keys + arr * P;
+    u64 x = a[lo], y = a[hi];
+    const bool asc = (lo & k) == 0;
+    if ((x > y) == asc) { a[lo] = y; a[hi] = x; }
+}
+
+static int sort_batched(u64* keys, long n_arrays, int P, hipStream_t s) {
+    const int tile = P < 2048 ? P : 2048;
+    const unsigned tiles = (unsigned)(n_arrays * (P / tile));
+    hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(256), tile * sizeof(u64), s, keys, P, tile, 0);
+    for (int k = tile << 1; k <= P; k <<= 1) {
+        const long n_pairs = n_arrays * (P >> 1);
+        for (int j = k >> 1; j >= tile; j >>= 1)
+            hipLaunchKernelGGL(k_bitonic_step, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, keys, P, n_pairs, k, j);
+        hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(256), tile * sizeof(u64), s, keys, P, tile, k);
+    }
+    return check_launch("index sort");
+}
+
+// ---------------------------------------------------------------- block-wide exclusive scan (1024 threads)
+// returns the exclusive prefix of v over the block; *total = the block's sum (same value in every thread)
+__device__ __forceinline__ int block_scan(int v, int* total) {
+    __shared__ int s_wave[kIxBlock / 64];
+    __shared__ int s_total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int w = 0; w < kIxBlock / 64; ++w) { const int t = s_wave[w]; s_wave[w] = acc; acc += t; }
+        s_total = acc;
+    }
+    __syncthreads();
+    const int out = x - v + s_wave[wave];
+    *total = s_total;
+    __syncthreads();   // s_wave / s_total may be rewritten by the next call
+    return out;
+}
+
+struct IxArgs {
+    const int64_t* triples; const int64_t* perm;
+    int64_t batch_stride, slice_lo;
+    int n, nb;                       // pairs per batch (of this rank's slice), batches
+    int E, nrows, seg, GPB, compact, c_extra;
+    int P1, P2, P3, NRcap, item_cap, multi_cap, words;
+    u64* keys1; u64* keys2; u64* keys3;
+    int* l_row; int* l_beg; int* l_cnt; int* gbase; int* open; int* meta;
+    int4* pairs; int* inc; int4* items; int4* multi; unsigned* skip; int* counts;
+};
+
+__global__ __launch_bounds__(256) void k_ix_keys(IxArgs a) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.P1) return;
+    u64 key = kKeyPad;
+    if (j < 3 * a.n) {
+        const int i = j / 3, role = j - 3 * i;
+        const int64_t row = a.perm[(int64_t)b * a.batch_stride + a.slice_lo + i];
+        const int h = (int)a.triples[3 * row], r = (int)a.triples[3 * row + 1], t = (int)a.triples[3 * row + 2];
+        const int g = role == 0 ? h : (role == 1 ? t : a.E + r);
+        key = ((u64)(unsigned)g << 32) | (u64)(unsigned)(4 * i + role);
+        if (role == 0) a.pairs[(int64_t)b * a.n + i] = make_int4(h, r, t, 0);
+    }
+    a.keys1[(int64_t)b * a.P1 + j] = key;
+}
+
+__device__ __forceinline__ int lower_bound_row(const u64* __restrict__ keys, int n, unsigned row) {
+    int lo = 0, hi = n;   // first j with (keys[j] >> 32) >= row
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((unsigned)(keys[mid] >> 32) < row) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int ilog2_pow2(int p) { return 31 - __clz(p); }
+__device__ __forceinline__ int next_pow2(int x) { return x <= 1 ? 1 : 1 << (32 - __clz(x - 1)); }
+
+// rows list, item classes, sort keys of the two placement orders; one workgroup per batch
+__global__ __launch_bounds__(kIxBlock) void k_ix_rows(IxArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int M = 3 * a.n;
+    const u64* keys = a.keys1 + (int64_t)b * a.P1;
+    int* inc = a.inc + (int64_t)b * M;
+    int* l_row = a.l_row + (int64_t)b * a.NRcap;
+    int* l_beg = a.l_beg + (int64_t)b * a.NRcap;
+    int* l_cnt = a.l_cnt + (int64_t)b * a.NRcap;
+    int* gbase = a.gbase + (int64_t)b * a.NRcap;
+    u64* keys2 = a.keys2 + (int64_t)b * a.P2;
+    u64* keys3 = a.keys3 + (int64_t)b * a.P3;
+    int4* multi = a.multi + (int64_t)b * a.multi_cap;
+    for (int j = tid; j < M; j += kIxBlock) inc[j] = (int)(unsigned)keys[j];
+    __shared__ int s_NR;
+    int tot;
+    if (a.compact) {
+        unsigned* skip = a.skip + (int64_t)b * a.words;
+        for (int w = tid; w < a.words; w += kIxBlock) skip[w] = 0u;
+        __syncthreads();
+        int carry = 0;
+        for (int j0 = 0; j0 < M; j0 += kIxBlock) {
+            const int j = j0 + tid;
+            const bool start = j < M && (j == 0 || (unsigned)(keys[j] >> 32) != (unsigned)(keys[j - 1] >> 32));
+            const int at = carry + block_scan(start ? 1 : 0, &tot);
+            if (start) {
+                const unsigned row = (unsigned)(keys[j] >> 32);
+                l_row[at] = (int)row; l_beg[at] = j;
+                atomicOr(skip + (row >> 5), 1u << (row & 31));
+            }
+            carry += tot;
+        }
+        if (tid == 0) s_NR = carry;
+        __syncthreads();
+        const int NR = s_NR;
+        for (int u = tid; u < NR; u += kIxBlock) l_cnt[u] = (u + 1 < NR ? l_beg[u + 1] : M) - l_beg[u];
+    } else {
+        for (int u = tid; u < a.nrows; u += kIxBlock) {
+            const int lo = lower_bound_row(keys, M, (unsigned)u), hi = lower_bound_row(keys, M, (unsigned)u + 1u);
+            l_row[u] = u; l_beg[u] = lo; l_cnt[u] = hi - lo;
+        }
+        if (tid == 0) s_NR = a.nrows;
+    }
+    __syncthreads();
+    const int NR = s_NR;
+    const int wmax = a.seg + a.c_extra;
+    int cL = 0, cB = 0, cG = 0, cM = 0;   // running totals: local rows, region-B items, partial slots, global rows
+    for (int u0 = 0; u0 < NR; u0 += kIxBlock) {
+        const int u = u0 + tid;
+        int nseg = 0, cnt = 0, row = 0;
+        if (u < NR) { cnt = l_cnt[u]; row = l_row[u]; nseg = (cnt + a.seg - 1) / a.seg; if (nseg < 1) nseg = 1; }
+        const bool local = u < NR && nseg >= 2 && nseg <= a.GPB;
+        const bool global = u < NR && nseg > a.GPB;
+        const int nbi = (u < NR && !local) ? nseg : 0;
+        const int iL = cL + block_scan(local ? 1 : 0, &tot); cL += tot;
+        const int iB = cB + block_scan(nbi, &tot); cB += tot;
+        const int iG = cG + block_scan(global ? nseg : 0, &tot); cG += tot;
+        const int iM = cM + block_scan(global ? 1 : 0, &tot); cM += tot;
+        if (u < NR) {
+            gbase[u] = global ? iG : 0;
+            if (local) {
+                const int p2 = next_pow2(nseg);
+                keys2[iL] = ((u64)(32 - ilog2_pow2(p2)) << 40) | (u64)(unsigned)u;
+            } else {
+                const int beg = l_beg[u];
+                for (int s = 0; s < nseg; ++s) {
+                    const int sb = beg + s * a.seg;
+                    int se = sb + a.seg; if (se > beg + cnt) se = beg + cnt;
+                    const int w = (se - sb) + ((row < a.E && s == 0) ? a.c_extra : 0);
+                    keys3[iB + s] = ((u64)(unsigned)(wmax - w) << 48) | ((u64)(unsigned)u << 22) | (u64)(unsigned)s;
+                }
+                if (global) multi[iM] = make_int4(row, iG, nseg, 0);
+            }
+        }
+    }
+    for (int i = cL + tid; i < a.P2; i += kIxBlock) keys2[i] = kKeyPad;
+    for (int i = cB + tid; i < a.P3; i += kIxBlock) keys3[i] = kKeyPad;
+    if (tid == 0) {
+        int* meta = a.meta + (int64_t)b * 8;
+        meta[0] = NR; meta[1] = cL; meta[2] = cB; meta[3] = cM; meta[4] = cG;
+    }
+}
+
+// the placement rule (generator.build_pull_batch); one workgroup per batch
+__global__ __launch_bounds__(kIxBlock) void k_ix_place(IxArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int* meta = a.meta + (int64_t)b * 8;
+    const int NL = meta[1], NB = meta[2];
+    const int* l_row = a.l_row + (int64_t)b * a.NRcap;
+    const int* l_beg = a.l_beg + (int64_t)b * a.NRcap;
+    const int* l_cnt = a.l_cnt + (int64_t)b * a.NRcap;
+    const int* gbase = a.gbase + (int64_t)b * a.NRcap;
+    const u64* keys2 = a.keys2 + (int64_t)b * a.P2;
+    const u64* keys3 = a.keys3 + (int64_t)b * a.P3;
+    int* open = a.open + (int64_t)b * a.item_cap;
+    int4* items = a.items + (int64_t)b * a.item_cap;
+    for (int i = tid; i < a.item_cap; i += kIxBlock) items[i] = make_int4(-1, 0, 0, 0);
+    __syncthreads();
+    // ---- region A: local rows in (p2 descending, row ascending) order
+    int cS = 0, cF = 0, tot;
+    for (int k0 = 0; k0 < NL; k0 += kIxBlock) {
+        const int k = k0 + tid;
+        int p2 = 0, nseg = 0, u = 0;
+        if (k < NL) {
+            const u64 key = keys2[k];
+            u = (int)(unsigned)(key & 0xFFFFFFFFFFull);
+            p2 = 1 << (32 - (int)(key >> 40));
+            nseg = (l_cnt[u] + a.seg - 1) / a.seg;
+        }
+        const int start = cS + block_scan(p2, &tot); cS += tot;
+        const int fbase = cF + block_scan(p2 - nseg, &tot); cF += tot;
+        if (k < NL) {
+            const int beg = l_beg[u], end = beg + l_cnt[u], row = l_row[u];
+            for (int s = 0; s < nseg; ++s) {
+                const int sb = beg + s * a.seg;
+                items[start + s] = make_int4(row, sb, sb + a.seg < end ? sb + a.seg : end, 3 | (s << 2) | (nseg << 6));
+            }
+            for (int f = 0; f < p2 - nseg; ++f) open[fbase + f] = start + nseg + f;
+        }
+    }
+    const int SA = cS, SA_pad = (SA + a.GPB - 1) / a.GPB * a.GPB;
+    for (int i = tid; i < SA_pad - SA; i += kIxBlock) open[cF + i] = SA + i;
+    const int F = cF + (SA_pad - SA);
+    __syncthreads();
+    // ---- region B: the q-th item in (weight descending, row ascending, segment ascending) order takes the q-th open slot
+    for (int q = tid; q < NB; q += kIxBlock) {
+        const u64 key = keys3[q];
+        const int u = (int)((key >> 22) & 0x3FFFFFFull), s = (int)(key & 0x3FFFFFull);
+        const int cnt = l_cnt[u], beg = l_beg[u];
+        int nseg = (cnt + a.seg - 1) / a.seg; if (nseg < 1) nseg = 1;
+        const int sb = beg + s * a.seg;
+        int se = sb + a.seg; if (se > beg + cnt) se = beg + cnt;
+        const int info = nseg > a.GPB ? ((s == 0 ? 1 : 2) | ((gbase[u] + s) << 2)) : 0;
+        const int slot = q < F ? open[q] : SA_pad + (q - F);
+        items[slot] = make_int4(l_row[u], sb, se, info);
+    }
+    if (tid == 0) {
+        int n_slots = SA_pad + (NB > F ? NB - F : 0);
+        n_slots = (n_slots + a.GPB - 1) / a.GPB * a.GPB;
+        if (n_slots < a.GPB) n_slots = a.GPB;
+        int* c = a.counts + (int64_t)b * 4;
+        c[0] = n_slots; c[1] = meta[3]; c[2] = meta[4]; c[3] = meta[0];
+    }
+}
+
+static int pow2_at_least(int64_t x, int lo) { int p = lo; while (p < x) p <<= 1; return p; }
+
+struct IxGeometry { int P1, P2, P3, NRcap, item_cap, multi_cap, words, c_extra; size_t ws_bytes; };
+
+static bool index_geometry(int64_t nb, int64_t n, int64_t E, int64_t R, int seg, int GPB, int compact, IxGeometry* g) {
+    const int64_t nrows = E + R, M = 3 * n;
+    if (nb <= 0 || n <= 0 || nrows <= 0 || seg < 1 || GPB < 1 || GPB > 16 || M >= (1ll << 30) || nrows >= (1ll << 26)) return false;
+    g->NRcap = (int)(compact ? (nrows < M ? nrows : M) : nrows);
+    const int64_t segs = (M + seg - 1) / seg;
+    g->P1 = pow2_at_least(M, 512);
+    g->P2 = pow2_at_least((g->NRcap < M / (seg + 1) + 1 ? g->NRcap : M / (seg + 1) + 1), 512);
+    g->P3 = pow2_at_least(g->NRcap + segs + 1, 512);
+    const int64_t cap = 2 * ((int64_t)g->NRcap + segs) + 2 * GPB;
+    g->item_cap = (int)((cap + GPB - 1) / GPB * GPB);
+    g->multi_cap = (int)(M / ((int64_t)GPB * seg) + 2);
+    g->words = (int)((nrows + 31) / 32);
+    int64_t ce = n / (E > 0 ? E : 1); if (ce < 1) ce = 1; if (ce > 4096) ce = 4096;
+    g->c_extra = (int)ce;
+    size_t b = 0;
+    b += (size_t)nb * ((size_t)g->P1 + g->P2 + g->P3) * sizeof(u64);
+    b += (size_t)nb * (size_t)g->NRcap * 4 * sizeof(int);
+    b += (size_t)nb * (size_t)g->item_cap * sizeof(int);
+    b += (size_t)nb * 8 * sizeof(int);
+    g->ws_bytes = b + 256;
+    return true;
+}
+
+}  // namespace kge
+
+using namespace kge;
+
+extern "C" {
+
+int kge_pull_index_geometry(int64_t n_batches, int64_t n_pairs, int64_t tot_entity, int64_t tot_relation, int32_t segment,
+                            int32_t groups_per_block, int32_t compact, int64_t* item_cap, int64_t* multi_cap, int64_t* words,
+                            size_t* workspace_bytes) {
+    IxGeometry g;
+    if (!index_geometry(n_batches, n_pairs, tot_entity, tot_relation, segment, groups_per_block, compact, &g)) {
+        set_error("kge_pull_index_geometry: bad sizes");
+        return -1;
+    }
+    if (item_cap) *item_cap = g.item_cap;
+    if (multi_cap) *multi_cap = g.multi_cap;
+    if (words) *words = g.words;
+    if (workspace_bytes) *workspace_bytes = g.ws_bytes;
+    return 0;
+}
+
+int kge_pull_index_build(const int64_t* triples, const int64_t* perm, int64_t batch_stride, int64_t slice_lo, int64_t n_pairs,
+                         int64_t n_batches, int64_t tot_entity, int64_t tot_relation, int32_t segment, int32_t groups_per_block,
+                         int32_t compact, int32_t* pairs, int32_t* inc, int32_t* items, int32_t* multi, uint32_t* skip,
+                         int32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
+    IxGeometry g;
+    if (!index_geometry(n_batches, n_pairs, tot_entity, tot_relation, segment, groups_per_block, compact, &g)) {
+        set_error("kge_pull_index_build: bad sizes");
+        return -1;
+    }
+    if (!triples || !perm || !pairs || !inc || !items || !multi || !counts || (compact && !skip) || !workspace ||
+        workspace_bytes < g.ws_bytes || batch_stride < n_pairs || slice_lo < 0) {
+        set_error("kge_pull_index_build: bad arguments (workspace of kge_pull_index_geometry bytes)");
+        return -1;
+    }
+    if (segment > 256 / groups_per_block) { set_error("kge_pull_index_build: segment %d exceeds the owner group width", segment); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    IxArgs a;
+    a.triples = triples; a.perm = perm; a.batch_stride = batch_stride; a.slice_lo = slice_lo;
+    a.n = (int)n_pairs; a.nb = (int)n_batches; a.E = (int)tot_entity; a.nrows = (int)(tot_entity + tot_relation);
+    a.seg = segment; a.GPB = groups_per_block; a.compact = compact ? 1 : 0; a.c_extra = g.c_extra;
+    a.P1 = g.P1; a.P2 = g.P2; a.P3 = g.P3; a.NRcap = g.NRcap; a.item_cap = g.item_cap; a.multi_cap = g.multi_cap; a.words = g.words;
+    char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    a.keys1 = (u64*)w; w += (size_t)a.nb * a.P1 * sizeof(u64);
+    a.keys2 = (u64*)w; w += (size_t)a.nb * a.P2 * sizeof(u64);
+    a.keys3 = (u64*)w; w += (size_t)a.nb * a.P3 * sizeof(u64);
+    a.l_row = (int*)w; w += (size_t)a.nb * a.NRcap * sizeof(int);
+    a.l_beg = (int*)w; w += (size_t)a.nb * a.NRcap * sizeof(int);
+    a.l_cnt = (int*)w; w += (size_t)a.nb * a.NRcap * sizeof(int);
+    a.gbase = (int*)w; w += (size_t)a.nb * a.NRcap * sizeof(int);
+    a.open = (int*)w; w += (size_t)a.nb * a.item_cap * sizeof(int);
+    a.meta = (int*)w;
+    a.pairs = (int4*)pairs; a.inc = inc; a.items = (int4*)items; a.multi = (int4*)multi; a.skip = skip; a.counts = counts;
+    hipLaunchKernelGGL(k_ix_keys, dim3((unsigned)((a.P1 + 255) / 256), (unsigned)a.nb), dim3(256), 0, s, a);
+    int rc = check_launch("k_ix_keys");
+    if (rc) return rc;
+    if ((rc = sort_batched(a.keys1, a.nb, a.P1, s))) return rc;
+    hipLaunchKernelGGL(k_ix_rows, dim3((unsigned)a.nb), dim3(kIxBlock), 0, s, a);
+    if ((rc = check_launch("k_ix_rows"))) return rc;
+    if ((rc = sort_batched(a.keys2, a.nb, a.P2, s))) return rc;
+    if ((rc = sort_batched(a.keys3, a.nb, a.P3, s))) return rc;
+    hipLaunchKernelGGL(k_ix_place, dim3((unsigned)a.nb), dim3(kIxBlock), 0, s, a);
+    return check_launch("k_ix_place");
+}
+
+}  // extern "C"

@@ -24,31 +24,10 @@
 #include "kge_row_kernels.h"
 #include "kge_opt_device.h"
 #include "kge_sampler_device.h"
+#include "kge_pull_device.h"
 #include <stdlib.h>
 
 namespace kge {
-
-constexpr int kRoleH = 0, kRoleT = 1, kRoleR = 2, kRoleC = 3;
-constexpr int kPullCap = 16;   // per-entity bucket of "drawn as corrupting entity" pairs; overflow goes to a linked list
-
-// per-step sampler output: which pairs drew entity e as their corrupting entity
-struct PullLists {
-    int32_t* pc;       // [B]  per pair: corrupting entity | (tail corrupted) << 24
-    int32_t* count;    // [E]  number of pairs that drew e this step (reset to 0 by e's owner)
-    int32_t* bucket;   // [E * kPullCap] the first kPullCap of them, in arrival (i.e. arbitrary) order
-    int32_t* head;     // [E]  overflow list head (-1: none; reset by e's owner)
-    int32_t* next;     // [B]  overflow list links
-};
-
-struct PullSampleArgs {
-    const int4* pairs;         // batch to sample: (h, r, t, -)
-    int64_t n, E;
-    const float* bern;
-    const unsigned long long* slots;
-    unsigned long long mask, seed, offset;
-    const int64_t* cursor;
-    PullLists out;
-};
 
 struct PullArgs {
     const float* tab_in[2];    // entity / relation table read by this step
@@ -77,39 +56,6 @@ struct PullArgs {
     const float* theta;        // TransM (pairwise.py:341-347): fixed per-relation weight of both energies; NULL = TransE
 };
 
-// one pair of the sampled batch: draw the corruption (same Philox counters as kge_sample_batch / the fused push kernels:
-// offset + pair index) and register the pair with the corrupting entity
-__device__ __forceinline__ void pull_sample_one(const PullSampleArgs& sa, int64_t i) {
-    const unsigned long long off = sa.cursor ? sa.offset + (unsigned long long)sa.cursor[1] : sa.offset;
-    const int4 p = sa.pairs[i];
-    int64_t nh, nt;
-    corrupt_one(p.x, p.y, p.z, sa.E, sa.bern, sa.slots, sa.mask, sa.seed, off + (unsigned long long)i, nh, nt);
-    const bool tail = nh == p.x;
-    const int c = (int)(tail ? nt : nh);
-    sa.out.pc[i] = c | ((int)tail << 24);
-    const int pos = atomicAdd(sa.out.count + c, 1);
-    if (pos < kPullCap) sa.out.bucket[(int64_t)c * kPullCap + pos] = (int)i;
-    else sa.out.next[i] = atomicExch(sa.out.head + c, (int)i);
-}
-
-// Rows as float4 per lane: lane gl of a G-lane group holds elements 4*(v*G + gl) .. +3 for v < NV (d % 4 == 0): one
-// 16-byte load / store instruction per lane moves a whole 100-float row with 25 lanes.
-template <int G, int NV>
-__device__ __forceinline__ void load_row4(float4 (&x)[NV], const float* __restrict__ row, int nvec, int gl) {
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int i = v * G + gl;
-        x[v] = i < nvec ? reinterpret_cast<const float4*>(row)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-template <int G, int NV>
-__device__ __forceinline__ void store_row4(float* __restrict__ row, const float4 (&x)[NV], int nvec, int gl) {
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int i = v * G + gl;
-        if (i < nvec) reinterpret_cast<float4*>(row)[i] = x[v];
-    }
-}
 #define KGE_F4_EACH(expr_x, expr_y, expr_z, expr_w) expr_x; expr_y; expr_z; expr_w;
 
 // gradient wrt the NORMALISED own row, summed over incidences -> normalisation backward -> optimiser -> new row, its
@@ -453,19 +399,13 @@ __global__ __launch_bounds__(256) void k_pull_lists_explicit(const int4* __restr
     if (i >= n) return;
     const bool tail = nh[i] == pairs[i].x;   // the sampler's own rule (kge_score.hip: my_tail = nh == sh)
     const int c = (int)(tail ? nt[i] : nh[i]);
-    out.pc[i] = c | ((int)tail << 24);
     const int pos = atomicAdd(out.count + c, 1);
+    out.pc[i] = c | ((int)tail << 24) | ((pos == 0 ? 1 : 0) << kPcFirstBit);
     if (pos < kPullCap) out.bucket[(int64_t)c * kPullCap + pos] = (int)i;
     else out.next[i] = atomicExch(out.head + c, (int)i);
 }
 
 // ------------------------------------------------------------------ host side
-static PullLists to_lists(const kge_pull_lists* l) {
-    PullLists o;
-    o.pc = l->pc; o.count = l->count; o.bucket = l->bucket; o.head = l->head; o.next = l->next;
-    return o;
-}
-
 // float4-per-lane geometry (row length d, d % 4 == 0, d <= 1024): G-lane owner groups, NV float4s per lane, padded row =
 // 4 * G * NV floats.  32-lane groups by default; KGE_PULL_G=16 selects 16-lane groups for rows of up to 128 floats (four
 // owners per wave share the per-visit fixed work, but diverge more: measured 38.8 vs 33.5 us per step at FB15k shape).
@@ -511,18 +451,6 @@ static int launch_pull_opt(PullArgs& a, const PullSampleArgs& sa, PullGeo g, flo
 
 int pull_partial_stride(int dim) { const PullGeo g = pull_geo(dim); return 4 * g.G * g.NV; }
 int pull_groups_per_block(int dim) { const PullGeo g = pull_geo(dim); return g.G ? kBlock / g.G : 0; }
-
-static PullSampleArgs make_sample_args(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots,
-                                       int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor,
-                                       const kge_pull_lists* out) {
-    PullSampleArgs sa;
-    sa.pairs = (const int4*)pairs; sa.n = n; sa.E = E; sa.bern = bern;
-    sa.slots = (const unsigned long long*)slots; sa.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
-    sa.seed = seed; sa.offset = offset; sa.cursor = cursor;
-    if (out) sa.out = to_lists(out);
-    else { sa.out.pc = sa.out.count = sa.out.bucket = sa.out.head = sa.out.next = nullptr; }
-    return sa;
-}
 
 int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
                      const float* norm_in, float* norm_out, float* const state1[2], float* const state2[2], const int32_t* pairs,

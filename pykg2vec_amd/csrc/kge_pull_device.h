@@ -1,0 +1,86 @@
+// kge_pull_device.h -- pieces shared by the owner-computes training steps (kge_pull.hip: TransE / TransM with the fused dense
+// optimiser; kge_own.hip: the two-phase step of the pointwise models): incidence roles, the per-step sampler lists and the
+// sampler that fills them, float4 row movement.
+#pragma once
+#include "kge_row_kernels.h"
+#include "kge_sampler_device.h"
+
+namespace kge {
+
+constexpr int kRoleH = 0, kRoleT = 1, kRoleR = 2, kRoleC = 3;
+constexpr int kPullCap = 16;   // per-entity bucket of "drawn as corrupting entity" pairs; overflow goes to a linked list
+constexpr int kPcFirstBit = 27;   // pc[i] bit 27: pair i was the FIRST to register with its corrupting entity this step (the entity's
+                                  // owner-by-default when the entity has no work item of its own: sparse optimisers, kge_own.hip)
+
+// per-step sampler output: which pairs drew entity e as their corrupting entity
+struct PullLists {
+    int32_t* pc;       // [B]  per pair: corrupting entity | (tail corrupted) << 24 | (first registrant of the entity) << 27
+    int32_t* count;    // [E]  number of pairs that drew e this step (reset to 0 by e's owner)
+    int32_t* bucket;   // [E * kPullCap] the first kPullCap of them, in arrival (i.e. arbitrary) order
+    int32_t* head;     // [E]  overflow list head (-1: none; reset by e's owner)
+    int32_t* next;     // [B]  overflow list links
+};
+
+struct PullSampleArgs {
+    const int4* pairs;         // batch to sample: (h, r, t, -)
+    int64_t n, E;
+    const float* bern;
+    const unsigned long long* slots;
+    unsigned long long mask, seed, offset;
+    const int64_t* cursor;
+    PullLists out;
+};
+
+// one pair of the sampled batch: draw the corruption (same Philox counters as kge_sample_batch / the fused push kernels:
+// offset + pair index) and register the pair with the corrupting entity
+__device__ __forceinline__ void pull_sample_one(const PullSampleArgs& sa, int64_t i) {
+    const unsigned long long off = sa.cursor ? sa.offset + (unsigned long long)sa.cursor[1] : sa.offset;
+    const int4 p = sa.pairs[i];
+    int64_t nh, nt;
+    corrupt_one(p.x, p.y, p.z, sa.E, sa.bern, sa.slots, sa.mask, sa.seed, off + (unsigned long long)i, nh, nt);
+    const bool tail = nh == p.x;
+    const int c = (int)(tail ? nt : nh);
+    const int pos = atomicAdd(sa.out.count + c, 1);
+    sa.out.pc[i] = c | ((int)tail << 24) | ((pos == 0 ? 1 : 0) << kPcFirstBit);
+    if (pos < kPullCap) sa.out.bucket[(int64_t)c * kPullCap + pos] = (int)i;
+    else sa.out.next[i] = atomicExch(sa.out.head + c, (int)i);
+}
+
+// Rows as float4 per lane: lane gl of a G-lane group holds elements 4*(v*G + gl) .. +3 for v < NV (d % 4 == 0): one
+// 16-byte load / store instruction per lane moves a whole 100-float row with 25 lanes.
+template <int G, int NV>
+__device__ __forceinline__ void load_row4(float4 (&x)[NV], const float* __restrict__ row, int nvec, int gl) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int i = v * G + gl;
+        x[v] = i < nvec ? reinterpret_cast<const float4*>(row)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int G, int NV>
+__device__ __forceinline__ void store_row4(float* __restrict__ row, const float4 (&x)[NV], int nvec, int gl) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int i = v * G + gl;
+        if (i < nvec) reinterpret_cast<float4*>(row)[i] = x[v];
+    }
+}
+static inline PullLists to_lists(const kge_pull_lists* l) {
+    PullLists o;
+    o.pc = l->pc; o.count = l->count; o.bucket = l->bucket; o.head = l->head; o.next = l->next;
+    return o;
+}
+
+static inline PullSampleArgs make_sample_args(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots,
+                                       int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* cursor,
+                                       const kge_pull_lists* out) {
+    PullSampleArgs sa;
+    sa.pairs = (const int4*)pairs; sa.n = n; sa.E = E; sa.bern = bern;
+    sa.slots = (const unsigned long long*)slots; sa.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
+    sa.seed = seed; sa.offset = offset; sa.cursor = cursor;
+    if (out) sa.out = to_lists(out);
+    else { sa.out.pc = sa.out.count = sa.out.bucket = sa.out.head = sa.out.next = nullptr; }
+    return sa;
+}
+
+
+}  // namespace kge

@@ -49,6 +49,11 @@ def bern_table(prob):
     return p32
 
 
+def _next_pow2(x):
+    x = np.asarray(x, dtype=np.int64)
+    return np.where(x <= 1, 1, 1 << np.ceil(np.log2(np.maximum(x, 1))).astype(np.int64))
+
+
 def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8, compact=False):
     """Incidence index of ONE batch for the owner-computes step (csrc/kge_pull.hip): every parameter row (entities first,
     then tot_entity + relation) gets the sorted list of the (pair, role) slots it occupies in the batch -- role 0 = head,
@@ -57,15 +62,24 @@ def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8,
     Item kinds: 0 = the row's only item; 3 = one of 2..groups_per_block items of a row, all placed in consecutive owner
     groups of ONE workgroup (they combine their partial sums through LDS, in segment order); 1 / 2 = first / later item
     of a row with more items than that (partial sums through global memory + the finishing kernel).  Items are laid out
-    in workgroup slots (groups_per_block per workgroup = kge_pull_groups_per_block(dim); padding items have row -1),
-    heaviest workgroups first.
+    in workgroup slots (groups_per_block per workgroup = kge_pull_groups_per_block(dim); padding items have row -1).
+
+    Placement -- THE rule, restated by the device builder (csrc/kge_index.hip: kge_pull_index_build produces the same arrays):
+      region A  rows of 2..groups_per_block items, ordered by (p2 descending, row ascending) with p2 = the item count rounded up to
+                a power of two; a row's items occupy the first slots of an aligned run of p2 slots (descending powers of two
+                keep every run inside one workgroup); the region is rounded up to whole workgroups;
+      region B  every other item (single-item rows, items of rows with more than groups_per_block items), ordered by
+                (weight descending, row ascending, segment ascending) with weight = incidences (+ ~B/E for an entity row's
+                first item, which also walks the row's corrupting-entity draws): the q-th of them takes the q-th OPEN slot --
+                first the slots region A left free, in slot order, then the slots after region A.
+    Heavy items therefore start first and the lightest workgroups run last.
     compact=True lists only the rows that have an incidence and returns, as a sixth value, the bitmap of those rows (int32
     words): the kernel visits every other row implicitly after the listed items (small batches of a big graph touch a small
     part of the tables, and an explicit item per untouched row and batch would dominate the index).
     Returns int32 arrays (pairs [B,4], inc [3B], items [n_slots,4], multi [n_multi,4]) and the number of partial slots."""
     pos = np.asarray(pos, dtype=np.int64).reshape(-1, 3)
     B, E, nrows = len(pos), int(tot_entity), int(tot_entity) + int(tot_relation)
-    GPB = int(groups_per_block)
+    GPB, seg = int(groups_per_block), int(segment)
     i = np.arange(B, dtype=np.int64)
     rows = np.concatenate([pos[:, 0], pos[:, 2], E + pos[:, 1]])
     vals = np.concatenate([4 * i, 4 * i + 1, 4 * i + 2])
@@ -73,69 +87,56 @@ def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8,
     inc = vals[order].astype(np.int32)
     counts = np.bincount(rows, minlength=nrows)
     row_off = np.cumsum(counts) - counts
-    nseg = np.maximum(0 if compact else 1, (counts + segment - 1) // segment)   # compact: untouched rows get no item
-    first = np.cumsum(nseg) - nseg
-    tot = int(nseg.sum())
-    item_row = np.repeat(np.arange(nrows, dtype=np.int64), nseg)
-    seg_idx = np.arange(tot, dtype=np.int64) - np.repeat(first, nseg)
-    beg = row_off[item_row] + seg_idx * segment
-    end = np.minimum(beg + segment, row_off[item_row] + counts[item_row])
-    nseg_i = nseg[item_row]
-    is_global = nseg_i > GPB                                # partial sums through global memory
-    is_local = (nseg_i > 1) & ~is_global                    # partial sums through LDS inside one workgroup
-    slot = np.cumsum(is_global) - 1                         # consecutive per row, in segment order
-    kind = np.where(is_global, np.where(seg_idx == 0, 1, 2), np.where(is_local, 3, 0))
-    info = np.where(is_global, kind | (slot << 2), np.where(is_local, 3 | (seg_idx << 2) | (nseg_i << 6), 0))
-    items = np.stack([item_row, beg, end, info], 1)
-    # ---- placement into workgroup slots: the items of a "local" row must sit in consecutive groups of one workgroup
+    # ---- the row list: every row, or (compact) the rows with an incidence, ascending
+    listed = np.flatnonzero(counts > 0) if compact else np.arange(nrows, dtype=np.int64)
+    beg, cnt = row_off[listed], counts[listed]
+    nseg = np.maximum(1, (cnt + seg - 1) // seg)
+    is_local = (nseg >= 2) & (nseg <= GPB)
+    is_global = nseg > GPB
     c_extra = max(1, B // max(E, 1))                        # entity owners also walk ~B/E corrupting-entity draws
-    weight = (end - beg) + np.where((item_row < E) & (seg_idx == 0), c_extra, 0)
-    local_rows = np.flatnonzero((nseg > 1) & (nseg <= GPB))
-    blocks = []                                             # lists of item indices, at most GPB each
-    open_by_free = {}                                       # free slots -> indices of blocks with that much room
-    for r in local_rows[np.argsort(-nseg[local_rows], kind="stable")]:
-        need = int(nseg[r])
-        members = list(range(int(first[r]), int(first[r]) + need))
-        fit = next((f for f in range(need, GPB) if open_by_free.get(f)), None)
-        if fit is None:
-            blocks.append(members)
-            bi, free = len(blocks) - 1, GPB - need
-        else:
-            bi = open_by_free[fit].pop()
-            blocks[bi].extend(members)
-            free = fit - need
-        if free > 0:
-            open_by_free.setdefault(free, []).append(bi)
-    rest = np.flatnonzero(~is_local)
-    rest = rest[np.argsort(-weight[rest], kind="stable")]             # singles and global-multi items, heaviest first
-    pos_r = 0
-    for bi in range(len(blocks)):                           # top up the workgroups that hold local rows
-        room = GPB - len(blocks[bi])
-        if room and pos_r < len(rest):
-            blocks[bi].extend(rest[pos_r:pos_r + room].tolist())
-            pos_r += room
-    # the bulk: the remaining items, GPB per workgroup in weight order (vectorised -- tens of thousands of workgroups per batch)
-    tail = rest[pos_r:]
-    n_tail_blocks = (len(tail) + GPB - 1) // GPB
-    tail_idx = np.full(n_tail_blocks * GPB, -1, dtype=np.int64)
-    tail_idx[:len(tail)] = tail
-    tail_idx = tail_idx.reshape(n_tail_blocks, GPB)
-    head_idx = np.full((len(blocks), GPB), -1, dtype=np.int64)
-    for bi, b in enumerate(blocks):
-        head_idx[bi, :len(b)] = b
-    all_idx = np.concatenate([head_idx, tail_idx]) if len(blocks) else tail_idx
-    wpad = np.concatenate([weight, [0]])                    # index -1 -> weight 0
-    bw = wpad[all_idx].max(axis=1) if len(all_idx) else np.zeros(0, dtype=np.int64)
-    all_idx = all_idx[np.argsort(-bw, kind="stable")]
-    out = np.full((len(all_idx) * GPB, 4), 0, dtype=np.int64)
+    # ---- region A
+    lu = np.flatnonzero(is_local)
+    p2 = _next_pow2(nseg[lu])
+    lu_order = np.lexsort((listed[lu], -p2))
+    lu, p2 = lu[lu_order], p2[lu_order]
+    a_start = np.cumsum(p2) - p2
+    SA = int(p2.sum())
+    SA_pad = (SA + GPB - 1) // GPB * GPB
+    # free slots of region A, in slot order
+    free_n = p2 - nseg[lu]
+    open_slots = np.concatenate([np.repeat(a_start + nseg[lu], free_n) + (np.arange(int(free_n.sum())) - np.repeat(np.cumsum(free_n) - free_n, free_n)),
+                                 np.arange(SA, SA_pad, dtype=np.int64)]).astype(np.int64)
+    F = len(open_slots)
+    # ---- region B items: (list index u, segment s)
+    nb_items = np.where(is_local, 0, nseg)
+    bu = np.repeat(np.arange(len(listed), dtype=np.int64), nb_items)
+    bs = np.arange(int(nb_items.sum()), dtype=np.int64) - np.repeat(np.cumsum(nb_items) - nb_items, nb_items)
+    b_beg = beg[bu] + bs * seg
+    b_end = np.minimum(b_beg + seg, beg[bu] + cnt[bu])
+    weight = (b_end - b_beg) + np.where((listed[bu] < E) & (bs == 0), c_extra, 0)
+    g_base = np.cumsum(np.where(is_global, nseg, 0)) - np.where(is_global, nseg, 0)     # partial slots, consecutive per row in row order
+    b_info = np.where(is_global[bu], np.where(bs == 0, 1, 2) | ((g_base[bu] + bs) << 2), 0)
+    b_order = np.lexsort((bs, listed[bu], -weight))
+    NB = len(bu)
+    q = np.arange(NB, dtype=np.int64)
+    b_slot = np.where(q < F, open_slots[np.minimum(q, max(F - 1, 0))] if F else 0, SA_pad + (q - F))
+    n_slots = max(SA_pad, SA_pad + max(0, NB - F))
+    n_slots = max(GPB, (n_slots + GPB - 1) // GPB * GPB)
+    out = np.zeros((n_slots, 4), dtype=np.int64)
     out[:, 0] = -1
-    flat = all_idx.reshape(-1)
-    live = flat >= 0
-    out[live] = items[flat[live]]
-    grows = np.flatnonzero(nseg > GPB)
-    multi = np.stack([grows, slot[first[grows]], nseg[grows], np.zeros_like(grows)], 1).astype(np.int32).reshape(-1, 4)
+    if NB:
+        o = b_order
+        out[b_slot] = np.stack([listed[bu][o], b_beg[o], b_end[o], b_info[o]], 1)
+    if len(lu):
+        au = np.repeat(np.arange(len(lu), dtype=np.int64), nseg[lu])
+        a_s = np.arange(int(nseg[lu].sum()), dtype=np.int64) - np.repeat(np.cumsum(nseg[lu]) - nseg[lu], nseg[lu])
+        u = lu[au]
+        a_beg = beg[u] + a_s * seg
+        out[a_start[au] + a_s] = np.stack([listed[u], a_beg, np.minimum(a_beg + seg, beg[u] + cnt[u]), 3 | (a_s << 2) | (nseg[u] << 6)], 1)
+    gu = np.flatnonzero(is_global)
+    multi = np.stack([listed[gu], g_base[gu], nseg[gu], np.zeros_like(gu)], 1).astype(np.int32).reshape(-1, 4)
     pairs = np.concatenate([pos, np.zeros((B, 1), np.int64)], 1).astype(np.int32)
-    res = (pairs, inc, np.ascontiguousarray(out.astype(np.int32)), np.ascontiguousarray(multi), int(is_global.sum()))
+    res = (pairs, inc, np.ascontiguousarray(out.astype(np.int32)), np.ascontiguousarray(multi), int(np.where(is_global, nseg, 0).sum()))
     if compact:
         bits = np.zeros((nrows + 31) // 32 * 32, dtype=np.uint8)
         bits[:nrows] = counts > 0
@@ -146,37 +147,66 @@ def build_pull_batch(pos, tot_entity, tot_relation, segment, groups_per_block=8,
 
 class PullIndex:
     """Device-resident incidence index of every batch of the epoch (a batch is a fixed slice of the generator's
-    permutation, data/generator.py:23-35, so the index is built once)."""
+    permutation, data/generator.py:23-35, so the index is built once).  Two builders with identical output:
+    `PullIndex(batches, ...)` -- numpy, for explicit one-off batches and CPU tests -- and `PullIndex.build_on_device(...)`
+    -- csrc/kge_index.hip, all batches of the epoch order in a handful of launches (the product path)."""
 
     SEGMENT = 8  # incidences per work item: rows with longer lists are cut up and finished by a second small kernel
 
-    def __init__(self, batches, tot_entity, tot_relation, device, segment=None, groups_per_block=8, compact=None):
+    @staticmethod
+    def _segment(segment, groups_per_block):
         import os
-        seg = int(segment or os.environ.get("KGE_PULL_SEGMENT") or self.SEGMENT)   # env: tuning sweeps only
+        seg = int(segment or os.environ.get("KGE_PULL_SEGMENT") or PullIndex.SEGMENT)   # env: tuning sweeps only
         group = 256 // int(groups_per_block)   # lanes of an owner group: one visit descriptor per lane
         if not 1 <= seg <= group:
             raise ValueError("PullIndex: segment %d must be in [1, %d] (incidences of a work item map one per lane)" % (seg, group))
+        return seg
+
+    @staticmethod
+    def _compact_rule(n_pairs, nrows):
+        """A batch touches at most 3 B rows: list only those when that is the smaller index."""
+        return 3 * n_pairs * 2 <= nrows
+
+    def __init__(self, batches, tot_entity, tot_relation, device, segment=None, groups_per_block=8, compact=None):
+        seg = self._segment(segment, groups_per_block)
         nrows = int(tot_entity) + int(tot_relation)
-        if compact is None:   # a batch touches at most 3 B rows: list only those when that is the smaller index
-            compact = bool(batches) and 3 * len(batches[0]) * 2 <= nrows
+        if compact is None:
+            compact = bool(batches) and self._compact_rule(len(batches[0]), nrows)
         self.compact = bool(compact)
+        self.segment, self.built_on = seg, "host"
         built = [build_pull_batch(b, tot_entity, tot_relation, seg, groups_per_block, compact=self.compact) for b in batches]
         self.words = (nrows + 31) // 32
-        self._skip = torch.from_numpy(np.concatenate([x[5] for x in built])).to(device) if (self.compact and built) else None
         self.n_batches = len(built)
         self.batch_size = len(batches[0]) if built else 0
         self.max_slots = max([x[4] for x in built] + [1])
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+        self._views = [tuple(dev(x[k]) for k in range(4)) for x in built]
+        self._skips = [dev(x[5]) for x in built] if self.compact else None
 
-        def cat(k):
-            return torch.from_numpy(np.concatenate([x[k] for x in built])).to(device) if built else None
-
-        self.pairs, self.inc, self.items, self.multi = cat(0), cat(1), cat(2), cat(3)
-        self.item_off = np.concatenate([[0], np.cumsum([len(x[2]) for x in built])]).astype(np.int64)
-        self.multi_off = np.concatenate([[0], np.cumsum([len(x[3]) for x in built])]).astype(np.int64)
+    @classmethod
+    def build_on_device(cls, backend, triples, perm, n_batches, batch_stride, slice_lo, n_pairs, tot_entity, tot_relation,
+                        segment=None, groups_per_block=8, compact=None):
+        """All `n_batches` batches at once on the device: batch b = triples[perm[b * batch_stride + slice_lo + i]], i < n_pairs."""
+        self = cls.__new__(cls)
+        seg = cls._segment(segment, groups_per_block)
+        nrows = int(tot_entity) + int(tot_relation)
+        self.compact = bool(cls._compact_rule(n_pairs, nrows) if compact is None else compact)
+        self.segment, self.built_on = seg, "device"
+        self.words = (nrows + 31) // 32
+        self.n_batches, self.batch_size = int(n_batches), int(n_pairs)
+        out = backend.pull_index_build(triples, perm, batch_stride, slice_lo, n_pairs, n_batches, tot_entity, tot_relation, seg,
+                                       groups_per_block, self.compact)
+        pairs, inc, items, multi, skip, counts = out
+        self._storage = out
+        cnt = counts.cpu().numpy().reshape(-1, 4)      # the one host read of the build: live slots / rows per batch
+        self.max_slots = int(max(1, cnt[:, 2].max())) if len(cnt) else 1
+        self._views = [(pairs[b], inc[b], items[b, :int(cnt[b, 0])], multi[b, :int(cnt[b, 1])]) for b in range(self.n_batches)]
+        self._skips = [skip[b] for b in range(self.n_batches)] if self.compact else None
+        return self
 
     def skip(self, b):
         """Bitmap (int32 words) of the rows batch b lists explicitly, or None when its items cover every row."""
-        return self._skip[b * self.words:(b + 1) * self.words] if self._skip is not None else None
+        return self._skips[b] if self._skips is not None else None
 
     @staticmethod
     def bytes_estimate(n_batches, batch_size, tot_entity, tot_relation):
@@ -186,9 +216,7 @@ class PullIndex:
 
     def batch(self, b):
         """(pairs, inc, items, multi) views of batch b; incidence / pair indices inside are relative to the batch."""
-        B = self.batch_size
-        return (self.pairs[b * B:(b + 1) * B], self.inc[3 * b * B:3 * (b + 1) * B],
-                self.items[self.item_off[b]:self.item_off[b + 1]], self.multi[self.multi_off[b]:self.multi_off[b + 1]])
+        return self._views[b]
 
 
 class StagedIndex:
@@ -305,12 +333,22 @@ class Generator:
         if self._pull_index is None:
             B = self.batch_size
             nb = self.n_train // B
-            pos = self._train_np[self._perm_np[:nb * B]].reshape(nb, B, 3)
+            gpb = self.K.pull_groups_per_block(self.model.hidden_size)
+            per, lo = B, 0
             if self.world_size > 1:   # data-parallel rank: its slice of every batch (the rule of _next_range; B % world == 0)
                 per = (B + self.world_size - 1) // self.world_size
-                pos = pos[:, self.rank * per:(self.rank + 1) * per]
-            self._pull_index = PullIndex(list(pos), self.config.tot_entity, self.config.tot_relation, self.device,
-                                         groups_per_block=self.K.pull_groups_per_block(self.model.hidden_size))
+                lo = self.rank * per
+            import time
+            t0 = time.perf_counter()
+            if hasattr(self.K, "pull_index_build") and self.triples.is_cuda and nb > 0:
+                # the product path: every batch of the epoch order indexed on the device (csrc/kge_index.hip)
+                self._pull_index = PullIndex.build_on_device(self.K, self.triples, self.perm, nb, B, lo, per, self.config.tot_entity,
+                                                             self.config.tot_relation, groups_per_block=gpb)
+            else:   # no device (CPU tests with an injected backend): the numpy restatement of the same rule
+                pos = self._train_np[self._perm_np[:nb * B]].reshape(nb, B, 3)[:, lo:lo + per]
+                self._pull_index = PullIndex(list(pos), self.config.tot_entity, self.config.tot_relation, self.device,
+                                             groups_per_block=gpb)
+            self.pull_index_ms = (time.perf_counter() - t0) * 1e3   # set-up cost of the owner-computes path (host wall, incl. the sync)
         return self._pull_index
 
     def staged_index(self):

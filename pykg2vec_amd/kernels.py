@@ -646,6 +646,33 @@ def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, s
     L.check(L.load().kge_pull_step(*args, _stream()), "kge_pull_step")
 
 
+def pull_index_build(triples, perm, batch_stride, slice_lo, n_pairs, n_batches, tot_entity, tot_relation, segment,
+                     groups_per_block, compact):
+    """kge_pull_index_build: the incidence index of `n_batches` batches of the permutation, built on the device.  Returns
+    (pairs [nb, n, 4], inc [nb, 3n], items [nb, item_cap, 4], multi [nb, multi_cap, 4], skip [nb, words] or None,
+    counts [nb, 4] = {item slots, multi rows, partial slots, listed rows}) -- int32 device tensors at fixed strides."""
+    lib = L.load()
+    dev = triples.device
+    nb, n = int(n_batches), int(n_pairs)
+    item_cap, multi_cap, words = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    ws_bytes = ctypes.c_size_t()
+    L.check(lib.kge_pull_index_geometry(nb, n, int(tot_entity), int(tot_relation), int(segment), int(groups_per_block),
+                                        1 if compact else 0, ctypes.byref(item_cap), ctypes.byref(multi_cap), ctypes.byref(words),
+                                        ctypes.byref(ws_bytes)), "kge_pull_index_geometry")
+    i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    pairs, inc = i32(nb, n, 4), i32(nb, 3 * n)
+    items, multi = i32(nb, item_cap.value, 4), i32(nb, multi_cap.value, 4)
+    skip = i32(nb, words.value) if compact else None
+    counts = i32(nb, 4)
+    ws = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
+    L.check(lib.kge_pull_index_build(_ids(triples, "triples"), _ids(perm, "perm"), int(batch_stride), int(slice_lo), n, nb,
+                                     int(tot_entity), int(tot_relation), int(segment), int(groups_per_block), 1 if compact else 0,
+                                     pairs.data_ptr(), inc.data_ptr(), items.data_ptr(), multi.data_ptr(),
+                                     skip.data_ptr() if skip is not None else None, counts.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     _stream()), "kge_pull_index_build")
+    return pairs, inc, items, multi, skip, counts
+
+
 class PullPlan:
     """struct kge_pull_plan for a (model, index, state) triple: everything that does not change from step to step,
     marshalled once.  `run` enqueues a whole sequence of steps with ONE foreign call (the per-step work is ~35 us of GPU

@@ -10,7 +10,7 @@ CASES = ["transe_l1", "transe_l2", "transh_l1", "transh_l2", "transd_l1", "trans
          "transm_l1", "transm_l2", "cp", "simple", "simple_ignr", "quate", "transr_l1", "transr_l2"]
 ORACLE_NAME = {"transe_l1": "transe", "transe_l2": "transe", "transh_l1": "transh", "transh_l2": "transh",
                "transd_l1": "transd", "transd_l2": "transd", "transm_l1": "transm", "transm_l2": "transm",
-               "transr_l1": "transr", "transr_l2": "transr"}
+               "transr_l1": "transr", "transr_l2": "transr", "simple_ties": "simple"}
 POINTWISE = ("distmult", "complex", "complexn3", "analogy", "cp", "simple", "simple_ignr", "quate")
 # state_dict entries that are parameter tables of the scoring path (QuatE also carries unused fc / bn modules)
 TABLES = {"cp": ("sub_embeddings", "rel_embeddings", "obj_embeddings"),

@@ -187,3 +187,35 @@ def test_gradient_mode_equals_the_atomic_gradient(hip, world, l1, monkeypatch):
     assert np.isclose(K.read_loss(tr.loss_buf).item(), loss_push, rtol=2e-5)
     n = E * D + R * D
     assert torch.allclose(got[:n], want[:n], atol=2e-5, rtol=1e-4), (got[:n] - want[:n]).abs().max().item()
+
+
+@pytest.mark.parametrize("E,R,B,nb,seg,gpb,compact,slice_", [
+    (53, 7, 32, 3, 8, 8, False, None), (53, 7, 64, 2, 2, 8, None, None), (40, 3, 200, 2, 1, 8, False, None),
+    (300, 5, 1000, 2, 8, 4, False, None), (14951, 1345, 4096, 3, 8, 8, None, None), (14951, 1345, 32768, 2, 8, 8, None, None),
+    (14951, 1345, 128, 20, 8, 8, None, None),       # compact: only touched rows listed + bitmap
+    (40943, 11, 5000, 3, 8, 4, None, None),         # C2 shape: relation lists of ~450 incidences -> global partial slots
+    (500, 20, 256, 4, 8, 8, None, (128, 128)),      # a data-parallel rank's slice of every batch
+    (17, 2, 4096, 2, 8, 8, False, None),            # tiny entity set: every row is long
+    (2000, 1, 2048, 1, 16, 16, False, None)])       # one relation, 16-lane owner groups
+def test_device_built_index_equals_the_numpy_one(hip, E, R, B, nb, seg, gpb, compact, slice_):
+    """csrc/kge_index.hip (kge_pull_index_build: keys -> batched bitonic sorts -> row list -> placement) against
+    generator.build_pull_batch, the numpy statement of the same layout rule: identical arrays for every batch."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.generator import PullIndex
+    rng = np.random.default_rng(E * 31 + B)
+    n_train = nb * B + 17
+    train = np.stack([rng.integers(E, size=n_train), rng.integers(R, size=n_train), rng.integers(E, size=n_train)], 1)
+    perm = rng.permutation(n_train)
+    lo, n = slice_ if slice_ is not None else (0, B)
+    host = PullIndex([train[perm[b * B + lo:b * B + lo + n]] for b in range(nb)], E, R, "cpu", segment=seg, groups_per_block=gpb,
+                     compact=compact)
+    devx = PullIndex.build_on_device(K, hip.dev(train), hip.dev(perm), nb, B, lo, n, E, R, segment=seg, groups_per_block=gpb,
+                                     compact=compact)
+    assert devx.compact == host.compact and devx.max_slots == host.max_slots and devx.n_batches == nb and devx.batch_size == n
+    for b in range(nb):
+        for name, a, d in zip(("pairs", "inc", "items", "multi"), host.batch(b), devx.batch(b)):
+            a, d = a.numpy(), d.cpu().numpy()
+            assert a.shape == d.shape, (b, name, a.shape, d.shape)
+            assert np.array_equal(a, d), (b, name, np.flatnonzero((a != d).reshape(len(a), -1).any(1))[:8])
+        if host.compact:
+            assert np.array_equal(host.skip(b).numpy(), devx.skip(b).cpu().numpy())
