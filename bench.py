@@ -272,7 +272,9 @@ def run_extra_config(key, device):
     edt = (time.perf_counter() - t0) / reps
     out = {"workload": c["name"],
            "mode": ("hipGraph replay" if tr._graph is not None else
-                    "eager, staged gradients (no atomics, kge_optimizer_step_staged)" if getattr(tr, "_staged", None) is not None else "eager"),
+                    "eager, staged gradients (no atomics, kge_optimizer_step_staged)" if getattr(tr, "_staged", None) is not None else
+                    "owner-computes, two phases (kge_own_run: k_own_step + k_own_apply per step, no atomics, one native call per epoch)"
+                    if getattr(tr, "_own", None) is not None else "eager"),
            "step_us": dt * 1e6, "scored_triples_per_s": rows / dt,
            "train_algorithmic_GBps_whole_step": rows * c["train_bytes"] / dt / 1e9,
            "train_hbm_frac_whole_step": rows * c["train_bytes"] / dt / 1e9 / HBM_PEAK_GBS,

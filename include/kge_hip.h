@@ -358,6 +358,51 @@ size_t kge_pull_plan_bytes(void);   /* sizeof(kge_pull_plan): lets a binding che
 int kge_pull_run(const kge_pull_plan* plan, int64_t first_batch, int64_t n_steps, int32_t src_half, int32_t cur_list,
                  int32_t lists_ready, int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream);
 
+/* ---- Owner-computes training step of the POINTWISE models, two phases (csrc/kge_own.hip): Generator (data/generator.py:99-158,
+ * neg_rate 1) + Trainer.train_step_pointwise (utils/trainer.py:176-180) + Criterion.pointwise_logistic (utils/criterion.py:31-34)
+ * + get_reg (pointwise.py:190-202,224-238,448-458) + loss.backward() + optimizer.step() (utils/trainer.py:298-299,112-131) for
+ * DistMult (tables ent, rel) and ComplEx / ComplexN3 (ent_re, ent_im, rel_re, rel_im), with no float atomics and bit-reproducible
+ * results.  A bundle = positive i of the batch and its one sampled corruption (the rows kge_sample_batch(layout 1) emits for
+ * neg_rate 1 with the same seed / offset); the per-step lists, the incidence index (pairs / inc / items / multi, built by
+ * kge_pull_index_build with groups_per_block = kge_own_groups_per_block) and the ride-along sampler are those of kge_pull_step.
+ *   kge_own_step   phase 1: one owner group per touched parameter row (an entity owner holds the re and im rows of its entity)
+ *                  re-evaluates the bundles the row occurs in and stores the row's gradient ONCE into m->grads (buffers of the
+ *                  tables' shapes; only touched rows are written, nothing needs clearing); rows cut into several items leave
+ *                  partial sums in `partials` (kge_own_partial_stride floats per slot).  The loss (incl. the regulariser value) is
+ *                  added to the striped accumulators.
+ *   kge_own_apply  phase 2: the dense-semantics optimiser, in place, on every row that has a gradient row / partial list.
+ * `listed`: the compact index's bitmap (kge_pull_batch.dense_skip) or NULL when every row has an item.  dense == 0 (SGD / Adagrad:
+ * a zero dense gradient leaves a row unchanged, so only touched rows are visited): an entity that was only DRAWN this step is
+ * owned by the first pair that drew it (pc bit 27).  dense != 0 (Adam / RMSprop move every row every step): every unlisted row is
+ * an implicit owner.  dim % 4 == 0, dim <= 512. */
+int kge_own_groups_per_block(int32_t model, int32_t dim);
+int kge_own_partial_stride(int32_t model, int32_t dim);
+int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists, const int32_t* items,
+                 int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int32_t dense, float lmbda,
+                 int32_t reg_type, int32_t reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern_prob,
+                 const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
+                 float* loss, void* stream);
+int kge_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
+                  const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* multi,
+                  int64_t n_multi, float* partials, int32_t dense, int32_t optimizer, float lr, int64_t step, void* stream);
+/* A run of consecutive steps enqueued by ONE native call (two launches per step, no host work in between). */
+typedef struct kge_own_plan {
+    kge_model_desc model;                 /* tables = the parameters (updated in place); grads = the gradient row buffers */
+    float* state1[KGE_MAX_TABLES];        /* optimiser state per table (NULL where unused) */
+    float* state2[KGE_MAX_TABLES];
+    kge_pull_lists lists[2];              /* the two sampler list sets */
+    const kge_pull_batch* batches;        /* HOST array of n_batches entries (dense_skip = the `listed` bitmap) */
+    int64_t n_batches;
+    float* partials;
+    int32_t optimizer; float lr; float lmbda; int32_t reg_type;
+    const float* bern_prob; const uint64_t* slots; int64_t n_slots; uint64_t seed;
+    int64_t draws_per_batch;
+    float* loss;
+} kge_own_plan;
+size_t kge_own_plan_bytes(void);
+int kge_own_run(const kge_own_plan* plan, int64_t first_batch, int64_t n_steps, int32_t cur_list, int32_t lists_ready,
+                int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream);
+
 /* ---- The incidence index of kge_pull_step / kge_own_step, built ON THE DEVICE for n_batches batches at once (csrc/kge_index.hip).
  * The reference's per-run set-up of the batch feed is one permutation (data/generator.py:19-35: a batch is a fixed slice of it);
  * the index is this path's own per-run structure over those slices.  Batch b covers the pairs

@@ -64,6 +64,15 @@ class PullPlanC(ctypes.Structure):
                 ("bern_prob", ctypes.c_void_p), ("slots", ctypes.c_void_p), ("n_slots", ctypes.c_int64),
                 ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p)]
 
+class OwnPlanC(ctypes.Structure):
+    """struct kge_own_plan"""
+    _fields_ = [("model", ModelDesc), ("state1", ctypes.c_void_p * KGE_MAX_TABLES), ("state2", ctypes.c_void_p * KGE_MAX_TABLES),
+                ("lists", PullLists * 2), ("batches", ctypes.POINTER(PullBatch)), ("n_batches", ctypes.c_int64),
+                ("partials", ctypes.c_void_p), ("optimizer", ctypes.c_int32), ("lr", ctypes.c_float), ("lmbda", ctypes.c_float),
+                ("reg_type", ctypes.c_int32), ("bern_prob", ctypes.c_void_p), ("slots", ctypes.c_void_p), ("n_slots", ctypes.c_int64),
+                ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p)]
+
+
 class StagedTable(ctypes.Structure):
     """struct kge_staged_table"""
     _fields_ = [("cls", ctypes.c_int32), ("site_a", ctypes.c_int32), ("site_b", ctypes.c_int32), ("dsite", ctypes.c_int32),
@@ -153,6 +162,20 @@ _SIGNATURES = {
                                      ctypes.c_int32, ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
                                      ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                      ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_own_groups_per_block": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
+    "kge_own_partial_stride": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
+    "kge_own_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(PullLists), ctypes.c_void_p,
+                                    ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_float,
+                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p,
+                                    ctypes.c_void_p]),
+    "kge_own_apply": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int64,
+                                     ctypes.c_void_p]),
+    "kge_own_plan_bytes": (ctypes.c_size_t, []),
+    "kge_own_run": (ctypes.c_int, [ctypes.POINTER(OwnPlanC), ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                   ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]),
     "kge_pull_index_geometry": (ctypes.c_int, [ctypes.c_int64] * 4 + [ctypes.c_int32] * 3 + [ctypes.POINTER(ctypes.c_int64)] * 3
                                 + [ctypes.POINTER(ctypes.c_size_t)]),
     "kge_pull_index_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int64] * 6 + [ctypes.c_int32] * 3

@@ -478,6 +478,81 @@ int kge_pull_run(const kge_pull_plan* p, int64_t first_batch, int64_t n_steps, i
     return 0;
 }
 
+/* ---- two-phase owner-computes step of the pointwise models, kge_own.hip */
+int kge_own_groups_per_block(int32_t model, int32_t dim) { return own_groups_per_block(model, dim); }
+int kge_own_partial_stride(int32_t model, int32_t dim) { return own_partial_stride(model, dim); }
+
+int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists, const int32_t* items,
+                 int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int32_t dense, float lmbda,
+                 int32_t reg_type, int32_t reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern_prob,
+                 const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
+                 float* loss, void* stream) {
+    if (validate(m, true, "kge_own_step")) return -1;
+    if (m->model != KGE_DISTMULT && m->model != KGE_COMPLEX) { set_error("kge_own_step: DistMult / ComplEx only (model %d)", m->model); return -1; }
+    if (n_pairs <= 0 || n_items <= 0 || !pairs || !lists_ok(lists) || !items || !inc || !partials || !loss ||
+        reg_type < KGE_REG_NONE || reg_type > KGE_REG_N3_ABS) {
+        set_error("kge_own_step: bad arguments");
+        return -1;
+    }
+    if (next_pairs) {
+        if (next_n < 0 || !lists_ok(next_lists) || next_lists->count == lists->count || (slots && (n_slots & (n_slots - 1)))) {
+            set_error("kge_own_step: the next batch's sampler needs its own list set");
+            return -1;
+        }
+        if (validate_packed_key(m, "kge_own_step")) return -1;
+    }
+    return launch_own_step(m, pairs, n_pairs, lists, items, n_items, listed, inc, partials, dense, lmbda, reg_type, reset_lists,
+                           next_pairs, next_n, bern_prob, slots, n_slots, seed, next_offset, next_lists, loss, (hipStream_t)stream);
+}
+
+int kge_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
+                  const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* multi,
+                  int64_t n_multi, float* partials, int32_t dense, int32_t optimizer, float lr, int64_t step, void* stream) {
+    if (validate(m, true, "kge_own_apply")) return -1;
+    if (m->model != KGE_DISTMULT && m->model != KGE_COMPLEX) { set_error("kge_own_apply: DistMult / ComplEx only (model %d)", m->model); return -1; }
+    if (n_pairs <= 0 || n_items <= 0 || n_multi < 0 || !pairs || !lists || !lists->pc || !items || (n_multi > 0 && (!multi || !partials)) || step < 1) {
+        set_error("kge_own_apply: bad arguments");
+        return -1;
+    }
+    return launch_own_apply(m, state1, state2, pairs, n_pairs, lists, items, n_items, listed, multi, n_multi, partials, dense,
+                            optimizer, lr, step, (hipStream_t)stream);
+}
+
+size_t kge_own_plan_bytes(void) { return sizeof(kge_own_plan); }
+
+int kge_own_run(const kge_own_plan* p, int64_t first_batch, int64_t n_steps, int32_t cur_list, int32_t lists_ready,
+                int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream) {
+    if (!p || !p->batches || n_steps < 0 || first_batch < 0 || first_batch + n_steps > p->n_batches || (cur_list & ~1) ||
+        first_opt_step < 1) {
+        set_error("kge_own_run: bad arguments");
+        return -1;
+    }
+    const int dense = (p->optimizer == KGE_OPT_ADAM || p->optimizer == KGE_OPT_RMSPROP) ? 1 : 0;
+    int cl = cur_list;
+    uint64_t offset = first_offset;
+    for (int64_t k = 0; k < n_steps; ++k) {
+        const kge_pull_batch* b = p->batches + first_batch + k;
+        int rc;
+        if (k == 0 && !lists_ready) {
+            rc = kge_pull_sample(b->pairs, b->n_pairs, p->model.tot_entity, p->bern_prob, p->slots, p->n_slots, p->seed, offset,
+                                 nullptr, &p->lists[cl], stream);
+            if (rc) return rc;
+        }
+        const bool has_next = (k + 1 < n_steps || sample_after_last) && first_batch + k + 1 < p->n_batches;
+        const kge_pull_batch* nb = has_next ? b + 1 : nullptr;
+        rc = kge_own_step(&p->model, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip, b->inc, p->partials,
+                          dense, p->lmbda, p->reg_type, 1, nb ? nb->pairs : nullptr, nb ? nb->n_pairs : 0, p->bern_prob, p->slots,
+                          p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch, nb ? &p->lists[1 - cl] : nullptr, p->loss, stream);
+        if (rc) return rc;
+        rc = kge_own_apply(&p->model, p->state1, p->state2, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip,
+                           b->multi, b->n_multi, p->partials, dense, p->optimizer, p->lr, first_opt_step + k, stream);
+        if (rc) return rc;
+        if (has_next) cl ^= 1;
+        offset += (uint64_t)p->draws_per_batch;
+    }
+    return 0;
+}
+
 int kge_head_1n_forward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
                         float* preds, void* stream) {
     return launch_head_forward(x, batch, dim, ent, tot_entity, bias, preds, (hipStream_t)stream);

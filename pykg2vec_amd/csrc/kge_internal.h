@@ -164,6 +164,17 @@ int launch_pull_sample(const int32_t* pairs, int64_t n, int64_t E, const float* 
 int launch_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n,
                                const kge_pull_lists* out, hipStream_t s);
 
+// kge_own.hip (two-phase owner-computes step of the pointwise models)
+int own_groups_per_block(int model, int dim);
+int own_partial_stride(int model, int dim);
+int launch_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists, const int32_t* items,
+                    int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int dense, float lmbda, int reg_type,
+                    int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern, const uint64_t* slots,
+                    int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss, hipStream_t s);
+int launch_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
+                     const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* multi,
+                     int64_t n_multi, float* partials, int dense, int optimizer, float lr, int64_t step, hipStream_t s);
+
 // kge_eval.hip
 size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n, int64_t tables = 1);
 int launch_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,

@@ -39,92 +39,134 @@ struct OwnArgs {
     OptArgs opt;
 };
 
-// the rows of one visit that the owner does not hold itself
-template <int NT, int NV>
+// Rows in registers: lane gl of a G-lane group holds NE = VEC * NV elements of a row.  VEC = 4 (hidden size % 4 == 0): NV float4
+// per lane, one 16-byte load per float4 (element 4 * (v * G + gl) + c); VEC = 1 (any hidden size): NV dwords per lane (element
+// v * G + gl).  All arithmetic below is per element and does not care.
+template <int VEC, int G, int NV>
+__device__ __forceinline__ void load_row_e(float (&x)[VEC * NV], const float* __restrict__ row, int d, int gl) {
+    if constexpr (VEC == 4) {
+        const int nvec = d >> 2;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = v * G + gl;
+            const float4 q = i < nvec ? reinterpret_cast<const float4*>(row)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[4 * v] = q.x; x[4 * v + 1] = q.y; x[4 * v + 2] = q.z; x[4 * v + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { const int e = v * G + gl; x[v] = e < d ? row[e] : 0.f; }
+    }
+}
+template <int VEC, int G, int NV>
+__device__ __forceinline__ void store_row_e(float* __restrict__ row, const float (&x)[VEC * NV], int d, int gl) {
+    if constexpr (VEC == 4) {
+        const int nvec = d >> 2;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = v * G + gl;
+            if (i < nvec) reinterpret_cast<float4*>(row)[i] = make_float4(x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { const int e = v * G + gl; if (e < d) row[e] = x[v]; }
+    }
+}
+
+// the rows of one visit
+template <int NT, int NE>
 struct OwnRows {
-    float4 hh[NT][NV], tt[NT][NV], cc[NT][NV], rr[NT][NV];
+    float hh[NT][NE], tt[NT][NE], cc[NT][NE], rr[NT][NE];
     int w;   // corrupting entity | tail << 24 | role << 25
 };
 
-template <int NT, int G, int NV>
-__device__ __forceinline__ void load_rows_nt(float4 (&x)[NT][NV], const float* const (&tab)[2], int64_t row, int d, int nvec, int gl) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) load_row4<G, NV>(x[t], tab[t] + row * d, nvec, gl);
+// (table pointers by value: a reference to a kernel-argument array would put the argument struct in scratch; d_eff = 0 turns the
+// loads of a row set that is not needed into zero fills)
+template <int NT, int VEC, int G, int NV>
+__device__ __forceinline__ void load_rows_nt(float (&x)[NT][VEC * NV], const float* t0, const float* t1, int64_t row, int d, int d_eff, int gl) {
+    load_row_e<VEC, G, NV>(x[0], t0 + row * d, d_eff, gl);
+    if constexpr (NT == 2) load_row_e<VEC, G, NV>(x[1], t1 + row * d, d_eff, gl);
 }
 
 // -(score) partial of one lane: sum over its elements of Re(<a, r, conj b>) (ComplEx) or a*r*b (DistMult)
-template <int NT, int NV>
-__device__ __forceinline__ float dot3(const float4 (&a)[NT][NV], const float4 (&r)[NT][NV], const float4 (&b)[NT][NV]) {
+template <int NT, int NE>
+__device__ __forceinline__ float dot3(const float (&a)[NT][NE], const float (&r)[NT][NE], const float (&b)[NT][NE]) {
     float p = 0.f;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-#define KGE_D3(c)                                                                                                       \
-        if constexpr (NT == 1) p = fmaf(a[0][v].c * r[0][v].c, b[0][v].c, p);                                             \
-        else {                                                                                                            \
-            const float ar = a[0][v].c, ai = a[1][v].c, rr_ = r[0][v].c, ri = r[1][v].c, br = b[0][v].c, bi = b[1][v].c;  \
-            p += ar * br * rr_ + ai * bi * rr_ + ar * bi * ri - ai * br * ri;                                             \
+    for (int e = 0; e < NE; ++e) {
+        if constexpr (NT == 1) p = fmaf(a[0][e] * r[0][e], b[0][e], p);
+        else {
+            const float ar = a[0][e], ai = a[1][e], rr_ = r[0][e], ri = r[1][e], br = b[0][e], bi = b[1][e];
+            p += ar * br * rr_ + ai * bi * rr_ + ar * bi * ri - ai * br * ri;
         }
-        KGE_D3(x) KGE_D3(y) KGE_D3(z) KGE_D3(w)
-#undef KGE_D3
     }
     return p;
 }
 
-// g += k * d(-score)/d(position) ; position 0 = head (uses r, b), 1 = tail (uses a, r), 2 = relation (uses a, b)
-template <int NT, int NV>
-__device__ __forceinline__ void add_grad(float4 (&g)[NT][NV], int pos, float k, const float4 (&a)[NT][NV], const float4 (&r)[NT][NV],
-                                         const float4 (&b)[NT][NV]) {
+// g += k * d(-score)/d(position) ; position 0 = head (uses r, b), 1 = tail (uses a, r), 2 = relation (uses a, b).  The position
+// is uniform over the owner group: one branch per visit, not a select per element
+template <int NT, int NE>
+__device__ __forceinline__ void add_grad(float (&g)[NT][NE], int pos, float k, const float (&a)[NT][NE], const float (&r)[NT][NE],
+                                         const float (&b)[NT][NE]) {
+    if (pos == 0) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-#define KGE_AG(c)                                                                                                       \
-        if constexpr (NT == 1) {                                                                                          \
-            const float x1 = pos == 0 ? r[0][v].c : a[0][v].c, x2 = pos == 1 ? r[0][v].c : b[0][v].c;                      \
-            g[0][v].c = fmaf(k, x1 * x2, g[0][v].c);                                                                      \
-        } else {                                                                                                          \
-            const float ar = a[0][v].c, ai = a[1][v].c, rr_ = r[0][v].c, ri = r[1][v].c, br = b[0][v].c, bi = b[1][v].c;  \
-            float gre, gim;                                                                                               \
-            if (pos == 0) { gre = br * rr_ + bi * ri; gim = bi * rr_ - br * ri; }                                         \
-            else if (pos == 1) { gre = ar * rr_ - ai * ri; gim = ai * rr_ + ar * ri; }                                    \
-            else { gre = ar * br + ai * bi; gim = ar * bi - ai * br; }                                                    \
-            g[0][v].c = fmaf(k, gre, g[0][v].c); g[1][v].c = fmaf(k, gim, g[1][v].c);                                     \
+        for (int e = 0; e < NE; ++e) {
+            if constexpr (NT == 1) g[0][e] = fmaf(k, r[0][e] * b[0][e], g[0][e]);
+            else {
+                g[0][e] = fmaf(k, b[0][e] * r[0][e] + b[1][e] * r[1][e], g[0][e]);
+                g[1][e] = fmaf(k, b[1][e] * r[0][e] - b[0][e] * r[1][e], g[1][e]);
+            }
         }
-        KGE_AG(x) KGE_AG(y) KGE_AG(z) KGE_AG(w)
-#undef KGE_AG
+    } else if (pos == 1) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if constexpr (NT == 1) g[0][e] = fmaf(k, a[0][e] * r[0][e], g[0][e]);
+            else {
+                g[0][e] = fmaf(k, a[0][e] * r[0][e] - a[1][e] * r[1][e], g[0][e]);
+                g[1][e] = fmaf(k, a[1][e] * r[0][e] + a[0][e] * r[1][e], g[1][e]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if constexpr (NT == 1) g[0][e] = fmaf(k, a[0][e] * b[0][e], g[0][e]);
+            else {
+                g[0][e] = fmaf(k, a[0][e] * b[0][e] + a[1][e] * b[1][e], g[0][e]);
+                g[1][e] = fmaf(k, a[0][e] * b[1][e] - a[1][e] * b[0][e], g[1][e]);
+            }
+        }
     }
 }
 
 // regulariser of one row set: value partial (sum of x^2 | x^3 | |x|^3 over this lane's elements)
-template <int NT, int NV>
-__device__ __forceinline__ float reg_value(const float4 (&x)[NT][NV], int reg_type) {
+template <int NT, int NE>
+__device__ __forceinline__ float reg_value(const float (&x)[NT][NE], int reg_type) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-#define KGE_RV(c) { const float q = x[t][v].c; s += reg_type == KGE_REG_F2 ? q * q : (reg_type == KGE_REG_N3 ? q * q * q : fabsf(q) * q * q); }
-            KGE_RV(x) KGE_RV(y) KGE_RV(z) KGE_RV(w)
-#undef KGE_RV
+        for (int e = 0; e < NE; ++e) {
+            const float q = x[t][e];
+            s += reg_type == KGE_REG_F2 ? q * q : (reg_type == KGE_REG_N3 ? q * q * q : fabsf(q) * q * q);
         }
     return s;
 }
 // g += k * d reg / d x  (k already carries lmbda / n and the number of occurrences)
-template <int NT, int NV>
-__device__ __forceinline__ void reg_grad(float4 (&g)[NT][NV], const float4 (&x)[NT][NV], float k, int reg_type) {
+template <int NT, int NE>
+__device__ __forceinline__ void reg_grad(float (&g)[NT][NE], const float (&x)[NT][NE], float k, int reg_type) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-#define KGE_RG(c) { const float q = x[t][v].c;                                                                         \
-                    const float dq = reg_type == KGE_REG_F2 ? 2.f * q : (reg_type == KGE_REG_N3 ? 3.f * q * q : 3.f * q * fabsf(q)); \
-                    g[t][v].c = fmaf(k, dq, g[t][v].c); }
-            KGE_RG(x) KGE_RG(y) KGE_RG(z) KGE_RG(w)
-#undef KGE_RG
+        for (int e = 0; e < NE; ++e) {
+            const float q = x[t][e];
+            const float dq = reg_type == KGE_REG_F2 ? 2.f * q : (reg_type == KGE_REG_N3 ? 3.f * q * q : 3.f * q * fabsf(q));
+            g[t][e] = fmaf(k, dq, g[t][e]);
         }
 }
 
-template <int NT, int G, int NV>
+template <int NT, int VEC, int G, int NV>
 __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs sa, float* __restrict__ loss) {
     constexpr int GPB = kBlock / G;
+    constexpr int NE = VEC * NV;
     if ((int)blockIdx.x < a.sample_blocks) {   // leading blocks: the sampler of the NEXT batch rides along (other list set)
         const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
         if (i < sa.n) pull_sample_one(sa, i);
@@ -133,9 +175,9 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
     const int gl = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const int gbase = (threadIdx.x & 63) / G * G;
-    const int d = a.d, nvec = a.d >> 2;
+    const int d = a.d;
     const int64_t item = (int64_t)((int)blockIdx.x - a.sample_blocks) * GPB + grp;
-    __shared__ float4 s_part[GPB][NT * NV * G];
+    __shared__ float s_part[GPB][NT * NE * G];
     __shared__ int4 s_desc[GPB][G];
     float acc = 0.f;
     int4 it = make_int4(-1, 0, 0, 0);
@@ -152,10 +194,13 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
     }
     const int g = it.x;
     const int kind = it.w & 3;
-    float4 X[NT][NV], gs[NT][NV];
+    float X[NT][NE], gs[NT][NE];
     if (g >= 0) {
         const bool is_rel = g >= a.E;
         const int64_t own = is_rel ? g - a.E : g;
+        // the owner's rows: requested first, they depend on nothing but the item
+        if (is_rel) load_rows_nt<NT, VEC, G, NV>(X, a.rel[0], a.rel[1], own, d, d, gl);
+        else load_rows_nt<NT, VEC, G, NV>(X, a.ent[0], a.ent[1], own, d, d, gl);
         const int n_static = it.z - it.y;
         int cnt = 0, nvis = 0;
         int vi = -1, vrole = 0, slot = gl;
@@ -179,50 +224,42 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
             pr.w = (a.lists.pc[vi] & 0x1FFFFFF) | (vrole << 25);
             s_desc[grp][slot] = pr;
         }
-        if (is_rel) load_rows_nt<NT, G, NV>(X, a.rel, own, d, nvec, gl);
-        else load_rows_nt<NT, G, NV>(X, a.ent, own, d, nvec, gl);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int v = 0; v < NV; ++v) gs[t][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = 0; e < NE; ++e) gs[t][e] = 0.f;
 
-        // which of the four row sets a visit needs besides the owner's own one.  P = (h, r, t); N = (h, r, c) when the tail was
-        // corrupted, (c, r, t) otherwise.  An entity owner only needs the partners of the triples it occurs in.
-        auto fetch = [&](int h, int r, int t, int w, OwnRows<NT, NV>& b) {
+        auto fetch = [&](int h, int r, int t, int w, OwnRows<NT, NE>& b) {
             b.w = w;
             const int role = (w >> 25) & 3;
             const bool tail = ((w >> 24) & 1) != 0;
             const int c = w & 0xFFFFFF;
-            const bool needH = role == kRoleR || role == kRoleT || (role == kRoleC && tail);
-            const bool needT = role == kRoleR || role == kRoleH || (role == kRoleC && !tail);
-            const bool needC = role == kRoleR || (role == kRoleH && tail) || (role == kRoleT && !tail);
-            const bool needR = role != kRoleR;
-            if (needH) load_rows_nt<NT, G, NV>(b.hh, a.ent, h, d, nvec, gl);
-            if (needT) load_rows_nt<NT, G, NV>(b.tt, a.ent, t, d, nvec, gl);
-            if (needC) load_rows_nt<NT, G, NV>(b.cc, a.ent, c, d, nvec, gl);
-            if (needR) load_rows_nt<NT, G, NV>(b.rr, a.rel, r, d, nvec, gl);
+            // P = (h, r, t) is evaluated by the owners of h, r, t; N = (h, r, c) | (c, r, t) by the owners of its three rows.  The
+            // owner's own rows are fetched like the others (L1 / L2 hot): the arithmetic below is then the same for every role
+            const bool inP = role != kRoleC;
+            const bool inN = role == kRoleR || role == kRoleC || (role == kRoleH && tail) || (role == kRoleT && !tail);
+            const bool needH = inP || (inN && tail), needT = inP || (inN && !tail), needC = inN;
+            load_rows_nt<NT, VEC, G, NV>(b.hh, a.ent[0], a.ent[1], h, d, needH ? d : 0, gl);
+            load_rows_nt<NT, VEC, G, NV>(b.tt, a.ent[0], a.ent[1], t, d, needT ? d : 0, gl);
+            load_rows_nt<NT, VEC, G, NV>(b.cc, a.ent[0], a.ent[1], c, d, needC ? d : 0, gl);
+            load_rows_nt<NT, VEC, G, NV>(b.rr, a.rel[0], a.rel[1], r, d, d, gl);
         };
-        auto fetch_visit = [&](int v, OwnRows<NT, NV>& b) {
+        auto fetch_visit = [&](int v, OwnRows<NT, NE>& b) {
             const int4 ds = s_desc[grp][v];
             fetch(ds.x, ds.y, ds.z, ds.w, b);
         };
-        auto compute = [&](OwnRows<NT, NV>& b) {
+        auto compute = [&](const OwnRows<NT, NE>& b) {
             const int role = (b.w >> 25) & 3;
             const bool tail = ((b.w >> 24) & 1) != 0;
-            // the owner's rows take their place among the four
-            if (role == kRoleH) { for (int t = 0; t < NT; ++t) for (int v = 0; v < NV; ++v) b.hh[t][v] = X[t][v]; }
-            else if (role == kRoleT) { for (int t = 0; t < NT; ++t) for (int v = 0; v < NV; ++v) b.tt[t][v] = X[t][v]; }
-            else if (role == kRoleC) { for (int t = 0; t < NT; ++t) for (int v = 0; v < NV; ++v) b.cc[t][v] = X[t][v]; }
-            else { for (int t = 0; t < NT; ++t) for (int v = 0; v < NV; ++v) b.rr[t][v] = X[t][v]; }
             const bool inP = role != kRoleC;
             const bool inN = role == kRoleR || role == kRoleC || (role == kRoleH && tail) || (role == kRoleT && !tail);
             float pP = 0.f, pN = 0.f, rs = 0.f;
-            if (inP) pP = dot3<NT, NV>(b.hh, b.rr, b.tt);
-            if (inN) pN = tail ? dot3<NT, NV>(b.hh, b.rr, b.cc) : dot3<NT, NV>(b.cc, b.rr, b.tt);
+            if (inP) pP = dot3<NT, NE>(b.hh, b.rr, b.tt);
+            if (inN) pN = tail ? dot3<NT, NE>(b.hh, b.rr, b.cc) : dot3<NT, NE>(b.cc, b.rr, b.tt);
             const bool reg_on = a.reg_type != KGE_REG_NONE;
             if (role == kRoleR && reg_on)   // the relation owner sees every row of both triples: it accounts for the loss terms
-                rs = reg_value<NT, NV>(b.hh, a.reg_type) + reg_value<NT, NV>(b.tt, a.reg_type) + reg_value<NT, NV>(b.cc, a.reg_type) +
-                     2.f * reg_value<NT, NV>(b.rr, a.reg_type) + (tail ? reg_value<NT, NV>(b.hh, a.reg_type) : reg_value<NT, NV>(b.tt, a.reg_type));
+                rs = reg_value<NT, NE>(b.hh, a.reg_type) + reg_value<NT, NE>(b.tt, a.reg_type) + reg_value<NT, NE>(b.cc, a.reg_type) +
+                     2.f * reg_value<NT, NE>(b.rr, a.reg_type) + (tail ? reg_value<NT, NE>(b.hh, a.reg_type) : reg_value<NT, NE>(b.tt, a.reg_type));
             gsum3<G>(pP, pN, rs);
             const float sP = -pP, sN = -pN;                      // energies
             // loss = mean softplus(y s): y = +1 for P, -1 for N (utils/criterion.py:31-34, utils/trainer.py:178)
@@ -232,12 +269,13 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
             // own position in P and in N (0 head, 1 tail, 2 relation); d s / d row = -(d dot3 / d row)
             const int posP = role == kRoleR ? 2 : role;            // H -> 0, T -> 1 (C: not in P)
             const int posN = role == kRoleR ? 2 : (role == kRoleC ? (tail ? 1 : 0) : role);
-            if (inP) add_grad<NT, NV>(gs, posP, -dP, b.hh, b.rr, b.tt);
-            if (inN) { if (tail) add_grad<NT, NV>(gs, posN, -dN, b.hh, b.rr, b.cc); else add_grad<NT, NV>(gs, posN, -dN, b.cc, b.rr, b.tt); }
-            if (reg_on) reg_grad<NT, NV>(gs, X, a.lmbda * a.inv_n * (float)((inP ? 1 : 0) + (inN ? 1 : 0)), a.reg_type);
+            if (inP) add_grad<NT, NE>(gs, posP, -dP, b.hh, b.rr, b.tt);
+            if (inN) { if (tail) add_grad<NT, NE>(gs, posN, -dN, b.hh, b.rr, b.cc); else add_grad<NT, NE>(gs, posN, -dN, b.cc, b.rr, b.tt); }
+            if (reg_on) reg_grad<NT, NE>(gs, X, a.lmbda * a.inv_n * (float)((inP ? 1 : 0) + (inN ? 1 : 0)), a.reg_type);
         };
+#ifdef KGE_OWN_PIPELINE
         if (nvis > 0) {   // software pipeline: the gathers of visit v+1 are in flight while visit v is evaluated
-            OwnRows<NT, NV> ba, bb;
+            OwnRows<NT, NE> ba, bb;
             fetch_visit(0, ba);
             for (int v = 0; v < nvis; v += 2) {
                 const bool more = v + 1 < nvis;
@@ -249,6 +287,15 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
                 }
             }
         }
+#else
+        // one visit at a time: the rows of a visit are 8 * 800 B at the C2 shape, and a second buffer for software pipelining
+        // costs more resident waves (the latency hiding that works here) than it buys
+        for (int v = 0; v < nvis; ++v) {
+            OwnRows<NT, NE> b;
+            fetch_visit(v, b);
+            compute(b);
+        }
+#endif
         if (cnt > 0 && !fast_c) {   // more drawers than the bucket / the lane group holds: ascending pair order, one at a time
             const int nb = cnt < kPullCap ? cnt : kPullCap;
             int last = -1;
@@ -258,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
                 for (int j = a.lists.head[g]; j >= 0; j = a.lists.next[j]) if (j > last && j < best) best = j;
                 if (best == 0x7FFFFFFF) break;
                 const int4 p2 = a.pairs[best];
-                OwnRows<NT, NV> b;
+                OwnRows<NT, NE> b;
                 fetch(p2.x, p2.y, p2.z, (a.lists.pc[best] & 0x1FFFFFF) | (kRoleC << 25), b);
                 compute(b);
                 last = best;
@@ -270,18 +317,18 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
         }
         if (kind == 0) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) store_row4<G, NV>((is_rel ? a.g_rel[t] : a.g_ent[t]) + own * d, gs[t], nvec, gl);
+            for (int t = 0; t < NT; ++t) store_row_e<VEC, G, NV>((is_rel ? a.g_rel[t] : a.g_ent[t]) + own * d, gs[t], d, gl);
         } else if (kind == 3) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int v = 0; v < NV; ++v) s_part[grp][(t * NV + v) * G + gl] = gs[t][v];
+                for (int e = 0; e < NE; ++e) s_part[grp][(t * NE + e) * G + gl] = gs[t][e];
         } else {
-            float4* out = reinterpret_cast<float4*>(a.partials) + (int64_t)(it.w >> 2) * (NT * NV * G);
+            float* out = a.partials + (int64_t)(it.w >> 2) * (NT * NE * G);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int v = 0; v < NV; ++v) out[(t * NV + v) * G + gl] = gs[t][v];
+                for (int e = 0; e < NE; ++e) out[(t * NE + e) * G + gl] = gs[t][e];
         }
     }
     __syncthreads();
@@ -293,32 +340,31 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const float4 p = s_part[grp + m][(t * NV + v) * G + gl];
-                    gs[t][v].x += p.x; gs[t][v].y += p.y; gs[t][v].z += p.z; gs[t][v].w += p.w;
-                }
+                for (int e = 0; e < NE; ++e) gs[t][e] += s_part[grp + m][(t * NE + e) * G + gl];
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) store_row4<G, NV>((is_rel ? a.g_rel[t] : a.g_ent[t]) + own * d, gs[t], nvec, gl);
+        for (int t = 0; t < NT; ++t) store_row_e<VEC, G, NV>((is_rel ? a.g_rel[t] : a.g_ent[t]) + own * d, gs[t], d, gl);
     }
     block_accumulate_loss<G>(acc, gl, loss);
 }
 
 // phase 2: the optimiser on every row that has a gradient row (or a list of partial sums)
-template <int OPT, int NT, int G, int NV>
+template <int OPT, int NT, int VEC, int G, int NV>
 __global__ __launch_bounds__(kBlock) void k_own_apply(OwnArgs a) {
     constexpr int GPB = kBlock / G;
+    constexpr int NE = VEC * NV;
     const int gl = threadIdx.x % G;
     const int64_t unit = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
-    const int d = a.d, nvec = a.d >> 2;
+    const int d = a.d;
     int g = -1, slot0 = 0, nslots = 0;
-    if (unit < a.n_items) {
-        const int4 it = a.items[unit];
+    // rows cut into many items come first (their partial lists are the long chains of this launch), then one unit per item
+    if (unit < a.n_multi) {
+        const int4 row = a.multi[unit];
+        g = row.x; slot0 = row.y; nslots = row.z;
+    } else if (unit < a.n_multi + a.n_items) {
+        const int4 it = a.items[unit - a.n_multi];
         const int kind = it.w & 3;
         if (it.x >= 0 && (kind == 0 || (kind == 3 && ((it.w >> 2) & 15) == 0))) g = it.x;
-    } else if (unit < a.n_items + a.n_multi) {
-        const int4 row = a.multi[unit - a.n_items];
-        g = row.x; slot0 = row.y; nslots = row.z;
     } else if (a.listed != nullptr) {
         const int64_t j = unit - a.n_items - a.n_multi;
         if (a.dense) {
@@ -332,63 +378,87 @@ __global__ __launch_bounds__(kBlock) void k_own_apply(OwnArgs a) {
     if (g < 0) return;
     const bool is_rel = g >= a.E;
     const int64_t off = (int64_t)(is_rel ? g - a.E : g) * d;
+    float gv[NT][NE], P[NT][NE], M1[NT][NE], M2[NT][NE];
+    // parameter and state rows first: they depend on nothing but the row id
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float* const p = const_cast<float*>(is_rel ? a.rel[t] : a.ent[t]) + off;
-        float* const s1 = (is_rel ? a.s1_rel[t] : a.s1_ent[t]);
-        float* const s2 = (is_rel ? a.s2_rel[t] : a.s2_ent[t]);
-        float4 gv[NV], P[NV], M1[NV], M2[NV];
-        if (nslots > 0) {   // rows cut into several items: partial sums added in segment order
+        load_row_e<VEC, G, NV>(P[t], (is_rel ? a.rel[t] : a.ent[t]) + off, d, gl);
+        if constexpr (OPT != KGE_OPT_SGD) load_row_e<VEC, G, NV>(M1[t], (is_rel ? a.s1_rel[t] : a.s1_ent[t]) + off, d, gl);
+        if constexpr (OPT == KGE_OPT_ADAM) load_row_e<VEC, G, NV>(M2[t], (is_rel ? a.s2_rel[t] : a.s2_ent[t]) + off, d, gl);
+    }
+    if (nslots > 0) {   // partial sums added in segment order, eight slots in flight
 #pragma unroll
-            for (int v = 0; v < NV; ++v) gv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s = 0; s < nslots; ++s) {
-                const float4* in = reinterpret_cast<const float4*>(a.partials) + (int64_t)(slot0 + s) * (NT * NV * G);
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const float4 q = in[(t * NV + v) * G + gl];
-                    gv[v].x += q.x; gv[v].y += q.y; gv[v].z += q.z; gv[v].w += q.w;
-                }
-            }
-        } else {
-            load_row4<G, NV>(gv, (is_rel ? a.g_rel[t] : a.g_ent[t]) + off, nvec, gl);
+            for (int e = 0; e < NE; ++e) gv[t][e] = 0.f;
+        const float* base = a.partials + (int64_t)slot0 * (NT * NE * G);
+        int s = 0;
+        for (; s + 4 <= nslots; s += 4) {
+            float q[4][NT][NE];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) q[u][t][e] = base[(int64_t)(s + u) * (NT * NE * G) + (t * NE + e) * G + gl];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) gv[t][e] += q[u][t][e];
         }
-        load_row4<G, NV>(P, p, nvec, gl);
-        if constexpr (OPT != KGE_OPT_SGD) load_row4<G, NV>(M1, s1 + off, nvec, gl);
-        if constexpr (OPT == KGE_OPT_ADAM) load_row4<G, NV>(M2, s2 + off, nvec, gl);
+        for (; s < nslots; ++s)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-#define KGE_UP(c) { float m1 = 0.f, m2 = 0.f;                                                        \
-                    if constexpr (OPT != KGE_OPT_SGD) m1 = M1[v].c;                                    \
-                    if constexpr (OPT == KGE_OPT_ADAM) m2 = M2[v].c;                                   \
-                    opt_update<OPT>(P[v].c, gv[v].c, m1, m2, a.opt);                                   \
-                    if constexpr (OPT != KGE_OPT_SGD) M1[v].c = m1;                                    \
-                    if constexpr (OPT == KGE_OPT_ADAM) M2[v].c = m2; }
-            KGE_UP(x) KGE_UP(y) KGE_UP(z) KGE_UP(w)
-#undef KGE_UP
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) gv[t][e] += base[(int64_t)s * (NT * NE * G) + (t * NE + e) * G + gl];
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) load_row_e<VEC, G, NV>(gv[t], (is_rel ? a.g_rel[t] : a.g_ent[t]) + off, d, gl);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            float m1 = 0.f, m2 = 0.f;
+            if constexpr (OPT != KGE_OPT_SGD) m1 = M1[t][e];
+            if constexpr (OPT == KGE_OPT_ADAM) m2 = M2[t][e];
+            opt_update<OPT>(P[t][e], gv[t][e], m1, m2, a.opt);
+            if constexpr (OPT != KGE_OPT_SGD) M1[t][e] = m1;
+            if constexpr (OPT == KGE_OPT_ADAM) M2[t][e] = m2;
         }
-        store_row4<G, NV>(p, P, nvec, gl);
-        if constexpr (OPT != KGE_OPT_SGD) store_row4<G, NV>(s1 + off, M1, nvec, gl);
-        if constexpr (OPT == KGE_OPT_ADAM) store_row4<G, NV>(s2 + off, M2, nvec, gl);
+        store_row_e<VEC, G, NV>(const_cast<float*>(is_rel ? a.rel[t] : a.ent[t]) + off, P[t], d, gl);
+        if constexpr (OPT != KGE_OPT_SGD) store_row_e<VEC, G, NV>((is_rel ? a.s1_rel[t] : a.s1_ent[t]) + off, M1[t], d, gl);
+        if constexpr (OPT == KGE_OPT_ADAM) store_row_e<VEC, G, NV>((is_rel ? a.s2_rel[t] : a.s2_ent[t]) + off, M2[t], d, gl);
     }
 }
 
 // ------------------------------------------------------------------ host side
-struct OwnGeo { int NT, G, NV; };
+struct OwnGeo { int NT, VEC, G, NV; };
 static OwnGeo own_geo(int model, int dim) {
-    OwnGeo g{0, 0, 0};
-    if (dim <= 0 || (dim & 3) || dim > 512) return g;
+    OwnGeo g{0, 0, 0, 0};
+    if (dim <= 0 || dim > 512) return g;
     g.NT = model == KGE_COMPLEX ? 2 : (model == KGE_DISTMULT ? 1 : 0);
     if (!g.NT) return g;
-    const int nvec = dim >> 2;
-    if (nvec <= 32) { g.G = 32; g.NV = 1; }
-    else if (nvec <= 64) { g.G = 64; g.NV = 1; }
-    else { g.G = 64; g.NV = 2; }
+    if ((dim & 3) == 0) {   // rows move as float4
+        const int nvec = dim >> 2;
+        g.VEC = 4;
+        if (nvec <= 32) { g.G = 32; g.NV = 1; }
+        else if (nvec <= 64) { g.G = 64; g.NV = 1; }
+        else { g.G = 64; g.NV = 2; }
+    } else {                // any other hidden size: one dword per element
+        g.VEC = 1;
+        if (dim <= 128) { g.G = 32; g.NV = 4; }
+        else if (dim <= 256) { g.G = 64; g.NV = 4; }
+        else { g.G = 64; g.NV = 8; }
+    }
     return g;
 }
 
 static int fill_own_args(const kge_model_desc* m, float* const* state1, float* const* state2, OwnArgs* a, OwnGeo* geo, const char* who) {
     *geo = own_geo(m->model, m->dim);
-    if (!geo->G) { set_error("%s: DistMult / ComplEx with a hidden size that is a multiple of 4 and at most 512 (model %d, dim %d)", who, m->model, m->dim); return -1; }
+    if (!geo->G) { set_error("%s: DistMult / ComplEx with a hidden size of at most 512 (model %d, dim %d)", who, m->model, m->dim); return -1; }
     const int NT = geo->NT;
     for (int t = 0; t < 2; ++t) {
         const bool on = t < NT;
@@ -397,7 +467,7 @@ static int fill_own_args(const kge_model_desc* m, float* const* state1, float* c
         a->s1_ent[t] = (on && state1) ? state1[t] : nullptr; a->s1_rel[t] = (on && state1) ? state1[NT + t] : nullptr;
         a->s2_ent[t] = (on && state2) ? state2[t] : nullptr; a->s2_rel[t] = (on && state2) ? state2[NT + t] : nullptr;
         if (on && (!a->ent[t] || !a->rel[t] || !a->g_ent[t] || !a->g_rel[t])) { set_error("%s: tables / gradient row buffers missing", who); return -1; }
-        if (on && ((((uintptr_t)a->ent[t] | (uintptr_t)a->rel[t] | (uintptr_t)a->g_ent[t] | (uintptr_t)a->g_rel[t]) & 15))) {
+        if (on && geo->VEC == 4 && ((((uintptr_t)a->ent[t] | (uintptr_t)a->rel[t] | (uintptr_t)a->g_ent[t] | (uintptr_t)a->g_rel[t]) & 15))) {
             set_error("%s: tables and gradient buffers must be 16-byte aligned", who); return -1;
         }
     }
@@ -405,13 +475,13 @@ static int fill_own_args(const kge_model_desc* m, float* const* state1, float* c
     return 0;
 }
 
-#define KGE_OWN_GEO(BODY)                                                                          \
-    if (geo.NT == 1 && geo.G == 32) { constexpr int NT = 1, G = 32, NV = 1; BODY }                  \
-    else if (geo.NT == 1 && geo.NV == 1) { constexpr int NT = 1, G = 64, NV = 1; BODY }            \
-    else if (geo.NT == 1) { constexpr int NT = 1, G = 64, NV = 2; BODY }                           \
-    else if (geo.G == 32) { constexpr int NT = 2, G = 32, NV = 1; BODY }                           \
-    else if (geo.NV == 1) { constexpr int NT = 2, G = 64, NV = 1; BODY }                           \
-    else { constexpr int NT = 2, G = 64, NV = 2; BODY }
+#define KGE_OWN_CASE(NT_, VEC_, G_, NV_, ...)                                                                      \
+    if (geo.NT == NT_ && geo.VEC == VEC_ && geo.G == G_ && geo.NV == NV_) { constexpr int NT = NT_, VEC = VEC_, G = G_, NV = NV_; __VA_ARGS__ }
+#define KGE_OWN_GEO(...)                                                                                            \
+    KGE_OWN_CASE(1, 4, 32, 1, __VA_ARGS__) KGE_OWN_CASE(1, 4, 64, 1, __VA_ARGS__) KGE_OWN_CASE(1, 4, 64, 2, __VA_ARGS__)  \
+    KGE_OWN_CASE(2, 4, 32, 1, __VA_ARGS__) KGE_OWN_CASE(2, 4, 64, 1, __VA_ARGS__) KGE_OWN_CASE(2, 4, 64, 2, __VA_ARGS__)  \
+    KGE_OWN_CASE(1, 1, 32, 4, __VA_ARGS__) KGE_OWN_CASE(1, 1, 64, 4, __VA_ARGS__) KGE_OWN_CASE(1, 1, 64, 8, __VA_ARGS__)  \
+    KGE_OWN_CASE(2, 1, 32, 4, __VA_ARGS__) KGE_OWN_CASE(2, 1, 64, 4, __VA_ARGS__) KGE_OWN_CASE(2, 1, 64, 8, __VA_ARGS__)
 
 static int64_t own_extra_units(const OwnArgs& a) { return a.listed ? (a.dense ? a.n_rows : a.n_pairs) : 0; }
 
@@ -432,7 +502,7 @@ int launch_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pai
     const int64_t units = n_items + own_extra_units(a);
     KGE_OWN_GEO({
         const int64_t blocks = (units + kBlock / G - 1) / (kBlock / G) + a.sample_blocks;
-        hipLaunchKernelGGL((k_own_step<NT, G, NV>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, sa, loss);
+        hipLaunchKernelGGL((k_own_step<NT, VEC, G, NV>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, sa, loss);
     })
     return check_launch("k_own_step");
 }
@@ -442,7 +512,7 @@ static int launch_own_apply_opt(OwnArgs& a, OwnGeo geo, hipStream_t s) {
     const int64_t units = a.n_items + a.n_multi + own_extra_units(a);
     KGE_OWN_GEO({
         const int64_t blocks = (units + kBlock / G - 1) / (kBlock / G);
-        hipLaunchKernelGGL((k_own_apply<OPT, NT, G, NV>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((k_own_apply<OPT, NT, VEC, G, NV>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
     })
     return check_launch("k_own_apply");
 }
@@ -473,6 +543,6 @@ int launch_own_apply(const kge_model_desc* m, float* const* state1, float* const
 }
 
 int own_groups_per_block(int model, int dim) { const OwnGeo g = own_geo(model, dim); return g.G ? kBlock / g.G : 0; }
-int own_partial_stride(int model, int dim) { const OwnGeo g = own_geo(model, dim); return g.G ? 4 * g.NT * g.NV * g.G : 0; }
+int own_partial_stride(int model, int dim) { const OwnGeo g = own_geo(model, dim); return g.G ? g.NT * g.VEC * g.NV * g.G : 0; }
 
 }  // namespace kge

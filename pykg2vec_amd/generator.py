@@ -328,12 +328,17 @@ class Generator:
         self._batch_idx = 0
         self._draws = 0  # Philox counter offset: unique per generated negative over the whole run
 
-    def pull_index(self):
-        """Incidence index of every FULL batch of the permutation (built on first use)."""
+    def pull_index(self, groups_per_block=None, compact=None):
+        """Incidence index of every FULL batch of the permutation (built on first use).  groups_per_block: owner groups per
+        workgroup of the consuming kernel (default: kge_pull_step's); compact: force / forbid the touched-rows-only form."""
+        key = (groups_per_block, compact)
+        if self._pull_index is not None and getattr(self, "_pull_index_key", key) != key:
+            self._pull_index = None
         if self._pull_index is None:
+            self._pull_index_key = key
             B = self.batch_size
             nb = self.n_train // B
-            gpb = self.K.pull_groups_per_block(self.model.hidden_size)
+            gpb = groups_per_block or self.K.pull_groups_per_block(self.model.hidden_size)
             per, lo = B, 0
             if self.world_size > 1:   # data-parallel rank: its slice of every batch (the rule of _next_range; B % world == 0)
                 per = (B + self.world_size - 1) // self.world_size
@@ -343,11 +348,11 @@ class Generator:
             if hasattr(self.K, "pull_index_build") and self.triples.is_cuda and nb > 0:
                 # the product path: every batch of the epoch order indexed on the device (csrc/kge_index.hip)
                 self._pull_index = PullIndex.build_on_device(self.K, self.triples, self.perm, nb, B, lo, per, self.config.tot_entity,
-                                                             self.config.tot_relation, groups_per_block=gpb)
+                                                             self.config.tot_relation, groups_per_block=gpb, compact=compact)
             else:   # no device (CPU tests with an injected backend): the numpy restatement of the same rule
                 pos = self._train_np[self._perm_np[:nb * B]].reshape(nb, B, 3)[:, lo:lo + per]
                 self._pull_index = PullIndex(list(pos), self.config.tot_entity, self.config.tot_relation, self.device,
-                                             groups_per_block=gpb)
+                                             groups_per_block=gpb, compact=compact)
             self.pull_index_ms = (time.perf_counter() - t0) * 1e3   # set-up cost of the owner-computes path (host wall, incl. the sync)
         return self._pull_index
 

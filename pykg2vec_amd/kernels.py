@@ -718,6 +718,91 @@ class PullPlan:
             L.check(rc, "kge_pull_run")
 
 
+# ---------------------------------------------------------------------------- two-phase owner-computes step (pointwise models)
+def own_groups_per_block(model_name, dim):
+    return int(L.load().kge_own_groups_per_block(MODEL_IDS[model_name], int(dim)))
+
+
+def own_partial_stride(model_name, dim):
+    return int(L.load().kge_own_partial_stride(MODEL_IDS[model_name], int(dim)))
+
+
+def _ptr_array(tensors, n=L.KGE_MAX_TABLES):
+    arr = (ctypes.c_void_p * n)()
+    for i, t in enumerate(tensors or ()):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def own_step(desc, pairs, lists, items, listed, inc, partials, dense, lmbda, reg_type, loss_buf, reset_lists=True, sample_next=None):
+    """Phase 1 (kge_own_step): gradient rows of every touched parameter row into desc.grads, no atomics."""
+    if sample_next is not None:
+        npairs, bern, slots, seed, noff, nlists = sample_next
+        nx = (_i32(npairs, "next_pairs"), npairs.shape[0], _dev(bern, torch.float32, "bern_prob") if bern is not None else None,
+              ctypes.c_void_p(slots.data_ptr()) if slots is not None else None, slots.numel() if slots is not None else 0,
+              int(seed) & (2 ** 64 - 1), int(noff) & (2 ** 64 - 1), ctypes.byref(nlists.c))
+    else:
+        nx = (None, 0, None, None, 0, 0, 0, None)
+    L.check(L.load().kge_own_step(ctypes.byref(desc), _i32(pairs, "pairs"), pairs.shape[0], ctypes.byref(lists.c), _i32(items, "items"),
+                                  items.shape[0], _i32(listed, "listed") if listed is not None else None, _i32(inc, "inc"),
+                                  _dev(partials, torch.float32, "partials"), 1 if dense else 0, float(lmbda), int(reg_type),
+                                  1 if reset_lists else 0, *nx, _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_own_step")
+
+
+def own_apply(desc, state1, state2, pairs, lists, items, listed, multi, partials, dense, optimizer, lr, step):
+    """Phase 2 (kge_own_apply): the optimiser, in place, on the rows phase 1 produced gradients for."""
+    s1, s2 = _ptr_array(state1), _ptr_array(state2)
+    n_multi = multi.shape[0] if multi is not None else 0
+    L.check(L.load().kge_own_apply(ctypes.byref(desc), ctypes.addressof(s1) if state1 is not None else None,
+                                   ctypes.addressof(s2) if state2 is not None else None, _i32(pairs, "pairs"), pairs.shape[0],
+                                   ctypes.byref(lists.c), _i32(items, "items"), items.shape[0],
+                                   _i32(listed, "listed") if listed is not None else None, _i32(multi, "multi") if n_multi else None,
+                                   n_multi, _dev(partials, torch.float32, "partials"), 1 if dense else 0, OPTIMIZER_IDS[optimizer],
+                                   float(lr), int(step), _stream()), "kge_own_apply")
+
+
+class OwnPlan:
+    """struct kge_own_plan: everything of the two-phase step that does not change between steps, marshalled once; `run` enqueues
+    a whole sequence of steps (two launches each) with ONE foreign call."""
+
+    def __init__(self, desc, state1, state2, lists, index, partials, optimizer, lr, lmbda, reg_type, loss_buf, bern, slots, seed,
+                 draws_per_batch):
+        self.keep = (desc, state1, state2, lists, index, partials, loss_buf, bern, slots)
+        c = L.OwnPlanC()
+        ctypes.memmove(ctypes.byref(c.model), ctypes.byref(desc), ctypes.sizeof(L.ModelDesc))
+        for i, t in enumerate(state1 or ()):
+            c.state1[i] = t.data_ptr() if t is not None else None
+        for i, t in enumerate(state2 or ()):
+            c.state2[i] = t.data_ptr() if t is not None else None
+        for half in (0, 1):
+            c.lists[half] = lists[half].c
+        self.batches = (L.PullBatch * index.n_batches)()
+        for b in range(index.n_batches):
+            pairs, inc, items, multi = index.batch(b)
+            skip = index.skip(b)
+            self.batches[b] = L.PullBatch(pairs.data_ptr(), items.data_ptr(), items.shape[0],
+                                          skip.data_ptr() if skip is not None else None, inc.data_ptr(),
+                                          multi.data_ptr() if multi.shape[0] else None, multi.shape[0], pairs.shape[0])
+        c.batches = ctypes.cast(self.batches, ctypes.POINTER(L.PullBatch))
+        c.n_batches = index.n_batches
+        c.partials = partials.data_ptr()
+        c.optimizer, c.lr, c.lmbda, c.reg_type = OPTIMIZER_IDS[optimizer], float(lr), float(lmbda), int(reg_type)
+        c.bern_prob = bern.data_ptr() if bern is not None else None
+        c.slots = slots.data_ptr() if slots is not None else None
+        c.n_slots = slots.numel() if slots is not None else 0
+        c.seed = int(seed) & (2 ** 64 - 1)
+        c.draws_per_batch = int(draws_per_batch)
+        c.loss = loss_buf.data_ptr()
+        self.c = c
+        self.fn = L.load().kge_own_run
+
+    def run(self, first_batch, n_steps, cur_list, lists_ready, first_opt_step, first_offset, sample_after_last):
+        rc = self.fn(ctypes.byref(self.c), int(first_batch), int(n_steps), int(cur_list), 1 if lists_ready else 0,
+                     int(first_opt_step), int(first_offset) & (2 ** 64 - 1), 1 if sample_after_last else 0, _stream())
+        if rc:
+            L.check(rc, "kge_own_run")
+
+
 # ---------------------------------------------------------------------------- 1-N scoring head (projection models)
 def _f32(t, what):
     return _dev(t, torch.float32, what)

@@ -430,6 +430,110 @@ class Trainer:
         ps.cur = 1
         ps.sync_out()
 
+    # ------------------------------------------------------------------ two-phase owner-computes step: DistMult / ComplEx
+    def _own_ok(self):
+        """DistMult / ComplEx(N3) + pointwise logistic with neg_rate 1 on one GPU: the whole step without float atomics in two
+        launches (csrc/kge_own.hip: gradient rows by their owners, then the in-place optimiser on the touched rows), the epoch
+        enqueued by one native call.  KGE_PW_PULL=0 / 1 overrides."""
+        m = self.model
+        if not (self.K is K and not self.distributed and m.kernel_name in ("distmult", "complex")
+                and m.training_strategy == TrainingStrategy.POINTWISE_BASED and int(self.config.neg_rate) == 1
+                and m.hidden_size % 4 == 0 and m.hidden_size <= 512
+                and len({p.weight.shape[1] for p in m.parameter_list}) == 1
+                and m.kernel_reg_type() in (0, 1, 2, 3)
+                and self.generator is not None and self.generator.n_train >= self.config.batch_size):
+            return False
+        if self.switches["pw_pull"] is not None:
+            return self.switches["pw_pull"]
+        if self.switches["staged"] is not None:    # an explicit KGE_STAGED=0 / 1 asks for the atomic / staged A/B pair
+            return False
+        # Owners re-evaluate every bundle their row occurs in: that pays while a batch touches the tables sparsely (C2: 1.4
+        # bundles per touched row, 75 vs 114 us per step) and loses once every row collects many incidences (DistMult FB15k
+        # B = 32768: 6.6 per row, 115 vs 99 us).  The rule is the compact-index rule: a batch lists at most half of the rows.
+        from .generator import PullIndex
+        return PullIndex._compact_rule(int(self.config.batch_size), int(self.config.tot_entity) + int(self.config.tot_relation))
+
+    def _own_dense(self):
+        return self.config.optimizer in ("adam", "rms")   # optimisers that move every row every step
+
+    def _own_state(self):
+        gen, cfg, flat = self.generator, self.config, self.flat
+        name = self.model.kernel_name
+        # sparse optimisers only ever visit touched rows: always the compact (touched rows + bitmap) index
+        idx = gen.pull_index(groups_per_block=K.own_groups_per_block(name, self.model.hidden_size),
+                             compact=None if self._own_dense() else True)
+        st = getattr(self, "_own", None)
+        if st is None or st["index"] is not idx:
+            dev = flat.param.device
+            gbuf = torch.empty_like(flat.param)      # gradient rows (only the touched ones are ever written / read)
+            off = [v.data_ptr() - flat.param.data_ptr() for v in flat.views]
+            view = lambda buf: [buf[o // 4:o // 4 + v.numel()].view_as(v) for o, v in zip(off, flat.views)]
+            desc = K.make_desc(name, flat.views, view(gbuf), tot_entity=cfg.tot_entity, tot_relation=cfg.tot_relation,
+                               **self.model.desc_kwargs())
+            s1 = view(flat.state1) if flat.state1 is not None else None
+            s2 = view(flat.state2) if flat.state2 is not None else None
+            lists = [K.PullListSet(idx.batch_size, cfg.tot_entity, dev) for _ in range(2)]
+            partials = torch.empty(max(1, idx.max_slots) * K.own_partial_stride(name, self.model.hidden_size), dtype=torch.float32, device=dev)
+            plan = K.OwnPlan(desc, s1, s2, lists, idx, partials, cfg.optimizer, cfg.learning_rate, self.model.kernel_lmbda(),
+                             self.model.kernel_reg_type(), self.loss_buf, gen.bern, gen.slots, gen.seed, idx.batch_size * gen.neg_rate)
+            st = self._own = dict(index=idx, gbuf=gbuf, desc=desc, s1=s1, s2=s2, lists=lists, partials=partials, plan=plan,
+                                  cur_list=0, ready=None)
+        return st
+
+    def _own_steps(self, n_steps):
+        """The next n_steps steps of the current epoch, enqueued by one native call (kge_own_run)."""
+        if n_steps <= 0:
+            return
+        st = self._own_state()
+        gen, idx = self.generator, st["index"]
+        B = idx.batch_size
+        first = gen._batch_idx
+        if gen._pending < n_steps or first + n_steps > idx.n_batches:
+            raise StopIteration
+        offset = gen._draws
+        gen._batch_idx += n_steps
+        gen._pending -= n_steps
+        gen._draws += n_steps * B * gen.neg_rate
+        ready = st["ready"] == (first, offset)
+        if not ready and st["ready"] is not None:   # a sampler rode along for a batch that is not the next one: discard
+            st["lists"][st["cur_list"]].clear()
+        after = gen._pending > 0 and first + n_steps < idx.n_batches
+        st["plan"].run(first, n_steps, st["cur_list"], ready, self.flat.step + 1, offset, after)
+        self.flat.step += n_steps
+        carried = n_steps - 1 + (1 if after else 0)
+        st["cur_list"] ^= carried & 1
+        st["ready"] = (first + n_steps, offset + n_steps * B * gen.neg_rate) if after else None
+
+    def own_step_explicit(self, h, r, t, y):
+        """The two-phase step on an explicit pointwise batch in the sampler's layout for neg_rate 1 (rows 2i = positive i, 2i+1 = its
+        corruption): the incidence index of this one batch is built on the host first -- parity tests and one-off batches."""
+        import numpy as np
+        from .generator import PullIndex
+        name, cfg, flat = self.model.kernel_name, self.config, self.flat
+        hh, rr, tt, yy = (x.detach().cpu().numpy() for x in (h, r, t, y))
+        if len(hh) % 2 or not (np.all(yy[0::2] == 1) and np.all(yy[1::2] == -1) and np.array_equal(rr[0::2], rr[1::2])):
+            raise ValueError("own_step_explicit: rows must alternate positive / its corruption (neg_rate 1 pointwise layout)")
+        pos = np.stack([hh[0::2], rr[0::2], tt[0::2]], 1)
+        dense = self._own_dense()
+        idx = PullIndex([pos], cfg.tot_entity, cfg.tot_relation, flat.param.device, None,
+                        K.own_groups_per_block(name, self.model.hidden_size), compact=None if dense else True)
+        pairs, inc, items, multi = idx.batch(0)
+        dev = flat.param.device
+        lists = K.PullListSet(len(pos), cfg.tot_entity, dev)
+        K.pull_lists_explicit(pairs, h[1::2].contiguous(), t[1::2].contiguous(), lists)
+        gbuf = torch.empty_like(flat.param)
+        off = [v.data_ptr() - flat.param.data_ptr() for v in flat.views]
+        view = lambda buf: [buf[o // 4:o // 4 + v.numel()].view_as(v) for o, v in zip(off, flat.views)]
+        gviews = view(gbuf)
+        desc = K.make_desc(name, flat.views, gviews, tot_entity=cfg.tot_entity, tot_relation=cfg.tot_relation, **self.model.desc_kwargs())
+        partials = torch.empty(max(1, idx.max_slots) * K.own_partial_stride(name, self.model.hidden_size), dtype=torch.float32, device=dev)
+        K.own_step(desc, pairs, lists, items, idx.skip(0), inc, partials, dense, self.model.kernel_lmbda(), self.model.kernel_reg_type(),
+                   self.loss_buf, reset_lists=False)
+        flat.step += 1
+        K.own_apply(desc, view(flat.state1) if flat.state1 is not None else None, view(flat.state2) if flat.state2 is not None else None,
+                    pairs, lists, items, idx.skip(0), multi, partials, dense, cfg.optimizer, cfg.learning_rate, flat.step)
+        return gviews
+
     # ------------------------------------------------------------------ staged (atomic-free) step of the long-row bundle kernels
     def _staged_ok(self):
         """RotatE self-adversarial / DistMult / ComplEx logistic step without a gradient buffer: the bundle kernel stages its
@@ -448,6 +552,8 @@ class Trainer:
             return False
         if self.switches["staged"] is not None:
             return self.switches["staged"]
+        if self._own_ok():
+            return False
         # default: the long-row RotatE bundles beyond the graph regime (C3: 320 -> 230 us per step).  For the pointwise models
         # the staged step is correct and deterministic but not faster than atomics + hipGraph replay at the measured shapes
         # (profiles/r02_experiments.md), so it stays opt-in (KGE_STAGED=1).
@@ -494,6 +600,9 @@ class Trainer:
         """n consecutive steps of the current epoch.  On the owner-computes path they are enqueued by one native call."""
         if n > 0 and self._pull_ok() and self.generator._batch_idx + n <= self.generator.n_train // self.config.batch_size:
             self._pull_steps(n)
+            return
+        if n > 0 and self._own_ok() and self.generator._batch_idx + n <= self.generator.n_train // self.config.batch_size:
+            self._own_steps(n)
             return
         if getattr(self, "_pull", None) is not None and not self._pull.grad_only:
             # leaving the single-GPU pull path (a short last batch): hand the tables back.  (The gradient-mode state of the
@@ -579,7 +688,7 @@ class Trainer:
             return False
         if self.switches["staged"] and self._staged_ok():   # the staged step is an eager two-launch step
             return False
-        if self.use_graph is None and self.generator is not None and self._pull_ok():   # one native call per epoch beats a replay per step
+        if self.use_graph is None and self.generator is not None and (self._pull_ok() or self._own_ok()):   # one native call per epoch beats a replay per step
             return False
         if self.distributed:
             # RCCL collectives are capturable (gloo is not); multi-rank capture is opt-in (use_graph=True or

@@ -1,0 +1,158 @@
+"""The two-phase owner-computes step of the pointwise models (csrc/kge_own.hip: DistMult, ComplEx / ComplexN3; no float
+atomics, in-place optimiser on the touched rows).  Held to (a) the live reference's golden post-optimiser weights on its
+golden batches, (b) the numpy oracle's dense gradient on the batch the sampler drew, (c) the atomic-scatter path on the same
+sampled batches over whole epochs, (d) itself, bit for bit, across runs."""
+import numpy as np
+import pytest
+import torch
+
+import kge_oracle as ko
+from golden_util import Case, close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import hip_util
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return hip_util
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam", "adagrad", "rms"])
+@pytest.mark.parametrize("name", ["distmult", "complex", "complexn3"])
+def test_three_own_steps_match_reference_weights(hip, name, opt):
+    """Golden batches of the live reference (pointwise layout, neg_rate 1), three steps: losses and post-optimiser tables."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.trainer import Trainer
+    c = Case(name)
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer=opt, lr=0.05)
+    m = hip.model_from_case(c)
+    tr = Trainer(m, cfg)
+    tr.build_model()
+    losses = []
+    for s in range(3):
+        b = [hip.dev(x) for x in c.batch(s)]
+        tr.loss_buf.zero_()
+        tr.own_step_explicit(*b)
+        losses.append(K.read_loss(tr.loss_buf).item())
+    assert close(np.asarray(losses), c.z["%s.losses" % opt], atol=3e-5, rtol=3e-5), (losses, c.z["%s.losses" % opt])
+    for k, p in hip.table_parameters(m):
+        ref = c.z["%s.final.%s" % (opt, k)]
+        got = p.detach().cpu().numpy()
+        assert np.allclose(got, ref, atol=1e-4, rtol=1e-4), (k, np.abs(got - ref).max())
+
+
+def _world(model, E, R, D, n_train, seed=11):
+    rng = np.random.default_rng(seed)
+    train = np.stack([rng.integers(E, size=n_train), rng.integers(R, size=n_train), rng.integers(E, size=n_train)], 1)
+    P = ko.init_params(model, rng, tot_entity=E, tot_relation=R, hidden_size=D)
+    return train, train[:8], P
+
+
+def _trainer(hip, model, world, E, R, D, B, opt, own, monkeypatch, lr=0.01, lmbda=1e-3):
+    from pykg2vec_amd.trainer import Trainer
+    train, test, P = world
+    hp = dict(hidden_size=D, lmbda=lmbda, neg_rate=1)
+    cfg = hip.make_config(E, R, hp, train, test, test, optimizer=opt, lr=lr, batch_size=B)
+    m = hip.model_from_params(model, P, hp, E, R)
+    monkeypatch.delenv("KGE_STAGED", raising=False)
+    monkeypatch.setenv("KGE_PW_PULL", "1" if own else "0")
+    tr = Trainer(m, cfg, use_graph=False)
+    tr.build_model()
+    tr.generator = tr._new_generator()
+    assert tr._own_ok() == own
+    return tr, m, cfg
+
+
+SHAPES = [("distmult", 53, 7, 40, 32), ("complex", 53, 7, 40, 32), ("complexn3", 53, 7, 40, 32),
+          ("complex", 12, 400, 8, 512),        # 512 draws over 12 entities: bucket overflow chains, every entity row long (many
+                                               # relations keep the train set far from saturating the 12 x 400 x 12 triples)
+          ("complex", 4000, 11, 200, 512),     # C2 row length, few relations: relation rows through the global partial sums
+          ("complex", 4000, 3, 200, 512),
+          ("distmult", 3000, 400, 100, 1024),
+          ("complex", 300, 5, 300, 256),       # two float4 per lane
+          ("distmult", 500, 9, 16, 64)]
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad", "adam", "rms"])
+@pytest.mark.parametrize("model,E,R,D,B", SHAPES)
+def test_own_epochs_equal_push_epochs(hip, monkeypatch, model, E, R, D, B, opt):
+    """Same generator seed => same batches and Philox draws on both paths: two epochs of three steps."""
+    world = _world(model, E, R, D, 3 * B + 5)
+    res = {}
+    for own in (False, True):
+        tr, m, cfg = _trainer(hip, model, world, E, R, D, B, opt, own, monkeypatch, lr=2e-4 if opt == "rms" else 0.01)
+        cfg.tot_train_triples = 3 * B
+        losses = [tr.train_model_epoch(e) for e in range(2)]
+        assert (getattr(tr, "_own", None) is not None) == own
+        res[own] = (losses, {k: p.detach().cpu().numpy().copy() for k, p in hip.table_parameters(m)})
+    assert np.allclose(res[True][0], res[False][0], rtol=3e-5), (res[True][0], res[False][0])
+    for k in res[True][1]:
+        a, b = res[True][1][k], res[False][1][k]
+        bad = ~np.isclose(a, b, atol=2e-5, rtol=1e-4)
+        lim = 0.0 if opt == "sgd" else 2e-3    # (order-dependent rounding residues under sign-like first steps, as in test_hip_staged)
+        assert bad.mean() <= lim, (opt, k, bad.mean(), np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("model,E,R,D,B,reg", [("complex", 300, 11, 64, 128, None), ("distmult", 300, 11, 64, 128, None),
+                                               ("complexn3", 300, 4, 200, 256, None), ("complex", 40943, 11, 200, 5000, None)])
+def test_own_gradient_matches_oracle(hip, monkeypatch, model, E, R, D, B, reg):
+    """One SGD step with lr = 1 turns the step into its own gradient: p_before - p_after must be the oracle's dense gradient of
+    the rows the sampler drew (kge_sample_batch, pointwise layout, same counters); the last case is config C2's size."""
+    from pykg2vec_amd import kernels as K
+    world = _world(model, E, R, D, B)
+    tr, m, cfg = _trainer(hip, model, world, E, R, D, B, "sgd", True, monkeypatch, lr=1.0)
+    before = {k[:-len(".weight")]: p.detach().cpu().numpy().copy() for k, p in hip.table_parameters(m)}
+    gen = tr.generator
+    h, r, t, y = [x.cpu().numpy() for x in K.sample_batch(gen.triples, gen.perm, 0, B, 1, E, gen.bern, gen.slots, gen.seed, 0,
+                                                         pointwise=True)]
+    loss = tr.train_model_epoch(0)
+    want_loss, grads, _, _ = ko.train_step_grads(model, before, (h, r, t, y), hidden_size=D, lmbda=1e-3)
+    assert np.isclose(loss, want_loss, rtol=3e-5), (loss, want_loss)
+    for k, p in hip.table_parameters(m):
+        name = k[:-len(".weight")]
+        got = before[name] - p.detach().cpu().numpy()
+        assert np.allclose(got, grads[name], atol=2e-6, rtol=2e-4), (k, np.abs(got - grads[name]).max())
+
+
+def test_own_training_is_bit_reproducible(hip, monkeypatch):
+    model, E, R, D, B = "complex", 4000, 11, 200, 512
+    world = _world(model, E, R, D, 3 * B)
+    out = []
+    for _ in range(2):
+        tr, m, cfg = _trainer(hip, model, world, E, R, D, B, "adagrad", True, monkeypatch)
+        losses = [tr.train_model_epoch(e) for e in range(2)]
+        out.append((losses, [p.detach().clone() for _, p in hip.table_parameters(m)]))
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b)
+
+
+def test_own_step_leaves_untouched_rows_alone(hip, monkeypatch):
+    """Adagrad / SGD: a row that takes part in no bundle keeps parameter AND state (a zero dense gradient changes nothing in
+    torch.optim); Adam moves every row every step -- both as the reference's dense optimisers do."""
+    model, E, R, D, B = "complex", 2000, 7, 64, 64
+    world = _world(model, E, R, D, B)
+    for opt, dense in (("adagrad", False), ("adam", True)):
+        tr, m, cfg = _trainer(hip, model, world, E, R, D, B, opt, True, monkeypatch)
+        before = m.ent_embeddings_real.weight.detach().clone()
+        tr.train_model_epoch(0)
+        tr.train_model_epoch(1)      # (the second epoch revisits the same batch: Adam's moments are non-zero by then)
+        moved = (m.ent_embeddings_real.weight.detach() != before).any(dim=1)
+        gen = tr.generator
+        touched = torch.zeros(E, dtype=torch.bool, device=moved.device)
+        for e in range(2):
+            h, r, t, y = K_sample(gen, B, E, e * B)
+            touched[h] = True
+            touched[t] = True
+        if dense:
+            assert bool(moved[touched].all())
+        else:
+            assert not bool(moved[~touched].any()) and bool(moved[touched].any())
+            assert float(tr.flat.state1.view(-1)[:E * D].view(E, D)[~touched].abs().sum()) == 0.0
+
+
+def K_sample(gen, B, E, offset):
+    from pykg2vec_amd import kernels as K
+    return K.sample_batch(gen.triples, gen.perm, 0, B, 1, E, gen.bern, gen.slots, gen.seed, offset, pointwise=True)
