@@ -465,7 +465,7 @@ def main():
         for ls in ps.lists:
             ls.clear()
         ps.ready, ps.cur_list = None, 0
-        K.pull_sample(pairs_b, E, gen.bern, gen.slots, gen.seed, 0, ps.lists[0])
+        K.pull_sample(pairs_b, idx.inv(0), E, gen.bern, gen.slots, gen.seed, 0, ps.lists[0])
         torch.cuda.synchronize()
         eb0.record()
         for _ in range(burst):
@@ -481,7 +481,7 @@ def main():
         for ls in ps.lists:   # a sampler riding in the last timed step may have filled a set for a batch that never ran
             ls.clear()
         ps.ready, ps.cur_list = None, 0
-        K.pull_sample(pairs_b, E, gen.bern, gen.slots, gen.seed, 0, ps.lists[0])
+        K.pull_sample(pairs_b, idx.inv(0), E, gen.bern, gen.slots, gen.seed, 0, ps.lists[0])
         desc_b = K.make_desc("transe", ps.tables[0], None, tot_entity=E, tot_relation=R, **model.desc_kwargs())
         torch.cuda.synchronize()
         eb0.record()

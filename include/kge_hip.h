@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 2
+#define KGE_ABI_VERSION 3
 #define KGE_MAX_TABLES 12
 
 /* model ids; tables[] order == the reference's `parameter_list` order */
@@ -295,26 +295,32 @@ typedef struct kge_pull_lists {
     int32_t* pc;      /* [n]  per pair: corrupting entity | (tail corrupted) << 24 | (first pair to register with that entity
                          this step) << 27 */
     int32_t* count;   /* [tot_entity]  pairs that drew the entity this step; all 0 between steps */
-    int32_t* bucket;  /* [tot_entity * KGE_PULL_BUCKET]  the first KGE_PULL_BUCKET of them */
+    int32_t* bucket;  /* [tot_entity * KGE_PULL_BUCKET]  the first KGE_PULL_BUCKET of them (pair indices; the overflow path) */
     int32_t* head;    /* [tot_entity]  overflow list head, all -1 between steps */
     int32_t* next;    /* [n]  overflow list links */
+    /* ready-made visit descriptors, written by the sampler so that an owner reads them with ONE dependent load:
+     *   sdesc   [3 n][4]  static incidences, in `inc` order: (h, r, t, corrupting entity | tail << 24 | role << 25)
+     *   dbucket [tot_entity * KGE_PULL_BUCKET][4]  the drawers of an entity: (h, r, t, PAIR INDEX | tail << 24 | 3 << 25) -- the
+     *           corrupting entity is the bucket's own; the owner orders the entries by pair index */
+    int32_t* sdesc;
+    int32_t* dbucket;
 } kge_pull_lists;
 int kge_pull_partial_stride(int32_t dim);
 int kge_pull_groups_per_block(int32_t dim);   /* owner groups per 256-thread workgroup: items are laid out in workgroup slots */
 int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, float* normalised, void* stream);
-int kge_pull_sample(const int32_t* pairs, int64_t n, int64_t tot_entity, const float* bern_prob, const uint64_t* slots,
-                    int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor, const kge_pull_lists* out,
-                    void* stream);
-int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n, const kge_pull_lists* out,
-                            void* stream);
+int kge_pull_sample(const int32_t* pairs, const int32_t* inv, int64_t n, int64_t tot_entity, const float* bern_prob,
+                    const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor,
+                    const kge_pull_lists* out, void* stream);
+int kge_pull_lists_explicit(const int32_t* pairs, const int32_t* inv, const int64_t* nh, const int64_t* nt, int64_t n,
+                            const kge_pull_lists* out, void* stream);
 int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
                   const float* norm_in, float* norm_out,
                   float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
                   const int32_t* items, int64_t n_items, const uint32_t* dense_skip, const int32_t* inc, float* partials, const int32_t* multi,
                   int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step, const float* dev_hyper,
-                  int32_t reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern_prob, const uint64_t* slots,
-                  int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
-                  void* stream);
+                  int32_t reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern_prob,
+                  const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
+                  float* loss, void* stream);
 
 /* A whole run of consecutive owner-computes steps enqueued by ONE native call (the per-step work is ~35 us of GPU time: a
  * Python-level loop cannot keep the queue full).  The plan holds everything that does not change between steps. */
@@ -326,6 +332,7 @@ typedef struct kge_pull_batch {
                                    only rows with a static incidence (bit set) and every other row is visited implicitly
                                    (dense optimisers move every row every step; its corrupting-entity draws are walked too) */
     const int32_t* inc;     /* [3 * n_pairs] */
+    const int32_t* inv;     /* [3 * n_pairs] inverse of inc (the sampler of this batch files its visit descriptors by it) */
     const int32_t* multi;   /* [n_multi, 4] or NULL */
     int64_t n_multi;
     int64_t n_pairs;
@@ -379,9 +386,9 @@ int kge_own_groups_per_block(int32_t model, int32_t dim);
 int kge_own_partial_stride(int32_t model, int32_t dim);
 int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists, const int32_t* items,
                  int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int32_t dense, float lmbda,
-                 int32_t reg_type, int32_t reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern_prob,
-                 const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
-                 float* loss, void* stream);
+                 int32_t reg_type, int32_t reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n,
+                 const float* bern_prob, const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
+                 const kge_pull_lists* next_lists, float* loss, void* stream);
 int kge_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
                   const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* multi,
                   int64_t n_multi, float* partials, int32_t dense, int32_t optimizer, float lr, int64_t step, void* stream);
@@ -410,6 +417,7 @@ int kge_own_run(const kge_own_plan* plan, int64_t first_batch, int64_t n_steps, 
  * Outputs, per batch b at fixed strides (device, int32):
  *   pairs  + b * n_pairs * 4          [n_pairs, 4]
  *   inc    + b * n_pairs * 3          [3 n_pairs]
+ *   inv    + b * n_pairs * 3          [3 n_pairs]  inverse of inc: inv[3 * pair + role] = position of that incidence in inc
  *   items  + b * item_cap * 4         [item_cap, 4], the first counts[4 b] slots are live (the rest is padding, row -1)
  *   multi  + b * multi_cap * 4        [multi_cap, 4], the first counts[4 b + 1] rows are live
  *   skip   + b * words                bitmap of the listed rows (compact != 0 only: kge_pull_batch.dense_skip)
@@ -422,7 +430,7 @@ int kge_pull_index_geometry(int64_t n_batches, int64_t n_pairs, int64_t tot_enti
                             size_t* workspace_bytes);
 int kge_pull_index_build(const int64_t* triples, const int64_t* perm, int64_t batch_stride, int64_t slice_lo, int64_t n_pairs,
                          int64_t n_batches, int64_t tot_entity, int64_t tot_relation, int32_t segment, int32_t groups_per_block,
-                         int32_t compact, int32_t* pairs, int32_t* inc, int32_t* items, int32_t* multi, uint32_t* skip,
+                         int32_t compact, int32_t* pairs, int32_t* inc, int32_t* inv, int32_t* items, int32_t* multi, uint32_t* skip,
                          int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- Atomic-free ("staged") training step for the long-row bundle kernels (RotatE self-adversarial; replaces the dense

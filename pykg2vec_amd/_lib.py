@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KGE_HIP_LIB", os.path.join(_HERE, "libkge_hip.so"))  # env override: A/B builds in dev tools
 
 KGE_MAX_TABLES = 12
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enum kge_model
 (TRANSE, TRANSH, TRANSD, ROTATE, RESCAL, NTN, DISTMULT, COMPLEX, ANALOGY, TRANSM, CP, SIMPLE, SIMPLE_IGNR,
@@ -42,7 +42,7 @@ class ModelDesc(ctypes.Structure):
 class PullLists(ctypes.Structure):
     """struct kge_pull_lists"""
     _fields_ = [("pc", ctypes.c_void_p), ("count", ctypes.c_void_p), ("bucket", ctypes.c_void_p), ("head", ctypes.c_void_p),
-                ("next", ctypes.c_void_p)]
+                ("next", ctypes.c_void_p), ("sdesc", ctypes.c_void_p), ("dbucket", ctypes.c_void_p)]
 
 
 PULL_BUCKET = 16
@@ -51,7 +51,7 @@ PULL_BUCKET = 16
 class PullBatch(ctypes.Structure):
     """struct kge_pull_batch"""
     _fields_ = [("pairs", ctypes.c_void_p), ("items", ctypes.c_void_p), ("n_items", ctypes.c_int64), ("dense_skip", ctypes.c_void_p),
-                ("inc", ctypes.c_void_p),
+                ("inc", ctypes.c_void_p), ("inv", ctypes.c_void_p),
                 ("multi", ctypes.c_void_p), ("n_multi", ctypes.c_int64), ("n_pairs", ctypes.c_int64)]
 
 
@@ -154,21 +154,21 @@ _SIGNATURES = {
     "kge_pull_partial_stride": (ctypes.c_int, [ctypes.c_int32]),
     "kge_pull_groups_per_block": (ctypes.c_int, [ctypes.c_int32]),
     "kge_row_norms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "kge_pull_sample": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+    "kge_pull_sample": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                        ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(PullLists), ctypes.c_void_p]),
-    "kge_pull_lists_explicit": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.POINTER(PullLists), ctypes.c_void_p]),
+    "kge_pull_lists_explicit": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.POINTER(PullLists), ctypes.c_void_p]),
     "kge_pull_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 8 + [ctypes.POINTER(PullLists), ctypes.c_void_p,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
                                      ctypes.c_int32, ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
-                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                      ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_void_p]),
     "kge_own_groups_per_block": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
     "kge_own_partial_stride": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
     "kge_own_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(PullLists), ctypes.c_void_p,
                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_float,
-                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                    ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p,
-                                    ctypes.c_void_p]),
+                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists),
+                                    ctypes.c_void_p, ctypes.c_void_p]),
     "kge_own_apply": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                      ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int64,
@@ -179,7 +179,7 @@ _SIGNATURES = {
     "kge_pull_index_geometry": (ctypes.c_int, [ctypes.c_int64] * 4 + [ctypes.c_int32] * 3 + [ctypes.POINTER(ctypes.c_int64)] * 3
                                 + [ctypes.POINTER(ctypes.c_size_t)]),
     "kge_pull_index_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int64] * 6 + [ctypes.c_int32] * 3
-                             + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]),
+                             + [ctypes.c_void_p] * 8 + [ctypes.c_size_t, ctypes.c_void_p]),
     "kge_pull_plan_bytes": (ctypes.c_size_t, []),
     "kge_pull_run": (ctypes.c_int, [ctypes.POINTER(PullPlanC), ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                     ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]),

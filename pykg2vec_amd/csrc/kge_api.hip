@@ -385,23 +385,23 @@ int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, f
     return launch_row_norms(table, rows, dim, norms, normalised, (hipStream_t)stream);
 }
 
-static int lists_ok(const kge_pull_lists* l) { return l && l->pc && l->count && l->bucket && l->head && l->next; }
+static int lists_ok(const kge_pull_lists* l) { return l && l->pc && l->count && l->bucket && l->head && l->next && l->sdesc && l->dbucket; }
 
-int kge_pull_sample(const int32_t* pairs, int64_t n, int64_t tot_entity, const float* bern_prob, const uint64_t* slots,
-                    int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor, const kge_pull_lists* out,
-                    void* stream) {
+int kge_pull_sample(const int32_t* pairs, const int32_t* inv, int64_t n, int64_t tot_entity, const float* bern_prob,
+                    const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t offset, const int64_t* dev_cursor,
+                    const kge_pull_lists* out, void* stream) {
     if (n == 0) return 0;
-    if (n < 0 || !pairs || !lists_ok(out) || tot_entity <= 0) { set_error("kge_pull_sample: bad arguments"); return -1; }
+    if (n < 0 || !pairs || !inv || !lists_ok(out) || tot_entity <= 0) { set_error("kge_pull_sample: bad arguments"); return -1; }
     if (tot_entity > (1 << 24)) { set_error("kge_pull_sample: more than 2^24 entities not supported by the packed key"); return -1; }
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_pull_sample: n_slots must be a power of two"); return -1; }
-    return launch_pull_sample(pairs, n, tot_entity, bern_prob, slots, n_slots, seed, offset, dev_cursor, out, (hipStream_t)stream);
+    return launch_pull_sample(pairs, inv, n, tot_entity, bern_prob, slots, n_slots, seed, offset, dev_cursor, out, (hipStream_t)stream);
 }
 
-int kge_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n, const kge_pull_lists* out,
-                            void* stream) {
+int kge_pull_lists_explicit(const int32_t* pairs, const int32_t* inv, const int64_t* nh, const int64_t* nt, int64_t n,
+                            const kge_pull_lists* out, void* stream) {
     if (n == 0) return 0;
-    if (n < 0 || !pairs || !nh || !nt || !lists_ok(out)) { set_error("kge_pull_lists_explicit: bad arguments"); return -1; }
-    return launch_pull_lists_explicit(pairs, nh, nt, n, out, (hipStream_t)stream);
+    if (n < 0 || !pairs || !inv || !nh || !nt || !lists_ok(out)) { set_error("kge_pull_lists_explicit: bad arguments"); return -1; }
+    return launch_pull_lists_explicit(pairs, inv, nh, nt, n, out, (hipStream_t)stream);
 }
 
 int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
@@ -409,9 +409,9 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
                   float* const state1[2], float* const state2[2], const int32_t* pairs, const kge_pull_lists* lists,
                   const int32_t* items, int64_t n_items, const uint32_t* dense_skip, const int32_t* inc, float* partials, const int32_t* multi,
                   int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step, const float* dev_hyper,
-                  int32_t reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern_prob, const uint64_t* slots,
-                  int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
-                  void* stream) {
+                  int32_t reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern_prob,
+                  const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
+                  float* loss, void* stream) {
     if (validate(m, false, "kge_pull_step")) return -1;
     if (m->model != KGE_TRANSE && m->model != KGE_TRANSM) { set_error("kge_pull_step: TransE / TransM only (model %d)", m->model); return -1; }
     const bool grad_only = optimizer == KGE_OPT_GRADIENT;   // writes gradient rows: no normalised copies / norms / state out
@@ -430,14 +430,14 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
     if (optimizer != KGE_OPT_SGD && !grad_only && (!state1 || !state1[0] || !state1[1])) { set_error("kge_pull_step: optimizer state missing"); return -1; }
     if (optimizer == KGE_OPT_ADAM && (!state2 || !state2[0] || !state2[1])) { set_error("kge_pull_step: adam needs two state buffers"); return -1; }
     if (next_pairs) {
-        if (next_n < 0 || !lists_ok(next_lists) || next_lists->count == lists->count || (slots && (n_slots & (n_slots - 1)))) {
-            set_error("kge_pull_step: the next batch's sampler needs its own list set");
+        if (next_n < 0 || !next_inv || !lists_ok(next_lists) || next_lists->count == lists->count || (slots && (n_slots & (n_slots - 1)))) {
+            set_error("kge_pull_step: the next batch's sampler needs its inverse incidence map and its own list set");
             return -1;
         }
         if (validate_packed_key(m, "kge_pull_step")) return -1;
     }
     return launch_pull_step(m, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, n_items, dense_skip, inc, partials, multi,
-                            n_multi, margin, optimizer, lr, step, dev_hyper, reset_lists, next_pairs, next_n, bern_prob, slots,
+                            n_multi, margin, optimizer, lr, step, dev_hyper, reset_lists, next_pairs, next_inv, next_n, bern_prob, slots,
                             n_slots, seed, next_offset, next_lists, loss, (hipStream_t)stream);
 }
 
@@ -456,7 +456,7 @@ int kge_pull_run(const kge_pull_plan* p, int64_t first_batch, int64_t n_steps, i
         const kge_pull_batch* b = p->batches + first_batch + k;
         int rc;
         if (k == 0 && !lists_ready) {
-            rc = kge_pull_sample(b->pairs, b->n_pairs, p->model[0].tot_entity, p->bern_prob, p->slots, p->n_slots, p->seed, offset,
+            rc = kge_pull_sample(b->pairs, b->inv, b->n_pairs, p->model[0].tot_entity, p->bern_prob, p->slots, p->n_slots, p->seed, offset,
                                  nullptr, &p->lists[cl], stream);
             if (rc) return rc;
         }
@@ -467,7 +467,7 @@ int kge_pull_run(const kge_pull_plan* p, int64_t first_batch, int64_t n_steps, i
         float* const hat_out[2] = {p->hat[1 - src][0], p->hat[1 - src][1]};
         rc = kge_pull_step(&p->model[src], tables_out, hat_in, hat_out, p->norm[src], p->norm[1 - src], p->state1, p->state2,
                            b->pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip, b->inc, p->partials, b->multi, b->n_multi, p->margin,
-                           p->optimizer, p->lr, first_opt_step + k, nullptr, 1, nb ? nb->pairs : nullptr, nb ? nb->n_pairs : 0,
+                           p->optimizer, p->lr, first_opt_step + k, nullptr, 1, nb ? nb->pairs : nullptr, nb ? nb->inv : nullptr, nb ? nb->n_pairs : 0,
                            p->bern_prob, p->slots, p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch,
                            nb ? &p->lists[1 - cl] : nullptr, p->loss, stream);
         if (rc) return rc;
@@ -484,9 +484,9 @@ int kge_own_partial_stride(int32_t model, int32_t dim) { return own_partial_stri
 
 int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists, const int32_t* items,
                  int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int32_t dense, float lmbda,
-                 int32_t reg_type, int32_t reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern_prob,
-                 const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
-                 float* loss, void* stream) {
+                 int32_t reg_type, int32_t reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n,
+                 const float* bern_prob, const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
+                 const kge_pull_lists* next_lists, float* loss, void* stream) {
     if (validate(m, true, "kge_own_step")) return -1;
     if (m->model != KGE_DISTMULT && m->model != KGE_COMPLEX) { set_error("kge_own_step: DistMult / ComplEx only (model %d)", m->model); return -1; }
     if (n_pairs <= 0 || n_items <= 0 || !pairs || !lists_ok(lists) || !items || !inc || !partials || !loss ||
@@ -495,14 +495,14 @@ int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs,
         return -1;
     }
     if (next_pairs) {
-        if (next_n < 0 || !lists_ok(next_lists) || next_lists->count == lists->count || (slots && (n_slots & (n_slots - 1)))) {
-            set_error("kge_own_step: the next batch's sampler needs its own list set");
+        if (next_n < 0 || !next_inv || !lists_ok(next_lists) || next_lists->count == lists->count || (slots && (n_slots & (n_slots - 1)))) {
+            set_error("kge_own_step: the next batch's sampler needs its inverse incidence map and its own list set");
             return -1;
         }
         if (validate_packed_key(m, "kge_own_step")) return -1;
     }
     return launch_own_step(m, pairs, n_pairs, lists, items, n_items, listed, inc, partials, dense, lmbda, reg_type, reset_lists,
-                           next_pairs, next_n, bern_prob, slots, n_slots, seed, next_offset, next_lists, loss, (hipStream_t)stream);
+                           next_pairs, next_inv, next_n, bern_prob, slots, n_slots, seed, next_offset, next_lists, loss, (hipStream_t)stream);
 }
 
 int kge_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
@@ -534,14 +534,14 @@ int kge_own_run(const kge_own_plan* p, int64_t first_batch, int64_t n_steps, int
         const kge_pull_batch* b = p->batches + first_batch + k;
         int rc;
         if (k == 0 && !lists_ready) {
-            rc = kge_pull_sample(b->pairs, b->n_pairs, p->model.tot_entity, p->bern_prob, p->slots, p->n_slots, p->seed, offset,
+            rc = kge_pull_sample(b->pairs, b->inv, b->n_pairs, p->model.tot_entity, p->bern_prob, p->slots, p->n_slots, p->seed, offset,
                                  nullptr, &p->lists[cl], stream);
             if (rc) return rc;
         }
         const bool has_next = (k + 1 < n_steps || sample_after_last) && first_batch + k + 1 < p->n_batches;
         const kge_pull_batch* nb = has_next ? b + 1 : nullptr;
         rc = kge_own_step(&p->model, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip, b->inc, p->partials,
-                          dense, p->lmbda, p->reg_type, 1, nb ? nb->pairs : nullptr, nb ? nb->n_pairs : 0, p->bern_prob, p->slots,
+                          dense, p->lmbda, p->reg_type, 1, nb ? nb->pairs : nullptr, nb ? nb->inv : nullptr, nb ? nb->n_pairs : 0, p->bern_prob, p->slots,
                           p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch, nb ? &p->lists[1 - cl] : nullptr, p->loss, stream);
         if (rc) return rc;
         rc = kge_own_apply(&p->model, p->state1, p->state2, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip,

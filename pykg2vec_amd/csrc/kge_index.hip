@@ -110,7 +110,7 @@ struct IxArgs {
     int P1, P2, P3, NRcap, item_cap, multi_cap, words;
     u64* keys1; u64* keys2; u64* keys3;
     int* l_row; int* l_beg; int* l_cnt; int* gbase; int* open; int* meta;
-    int4* pairs; int* inc; int4* items; int4* multi; unsigned* skip; int* counts;
+    int4* pairs; int* inc; int* inv; int4* items; int4* multi; unsigned* skip; int* counts;
 };
 
 __global__ __launch_bounds__(256) void k_ix_keys(IxArgs a) {
@@ -154,7 +154,12 @@ __global__ __launch_bounds__(kIxBlock) void k_ix_rows(IxArgs a) {
     u64* keys2 = a.keys2 + (int64_t)b * a.P2;
     u64* keys3 = a.keys3 + (int64_t)b * a.P3;
     int4* multi = a.multi + (int64_t)b * a.multi_cap;
-    for (int j = tid; j < M; j += kIxBlock) inc[j] = (int)(unsigned)keys[j];
+    int* inv = a.inv + (int64_t)b * M;   // inverse of inc: inv[3 * pair + role] = position of that incidence in the sorted list
+    for (int j = tid; j < M; j += kIxBlock) {
+        const int val = (int)(unsigned)keys[j];
+        inc[j] = val;
+        inv[3 * (val >> 2) + (val & 3)] = j;
+    }
     __shared__ int s_NR;
     int tot;
     if (a.compact) {
@@ -336,14 +341,14 @@ int kge_pull_index_geometry(int64_t n_batches, int64_t n_pairs, int64_t tot_enti
 
 int kge_pull_index_build(const int64_t* triples, const int64_t* perm, int64_t batch_stride, int64_t slice_lo, int64_t n_pairs,
                          int64_t n_batches, int64_t tot_entity, int64_t tot_relation, int32_t segment, int32_t groups_per_block,
-                         int32_t compact, int32_t* pairs, int32_t* inc, int32_t* items, int32_t* multi, uint32_t* skip,
+                         int32_t compact, int32_t* pairs, int32_t* inc, int32_t* inv, int32_t* items, int32_t* multi, uint32_t* skip,
                          int32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
     IxGeometry g;
     if (!index_geometry(n_batches, n_pairs, tot_entity, tot_relation, segment, groups_per_block, compact, &g)) {
         set_error("kge_pull_index_build: bad sizes");
         return -1;
     }
-    if (!triples || !perm || !pairs || !inc || !items || !multi || !counts || (compact && !skip) || !workspace ||
+    if (!triples || !perm || !pairs || !inc || !inv || !items || !multi || !counts || (compact && !skip) || !workspace ||
         workspace_bytes < g.ws_bytes || batch_stride < n_pairs || slice_lo < 0) {
         set_error("kge_pull_index_build: bad arguments (workspace of kge_pull_index_geometry bytes)");
         return -1;
@@ -365,7 +370,7 @@ int kge_pull_index_build(const int64_t* triples, const int64_t* perm, int64_t ba
     a.gbase = (int*)w; w += (size_t)a.nb * a.NRcap * sizeof(int);
     a.open = (int*)w; w += (size_t)a.nb * a.item_cap * sizeof(int);
     a.meta = (int*)w;
-    a.pairs = (int4*)pairs; a.inc = inc; a.items = (int4*)items; a.multi = (int4*)multi; a.skip = skip; a.counts = counts;
+    a.pairs = (int4*)pairs; a.inc = inc; a.inv = inv; a.items = (int4*)items; a.multi = (int4*)multi; a.skip = skip; a.counts = counts;
     hipLaunchKernelGGL(k_ix_keys, dim3((unsigned)((a.P1 + 255) / 256), (unsigned)a.nb), dim3(256), 0, s, a);
     int rc = check_launch("k_ix_keys");
     if (rc) return rc;

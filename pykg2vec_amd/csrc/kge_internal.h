@@ -155,13 +155,13 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
                      const float* norm_in, float* norm_out, float* const state1[2], float* const state2[2], const int32_t* pairs,
                      const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* dense_skip, const int32_t* inc, float* partials,
                      const int32_t* multi, int64_t n_multi, float margin, int optimizer, float lr, int64_t step,
-                     const float* dev_hyper, int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern,
+                     const float* dev_hyper, int reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern,
                      const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
                      const kge_pull_lists* next_lists, float* loss, hipStream_t s);
 int launch_row_norms(const float* table, int64_t rows, int dim, float* out, float* hat, hipStream_t s);
-int launch_pull_sample(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots,
+int launch_pull_sample(const int32_t* pairs, const int32_t* inv, int64_t n, int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots,
                        uint64_t seed, uint64_t offset, const int64_t* cursor, const kge_pull_lists* out, hipStream_t s);
-int launch_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n,
+int launch_pull_lists_explicit(const int32_t* pairs, const int32_t* inv, const int64_t* nh, const int64_t* nt, int64_t n,
                                const kge_pull_lists* out, hipStream_t s);
 
 // kge_own.hip (two-phase owner-computes step of the pointwise models)
@@ -169,8 +169,9 @@ int own_groups_per_block(int model, int dim);
 int own_partial_stride(int model, int dim);
 int launch_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists, const int32_t* items,
                     int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int dense, float lmbda, int reg_type,
-                    int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern, const uint64_t* slots,
-                    int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss, hipStream_t s);
+                    int reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern,
+                    const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
+                    float* loss, hipStream_t s);
 int launch_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
                      const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* multi,
                      int64_t n_multi, float* partials, int dense, int optimizer, float lr, int64_t step, hipStream_t s);

@@ -20,6 +20,7 @@
 #include "kge_pull_device.h"
 #include "kge_opt_device.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace kge {
 
@@ -71,13 +72,6 @@ __device__ __forceinline__ void store_row_e(float* __restrict__ row, const float
         for (int v = 0; v < NV; ++v) { const int e = v * G + gl; if (e < d) row[e] = x[v]; }
     }
 }
-
-// the rows of one visit
-template <int NT, int NE>
-struct OwnRows {
-    float hh[NT][NE], tt[NT][NE], cc[NT][NE], rr[NT][NE];
-    int w;   // corrupting entity | tail << 24 | role << 25
-};
 
 // (table pointers by value: a reference to a kernel-argument array would put the argument struct in scratch; d_eff = 0 turns the
 // loads of a row set that is not needed into zero fills)
@@ -163,8 +157,12 @@ __device__ __forceinline__ void reg_grad(float (&g)[NT][NE], const float (&x)[NT
         }
 }
 
+// resident waves per SIMD the register allocation must allow (A/B builds: -DKGE_OWN_WAVES=n)
+#ifndef KGE_OWN_WAVES
+#define KGE_OWN_WAVES 4
+#endif
 template <int NT, int VEC, int G, int NV>
-__global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs sa, float* __restrict__ loss) {
+__global__ __launch_bounds__(kBlock, KGE_OWN_WAVES) void k_own_step(OwnArgs a, PullSampleArgs sa, float* __restrict__ loss) {
     constexpr int GPB = kBlock / G;
     constexpr int NE = VEC * NV;
     if ((int)blockIdx.x < a.sample_blocks) {   // leading blocks: the sampler of the NEXT batch rides along (other list set)
@@ -201,101 +199,76 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
         // the owner's rows: requested first, they depend on nothing but the item
         if (is_rel) load_rows_nt<NT, VEC, G, NV>(X, a.rel[0], a.rel[1], own, d, d, gl);
         else load_rows_nt<NT, VEC, G, NV>(X, a.ent[0], a.ent[1], own, d, d, gl);
-        const int n_static = it.z - it.y;
-        int cnt = 0, nvis = 0;
-        int vi = -1, vrole = 0, slot = gl;
-        if (gl < n_static) { const int e = a.inc[it.y + gl]; vi = e >> 2; vrole = e & 3; }
+        int cnt = 0;
+        bool fast_c = true;
         const bool walks_c = !is_rel && (kind == 0 || kind == 1 || (kind == 3 && ((it.w >> 2) & 15) == 0));
-        if (walks_c) cnt = a.lists.count[g];
-        const bool fast_c = cnt <= kPullCap && n_static + cnt <= G;
-        nvis = n_static;
-        if (cnt > 0 && fast_c) {
-            const int q = gl - n_static;
-            if (q >= 0 && q < cnt) { vi = a.lists.bucket[(int64_t)g * kPullCap + q]; vrole = kRoleC; }
-            if (cnt > 1) {   // arrival order is arbitrary: rank the entries by pair index, visit by rank
-                int rank = 0;
-                for (int m = 0; m < cnt; ++m) rank += __shfl(vi, gbase + n_static + m, 64) < vi ? 1 : 0;
-                if (q >= 0 && q < cnt) slot = n_static + rank;
-            }
-            nvis += cnt;
-        }
-        if (vi >= 0) {
-            int4 pr = a.pairs[vi];
-            pr.w = (a.lists.pc[vi] & 0x1FFFFFF) | (vrole << 25);
-            s_desc[grp][slot] = pr;
-        }
+        const int nvis = own_visit_list<G>(a.lists, it, g, walks_c, gl, gbase, s_desc[grp], &cnt, &fast_c);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e = 0; e < NE; ++e) gs[t][e] = 0.f;
 
-        auto fetch = [&](int h, int r, int t, int w, OwnRows<NT, NE>& b) {
-            b.w = w;
+        // One visit = the bundle (P = (h, r, t), N = (h, r, c) | (c, r, t)) seen from the owner's row.  The two triples are
+        // independent loss terms, so they are evaluated one after the other with a working set of three row sets (head, relation,
+        // tail -- the owner's own set among them is X itself): 40 row registers instead of the 72 a whole-bundle evaluation holds,
+        // which is what decides how many owners a CU keeps in flight (the kernel is latency x occupancy bound).
+        const bool reg_on = a.reg_type != KGE_REG_NONE;
+        const float reg_k = a.lmbda * a.inv_n;
+        // triple (hd, rl, tl) with label y, the owner at position POS (0 head, 1 tail, 2 relation); RL = the relation rows when
+        // the owner is an entity (loaded once per visit)
+        // the arithmetic of one triple once its rows are in registers
+        auto triple_core = [&](auto pos_tag, float y, const float (&A)[NT][NE], const float (&RL)[NT][NE], const float (&B)[NT][NE]) {
+            constexpr int POS = decltype(pos_tag)::value;
+            float p, rs = 0.f;
+            if constexpr (POS == 0) p = dot3<NT, NE>(X, RL, B);
+            else if constexpr (POS == 1) p = dot3<NT, NE>(A, RL, X);
+            else {
+                p = dot3<NT, NE>(A, X, B);
+                if (reg_on) rs = reg_value<NT, NE>(A, a.reg_type) + reg_value<NT, NE>(X, a.reg_type) + reg_value<NT, NE>(B, a.reg_type);
+            }
+            if constexpr (POS == 2) gsum2<G>(p, rs); else p = gsum<G>(p);
+            const float x = -y * p;                                   // y * energy, energy = -p
+            const float ds = y * sigmoid_t(x) * a.inv_n;              // d loss / d energy   (loss = mean softplus(y * energy))
+            if constexpr (POS == 2) acc += softplus_t(x) * a.inv_n + reg_k * rs;   // the relation owner accounts for the loss terms
+            if constexpr (POS == 0) add_grad<NT, NE>(gs, 0, -ds, X, RL, B);
+            else if constexpr (POS == 1) add_grad<NT, NE>(gs, 1, -ds, A, RL, X);
+            else add_grad<NT, NE>(gs, 2, -ds, A, X, B);
+            if (reg_on) reg_grad<NT, NE>(gs, X, reg_k, a.reg_type);
+        };
+        auto triple = [&](auto pos_tag, int hd, int tl, float y, const float (&RL)[NT][NE]) {
+            constexpr int POS = decltype(pos_tag)::value;
+            float A[NT][NE], B[NT][NE];
+            if constexpr (POS != 0) load_rows_nt<NT, VEC, G, NV>(A, a.ent[0], a.ent[1], hd, d, d, gl);
+            if constexpr (POS != 1) load_rows_nt<NT, VEC, G, NV>(B, a.ent[0], a.ent[1], tl, d, d, gl);
+            triple_core(pos_tag, y, A, RL, B);
+        };
+        auto visit = [&](int h, int r, int t, int w) {
             const int role = (w >> 25) & 3;
             const bool tail = ((w >> 24) & 1) != 0;
             const int c = w & 0xFFFFFF;
-            // P = (h, r, t) is evaluated by the owners of h, r, t; N = (h, r, c) | (c, r, t) by the owners of its three rows.  The
-            // owner's own rows are fetched like the others (L1 / L2 hot): the arithmetic below is then the same for every role
-            const bool inP = role != kRoleC;
-            const bool inN = role == kRoleR || role == kRoleC || (role == kRoleH && tail) || (role == kRoleT && !tail);
-            const bool needH = inP || (inN && tail), needT = inP || (inN && !tail), needC = inN;
-            load_rows_nt<NT, VEC, G, NV>(b.hh, a.ent[0], a.ent[1], h, d, needH ? d : 0, gl);
-            load_rows_nt<NT, VEC, G, NV>(b.tt, a.ent[0], a.ent[1], t, d, needT ? d : 0, gl);
-            load_rows_nt<NT, VEC, G, NV>(b.cc, a.ent[0], a.ent[1], c, d, needC ? d : 0, gl);
-            load_rows_nt<NT, VEC, G, NV>(b.rr, a.rel[0], a.rel[1], r, d, d, gl);
-        };
-        auto fetch_visit = [&](int v, OwnRows<NT, NE>& b) {
-            const int4 ds = s_desc[grp][v];
-            fetch(ds.x, ds.y, ds.z, ds.w, b);
-        };
-        auto compute = [&](const OwnRows<NT, NE>& b) {
-            const int role = (b.w >> 25) & 3;
-            const bool tail = ((b.w >> 24) & 1) != 0;
-            const bool inP = role != kRoleC;
-            const bool inN = role == kRoleR || role == kRoleC || (role == kRoleH && tail) || (role == kRoleT && !tail);
-            float pP = 0.f, pN = 0.f, rs = 0.f;
-            if (inP) pP = dot3<NT, NE>(b.hh, b.rr, b.tt);
-            if (inN) pN = tail ? dot3<NT, NE>(b.hh, b.rr, b.cc) : dot3<NT, NE>(b.cc, b.rr, b.tt);
-            const bool reg_on = a.reg_type != KGE_REG_NONE;
-            if (role == kRoleR && reg_on)   // the relation owner sees every row of both triples: it accounts for the loss terms
-                rs = reg_value<NT, NE>(b.hh, a.reg_type) + reg_value<NT, NE>(b.tt, a.reg_type) + reg_value<NT, NE>(b.cc, a.reg_type) +
-                     2.f * reg_value<NT, NE>(b.rr, a.reg_type) + (tail ? reg_value<NT, NE>(b.hh, a.reg_type) : reg_value<NT, NE>(b.tt, a.reg_type));
-            gsum3<G>(pP, pN, rs);
-            const float sP = -pP, sN = -pN;                      // energies
-            // loss = mean softplus(y s): y = +1 for P, -1 for N (utils/criterion.py:31-34, utils/trainer.py:178)
-            const float dP = inP ? sigmoid_t(sP) * a.inv_n : 0.f;          // d loss / d sP
-            const float dN = inN ? -sigmoid_t(-sN) * a.inv_n : 0.f;        // d loss / d sN
-            if (role == kRoleR) acc += (softplus_t(sP) + softplus_t(-sN)) * a.inv_n + a.lmbda * a.inv_n * rs;
-            // own position in P and in N (0 head, 1 tail, 2 relation); d s / d row = -(d dot3 / d row)
-            const int posP = role == kRoleR ? 2 : role;            // H -> 0, T -> 1 (C: not in P)
-            const int posN = role == kRoleR ? 2 : (role == kRoleC ? (tail ? 1 : 0) : role);
-            if (inP) add_grad<NT, NE>(gs, posP, -dP, b.hh, b.rr, b.tt);
-            if (inN) { if (tail) add_grad<NT, NE>(gs, posN, -dN, b.hh, b.rr, b.cc); else add_grad<NT, NE>(gs, posN, -dN, b.cc, b.rr, b.tt); }
-            if (reg_on) reg_grad<NT, NE>(gs, X, a.lmbda * a.inv_n * (float)((inP ? 1 : 0) + (inN ? 1 : 0)), a.reg_type);
-        };
-#ifdef KGE_OWN_PIPELINE
-        if (nvis > 0) {   // software pipeline: the gathers of visit v+1 are in flight while visit v is evaluated
-            OwnRows<NT, NE> ba, bb;
-            fetch_visit(0, ba);
-            for (int v = 0; v < nvis; v += 2) {
-                const bool more = v + 1 < nvis;
-                if (more) fetch_visit(v + 1, bb);
-                compute(ba);
-                if (more) {
-                    if (v + 2 < nvis) fetch_visit(v + 2, ba);
-                    compute(bb);
-                }
+            const int nhd = tail ? h : c, ntl = tail ? c : t;          // the corrupted triple
+            if (role == kRoleR) {
+                triple(std::integral_constant<int, 2>{}, h, t, 1.f, X);
+                triple(std::integral_constant<int, 2>{}, nhd, ntl, -1.f, X);
+                return;
             }
-        }
-#else
-        // one visit at a time: the rows of a visit are 8 * 800 B at the C2 shape, and a second buffer for software pipelining
-        // costs more resident waves (the latency hiding that works here) than it buys
+            float RL[NT][NE];
+            load_rows_nt<NT, VEC, G, NV>(RL, a.rel[0], a.rel[1], r, d, d, gl);
+            if (role == kRoleH) {
+                triple(std::integral_constant<int, 0>{}, h, t, 1.f, RL);
+                if (tail) triple(std::integral_constant<int, 0>{}, nhd, ntl, -1.f, RL);
+            } else if (role == kRoleT) {
+                triple(std::integral_constant<int, 1>{}, h, t, 1.f, RL);
+                if (!tail) triple(std::integral_constant<int, 1>{}, nhd, ntl, -1.f, RL);
+            } else {   // drawn as the corrupting entity: only the corrupted triple, as its tail (tail corrupted) or head
+                if (tail) triple(std::integral_constant<int, 1>{}, nhd, ntl, -1.f, RL);
+                else triple(std::integral_constant<int, 0>{}, nhd, ntl, -1.f, RL);
+            }
+        };
         for (int v = 0; v < nvis; ++v) {
-            OwnRows<NT, NE> b;
-            fetch_visit(v, b);
-            compute(b);
+            const int4 ds = s_desc[grp][v];   // same address for the whole group: a broadcast read
+            visit(ds.x, ds.y, ds.z, ds.w);
         }
-#endif
         if (cnt > 0 && !fast_c) {   // more drawers than the bucket / the lane group holds: ascending pair order, one at a time
             const int nb = cnt < kPullCap ? cnt : kPullCap;
             int last = -1;
@@ -305,9 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
                 for (int j = a.lists.head[g]; j >= 0; j = a.lists.next[j]) if (j > last && j < best) best = j;
                 if (best == 0x7FFFFFFF) break;
                 const int4 p2 = a.pairs[best];
-                OwnRows<NT, NE> b;
-                fetch(p2.x, p2.y, p2.z, (a.lists.pc[best] & 0x1FFFFFF) | (kRoleC << 25), b);
-                compute(b);
+                visit(p2.x, p2.y, p2.z, (a.lists.pc[best] & 0x1FFFFFF) | (kRoleC << 25));
                 last = best;
             }
         }
@@ -348,52 +319,32 @@ __global__ __launch_bounds__(kBlock) void k_own_step(OwnArgs a, PullSampleArgs s
     block_accumulate_loss<G>(acc, gl, loss);
 }
 
-// phase 2: the optimiser on every row that has a gradient row (or a list of partial sums)
+// phase 2: the optimiser on every row that has a gradient row (or a list of partial sums).  Blocks [0, n_multi): one WORKGROUP
+// per row that was cut into many items (its partial list is the long chain of this launch: the owner groups of the workgroup
+// each add a contiguous share of the slots, the shares are then added in order); the other blocks: one owner group per row.
 template <int OPT, int NT, int VEC, int G, int NV>
 __global__ __launch_bounds__(kBlock) void k_own_apply(OwnArgs a) {
     constexpr int GPB = kBlock / G;
     constexpr int NE = VEC * NV;
     const int gl = threadIdx.x % G;
-    const int64_t unit = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
+    const int grp = threadIdx.x / G;
     const int d = a.d;
-    int g = -1, slot0 = 0, nslots = 0;
-    // rows cut into many items come first (their partial lists are the long chains of this launch), then one unit per item
-    if (unit < a.n_multi) {
-        const int4 row = a.multi[unit];
-        g = row.x; slot0 = row.y; nslots = row.z;
-    } else if (unit < a.n_multi + a.n_items) {
-        const int4 it = a.items[unit - a.n_multi];
-        const int kind = it.w & 3;
-        if (it.x >= 0 && (kind == 0 || (kind == 3 && ((it.w >> 2) & 15) == 0))) g = it.x;
-    } else if (a.listed != nullptr) {
-        const int64_t j = unit - a.n_items - a.n_multi;
-        if (a.dense) {
-            if (j < a.n_rows && !((a.listed[j >> 5] >> (j & 31)) & 1u)) g = (int)j;
-        } else if (j < a.n_pairs) {
-            const int w = a.lists.pc[j];
-            const int c = w & 0xFFFFFF;
-            if (((w >> kPcFirstBit) & 1) && !((a.listed[c >> 5] >> (c & 31)) & 1u)) g = c;
-        }
-    }
-    if (g < 0) return;
-    const bool is_rel = g >= a.E;
-    const int64_t off = (int64_t)(is_rel ? g - a.E : g) * d;
-    float gv[NT][NE], P[NT][NE], M1[NT][NE], M2[NT][NE];
-    // parameter and state rows first: they depend on nothing but the row id
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        load_row_e<VEC, G, NV>(P[t], (is_rel ? a.rel[t] : a.ent[t]) + off, d, gl);
-        if constexpr (OPT != KGE_OPT_SGD) load_row_e<VEC, G, NV>(M1[t], (is_rel ? a.s1_rel[t] : a.s1_ent[t]) + off, d, gl);
-        if constexpr (OPT == KGE_OPT_ADAM) load_row_e<VEC, G, NV>(M2[t], (is_rel ? a.s2_rel[t] : a.s2_ent[t]) + off, d, gl);
-    }
-    if (nslots > 0) {   // partial sums added in segment order, eight slots in flight
+    __shared__ float s_sum[GPB][NT * NE * G];
+    int g = -1;
+    float gv[NT][NE];
+    bool have_g = false;
+    if ((int64_t)blockIdx.x < a.n_multi) {
+        const int4 row = a.multi[blockIdx.x];
+        const int nslots = row.z;
+        const int per = (nslots + GPB - 1) / GPB;
+        const int s0 = grp * per, s1 = min(nslots, s0 + per);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e = 0; e < NE; ++e) gv[t][e] = 0.f;
-        const float* base = a.partials + (int64_t)slot0 * (NT * NE * G);
-        int s = 0;
-        for (; s + 4 <= nslots; s += 4) {
+        const float* base = a.partials + (int64_t)row.y * (NT * NE * G);
+        int s = s0;
+        for (; s + 4 <= s1; s += 4) {   // four slots in flight, added in slot order
             float q[4][NT][NE];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -408,14 +359,51 @@ __global__ __launch_bounds__(kBlock) void k_own_apply(OwnArgs a) {
 #pragma unroll
                     for (int e = 0; e < NE; ++e) gv[t][e] += q[u][t][e];
         }
-        for (; s < nslots; ++s)
+        for (; s < s1; ++s)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int e = 0; e < NE; ++e) gv[t][e] += base[(int64_t)s * (NT * NE * G) + (t * NE + e) * G + gl];
-    } else {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) load_row_e<VEC, G, NV>(gv[t], (is_rel ? a.g_rel[t] : a.g_ent[t]) + off, d, gl);
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) s_sum[grp][(t * NE + e) * G + gl] = gv[t][e];
+        __syncthreads();
+        if (grp != 0) return;
+        for (int m = 1; m < GPB; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) gv[t][e] += s_sum[m][(t * NE + e) * G + gl];
+        g = row.x;
+        have_g = true;
+    } else {
+        const int64_t unit = ((int64_t)blockIdx.x - a.n_multi) * GPB + grp;
+        if (unit < a.n_items) {
+            const int4 it = a.items[unit];
+            const int kind = it.w & 3;
+            if (it.x >= 0 && (kind == 0 || (kind == 3 && ((it.w >> 2) & 15) == 0))) g = it.x;
+        } else if (a.listed != nullptr) {
+            const int64_t j = unit - a.n_items;
+            if (a.dense) {
+                if (j < a.n_rows && !((a.listed[j >> 5] >> (j & 31)) & 1u)) g = (int)j;
+            } else if (j < a.n_pairs) {
+                const int w = a.lists.pc[j];
+                const int c = w & 0xFFFFFF;
+                if (((w >> kPcFirstBit) & 1) && !((a.listed[c >> 5] >> (c & 31)) & 1u)) g = c;
+            }
+        }
+    }
+    if (g < 0) return;
+    const bool is_rel = g >= a.E;
+    const int64_t off = (int64_t)(is_rel ? g - a.E : g) * d;
+    float P[NT][NE], M1[NT][NE], M2[NT][NE];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        load_row_e<VEC, G, NV>(P[t], (is_rel ? a.rel[t] : a.ent[t]) + off, d, gl);
+        if constexpr (OPT != KGE_OPT_SGD) load_row_e<VEC, G, NV>(M1[t], (is_rel ? a.s1_rel[t] : a.s1_ent[t]) + off, d, gl);
+        if constexpr (OPT == KGE_OPT_ADAM) load_row_e<VEC, G, NV>(M2[t], (is_rel ? a.s2_rel[t] : a.s2_ent[t]) + off, d, gl);
+        if (!have_g) load_row_e<VEC, G, NV>(gv[t], (is_rel ? a.g_rel[t] : a.g_ent[t]) + off, d, gl);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -487,8 +475,9 @@ static int64_t own_extra_units(const OwnArgs& a) { return a.listed ? (a.dense ? 
 
 int launch_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists, const int32_t* items,
                     int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int dense, float lmbda, int reg_type,
-                    int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern, const uint64_t* slots,
-                    int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss, hipStream_t s) {
+                    int reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern,
+                    const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
+                    float* loss, hipStream_t s) {
     OwnArgs a;
     OwnGeo geo;
     if (fill_own_args(m, nullptr, nullptr, &a, &geo, "kge_own_step")) return -1;
@@ -496,8 +485,8 @@ int launch_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pai
     a.multi = nullptr; a.n_items = n_items; a.n_multi = 0; a.listed = listed; a.n_pairs = (int)n_pairs; a.dense = dense ? 1 : 0;
     a.reset_lists = reset_lists; a.inv_n = 1.0f / (float)(2 * n_pairs); a.lmbda = lmbda; a.reg_type = reg_type;
     a.opt = make_opt_args(0.f, 1);
-    const PullSampleArgs sa = make_sample_args(next_pairs, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots, n_slots,
-                                               seed, next_offset, nullptr, next_lists);
+    const PullSampleArgs sa = make_sample_args(next_pairs, next_inv, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
+                                               n_slots, seed, next_offset, nullptr, next_lists);
     a.sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
     const int64_t units = n_items + own_extra_units(a);
     KGE_OWN_GEO({
@@ -509,9 +498,9 @@ int launch_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pai
 
 template <int OPT>
 static int launch_own_apply_opt(OwnArgs& a, OwnGeo geo, hipStream_t s) {
-    const int64_t units = a.n_items + a.n_multi + own_extra_units(a);
+    const int64_t units = a.n_items + own_extra_units(a);
     KGE_OWN_GEO({
-        const int64_t blocks = (units + kBlock / G - 1) / (kBlock / G);
+        const int64_t blocks = a.n_multi + (units + kBlock / G - 1) / (kBlock / G);
         hipLaunchKernelGGL((k_own_apply<OPT, NT, VEC, G, NV>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
     })
     return check_launch("k_own_apply");

@@ -169,35 +169,14 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
     float nX = 0.f;
     if (g >= 0) {
         const bool is_rel = g >= a.E;
-        const int n_static = it.z - it.y;
-        int cnt = 0, nvis = 0;
-        bool fast_c = true;
-        // ---- the owner's visit list, one descriptor per lane: static incidences first, then the pairs that drew this
-        // entity as their corrupting entity (bucket entries, visited in pair order)
-        int vi = -1, vrole = 0, slot = gl;   // slot: this lane's position in the visit order
-        if (gl < n_static) { const int e = a.inc[it.y + gl]; vi = e >> 2; vrole = e & 3; }
-        // the row's corrupting-entity draws are walked by its first (or only) item
-        const bool walks_c = !is_rel && (kind == 0 || kind == 1 || (kind == 3 && ((it.w >> 2) & 15) == 0));
-        if (walks_c) cnt = a.lists.count[g];
-        fast_c = cnt <= kPullCap && n_static + cnt <= G;
-        nvis = n_static;
-        if (cnt > 0 && fast_c) {
-            const int q = gl - n_static;
-            if (q >= 0 && q < cnt) { vi = a.lists.bucket[(int64_t)g * kPullCap + q]; vrole = kRoleC; }
-            if (cnt > 1) {   // arrival order is arbitrary: rank the entries by pair index, visit by rank
-                int rank = 0;
-                for (int m = 0; m < cnt; ++m) rank += __shfl(vi, gbase + n_static + m, 64) < vi ? 1 : 0;
-                if (q >= 0 && q < cnt) slot = n_static + rank;
-            }
-            nvis += cnt;
-        }
-        if (vi >= 0) {
-            int4 pr = a.pairs[vi];
-            pr.w = a.lists.pc[vi] | (vrole << 25);
-            s_desc[threadIdx.x / G][slot] = pr;
-        }
+        // the owner's row and norm depend on nothing but the item: requested first
         load_row4<G, NV>(X, (is_rel ? a.tab_in[1] : a.tab_in[0]) + (int64_t)(is_rel ? g - a.E : g) * d, nvec, gl);
         nX = a.norm_in[g];
+        int cnt = 0;
+        bool fast_c = true;
+        // the row's corrupting-entity draws are walked by its first (or only) item
+        const bool walks_c = !is_rel && (kind == 0 || kind == 1 || (kind == 3 && ((it.w >> 2) & 15) == 0));
+        const int nvis = own_visit_list<G>(a.lists, it, g, walks_c, gl, gbase, s_desc[threadIdx.x / G], &cnt, &fast_c);
 #pragma unroll
         for (int v = 0; v < NV; ++v) gs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -393,16 +372,22 @@ __global__ __launch_bounds__(256) void k_pull_sample(PullSampleArgs sa) {
 }
 
 // the same registration from explicit negatives (parity tests drive the step with the reference's golden batches)
-__global__ __launch_bounds__(256) void k_pull_lists_explicit(const int4* __restrict__ pairs, const int64_t* __restrict__ nh,
-                                                             const int64_t* __restrict__ nt, int64_t n, PullLists out) {
+__global__ __launch_bounds__(256) void k_pull_lists_explicit(const int4* __restrict__ pairs, const int32_t* __restrict__ inv,
+                                                             const int64_t* __restrict__ nh, const int64_t* __restrict__ nt, int64_t n,
+                                                             PullLists out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const bool tail = nh[i] == pairs[i].x;   // the sampler's own rule (kge_score.hip: my_tail = nh == sh)
+    const int4 p = pairs[i];
+    const bool tail = nh[i] == p.x;   // the sampler's own rule (kge_score.hip: my_tail = nh == sh)
     const int c = (int)(tail ? nt[i] : nh[i]);
     const int pos = atomicAdd(out.count + c, 1);
     out.pc[i] = c | ((int)tail << 24) | ((pos == 0 ? 1 : 0) << kPcFirstBit);
-    if (pos < kPullCap) out.bucket[(int64_t)c * kPullCap + pos] = (int)i;
-    else out.next[i] = atomicExch(out.head + c, (int)i);
+    if (pos < kPullCap) {
+        out.bucket[(int64_t)c * kPullCap + pos] = (int)i;
+        out.dbucket[(int64_t)c * kPullCap + pos] = make_int4(p.x, p.y, p.z, (int)i | ((int)tail << 24) | (kRoleC << 25));
+    } else out.next[i] = atomicExch(out.head + c, (int)i);
+    const int w = c | ((int)tail << 24);
+    for (int role = 0; role < 3; ++role) out.sdesc[inv[3 * i + role]] = make_int4(p.x, p.y, p.z, w | (role << 25));
 }
 
 // ------------------------------------------------------------------ host side
@@ -456,7 +441,7 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
                      const float* norm_in, float* norm_out, float* const state1[2], float* const state2[2], const int32_t* pairs,
                      const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* dense_skip, const int32_t* inc, float* partials,
                      const int32_t* multi, int64_t n_multi, float margin, int optimizer, float lr, int64_t step,
-                     const float* dev_hyper, int reset_lists, const int32_t* next_pairs, int64_t next_n, const float* bern,
+                     const float* dev_hyper, int reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern,
                      const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
                      const kge_pull_lists* next_lists, float* loss, hipStream_t s) {
     const PullGeo geo = pull_geo(m->dim);
@@ -486,7 +471,7 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
     a.theta = m->model == KGE_TRANSM ? m->tables[2] : nullptr;
     a.opt = make_opt_args(lr, step < 1 ? 1 : step);
     a.dev_hyper = dev_hyper;
-    const PullSampleArgs sa = make_sample_args(next_pairs, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
+    const PullSampleArgs sa = make_sample_args(next_pairs, next_inv, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
                                                n_slots, seed, next_offset, nullptr, next_lists);
     switch (optimizer) {
         case KGE_OPT_SGD: return launch_pull_opt<KGE_OPT_SGD>(a, sa, geo, loss, s);
@@ -514,16 +499,16 @@ int launch_row_norms(const float* table, int64_t rows, int dim, float* out, floa
     return -1;
 }
 
-int launch_pull_sample(const int32_t* pairs, int64_t n, int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots,
+int launch_pull_sample(const int32_t* pairs, const int32_t* inv, int64_t n, int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots,
                        uint64_t seed, uint64_t offset, const int64_t* cursor, const kge_pull_lists* out, hipStream_t s) {
-    const PullSampleArgs sa = make_sample_args(pairs, n, E, bern, slots, n_slots, seed, offset, cursor, out);
+    const PullSampleArgs sa = make_sample_args(pairs, inv, n, E, bern, slots, n_slots, seed, offset, cursor, out);
     hipLaunchKernelGGL(k_pull_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sa);
     return check_launch("k_pull_sample");
 }
 
-int launch_pull_lists_explicit(const int32_t* pairs, const int64_t* nh, const int64_t* nt, int64_t n,
+int launch_pull_lists_explicit(const int32_t* pairs, const int32_t* inv, const int64_t* nh, const int64_t* nt, int64_t n,
                                const kge_pull_lists* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_pull_lists_explicit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int4*)pairs, nh, nt, n,
+    hipLaunchKernelGGL(k_pull_lists_explicit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int4*)pairs, inv, nh, nt, n,
                        to_lists(out));
     return check_launch("k_pull_lists_explicit");
 }

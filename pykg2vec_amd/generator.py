@@ -182,6 +182,12 @@ class PullIndex:
         dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
         self._views = [tuple(dev(x[k]) for k in range(4)) for x in built]
         self._skips = [dev(x[5]) for x in built] if self.compact else None
+        self._invs = []
+        for x in built:   # inverse of the sorted incidence list: inv[3 * pair + role] = its position (what the sampler files by)
+            inc = x[1].astype(np.int64)
+            inv = np.empty(len(inc), dtype=np.int32)
+            inv[3 * (inc >> 2) + (inc & 3)] = np.arange(len(inc), dtype=np.int32)
+            self._invs.append(dev(inv))
 
     @classmethod
     def build_on_device(cls, backend, triples, perm, n_batches, batch_stride, slice_lo, n_pairs, tot_entity, tot_relation,
@@ -196,13 +202,18 @@ class PullIndex:
         self.n_batches, self.batch_size = int(n_batches), int(n_pairs)
         out = backend.pull_index_build(triples, perm, batch_stride, slice_lo, n_pairs, n_batches, tot_entity, tot_relation, seg,
                                        groups_per_block, self.compact)
-        pairs, inc, items, multi, skip, counts = out
+        pairs, inc, inv, items, multi, skip, counts = out
+        self._invs = [inv[b] for b in range(self.n_batches)]
         self._storage = out
         cnt = counts.cpu().numpy().reshape(-1, 4)      # the one host read of the build: live slots / rows per batch
         self.max_slots = int(max(1, cnt[:, 2].max())) if len(cnt) else 1
         self._views = [(pairs[b], inc[b], items[b, :int(cnt[b, 0])], multi[b, :int(cnt[b, 1])]) for b in range(self.n_batches)]
         self._skips = [skip[b] for b in range(self.n_batches)] if self.compact else None
         return self
+
+    def inv(self, b):
+        """Inverse of batch b's sorted incidence list: inv[3 * pair + role] = position in `inc`."""
+        return self._invs[b]
 
     def skip(self, b):
         """Bitmap (int32 words) of the rows batch b lists explicitly, or None when its items cover every row."""

@@ -569,7 +569,8 @@ def pull_groups_per_block(dim):
 
 
 class PullListSet:
-    """One kge_pull_lists set: per-step sampler output of the owner-computes step (count all 0 / head all -1 between steps)."""
+    """One kge_pull_lists set: per-step sampler output of the owner-computes steps (count all 0 / head all -1 between steps),
+    incl. the ready-made visit descriptors (sdesc: one per static incidence, dbucket: one per bucket entry)."""
 
     def __init__(self, batch_size, tot_entity, device):
         self.pc = torch.empty(batch_size, dtype=torch.int32, device=device)
@@ -577,27 +578,29 @@ class PullListSet:
         self.count = torch.zeros(tot_entity, dtype=torch.int32, device=device)
         self.bucket = torch.empty(tot_entity * L.PULL_BUCKET, dtype=torch.int32, device=device)
         self.head = torch.full((tot_entity,), -1, dtype=torch.int32, device=device)
+        self.sdesc = torch.empty(3 * batch_size, 4, dtype=torch.int32, device=device)
+        self.dbucket = torch.empty(tot_entity * L.PULL_BUCKET, 4, dtype=torch.int32, device=device)
         self.c = L.PullLists(self.pc.data_ptr(), self.count.data_ptr(), self.bucket.data_ptr(), self.head.data_ptr(),
-                             self.next.data_ptr())
+                             self.next.data_ptr(), self.sdesc.data_ptr(), self.dbucket.data_ptr())
 
     def clear(self):
         self.count.zero_()
         self.head.fill_(-1)
 
 
-def pull_sample(pairs, tot_entity, bern_prob, slots, seed, offset, lists, cursor=None):
+def pull_sample(pairs, inv, tot_entity, bern_prob, slots, seed, offset, lists, cursor=None):
     """Draw the corruption of every pair of a batch (the draws kge_sample_batch makes for the same seed / offset) and
     register each pair with the entity it drew (`lists`: a cleared PullListSet)."""
     bp = _dev(bern_prob, torch.float32, "bern_prob") if bern_prob is not None else None
     sp = ctypes.c_void_p(slots.data_ptr()) if slots is not None else None
     pcur = _dev(cursor, torch.int64, "cursor") if cursor is not None else None
-    L.check(L.load().kge_pull_sample(_i32(pairs, "pairs"), pairs.shape[0], int(tot_entity), bp, sp,
+    L.check(L.load().kge_pull_sample(_i32(pairs, "pairs"), _i32(inv, "inv"), pairs.shape[0], int(tot_entity), bp, sp,
                                      slots.numel() if slots is not None else 0, int(seed) & (2 ** 64 - 1),
                                      int(offset) & (2 ** 64 - 1), pcur, ctypes.byref(lists.c), _stream()), "kge_pull_sample")
 
 
-def pull_lists_explicit(pairs, nh, nt, lists):
-    L.check(L.load().kge_pull_lists_explicit(_i32(pairs, "pairs"), _ids(nh, "nh"), _ids(nt, "nt"), pairs.shape[0],
+def pull_lists_explicit(pairs, inv, nh, nt, lists):
+    L.check(L.load().kge_pull_lists_explicit(_i32(pairs, "pairs"), _i32(inv, "inv"), _ids(nh, "nh"), _ids(nt, "nt"), pairs.shape[0],
                                              ctypes.byref(lists.c), _stream()), "kge_pull_lists_explicit")
 
 
@@ -607,18 +610,18 @@ def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, s
     """One whole training step (scoring, hinge, backward, dense optimiser) without atomics: see csrc/kge_pull.hip.
     desc_in: descriptor over the tables READ; tables_out: [ent, rel] of the other half of the double buffer; hat_in /
     hat_out: the row-normalised copies of both halves.
-    sample_next = (next_pairs, bern_prob, slots, seed, next_offset, next_lists): the sampler of the next batch rides
+    sample_next = (next_pairs, next_inv, bern_prob, slots, seed, next_offset, next_lists): the sampler of the next batch rides
     in this launch and fills `next_lists` (a cleared second PullListSet)."""
     to, s1, s2, hi, ho = _ptr_pair(tables_out), _ptr_pair(state1), _ptr_pair(state2), _ptr_pair(hat_in), _ptr_pair(hat_out)
     # run_finish=False (timing only): the owners still write their partial sums, the finishing launch is skipped
     n_multi = multi.shape[0] if (multi is not None and run_finish) else 0
     if sample_next is not None:
-        npairs, bern, slots, seed, noff, nlists = sample_next
-        nx = (_i32(npairs, "next_pairs"), npairs.shape[0], _dev(bern, torch.float32, "bern_prob") if bern is not None else None,
+        npairs, ninv, bern, slots, seed, noff, nlists = sample_next
+        nx = (_i32(npairs, "next_pairs"), _i32(ninv, "next_inv"), npairs.shape[0], _dev(bern, torch.float32, "bern_prob") if bern is not None else None,
               ctypes.c_void_p(slots.data_ptr()) if slots is not None else None, slots.numel() if slots is not None else 0,
               int(seed) & (2 ** 64 - 1), int(noff) & (2 ** 64 - 1), ctypes.byref(nlists.c))
     else:
-        nx = (None, 0, None, None, 0, 0, 0, None)
+        nx = (None, None, 0, None, None, 0, 0, 0, None)
     args = (
         ctypes.byref(desc_in), ctypes.addressof(to), ctypes.addressof(hi), ctypes.addressof(ho) if hat_out is not None else None,
         _dev(norm_in, torch.float32, "norm_in"),
@@ -649,7 +652,7 @@ def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, s
 def pull_index_build(triples, perm, batch_stride, slice_lo, n_pairs, n_batches, tot_entity, tot_relation, segment,
                      groups_per_block, compact):
     """kge_pull_index_build: the incidence index of `n_batches` batches of the permutation, built on the device.  Returns
-    (pairs [nb, n, 4], inc [nb, 3n], items [nb, item_cap, 4], multi [nb, multi_cap, 4], skip [nb, words] or None,
+    (pairs [nb, n, 4], inc [nb, 3n], inv [nb, 3n], items [nb, item_cap, 4], multi [nb, multi_cap, 4], skip [nb, words] or None,
     counts [nb, 4] = {item slots, multi rows, partial slots, listed rows}) -- int32 device tensors at fixed strides."""
     lib = L.load()
     dev = triples.device
@@ -660,17 +663,17 @@ def pull_index_build(triples, perm, batch_stride, slice_lo, n_pairs, n_batches, 
                                         1 if compact else 0, ctypes.byref(item_cap), ctypes.byref(multi_cap), ctypes.byref(words),
                                         ctypes.byref(ws_bytes)), "kge_pull_index_geometry")
     i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
-    pairs, inc = i32(nb, n, 4), i32(nb, 3 * n)
+    pairs, inc, inv = i32(nb, n, 4), i32(nb, 3 * n), i32(nb, 3 * n)
     items, multi = i32(nb, item_cap.value, 4), i32(nb, multi_cap.value, 4)
     skip = i32(nb, words.value) if compact else None
     counts = i32(nb, 4)
     ws = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
     L.check(lib.kge_pull_index_build(_ids(triples, "triples"), _ids(perm, "perm"), int(batch_stride), int(slice_lo), n, nb,
                                      int(tot_entity), int(tot_relation), int(segment), int(groups_per_block), 1 if compact else 0,
-                                     pairs.data_ptr(), inc.data_ptr(), items.data_ptr(), multi.data_ptr(),
+                                     pairs.data_ptr(), inc.data_ptr(), inv.data_ptr(), items.data_ptr(), multi.data_ptr(),
                                      skip.data_ptr() if skip is not None else None, counts.data_ptr(), ws.data_ptr(), ws.numel(),
                                      _stream()), "kge_pull_index_build")
-    return pairs, inc, items, multi, skip, counts
+    return pairs, inc, inv, items, multi, skip, counts
 
 
 class PullPlan:
@@ -696,7 +699,7 @@ class PullPlan:
             pairs, inc, items, multi = index.batch(b)
             skip = index.skip(b)
             self.batches[b] = L.PullBatch(pairs.data_ptr(), items.data_ptr(), items.shape[0],
-                                          skip.data_ptr() if skip is not None else None, inc.data_ptr(),
+                                          skip.data_ptr() if skip is not None else None, inc.data_ptr(), index.inv(b).data_ptr(),
                                           multi.data_ptr() if multi.shape[0] else None, multi.shape[0], pairs.shape[0])
         c.batches = ctypes.cast(self.batches, ctypes.POINTER(L.PullBatch))
         c.n_batches = index.n_batches
@@ -737,12 +740,12 @@ def _ptr_array(tensors, n=L.KGE_MAX_TABLES):
 def own_step(desc, pairs, lists, items, listed, inc, partials, dense, lmbda, reg_type, loss_buf, reset_lists=True, sample_next=None):
     """Phase 1 (kge_own_step): gradient rows of every touched parameter row into desc.grads, no atomics."""
     if sample_next is not None:
-        npairs, bern, slots, seed, noff, nlists = sample_next
-        nx = (_i32(npairs, "next_pairs"), npairs.shape[0], _dev(bern, torch.float32, "bern_prob") if bern is not None else None,
+        npairs, ninv, bern, slots, seed, noff, nlists = sample_next
+        nx = (_i32(npairs, "next_pairs"), _i32(ninv, "next_inv"), npairs.shape[0], _dev(bern, torch.float32, "bern_prob") if bern is not None else None,
               ctypes.c_void_p(slots.data_ptr()) if slots is not None else None, slots.numel() if slots is not None else 0,
               int(seed) & (2 ** 64 - 1), int(noff) & (2 ** 64 - 1), ctypes.byref(nlists.c))
     else:
-        nx = (None, 0, None, None, 0, 0, 0, None)
+        nx = (None, None, 0, None, None, 0, 0, 0, None)
     L.check(L.load().kge_own_step(ctypes.byref(desc), _i32(pairs, "pairs"), pairs.shape[0], ctypes.byref(lists.c), _i32(items, "items"),
                                   items.shape[0], _i32(listed, "listed") if listed is not None else None, _i32(inc, "inc"),
                                   _dev(partials, torch.float32, "partials"), 1 if dense else 0, float(lmbda), int(reg_type),
@@ -781,7 +784,7 @@ class OwnPlan:
             pairs, inc, items, multi = index.batch(b)
             skip = index.skip(b)
             self.batches[b] = L.PullBatch(pairs.data_ptr(), items.data_ptr(), items.shape[0],
-                                          skip.data_ptr() if skip is not None else None, inc.data_ptr(),
+                                          skip.data_ptr() if skip is not None else None, inc.data_ptr(), index.inv(b).data_ptr(),
                                           multi.data_ptr() if multi.shape[0] else None, multi.shape[0], pairs.shape[0])
         c.batches = ctypes.cast(self.batches, ctypes.POINTER(L.PullBatch))
         c.n_batches = index.n_batches

@@ -343,22 +343,22 @@ class Trainer:
         cur = ps.cur_list
         if ps.ready != (b, offset):
             ps.lists[cur].clear()
-            K.pull_sample(pairs, cfg.tot_entity, gen.bern, gen.slots, gen.seed, offset, ps.lists[cur])
+            K.pull_sample(pairs, idx.inv(b), cfg.tot_entity, gen.bern, gen.slots, gen.seed, offset, ps.lists[cur])
         nxt = None
         if gen._pending > 0 and b + 1 < idx.n_batches:   # the next batch's sampler rides in this launch
             per = idx.batch_size
             off_next = gen._draws + self.rank * per * gen.neg_rate
-            nxt = (idx.batch(b + 1)[0], gen.bern, gen.slots, gen.seed, off_next, ps.lists[cur ^ 1])
+            nxt = (idx.batch(b + 1)[0], idx.inv(b + 1), gen.bern, gen.slots, gen.seed, off_next, ps.lists[cur ^ 1])
         key = (b, cur, nxt is not None)
         call = ps.calls.get(key)
         if call is None:   # arguments marshalled once per (batch, list set); only the ride-along Philox offset changes per epoch
             call = ps.calls[key] = K.pull_step(self._desc, ps.tables[1], ps.hats[0], None, ps.norms[0], None, None, None, pairs,
                                                ps.lists[cur], items, inc, ps.partials, multi, cfg.margin, "gradient", 0.0, 1,
                                                self.loss_buf, sample_next=nxt, dense_skip=idx.skip(b), prepare_only=True)
-        call(nxt[4] if nxt is not None else None)
+        call(nxt[5] if nxt is not None else None)
         if nxt is not None:
             ps.cur_list ^= 1
-            ps.ready = (b + 1, nxt[4])
+            ps.ready = (b + 1, nxt[5])
         else:
             ps.ready = None
         self._reduce_and_step(clear_local_grad=False)   # every row of the local gradient is rewritten by the next step
@@ -419,7 +419,7 @@ class Trainer:
         ps.sync_in()
         pairs, inc, items, multi = idx.batch(0)
         skip = idx.skip(0)
-        K.pull_lists_explicit(pairs, nh.contiguous(), nt.contiguous(), ps.lists[0])
+        K.pull_lists_explicit(pairs, idx.inv(0), nh.contiguous(), nt.contiguous(), ps.lists[0])
         self.flat.step += 1
         desc = K.make_desc(self.model.kernel_name, ps.tables[0] + self._pull_fixed_tables(), None, tot_entity=self.config.tot_entity,
                            tot_relation=self.config.tot_relation, **self.model.desc_kwargs())
@@ -447,11 +447,15 @@ class Trainer:
             return self.switches["pw_pull"]
         if self.switches["staged"] is not None:    # an explicit KGE_STAGED=0 / 1 asks for the atomic / staged A/B pair
             return False
-        # Owners re-evaluate every bundle their row occurs in: that pays while a batch touches the tables sparsely (C2: 1.4
-        # bundles per touched row, 75 vs 114 us per step) and loses once every row collects many incidences (DistMult FB15k
-        # B = 32768: 6.6 per row, 115 vs 99 us).  The rule is the compact-index rule: a batch lists at most half of the rows.
+        # Measured against the atomic-scatter step (profiles/r03_own_vs_atomic.md): the two-phase step wins beyond the hipGraph
+        # regime (DistMult FB15k B = 32768: 70 vs 98 us) and wherever a batch touches the tables sparsely (C2: 72 vs 113 us;
+        # YAGO3-10 shape B = 8192: 94 vs 152 us); the graph-replayed atomic step keeps the small dense batches (DistMult FB15k
+        # B = 4096: 32 vs 38 us) and the launch-bound B = 128 presets.
         from .generator import PullIndex
-        return PullIndex._compact_rule(int(self.config.batch_size), int(self.config.tot_entity) + int(self.config.tot_relation))
+        B = int(self.config.batch_size)
+        rows = B * (1 + int(self.config.neg_rate))
+        sparse = PullIndex._compact_rule(B, int(self.config.tot_entity) + int(self.config.tot_relation))
+        return rows > self.GRAPH_MAX_ROWS or (sparse and B >= 1024)
 
     def _own_dense(self):
         return self.config.optimizer in ("adam", "rms")   # optimisers that move every row every step
@@ -520,7 +524,7 @@ class Trainer:
         pairs, inc, items, multi = idx.batch(0)
         dev = flat.param.device
         lists = K.PullListSet(len(pos), cfg.tot_entity, dev)
-        K.pull_lists_explicit(pairs, h[1::2].contiguous(), t[1::2].contiguous(), lists)
+        K.pull_lists_explicit(pairs, idx.inv(0), h[1::2].contiguous(), t[1::2].contiguous(), lists)
         gbuf = torch.empty_like(flat.param)
         off = [v.data_ptr() - flat.param.data_ptr() for v in flat.views]
         view = lambda buf: [buf[o // 4:o // 4 + v.numel()].view_as(v) for o, v in zip(off, flat.views)]

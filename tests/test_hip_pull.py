@@ -178,7 +178,7 @@ def test_gradient_mode_equals_the_atomic_gradient(hip, world, l1, monkeypatch):
     ps = PullState(tr.flat, m, idx.batch_size, idx.max_slots, grad_only=True)
     ps.refresh_norms()
     pairs, inc, items, multi = idx.batch(0)
-    K.pull_sample(pairs, E, gen.bern, gen.slots, gen.seed, 0, ps.lists[0])
+    K.pull_sample(pairs, idx.inv(0), E, gen.bern, gen.slots, gen.seed, 0, ps.lists[0])
     tr.flat.grad.fill_(7.0)                          # every row must be overwritten
     tr.loss_buf.zero_()
     K.pull_step(tr._desc, ps.tables[1], ps.hats[0], None, ps.norms[0], None, None, None, pairs, ps.lists[0], items, inc,
@@ -217,5 +217,6 @@ def test_device_built_index_equals_the_numpy_one(hip, E, R, B, nb, seg, gpb, com
             a, d = a.numpy(), d.cpu().numpy()
             assert a.shape == d.shape, (b, name, a.shape, d.shape)
             assert np.array_equal(a, d), (b, name, np.flatnonzero((a != d).reshape(len(a), -1).any(1))[:8])
+        assert np.array_equal(host.inv(b).numpy(), devx.inv(b).cpu().numpy())
         if host.compact:
             assert np.array_equal(host.skip(b).numpy(), devx.skip(b).cpu().numpy())

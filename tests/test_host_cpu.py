@@ -233,7 +233,8 @@ def test_pull_plan_struct_layout_matches_the_library():
     from pykg2vec_amd import _lib
     lib = _lib.load()
     assert lib.kge_pull_plan_bytes() == ctypes.sizeof(_lib.PullPlanC)
-    assert ctypes.sizeof(_lib.PullBatch) == 64 and ctypes.sizeof(_lib.PullLists) == 40
+    assert ctypes.sizeof(_lib.PullBatch) == 72 and ctypes.sizeof(_lib.PullLists) == 56
+    assert lib.kge_own_plan_bytes() == ctypes.sizeof(_lib.OwnPlanC)
     assert lib.kge_staged_step_bytes() == ctypes.sizeof(_lib.StagedStep)
     assert lib.kge_pull_partial_stride(100) == 128 and lib.kge_pull_partial_stride(102) == 0   # rows move as float4
     assert lib.kge_pull_groups_per_block(100) in (8, 16) and lib.kge_pull_groups_per_block(1000) == 8
