@@ -96,8 +96,8 @@ int kge_rescal_normalize(float* ent, int64_t tot_entity, float* rel, int64_t tot
 /* The same with a caller-owned scratch (kge_rescal_normalize_scratch_bytes): long relation-matrix rows are then normalised
  * by many workgroups per row (partial sums of squares per 4096-float chunk, added in chunk order) instead of one. */
 size_t kge_rescal_normalize_scratch_bytes(int64_t tot_relation, int32_t k);
-int kge_rescal_normalize_ws(float* ent, int64_t tot_entity, float* rel, int64_t tot_relation, int32_t k, void* scratch,
-                            size_t scratch_bytes, void* stream);
+int kge_rescal_normalize_ws(float* ent /* NULL: relation matrices only */, int64_t tot_entity, float* rel, int64_t tot_relation,
+                            int32_t k, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Fused Trainer.train_step_pairwise (utils/trainer.py:147-157) with Criterion.pairwise_hinge
  * (utils/criterion.py:25-29): scores both triples of each of the n pairs, adds sum(max(0, s+ + margin - s-))
@@ -167,6 +167,15 @@ int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, f
                        int64_t numel, float lr, int64_t step, int32_t zero_grad,
                        const float* dev_hyper /* NULL, or device {lr, step_size, bc2_sqrt} from kge_step_advance */,
                        void* stream);
+
+/* The same optimiser with one wave per table ROW, optionally followed by the row renormalisation Rescal.embed applies to its
+ * tables at the start of the NEXT forward (pairwise.py:843-844,862-865: W <- W / ||W_row||_2): normalize != 0 stores the
+ * renormalised row, so the next step's kge_rescal_normalize pass over this table (a full read + write of it) disappears.  The
+ * result equals kge_optimizer_step followed by kge_rescal_normalize up to the fp32 summation order of the row norm.  A caller must leave
+ * normalize == 0 on the last step before the tables are observed (the reference leaves them as the optimiser wrote them).
+ * rows of at most 1024 floats. */
+int kge_optimizer_step_rows(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
+                            float lr, int64_t step, int32_t zero_grad, int32_t normalize, const float* dev_hyper, void* stream);
 
 /* NTN.get_reg (pairwise.py:962-963): loss += lmbda * sqrt(sum_i param[i]^2), grad += lmbda * param / that root, over
  * ONE flat buffer holding every table of the model (pad with zeros).  scratch: 1 float. */

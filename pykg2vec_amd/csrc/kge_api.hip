@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <cstdlib>
 #include "kge_internal.h"
 
 namespace kge {
@@ -147,7 +148,7 @@ size_t kge_rescal_normalize_scratch_bytes(int64_t tot_relation, int32_t k) {
 
 int kge_rescal_normalize_ws(float* ent, int64_t tot_entity, float* rel, int64_t tot_relation, int32_t k, void* scratch,
                             size_t scratch_bytes, void* stream) {
-    if (!ent || !rel || k <= 0) { set_error("kge_rescal_normalize_ws: bad arguments"); return -1; }
+    if (!rel || k <= 0) { set_error("kge_rescal_normalize_ws: bad arguments"); return -1; }
     return launch_rescal_normalize(ent, tot_entity, rel, tot_relation, k, (float*)scratch, scratch_bytes / sizeof(float),
                                    (hipStream_t)stream);
 }
@@ -171,6 +172,10 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
     float* sn = sp + n;
     int rc;
     if (m->model == KGE_RESCAL) {
+        // nr == pr (the same buffer: the caller's way of saying that negatives keep their positives' relations, as every sampler
+        // of the reference does): scores, hinge and gradients of a (relation, 16 pairs) tile in one launch
+        if (nr == pr && rescal_pair_step_ok(m, n, 2 * gws) && !getenv("KGE_RESCAL_UNFUSED"))
+            return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, wsp, 2 * gws, s);
         // positives and negatives as ONE grouped batch of 2n triples (scores / coefficients contiguous: sp | sn); the
         // region of the two per-side workspaces holds the grouping of 2n triples (group_ws_bytes(R, 2n) <= 2 gws)
         if ((rc = launch_rescal_pair_forward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s))) return rc;
@@ -361,6 +366,14 @@ int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, f
     if (numel == 0) return 0;
     return launch_optimizer(kind, param, grad, state1, state2, numel, lr, step < 1 ? 1 : step, zero_grad, dev_hyper,
                             nullptr, nullptr, nullptr, 0, 1, 0, (hipStream_t)stream);
+}
+
+int kge_optimizer_step_rows(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
+                            float lr, int64_t step, int32_t zero_grad, int32_t normalize, const float* dev_hyper, void* stream) {
+    if (!param || !grad || rows < 0 || dim <= 0 || dim > 1024 || (step < 1 && !dev_hyper)) { set_error("kge_optimizer_step_rows: bad arguments (rows of at most 1024 floats)"); return -1; }
+    if (rows == 0) return 0;
+    return launch_optimizer_rows(kind, param, grad, state1, state2, rows, dim, lr, step < 1 ? 1 : step, zero_grad, normalize, dev_hyper,
+                                 (hipStream_t)stream);
 }
 
 int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,

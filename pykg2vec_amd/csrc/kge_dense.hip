@@ -27,13 +27,13 @@ __global__ void k_rel_hist(IdSplit r, int64_t n, int* __restrict__ counts) {
 
 // single block: exclusive scans of counts and of ceil(counts / TILE)
 __global__ __launch_bounds__(256) void k_rel_scan(const int* __restrict__ counts, int R, int* __restrict__ offsets,
-                                                  int* __restrict__ tile_off) {
+                                                  int* __restrict__ tile_off, int tile) {
     __shared__ int s_a[256], s_b[256];
     int run_a = 0, run_b = 0;
     for (int base = 0; base < R; base += 256) {
         const int idx = base + threadIdx.x;
         const int c = idx < R ? counts[idx] : 0;
-        const int tl = (c + TILE - 1) / TILE;
+        const int tl = (c + tile - 1) / tile;
         s_a[threadIdx.x] = c; s_b[threadIdx.x] = tl;
         __syncthreads();
         for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan
@@ -52,26 +52,91 @@ __global__ __launch_bounds__(256) void k_rel_scan(const int* __restrict__ counts
 
 __global__ void k_rel_scatter(IdSplit r, int64_t n, const int* __restrict__ offsets,
                               const int* __restrict__ tile_off, int* __restrict__ cursor, int* __restrict__ perm,
-                              int* __restrict__ tile_rel) {
+                              int* __restrict__ tile_rel, int tile) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int rel = (int)r.at(i);
     const int local = atomicAdd(cursor + rel, 1);
     perm[offsets[rel] + local] = (int)i;
-    if (local % TILE == 0) tile_rel[tile_off[rel] + local / TILE] = rel;  // the first row of a tile names its relation
+    if (local % tile == 0) tile_rel[tile_off[rel] + local / tile] = rel;  // the first row of a tile names its relation
 }
 
 int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s) {
     return group_by_relation_split(id_whole(r, n), n, R, g, s);
 }
 
-int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s) {
+// Small batches (the reference's own batch sizes: a few thousand triples): histogram, both scans and the scatter in ONE launch
+// of one 1024-thread workgroup with the counters in LDS -- instead of a memset and three dependent launches whose atomics all
+// hit the same few dozen global counters (measured 10.6 + 4.7 + 10.6 us at the C4 shape, plus the gaps between them).
+constexpr int kSmallGroupMaxR = 4096;      // relations whose three int arrays fit the workgroup's LDS (48 KB)
+constexpr int kSmallGroupMaxN = 16384;
+__global__ __launch_bounds__(1024) void k_rel_group_small(IdSplit r, int n, int R, int* __restrict__ offsets, int* __restrict__ tile_off,
+                                                          int* __restrict__ perm, int* __restrict__ tile_rel,
+                                                          float* __restrict__ zero_buf, int zero_n, int tile) {
+    for (int i = threadIdx.x; i < zero_n; i += 1024) zero_buf[i] = 0.f;   // (the scorer's accumulation target: saves a memset launch)
+    extern __shared__ int s_grp[];
+    int* s_cnt = s_grp;            // [R]   counts, then scatter cursors
+    int* s_off = s_cnt + R;        // [R+1] first grouped position of each relation
+    int* s_toff = s_off + R + 1;   // [R+1] first tile of each relation
+    __shared__ int s_wave[2][16];
+    __shared__ int s_carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < R; i += 1024) s_cnt[i] = 0;
+    if (tid < 2) s_carry[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&s_cnt[(int)r.at(i)], 1);
+    __syncthreads();
+    for (int base = 0; base < R; base += 1024) {   // exclusive scans of counts and of ceil(counts / TILE), 1024 relations per pass
+        const int idx = base + tid;
+        const int c = idx < R ? s_cnt[idx] : 0;
+        const int tl = (c + tile - 1) / tile;
+        int xa = c, xb = tl;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int ya = __shfl_up(xa, o, 64), yb = __shfl_up(xb, o, 64);
+            if (lane >= o) { xa += ya; xb += yb; }
+        }
+        if (lane == 63) { s_wave[0][wave] = xa; s_wave[1][wave] = xb; }
+        __syncthreads();
+        if (tid < 2) {
+            int acc = s_carry[tid];
+            for (int w = 0; w < 16; ++w) { const int t = s_wave[tid][w]; s_wave[tid][w] = acc; acc += t; }
+            s_carry[tid] = acc;
+        }
+        __syncthreads();
+        if (idx < R) {
+            const int oa = xa - c + s_wave[0][wave], ob = xb - tl + s_wave[1][wave];
+            s_off[idx] = oa; s_toff[idx] = ob; offsets[idx] = oa; tile_off[idx] = ob;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { s_off[R] = s_carry[0]; s_toff[R] = s_carry[1]; offsets[R] = s_carry[0]; tile_off[R] = s_carry[1]; }
+    for (int i = tid; i < R; i += 1024) s_cnt[i] = 0;   // now the scatter cursors
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int rel = (int)r.at(i);
+        const int local = atomicAdd(&s_cnt[rel], 1);
+        perm[s_off[rel] + local] = i;
+        if (local % tile == 0) tile_rel[s_toff[rel] + local / tile] = rel;
+    }
+}
+
+int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s, float* zero_buf, int64_t zero_n, int tile) {
+    if (n <= kSmallGroupMaxN && R <= kSmallGroupMaxR && zero_n <= kSmallGroupMaxN) {
+        hipLaunchKernelGGL(k_rel_group_small, dim3(1), dim3(1024), (size_t)(3 * R + 2) * sizeof(int), s, r, (int)n, (int)R, g.offsets,
+                           g.tile_off, g.perm, g.tile_rel, zero_buf, (int)(zero_buf ? zero_n : 0), tile);
+        return check_launch("k_rel_group_small");
+    }
+    if (zero_buf && zero_n > 0) {
+        hipError_t ez = hipMemsetAsync(zero_buf, 0, (size_t)zero_n * sizeof(float), s);
+        if (ez != hipSuccess) { set_error("grouping: memset: %s", hipGetErrorString(ez)); return -2; }
+    }
     hipError_t e = hipMemsetAsync(g.counts, 0, (size_t)2 * (R + 1) * sizeof(int), s);  // counts + cursor
     if (e != hipSuccess) { set_error("rescal grouping memset: %s", hipGetErrorString(e)); return -2; }
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_rel_hist, dim3(nb), dim3(256), 0, s, r, n, g.counts);
-    hipLaunchKernelGGL(k_rel_scan, dim3(1), dim3(256), 0, s, g.counts, (int)R, g.offsets, g.tile_off);
-    hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(256), 0, s, r, n, g.offsets, g.tile_off, g.cursor, g.perm, g.tile_rel);
+    hipLaunchKernelGGL(k_rel_scan, dim3(1), dim3(256), 0, s, g.counts, (int)R, g.offsets, g.tile_off, tile);
+    hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(256), 0, s, r, n, g.offsets, g.tile_off, g.cursor, g.perm, g.tile_rel, tile);
     return check_launch("rescal grouping");
 }
 
@@ -107,90 +172,87 @@ __global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, c
         sSc[threadIdx.x] = 0.f;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < TILE * k; idx += 256) {  // coalesced row gathers into LDS
-        const int i = idx / k, c = idx - i * k;
-        const bool ok = i < cnt;
-        sT[i * S + c] = ok ? ent[sTid[i] * k + c] : 0.f;
-        sH[i * S + c] = ok ? ent[sHid[i] * k + c] : 0.f;
+    if ((k & 3) == 0) {
+        // row gathers into LDS, 16 bytes per load, ALL of a thread's loads issued before the first LDS store: one memory round trip
+        // for the whole tile instead of one per 256 elements (the staging loop used to be most of this kernel at small batches)
+        const int nv = k >> 2;                       // float4 per row
+        constexpr int kMaxPer = 16;                  // TILE * nv / 256 float4 per thread and matrix (k <= 512)
+        float4 rt[kMaxPer], rh[kMaxPer];
+#pragma unroll
+        for (int j = 0; j < kMaxPer; ++j) {
+            const int idx = threadIdx.x + 256 * j;
+            const int i = idx / nv, c = idx - i * nv;
+            const bool ok = idx < TILE * nv && i < cnt;
+            rt[j] = ok ? reinterpret_cast<const float4*>(ent + sTid[i] * k)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rh[j] = ok ? reinterpret_cast<const float4*>(ent + sHid[i] * k)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxPer; ++j) {
+            const int idx = threadIdx.x + 256 * j;
+            if (idx < TILE * nv) {
+                const int i = idx / nv, c = (idx - i * nv) * 4;
+                float* dt = sT + i * S + c;
+                float* dh = sH + i * S + c;
+                dt[0] = rt[j].x; dt[1] = rt[j].y; dt[2] = rt[j].z; dt[3] = rt[j].w;
+                dh[0] = rh[j].x; dh[1] = rh[j].y; dh[2] = rh[j].z; dh[3] = rh[j].w;
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < TILE * k; idx += 256) {  // coalesced row gathers into LDS
+            const int i = idx / k, c = idx - i * k;
+            const bool ok = i < cnt;
+            sT[i * S + c] = ok ? ent[sTid[i] * k + c] : 0.f;
+            sH[i * S + c] = ok ? ent[sHid[i] * k + c] : 0.f;
+        }
     }
     __syncthreads();
     const float* M = relm + (int64_t)rel * k * k;
     const int ntile = (k + 31) / 32;
     const int li = lane & 31, lk = lane >> 5;
 
-    // Work units of this tile, dealt round-robin to the 4*gridDim.y waves that share it:
-    //   [0, ntile)              U = T M^T  column tile `at`   (forward score / grad_h)
-    //   [ntile, 2 ntile)        V = H M    column tile `bt`   (grad_t)
-    //   [2 ntile, 2 ntile + ntile^2)   G = (ds*H)^T T  tile (at, bt)   (grad_M)
-    const int n_units = MODE == 0 ? ntile : 2 * ntile + ntile * ntile;
-    float* gM = MODE == 1 ? g_rel + (int64_t)rel * k * k : nullptr;
-    for (int u = blockIdx.y * 4 + wave; u < n_units; u += 4 * gridDim.y) {
-        if (MODE == 1 && u < ntile) {  // ---- U[i][a] = sum_b T[i][b] M[a][b] ;  grad_h = -ds U
-            const int a = u * 32 + li;
-            f32x16 acc = {0};
-            // (lane a reads M[a][b]: a 4-byte gather over 32 rows.  Staging the rows through LDS and a transposed copy of M
-            // were both measured and did not pay: the unit is bound by the dependent-load latency, not by the sectors)
-            for (int k0 = 0; k0 < k; k0 += 16) {  // fixed-trip inner loop: 8 operand loads in flight
-                float av[8], bv[8];
+    // Work units of this tile, one (or four) per workgroup along gridDim.y:
+    //   y in [0, ntile)              U = T M^T  column tile   (backward: grad_h)      } the four waves of the workgroup SPLIT K
+    //   y in [ntile, 2 ntile)        V = H M    column tile   (forward score / grad_t) } (k/4 each) and add their accumulators
+    // (the relation-matrix gradient G = (ds*H)^T T has its own relation-owner kernel, k_rescal_gm)
+    // At the reference's batch sizes a tile is a handful of MFMA steps behind a chain of dependent operand loads: the chain, not
+    // the matrix pipe, is the cost, so it is cut four ways (37 -> ~12 us forward, 50 -> ~20 us backward at the C4 shape).
+    float* sAcc = (float*)(sTid + TILE);       // [4][16][64] accumulators of the K split
+    const int kq = ((k + 7) / 8) * 2;          // K span of one wave (even: an MFMA step takes two k)
+    const int k_lo = wave * kq, k_hi = min(k, k_lo + kq);
+    const int y = blockIdx.y;
+    const bool unit_u = MODE == 1 && y < ntile;
+    const bool unit_v = MODE == 0 ? y < ntile : (y >= ntile && y < 2 * ntile);
+    if (unit_u || unit_v) {
+        const int ct = unit_u ? y : (MODE == 0 ? y : y - ntile);
+        const int col = ct * 32 + li;      // U: a (row of M);  V: b (column of M)
+        const float* sX = unit_u ? sT : sH;
+        f32x16 acc = {0};
+        for (int k0 = k_lo; k0 < k_hi; k0 += 16) {  // fixed-trip inner loop: 8 operand loads in flight
+            float av[8], bv[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int b = k0 + 2 * q + lk;
-                    av[q] = b < k ? sT[li * S + b] : 0.f;
-                    bv[q] = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+            for (int q = 0; q < 8; ++q) {
+                const int kk = k0 + 2 * q + lk;
+                const bool on = kk < k_hi;
+                av[q] = on ? sX[li * S + kk] : 0.f;
+                // U[i][a] = sum_b T[i][b] M[a][b] (lane a reads M[a][b]: a 4-byte gather over 32 rows); V[i][b] = sum_a H[i][a] M[a][b]
+                bv[q] = (on && col < k) ? (unit_u ? M[(int64_t)col * k + kk] : M[(int64_t)kk * k + col]) : 0.f;
             }
-            if (a < k) {
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                    if (i < cnt && sDs[i] != 0.f) unsafeAtomicAdd(g_ent + sHid[i] * k + a, -sDs[i] * acc[reg]);   // grad_h = -ds U
-                }
-            }
-        } else if (MODE == 0 || u < 2 * ntile) {  // ---- V[i][b] = sum_a H[i][a] M[a][b]  (M rows read coalesced)
-            // MODE 0: score_i = -V_i . t_i ;  MODE 1: grad_t = -ds V
-            const int b = (MODE == 0 ? u : u - ntile) * 32 + li;
-            f32x16 acc = {0};
-            for (int k0 = 0; k0 < k; k0 += 16) {
-                float av[8], bv[8];
+            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+        }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int a = k0 + 2 * u + lk;
-                    av[u] = a < k ? sH[li * S + a] : 0.f;
-                    bv[u] = (a < k && b < k) ? M[(int64_t)a * k + b] : 0.f;
-                }
+        for (int reg = 0; reg < 16; ++reg) sAcc[(wave * 16 + reg) * 64 + lane] = acc[reg];
+        __syncthreads();
+        if (wave == 0 && col < k) {   // the four K shares, added in wave order
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-            }
-            if (b < k) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                    if (MODE == 0) {
-                        atomicAdd(&sSc[i], sT[i * S + b] * acc[reg]);          // LDS atomic: score_i += V[i][b] t_i[b]
-                    } else if (i < cnt && sDs[i] != 0.f) {
-                        unsafeAtomicAdd(g_ent + sTid[i] * k + b, -sDs[i] * acc[reg]);
-                    }
-                }
-            }
-        } else {  // ---- G[a][b] = sum_i ds_i H[i][a] T[i][b] ;  grad_M = -G
-            const int tl = u - 2 * ntile;
-            const int at = tl / ntile, bt = tl - at * ntile;
-            const int a_in = at * 32 + li, b_in = bt * 32 + li;
-            f32x16 acc = {0};
-#pragma unroll 4
-            for (int kk = 0; kk < TILE; kk += 2) {
-                const int i = kk + lk;
-                const float av = a_in < k ? sDs[i] * sH[i * S + a_in] : 0.f;
-                const float bv = b_in < k ? sT[i * S + b_in] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-            }
-            if (b_in < k) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int a = at * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                    if (a < k && acc[reg] != 0.f) unsafeAtomicAdd(gM + (int64_t)a * k + b_in, -acc[reg]);
+            for (int reg = 0; reg < 16; ++reg) {
+                const float v = ((sAcc[(0 * 16 + reg) * 64 + lane] + sAcc[(1 * 16 + reg) * 64 + lane]) + sAcc[(2 * 16 + reg) * 64 + lane]) +
+                                sAcc[(3 * 16 + reg) * 64 + lane];
+                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                if (MODE == 0) {
+                    atomicAdd(&sSc[i], sT[i * S + col] * v);          // LDS atomic: score_i += V[i][b] t_i[b]
+                } else if (i < cnt && sDs[i] != 0.f) {
+                    unsafeAtomicAdd(g_ent + (unit_u ? sHid[i] : sTid[i]) * k + col, -sDs[i] * v);   // grad_h = -ds U ; grad_t = -ds V
                 }
             }
         }
@@ -202,10 +264,69 @@ __global__ __launch_bounds__(256) void k_rescal(const float* __restrict__ ent, c
     }
 }
 
+// grad_M[rel] -= sum_i ds_i h_i t_i^T, relation-owner form: the workgroup of a relation's FIRST tile of every run of kGmRun tiles
+// walks that run's triples (32 per round trip: both operand rows of 16 MFMA steps in flight) and owns the 32x32 output tiles its
+// four waves hold, so a relation with at most kGmRun tiles (every relation at the reference's batch sizes) is accumulated with
+// plain read-modify-writes in a fixed order -- no float atomics, no 40 000 atomics per 32 triples.  Longer relations (skewed
+// large batches) split into runs that add atomically.
+constexpr int kGmRun = 8;
+__global__ __launch_bounds__(256) void k_rescal_gm(const float* __restrict__ ent, float* __restrict__ g_rel, IdSplit h, IdSplit t,
+                                                   const int* __restrict__ offsets, const int* __restrict__ tile_off,
+                                                   const int* __restrict__ tile_rel, const int* __restrict__ perm, int R, int k,
+                                                   const float* __restrict__ dscore) {
+    __shared__ float sDs[TILE];
+    __shared__ long long sHid[TILE], sTid[TILE];
+    int rel, tin;
+    if (!locate_tile(tile_off, tile_rel, R, blockIdx.x, rel, tin)) return;
+    if (tin % kGmRun) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int ntile = (k + 31) / 32;
+    const int tl = blockIdx.y * 4 + wave;
+    const bool live = tl < ntile * ntile;
+    const int at = live ? tl / ntile : 0, bt = live ? tl - at * ntile : 0;
+    const int a_in = at * 32 + li, b_in = bt * 32 + li;
+    const int r0 = offsets[rel], r1 = offsets[rel + 1];
+    const int g_lo = r0 + tin * TILE, g_hi = min(r1, g_lo + kGmRun * TILE);
+    const bool shared_rel = (r1 - r0) > kGmRun * TILE;     // other runs of this relation add to the same matrix
+    f32x16 acc = {0};
+    for (int g0 = g_lo; g0 < g_hi; g0 += TILE) {
+        __syncthreads();
+        if (threadIdx.x < TILE) {
+            const int row = g0 + (int)threadIdx.x < g_hi ? perm[g0 + threadIdx.x] : -1;
+            sHid[threadIdx.x] = row >= 0 ? h.at(row) : 0;
+            sTid[threadIdx.x] = row >= 0 ? t.at(row) : 0;
+            sDs[threadIdx.x] = row >= 0 ? dscore[row] : 0.f;
+        }
+        __syncthreads();
+        if (!live) continue;
+        float av[TILE / 2], bv[TILE / 2];
+#pragma unroll
+        for (int q = 0; q < TILE / 2; ++q) {
+            const int i = 2 * q + lk;
+            const float ds = sDs[i];
+            av[q] = (ds != 0.f && a_in < k) ? ent[sHid[i] * k + a_in] : 0.f;
+            bv[q] = (ds != 0.f && b_in < k) ? ent[sTid[i] * k + b_in] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < TILE / 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sDs[2 * q + lk] * av[q], bv[q], acc, 0, 0, 0);
+    }
+    if (!live || b_in >= k) return;
+    float* gM = g_rel + (int64_t)rel * k * k;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int a = at * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+        if (a < k && acc[reg] != 0.f) {
+            float* p = gM + (int64_t)a * k + b_in;
+            if (shared_rel) unsafeAtomicAdd(p, -acc[reg]); else *p -= acc[reg];
+        }
+    }
+}
+
 static size_t rescal_lds_bytes(int k) {
     const int S = (k + 1) | 1;
     return (size_t)(2 * TILE * S + 2 * TILE) * sizeof(float) + (size_t)(TILE + (TILE & 1)) * sizeof(int) +
-           (size_t)2 * TILE * sizeof(long long);
+           (size_t)2 * TILE * sizeof(long long) + (size_t)4 * 16 * 64 * sizeof(float);   // + the K-split accumulators
 }
 
 
@@ -228,9 +349,11 @@ static int rescal_run(int mode, const kge_model_desc* m, IdSplit h, IdSplit r, I
         return -1;
     }
     const GroupWs g = carve_group_ws(ws, R, n);
+    bool zeroed = false;
     if (!grouped) {  // the fused train step's backward reuses the grouping its forward left in this workspace
-        int rc = group_by_relation_split(r, n, R, g, s);
+        int rc = group_by_relation_split(r, n, R, g, s, mode == 0 ? scores : nullptr, mode == 0 ? n : 0);   // (+ clears the score buffer)
         if (rc) return rc;
+        zeroed = mode == 0;
     }
     const unsigned max_tiles = (unsigned)group_max_tiles(R, n);  // surplus blocks exit
     const size_t lds = rescal_lds_bytes(k);
@@ -238,16 +361,18 @@ static int rescal_run(int mode, const kge_model_desc* m, IdSplit h, IdSplit r, I
     if (mode == 0) {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)k_rescal<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e = hipMemsetAsync(scores, 0, (size_t)n * sizeof(float), s);
-        if (e != hipSuccess) { set_error("rescal: memset: %s", hipGetErrorString(e)); return -2; }
-        hipLaunchKernelGGL(k_rescal<0>, dim3(max_tiles, (unsigned)((ntile + 3) / 4)), dim3(256), lds, s, m->tables[0], m->tables[1], nullptr, nullptr, h, t,
+        if (!zeroed) {
+            hipError_t e = hipMemsetAsync(scores, 0, (size_t)n * sizeof(float), s);
+            if (e != hipSuccess) { set_error("rescal: memset: %s", hipGetErrorString(e)); return -2; }
+        }
+        hipLaunchKernelGGL(k_rescal<0>, dim3(max_tiles, (unsigned)ntile), dim3(256), lds, s, m->tables[0], m->tables[1], nullptr, nullptr, h, t,
                            g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, nullptr, scores);
     } else {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)k_rescal<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        const int units = 2 * ntile + ntile * ntile;
-        const unsigned ysplit = (unsigned)min(16, (units + 3) / 4);  // ~1 unit per wave
-        hipLaunchKernelGGL(k_rescal<1>, dim3(max_tiles, ysplit), dim3(256), lds, s, m->tables[0], m->tables[1], m->grads[0],
+        hipLaunchKernelGGL(k_rescal_gm, dim3(max_tiles, (unsigned)((ntile * ntile + 3) / 4)), dim3(256), 0, s, m->tables[0], m->grads[1], h, t,
+                           g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, dscore);
+        hipLaunchKernelGGL(k_rescal<1>, dim3(max_tiles, (unsigned)(2 * ntile)), dim3(256), lds, s, m->tables[0], m->tables[1], m->grads[0],
                            m->grads[1], h, t, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, dscore, nullptr);
     }
     return check_launch("k_rescal");
@@ -377,9 +502,246 @@ static void normalize_rows(float* w, int64_t rows, int64_t dim, hipStream_t s, f
 
 int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k, float* scratch, size_t scratch_floats,
                             hipStream_t s) {
-    normalize_rows(ent, E, (int64_t)k, s);
+    if (ent) normalize_rows(ent, E, (int64_t)k, s);   // (ent == NULL: the entity rows were renormalised by kge_optimizer_step_rows)
     normalize_rows(rel, R, (int64_t)k * k, s, scratch, scratch_floats);
     return check_launch("k_row_normalize");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The pairwise RESCAL step (scores of both sides, margin hinge, all three gradients) as ONE launch after the grouping.
+// A negative shares its positive's relation (the sampler corrupts heads and tails only), so PAIRS are grouped by relation and
+// a workgroup owns (relation, 16 pairs) = 32 triples: rows 0..15 the positives, 16..31 their negatives.  With both sides of
+// every pair in one workgroup the hinge is local, and the forward / coefficient / backward launches -- each a chain of
+// dependent loads (tile lookup, ids, rows, matrix operands) that costs more than its arithmetic at the reference's batch sizes
+// -- become one chain.  16 waves: (column tile, K half) units for V = H M and U = T M^T, every operand of a unit's MFMA steps
+// loaded before the first step (one round trip), the two K halves added through LDS in a fixed order; G = (ds H)^T T from LDS.
+// Entity gradients and the relation-matrix gradient leave through float atomics as in k_rescal.  k % 4 == 0, k <= 256.
+constexpr int kPairTile = 16;      // pairs per workgroup
+constexpr int kPairSteps = 52;     // V: MFMA steps (two k each) of operand loads in flight per wave
+constexpr int kPairQuads = 13;     // U: float4 operand loads (eight k each over the two lane halves) in flight per wave
+
+__global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ ent, const float* __restrict__ relm,
+                                                      float* __restrict__ g_ent, float* __restrict__ g_rel,
+                                                      const int64_t* __restrict__ ph, const int64_t* __restrict__ pt,
+                                                      const int64_t* __restrict__ nh, const int64_t* __restrict__ nt,
+                                                      const int* __restrict__ offsets, const int* __restrict__ tile_off,
+                                                      const int* __restrict__ tile_rel, const int* __restrict__ perm, int R, int k,
+                                                      float margin, float* __restrict__ loss) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int rel, tin;
+    if (!locate_tile(tile_off, tile_rel, R, blockIdx.x, rel, tin)) return;
+    const int S = (k + 1) | 1;                 // odd LDS row stride: conflict-free column reads
+    float* sT = smem;                          // [32][S]
+    float* sH = sT + TILE * S;                 // [32][S]
+    float* sRed = sH + TILE * S;               // [8][16][64] accumulators of the second K half
+    float* sPs = sRed + 8 * 16 * 64;           // [8][32]     score partials per column tile
+    float* sDs = sPs + 8 * TILE;               // [32]        dL/denergy
+    long long* sHid = (long long*)(sDs + TILE);
+    long long* sTid = sHid + TILE;
+    int* sAny = (int*)(sTid + TILE);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int g0 = offsets[rel] + tin * kPairTile;
+    const int cnt = min(kPairTile, offsets[rel + 1] - g0);
+    if (threadIdx.x < TILE) {
+        const int p = threadIdx.x & (kPairTile - 1);
+        const bool neg = threadIdx.x >= kPairTile;
+        const int pair = p < cnt ? perm[g0 + p] : -1;
+        sHid[threadIdx.x] = pair >= 0 ? (neg ? nh[pair] : ph[pair]) : 0;
+        sTid[threadIdx.x] = pair >= 0 ? (neg ? nt[pair] : pt[pair]) : 0;
+        sDs[threadIdx.x] = 0.f;
+    }
+    if (threadIdx.x < 8 * TILE) sPs[threadIdx.x] = 0.f;
+    __syncthreads();
+    {   // row gathers into LDS: 16 bytes per load, every load of a thread issued before its first LDS store
+        const int nv = k >> 2;
+        constexpr int kMaxPer = 2;                   // TILE * nv / 1024 float4 per thread and matrix (k <= 256)
+        float4 rt[kMaxPer], rh[kMaxPer];
+#pragma unroll
+        for (int j = 0; j < kMaxPer; ++j) {
+            const int idx = threadIdx.x + 1024 * j;
+            const int i = idx / nv, c = idx - i * nv;
+            const bool ok = idx < TILE * nv && (i & (kPairTile - 1)) < cnt;
+            rt[j] = ok ? reinterpret_cast<const float4*>(ent + sTid[i] * k)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rh[j] = ok ? reinterpret_cast<const float4*>(ent + sHid[i] * k)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxPer; ++j) {
+            const int idx = threadIdx.x + 1024 * j;
+            if (idx < TILE * nv) {
+                const int i = idx / nv, c = (idx - i * nv) * 4;
+                float* dt = sT + i * S + c;
+                float* dh = sH + i * S + c;
+                dt[0] = rt[j].x; dt[1] = rt[j].y; dt[2] = rt[j].z; dt[3] = rt[j].w;
+                dh[0] = rh[j].x; dh[1] = rh[j].y; dh[2] = rh[j].z; dh[3] = rh[j].w;
+            }
+        }
+    }
+    __syncthreads();
+    const float* M = relm + (int64_t)rel * k * k;
+    const int ntile = (k + 31) / 32;           // <= 8
+    const int khalf = ((k + 15) / 16) * 8;     // K span of one wave: a multiple of eight
+    const int u = wave >> 1, ks = wave & 1;    // unit: column tile u, K half ks
+    const bool live = u < ntile;
+    const int k_lo = ks * khalf, k_hi = min(k, k_lo + khalf);
+    const int col = u * 32 + li;               // V: b (column of M);  U: a (row of M)
+
+    // ---- V[i][b] = sum_a H[i][a] M[a][b]
+    f32x16 acc = {0};
+    if (live) {
+        for (int kc = k_lo; kc < k_hi; kc += 2 * kPairSteps) {
+            float bv[kPairSteps];
+#pragma unroll
+            for (int q = 0; q < kPairSteps; ++q) {
+                const int kk = kc + 2 * q + lk;
+                bv[q] = (kk < k_hi && col < k) ? M[(int64_t)kk * k + col] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < kPairSteps; ++q) {
+                const int kk = kc + 2 * q + lk;
+                const float av = kk < k_hi ? sH[li * S + kk] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[q], acc, 0, 0, 0);
+            }
+        }
+        if (ks == 1) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) sRed[(u * 16 + reg) * 64 + lane] = acc[reg];
+        }
+    }
+    __syncthreads();
+    if (live && ks == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            acc[reg] += sRed[(u * 16 + reg) * 64 + lane];
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+            float p = col < k ? acc[reg] * sT[i * S + col] : 0.f;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) p += __shfl_xor(p, o, 64);      // over the 32 columns of this half-wave
+            if (li == 0) sPs[u * TILE + i] = p;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // margin hinge of the tile's pairs (as k_hinge_coeffs: energies = -h^T M t)
+        const int p = threadIdx.x;
+        float v = 0.f, c = 0.f;
+        if (p < cnt) {
+            float sp = 0.f, sn = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { sp += sPs[q * TILE + p]; sn += sPs[q * TILE + kPairTile + p]; }
+            v = (-sp) + margin - (-sn);
+            c = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);
+            sDs[p] = c; sDs[kPairTile + p] = -c;
+        }
+        const float tot = wave_sum(fmaxf(v, 0.f));
+        const unsigned long long any = __ballot(c != 0.f);
+        if (p == 0) {
+            if (tot != 0.f) unsafeAtomicAdd(loss + (blockIdx.x % kLossSlots) * kLossStride, tot);
+            *sAny = any != 0ull;
+        }
+    }
+    __syncthreads();
+    if (!*sAny) return;        // every pair of the tile inside the margin: no gradient
+
+    // ---- grad_t = -ds V (from the registers of the first K half's waves)
+    if (live && ks == 0 && col < k) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+            const float ds = sDs[i];
+            if (ds != 0.f) unsafeAtomicAdd(g_ent + sTid[i] * k + col, -ds * acc[reg]);
+        }
+    }
+    // ---- U[i][a] = sum_b T[i][b] M[a][b]: lane a reads its row of M sixteen bytes at a time; the four values of a load feed four
+    // MFMA steps (lane half 0 carries k = kb .. kb+3, half 1 carries kb+4 .. kb+7: the k order inside a step is free)
+    f32x16 ua = {0};
+    if (live) {
+        for (int kc = k_lo; kc < k_hi; kc += 8 * kPairQuads) {
+            float4 mv[kPairQuads];
+#pragma unroll
+            for (int j = 0; j < kPairQuads; ++j) {
+                const int kb = kc + 8 * j + 4 * lk;
+                mv[j] = (kb < k_hi && col < k) ? *reinterpret_cast<const float4*>(M + (int64_t)col * k + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < kPairQuads; ++j) {
+                const int kb = kc + 8 * j + 4 * lk;
+                const bool on = kb < k_hi;
+                const float* tr = sT + li * S + kb;
+                ua = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? tr[0] : 0.f, mv[j].x, ua, 0, 0, 0);
+                ua = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? tr[1] : 0.f, mv[j].y, ua, 0, 0, 0);
+                ua = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? tr[2] : 0.f, mv[j].z, ua, 0, 0, 0);
+                ua = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? tr[3] : 0.f, mv[j].w, ua, 0, 0, 0);
+            }
+        }
+        if (ks == 1) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) sRed[(u * 16 + reg) * 64 + lane] = ua[reg];
+        }
+    }
+    __syncthreads();
+    if (live && ks == 0 && col < k) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+            const float ds = sDs[i];
+            const float v = ua[reg] + sRed[(u * 16 + reg) * 64 + lane];
+            if (ds != 0.f) unsafeAtomicAdd(g_ent + sHid[i] * k + col, -ds * v);     // grad_h = -ds U
+        }
+    }
+    // ---- G[a][b] = sum_i ds_i H[i][a] T[i][b] ;  grad_M = -G
+    float* gM = g_rel + (int64_t)rel * k * k;
+    for (int tl = wave; tl < ntile * ntile; tl += 16) {
+        const int at = tl / ntile, bt = tl - at * ntile;
+        const int a_in = at * 32 + li, b_in = bt * 32 + li;
+        f32x16 ga = {0};
+#pragma unroll
+        for (int kk = 0; kk < TILE; kk += 2) {
+            const int i = kk + lk;
+            const float av = a_in < k ? sDs[i] * sH[i * S + a_in] : 0.f;
+            const float bv = b_in < k ? sT[i * S + b_in] : 0.f;
+            ga = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, ga, 0, 0, 0);
+        }
+        if (b_in < k) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int a = at * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                if (a < k && ga[reg] != 0.f) unsafeAtomicAdd(gM + (int64_t)a * k + b_in, -ga[reg]);
+            }
+        }
+    }
+}
+
+static size_t rescal_pair_lds_bytes(int k) {
+    const int S = (k + 1) | 1;
+    return (size_t)(2 * TILE * S + 8 * 16 * 64 + 8 * TILE + TILE) * sizeof(float) + (size_t)2 * TILE * sizeof(long long) + 16;
+}
+static size_t rescal_pair_ws_bytes(int64_t R, int64_t n) {
+    return (size_t)(4 * (R + 1) + n + (n / kPairTile + R + 1) + 8) * sizeof(int);
+}
+
+bool rescal_pair_step_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
+    return m->dim % 4 == 0 && m->dim <= 256 && n < (1ll << 31) && ws_bytes >= rescal_pair_ws_bytes(m->tot_relation, n);
+}
+
+// negatives share pr (the caller passed nr == pr); ws: the pairwise step's scorer workspace
+int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
+                            const int64_t* nt, int64_t n, float margin, float* loss, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int k = m->dim;
+    const int64_t R = m->tot_relation;
+    if (!rescal_pair_step_ok(m, n, ws_bytes)) { set_error("RESCAL pair step: unsupported shape or workspace"); return -1; }
+    const GroupWs g = carve_group_ws(ws, R, n);       // (tile_rel, the last array, holds n / 16 + R + 1 entries here)
+    int rc = group_by_relation_split(id_whole(pr, n), n, R, g, s, nullptr, 0, kPairTile);
+    if (rc) return rc;
+    const size_t lds = rescal_pair_lds_bytes(k);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_rescal_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_rescal_pair, dim3((unsigned)(n / kPairTile + R + 1)), dim3(1024), lds, s, m->tables[0], m->tables[1], m->grads[0],
+                       m->grads[1], ph, pt, nh, nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss);
+    return check_launch("k_rescal_pair");
 }
 
 // ---- hinge coefficients for models scored by separate forward/backward launches (RESCAL, NTN):

@@ -894,7 +894,14 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GT = 128;      // tile edge (queries and candidates) per workgroup
 constexpr int GKS = 16;      // K slab
+// MFMA form of the sweep: v_mfma_f32_16x16x4_f32 (default) or v_mfma_f32_32x32x2_f32 (-DKGE_GEMM_32X32, the round-2 form).  Both run
+// at the same peak; the 16x16x4 form has a 40-cycle dependent latency instead of 64 and holds its issue rate with four waves per
+// SIMD (tools/mfma_bench.hip: 154 vs 129 TF), which is how this kernel runs (3-4 workgroups per CU).
+#ifdef KGE_GEMM_32X32
 constexpr int GLD = GT + 4;  // LDS row length (k-major tiles: [k][GT + pad])
+#else
+constexpr int GLD = GT + 16; // 16 lanes read 16 consecutive floats of row k, the next 16 lanes row k + 1: rows 16 banks apart
+#endif
 
 // queries [nq][Kpad] -> k-major tiles qT[tile][k][GT] (zero rows beyond nq): the layout the candidate table already has
 __global__ __launch_bounds__(256) void k_eval_qt(const float* __restrict__ qvec, int64_t nq, int Kpad, float* __restrict__ qT) {
@@ -943,11 +950,20 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
 #pragma unroll
     for (int j = 0; j < 2; ++j) { const int idx = threadIdx.x + 256 * j; sk[j] = idx >> 5; sc4[j] = idx & 31; }
     const float* qsrc = qT + (int64_t)qt * Kpad * GT;
-    float thr[2], qn2[2];
-    int cnt[2] = {0, 0};
+#ifdef KGE_GEMM_32X32
+    constexpr int NB = 2, BW = 32;   // column blocks per wave, their width
+    const int lcol = li;
+#else
+    constexpr int NB = 4, BW = 16;
+    const int lcol = lane & 15;
+    const int lk4 = lane >> 4;       // k index of this lane's operands inside a 16x16x4 step
+#endif
+    float thr[NB], qn2[NB];
+    int cnt[NB];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 32 + li;
+    for (int ni = 0; ni < NB; ++ni) {
+        const int64_t q = (int64_t)qt * GT + wc * 64 + ni * BW + lcol;
+        cnt[ni] = 0;
         thr[ni] = (!WRITE && q < nq) ? st[q] : 0.f;
         qn2[ni] = (SQM && q < nq) ? qn[q] : 0.f;
     }
@@ -976,6 +992,7 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
             rb[j] = live ? *reinterpret_cast<const float4*>(qsrc + (int64_t)k * GT + sc4[j] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+#ifdef KGE_GEMM_32X32
     f32x16 acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -1051,6 +1068,86 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
         }
     }
 }
+#else
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[4][4];   // 64 x 64 sub-tile of the wave as 4 x 4 blocks of 16 x 16: candidate rows mi, query columns ni
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nsteps > 0) load_step(0);
+    int buf = 0;
+    for (int64_t g = 0; g < nsteps; ++g) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<float4*>(&sA[buf][sk[j]][sc4[j] * 4]) = ra[j];
+            *reinterpret_cast<float4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
+        }
+        __syncthreads();   // step g is in LDS; everybody finished reading the buffer that is written next
+        if (g + 1 < nsteps) load_step(g + 1);
+        // operands of k-step kk + 4 are read from LDS before the MFMAs of k-step kk are issued (register double buffer)
+        float na[4], nb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { na[i] = sA[buf][lk4][wr * 64 + i * 16 + lcol]; nb[i] = sB[buf][lk4][wc * 64 + i * 16 + lcol]; }
+#pragma unroll
+        for (int kk = 0; kk < GKS; kk += 4) {
+            float a4[4], b4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a4[i] = na[i]; b4[i] = nb[i]; }
+            if (kk + 4 < GKS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { na[i] = sA[buf][kk + 4 + lk4][wr * 64 + i * 16 + lcol]; nb[i] = sB[buf][kk + 4 + lk4][wc * 64 + i * 16 + lcol]; }
+            }
+            KGE_KEEP_READS_AHEAD();
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi], b4[ni], acc[mi][ni], 0, 0, 0);
+        }
+        buf ^= 1;
+        if ((int)(g % nslab) != nslab - 1) continue;
+        // ---- last slab of a candidate tile: epilogue.  energy = -dot (+ post-op); the lane owns query column (ni, lcol), its 4
+        // registers per block are candidate rows 4 * lk4 + reg of block mi
+        const int64_t ct = sp + (g / nslab) * S;
+        const int e_base = (int)(ct * GT) + wr * 64 + 4 * lk4;   // candidate ids fit 31 bits (packed keys: < 2^24)
+        const int e_lim = (int)E;
+        const bool full = ct * GT + GT <= E && (ct * 2 + 1 < ntiles64);
+        const int e_pad = (int)(ntiles64 * 64);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int e = e_base + mi * 16 + reg;
+                float cn2 = 0.f;
+                if constexpr (SQM) cn2 = e < e_pad ? cn[e] : 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const float sc = energy(acc[mi][ni][reg], ni, cn2);
+                    if constexpr (WRITE) {
+                        const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 16 + lcol;
+                        if (q < nq && e < e_lim) scores_out[q * E + e] = sc;
+                    } else {
+                        cnt[ni] += (sc < thr[ni] && (full || e < e_lim)) ? 1 : 0;
+                    }
+                }
+            }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (!WRITE) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            int c2 = cnt[ni] + __shfl_xor(cnt[ni], 16, 64);   // the four lanes that own the same query column
+            c2 += __shfl_xor(c2, 32, 64);
+            const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 16 + lcol;
+            if (lk4 == 0 && q < nq && c2 != 0) atomicAdd(rcount + q, c2);
+        }
+    }
+}
+
+#endif
 
 __global__ void k_eval_finalize(const int32_t* __restrict__ rcount, const int32_t* __restrict__ fcount, int64_t n,
                                 int32_t* __restrict__ ranks) {

@@ -97,6 +97,147 @@ static int launch_kind(float* p, float* g, float* s1, float* s2, int64_t numel, 
     return check_launch("k_opt");
 }
 
+// ---- one wave per ROW: the dense optimiser on the row, then (NORM) the row renormalisation Rescal.embed would apply at the next
+// forward (kge_dense.hip: k_row_normalize -- same element-to-lane map and summation order, so the stored row is bit-identical
+// to optimiser sweep + normalisation pass).  Saves the normalisation's read + write of the whole entity table per step.
+template <int KIND, int NCH, bool NORM>
+__global__ __launch_bounds__(256) void k_opt_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
+                                                  float* __restrict__ s2, int64_t rows, int dim, OptArgs a,
+                                                  const float* __restrict__ dev_hyper, int zero) {
+    if (dev_hyper) { a.lr = dev_hyper[0]; a.step_size = dev_hyper[1]; a.bc2_sqrt = dev_hyper[2]; }
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t base = row * dim;
+        float pv[NCH], gv[NCH], av[NCH], bv[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int e = lane + 64 * c;
+            const bool on = e < dim;
+            pv[c] = on ? p[base + e] : 0.f;
+            gv[c] = on ? g[base + e] : 0.f;
+            av[c] = (KIND != KGE_OPT_SGD && on) ? s1[base + e] : 0.f;
+            bv[c] = (KIND == KGE_OPT_ADAM && on) ? s2[base + e] : 0.f;
+        }
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            opt_update<KIND>(pv[c], gv[c], av[c], bv[c], a);
+            n2 = fmaf(pv[c], pv[c], n2);   // (lanes beyond the row hold p = g = state = 0: every optimiser leaves them at 0)
+        }
+        float nrm = 1.f;
+        if constexpr (NORM) nrm = sqrtf(wave_sum(n2));
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int e = lane + 64 * c;
+            if (e < dim) {
+                p[base + e] = NORM ? pv[c] / nrm : pv[c];
+                if constexpr (KIND != KGE_OPT_SGD) s1[base + e] = av[c];
+                if constexpr (KIND == KGE_OPT_ADAM) s2[base + e] = bv[c];
+                if (zero && gv[c] != 0.f) g[base + e] = 0.f;
+            }
+        }
+    }
+}
+
+// the same for rows of float4s (dim % 4 == 0): a 32-lane group per row, NV float4 per lane, two rows per wave, 16-byte accesses,
+// optimiser state streamed non-temporally when the tables exceed the Infinity Cache (as k_opt does)
+template <int KIND, int NV, bool NORM, bool NT>
+__global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
+                                                   float* __restrict__ s2, int64_t rows, int dim, OptArgs a,
+                                                   const float* __restrict__ dev_hyper, int zero) {
+    if (dev_hyper) { a.lr = dev_hyper[0]; a.step_size = dev_hyper[1]; a.bc2_sqrt = dev_hyper[2]; }
+    const int gl = threadIdx.x & 31;
+    const int nvec = dim >> 2;
+    for (int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); row < rows; row += (int64_t)gridDim.x * 8) {
+        float4* pr = reinterpret_cast<float4*>(p + row * dim);
+        float4* gr = reinterpret_cast<float4*>(g + row * dim);
+        float4* ar = reinterpret_cast<float4*>(s1 + row * dim);
+        float4* br = reinterpret_cast<float4*>(s2 + row * dim);
+        float4 pv[NV], gv[NV], av[NV], bv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = v * 32 + gl;
+            const bool on = i < nvec;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            pv[v] = on ? pr[i] : z;
+            gv[v] = on ? stream_load<NT>(gr + i) : z;
+            av[v] = (KIND != KGE_OPT_SGD && on) ? stream_load<NT>(ar + i) : z;
+            bv[v] = (KIND == KGE_OPT_ADAM && on) ? stream_load<NT>(br + i) : z;
+        }
+        float n2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            opt_update<KIND>(pv[v].x, gv[v].x, av[v].x, bv[v].x, a); opt_update<KIND>(pv[v].y, gv[v].y, av[v].y, bv[v].y, a);
+            opt_update<KIND>(pv[v].z, gv[v].z, av[v].z, bv[v].z, a); opt_update<KIND>(pv[v].w, gv[v].w, av[v].w, bv[v].w, a);
+            n2 = fmaf(pv[v].x, pv[v].x, n2); n2 = fmaf(pv[v].y, pv[v].y, n2); n2 = fmaf(pv[v].z, pv[v].z, n2); n2 = fmaf(pv[v].w, pv[v].w, n2);
+        }
+        float nrm = 1.f;
+        if constexpr (NORM) nrm = sqrtf(gsum<32>(n2));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = v * 32 + gl;
+            if (i < nvec) {
+                if constexpr (NORM) { pv[v].x = pv[v].x / nrm; pv[v].y = pv[v].y / nrm; pv[v].z = pv[v].z / nrm; pv[v].w = pv[v].w / nrm; }
+                pr[i] = pv[v];   // (the next step gathers parameter rows: plain store)
+                if constexpr (KIND != KGE_OPT_SGD) stream_store<NT>(ar + i, av[v]);
+                if constexpr (KIND == KGE_OPT_ADAM) stream_store<NT>(br + i, bv[v]);
+                if (zero && (gv[v].x != 0.f || gv[v].y != 0.f || gv[v].z != 0.f || gv[v].w != 0.f)) gr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+}
+
+template <int KIND>
+static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t rows, int dim, OptArgs a, int zero, int normalize,
+                            const float* dh, hipStream_t s) {
+    if ((dim & 3) == 0 && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)s1 | (uintptr_t)s2) & 15) == 0)) {
+        int64_t blocks4 = (rows + 7) / 8;
+        if (blocks4 > 256 * 32) blocks4 = 256 * 32;
+        const int streams = KIND == KGE_OPT_SGD ? 2 : KIND == KGE_OPT_ADAM ? 4 : 3;
+        const bool nt = (int64_t)streams * rows * dim * 4 > ((int64_t)256 << 20);
+#define KGE_ROWS4(NV_)                                                                                                    \
+        if (dim <= 128 * NV_) {                                                                                            \
+            if (normalize && nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero); \
+            else if (normalize) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero); \
+            else if (nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero); \
+            else hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero); \
+            return check_launch("k_opt_rows4");                                                                            \
+        }
+        KGE_ROWS4(1) KGE_ROWS4(2) KGE_ROWS4(4) KGE_ROWS4(8)
+#undef KGE_ROWS4
+    }
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+#define KGE_ROWS(NCH_)                                                                                                   \
+    if (dim <= 64 * NCH_) {                                                                                               \
+        if (normalize) hipLaunchKernelGGL((k_opt_rows<KIND, NCH_, true>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero); \
+        else hipLaunchKernelGGL((k_opt_rows<KIND, NCH_, false>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero);        \
+        return check_launch("k_opt_rows");                                                                                \
+    }
+    KGE_ROWS(4) KGE_ROWS(8) KGE_ROWS(16)
+#undef KGE_ROWS
+    return -1;
+}
+
+int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float lr, int64_t step,
+                          int zero_grad, int normalize, const float* dev_hyper, hipStream_t s) {
+    const OptArgs a = make_opt_args(lr, step);
+    switch (kind) {
+        case KGE_OPT_SGD: return launch_rows_kind<KGE_OPT_SGD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, s);
+        case KGE_OPT_ADAM:
+            if (!s1 || !s2) { set_error("adam needs two state buffers"); return -1; }
+            return launch_rows_kind<KGE_OPT_ADAM>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, s);
+        case KGE_OPT_ADAGRAD:
+            if (!s1) { set_error("adagrad needs a state buffer"); return -1; }
+            return launch_rows_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, s);
+        case KGE_OPT_RMSPROP:
+            if (!s1) { set_error("rmsprop needs a state buffer"); return -1; }
+            return launch_rows_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, s);
+    }
+    set_error("kge_optimizer_step_rows: unknown optimizer %d", kind);
+    return -1;
+}
+
 int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t numel, float lr, int64_t step,
                      int zero_grad, const float* dev_hyper, const int64_t* cursor_in, int64_t* cursor_out, float* hyper_out,
                      int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, hipStream_t s) {

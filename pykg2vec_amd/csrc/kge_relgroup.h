@@ -35,7 +35,9 @@ inline GroupWs carve_group_ws(void* ws, int64_t R, int64_t n) {
 }
 
 int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s);  // kge_dense.hip
-int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s);   // n = total length
+int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s, float* zero_buf = nullptr,
+                            int64_t zero_n = 0, int tile = TILE);   // n = total length; zero_buf: optional float buffer cleared on
+                                                                    // the way; tile: items per tile (tile_rel then needs n / tile + R + 1)
 
 // which (relation, tile-in-relation) is block `b`?  (tile_rel is written by the grouping's scatter pass)
 __device__ __forceinline__ bool locate_tile(const int* __restrict__ tile_off, const int* __restrict__ tile_rel, int R, int b,

@@ -355,6 +355,29 @@ def optimizer_step(kind, param, grad, state1, state2, lr, step, zero_grad=True, 
                                         1 if zero_grad else 0, ph, _stream()), "kge_optimizer_step")
 
 
+def optimizer_step_rows(kind, param, grad, state1, state2, rows, dim, lr, step, zero_grad=True, normalize=False, dev_hyper=None):
+    """kge_optimizer_step_rows: the dense optimiser with one wave per row of a [rows, dim] table (flat views), optionally storing
+    the row renormalised (RESCAL: what the next forward's in-place normalisation would make of it)."""
+    p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
+    p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
+    ph = _dev(dev_hyper, torch.float32, "dev_hyper") if dev_hyper is not None else None
+    L.check(L.load().kge_optimizer_step_rows(OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"), _dev(grad, torch.float32, "grad"),
+                                             p1, p2, int(rows), int(dim), float(lr), int(step), 1 if zero_grad else 0,
+                                             1 if normalize else 0, ph, _stream()), "kge_optimizer_step_rows")
+
+
+def rescal_normalize_relations(rel, k):
+    """The relation-matrix half of Rescal's in-place renormalisation (the entity half rides in kge_optimizer_step_rows)."""
+    lib = L.load()
+    need = lib.kge_rescal_normalize_scratch_bytes(rel.shape[0], int(k))
+    key = (rel.device, need)
+    if key not in _rescal_scratch:
+        _rescal_scratch[key] = torch.empty(max(1, need // 4), dtype=torch.float32, device=rel.device)
+    sc = _rescal_scratch[key]
+    L.check(lib.kge_rescal_normalize_ws(None, 0, _dev(rel, torch.float32, "rel"), rel.shape[0], k, sc.data_ptr(), sc.numel() * 4,
+                                        _stream()), "kge_rescal_normalize_ws")
+
+
 def optimizer_step_advance(kind, param, grad, state1, state2, lr, hyper, cursor, next_cursor, next_hyper, batch_stride,
                            n_batches, draws_per_batch, zero_grad=True):
     """Dense optimiser sweep of a graph-replayed step + the next step's device-resident state (kge_optimizer_step_advance)."""

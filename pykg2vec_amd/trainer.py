@@ -76,6 +76,23 @@ class FlatState:
         self.K.optimizer_step_advance(self.optimizer, self.param_shard, self.grad_shard, self.state1, self.state2, lr, hyper,
                                       cursor, next_cursor, next_hyper, batch_stride, n_batches, draws, zero_grad=True)
 
+    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None):
+        """The optimiser step with the FIRST table ([rows, dim], at offset 0 of the flat buffers) handled by the row-owner kernel
+        (which can store the rows renormalised: RESCAL) and the remaining tables by the flat sweep.  advance: as
+        optimizer_step_advance (device-resident step state of hipGraph-replayed steps); single GPU only."""
+        self.step += 1
+        n0 = rows * dim
+        cut = self.offsets[1] if len(self.offsets) > 1 else self.numel
+        sl = lambda buf, a, b: buf[a:b] if buf is not None else None
+        hyper = advance[0] if advance is not None else None
+        self.K.optimizer_step_rows(self.optimizer, self.param[:n0], self.grad[:n0], sl(self.state1, 0, n0), sl(self.state2, 0, n0),
+                                   rows, dim, lr, self.step, zero_grad=True, normalize=normalize, dev_hyper=hyper)
+        rest = (self.param[cut:], self.grad[cut:], sl(self.state1, cut, self.numel), sl(self.state2, cut, self.numel))
+        if advance is not None:
+            self.K.optimizer_step_advance(self.optimizer, *rest, lr, *advance, zero_grad=True)
+        else:
+            self.K.optimizer_step(self.optimizer, *rest, lr, self.step, zero_grad=True)
+
     def optimizer_step(self, lr, dev_hyper=None):
         """Dense optimiser sweep over this rank's shard (the whole buffer when world_size == 1); clears the reduced
         gradient it consumed."""
@@ -176,7 +193,7 @@ class Trainer:
         env = os.environ.get
         flag = lambda name: None if env(name) is None else env(name) == "1"
         return {"pull": flag("KGE_PULL"), "staged": flag("KGE_STAGED"), "graph_multi": flag("KGE_GRAPH_MULTI"),
-                "pw_pull": flag("KGE_PW_PULL")}
+                "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED")}
 
     def _init_hot_path(self, process_group=None, backend=None, use_graph=None):
         # `backend` exists so that the multi-process plumbing (batch sharding, gradient collectives, replica
@@ -213,9 +230,14 @@ class Trainer:
             torch.distributed.broadcast(self.flat.param, src=0, group=self.process_group)
 
     # ------------------------------------------------------------------ one step (gradients into flat.grad)
-    def _accumulate_pairwise(self, ph, pr, pt, nh, nr, nt):
+    def _accumulate_pairwise(self, ph, pr, pt, nh, nr, nt, sampled=False):
         name = self.model.model_name.lower()
-        if name == "rescal":
+        if sampled and name == "rescal" and nr.numel() == pr.numel():
+            nr = pr      # our sampler corrupts heads and tails only: passing the SAME buffer lets kge_train_pairwise_hinge group
+                         # pairs by relation and run the whole step in one launch (k_rescal_pair)
+        if name == "rescal" and not getattr(self, "_rescal_normalised", False):
+            # Rescal.embed renormalises both tables in place on every forward (pairwise.py:843-844).  Inside an epoch the
+            # previous step's optimiser already stored them renormalised (_reduce_and_step): then this pass is skipped.
             self.K.rescal_normalize(self.flat.views[0], self.flat.views[1], self.model.hidden_size)
         if name == "rotate":
             self._selfadv_ws = self.K.train_pairwise_selfadv(self._desc, ph, pr, pt, nh, nr, nt, self.config.neg_rate,
@@ -274,7 +296,7 @@ class Trainer:
         else:
             data = next(gen)
         if self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED:
-            self._accumulate_pairwise(*data)
+            self._accumulate_pairwise(*data, sampled=True)
         else:
             self._accumulate_pointwise(*data)
 
@@ -622,8 +644,21 @@ class Trainer:
                 self._pull_dp_step()
             return
         for _ in range(n):
+            self._rescal_last = self.generator._pending == 1   # the epoch's last step leaves RESCAL's tables as the optimiser wrote them
             self._accumulate_next_batch()
             self._reduce_and_step()
+
+    def _rescal_fused(self):
+        """RESCAL's renormalisation folded into the optimiser launch: inside train_model_epoch, one GPU, the HIP backend, rows that
+        fit the row-owner kernel.  KGE_RESCAL_FUSED=0 switches it off (A/B)."""
+        if not (getattr(self, "_in_epoch", False) and self.K is K and not self.distributed and self.model.kernel_name == "rescal"
+                and self.model.hidden_size <= 1024):
+            return False
+        if self.switches.get("rescal_fused") is not None:
+            return self.switches["rescal_fused"]
+        # pays once the entity table is a real stream (C4, 98.5 MB: 262 -> 251 us per step); on small tables the second optimiser
+        # launch costs more than the pass it saves (FB15k preset, 3 MB: 64.5 -> 68.6 us)
+        return self.flat.views[0].numel() * 4 >= (32 << 20)
 
     def _mean_type_loss(self):
         """pointwise_logistic and the self-adversarial loss are MEANS over the batch (criterion.py:13-23,31-34);
@@ -643,6 +678,19 @@ class Trainer:
         flat = self.flat
 
         def optimise():
+            if self._rescal_fused():
+                # RESCAL, single GPU: the optimiser stores the entity rows already renormalised for the next step's forward
+                # (kge_optimizer_step_rows) and the relation matrices are renormalised right behind it, so the next step skips its
+                # normalisation pass -- except after the epoch's last step, which leaves the tables as the optimiser wrote
+                # them (that is what the reference's tables hold when an epoch ends).
+                keep = not self._rescal_last
+                ent = flat.views[0]
+                flat.optimizer_step_rows_first(self.config.learning_rate, ent.shape[0], ent.shape[1], keep, advance)
+                if keep:
+                    self.K.rescal_normalize_relations(flat.views[1], self.model.hidden_size)
+                self._rescal_normalised = keep
+                return
+            self._rescal_normalised = False
             if advance is not None:
                 flat.optimizer_step_advance(self.config.learning_rate, *advance)
             else:
@@ -732,6 +780,7 @@ class Trainer:
             self._accumulate_next_batch(cursor=cur[p], fixed_range=shard)
             self._reduce_and_step(advance=(hyp[p], cur[p], cur[1 - p], hyp[1 - p], B, num_batch, B * gen.neg_rate))
 
+        self._graph_body = body
         body(0)  # the epoch's FIRST step runs eagerly (loads kernels, sizes workspaces) ...
         torch.cuda.synchronize()
         self._graphs = []
@@ -758,24 +807,41 @@ class Trainer:
         num_batch = self.config.tot_train_triples // self.config.batch_size if not self.config.debug else 10
         self.generator.start_one_epoch(num_batch)
         self.model.train()
+        # RESCAL (see _reduce_and_step): inside the epoch the optimiser hands the tables to the next step already renormalised
+        self._in_epoch, self._rescal_normalised, self._rescal_last = True, False, num_batch == 1
+        try:
+            return self._train_epoch_body(epoch_idx, num_batch)
+        finally:
+            self._in_epoch, self._rescal_normalised, self._rescal_last = False, False, False
+
+    def _train_epoch_body(self, epoch_idx, num_batch):
         if num_batch > 0 and self._graph_wanted(num_batch):
             self.loss_buf.zero_()
             gen = self.generator
             step0, draws0 = self.flat.step, gen._draws  # host mirrors of the device-resident counters
             done = 0
+            fused = self._rescal_fused()
             if self._graph is None or self._graph_batches != num_batch:
                 done = self._capture_step(num_batch)
+            elif fused:   # the captured steps expect renormalised tables (their normalisation rides in the previous optimiser launch)
+                self.K.rescal_normalize(self.flat.views[0], self.flat.views[1], self.model.hidden_size)
+                self._rescal_normalised = True
             # (an epoch is exactly num_batch steps, so the device-side batch index has wrapped to 0 by itself: every
             # epoch walks the permutation from its start, data/generator.py:28-35)
             remaining = num_batch - done
-            while remaining > 0:
-                if self._graph_multi is not None and self._parity == 1 and remaining >= self.GRAPH_UNROLL:
+            tail = 1 if (fused and remaining > 0) else 0   # RESCAL: the epoch's last step runs eagerly, without the renormalisation
+            while remaining > tail:
+                if self._graph_multi is not None and self._parity == 1 and remaining - tail >= self.GRAPH_UNROLL:
                     self._graph_multi.replay()  # an even number of steps: parity unchanged
                     remaining -= self.GRAPH_UNROLL
                 else:
                     self._graphs[self._parity].replay()
                     self._parity ^= 1
                     remaining -= 1
+            if tail:
+                self._rescal_last = True
+                self._graph_body(self._parity)
+                self._parity ^= 1
             self.flat.step = step0 + num_batch
             gen._draws = draws0 + num_batch * gen.batch_size * gen.neg_rate
             gen._pending = 0

@@ -326,6 +326,44 @@ def test_scores_loss_grads_vs_oracle_other_shapes(hip, model, hp, neg_rate):
         assert np.allclose(got, G_ref[nme], atol=5e-5 * scale, rtol=2e-4), (nme, np.abs(got - G_ref[nme]).max())
 
 
+@pytest.mark.parametrize("k,E,R,B,margin", [(200, 300, 11, 160, 1.0), (64, 300, 3, 333, 1.0), (256, 50, 1, 40, 2.0), (4, 300, 40, 160, 1.0),
+                                              (200, 3000, 400, 1024, 0.5), (120, 300, 11, 160, 0.02), (36, 9, 2, 1, 1.0)])
+def test_rescal_pair_step_in_one_launch_matches_oracle(hip, monkeypatch, k, E, R, B, margin):
+    """nr IS pr (one buffer): kge_train_pairwise_hinge groups PAIRS by relation and runs scores, hinge and the three gradients in
+    one launch (k_rescal_pair).  Against the oracle, and against the three-launch path on the same batch (margin 0.02: most
+    pairs inside the margin, whole tiles without gradient)."""
+    from pykg2vec_amd.trainer import Trainer
+    rng = np.random.default_rng(k + B)
+    P = ko.init_params("rescal", rng, tot_entity=E, tot_relation=R, hidden_size=k)
+    hp = dict(hidden_size=k, margin=margin, neg_rate=1)
+    pos = np.stack([rng.integers(E, size=B), rng.integers(R, size=B) if B > 200 else np.sort(rng.integers(R, size=B)),
+                    rng.integers(E, size=B)], 1)
+    flip = rng.random(B) > 0.5
+    rnd = rng.integers(E, size=B)
+    nh = np.where(flip, pos[:, 0], rnd); nt = np.where(flip, rnd, pos[:, 2])
+    batch = (pos[:, 0], pos[:, 1], pos[:, 2], nh, pos[:, 1], nt)
+    loss_ref, G_ref, _, _ = ko.train_step_grads("rescal", P, batch, **hp)
+    out = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("KGE_RESCAL_UNFUSED", raising=False)
+        else:
+            monkeypatch.setenv("KGE_RESCAL_UNFUSED", "1")
+        m = hip.model_from_params("rescal", P, hp, E, R, train=pos)
+        cfg = hip.make_config(E, R, hp, pos, pos[:1], pos[:1])
+        tr = Trainer(m, cfg)
+        tr.build_model()
+        b = [hip.dev(x) for x in batch]
+        loss = tr.train_step_pairwise(b[0], b[1], b[2], b[3], b[1], b[5])
+        assert np.isclose(loss.item(), loss_ref, rtol=5e-5, atol=5e-5), (fused, loss.item(), loss_ref)
+        out[fused] = [g.cpu().numpy().copy() for g in tr.flat.grad_views]
+        for nme, got in zip(["ent_embeddings", "rel_matrices"], out[fused]):
+            scale = max(1.0, np.abs(G_ref[nme]).max())
+            assert np.allclose(got, G_ref[nme], atol=5e-5 * scale, rtol=2e-4), (fused, nme, np.abs(got - G_ref[nme]).max())
+    for a, c in zip(out[True], out[False]):
+        assert np.allclose(a, c, atol=2e-5, rtol=1e-4)
+
+
 def test_missing_gpu_tensor_fails_loudly(hip):
     import pykg2vec_amd.pairwise as pw
     from pykg2vec_amd._lib import KgeHipError
@@ -385,6 +423,33 @@ def test_graph_replayed_epochs_equal_eager_epochs(hip, name, opt):
     assert np.allclose(l0, l1, rtol=2e-4), (l0, l1)
     for k in p0:  # float atomics make the two runs differ in summation order only
         assert np.allclose(p0[k], p1[k], atol=2e-4, rtol=1e-3), (k, np.abs(p0[k] - p1[k]).max())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("opt", ["sgd", "adam", "adagrad"])
+def test_rescal_renormalisation_inside_the_optimiser_equals_the_separate_pass(hip, monkeypatch, opt, use_graph):
+    """RESCAL renormalises its tables at the start of every forward (pairwise.py:843-844).  Inside an epoch the optimiser
+    launch stores the rows already renormalised (kge_optimizer_step_rows) and the next step skips the pass; the epoch's last
+    step does not, so the tables end the epoch exactly as with the separate pass (KGE_RESCAL_FUSED=0): not normalised."""
+    from pykg2vec_amd.trainer import Trainer
+    c = Case("rescal")
+    out = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("KGE_RESCAL_FUSED", fused)
+        cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer=opt, lr=0.02, batch_size=16)
+        m = hip.model_from_case(c)
+        tr = Trainer(m, cfg, use_graph=use_graph)
+        tr.build_model()
+        tr.generator = tr._new_generator()
+        losses = [tr.train_model_epoch(e) for e in range(3)]
+        assert (tr._graph is not None) == use_graph
+        out.append((losses, {k: p.detach().cpu().numpy() for k, p in hip.table_parameters(m)}))
+    (l0, p0), (l1, p1) = out
+    assert np.allclose(l0, l1, rtol=2e-4), (l0, l1)
+    for k in p0:  # float atomics in the gradient: summation order only
+        assert np.allclose(p0[k], p1[k], atol=2e-4, rtol=1e-3), (k, np.abs(p0[k] - p1[k]).max())
+    norms = np.linalg.norm(p1["ent_embeddings.weight"], axis=1)
+    assert np.abs(norms - 1.0).max() > 1e-4     # the last step's update was NOT followed by a renormalisation
 
 
 @pytest.mark.parametrize("name", ["transe_l1", "transe_l2", "transh_l1", "transh_l2", "transd_l1", "transd_l2",
