@@ -173,9 +173,26 @@ int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, f
  * renormalised row, so the next step's kge_rescal_normalize pass over this table (a full read + write of it) disappears.  The
  * result equals kge_optimizer_step followed by kge_rescal_normalize up to the fp32 summation order of the row norm.  A caller must leave
  * normalize == 0 on the last step before the tables are observed (the reference leaves them as the optimiser wrote them).
- * rows of at most 1024 floats. */
+ * rows of at most 1024 floats.
+ * touched_rows (may be NULL): one bit per row (uint32 words, bit r & 31 of word r >> 5), set by the step that accumulated
+ * gradients (kge_rescal_pair_step); a clear bit promises that the row of `grad` is zero, and the sweep does not read it.
+ * touched_clear (may be NULL): the bitmap of the OTHER step parity, reset to zero on the way (two bitmaps alternate so that a
+ * step's optimiser never clears bits its own sweep still reads). */
 int kge_optimizer_step_rows(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
-                            float lr, int64_t step, int32_t zero_grad, int32_t normalize, const float* dev_hyper, void* stream);
+                            float lr, int64_t step, int32_t zero_grad, int32_t normalize, const float* dev_hyper,
+                            const uint32_t* touched_rows, uint32_t* touched_clear, void* stream);
+
+/* The pairwise RESCAL train step of kge_train_pairwise_hinge (Trainer.train_model_epoch -> model.forward on both sides ->
+ * Criterion.pairwise_hinge -> backward, utils/trainer.py:262-276 with pairwise.py:838-870) for batches whose negatives keep
+ * their positives' relation ids (every sampler of the reference: data/generator.py:143-196 corrupts heads and tails only):
+ * pairs are grouped by relation and each (relation, 16 pairs) tile computes scores, hinge and the three gradients in one
+ * workgroup.  kge_train_pairwise_hinge takes this path by itself when called with nr == pr (the same buffer).
+ * hidden size: a multiple of 4, at most 256 (kge_rescal_pair_step_ok).  workspace: kge_workspace_bytes(m, n) bytes.
+ * touched_rows (may be NULL): entity rows that received a gradient get their bit set (see kge_optimizer_step_rows). */
+int kge_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
+                         const int64_t* nt, int64_t n, float margin, void* workspace, size_t workspace_bytes, float* loss,
+                         uint32_t* touched_rows, void* stream);
+int kge_rescal_pair_step_ok(const kge_model_desc* m, int64_t n);
 
 /* NTN.get_reg (pairwise.py:962-963): loss += lmbda * sqrt(sum_i param[i]^2), grad += lmbda * param / that root, over
  * ONE flat buffer holding every table of the model (pad with zeros).  scratch: 1 float. */

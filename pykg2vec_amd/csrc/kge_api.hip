@@ -174,8 +174,9 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
     if (m->model == KGE_RESCAL) {
         // nr == pr (the same buffer: the caller's way of saying that negatives keep their positives' relations, as every sampler
         // of the reference does): scores, hinge and gradients of a (relation, 16 pairs) tile in one launch
-        if (nr == pr && rescal_pair_step_ok(m, n, 2 * gws) && !getenv("KGE_RESCAL_UNFUSED"))
-            return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, wsp, 2 * gws, s);
+        static const bool unfused = getenv("KGE_RESCAL_UNFUSED") != nullptr;   // A/B switch, read once
+        if (nr == pr && rescal_pair_step_ok(m, n, 2 * gws) && !unfused)
+            return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, wsp, 2 * gws, nullptr, s);
         // positives and negatives as ONE grouped batch of 2n triples (scores / coefficients contiguous: sp | sn); the
         // region of the two per-side workspaces holds the grouping of 2n triples (group_ws_bytes(R, 2n) <= 2 gws)
         if ((rc = launch_rescal_pair_forward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s))) return rc;
@@ -368,12 +369,32 @@ int kge_optimizer_step(int32_t kind, float* param, float* grad, float* state1, f
                             nullptr, nullptr, nullptr, 0, 1, 0, (hipStream_t)stream);
 }
 
+int kge_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
+                         const int64_t* nt, int64_t n, float margin, void* workspace, size_t workspace_bytes, float* loss,
+                         uint32_t* touched_rows, void* stream) {
+    if (validate(m, true, "kge_rescal_pair_step")) return -1;
+    if (m->model != KGE_RESCAL) { set_error("kge_rescal_pair_step: not a RESCAL model"); return -1; }
+    if (n == 0) return 0;
+    if (n < 0 || !ph || !pr || !pt || !nh || !nt || !loss || !workspace) { set_error("kge_rescal_pair_step: bad arguments"); return -1; }
+    if (!rescal_pair_step_ok(m, n, workspace_bytes)) {
+        set_error("kge_rescal_pair_step: hidden size %d (needs a multiple of 4, at most 256) or workspace (kge_workspace_bytes)", m->dim);
+        return -1;
+    }
+    return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, workspace, workspace_bytes, touched_rows, (hipStream_t)stream);
+}
+
+int kge_rescal_pair_step_ok(const kge_model_desc* m, int64_t n) {
+    return m && m->model == KGE_RESCAL && rescal_pair_step_ok(m, n, (size_t)-1) ? 1 : 0;
+}
+
 int kge_optimizer_step_rows(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
-                            float lr, int64_t step, int32_t zero_grad, int32_t normalize, const float* dev_hyper, void* stream) {
+                            float lr, int64_t step, int32_t zero_grad, int32_t normalize, const float* dev_hyper,
+                            const uint32_t* touched_rows, uint32_t* touched_clear, void* stream) {
     if (!param || !grad || rows < 0 || dim <= 0 || dim > 1024 || (step < 1 && !dev_hyper)) { set_error("kge_optimizer_step_rows: bad arguments (rows of at most 1024 floats)"); return -1; }
     if (rows == 0) return 0;
+    if (touched_rows && touched_rows == touched_clear) { set_error("kge_optimizer_step_rows: the bitmap to clear must be the other parity's"); return -1; }
     return launch_optimizer_rows(kind, param, grad, state1, state2, rows, dim, lr, step < 1 ? 1 : step, zero_grad, normalize, dev_hyper,
-                                 (hipStream_t)stream);
+                                 touched_rows, touched_clear, (hipStream_t)stream);
 }
 
 int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,

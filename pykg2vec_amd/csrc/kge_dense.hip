@@ -526,7 +526,7 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
                                                       const int64_t* __restrict__ nh, const int64_t* __restrict__ nt,
                                                       const int* __restrict__ offsets, const int* __restrict__ tile_off,
                                                       const int* __restrict__ tile_rel, const int* __restrict__ perm, int R, int k,
-                                                      float margin, float* __restrict__ loss) {
+                                                      float margin, float* __restrict__ loss, unsigned* __restrict__ touched) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rel, tin;
     if (!locate_tile(tile_off, tile_rel, R, blockIdx.x, rel, tin)) return;
@@ -642,6 +642,11 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
     }
     __syncthreads();
     if (!*sAny) return;        // every pair of the tile inside the margin: no gradient
+    if (touched && threadIdx.x < TILE && sDs[threadIdx.x] != 0.f) {   // entity rows this tile writes a gradient into
+        const long long a = sHid[threadIdx.x], b = sTid[threadIdx.x];
+        atomicOr(touched + (a >> 5), 1u << (a & 31));
+        atomicOr(touched + (b >> 5), 1u << (b & 31));
+    }
 
     // ---- grad_t = -ds V (from the registers of the first K half's waves)
     if (live && ks == 0 && col < k) {
@@ -726,7 +731,8 @@ bool rescal_pair_step_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
 
 // negatives share pr (the caller passed nr == pr); ws: the pairwise step's scorer workspace
 int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
-                            const int64_t* nt, int64_t n, float margin, float* loss, void* ws, size_t ws_bytes, hipStream_t s) {
+                            const int64_t* nt, int64_t n, float margin, float* loss, void* ws, size_t ws_bytes, unsigned* touched,
+                            hipStream_t s) {
     const int k = m->dim;
     const int64_t R = m->tot_relation;
     if (!rescal_pair_step_ok(m, n, ws_bytes)) { set_error("RESCAL pair step: unsupported shape or workspace"); return -1; }
@@ -740,7 +746,7 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
         attr_set = true;
     }
     hipLaunchKernelGGL(k_rescal_pair, dim3((unsigned)(n / kPairTile + R + 1)), dim3(1024), lds, s, m->tables[0], m->tables[1], m->grads[0],
-                       m->grads[1], ph, pt, nh, nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss);
+                       m->grads[1], ph, pt, nh, nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched);
     return check_launch("k_rescal_pair");
 }
 

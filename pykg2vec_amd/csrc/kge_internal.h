@@ -145,7 +145,8 @@ int launch_hinge_coeffs(float* pos, float* neg, int64_t n, float margin, float* 
 // the whole pairwise RESCAL step in one launch after the grouping (negatives share the positives' relation ids)
 bool rescal_pair_step_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes);
 int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
-                            const int64_t* nt, int64_t n, float margin, float* loss, void* ws, size_t ws_bytes, hipStream_t s);
+                            const int64_t* nt, int64_t n, float margin, float* loss, void* ws, size_t ws_bytes, unsigned* touched,
+                            hipStream_t s);
 
 // kge_opt.hip
 int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t numel, float lr, int64_t step,
@@ -153,7 +154,8 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
                      int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, hipStream_t s);
 
 int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float lr, int64_t step,
-                          int zero_grad, int normalize, const float* dev_hyper, hipStream_t s);
+                          int zero_grad, int normalize, const float* dev_hyper, const unsigned* touched, unsigned* touched_clear,
+                          hipStream_t s);
 
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);

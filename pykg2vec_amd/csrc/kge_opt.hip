@@ -144,11 +144,16 @@ __global__ __launch_bounds__(256) void k_opt_rows(float* __restrict__ p, float* 
 template <int KIND, int NV, bool NORM, bool NT>
 __global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                    float* __restrict__ s2, int64_t rows, int dim, OptArgs a,
-                                                   const float* __restrict__ dev_hyper, int zero) {
+                                                   const float* __restrict__ dev_hyper, int zero,
+                                                   const unsigned* __restrict__ touched, unsigned* __restrict__ touched_clear) {
     if (dev_hyper) { a.lr = dev_hyper[0]; a.step_size = dev_hyper[1]; a.bc2_sqrt = dev_hyper[2]; }
     const int gl = threadIdx.x & 31;
     const int nvec = dim >> 2;
     for (int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); row < rows; row += (int64_t)gridDim.x * 8) {
+        // touched: one bit per row, set by the step that wrote a gradient into it; a clear bit means the row of `g` is zero
+        // and is not read (one of the seven streams of a dense Adam sweep).  touched_clear: the OTHER step parity's bitmap, reset here.
+        const bool has_g = !touched || ((touched[row >> 5] >> (row & 31)) & 1u);
+        if (touched_clear && gl == 0 && (row & 31) == 0) touched_clear[row >> 5] = 0u;
         float4* pr = reinterpret_cast<float4*>(p + row * dim);
         float4* gr = reinterpret_cast<float4*>(g + row * dim);
         float4* ar = reinterpret_cast<float4*>(s1 + row * dim);
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float*
             const bool on = i < nvec;
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             pv[v] = on ? pr[i] : z;
-            gv[v] = on ? stream_load<NT>(gr + i) : z;
+            gv[v] = (on && has_g) ? stream_load<NT>(gr + i) : z;
             av[v] = (KIND != KGE_OPT_SGD && on) ? stream_load<NT>(ar + i) : z;
             bv[v] = (KIND == KGE_OPT_ADAM && on) ? stream_load<NT>(br + i) : z;
         }
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float*
 
 template <int KIND>
 static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t rows, int dim, OptArgs a, int zero, int normalize,
-                            const float* dh, hipStream_t s) {
+                            const float* dh, const unsigned* touched, unsigned* tclear, hipStream_t s) {
     if ((dim & 3) == 0 && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)s1 | (uintptr_t)s2) & 15) == 0)) {
         int64_t blocks4 = (rows + 7) / 8;
         if (blocks4 > 256 * 32) blocks4 = 256 * 32;
@@ -197,14 +202,18 @@ static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t ro
         const bool nt = (int64_t)streams * rows * dim * 4 > ((int64_t)256 << 20);
 #define KGE_ROWS4(NV_)                                                                                                    \
         if (dim <= 128 * NV_) {                                                                                            \
-            if (normalize && nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero); \
-            else if (normalize) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero); \
-            else if (nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero); \
-            else hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero); \
+            if (normalize && nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear); \
+            else if (normalize) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear); \
+            else if (nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear); \
+            else hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear); \
             return check_launch("k_opt_rows4");                                                                            \
         }
         KGE_ROWS4(1) KGE_ROWS4(2) KGE_ROWS4(4) KGE_ROWS4(8)
 #undef KGE_ROWS4
+    }
+    if (tclear) {   // (the dword kernel reads every gradient row: a superset of the touched ones)
+        hipError_t e = hipMemsetAsync(tclear, 0, (size_t)((rows + 31) / 32) * sizeof(unsigned), s);
+        if (e != hipSuccess) { set_error("optimizer rows: memset: %s", hipGetErrorString(e)); return -2; }
     }
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
@@ -220,19 +229,20 @@ static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t ro
 }
 
 int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float lr, int64_t step,
-                          int zero_grad, int normalize, const float* dev_hyper, hipStream_t s) {
+                          int zero_grad, int normalize, const float* dev_hyper, const unsigned* touched, unsigned* touched_clear,
+                          hipStream_t s) {
     const OptArgs a = make_opt_args(lr, step);
     switch (kind) {
-        case KGE_OPT_SGD: return launch_rows_kind<KGE_OPT_SGD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, s);
+        case KGE_OPT_SGD: return launch_rows_kind<KGE_OPT_SGD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, s);
         case KGE_OPT_ADAM:
             if (!s1 || !s2) { set_error("adam needs two state buffers"); return -1; }
-            return launch_rows_kind<KGE_OPT_ADAM>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, s);
+            return launch_rows_kind<KGE_OPT_ADAM>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, s);
         case KGE_OPT_ADAGRAD:
             if (!s1) { set_error("adagrad needs a state buffer"); return -1; }
-            return launch_rows_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, s);
+            return launch_rows_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, s);
         case KGE_OPT_RMSPROP:
             if (!s1) { set_error("rmsprop needs a state buffer"); return -1; }
-            return launch_rows_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, s);
+            return launch_rows_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, s);
     }
     set_error("kge_optimizer_step_rows: unknown optimizer %d", kind);
     return -1;

@@ -355,15 +355,37 @@ def optimizer_step(kind, param, grad, state1, state2, lr, step, zero_grad=True, 
                                         1 if zero_grad else 0, ph, _stream()), "kge_optimizer_step")
 
 
-def optimizer_step_rows(kind, param, grad, state1, state2, rows, dim, lr, step, zero_grad=True, normalize=False, dev_hyper=None):
+def optimizer_step_rows(kind, param, grad, state1, state2, rows, dim, lr, step, zero_grad=True, normalize=False, dev_hyper=None,
+                        touched=None, touched_clear=None):
     """kge_optimizer_step_rows: the dense optimiser with one wave per row of a [rows, dim] table (flat views), optionally storing
-    the row renormalised (RESCAL: what the next forward's in-place normalisation would make of it)."""
+    the row renormalised (RESCAL: what the next forward's in-place normalisation would make of it).  touched / touched_clear:
+    int32 bitmaps of rows with a gradient (this step's, read; the other parity's, reset)."""
     p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
     p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
     ph = _dev(dev_hyper, torch.float32, "dev_hyper") if dev_hyper is not None else None
     L.check(L.load().kge_optimizer_step_rows(OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"), _dev(grad, torch.float32, "grad"),
                                              p1, p2, int(rows), int(dim), float(lr), int(step), 1 if zero_grad else 0,
-                                             1 if normalize else 0, ph, _stream()), "kge_optimizer_step_rows")
+                                             1 if normalize else 0, ph,
+                                             _dev(touched, torch.int32, "touched") if touched is not None else None,
+                                             _dev(touched_clear, torch.int32, "touched_clear") if touched_clear is not None else None,
+                                             _stream()), "kge_optimizer_step_rows")
+
+
+def rescal_pair_step_ok(desc, n):
+    return bool(L.load().kge_rescal_pair_step_ok(ctypes.byref(desc), int(n)))
+
+
+def rescal_pair_step(desc, ph, pr, pt, nh, nt, margin, loss_buf, touched=None):
+    """kge_rescal_pair_step: the pairwise RESCAL step for negatives that keep their positives' relations, one launch per
+    (relation, 16 pairs) tile; touched: int32 bitmap [ceil(E / 32)] that receives the entity rows with a gradient."""
+    n = ph.numel()
+    if nh.numel() != n:
+        raise ValueError("pairwise_hinge needs neg_rate == 1 (criterion.py:27 adds [B] to [B*neg_rate])")
+    wp, wb, _keep = _workspace(desc, n, ph.device)
+    L.check(L.load().kge_rescal_pair_step(ctypes.byref(desc), _ids(ph, "ph"), _ids(pr, "pr"), _ids(pt, "pt"), _ids(nh, "nh"),
+                                          _ids(nt, "nt"), n, float(margin), wp, wb, _dev(loss_buf, torch.float32, "loss"),
+                                          _dev(touched, torch.int32, "touched") if touched is not None else None, _stream()),
+            "kge_rescal_pair_step")
 
 
 def rescal_normalize_relations(rel, k):

@@ -76,7 +76,7 @@ class FlatState:
         self.K.optimizer_step_advance(self.optimizer, self.param_shard, self.grad_shard, self.state1, self.state2, lr, hyper,
                                       cursor, next_cursor, next_hyper, batch_stride, n_batches, draws, zero_grad=True)
 
-    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None):
+    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None, touched=None, touched_clear=None):
         """The optimiser step with the FIRST table ([rows, dim], at offset 0 of the flat buffers) handled by the row-owner kernel
         (which can store the rows renormalised: RESCAL) and the remaining tables by the flat sweep.  advance: as
         optimizer_step_advance (device-resident step state of hipGraph-replayed steps); single GPU only."""
@@ -86,7 +86,8 @@ class FlatState:
         sl = lambda buf, a, b: buf[a:b] if buf is not None else None
         hyper = advance[0] if advance is not None else None
         self.K.optimizer_step_rows(self.optimizer, self.param[:n0], self.grad[:n0], sl(self.state1, 0, n0), sl(self.state2, 0, n0),
-                                   rows, dim, lr, self.step, zero_grad=True, normalize=normalize, dev_hyper=hyper)
+                                   rows, dim, lr, self.step, zero_grad=True, normalize=normalize, dev_hyper=hyper,
+                                   touched=touched, touched_clear=touched_clear)
         rest = (self.param[cut:], self.grad[cut:], sl(self.state1, cut, self.numel), sl(self.state2, cut, self.numel))
         if advance is not None:
             self.K.optimizer_step_advance(self.optimizer, *rest, lr, *advance, zero_grad=True)
@@ -193,7 +194,8 @@ class Trainer:
         env = os.environ.get
         flag = lambda name: None if env(name) is None else env(name) == "1"
         return {"pull": flag("KGE_PULL"), "staged": flag("KGE_STAGED"), "graph_multi": flag("KGE_GRAPH_MULTI"),
-                "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED")}
+                "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED"),
+                "rescal_unfused": flag("KGE_RESCAL_UNFUSED")}
 
     def _init_hot_path(self, process_group=None, backend=None, use_graph=None):
         # `backend` exists so that the multi-process plumbing (batch sharding, gradient collectives, replica
@@ -204,6 +206,7 @@ class Trainer:
         self.process_group = process_group
         self.use_graph = use_graph
         self.switches = self._switches()
+        self._touched, self._touch_parity, self._touched_step = None, 0, None   # RESCAL: bitmaps of entity rows with a gradient
         self._graph = None
         self.world_size = 1
         self.rank = 0
@@ -232,13 +235,22 @@ class Trainer:
     # ------------------------------------------------------------------ one step (gradients into flat.grad)
     def _accumulate_pairwise(self, ph, pr, pt, nh, nr, nt, sampled=False):
         name = self.model.model_name.lower()
-        if sampled and name == "rescal" and nr.numel() == pr.numel():
-            nr = pr      # our sampler corrupts heads and tails only: passing the SAME buffer lets kge_train_pairwise_hinge group
-                         # pairs by relation and run the whole step in one launch (k_rescal_pair)
         if name == "rescal" and not getattr(self, "_rescal_normalised", False):
             # Rescal.embed renormalises both tables in place on every forward (pairwise.py:843-844).  Inside an epoch the
             # previous step's optimiser already stored them renormalised (_reduce_and_step): then this pass is skipped.
             self.K.rescal_normalize(self.flat.views[0], self.flat.views[1], self.model.hidden_size)
+        if sampled and name == "rescal" and nr.numel() == pr.numel():
+            nr = pr      # our sampler corrupts heads and tails only: passing the SAME buffer lets kge_train_pairwise_hinge group
+                         # pairs by relation and run the whole step in one launch (k_rescal_pair)
+            if self._rescal_fused() and self.K.rescal_pair_step_ok(self._desc, ph.numel()) and not self.switches.get("rescal_unfused"):
+                # ... which also marks the entity rows it writes a gradient into, so that the row-owner optimiser of this step
+                # (_reduce_and_step) reads the gradient of those rows only.  Two bitmaps alternate with the step parity: a
+                # step's optimiser resets the other one.  (A parity that repeats after an epoch boundary only leaves stale
+                # bits behind: rows read needlessly, never a gradient missed.)
+                par = self._touch_parity
+                self.K.rescal_pair_step(self._desc, ph, pr, pt, nh, nt, self.config.margin, self.loss_buf, touched=self._touched_bitmaps()[par])
+                self._touched_step = par
+                return
         if name == "rotate":
             self._selfadv_ws = self.K.train_pairwise_selfadv(self._desc, ph, pr, pt, nh, nr, nt, self.config.neg_rate,
                                                         self.config.alpha, self.loss_buf, self._selfadv_ws)
@@ -648,6 +660,13 @@ class Trainer:
             self._accumulate_next_batch()
             self._reduce_and_step()
 
+    def _touched_bitmaps(self):
+        if getattr(self, "_touched", None) is None:
+            words = (self.flat.views[0].shape[0] + 31) // 32
+            buf = torch.zeros(2 * words, dtype=torch.int32, device=self.flat.param.device)
+            self._touched = (buf[:words], buf[words:])
+        return self._touched
+
     def _rescal_fused(self):
         """RESCAL's renormalisation folded into the optimiser launch: inside train_model_epoch, one GPU, the HIP backend, rows that
         fit the row-owner kernel.  KGE_RESCAL_FUSED=0 switches it off (A/B)."""
@@ -685,7 +704,12 @@ class Trainer:
                 # them (that is what the reference's tables hold when an epoch ends).
                 keep = not self._rescal_last
                 ent = flat.views[0]
-                flat.optimizer_step_rows_first(self.config.learning_rate, ent.shape[0], ent.shape[1], keep, advance)
+                par, self._touched_step = self._touched_step, None
+                bm = self._touched_bitmaps() if par is not None else (None, None)
+                flat.optimizer_step_rows_first(self.config.learning_rate, ent.shape[0], ent.shape[1], keep, advance,
+                                               touched=bm[par] if par is not None else None,
+                                               touched_clear=bm[1 - par] if par is not None else None)
+                self._touch_parity ^= 1
                 if keep:
                     self.K.rescal_normalize_relations(flat.views[1], self.model.hidden_size)
                 self._rescal_normalised = keep
@@ -777,6 +801,7 @@ class Trainer:
         shard = (self.rank * per, per, self.rank * per * gen.neg_rate)
 
         def body(p):
+            self._touch_parity = p
             self._accumulate_next_batch(cursor=cur[p], fixed_range=shard)
             self._reduce_and_step(advance=(hyp[p], cur[p], cur[1 - p], hyp[1 - p], B, num_batch, B * gen.neg_rate))
 

@@ -344,17 +344,15 @@ def test_rescal_pair_step_in_one_launch_matches_oracle(hip, monkeypatch, k, E, R
     batch = (pos[:, 0], pos[:, 1], pos[:, 2], nh, pos[:, 1], nt)
     loss_ref, G_ref, _, _ = ko.train_step_grads("rescal", P, batch, **hp)
     out = {}
+    monkeypatch.delenv("KGE_RESCAL_UNFUSED", raising=False)
     for fused in (True, False):
-        if fused:
-            monkeypatch.delenv("KGE_RESCAL_UNFUSED", raising=False)
-        else:
-            monkeypatch.setenv("KGE_RESCAL_UNFUSED", "1")
         m = hip.model_from_params("rescal", P, hp, E, R, train=pos)
         cfg = hip.make_config(E, R, hp, pos, pos[:1], pos[:1])
         tr = Trainer(m, cfg)
         tr.build_model()
         b = [hip.dev(x) for x in batch]
-        loss = tr.train_step_pairwise(b[0], b[1], b[2], b[3], b[1], b[5])
+        # (a separate nr buffer with the same contents: the three-launch path)
+        loss = tr.train_step_pairwise(b[0], b[1], b[2], b[3], b[1] if fused else b[4], b[5])
         assert np.isclose(loss.item(), loss_ref, rtol=5e-5, atol=5e-5), (fused, loss.item(), loss_ref)
         out[fused] = [g.cpu().numpy().copy() for g in tr.flat.grad_views]
         for nme, got in zip(["ent_embeddings", "rel_matrices"], out[fused]):
@@ -450,6 +448,39 @@ def test_rescal_renormalisation_inside_the_optimiser_equals_the_separate_pass(hi
         assert np.allclose(p0[k], p1[k], atol=2e-4, rtol=1e-3), (k, np.abs(p0[k] - p1[k]).max())
     norms = np.linalg.norm(p1["ent_embeddings.weight"], axis=1)
     assert np.abs(norms - 1.0).max() > 1e-4     # the last step's update was NOT followed by a renormalisation
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("opt", ["adam", "adagrad"])
+def test_rescal_optimiser_reads_only_touched_gradient_rows(hip, monkeypatch, opt, use_graph):
+    """With the step in one launch (k_rescal_pair) the entity rows that receive a gradient are marked in a bitmap and the
+    row-owner optimiser skips the gradient read of every other row (two bitmaps alternating with the step parity, the
+    optimiser resetting the other one).  Three epochs of eleven steps against the path without the bitmaps."""
+    from pykg2vec_amd.trainer import Trainer
+    E, R, k, B = 3000, 40, 64, 256
+    rng = np.random.default_rng(5)
+    train = np.stack([rng.integers(E, size=11 * B + 7), rng.integers(R, size=11 * B + 7), rng.integers(E, size=11 * B + 7)], 1)
+    P = ko.init_params("rescal", rng, tot_entity=E, tot_relation=R, hidden_size=k)
+    hp = dict(hidden_size=k, margin=1.0, neg_rate=1)
+    out = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("KGE_RESCAL_FUSED", fused)
+        cfg = hip.make_config(E, R, hp, train, train[:4], train[:4], optimizer=opt, lr=0.01, batch_size=B)
+        m = hip.model_from_params("rescal", P, hp, E, R, train=train)
+        tr = Trainer(m, cfg, use_graph=use_graph)
+        tr.build_model()
+        tr.generator = tr._new_generator()
+        losses = [tr.train_model_epoch(e) for e in range(3)]
+        assert (tr._touched is not None) == (fused == "1")
+        if fused == "1":   # exactly one bitmap holds the last step's rows, the other was reset by its optimiser
+            used = [int((b != 0).sum()) for b in tr._touched]
+            assert min(used) == 0 and max(used) > 0, used
+            assert bool((tr.flat.grad == 0).all())
+        out.append((losses, {n: p.detach().cpu().numpy() for n, p in hip.table_parameters(m)}))
+    (l0, p0), (l1, p1) = out
+    assert np.allclose(l0, l1, rtol=2e-4), (l0, l1)
+    for n in p0:
+        assert np.allclose(p0[n], p1[n], atol=2e-4, rtol=1e-3), (n, np.abs(p0[n] - p1[n]).max())
 
 
 @pytest.mark.parametrize("name", ["transe_l1", "transe_l2", "transh_l1", "transh_l2", "transd_l1", "transd_l2",

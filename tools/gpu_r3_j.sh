@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out
-timeout 300 python -m pytest tests/test_hip_parity.py -x -q -m gpu --timeout 100 -k "rescal_pair_step" > $O/j3_pair.log 2>&1; tail -15 $O/j3_pair.log | cut -c1-300
+timeout 300 python -m pytest tests/test_hip_parity.py -x -q -m gpu --timeout 100 -k "rescal_pair_step or touched_gradient" > $O/j3_pair.log 2>&1; tail -15 $O/j3_pair.log | cut -c1-300
 timeout 400 python -m pytest tests/test_hip_parity.py tests/test_fullsize_golden.py tests/test_hip_edges.py -x -q -m gpu --timeout 200 -k "rescal or transr or graph_replayed or ntn" > $O/j3_tests.log 2>&1; tail -4 $O/j3_tests.log | cut -c1-300
 run() { ONLY="$1" N_EVAL=64 timeout 120 python tools/config_perf.py 2>&1 | tail -1; }
 for u in 1 0; do
