@@ -61,6 +61,48 @@ __global__ void k_rel_scatter(IdSplit r, int64_t n, const int* __restrict__ offs
     if (local % tile == 0) tile_rel[tile_off[rel] + local / tile] = rel;  // the first row of a tile names its relation
 }
 
+// Large batches over few relations (tens of thousands of items on a few dozen counters): the histogram and the scatter cursors
+// are taken per block in LDS first, so the global counters see one atomic per (block, relation with items in the block).
+constexpr int kGroupItems = 4096;      // items per 1024-thread block
+__global__ __launch_bounds__(1024) void k_rel_hist_lds(IdSplit r, int64_t n, int R, int* __restrict__ counts) {
+    extern __shared__ int s_h[];
+    for (int i = threadIdx.x; i < R; i += 1024) s_h[i] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * kGroupItems;
+    for (int j = threadIdx.x; j < kGroupItems && lo + j < n; j += 1024) atomicAdd(&s_h[(int)r.at(lo + j)], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < R; i += 1024)
+        if (s_h[i]) atomicAdd(counts + i, s_h[i]);
+}
+
+__global__ __launch_bounds__(1024) void k_rel_scatter_lds(IdSplit r, int64_t n, int R, const int* __restrict__ offsets,
+                                                          const int* __restrict__ tile_off, int* __restrict__ cursor,
+                                                          int* __restrict__ perm, int* __restrict__ tile_rel, int tile) {
+    extern __shared__ int s_h[];
+    int* s_cnt = s_h;          // [R] items of this block per relation
+    int* s_base = s_h + R;     // [R] first position (inside the relation's range) this block reserved
+    for (int i = threadIdx.x; i < R; i += 1024) s_cnt[i] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * kGroupItems;
+    int rel[kGroupItems / 1024], rank[kGroupItems / 1024];
+#pragma unroll
+    for (int q = 0; q < kGroupItems / 1024; ++q) {
+        const int64_t i = lo + threadIdx.x + 1024 * q;
+        rel[q] = i < n ? (int)r.at(i) : -1;
+        rank[q] = rel[q] >= 0 ? atomicAdd(&s_cnt[rel[q]], 1) : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R; i += 1024) s_base[i] = s_cnt[i] ? atomicAdd(cursor + i, s_cnt[i]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kGroupItems / 1024; ++q) {
+        if (rel[q] < 0) continue;
+        const int local = s_base[rel[q]] + rank[q];
+        perm[offsets[rel[q]] + local] = (int)(lo + threadIdx.x + 1024 * q);
+        if (local % tile == 0) tile_rel[tile_off[rel[q]] + local / tile] = rel[q];
+    }
+}
+
 int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s) {
     return group_by_relation_split(id_whole(r, n), n, R, g, s);
 }
@@ -133,6 +175,14 @@ int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, h
     }
     hipError_t e = hipMemsetAsync(g.counts, 0, (size_t)2 * (R + 1) * sizeof(int), s);  // counts + cursor
     if (e != hipSuccess) { set_error("rescal grouping memset: %s", hipGetErrorString(e)); return -2; }
+    if (R <= kSmallGroupMaxR) {   // block-local histogram / ranks in LDS: one global atomic per (block, relation) instead of one per item
+        const unsigned nbl = (unsigned)((n + kGroupItems - 1) / kGroupItems);
+        hipLaunchKernelGGL(k_rel_hist_lds, dim3(nbl), dim3(1024), (size_t)R * sizeof(int), s, r, n, (int)R, g.counts);
+        hipLaunchKernelGGL(k_rel_scan, dim3(1), dim3(256), 0, s, g.counts, (int)R, g.offsets, g.tile_off, tile);
+        hipLaunchKernelGGL(k_rel_scatter_lds, dim3(nbl), dim3(1024), (size_t)2 * R * sizeof(int), s, r, n, (int)R, g.offsets, g.tile_off,
+                           g.cursor, g.perm, g.tile_rel, tile);
+        return check_launch("rescal grouping");
+    }
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_rel_hist, dim3(nb), dim3(256), 0, s, r, n, g.counts);
     hipLaunchKernelGGL(k_rel_scan, dim3(1), dim3(256), 0, s, g.counts, (int)R, g.offsets, g.tile_off, tile);
@@ -526,7 +576,8 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
                                                       const int64_t* __restrict__ nh, const int64_t* __restrict__ nt,
                                                       const int* __restrict__ offsets, const int* __restrict__ tile_off,
                                                       const int* __restrict__ tile_rel, const int* __restrict__ perm, int R, int k,
-                                                      float margin, float* __restrict__ loss, unsigned* __restrict__ touched) {
+                                                      float margin, float* __restrict__ loss, unsigned* __restrict__ touched,
+                                                      float* __restrict__ ds_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rel, tin;
     if (!locate_tile(tile_off, tile_rel, R, blockIdx.x, rel, tin)) return;
@@ -544,10 +595,12 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
     const int li = lane & 31, lk = lane >> 5;
     const int g0 = offsets[rel] + tin * kPairTile;
     const int cnt = min(kPairTile, offsets[rel + 1] - g0);
+    int my_pair = -1;
     if (threadIdx.x < TILE) {
         const int p = threadIdx.x & (kPairTile - 1);
         const bool neg = threadIdx.x >= kPairTile;
         const int pair = p < cnt ? perm[g0 + p] : -1;
+        my_pair = pair;
         sHid[threadIdx.x] = pair >= 0 ? (neg ? nh[pair] : ph[pair]) : 0;
         sTid[threadIdx.x] = pair >= 0 ? (neg ? nt[pair] : pt[pair]) : 0;
         sDs[threadIdx.x] = 0.f;
@@ -632,6 +685,7 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
             v = (-sp) + margin - (-sn);
             c = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);
             sDs[p] = c; sDs[kPairTile + p] = -c;
+            if (ds_out) ds_out[my_pair] = c;     // large batches: the relation-matrix gradient is a second, relation-owner launch
         }
         const float tot = wave_sum(fmaxf(v, 0.f));
         const unsigned long long any = __ballot(c != 0.f);
@@ -649,12 +703,22 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
     }
 
     // ---- grad_t = -ds V (from the registers of the first K half's waves)
+    // (rows i and i + 16 are the two sides of one pair: register reg and reg + 8 of the same lane; the side the sampler did not
+    // corrupt is the SAME entity row, whose two contributions leave as one atomic: a quarter of the float atomics of a batch)
     if (live && ks == 0 && col < k) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
+        for (int reg = 0; reg < 8; ++reg) {
             const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
             const float ds = sDs[i];
-            if (ds != 0.f) unsafeAtomicAdd(g_ent + sTid[i] * k + col, -ds * acc[reg]);
+            if (ds != 0.f) {
+                const long long ta = sTid[i], tb = sTid[i + kPairTile];
+                if (ta == tb) {
+                    unsafeAtomicAdd(g_ent + ta * k + col, -ds * (acc[reg] - acc[reg + 8]));
+                } else {
+                    unsafeAtomicAdd(g_ent + ta * k + col, -ds * acc[reg]);
+                    unsafeAtomicAdd(g_ent + tb * k + col, ds * acc[reg + 8]);
+                }
+            }
         }
     }
     // ---- U[i][a] = sum_b T[i][b] M[a][b]: lane a reads its row of M sixteen bytes at a time; the four values of a load feed four
@@ -687,14 +751,24 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
     __syncthreads();
     if (live && ks == 0 && col < k) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
+        for (int reg = 0; reg < 8; ++reg) {
             const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
             const float ds = sDs[i];
-            const float v = ua[reg] + sRed[(u * 16 + reg) * 64 + lane];
-            if (ds != 0.f) unsafeAtomicAdd(g_ent + sHid[i] * k + col, -ds * v);     // grad_h = -ds U
+            const float va = ua[reg] + sRed[(u * 16 + reg) * 64 + lane];
+            const float vb = ua[reg + 8] + sRed[(u * 16 + reg + 8) * 64 + lane];
+            if (ds != 0.f) {     // grad_h = -ds U
+                const long long ha = sHid[i], hb = sHid[i + kPairTile];
+                if (ha == hb) {
+                    unsafeAtomicAdd(g_ent + ha * k + col, -ds * (va - vb));
+                } else {
+                    unsafeAtomicAdd(g_ent + ha * k + col, -ds * va);
+                    unsafeAtomicAdd(g_ent + hb * k + col, ds * vb);
+                }
+            }
         }
     }
     // ---- G[a][b] = sum_i ds_i H[i][a] T[i][b] ;  grad_M = -G
+    if (ds_out) return;
     float* gM = g_rel + (int64_t)rel * k * k;
     for (int tl = wave; tl < ntile * ntile; tl += 16) {
         const int at = tl / ntile, bt = tl - at * ntile;
@@ -717,12 +791,120 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
     }
 }
 
+// Large batches: a (relation, 16 pairs) tile adding its 32-triple share of G with k^2 float atomics makes the atomics the whole
+// cost (2085 tiles x 40 000 at B = 32768 on YAGO3-10's 37 relations: 485 us of a 568 us launch).  Then k_rescal_pair only
+// leaves dL/denergy of every pair behind and this kernel accumulates G over runs of kPairGmRun tiles: the workgroup of a run's
+// first tile stages 32 triples at a time in LDS (rows of H pre-multiplied by ds) and its sixteen waves hold ALL ceil(k/32)^2 output
+// tiles in registers across the run, so the rows are read once per run and a relation of at most one run is written with k^2
+// plain read-modify-writes; longer relations add atomically, once per run.
+constexpr int kPairGmRun = 8;
+__global__ __launch_bounds__(1024) void k_rescal_pair_gm(const float* __restrict__ ent, float* __restrict__ g_rel,
+                                                        const int64_t* __restrict__ ph, const int64_t* __restrict__ pt,
+                                                        const int64_t* __restrict__ nh, const int64_t* __restrict__ nt,
+                                                        const int* __restrict__ offsets, const int* __restrict__ tile_off,
+                                                        const int* __restrict__ tile_rel, const int* __restrict__ perm, int R, int k,
+                                                        const float* __restrict__ ds) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int rel, tin;
+    if (!locate_tile(tile_off, tile_rel, R, blockIdx.x, rel, tin)) return;
+    if (tin % kPairGmRun) return;
+    const int S = (k + 1) | 1;
+    float* sT = smem;                          // [32][S]
+    float* sH = sT + TILE * S;                 // [32][S]  ds_i * h_i
+    float* sDs = sH + TILE * S;                // [32]
+    long long* sHid = (long long*)(sDs + TILE);
+    long long* sTid = sHid + TILE;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the per-tile branches below stay branches)
+    const int li = lane & 31, lk = lane >> 5;
+    const int ntile = (k + 31) / 32, nt2 = ntile * ntile;      // <= 64 tiles: four per wave
+    const int r0 = offsets[rel], r1 = offsets[rel + 1];
+    const int g_lo = r0 + tin * kPairTile, g_hi = min(r1, g_lo + kPairGmRun * kPairTile);
+    const bool shared_rel = (r1 - r0) > kPairGmRun * kPairTile;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x16{0};
+    const int nv = k >> 2;
+    for (int g0 = g_lo; g0 < g_hi; g0 += kPairTile) {
+        __syncthreads();
+        if (threadIdx.x < TILE) {
+            const int p = threadIdx.x & (kPairTile - 1);
+            const bool neg = threadIdx.x >= kPairTile;
+            const int pair = g0 + p < g_hi ? perm[g0 + p] : -1;
+            const float c = pair >= 0 ? ds[pair] : 0.f;
+            sHid[threadIdx.x] = pair >= 0 ? (neg ? nh[pair] : ph[pair]) : 0;
+            sTid[threadIdx.x] = pair >= 0 ? (neg ? nt[pair] : pt[pair]) : 0;
+            sDs[threadIdx.x] = neg ? -c : c;
+        }
+        __syncthreads();
+        constexpr int kMaxPer = 2;                   // TILE * nv / 1024 float4 per thread and matrix (k <= 256)
+        float4 rt[kMaxPer], rh[kMaxPer];
+#pragma unroll
+        for (int j = 0; j < kMaxPer; ++j) {
+            const int idx = threadIdx.x + 1024 * j;
+            const int i = idx / nv, c = idx - i * nv;
+            const bool ok = idx < TILE * nv && sDs[i] != 0.f;
+            rt[j] = ok ? reinterpret_cast<const float4*>(ent + sTid[i] * k)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rh[j] = ok ? reinterpret_cast<const float4*>(ent + sHid[i] * k)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxPer; ++j) {
+            const int idx = threadIdx.x + 1024 * j;
+            if (idx < TILE * nv) {
+                const int i = idx / nv, c = (idx - i * nv) * 4;
+                const float d = sDs[i];
+                float* dt = sT + i * S + c;
+                float* dh = sH + i * S + c;
+                dt[0] = rt[j].x; dt[1] = rt[j].y; dt[2] = rt[j].z; dt[3] = rt[j].w;
+                dh[0] = d * rh[j].x; dh[1] = d * rh[j].y; dh[2] = d * rh[j].z; dh[3] = d * rh[j].w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int tl = wave + 16 * t;
+            if (tl < nt2) {
+                const int at = tl / ntile, bt = tl - at * ntile;
+                int a_in = min(at * 32 + li, k - 1), b_in = min(bt * 32 + li, k - 1);   // (clamped columns are never stored)
+                // (opaque to the optimiser: otherwise the 128 loop-invariant LDS addresses of the four tiles are hoisted out of the
+                // chunk loop and spilled)
+                asm volatile("" : "+v"(a_in), "+v"(b_in));
+#pragma unroll
+                for (int kk = 0; kk < TILE; kk += 2) {
+                    const int i = kk + lk;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sH[i * S + a_in], sT[i * S + b_in], acc[t], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the LDS operand reads of later tiles from being hoisted over this one: registers)
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tl = wave + 16 * t;
+        const int at = tl / ntile, bt = tl - at * ntile;
+        const int b_in = bt * 32 + li;
+        const bool on = tl < nt2 && b_in < k;
+        float* gM = g_rel + (int64_t)rel * k * k;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int a = at * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+            if (on && a < k && acc[t][reg] != 0.f) {
+                float* q = gM + (int64_t)a * k + b_in;
+                if (shared_rel) unsafeAtomicAdd(q, -acc[t][reg]); else *q -= acc[t][reg];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+constexpr int64_t kPairSplitG = 8192;      // pairs from which the relation-matrix gradient gets its own launch
+
 static size_t rescal_pair_lds_bytes(int k) {
     const int S = (k + 1) | 1;
     return (size_t)(2 * TILE * S + 8 * 16 * 64 + 8 * TILE + TILE) * sizeof(float) + (size_t)2 * TILE * sizeof(long long) + 16;
 }
 static size_t rescal_pair_ws_bytes(int64_t R, int64_t n) {
-    return (size_t)(4 * (R + 1) + n + (n / kPairTile + R + 1) + 8) * sizeof(int);
+    return (size_t)(4 * (R + 1) + n + (n / kPairTile + R + 1) + 8 + (n >= kPairSplitG ? n : 0)) * sizeof(int);
 }
 
 bool rescal_pair_step_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
@@ -745,8 +927,16 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
         (void)hipFuncSetAttribute((const void*)k_rescal_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_rescal_pair, dim3((unsigned)(n / kPairTile + R + 1)), dim3(1024), lds, s, m->tables[0], m->tables[1], m->grads[0],
-                       m->grads[1], ph, pt, nh, nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched);
+    const unsigned tiles = (unsigned)(n / kPairTile + R + 1);
+    float* ds = n >= kPairSplitG ? (float*)(g.tile_rel + tiles) : nullptr;
+    hipLaunchKernelGGL(k_rescal_pair, dim3(tiles), dim3(1024), lds, s, m->tables[0], m->tables[1], m->grads[0],
+                       m->grads[1], ph, pt, nh, nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched, ds);
+    if (ds) {
+        const int S = (k + 1) | 1;
+        const size_t lds_gm = (size_t)(2 * TILE * S + TILE) * sizeof(float) + (size_t)2 * TILE * sizeof(long long);
+        hipLaunchKernelGGL(k_rescal_pair_gm, dim3(tiles), dim3(1024), lds_gm, s, m->tables[0], m->grads[1], ph, pt, nh, nt, g.offsets,
+                           g.tile_off, g.tile_rel, g.perm, (int)R, k, ds);
+    }
     return check_launch("k_rescal_pair");
 }
 

@@ -327,7 +327,10 @@ def test_scores_loss_grads_vs_oracle_other_shapes(hip, model, hp, neg_rate):
 
 
 @pytest.mark.parametrize("k,E,R,B,margin", [(200, 300, 11, 160, 1.0), (64, 300, 3, 333, 1.0), (256, 50, 1, 40, 2.0), (4, 300, 40, 160, 1.0),
-                                              (200, 3000, 400, 1024, 0.5), (120, 300, 11, 160, 0.02), (36, 9, 2, 1, 1.0)])
+                                              (200, 3000, 400, 1024, 0.5), (120, 300, 11, 160, 0.02), (36, 9, 2, 1, 1.0),
+                                              # >= 8192 pairs: dL/denergy left behind, relation-matrix gradient by the relation-owner
+                                              # launch (k_rescal_pair_gm); > 16384: the block-aggregated grouping kernels
+                                              (64, 3000, 5, 9000, 1.0), (32, 5000, 7, 20000, 1.0), (32, 5000, 700, 20000, 1.0)])
 def test_rescal_pair_step_in_one_launch_matches_oracle(hip, monkeypatch, k, E, R, B, margin):
     """nr IS pr (one buffer): kge_train_pairwise_hinge groups PAIRS by relation and runs scores, hinge and the three gradients in
     one launch (k_rescal_pair).  Against the oracle, and against the three-launch path on the same batch (margin 0.02: most

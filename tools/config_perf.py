@@ -35,6 +35,10 @@ CONFIGS = [
     ("QuatE FB15k d=200 B=100 adagrad (preset)", "quate", "fb15k", dict(hidden_size=200, lmbda=0.1), "adagrad", 100, 1, 2048),
     ("QuatE FB15k d=100 B=32768 adagrad", "quate", "fb15k", dict(hidden_size=100, lmbda=0.1), "adagrad", 32768, 1, 0),
     ("QuatE WN18 d=300 B=4096 adagrad", "quate", "wn18rr", dict(hidden_size=300, lmbda=0.05), "adagrad", 4096, 1, 0),
+    ("mfma-batch RESCAL YAGO3-10 k=200 B=32768 adam", "rescal", "yago310", dict(hidden_size=200, margin=1.0), "adam", 32768, 1, 0),
+    ("mfma-batch RESCAL FB15k k=200 B=32768 adam", "rescal", "fb15k", dict(hidden_size=200, margin=1.0), "adam", 32768, 1, 0),
+    ("mfma-batch TransR FB15k 100/100 B=32768 adam", "transr", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 0),
+    ("mfma-batch NTN FB15k d=k=100 B=32768 adam", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 32768, 1, 0),
     ("NTN FB15k d=k=100 B=128 adam (preset)", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 128, 1, 64),
 ]
 if os.environ.get("GRAPH_UNROLL"):
