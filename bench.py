@@ -445,6 +445,26 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    # ---- N > 1: where a step's time goes.  A separate, untimed pass of 16 steps with an event at every phase boundary of the
+    # data-parallel step (Trainer._mark): compute (the owner-computes kernel writing this rank's dense gradient rows, next batch's
+    # sampler riding along) / reduce-scatter / optimiser on the rank's shard / all-gather of the updated tables / row norms of the
+    # gathered tables.  Mean per phase, MAX over ranks.  (Outside the timed region: the events serialise the async all-gather.)
+    phases_us = None
+    if world > 1:
+        reset_model()
+        tr.phase_marks = []
+        run_steps(16)
+        torch.cuda.synchronize()
+        marks, tr.phase_marks = tr.phase_marks, None
+        acc = {}
+        for (n0, e0), (n1, e1) in zip(marks, marks[1:]):
+            if n1 != "begin":
+                acc.setdefault(n1, []).append(e0.elapsed_time(e1) * 1e3)
+        names = ["compute", "reduce_scatter", "optimiser", "all_gather", "row_norms"]
+        vec = torch.tensor([float(np.mean(acc[k])) if k in acc else 0.0 for k in names], dtype=torch.float64, device=device)
+        dist.all_reduce(vec, op=dist.ReduceOp.MAX)
+        phases_us = {k: float(v) for k, v in zip(names, vec.tolist())}
+        phases_us["steps"] = 16
     per_rank_batch = args.batch
     scored_per_step = 2 * per_rank_batch * world
     value = scored_per_step * args.steps / dt
@@ -627,6 +647,7 @@ def main():
             if ref is not None:
                 out["cpu_baseline"]["reference_in_build_container"] = ref
         if world > 1:
+            out["phases_us"] = phases_us
             out["collectives"] = {"backend": dist.get_backend(), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "(unset: RCCL picks)"),
                                   "NCCL_PROTO": os.environ.get("NCCL_PROTO", "(unset)"),
                                   "per_step": "reduce_scatter(flat grad, %d B) + all_gather(flat param)" % (tr.flat.numel * 4),

@@ -207,6 +207,8 @@ class Trainer:
         self.use_graph = use_graph
         self.switches = self._switches()
         self._touched, self._touch_parity, self._touched_step = None, 0, None   # RESCAL: bitmaps of entity rows with a gradient
+        self._gather_work = None      # N > 1: the in-flight all-gather of the previous step's parameters (see _reduce_and_step)
+        self.phase_marks = None       # bench.py at N > 1: a list that receives (phase name, event) at the phase boundaries of a step
         self._graph = None
         self.world_size = 1
         self.rank = 0
@@ -231,6 +233,22 @@ class Trainer:
         self._selfadv_ws = None
         if self.distributed:  # replicas must start identical
             torch.distributed.broadcast(self.flat.param, src=0, group=self.process_group)
+
+    def _mark(self, name):
+        """Per-phase timing of the multi-GPU step (bench.py --gpus N): an event on the current stream at a phase boundary.  The
+        collectives are issued synchronously with respect to the stream (the stream waits for RCCL's), so an event behind a
+        collective completes when the collective has."""
+        if self.phase_marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.phase_marks.append((name, ev))
+
+    def _wait_gather(self):
+        """The previous step's parameter all-gather was issued asynchronously (N > 1, eager steps): everything that does not read
+        the tables -- the next batch's sampler launch, host-side argument marshalling -- runs under it; the first reader waits here."""
+        if self._gather_work is not None:
+            self._gather_work.wait()
+            self._gather_work = None
 
     # ------------------------------------------------------------------ one step (gradients into flat.grad)
     def _accumulate_pairwise(self, ph, pr, pt, nh, nr, nt, sampled=False):
@@ -286,17 +304,20 @@ class Trainer:
         gen = self.generator
         if self._fused_rotate_ok():
             start, n, offset = fixed_range if fixed_range is not None else gen._next_range()
+            self._wait_gather()
             K.train_pairwise_selfadv_sampled(self._desc, gen.triples, gen.perm, start, n, gen.neg_rate, self.config.alpha,
                                              gen.bern, gen.slots, gen.seed, offset, self.loss_buf, cursor=cursor)
             return
         if self._fused_pointwise_ok():
             start, n, offset = fixed_range if fixed_range is not None else gen._next_range()
+            self._wait_gather()
             K.train_pointwise_logistic_sampled(self._desc, gen.triples, gen.perm, start, n, gen.neg_rate, gen.bern, gen.slots,
                                                gen.seed, offset, self.model.kernel_lmbda(), self.model.kernel_reg_type(),
                                                self.loss_buf, cursor=cursor)
             return
         if self._fused_sampler_ok():
             start, n, offset = fixed_range if fixed_range is not None else gen._next_range()
+            self._wait_gather()
             K.train_pairwise_hinge_sampled(self._desc, gen.triples, gen.perm, start, n, gen.bern, gen.slots, gen.seed,
                                            offset, self.config.margin, self.loss_buf, cursor=cursor)
             return
@@ -307,6 +328,7 @@ class Trainer:
                                   cursor=cursor)
         else:
             data = next(gen)
+        self._wait_gather()      # (the sampler launch above ran under the previous step's parameter all-gather)
         if self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED:
             self._accumulate_pairwise(*data, sampled=True)
         else:
@@ -375,6 +397,7 @@ class Trainer:
             return
         pairs, inc, items, multi = idx.batch(b)
         cur = ps.cur_list
+        self._mark("begin")
         if ps.ready != (b, offset):
             ps.lists[cur].clear()
             K.pull_sample(pairs, idx.inv(b), cfg.tot_entity, gen.bern, gen.slots, gen.seed, offset, ps.lists[cur])
@@ -397,6 +420,7 @@ class Trainer:
             ps.ready = None
         self._reduce_and_step(clear_local_grad=False)   # every row of the local gradient is rewritten by the next step
         ps.refresh_norms()
+        self._mark("row_norms")
 
     def _pull_fixed_tables(self):
         """Non-trainable descriptor tables after the two embedding tables (TransM: the per-relation weights theta)."""
@@ -655,10 +679,14 @@ class Trainer:
             for _ in range(n):
                 self._pull_dp_step()
             return
-        for _ in range(n):
-            self._rescal_last = self.generator._pending == 1   # the epoch's last step leaves RESCAL's tables as the optimiser wrote them
-            self._accumulate_next_batch()
-            self._reduce_and_step()
+        try:
+            for _ in range(n):
+                self._rescal_last = self.generator._pending == 1   # the epoch's last step leaves RESCAL's tables as the optimiser wrote them
+                self._mark("begin")
+                self._accumulate_next_batch()
+                self._reduce_and_step(overlap_gather=self.distributed)
+        finally:
+            self._wait_gather()
 
     def _touched_bitmaps(self):
         if getattr(self, "_touched", None) is None:
@@ -691,7 +719,7 @@ class Trainer:
         name = torch.distributed.get_backend(self.process_group)
         return name == "nccl", name
 
-    def _reduce_and_step(self, advance=None, clear_local_grad=True):
+    def _reduce_and_step(self, advance=None, clear_local_grad=True, overlap_gather=False):
         """Gradient exchange (N > 1) + dense optimiser.  `advance`: the device-resident step-state arguments of
         FlatState.optimizer_step_advance when the step is being captured into a hipGraph."""
         flat = self.flat
@@ -730,6 +758,8 @@ class Trainer:
         dist = torch.distributed
         mean = self._mean_type_loss()
         fused, _ = self._collectives()
+        self._wait_gather()
+        self._mark("compute")
         if fused:
             dist.reduce_scatter_tensor(flat.grad_shard, flat.grad, op=dist.ReduceOp.AVG if mean else dist.ReduceOp.SUM,
                                        group=self.process_group)
@@ -740,8 +770,16 @@ class Trainer:
                 flat.grad_shard.div_(self.world_size)
         if clear_local_grad:
             flat.grad.zero_()      # the local accumulation buffer of the next step (the optimiser clears only grad_shard)
+        self._mark("reduce_scatter")
         optimise()
-        dist.all_gather_into_tensor(flat.param, flat.param_shard, group=self.process_group)
+        self._mark("optimiser")
+        if overlap_gather and advance is None and self.phase_marks is None:
+            # eager steps inside an epoch: the all-gather runs on RCCL's stream while the host marshals -- and the GPU runs -- the
+            # next batch's sampler; the first launch that reads the tables waits for it (_wait_gather).  Same values, same order.
+            self._gather_work = dist.all_gather_into_tensor(flat.param, flat.param_shard, group=self.process_group, async_op=True)
+        else:
+            dist.all_gather_into_tensor(flat.param, flat.param_shard, group=self.process_group)
+            self._mark("all_gather")
 
     def train_step_pairwise(self, pos_h, pos_r, pos_t, neg_h, neg_r, neg_t):
         """Loss of one batch as a device scalar (no sync); gradients are left in the flat buffer."""

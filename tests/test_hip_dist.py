@@ -100,7 +100,8 @@ def _run_rccl_one_rank(rank, port, case, out_dir):
     E, R, D, B = 600, 19, 32, 256
     n_train = 4 * B
     train = np.stack([rng.integers(E, size=n_train), rng.integers(R, size=n_train), rng.integers(E, size=n_train)], 1)
-    hp = dict(hidden_size=D, l1_flag=True, margin=1.0) if model == "transe" else dict(hidden_size=D, lmbda=1e-3)
+    hp = (dict(hidden_size=D, l1_flag=True, margin=1.0) if model == "transe" else
+          dict(hidden_size=D, margin=1.0) if model == "rescal" else dict(hidden_size=D, lmbda=1e-3))
     P = ko.init_params(model, rng, tot_entity=E, tot_relation=R, hidden_size=D)
     out = {}
     for label, pg in (("plain", None), ("rccl", dist.group.WORLD)):
@@ -123,19 +124,34 @@ def _run_rccl_one_rank(rank, port, case, out_dir):
             assert tr._graph is not None
         torch.cuda.synchronize()
         out[label] = (losses, {n: p.detach().cpu().numpy() for n, p in m.named_parameters()})
-    np.savez(os.path.join(out_dir, "rccl1.npz"), plain_losses=np.asarray(out["plain"][0]), rccl_losses=np.asarray(out["rccl"][0]),
+        if pg is not None and mode != "graph":   # the per-phase events bench.py reads at N > 1
+            tr.phase_marks = []
+            tr.train_model_epoch(2)
+            torch.cuda.synchronize()
+            names = [n for n, _ in tr.phase_marks]
+            times = [a[1].elapsed_time(b[1]) for a, b in zip(tr.phase_marks, tr.phase_marks[1:])]
+            assert min(times) >= 0.0
+            tr.phase_marks = None
+            out["marks"] = names
+    np.savez(os.path.join(out_dir, "rccl1.npz"), marks=np.asarray(out.get("marks", []), dtype="U32"), plain_losses=np.asarray(out["plain"][0]), rccl_losses=np.asarray(out["rccl"][0]),
              **{"plain." + k: v for k, v in out["plain"][1].items()}, **{"rccl." + k: v for k, v in out["rccl"][1].items()})
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("case", [("transe", "adam", "eager"), ("transe", "adam", "graph"), ("transe", "sgd", "pull"),
-                                  ("complex", "adagrad", "eager"), ("complex", "adagrad", "graph")],
+                                  ("complex", "adagrad", "eager"), ("complex", "adagrad", "graph"),
+                                  ("rescal", "adam", "eager")],   # separate sampler launch: it runs under the async all-gather
                          ids=lambda c: "-".join(c))
 def test_one_rank_rccl_group_runs_the_collective_step(tmp_path, case):
     out = str(tmp_path)
     mp.spawn(_run_rccl_one_rank, args=(_free_port(), case, out), nprocs=1, join=True)
     z = np.load(os.path.join(out, "rccl1.npz"))
     assert np.allclose(z["plain_losses"], z["rccl_losses"], rtol=1e-4), (z["plain_losses"], z["rccl_losses"])
+    marks = [str(x) for x in z["marks"]]
+    if case[2] == "pull":      # four full batches through the owner-computes gradient step
+        assert marks == ["begin", "compute", "reduce_scatter", "optimiser", "all_gather", "row_norms"] * 4, marks
+    elif case[2] == "eager":
+        assert marks == ["begin", "compute", "reduce_scatter", "optimiser", "all_gather"] * 4, marks
     for k in z.files:
         if not k.startswith("plain."):
             continue

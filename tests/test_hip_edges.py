@@ -147,6 +147,8 @@ def test_bench_two_ranks_owner_computes_gradient():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "owner-computes gradient" in d["config"]["step_path"]
     assert d["value"] > 0 and "REPLICAS_IDENTICAL 1" in out.stdout
+    ph = d["phases_us"]     # per-phase event times of the data-parallel step (max over ranks)
+    assert all(ph[k] > 0 for k in ("compute", "reduce_scatter", "optimiser", "all_gather", "row_norms")), ph
 
 
 def test_bench_two_ranks_share_one_gpu():
@@ -166,6 +168,8 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8192
     assert d["value"] > 0 and d["eval"]["value"] > 0 and "cpu_baseline" not in d
     assert "REPLICAS_IDENTICAL 1" in out.stdout
+    ph = d["phases_us"]
+    assert all(ph[k] > 0 for k in ("compute", "reduce_scatter", "optimiser", "all_gather")), ph
 
 
 @pytest.mark.parametrize("model,hp,opt,lr,fmr_drop,mrr_gain", [
