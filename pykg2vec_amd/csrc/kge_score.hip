@@ -608,6 +608,167 @@ __global__ __launch_bounds__(kBlock) void k_rotate_bundle_staged(DeviceModel m, 
     block_accumulate_loss<G>(acc, gl, loss);
 }
 
+// ---- the same single-pass staged step with a bundle's ROWS SPLIT OVER TWO WAVES (64-lane groups only: rows of more than 512
+// floats).  One wave per bundle holds eleven 1024-float rows in registers (256 VGPRs + 244 AGPRs): one wave per SIMD, and C3's
+// 1024 bundles walk their 16 negatives as a chain of dependent (gather -> evaluate) rounds with nothing to hide the round trips
+// behind.  Here each of the two waves of a bundle owns one half of every row (NCH/2 chunks: ~180 registers, two waves per SIMD);
+// the only coupling is the energy of a triple, whose two partial sums meet in LDS (one workgroup barrier per negative, double
+// buffered).  Everything derived from the energy (softmax state, weights) is computed redundantly by both waves.  Same
+// mathematics; the energy is the sum of two half-row sums instead of one 64-lane butterfly over the whole row.
+// (Splitting the NEGATIVES over two waves instead keeps all eleven rows per wave: 626 spilled registers at two waves per SIMD.)
+template <int NCH, int SPLIT>
+__global__ __launch_bounds__(kBlock, SPLIT) void k_rotate_bundle_staged_split(DeviceModel m, int64_t n_pos, int neg_rate, float alpha,
+                                                                          float* __restrict__ loss, FusedSampler fs, StageSink sink,
+                                                                          float* __restrict__ pair_scale) {
+    constexpr int G = 64;
+    constexpr int BPB = kBlock / (64 * SPLIT);  // bundles per workgroup (SPLIT waves each)
+    constexpr int HALF = G * NCH;              // floats of a row one wave owns
+    __shared__ float s_p[2][BPB][SPLIT];       // [parity][bundle][part] partial energies
+    const int gl = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, half = wave % SPLIT, slot_b = wave / SPLIT;   // half: which part of every row
+    const int d = m.dim;
+    const int dh = min(max(d - half * HALF, 0), HALF);     // this wave's share of a row
+    const int64_t ho = (int64_t)half * HALF;
+    const float inv_b = 1.0f / (float)n_pos;
+    float acc = 0.f;
+    int par = 0;
+    for (int64_t i0 = (int64_t)blockIdx.x * BPB; i0 < n_pos; i0 += (int64_t)gridDim.x * BPB) {
+        const int64_t i = i0 + slot_b;
+        const bool valid = i < n_pos;
+        int64_t h = 0, r = 0, t = 0;
+        int my_c = 0, my_tail = 0;
+        if (valid) {
+            const int64_t row = fs.perm[fs.start + i];
+            h = fs.triples[3 * row]; r = fs.triples[3 * row + 1]; t = fs.triples[3 * row + 2];
+            if (gl < neg_rate) {
+                int64_t nh, nt;
+                corrupt_one(h, r, t, fs.E, fs.bern, fs.slots, fs.mask, fs.seed, fs.offset + (unsigned long long)(i * neg_rate + gl), nh, nt);
+                my_tail = nh == h;
+                my_c = (int)(my_tail ? nt : nh);
+            }
+        }
+        const int dv = valid ? dh : 0;         // (an invalid bundle loads and stores nothing but keeps the barriers)
+        float HR[NCH], HI[NCH], TR[NCH], TI[NCH], CS[NCH], SN[NCH];
+        {
+            float RL[NCH];
+            load_row<G, NCH>(HR, m.tab[0] + h * (int64_t)d + ho, dv, gl);
+            load_row<G, NCH>(HI, m.tab[1] + h * (int64_t)d + ho, dv, gl);
+            load_row<G, NCH>(RL, m.tab[2] + r * (int64_t)d + ho, dv, gl);
+            load_row<G, NCH>(TR, m.tab[0] + t * (int64_t)d + ho, dv, gl);
+            load_row<G, NCH>(TI, m.tab[1] + t * (int64_t)d + ho, dv, gl);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) sincosf(RL[k] / m.phase_div, &SN[k], &CS[k]);
+        }
+        float aHR[NCH], aHI[NCH], aTR[NCH], aTI[NCH], aP[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) { aHR[k] = aHI[k] = aTR[k] = aTI[k] = aP[k] = 0.f; }
+        float M = -INFINITY, D = 0.f, Lw = 0.f, m_mine = 0.f;
+        float NR[NCH], NI[NCH];
+        {
+            const int64_t c0 = __shfl(my_c, 0, 64);
+            load_row<G, NCH>(NR, m.tab[0] + c0 * (int64_t)d + ho, dv, gl);
+            load_row<G, NCH>(NI, m.tab[1] + c0 * (int64_t)d + ho, dv, gl);
+        }
+        for (int j = 0; j < neg_rate; ++j) {
+            const int64_t c = __shfl(my_c, j, 64);
+            const bool tail = __shfl(my_tail, j, 64) != 0;
+            float CR[NCH], CI[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { CR[k] = NR[k]; CI[k] = NI[k]; }
+            if (j + 1 < neg_rate) {
+                const int64_t cn1 = __shfl(my_c, j + 1, 64);
+                load_row<G, NCH>(NR, m.tab[0] + cn1 * (int64_t)d + ho, dv, gl);
+                load_row<G, NCH>(NI, m.tab[1] + cn1 * (int64_t)d + ho, dv, gl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float re[NCH], im[NCH], p = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const float ar = tail ? HR[k] : CR[k], ai = tail ? HI[k] : CI[k];
+                const float br = tail ? CR[k] : TR[k], bi = tail ? CI[k] : TI[k];
+                re[k] = ar * CS[k] - ai * SN[k] - br;
+                im[k] = ar * SN[k] + ai * CS[k] - bi;
+                p += re[k] * re[k] + im[k] * im[k];
+            }
+            p = gsum<G>(p);
+            if (gl == 0) s_p[par][slot_b][half] = p;
+            __syncthreads();
+            float en = 0.f;
+#pragma unroll
+            for (int q = 0; q < SPLIT; ++q) en += s_p[par][slot_b][q];
+            const float nj = m.margin - en;   // = -(energy of negative j)
+            par ^= 1;
+            const float a = nj * alpha;
+            const float Mn = fmaxf(M, a);
+            const float f = expf(M - Mn);
+            const float e = expf(a - Mn);
+            const float wt = e * sigmoid_t(nj);
+            D = D * f + e;
+            Lw = Lw * f + e * logsigmoid_t(-nj);
+            M = Mn;
+            if (gl == j) m_mine = Mn;
+            float gCR[NCH], gCI[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const float Rr = 2.f * wt * re[k], Ii = 2.f * wt * im[k];
+                aHR[k] *= f; aHI[k] *= f; aTR[k] *= f; aTI[k] *= f; aP[k] *= f;
+                if (tail) {
+                    gCR[k] = -Rr; gCI[k] = -Ii;
+                    aHR[k] += Rr * CS[k] + Ii * SN[k];
+                    aHI[k] += -Rr * SN[k] + Ii * CS[k];
+                    aP[k] += Rr * (-HR[k] * SN[k] - HI[k] * CS[k]) + Ii * (HR[k] * CS[k] - HI[k] * SN[k]);
+                } else {
+                    gCR[k] = Rr * CS[k] + Ii * SN[k];
+                    gCI[k] = -Rr * SN[k] + Ii * CS[k];
+                    aTR[k] -= Rr; aTI[k] -= Ii;
+                    aP[k] += Rr * (-CR[k] * SN[k] - CI[k] * CS[k]) + Ii * (CR[k] * CS[k] - CI[k] * SN[k]);
+                }
+            }
+            const int64_t pair = i * neg_rate + j;
+            float* slot = sink.stage + (n_pos * sink.ns + pair * sink.nd) * sink.stride + ho;
+            store_row<G, NCH>(slot, gCR, dv, gl);
+            store_row<G, NCH>(slot + sink.stride, gCI, dv, gl);
+            if (valid && half == 0 && gl == 0) stage_register(sink, (int)c, (int)pair);
+        }
+        const float cn = -inv_b / D;
+        if (valid && half == 0 && gl < neg_rate) pair_scale[i * neg_rate + gl] = expf(m_mine - M) * cn;
+        float p0 = 0.f, re0[NCH], im0[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            re0[k] = HR[k] * CS[k] - HI[k] * SN[k] - TR[k];
+            im0[k] = HR[k] * SN[k] + HI[k] * CS[k] - TI[k];
+            p0 += re0[k] * re0[k] + im0[k] * im0[k];
+        }
+        p0 = gsum<G>(p0);
+        if (gl == 0) s_p[par][slot_b][half] = p0;
+        __syncthreads();
+        float e0 = 0.f;
+#pragma unroll
+        for (int q = 0; q < SPLIT; ++q) e0 += s_p[par][slot_b][q];
+        const float s_pos = -(m.margin - e0);
+        par ^= 1;
+        if (valid && half == 0) acc += (-(Lw / D) - logsigmoid_t(-s_pos)) * inv_b;
+        const float c_pos = sigmoid_t(s_pos) * inv_b;
+        float gHR[NCH], gHI[NCH], gTR[NCH], gTI[NCH], GP[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const float Rr = 2.f * c_pos * re0[k], Ii = 2.f * c_pos * im0[k];
+            gHR[k] = Rr * CS[k] + Ii * SN[k] + cn * aHR[k];
+            gHI[k] = -Rr * SN[k] + Ii * CS[k] + cn * aHI[k];
+            gTR[k] = -Rr + cn * aTR[k];
+            gTI[k] = -Ii + cn * aTI[k];
+            GP[k] = (Rr * (-HR[k] * SN[k] - HI[k] * CS[k]) + Ii * (HR[k] * CS[k] - HI[k] * SN[k]) + cn * aP[k]) / m.phase_div;
+        }
+        float* slot = sink.stage + i * sink.ns * sink.stride + ho;
+        store_row<G, NCH>(slot, gHR, dv, gl);
+        store_row<G, NCH>(slot + sink.stride, gHI, dv, gl);
+        store_row<G, NCH>(slot + 2 * sink.stride, GP, dv, gl);
+        store_row<G, NCH>(slot + 3 * sink.stride, gTR, dv, gl);
+        store_row<G, NCH>(slot + 4 * sink.stride, gTI, dv, gl);
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
+
 // ---- self-adversarial loss coefficients (criterion.py:13-23).  In: energies.  Out (in place): dL/d energy.
 __global__ __launch_bounds__(kBlock) void k_selfadv_coeffs(float* __restrict__ pos, float* __restrict__ neg,
                                                            int64_t n_pos, int neg_rate, float alpha,
@@ -695,6 +856,18 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
     fs.triples = triples; fs.perm = perm; fs.start = start; fs.E = m->tot_entity; fs.bern = bern;
     fs.slots = (const unsigned long long*)slots; fs.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
     fs.seed = seed; fs.offset = offset; fs.cursor = cursor;
+    static const int split = getenv("KGE_ROTATE_SPLIT") ? atoi(getenv("KGE_ROTATE_SPLIT")) : 2;   // A/B switch (0 / 2 / 4), read once; measured 83 / 73 / 79 us at C3
+    if (sink && geo.G == 64 && (split == 2 || split == 4)) {   // rows of more than 512 floats: a bundle's rows over two or four waves
+        int64_t b = (n_pos * split + 3) / 4;
+        if (b > kMaxBlocks) b = kMaxBlocks;
+#define KGE_RS(NCH_, SP_) k_rotate_bundle_staged_split<NCH_, SP_><<<dim3((unsigned)b), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs, *sink, pair_scale)
+        if (geo.NCH == 8 && split == 2) KGE_RS(4, 2);
+        else if (geo.NCH == 8) KGE_RS(2, 4);
+        else if (split == 2) KGE_RS(8, 2);
+        else KGE_RS(4, 4);
+#undef KGE_RS
+        return check_launch("k_rotate_bundle_staged_split");
+    }
 #define KGE_RB(G_, NCH_)                                                                                                      \
     if (geo.G == G_ && geo.NCH == NCH_) {                                                                                      \
         if (sink)                                                                                                              \
