@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""Summarise a rocprofv3 (ROCm 7.2) rocpd SQLite result: one row per (kernel, grid) -- calls / total / avg / min / max
+"""Summarise a rocprofv3 (ROCm 7.2) rocpd SQLite result: one row per (kernel, grid bucket) -- calls / total / avg / min / max
 duration and register counts, the content of `--stats` kernel_stats.csv split by launch geometry (the same kernel name is
-launched at several batch sizes inside one bench run; a per-name average would mix them).
+launched at several batch sizes inside one bench run; a per-name average would mix them).  A bucket is 16 384 threads of
+grid.x wide: the owner-computes step's grid follows the item count of each batch's incidence index (677 376 ... 679 680
+threads over the 14 batches of the B = 32 768 epoch), which is one workload, not fourteen.
 Usage: rocpd_summary.py results.db [out.md]"""
 import sqlite3
 import sys
@@ -10,9 +12,10 @@ import sys
 def rows_of(db):
     cur = sqlite3.connect(db).cursor()
     return cur.execute(
-        "select name, grid_x, grid_y, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), "
+        "select name, case when min(grid_x) = max(grid_x) then cast(min(grid_x) as text) else min(grid_x) || '-' || max(grid_x) end, "
+        "grid_y, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), "
         "max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(workgroup_x) "
-        "from kernels group by name, grid_x, grid_y order by sum(duration) desc").fetchall()
+        "from kernels group by name, grid_x / 16384, grid_y order by sum(duration) desc").fetchall()
 
 
 def table(rows):
