@@ -252,7 +252,12 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                 }
             }
         };
-        // software pipeline: the gathers of visit v+1 are in flight while visit v is evaluated (two buffers, no copies)
+        // software pipeline: the gathers of the next visits are in flight while a visit is evaluated (a ring of row buffers
+        // indexed at compile time, no copies)
+#ifndef KGE_PULL_DEPTH
+#define KGE_PULL_DEPTH 2
+#endif
+#if KGE_PULL_DEPTH == 2
         if (nvis > 0) {
             PullRows<NV> ba, bb;
             fetch_visit(0, ba);
@@ -266,6 +271,23 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                 }
             }
         }
+#else
+        if (nvis > 0) {
+            constexpr int D = KGE_PULL_DEPTH;
+            PullRows<NV> buf[D];
+#pragma unroll
+            for (int q = 0; q < D; ++q) if (q < nvis) fetch_visit(q, buf[q]);
+            for (int v = 0; v < nvis; v += D) {
+#pragma unroll
+                for (int q = 0; q < D; ++q) {
+                    if (v + q < nvis) {
+                        compute(buf[q]);
+                        if (v + q + D < nvis) fetch_visit(v + q + D, buf[q]);
+                    }
+                }
+            }
+        }
+#endif
         if (cnt > 0 && !fast_c) {
             // more drawers than the lane group or the bucket holds (tiny entity sets only): pair-ordered selection over
             // the bucket and the overflow list, one unpipelined visit at a time
