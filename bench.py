@@ -346,6 +346,7 @@ def main():
     steps_per_epoch = N_TRAIN // cfg.batch_size
     init_param = tr.flat.param.clone()
     pull = tr._pull_ok()   # single GPU, big batch: the atomic-free owner-computes step (csrc/kge_pull.hip)
+    two_phase = bool(pull and tr._pull_two_phase())   # ... in two launches: every pair evaluated once, owners sum the records
     pull_dp = tr._pull_dp_ok()   # N > 1: the same kernel writes the rank's dense gradient (no atomics), then the sharded step
 
     # ---- per-run set-up of the owner-computes path: the incidence index of every batch of the epoch order, built on the device
@@ -512,7 +513,8 @@ def main():
         for _ in range(burst):   # same inputs every time (lists kept, no buffer swap): the kernel's own duration
             K.pull_step(desc_b, ps.tables[1], ps.hats[0], ps.hats[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs_b, ps.lists[0],
                         items_b, inc_b, ps.partials, multi_b, cfg.margin, cfg.optimizer, cfg.learning_rate, 1, tr.loss_buf,
-                        reset_lists=False, run_finish=False, dense_skip=idx.skip(0))   # the small finishing launch of multi-segment rows is not in the burst
+                        reset_lists=False, run_finish=False, dense_skip=idx.skip(0),   # the small finishing launch of multi-segment rows is not in the burst
+                        direction=ps.direction)
         eb1.record()
         torch.cuda.synchronize()
         ps.lists[0].clear()
@@ -580,13 +582,21 @@ def main():
         del tr_s
 
     out = None
-    kernel_label = ("k_pull_step<Adam,G=32,NCH=4> (owner-computes step: per-row re-evaluation of incident pairs, hinge, backward, "
+    kernel_label = ("k_pull_eval<L1,G=32> + k_pull_step<Adam,L1,G=32,two-phase> (owner-computes step in two launches: every pair evaluated "
+                    "once -- 4 row gathers, hinge, 2-bit direction codes --, then one owner per row sums the records of its incidences, "
+                    "normalisation backward, dense Adam; no atomics.  Durations and traffic are the SUM of the two kernels)" if two_phase else
+                    "k_pull_step<Adam,G=32,NCH=4> (owner-computes step: per-row re-evaluation of incident pairs, hinge, backward, "
                     "normalisation backward, dense Adam; no atomics)" if pull else
                     "k_pull_step<gradient,G=32,NCH=4> (owner-computes gradient of the rank's share of the batch: per-row re-evaluation of "
                     "incident pairs, hinge, backward, normalisation backward; dense gradient rows written once, no atomics)" if pull_dp else
                     "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)")
-    traffic, traffic_src = (None, None) if pull_dp else pmc_traffic(
-        "kge::k_pull_step<1, true, 32" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch, fetch_scale=2.0 if pull else 1.0)
+    if two_phase:
+        t1, s1 = pmc_traffic("kge::k_pull_step<1, true, 32, 1, true>", per_rank_batch, fetch_scale=2.0)
+        t2, s2 = pmc_traffic("kge::k_pull_eval<true, 32", per_rank_batch, fetch_scale=2.0)
+        traffic, traffic_src = (t1 + t2, "%s + %s" % (s1, s2)) if (t1 is not None and t2 is not None) else (None, None)
+    else:
+        traffic, traffic_src = (None, None) if pull_dp else pmc_traffic(
+            "kge::k_pull_step<1, true, 32, 1, false>" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch, fetch_scale=2.0 if pull else 1.0)
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
@@ -599,15 +609,16 @@ def main():
                        "scored_triples_per_step": scored_per_step, "parallelism": "dp%d" % world,
                        "warmup_steps_run": args.warmup + warm_extra,
                        "model_state": "timed steps start from the freshly initialised tables (reset after warm-up)",
-                       "step_path": "owner-computes (pull): kge_pull_run, one k_pull_step launch per step (the next batch's sampler rides in its leading blocks)" if pull else
+                       "step_path": "owner-computes (pull), two-phase: kge_pull_run, k_pull_eval + k_pull_step<two-phase> per step (the next batch's sampler rides in the second launch)" if two_phase else
+                                    "owner-computes (pull): kge_pull_run, one k_pull_step launch per step (the next batch's sampler rides in its leading blocks)" if pull else
                                     "owner-computes gradient (k_pull_step, KGE_OPT_GRADIENT: no atomics) + reduce-scatter + sharded kge_optimizer_step + all-gather + kge_row_norms" if pull_dp else
                                     "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step"},
             "roofline": {"kernel": kernel_label, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_note": ("2 x FETCH_SIZE (gfx950: 16-byte-per-lane reads are tallied at half) + WRITE_SIZE" if pull else "FETCH_SIZE + WRITE_SIZE, raw"), "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_ms,
-                         "avg_launch_ms_method": ("HIP events on the launch stream around the timed region / steps (one launch per step; "
-                                                  "includes the dispatch gap between consecutive launches)" if pull else
+                         "avg_launch_ms_method": ("HIP events on the launch stream around the timed region / steps (%s per step; "
+                                                  "includes the dispatch gaps between consecutive launches)" % ("two launches" if two_phase else "one launch") if pull else
                                                   "HIP events around a burst of %d back-to-back launches of the kernel right after "
                                                   "the timed region (= rocprofv3 kernel duration)" % burst),
                          "burst_launch_ms": burst_ms,

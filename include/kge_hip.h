@@ -331,6 +331,20 @@ typedef struct kge_pull_lists {
     int32_t* sdesc;
     int32_t* dbucket;
 } kge_pull_lists;
+/* Two-phase ("staged direction") form of the step, selected by passing a kge_pull_direction with non-NULL buffers: phase 1
+ * (k_pull_eval) evaluates every pair of the batch ONCE -- same gathers and arithmetic as an owner's visit -- and leaves a
+ * 16-byte record (hinge coefficient, both energies, which side was corrupted) plus the signed direction of both residuals
+ * (L1: 2 bits per element; L2: the residual rows); phase 2 is the owner-computes kernel with visits that read those records
+ * instead of re-evaluating the pair (3.25 evaluations per pair -> 1).  Same gradients bit for bit (same coefficients, same fused
+ * multiply-adds in the same order); the loss is accumulated by phase 1.  lists_without_descriptors != 0: the sampler riding in
+ * this launch skips sdesc / dbucket (the NEXT step must then also be two-phase). */
+typedef struct kge_pull_direction {
+    void* codes;       /* kge_pull_direction_bytes(...).codes bytes */
+    float* recs;       /* 4 floats per pair */
+    int64_t n_pairs;   /* pairs in the batch */
+    int32_t lists_without_descriptors;
+} kge_pull_direction;
+int kge_pull_direction_bytes(int32_t dim, int32_t l1, int64_t n_pairs, size_t* codes_bytes, size_t* recs_bytes);
 int kge_pull_partial_stride(int32_t dim);
 int kge_pull_groups_per_block(int32_t dim);   /* owner groups per 256-thread workgroup: items are laid out in workgroup slots */
 int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, float* normalised, void* stream);
@@ -346,7 +360,7 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
                   int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step, const float* dev_hyper,
                   int32_t reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern_prob,
                   const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
-                  float* loss, void* stream);
+                  float* loss, const kge_pull_direction* direction /* NULL: one-phase step */, void* stream);
 
 /* A whole run of consecutive owner-computes steps enqueued by ONE native call (the per-step work is ~35 us of GPU time: a
  * Python-level loop cannot keep the queue full).  The plan holds everything that does not change between steps. */
@@ -382,6 +396,7 @@ typedef struct kge_pull_plan {
     uint64_t seed;
     int64_t draws_per_batch;      /* Philox counters consumed per batch (= n_pairs * neg_rate) */
     float* loss;
+    kge_pull_direction direction; /* codes == NULL: one-phase steps; else the two-phase form (n_pairs is taken from each batch) */
 } kge_pull_plan;
 /* Steps on batches first_batch .. first_batch + n_steps - 1.  src_half: the table half the first step reads (halves
  * alternate); cur_list: the list set the first step consumes; lists_ready == 0: a stand-alone sampler launch fills it first

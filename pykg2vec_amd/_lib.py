@@ -55,6 +55,12 @@ class PullBatch(ctypes.Structure):
                 ("multi", ctypes.c_void_p), ("n_multi", ctypes.c_int64), ("n_pairs", ctypes.c_int64)]
 
 
+class PullDirection(ctypes.Structure):
+    """struct kge_pull_direction"""
+    _fields_ = [("codes", ctypes.c_void_p), ("recs", ctypes.c_void_p), ("n_pairs", ctypes.c_int64),
+                ("lists_without_descriptors", ctypes.c_int32)]
+
+
 class PullPlanC(ctypes.Structure):
     """struct kge_pull_plan"""
     _fields_ = [("model", ModelDesc * 2), ("hat", (ctypes.c_void_p * 2) * 2), ("norm", ctypes.c_void_p * 2),
@@ -62,7 +68,8 @@ class PullPlanC(ctypes.Structure):
                 ("batches", ctypes.POINTER(PullBatch)), ("n_batches", ctypes.c_int64), ("partials", ctypes.c_void_p),
                 ("margin", ctypes.c_float), ("optimizer", ctypes.c_int32), ("lr", ctypes.c_float),
                 ("bern_prob", ctypes.c_void_p), ("slots", ctypes.c_void_p), ("n_slots", ctypes.c_int64),
-                ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p)]
+                ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p),
+                ("direction", PullDirection)]
 
 class OwnPlanC(ctypes.Structure):
     """struct kge_own_plan"""
@@ -166,7 +173,10 @@ _SIGNATURES = {
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
                                      ctypes.c_int32, ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
-                                     ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_void_p]),
+                                     ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p,
+                                     ctypes.POINTER(PullDirection), ctypes.c_void_p]),
+    "kge_pull_direction_bytes": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t),
+                                                ctypes.POINTER(ctypes.c_size_t)]),
     "kge_own_groups_per_block": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
     "kge_own_partial_stride": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
     "kge_own_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(PullLists), ctypes.c_void_p,

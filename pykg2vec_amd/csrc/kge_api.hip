@@ -445,8 +445,13 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
                   int64_t n_multi, float margin, int32_t optimizer, float lr, int64_t step, const float* dev_hyper,
                   int32_t reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern_prob,
                   const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
-                  float* loss, void* stream) {
+                  float* loss, const kge_pull_direction* direction, void* stream) {
     if (validate(m, false, "kge_pull_step")) return -1;
+    if (direction && (!direction->codes != !direction->recs || (direction->codes && direction->n_pairs <= 0))) {
+        set_error("kge_pull_step: the two-phase form needs both scratch buffers and the batch's pair count");
+        return -1;
+    }
+    if (direction && !direction->codes) direction = nullptr;
     if (m->model != KGE_TRANSE && m->model != KGE_TRANSM) { set_error("kge_pull_step: TransE / TransM only (model %d)", m->model); return -1; }
     const bool grad_only = optimizer == KGE_OPT_GRADIENT;   // writes gradient rows: no normalised copies / norms / state out
     if (n_items <= 0 || n_multi < 0 || !tables_out || !tables_out[0] || !tables_out[1] || !hat_in || !hat_in[0] || !hat_in[1] ||
@@ -472,7 +477,14 @@ int kge_pull_step(const kge_model_desc* m, float* const tables_out[2], const flo
     }
     return launch_pull_step(m, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, n_items, dense_skip, inc, partials, multi,
                             n_multi, margin, optimizer, lr, step, dev_hyper, reset_lists, next_pairs, next_inv, next_n, bern_prob, slots,
-                            n_slots, seed, next_offset, next_lists, loss, (hipStream_t)stream);
+                            n_slots, seed, next_offset, next_lists, loss, direction, (hipStream_t)stream);
+}
+
+int kge_pull_direction_bytes(int32_t dim, int32_t l1, int64_t n_pairs, size_t* codes_bytes, size_t* recs_bytes) {
+    if (!codes_bytes || !recs_bytes || n_pairs < 0) { set_error("kge_pull_direction_bytes: bad arguments"); return -1; }
+    pull_direction_bytes(dim, l1, n_pairs, codes_bytes, recs_bytes);
+    if (!*codes_bytes && n_pairs) { set_error("kge_pull_direction_bytes: hidden size %d must be a multiple of 4 and at most 1024", dim); return -1; }
+    return 0;
 }
 
 size_t kge_pull_plan_bytes(void) { return sizeof(kge_pull_plan); }
@@ -499,11 +511,14 @@ int kge_pull_run(const kge_pull_plan* p, int64_t first_batch, int64_t n_steps, i
         float* const tables_out[2] = {const_cast<float*>(p->model[1 - src].tables[0]), const_cast<float*>(p->model[1 - src].tables[1])};
         const float* const hat_in[2] = {p->hat[src][0], p->hat[src][1]};
         float* const hat_out[2] = {p->hat[1 - src][0], p->hat[1 - src][1]};
+        kge_pull_direction dir = p->direction;
+        dir.n_pairs = b->n_pairs;
+        dir.lists_without_descriptors = 1;
         rc = kge_pull_step(&p->model[src], tables_out, hat_in, hat_out, p->norm[src], p->norm[1 - src], p->state1, p->state2,
                            b->pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip, b->inc, p->partials, b->multi, b->n_multi, p->margin,
                            p->optimizer, p->lr, first_opt_step + k, nullptr, 1, nb ? nb->pairs : nullptr, nb ? nb->inv : nullptr, nb ? nb->n_pairs : 0,
                            p->bern_prob, p->slots, p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch,
-                           nb ? &p->lists[1 - cl] : nullptr, p->loss, stream);
+                           nb ? &p->lists[1 - cl] : nullptr, p->loss, dir.codes ? &dir : nullptr, stream);
         if (rc) return rc;
         src ^= 1;
         if (has_next) cl ^= 1;

@@ -159,6 +159,7 @@ int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, in
 
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);
+void pull_direction_bytes(int dim, int l1, int64_t n, size_t* codes, size_t* recs);
 int pull_groups_per_block(int dim);
 int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
                      const float* norm_in, float* norm_out, float* const state1[2], float* const state2[2], const int32_t* pairs,
@@ -166,7 +167,7 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
                      const int32_t* multi, int64_t n_multi, float margin, int optimizer, float lr, int64_t step,
                      const float* dev_hyper, int reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern,
                      const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
-                     const kge_pull_lists* next_lists, float* loss, hipStream_t s);
+                     const kge_pull_lists* next_lists, float* loss, const kge_pull_direction* dir, hipStream_t s);
 int launch_row_norms(const float* table, int64_t rows, int dim, float* out, float* hat, hipStream_t s);
 int launch_pull_sample(const int32_t* pairs, const int32_t* inv, int64_t n, int64_t E, const float* bern, const uint64_t* slots, int64_t n_slots,
                        uint64_t seed, uint64_t offset, const int64_t* cursor, const kge_pull_lists* out, hipStream_t s);

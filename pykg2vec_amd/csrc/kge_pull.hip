@@ -26,6 +26,7 @@
 #include "kge_sampler_device.h"
 #include "kge_pull_device.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace kge {
 
@@ -54,15 +55,20 @@ struct PullArgs {
     OptArgs opt;
     const float* dev_hyper;    // optional device-resident {lr, step_size, bc2_sqrt}
     const float* theta;        // TransM (pairwise.py:341-347): fixed per-relation weight of both energies; NULL = TransE
+    // two-phase ("staged direction") form: k_pull_eval leaves one record per pair, the owners of k_pull_step<..., DIR> sum them
+    float4* recs;              // [n_pairs] (coef * theta, energy(+), energy(-), tail as 0 / 1)
+    void* codes;               // [n_pairs][2][G * NV] L1: one byte per lane = the signs of its four residual elements (2 bits each);
+                               //                       L2: float4 per lane = the residuals themselves
+    int64_t n_pairs;
 };
 
 #define KGE_F4_EACH(expr_x, expr_y, expr_z, expr_w) expr_x; expr_y; expr_z; expr_w;
 
 // gradient wrt the NORMALISED own row, summed over incidences -> normalisation backward -> optimiser -> new row, its
 // normalised copy and its norm
-template <int OPT, int G, int NV>
+template <int OPT, int G, int NV, bool PRE = false>
 __device__ __forceinline__ void pull_finish_row(const PullArgs& a, int g, const float4 (&X)[NV], float nX, const float4 (&gs)[NV],
-                                                int gl) {
+                                                int gl, const float4* pre1 = nullptr, const float4* pre2 = nullptr) {
     const int nvec = a.d >> 2;
     const bool is_rel = g >= a.E;
     // (pointer selects, not a[tb]: a runtime index into a kernel-argument array would put the array in scratch)
@@ -95,8 +101,13 @@ __device__ __forceinline__ void pull_finish_row(const PullArgs& a, int g, const 
     OptArgs o = a.opt;
     if (a.dev_hyper) { o.lr = a.dev_hyper[0]; o.step_size = a.dev_hyper[1]; o.bc2_sqrt = a.dev_hyper[2]; }
     float4 P[NV], M1[NV], M2[NV];
-    if constexpr (OPT != KGE_OPT_SGD && OPT != KGE_OPT_GRADIENT) load_row4<G, NV>(M1, st1 + off, nvec, gl);
-    if constexpr (OPT == KGE_OPT_ADAM) load_row4<G, NV>(M2, st2 + off, nvec, gl);
+    if constexpr (PRE) {   // (two-phase form: the state rows were requested together with the row itself, before the visits)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { M1[v] = pre1[v]; M2[v] = pre2[v]; }
+    } else {
+        if constexpr (OPT != KGE_OPT_SGD && OPT != KGE_OPT_GRADIENT) load_row4<G, NV>(M1, st1 + off, nvec, gl);
+        if constexpr (OPT == KGE_OPT_ADAM) load_row4<G, NV>(M2, st2 + off, nvec, gl);
+    }
     float n2 = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -139,7 +150,81 @@ struct PullRows {
     float th;   // TransM weight of the pair's relation (1 for TransE)
 };
 
-template <int OPT, bool L1, int G, int NV>
+// ---- phase 1 of the two-phase form: every pair of the batch is evaluated ONCE by one lane group -- the same four gathers, the
+// same arithmetic in the same order as a visit of k_pull_step -- and leaves a record: the hinge coefficient, and the signed
+// direction of both residuals (L1: two bits per element; L2: the residual rows and their norms).  No sampling here: the draw was
+// registered by the sampler riding in the previous step's launch.
+template <bool L1, int G, int NV>
+__global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restrict__ loss) {
+    constexpr int GPB = kBlock / G;
+    const int gl = threadIdx.x % G;
+    const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
+    float acc = 0.f;
+    if (i < a.n_pairs) {
+        const int4 p = a.pairs[i];
+        const int w = a.lists.pc[i];
+        const bool tail = ((w >> 24) & 1) != 0;
+        const char* __restrict__ hat_e = reinterpret_cast<const char*>(a.hat_in[0]);
+        const char* __restrict__ hat_r = reinterpret_cast<const char*>(a.hat_in[1]);
+        constexpr unsigned kRowBytes = 16u * G * NV;
+        const unsigned lane_off = 16u * gl;
+        const unsigned oh = (unsigned)p.x * kRowBytes + lane_off, orr = (unsigned)p.y * kRowBytes + lane_off;
+        const unsigned ot = (unsigned)p.z * kRowBytes + lane_off, oc = (unsigned)(w & 0xFFFFFF) * kRowBytes + lane_off;
+        float4 hh[NV], rr[NV], tt[NV], cc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            hh[v] = *reinterpret_cast<const float4*>(hat_e + (oh + 16u * G * v));
+            rr[v] = *reinterpret_cast<const float4*>(hat_r + (orr + 16u * G * v));
+            tt[v] = *reinterpret_cast<const float4*>(hat_e + (ot + 16u * G * v));
+            cc[v] = *reinterpret_cast<const float4*>(hat_e + (oc + 16u * G * v));
+        }
+        const float th = a.theta ? a.theta[p.y] : 1.0f;
+        float4 up[NV], un[NV];
+        float sp = 0.f, sn = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+#define KGE_FWD(c)                                                                                            \
+            up[v].c = hh[v].c + rr[v].c - tt[v].c;                                                            \
+            un[v].c = (tail ? hh[v].c : cc[v].c) + rr[v].c - (tail ? cc[v].c : tt[v].c);                      \
+            sp = L1 ? sp + fabsf(up[v].c) : fmaf(up[v].c, up[v].c, sp);                                       \
+            sn = L1 ? sn + fabsf(un[v].c) : fmaf(un[v].c, un[v].c, sn);
+            KGE_FWD(x) KGE_FWD(y) KGE_FWD(z) KGE_FWD(w)
+#undef KGE_FWD
+        }
+        gsum2<G>(sp, sn);
+        if constexpr (!L1) { sp = sqrtf(sp); sn = sqrtf(sn); }
+        const float vv = th * sp + a.margin - th * sn;
+        acc = fmaxf(vv, 0.f);
+        const float coef = (vv > 0.f ? 1.f : (vv == 0.f ? 0.5f : 0.f)) * th;
+        if (gl == 0) a.recs[i] = make_float4(tail ? -coef : coef, sp, sn, 0.f);   // (coef >= 0: its sign carries `tail`)
+        if (coef != 0.f) {
+            if constexpr (L1) {
+                unsigned char* cp = reinterpret_cast<unsigned char*>(a.codes) + i * (int64_t)(2 * G * NV);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    // the sign k_pull_step uses: clamp(x * 2^100, -1, 1); code 0 = zero, 1 = positive, 2 = negative
+                    unsigned bp = 0, bn = 0;
+#define KGE_CODE(c, sh)                                                                                       \
+                    { const float s1 = __builtin_amdgcn_fmed3f(up[v].c * 0x1p100f, -1.f, 1.f);                 \
+                      const float s2 = __builtin_amdgcn_fmed3f(un[v].c * 0x1p100f, -1.f, 1.f);                 \
+                      bp |= (s1 > 0.f ? 1u : (s1 < 0.f ? 2u : 0u)) << sh;                                      \
+                      bn |= (s2 > 0.f ? 1u : (s2 < 0.f ? 2u : 0u)) << sh; }
+                    KGE_CODE(x, 0) KGE_CODE(y, 2) KGE_CODE(z, 4) KGE_CODE(w, 6)
+#undef KGE_CODE
+                    cp[v * G + gl] = (unsigned char)bp;
+                    cp[G * NV + v * G + gl] = (unsigned char)bn;
+                }
+            } else {
+                float4* cp = reinterpret_cast<float4*>(a.codes) + i * (int64_t)(2 * G * NV);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) { cp[v * G + gl] = up[v]; cp[G * NV + v * G + gl] = un[v]; }
+            }
+        }
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
+
+template <int OPT, bool L1, int G, int NV, bool DIR = false>
 __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs sa, float* __restrict__ loss) {
     constexpr int GPB = kBlock / G;
     if ((int)blockIdx.x < a.sample_blocks) {   // leading blocks: the sampler of the NEXT batch rides along (writes the other list set)
@@ -166,19 +251,122 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
     const int g = it.x;
     const int kind = it.w & 3;
     float4 X[NV], gs[NV];
+    float4 S1[NV], S2[NV];     // (two-phase form only: prefetched optimiser state)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { S1[v] = make_float4(0.f, 0.f, 0.f, 0.f); S2[v] = S1[v]; }
     float nX = 0.f;
     if (g >= 0) {
         const bool is_rel = g >= a.E;
         // the owner's row and norm depend on nothing but the item: requested first
         load_row4<G, NV>(X, (is_rel ? a.tab_in[1] : a.tab_in[0]) + (int64_t)(is_rel ? g - a.E : g) * d, nvec, gl);
         nX = a.norm_in[g];
+        if constexpr (DIR && OPT != KGE_OPT_GRADIENT) {
+            // the visits of the two-phase form need few registers: the optimiser state of a row this item will finish is requested
+            // now instead of after the last visit (one dependent round trip less at the end of every owner)
+            if (kind == 0 || (kind == 3 && ((it.w >> 2) & 15) == 0)) {
+                const int64_t off0 = (int64_t)(is_rel ? g - a.E : g) * d;
+                if constexpr (OPT != KGE_OPT_SGD) load_row4<G, NV>(S1, (is_rel ? a.s1[1] : a.s1[0]) + off0, nvec, gl);
+                if constexpr (OPT == KGE_OPT_ADAM) load_row4<G, NV>(S2, (is_rel ? a.s2[1] : a.s2[0]) + off0, nvec, gl);
+            }
+        }
         int cnt = 0;
         bool fast_c = true;
         // the row's corrupting-entity draws are walked by its first (or only) item
         const bool walks_c = !is_rel && (kind == 0 || kind == 1 || (kind == 3 && ((it.w >> 2) & 15) == 0));
-        const int nvis = own_visit_list<G>(a.lists, it, g, walks_c, gl, gbase, s_desc[threadIdx.x / G], &cnt, &fast_c);
+        int nvis;
+        if constexpr (DIR) nvis = own_visit_list_dir<G>(a.lists, a.inc, it, g, walks_c, gl, gbase, reinterpret_cast<int*>(s_desc[threadIdx.x / G]), &cnt, &fast_c);
+        else nvis = own_visit_list<G>(a.lists, it, g, walks_c, gl, gbase, s_desc[threadIdx.x / G], &cnt, &fast_c);
 #pragma unroll
         for (int v = 0; v < NV; ++v) gs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (DIR) {
+            // two-phase form: a visit is the pair's record + this lane's share of its two direction codes -- no row gathers,
+            // no reductions.  Same coefficients, same fused multiply-adds in the same order as the one-phase visit below.
+            const int* __restrict__ vis = reinterpret_cast<const int*>(s_desc[threadIdx.x / G]);
+            using RecT = typename std::conditional<L1, float, float4>::type;   // L1 needs only the signed coefficient
+            auto rec_x = [](const RecT& r) { if constexpr (L1) return r; else return r.x; };
+            auto visit_dir = [&](int e, const RecT rec, const auto& cpv, const auto& cnv) {
+                const int role = e & 3;
+                const bool tail = __float_as_uint(rec_x(rec)) >> 31;
+                const float coef = fabsf(rec_x(rec));
+                if (coef == 0.f) return;
+                float su = role == kRoleT ? -coef : (role == kRoleC ? 0.f : coef);
+                float sv = role == kRoleR ? -coef : (role == kRoleH ? (tail ? -coef : 0.f) : role == kRoleT ? (tail ? 0.f : coef) : (tail ? coef : -coef));
+                if constexpr (L1) {
+#pragma unroll
+                    for (int v2 = 0; v2 < NV; ++v2) {
+                        const unsigned bp = cpv[v2], bn = cnv[v2];
+#define KGE_DEC(b, sh) ((((b) >> (sh)) & 3u) == 1u ? 1.f : ((((b) >> (sh)) & 3u) == 2u ? -1.f : 0.f))
+                        gs[v2].x = fmaf(sv, KGE_DEC(bn, 0), fmaf(su, KGE_DEC(bp, 0), gs[v2].x));
+                        gs[v2].y = fmaf(sv, KGE_DEC(bn, 2), fmaf(su, KGE_DEC(bp, 2), gs[v2].y));
+                        gs[v2].z = fmaf(sv, KGE_DEC(bn, 4), fmaf(su, KGE_DEC(bp, 4), gs[v2].z));
+                        gs[v2].w = fmaf(sv, KGE_DEC(bn, 6), fmaf(su, KGE_DEC(bp, 6), gs[v2].w));
+#undef KGE_DEC
+                    }
+                } else {
+                    if constexpr (!L1) {
+                        su = rec.y > 0.f ? su / rec.y : 0.f;
+                        sv = rec.z > 0.f ? sv / rec.z : 0.f;
+                    }
+#pragma unroll
+                    for (int v2 = 0; v2 < NV; ++v2) {
+                        gs[v2].x = fmaf(sv, cnv[v2].x, fmaf(su, cpv[v2].x, gs[v2].x)); gs[v2].y = fmaf(sv, cnv[v2].y, fmaf(su, cpv[v2].y, gs[v2].y));
+                        gs[v2].z = fmaf(sv, cnv[v2].z, fmaf(su, cpv[v2].z, gs[v2].z)); gs[v2].w = fmaf(sv, cnv[v2].w, fmaf(su, cpv[v2].w, gs[v2].w));
+                    }
+                }
+            };
+            using CodeT = typename std::conditional<L1, unsigned, float4>::type;
+            auto load_codes = [&](int pair, CodeT (&cpv)[NV], CodeT (&cnv)[NV]) {
+                if constexpr (L1) {
+                    const unsigned char* cp = reinterpret_cast<const unsigned char*>(a.codes) + pair * (int64_t)(2 * G * NV);
+#pragma unroll
+                    for (int v2 = 0; v2 < NV; ++v2) { cpv[v2] = cp[v2 * G + gl]; cnv[v2] = cp[G * NV + v2 * G + gl]; }
+                } else {
+                    const float4* cp = reinterpret_cast<const float4*>(a.codes) + pair * (int64_t)(2 * G * NV);
+#pragma unroll
+                    for (int v2 = 0; v2 < NV; ++v2) { cpv[v2] = cp[v2 * G + gl]; cnv[v2] = cp[G * NV + v2 * G + gl]; }
+                }
+            };
+#ifndef KGE_DIR_BATCH
+#define KGE_DIR_BATCH 4
+#endif
+            constexpr int kDirBatch = L1 ? KGE_DIR_BATCH : 2;     // visits whose records and codes are requested before the first is summed
+#ifdef KGE_DIR_NOVISIT   /* timing experiment only: how long is phase 2 without its visits? */
+            nvis = 0;
+#endif
+            for (int v0 = 0; v0 < nvis; v0 += kDirBatch) {
+                int e[kDirBatch];
+                RecT rec[kDirBatch];
+                CodeT cpv[kDirBatch][NV], cnv[kDirBatch][NV];
+#pragma unroll
+                for (int q = 0; q < kDirBatch; ++q) {
+                    e[q] = v0 + q < nvis ? vis[v0 + q] : -1;
+                    const int pair = e[q] >= 0 ? (e[q] >> 2) : 0;
+                    if constexpr (L1) rec[q] = reinterpret_cast<const float*>(a.recs)[4 * (int64_t)pair];
+                    else rec[q] = a.recs[pair];
+                    load_codes(pair, cpv[q], cnv[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < kDirBatch; ++q)
+                    if (e[q] >= 0) visit_dir(e[q], rec[q], cpv[q], cnv[q]);
+            }
+            if (cnt > 0 && !fast_c) {   // more drawers than the bucket / lane group holds: pair-ordered walk over bucket + chain
+                const int nb = cnt < kPullCap ? cnt : kPullCap;
+                int last = -1;
+                for (;;) {
+                    int best = 0x7FFFFFFF;
+                    for (int m = 0; m < nb; ++m) { const int j = a.lists.bucket[(int64_t)g * kPullCap + m]; if (j > last && j < best) best = j; }
+                    for (int j = a.lists.head[g]; j >= 0; j = a.lists.next[j]) if (j > last && j < best) best = j;
+                    if (best == 0x7FFFFFFF) break;
+                    CodeT c1[NV], c2[NV];
+                    load_codes(best, c1, c2);
+                    RecT rb;
+                    if constexpr (L1) rb = reinterpret_cast<const float*>(a.recs)[4 * (int64_t)best];
+                    else rb = a.recs[best];
+                    visit_dir((best << 2) | kRoleC, rb, c1, c2);
+                    last = best;
+                }
+            }
+        } else {
 
         // gather the four normalised rows of one incident pair (the owner's own row among them: it is L1 / L2 hot, and
         // loading it like the others keeps the gather branch-free and the arithmetic identical for all four owners)
@@ -305,12 +493,13 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                 last = best;
             }
         }
+        }   // (one-phase visits)
         if (cnt > 0 && a.reset_lists && gl == 0) {
             a.lists.count[g] = 0;
             if (cnt > kPullCap) a.lists.head[g] = -1;
         }
         if (kind == 0) {
-            pull_finish_row<OPT, G, NV>(a, g, X, nX, gs, gl);
+            pull_finish_row<OPT, G, NV, DIR && OPT != KGE_OPT_GRADIENT>(a, g, X, nX, gs, gl, S1, S2);
         } else if (kind == 3) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) s_part[threadIdx.x / G][v * G + gl] = gs[v];
@@ -330,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                 gs[v].x += p.x; gs[v].y += p.y; gs[v].z += p.z; gs[v].w += p.w;
             }
         }
-        pull_finish_row<OPT, G, NV>(a, g, X, nX, gs, gl);
+        pull_finish_row<OPT, G, NV, DIR && OPT != KGE_OPT_GRADIENT>(a, g, X, nX, gs, gl, S1, S2);
     }
     block_accumulate_loss<G>(acc, gl, loss);
 }
@@ -438,7 +627,16 @@ static int launch_pull_geo(PullArgs& a, const PullSampleArgs& sa, float* loss, h
     constexpr int GPB = kBlock / G;
     const int item_blocks = (int)((a.n_items + (a.dense_skip ? a.n_rows : 0) + GPB - 1) / GPB);
     a.sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
-    if (a.l1)
+    if (a.recs) {   // two-phase form: evaluate every pair once, then let the owners sum the records
+        const unsigned eb = (unsigned)((a.n_pairs + GPB - 1) / GPB);
+        if (a.l1) {
+            hipLaunchKernelGGL((k_pull_eval<true, G, NV>), dim3(eb), dim3(kBlock), 0, s, a, loss);
+            hipLaunchKernelGGL((k_pull_step<OPT, true, G, NV, true>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
+        } else {
+            hipLaunchKernelGGL((k_pull_eval<false, G, NV>), dim3(eb), dim3(kBlock), 0, s, a, loss);
+            hipLaunchKernelGGL((k_pull_step<OPT, false, G, NV, true>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
+        }
+    } else if (a.l1)
         hipLaunchKernelGGL((k_pull_step<OPT, true, G, NV>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
     else
         hipLaunchKernelGGL((k_pull_step<OPT, false, G, NV>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
@@ -456,6 +654,12 @@ static int launch_pull_opt(PullArgs& a, const PullSampleArgs& sa, PullGeo g, flo
     return -1;
 }
 
+// bytes of the two-phase form's scratch for n pairs: direction codes (L1: one byte per lane and residual; L2: a float4) and records
+void pull_direction_bytes(int dim, int l1, int64_t n, size_t* codes, size_t* recs) {
+    const PullGeo g = pull_geo(dim);
+    *codes = g.G ? (size_t)n * 2 * g.G * g.NV * (l1 ? 1 : 16) : 0;
+    *recs = (size_t)n * 16;
+}
 int pull_partial_stride(int dim) { const PullGeo g = pull_geo(dim); return 4 * g.G * g.NV; }
 int pull_groups_per_block(int dim) { const PullGeo g = pull_geo(dim); return g.G ? kBlock / g.G : 0; }
 
@@ -465,7 +669,7 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
                      const int32_t* multi, int64_t n_multi, float margin, int optimizer, float lr, int64_t step,
                      const float* dev_hyper, int reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern,
                      const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
-                     const kge_pull_lists* next_lists, float* loss, hipStream_t s) {
+                     const kge_pull_lists* next_lists, float* loss, const kge_pull_direction* dir, hipStream_t s) {
     const PullGeo geo = pull_geo(m->dim);
     if (!geo.G) { set_error("kge_pull_step: hidden size %d must be a multiple of 4 and at most 1024", m->dim); return -1; }
     {   // the row gathers use 32-bit byte offsets into the padded normalised tables (16 * G * NV bytes per row)
@@ -493,8 +697,12 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
     a.theta = m->model == KGE_TRANSM ? m->tables[2] : nullptr;
     a.opt = make_opt_args(lr, step < 1 ? 1 : step);
     a.dev_hyper = dev_hyper;
-    const PullSampleArgs sa = make_sample_args(next_pairs, next_inv, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
-                                               n_slots, seed, next_offset, nullptr, next_lists);
+    a.recs = dir && dir->recs ? reinterpret_cast<float4*>(dir->recs) : nullptr;
+    a.codes = dir ? dir->codes : nullptr;
+    a.n_pairs = dir ? dir->n_pairs : 0;
+    PullSampleArgs sa = make_sample_args(next_pairs, next_inv, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
+                                         n_slots, seed, next_offset, nullptr, next_lists);
+    sa.no_desc = a.recs && dir->lists_without_descriptors ? 1 : 0;
     switch (optimizer) {
         case KGE_OPT_SGD: return launch_pull_opt<KGE_OPT_SGD>(a, sa, geo, loss, s);
         case KGE_OPT_ADAM: return launch_pull_opt<KGE_OPT_ADAM>(a, sa, geo, loss, s);

@@ -32,6 +32,7 @@ struct PullSampleArgs {
     unsigned long long mask, seed, offset;
     const int64_t* cursor;
     PullLists out;
+    int no_desc;               // != 0: skip the visit descriptors (the two-phase step's owners read pair records instead)
 };
 
 // one pair of the sampled batch: draw the corruption (same Philox counters as kge_sample_batch / the fused push kernels:
@@ -47,8 +48,9 @@ __device__ __forceinline__ void pull_sample_one(const PullSampleArgs& sa, int64_
     sa.out.pc[i] = c | ((int)tail << 24) | ((pos == 0 ? 1 : 0) << kPcFirstBit);
     if (pos < kPullCap) {
         sa.out.bucket[(int64_t)c * kPullCap + pos] = (int)i;
-        sa.out.dbucket[(int64_t)c * kPullCap + pos] = make_int4(p.x, p.y, p.z, (int)i | ((int)tail << 24) | (kRoleC << 25));
+        if (!sa.no_desc) sa.out.dbucket[(int64_t)c * kPullCap + pos] = make_int4(p.x, p.y, p.z, (int)i | ((int)tail << 24) | (kRoleC << 25));
     } else sa.out.next[i] = atomicExch(sa.out.head + c, (int)i);
+    if (sa.no_desc) return;
     // the three static incidences of the pair, ready for their owners (one dependent load instead of inc -> pairs + pc)
     const int w = c | ((int)tail << 24);
 #pragma unroll
@@ -91,6 +93,41 @@ __device__ __forceinline__ int own_visit_list(const PullLists& lists, const int4
     return nvis;
 }
 
+// The same list for the two-phase ("staged direction") step: a visit is (pair << 2 | role) -- static incidences straight from
+// `inc`, drawers from the entity's bucket of pair indices, ranked by pair index -- because the owner needs nothing but the pair's
+// evaluation record, which phase 1 left behind.
+template <int G>
+__device__ __forceinline__ int own_visit_list_dir(const PullLists& lists, const int32_t* __restrict__ inc, const int4 it, int g,
+                                                  bool walks_c, int gl, int gbase, int* __restrict__ s_vis_row, int* cnt_out,
+                                                  bool* fast) {
+    const int n_static = it.z - it.y;
+    const int q = gl - n_static;
+    int e = -1;
+    bool have = false;
+    if (gl < n_static) { e = inc[it.y + gl]; have = true; }
+    int cnt = 0, dd = 0x7FFFFFFF;
+    if (walks_c) {
+        cnt = lists.count[g];
+        if (q >= 0 && q < kPullCap) dd = lists.bucket[(int64_t)g * kPullCap + q];   // speculative: valid for q < cnt
+    }
+    const bool fast_c = cnt <= kPullCap && n_static + cnt <= G;
+    int slot = gl, nvis = n_static;
+    if (cnt > 0 && fast_c) {
+        const bool mine = q >= 0 && q < cnt;
+        const int key = mine ? dd : 0x7FFFFFFF;
+        if (cnt > 1) {
+            int rank = 0;
+            for (int m = 0; m < cnt; ++m) rank += __shfl(key, gbase + n_static + m, 64) < key ? 1 : 0;
+            if (mine) slot = n_static + rank;
+        }
+        if (mine) { e = (dd << 2) | kRoleC; have = true; }
+        nvis += cnt;
+    }
+    if (have) s_vis_row[slot] = e;
+    *cnt_out = cnt; *fast = fast_c;
+    return nvis;
+}
+
 // Rows as float4 per lane: lane gl of a G-lane group holds elements 4*(v*G + gl) .. +3 for v < NV (d % 4 == 0): one
 // 16-byte load / store instruction per lane moves a whole 100-float row with 25 lanes.
 template <int G, int NV>
@@ -122,7 +159,7 @@ static inline PullSampleArgs make_sample_args(const int32_t* pairs, const int32_
     PullSampleArgs sa;
     sa.pairs = (const int4*)pairs; sa.inv = inv; sa.n = n; sa.E = E; sa.bern = bern;
     sa.slots = (const unsigned long long*)slots; sa.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
-    sa.seed = seed; sa.offset = offset; sa.cursor = cursor;
+    sa.seed = seed; sa.offset = offset; sa.cursor = cursor; sa.no_desc = 0;
     if (out) sa.out = to_lists(out);
     else { sa.out.pc = sa.out.count = sa.out.bucket = sa.out.head = sa.out.next = nullptr; sa.out.sdesc = sa.out.dbucket = nullptr; }
     return sa;

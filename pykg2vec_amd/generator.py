@@ -339,10 +339,12 @@ class Generator:
         self._batch_idx = 0
         self._draws = 0  # Philox counter offset: unique per generated negative over the whole run
 
-    def pull_index(self, groups_per_block=None, compact=None):
+    def pull_index(self, groups_per_block=None, compact=None, segment=None):
         """Incidence index of every FULL batch of the permutation (built on first use).  groups_per_block: owner groups per
-        workgroup of the consuming kernel (default: kge_pull_step's); compact: force / forbid the touched-rows-only form."""
-        key = (groups_per_block, compact)
+        workgroup of the consuming kernel (default: kge_pull_step's); compact: force / forbid the touched-rows-only form;
+        segment: incidences per work item (default: `self.pull_segment` if the trainer set one, else PullIndex.SEGMENT)."""
+        segment = segment or getattr(self, "pull_segment", None)
+        key = (groups_per_block, compact, segment)
         if self._pull_index is not None and getattr(self, "_pull_index_key", key) != key:
             self._pull_index = None
         if self._pull_index is None:
@@ -359,10 +361,11 @@ class Generator:
             if hasattr(self.K, "pull_index_build") and self.triples.is_cuda and nb > 0:
                 # the product path: every batch of the epoch order indexed on the device (csrc/kge_index.hip)
                 self._pull_index = PullIndex.build_on_device(self.K, self.triples, self.perm, nb, B, lo, per, self.config.tot_entity,
-                                                             self.config.tot_relation, groups_per_block=gpb, compact=compact)
+                                                             self.config.tot_relation, segment=segment, groups_per_block=gpb,
+                                                             compact=compact)
             else:   # no device (CPU tests with an injected backend): the numpy restatement of the same rule
                 pos = self._train_np[self._perm_np[:nb * B]].reshape(nb, B, 3)[:, lo:lo + per]
-                self._pull_index = PullIndex(list(pos), self.config.tot_entity, self.config.tot_relation, self.device,
+                self._pull_index = PullIndex(list(pos), self.config.tot_entity, self.config.tot_relation, self.device, segment,
                                              groups_per_block=gpb, compact=compact)
             self.pull_index_ms = (time.perf_counter() - t0) * 1e3   # set-up cost of the owner-computes path (host wall, incl. the sync)
         return self._pull_index

@@ -649,9 +649,22 @@ def pull_lists_explicit(pairs, inv, nh, nt, lists):
                                              ctypes.byref(lists.c), _stream()), "kge_pull_lists_explicit")
 
 
+class PullDirection:
+    """Scratch of the two-phase ("staged direction") form of the owner-computes step (struct kge_pull_direction): one record and
+    two direction codes per pair of the batch."""
+
+    def __init__(self, n_pairs, dim, l1, device):
+        cb, rb = ctypes.c_size_t(), ctypes.c_size_t()
+        L.check(L.load().kge_pull_direction_bytes(int(dim), 1 if l1 else 0, int(n_pairs), ctypes.byref(cb), ctypes.byref(rb)),
+                "kge_pull_direction_bytes")
+        self.codes = torch.zeros(max(1, cb.value), dtype=torch.uint8, device=device)
+        self.recs = torch.zeros(max(4, rb.value // 4), dtype=torch.float32, device=device)
+        self.c = L.PullDirection(self.codes.data_ptr(), self.recs.data_ptr(), int(n_pairs), 0)
+
+
 def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, inc, partials, multi,
               margin, optimizer, lr, step, loss_buf, reset_lists=True, dev_hyper=None, run_finish=True, sample_next=None,
-              dense_skip=None, prepare_only=False):
+              dense_skip=None, prepare_only=False, direction=None):
     """One whole training step (scoring, hinge, backward, dense optimiser) without atomics: see csrc/kge_pull.hip.
     desc_in: descriptor over the tables READ; tables_out: [ent, rel] of the other half of the double buffer; hat_in /
     hat_out: the row-normalised copies of both halves.
@@ -677,13 +690,13 @@ def pull_step(desc_in, tables_out, hat_in, hat_out, norm_in, norm_out, state1, s
         _i32(inc, "inc"), _dev(partials, torch.float32, "partials"),
         _i32(multi, "multi") if n_multi else None, n_multi, float(margin), OPTIMIZER_IDS[optimizer], float(lr), int(step),
         _dev(dev_hyper, torch.float32, "dev_hyper") if dev_hyper is not None else None, 1 if reset_lists else 0,
-        *nx, _dev(loss_buf, torch.float32, "loss"))
+        *nx, _dev(loss_buf, torch.float32, "loss"), ctypes.byref(direction.c) if direction is not None else None)
     keep = (desc_in, to, hi, ho, s1, s2, tables_out, hat_in, hat_out, norm_in, norm_out, state1, state2, pairs, lists, items, inc,
-            partials, multi, loss_buf, dense_skip, sample_next)
+            partials, multi, loss_buf, dense_skip, sample_next, direction)
     if prepare_only:   # marshal once, call many times (a data-parallel step runs this launch between two collectives:
         fn = L.load().kge_pull_step                                   # host time per step matters there)
         argl = list(args)
-        off_idx = len(argl) - 3      # next_offset: the one argument that differs from epoch to epoch (Philox counters advance)
+        off_idx = len(argl) - 4      # next_offset: the one argument that differs from epoch to epoch (Philox counters advance)
 
         def call(next_offset=None):
             if next_offset is not None:
@@ -727,8 +740,8 @@ class PullPlan:
     time: a Python-level loop could not keep the queue full)."""
 
     def __init__(self, model_name, desc_kwargs, tot_entity, tot_relation, tables, hats, norms, state1, state2, lists, index,
-                 partials, margin, optimizer, lr, loss_buf, bern, slots, seed, draws_per_batch):
-        self.keep = (tables, hats, norms, state1, state2, lists, index, partials, loss_buf, bern, slots)   # keep storage alive
+                 partials, margin, optimizer, lr, loss_buf, bern, slots, seed, draws_per_batch, direction=None):
+        self.keep = (tables, hats, norms, state1, state2, lists, index, partials, loss_buf, bern, slots, direction)   # keep storage alive
         c = L.PullPlanC()
         for half in (0, 1):
             c.model[half] = make_desc(model_name, tables[half], None, tot_entity=tot_entity, tot_relation=tot_relation, **desc_kwargs)
@@ -756,6 +769,8 @@ class PullPlan:
         c.seed = int(seed) & (2 ** 64 - 1)
         c.draws_per_batch = int(draws_per_batch)
         c.loss = loss_buf.data_ptr()
+        if direction is not None:      # two-phase steps (kge_pull_run fills n_pairs per batch)
+            c.direction = direction.c
         self.c = c
         self.fn = L.load().kge_pull_run
 

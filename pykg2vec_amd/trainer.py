@@ -107,7 +107,7 @@ class PullState:
     tables, the row norms of both halves and the per-step sampler lists.  `cur` = which half holds the current tables
     (0 = FlatState.param, i.e. the storage behind the model's nn.Parameters)."""
 
-    def __init__(self, flat, model, batch_size, max_slots, grad_only=False):
+    def __init__(self, flat, model, batch_size, max_slots, grad_only=False, two_phase=False):
         dev = flat.param.device
         self.flat = flat
         # grad_only (data-parallel ranks): the step writes gradient rows into FlatState.grad instead of updated tables, so
@@ -137,6 +137,8 @@ class PullState:
         self.ready = None
         self.calls = {}   # prepared kge_pull_step calls of the data-parallel gradient step
         self.partials = torch.empty(max(1, max_slots) * K.pull_partial_stride(d), dtype=torch.float32, device=dev)
+        # two-phase ("staged direction") form: every pair evaluated once (k_pull_eval), the owners sum its record
+        self.direction = K.PullDirection(batch_size, d, bool(getattr(model, "l1_flag", True)), dev) if two_phase else None
         self.cur = 0
 
     def sync_in(self):
@@ -176,6 +178,7 @@ class Trainer:
     GRAPH_MAX_ROWS = 16384  # steps scoring at most this many triples are launch-bound: replay them as one hipGraph
     PULL_INDEX_BUDGET = 256 << 20   # bytes of per-batch incidence index the owner-computes path may build (see _pull_ok)
     GRAPH_UNROLL = 8        # steps per replayed multi-step graph (even; 0 = single-step graphs only)
+    PULL_TWO_PHASE_MIN_BATCH = 16384   # owner-computes step in two launches (each pair evaluated once) from this batch size on
 
     def __init__(self, model, config, process_group=None, backend=None, use_graph=None):
         self.model = model
@@ -195,7 +198,7 @@ class Trainer:
         flag = lambda name: None if env(name) is None else env(name) == "1"
         return {"pull": flag("KGE_PULL"), "staged": flag("KGE_STAGED"), "graph_multi": flag("KGE_GRAPH_MULTI"),
                 "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED"),
-                "rescal_unfused": flag("KGE_RESCAL_UNFUSED")}
+                "rescal_unfused": flag("KGE_RESCAL_UNFUSED"), "pull_dir": flag("KGE_PULL_DIR")}
 
     def _init_hot_path(self, process_group=None, backend=None, use_graph=None):
         # `backend` exists so that the multi-process plumbing (batch sharding, gradient collectives, replica
@@ -426,17 +429,27 @@ class Trainer:
         """Non-trainable descriptor tables after the two embedding tables (TransM: the per-relation weights theta)."""
         return [self.model.theta.to(self.flat.param.device).contiguous()] if self.model.kernel_name == "transm" else []
 
+    def _pull_two_phase(self):
+        """The owner-computes step in two launches: every pair evaluated once, the owners sum the pairs' records
+        (csrc/kge_pull.hip: k_pull_eval + k_pull_step<..., DIR>).  KGE_PULL_DIR=0 / 1 overrides."""
+        if self.switches.get("pull_dir") is not None:
+            return self.switches["pull_dir"]
+        # measured (profiles/r03_experiments.md section 11): L1, B = 32768: 35.0 -> 30.3 us per step (TransM 47.4 -> 44.9);
+        # B = 4096: 19.1 -> 20.4, B = 128: 13.0 -> 15.6 (a second launch costs more than the re-evaluations it saves);
+        # L2: 46.3 -> 53.6 (the direction of an L2 residual is a float row, 1 KB per pair, not 2 bits per element)
+        return bool(getattr(self.model, "l1_flag", False)) and int(self.config.batch_size) >= self.PULL_TWO_PHASE_MIN_BATCH
+
     def _pull_state(self):
         idx = self.generator.pull_index()
         if getattr(self, "_pull", None) is None or self._pull.batch_size != idx.batch_size:
-            ps = self._pull = PullState(self.flat, self.model, idx.batch_size, idx.max_slots)
+            ps = self._pull = PullState(self.flat, self.model, idx.batch_size, idx.max_slots, two_phase=self._pull_two_phase())
             ps.sync_in()
             gen, cfg = self.generator, self.config
             ps.plan = K.PullPlan(self.model.kernel_name, self.model.desc_kwargs(), cfg.tot_entity, cfg.tot_relation,
                                  [t + self._pull_fixed_tables() for t in ps.tables], ps.hats,
                                  ps.norms, ps.state1, ps.state2, ps.lists, idx, ps.partials, cfg.margin, cfg.optimizer,
                                  cfg.learning_rate, self.loss_buf, gen.bern, gen.slots, gen.seed,
-                                 idx.batch_size * gen.neg_rate)
+                                 idx.batch_size * gen.neg_rate, direction=ps.direction)
         return self._pull, idx
 
     def _pull_steps(self, n_steps):
@@ -473,7 +486,7 @@ class Trainer:
         pos = np.stack([x.detach().cpu().numpy() for x in (ph, pr, pt)], 1)
         idx = PullIndex([pos], self.config.tot_entity, self.config.tot_relation, self.flat.param.device, segment,
                         K.pull_groups_per_block(self.model.hidden_size), compact=compact)
-        ps = PullState(self.flat, self.model, len(pos), idx.max_slots)
+        ps = PullState(self.flat, self.model, len(pos), idx.max_slots, two_phase=self._pull_two_phase())
         ps.sync_in()
         pairs, inc, items, multi = idx.batch(0)
         skip = idx.skip(0)
@@ -484,7 +497,7 @@ class Trainer:
         K.pull_step(desc, ps.tables[1], ps.hats[0], ps.hats[1], ps.norms[0], ps.norms[1], ps.state1, ps.state2, pairs,
                     ps.lists[0], items, inc,
                     ps.partials, multi, self.config.margin, self.config.optimizer, self.config.learning_rate,
-                    self.flat.step, self.loss_buf, dense_skip=skip)
+                    self.flat.step, self.loss_buf, dense_skip=skip, direction=ps.direction)
         ps.cur = 1
         ps.sync_out()
 
@@ -924,7 +937,10 @@ class Trainer:
         return acc_loss
 
     def _new_generator(self):
-        return Generator(self.model, self.config, rank=self.rank, world_size=self.world_size, backend=self.K)
+        gen = Generator(self.model, self.config, rank=self.rank, world_size=self.world_size, backend=self.K)
+        if self.K is K and not self.distributed and self.model.kernel_name in ("transe", "transm") and self._pull_two_phase():
+            gen.pull_segment = 32    # two-phase step: a visit is a few bytes, so an item carries a whole row's incidences (32 / item)
+        return gen
 
     # ------------------------------------------------------------------ checkpoints (reference format, utils/trainer.py:388-409)
     def save_model(self, path):

@@ -48,6 +48,58 @@ def test_three_pull_steps_match_reference_weights(hip, name, opt, segment, compa
         assert np.allclose(got, ref, atol=1e-4, rtol=1e-4), (k, np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize("segment,compact", [(None, False), (2, False), (1, False), (1, True)])
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+@pytest.mark.parametrize("name", ["transe_l1", "transe_l2", "transm_l1", "transm_l2"])
+def test_two_phase_step_is_the_one_phase_step_bit_for_bit(hip, monkeypatch, name, opt, segment, compact):
+    """KGE_PULL_DIR=1: k_pull_eval evaluates every pair once and the owners sum the pairs' records (L1: 2-bit direction codes;
+    L2: the residual rows) instead of re-evaluating them.  Same coefficients, same fused multiply-adds in the same order: the
+    tables, optimiser state and the golden weights of the live reference must come out identical to the one-phase step."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.trainer import Trainer
+    c = Case(name)
+    out = []
+    for two_phase in ("0", "1"):
+        monkeypatch.setenv("KGE_PULL_DIR", two_phase)
+        cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer=opt, lr=0.05)
+        m = hip.model_from_case(c)
+        tr = Trainer(m, cfg)
+        tr.build_model()
+        assert tr._pull_two_phase() == (two_phase == "1")
+        losses = []
+        for s in range(3):
+            b = [hip.dev(x) for x in c.batch(s)]
+            tr.loss_buf.zero_()
+            tr.pull_step_explicit(*b, segment=segment, compact=compact)
+            losses.append(K.read_loss(tr.loss_buf).item())
+        assert close(np.asarray(losses), c.z["%s.losses" % opt], atol=3e-5, rtol=3e-5), (two_phase, losses)
+        out.append((tr.flat.param.clone(), None if tr.flat.state1 is None else tr.flat.state1.clone()))
+    assert torch.equal(out[0][0], out[1][0])
+    if out[0][1] is not None:
+        assert torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("l1,opt", [(True, "adam"), (False, "adam"), (True, "sgd")])
+def test_two_phase_epochs_equal_one_phase_epochs_at_baseline_size(hip, world, l1, opt, monkeypatch):
+    """Two epochs of four B = 32 768 steps through kge_pull_run (ride-along sampler without visit descriptors, bucket overflow
+    ranking, multi-item relation rows): byte-identical tables and optimiser state, equal losses."""
+    res = []
+    for two_phase in ("0", "1"):
+        monkeypatch.setenv("KGE_PULL_DIR", two_phase)
+        tr, m, cfg = _trainer(hip, world, l1, opt, True, monkeypatch)
+        losses = [tr.train_model_epoch(e) for e in range(2)]
+        assert (tr._pull.direction is not None) == (two_phase == "1")
+        res.append((losses, tr.flat.param.clone(), None if tr.flat.state1 is None else tr.flat.state1.clone()))
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-5), (res[0][0], res[1][0])
+    # the two-phase run cuts the incidence lists into items of 32 instead of 8: the partial sums of long rows group differently.
+    # L1 gradients are sums of +-1 / +-0.5 (exact in fp32 in any order): byte-identical.  L2: rounding-level differences.
+    # (Adam turns a rounding-residue gradient into a +-lr step: isolated entries may differ, as in the pull-vs-push test above)
+    same = torch.equal if l1 else (lambda a, b: float((~torch.isclose(a, b, atol=2e-5, rtol=1e-4)).float().mean()) <= 2e-3)
+    assert same(res[0][1], res[1][1])
+    if res[0][2] is not None:
+        assert same(res[0][2], res[1][2])
+
+
 E, R, D, B = 14951, 1345, 100, 32768
 
 
