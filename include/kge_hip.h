@@ -401,7 +401,8 @@ typedef struct kge_pull_plan {
 /* Steps on batches first_batch .. first_batch + n_steps - 1.  src_half: the table half the first step reads (halves
  * alternate); cur_list: the list set the first step consumes; lists_ready == 0: a stand-alone sampler launch fills it first
  * (it must be cleared).  first_opt_step: optimiser step number of the first step (1-based); first_offset: its Philox
- * offset.  sample_after_last != 0: the last step also carries the sampler of batch first_batch + n_steps. */
+ * offset.  sample_after_last == 1: the last step also carries the sampler of batch first_batch + n_steps; == 2: of batch 0 (the
+ * first batch of the next epoch over the same permutation; its Philox offset continues from the last step's). */
 size_t kge_pull_plan_bytes(void);   /* sizeof(kge_pull_plan): lets a binding check its struct layout */
 int kge_pull_run(const kge_pull_plan* plan, int64_t first_batch, int64_t n_steps, int32_t src_half, int32_t cur_list,
                  int32_t lists_ready, int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream);

@@ -506,8 +506,13 @@ int kge_pull_run(const kge_pull_plan* p, int64_t first_batch, int64_t n_steps, i
                                  nullptr, &p->lists[cl], stream);
             if (rc) return rc;
         }
-        const bool has_next = (k + 1 < n_steps || sample_after_last) && first_batch + k + 1 < p->n_batches;
-        const kge_pull_batch* nb = has_next ? b + 1 : nullptr;
+        // the sampler of the following batch rides in this step's launch: the next step of this run, or -- after the last step --
+        // the batch that follows (sample_after_last == 1) or batch 0 of the next epoch (== 2: the same permutation is walked again,
+        // the Philox counters just keep counting)
+        const bool last = k + 1 == n_steps;
+        const bool wrap = last && sample_after_last == 2;
+        const bool has_next = wrap || ((!last || sample_after_last == 1) && first_batch + k + 1 < p->n_batches);
+        const kge_pull_batch* nb = wrap ? p->batches : (has_next ? b + 1 : nullptr);
         float* const tables_out[2] = {const_cast<float*>(p->model[1 - src].tables[0]), const_cast<float*>(p->model[1 - src].tables[1])};
         const float* const hat_in[2] = {p->hat[src][0], p->hat[src][1]};
         float* const hat_out[2] = {p->hat[1 - src][0], p->hat[1 - src][1]};
@@ -587,8 +592,10 @@ int kge_own_run(const kge_own_plan* p, int64_t first_batch, int64_t n_steps, int
                                  nullptr, &p->lists[cl], stream);
             if (rc) return rc;
         }
-        const bool has_next = (k + 1 < n_steps || sample_after_last) && first_batch + k + 1 < p->n_batches;
-        const kge_pull_batch* nb = has_next ? b + 1 : nullptr;
+        const bool last = k + 1 == n_steps;      // (sample_after_last: as kge_pull_run -- 1 = the following batch, 2 = batch 0 of the next epoch)
+        const bool wrap = last && sample_after_last == 2;
+        const bool has_next = wrap || ((!last || sample_after_last == 1) && first_batch + k + 1 < p->n_batches);
+        const kge_pull_batch* nb = wrap ? p->batches : (has_next ? b + 1 : nullptr);
         rc = kge_own_step(&p->model, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip, b->inc, p->partials,
                           dense, p->lmbda, p->reg_type, 1, nb ? nb->pairs : nullptr, nb ? nb->inv : nullptr, nb ? nb->n_pairs : 0, p->bern_prob, p->slots,
                           p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch, nb ? &p->lists[1 - cl] : nullptr, p->loss, stream);

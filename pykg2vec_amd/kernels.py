@@ -776,7 +776,7 @@ class PullPlan:
 
     def run(self, first_batch, n_steps, src_half, cur_list, lists_ready, first_opt_step, first_offset, sample_after_last):
         rc = self.fn(ctypes.byref(self.c), int(first_batch), int(n_steps), int(src_half), int(cur_list), 1 if lists_ready else 0,
-                     int(first_opt_step), int(first_offset) & (2 ** 64 - 1), 1 if sample_after_last else 0, _stream())
+                     int(first_opt_step), int(first_offset) & (2 ** 64 - 1), int(sample_after_last), _stream())
         if rc:
             L.check(rc, "kge_pull_run")
 
@@ -861,7 +861,7 @@ class OwnPlan:
 
     def run(self, first_batch, n_steps, cur_list, lists_ready, first_opt_step, first_offset, sample_after_last):
         rc = self.fn(ctypes.byref(self.c), int(first_batch), int(n_steps), int(cur_list), 1 if lists_ready else 0,
-                     int(first_opt_step), int(first_offset) & (2 ** 64 - 1), 1 if sample_after_last else 0, _stream())
+                     int(first_opt_step), int(first_offset) & (2 ** 64 - 1), int(sample_after_last), _stream())
         if rc:
             L.check(rc, "kge_own_run")
 
