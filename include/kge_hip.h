@@ -407,6 +407,25 @@ size_t kge_pull_plan_bytes(void);   /* sizeof(kge_pull_plan): lets a binding che
 int kge_pull_run(const kge_pull_plan* plan, int64_t first_batch, int64_t n_steps, int32_t src_half, int32_t cur_list,
                  int32_t lists_ready, int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream);
 
+/* ---- TransH / TransD gradients without float atomics (csrc/kge_pullx.hip): Generator (data/generator.py:42-97, neg_rate 1) +
+ * Trainer.train_step_pairwise (utils/trainer.py:147-157) + Criterion.pairwise_hinge (utils/criterion.py:25-29) + loss.backward()
+ * for TransH (models/pairwise.py:143-182; tables ent, rel, w) and TransD (:229-278; tables ent, rel, ent_mappings, rel_mappings),
+ * in the two-launch owner-computes form: every (positive, negative) pair is evaluated once and its gradient rows are stored to
+ * the pair's slots of `stage`; one owner per parameter row then sums the staged rows of its incidences in a fixed order and
+ * writes the row ONCE into m->grads (dense tables of the parameters' shapes; rows without incidence are not written: the
+ * buffers must be zero there, which kge_optimizer_step(zero_grad) leaves behind).  The optimiser is the caller's next call.
+ * Index: kge_pull_index_build(groups_per_block = kge_transx_groups_per_block(dim), compact = 1); lists / ride-along sampler as
+ * kge_pull_step.  dim % 4 == 0, dim <= 512.  The loss is added to the striped accumulators. */
+int kge_transx_groups_per_block(int32_t dim);
+int kge_transx_partial_stride(int32_t dim);          /* floats per partial slot */
+int kge_transx_scratch_bytes(int32_t model, int32_t dim, int64_t n_pairs, size_t* stage_bytes, size_t* recs_bytes);
+int kge_transx_grad_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists,
+                         const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials,
+                         const int32_t* multi, int64_t n_multi, float margin, float* stage, float* recs, int32_t reset_lists,
+                         const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern_prob,
+                         const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
+                         const kge_pull_lists* next_lists, float* loss, void* stream);
+
 /* ---- Owner-computes training step of the POINTWISE models, two phases (csrc/kge_own.hip): Generator (data/generator.py:99-158,
  * neg_rate 1) + Trainer.train_step_pointwise (utils/trainer.py:176-180) + Criterion.pointwise_logistic (utils/criterion.py:31-34)
  * + get_reg (pointwise.py:190-202,224-238,448-458) + loss.backward() + optimizer.step() (utils/trainer.py:298-299,112-131) for

@@ -532,6 +532,43 @@ int kge_pull_run(const kge_pull_plan* p, int64_t first_batch, int64_t n_steps, i
     return 0;
 }
 
+/* ---- TransH / TransD gradients in the two-launch owner-computes form, kge_pullx.hip */
+int kge_transx_groups_per_block(int32_t dim) { return transx_groups_per_block(dim); }
+int kge_transx_partial_stride(int32_t dim) { return transx_partial_stride(dim); }
+int kge_transx_scratch_bytes(int32_t model, int32_t dim, int64_t n_pairs, size_t* stage_bytes, size_t* recs_bytes) {
+    if (!stage_bytes || !recs_bytes || n_pairs < 0 || (model != KGE_TRANSH && model != KGE_TRANSD)) { set_error("kge_transx_scratch_bytes: bad arguments"); return -1; }
+    transx_scratch_bytes(model, dim, n_pairs, stage_bytes, recs_bytes);
+    if (!*stage_bytes && n_pairs) { set_error("kge_transx_scratch_bytes: hidden size %d must be a multiple of 4 and at most 512", dim); return -1; }
+    return 0;
+}
+int kge_transx_grad_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists,
+                         const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials,
+                         const int32_t* multi, int64_t n_multi, float margin, float* stage, float* recs, int32_t reset_lists,
+                         const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern_prob,
+                         const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
+                         const kge_pull_lists* next_lists, float* loss, void* stream) {
+    if (validate(m, true, "kge_transx_grad_step")) return -1;
+    if (m->model != KGE_TRANSH && m->model != KGE_TRANSD) { set_error("kge_transx_grad_step: TransH / TransD only (model %d)", m->model); return -1; }
+    const int nt = m->model == KGE_TRANSH ? 3 : 4;
+    for (int k = 0; k < nt; ++k)
+        if (!m->tables[k] || !m->grads[k]) { set_error("kge_transx_grad_step: table / gradient buffer %d missing", k); return -1; }
+    if (n_pairs <= 0 || n_items < 0 || n_multi < 0 || !pairs || !lists_ok(lists) || (n_items > 0 && !items) || !inc || !loss || !partials ||
+        !stage || !recs || (n_multi > 0 && !multi) || (n_items == 0 && !listed)) {
+        set_error("kge_transx_grad_step: bad arguments");
+        return -1;
+    }
+    if (next_pairs) {
+        if (next_n < 0 || !next_inv || !lists_ok(next_lists) || next_lists->count == lists->count || (slots && (n_slots & (n_slots - 1)))) {
+            set_error("kge_transx_grad_step: the next batch's sampler needs its inverse incidence map and its own list set");
+            return -1;
+        }
+        if (validate_packed_key(m, "kge_transx_grad_step")) return -1;
+    }
+    return launch_transx_grad_step(m, pairs, n_pairs, lists, items, n_items, listed, inc, partials, multi, n_multi, margin, stage, recs,
+                                   reset_lists, next_pairs, next_inv, next_n, bern_prob, slots, n_slots, seed, next_offset, next_lists, loss,
+                                   (hipStream_t)stream);
+}
+
 /* ---- two-phase owner-computes step of the pointwise models, kge_own.hip */
 int kge_own_groups_per_block(int32_t model, int32_t dim) { return own_groups_per_block(model, dim); }
 int kge_own_partial_stride(int32_t model, int32_t dim) { return own_partial_stride(model, dim); }

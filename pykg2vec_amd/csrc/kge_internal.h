@@ -159,6 +159,16 @@ int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, in
 
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);
+// TransH / TransD gradients in the two-launch owner-computes form (kge_pullx.hip)
+int transx_groups_per_block(int dim);
+int transx_partial_stride(int dim);
+void transx_scratch_bytes(int model, int dim, int64_t n, size_t* stage, size_t* recs);
+int launch_transx_grad_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists,
+                            const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials,
+                            const int32_t* multi, int64_t n_multi, float margin, float* stage, float* recs, int reset_lists,
+                            const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern,
+                            const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
+                            const kge_pull_lists* next_lists, float* loss, hipStream_t s);
 void pull_direction_bytes(int dim, int l1, int64_t n, size_t* codes, size_t* recs);
 int pull_groups_per_block(int dim);
 int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],

@@ -781,6 +781,57 @@ class PullPlan:
             L.check(rc, "kge_pull_run")
 
 
+# ---------------------------------------------------------------------------- TransH / TransD gradients, two-launch owner-computes form
+def transx_groups_per_block(dim):
+    return int(L.load().kge_transx_groups_per_block(int(dim)))
+
+
+def transx_partial_stride(dim):
+    return int(L.load().kge_transx_partial_stride(int(dim)))
+
+
+class TransXScratch:
+    """Staging rows (5 / 8 gradient rows per pair) and hinge coefficients of kge_transx_grad_step."""
+
+    def __init__(self, model_name, dim, n_pairs, device):
+        sb, rb = ctypes.c_size_t(), ctypes.c_size_t()
+        L.check(L.load().kge_transx_scratch_bytes(MODEL_IDS[model_name], int(dim), int(n_pairs), ctypes.byref(sb), ctypes.byref(rb)),
+                "kge_transx_scratch_bytes")
+        self.stage = torch.empty(max(4, sb.value // 4), dtype=torch.float32, device=device)
+        self.recs = torch.zeros(max(1, rb.value // 4), dtype=torch.float32, device=device)
+
+
+def transx_grad_step(desc, pairs, lists, items, listed, inc, partials, multi, margin, scratch, loss_buf, reset_lists=True,
+                     sample_next=None, prepare_only=False):
+    """kge_transx_grad_step: the TransH / TransD gradients of one batch into desc's dense gradient tables, no float atomics
+    (csrc/kge_pullx.hip).  sample_next as pull_step."""
+    n_multi = multi.shape[0] if multi is not None else 0
+    if sample_next is not None:
+        npairs, ninv, bern, slots, seed, noff, nlists = sample_next
+        nx = (_i32(npairs, "next_pairs"), _i32(ninv, "next_inv"), npairs.shape[0], _dev(bern, torch.float32, "bern_prob") if bern is not None else None,
+              ctypes.c_void_p(slots.data_ptr()) if slots is not None else None, slots.numel() if slots is not None else 0,
+              int(seed) & (2 ** 64 - 1), int(noff) & (2 ** 64 - 1), ctypes.byref(nlists.c))
+    else:
+        nx = (None, None, 0, None, None, 0, 0, 0, None)
+    args = [ctypes.byref(desc), _i32(pairs, "pairs"), pairs.shape[0], ctypes.byref(lists.c),
+            _i32(items, "items") if items.shape[0] else None, items.shape[0], _i32(listed, "listed") if listed is not None else None,
+            _i32(inc, "inc"), _dev(partials, torch.float32, "partials"), _i32(multi, "multi") if n_multi else None, n_multi,
+            float(margin), _dev(scratch.stage, torch.float32, "stage"), _dev(scratch.recs, torch.float32, "recs"),
+            1 if reset_lists else 0, *nx, _dev(loss_buf, torch.float32, "loss")]
+    fn = L.load().kge_transx_grad_step
+    if prepare_only:
+        off_idx = len(args) - 3      # next_offset: the one argument that changes from epoch to epoch
+        keep = (desc, pairs, lists, items, listed, inc, partials, multi, scratch, loss_buf, sample_next)
+
+        def call(next_offset=None):
+            if next_offset is not None:
+                args[off_idx] = int(next_offset) & (2 ** 64 - 1)
+            L.check(fn(*args, _stream()), "kge_transx_grad_step")
+        call.keep = keep
+        return call
+    L.check(fn(*args, _stream()), "kge_transx_grad_step")
+
+
 # ---------------------------------------------------------------------------- two-phase owner-computes step (pointwise models)
 def own_groups_per_block(model_name, dim):
     return int(L.load().kge_own_groups_per_block(MODEL_IDS[model_name], int(dim)))

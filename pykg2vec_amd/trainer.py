@@ -198,7 +198,8 @@ class Trainer:
         flag = lambda name: None if env(name) is None else env(name) == "1"
         return {"pull": flag("KGE_PULL"), "staged": flag("KGE_STAGED"), "graph_multi": flag("KGE_GRAPH_MULTI"),
                 "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED"),
-                "rescal_unfused": flag("KGE_RESCAL_UNFUSED"), "pull_dir": flag("KGE_PULL_DIR")}
+                "rescal_unfused": flag("KGE_RESCAL_UNFUSED"), "pull_dir": flag("KGE_PULL_DIR"),
+                "transx_own": flag("KGE_TRANSX_OWN")}
 
     def _init_hot_path(self, process_group=None, backend=None, use_graph=None):
         # `backend` exists so that the multi-process plumbing (batch sharding, gradient collectives, replica
@@ -614,6 +615,83 @@ class Trainer:
                     pairs, lists, items, idx.skip(0), multi, partials, dense, cfg.optimizer, cfg.learning_rate, flat.step)
         return gviews
 
+    # ------------------------------------------------------------------ TransH / TransD: gradients without float atomics
+    TRANSX_OWN_MIN_BATCH = 16384
+
+    def _transx_ok(self):
+        """TransH / TransD hinge step with neg_rate 1 on one GPU at large batches: every pair evaluated once with its gradient
+        rows staged, one owner per parameter row sums them into the dense gradient tables (csrc/kge_pullx.hip), then the flat
+        optimiser.  No float atomics, bit-reproducible.  KGE_TRANSX_OWN=0 / 1 overrides the batch-size rule."""
+        m = self.model
+        if not (self.K is K and not self.distributed and m.kernel_name in ("transh", "transd")
+                and m.training_strategy == TrainingStrategy.PAIRWISE_BASED and int(self.config.neg_rate) == 1
+                and len({p.weight.shape[1] for p in m.parameter_list}) == 1
+                and m.parameter_list[0].weight.shape[1] % 4 == 0 and m.parameter_list[0].weight.shape[1] <= 512
+                and self.generator is not None and self.generator.n_train >= self.config.batch_size):
+            return False
+        if self.switches.get("transx_own") is not None:
+            return self.switches["transx_own"]
+        return int(self.config.batch_size) >= self.TRANSX_OWN_MIN_BATCH
+
+    def _transx_state(self):
+        st = getattr(self, "_transx", None)
+        d = self.model.parameter_list[0].weight.shape[1]
+        idx = self.generator.pull_index(groups_per_block=K.transx_groups_per_block(d), compact=True, segment=32)
+        if st is None or st["index"] is not idx:
+            dev = self.flat.param.device
+            E = int(self.config.tot_entity)
+            st = self._transx = {
+                "index": idx, "lists": [K.PullListSet(idx.batch_size, E, dev) for _ in range(2)], "cur_list": 0, "ready": None,
+                "partials": torch.empty(max(1, idx.max_slots) * K.transx_partial_stride(d), dtype=torch.float32, device=dev),
+                "scratch": K.TransXScratch(self.model.kernel_name, d, idx.batch_size, dev), "calls": {}}
+        return st
+
+    def _transx_step(self):
+        """One step: [stand-alone sampler if no sampler rode along] -> kge_transx_grad_step (evaluate pairs / owners sum / finish; the
+        next batch's sampler rides in the second launch) -> dense optimiser over the flat buffers."""
+        st = self._transx_state()
+        gen, cfg, idx = self.generator, self.config, st["index"]
+        b = gen._batch_idx
+        start, n, offset = gen._next_range()
+        pairs, inc, items, multi = idx.batch(b)
+        cur = st["cur_list"]
+        if st["ready"] != (b, offset):
+            st["lists"][cur].clear()
+            K.pull_sample(pairs, idx.inv(b), cfg.tot_entity, gen.bern, gen.slots, gen.seed, offset, st["lists"][cur])
+        # the following batch's sampler rides along: the next one of this epoch, or batch 0 of the next epoch (same permutation)
+        nb = b + 1 if (gen._pending > 0 and b + 1 < idx.n_batches) else (0 if gen._pending == 0 else None)
+        nxt = None
+        if nb is not None:
+            nxt = (idx.batch(nb)[0], idx.inv(nb), gen.bern, gen.slots, gen.seed, gen._draws, st["lists"][cur ^ 1])
+        key = (b, cur, nb)
+        call = st["calls"].get(key)
+        if call is None:
+            call = st["calls"][key] = K.transx_grad_step(self._desc, pairs, st["lists"][cur], items, idx.skip(b), inc, st["partials"], multi,
+                                                         cfg.margin, st["scratch"], self.loss_buf, sample_next=nxt, prepare_only=True)
+        call(nxt[5] if nxt is not None else None)
+        if nxt is not None:
+            st["cur_list"] ^= 1
+            st["ready"] = (nb, nxt[5])
+        else:
+            st["ready"] = None
+        self._reduce_and_step()
+
+    def transx_step_explicit(self, ph, pr, pt, nh, nr, nt):
+        """The same step on an explicit batch (positives + given negatives, neg_rate 1): gradients into the flat buffer, no
+        optimiser (parity tests read them; the caller steps).  The incidence index of this one batch is built on the host."""
+        import numpy as np
+        from .generator import PullIndex
+        d = self.model.parameter_list[0].weight.shape[1]
+        dev = self.flat.param.device
+        pos = np.stack([x.detach().cpu().numpy() for x in (ph, pr, pt)], 1)
+        idx = PullIndex([pos], self.config.tot_entity, self.config.tot_relation, dev, 32, K.transx_groups_per_block(d), compact=True)
+        lists = K.PullListSet(len(pos), int(self.config.tot_entity), dev)
+        pairs, inc, items, multi = idx.batch(0)
+        K.pull_lists_explicit(pairs, idx.inv(0), nh.contiguous(), nt.contiguous(), lists)
+        partials = torch.empty(max(1, idx.max_slots) * K.transx_partial_stride(d), dtype=torch.float32, device=dev)
+        scratch = K.TransXScratch(self.model.kernel_name, d, len(pos), dev)
+        K.transx_grad_step(self._desc, pairs, lists, items, idx.skip(0), inc, partials, multi, self.config.margin, scratch, self.loss_buf)
+
     # ------------------------------------------------------------------ staged (atomic-free) step of the long-row bundle kernels
     def _staged_ok(self):
         """RotatE self-adversarial / DistMult / ComplEx logistic step without a gradient buffer: the bundle kernel stages its
@@ -692,6 +770,10 @@ class Trainer:
         if self._staged_ok():
             for _ in range(n):
                 self._staged_step()
+            return
+        if n > 0 and self._transx_ok() and self.generator._batch_idx + n <= self.generator.n_train // self.config.batch_size:
+            for _ in range(n):
+                self._transx_step()
             return
         if self._pull_dp_ok():
             for _ in range(n):
@@ -819,6 +901,8 @@ class Trainer:
         if self.K is not K:
             return False
         if self.switches["staged"] and self._staged_ok():   # the staged step is an eager two-launch step
+            return False
+        if self.generator is not None and self._transx_ok():   # an eager three-launch step
             return False
         if self.use_graph is None and self.generator is not None and (self._pull_ok() or self._own_ok()):   # one native call per epoch beats a replay per step
             return False

@@ -1,0 +1,115 @@
+"""TransH / TransD gradients in the two-launch owner-computes form (csrc/kge_pullx.hip: every pair evaluated once with its
+gradient rows staged, one owner per parameter row sums them; no float atomics).  Held to (a) the numpy oracle's dense gradient
+on explicit batches, (b) the atomic-scatter path on the sampler's batches over whole epochs, (c) itself, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import kge_oracle as ko
+from golden_util import Case, close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import hip_util
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return hip_util
+
+
+SHAPES = [("transh", dict(hidden_size=100, l1_flag=True), 300, 11, 160),
+          ("transh", dict(hidden_size=64, l1_flag=False), 300, 11, 160),
+          ("transh", dict(hidden_size=200, l1_flag=True), 50, 2, 2000),      # two relations with ~1000 incidences: rows cut into
+                                                                            # items across workgroups (partials + finishing launch)
+          ("transh", dict(hidden_size=36, l1_flag=False), 9, 3, 700),         # 9 entities: bucket overflow chains
+          ("transd", dict(ent_hidden_size=64, rel_hidden_size=64, l1_flag=False), 300, 11, 160),
+          ("transd", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=True), 3000, 40, 4096),
+          ("transd", dict(ent_hidden_size=260, rel_hidden_size=260, l1_flag=True), 40, 2, 600)]
+
+
+@pytest.mark.parametrize("model,hp,E,R,B", SHAPES)
+def test_transx_gradients_match_oracle(hip, model, hp, E, R, B):
+    from pykg2vec_amd.trainer import Trainer
+    rng = np.random.default_rng(B + E)
+    shape_kw = {k: v for k, v in hp.items() if k in ("hidden_size", "ent_hidden_size", "rel_hidden_size")}
+    P = ko.init_params(model, rng, tot_entity=E, tot_relation=R, **shape_kw)
+    hp = dict(hp, margin=1.0)
+    pos = np.stack([rng.integers(E, size=B), rng.integers(R, size=B), rng.integers(E, size=B)], 1)
+    flip = rng.random(B) > 0.5
+    rnd = rng.integers(E, size=B)
+    nh = np.where(flip, pos[:, 0], rnd); nt = np.where(flip, rnd, pos[:, 2])
+    batch = (pos[:, 0], pos[:, 1], pos[:, 2], nh, pos[:, 1], nt)
+    hp_run = dict(hp, neg_rate=1)
+    loss_ref, G_ref, _, _ = ko.train_step_grads(model, P, batch, **hp_run)
+    m = hip.model_from_params(model, P, hp, E, R, train=pos)
+    cfg = hip.make_config(E, R, hp_run, pos, pos[:1], pos[:1])
+    tr = Trainer(m, cfg)
+    tr.build_model()
+    b = [hip.dev(x) for x in batch]
+    tr.loss_buf.zero_()
+    tr.transx_step_explicit(*b)
+    from pykg2vec_amd import kernels as K
+    loss = K.read_loss(tr.loss_buf).item()
+    assert np.isclose(loss, loss_ref, rtol=5e-5, atol=5e-5), (loss, loss_ref)
+    names = [n.split(".")[0] for n, _ in hip.table_parameters(m)]
+    for nme, g in zip(names, tr.flat.grad_views):
+        got = g.cpu().numpy()
+        scale = max(1.0, np.abs(G_ref[nme]).max())
+        assert np.allclose(got, G_ref[nme], atol=5e-5 * scale, rtol=2e-4), (nme, np.abs(got - G_ref[nme]).max())
+
+
+def _world(model, E, R, D, n_train, seed=11):
+    rng = np.random.default_rng(seed)
+    train = np.stack([rng.integers(E, size=n_train), rng.integers(R, size=n_train), rng.integers(E, size=n_train)], 1)
+    kw = dict(hidden_size=D) if model == "transh" else dict(ent_hidden_size=D, rel_hidden_size=D)
+    P = ko.init_params(model, rng, tot_entity=E, tot_relation=R, **kw)
+    return train, train[:8], P, kw
+
+
+def _trainer(hip, model, world, E, R, B, opt, own, monkeypatch, l1=True):
+    from pykg2vec_amd.trainer import Trainer
+    train, test, P, kw = world
+    hp = dict(kw, l1_flag=l1, margin=1.0, neg_rate=1)
+    cfg = hip.make_config(E, R, hp, train, test, test, optimizer=opt, lr=0.01, batch_size=B)
+    m = hip.model_from_params(model, P, hp, E, R, train=train)
+    monkeypatch.setenv("KGE_TRANSX_OWN", "1" if own else "0")
+    tr = Trainer(m, cfg, use_graph=False)
+    tr.build_model()
+    tr.generator = tr._new_generator()
+    assert tr._transx_ok() == own
+    return tr, m, cfg
+
+
+@pytest.mark.parametrize("model,E,R,D,B,opt,l1", [("transh", 500, 9, 100, 1024, "sgd", True), ("transh", 500, 9, 64, 1024, "adam", False),
+                                                   ("transd", 500, 9, 100, 1024, "sgd", True), ("transd", 2000, 300, 64, 2048, "adagrad", False),
+                                                   ("transh", 14951, 1345, 100, 32768, "adam", True)])
+def test_transx_epochs_equal_push_epochs(hip, monkeypatch, model, E, R, D, B, opt, l1):
+    """Same generator seed => same batches and Philox draws on both paths: two epochs of three steps."""
+    world = _world(model, E, R, D, 3 * B + 5)
+    res = {}
+    for own in (False, True):
+        tr, m, cfg = _trainer(hip, model, world, E, R, B, opt, own, monkeypatch, l1)
+        cfg.tot_train_triples = 3 * B
+        losses = [tr.train_model_epoch(e) for e in range(2)]
+        assert (getattr(tr, "_transx", None) is not None) == own
+        res[own] = (losses, {k: p.detach().cpu().numpy().copy() for k, p in hip.table_parameters(m)})
+    assert np.allclose(res[True][0], res[False][0], rtol=3e-5), (res[True][0], res[False][0])
+    for k in res[True][1]:
+        a, b = res[True][1][k], res[False][1][k]
+        bad = ~np.isclose(a, b, atol=2e-5, rtol=1e-4)
+        lim = 0.0 if opt == "sgd" else 2e-3    # (order-dependent rounding residues under sign-like first steps)
+        assert bad.mean() <= lim, (opt, k, bad.mean(), np.abs(a - b).max())
+
+
+def test_transx_training_is_bit_reproducible(hip, monkeypatch):
+    model, E, R, D, B = "transd", 800, 7, 64, 1024
+    world = _world(model, E, R, D, 3 * B)
+    out = []
+    for _ in range(2):
+        tr, m, cfg = _trainer(hip, model, world, E, R, B, "adam", True, monkeypatch)
+        losses = [tr.train_model_epoch(e) for e in range(2)]
+        out.append((losses, [p.detach().clone() for _, p in hip.table_parameters(m)]))
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b)
