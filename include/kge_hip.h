@@ -426,6 +426,26 @@ int kge_transx_grad_step(const kge_model_desc* m, const int32_t* pairs, int64_t 
                          const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
                          const kge_pull_lists* next_lists, float* loss, void* stream);
 
+/* A run of consecutive TransH / TransD steps enqueued by ONE native call: per step kge_transx_grad_step (three launches) and the
+ * dense optimiser over the flat buffers (kge_optimizer_step with zero_grad: the gradient tables of `model` must be views into
+ * flat_grad).  Arguments as kge_pull_run. */
+typedef struct kge_transx_plan {
+    kge_model_desc model;                 /* tables = the parameters (views into flat_param); grads = views into flat_grad */
+    kge_pull_lists lists[2];
+    const kge_pull_batch* batches;        /* HOST array of n_batches entries (dense_skip = the `listed` bitmap of the compact index) */
+    int64_t n_batches;
+    float* partials; float* stage; float* recs;
+    float margin;
+    float* flat_param; float* flat_grad; float* flat_state1; float* flat_state2; int64_t flat_numel;
+    int32_t optimizer; float lr;
+    const float* bern_prob; const uint64_t* slots; int64_t n_slots; uint64_t seed;
+    int64_t draws_per_batch;
+    float* loss;
+} kge_transx_plan;
+size_t kge_transx_plan_bytes(void);
+int kge_transx_run(const kge_transx_plan* plan, int64_t first_batch, int64_t n_steps, int32_t cur_list, int32_t lists_ready,
+                   int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream);
+
 /* ---- Owner-computes training step of the POINTWISE models, two phases (csrc/kge_own.hip): Generator (data/generator.py:99-158,
  * neg_rate 1) + Trainer.train_step_pointwise (utils/trainer.py:176-180) + Criterion.pointwise_logistic (utils/criterion.py:31-34)
  * + get_reg (pointwise.py:190-202,224-238,448-458) + loss.backward() + optimizer.step() (utils/trainer.py:298-299,112-131) for

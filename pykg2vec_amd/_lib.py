@@ -71,6 +71,16 @@ class PullPlanC(ctypes.Structure):
                 ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p),
                 ("direction", PullDirection)]
 
+class TransXPlanC(ctypes.Structure):
+    """struct kge_transx_plan"""
+    _fields_ = [("model", ModelDesc), ("lists", PullLists * 2), ("batches", ctypes.POINTER(PullBatch)), ("n_batches", ctypes.c_int64),
+                ("partials", ctypes.c_void_p), ("stage", ctypes.c_void_p), ("recs", ctypes.c_void_p), ("margin", ctypes.c_float),
+                ("flat_param", ctypes.c_void_p), ("flat_grad", ctypes.c_void_p), ("flat_state1", ctypes.c_void_p),
+                ("flat_state2", ctypes.c_void_p), ("flat_numel", ctypes.c_int64), ("optimizer", ctypes.c_int32), ("lr", ctypes.c_float),
+                ("bern_prob", ctypes.c_void_p), ("slots", ctypes.c_void_p), ("n_slots", ctypes.c_int64), ("seed", ctypes.c_uint64),
+                ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p)]
+
+
 class OwnPlanC(ctypes.Structure):
     """struct kge_own_plan"""
     _fields_ = [("model", ModelDesc), ("state1", ctypes.c_void_p * KGE_MAX_TABLES), ("state2", ctypes.c_void_p * KGE_MAX_TABLES),
@@ -186,6 +196,9 @@ _SIGNATURES = {
                                             ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_transx_plan_bytes": (ctypes.c_size_t, []),
+    "kge_transx_run": (ctypes.c_int, [ctypes.POINTER(TransXPlanC), ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]),
     "kge_own_groups_per_block": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
     "kge_own_partial_stride": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
     "kge_own_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(PullLists), ctypes.c_void_p,

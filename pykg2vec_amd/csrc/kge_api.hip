@@ -569,6 +569,43 @@ int kge_transx_grad_step(const kge_model_desc* m, const int32_t* pairs, int64_t 
                                    (hipStream_t)stream);
 }
 
+size_t kge_transx_plan_bytes(void) { return sizeof(kge_transx_plan); }
+
+int kge_transx_run(const kge_transx_plan* p, int64_t first_batch, int64_t n_steps, int32_t cur_list, int32_t lists_ready,
+                   int64_t first_opt_step, uint64_t first_offset, int32_t sample_after_last, void* stream) {
+    if (!p || !p->batches || n_steps < 0 || first_batch < 0 || first_batch + n_steps > p->n_batches || (cur_list & ~1) ||
+        first_opt_step < 1 || !p->flat_param || !p->flat_grad || p->flat_numel <= 0) {
+        set_error("kge_transx_run: bad arguments");
+        return -1;
+    }
+    int cl = cur_list;
+    uint64_t offset = first_offset;
+    for (int64_t k = 0; k < n_steps; ++k) {
+        const kge_pull_batch* b = p->batches + first_batch + k;
+        int rc;
+        if (k == 0 && !lists_ready) {
+            rc = kge_pull_sample(b->pairs, b->inv, b->n_pairs, p->model.tot_entity, p->bern_prob, p->slots, p->n_slots, p->seed, offset,
+                                 nullptr, &p->lists[cl], stream);
+            if (rc) return rc;
+        }
+        const bool last = k + 1 == n_steps;      // (sample_after_last: as kge_pull_run)
+        const bool wrap = last && sample_after_last == 2;
+        const bool has_next = wrap || ((!last || sample_after_last == 1) && first_batch + k + 1 < p->n_batches);
+        const kge_pull_batch* nb = wrap ? p->batches : (has_next ? b + 1 : nullptr);
+        rc = kge_transx_grad_step(&p->model, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip, b->inc, p->partials,
+                                  b->multi, b->n_multi, p->margin, p->stage, p->recs, 1, nb ? nb->pairs : nullptr, nb ? nb->inv : nullptr,
+                                  nb ? nb->n_pairs : 0, p->bern_prob, p->slots, p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch,
+                                  nb ? &p->lists[1 - cl] : nullptr, p->loss, stream);
+        if (rc) return rc;
+        rc = kge_optimizer_step(p->optimizer, p->flat_param, p->flat_grad, p->flat_state1, p->flat_state2, p->flat_numel, p->lr,
+                                first_opt_step + k, 1, nullptr, stream);
+        if (rc) return rc;
+        if (has_next) cl ^= 1;
+        offset += (uint64_t)p->draws_per_batch;
+    }
+    return 0;
+}
+
 /* ---- two-phase owner-computes step of the pointwise models, kge_own.hip */
 int kge_own_groups_per_block(int32_t model, int32_t dim) { return own_groups_per_block(model, dim); }
 int kge_own_partial_stride(int32_t model, int32_t dim) { return own_partial_stride(model, dim); }

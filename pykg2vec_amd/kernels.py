@@ -832,6 +832,48 @@ def transx_grad_step(desc, pairs, lists, items, listed, inc, partials, multi, ma
     L.check(fn(*args, _stream()), "kge_transx_grad_step")
 
 
+class TransXPlan:
+    """struct kge_transx_plan: everything of the TransH / TransD step that does not change between steps; `run` enqueues a whole
+    sequence of steps (gradients without atomics + flat optimiser) with ONE foreign call."""
+
+    def __init__(self, desc, flat, lists, index, partials, scratch, margin, optimizer, lr, loss_buf, bern, slots, seed, draws_per_batch):
+        self.keep = (desc, flat, lists, index, partials, scratch, loss_buf, bern, slots)
+        c = L.TransXPlanC()
+        ctypes.memmove(ctypes.byref(c.model), ctypes.byref(desc), ctypes.sizeof(L.ModelDesc))
+        for half in (0, 1):
+            c.lists[half] = lists[half].c
+        self.batches = (L.PullBatch * index.n_batches)()
+        for b in range(index.n_batches):
+            pairs, inc, items, multi = index.batch(b)
+            skip = index.skip(b)
+            self.batches[b] = L.PullBatch(pairs.data_ptr(), items.data_ptr() if items.shape[0] else None, items.shape[0],
+                                          skip.data_ptr() if skip is not None else None, inc.data_ptr(), index.inv(b).data_ptr(),
+                                          multi.data_ptr() if multi.shape[0] else None, multi.shape[0], pairs.shape[0])
+        c.batches = ctypes.cast(self.batches, ctypes.POINTER(L.PullBatch))
+        c.n_batches = index.n_batches
+        c.partials, c.stage, c.recs = partials.data_ptr(), scratch.stage.data_ptr(), scratch.recs.data_ptr()
+        c.margin = float(margin)
+        c.flat_param, c.flat_grad = flat.param.data_ptr(), flat.grad.data_ptr()
+        c.flat_state1 = flat.state1.data_ptr() if flat.state1 is not None else None
+        c.flat_state2 = flat.state2.data_ptr() if flat.state2 is not None else None
+        c.flat_numel = flat.param.numel()
+        c.optimizer, c.lr = OPTIMIZER_IDS[optimizer], float(lr)
+        c.bern_prob = bern.data_ptr() if bern is not None else None
+        c.slots = slots.data_ptr() if slots is not None else None
+        c.n_slots = slots.numel() if slots is not None else 0
+        c.seed = int(seed) & (2 ** 64 - 1)
+        c.draws_per_batch = int(draws_per_batch)
+        c.loss = loss_buf.data_ptr()
+        self.c = c
+        self.fn = L.load().kge_transx_run
+
+    def run(self, first_batch, n_steps, cur_list, lists_ready, first_opt_step, first_offset, sample_after_last):
+        rc = self.fn(ctypes.byref(self.c), int(first_batch), int(n_steps), int(cur_list), 1 if lists_ready else 0,
+                     int(first_opt_step), int(first_offset) & (2 ** 64 - 1), int(sample_after_last), _stream())
+        if rc:
+            L.check(rc, "kge_transx_run")
+
+
 # ---------------------------------------------------------------------------- two-phase owner-computes step (pointwise models)
 def own_groups_per_block(model_name, dim):
     return int(L.load().kge_own_groups_per_block(MODEL_IDS[model_name], int(dim)))

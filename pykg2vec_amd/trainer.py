@@ -643,38 +643,34 @@ class Trainer:
             st = self._transx = {
                 "index": idx, "lists": [K.PullListSet(idx.batch_size, E, dev) for _ in range(2)], "cur_list": 0, "ready": None,
                 "partials": torch.empty(max(1, idx.max_slots) * K.transx_partial_stride(d), dtype=torch.float32, device=dev),
-                "scratch": K.TransXScratch(self.model.kernel_name, d, idx.batch_size, dev), "calls": {}}
+                "scratch": K.TransXScratch(self.model.kernel_name, d, idx.batch_size, dev), "plan": None}
         return st
 
-    def _transx_step(self):
-        """One step: [stand-alone sampler if no sampler rode along] -> kge_transx_grad_step (evaluate pairs / owners sum / finish; the
-        next batch's sampler rides in the second launch) -> dense optimiser over the flat buffers."""
+    def _transx_steps(self, n_steps):
+        """The next n_steps steps of the current epoch, enqueued by one native call (kge_transx_run: per step evaluate pairs /
+        owners sum / finish, with the next batch's sampler riding along, then the dense optimiser over the flat buffers)."""
         st = self._transx_state()
         gen, cfg, idx = self.generator, self.config, st["index"]
-        b = gen._batch_idx
-        start, n, offset = gen._next_range()
-        pairs, inc, items, multi = idx.batch(b)
-        cur = st["cur_list"]
-        if st["ready"] != (b, offset):
-            st["lists"][cur].clear()
-            K.pull_sample(pairs, idx.inv(b), cfg.tot_entity, gen.bern, gen.slots, gen.seed, offset, st["lists"][cur])
-        # the following batch's sampler rides along: the next one of this epoch, or batch 0 of the next epoch (same permutation)
-        nb = b + 1 if (gen._pending > 0 and b + 1 < idx.n_batches) else (0 if gen._pending == 0 else None)
-        nxt = None
-        if nb is not None:
-            nxt = (idx.batch(nb)[0], idx.inv(nb), gen.bern, gen.slots, gen.seed, gen._draws, st["lists"][cur ^ 1])
-        key = (b, cur, nb)
-        call = st["calls"].get(key)
-        if call is None:
-            call = st["calls"][key] = K.transx_grad_step(self._desc, pairs, st["lists"][cur], items, idx.skip(b), inc, st["partials"], multi,
-                                                         cfg.margin, st["scratch"], self.loss_buf, sample_next=nxt, prepare_only=True)
-        call(nxt[5] if nxt is not None else None)
-        if nxt is not None:
-            st["cur_list"] ^= 1
-            st["ready"] = (nb, nxt[5])
-        else:
-            st["ready"] = None
-        self._reduce_and_step()
+        B = idx.batch_size
+        if st.get("plan") is None:
+            st["plan"] = K.TransXPlan(self._desc, self.flat, st["lists"], idx, st["partials"], st["scratch"], cfg.margin, cfg.optimizer,
+                                      cfg.learning_rate, self.loss_buf, gen.bern, gen.slots, gen.seed, B * gen.neg_rate)
+        first = gen._batch_idx
+        if gen._pending < n_steps or first + n_steps > idx.n_batches:
+            raise StopIteration
+        offset = gen._draws
+        gen._batch_idx += n_steps
+        gen._pending -= n_steps
+        gen._draws += n_steps * B * gen.neg_rate
+        ready = st["ready"] == (first, offset)
+        if not ready and st["ready"] is not None:   # a sampler rode along for a batch that is not the next one: discard
+            st["lists"][st["cur_list"]].clear()
+        after = 1 if (gen._pending > 0 and first + n_steps < idx.n_batches) else (2 if gen._pending == 0 else 0)
+        st["plan"].run(first, n_steps, st["cur_list"], ready, self.flat.step + 1, offset, after)
+        self.flat.step += n_steps
+        carried = n_steps - 1 + (1 if after else 0)
+        st["cur_list"] ^= carried & 1
+        st["ready"] = ((first + n_steps if after == 1 else 0), offset + n_steps * B * gen.neg_rate) if after else None
 
     def transx_step_explicit(self, ph, pr, pt, nh, nr, nt):
         """The same step on an explicit batch (positives + given negatives, neg_rate 1): gradients into the flat buffer, no
@@ -772,8 +768,7 @@ class Trainer:
                 self._staged_step()
             return
         if n > 0 and self._transx_ok() and self.generator._batch_idx + n <= self.generator.n_train // self.config.batch_size:
-            for _ in range(n):
-                self._transx_step()
+            self._transx_steps(n)
             return
         if self._pull_dp_ok():
             for _ in range(n):

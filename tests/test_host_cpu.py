@@ -235,6 +235,9 @@ def test_pull_plan_struct_layout_matches_the_library():
     assert lib.kge_pull_plan_bytes() == ctypes.sizeof(_lib.PullPlanC)
     assert ctypes.sizeof(_lib.PullBatch) == 72 and ctypes.sizeof(_lib.PullLists) == 56
     assert lib.kge_own_plan_bytes() == ctypes.sizeof(_lib.OwnPlanC)
+    assert lib.kge_transx_plan_bytes() == ctypes.sizeof(_lib.TransXPlanC)
+    assert ctypes.sizeof(_lib.PullDirection) == 32
+    assert lib.kge_transx_groups_per_block(100) == 8 and lib.kge_transx_partial_stride(100) == 256 and lib.kge_transx_groups_per_block(600) == 0
     assert lib.kge_staged_step_bytes() == ctypes.sizeof(_lib.StagedStep)
     assert lib.kge_pull_partial_stride(100) == 128 and lib.kge_pull_partial_stride(102) == 0   # rows move as float4
     assert lib.kge_pull_groups_per_block(100) in (8, 16) and lib.kge_pull_groups_per_block(1000) == 8
