@@ -414,8 +414,8 @@ int kge_pull_run(const kge_pull_plan* plan, int64_t first_batch, int64_t n_steps
  * the pair's slots of `stage`; one owner per parameter row then sums the staged rows of its incidences in a fixed order and
  * writes the row ONCE into m->grads (dense tables of the parameters' shapes; rows without incidence are not written: the
  * buffers must be zero there, which kge_optimizer_step(zero_grad) leaves behind).  The optimiser is the caller's next call.
- * Index: kge_pull_index_build(groups_per_block = kge_transx_groups_per_block(dim), compact = 1); lists / ride-along sampler as
- * kge_pull_step.  dim % 4 == 0, dim <= 512.  The loss is added to the striped accumulators. */
+ * Index: kge_pull_index_build(groups_per_block = kge_transx_groups_per_block(dim)), compact (`listed` = its bitmap: entities that
+ * were only drawn are then owned by the first pair that drew them) or not (`listed` = NULL); lists / ride-along sampler as kge_pull_step.  dim % 4 == 0, dim <= 512.  The loss is added to the striped accumulators. */
 int kge_transx_groups_per_block(int32_t dim);
 int kge_transx_partial_stride(int32_t dim);          /* floats per partial slot */
 int kge_transx_scratch_bytes(int32_t model, int32_t dim, int64_t n_pairs, size_t* stage_bytes, size_t* recs_bytes);

@@ -325,7 +325,8 @@ __global__ __launch_bounds__(kBlock) void k_transx_own(XArgs a, PullSampleArgs s
             if (cnt > kPullCap) a.lists.head[g] = -1;
         }
         if (kind == 0) {
-            xfinish<M, G, NV>(a, g, A0, A1, gl);
+            // (a row nobody touched this step keeps the zero gradient the optimiser left behind: nothing to write)
+            if (nvis > 0 || cnt > 0) xfinish<M, G, NV>(a, g, A0, A1, gl);
         } else if (kind == 3) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {

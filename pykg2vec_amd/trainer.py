@@ -636,7 +636,8 @@ class Trainer:
     def _transx_state(self):
         st = getattr(self, "_transx", None)
         d = self.model.parameter_list[0].weight.shape[1]
-        idx = self.generator.pull_index(groups_per_block=K.transx_groups_per_block(d), compact=True, segment=32)
+        # (compact = None: the index lists only the touched rows when the batch touches a small part of the tables, else every row)
+        idx = self.generator.pull_index(groups_per_block=K.transx_groups_per_block(d), segment=32)
         if st is None or st["index"] is not idx:
             dev = self.flat.param.device
             E = int(self.config.tot_entity)
