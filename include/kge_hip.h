@@ -462,14 +462,19 @@ int kge_transx_run(const kge_transx_plan* plan, int64_t first_batch, int64_t n_s
  * `listed`: the compact index's bitmap (kge_pull_batch.dense_skip) or NULL when every row has an item.  dense == 0 (SGD / Adagrad:
  * a zero dense gradient leaves a row unchanged, so only touched rows are visited): an entity that was only DRAWN this step is
  * owned by the first pair that drew it (pc bit 27).  dense != 0 (Adam / RMSprop move every row every step): every unlisted row is
- * an implicit owner.  dim % 4 == 0, dim <= 512. */
+ * an implicit owner.  dim % 4 == 0, dim <= 512.
+ * STAGED FORM (stage != NULL, the default of the Python trainer): kge_own_step first evaluates every bundle ONCE (k_own_eval: one
+ * lane group per bundle) and stores the gradient rows it produces -- for its head, tail, relation and drawn entity -- in the bundle's
+ * four slots of `stage`; the owners then only add the staged rows of their incidences (every staged row has exactly one reader)
+ * instead of re-evaluating each bundle they occur in.  Outputs, kge_own_apply and all semantics are unchanged. */
 int kge_own_groups_per_block(int32_t model, int32_t dim);
 int kge_own_partial_stride(int32_t model, int32_t dim);
 int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists, const int32_t* items,
                  int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int32_t dense, float lmbda,
                  int32_t reg_type, int32_t reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n,
                  const float* bern_prob, const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
-                 const kge_pull_lists* next_lists, float* loss, void* stream);
+                 const kge_pull_lists* next_lists, float* loss,
+                 float* stage /* NULL, or 4 * n_pairs * kge_own_partial_stride floats: the staged form (see below) */, void* stream);
 int kge_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
                   const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* multi,
                   int64_t n_multi, float* partials, int32_t dense, int32_t optimizer, float lr, int64_t step, void* stream);
@@ -486,6 +491,7 @@ typedef struct kge_own_plan {
     const float* bern_prob; const uint64_t* slots; int64_t n_slots; uint64_t seed;
     int64_t draws_per_batch;
     float* loss;
+    float* stage;                         /* NULL: owners re-evaluate; else the staged form (4 * n_pairs * kge_own_partial_stride floats) */
 } kge_own_plan;
 size_t kge_own_plan_bytes(void);
 int kge_own_run(const kge_own_plan* plan, int64_t first_batch, int64_t n_steps, int32_t cur_list, int32_t lists_ready,

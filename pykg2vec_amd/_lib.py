@@ -87,7 +87,7 @@ class OwnPlanC(ctypes.Structure):
                 ("lists", PullLists * 2), ("batches", ctypes.POINTER(PullBatch)), ("n_batches", ctypes.c_int64),
                 ("partials", ctypes.c_void_p), ("optimizer", ctypes.c_int32), ("lr", ctypes.c_float), ("lmbda", ctypes.c_float),
                 ("reg_type", ctypes.c_int32), ("bern_prob", ctypes.c_void_p), ("slots", ctypes.c_void_p), ("n_slots", ctypes.c_int64),
-                ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p)]
+                ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p), ("stage", ctypes.c_void_p)]
 
 
 class StagedTable(ctypes.Structure):
@@ -205,7 +205,7 @@ _SIGNATURES = {
                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_float,
                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(PullLists),
-                                    ctypes.c_void_p, ctypes.c_void_p]),
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_own_apply": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                      ctypes.POINTER(PullLists), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int64,

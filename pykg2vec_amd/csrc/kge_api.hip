@@ -614,7 +614,7 @@ int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs,
                  int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int32_t dense, float lmbda,
                  int32_t reg_type, int32_t reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n,
                  const float* bern_prob, const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset,
-                 const kge_pull_lists* next_lists, float* loss, void* stream) {
+                 const kge_pull_lists* next_lists, float* loss, float* stage, void* stream) {
     if (validate(m, true, "kge_own_step")) return -1;
     if (m->model != KGE_DISTMULT && m->model != KGE_COMPLEX) { set_error("kge_own_step: DistMult / ComplEx only (model %d)", m->model); return -1; }
     if (n_pairs <= 0 || n_items <= 0 || !pairs || !lists_ok(lists) || !items || !inc || !partials || !loss ||
@@ -630,7 +630,7 @@ int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs,
         if (validate_packed_key(m, "kge_own_step")) return -1;
     }
     return launch_own_step(m, pairs, n_pairs, lists, items, n_items, listed, inc, partials, dense, lmbda, reg_type, reset_lists,
-                           next_pairs, next_inv, next_n, bern_prob, slots, n_slots, seed, next_offset, next_lists, loss, (hipStream_t)stream);
+                           next_pairs, next_inv, next_n, bern_prob, slots, n_slots, seed, next_offset, next_lists, loss, stage, (hipStream_t)stream);
 }
 
 int kge_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
@@ -643,7 +643,7 @@ int kge_own_apply(const kge_model_desc* m, float* const* state1, float* const* s
         return -1;
     }
     return launch_own_apply(m, state1, state2, pairs, n_pairs, lists, items, n_items, listed, multi, n_multi, partials, dense,
-                            optimizer, lr, step, (hipStream_t)stream);
+                            optimizer, lr, step, 0, (hipStream_t)stream);
 }
 
 size_t kge_own_plan_bytes(void) { return sizeof(kge_own_plan); }
@@ -670,13 +670,29 @@ int kge_own_run(const kge_own_plan* p, int64_t first_batch, int64_t n_steps, int
         const bool wrap = last && sample_after_last == 2;
         const bool has_next = wrap || ((!last || sample_after_last == 1) && first_batch + k + 1 < p->n_batches);
         const kge_pull_batch* nb = wrap ? p->batches : (has_next ? b + 1 : nullptr);
-        rc = kge_own_step(&p->model, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip, b->inc, p->partials,
-                          dense, p->lmbda, p->reg_type, 1, nb ? nb->pairs : nullptr, nb ? nb->inv : nullptr, nb ? nb->n_pairs : 0, p->bern_prob, p->slots,
-                          p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch, nb ? &p->lists[1 - cl] : nullptr, p->loss, stream);
-        if (rc) return rc;
-        rc = kge_own_apply(&p->model, p->state1, p->state2, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip,
-                           b->multi, b->n_multi, p->partials, dense, p->optimizer, p->lr, first_opt_step + k, stream);
-        if (rc) return rc;
+        if (p->stage) {
+            // staged form: the owners apply the optimiser themselves; only rows cut across workgroups go through k_own_apply
+            rc = launch_own_step_fused(&p->model, p->state1, p->state2, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items,
+                                       b->dense_skip, b->inc, p->partials, dense, p->lmbda, p->reg_type, p->optimizer, p->lr,
+                                       first_opt_step + k, nb ? nb->pairs : nullptr, nb ? nb->inv : nullptr, nb ? nb->n_pairs : 0,
+                                       p->bern_prob, p->slots, p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch,
+                                       nb ? &p->lists[1 - cl] : nullptr, p->loss, p->stage, (hipStream_t)stream);
+            if (rc) return rc;
+            if (b->n_multi > 0) {
+                rc = launch_own_apply(&p->model, p->state1, p->state2, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items,
+                                      b->dense_skip, b->multi, b->n_multi, p->partials, dense, p->optimizer, p->lr, first_opt_step + k, 1,
+                                      (hipStream_t)stream);
+                if (rc) return rc;
+            }
+        } else {
+            rc = kge_own_step(&p->model, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip, b->inc, p->partials,
+                              dense, p->lmbda, p->reg_type, 1, nb ? nb->pairs : nullptr, nb ? nb->inv : nullptr, nb ? nb->n_pairs : 0, p->bern_prob, p->slots,
+                              p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch, nb ? &p->lists[1 - cl] : nullptr, p->loss, nullptr, stream);
+            if (rc) return rc;
+            rc = kge_own_apply(&p->model, p->state1, p->state2, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip,
+                               b->multi, b->n_multi, p->partials, dense, p->optimizer, p->lr, first_opt_step + k, stream);
+            if (rc) return rc;
+        }
         if (has_next) cl ^= 1;
         offset += (uint64_t)p->draws_per_batch;
     }

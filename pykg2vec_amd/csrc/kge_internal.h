@@ -191,10 +191,16 @@ int launch_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pai
                     int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int dense, float lmbda, int reg_type,
                     int reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern,
                     const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
-                    float* loss, hipStream_t s);
+                    float* loss, float* stage, hipStream_t s);
 int launch_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
                      const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* multi,
-                     int64_t n_multi, float* partials, int dense, int optimizer, float lr, int64_t step, hipStream_t s);
+                     int64_t n_multi, float* partials, int dense, int optimizer, float lr, int64_t step, int multi_only, hipStream_t s);
+int launch_own_step_fused(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
+                          const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* inc,
+                          float* partials, int dense, float lmbda, int reg_type, int optimizer, float lr, int64_t step,
+                          const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern, const uint64_t* slots,
+                          int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
+                          float* stage, hipStream_t s);
 
 // kge_eval.hip
 size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n, int64_t tables = 1);

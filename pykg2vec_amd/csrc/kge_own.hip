@@ -38,6 +38,8 @@ struct OwnArgs {
     int sample_blocks, E, d, reset_lists;
     float inv_n, lmbda; int reg_type;
     OptArgs opt;
+    int multi_only;            // k_own_apply: only the rows cut into many items (the staged step applied the others itself)
+    float* stage;              // staged form: [n_pairs][4 roles: H T R C][NT][VEC * NV * G] gradient rows left by k_own_eval; NULL: owners re-evaluate
 };
 
 // Rows in registers: lane gl of a G-lane group holds NE = VEC * NV elements of a row.  VEC = 4 (hidden size % 4 == 0): NV float4
@@ -157,12 +159,135 @@ __device__ __forceinline__ void reg_grad(float (&g)[NT][NE], const float (&x)[NT
         }
 }
 
+// the dense-semantics optimiser on ONE row set, in place: parameter, state (and, unless the caller holds it, the gradient row) are
+// requested together
+template <int OPT, int NT, int VEC, int G, int NV>
+__device__ __forceinline__ void own_apply_row(const OwnArgs& a, int g, float (&gv)[NT][VEC * NV], bool have_g, int gl) {
+    constexpr int NE = VEC * NV;
+    const int d = a.d;
+    const bool is_rel = g >= a.E;
+    const int64_t off = (int64_t)(is_rel ? g - a.E : g) * d;
+    float P[NT][NE], M1[NT][NE], M2[NT][NE];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        load_row_e<VEC, G, NV>(P[t], (is_rel ? a.rel[t] : a.ent[t]) + off, d, gl);
+        if constexpr (OPT != KGE_OPT_SGD) load_row_e<VEC, G, NV>(M1[t], (is_rel ? a.s1_rel[t] : a.s1_ent[t]) + off, d, gl);
+        if constexpr (OPT == KGE_OPT_ADAM) load_row_e<VEC, G, NV>(M2[t], (is_rel ? a.s2_rel[t] : a.s2_ent[t]) + off, d, gl);
+        if (!have_g) load_row_e<VEC, G, NV>(gv[t], (is_rel ? a.g_rel[t] : a.g_ent[t]) + off, d, gl);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            float m1 = 0.f, m2 = 0.f;
+            if constexpr (OPT != KGE_OPT_SGD) m1 = M1[t][e];
+            if constexpr (OPT == KGE_OPT_ADAM) m2 = M2[t][e];
+            opt_update<OPT>(P[t][e], gv[t][e], m1, m2, a.opt);
+            if constexpr (OPT != KGE_OPT_SGD) M1[t][e] = m1;
+            if constexpr (OPT == KGE_OPT_ADAM) M2[t][e] = m2;
+        }
+        store_row_e<VEC, G, NV>(const_cast<float*>(is_rel ? a.rel[t] : a.ent[t]) + off, P[t], d, gl);
+        if constexpr (OPT != KGE_OPT_SGD) store_row_e<VEC, G, NV>((is_rel ? a.s1_rel[t] : a.s1_ent[t]) + off, M1[t], d, gl);
+        if constexpr (OPT == KGE_OPT_ADAM) store_row_e<VEC, G, NV>((is_rel ? a.s2_rel[t] : a.s2_ent[t]) + off, M2[t], d, gl);
+    }
+}
+
+// ---- staged form, phase 0: every bundle (positive i and the negative the sampler drew for it) is evaluated ONCE by one lane
+// group and leaves the gradient rows it produces in its own four slots of `stage` -- for the head entity (the negative's share
+// merged in when the tail was corrupted), the tail entity (likewise), the relation (both triples) and the drawn entity -- with plain
+// coalesced stores; the owners of k_own_step<..., STAGED> then only ADD the rows of their incidences (each staged row has exactly
+// one reader) instead of re-evaluating every bundle they occur in (3.25 evaluations per bundle -> 1, and the 127-VGPR evaluation
+// leaves the kernel whose occupancy decides the step).  Loss and regulariser value are accounted here.
+template <int NT, int VEC, int G, int NV>
+__global__ __launch_bounds__(kBlock, NT == 2 ? 5 : 4) void k_own_eval(OwnArgs a, float* __restrict__ loss) {
+    constexpr int GPB = kBlock / G;
+    constexpr int NE = VEC * NV;
+    constexpr int RSE = NE * G;
+    const int gl = threadIdx.x % G;
+    const int d = a.d;
+    const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
+    float acc = 0.f;
+    if (i < a.n_pairs) {
+        const int4 p = a.pairs[i];
+        const int w = a.lists.pc[i];
+        const bool tail = ((w >> 24) & 1) != 0;
+        const int c = w & 0xFFFFFF;
+        float A[NT][NE], RL[NT][NE], B[NT][NE], C[NT][NE];
+        load_rows_nt<NT, VEC, G, NV>(A, a.ent[0], a.ent[1], p.x, d, d, gl);
+        load_rows_nt<NT, VEC, G, NV>(RL, a.rel[0], a.rel[1], p.y, d, d, gl);
+        load_rows_nt<NT, VEC, G, NV>(B, a.ent[0], a.ent[1], p.z, d, d, gl);
+        load_rows_nt<NT, VEC, G, NV>(C, a.ent[0], a.ent[1], c, d, d, gl);
+        const bool reg_on = a.reg_type != KGE_REG_NONE;
+        const float reg_k = a.lmbda * a.inv_n;
+        // both energies first (two butterflies), then ONE output row set at a time, stored as soon as it is complete: four live
+        // row sets of inputs + one of output instead of eight (146 -> ~70 VGPRs: the kernel is a latency chain, occupancy decides it)
+        float pp = dot3<NT, NE>(A, RL, B), rsp = 0.f, pn, rsn = 0.f;
+        if (tail) pn = dot3<NT, NE>(A, RL, C); else pn = dot3<NT, NE>(C, RL, B);
+        if (reg_on) {
+            const float ra = reg_value<NT, NE>(A, a.reg_type), rr = reg_value<NT, NE>(RL, a.reg_type), rb = reg_value<NT, NE>(B, a.reg_type);
+            rsp = ra + rr + rb;
+            rsn = (tail ? ra : rb) + rr + reg_value<NT, NE>(C, a.reg_type);
+        }
+        gsum2<G>(pp, rsp);
+        gsum2<G>(pn, rsn);
+        const float xp = -pp, xn = pn;                         // y * energy, energy = -p; labels +1 / -1
+        const float dsp = sigmoid_t(xp) * a.inv_n, dsn = -sigmoid_t(xn) * a.inv_n;
+        acc += (softplus_t(xp) * a.inv_n + reg_k * rsp) + (softplus_t(xn) * a.inv_n + reg_k * rsn);
+        float* st = a.stage + i * (int64_t)(4 * NT * RSE);
+        auto zero = [](float (&g)[NT][NE]) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) g[t][e] = 0.f;
+        };
+        auto put = [&](int role, const float (&g)[NT][NE]) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) store_row_e<VEC, G, NV>(st + (role * NT + t) * RSE, g[t], d, gl);
+        };
+        {   // head entity: the positive, and the negative when it kept the head
+            float g[NT][NE]; zero(g);
+            add_grad<NT, NE>(g, 0, -dsp, A, RL, B);
+            if (reg_on) reg_grad<NT, NE>(g, A, reg_k, a.reg_type);
+            if (tail) { add_grad<NT, NE>(g, 0, -dsn, A, RL, C); if (reg_on) reg_grad<NT, NE>(g, A, reg_k, a.reg_type); }
+            put(kRoleH, g);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (one output row set at a time: keeps the four computations from being interleaved)
+        {   // tail entity
+            float g[NT][NE]; zero(g);
+            add_grad<NT, NE>(g, 1, -dsp, A, RL, B);
+            if (reg_on) reg_grad<NT, NE>(g, B, reg_k, a.reg_type);
+            if (!tail) { add_grad<NT, NE>(g, 1, -dsn, C, RL, B); if (reg_on) reg_grad<NT, NE>(g, B, reg_k, a.reg_type); }
+            put(kRoleT, g);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (one output row set at a time: keeps the four computations from being interleaved)
+        {   // relation: both triples
+            float g[NT][NE]; zero(g);
+            add_grad<NT, NE>(g, 2, -dsp, A, RL, B);
+            if (reg_on) reg_grad<NT, NE>(g, RL, reg_k, a.reg_type);
+            if (tail) add_grad<NT, NE>(g, 2, -dsn, A, RL, C); else add_grad<NT, NE>(g, 2, -dsn, C, RL, B);
+            if (reg_on) reg_grad<NT, NE>(g, RL, reg_k, a.reg_type);
+            put(kRoleR, g);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (one output row set at a time: keeps the four computations from being interleaved)
+        {   // the drawn entity: the negative only, as its tail (tail corrupted) or head
+            float g[NT][NE]; zero(g);
+            if (tail) add_grad<NT, NE>(g, 1, -dsn, A, RL, C); else add_grad<NT, NE>(g, 0, -dsn, C, RL, B);
+            if (reg_on) reg_grad<NT, NE>(g, C, reg_k, a.reg_type);
+            put(kRoleC, g);
+        }
+    }
+    block_accumulate_loss<G>(acc, gl, loss);
+}
+
 // resident waves per SIMD the register allocation must allow (A/B builds: -DKGE_OWN_WAVES=n)
 #ifndef KGE_OWN_WAVES
 #define KGE_OWN_WAVES 4
 #endif
-template <int NT, int VEC, int G, int NV>
+// OPT >= 0 (staged form only): the owner applies the optimiser to its row set in place as soon as the row's gradient is complete
+// -- safe because a staged owner reads nobody else's parameters -- instead of storing a gradient row for k_own_apply to pick up.
+template <int NT, int VEC, int G, int NV, bool STAGED = false, int OPT = -1>
 __global__ __launch_bounds__(kBlock, KGE_OWN_WAVES) void k_own_step(OwnArgs a, PullSampleArgs sa, float* __restrict__ loss) {
+    static_assert(OPT < 0 || STAGED, "the fused apply needs the staged form");
     constexpr int GPB = kBlock / G;
     constexpr int NE = VEC * NV;
     if ((int)blockIdx.x < a.sample_blocks) {   // leading blocks: the sampler of the NEXT batch rides along (other list set)
@@ -196,17 +321,63 @@ __global__ __launch_bounds__(kBlock, KGE_OWN_WAVES) void k_own_step(OwnArgs a, P
     if (g >= 0) {
         const bool is_rel = g >= a.E;
         const int64_t own = is_rel ? g - a.E : g;
-        // the owner's rows: requested first, they depend on nothing but the item
-        if (is_rel) load_rows_nt<NT, VEC, G, NV>(X, a.rel[0], a.rel[1], own, d, d, gl);
-        else load_rows_nt<NT, VEC, G, NV>(X, a.ent[0], a.ent[1], own, d, d, gl);
+        // the owner's rows: requested first, they depend on nothing but the item (the staged form adds rows and never evaluates)
+        if constexpr (!STAGED) {
+            if (is_rel) load_rows_nt<NT, VEC, G, NV>(X, a.rel[0], a.rel[1], own, d, d, gl);
+            else load_rows_nt<NT, VEC, G, NV>(X, a.ent[0], a.ent[1], own, d, d, gl);
+        }
         int cnt = 0;
         bool fast_c = true;
         const bool walks_c = !is_rel && (kind == 0 || kind == 1 || (kind == 3 && ((it.w >> 2) & 15) == 0));
-        const int nvis = own_visit_list<G>(a.lists, it, g, walks_c, gl, gbase, s_desc[grp], &cnt, &fast_c);
+        int nvis;
+        if constexpr (STAGED) nvis = own_visit_list_dir<G>(a.lists, a.inc, it, g, walks_c, gl, gbase, reinterpret_cast<int*>(s_desc[grp]), &cnt, &fast_c);
+        else nvis = own_visit_list<G>(a.lists, it, g, walks_c, gl, gbase, s_desc[grp], &cnt, &fast_c);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e = 0; e < NE; ++e) gs[t][e] = 0.f;
+        if constexpr (STAGED) {
+            // a visit = (pair << 2 | role): add the NT rows k_own_eval staged for that role of that bundle (slot = role)
+            constexpr int RSE = NE * G;
+            const int* __restrict__ vis = reinterpret_cast<const int*>(s_desc[grp]);
+            auto rows_of = [&](int e, float (&r)[NT][NE]) {
+                const float* st = a.stage + ((int64_t)(e >> 2) * 4 + (e & 3)) * (NT * RSE);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) load_row_e<VEC, G, NV>(r[t], st + t * RSE, d, gl);
+            };
+            constexpr int kBatch = 4;     // visits whose rows are requested before the first is added
+            for (int v0 = 0; v0 < nvis; v0 += kBatch) {
+                float r[kBatch][NT][NE];
+#pragma unroll
+                for (int q = 0; q < kBatch; ++q)
+                    if (v0 + q < nvis) rows_of(vis[v0 + q], r[q]);
+#pragma unroll
+                for (int q = 0; q < kBatch; ++q)
+                    if (v0 + q < nvis) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) gs[t][e] += r[q][t][e];
+                    }
+            }
+            if (cnt > 0 && !fast_c) {   // more drawers than the bucket / the lane group holds: ascending pair order, one at a time
+                const int nb = cnt < kPullCap ? cnt : kPullCap;
+                int last = -1;
+                for (;;) {
+                    int best = 0x7FFFFFFF;
+                    for (int m = 0; m < nb; ++m) { const int j = a.lists.bucket[(int64_t)g * kPullCap + m]; if (j > last && j < best) best = j; }
+                    for (int j = a.lists.head[g]; j >= 0; j = a.lists.next[j]) if (j > last && j < best) best = j;
+                    if (best == 0x7FFFFFFF) break;
+                    float r[NT][NE];
+                    rows_of((best << 2) | kRoleC, r);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) gs[t][e] += r[t][e];
+                    last = best;
+                }
+            }
+        } else {
 
         // One visit = the bundle (P = (h, r, t), N = (h, r, c) | (c, r, t)) seen from the owner's row.  The two triples are
         // independent loss terms, so they are evaluated one after the other with a working set of three row sets (head, relation,
@@ -282,13 +453,17 @@ __global__ __launch_bounds__(kBlock, KGE_OWN_WAVES) void k_own_step(OwnArgs a, P
                 last = best;
             }
         }
+        }   // (owners that re-evaluate)
         if (cnt > 0 && a.reset_lists && gl == 0) {
             a.lists.count[g] = 0;
             if (cnt > kPullCap) a.lists.head[g] = -1;
         }
         if (kind == 0) {
+            if constexpr (OPT >= 0) own_apply_row<OPT, NT, VEC, G, NV>(a, g, gs, true, gl);
+            else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) store_row_e<VEC, G, NV>((is_rel ? a.g_rel[t] : a.g_ent[t]) + own * d, gs[t], d, gl);
+                for (int t = 0; t < NT; ++t) store_row_e<VEC, G, NV>((is_rel ? a.g_rel[t] : a.g_ent[t]) + own * d, gs[t], d, gl);
+            }
         } else if (kind == 3) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -313,8 +488,11 @@ __global__ __launch_bounds__(kBlock, KGE_OWN_WAVES) void k_own_step(OwnArgs a, P
 #pragma unroll
                 for (int e = 0; e < NE; ++e) gs[t][e] += s_part[grp + m][(t * NE + e) * G + gl];
         }
+        if constexpr (OPT >= 0) own_apply_row<OPT, NT, VEC, G, NV>(a, g, gs, true, gl);
+        else {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) store_row_e<VEC, G, NV>((is_rel ? a.g_rel[t] : a.g_ent[t]) + own * d, gs[t], d, gl);
+            for (int t = 0; t < NT; ++t) store_row_e<VEC, G, NV>((is_rel ? a.g_rel[t] : a.g_ent[t]) + own * d, gs[t], d, gl);
+        }
     }
     block_accumulate_loss<G>(acc, gl, loss);
 }
@@ -378,6 +556,7 @@ __global__ __launch_bounds__(kBlock) void k_own_apply(OwnArgs a) {
         g = row.x;
         have_g = true;
     } else {
+        if (a.multi_only) return;
         const int64_t unit = ((int64_t)blockIdx.x - a.n_multi) * GPB + grp;
         if (unit < a.n_items) {
             const int4 it = a.items[unit];
@@ -395,31 +574,7 @@ __global__ __launch_bounds__(kBlock) void k_own_apply(OwnArgs a) {
         }
     }
     if (g < 0) return;
-    const bool is_rel = g >= a.E;
-    const int64_t off = (int64_t)(is_rel ? g - a.E : g) * d;
-    float P[NT][NE], M1[NT][NE], M2[NT][NE];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        load_row_e<VEC, G, NV>(P[t], (is_rel ? a.rel[t] : a.ent[t]) + off, d, gl);
-        if constexpr (OPT != KGE_OPT_SGD) load_row_e<VEC, G, NV>(M1[t], (is_rel ? a.s1_rel[t] : a.s1_ent[t]) + off, d, gl);
-        if constexpr (OPT == KGE_OPT_ADAM) load_row_e<VEC, G, NV>(M2[t], (is_rel ? a.s2_rel[t] : a.s2_ent[t]) + off, d, gl);
-        if (!have_g) load_row_e<VEC, G, NV>(gv[t], (is_rel ? a.g_rel[t] : a.g_ent[t]) + off, d, gl);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            float m1 = 0.f, m2 = 0.f;
-            if constexpr (OPT != KGE_OPT_SGD) m1 = M1[t][e];
-            if constexpr (OPT == KGE_OPT_ADAM) m2 = M2[t][e];
-            opt_update<OPT>(P[t][e], gv[t][e], m1, m2, a.opt);
-            if constexpr (OPT != KGE_OPT_SGD) M1[t][e] = m1;
-            if constexpr (OPT == KGE_OPT_ADAM) M2[t][e] = m2;
-        }
-        store_row_e<VEC, G, NV>(const_cast<float*>(is_rel ? a.rel[t] : a.ent[t]) + off, P[t], d, gl);
-        if constexpr (OPT != KGE_OPT_SGD) store_row_e<VEC, G, NV>((is_rel ? a.s1_rel[t] : a.s1_ent[t]) + off, M1[t], d, gl);
-        if constexpr (OPT == KGE_OPT_ADAM) store_row_e<VEC, G, NV>((is_rel ? a.s2_rel[t] : a.s2_ent[t]) + off, M2[t], d, gl);
-    }
+    own_apply_row<OPT, NT, VEC, G, NV>(a, g, gv, have_g, gl);
 }
 
 // ------------------------------------------------------------------ host side
@@ -477,18 +632,30 @@ int launch_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pai
                     int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int dense, float lmbda, int reg_type,
                     int reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern,
                     const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
-                    float* loss, hipStream_t s) {
+                    float* loss, float* stage, hipStream_t s) {
     OwnArgs a;
     OwnGeo geo;
     if (fill_own_args(m, nullptr, nullptr, &a, &geo, "kge_own_step")) return -1;
+    a.stage = stage; a.multi_only = 0;
     a.pairs = (const int4*)pairs; a.lists = to_lists(lists); a.items = (const int4*)items; a.inc = inc; a.partials = partials;
     a.multi = nullptr; a.n_items = n_items; a.n_multi = 0; a.listed = listed; a.n_pairs = (int)n_pairs; a.dense = dense ? 1 : 0;
     a.reset_lists = reset_lists; a.inv_n = 1.0f / (float)(2 * n_pairs); a.lmbda = lmbda; a.reg_type = reg_type;
     a.opt = make_opt_args(0.f, 1);
-    const PullSampleArgs sa = make_sample_args(next_pairs, next_inv, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
-                                               n_slots, seed, next_offset, nullptr, next_lists);
+    PullSampleArgs sa = make_sample_args(next_pairs, next_inv, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
+                                         n_slots, seed, next_offset, nullptr, next_lists);
     a.sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
     const int64_t units = n_items + own_extra_units(a);
+    if (stage) {   // staged form: evaluate every bundle once, then the owners add the staged rows
+        KGE_OWN_GEO({
+            const int save = a.sample_blocks;
+            a.sample_blocks = 0;
+            hipLaunchKernelGGL((k_own_eval<NT, VEC, G, NV>), dim3((unsigned)((n_pairs + kBlock / G - 1) / (kBlock / G))), dim3(kBlock), 0, s, a, loss);
+            a.sample_blocks = save;
+            const int64_t blocks = (units + kBlock / G - 1) / (kBlock / G) + a.sample_blocks;
+            hipLaunchKernelGGL((k_own_step<NT, VEC, G, NV, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, sa, loss);
+        })
+        return check_launch("k_own_step (staged)");
+    }
     KGE_OWN_GEO({
         const int64_t blocks = (units + kBlock / G - 1) / (kBlock / G) + a.sample_blocks;
         hipLaunchKernelGGL((k_own_step<NT, VEC, G, NV>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, sa, loss);
@@ -496,22 +663,70 @@ int launch_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pai
     return check_launch("k_own_step");
 }
 
+// the staged step with the optimiser fused into the owners (kge_own_run): evaluate every bundle once, then every owner adds its
+// staged rows and updates its row set in place; only rows cut across workgroups are left to k_own_apply (multi_only)
 template <int OPT>
-static int launch_own_apply_opt(OwnArgs& a, OwnGeo geo, hipStream_t s) {
+static int launch_own_fused_opt(OwnArgs& a, OwnGeo geo, PullSampleArgs& sa, int64_t n_pairs, float* loss, hipStream_t s) {
     const int64_t units = a.n_items + own_extra_units(a);
     KGE_OWN_GEO({
+        const int save = a.sample_blocks;
+        a.sample_blocks = 0;
+        hipLaunchKernelGGL((k_own_eval<NT, VEC, G, NV>), dim3((unsigned)((n_pairs + kBlock / G - 1) / (kBlock / G))), dim3(kBlock), 0, s, a, loss);
+        a.sample_blocks = save;
+        const int64_t blocks = (units + kBlock / G - 1) / (kBlock / G) + a.sample_blocks;
+        hipLaunchKernelGGL((k_own_step<NT, VEC, G, NV, true, OPT>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, sa, loss);
+    })
+    return check_launch("k_own_step (staged, fused optimiser)");
+}
+
+int launch_own_step_fused(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
+                          const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* inc,
+                          float* partials, int dense, float lmbda, int reg_type, int optimizer, float lr, int64_t step,
+                          const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern, const uint64_t* slots,
+                          int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists, float* loss,
+                          float* stage, hipStream_t s) {
+    OwnArgs a;
+    OwnGeo geo;
+    if (fill_own_args(m, state1, state2, &a, &geo, "kge_own_run")) return -1;
+    for (int t = 0; t < geo.NT; ++t) {
+        if (optimizer != KGE_OPT_SGD && (!a.s1_ent[t] || !a.s1_rel[t])) { set_error("kge_own_run: optimizer state missing"); return -1; }
+        if (optimizer == KGE_OPT_ADAM && (!a.s2_ent[t] || !a.s2_rel[t])) { set_error("kge_own_run: adam needs two state buffers"); return -1; }
+    }
+    a.stage = stage; a.multi_only = 0;
+    a.pairs = (const int4*)pairs; a.lists = to_lists(lists); a.items = (const int4*)items; a.inc = inc; a.partials = partials;
+    a.multi = nullptr; a.n_items = n_items; a.n_multi = 0; a.listed = listed; a.n_pairs = (int)n_pairs; a.dense = dense ? 1 : 0;
+    a.reset_lists = 1; a.inv_n = 1.0f / (float)(2 * n_pairs); a.lmbda = lmbda; a.reg_type = reg_type;
+    a.opt = make_opt_args(lr, step < 1 ? 1 : step);
+    PullSampleArgs sa = make_sample_args(next_pairs, next_inv, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
+                                         n_slots, seed, next_offset, nullptr, next_lists);
+    a.sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
+    switch (optimizer) {
+        case KGE_OPT_SGD: return launch_own_fused_opt<KGE_OPT_SGD>(a, geo, sa, n_pairs, loss, s);
+        case KGE_OPT_ADAM: return launch_own_fused_opt<KGE_OPT_ADAM>(a, geo, sa, n_pairs, loss, s);
+        case KGE_OPT_ADAGRAD: return launch_own_fused_opt<KGE_OPT_ADAGRAD>(a, geo, sa, n_pairs, loss, s);
+        case KGE_OPT_RMSPROP: return launch_own_fused_opt<KGE_OPT_RMSPROP>(a, geo, sa, n_pairs, loss, s);
+    }
+    set_error("kge_own_run: unknown optimizer %d", optimizer);
+    return -1;
+}
+
+template <int OPT>
+static int launch_own_apply_opt(OwnArgs& a, OwnGeo geo, hipStream_t s) {
+    const int64_t units = a.multi_only ? 0 : a.n_items + own_extra_units(a);
+    KGE_OWN_GEO({
         const int64_t blocks = a.n_multi + (units + kBlock / G - 1) / (kBlock / G);
-        hipLaunchKernelGGL((k_own_apply<OPT, NT, VEC, G, NV>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+        if (blocks > 0) hipLaunchKernelGGL((k_own_apply<OPT, NT, VEC, G, NV>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
     })
     return check_launch("k_own_apply");
 }
 
 int launch_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
                      const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* multi,
-                     int64_t n_multi, float* partials, int dense, int optimizer, float lr, int64_t step, hipStream_t s) {
+                     int64_t n_multi, float* partials, int dense, int optimizer, float lr, int64_t step, int multi_only, hipStream_t s) {
     OwnArgs a;
     OwnGeo geo;
     if (fill_own_args(m, state1, state2, &a, &geo, "kge_own_apply")) return -1;
+    a.multi_only = multi_only;
     const int NT = geo.NT;
     for (int t = 0; t < NT; ++t) {
         if (optimizer != KGE_OPT_SGD && (!a.s1_ent[t] || !a.s1_rel[t])) { set_error("kge_own_apply: optimizer state missing"); return -1; }
@@ -519,7 +734,7 @@ int launch_own_apply(const kge_model_desc* m, float* const* state1, float* const
     }
     a.pairs = (const int4*)pairs; a.lists = to_lists(lists); a.items = (const int4*)items; a.inc = nullptr; a.partials = partials;
     a.multi = (const int4*)multi; a.n_items = n_items; a.n_multi = n_multi; a.listed = listed; a.n_pairs = (int)n_pairs;
-    a.dense = dense ? 1 : 0; a.reset_lists = 0; a.inv_n = 0.f; a.lmbda = 0.f; a.reg_type = 0; a.sample_blocks = 0;
+    a.dense = dense ? 1 : 0; a.reset_lists = 0; a.inv_n = 0.f; a.lmbda = 0.f; a.reg_type = 0; a.sample_blocks = 0; a.stage = nullptr;
     a.opt = make_opt_args(lr, step < 1 ? 1 : step);
     switch (optimizer) {
         case KGE_OPT_SGD: return launch_own_apply_opt<KGE_OPT_SGD>(a, geo, s);

@@ -890,7 +890,8 @@ def _ptr_array(tensors, n=L.KGE_MAX_TABLES):
     return arr
 
 
-def own_step(desc, pairs, lists, items, listed, inc, partials, dense, lmbda, reg_type, loss_buf, reset_lists=True, sample_next=None):
+def own_step(desc, pairs, lists, items, listed, inc, partials, dense, lmbda, reg_type, loss_buf, reset_lists=True, sample_next=None,
+             stage=None):
     """Phase 1 (kge_own_step): gradient rows of every touched parameter row into desc.grads, no atomics."""
     if sample_next is not None:
         npairs, ninv, bern, slots, seed, noff, nlists = sample_next
@@ -902,7 +903,8 @@ def own_step(desc, pairs, lists, items, listed, inc, partials, dense, lmbda, reg
     L.check(L.load().kge_own_step(ctypes.byref(desc), _i32(pairs, "pairs"), pairs.shape[0], ctypes.byref(lists.c), _i32(items, "items"),
                                   items.shape[0], _i32(listed, "listed") if listed is not None else None, _i32(inc, "inc"),
                                   _dev(partials, torch.float32, "partials"), 1 if dense else 0, float(lmbda), int(reg_type),
-                                  1 if reset_lists else 0, *nx, _dev(loss_buf, torch.float32, "loss"), _stream()), "kge_own_step")
+                                  1 if reset_lists else 0, *nx, _dev(loss_buf, torch.float32, "loss"),
+                                  _dev(stage, torch.float32, "stage") if stage is not None else None, _stream()), "kge_own_step")
 
 
 def own_apply(desc, state1, state2, pairs, lists, items, listed, multi, partials, dense, optimizer, lr, step):
@@ -922,8 +924,8 @@ class OwnPlan:
     a whole sequence of steps (two launches each) with ONE foreign call."""
 
     def __init__(self, desc, state1, state2, lists, index, partials, optimizer, lr, lmbda, reg_type, loss_buf, bern, slots, seed,
-                 draws_per_batch):
-        self.keep = (desc, state1, state2, lists, index, partials, loss_buf, bern, slots)
+                 draws_per_batch, stage=None):
+        self.keep = (desc, state1, state2, lists, index, partials, loss_buf, bern, slots, stage)
         c = L.OwnPlanC()
         ctypes.memmove(ctypes.byref(c.model), ctypes.byref(desc), ctypes.sizeof(L.ModelDesc))
         for i, t in enumerate(state1 or ()):
@@ -949,6 +951,7 @@ class OwnPlan:
         c.seed = int(seed) & (2 ** 64 - 1)
         c.draws_per_batch = int(draws_per_batch)
         c.loss = loss_buf.data_ptr()
+        c.stage = stage.data_ptr() if stage is not None else None
         self.c = c
         self.fn = L.load().kge_own_run
 

@@ -199,7 +199,7 @@ class Trainer:
         return {"pull": flag("KGE_PULL"), "staged": flag("KGE_STAGED"), "graph_multi": flag("KGE_GRAPH_MULTI"),
                 "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED"),
                 "rescal_unfused": flag("KGE_RESCAL_UNFUSED"), "pull_dir": flag("KGE_PULL_DIR"),
-                "transx_own": flag("KGE_TRANSX_OWN")}
+                "transx_own": flag("KGE_TRANSX_OWN"), "own_staged": flag("KGE_OWN_STAGED")}
 
     def _init_hot_path(self, process_group=None, backend=None, use_graph=None):
         # `backend` exists so that the multi-process plumbing (batch sharding, gradient collectives, replica
@@ -553,11 +553,17 @@ class Trainer:
             s1 = view(flat.state1) if flat.state1 is not None else None
             s2 = view(flat.state2) if flat.state2 is not None else None
             lists = [K.PullListSet(idx.batch_size, cfg.tot_entity, dev) for _ in range(2)]
-            partials = torch.empty(max(1, idx.max_slots) * K.own_partial_stride(name, self.model.hidden_size), dtype=torch.float32, device=dev)
+            stride = K.own_partial_stride(name, self.model.hidden_size)
+            partials = torch.empty(max(1, idx.max_slots) * stride, dtype=torch.float32, device=dev)
+            # staged form (default; KGE_OWN_STAGED=0: owners re-evaluate): every bundle evaluated once, its gradient rows left in
+            # four slots per bundle for their owners to add
+            staged = self.switches.get("own_staged")
+            stage = torch.empty(4 * idx.batch_size * stride, dtype=torch.float32, device=dev) if (staged is None or staged) else None
             plan = K.OwnPlan(desc, s1, s2, lists, idx, partials, cfg.optimizer, cfg.learning_rate, self.model.kernel_lmbda(),
-                             self.model.kernel_reg_type(), self.loss_buf, gen.bern, gen.slots, gen.seed, idx.batch_size * gen.neg_rate)
+                             self.model.kernel_reg_type(), self.loss_buf, gen.bern, gen.slots, gen.seed, idx.batch_size * gen.neg_rate,
+                             stage=stage)
             st = self._own = dict(index=idx, gbuf=gbuf, desc=desc, s1=s1, s2=s2, lists=lists, partials=partials, plan=plan,
-                                  cur_list=0, ready=None)
+                                  cur_list=0, ready=None, stage=stage)
         return st
 
     def _own_steps(self, n_steps):
@@ -607,9 +613,12 @@ class Trainer:
         view = lambda buf: [buf[o // 4:o // 4 + v.numel()].view_as(v) for o, v in zip(off, flat.views)]
         gviews = view(gbuf)
         desc = K.make_desc(name, flat.views, gviews, tot_entity=cfg.tot_entity, tot_relation=cfg.tot_relation, **self.model.desc_kwargs())
-        partials = torch.empty(max(1, idx.max_slots) * K.own_partial_stride(name, self.model.hidden_size), dtype=torch.float32, device=dev)
+        stride = K.own_partial_stride(name, self.model.hidden_size)
+        partials = torch.empty(max(1, idx.max_slots) * stride, dtype=torch.float32, device=dev)
+        staged = self.switches.get("own_staged")
+        stage = torch.empty(4 * len(pos) * stride, dtype=torch.float32, device=dev) if (staged is None or staged) else None
         K.own_step(desc, pairs, lists, items, idx.skip(0), inc, partials, dense, self.model.kernel_lmbda(), self.model.kernel_reg_type(),
-                   self.loss_buf, reset_lists=False)
+                   self.loss_buf, reset_lists=False, stage=stage)
         flat.step += 1
         K.own_apply(desc, view(flat.state1) if flat.state1 is not None else None, view(flat.state2) if flat.state2 is not None else None,
                     pairs, lists, items, idx.skip(0), multi, partials, dense, cfg.optimizer, cfg.learning_rate, flat.step)
