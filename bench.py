@@ -614,7 +614,13 @@ def main():
                                     "owner-computes gradient (k_pull_step, KGE_OPT_GRADIENT: no atomics) + reduce-scatter + sharded kge_optimizer_step + all-gather + kge_row_norms" if pull_dp else
                                     "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step"},
             "roofline": {"kernel": kernel_label, "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "frac_note": ("`achieved` divides the ALGORITHMIC bytes of SURVEY section 8(d) (forward gathers + gradient read-modify-"
+                                       "write + ids per scored triple: 3628 B) by the measured duration.  The owner-computes step performs no "
+                                       "gradient read-modify-write and evaluates every pair once, so this nominal figure can exceed 1; the "
+                                       "bytes that actually cross the fabric are `traffic` (PMC), i.e. `traffic_frac` of the HBM peak"),
+                         "traffic_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_note": ("2 x FETCH_SIZE (gfx950: 16-byte-per-lane reads are tallied at half) + WRITE_SIZE" if pull else "FETCH_SIZE + WRITE_SIZE, raw"), "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_ms,
                          "avg_launch_ms_method": ("HIP events on the launch stream around the timed region / steps (%s per step; "
