@@ -187,7 +187,7 @@ int kge_optimizer_step_rows(int32_t kind, float* param, float* grad, float* stat
  * their positives' relation ids (every sampler of the reference: data/generator.py:143-196 corrupts heads and tails only):
  * pairs are grouped by relation and each (relation, 16 pairs) tile computes scores, hinge and the three gradients in one
  * workgroup.  kge_train_pairwise_hinge takes this path by itself when called with nr == pr (the same buffer).
- * hidden size: a multiple of 4, at most 256 (kge_rescal_pair_step_ok).  workspace: kge_workspace_bytes(m, n) bytes.
+ * hidden size: even, at most 256 (kge_rescal_pair_step_ok).  workspace: kge_workspace_bytes(m, n) bytes.
  * touched_rows (may be NULL): entity rows that received a gradient get their bit set (see kge_optimizer_step_rows). */
 int kge_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
                          const int64_t* nt, int64_t n, float margin, void* workspace, size_t workspace_bytes, float* loss,

@@ -377,7 +377,7 @@ int kge_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64
     if (n == 0) return 0;
     if (n < 0 || !ph || !pr || !pt || !nh || !nt || !loss || !workspace) { set_error("kge_rescal_pair_step: bad arguments"); return -1; }
     if (!rescal_pair_step_ok(m, n, workspace_bytes)) {
-        set_error("kge_rescal_pair_step: hidden size %d (needs a multiple of 4, at most 256) or workspace (kge_workspace_bytes)", m->dim);
+        set_error("kge_rescal_pair_step: hidden size %d (needs an even size, at most 256) or workspace (kge_workspace_bytes)", m->dim);
         return -1;
     }
     return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, workspace, workspace_bytes, touched_rows, (hipStream_t)stream);

@@ -565,11 +565,19 @@ int launch_rescal_normalize(float* ent, int64_t E, float* rel, int64_t R, int k,
 // dependent loads (tile lookup, ids, rows, matrix operands) that costs more than its arithmetic at the reference's batch sizes
 // -- become one chain.  16 waves: (column tile, K half) units for V = H M and U = T M^T, every operand of a unit's MFMA steps
 // loaded before the first step (one round trip), the two K halves added through LDS in a fixed order; G = (ds H)^T T from LDS.
-// Entity gradients and the relation-matrix gradient leave through float atomics as in k_rescal.  k % 4 == 0, k <= 256.
+// Entity gradients and the relation-matrix gradient leave through float atomics as in k_rescal.  k even (rows move as float4 when
+// k % 4 == 0, as float2 otherwise: the reference's default k = 50), k <= 256.
+// VK consecutive floats of a row as one load (VK = 4: hidden size % 4 == 0; VK = 2: any even hidden size, e.g. the reference's k = 50)
+template <int VK>
+__device__ __forceinline__ void ldv(float (&o)[VK], const float* __restrict__ p) {
+    if constexpr (VK == 4) { const float4 q = *reinterpret_cast<const float4*>(p); o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; }
+    else { const float2 q = *reinterpret_cast<const float2*>(p); o[0] = q.x; o[1] = q.y; }
+}
 constexpr int kPairTile = 16;      // pairs per workgroup
 constexpr int kPairSteps = 52;     // V: MFMA steps (two k each) of operand loads in flight per wave
-constexpr int kPairQuads = 13;     // U: float4 operand loads (eight k each over the two lane halves) in flight per wave
+constexpr int kPairUK = 104;       // U: k covered by the operand loads one wave keeps in flight (13 float4 or 26 float2 per lane)
 
+template <int VK>
 __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ ent, const float* __restrict__ relm,
                                                       float* __restrict__ g_ent, float* __restrict__ g_rel,
                                                       const int64_t* __restrict__ ph, const int64_t* __restrict__ pt,
@@ -607,34 +615,33 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
     }
     if (threadIdx.x < 8 * TILE) sPs[threadIdx.x] = 0.f;
     __syncthreads();
-    {   // row gathers into LDS: 16 bytes per load, every load of a thread issued before its first LDS store
-        const int nv = k >> 2;
-        constexpr int kMaxPer = 2;                   // TILE * nv / 1024 float4 per thread and matrix (k <= 256)
-        float4 rt[kMaxPer], rh[kMaxPer];
+    {   // row gathers into LDS: VK floats per load, every load of a thread issued before its first LDS store
+        const int nv = k / VK;
+        constexpr int kMaxPer = 8 / VK;              // TILE * nv / 1024 loads per thread and matrix (k <= 256)
+        float rt[kMaxPer][VK], rh[kMaxPer][VK];
 #pragma unroll
         for (int j = 0; j < kMaxPer; ++j) {
             const int idx = threadIdx.x + 1024 * j;
             const int i = idx / nv, c = idx - i * nv;
             const bool ok = idx < TILE * nv && (i & (kPairTile - 1)) < cnt;
-            rt[j] = ok ? reinterpret_cast<const float4*>(ent + sTid[i] * k)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            rh[j] = ok ? reinterpret_cast<const float4*>(ent + sHid[i] * k)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < VK; ++q) { rt[j][q] = 0.f; rh[j][q] = 0.f; }
+            if (ok) { ldv<VK>(rt[j], ent + sTid[i] * k + c * VK); ldv<VK>(rh[j], ent + sHid[i] * k + c * VK); }
         }
 #pragma unroll
         for (int j = 0; j < kMaxPer; ++j) {
             const int idx = threadIdx.x + 1024 * j;
             if (idx < TILE * nv) {
-                const int i = idx / nv, c = (idx - i * nv) * 4;
-                float* dt = sT + i * S + c;
-                float* dh = sH + i * S + c;
-                dt[0] = rt[j].x; dt[1] = rt[j].y; dt[2] = rt[j].z; dt[3] = rt[j].w;
-                dh[0] = rh[j].x; dh[1] = rh[j].y; dh[2] = rh[j].z; dh[3] = rh[j].w;
+                const int i = idx / nv, c = (idx - i * nv) * VK;
+#pragma unroll
+                for (int q = 0; q < VK; ++q) { sT[i * S + c + q] = rt[j][q]; sH[i * S + c + q] = rh[j][q]; }
             }
         }
     }
     __syncthreads();
     const float* M = relm + (int64_t)rel * k * k;
     const int ntile = (k + 31) / 32;           // <= 8
-    const int khalf = ((k + 15) / 16) * 8;     // K span of one wave: a multiple of eight
+    const int khalf = ((k + 4 * VK - 1) / (4 * VK)) * (2 * VK);     // K span of one wave: a multiple of 2 VK
     const int u = wave >> 1, ks = wave & 1;    // unit: column tile u, K half ks
     const bool live = u < ntile;
     const int k_lo = ks * khalf, k_hi = min(k, k_lo + khalf);
@@ -721,26 +728,27 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
             }
         }
     }
-    // ---- U[i][a] = sum_b T[i][b] M[a][b]: lane a reads its row of M sixteen bytes at a time; the four values of a load feed four
-    // MFMA steps (lane half 0 carries k = kb .. kb+3, half 1 carries kb+4 .. kb+7: the k order inside a step is free)
+    // ---- U[i][a] = sum_b T[i][b] M[a][b]: lane a reads its row of M VK floats at a time; the VK values of a load feed VK MFMA
+    // steps (lane half 0 carries k = kb .. kb+VK-1, half 1 the next VK: the k order inside a step is free)
     f32x16 ua = {0};
     if (live) {
-        for (int kc = k_lo; kc < k_hi; kc += 8 * kPairQuads) {
-            float4 mv[kPairQuads];
+        constexpr int kQ = kPairUK / (2 * VK);       // loads per lane and chunk
+        for (int kc = k_lo; kc < k_hi; kc += kPairUK) {
+            float mv[kQ][VK];
 #pragma unroll
-            for (int j = 0; j < kPairQuads; ++j) {
-                const int kb = kc + 8 * j + 4 * lk;
-                mv[j] = (kb < k_hi && col < k) ? *reinterpret_cast<const float4*>(M + (int64_t)col * k + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < kQ; ++j) {
+                const int kb = kc + 2 * VK * j + VK * lk;
+#pragma unroll
+                for (int q = 0; q < VK; ++q) mv[j][q] = 0.f;
+                if (kb < k_hi && col < k) ldv<VK>(mv[j], M + (int64_t)col * k + kb);
             }
 #pragma unroll
-            for (int j = 0; j < kPairQuads; ++j) {
-                const int kb = kc + 8 * j + 4 * lk;
+            for (int j = 0; j < kQ; ++j) {
+                const int kb = kc + 2 * VK * j + VK * lk;
                 const bool on = kb < k_hi;
                 const float* tr = sT + li * S + kb;
-                ua = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? tr[0] : 0.f, mv[j].x, ua, 0, 0, 0);
-                ua = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? tr[1] : 0.f, mv[j].y, ua, 0, 0, 0);
-                ua = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? tr[2] : 0.f, mv[j].z, ua, 0, 0, 0);
-                ua = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? tr[3] : 0.f, mv[j].w, ua, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < VK; ++q) ua = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? tr[q] : 0.f, mv[j][q], ua, 0, 0, 0);
             }
         }
         if (ks == 1) {
@@ -798,6 +806,7 @@ __global__ __launch_bounds__(1024) void k_rescal_pair(const float* __restrict__ 
 // tiles in registers across the run, so the rows are read once per run and a relation of at most one run is written with k^2
 // plain read-modify-writes; longer relations add atomically, once per run.
 constexpr int kPairGmRun = 8;
+template <int VK>
 __global__ __launch_bounds__(1024) void k_rescal_pair_gm(const float* __restrict__ ent, float* __restrict__ g_rel,
                                                         const int64_t* __restrict__ ph, const int64_t* __restrict__ pt,
                                                         const int64_t* __restrict__ nh, const int64_t* __restrict__ nt,
@@ -824,7 +833,7 @@ __global__ __launch_bounds__(1024) void k_rescal_pair_gm(const float* __restrict
     f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x16{0};
-    const int nv = k >> 2;
+    const int nv = k / VK;
     for (int g0 = g_lo; g0 < g_hi; g0 += kPairTile) {
         __syncthreads();
         if (threadIdx.x < TILE) {
@@ -837,26 +846,25 @@ __global__ __launch_bounds__(1024) void k_rescal_pair_gm(const float* __restrict
             sDs[threadIdx.x] = neg ? -c : c;
         }
         __syncthreads();
-        constexpr int kMaxPer = 2;                   // TILE * nv / 1024 float4 per thread and matrix (k <= 256)
-        float4 rt[kMaxPer], rh[kMaxPer];
+        constexpr int kMaxPer = 8 / VK;              // TILE * nv / 1024 loads per thread and matrix (k <= 256)
+        float rt[kMaxPer][VK], rh[kMaxPer][VK];
 #pragma unroll
         for (int j = 0; j < kMaxPer; ++j) {
             const int idx = threadIdx.x + 1024 * j;
             const int i = idx / nv, c = idx - i * nv;
             const bool ok = idx < TILE * nv && sDs[i] != 0.f;
-            rt[j] = ok ? reinterpret_cast<const float4*>(ent + sTid[i] * k)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            rh[j] = ok ? reinterpret_cast<const float4*>(ent + sHid[i] * k)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < VK; ++q) { rt[j][q] = 0.f; rh[j][q] = 0.f; }
+            if (ok) { ldv<VK>(rt[j], ent + sTid[i] * k + c * VK); ldv<VK>(rh[j], ent + sHid[i] * k + c * VK); }
         }
 #pragma unroll
         for (int j = 0; j < kMaxPer; ++j) {
             const int idx = threadIdx.x + 1024 * j;
             if (idx < TILE * nv) {
-                const int i = idx / nv, c = (idx - i * nv) * 4;
+                const int i = idx / nv, c = (idx - i * nv) * VK;
                 const float d = sDs[i];
-                float* dt = sT + i * S + c;
-                float* dh = sH + i * S + c;
-                dt[0] = rt[j].x; dt[1] = rt[j].y; dt[2] = rt[j].z; dt[3] = rt[j].w;
-                dh[0] = d * rh[j].x; dh[1] = d * rh[j].y; dh[2] = d * rh[j].z; dh[3] = d * rh[j].w;
+#pragma unroll
+                for (int q = 0; q < VK; ++q) { sT[i * S + c + q] = rt[j][q]; sH[i * S + c + q] = d * rh[j][q]; }
             }
         }
         __syncthreads();
@@ -908,7 +916,7 @@ static size_t rescal_pair_ws_bytes(int64_t R, int64_t n) {
 }
 
 bool rescal_pair_step_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
-    return m->dim % 4 == 0 && m->dim <= 256 && n < (1ll << 31) && ws_bytes >= rescal_pair_ws_bytes(m->tot_relation, n);
+    return m->dim % 2 == 0 && m->dim <= 256 && n < (1ll << 31) && ws_bytes >= rescal_pair_ws_bytes(m->tot_relation, n);
 }
 
 // negatives share pr (the caller passed nr == pr); ws: the pairwise step's scorer workspace
@@ -924,19 +932,24 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
     const size_t lds = rescal_pair_lds_bytes(k);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_rescal_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        (void)hipFuncSetAttribute((const void*)k_rescal_pair<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        (void)hipFuncSetAttribute((const void*)k_rescal_pair<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         attr_set = true;
     }
     const unsigned tiles = (unsigned)(n / kPairTile + R + 1);
     float* ds = n >= kPairSplitG ? (float*)(g.tile_rel + tiles) : nullptr;
-    hipLaunchKernelGGL(k_rescal_pair, dim3(tiles), dim3(1024), lds, s, m->tables[0], m->tables[1], m->grads[0],
-                       m->grads[1], ph, pt, nh, nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched, ds);
-    if (ds) {
-        const int S = (k + 1) | 1;
-        const size_t lds_gm = (size_t)(2 * TILE * S + TILE) * sizeof(float) + (size_t)2 * TILE * sizeof(long long);
-        hipLaunchKernelGGL(k_rescal_pair_gm, dim3(tiles), dim3(1024), lds_gm, s, m->tables[0], m->grads[1], ph, pt, nh, nt, g.offsets,
-                           g.tile_off, g.tile_rel, g.perm, (int)R, k, ds);
+    const int S = (k + 1) | 1;
+    const size_t lds_gm = (size_t)(2 * TILE * S + TILE) * sizeof(float) + (size_t)2 * TILE * sizeof(long long);
+#define KGE_RP(VK_)                                                                                                              \
+    {                                                                                                                            \
+        hipLaunchKernelGGL(k_rescal_pair<VK_>, dim3(tiles), dim3(1024), lds, s, m->tables[0], m->tables[1], m->grads[0], m->grads[1], ph, pt, \
+                           nh, nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched, ds);              \
+        if (ds)                                                                                                                  \
+            hipLaunchKernelGGL(k_rescal_pair_gm<VK_>, dim3(tiles), dim3(1024), lds_gm, s, m->tables[0], m->grads[1], ph, pt, nh, nt, g.offsets, \
+                               g.tile_off, g.tile_rel, g.perm, (int)R, k, ds);                                                   \
     }
+    if ((k & 3) == 0) KGE_RP(4) else KGE_RP(2)
+#undef KGE_RP
     return check_launch("k_rescal_pair");
 }
 

@@ -328,6 +328,8 @@ def test_scores_loss_grads_vs_oracle_other_shapes(hip, model, hp, neg_rate):
 
 @pytest.mark.parametrize("k,E,R,B,margin", [(200, 300, 11, 160, 1.0), (64, 300, 3, 333, 1.0), (256, 50, 1, 40, 2.0), (4, 300, 40, 160, 1.0),
                                               (200, 3000, 400, 1024, 0.5), (120, 300, 11, 160, 0.02), (36, 9, 2, 1, 1.0),
+                                              (50, 300, 11, 160, 1.0), (6, 40, 3, 70, 1.0), (250, 30, 2, 33, 1.0),      # k % 4 != 0: rows as float2
+                                              (50, 3000, 400, 9000, 1.0),
                                               # >= 8192 pairs: dL/denergy left behind, relation-matrix gradient by the relation-owner
                                               # launch (k_rescal_pair_gm); > 16384: the block-aggregated grouping kernels
                                               (64, 3000, 5, 9000, 1.0), (32, 5000, 7, 20000, 1.0), (32, 5000, 700, 20000, 1.0)])
