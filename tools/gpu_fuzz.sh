@@ -9,3 +9,4 @@ ITERS=${FUZZ_PARITY:-160} SEED=77 timeout 600 python tools/fuzz_parity.py > gpur
 ITERS=${FUZZ_GRAPH:-84} SEED=9 timeout 600 python tools/fuzz_graph.py > gpurun_out/fuzz_graph.log 2>&1; echo "fuzz_graph rc=$?"; tail -2 gpurun_out/fuzz_graph.log
 ITERS=${FUZZ_PULL:-64} SEED=3 timeout 600 python tools/fuzz_pull.py > gpurun_out/fuzz_pull.log 2>&1; echo "fuzz_pull rc=$?"; tail -4 gpurun_out/fuzz_pull.log
 ITERS=${FUZZ_STAGED:-60} SEED=21 timeout 600 python tools/fuzz_staged.py > gpurun_out/fuzz_staged.log 2>&1; echo "fuzz_staged rc=$?"; tail -6 gpurun_out/fuzz_staged.log
+ITERS=${FUZZ_OWN:-96} SEED=5 timeout 900 python tools/fuzz_own.py > gpurun_out/fuzz_own.log 2>&1; echo "fuzz_own rc=$?"; tail -6 gpurun_out/fuzz_own.log
