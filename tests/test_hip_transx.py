@@ -23,6 +23,7 @@ SHAPES = [("transh", dict(hidden_size=100, l1_flag=True), 300, 11, 160),
           ("transh", dict(hidden_size=200, l1_flag=True), 50, 2, 2000),      # two relations with ~1000 incidences: rows cut into
                                                                             # items across workgroups (partials + finishing launch)
           ("transh", dict(hidden_size=36, l1_flag=False), 9, 3, 700),         # 9 entities: bucket overflow chains
+          ("transh", dict(hidden_size=232, l1_flag=True), 21, 33, 943),       # 135 incidences per entity: overflow chains on every row
           ("transd", dict(ent_hidden_size=64, rel_hidden_size=64, l1_flag=False), 300, 11, 160),
           ("transd", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=True), 3000, 40, 4096),
           ("transd", dict(ent_hidden_size=260, rel_hidden_size=260, l1_flag=True), 40, 2, 600)]
@@ -102,7 +103,9 @@ def test_transx_epochs_equal_push_epochs(hip, monkeypatch, model, E, R, D, B, op
         bad = ~np.isclose(a, b, atol=2e-5, rtol=1e-4)
         # (the atomic path sums in arbitrary order: under Adam / Adagrad a rounding-residue gradient becomes a +-lr first step;
         # the fraction of such entries varies from run to run around 2e-3 for the w table of the FB15k-shape case)
-        lim = 0.0 if opt == "sgd" else 5e-3
+        # (L1 distances under SGD: a residual element at rounding distance from zero can take either sign on the two paths -- their
+        # group reductions add in different orders -- which moves isolated parameter elements by ~lr)
+        lim = (1e-3 if l1 else 0.0) if opt == "sgd" else 5e-3
         assert bad.mean() <= lim, (opt, k, bad.mean(), np.abs(a - b).max())
 
 
