@@ -178,7 +178,7 @@ class Trainer:
     GRAPH_MAX_ROWS = 16384  # steps scoring at most this many triples are launch-bound: replay them as one hipGraph
     PULL_INDEX_BUDGET = 256 << 20   # bytes of per-batch incidence index the owner-computes path may build (see _pull_ok)
     GRAPH_UNROLL = 8        # steps per replayed multi-step graph (even; 0 = single-step graphs only)
-    PULL_TWO_PHASE_MIN_BATCH = 16384   # owner-computes step in two launches (each pair evaluated once) from this batch size on
+    PULL_TWO_PHASE_MIN_BATCH = 8192    # owner-computes step in two launches (each pair evaluated once) from this batch size on
 
     def __init__(self, model, config, process_group=None, backend=None, use_graph=None):
         self.model = model
@@ -436,7 +436,8 @@ class Trainer:
         if self.switches.get("pull_dir") is not None:
             return self.switches["pull_dir"]
         # measured (profiles/r03_experiments.md section 11): L1, B = 32768: 35.0 -> 30.3 us per step (TransM 47.4 -> 44.9);
-        # B = 4096: 19.1 -> 20.4, B = 128: 13.0 -> 15.6 (a second launch costs more than the re-evaluations it saves);
+        # B = 16384: 31.5 -> 30.8, B = 8192: 27.3 -> 23.7, B = 4096: 19.1 -> 20.4, B = 128: 13.0 -> 15.6 (a second launch costs
+        # more than the re-evaluations it saves);
         # L2: 46.3 -> 53.6 (the direction of an L2 residual is a float row, 1 KB per pair, not 2 bits per element)
         return bool(getattr(self.model, "l1_flag", False)) and int(self.config.batch_size) >= self.PULL_TWO_PHASE_MIN_BATCH
 

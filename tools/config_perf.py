@@ -13,6 +13,8 @@ CONFIGS = [
     ("C0 TransE UMLS d=50 B=128 adam", "transe", "umls", dict(hidden_size=50, l1_flag=True, margin=0.8), "adam", 128, 1, 661),
     ("C1 TransE FB15k d=100 B=128 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 128, 1, 0),
     ("C1 TransE FB15k d=100 B=4096 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 4096, 1, 0),
+    ("C1 TransE FB15k d=100 B=8192 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 8192, 1, 0),
+    ("C1 TransE FB15k d=100 B=16384 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 16384, 1, 0),
     ("C1 TransE FB15k d=100 B=32768 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 8192),
     ("C1 TransE-L2 FB15k d=100 B=32768 sgd", "transe", "fb15k", dict(hidden_size=100, l1_flag=False, margin=1.0), "sgd", 32768, 1, 8192),
     ("TransH FB15k d=100 B=32768 adam", "transh", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 2048),
