@@ -524,15 +524,10 @@ class Trainer:
             return self.switches["pw_pull"]
         if self.switches["staged"] is not None:    # an explicit KGE_STAGED=0 / 1 asks for the atomic / staged A/B pair
             return False
-        # Measured against the atomic-scatter step (profiles/r03_own_vs_atomic.md): the two-phase step wins beyond the hipGraph
-        # regime (DistMult FB15k B = 32768: 70 vs 98 us) and wherever a batch touches the tables sparsely (C2: 72 vs 113 us;
-        # YAGO3-10 shape B = 8192: 94 vs 152 us); the graph-replayed atomic step keeps the small dense batches (DistMult FB15k
-        # B = 4096: 32 vs 38 us) and the launch-bound B = 128 presets.
-        from .generator import PullIndex
-        B = int(self.config.batch_size)
-        rows = B * (1 + int(self.config.neg_rate))
-        sparse = PullIndex._compact_rule(B, int(self.config.tot_entity) + int(self.config.tot_relation))
-        return rows > self.GRAPH_MAX_ROWS or (sparse and B >= 1024)
+        # Measured against the (hipGraph-replayed) atomic-scatter step with the staged form (profiles/r03_experiments.md section 14):
+        # it wins at every batch size and optimiser tried -- DistMult FB15k B = 128 / 1024 / 4096 / 8192 / 32768: 16.8 / 19.7 / 32.4
+        # / 50.2 / 70 -> 14.3 / 17.6 / 23.6 / 29.8 / 57.6 us; ComplEx WN18RR B = 128 Adagrad 39.9 -> 16.1, Adam 94.5 -> 70.3 us.
+        return True
 
     def _own_dense(self):
         return self.config.optimizer in ("adam", "rms")   # optimisers that move every row every step
@@ -626,7 +621,7 @@ class Trainer:
         return gviews
 
     # ------------------------------------------------------------------ TransH / TransD: gradients without float atomics
-    TRANSX_OWN_MIN_BATCH = 16384
+    TRANSX_OWN_MIN_BATCH = 1
 
     def _transx_ok(self):
         """TransH / TransD hinge step with neg_rate 1 on one GPU at large batches: every pair evaluated once with its gradient
@@ -641,6 +636,9 @@ class Trainer:
             return False
         if self.switches.get("transx_own") is not None:
             return self.switches["transx_own"]
+        # measured against the hipGraph-replayed atomic step at FB15k shape (profiles/r03_experiments.md section 14): TransH B = 128 /
+        # 1024 / 4096 / 8192 / 32768: 27.3 / 29.0 / 31.2 / 36.8 / 80 -> 19.8 / 22.5 / 27.9 / 35.4 / 64 us; TransD 1024 / 4096 / 8192 /
+        # 32768: 40.0 / 42.6 / 51.5 / 117 -> 30.1 / 35.7 / 43.4 / 84 us
         return int(self.config.batch_size) >= self.TRANSX_OWN_MIN_BATCH
 
     def _transx_state(self):
@@ -908,9 +906,7 @@ class Trainer:
             return False
         if self.switches["staged"] and self._staged_ok():   # the staged step is an eager two-launch step
             return False
-        if self.generator is not None and self._transx_ok():   # an eager three-launch step
-            return False
-        if self.use_graph is None and self.generator is not None and (self._pull_ok() or self._own_ok()):   # one native call per epoch beats a replay per step
+        if self.use_graph is None and self.generator is not None and (self._pull_ok() or self._own_ok() or self._transx_ok()):   # one native call per epoch beats a replay per step
             return False
         if self.distributed:
             # RCCL collectives are capturable (gloo is not); multi-rank capture is opt-in (use_graph=True or

@@ -17,6 +17,24 @@ CONFIGS = [
     ("C1 TransE FB15k d=100 B=16384 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 16384, 1, 0),
     ("C1 TransE FB15k d=100 B=32768 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 8192),
     ("C1 TransE-L2 FB15k d=100 B=32768 sgd", "transe", "fb15k", dict(hidden_size=100, l1_flag=False, margin=1.0), "sgd", 32768, 1, 8192),
+    ("TransH FB15k d=100 B=8192 adam", "transh", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 8192, 1, 0),
+    ("TransD FB15k d=100 B=8192 adam", "transd", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=True, margin=1.0), "adam", 8192, 1, 0),
+    ("DistMult FB15k d=100 B=128 adam", "distmult", "fb15k", dict(hidden_size=100, lmbda=1e-4), "adam", 128, 1, 0),
+    ("ComplEx WN18RR d=200 B=128 adam", "complex", "wn18rr", dict(hidden_size=200, lmbda=1e-4), "adam", 128, 1, 0),
+    ("ComplEx WN18RR d=200 B=1024 adam", "complex", "wn18rr", dict(hidden_size=200, lmbda=1e-4), "adam", 1024, 1, 0),
+    ("DistMult FB15k d=100 B=128 adagrad", "distmult", "fb15k", dict(hidden_size=100, lmbda=1e-4), "adagrad", 128, 1, 0),
+    ("ComplEx WN18RR d=200 B=128 adagrad", "complex", "wn18rr", dict(hidden_size=200, lmbda=1e-4), "adagrad", 128, 1, 0),
+    ("ComplEx WN18RR d=200 B=512 adagrad", "complex", "wn18rr", dict(hidden_size=200, lmbda=1e-4), "adagrad", 512, 1, 0),
+    ("TransH FB15k d=100 B=128 adam", "transh", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 128, 1, 0),
+    ("TransH FB15k d=100 B=1024 adam", "transh", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 1024, 1, 0),
+    ("TransD FB15k d=100 B=1024 adam", "transd", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=True, margin=1.0), "adam", 1024, 1, 0),
+    ("DistMult FB15k d=100 B=1024 adagrad", "distmult", "fb15k", dict(hidden_size=100, lmbda=1e-4), "adagrad", 1024, 1, 0),
+    ("DistMult FB15k d=100 B=4096 adagrad", "distmult", "fb15k", dict(hidden_size=100, lmbda=1e-4), "adagrad", 4096, 1, 0),
+    ("ComplEx FB15k d=200 B=4096 adagrad", "complex", "fb15k", dict(hidden_size=200, lmbda=1e-4), "adagrad", 4096, 1, 0),
+    ("ComplEx FB15k d=200 B=4096 adam", "complex", "fb15k", dict(hidden_size=200, lmbda=1e-4), "adam", 4096, 1, 0),
+    ("TransH FB15k d=100 B=4096 adam", "transh", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 4096, 1, 0),
+    ("TransD FB15k d=100 B=4096 adam", "transd", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=True, margin=1.0), "adam", 4096, 1, 0),
+    ("DistMult FB15k d=100 B=8192 adagrad", "distmult", "fb15k", dict(hidden_size=100, lmbda=1e-4), "adagrad", 8192, 1, 0),
     ("TransH FB15k d=100 B=32768 adam", "transh", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 2048),
     ("TransD FB15k d=100 B=32768 adam", "transd", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 2048),
     ("DistMult FB15k d=100 B=32768 adagrad", "distmult", "fb15k", dict(hidden_size=100, lmbda=1e-4), "adagrad", 32768, 1, 8192),

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round 3, call Z: where does the two-launch TransE step start to pay?  (B = 8192 / 16384; TransH / DistMult at 8192 for their rules)
+# Round 3, call Z5: the pointwise owner-computes step under a DENSE optimiser (Adam) at small batches
 ulimit -c 0
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 run() { ONLY="$1" timeout 200 python tools/config_perf.py 2>&1 | tail -1 | cut -c1-100; }
-for dir in 0 1; do echo "== KGE_PULL_DIR=$dir"; KGE_PULL_DIR=$dir run "C1 TransE FB15k d=100 B=8192"; KGE_PULL_DIR=$dir run "C1 TransE FB15k d=100 B=16384"; done | tee gpurun_out/z3_ab.log
+for v in 0 1; do echo "== KGE_PW_PULL=$v"; for c in "DistMult FB15k d=100 B=128 adam" "ComplEx WN18RR d=200 B=128 adam" "ComplEx WN18RR d=200 B=1024 adam"; do KGE_PW_PULL=$v run "$c"; done; done | tee gpurun_out/z3_ab5.log
