@@ -469,6 +469,7 @@ int kge_transx_run(const kge_transx_plan* plan, int64_t first_batch, int64_t n_s
  * instead of re-evaluating each bundle they occur in.  Outputs, kge_own_apply and all semantics are unchanged. */
 int kge_own_groups_per_block(int32_t model, int32_t dim);
 int kge_own_partial_stride(int32_t model, int32_t dim);
+size_t kge_own_stage_bytes(int32_t model, int32_t dim, int64_t n_pairs);   /* the staged form's buffer */
 int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists, const int32_t* items,
                  int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int32_t dense, float lmbda,
                  int32_t reg_type, int32_t reset_lists, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n,
@@ -478,7 +479,11 @@ int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs,
 int kge_own_apply(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
                   const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* multi,
                   int64_t n_multi, float* partials, int32_t dense, int32_t optimizer, float lr, int64_t step, void* stream);
-/* A run of consecutive steps enqueued by ONE native call (two launches per step, no host work in between). */
+/* A run of consecutive steps enqueued by ONE native call (two launches per step, no host work in between).
+ * kge_own_run also takes ANALOGY, CP, SimplE, SimplE_ignr and QuatE (pointwise.py:241-387,461-768; hidden size <= 256; `stage`
+ * required): csrc/kge_ownx.hip evaluates every triple once with the scorer's own forward / backward, stages one gradient row per role,
+ * and the owner of an entity / relation adds the rows sourced from its id into one accumulator per table it holds, then applies the
+ * optimiser in place. */
 typedef struct kge_own_plan {
     kge_model_desc model;                 /* tables = the parameters (updated in place); grads = the gradient row buffers */
     float* state1[KGE_MAX_TABLES];        /* optimiser state per table (NULL where unused) */

@@ -607,8 +607,13 @@ int kge_transx_run(const kge_transx_plan* p, int64_t first_batch, int64_t n_step
 }
 
 /* ---- two-phase owner-computes step of the pointwise models, kge_own.hip */
-int kge_own_groups_per_block(int32_t model, int32_t dim) { return own_groups_per_block(model, dim); }
-int kge_own_partial_stride(int32_t model, int32_t dim) { return own_partial_stride(model, dim); }
+int kge_own_groups_per_block(int32_t model, int32_t dim) { return ownx_model(model) ? ownx_groups_per_block(model, dim) : own_groups_per_block(model, dim); }
+int kge_own_partial_stride(int32_t model, int32_t dim) { return ownx_model(model) ? ownx_partial_stride(model, dim) : own_partial_stride(model, dim); }
+size_t kge_own_stage_bytes(int32_t model, int32_t dim, int64_t n_pairs) {
+    if (n_pairs < 0) return 0;
+    if (ownx_model(model)) return ownx_stage_floats(model, dim, n_pairs) * sizeof(float);
+    return (size_t)4 * (size_t)n_pairs * (size_t)own_partial_stride(model, dim) * sizeof(float);
+}
 
 int kge_own_step(const kge_model_desc* m, const int32_t* pairs, int64_t n_pairs, const kge_pull_lists* lists, const int32_t* items,
                  int64_t n_items, const uint32_t* listed, const int32_t* inc, float* partials, int32_t dense, float lmbda,
@@ -670,7 +675,15 @@ int kge_own_run(const kge_own_plan* p, int64_t first_batch, int64_t n_steps, int
         const bool wrap = last && sample_after_last == 2;
         const bool has_next = wrap || ((!last || sample_after_last == 1) && first_batch + k + 1 < p->n_batches);
         const kge_pull_batch* nb = wrap ? p->batches : (has_next ? b + 1 : nullptr);
-        if (p->stage) {
+        if (ownx_model(p->model.model)) {
+            // ANALOGY / CP / SimplE / QuatE: the model-generic staged step (kge_ownx.hip)
+            rc = launch_ownx_step(&p->model, p->state1, p->state2, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items, b->dense_skip,
+                                  b->inc, p->partials, b->multi, b->n_multi, dense, p->lmbda, p->reg_type, p->optimizer, p->lr,
+                                  first_opt_step + k, nb ? nb->pairs : nullptr, nb ? nb->inv : nullptr, nb ? nb->n_pairs : 0, p->bern_prob,
+                                  p->slots, p->n_slots, p->seed, offset + (uint64_t)p->draws_per_batch, nb ? &p->lists[1 - cl] : nullptr,
+                                  p->loss, p->stage, (hipStream_t)stream);
+            if (rc) return rc;
+        } else if (p->stage) {
             // staged form: the owners apply the optimiser themselves; only rows cut across workgroups go through k_own_apply
             rc = launch_own_step_fused(&p->model, p->state1, p->state2, b->pairs, b->n_pairs, &p->lists[cl], b->items, b->n_items,
                                        b->dense_skip, b->inc, p->partials, dense, p->lmbda, p->reg_type, p->optimizer, p->lr,

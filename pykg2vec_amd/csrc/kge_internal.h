@@ -159,6 +159,17 @@ int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, in
 
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);
+// the staged owner-computes step of the remaining pointwise gather models (kge_ownx.hip)
+bool ownx_model(int model);
+int ownx_groups_per_block(int model, int dim);
+int ownx_partial_stride(int model, int dim);
+size_t ownx_stage_floats(int model, int dim, int64_t n_pairs);
+int launch_ownx_step(const kge_model_desc* m, float* const* state1, float* const* state2, const int32_t* pairs, int64_t n_pairs,
+                     const kge_pull_lists* lists, const int32_t* items, int64_t n_items, const uint32_t* listed, const int32_t* inc,
+                     float* partials, const int32_t* multi, int64_t n_multi, int dense, float lmbda, int reg_type, int optimizer, float lr,
+                     int64_t step, const int32_t* next_pairs, const int32_t* next_inv, int64_t next_n, const float* bern,
+                     const uint64_t* slots, int64_t n_slots, uint64_t seed, uint64_t next_offset, const kge_pull_lists* next_lists,
+                     float* loss, float* stage, hipStream_t s);
 // TransH / TransD gradients in the two-launch owner-computes form (kge_pullx.hip)
 int transx_groups_per_block(int dim);
 int transx_partial_stride(int dim);

@@ -883,6 +883,11 @@ def own_partial_stride(model_name, dim):
     return int(L.load().kge_own_partial_stride(MODEL_IDS[model_name], int(dim)))
 
 
+def own_stage_floats(model_name, dim, n_pairs):
+    """Floats of the staged form's buffer for a batch of n_pairs bundles (kge_own_stage_bytes)."""
+    return int(L.load().kge_own_stage_bytes(MODEL_IDS[model_name], int(dim), int(n_pairs))) // 4
+
+
 def _ptr_array(tensors, n=L.KGE_MAX_TABLES):
     arr = (ctypes.c_void_p * n)()
     for i, t in enumerate(tensors or ()):

@@ -178,6 +178,7 @@ class Trainer:
     GRAPH_MAX_ROWS = 16384  # steps scoring at most this many triples are launch-bound: replay them as one hipGraph
     PULL_INDEX_BUDGET = 256 << 20   # bytes of per-batch incidence index the owner-computes path may build (see _pull_ok)
     GRAPH_UNROLL = 8        # steps per replayed multi-step graph (even; 0 = single-step graphs only)
+    OWN_GENERIC_MODELS = ("analogy", "cp", "simple", "simple_ignr", "quate")
     PULL_TWO_PHASE_MIN_BATCH = 8192    # owner-computes step in two launches (each pair evaluated once) from this batch size on
 
     def __init__(self, model, config, process_group=None, backend=None, use_graph=None):
@@ -513,12 +514,18 @@ class Trainer:
         launches (csrc/kge_own.hip: gradient rows by their owners, then the in-place optimiser on the touched rows), the epoch
         enqueued by one native call.  KGE_PW_PULL=0 / 1 overrides."""
         m = self.model
-        if not (self.K is K and not self.distributed and m.kernel_name in ("distmult", "complex")
-                and m.training_strategy == TrainingStrategy.POINTWISE_BASED and int(self.config.neg_rate) == 1
-                and m.hidden_size % 4 == 0 and m.hidden_size <= 512
-                and len({p.weight.shape[1] for p in m.parameter_list}) == 1
-                and m.kernel_reg_type() in (0, 1, 2, 3)
+        if not (self.K is K and not self.distributed and m.training_strategy == TrainingStrategy.POINTWISE_BASED
+                and int(self.config.neg_rate) == 1
                 and self.generator is not None and self.generator.n_train >= self.config.batch_size):
+            return False
+        if m.kernel_name in ("distmult", "complex"):          # the specialised kernels (csrc/kge_own.hip)
+            if not (m.hidden_size % 4 == 0 and m.hidden_size <= 512 and len({p.weight.shape[1] for p in m.parameter_list}) == 1
+                    and m.kernel_reg_type() in (0, 1, 2, 3)):
+                return False
+        elif m.kernel_name in self.OWN_GENERIC_MODELS:        # the model-generic staged step (csrc/kge_ownx.hip)
+            if not (K.own_groups_per_block(m.kernel_name, m.hidden_size) > 0 and self.switches.get("own_staged") is not False):
+                return False
+        else:
             return False
         if self.switches["pw_pull"] is not None:
             return self.switches["pw_pull"]
@@ -544,8 +551,7 @@ class Trainer:
             gbuf = torch.empty_like(flat.param)      # gradient rows (only the touched ones are ever written / read)
             off = [v.data_ptr() - flat.param.data_ptr() for v in flat.views]
             view = lambda buf: [buf[o // 4:o // 4 + v.numel()].view_as(v) for o, v in zip(off, flat.views)]
-            desc = K.make_desc(name, flat.views, view(gbuf), tot_entity=cfg.tot_entity, tot_relation=cfg.tot_relation,
-                               **self.model.desc_kwargs())
+            desc = self.model.make_desc(flat.views, view(gbuf))
             s1 = view(flat.state1) if flat.state1 is not None else None
             s2 = view(flat.state2) if flat.state2 is not None else None
             lists = [K.PullListSet(idx.batch_size, cfg.tot_entity, dev) for _ in range(2)]
@@ -554,7 +560,8 @@ class Trainer:
             # staged form (default; KGE_OWN_STAGED=0: owners re-evaluate): every bundle evaluated once, its gradient rows left in
             # four slots per bundle for their owners to add
             staged = self.switches.get("own_staged")
-            stage = torch.empty(4 * idx.batch_size * stride, dtype=torch.float32, device=dev) if (staged is None or staged) else None
+            stage = (torch.empty(K.own_stage_floats(name, self.model.hidden_size, idx.batch_size), dtype=torch.float32, device=dev)
+                     if (staged is None or staged) else None)
             plan = K.OwnPlan(desc, s1, s2, lists, idx, partials, cfg.optimizer, cfg.learning_rate, self.model.kernel_lmbda(),
                              self.model.kernel_reg_type(), self.loss_buf, gen.bern, gen.slots, gen.seed, idx.batch_size * gen.neg_rate,
                              stage=stage)
@@ -612,7 +619,17 @@ class Trainer:
         stride = K.own_partial_stride(name, self.model.hidden_size)
         partials = torch.empty(max(1, idx.max_slots) * stride, dtype=torch.float32, device=dev)
         staged = self.switches.get("own_staged")
-        stage = torch.empty(4 * len(pos) * stride, dtype=torch.float32, device=dev) if (staged is None or staged) else None
+        stage = (torch.empty(K.own_stage_floats(name, self.model.hidden_size, len(pos)), dtype=torch.float32, device=dev)
+                 if (staged is None or staged) else None)
+        if name in self.OWN_GENERIC_MODELS:     # the model-generic step exists as a run only: a one-batch plan, lists given
+            desc = self.model.make_desc(flat.views, gviews)
+            plan = K.OwnPlan(desc, view(flat.state1) if flat.state1 is not None else None,
+                             view(flat.state2) if flat.state2 is not None else None, [lists, K.PullListSet(len(pos), cfg.tot_entity, dev)],
+                             idx, partials, cfg.optimizer, cfg.learning_rate, self.model.kernel_lmbda(), self.model.kernel_reg_type(),
+                             self.loss_buf, None, None, 0, len(pos), stage=stage)
+            flat.step += 1
+            plan.run(0, 1, 0, True, flat.step, 0, 0)
+            return None
         K.own_step(desc, pairs, lists, items, idx.skip(0), inc, partials, dense, self.model.kernel_lmbda(), self.model.kernel_reg_type(),
                    self.loss_buf, reset_lists=False, stage=stage)
         flat.step += 1

@@ -20,7 +20,7 @@ def hip():
 
 
 @pytest.mark.parametrize("opt", ["sgd", "adam", "adagrad", "rms"])
-@pytest.mark.parametrize("name", ["distmult", "complex", "complexn3"])
+@pytest.mark.parametrize("name", ["distmult", "complex", "complexn3", "analogy", "cp", "simple", "simple_ignr", "quate"])
 def test_three_own_steps_match_reference_weights(hip, name, opt):
     """Golden batches of the live reference (pointwise layout, neg_rate 1), three steps: losses and post-optimiser tables."""
     from pykg2vec_amd import kernels as K
@@ -40,6 +40,13 @@ def test_three_own_steps_match_reference_weights(hip, name, opt):
     for k, p in hip.table_parameters(m):
         ref = c.z["%s.final.%s" % (opt, k)]
         got = p.detach().cpu().numpy()
+        if opt == "rms":
+            # RMSprop's first steps move a weight by ~10*lr*sign(g) however small g is: an entry whose gradient is a rounding residue
+            # of cancelling contributions (summation order: fixed here, but not torch's) may land elsewhere; such entries are isolated
+            # (tests/test_hip_parity.py handles the atomic path the same way)
+            bad = np.abs(got - ref) > 2e-3 + 1e-4 * np.abs(ref)
+            assert bad.mean() < 2e-3, (k, bad.sum(), np.abs(got - ref).max())
+            continue
         assert np.allclose(got, ref, atol=1e-4, rtol=1e-4), (k, np.abs(got - ref).max())
 
 
@@ -66,6 +73,10 @@ def _trainer(hip, model, world, E, R, D, B, opt, own, monkeypatch, lr=0.01, lmbd
 
 
 SHAPES = [("distmult", 53, 7, 40, 32), ("complex", 53, 7, 40, 32), ("complexn3", 53, 7, 40, 32),
+          # the model-generic staged step (csrc/kge_ownx.hip): one gradient row per role staged per triple
+          ("analogy", 53, 7, 40, 32), ("cp", 53, 7, 40, 32), ("simple", 53, 7, 40, 32), ("simple_ignr", 53, 7, 40, 32), ("quate", 53, 7, 40, 32),
+          ("cp", 12, 400, 8, 512), ("analogy", 3000, 3, 100, 1024), ("simple", 4000, 11, 200, 512), ("quate", 300, 5, 100, 256),
+          ("analogy", 500, 9, 22, 64),
           ("complex", 12, 400, 8, 512),        # 512 draws over 12 entities: bucket overflow chains, every entity row long (many
                                                # relations keep the train set far from saturating the 12 x 400 x 12 triples)
           ("complex", 4000, 11, 200, 512),     # C2 row length, few relations: relation rows through the global partial sums
