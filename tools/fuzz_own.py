@@ -30,8 +30,9 @@ for it in range(N):
         continue
     exact = False
     if fam == "pointwise":
-        model = ["distmult", "complex", "complexn3"][int(rng.integers(3))]
-        d = 4 * int(rng.integers(1, 80))
+        model = ["distmult", "complex", "complexn3", "analogy", "cp", "simple", "simple_ignr", "quate"][int(rng.integers(8))]
+        generic = model in ("analogy", "cp", "simple", "simple_ignr", "quate")      # csrc/kge_ownx.hip: any hidden size <= 256
+        d = (2 * int(rng.integers(1, 100)) if generic else 4 * int(rng.integers(1, 80)))
         hp = dict(hidden_size=d, lmbda=float(rng.choice([0.0, 1e-3, 0.05])), neg_rate=1)
         kw, env = dict(hidden_size=d), ("KGE_PW_PULL", "0", "1")
     elif fam == "transx":
