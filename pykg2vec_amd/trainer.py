@@ -548,10 +548,11 @@ class Trainer:
         st = getattr(self, "_own", None)
         if st is None or st["index"] is not idx:
             dev = flat.param.device
-            gbuf = torch.empty_like(flat.param)      # gradient rows (only the touched ones are ever written / read)
+            generic = name in self.OWN_GENERIC_MODELS     # (csrc/kge_ownx.hip: owners apply in place, no gradient rows are kept)
+            gbuf = None if generic else torch.empty_like(flat.param)      # gradient rows (only the touched ones are ever written / read)
             off = [v.data_ptr() - flat.param.data_ptr() for v in flat.views]
             view = lambda buf: [buf[o // 4:o // 4 + v.numel()].view_as(v) for o, v in zip(off, flat.views)]
-            desc = self.model.make_desc(flat.views, view(gbuf))
+            desc = self.model.make_desc(flat.views, None if generic else view(gbuf))
             s1 = view(flat.state1) if flat.state1 is not None else None
             s2 = view(flat.state2) if flat.state2 is not None else None
             lists = [K.PullListSet(idx.batch_size, cfg.tot_entity, dev) for _ in range(2)]
