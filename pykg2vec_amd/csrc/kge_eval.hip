@@ -891,6 +891,9 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
 // and the count epilogue needs one threshold and one counter per lane and column block.  The fp32 result of an MFMA chain
 // is bit-identical to one fmaf chain over k, which is the order k_eval_target_filter<CHAIN> uses for s(q, true): integer
 // ranks stay exact functions of the fp32 energies.
+#ifndef KGE_GEMM_PRIO
+#define KGE_GEMM_PRIO 0
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GT = 128;      // tile edge (queries and candidates) per workgroup
 constexpr int GKS = 16;      // K slab
@@ -960,9 +963,15 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
 #endif
     float thr[NB], qn2[NB];
     int cnt[NB];
+    // query column (inside the workgroup's 128) that column block ni holds for this lane
+#if defined(KGE_GEMM_32X32) || defined(KGE_GEMM_B32READS)
+    auto qcol = [&](int ni) { return wc * 64 + ni * BW + lcol; };
+#else
+    auto qcol = [&](int ni) { return wc * 64 + 4 * lcol + ni; };   // four consecutive columns per lane: one 16-byte LDS read
+#endif
 #pragma unroll
     for (int ni = 0; ni < NB; ++ni) {
-        const int64_t q = (int64_t)qt * GT + wc * 64 + ni * BW + lcol;
+        const int64_t q = (int64_t)qt * GT + qcol(ni);
         cnt[ni] = 0;
         thr[ni] = (!WRITE && q < nq) ? st[q] : 0.f;
         qn2[ni] = (SQM && q < nq) ? qn[q] : 0.f;
@@ -979,18 +988,30 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
     const int64_t my_tiles = sp < ctiles ? (ctiles - sp + S - 1) / S : 0;
     const int64_t nsteps = my_tiles * nslab;
     float4 ra[2], rb[2];
-    auto load_step = [&](int64_t g) {
-        const int64_t ct = sp + (g / nslab) * S;
-        const int sl = (int)(g % nslab);
+    int64_t ld_ct = sp, cu_ct = sp;   // candidate tile / slab of the next load step and of the current compute step (steps are
+    int ld_sl = 0, cu_sl = 0;         // visited in order: counters instead of a 64-bit division per step)
+    // a lane's two float4 of a slab sit at FIXED offsets from a base that is the same for the whole workgroup: scalar base
+    // (advanced by one slab, or re-pointed at the next candidate tile pair) + 32-bit lane offset, no per-step address arithmetic
+    int la[2], la0[2], lq[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        la0[j] = sk[j] * 64 + (sc4[j] & 15) * 4;                 // inside the first 64-candidate tile of the pair
+        la[j] = (sc4[j] >> 4) * Kpad * 64 + la0[j];              // two 64-candidate tiles of the sweep layout side by side
+        lq[j] = sk[j] * GT + sc4[j] * 4;
+    }
+    const float* ld_c = cand + ld_ct * 2 * Kpad * 64;
+    const float* ld_q = qsrc;
+    auto load_step = [&]() {
+        const bool pair = ld_ct * 2 + 1 < ntiles64;   // odd tile count: the last pair repeats its first tile (masked in the epilogue)
+        const int krem = Kpad - ld_sl * GKS;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            int64_t t64 = ct * 2 + (sc4[j] >> 4);   // two 64-candidate tiles of the sweep layout side by side
-            if (t64 >= ntiles64) t64 = ntiles64 - 1;   // odd tile count: the duplicate rows are masked in the epilogue
-            const int k = sl * GKS + sk[j];
-            const bool live = k < Kpad;
-            ra[j] = live ? *reinterpret_cast<const float4*>(cand + (t64 * Kpad + k) * 64 + (sc4[j] & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[j] = live ? *reinterpret_cast<const float4*>(qsrc + (int64_t)k * GT + sc4[j] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool live = sk[j] < krem;
+            ra[j] = live ? *reinterpret_cast<const float4*>(ld_c + (pair ? la[j] : la0[j])) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = live ? *reinterpret_cast<const float4*>(ld_q + lq[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (++ld_sl == nslab) { ld_sl = 0; ld_ct += S; ld_c = cand + ld_ct * 2 * Kpad * 64; ld_q = qsrc; }
+        else { ld_c += GKS * 64; ld_q += GKS * GT; }
     };
 #ifdef KGE_GEMM_32X32
     f32x16 acc[2][2];
@@ -998,7 +1019,7 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x16{0};
-    if (nsteps > 0) load_step(0);
+    if (nsteps > 0) load_step();
     int buf = 0;
     for (int64_t g = 0; g < nsteps; ++g) {
 #pragma unroll
@@ -1007,7 +1028,7 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
             *reinterpret_cast<float4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
         }
         __syncthreads();   // step g is in LDS; everybody finished reading the buffer that is written next
-        if (g + 1 < nsteps) load_step(g + 1);
+        if (g + 1 < nsteps) load_step();
         // operands of step kk + 2 are read from LDS before the MFMAs of step kk are issued (register double buffer; the
         // scheduling barrier keeps the compiler from sinking the reads back in front of their use)
         float na0 = sA[buf][lk][wr * 64 + li], na1 = sA[buf][lk][wr * 64 + 32 + li];
@@ -1026,10 +1047,12 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         buf ^= 1;
-        if ((int)(g % nslab) != nslab - 1) continue;
+        if (++cu_sl != nslab) continue;
+        cu_sl = 0;
         // ---- last slab of a candidate tile: epilogue.  energy = -dot (+ post-op); the lane owns query column (ni, li),
         // its 16 registers per block are candidate rows
-        const int64_t ct = sp + (g / nslab) * S;
+        const int64_t ct = cu_ct;
+        cu_ct += S;
         const int e_base = (int)(ct * GT) + wr * 64 + 4 * lk;   // candidate ids fit 31 bits (packed keys: < 2^24)
         const int e_lim = (int)E;
         const bool full = ct * GT + GT <= E && (ct * 2 + 1 < ntiles64);
@@ -1075,7 +1098,7 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nsteps > 0) load_step(0);
+    if (nsteps > 0) load_step();
     int buf = 0;
     for (int64_t g = 0; g < nsteps; ++g) {
 #pragma unroll
@@ -1084,32 +1107,57 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
             *reinterpret_cast<float4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
         }
         __syncthreads();   // step g is in LDS; everybody finished reading the buffer that is written next
-        if (g + 1 < nsteps) load_step(g + 1);
+        if (g + 1 < nsteps) load_step();
         // operands of k-step kk + 4 are read from LDS before the MFMAs of k-step kk are issued (register double buffer)
         float na[4], nb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { na[i] = sA[buf][lk4][wr * 64 + i * 16 + lcol]; nb[i] = sB[buf][lk4][wc * 64 + i * 16 + lcol]; }
+#ifdef KGE_GEMM_B32READS
+#define KGE_GEMM_READ(K)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                        \
+        na[i] = sA[buf][(K) + lk4][wr * 64 + i * 16 + lcol];                                                               \
+        nb[i] = sB[buf][(K) + lk4][wc * 64 + i * 16 + lcol];                                                               \
+    }
+#else
+        // row block mi of the wave holds candidate rows 4 r + mi (r = row inside the MFMA block), column block ni query columns
+        // 4 c + ni: a lane's four A operands (and four B operands) of a k-step are 16 consecutive bytes of the k-major slab
+#define KGE_GEMM_READ(K)                                                                                                   \
+    {                                                                                                                      \
+        const float4 va = *reinterpret_cast<const float4*>(&sA[buf][(K) + lk4][wr * 64 + 4 * lcol]);                       \
+        const float4 vb = *reinterpret_cast<const float4*>(&sB[buf][(K) + lk4][wc * 64 + 4 * lcol]);                       \
+        na[0] = va.x; na[1] = va.y; na[2] = va.z; na[3] = va.w;                                                            \
+        nb[0] = vb.x; nb[1] = vb.y; nb[2] = vb.z; nb[3] = vb.w;                                                            \
+    }
+#endif
+        KGE_GEMM_READ(0)
 #pragma unroll
         for (int kk = 0; kk < GKS; kk += 4) {
             float a4[4], b4[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { a4[i] = na[i]; b4[i] = nb[i]; }
-            if (kk + 4 < GKS) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { na[i] = sA[buf][kk + 4 + lk4][wr * 64 + i * 16 + lcol]; nb[i] = sB[buf][kk + 4 + lk4][wc * 64 + i * 16 + lcol]; }
-            }
+            if (kk + 4 < GKS) KGE_GEMM_READ(kk + 4)
             KGE_KEEP_READS_AHEAD();
+#if KGE_GEMM_PRIO == 1
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi], b4[ni], acc[mi][ni], 0, 0, 0);
+#if KGE_GEMM_PRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         buf ^= 1;
-        if ((int)(g % nslab) != nslab - 1) continue;
+        if (++cu_sl != nslab) continue;
+        cu_sl = 0;
         // ---- last slab of a candidate tile: epilogue.  energy = -dot (+ post-op); the lane owns query column (ni, lcol), its 4
         // registers per block are candidate rows 4 * lk4 + reg of block mi
-        const int64_t ct = sp + (g / nslab) * S;
+        const int64_t ct = cu_ct;
+        cu_ct += S;
+#ifdef KGE_GEMM_B32READS
         const int e_base = (int)(ct * GT) + wr * 64 + 4 * lk4;   // candidate ids fit 31 bits (packed keys: < 2^24)
+#else
+        const int e_base = (int)(ct * GT) + wr * 64 + 16 * lk4;  // MFMA block row 4 lk4 + reg of block mi = candidate row 4 (4 lk4 + reg) + mi
+#endif
         const int e_lim = (int)E;
         const bool full = ct * GT + GT <= E && (ct * 2 + 1 < ntiles64);
         const int e_pad = (int)(ntiles64 * 64);
@@ -1117,14 +1165,18 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
+#ifdef KGE_GEMM_B32READS
                 const int e = e_base + mi * 16 + reg;
+#else
+                const int e = e_base + 4 * reg + mi;
+#endif
                 float cn2 = 0.f;
                 if constexpr (SQM) cn2 = e < e_pad ? cn[e] : 0.f;
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const float sc = energy(acc[mi][ni][reg], ni, cn2);
                     if constexpr (WRITE) {
-                        const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 16 + lcol;
+                        const int64_t q = (int64_t)qt * GT + qcol(ni);
                         if (q < nq && e < e_lim) scores_out[q * E + e] = sc;
                     } else {
                         cnt[ni] += (sc < thr[ni] && (full || e < e_lim)) ? 1 : 0;
@@ -1141,11 +1193,12 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
         for (int ni = 0; ni < 4; ++ni) {
             int c2 = cnt[ni] + __shfl_xor(cnt[ni], 16, 64);   // the four lanes that own the same query column
             c2 += __shfl_xor(c2, 32, 64);
-            const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 16 + lcol;
+            const int64_t q = (int64_t)qt * GT + qcol(ni);
             if (lk4 == 0 && q < nq && c2 != 0) atomicAdd(rcount + q, c2);
         }
     }
 }
+#undef KGE_GEMM_READ
 
 #endif
 
