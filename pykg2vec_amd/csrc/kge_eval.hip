@@ -199,6 +199,83 @@ __global__ __launch_bounds__(256) void k_eval_cnorm(PrepArgs a, float* __restric
     if (lane == 0) aux[e] = n2;
 }
 
+// The plain re-layout (no normalisation, no TransD dot product, every table width a multiple of 4) with 16-byte accesses:
+// a workgroup moves 64 candidates x 128 k per step -- 512 contiguous bytes per row and half wave on the way in, float4 of
+// four candidates per k on the way out -- and grid.y splits K so that the chip is full whatever the tile count is.  |c|^2
+// (squared-distance sweep) is a by-product: per (row, K split) partial sums, added up in split order by k_eval_cnorm_parts
+// (part == nullptr with one split: aux is written here), so the table is read once.
+__device__ __forceinline__ float4 prep_elem4(const PrepArgs& a, int64_t e, int k) {
+    int kk = k;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s < a.nseg) {
+            if (kk < a.seg_dim[s]) return *reinterpret_cast<const float4*>(a.seg[s] + e * a.seg_dim[s] + kk);
+            kk -= a.seg_dim[s];
+        }
+    }
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_eval_prepare4(PrepArgs a, float* __restrict__ cand, float* __restrict__ aux,
+                                                       float* __restrict__ part) {
+    __shared__ float s_tile[64][129];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, kq = lane & 31;
+    const int64_t tile = blockIdx.x, e0 = tile * 64;
+    const int k_lo = blockIdx.y * a.kper, k_hi = min(a.Kpad, k_lo + a.kper);
+    float n2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) n2[j] = 0.f;
+    for (int k0 = k_lo; k0 < k_hi; k0 += 128) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t e = e0 + wave * 16 + 2 * j + half;
+            const int k = k0 + 4 * kq;
+            v[j] = (e < a.E && k < a.K) ? prep_elem4(a, e, k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float* row = s_tile[wave * 16 + 2 * j + half] + 4 * kq;
+            row[0] = v[j].x; row[1] = v[j].y; row[2] = v[j].z; row[3] = v[j].w;
+            n2[j] = fmaf(v[j].x, v[j].x, n2[j]); n2[j] = fmaf(v[j].y, v[j].y, n2[j]);
+            n2[j] = fmaf(v[j].z, v[j].z, n2[j]); n2[j] = fmaf(v[j].w, v[j].w, n2[j]);
+        }
+        __syncthreads();
+        const int c4 = threadIdx.x & 15;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int kk = it * 16 + (threadIdx.x >> 4);
+            if (k0 + kk < k_hi) {
+                const float4 o = make_float4(s_tile[4 * c4][kk], s_tile[4 * c4 + 1][kk], s_tile[4 * c4 + 2][kk], s_tile[4 * c4 + 3][kk]);
+                *reinterpret_cast<float4*>(cand + (tile * a.Kpad + k0 + kk) * 64 + 4 * c4) = o;
+            }
+        }
+        __syncthreads();
+    }
+    if (a.want_n2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = n2[j];
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);   // the 32 lanes of the row's half wave, fixed order
+            if (kq == 0) {
+                const int64_t e = e0 + wave * 16 + 2 * j + half;
+                if (part) part[e * gridDim.y + blockIdx.y] = t;
+                else aux[e] = t;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_eval_cnorm_parts(const float* __restrict__ part, int nky, int64_t rows, float* __restrict__ aux) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows) return;
+    float t = 0.f;
+    for (int y = 0; y < nky; ++y) t += part[e * nky + y];
+    aux[e] = t;
+}
+
 // ---- per-relation candidate tables for TransH / TransD (grouped evaluation): the candidate-side transform depends on the
 // query only through its relation (hyperplane normal w_r / mapping r_m), so for a group of queries sharing r it is applied
 // ONCE per candidate -- project, normalise, write the sweep layout -- and the queries then run the plain L1 / L2 sweep
@@ -309,13 +386,16 @@ __global__ __launch_bounds__(256) void k_eval_prepare_xf(XfPrepArgs a, float* __
 }
 
 // ------------------------------------------------------------------ 2. query vectors
-// one wave per test triple; writes qvec[(2i+side)*QV*Kpad ...], side 0 = tail sweep (h,r,?), 1 = head sweep (?,r,t)
+// one wave (translation family) or one workgroup per test triple; writes qvec[(2i+side)*QV*Kpad ...], side 0 = tail sweep (h,r,?), 1 = head sweep (?,r,t)
 template <int M>
 __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64_t* __restrict__ triples, int64_t n,
                                                       int K, int Kpad, int QV, float* __restrict__ qvec,
                                                       float* __restrict__ qscale) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the translation family needs wave-wide row reductions: one wave per triple; everything else is element-wise over k
+    // (or independent per output column, RESCAL): the whole workgroup takes one triple, four times the loads in flight per row
+    constexpr int TPT = (M == KGE_TRANSE || M == KGE_TRANSH || M == KGE_TRANSD || M == KGE_TRANSM) ? 64 : 256;
+    const int lane = threadIdx.x % TPT;
+    const int64_t i = (int64_t)blockIdx.x * (256 / TPT) + threadIdx.x / TPT;
     if (i >= n) return;
     const int64_t h = triples[3 * i], r = triples[3 * i + 1], t = triples[3 * i + 2];
     if (lane == 0) {
@@ -325,7 +405,7 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
     float* qt = qvec + (2 * i) * (int64_t)QV * Kpad;
     float* qh = qvec + (2 * i + 1) * (int64_t)QV * Kpad;
     const int d = m.dim;
-    for (int k = K + lane; k < Kpad; k += 64) {
+    for (int k = K + lane; k < Kpad; k += TPT) {
         qt[k] = 0.f; qh[k] = 0.f;
         if (QV == 2) { qt[Kpad + k] = 0.f; qh[Kpad + k] = 0.f; }
     }
@@ -375,7 +455,7 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
         }
     } else if constexpr (M == KGE_DISTMULT) {
         const float* eh = m.tab[0] + h * d; const float* er = m.tab[1] + r * d; const float* et = m.tab[0] + t * d;
-        for (int k = lane; k < d; k += 64) { qt[k] = eh[k] * er[k]; qh[k] = er[k] * et[k]; }
+        for (int k = lane; k < d; k += TPT) { qt[k] = eh[k] * er[k]; qh[k] = er[k] * et[k]; }
     } else if constexpr (M == KGE_COMPLEX || M == KGE_ANALOGY) {
         constexpr int o = (M == KGE_ANALOGY) ? 2 : 0;
         const int dc = (M == KGE_ANALOGY) ? d / 2 : d;
@@ -383,7 +463,7 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
         const float* hr = m.tab[o + 0] + h * dc; const float* hi = m.tab[o + 1] + h * dc;
         const float* rr = m.tab[o + 2] + r * dc; const float* ri = m.tab[o + 3] + r * dc;
         const float* tr = m.tab[o + 0] + t * dc; const float* ti = m.tab[o + 1] + t * dc;
-        for (int k = lane; k < dc; k += 64) {
+        for (int k = lane; k < dc; k += TPT) {
             qt[base + k] = hr[k] * rr[k] - hi[k] * ri[k];
             qt[base + dc + k] = hi[k] * rr[k] + hr[k] * ri[k];
             qh[base + k] = tr[k] * rr[k] + ti[k] * ri[k];
@@ -391,12 +471,12 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
         }
         if constexpr (M == KGE_ANALOGY) {
             const float* eh = m.tab[0] + h * d; const float* er = m.tab[1] + r * d; const float* et = m.tab[0] + t * d;
-            for (int k = lane; k < d; k += 64) { qt[k] = eh[k] * er[k]; qh[k] = er[k] * et[k]; }
+            for (int k = lane; k < d; k += TPT) { qt[k] = eh[k] * er[k]; qh[k] = er[k] * et[k]; }
         }
     } else if constexpr (M == KGE_ROTATE) {
         const float* hr = m.tab[0] + h * d; const float* hi = m.tab[1] + h * d; const float* rl = m.tab[2] + r * d;
         const float* tr = m.tab[0] + t * d; const float* ti = m.tab[1] + t * d;
-        for (int k = lane; k < d; k += 64) {
+        for (int k = lane; k < d; k += TPT) {
             float sn, cs;
             sincosf(rl[k] / m.phase_div, &sn, &cs);
             qt[k] = hr[k] * cs - hi[k] * sn;       // h o r ;  score = |h o r - t|^2 - margin
@@ -406,7 +486,7 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
         }
     } else if constexpr (M == KGE_CP) {  // candidate row [sub[e] | obj[e]]
         const float* sh = m.tab[0] + h * d; const float* er = m.tab[1] + r * d; const float* ot = m.tab[2] + t * d;
-        for (int k = lane; k < d; k += 64) {
+        for (int k = lane; k < d; k += TPT) {
             qt[k] = 0.f; qt[d + k] = sh[k] * er[k];     // tail sweep: <sub[h] o rel[r], obj[e]>
             qh[k] = er[k] * ot[k]; qh[d + k] = 0.f;     // head sweep: <sub[e], rel[r] o obj[t]>
         }
@@ -415,7 +495,7 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
         const float* hh = m.tab[0] + h * d; const float* ht = m.tab[0] + t * d;   // head-role rows of h and t
         const float* th = m.tab[1] + h * d; const float* tt = m.tab[1] + t * d;   // tail-role rows of h and t
         const float* r1 = m.tab[2] + r * d; const float* r2 = m.tab[3] + r * d;
-        for (int k = lane; k < d; k += 64) {
+        for (int k = lane; k < d; k += TPT) {
             qt[k] = hh[k] * r1[k];              // <head[h], rel, tail[e]>
             qt[d + k] = w2 * (r2[k] * th[k]);   // <head[e], rel_inv, tail[h]>
             qh[k] = w2 * (ht[k] * r2[k]);       // <head[t], rel_inv, tail[e]>
@@ -424,7 +504,7 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
     } else if constexpr (M == KGE_QUATE) {  // candidate row [s | x | y | z][e]
         const float* H[4]; const float* T[4]; const float* Rq[4];
         for (int c = 0; c < 4; ++c) { H[c] = m.tab[c] + h * d; T[c] = m.tab[c] + t * d; Rq[c] = m.tab[4 + c] + r * d; }
-        for (int k = lane; k < d; k += 64) {
+        for (int k = lane; k < d; k += TPT) {
             const float rs = Rq[0][k], rx = Rq[1][k], ry = Rq[2][k], rz = Rq[3][k];
             const float den = sqrtf(rs * rs + rx * rx + ry * ry + rz * rz);
             const float inv = den > 0.f ? 1.0f / den : 0.f;
@@ -443,7 +523,7 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
     } else if constexpr (M == KGE_RESCAL) {
         const float* eh = m.tab[0] + h * d; const float* et = m.tab[0] + t * d;
         const float* Mr = m.tab[1] + r * (int64_t)d * d;
-        for (int j = lane; j < d; j += 64) {
+        for (int j = lane; j < d; j += TPT) {
             float a = 0.f, b = 0.f;
             int i2 = 0;
             for (; i2 + KC <= d; i2 += KC) {  // operands of KC steps in flight before the dependent fma chains
@@ -507,39 +587,13 @@ __device__ __forceinline__ float pair_post(float s, float scale) {
 // squared L2 distance from the dot product and the two squared norms (matrix-core sweep and its target / filter twin)
 __device__ __forceinline__ float sqm_from_dot(float dot, float qn, float cn) { return fmaf(-2.0f, dot, qn + cn); }
 
-// full sequential score of one (query, candidate) pair by ONE lane (target / filter path).  CHAIN: the dot product as
-// ONE fmaf chain over k -- the order v_mfma_f32_32x32x2_f32 accumulates in (k_eval_gemm) -- instead of the packed sweep's
-// even / odd split.
-template <int FORM, int XFORM, int POST, bool CHAIN = false>
+// full sequential score of one (query, candidate) pair by ONE lane (target / filter path of the VALU sweep)
+template <int FORM, int XFORM, int POST>
 __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand, const float* __restrict__ aux,
                                                  const float* __restrict__ q, int64_t e, int Kpad, float margin,
                                                  float scale) {
     const float* c = cand + ((e >> 6) * Kpad) * 64 + (e & 63);
     float acc = 0.f;
-    if constexpr (CHAIN) {
-        static_assert(!CHAIN || ((FORM == F_NEGDOT || FORM == F_SQM) && XFORM == X_NONE), "chain order: plain dot-product based forms");
-        // (long rows: 32 operands per dependent round trip -- Kpad is a multiple of 8, the tail runs 8 at a time)
-        constexpr int KL = 32;
-        int k0 = 0;
-        for (; k0 + KL <= Kpad; k0 += KL) {
-            float cv[KL], qv[KL];
-#pragma unroll
-            for (int j = 0; j < KL; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; qv[j] = q[k0 + j]; }
-#pragma unroll
-            for (int j = 0; j < KL; ++j) acc = fmaf(cv[j], qv[j], acc);
-        }
-        for (; k0 < Kpad; k0 += KC) {
-            float cv[KC], qv[KC];
-#pragma unroll
-            for (int j = 0; j < KC; ++j) { cv[j] = c[(int64_t)(k0 + j) * 64]; qv[j] = q[k0 + j]; }
-#pragma unroll
-            for (int j = 0; j < KC; ++j) acc = fmaf(cv[j], qv[j], acc);
-        }
-        // squared distance through the expansion |q|^2 + |c|^2 - 2 <q, c> the matrix-core sweep uses (`scale` = |q|^2,
-        // aux[e] = |c|^2): same stored norms, same operation order => same bits as k_eval_gemm
-        if constexpr (FORM == F_SQM) acc = sqm_from_dot(acc, scale, aux[e]);
-        return pair_post<POST>(pair_finish<FORM>(acc, margin), 1.0f);
-    }
     // candidate / query elements are fetched KC at a time BEFORE the dependent accumulation chain (one memory round trip
     // per KC elements instead of one per element); the accumulation order is unchanged
     if constexpr (XFORM == X_NONE && FORM != F_L1) {
@@ -621,7 +675,7 @@ __device__ __forceinline__ float pair_score_lane(const float* __restrict__ cand,
 }
 
 // ------------------------------------------------------------------ 3. target score + filtered count
-template <int FORM, int XFORM, int POST, bool CHAIN = false>
+template <int FORM, int XFORM, int POST>
 __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restrict__ cand, const float* __restrict__ aux,
                                                             const float* __restrict__ qvec, const float* __restrict__ qscale,
                                                             const int64_t* __restrict__ triples,
@@ -638,33 +692,9 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
     const int side = (int)(qi & 1);
     const int64_t truth = side == 0 ? triples[3 * i + 2] : triples[3 * i];
     const float* q = qvec + qi * (int64_t)QV * Kpad;
-    const float scale = (POST == P_SCALE || (CHAIN && FORM == F_SQM)) ? qscale[qi] : 1.0f;   // CHAIN SQM: |q|^2
+    const float scale = POST == P_SCALE ? qscale[qi] : 1.0f;
     float s_true = 0.f;
-    if constexpr (CHAIN) {
-        // the true candidate's energy is ONE fmaf chain over k (the order the matrix-core sweep accumulates in), but its
-        // operands sit 256 bytes apart in the sweep layout: the wave fetches 64 of them per round trip into LDS (instead of a
-        // few per dependent round trip of one lane), then lane 0 runs the chain out of LDS -- same operands, same order
-        constexpr int CHUNK = 512;
-        __shared__ float s_c[4][CHUNK], s_q[4][CHUNK];
-        const int wv = threadIdx.x >> 6;
-        const float* c = cand + ((truth >> 6) * Kpad) * 64 + (truth & 63);
-        float acc = 0.f;
-        for (int k0 = 0; k0 < Kpad; k0 += CHUNK) {
-            const int nk = min(CHUNK, Kpad - k0);
-            for (int k = lane; k < nk; k += 64) { s_c[wv][k] = c[(int64_t)(k0 + k) * 64]; s_q[wv][k] = q[k0 + k]; }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0);   // (LDS writes of this wave are visible to its lane 0 below)
-            if (lane == 0)
-                for (int k = 0; k < nk; ++k) acc = fmaf(s_c[wv][k], s_q[wv][k], acc);
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (lane == 0) {
-            if constexpr (FORM == F_SQM) acc = sqm_from_dot(acc, scale, aux[truth]);
-            s_true = pair_post<POST>(pair_finish<FORM>(acc, margin), 1.0f);
-        }
-    } else {
-        if (lane == 0) s_true = pair_score_lane<FORM, XFORM, POST, CHAIN>(cand, aux, q, truth, Kpad, margin, scale);
-    }
+    if (lane == 0) s_true = pair_score_lane<FORM, XFORM, POST>(cand, aux, q, truth, Kpad, margin, scale);
     s_true = __shfl(s_true, 0, 64);
     const int64_t* off = side == 0 ? tail_off : head_off;
     const int32_t* ids = side == 0 ? tail_ids : head_ids;
@@ -674,10 +704,112 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
         for (int64_t j = b + lane; j < e_; j += 64) {
             const int64_t e = ids[j];
             if (e != truth) {
-                const float s = pair_score_lane<FORM, XFORM, POST, CHAIN>(cand, aux, q, e, Kpad, margin, scale);
+                const float s = pair_score_lane<FORM, XFORM, POST>(cand, aux, q, e, Kpad, margin, scale);
                 cnt += (s < s_true) ? 1 : 0;
             }
         }
+    }
+    cnt = (int)wave_sum((float)cnt);  // < 2^24 known entities per query
+    if (lane == 0) { st[qi] = s_true; fcount[qi] = cnt; }
+}
+
+// ---- the same step for the matrix-core sweep (k_eval_gemm): every energy is ONE fmaf chain over k, the order the f32 MFMA
+// accumulates in, so ranks stay exact functions of bit-identical energies.  A chain is sequential, its operands need not be:
+// one wave per query takes the true candidate and the query's known entities as a list of (query, candidate) pairs, fetches a
+// K chunk of up to PG candidate rows -- from the row-major tables the sweep layout was copied from (PrepArgs segments), 256
+// coalesced bytes per row and instruction, all in flight together -- into LDS, and PG lanes run their chains out of LDS.
+// PG x chunk = 2 048 elements: few pairs (the common case) take long chunks and few round trips, long lists 64 chains at once.
+constexpr int kChainElems = 2048;
+template <int FORM, int POST>
+__global__ __launch_bounds__(256) void k_eval_target_filter_chain(PrepArgs a, const float* __restrict__ aux,
+                                                                  const float* __restrict__ qvec, const float* __restrict__ qnorm,
+                                                                  const int64_t* __restrict__ triples, int64_t n, int Kpad, float margin,
+                                                                  const int64_t* __restrict__ tail_off, const int32_t* __restrict__ tail_ids,
+                                                                  const int64_t* __restrict__ head_off, const int32_t* __restrict__ head_ids,
+                                                                  float* __restrict__ st, int32_t* __restrict__ fcount) {
+    static_assert(FORM == F_NEGDOT || FORM == F_SQM, "chain order: plain dot-product based forms");
+    __shared__ __attribute__((aligned(16))) float s_c[4][kChainElems + 4 * 64];   // [pair][chunk + 4]: rows 4 banks apart
+    __shared__ __attribute__((aligned(16))) float s_q[4][512];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wv;
+    if (qi >= 2 * n) return;
+    const int64_t i = qi >> 1;
+    const int side = (int)(qi & 1);
+    const int truth = (int)(side == 0 ? triples[3 * i + 2] : triples[3 * i]);
+    const float* q = qvec + qi * (int64_t)Kpad;
+    const float qn = FORM == F_SQM ? qnorm[qi] : 0.f;   // |q|^2
+    const int64_t* off = side == 0 ? tail_off : head_off;
+    const int32_t* ids = side == 0 ? tail_ids : head_ids;
+    const int64_t b = off ? off[i] : 0;
+    const int np = 1 + (off ? (int)(off[i + 1] - b) : 0);   // pair 0: the true candidate
+    float* sc = s_c[wv];
+    float* sq = s_q[wv];
+    float s_true = 0.f;
+    int cnt = 0;
+    for (int base = 0; base < np;) {
+        const int rem = np - base;
+        const int lg = rem > 16 ? 6 : rem > 4 ? 4 : 2;   // log2 of the pairs of this group
+        const int pg = min(1 << lg, rem);
+        const int lc = 11 - lg, ch = 1 << lc;             // chunk length: 512 / 128 / 32
+        const int pitch = ch + 4;
+        const int idx = base + lane;
+        int e = truth;
+        if (lane < pg && idx > 0) e = ids[b + idx - 1];
+        float acc = 0.f;
+        for (int k0 = 0; k0 < Kpad; k0 += ch) {
+            const int total = pg << lc;
+            for (int t0 = 0; t0 < total; t0 += 64 * 8) {   // eight loads per lane in flight, then their LDS stores
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + 64 * u + lane;
+                    const int pp = t >> lc, kk = k0 + (t & (ch - 1));
+                    const int ee = __shfl(e, pp & 63, 64);
+                    v[u] = (t < total && kk < a.K) ? prep_elem(a, ee, kk) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + 64 * u + lane;
+                    if (t < total) sc[(t >> lc) * pitch + (t & (ch - 1))] = v[u];
+                }
+            }
+            for (int kk = lane; kk < ch; kk += 64) sq[kk] = k0 + kk < Kpad ? q[k0 + kk] : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0);   // (this wave's LDS writes are visible to its chain lanes)
+            if (lane < pg) {
+                const float* cr = sc + lane * pitch;
+                const int nk = min(ch, Kpad - k0);   // Kpad is a multiple of 8
+                // (32 operands per LDS round trip: the reads of a block are issued together, then its 32 dependent fmas)
+                int kk = 0;
+                for (; kk + 32 <= nk; kk += 32) {
+                    float4 c4[8], q4[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        c4[u] = *reinterpret_cast<const float4*>(cr + kk + 4 * u);
+                        q4[u] = *reinterpret_cast<const float4*>(sq + kk + 4 * u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        acc = fmaf(c4[u].x, q4[u].x, acc); acc = fmaf(c4[u].y, q4[u].y, acc);
+                        acc = fmaf(c4[u].z, q4[u].z, acc); acc = fmaf(c4[u].w, q4[u].w, acc);
+                    }
+                }
+                for (; kk < nk; kk += 8) {
+                    const float4 c0 = *reinterpret_cast<const float4*>(cr + kk), c1 = *reinterpret_cast<const float4*>(cr + kk + 4);
+                    const float4 q0 = *reinterpret_cast<const float4*>(sq + kk), q1 = *reinterpret_cast<const float4*>(sq + kk + 4);
+                    acc = fmaf(c0.x, q0.x, acc); acc = fmaf(c0.y, q0.y, acc); acc = fmaf(c0.z, q0.z, acc); acc = fmaf(c0.w, q0.w, acc);
+                    acc = fmaf(c1.x, q1.x, acc); acc = fmaf(c1.y, q1.y, acc); acc = fmaf(c1.z, q1.z, acc); acc = fmaf(c1.w, q1.w, acc);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // squared distance through the expansion |q|^2 + |c|^2 - 2 <q, c> the matrix-core sweep uses (aux[e] = |c|^2): same
+        // stored norms, same operation order => same bits as k_eval_gemm
+        if constexpr (FORM == F_SQM) acc = sqm_from_dot(acc, qn, lane < pg ? aux[e] : 0.f);
+        const float sco = pair_post<POST>(pair_finish<FORM>(acc, margin), 1.0f);
+        if (base == 0) s_true = __shfl(sco, 0, 64);
+        if (lane < pg && idx > 0 && e != truth) cnt += (sco < s_true) ? 1 : 0;
+        base += pg;
     }
     cnt = (int)wave_sum((float)cnt);  // < 2^24 known entities per query
     if (lane == 0) { st[qi] = s_true; fcount[qi] = cnt; }
@@ -889,11 +1021,8 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
 // LDS in 16-deep K slabs (one 16-byte load per operand float4, issued a slab ahead, double-buffered, one barrier per
 // slab): 64 FMAs per operand float fetched instead of 16.  Candidates are the M side, so every lane owns ONE query column
 // and the count epilogue needs one threshold and one counter per lane and column block.  The fp32 result of an MFMA chain
-// is bit-identical to one fmaf chain over k, which is the order k_eval_target_filter<CHAIN> uses for s(q, true): integer
+// is bit-identical to one fmaf chain over k, which is the order k_eval_target_filter_chain uses for s(q, true): integer
 // ranks stay exact functions of the fp32 energies.
-#ifndef KGE_GEMM_PRIO
-#define KGE_GEMM_PRIO 0
-#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GT = 128;      // tile edge (queries and candidates) per workgroup
 constexpr int GKS = 16;      // K slab
@@ -944,7 +1073,6 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
                                                    const float* __restrict__ cn, float margin) {
     __shared__ float sA[2][GKS][GLD], sB[2][GKS][GLD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 31, lk = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;   // wave's 64 x 64 sub-tile: candidate rows wr, query columns wc
     const int qt = blockIdx.x % qtiles, sp = blockIdx.x / qtiles;
     const int64_t ctiles = (ntiles64 + 1) / 2;   // 128-candidate tiles
@@ -954,18 +1082,18 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
     for (int j = 0; j < 2; ++j) { const int idx = threadIdx.x + 256 * j; sk[j] = idx >> 5; sc4[j] = idx & 31; }
     const float* qsrc = qT + (int64_t)qt * Kpad * GT;
 #ifdef KGE_GEMM_32X32
-    constexpr int NB = 2, BW = 32;   // column blocks per wave, their width
-    const int lcol = li;
+    constexpr int NB = 2;            // column blocks per wave (32 wide)
+    const int li = lane & 31, lk = lane >> 5;
 #else
-    constexpr int NB = 4, BW = 16;
+    constexpr int NB = 4;            // (16 wide)
     const int lcol = lane & 15;
     const int lk4 = lane >> 4;       // k index of this lane's operands inside a 16x16x4 step
 #endif
     float thr[NB], qn2[NB];
     int cnt[NB];
     // query column (inside the workgroup's 128) that column block ni holds for this lane
-#if defined(KGE_GEMM_32X32) || defined(KGE_GEMM_B32READS)
-    auto qcol = [&](int ni) { return wc * 64 + ni * BW + lcol; };
+#ifdef KGE_GEMM_32X32
+    auto qcol = [&](int ni) { return wc * 64 + ni * 32 + li; };
 #else
     auto qcol = [&](int ni) { return wc * 64 + 4 * lcol + ni; };   // four consecutive columns per lane: one 16-byte LDS read
 #endif
@@ -1110,13 +1238,6 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
         if (g + 1 < nsteps) load_step();
         // operands of k-step kk + 4 are read from LDS before the MFMAs of k-step kk are issued (register double buffer)
         float na[4], nb[4];
-#ifdef KGE_GEMM_B32READS
-#define KGE_GEMM_READ(K)                                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                        \
-        na[i] = sA[buf][(K) + lk4][wr * 64 + i * 16 + lcol];                                                               \
-        nb[i] = sB[buf][(K) + lk4][wc * 64 + i * 16 + lcol];                                                               \
-    }
-#else
         // row block mi of the wave holds candidate rows 4 r + mi (r = row inside the MFMA block), column block ni query columns
         // 4 c + ni: a lane's four A operands (and four B operands) of a k-step are 16 consecutive bytes of the k-major slab
 #define KGE_GEMM_READ(K)                                                                                                   \
@@ -1126,7 +1247,6 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
         na[0] = va.x; na[1] = va.y; na[2] = va.z; na[3] = va.w;                                                            \
         nb[0] = vb.x; nb[1] = vb.y; nb[2] = vb.z; nb[3] = vb.w;                                                            \
     }
-#endif
         KGE_GEMM_READ(0)
 #pragma unroll
         for (int kk = 0; kk < GKS; kk += 4) {
@@ -1135,16 +1255,10 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
             for (int i = 0; i < 4; ++i) { a4[i] = na[i]; b4[i] = nb[i]; }
             if (kk + 4 < GKS) KGE_GEMM_READ(kk + 4)
             KGE_KEEP_READS_AHEAD();
-#if KGE_GEMM_PRIO == 1
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi], b4[ni], acc[mi][ni], 0, 0, 0);
-#if KGE_GEMM_PRIO == 1
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
         buf ^= 1;
         if (++cu_sl != nslab) continue;
@@ -1153,11 +1267,8 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
         // registers per block are candidate rows 4 * lk4 + reg of block mi
         const int64_t ct = cu_ct;
         cu_ct += S;
-#ifdef KGE_GEMM_B32READS
-        const int e_base = (int)(ct * GT) + wr * 64 + 4 * lk4;   // candidate ids fit 31 bits (packed keys: < 2^24)
-#else
-        const int e_base = (int)(ct * GT) + wr * 64 + 16 * lk4;  // MFMA block row 4 lk4 + reg of block mi = candidate row 4 (4 lk4 + reg) + mi
-#endif
+        // candidate ids fit 31 bits (packed keys: < 2^24); MFMA block row 4 lk4 + reg of block mi = candidate row 4 (4 lk4 + reg) + mi
+        const int e_base = (int)(ct * GT) + wr * 64 + 16 * lk4;
         const int e_lim = (int)E;
         const bool full = ct * GT + GT <= E && (ct * 2 + 1 < ntiles64);
         const int e_pad = (int)(ntiles64 * 64);
@@ -1165,11 +1276,7 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-#ifdef KGE_GEMM_B32READS
-                const int e = e_base + mi * 16 + reg;
-#else
                 const int e = e_base + 4 * reg + mi;
-#endif
                 float cn2 = 0.f;
                 if constexpr (SQM) cn2 = e < e_pad ? cn[e] : 0.f;
 #pragma unroll
@@ -1311,9 +1418,11 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
             if (SQM)   // |q|^2 per query (p.qscale is free in this form); |c|^2 per candidate was left in p.aux by k_eval_prepare
                 hipLaunchKernelGGL(k_eval_qnorm, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p.qvec, nq, p.Kpad, p.qscale);
             if (scores_out == nullptr) {
-                hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM, POST, true>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s,
-                                   p.cand, p.aux, p.qvec, p.qscale, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids,
-                                   head_off, head_ids, p.st, p.fcount, group_of_triple, p.table_stride);
+                PrepArgs pa;
+                fill_prep(m, p, &pa);
+                hipLaunchKernelGGL((k_eval_target_filter_chain<FORM, POST>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, pa, p.aux,
+                                   p.qvec, p.qscale, triples, p.n, p.Kpad, m->margin, tail_off, tail_ids, head_off, head_ids, p.st,
+                                   p.fcount);
                 hipLaunchKernelGGL((k_eval_gemm<false, POST, SQM>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
                                    nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, nullptr, p.qscale, p.aux, m->margin);
             } else {
@@ -1355,10 +1464,28 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     PrepArgs pa;
     fill_prep(m, p, &pa);
     pa.want_n2 = (p.form == F_SQM && p.xform == X_NONE && p.qT != nullptr && use_gemm_sweep(p, 2 * n)) ? 1 : 0;
+    bool vec = !pa.normalize && !pa.dot_tab;
+    for (int sg = 0; sg < pa.nseg; ++sg) vec = vec && pa.seg_dim[sg] % 4 == 0 && (uintptr_t)pa.seg[sg] % 16 == 0;
+    if (vec) {   // 16-byte re-layout, K split over grid.y
+        const int64_t nchunks = (p.Kpad + 127) / 128;
+        int64_t nky = min(nchunks, (2048 + p.ntiles - 1) / p.ntiles);
+        if (pa.want_n2 && nky > 1) {   // per-split partial norms borrow the (not yet written) query-tile buffer
+            const int64_t cap = (int64_t)((2 * n + 127) / 128) * p.Kpad * 128 / (p.ntiles * 64);
+            if (cap < nky) nky = cap;
+        }
+        if (nky < 1) nky = 1;
+        pa.kper = (int)((nchunks + nky - 1) / nky * 128);
+        nky = (p.Kpad + pa.kper - 1) / pa.kper;
+        float* part = (pa.want_n2 && nky > 1) ? p.qT : nullptr;
+        hipLaunchKernelGGL(k_eval_prepare4, dim3((unsigned)p.ntiles, (unsigned)nky), dim3(256), 0, s, pa, p.cand, p.aux, part);
+        if (part)
+            hipLaunchKernelGGL(k_eval_cnorm_parts, dim3((unsigned)((p.ntiles * 64 + 255) / 256)), dim3(256), 0, s, part, (int)nky,
+                               p.ntiles * 64, p.aux);
+    } else {
     // K split: only where nothing but the re-layout happens per element (no normalisation, no TransD dot product)
     int ksplit = 1;
-    if (!pa.normalize && !pa.dot_tab && p.Kpad >= 512 && p.ntiles < 1024) {
-        ksplit = (int)min((int64_t)(p.Kpad / 128), (1024 + p.ntiles - 1) / p.ntiles);
+    if (!pa.normalize && !pa.dot_tab) {
+        ksplit = (int)min((int64_t)((p.Kpad + 63) / 64), (4096 + p.ntiles - 1) / p.ntiles);
         if (ksplit < 1) ksplit = 1;
     }
     pa.kper = ((p.Kpad + ksplit - 1) / ksplit + 63) / 64 * 64;
@@ -1367,9 +1494,10 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     if (ksplit > 1 && pa.want_n2) {
         hipLaunchKernelGGL(k_eval_cnorm, dim3((unsigned)(p.ntiles * 16)), dim3(256), 0, s, pa, p.aux);   // 64 rows per tile, 4 per block
     }
+    }
     const DeviceModel dm = to_device_model(m);
     const unsigned qb = (unsigned)((n + 3) / 4);
-#define KGE_Q(MID) case MID: hipLaunchKernelGGL((k_eval_queries<MID>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale); break;
+#define KGE_Q(MID) case MID: hipLaunchKernelGGL((k_eval_queries<MID>), dim3((MID == KGE_TRANSE || MID == KGE_TRANSH || MID == KGE_TRANSD || MID == KGE_TRANSM) ? qb : (unsigned)n), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale); break;
     switch (m->model) {
         KGE_Q(KGE_TRANSE) KGE_Q(KGE_TRANSH) KGE_Q(KGE_TRANSD) KGE_Q(KGE_ROTATE) KGE_Q(KGE_DISTMULT)
         KGE_Q(KGE_COMPLEX) KGE_Q(KGE_ANALOGY) KGE_Q(KGE_RESCAL)
