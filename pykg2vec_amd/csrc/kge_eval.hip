@@ -127,6 +127,22 @@ __device__ __forceinline__ float prep_elem(const PrepArgs& a, int64_t e, int k) 
     return 0.f;
 }
 
+// address of element k of candidate row e (nullptr beyond the last table), without control flow: many of these are issued
+// back to back by k_eval_target_filter_chain
+__device__ __forceinline__ const float* prep_addr(const PrepArgs& a, int64_t e, int k) {
+    const float* ptr = nullptr;
+    int kk = k;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s < a.nseg) {
+            const bool in = kk >= 0 && kk < a.seg_dim[s];
+            ptr = in ? a.seg[s] + e * a.seg_dim[s] + kk : ptr;
+            kk -= a.seg_dim[s];
+        }
+    }
+    return ptr;
+}
+
 // one block = one tile of 64 candidates; 4 waves; each wave owns 16 candidates for the row reductions
 __global__ __launch_bounds__(256) void k_eval_prepare(PrepArgs a, float* __restrict__ cand, float* __restrict__ aux) {
     __shared__ float s_scale[64];
@@ -718,10 +734,10 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
 // one wave per query takes the true candidate and the query's known entities as a list of (query, candidate) pairs, fetches a
 // K chunk of up to PG candidate rows -- from the row-major tables the sweep layout was copied from (PrepArgs segments), 256
 // coalesced bytes per row and instruction, all in flight together -- into LDS, and PG lanes run their chains out of LDS.
-// PG x chunk = 2 048 elements: few pairs (the common case) take long chunks and few round trips, long lists 64 chains at once.
-constexpr int kChainElems = 2048;
+// PG x chunk = 1 024 elements: few pairs (the common case) take long chunks and few round trips, long lists 64 chains at once.
+constexpr int kChainElems = 1024;
 template <int FORM, int POST>
-__global__ __launch_bounds__(256) void k_eval_target_filter_chain(PrepArgs a, const float* __restrict__ aux,
+__global__ __launch_bounds__(256, 4) void k_eval_target_filter_chain(PrepArgs a, const float* __restrict__ aux,
                                                                   const float* __restrict__ qvec, const float* __restrict__ qnorm,
                                                                   const int64_t* __restrict__ triples, int64_t n, int Kpad, float margin,
                                                                   const int64_t* __restrict__ tail_off, const int32_t* __restrict__ tail_ids,
@@ -729,7 +745,7 @@ __global__ __launch_bounds__(256) void k_eval_target_filter_chain(PrepArgs a, co
                                                                   float* __restrict__ st, int32_t* __restrict__ fcount) {
     static_assert(FORM == F_NEGDOT || FORM == F_SQM, "chain order: plain dot-product based forms");
     __shared__ __attribute__((aligned(16))) float s_c[4][kChainElems + 4 * 64];   // [pair][chunk + 4]: rows 4 banks apart
-    __shared__ __attribute__((aligned(16))) float s_q[4][512];
+    __shared__ __attribute__((aligned(16))) float s_q[4][kChainElems / 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wv;
     if (qi >= 2 * n) return;
@@ -750,46 +766,66 @@ __global__ __launch_bounds__(256) void k_eval_target_filter_chain(PrepArgs a, co
         const int rem = np - base;
         const int lg = rem > 16 ? 6 : rem > 4 ? 4 : 2;   // log2 of the pairs of this group
         const int pg = min(1 << lg, rem);
-        const int lc = 11 - lg, ch = 1 << lc;             // chunk length: 512 / 128 / 32
+        const int lc = 10 - lg, ch = 1 << lc;             // chunk length: 256 / 64 / 16
         const int pitch = ch + 4;
         const int idx = base + lane;
         int e = truth;
         if (lane < pg && idx > 0) e = ids[b + idx - 1];
         float acc = 0.f;
-        for (int k0 = 0; k0 < Kpad; k0 += ch) {
-            const int total = pg << lc;
-            for (int t0 = 0; t0 < total; t0 += 64 * 8) {   // eight loads per lane in flight, then their LDS stores
-                float v[8];
+        const int total = pg << lc;
+        // a chunk's operands travel global -> registers -> LDS; the NEXT chunk's loads are issued before this chunk's chains
+        // run, so their round trip hides behind the (sequential) arithmetic
+        float v[16], qv[4];
+        const int total_u = __builtin_amdgcn_readfirstlane(total), lc_u = __builtin_amdgcn_readfirstlane(lc);
+        auto fetch = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int t = t0 + 64 * u + lane;
-                    const int pp = t >> lc, kk = k0 + (t & (ch - 1));
-                    const int ee = __shfl(e, pp & 63, 64);
-                    v[u] = (t < total && kk < a.K) ? prep_elem(a, ee, kk) : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int t = t0 + 64 * u + lane;
-                    if (t < total) sc[(t >> lc) * pitch + (t & (ch - 1))] = v[u];
+            for (int u = 0; u < 16; ++u) {
+                v[u] = 0.f;
+                if (64 * u < total_u) {   // (wave-uniform: a short list skips the address arithmetic of the unused slots)
+                    const int t = 64 * u + lane;
+                    const int kk = k0 + (t & (ch - 1));
+                    // chunks of >= 64 elements: the 64 lanes of one load read ONE pair's row -- scalar row base
+                    int ee = lc_u >= 6 ? __builtin_amdgcn_readlane(e, (64 * u) >> lc_u) : __shfl(e, (t >> lc_u) & 63, 64);
+                    asm volatile("" : "+v"(ee));   // (keeps 16 row addresses from being hoisted out of the chunk loop: 32 live registers)
+                    const float* src = prep_addr(a, ee, kk);
+                    if (t < total && src) v[u] = *src;
                 }
             }
-            for (int kk = lane; kk < ch; kk += 64) sq[kk] = k0 + kk < Kpad ? q[k0 + kk] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = 64 * u + lane;
+                qv[u] = (kk < ch && k0 + kk < Kpad) ? q[k0 + kk] : 0.f;
+            }
+        };
+        fetch(0);
+        for (int k0 = 0; k0 < Kpad; k0 += ch) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int t = 64 * u + lane;
+                if (64 * u < total_u && t < total) sc[(t >> lc) * pitch + (t & (ch - 1))] = v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = 64 * u + lane;
+                if (kk < ch) sq[kk] = qv[u];
+            }
+            if (k0 + ch < Kpad) fetch(k0 + ch);
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0);   // (this wave's LDS writes are visible to its chain lanes)
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only: this wave's LDS writes have landed; the prefetch stays in flight
             if (lane < pg) {
                 const float* cr = sc + lane * pitch;
                 const int nk = min(ch, Kpad - k0);   // Kpad is a multiple of 8
-                // (32 operands per LDS round trip: the reads of a block are issued together, then its 32 dependent fmas)
+                // (16 operands per LDS round trip: the reads of a block are issued together, then its 16 dependent fmas)
                 int kk = 0;
-                for (; kk + 32 <= nk; kk += 32) {
-                    float4 c4[8], q4[8];
+                for (; kk + 16 <= nk; kk += 16) {
+                    float4 c4[4], q4[4];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 4; ++u) {
                         c4[u] = *reinterpret_cast<const float4*>(cr + kk + 4 * u);
                         q4[u] = *reinterpret_cast<const float4*>(sq + kk + 4 * u);
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 4; ++u) {
                         acc = fmaf(c4[u].x, q4[u].x, acc); acc = fmaf(c4[u].y, q4[u].y, acc);
                         acc = fmaf(c4[u].z, q4[u].z, acc); acc = fmaf(c4[u].w, q4[u].w, acc);
                     }

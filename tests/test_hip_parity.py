@@ -808,7 +808,7 @@ GEMM_CASES = ["distmult", "complex", "complexn3", "analogy", "rescal", "cp", "si
 def test_matrix_core_sweep_scores_and_ranks(hip, name, monkeypatch):
     """k_eval_gemm (the dot-product sweep on the f32 matrix cores), forced on for the small golden tables: energies within
     the fp32 tolerance of the live reference's, integer ranks EXACT functions of the kernel's own energies (the target
-    energy comes from k_eval_target_filter<CHAIN>, which must round like the MFMA chain), and ranks against the
+    energy comes from k_eval_target_filter_chain, which must round like the MFMA chain), and ranks against the
     reference inside the score band."""
     from pykg2vec_amd import kernels as K
     from pykg2vec_amd.evaluator import Evaluator
@@ -830,6 +830,35 @@ def test_matrix_core_sweep_scores_and_ranks(hip, name, monkeypatch):
         assert (ranks[1, i], ranks[3, i]) == rt and (ranks[0, i], ranks[2, i]) == rh, (i, ranks[:, i], rt, rh)
     ref = np.stack([c.z["eval.rank_head"], c.z["eval.rank_tail"], c.z["eval.frank_head"], c.z["eval.frank_tail"]])
     assert_ranks_inside_band(name + "_gemm", ranks, ref, scores, c.test[:n])
+
+
+@pytest.mark.parametrize("model,d", [("distmult", 50), ("rotate", 50), ("complex", 52), ("rotate", 300), ("quate", 12)])
+def test_matrix_core_sweep_ranks_with_long_filter_lists(hip, model, d, monkeypatch):
+    """k_eval_target_filter_chain takes a query's (true candidate + known entities) list in groups of 4 / 16 / 64 pairs with
+    K chunks of 256 / 64 / 16: lists of every length class (empty ... > 128 known entities, the true candidate inside the
+    list), table widths that are not multiples of 4 (scalar re-layout path) and K that is no multiple of any chunk length.
+    Ranks must be exact functions of the sweep's own energies (k_eval_gemm and the chain kernel round alike)."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.evaluator import Evaluator
+    monkeypatch.setenv("KGE_EVAL_GEMM", "1")
+    rng = np.random.default_rng(5)
+    E, R, n = 300, 3, 280
+    P = ko.init_params(model, rng, tot_entity=E, tot_relation=R, hidden_size=d, margin=6.0)
+    # known tails per (h, r): h = 0 -> 150, h = 1 -> 70, h = 2 -> 17, h = 3 -> 5, then a random background
+    heavy = [(h, 0, t) for h, cnt in ((0, 150), (1, 70), (2, 17), (3, 5)) for t in rng.choice(E, size=cnt, replace=False)]
+    back = np.stack([rng.integers(E, size=2500), rng.integers(R, size=2500), rng.integers(E, size=2500)], 1)
+    known = np.concatenate([np.asarray(heavy, dtype=np.int64), back])
+    test = np.concatenate([np.asarray(heavy, dtype=np.int64)[::9][:40], back[:n - 40]])[:n]
+    hp = dict(hidden_size=d, lmbda=0.01, margin=6.0, alpha=1.0)
+    cfg = hip.make_config(E, R, hp, known, known[:8], test)
+    m = hip.model_from_params(model, P, hp, E, R)
+    ranks = Evaluator(m, cfg).rank_all(test, n).cpu().numpy()
+    scores = K.eval_sweep_scores(m.make_desc(), hip.dev(test)).cpu().numpy()
+    hr_t, tr_h = cfg.knowledge_graph.cache["hr_t"], cfg.knowledge_graph.cache["tr_h"]
+    assert max(len(v) for v in hr_t.values()) >= 150
+    for i, (h, r, t) in enumerate(test):
+        assert (ranks[1, i], ranks[3, i]) == ko.rank_from_scores(scores[2 * i], int(t), hr_t[(int(h), int(r))]), i
+        assert (ranks[0, i], ranks[2, i]) == ko.rank_from_scores(scores[2 * i + 1], int(h), tr_h[(int(t), int(r))]), i
 
 
 @pytest.mark.parametrize("model,E,d", [("distmult", 333, 100), ("complex", 1000, 36), ("distmult", 129, 8)])
