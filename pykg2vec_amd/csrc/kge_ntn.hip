@@ -13,6 +13,7 @@
 // MFMA operand maps: A: lane l holds A[i=l&31][k=l>>5]; B: lane l holds B[k=l>>5][j=l&31];
 // C/D: col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "kge_internal.h"
+#include <stdlib.h>
 
 namespace kge {
 
@@ -387,6 +388,435 @@ __global__ __launch_bounds__(256) void k_ntn_scatter(IdSplit h, IdSplit t,
     }
 }
 
+// ================================================================== large batches: the same contractions as dense GEMMs
+// W is ONE [k_r, d, d] tensor shared by all relations (pairwise.py:884-886), so for a large batch the bilinear term is a
+// plain GEMM with the batch as M:  X = H^ [n x d] * W_flat [d x (k_r d)],  bil[n][s] = <X[n][s,:], T^[n]>  (forward),
+// GT^ = sum_s gz_s o (H^ W_s), GH^ = sum_s gz_s o (T^ W_s^T) (K = k_r d with the row scaling folded into the A operand), and
+// gW_s = (gz_s o H^)^T T^ (K = the batch).  The tile-per-(32 triples, slice) kernels above re-read their operands from
+// global memory per MFMA and leave gW to one wave per 32 x 32 tile walking the whole batch; these keep the batch-side
+// operand of 128 triples in REGISTERS across all slices, stream W (or the batch, for gW) through LDS in 16-deep slabs and
+// run v_mfma_f32_16x16x4_f32 with 2 x NBJ accumulator blocks per wave.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int kBigRows = 128;   // triples per workgroup of k_ntn_rows: 4 waves x 2 row blocks of 16
+
+// NB column (or row) blocks of 16: a lane's operands for groups of four blocks are 16 consecutive bytes of an LDS row (then
+// 8, then 4), i.e. block b of a group of four holds elements 4 l + b.  at(b, l): element of lane-in-block l of block b.
+template <int NB> struct BlkMap {
+    static constexpr int G4 = NB / 4, G2 = (NB % 4) / 2, G1 = NB % 2;
+    __host__ __device__ static constexpr int at(int b, int l) {
+        return b < 4 * G4 ? 64 * (b / 4) + 4 * l + (b % 4) : b < 4 * G4 + 2 * G2 ? 64 * G4 + 2 * l + (b - 4 * G4) : 64 * G4 + 32 * G2 + l;
+    }
+};
+template <int NB>
+__device__ __forceinline__ void read_blocks(const float* __restrict__ rowp, int l, float (&b)[NB]) {
+    using M = BlkMap<NB>;
+#pragma unroll
+    for (int g = 0; g < M::G4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(rowp + 64 * g + 4 * l);
+        b[4 * g] = v.x; b[4 * g + 1] = v.y; b[4 * g + 2] = v.z; b[4 * g + 3] = v.w;
+    }
+    if constexpr (M::G2) {
+        const float2 v = *reinterpret_cast<const float2*>(rowp + 64 * M::G4 + 2 * l);
+        b[4 * M::G4] = v.x; b[4 * M::G4 + 1] = v.y;
+    }
+    if constexpr (M::G1) b[NB - 1] = rowp[64 * M::G4 + 32 * M::G2 + l];
+}
+
+// MODE 0: Z[n][s] = bil[n][s] (forward);  1: GT^ += sum_s gz_s (H^ W_s);  2: GH^ += sum_s gz_s (T^ W_s^T).
+// grid = (tiles of 128 triples, slice groups): a workgroup walks slices [s_lo, s_hi); with more than one slice group the
+// row gradients of the groups meet through float atomics (small batches only).
+// (two workgroups per CU; the forward of the widest shape parks 64 KB of T^ in LDS: one)
+template <int NBJ, int MODE>
+__global__ __launch_bounds__(256, (MODE == 0 && NBJ == 8) ? 1 : 2) void k_ntn_rows(const float* __restrict__ W, int64_t n, int d, int kr, int s_per, NtnWs w) {
+    constexpr int DP = 16 * NBJ, PITCH = DP + 4, NK = 4 * NBJ;
+    __shared__ __attribute__((aligned(16))) float sW[2][16][PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 15, lk = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * kBigRows + wave * 32;
+    const int s_lo = blockIdx.y * s_per, s_hi = min(kr, s_lo + s_per);
+    const float* __restrict__ X = MODE == 2 ? w.Tn : w.Hn;
+    // the batch-side operand of the wave's 32 triples, for every k-step: A[row = 16 rb + l][k = 4 ks + lk]
+    float a[2][NK];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int64_t row = row0 + 16 * rb + l;
+            const int k = 4 * ks + lk;
+            a[rb][ks] = (row < n && k < d) ? X[row * d + k] : 0.f;
+        }
+    // forward: the T^ elements the accumulators meet in the epilogue (C layout: row = 16 rb + 4 lk + reg, column at(cb, l)),
+    // parked in LDS in accumulator order -- one 16-byte read per accumulator block and slice instead of 8 NBJ live registers
+    __shared__ __attribute__((aligned(16))) float sT[MODE == 0 ? 4 : 1][MODE == 0 ? 2 * NBJ : 1][64][4];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < NBJ; ++cb) {
+                float4 v;
+                float* pv = reinterpret_cast<float*>(&v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t row = row0 + 16 * rb + 4 * lk + q;
+                    const int col = BlkMap<NBJ>::at(cb, l);
+                    pv[q] = (row < n && col < d) ? w.Tn[row * d + col] : 0.f;
+                }
+                *reinterpret_cast<float4*>(&sT[wave][rb * NBJ + cb][lane][0]) = v;   // (read back by the same lane only)
+            }
+    }
+    f32x4v acc[2][NBJ];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NBJ; ++cb) acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // slab (s, kb): rows k = 16 kb .. + 15 of B_s (B_s = W_s, or W_s^T for MODE 2), DP columns.  A thread's NBJ elements sit at a
+    // fixed per-thread offset + a scalar that depends on (kb, u) only: slab row kq, columns c0 + 16 u
+    //   MODE 0 / 1: kq = tid / 16, c0 = tid % 16: element W_s[16 kb + kq][c0 + 16 u]      (64 contiguous bytes per 16 threads)
+    //   MODE 2    : kq = tid % 16, c0 = tid / 16: element W_s[c0 + 16 u][16 kb + kq]      (the transposed read, same 64 bytes)
+    const int kq = MODE == 2 ? (threadIdx.x & 15) : (threadIdx.x >> 4), c0 = MODE == 2 ? (threadIdx.x >> 4) : (threadIdx.x & 15);
+    const int toff = MODE == 2 ? c0 * d + kq : kq * d + c0;
+    float st[NBJ];
+    auto fetch = [&](int s, int kb) __attribute__((always_inline)) {
+        const float* __restrict__ Ws = W + (int64_t)s * d * d + (MODE == 2 ? 16 * kb : 16 * kb * d);
+#pragma unroll
+        for (int u = 0; u < NBJ; ++u)
+            st[u] = (16 * kb + kq < d && c0 + 16 * u < d) ? Ws[toff + (MODE == 2 ? 16 * u * d : 16 * u)] : 0.f;
+    };
+    auto stash = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NBJ; ++u) sW[buf][kq][c0 + 16 * u] = st[u];
+    };
+    auto gz_of = [&](int s, int rb) __attribute__((always_inline)) {
+        const int64_t row = row0 + 16 * rb + l;
+        return (row < n && s < s_hi) ? w.GZ[row * kr + s] : 0.f;
+    };
+    int buf = 0;
+    if (s_lo < s_hi) fetch(s_lo, 0);
+    float gn0 = 0.f, gn1 = 0.f;
+    if constexpr (MODE != 0) { gn0 = gz_of(s_lo, 0); gn1 = gz_of(s_lo, 1); }
+    for (int s = s_lo; s < s_hi; ++s) {
+        const float g0 = gn0, g1 = gn1;
+        if constexpr (MODE != 0) { gn0 = gz_of(s + 1, 0); gn1 = gz_of(s + 1, 1); }   // next slice's row scales, a slice ahead
+#pragma unroll
+        for (int kb = 0; kb < NBJ; ++kb) {
+            stash(buf);
+            __syncthreads();   // slab (s, kb) is in LDS; everybody finished reading the buffer that is written next
+            if (kb + 1 < NBJ) fetch(s, kb + 1);
+            else if (s + 1 < s_hi) fetch(s + 1, 0);
+            // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued (register double buffer)
+            float b[2][NBJ];
+            read_blocks<NBJ>(&sW[buf][lk][0], l, b[0]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk + 1 < 4) read_blocks<NBJ>(&sW[buf][4 * (kk + 1) + lk][0], l, b[(kk + 1) & 1]);
+                KGE_KEEP_READS_AHEAD();
+                float a0 = a[0][4 * kb + kk], a1 = a[1][4 * kb + kk];
+                if constexpr (MODE != 0) { a0 *= g0; a1 *= g1; }
+#pragma unroll
+                for (int cb = 0; cb < NBJ; ++cb) {
+                    acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[kk & 1][cb], acc[0][cb], 0, 0, 0);
+                    acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[kk & 1][cb], acc[1][cb], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+        if constexpr (MODE == 0) {   // bil[row][s] = <X_s[row], T^[row]>: per-lane partial over its columns, then the 16 lanes of a row
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cb = 0; cb < NBJ; ++cb) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(&sT[wave][rb * NBJ + cb][lane][0]);
+                    p[0] = fmaf(acc[rb][cb][0], t4.x, p[0]); p[1] = fmaf(acc[rb][cb][1], t4.y, p[1]);
+                    p[2] = fmaf(acc[rb][cb][2], t4.z, p[2]); p[3] = fmaf(acc[rb][cb][3], t4.w, p[3]);
+                    acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t = p[q];
+                    t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                    const int64_t row = row0 + 16 * rb + 4 * lk + q;
+                    if (l == 0 && row < n) w.Z[row * kr + s] = t;
+                }
+            }
+        }
+    }
+    if constexpr (MODE != 0) {
+        float* __restrict__ out = MODE == 1 ? w.GT : w.GH;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < NBJ; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t row = row0 + 16 * rb + 4 * lk + q;
+                    const int col = BlkMap<NBJ>::at(cb, l);
+                    if (row < n && col < d) {
+                        if (gridDim.y == 1) out[row * d + col] += acc[rb][cb][q];   // single writer
+                        else unsafeAtomicAdd(out + row * d + col, acc[rb][cb][q]);
+                    }
+                }
+    }
+}
+
+// out[i][j] += sum over the rows n of a batch chunk of A[n][i] B[n][j] (K = the batch), split-K over blockIdx.x:
+//   MODE 0: gW_s (s = blockIdx.y): A = gz[:, s] o H^, B = T^;   MODE 1: gM1: A = H^, B = gz;   MODE 2: gM2: A = T^, B = gz.
+// Row block b of the output goes to wave b % 4 (natural row order: an A operand is one 4-byte LDS read per block).
+template <int NBI, int NBJ, int MODE>
+__global__ __launch_bounds__(256) void k_ntn_outer(float* __restrict__ out, int64_t n, int d, int kr, int64_t rows_per, NtnWs w) {
+    constexpr int DPI = 16 * NBI, DPJ = 16 * NBJ, PA = DPI + 4, PB = DPJ + 4;
+    constexpr int RBW = (NBI + 3) / 4;   // row blocks per wave
+    __shared__ __attribute__((aligned(16))) float sA[2][16][PA], sB[2][16][PB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 15, lk = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * rows_per, n1 = min(n, n0 + rows_per);
+    const int s = blockIdx.y;
+    const float* __restrict__ Asrc = MODE == 2 ? w.Tn : w.Hn;
+    const float* __restrict__ Bsrc = MODE == 0 ? w.Tn : w.GZ;
+    const int ni = d, nj = MODE == 0 ? d : kr;   // rows / columns of the output
+    f32x4v acc[RBW][NBJ];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NBJ; ++cb) acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // staging roles: slab row kq = tid / 16 (a batch row), columns c0 + 16 u
+    const int kq = threadIdx.x >> 4, c0 = threadIdx.x & 15;
+    float sta[NBI], stb[NBJ], stg = 1.f;
+    auto fetch = [&](int64_t r0) __attribute__((always_inline)) {
+        const int64_t row = r0 + kq;
+        const bool live = row < n1;
+        if constexpr (MODE == 0) stg = live ? w.GZ[row * kr + s] : 0.f;
+        const float* __restrict__ ar = Asrc + row * d + c0;
+        const float* __restrict__ br = Bsrc + row * nj + c0;
+#pragma unroll
+        for (int u = 0; u < NBI; ++u) sta[u] = (live && c0 + 16 * u < ni) ? ar[16 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < NBJ; ++u) stb[u] = (live && c0 + 16 * u < nj) ? br[16 * u] : 0.f;
+    };
+    auto stash = [&](int buf) __attribute__((always_inline)) {   // (the row scale is applied HERE: a multiply inside fetch would wait for the loads)
+#pragma unroll
+        for (int u = 0; u < NBI; ++u) sA[buf][kq][c0 + 16 * u] = MODE == 0 ? sta[u] * stg : sta[u];
+#pragma unroll
+        for (int u = 0; u < NBJ; ++u) sB[buf][kq][c0 + 16 * u] = stb[u];
+    };
+    int buf = 0;
+    if (n0 < n1) fetch(n0);
+    for (int64_t r0 = n0; r0 < n1; r0 += 16) {
+        stash(buf);
+        __syncthreads();
+        if (r0 + 16 < n1) fetch(r0 + 16);
+        // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued (register double buffer)
+        float b[2][NBJ], av[2][RBW];
+        auto operands = [&](int kk, int slot) __attribute__((always_inline)) {
+            read_blocks<NBJ>(&sB[buf][4 * kk + lk][0], l, b[slot]);
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) av[slot][rb] = wave + 4 * rb < NBI ? sA[buf][4 * kk + lk][16 * (wave + 4 * rb) + l] : 0.f;
+        };
+        operands(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk + 1 < 4) operands(kk + 1, (kk + 1) & 1);
+            KGE_KEEP_READS_AHEAD();
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) {
+                if (wave + 4 * rb < NBI) {   // wave-uniform
+#pragma unroll
+                    for (int cb = 0; cb < NBJ; ++cb)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk & 1][rb], b[kk & 1][cb], acc[rb][cb], 0, 0, 0);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    float* __restrict__ o = out + (MODE == 0 ? (int64_t)s * d * d : 0);
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+        if (wave + 4 * rb >= NBI) continue;
+#pragma unroll
+        for (int cb = 0; cb < NBJ; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * (wave + 4 * rb) + 4 * lk + q, j = BlkMap<NBJ>::at(cb, l);
+                if (i < ni && j < nj) {
+                    if (gridDim.x == 1) o[(int64_t)i * nj + j] += acc[rb][cb][q];
+                    else unsafeAtomicAdd(o + (int64_t)i * nj + j, acc[rb][cb][q]);
+                }
+            }
+    }
+}
+
+// gb[s] += sum_n gz[n][s]: 128 rows per workgroup, thread = (slice, row phase)
+__global__ __launch_bounds__(256) void k_ntn_gb(float* __restrict__ gb, int64_t n, int kr, NtnWs w) {
+    const int64_t r0 = (int64_t)blockIdx.x * 128, r1 = min(n, r0 + 128);
+    for (int s = threadIdx.x; s < kr; s += 256) {
+        double t = 0.0;   // (the workgroup's 128 terms without rounding; the float atomics then add n / 128 partials)
+#pragma unroll 8
+        for (int64_t r = r0; r < r1; ++r) t += (double)w.GZ[r * kr + s];
+        unsafeAtomicAdd(gb + s, (float)t);
+    }
+}
+
+// The two [d, k_r] linear maps as GEMMs with the batch as M (NB = blocks of 16 covering max(d, k_r)):
+//   MODE 0 (forward):  Z[n][s] += (H^ M1)[n][s] + (T^ M2)[n][s]          two passes, K = d, B[k][col] = M[k][col]
+//   MODE 1 (backward): out[n][c] = sum_s gz[n][s] M[c][s]                 K = k_r, B[k][col] = M[col][k]  (out = GH^ with M1, GT^ with M2)
+template <int NB, int MODE>
+__global__ __launch_bounds__(256, 2) void k_ntn_lin(const float* __restrict__ Ma, const float* __restrict__ Mb, float* __restrict__ out,
+                                                    int64_t n, int d, int kr, NtnWs w) {
+    constexpr int DP = 16 * NB, PITCH = DP + 4, NK = 4 * NB;
+    __shared__ __attribute__((aligned(16))) float sW[2][16][PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 15, lk = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * kBigRows + wave * 32;
+    const int K = MODE == 0 ? d : kr, N = MODE == 0 ? kr : d;
+    f32x4v acc[2][NB];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int kq = MODE == 1 ? (threadIdx.x & 15) : (threadIdx.x >> 4), c0 = MODE == 1 ? (threadIdx.x >> 4) : (threadIdx.x & 15);
+    const int toff = MODE == 1 ? c0 * kr + kq : kq * kr + c0;   // both matrices are [d][k_r] row-major
+    int buf = 0;
+    for (int pass = 0; pass < (MODE == 0 ? 2 : 1); ++pass) {
+        const float* __restrict__ X = MODE == 1 ? w.GZ : pass == 0 ? w.Hn : w.Tn;
+        const float* __restrict__ M = pass == 0 ? Ma : Mb;
+        float a[2][NK];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int64_t row = row0 + 16 * rb + l;
+                const int k = 4 * ks + lk;
+                a[rb][ks] = (row < n && k < K) ? X[row * K + k] : 0.f;
+            }
+        float st[NB];
+        auto fetch = [&](int kb) __attribute__((always_inline)) {
+            const float* __restrict__ Ms = M + (MODE == 1 ? 16 * kb : 16 * kb * kr);
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                st[u] = (16 * kb + kq < K && c0 + 16 * u < N) ? Ms[toff + (MODE == 1 ? 16 * u * kr : 16 * u)] : 0.f;
+        };
+        fetch(0);
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) sW[buf][kq][c0 + 16 * u] = st[u];
+            __syncthreads();
+            if (kb + 1 < NB) fetch(kb + 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float b[NB];
+                read_blocks<NB>(&sW[buf][4 * kk + lk][0], l, b);
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) {
+                    acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][4 * kb + kk], b[cb], acc[0][cb], 0, 0, 0);
+                    acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][4 * kb + kk], b[cb], acc[1][cb], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t row = row0 + 16 * rb + 4 * lk + q;
+                const int col = BlkMap<NB>::at(cb, l);
+                if (row < n && col < N) {
+                    if constexpr (MODE == 0) out[row * N + col] += acc[rb][cb][q];
+                    else out[row * N + col] = acc[rb][cb][q];
+                }
+            }
+}
+
+// what is left of k_ntn_finish / k_ntn_gz once the linear maps are GEMMs: one wave per triple, element-wise over the slices
+__global__ __launch_bounds__(256) void k_ntn_finish_ew(const float* __restrict__ b, int64_t n, int kr, NtnWs w, float* __restrict__ scores) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float tot = 0.f;
+    for (int s = lane; s < kr; s += 64) {
+        const float z = tanhf(w.Z[i * kr + s] + b[s]);
+        w.Z[i * kr + s] = z;
+        tot = fmaf(w.Rn[i * kr + s], z, tot);
+    }
+    tot = wave_sum(tot);
+    if (lane == 0 && scores) scores[i] = -tot;
+}
+__global__ __launch_bounds__(256) void k_ntn_gz_ew(IdSplit r, const float* __restrict__ dscore, float* __restrict__ g_rel, int64_t n, int kr, NtnWs w) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float ds = dscore[i];
+    float dot = 0.f;
+    for (int s = lane; s < kr; s += 64) {
+        const float z = w.Z[i * kr + s], rn = w.Rn[i * kr + s];
+        w.GZ[i * kr + s] = -ds * rn * (1.f - z * z);
+        dot = fmaf(rn, -ds * z, dot);
+    }
+    dot = wave_sum(dot);
+    if (ds == 0.f) return;
+    const float ir = w.inv[3 * i + 2];
+    const bool fr = w.flag[3 * i + 2] != 0.f;
+    float* gr = g_rel + r.at(i) * kr;
+    for (int s = lane; s < kr; s += 64) {
+        const float g = -ds * w.Z[i * kr + s];
+        unsafeAtomicAdd(gr + s, fr ? (g - w.Rn[i * kr + s] * dot) * ir : g * ir);
+    }
+}
+
+template <int MODE>
+static void launch_ntn_lin(const float* Ma, const float* Mb, float* out, int64_t n, int d, int kr, const NtnWs& w, hipStream_t s) {
+    const int nb = (max(d, kr) + 15) / 16;
+    const dim3 grid((unsigned)((n + kBigRows - 1) / kBigRows));
+#define KGE_NTN_LIN(J) case J: hipLaunchKernelGGL((k_ntn_lin<J, MODE>), grid, dim3(256), 0, s, Ma, Mb, out, n, d, kr, w); break;
+    switch (nb) { KGE_NTN_LIN(1) KGE_NTN_LIN(2) KGE_NTN_LIN(3) KGE_NTN_LIN(4) KGE_NTN_LIN(5) KGE_NTN_LIN(6) KGE_NTN_LIN(7) KGE_NTN_LIN(8) }
+#undef KGE_NTN_LIN
+}
+
+// the GEMM forms pay off once the batch fills the chip with 128-triple tiles; d and k_r up to 128 (8 blocks of 16)
+static bool ntn_big_ok(int64_t n, int d, int kr) {
+    if (d > 128 || kr > 128) return false;
+    const char* force = getenv("KGE_NTN_BIG");   // A/B and tests: 0 / 1 (read per call, like KGE_EVAL_GEMM)
+    if (force) return force[0] == '1';
+    return n >= 8192;
+}
+static int ntn_slices_per_group(int64_t n, int kr) {
+    const int64_t tiles = (n + kBigRows - 1) / kBigRows;
+    int64_t groups = (512 + tiles - 1) / tiles;   // >= 512 workgroups (two per CU) where the batch alone does not give them
+    if (groups > kr) groups = kr;
+    if (groups < 1) groups = 1;
+    return (int)((kr + groups - 1) / groups);
+}
+
+template <int MODE>
+static void launch_ntn_rows(const float* W, int64_t n, int d, int kr, const NtnWs& w, hipStream_t s) {
+    const int nbj = (d + 15) / 16;
+    const int s_per = ntn_slices_per_group(n, kr);
+    const dim3 grid((unsigned)((n + kBigRows - 1) / kBigRows), (unsigned)((kr + s_per - 1) / s_per));
+#define KGE_NTN_ROWS(J) case J: hipLaunchKernelGGL((k_ntn_rows<J, MODE>), grid, dim3(256), 0, s, W, n, d, kr, s_per, w); break;
+    switch (nbj) { KGE_NTN_ROWS(1) KGE_NTN_ROWS(2) KGE_NTN_ROWS(3) KGE_NTN_ROWS(4) KGE_NTN_ROWS(5) KGE_NTN_ROWS(6) KGE_NTN_ROWS(7) KGE_NTN_ROWS(8) }
+#undef KGE_NTN_ROWS
+}
+
+template <int NBI, int MODE>
+static void launch_ntn_outer_j(float* out, int64_t n, int d, int kr, int nbj, dim3 grid, int64_t rows_per, const NtnWs& w, hipStream_t s) {
+#define KGE_NTN_OUTER(J) case J: hipLaunchKernelGGL((k_ntn_outer<NBI, J, MODE>), grid, dim3(256), 0, s, out, n, d, kr, rows_per, w); break;
+    switch (nbj) { KGE_NTN_OUTER(1) KGE_NTN_OUTER(2) KGE_NTN_OUTER(3) KGE_NTN_OUTER(4) KGE_NTN_OUTER(5) KGE_NTN_OUTER(6) KGE_NTN_OUTER(7) KGE_NTN_OUTER(8) }
+#undef KGE_NTN_OUTER
+}
+template <int MODE>
+static void launch_ntn_outer(float* out, int64_t n, int d, int kr, const NtnWs& w, hipStream_t s) {
+    const int nbi = (d + 15) / 16, nbj = ((MODE == 0 ? d : kr) + 15) / 16;
+    const int64_t slices = MODE == 0 ? kr : 1;
+    int64_t chunks = (1024 + slices - 1) / slices;               // >= 1 024 workgroups
+    int64_t rows_per = ((n + chunks - 1) / chunks + 15) / 16 * 16;
+    if (rows_per < 256) rows_per = 256;                          // (a chunk amortises its k^2 atomics over >= 16 slabs)
+    chunks = (n + rows_per - 1) / rows_per;
+    const dim3 grid((unsigned)chunks, (unsigned)slices);
+#define KGE_NTN_OUTER_I(I) case I: launch_ntn_outer_j<I, MODE>(out, n, d, kr, nbj, grid, rows_per, w, s); break;
+    switch (nbi) { KGE_NTN_OUTER_I(1) KGE_NTN_OUTER_I(2) KGE_NTN_OUTER_I(3) KGE_NTN_OUTER_I(4) KGE_NTN_OUTER_I(5) KGE_NTN_OUTER_I(6) KGE_NTN_OUTER_I(7) KGE_NTN_OUTER_I(8) }
+#undef KGE_NTN_OUTER_I
+}
+
 // ---- host
 static int ntn_check(const kge_model_desc* m, int64_t n, void* ws, size_t ws_bytes) {
     if (m->dim > 256 || m->rel_dim > 1024) { set_error("NTN: ent_hidden_size <= 256 and rel_hidden_size <= 1024 supported"); return -1; }
@@ -402,9 +832,16 @@ static int ntn_forward_core(const kge_model_desc* m, IdSplit h, IdSplit r, IdSpl
     const int d = m->dim, kr = m->rel_dim;
     const unsigned rows4 = (unsigned)((n + 3) / 4), tiles = (unsigned)((n + NT - 1) / NT);
     hipLaunchKernelGGL(k_ntn_prep, dim3(rows4), dim3(256), 0, s, m->tables[0], m->tables[1], h, r, t, n, d, kr, w);
-    const int S = (d + 1) | 1;
-    const size_t lds = (size_t)(2 * NT * S + 4 * NT) * sizeof(float);
-    hipLaunchKernelGGL(k_ntn_bil, dim3(tiles, (unsigned)kr), dim3(256), lds, s, m->tables[5], n, d, kr, w);
+    if (ntn_big_ok(n, d, kr)) {
+        launch_ntn_rows<0>(m->tables[5], n, d, kr, w, s);
+        launch_ntn_lin<0>(m->tables[2], m->tables[3], w.Z, n, d, kr, w, s);
+        hipLaunchKernelGGL(k_ntn_finish_ew, dim3(rows4), dim3(256), 0, s, m->tables[4], n, kr, w, scores);
+        return check_launch("ntn forward");
+    } else {
+        const int S = (d + 1) | 1;
+        const size_t lds = (size_t)(2 * NT * S + 4 * NT) * sizeof(float);
+        hipLaunchKernelGGL(k_ntn_bil, dim3(tiles, (unsigned)kr), dim3(256), lds, s, m->tables[5], n, d, kr, w);
+    }
     hipLaunchKernelGGL(k_ntn_finish, dim3((unsigned)n), dim3(256), 0, s, m->tables[2], m->tables[3], m->tables[4], n, d, kr, w,
                        scores);
     return check_launch("ntn forward");
@@ -449,6 +886,19 @@ static int ntn_backward_core(const kge_model_desc* m, IdSplit h, IdSplit r, IdSp
         if (rc) return rc;
     }
     const unsigned rows4 = (unsigned)((n + 3) / 4), tiles = (unsigned)((n + NT - 1) / NT);
+    if (ntn_big_ok(n, d, kr)) {
+        hipLaunchKernelGGL(k_ntn_gz_ew, dim3(rows4), dim3(256), 0, s, r, dscore, m->grads[1], n, kr, w);
+        launch_ntn_lin<1>(m->tables[2], nullptr, w.GH, n, d, kr, w, s);
+        launch_ntn_lin<1>(m->tables[3], nullptr, w.GT, n, d, kr, w, s);
+        launch_ntn_outer<1>(m->grads[2], n, d, kr, w, s);
+        launch_ntn_outer<2>(m->grads[3], n, d, kr, w, s);
+        hipLaunchKernelGGL(k_ntn_gb, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, s, m->grads[4], n, kr, w);
+        launch_ntn_rows<1>(m->tables[5], n, d, kr, w, s);
+        launch_ntn_rows<2>(m->tables[5], n, d, kr, w, s);
+        launch_ntn_outer<0>(m->grads[5], n, d, kr, w, s);
+        hipLaunchKernelGGL(k_ntn_scatter, dim3(rows4), dim3(256), 0, s, h, t, dscore, m->grads[0], n, d, w);
+        return check_launch("ntn backward");
+    }
     hipLaunchKernelGGL(k_ntn_gz, dim3(rows4), dim3(256), (size_t)4 * kr * sizeof(float), s, m->tables[2], m->tables[3], r,
                        dscore, m->grads[1], n, d, kr, w);
     hipLaunchKernelGGL(k_ntn_small, dim3((unsigned)(((int64_t)(d + 1) * kr + 255) / 256)), dim3(256), 0, s, m->grads[2],
