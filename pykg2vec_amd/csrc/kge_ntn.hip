@@ -565,7 +565,8 @@ template <int NBI, int NBJ, int MODE>
 __global__ __launch_bounds__(256) void k_ntn_outer(float* __restrict__ out, int64_t n, int d, int kr, int64_t rows_per, NtnWs w) {
     constexpr int DPI = 16 * NBI, DPJ = 16 * NBJ, PA = DPI + 4, PB = DPJ + 4;
     constexpr int RBW = (NBI + 3) / 4;   // row blocks per wave
-    __shared__ __attribute__((aligned(16))) float sA[2][16][PA], sB[2][16][PB];
+    constexpr int SK = 16, SH = SK / 16;   // batch rows per slab (32 -- half the barriers -- measured 3 % slower for gW)
+    __shared__ __attribute__((aligned(16))) float sA[2][SK][PA], sB[2][SK][PB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 15, lk = lane >> 4;
     const int64_t n0 = (int64_t)blockIdx.x * rows_per, n1 = min(n, n0 + rows_per);
     const int s = blockIdx.y;
@@ -577,32 +578,39 @@ __global__ __launch_bounds__(256) void k_ntn_outer(float* __restrict__ out, int6
     for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
         for (int cb = 0; cb < NBJ; ++cb) acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    // staging roles: slab row kq = tid / 16 (a batch row), columns c0 + 16 u
+    // staging roles: slab rows kq + 16 h (batch rows), columns c0 + 16 u
     const int kq = threadIdx.x >> 4, c0 = threadIdx.x & 15;
-    float sta[NBI], stb[NBJ], stg = 1.f;
+    float sta[SH][NBI], stb[SH][NBJ], stg[SH];
     auto fetch = [&](int64_t r0) __attribute__((always_inline)) {
-        const int64_t row = r0 + kq;
-        const bool live = row < n1;
-        if constexpr (MODE == 0) stg = live ? w.GZ[row * kr + s] : 0.f;
-        const float* __restrict__ ar = Asrc + row * d + c0;
-        const float* __restrict__ br = Bsrc + row * nj + c0;
 #pragma unroll
-        for (int u = 0; u < NBI; ++u) sta[u] = (live && c0 + 16 * u < ni) ? ar[16 * u] : 0.f;
+        for (int h = 0; h < SH; ++h) {
+            const int64_t row = r0 + kq + 16 * h;
+            const bool live = row < n1;
+            stg[h] = 1.f;
+            if constexpr (MODE == 0) stg[h] = live ? w.GZ[row * kr + s] : 0.f;
+            const float* __restrict__ ar = Asrc + row * d + c0;
+            const float* __restrict__ br = Bsrc + row * nj + c0;
 #pragma unroll
-        for (int u = 0; u < NBJ; ++u) stb[u] = (live && c0 + 16 * u < nj) ? br[16 * u] : 0.f;
+            for (int u = 0; u < NBI; ++u) sta[h][u] = (live && c0 + 16 * u < ni) ? ar[16 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < NBJ; ++u) stb[h][u] = (live && c0 + 16 * u < nj) ? br[16 * u] : 0.f;
+        }
     };
     auto stash = [&](int buf) __attribute__((always_inline)) {   // (the row scale is applied HERE: a multiply inside fetch would wait for the loads)
 #pragma unroll
-        for (int u = 0; u < NBI; ++u) sA[buf][kq][c0 + 16 * u] = MODE == 0 ? sta[u] * stg : sta[u];
+        for (int h = 0; h < SH; ++h) {
 #pragma unroll
-        for (int u = 0; u < NBJ; ++u) sB[buf][kq][c0 + 16 * u] = stb[u];
+            for (int u = 0; u < NBI; ++u) sA[buf][kq + 16 * h][c0 + 16 * u] = MODE == 0 ? sta[h][u] * stg[h] : sta[h][u];
+#pragma unroll
+            for (int u = 0; u < NBJ; ++u) sB[buf][kq + 16 * h][c0 + 16 * u] = stb[h][u];
+        }
     };
     int buf = 0;
     if (n0 < n1) fetch(n0);
-    for (int64_t r0 = n0; r0 < n1; r0 += 16) {
+    for (int64_t r0 = n0; r0 < n1; r0 += SK) {
         stash(buf);
         __syncthreads();
-        if (r0 + 16 < n1) fetch(r0 + 16);
+        if (r0 + SK < n1) fetch(r0 + SK);
         // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued (register double buffer)
         float b[2][NBJ], av[2][RBW];
         auto operands = [&](int kk, int slot) __attribute__((always_inline)) {
@@ -612,8 +620,8 @@ __global__ __launch_bounds__(256) void k_ntn_outer(float* __restrict__ out, int6
         };
         operands(0, 0);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk + 1 < 4) operands(kk + 1, (kk + 1) & 1);
+        for (int kk = 0; kk < SK / 4; ++kk) {
+            if (kk + 1 < SK / 4) operands(kk + 1, (kk + 1) & 1);
             KGE_KEEP_READS_AHEAD();
 #pragma unroll
             for (int rb = 0; rb < RBW; ++rb) {
@@ -808,6 +816,9 @@ static void launch_ntn_outer(float* out, int64_t n, int d, int kr, const NtnWs& 
     const int nbi = (d + 15) / 16, nbj = ((MODE == 0 ? d : kr) + 15) / 16;
     const int64_t slices = MODE == 0 ? kr : 1;
     int64_t chunks = (1024 + slices - 1) / slices;               // >= 1 024 workgroups
+    // blockIdx.x = chunk, and workgroups go to XCD (flat id % 8): with a multiple of 8 chunks every workgroup of a chunk -- all
+    // slices, which stream the SAME batch rows -- runs on one XCD and shares its L2
+    if (chunks > 8) chunks = (chunks + 7) / 8 * 8;
     int64_t rows_per = ((n + chunks - 1) / chunks + 15) / 16 * 16;
     if (rows_per < 256) rows_per = 256;                          // (a chunk amortises its k^2 atomics over >= 16 slabs)
     chunks = (n + rows_per - 1) / rows_per;
