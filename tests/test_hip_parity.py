@@ -289,7 +289,7 @@ def test_scores_loss_grads_vs_oracle_other_shapes(hip, model, hp, neg_rate):
 @pytest.mark.parametrize("d,kr,B", [(100, 100, 300), (40, 33, 70), (50, 7, 129), (128, 128, 64), (17, 1, 200), (96, 64, 1100)])
 def test_ntn_gemm_forms_vs_oracle(hip, d, kr, B, monkeypatch):
     """The large-batch NTN kernels (k_ntn_rows / k_ntn_outer: batch-as-M GEMMs on v_mfma_f32_16x16x4_f32, default from
-    8 192 rows on), forced on for oracle-sized batches: every block-count instantiation class (1 ... 8 blocks of 16, widths
+    1 024 rows on), forced on for oracle-sized batches: every block-count instantiation class (1 ... 8 blocks of 16, widths
     that are not multiples of 4 or 16), partial 128-triple tiles, several slice groups and split-K chunks."""
     monkeypatch.setenv("KGE_NTN_BIG", "1")
     # (the bias gradient is a sum of 2 B terms of either sign: its fp32 error against the float64 oracle grows with the batch,

@@ -59,6 +59,11 @@ CONFIGS = [
     ("mfma-batch RESCAL FB15k k=200 B=32768 adam", "rescal", "fb15k", dict(hidden_size=200, margin=1.0), "adam", 32768, 1, 0),
     ("mfma-batch TransR FB15k 100/100 B=32768 adam", "transr", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 0),
     ("mfma-batch NTN FB15k d=k=100 B=32768 adam", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 32768, 1, 0),
+    ("ntn-mid NTN FB15k d=k=100 B=512 adam", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 512, 1, 0),
+    ("ntn-mid NTN FB15k d=k=100 B=1024 adam", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 1024, 1, 0),
+    ("ntn-mid NTN FB15k d=k=100 B=2048 adam", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 2048, 1, 0),
+    ("ntn-mid NTN FB15k d=k=100 B=4096 adam", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 4096, 1, 0),
+    ("ntn-mid NTN FB15k d=k=100 B=8192 adam", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 8192, 1, 0),
     ("NTN FB15k d=k=100 B=128 adam (preset)", "ntn", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, lmbda=1e-4, margin=1.0), "adam", 128, 1, 64),
 ]
 if os.environ.get("GRAPH_UNROLL"):
