@@ -77,7 +77,8 @@ def test_staged_training_is_bit_reproducible(hip, monkeypatch):
     for _ in range(2):
         tr, m = _trainer(hip, world, E, R, D, B, neg, "adam", True, monkeypatch)
         out.append(_run(tr, m, hip, 3))
-    assert out[0][0] == out[1][0]
+    # (the reported loss is a float-atomic sum: equal up to the order of those additions; tables involve no atomics)
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-6), (out[0][0], out[1][0])
     for k in out[0][1]:
         assert torch.equal(out[0][1][k], out[1][1][k]), k
 
