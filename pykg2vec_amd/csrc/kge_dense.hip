@@ -15,6 +15,9 @@
 // B[k=l>>5][j=l&31]; C/D: col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "kge_internal.h"
 #include "kge_relgroup.h"
+#include "kge_mfma_blocks.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace kge {
 
@@ -905,6 +908,160 @@ __global__ __launch_bounds__(1024) void k_rescal_pair_gm(const float* __restrict
     }
 }
 
+// Large batches, second form of the pair step: V = H M_r and U = T M_r^T as GEMMs with the rows of 32 pairs (64 triples, two
+// consecutive 16-pair tiles of one relation) as M, the way kge_ntn.hip treats NTN's shared tensor.  A wave owns 8 pairs = one
+// 16-row block (rows 2 p and 2 p + 1: a pair's positive and its negative, so both energies of a pair meet in ONE lane of the
+// accumulator layout and the hinge is a few register operations); its rows' H (then T) operand lives in registers for the whole
+// pass, M_r streams through LDS in 16-deep slabs (transposed while staging for U), v_mfma_f32_16x16x4_f32 with NB accumulator
+// blocks per wave.  Entity gradients leave through float atomics as in k_rescal_pair (the uncorrupted side of a pair: one merged
+// atomic); dL/denergy goes to ds_out for k_rescal_pair_gm.  k <= 16 NB, any k.
+template <int NB>
+__global__ __launch_bounds__(256, 2) void k_rescal_rows(const float* __restrict__ ent, const float* __restrict__ relm,
+                                                        float* __restrict__ g_ent, const int64_t* __restrict__ ph,
+                                                        const int64_t* __restrict__ pt, const int64_t* __restrict__ nh,
+                                                        const int64_t* __restrict__ nt, const int* __restrict__ offsets,
+                                                        const int* __restrict__ tile_off, const int* __restrict__ tile_rel,
+                                                        const int* __restrict__ perm, int R, int k, float margin, float* __restrict__ loss,
+                                                        unsigned* __restrict__ touched, float* __restrict__ ds_out) {
+    constexpr int DP = 16 * NB, PITCH = DP + 4, NK = 4 * NB;
+    __shared__ __attribute__((aligned(16))) float sW[2][16][PITCH];
+    int rel, tin;
+    if (!locate_tile(tile_off, tile_rel, R, blockIdx.x, rel, tin)) return;
+    if (tin & 1) return;                       // (the workgroup of an even tile takes the odd one after it as well)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 15, lk = lane >> 4;
+    const int g_lo = offsets[rel] + tin * kPairTile, g_hi = min(offsets[rel + 1], g_lo + 2 * kPairTile);
+    // A-operand row of this lane: row l of the wave = pair 8 wave + l / 2, side l & 1
+    int a_h, a_t;
+    bool a_on;
+    {
+        const int gp = g_lo + 8 * wave + (l >> 1);
+        a_on = gp < g_hi;
+        const int pair = a_on ? perm[gp] : 0;
+        a_h = a_on ? (int)((l & 1) ? nh[pair] : ph[pair]) : 0;
+        a_t = a_on ? (int)((l & 1) ? nt[pair] : pt[pair]) : 0;
+    }
+    // accumulator rows of this lane: 4 lk + q = pairs 2 lk (q = 0 positive, 1 negative) and 2 lk + 1 (q = 2, 3)
+    int c_h[4], c_t[4], c_pair[2];
+    bool c_on[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gp = g_lo + 8 * wave + 2 * lk + j;
+        c_on[j] = gp < g_hi;
+        c_pair[j] = c_on[j] ? perm[gp] : 0;
+        c_h[2 * j] = c_on[j] ? (int)ph[c_pair[j]] : 0; c_h[2 * j + 1] = c_on[j] ? (int)nh[c_pair[j]] : 0;
+        c_t[2 * j] = c_on[j] ? (int)pt[c_pair[j]] : 0; c_t[2 * j + 1] = c_on[j] ? (int)nt[c_pair[j]] : 0;
+    }
+    float a[NK];
+    unroll_seq([&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        const int kk = 4 * ks + lk;
+        a[ks] = (a_on && kk < k) ? ent[(int64_t)a_h * k + kk] : 0.f;
+    }, std::make_integer_sequence<int, NK>{});
+    f32x4v acc[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ M = relm + (int64_t)rel * k * k;
+    float st[NB];
+    int buf = 0;
+    // one pass over M_r: TR = false: B[kq][c] = M[16 kb + kq][c] (V = H M); TR = true: B[kq][c] = M[c][16 kb + kq] (U = T M^T)
+    auto pass = [&](auto tr_tag) __attribute__((always_inline)) {
+        constexpr bool TR = decltype(tr_tag)::value;
+        const int kq = TR ? (threadIdx.x & 15) : (threadIdx.x >> 4), c0 = TR ? (threadIdx.x >> 4) : (threadIdx.x & 15);
+        const int toff = TR ? c0 * k + kq : kq * k + c0;
+        auto fetch = [&](int kb) __attribute__((always_inline)) {
+            const float* __restrict__ Ms = M + (TR ? 16 * kb : 16 * kb * k);
+#pragma unroll
+            for (int u = 0; u < NB; ++u) st[u] = (16 * kb + kq < k && c0 + 16 * u < k) ? Ms[toff + (TR ? 16 * u * k : 16 * u)] : 0.f;
+        };
+        fetch(0);
+        unroll_seq([&](auto kbc) __attribute__((always_inline)) {
+            constexpr int kb = decltype(kbc)::value;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) sW[buf][kq][BlkMapNat<NB>::pos(u, c0)] = st[u];   // (natural accumulator columns: coalesced atomics)
+            __syncthreads();   // slab kb is in LDS; everybody finished reading the buffer that is written next
+            if (kb + 1 < NB) fetch(kb + 1);
+            float b[2][NB];
+            read_blocks<NB>(&sW[buf][lk][0], l, b[0]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk + 1 < 4) read_blocks<NB>(&sW[buf][4 * (kk + 1) + lk][0], l, b[(kk + 1) & 1]);
+                KGE_KEEP_READS_AHEAD();
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * kb + kk], b[kk & 1][cb], acc[cb], 0, 0, 0);
+            }
+            buf ^= 1;
+        }, std::make_integer_sequence<int, NB>{});
+    };
+    pass(std::false_type{});
+    // ---- energies -s = -<V, T>, margin hinge of the lane's two pairs (as k_hinge_coeffs).  The T elements the accumulators meet are
+    // fetched in accumulator layout only now: 4 NB registers that are not live during the MFMA passes (three waves per SIMD)
+    float tq[NB][4];
+    unroll_seq([&](auto cbc) __attribute__((always_inline)) {
+        constexpr int cb = decltype(cbc)::value;
+        const int col = 16 * cb + l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tq[cb][q] = (c_on[q >> 1] && col < k) ? ent[(int64_t)c_t[q] * k + col] : 0.f;
+    }, std::make_integer_sequence<int, NB>{});
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    unroll_seq([&](auto cbc) __attribute__((always_inline)) {
+        constexpr int cb = decltype(cbc)::value;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p[q] = fmaf(acc[cb][q], tq[cb][q], p[q]);
+    }, std::make_integer_sequence<int, NB>{});
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { p[q] += __shfl_xor(p[q], 1, 64); p[q] += __shfl_xor(p[q], 2, 64); p[q] += __shfl_xor(p[q], 4, 64); p[q] += __shfl_xor(p[q], 8, 64); }
+    float c[2], hl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float v = (-p[2 * j]) + margin - (-p[2 * j + 1]);
+        c[j] = c_on[j] ? (v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f)) : 0.f;
+        if (c_on[j]) hl += fmaxf(v, 0.f);
+        if (l == 0 && c_on[j]) ds_out[c_pair[j]] = c[j];
+    }
+    {
+        const float tot = wave_sum(l == 0 ? hl : 0.f);
+        if (lane == 0 && tot != 0.f) unsafeAtomicAdd(loss + (blockIdx.x % kLossSlots) * kLossStride, tot);
+    }
+    if (!__syncthreads_or(c[0] != 0.f || c[1] != 0.f)) return;   // every pair of the workgroup inside the margin: no gradient
+    if (touched && l == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c[q >> 1] != 0.f) {
+                atomicOr(touched + (c_h[q] >> 5), 1u << (c_h[q] & 31));
+                atomicOr(touched + (c_t[q] >> 5), 1u << (c_t[q] & 31));
+            }
+    }
+    // rows of a pair leave as grad = -ds x: positive row -c x_pos, negative row +c x_neg; the same entity on both sides: one atomic
+    auto scatter = [&](const int (&ids)[4]) __attribute__((always_inline)) {
+        unroll_seq([&](auto cbc) __attribute__((always_inline)) {
+            constexpr int cb = decltype(cbc)::value;
+            const int col = 16 * cb + l;
+            if (col < k) {
+                const float x0 = acc[cb][0], x1 = acc[cb][1], x2 = acc[cb][2], x3 = acc[cb][3];
+                if (c[0] != 0.f) {
+                    if (ids[0] == ids[1]) unsafeAtomicAdd(g_ent + (int64_t)ids[0] * k + col, -c[0] * (x0 - x1));
+                    else { unsafeAtomicAdd(g_ent + (int64_t)ids[0] * k + col, -c[0] * x0); unsafeAtomicAdd(g_ent + (int64_t)ids[1] * k + col, c[0] * x1); }
+                }
+                if (c[1] != 0.f) {
+                    if (ids[2] == ids[3]) unsafeAtomicAdd(g_ent + (int64_t)ids[2] * k + col, -c[1] * (x2 - x3));
+                    else { unsafeAtomicAdd(g_ent + (int64_t)ids[2] * k + col, -c[1] * x2); unsafeAtomicAdd(g_ent + (int64_t)ids[3] * k + col, c[1] * x3); }
+                }
+            }
+        }, std::make_integer_sequence<int, NB>{});
+    };
+    scatter(c_t);                              // grad_t = -ds V
+    // ---- U = T M^T, grad_h = -ds U
+    unroll_seq([&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        const int kk = 4 * ks + lk;
+        a[ks] = (a_on && kk < k) ? ent[(int64_t)a_t * k + kk] : 0.f;
+    }, std::make_integer_sequence<int, NK>{});
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    pass(std::true_type{});
+    scatter(c_h);
+}
+
 constexpr int64_t kPairSplitG = 8192;      // pairs from which the relation-matrix gradient gets its own launch
 
 static size_t rescal_pair_lds_bytes(int k) {
@@ -940,8 +1097,19 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
     float* ds = n >= kPairSplitG ? (float*)(g.tile_rel + tiles) : nullptr;
     const int S = (k + 1) | 1;
     const size_t lds_gm = (size_t)(2 * TILE * S + TILE) * sizeof(float) + (size_t)2 * TILE * sizeof(long long);
+    // large batches: V / U as batch-as-M GEMMs (k_rescal_rows), dL/denergy to the relation-owner launch below (KGE_RESCAL_ROWS=0/1: A/B)
+    const char* rows_env = getenv("KGE_RESCAL_ROWS");
+    const bool rows = ds != nullptr && k <= 208 && !(rows_env && rows_env[0] == '0');
+    if (rows) {
+        const int nb = (k + 15) / 16;
+#define KGE_RR(J) case J: hipLaunchKernelGGL(k_rescal_rows<J>, dim3(tiles), dim3(256), 0, s, m->tables[0], m->tables[1], m->grads[0], ph, pt, nh, \
+                                             nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched, ds); break;
+        switch (nb) { KGE_RR(1) KGE_RR(2) KGE_RR(3) KGE_RR(4) KGE_RR(5) KGE_RR(6) KGE_RR(7) KGE_RR(8) KGE_RR(9) KGE_RR(10) KGE_RR(11) KGE_RR(12) KGE_RR(13) }
+#undef KGE_RR
+    }
 #define KGE_RP(VK_)                                                                                                              \
     {                                                                                                                            \
+        if (!rows)                                                                                                               \
         hipLaunchKernelGGL(k_rescal_pair<VK_>, dim3(tiles), dim3(1024), lds, s, m->tables[0], m->tables[1], m->grads[0], m->grads[1], ph, pt, \
                            nh, nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched, ds);              \
         if (ds)                                                                                                                  \

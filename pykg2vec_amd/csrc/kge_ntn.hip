@@ -13,6 +13,7 @@
 // MFMA operand maps: A: lane l holds A[i=l&31][k=l>>5]; B: lane l holds B[k=l>>5][j=l&31];
 // C/D: col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "kge_internal.h"
+#include "kge_mfma_blocks.h"
 #include <stdlib.h>
 
 namespace kge {
@@ -396,31 +397,7 @@ __global__ __launch_bounds__(256) void k_ntn_scatter(IdSplit h, IdSplit t,
 // global memory per MFMA and leave gW to one wave per 32 x 32 tile walking the whole batch; these keep the batch-side
 // operand of 128 triples in REGISTERS across all slices, stream W (or the batch, for gW) through LDS in 16-deep slabs and
 // run v_mfma_f32_16x16x4_f32 with 2 x NBJ accumulator blocks per wave.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int kBigRows = 128;   // triples per workgroup of k_ntn_rows: 4 waves x 2 row blocks of 16
-
-// NB column (or row) blocks of 16: a lane's operands for groups of four blocks are 16 consecutive bytes of an LDS row (then
-// 8, then 4), i.e. block b of a group of four holds elements 4 l + b.  at(b, l): element of lane-in-block l of block b.
-template <int NB> struct BlkMap {
-    static constexpr int G4 = NB / 4, G2 = (NB % 4) / 2, G1 = NB % 2;
-    __host__ __device__ static constexpr int at(int b, int l) {
-        return b < 4 * G4 ? 64 * (b / 4) + 4 * l + (b % 4) : b < 4 * G4 + 2 * G2 ? 64 * G4 + 2 * l + (b - 4 * G4) : 64 * G4 + 32 * G2 + l;
-    }
-};
-template <int NB>
-__device__ __forceinline__ void read_blocks(const float* __restrict__ rowp, int l, float (&b)[NB]) {
-    using M = BlkMap<NB>;
-#pragma unroll
-    for (int g = 0; g < M::G4; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(rowp + 64 * g + 4 * l);
-        b[4 * g] = v.x; b[4 * g + 1] = v.y; b[4 * g + 2] = v.z; b[4 * g + 3] = v.w;
-    }
-    if constexpr (M::G2) {
-        const float2 v = *reinterpret_cast<const float2*>(rowp + 64 * M::G4 + 2 * l);
-        b[4 * M::G4] = v.x; b[4 * M::G4 + 1] = v.y;
-    }
-    if constexpr (M::G1) b[NB - 1] = rowp[64 * M::G4 + 32 * M::G2 + l];
-}
 
 // MODE 0: Z[n][s] = bil[n][s] (forward);  1: GT^ += sum_s gz_s (H^ W_s);  2: GH^ += sum_s gz_s (T^ W_s^T).
 // grid = (tiles of 128 triples, slice groups): a workgroup walks slices [s_lo, s_hi); with more than one slice group the
