@@ -506,7 +506,6 @@ __global__ __launch_bounds__(kBlock) void k_own_apply(OwnArgs a) {
     constexpr int NE = VEC * NV;
     const int gl = threadIdx.x % G;
     const int grp = threadIdx.x / G;
-    const int d = a.d;
     __shared__ float s_sum[GPB][NT * NE * G];
     int g = -1;
     float gv[NT][NE];
