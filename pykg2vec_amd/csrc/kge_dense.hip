@@ -1062,6 +1062,126 @@ __global__ __launch_bounds__(256, 2) void k_rescal_rows(const float* __restrict_
     scatter(c_h);
 }
 
+// The relation-matrix gradient of the large-batch step as a GEMM over gathered rows, G_r = sum_i ds_i h_i t_i^T (K = the triples of
+// the relation), in the style of kge_ntn.hip's k_ntn_outer: a workgroup takes a run of kGRun 16-pair tiles of one relation (256 rows)
+// and ONE half of the output columns (NBJ blocks from column blockIdx.y * 16 NBJ on), stages 16 rows per slab
+// -- ds_i h_i in natural order, t_i permuted so that accumulator block b, lane l is column jbase + 16 b + l -- and holds NBI x NBJ
+// accumulator blocks over its four waves (row block b on wave b % 4).  The ids of a slab's rows hang on perm -> pair -> ids: they are
+// resolved two slabs ahead, the rows one slab ahead.  grad_M = -G: plain read-modify-write when the relation has a single run, float
+// atomics otherwise.
+constexpr int kGRun = 8;
+template <int NBI, int NBJ>
+__global__ __launch_bounds__(256, 2) void k_rescal_g(const float* __restrict__ ent, float* __restrict__ g_rel,
+                                                     const int64_t* __restrict__ ph, const int64_t* __restrict__ pt,
+                                                     const int64_t* __restrict__ nh, const int64_t* __restrict__ nt,
+                                                     const int* __restrict__ offsets, const int* __restrict__ tile_off,
+                                                     const int* __restrict__ tile_rel, const int* __restrict__ perm, int R, int k,
+                                                     const float* __restrict__ ds) {
+    constexpr int DPI = 16 * NBI, DPJ = 16 * NBJ, PA = DPI + 4, PB = DPJ + 4;
+    const int jbase = blockIdx.y * DPJ;   // the workgroup's half of the output columns
+    constexpr int RBW = (NBI + 3) / 4;   // row blocks per wave
+    __shared__ __attribute__((aligned(16))) float sA[2][16][PA], sB[2][16][PB];
+    int rel, tin;
+    if (!locate_tile(tile_off, tile_rel, R, blockIdx.x, rel, tin)) return;
+    if (tin % kGRun) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 15, lk = lane >> 4;
+    const int r0 = offsets[rel], r1 = offsets[rel + 1];
+    const int g_lo = r0 + tin * kPairTile, g_hi = min(r1, g_lo + kGRun * kPairTile);
+    const bool shared_rel = (r1 - r0) > kGRun * kPairTile;
+    const int nslab = (g_hi - g_lo + 7) / 8;   // 8 pairs = 16 rows per slab
+    f32x4v acc[RBW][NBJ];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NBJ; ++cb) acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // staging roles: slab row kq = tid / 16 = pair kq / 2, side kq & 1; columns c0 + 16 u
+    const int kq = threadIdx.x >> 4, c0 = threadIdx.x & 15;
+    int64_t id_h = 0, id_t = 0;
+    float id_s = 0.f;
+    auto resolve = [&](int sl) __attribute__((always_inline)) {   // ids and signed coefficient of this thread's row of slab sl
+        const int g = g_lo + 8 * sl + (kq >> 1);
+        id_s = 0.f; id_h = 0; id_t = 0;
+        if (sl < nslab && g < g_hi) {
+            const int pair = perm[g];
+            const float c = ds[pair];
+            const bool neg = kq & 1;
+            id_s = neg ? -c : c;
+            id_h = neg ? nh[pair] : ph[pair];
+            id_t = neg ? nt[pair] : pt[pair];
+        }
+    };
+    float sta[NBI], stb[NBJ], st_s = 0.f, nx_s = 0.f;
+    auto fetch = [&]() __attribute__((always_inline)) {   // rows of the slab whose ids are resolved; its coefficient travels with them
+        nx_s = id_s;
+        const bool live = id_s != 0.f;
+        const float* __restrict__ hr = ent + id_h * k + c0;
+        const float* __restrict__ tr = ent + id_t * k + jbase + c0;
+#pragma unroll
+        for (int u = 0; u < NBI; ++u) sta[u] = (live && c0 + 16 * u < k) ? hr[16 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < NBJ; ++u) stb[u] = (live && jbase + c0 + 16 * u < k) ? tr[16 * u] : 0.f;
+    };
+    int buf = 0;
+    resolve(0);
+    fetch();
+    st_s = nx_s;
+    resolve(1);
+    for (int sl = 0; sl < nslab; ++sl) {
+#pragma unroll
+        for (int u = 0; u < NBI; ++u) sA[buf][kq][c0 + 16 * u] = sta[u] * st_s;
+#pragma unroll
+        for (int u = 0; u < NBJ; ++u) sB[buf][kq][BlkMapNat<NBJ>::pos(u, c0)] = stb[u];
+        __syncthreads();
+        if (sl + 1 < nslab) { fetch(); st_s = nx_s; }   // rows of slab sl + 1 (ids resolved one iteration ago)
+        resolve(sl + 2);                                   // ids of slab sl + 2: three dependent loads, two slabs of MFMAs to land
+        float b[2][NBJ], av[2][RBW];
+        auto operands = [&](int kk, int slot) __attribute__((always_inline)) {
+            read_blocks<NBJ>(&sB[buf][4 * kk + lk][0], l, b[slot]);
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) av[slot][rb] = wave + 4 * rb < NBI ? sA[buf][4 * kk + lk][16 * (wave + 4 * rb) + l] : 0.f;
+        };
+        operands(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk + 1 < 4) operands(kk + 1, (kk + 1) & 1);
+            KGE_KEEP_READS_AHEAD();
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) {
+                if (wave + 4 * rb < NBI) {   // wave-uniform
+#pragma unroll
+                    for (int cb = 0; cb < NBJ; ++cb)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk & 1][rb], b[kk & 1][cb], acc[rb][cb], 0, 0, 0);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    float* __restrict__ gM = g_rel + (int64_t)rel * k * k;
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+        if (wave + 4 * rb >= NBI) continue;
+#pragma unroll
+        for (int cb = 0; cb < NBJ; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * (wave + 4 * rb) + 4 * lk + q, j = jbase + 16 * cb + l;
+                const float v = acc[rb][cb][q];
+                if (i < k && j < k && v != 0.f) {
+                    float* o = gM + (int64_t)i * k + j;
+                    if (shared_rel) unsafeAtomicAdd(o, -v); else *o -= v;
+                }
+            }
+    }
+}
+
+template <int NBI>
+static void launch_rescal_g(const kge_model_desc* m, const int64_t* ph, const int64_t* pt, const int64_t* nh, const int64_t* nt,
+                            const GroupWs& g, unsigned tiles, int R, int k, const float* ds, hipStream_t s) {
+    constexpr int JA = (NBI + 1) / 2;   // column blocks per half (an odd NBI leaves one masked block in the second half)
+    hipLaunchKernelGGL((k_rescal_g<NBI, JA>), dim3(tiles, NBI > 1 ? 2 : 1), dim3(256), 0, s, m->tables[0], m->grads[1], ph, pt, nh, nt,
+                       g.offsets, g.tile_off, g.tile_rel, g.perm, R, k, ds);
+}
+
 constexpr int64_t kPairSplitG = 8192;      // pairs from which the relation-matrix gradient gets its own launch
 
 static size_t rescal_pair_lds_bytes(int k) {
@@ -1107,17 +1227,25 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
         switch (nb) { KGE_RR(1) KGE_RR(2) KGE_RR(3) KGE_RR(4) KGE_RR(5) KGE_RR(6) KGE_RR(7) KGE_RR(8) KGE_RR(9) KGE_RR(10) KGE_RR(11) KGE_RR(12) KGE_RR(13) }
 #undef KGE_RR
     }
+    const char* g_env = getenv("KGE_RESCAL_G");
+    // the relation-matrix gradient as a GEMM over gathered rows (k_rescal_g) where relations span several 128-pair runs
+    const bool gemm_g = rows && (g_env ? g_env[0] == '1' : n >= 128 * R);
 #define KGE_RP(VK_)                                                                                                              \
     {                                                                                                                            \
         if (!rows)                                                                                                               \
         hipLaunchKernelGGL(k_rescal_pair<VK_>, dim3(tiles), dim3(1024), lds, s, m->tables[0], m->tables[1], m->grads[0], m->grads[1], ph, pt, \
                            nh, nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched, ds);              \
-        if (ds)                                                                                                                  \
+        if (ds && !gemm_g)                                                                                                       \
             hipLaunchKernelGGL(k_rescal_pair_gm<VK_>, dim3(tiles), dim3(1024), lds_gm, s, m->tables[0], m->grads[1], ph, pt, nh, nt, g.offsets, \
                                g.tile_off, g.tile_rel, g.perm, (int)R, k, ds);                                                   \
     }
     if ((k & 3) == 0) KGE_RP(4) else KGE_RP(2)
 #undef KGE_RP
+    if (gemm_g) {
+#define KGE_RG(I) case I: launch_rescal_g<I>(m, ph, pt, nh, nt, g, tiles, (int)R, k, ds, s); break;
+        switch ((k + 15) / 16) { KGE_RG(1) KGE_RG(2) KGE_RG(3) KGE_RG(4) KGE_RG(5) KGE_RG(6) KGE_RG(7) KGE_RG(8) KGE_RG(9) KGE_RG(10) KGE_RG(11) KGE_RG(12) KGE_RG(13) }
+#undef KGE_RG
+    }
     return check_launch("k_rescal_pair");
 }
 
