@@ -40,6 +40,17 @@ __device__ __forceinline__ void read_blocks(const float* __restrict__ rowp, int 
     if constexpr (M::G1) b[NB - 1] = rowp[64 * M::G4 + 32 * M::G2 + l];
 }
 
+// (compile-time check of the two maps for every block count in use: read_blocks hands LDS position 64 g + 4 l + q to block 4 g + q,
+// lane l -- BlkMap calls that element at(b, l); BlkMapNat stores column 16 b + l exactly there)
+template <int NB> constexpr bool blk_maps_agree() {
+    for (int b = 0; b < NB; ++b)
+        for (int l = 0; l < 16; ++l)
+            if (BlkMapNat<NB>::pos(b, l) != BlkMap<NB>::at(b, l) || BlkMap<NB>::at(b, l) >= 16 * NB) return false;
+    return true;
+}
+static_assert(blk_maps_agree<1>() && blk_maps_agree<2>() && blk_maps_agree<3>() && blk_maps_agree<4>() && blk_maps_agree<5>() &&
+              blk_maps_agree<6>() && blk_maps_agree<7>() && blk_maps_agree<8>() && blk_maps_agree<13>(), "block maps");
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop the compiler cannot decline to unroll (register arrays
 // indexed by the loop variable stay registers whatever the body size)
 template <class F, int... I>
