@@ -1,0 +1,69 @@
+"""Dev tool: randomised A/B of the large-batch forms of the relation-matrix models against the tile kernels they replace, on one
+MI355X: NTN (KGE_NTN_BIG=0/1, random d, k_r <= 128, batch) and RESCAL (KGE_RESCAL_ROWS / KGE_RESCAL_G = 0/1, random even k <= 208,
+relations, >= 8 192 pairs).  Same batch, same tables: loss and every gradient table must agree within fp32 summation-order noise."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import hip_util, kge_oracle as ko
+from pykg2vec_amd.trainer import Trainer
+
+rng = np.random.default_rng(int(os.environ.get("SEED", "41")))
+bad = 0
+N = int(os.environ.get("ITERS", "40"))
+
+
+def step(model, P, hp, E, R, pos, batch, env, share_nr=False):
+    for k_, v in env.items():
+        os.environ[k_] = v
+    m = hip_util.model_from_params(model, P, hp, E, R, train=pos)
+    cfg = hip_util.make_config(E, R, dict(hp, neg_rate=1), pos, pos[:1], pos[:1])
+    tr = Trainer(m, cfg, use_graph=False); tr.build_model()
+    b = [hip_util.dev(x) for x in batch]
+    loss = tr.train_step_pairwise(b[0], b[1], b[2], b[3], b[1] if share_nr else b[4], b[5]).item()
+    return loss, [g.cpu().numpy().copy() for g in tr.flat.grad_views]
+
+
+def compare(tag, info, ref, got):
+    global bad
+    ok = np.isclose(ref[0], got[0], rtol=2e-5, atol=1e-4)
+    worst = 0.0
+    for a, b in zip(ref[1], got[1]):
+        scale = max(1.0, float(np.abs(a).max()))
+        worst = max(worst, float(np.abs(a - b).max()) / scale)
+    if not ok or worst > 2e-4:
+        bad += 1
+        print("FAIL", tag, info, "loss", ref[0], got[0], "grad err", worst, flush=True)
+
+
+for it in range(N):
+    try:
+        if it % 2 == 0:
+            d, kr = int(rng.integers(2, 129)), int(rng.integers(1, 129))
+            E, R, B = int(rng.integers(20, 500)), int(rng.integers(1, 20)), int(rng.integers(40, 900))
+            hp = dict(ent_hidden_size=d, rel_hidden_size=kr, lmbda=1e-3, margin=float(rng.uniform(0.5, 3)))
+            P = ko.init_params("ntn", rng, tot_entity=E, tot_relation=R, ent_hidden_size=d, rel_hidden_size=kr)
+            pos = np.stack([rng.integers(E, size=B), rng.integers(R, size=B), rng.integers(E, size=B)], 1)
+            flip = rng.random(B) > 0.5; rnd = rng.integers(E, size=B)
+            batch = (pos[:, 0], pos[:, 1], pos[:, 2], np.where(flip, pos[:, 0], rnd), pos[:, 1].copy(), np.where(flip, rnd, pos[:, 2]))
+            ref = step("ntn", P, hp, E, R, pos, batch, {"KGE_NTN_BIG": "0"})
+            got = step("ntn", P, hp, E, R, pos, batch, {"KGE_NTN_BIG": "1"})
+            compare("ntn", dict(d=d, kr=kr, E=E, R=R, B=B), ref, got)
+        else:
+            k = 2 * int(rng.integers(1, 105))
+            E, R, B = int(rng.integers(50, 4000)), int(rng.integers(1, 120)), int(rng.integers(8192, 11000))
+            hp = dict(hidden_size=k, margin=float(rng.choice([0.02, 0.5, 1.0, 2.0])))
+            P = ko.init_params("rescal", rng, tot_entity=E, tot_relation=R, hidden_size=k)
+            pos = np.stack([rng.integers(E, size=B), rng.integers(R, size=B), rng.integers(E, size=B)], 1)
+            flip = rng.random(B) > 0.5; rnd = rng.integers(E, size=B)
+            batch = (pos[:, 0], pos[:, 1], pos[:, 2], np.where(flip, pos[:, 0], rnd), pos[:, 1].copy(), np.where(flip, rnd, pos[:, 2]))
+            ref = step("rescal", P, hp, E, R, pos, batch, {"KGE_RESCAL_ROWS": "0", "KGE_RESCAL_G": "0"}, share_nr=True)
+            for g_ in ("0", "1"):
+                got = step("rescal", P, hp, E, R, pos, batch, {"KGE_RESCAL_ROWS": "1", "KGE_RESCAL_G": g_}, share_nr=True)
+                compare("rescal g=" + g_, dict(k=k, E=E, R=R, B=B, margin=hp["margin"]), ref, got)
+    except Exception as ex:  # noqa
+        bad += 1
+        print("ERROR", it, repr(ex)[:300], flush=True)
+print("fuzz done: %d cases, %d bad" % (N, bad))
+sys.exit(1 if bad else 0)

@@ -11,3 +11,4 @@ ITERS=${FUZZ_PULL:-64} SEED=3 timeout 600 python tools/fuzz_pull.py > gpurun_out
 ITERS=${FUZZ_STAGED:-60} SEED=21 timeout 600 python tools/fuzz_staged.py > gpurun_out/fuzz_staged.log 2>&1; echo "fuzz_staged rc=$?"; tail -6 gpurun_out/fuzz_staged.log
 ITERS=${FUZZ_OWN:-96} SEED=5 timeout 900 python tools/fuzz_own.py > gpurun_out/fuzz_own.log 2>&1; echo "fuzz_own rc=$?"; tail -6 gpurun_out/fuzz_own.log
 ITERS=${FUZZ_EVAL_GEMM:-80} SEED=31 timeout 900 python tools/fuzz_eval_gemm.py > gpurun_out/fuzz_eval_gemm.log 2>&1; echo "fuzz_eval_gemm rc=$?"; tail -6 gpurun_out/fuzz_eval_gemm.log
+ITERS=${FUZZ_BIG:-60} SEED=41 timeout 600 python tools/fuzz_big_paths.py > gpurun_out/fuzz_big_paths.log 2>&1; echo "fuzz_big_paths rc=$?"; tail -4 gpurun_out/fuzz_big_paths.log
