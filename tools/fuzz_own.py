@@ -66,17 +66,23 @@ for it in range(N):
     res = {}
     for val in env[1:]:
         os.environ[env[0]] = val
-        cfg = hip_util.make_config(E, R, hp, train, train[:2], train[:2], optimizer=opt, lr=0.01, batch_size=B)
+        cfg = hip_util.make_config(E, R, hp, train, train[:2], train[:2], optimizer=opt, lr=float(os.environ.get("FORCE_LR", 0.01)), batch_size=B)
         m = hip_util.model_from_params(model, P, hp, E, R, train=train)
         tr = Trainer(m, cfg, use_graph=False)
         tr.build_model()
         tr.generator = tr._new_generator()
-        losses = [tr.train_model_epoch(e) for e in range(2)]
+        losses = [tr.train_model_epoch(e) for e in range(int(os.environ.get("FORCE_EPOCHS", 2)))]
         res[val] = (losses, [p.detach().cpu().numpy().copy() for _, p in hip_util.table_parameters(m)])
         del tr, m
     os.environ.pop(env[0], None)
     os.environ.pop("KGE_PULL", None)
     counts[fam] = counts.get(fam, 0) + 1
+    if os.environ.get("ONLY_IT"):      # replay: how far the two paths' tables are apart, relative to how far they moved from the start
+        init = [np.asarray(P[k]) for k in ko.PARAM_NAMES["transe" if model == "transm" else model]]
+        for nme, a, b, p0 in zip(ko.PARAM_NAMES["transe" if model == "transm" else model], res["0"][1], res["1"][1], init):
+            moved = np.abs(a - p0)
+            rel = np.abs(a - b) / np.maximum(moved, 1e-12)
+            print("   ", nme, "max |a-b| %.3g" % np.abs(a - b).max(), "median move %.3g" % np.median(moved), "median / 99th pct of |a-b| / move: %.3g / %.3g" % (np.median(rel), np.percentile(rel, 99)), flush=True)
     ok = np.allclose(res["0"][0], res["1"][0], rtol=1e-4)
     fracs = []
     for a, b in zip(res["0"][1], res["1"][1]):
