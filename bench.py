@@ -8,8 +8,16 @@ negative corruption, score(+), score(-), hinge and the backward scatter (kge_tra
 (kge_optimizer_step) -> [N>1: RCCL all-gather of the updated tables].  Nothing is skipped or cached inside the timed
 region.  After the timed training steps the same process times the filtered-rank evaluation sweep (kge_eval_ranks),
 the other BASELINE configs (C2 ComplEx-WN18RR, C3 RotatE-FB15k-237, C4 RESCAL-YAGO3-10; N=1 only, `extra`) and, on
-rank 0 at N=1, the CPU baseline (a multi-threaded C *port* of the reference algorithm, oracle/kge_oracle_c.c, pinned
-to the numpy oracle and the reference's golden vectors -- on a bounded sample of the same workload, all host cores).
+rank 0 at N=1, the CPU baseline: the UNMODIFIED reference's CPU-PyTorch path when its tree can be imported
+(oracle/ref_cpu_baseline.py, `kind: "reference"`; the tree does not exist on the GPU box), else a multi-threaded C *port* of the
+reference algorithm (oracle/kge_oracle_c.c, pinned to the numpy oracle and the reference's golden vectors, `kind: "port"`) --
+on a bounded sample of the same workload, all host cores.
+
+HBM traffic (`roofline.traffic`, `eval.roofline.traffic`, `extra.C*.traffic`) is OBSERVED IN THIS RUN when rocprofv3 is on the
+box: rank 0 at N=1 re-runs a short version of every leg as a child process under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and
+again under `--pmc WRITE_SIZE` (separate passes, MI355X_MICROARCH.md), each leg's timed steps bracketed by marker launches
+(kge_debug_marker), and sums the counters of all kernels between the markers.  `--no-live-pmc` (or a missing / failing
+rocprofv3) falls back to the committed passes under profiles/ and says so in `traffic_source`.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          N>1 without a torch.distributed environment: bench.py re-executes itself under torch.distributed.run
@@ -48,6 +56,13 @@ L1_SWEEP_CYCLES_PER_ELEMENT_PER_WAVE = 4.0              # 2 plain VALU issues x 
 L1_SWEEP_ISSUES_PER_ELEMENT = 2.0
 L1_SWEEP_MICROBENCH_TELEMS = 32.9                       # register-resident ceiling of the same mix (tools/valu_bench.hip)
 MIN_WARM_SECONDS = 0.05                                 # warm until >= 50 ms of GPU work has run, whatever --warmup says
+# marker tags of the counter child (kge_debug_marker: grid.x = 64 x tag); a segment runs from its tag to the next marker
+PMC_TAGS = {"C1_train": 101, "C1_eval": 102, "C1_small": 103, "C2_train": 111, "C2_eval": 112, "C3_train": 121, "C3_eval": 122,
+            "C4_train": 131, "C4_eval": 132, "end": 99}
+PMC_C1_STEPS, PMC_EVAL_REPS, PMC_EXTRA_STEPS, PMC_SMALL_STEPS = 28, 2, 40, 400
+# dependent-load latency under load, from the committed random-row microbenchmark (profiles/r03_gather_bench.txt, 16 296-row table,
+# "chain G=32 8 hops": 21.53 us at 32 768 groups, 9.23 us at 8 192 groups -> us per hop)
+HOP_US_AT_32K_GROUPS, HOP_US_AT_8K_GROUPS = 21.53 / 8, 9.23 / 8
 
 
 class _KG:
@@ -152,16 +167,50 @@ def cpu_baseline_eval(P_np, test, csr, budget_s=8.0):
 
 
 def reference_cpu_numbers():
-    """The UNMODIFIED reference's CPU-PyTorch throughput on this workload, measured in the build container (the
-    reference tree cannot travel to the GPU box): profiles/r02_reference_cpu_baseline.json, written by
-    tools/ref_cpu_baseline.py.  Reported next to the in-run port; never used as `value`."""
-    path = os.path.join(ROOT, "profiles", "r02_reference_cpu_baseline.json")
-    if not os.path.exists(path):
-        return None
-    doc = json.load(open(path))
-    return {"train_scored_triples_per_s": doc["train"]["value"], "eval_test_triples_per_s": doc["eval"]["value"],
-            "cores": doc["cores"], "host": doc["host"], "source": "profiles/r02_reference_cpu_baseline.json",
-            "same_run": False, "same_host": False}
+    """The UNMODIFIED reference's CPU-PyTorch throughput on this workload as measured in the build container
+    (profiles/r04_reference_cpu_baseline.json, tools/ref_cpu_baseline.py; the round-2 file when that is absent).  Quoted next to
+    the in-run port wherever the reference tree cannot be imported (the GPU box); never used as `value`."""
+    for name in ("r04_reference_cpu_baseline.json", "r02_reference_cpu_baseline.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            doc = json.load(open(path))
+            return {"train_scored_triples_per_s": doc["train"]["value"], "eval_test_triples_per_s": doc["eval"]["value"],
+                    "cores": doc["cores"], "host": doc["host"], "source": "profiles/" + name, "same_run": False, "same_host": False}
+    return None
+
+
+def cpu_baseline(H):
+    """`cpu_baseline` of the JSON line.  First choice: the reference itself (Trainer.train_step_pairwise + backward +
+    optimizer.step, utils/trainer.py:147-157,298-299; Evaluator.test on 200 triples, utils/evaluator.py:309-334) on this host's
+    cores in this run -- possible wherever its tree is importable (PYKG2VEC_REFERENCE, default /root/reference; NOT on the GPU box).
+    Otherwise the C/OpenMP port of the same step, with the stored reference measurement quoted beside it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from pykg2vec_amd.evaluator import build_filter_csr
+    tried = None
+    try:
+        import ref_cpu_baseline
+        if ref_cpu_baseline.available():
+            n_ref = 200
+            hr_t, tr_h = build_filters(np.concatenate([H.train, H.valid, H.test]), H.test[:n_ref], R)
+            doc = ref_cpu_baseline.measure(E, R, DIM, H.train, H.valid, H.test, hr_t, tr_h, batch=H.cfg.batch_size, n_eval=n_ref)
+            return {"value": doc["train"]["value"], "unit": "scored triples/s", "cores": doc["cores"], "kind": "reference",
+                    "sample": doc["train"]["sample"], "what": doc["what"], "host": doc["host"], "same_run": True,
+                    "eval": {"value": doc["eval"]["value"], "unit": "test triples ranked/s", "sample": doc["eval"]["sample"]}}
+        tried = "reference tree not present at %s" % ref_cpu_baseline.ref_shim.REFERENCE_ROOT
+    except Exception as e:   # the baseline leg must never take the line down
+        tried = "reference import / run failed: %s: %s" % (type(e).__name__, e)
+    v, cores, sample = cpu_baseline_train(H.train)
+    P_np = {"ent_embeddings": H.model.ent_embeddings.weight.detach().cpu().numpy(),
+            "rel_embeddings": H.model.rel_embeddings.weight.detach().cpu().numpy()}
+    ve, ne = cpu_baseline_eval(P_np, H.my_test, build_filter_csr(H.my_test, H.hr_t, H.tr_h))
+    out = {"value": v, "unit": "scored triples/s", "cores": cores, "kind": "port", "sample": sample,
+           "kind_note": "C/OpenMP restatement of the reference step (oracle/kge_oracle_c.c), NOT the reference's CPU-PyTorch path: %s" % tried,
+           "eval": {"value": ve, "unit": "test triples ranked/s",
+                    "sample": "%d test triples, two full-entity sweeps each, C/OpenMP fp32" % ne}}
+    ref = reference_cpu_numbers()
+    if ref is not None:
+        out["reference_in_build_container"] = ref
+    return out
 
 
 def pmc_traffic(kernel_prefix, batch, fetch_scale=1.0):
@@ -238,10 +287,9 @@ EXTRA_CONFIGS = {
 }
 
 
-def run_extra_config(key, device):
+def build_extra_config(key, device, steps_cap=200):
     import torch
     import pykg2vec_amd as pa
-    from pykg2vec_amd.evaluator import Evaluator
     from pykg2vec_amd.trainer import Trainer
     c = EXTRA_CONFIGS[key]
     E_, R_ = c["E"], c["R"]
@@ -250,20 +298,30 @@ def run_extra_config(key, device):
     hr_t, tr_h = build_filters(np.concatenate([train, valid, test]), q, R_)
     hp = dict(c["hp"])
     cfg = make_config(E_, R_, len(train), c["batch"], device, optimizer=c["optimizer"], neg_rate=c["neg"], **hp)
-    cfg.knowledge_graph = _KG({"triplets_train": train, "triplets_valid": valid[:16], "triplets_test": q, "hr_t": hr_t,
+    cfg.knowledge_graph = _KG({"triplets_train": train, "triplets_valid": valid, "triplets_test": test, "hr_t": hr_t,
                                "tr_h": tr_h}, key)
     torch.manual_seed(0)
     model = pa.import_model(c["model"])(**cfg.__dict__)
     tr = Trainer(model, cfg)
     tr.build_model()
     tr.generator = tr._new_generator()
-    steps = min(200, len(train) // c["batch"])
+    steps = min(steps_cap, len(train) // c["batch"])
     cfg.tot_train_triples = steps * c["batch"]
+    return c, cfg, model, tr, q, steps
+
+
+def run_extra_config(key, device):
+    import torch
+    from pykg2vec_amd.evaluator import Evaluator
+    c, cfg, model, tr, q, steps = build_extra_config(key, device)
+    E_ = c["E"]
     dt = timed_epochs(tr, steps)
     rows = c["batch"] * (1 + c["neg"])
     ev = Evaluator(model, cfg)
-    ev.rank_all(q, len(q))
+    t0 = time.perf_counter()
+    ev.rank_all(q, len(q))   # first pass: builds the per-query filter CSR (host) and uploads it
     torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
@@ -271,14 +329,12 @@ def run_extra_config(key, device):
     torch.cuda.synchronize()
     edt = (time.perf_counter() - t0) / reps
     out = {"workload": c["name"],
-           "mode": ("hipGraph replay" if tr._graph is not None else
-                    "eager, staged gradients (no atomics, kge_optimizer_step_staged)" if getattr(tr, "_staged", None) is not None else
-                    "owner-computes, two phases (kge_own_run: k_own_step + k_own_apply per step, no atomics, one native call per epoch)"
-                    if getattr(tr, "_own", None) is not None else "eager"),
+           "mode": step_mode(tr),
            "step_us": dt * 1e6, "scored_triples_per_s": rows / dt,
            "train_algorithmic_GBps_whole_step": rows * c["train_bytes"] / dt / 1e9,
-           "train_hbm_frac_whole_step": rows * c["train_bytes"] / dt / 1e9 / HBM_PEAK_GBS,
+           "train_nominal_hbm_frac_whole_step": rows * c["train_bytes"] / dt / 1e9 / HBM_PEAK_GBS,
            "eval_test_triples_per_s": len(q) / edt, "eval_ms_per_pass": edt * 1e3, "eval_test_triples": len(q),
+           "eval_setup_ms": max(0.0, first_ms - edt * 1e3),
            "eval_algorithmic_GBps": 2.0 * len(q) * E_ * c["eval_bytes"] / edt / 1e9,
            "eval_sweep": ("matrix cores (k_eval_gemm, f32 MFMA)" if c["model"] in ("complex", "rotate", "rescal") and 2 * len(q) >= 512
                           else "VALU (k_eval_sweep)"),
@@ -291,6 +347,194 @@ def run_extra_config(key, device):
     return out
 
 
+def step_mode(tr):
+    return ("hipGraph replay" if tr._graph is not None else
+            "eager, staged gradients (no atomics, kge_optimizer_step_staged)" if getattr(tr, "_staged", None) is not None else
+            "owner-computes, staged (kge_own_run: k_own_eval + k_own_step per step, no atomics, one native call per epoch)"
+            if getattr(tr, "_own", None) is not None else
+            "owner-computes (kge_pull_run)" if getattr(tr, "_pull", None) is not None else "eager")
+
+
+# ---------------------------------------------------------------------------- HBM counters observed in this run
+def pmc_child(args):
+    """The process rocprofv3 wraps (one pass per counter): a short version of every leg, each timed part bracketed by
+    kge_debug_marker launches so that the parent can cut the dispatch sequence into per-leg segments.  Prints nothing."""
+    import torch
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.evaluator import Evaluator
+    torch.cuda.set_device(0)
+    device = "cuda:0"
+    mark = lambda name: K.debug_marker(PMC_TAGS[name])
+    H = setup_headline(args.batch, args.eval_triples, device)
+    run_headline_steps(H, 2 * H.steps_per_epoch)        # warm: index build, code objects, list sets
+    reset_headline(H)
+    torch.cuda.synchronize()
+    mark("C1_train")
+    run_headline_steps(H, PMC_C1_STEPS)
+    mark("end")
+    H.tr.sync_model()
+    ev = Evaluator(H.model, H.cfg)
+    ev.rank_all(H.my_test, H.n_eval)
+    mark("C1_eval")
+    for _ in range(PMC_EVAL_REPS):
+        ev.rank_all(H.my_test, H.n_eval)
+    mark("end")
+    torch.cuda.synchronize()
+    for key in EXTRA_CONFIGS:
+        c, cfg, model, tr, q, steps = build_extra_config(key, device, steps_cap=PMC_EXTRA_STEPS)
+        tr.train_model_epoch(0)                           # warm (captures the hipGraph where the step is launch-bound)
+        torch.cuda.synchronize()
+        mark(key + "_train")
+        tr.train_model_epoch(1)
+        mark("end")
+        ev = Evaluator(model, cfg)
+        ev.rank_all(q, len(q))
+        mark(key + "_eval")
+        for _ in range(PMC_EVAL_REPS):
+            ev.rank_all(q, len(q))
+        mark("end")
+        torch.cuda.synchronize()
+        del tr, ev, model
+        torch.cuda.empty_cache()
+
+
+def pmc_child_units(batch, eval_triples):
+    """Units (train steps / eval passes) the child runs inside each marker segment -- what a segment's counter sum is divided by."""
+    units = {PMC_TAGS["C1_train"]: PMC_C1_STEPS, PMC_TAGS["C1_eval"]: PMC_EVAL_REPS}
+    for key, c in EXTRA_CONFIGS.items():
+        units[PMC_TAGS[key + "_train"]] = min(PMC_EXTRA_STEPS, c["splits"][0] // c["batch"])
+        units[PMC_TAGS[key + "_eval"]] = PMC_EVAL_REPS
+    return units
+
+
+def live_pmc(args, timeout_s=240):
+    """Run the counter child under rocprofv3 once per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass) and return
+    {leg: {"fetch_raw_bytes", "write_bytes", "bytes" (2 x fetch + write), "kernels": {...}}} per unit (step / pass), or
+    (None, reason).  Everything is best effort: a missing rocprofv3, a timeout or an unreadable result only costs the live figure."""
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rocpd_pmc
+    units = pmc_child_units(args.batch, args.eval_triples)
+    name_of = {v: k for k, v in PMC_TAGS.items()}
+    legs, meta = {}, {}
+    tmp = tempfile.mkdtemp(prefix="kge_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", out_dir, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--batch", str(args.batch), "--eval-triples", str(args.eval_triples)]
+            t0 = time.perf_counter()
+            try:
+                res = subprocess.run(cmd, env=env, cwd="/tmp", timeout=timeout_s, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s pass exceeded %d s" % (ctr, timeout_s)
+            meta[ctr + "_pass_s"] = time.perf_counter() - t0
+            dbs = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
+            if res.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d, %d result files): %s" % (
+                    ctr, res.returncode, len(dbs), res.stdout.decode(errors="replace")[-300:])
+            seg = rocpd_pmc.segments(dbs[0])
+            if "error" in seg:
+                return None, "%s (columns: %s)" % (seg["error"], seg.get("columns"))
+            meta["order_by"] = seg["order_by"]
+            for tag, rec in seg["segments"].items():
+                if tag not in units:
+                    continue
+                leg = legs.setdefault(name_of[tag], {"units": units[tag], "kernels": {}})
+                total_kb = rec["counters"].get(ctr, 0.0)
+                leg["fetch_raw_bytes" if ctr == "FETCH_SIZE" else "write_bytes"] = total_kb * 1024.0 / units[tag]
+                for kname, k in rec["kernels"].items():
+                    kk = leg["kernels"].setdefault(kname, {})
+                    kk[ctr + "_KB_per_unit"] = k.get(ctr, 0.0) / units[tag]
+                    kk["launches_per_unit"] = k["rows"] / units[tag]
+                    kk["us_per_unit_in_counter_pass"] = k["duration_us"] / units[tag]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for leg in legs.values():
+        if "fetch_raw_bytes" in leg and "write_bytes" in leg:
+            # gfx950: FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 B (MI355X_MICROARCH.md, HBM section):
+            # doubled, as the guide prescribes for 16-byte-per-lane reads, which is how these kernels read rows and streams
+            leg["bytes"] = 2.0 * leg["fetch_raw_bytes"] + leg["write_bytes"]
+    return legs, meta
+
+
+def setup_headline(batch, eval_triples, device, world=1, rank=0):
+    """The headline workload (configs[1]): FB15k-shape TransE d=100 L1, synthetic ids, model + Trainer + generator on `device`."""
+    import torch
+    import pykg2vec_amd.pairwise as pw
+    from pykg2vec_amd.trainer import Trainer
+    H = types.SimpleNamespace()
+    H.train, H.valid, H.test = synthetic_split(E, R, (N_TRAIN, N_VALID, N_TEST))
+    H.n_eval = min(eval_triples, N_TEST // world)
+    H.my_test = H.test[rank * H.n_eval:(rank + 1) * H.n_eval]  # queries sharded over ranks, tables replicated: no collective
+    H.hr_t, H.tr_h = build_filters(np.concatenate([H.train, H.valid, H.test]), H.my_test, R)
+    H.cfg = make_config(E, R, N_TRAIN, batch * world, device, hidden_size=DIM, l1_flag=True)
+    # the cache carries the three splits as arrays (the Evaluator builds its filter lists from them on the device) and, for the
+    # CPU baselines, the reference-format dicts of sets restricted to the evaluated queries
+    H.cfg.knowledge_graph = _KG({"triplets_train": H.train, "triplets_valid": H.valid, "triplets_test": H.test,
+                                 "hr_t": H.hr_t, "tr_h": H.tr_h})
+    torch.manual_seed(0)
+    H.model = pw.TransE(**H.cfg.__dict__)
+    H.tr = Trainer(H.model, H.cfg)
+    H.tr.build_model()
+    H.gen = H.tr._new_generator()
+    H.tr.generator = H.gen
+    H.steps_per_epoch = N_TRAIN // H.cfg.batch_size
+    H.init_param = H.tr.flat.param.clone()
+    H.pull = H.tr._pull_ok()   # single GPU, big batch: the atomic-free owner-computes step (csrc/kge_pull.hip)
+    H.two_phase = bool(H.pull and H.tr._pull_two_phase())   # ... in two launches: every pair evaluated once, owners sum the records
+    H.pull_dp = H.tr._pull_dp_ok()   # N > 1: the same kernel writes the rank's dense gradient (no atomics), then the sharded step
+    return H
+
+
+def reset_headline(H):
+    """Back to the freshly initialised tables and optimiser state.  The hinge kernel skips the backward of pairs whose
+    margin is already satisfied, so a step gets cheaper as training progresses: every measurement starts
+    from the same (initial, all-margins-violated) state, whatever the warm-up length."""
+    tr = H.tr
+    ps = getattr(tr, "_pull", None)
+    if ps is not None:
+        ps.cur = 0
+    tr.flat.param.copy_(H.init_param)
+    tr.flat.grad.zero_()
+    for st in (tr.flat.state1, tr.flat.state2):
+        if st is not None:
+            st.zero_()
+    tr.flat.step = 0
+    if ps is not None:
+        ps.sync_in()   # row norms of the restored tables
+
+
+def run_headline_steps(H, n, events=None):
+    """n training steps through the product's step path.  Owner-computes path: the steps of an epoch are enqueued by one
+    native call (kge_pull_run), so there are no per-step events.  Push path: ONE launch does corruption + score(+) + score(-) +
+    hinge + backward scatter, then the optimiser."""
+    tr, gen = H.tr, H.gen
+    if not (H.pull or H.pull_dp):
+        for k in range(n):
+            if gen._pending <= 0:
+                gen.start_one_epoch(H.steps_per_epoch)
+            if events is not None:
+                events[k][0].record()
+            tr._accumulate_next_batch()
+            if events is not None:
+                events[k][1].record()
+            tr._reduce_and_step()
+        return
+    while n > 0:
+        if gen._pending <= 0:
+            gen.start_one_epoch(H.steps_per_epoch)
+        k = min(n, gen._pending)
+        tr.step_next_batches(k)
+        n -= k
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,8 +544,12 @@ def main():
     ap.add_argument("--eval-triples", type=int, default=8192, help="test triples ranked per GPU in the eval leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the C2 / C3 / C4 `extra` records (N=1 only)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 counter passes (use the committed ones)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.pmc_child:
+        return pmc_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
 
@@ -328,26 +576,11 @@ def main():
     import pykg2vec_amd.pairwise as pw
     from pykg2vec_amd import kernels as K
     from pykg2vec_amd.evaluator import Evaluator, build_filter_csr
-    from pykg2vec_amd.trainer import Trainer
 
-    train, valid, test = synthetic_split(E, R, (N_TRAIN, N_VALID, N_TEST))
-    n_eval = min(args.eval_triples, N_TEST // world)
-    my_test = test[rank * n_eval:(rank + 1) * n_eval]  # queries sharded over ranks, tables replicated: no collective
-    hr_t, tr_h = build_filters(np.concatenate([train, valid, test]), my_test, R)
-    cfg = make_config(E, R, N_TRAIN, args.batch * world, device, hidden_size=DIM, l1_flag=True)
-    cfg.knowledge_graph = _KG({"triplets_train": train, "triplets_valid": valid[:16], "triplets_test": my_test,
-                               "hr_t": hr_t, "tr_h": tr_h})
-    torch.manual_seed(0)
-    model = pw.TransE(**cfg.__dict__)
-    tr = Trainer(model, cfg)
-    tr.build_model()
-    gen = tr._new_generator()
-    tr.generator = gen
-    steps_per_epoch = N_TRAIN // cfg.batch_size
-    init_param = tr.flat.param.clone()
-    pull = tr._pull_ok()   # single GPU, big batch: the atomic-free owner-computes step (csrc/kge_pull.hip)
-    two_phase = bool(pull and tr._pull_two_phase())   # ... in two launches: every pair evaluated once, owners sum the records
-    pull_dp = tr._pull_dp_ok()   # N > 1: the same kernel writes the rank's dense gradient (no atomics), then the sharded step
+    H = setup_headline(args.batch, args.eval_triples, device, world, rank)
+    train, valid, test, my_test, n_eval, hr_t, tr_h = H.train, H.valid, H.test, H.my_test, H.n_eval, H.hr_t, H.tr_h
+    cfg, model, tr, gen, steps_per_epoch = H.cfg, H.model, H.tr, H.gen, H.steps_per_epoch
+    pull, two_phase, pull_dp = H.pull, H.two_phase, H.pull_dp
 
     # ---- per-run set-up of the owner-computes path: the incidence index of every batch of the epoch order, built on the device
     # (csrc/kge_index.hip).  Timed twice: cold (first call: includes loading the code objects) and warm (a rebuild), host wall
@@ -372,46 +605,8 @@ def main():
                  "host_wall_ms_cold": cold_ms, "host_wall_ms_warm": warm_ms, "device_ms_warm": es0.elapsed_time(es1),
                  "gpu_step_equivalents": None}
 
-    def reset_model():
-        """Back to the freshly initialised tables and optimiser state.  The hinge kernel skips the backward of pairs whose
-        margin is already satisfied, so a step gets cheaper as training progresses: every measurement below starts
-        from the same (initial, all-margins-violated) state, whatever the warm-up length."""
-        ps = getattr(tr, "_pull", None)
-        if ps is not None:
-            ps.cur = 0
-        tr.flat.param.copy_(init_param)
-        tr.flat.grad.zero_()
-        for st in (tr.flat.state1, tr.flat.state2):
-            if st is not None:
-                st.zero_()
-        tr.flat.step = 0
-        if ps is not None:
-            ps.sync_in()   # row norms of the restored tables
-
-    def one_step(ev_pair=None):
-        if gen._pending <= 0:
-            gen.start_one_epoch(steps_per_epoch)
-        if ev_pair is not None:
-            ev_pair[0].record()
-        tr._accumulate_next_batch()  # ONE launch: corruption + score(+) + score(-) + hinge + backward scatter
-        if ev_pair is not None:
-            ev_pair[1].record()
-        tr._reduce_and_step()
-
-    def run_steps(n, events=None):
-        """n training steps through the product's step path.  Owner-computes path: each step is ONE launch (next batch's
-        sampler + per-row re-evaluation, hinge, backward, dense Adam; no atomics) and the steps of an epoch are enqueued
-        by one native call (kge_pull_run), so there are no per-step events."""
-        if not (pull or pull_dp):
-            for k in range(n):
-                one_step(None if events is None else events[k])
-            return
-        while n > 0:
-            if gen._pending <= 0:
-                gen.start_one_epoch(steps_per_epoch)
-            k = min(n, gen._pending)
-            tr.step_next_batches(k)
-            n -= k
+    reset_model = lambda: reset_headline(H)
+    run_steps = lambda n, events=None: run_headline_steps(H, n, events)
 
     def barrier():
         torch.cuda.synchronize()
@@ -536,12 +731,16 @@ def main():
     kern_ms = region_ms_per_step if pull else burst_ms
     reset_model()
     alg_bytes = 2 * per_rank_batch * TRAIN_BYTES_PER_SCORED_TRIPLE
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     tr.sync_model()
     # ---- eval leg: filtered ranks of n_eval test triples per rank
     ev = Evaluator(model, cfg)
-    ev.rank_all(my_test, n_eval)  # warm-up (also builds the device CSR once)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev.rank_all(my_test, n_eval)  # first pass: builds the per-query filter CSR, uploads it, loads the code objects
+    torch.cuda.synchronize()
+    eval_first_ms = (time.perf_counter() - t0) * 1e3
+    eval_setup = dict(getattr(ev, "setup_stats", {}) or {})
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -565,7 +764,7 @@ def main():
     mean_rank = float(ranks[:2].float().mean().item()) + 1.0
 
     # ---- the reference's DEFAULT batch (B=128, common.py:48) through Trainer.train_model_epoch: the launch-bound
-    # regime, replayed as a hipGraph (N=1 only; informational, not `value`)
+    # regime (N=1 only; informational, not `value`)
     small = None
     if world == 1:
         cfg_s = make_config(E, R, 128 * 400, 128, device, hidden_size=DIM, l1_flag=True)
@@ -581,6 +780,9 @@ def main():
                           else "eager")}
         del tr_s
 
+    # ---- HBM traffic of every leg, observed in THIS run by two rocprofv3 counter passes over a short child run (N=1, rank 0)
+    live, live_meta = (None, "disabled (--no-live-pmc)") if (args.no_live_pmc or world > 1) else live_pmc(args)
+
     out = None
     kernel_label = ("k_pull_eval<L1,G=32> + k_pull_step<Adam,L1,G=32,two-phase> (owner-computes step in two launches: every pair evaluated "
                     "once -- 4 row gathers, hinge, 2-bit direction codes --, then one owner per row sums the records of its incidences, "
@@ -590,13 +792,42 @@ def main():
                     "k_pull_step<gradient,G=32,NCH=4> (owner-computes gradient of the rank's share of the batch: per-row re-evaluation of "
                     "incident pairs, hinge, backward, normalisation backward; dense gradient rows written once, no atomics)" if pull_dp else
                     "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)")
-    if two_phase:
+    traffic_kernels = None
+    if live is not None and "bytes" in live.get("C1_train", {}):
+        leg = live["C1_train"]
+        traffic, traffic_src = leg["bytes"], ("observed in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) "
+                                             "over %d steps of the same step path in a child process, all kernels between the marker launches" % leg["units"])
+        traffic_kernels = leg["kernels"]
+    elif two_phase:
         t1, s1 = pmc_traffic("kge::k_pull_step<1, true, 32, 1, true>", per_rank_batch, fetch_scale=2.0)
         t2, s2 = pmc_traffic("kge::k_pull_eval<true, 32", per_rank_batch, fetch_scale=2.0)
-        traffic, traffic_src = (t1 + t2, "%s + %s" % (s1, s2)) if (t1 is not None and t2 is not None) else (None, None)
+        traffic, traffic_src = (t1 + t2, "committed passes (not observed in this run: %s): %s + %s" % (live_meta, s1, s2)) if (t1 is not None and t2 is not None) else (None, None)
     else:
         traffic, traffic_src = (None, None) if pull_dp else pmc_traffic(
             "kge::k_pull_step<1, true, 32, 1, false>" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch, fetch_scale=2.0 if pull else 1.0)
+        if traffic is not None:
+            traffic_src = "committed passes (not observed in this run: %s): %s" % (live_meta, traffic_src)
+    nominal = alg_bytes / (kern_ms * 1e-3) / 1e9
+    achieved = traffic / (kern_ms * 1e-3) / 1e9 if traffic else nominal
+    # what bounds the owner kernel when it is not bandwidth: one residency round of owner groups, each a chain of dependent loads
+    # (item -> row + optimiser state + visit lists -> records / direction codes -> stores).  Hop latency under load from the committed
+    # random-row microbenchmark, interpolated in the number of concurrently resident groups.
+    latency_model = None
+    if pull and not pull_dp:
+        ps_, idx_ = tr._pull_state()
+        n_groups = int(idx_.batch(0)[2].shape[0]) * K.pull_groups_per_block(DIM)
+        resident = 256 * 4 * 8 * 2     # CUs x SIMDs x 8 waves (36-62 VGPRs) x two 32-lane owner groups per wave
+        load = min(1.0, max(0.0, (min(n_groups, resident) - 8192) / (32768 - 8192.0)))
+        hop_us = HOP_US_AT_8K_GROUPS + load * (HOP_US_AT_32K_GROUPS - HOP_US_AT_8K_GROUPS)
+        hops = 4 if two_phase else 5    # item -> {row, state, lists} -> {records + codes | three hat rows per visit -> ...} -> store drain
+        rounds = max(1.0, n_groups / float(resident))
+        latency_model = {"owner_groups": n_groups, "resident_groups": resident, "residency_rounds": rounds,
+                         "dependent_hops_per_owner": hops, "hop_latency_us": hop_us,
+                         "hop_latency_source": "profiles/r03_gather_bench.txt (chain G=32: 21.53 us / 8 hops at 32768 groups, 9.23 us / 8 at 8192)",
+                         "predicted_owner_kernel_us": rounds * hops * hop_us,
+                         "note": "floor of the owner launch from latency alone: rounds x hops x loaded hop latency; the measured launch adds "
+                                 "the visits' arithmetic (4.3 us with the visits compiled out, profiles/r03_experiments.md section 11) and the "
+                                 "Adam finish (IEEE div / sqrt per element).  Compare with rocprofv3's k_pull_step average in profiles/r04_kernel_stats.md"}
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
@@ -615,13 +846,21 @@ def main():
                                     "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step"},
             "roofline": {"kernel": kernel_label, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "frac_note": ("`achieved` divides the ALGORITHMIC bytes of SURVEY section 8(d) (forward gathers + gradient read-modify-"
-                                       "write + ids per scored triple: 3628 B) by the measured duration.  The owner-computes step performs no "
-                                       "gradient read-modify-write and evaluates every pair once, so this nominal figure can exceed 1; the "
-                                       "bytes that actually cross the fabric are `traffic` (PMC), i.e. `traffic_frac` of the HBM peak"),
-                         "traffic_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "frac_basis": ("bytes that crossed the L2 <-> fabric boundary per step (PMC: 2 x FETCH_SIZE + WRITE_SIZE, `traffic`) / "
+                                        "avg_launch_ms / peak: a physical fraction, <= 1 by construction" if traffic else
+                                        "NO counter figure available (%s): algorithmic bytes / avg_launch_ms / peak -- nominal, see nominal_note" % (live_meta,)),
                          "traffic": traffic,
-                         "traffic_source": traffic_src, "traffic_note": ("2 x FETCH_SIZE (gfx950: 16-byte-per-lane reads are tallied at half) + WRITE_SIZE" if pull else "FETCH_SIZE + WRITE_SIZE, raw"), "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic_source": traffic_src,
+                         "traffic_note": ("2 x FETCH_SIZE (gfx950: 16-byte-per-lane reads are tallied at half, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; "
+                                          "the counters sit on the fabric side of the per-XCD L2s and include Infinity-Cache hits" if pull else "FETCH_SIZE + WRITE_SIZE, raw"),
+                         "traffic_kernels": traffic_kernels,
+                         "nominal_achieved": nominal, "nominal_frac": nominal / HBM_PEAK_GBS,
+                         "nominal_note": ("ALGORITHMIC bytes of SURVEY section 8(d) (forward gathers + gradient read-modify-write + ids per scored "
+                                          "triple: 3628 B) / avg_launch_ms.  The owner-computes step performs no gradient read-modify-write and "
+                                          "gathers from 6.5 MB tables that stay in L2 / Infinity Cache, so this figure can exceed 1: it is kept "
+                                          "for continuity with SURVEY 8(d), it is not a fraction of a roof the kernel can hit"),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "latency_model": latency_model,
                          "avg_launch_ms": kern_ms,
                          "avg_launch_ms_method": ("HIP events on the launch stream around the timed region / steps (%s per step; "
                                                   "includes the dispatch gaps between consecutive launches)" % ("two launches" if two_phase else "one launch") if pull else
@@ -634,6 +873,10 @@ def main():
                                                        "the dispatch gap in front of the kernel"},
             "eval": {"value": eval_value, "unit": "test triples ranked/s", "test_triples_per_gpu": n_eval,
                      "ms_per_pass": edt * 1e3, "mean_rank_check": mean_rank,
+                     "setup_ms": eval_setup.get("csr_ms", max(0.0, eval_first_ms - edt * 1e3)),
+                     "setup": dict(eval_setup, first_pass_ms=eval_first_ms,
+                                   what="per-query filter lists (hr_t / tr_h of train + valid + test, data/kgcontroller.py:410-428) as CSR on the "
+                                        "device, built once per evaluated split; the reference looks the sets up per query inside its rank loop"),
                      "roofline": {"kernel": "kge_eval_ranks pipeline (k_eval_sweep<L1,QT=16> dominant)", "bound": "valu",
                                   "achieved": eval_elem_rate / 1e12, "peak": valu_peak_elems / 1e12,
                                   "unit": "T (query,candidate,k) elements/s", "frac": eval_elem_rate / valu_peak_elems,
@@ -648,35 +891,48 @@ def main():
                                   "algorithmic_note": "400 B per scored candidate (SURVEY 8d); each candidate tile is "
                                                       "reused by 16 queries from registers, so this exceeds the HBM "
                                                       "peak and is not the bound",
-                                  "traffic": None}},
+                                  "traffic": None, "traffic_source": None}},
         }
+        er = out["eval"]["roofline"]
+        if live is not None and "bytes" in live.get("C1_eval", {}):
+            leg = live["C1_eval"]
+            er["traffic"], er["traffic_source"] = leg["bytes"], "observed in this run (rocprofv3 counter passes, %d passes, all kernels of a pass)" % leg["units"]
+            er["traffic_kernels"] = leg["kernels"]
+        else:
+            tsw, ssw = pmc_traffic("kge::k_eval_sweep<0, 0, 16", 32768, fetch_scale=2.0)
+            if tsw is not None:
+                er["traffic"], er["traffic_source"] = tsw, "committed passes, k_eval_sweep only (not observed in this run: %s): %s" % (live_meta, ssw)
+        if er["traffic"]:
+            er["traffic_GBps"] = er["traffic"] / (eval_kern_ms * 1e-3) / 1e9
+            er["traffic_hbm_frac"] = er["traffic_GBps"] / HBM_PEAK_GBS
         if setup is not None:
             setup["gpu_step_equivalents"] = setup["host_wall_ms_warm"] / (dt / args.steps * 1e3)
             out["setup_ms"] = setup["host_wall_ms_warm"]
             out["setup"] = setup
         if small is not None:
             out["train_reference_default_batch"] = small
+        out["live_pmc"] = live_meta if not isinstance(live_meta, str) else {"unavailable": live_meta}
     if world == 1 and not args.no_extra_configs:
         extra = {}
         for key in EXTRA_CONFIGS:
             try:
                 extra[key] = run_extra_config(key, device)
+                for legname, field in ((key + "_train", "train"), (key + "_eval", "eval")):
+                    leg = (live or {}).get(legname)
+                    if leg and "bytes" in leg:
+                        secs = extra[key]["step_us"] * 1e-6 if field == "train" else extra[key]["eval_ms_per_pass"] * 1e-3
+                        extra[key][field + "_traffic"] = {
+                            "bytes_per_" + ("step" if field == "train" else "pass"): leg["bytes"], "fetch_raw_bytes": leg["fetch_raw_bytes"],
+                            "write_bytes": leg["write_bytes"], "GBps": leg["bytes"] / secs / 1e9, "hbm_frac": leg["bytes"] / secs / 1e9 / HBM_PEAK_GBS,
+                            "source": "observed in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over %d %s" % (
+                                leg["units"], "steps" if field == "train" else "passes"),
+                            "kernels": leg["kernels"]}
             except Exception as e:  # an `extra` record must never take the headline line down
                 extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["extra"] = extra
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            v, cores, sample = cpu_baseline_train(train)
-            P_np = {"ent_embeddings": model.ent_embeddings.weight.detach().cpu().numpy(),
-                    "rel_embeddings": model.rel_embeddings.weight.detach().cpu().numpy()}
-            ve, ne = cpu_baseline_eval(P_np, my_test, build_filter_csr(my_test, hr_t, tr_h))
-            out["cpu_baseline"] = {"value": v, "unit": "scored triples/s", "cores": cores, "kind": "port",
-                                   "sample": sample,
-                                   "eval": {"value": ve, "unit": "test triples ranked/s",
-                                            "sample": "%d test triples, two full-entity sweeps each, C/OpenMP fp32" % ne}}
-            ref = reference_cpu_numbers()
-            if ref is not None:
-                out["cpu_baseline"]["reference_in_build_container"] = ref
+            out["cpu_baseline"] = cpu_baseline(H)
         if world > 1:
             out["phases_us"] = phases_us
             out["collectives"] = {"backend": dist.get_backend(), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "(unset: RCCL picks)"),

@@ -75,6 +75,42 @@ typedef struct kge_model_desc {
 int kge_abi_version(void);
 const char* kge_last_error(void);
 
+/* Debug mode: range-check every id the caller hands in against its table before anything is launched
+ * (0 <= entity id < tot_entity, 0 <= relation id < tot_relation) -- what nn.Embedding does for the reference by raising
+ * IndexError (models/Domain.py:8-13).  Off by default (the kernels index with the ids as given); on with kge_set_debug(1) or
+ * KGE_DEBUG_IDS=1 in the environment.  A failing call returns -3, kge_last_error() names the entry point, the column, the first
+ * offending position and value.  The scan synchronises the stream (skipped while the stream is being captured).
+ * Covered: kge_score_forward/backward, kge_train_pairwise_hinge, kge_train_pairwise_selfadv, kge_train_pointwise_logistic,
+ * kge_rescal_pair_step, every *_sampled entry point (the batch rows triples[perm[start..start+n)]), kge_sample_batch, kge_corrupt,
+ * kge_triple_set_build, kge_pull_index_build (all listed batches: which covers the owner-computes runs built on that index),
+ * kge_eval_ranks / _grouped / kge_eval_sweep_scores, kge_rank_from_scores. */
+int kge_set_debug(int32_t check_ids);
+/* A/B switches of the dispatch rules: RESCAL_UNFUSED, RESCAL_ROWS, RESCAL_G, EVAL_GEMM, HEAD_TILE, NTN_BIG,
+ * OPT_NT, PULL_G, ROTATE_SPLIT.  value >= 0 forces it, -1 hands the decision back to the environment variable KGE_<name> (an
+ * integer; "0" off, "1" on) or, if that is unset, to the built-in rule.  Same meaning on both sides of the boundary. */
+int kge_set_switch(const char* name, int32_t value);
+int kge_get_debug(void);
+/* The scan itself, unconditionally: -3 if some ids[i] is outside [0, bound). */
+int kge_check_ids(const int64_t* ids, int64_t n, int64_t bound, void* stream);
+/* ---- filter lists of the rank sweep, built on the device (kge_index.hip).
+ * Replaces the per-query lookups into hr_t[(h, r)] / tr_h[(t, r)] -- dicts of sets over train + valid + test,
+ * data/kgcontroller.py:410-428, consulted inside the reference's rank loop utils/evaluator.py:70-123 -- by per-query CSR lists:
+ * query i's known tails are tail_ids[tail_off[i] .. tail_off[i+1]) (distinct, ascending), its known heads likewise.
+ * known: int64 [n_known, 3] (the three splits concatenated, duplicates allowed), queries: int64 [n_queries, 3].
+ * Two calls because the caller owns every buffer: _count sorts the packed keys into `workspace` (kge_filter_csr_workspace_bytes)
+ * and writes the offsets [n_queries + 1] and totals[2] = {sum of tail list lengths, sum of head list lengths}; the caller reads
+ * totals, sizes the id arrays, and _fill writes them (same workspace, untouched in between). */
+size_t kge_filter_csr_workspace_bytes(int64_t n_known, int64_t n_queries);
+int kge_filter_csr_count(const int64_t* known, int64_t n_known, const int64_t* queries, int64_t n_queries, int64_t tot_entity,
+                         int64_t tot_relation, void* workspace, size_t workspace_bytes, int64_t* tail_off, int64_t* head_off,
+                         int64_t* totals, void* stream);
+int kge_filter_csr_fill(const int64_t* queries, int64_t n_queries, int64_t n_known, const void* workspace, const int64_t* tail_off,
+                        const int64_t* head_off, int32_t* tail_ids, int32_t* head_ids, void* stream);
+
+/* An empty kernel launch of `tag` workgroups of 64 threads ("kge::k_marker"): a boundary that shows up in a rocprofv3 kernel /
+ * counter trace.  bench.py's counter passes use it to cut one process's dispatch sequence into per-configuration segments. */
+int kge_debug_marker(int32_t tag, void* stream);
+
 /* Scratch bytes the score / train entry points need for a call on n rows (n pairs for the pairwise step).
  * 0 for the gather-type models; RESCAL and TransR group the batch by relation on the device (about 5R + n + n/32 ints per side),
  * NTN keeps n*(4d + 3k_r + 6) floats of intermediates per side; the hinge step adds 2n floats. */

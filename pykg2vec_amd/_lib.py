@@ -128,6 +128,16 @@ _SIGNATURES = {
                                                                     ctypes.c_void_p]),
     "kge_optimizer_step_staged": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(StagedStep), ctypes.c_float, ctypes.c_int64, ctypes.c_void_p]),
     "kge_abi_version": (ctypes.c_int, []),
+    "kge_set_debug": (ctypes.c_int, [ctypes.c_int32]),
+    "kge_set_switch": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32]),
+    "kge_get_debug": (ctypes.c_int, []),
+    "kge_check_ids": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "kge_debug_marker": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p]),
+    "kge_filter_csr_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64]),
+    "kge_filter_csr_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_filter_csr_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_last_error": (ctypes.c_char_p, []),
     "kge_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc), ctypes.c_int64]),
     "kge_score_forward": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

@@ -119,6 +119,7 @@ int kge_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* 
     if (n == 0) return 0;
     if (n < 0 || !h || !r || !t || !scores) { set_error("kge_score_forward: bad arguments"); return -1; }
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = debug_check_hrt("kge_score_forward", m, h, r, t, n, s)) return rc;
     if (m->model == KGE_RESCAL) return launch_rescal_forward(m, h, r, t, n, scores, workspace, workspace_bytes, s);
     if (m->model == KGE_NTN) return launch_ntn_forward(m, h, r, t, n, scores, workspace, workspace_bytes, s);
     if (m->model == KGE_TRANSR) return launch_transr_forward(m, h, r, t, n, scores, workspace, workspace_bytes, s);
@@ -131,6 +132,7 @@ int kge_score_backward(const kge_model_desc* m, const int64_t* h, const int64_t*
     if (n == 0) return 0;
     if (n < 0 || !h || !r || !t || !dscore) { set_error("kge_score_backward: bad arguments"); return -1; }
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = debug_check_hrt("kge_score_backward", m, h, r, t, n, s)) return rc;
     if (m->model == KGE_RESCAL) return launch_rescal_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, false, s);
     if (m->model == KGE_NTN) return launch_ntn_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, false, s);
     if (m->model == KGE_TRANSR) return launch_transr_backward(m, h, r, t, n, dscore, workspace, workspace_bytes, false, s);
@@ -160,6 +162,8 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
     if (n == 0) return 0;
     if (n < 0 || !ph || !pr || !pt || !nh || !nr || !nt || !loss) { set_error("kge_train_pairwise_hinge: bad arguments"); return -1; }
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = debug_check_hrt("kge_train_pairwise_hinge (positives)", m, ph, pr, pt, n, s)) return rc;
+    if (int rc = debug_check_hrt("kge_train_pairwise_hinge (negatives)", m, nh, nr, nt, n, s)) return rc;
     if (is_vector_model(m->model)) return launch_pairwise_hinge(m, ph, pr, pt, nh, nr, nt, n, margin, loss, s);
     // dense-contraction models: forward over [positives | negatives], hinge coefficients in place, backward over the same 2n
     const size_t gws = align256(dense_workspace_bytes(m, n));
@@ -174,7 +178,7 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
     if (m->model == KGE_RESCAL) {
         // nr == pr (the same buffer: the caller's way of saying that negatives keep their positives' relations, as every sampler
         // of the reference does): scores, hinge and gradients of a (relation, 16 pairs) tile in one launch
-        static const bool unfused = getenv("KGE_RESCAL_UNFUSED") != nullptr;   // A/B switch, read once
+        const bool unfused = switch_value("RESCAL_UNFUSED") == 1;   // A/B switch (same 0 / 1 meaning as Trainer.switches)
         if (nr == pr && rescal_pair_step_ok(m, n, 2 * gws) && !unfused)
             return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, wsp, 2 * gws, nullptr, s);
         // positives and negatives as ONE grouped batch of 2n triples (scores / coefficients contiguous: sp | sn); the
@@ -210,6 +214,8 @@ int kge_train_pairwise_hinge_sampled(const kge_model_desc* m, const int64_t* tri
         set_error("kge_train_pairwise_hinge_sampled: model %d needs kge_sample_batch + kge_train_pairwise_hinge", m->model);
         return -1;
     }
+    if (!dev_cursor)
+        if (int rc = debug_check_triples("kge_train_pairwise_hinge_sampled", m->tot_entity, m->tot_relation, triples, n, (hipStream_t)stream, perm, start)) return rc;
     return launch_pairwise_hinge_sampled(m, triples, perm, start, n, bern_prob, slots, n_slots, seed, offset, dev_cursor,
                                          margin, loss, (hipStream_t)stream);
 }
@@ -225,6 +231,8 @@ int kge_train_pairwise_selfadv(const kge_model_desc* m, const int64_t* ph, const
     }
     if (!is_vector_model(m->model)) { set_error("kge_train_pairwise_selfadv: unsupported model %d", m->model); return -1; }
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = debug_check_hrt("kge_train_pairwise_selfadv (positives)", m, ph, pr, pt, n_pos, s)) return rc;
+    if (int rc = debug_check_hrt("kge_train_pairwise_selfadv (negatives)", m, nh, nr, nt, n_pos * neg_rate, s)) return rc;
     {   // fused bundle kernel (one launch) whenever the negatives of a positive fit one lane group
         const int rc1 = launch_selfadv_bundle(m, ph, pr, pt, nh, nr, nt, n_pos, neg_rate, alpha, loss, s);
         if (rc1 <= 0) return rc1;
@@ -252,6 +260,8 @@ int kge_train_pairwise_selfadv_sampled(const kge_model_desc* m, const int64_t* t
         return -1;
     }
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_train_pairwise_selfadv_sampled: n_slots must be a power of two"); return -1; }
+    if (!dev_cursor)
+        if (int rc = debug_check_triples("kge_train_pairwise_selfadv_sampled", m->tot_entity, m->tot_relation, triples, n_pos, (hipStream_t)stream, perm, start)) return rc;
     return launch_rotate_bundle_sampled(m, triples, perm, start, n_pos, neg_rate, alpha, bern_prob, slots, n_slots, seed,
                                         offset, dev_cursor, loss, nullptr, nullptr, (hipStream_t)stream);
 }
@@ -301,6 +311,7 @@ int kge_train_pairwise_selfadv_sampled_staged(const kge_model_desc* m, const int
     if (slots && (n_slots & (n_slots - 1))) { set_error("%s: n_slots must be a power of two", who); return -1; }
     if (m->model != KGE_ROTATE) { set_error("%s: RotatE only", who); return -1; }
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = debug_check_triples(who, m->tot_entity, m->tot_relation, triples, n_pos, s, perm, start)) return rc;
     StageSink sink;
     const int rc = staged_sink(m, st, n_pos, neg_rate, 5, 2, who, s, &sink);
     if (rc) return rc;
@@ -322,6 +333,7 @@ int kge_train_pointwise_logistic_sampled_staged(const kge_model_desc* m, const i
     if (slots && (n_slots & (n_slots - 1))) { set_error("%s: n_slots must be a power of two", who); return -1; }
     if (reg_type < KGE_REG_NONE || reg_type > KGE_REG_ID_N3) { set_error("%s: bad reg_type %d", who, reg_type); return -1; }
     if (m->model != KGE_DISTMULT && m->model != KGE_COMPLEX) { set_error("%s: DistMult / ComplEx only", who); return -1; }
+    if (int rc = debug_check_triples(who, m->tot_entity, m->tot_relation, triples, n_pos, (hipStream_t)stream, perm, start)) return rc;
     StageSink sink;
     const int rc = staged_sink(m, st, n_pos, neg_rate, m->model == KGE_COMPLEX ? 6 : 3, m->model == KGE_COMPLEX ? 2 : 1, who,
                                (hipStream_t)stream, &sink);
@@ -343,6 +355,7 @@ int kge_train_pointwise_logistic(const kge_model_desc* m, const int64_t* h, cons
     if (n < 0 || !h || !r || !t || !y || !loss) { set_error("kge_train_pointwise_logistic: bad arguments"); return -1; }
     if (reg_type < KGE_REG_NONE || reg_type > KGE_REG_ID_N3) { set_error("kge_train_pointwise_logistic: bad reg_type %d", reg_type); return -1; }
     if (!is_vector_model(m->model)) { set_error("kge_train_pointwise_logistic: unsupported model %d", m->model); return -1; }
+    if (int rc = debug_check_hrt("kge_train_pointwise_logistic", m, h, r, t, n, (hipStream_t)stream)) return rc;
     return launch_pointwise_logistic(m, h, r, t, y, n, bundle, lmbda, reg_type, loss, nullptr, (hipStream_t)stream);
 }
 
@@ -357,6 +370,8 @@ int kge_train_pointwise_logistic_sampled(const kge_model_desc* m, const int64_t*
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_train_pointwise_logistic_sampled: n_slots must be a power of two"); return -1; }
     if (reg_type < KGE_REG_NONE || reg_type > KGE_REG_ID_N3) { set_error("kge_train_pointwise_logistic_sampled: bad reg_type %d", reg_type); return -1; }
     if (!is_vector_model(m->model)) { set_error("kge_train_pointwise_logistic_sampled: unsupported model %d", m->model); return -1; }
+    if (!dev_cursor)
+        if (int rc = debug_check_triples("kge_train_pointwise_logistic_sampled", m->tot_entity, m->tot_relation, triples, n_pos, (hipStream_t)stream, perm, start)) return rc;
     return launch_pointwise_logistic_sampled(m, triples, perm, start, n_pos, neg_rate, bern_prob, slots, n_slots, seed, offset,
                                              dev_cursor, lmbda, reg_type, loss, (hipStream_t)stream);
 }
@@ -380,6 +395,8 @@ int kge_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64
         set_error("kge_rescal_pair_step: hidden size %d (needs an even size, at most 256) or workspace (kge_workspace_bytes)", m->dim);
         return -1;
     }
+    if (int rc = debug_check_hrt("kge_rescal_pair_step (positives)", m, ph, pr, pt, n, (hipStream_t)stream)) return rc;
+    if (int rc = debug_check_hrt("kge_rescal_pair_step (negatives)", m, nh, pr, nt, n, (hipStream_t)stream)) return rc;
     return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, workspace, workspace_bytes, touched_rows, (hipStream_t)stream);
 }
 
@@ -752,6 +769,7 @@ int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, c
     if (n == 0) return 0;
     if (n < 0 || !triples || !ranks) { set_error("kge_eval_ranks: bad arguments"); return -1; }
     if ((tail_off && !tail_ids) || (head_off && !head_ids)) { set_error("kge_eval_ranks: CSR offsets without ids"); return -1; }
+    if (int rc = debug_check_triples("kge_eval_ranks", m->tot_entity, m->tot_relation, triples, n, (hipStream_t)stream)) return rc;
     return launch_eval_ranks(m, triples, n, tail_off, tail_ids, head_off, head_ids, workspace, workspace_bytes, ranks,
                              (hipStream_t)stream);
 }
@@ -772,6 +790,7 @@ int kge_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int6
         return -1;
     }
     if ((tail_off && !tail_ids) || (head_off && !head_ids)) { set_error("kge_eval_ranks_grouped: CSR offsets without ids"); return -1; }
+    if (int rc = debug_check_triples("kge_eval_ranks_grouped", m->tot_entity, m->tot_relation, triples, n, (hipStream_t)stream)) return rc;
     return launch_eval_ranks_grouped(m, triples, n, group_of_triple, group_rel, n_groups, qblocks, n_qblocks, tail_off, tail_ids,
                                      head_off, head_ids, workspace, workspace_bytes, ranks, (hipStream_t)stream);
 }
@@ -781,6 +800,7 @@ int kge_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64
     if (validate(m, false, "kge_eval_sweep_scores")) return -1;
     if (n == 0) return 0;
     if (n < 0 || !triples || !scores) { set_error("kge_eval_sweep_scores: bad arguments"); return -1; }
+    if (int rc = debug_check_triples("kge_eval_sweep_scores", m->tot_entity, m->tot_relation, triples, n, (hipStream_t)stream)) return rc;
     return launch_eval_sweep_scores(m, triples, n, workspace, workspace_bytes, scores, (hipStream_t)stream);
 }
 
@@ -791,6 +811,7 @@ int kge_rank_from_scores(const float* scores, int64_t nq, int64_t tot_entity, co
         set_error("kge_rank_from_scores: bad arguments");
         return -1;
     }
+    if (int rc = debug_check_ids("kge_rank_from_scores", "true entity", truth, nq, 1, 0, tot_entity, (hipStream_t)stream)) return rc;
     return launch_rank_from_scores(scores, nq, tot_entity, truth, off, ids, rank, frank, (hipStream_t)stream);
 }
 
@@ -799,6 +820,8 @@ int kge_triple_set_build(const int64_t* triples, int64_t n, uint64_t* slots, int
         set_error("kge_triple_set_build: n_slots must be a power of two >= 2n");
         return -1;
     }
+    // (the packed key h:24 | r:16 | t:24 is the only bound this entry point knows)
+    if (int rc = debug_check_triples("kge_triple_set_build", (int64_t)1 << 24, (int64_t)1 << 16, triples, n, (hipStream_t)stream)) return rc;
     return launch_triple_set_build(triples, n, slots, n_slots, (hipStream_t)stream);
 }
 
@@ -811,6 +834,8 @@ int kge_corrupt(const int64_t* ph, const int64_t* pr, const int64_t* pt, int64_t
         return -1;
     }
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_corrupt: n_slots must be a power of two"); return -1; }
+    if (int rc = debug_check_ids("kge_corrupt", "head", ph, n_pos, 1, 0, tot_entity, (hipStream_t)stream)) return rc;
+    if (int rc = debug_check_ids("kge_corrupt", "tail", pt, n_pos, 1, 0, tot_entity, (hipStream_t)stream)) return rc;
     return launch_corrupt(ph, pr, pt, n_pos, neg_rate, tot_entity, bern_prob, slots, n_slots, seed, offset, nh, nr, nt,
                           (hipStream_t)stream);
 }
@@ -826,6 +851,10 @@ int kge_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start,
         return -1;
     }
     if (slots && (n_slots & (n_slots - 1))) { set_error("kge_sample_batch: n_slots must be a power of two"); return -1; }
+    if (!dev_cursor) {   // (entity columns only: this entry point is not told the relation count)
+        if (int rc = debug_check_ids("kge_sample_batch", "head", triples, n_pos, 3, 0, tot_entity, (hipStream_t)stream, perm, start)) return rc;
+        if (int rc = debug_check_ids("kge_sample_batch", "tail", triples, n_pos, 3, 2, tot_entity, (hipStream_t)stream, perm, start)) return rc;
+    }
     int64_t* const out[6] = {o0, o1, o2, o3, o4, o5};
     return launch_sample_batch(triples, perm, start, n_pos, neg_rate, tot_entity, bern_prob, slots, n_slots, seed, offset,
                                layout, out, dev_cursor, (hipStream_t)stream);

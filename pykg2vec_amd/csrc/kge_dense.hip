@@ -1218,8 +1218,7 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
     const int S = (k + 1) | 1;
     const size_t lds_gm = (size_t)(2 * TILE * S + TILE) * sizeof(float) + (size_t)2 * TILE * sizeof(long long);
     // large batches: V / U as batch-as-M GEMMs (k_rescal_rows), dL/denergy to the relation-owner launch below (KGE_RESCAL_ROWS=0/1: A/B)
-    const char* rows_env = getenv("KGE_RESCAL_ROWS");
-    const bool rows = ds != nullptr && k <= 208 && !(rows_env && rows_env[0] == '0');
+    const bool rows = ds != nullptr && k <= 208 && switch_value("RESCAL_ROWS") != 0;
     if (rows) {
         const int nb = (k + 15) / 16;
 #define KGE_RR(J) case J: hipLaunchKernelGGL(k_rescal_rows<J>, dim3(tiles), dim3(256), 0, s, m->tables[0], m->tables[1], m->grads[0], ph, pt, nh, \
@@ -1227,9 +1226,9 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
         switch (nb) { KGE_RR(1) KGE_RR(2) KGE_RR(3) KGE_RR(4) KGE_RR(5) KGE_RR(6) KGE_RR(7) KGE_RR(8) KGE_RR(9) KGE_RR(10) KGE_RR(11) KGE_RR(12) KGE_RR(13) }
 #undef KGE_RR
     }
-    const char* g_env = getenv("KGE_RESCAL_G");
+    const int g_sw = switch_value("RESCAL_G");
     // the relation-matrix gradient as a GEMM over gathered rows (k_rescal_g) where relations span several 128-pair runs
-    const bool gemm_g = rows && (g_env ? g_env[0] == '1' : n >= 128 * R);
+    const bool gemm_g = rows && (g_sw >= 0 ? g_sw == 1 : n >= 128 * R);
 #define KGE_RP(VK_)                                                                                                              \
     {                                                                                                                            \
         if (!rows)                                                                                                               \

@@ -1417,8 +1417,8 @@ static void fill_prep(const kge_model_desc* m, const EvalPlan& p, PrepArgs* a) {
 // Dot-product forms go to the matrix cores when there are enough queries to fill 128-wide tiles; KGE_EVAL_GEMM=0 / 1 forces
 // the choice (A/B runs).
 static bool use_gemm_sweep(const EvalPlan& p, int64_t nq) {
-    const char* force = getenv("KGE_EVAL_GEMM");
-    if (force) return force[0] == '1';
+    const int force = switch_value("EVAL_GEMM");
+    if (force >= 0) return force == 1;
     return nq >= 512 && p.Kpad >= 32;
 }
 

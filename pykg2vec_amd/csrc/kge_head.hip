@@ -201,8 +201,8 @@ __global__ __launch_bounds__(256, 3) void k_head_gemm128(HeadArgs a) {
 
 // the large tile pays once the grid fills the chip with it and the rows can be fetched 16 bytes at a time
 static bool head_use_128(const HeadArgs& a) {
-    const char* force = getenv("KGE_HEAD_TILE");
-    if (force) return force[0] == '1' && a.d % 4 == 0;
+    const int force = switch_value("HEAD_TILE");
+    if (force >= 0) return force == 1 && a.d % 4 == 0;
     const int64_t tiles = ((a.E + HT2 - 1) / HT2) * ((a.B + HT2 - 1) / HT2);
     return a.d % 4 == 0 && (((uintptr_t)a.x | (uintptr_t)a.ent) & 15) == 0 && tiles >= 512;
 }

@@ -318,11 +318,136 @@ static bool index_geometry(int64_t nb, int64_t n, int64_t E, int64_t R, int seg,
     return true;
 }
 
+// ================================================================ filter lists of the rank sweep as per-query CSR, on the device
+// What it replaces: the reference keeps hr_t[(h, r)] / tr_h[(t, r)] as dicts of python sets built from train + valid + test
+// (data/kgcontroller.py:410-428) and looks them up per query inside its rank loop (utils/evaluator.py:70-123).  Round 3 flattened the
+// dicts with a python loop on the host (17 ms for 8 192 queries, 124 ms for the FB15k test set).  Here: pack every known triple into
+// two 64-bit keys (h:24 | r:16 | t:24 and t:24 | r:16 | h:24), sort both arrays with the batched bitonic sort above, and let one
+// wave per query find its run by binary search; duplicates (a triple present in two splits) are dropped because the lists are SETS.
+// Pass 1 counts, a one-block scan turns counts into int64 offsets, pass 2 (after the caller has sized the id arrays) fills them.
+// Integer work only.  Ids of a query come out ascending (the dict's iteration order is arbitrary; the sweep only tests membership).
+__global__ __launch_bounds__(256) void k_csr_keys(const int64_t* __restrict__ known, int64_t M, int P, u64* __restrict__ keys) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= P) return;
+    u64 a = kKeyPad, b = kKeyPad;
+    if (j < M) {
+        const u64 h = (u64)known[3 * j], r = (u64)known[3 * j + 1], t = (u64)known[3 * j + 2];
+        a = (h << 40) | (r << 24) | t;
+        b = (t << 40) | (r << 24) | h;
+    }
+    keys[j] = a;
+    keys[(int64_t)P + j] = b;
+}
+
+__device__ __forceinline__ int64_t csr_lower_bound(const u64* __restrict__ k, int64_t n, u64 v) {   // first index with k[i] >= v
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (k[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// one wave per (query, side): side 0 = tails of (h, r, *), side 1 = heads of (*, r, t).  FILL = false: count[side][q] = number of
+// distinct ids; FILL = true: ids[off[q] ...] = the distinct ids, ascending.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_csr_query(const int64_t* __restrict__ queries, int64_t n, const u64* __restrict__ keys, int P,
+                                                   int64_t M, int* __restrict__ count, const int64_t* __restrict__ off_t,
+                                                   const int64_t* __restrict__ off_h, int32_t* __restrict__ ids_t, int32_t* __restrict__ ids_h) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= 2 * n) return;
+    const int side = (int)(w & 1);
+    const int64_t q = w >> 1;
+    const u64 a = (u64)queries[3 * q + (side ? 2 : 0)], r = (u64)queries[3 * q + 1];
+    const u64 lo_key = (a << 40) | (r << 24);
+    const u64* k = keys + (side ? (int64_t)P : 0);
+    const int64_t lo = csr_lower_bound(k, M, lo_key), hi = csr_lower_bound(k, M, lo_key | 0xFFFFFFull) ;
+    // (upper bound of the run: first key > lo_key | 0xFFFFFF == lower bound of the next prefix; ids are < 2^24 so the all-ones id never occurs)
+    const int64_t hi2 = (hi < M && k[hi] == (lo_key | 0xFFFFFFull)) ? hi + 1 : hi;
+    int total = 0;
+    int32_t* out = nullptr;
+    if constexpr (FILL) out = side ? ids_h + off_h[q] : ids_t + off_t[q];
+    for (int64_t base = lo; base < hi2; base += 64) {
+        const int64_t j = base + lane;
+        const bool in = j < hi2;
+        const u64 key = in ? k[j] : 0;
+        const bool fresh = in && (j == lo || k[j - 1] != key);
+        const unsigned long long m = __ballot(fresh);
+        if constexpr (FILL) {
+            if (fresh) out[total + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)(key & 0xFFFFFFull);
+        }
+        total += __popcll(m);
+    }
+    if constexpr (!FILL) { if (lane == 0) count[side * n + q] = total; }
+}
+
+// exclusive scan of the two count rows into int64 offsets [n + 1] each; one 1024-thread block
+__global__ __launch_bounds__(kIxBlock) void k_csr_scan(const int* __restrict__ count, int64_t n, int64_t* __restrict__ off_t,
+                                                       int64_t* __restrict__ off_h, int64_t* __restrict__ totals) {
+    __shared__ long long s_carry;
+    for (int side = 0; side < 2; ++side) {
+        int64_t* off = side ? off_h : off_t;
+        if (threadIdx.x == 0) s_carry = 0;
+        __syncthreads();
+        for (int64_t base = 0; base < n; base += kIxBlock) {
+            const int64_t i = base + threadIdx.x;
+            const int v = i < n ? count[side * n + i] : 0;
+            int tot;
+            const int ex = block_scan(v, &tot);
+            const long long carry = s_carry;
+            if (i < n) off[i] = carry + ex;
+            __syncthreads();
+            if (threadIdx.x == 0) s_carry = carry + tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { off[n] = s_carry; totals[side] = s_carry; }
+        __syncthreads();
+    }
+}
+
+static int csr_P(int64_t M) { return pow2_at_least(M, 2048); }
+
 }  // namespace kge
 
 using namespace kge;
 
 extern "C" {
+
+size_t kge_filter_csr_workspace_bytes(int64_t n_known, int64_t n_queries) {
+    if (n_known <= 0 || n_known >= (1ll << 30) || n_queries < 0) return 0;
+    return (size_t)2 * csr_P(n_known) * sizeof(u64) + (size_t)2 * (n_queries + 1) * sizeof(int) + 512;
+}
+
+int kge_filter_csr_count(const int64_t* known, int64_t n_known, const int64_t* queries, int64_t n_queries, int64_t tot_entity,
+                         int64_t tot_relation, void* workspace, size_t workspace_bytes, int64_t* tail_off, int64_t* head_off,
+                         int64_t* totals, void* stream) {
+    const char* who = "kge_filter_csr_count";
+    if (!known || !queries || !workspace || !tail_off || !head_off || !totals || n_known <= 0 || n_queries <= 0) { set_error("%s: bad arguments", who); return -1; }
+    if (tot_entity > (1 << 24) || tot_relation > (1 << 16)) { set_error("%s: the packed key holds 2^24 entities and 2^16 relations", who); return -1; }
+    if (workspace_bytes < kge_filter_csr_workspace_bytes(n_known, n_queries)) { set_error("%s: workspace too small", who); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = debug_check_triples(who, tot_entity, tot_relation, known, n_known, s)) return rc;
+    if (int rc = debug_check_triples(who, tot_entity, tot_relation, queries, n_queries, s)) return rc;
+    const int P = csr_P(n_known);
+    u64* keys = (u64*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    int* count = (int*)(keys + (size_t)2 * P);
+    hipLaunchKernelGGL(k_csr_keys, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, known, n_known, P, keys);
+    int rc = check_launch("k_csr_keys");
+    if (rc) return rc;
+    if ((rc = sort_batched(keys, 2, P, s))) return rc;
+    hipLaunchKernelGGL((k_csr_query<false>), dim3((unsigned)((2 * n_queries + 3) / 4)), dim3(256), 0, s, queries, n_queries, keys, P, n_known,
+                       count, (const int64_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_csr_scan, dim3(1), dim3(kIxBlock), 0, s, count, n_queries, tail_off, head_off, totals);
+    return check_launch("k_csr_scan");
+}
+
+int kge_filter_csr_fill(const int64_t* queries, int64_t n_queries, int64_t n_known, const void* workspace, const int64_t* tail_off,
+                        const int64_t* head_off, int32_t* tail_ids, int32_t* head_ids, void* stream) {
+    if (!queries || !workspace || !tail_off || !head_off || n_queries <= 0 || n_known <= 0) { set_error("kge_filter_csr_fill: bad arguments"); return -1; }
+    const int P = csr_P(n_known);
+    const u64* keys = (const u64*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    hipLaunchKernelGGL((k_csr_query<true>), dim3((unsigned)((2 * n_queries + 3) / 4)), dim3(256), 0, (hipStream_t)stream, queries, n_queries, keys, P,
+                       n_known, (int*)nullptr, tail_off, head_off, tail_ids, head_ids);
+    return check_launch("k_csr_query");
+}
 
 int kge_pull_index_geometry(int64_t n_batches, int64_t n_pairs, int64_t tot_entity, int64_t tot_relation, int32_t segment,
                             int32_t groups_per_block, int32_t compact, int64_t* item_cap, int64_t* multi_cap, int64_t* words,
@@ -355,6 +480,14 @@ int kge_pull_index_build(const int64_t* triples, const int64_t* perm, int64_t ba
     }
     if (segment > 256 / groups_per_block) { set_error("kge_pull_index_build: segment %d exceeds the owner group width", segment); return -1; }
     hipStream_t s = (hipStream_t)stream;
+    if (debug_ids()) {   // every triple the index is about to list (contiguous batches: one scan)
+        if (batch_stride == n_pairs) {
+            if (int rc = debug_check_triples("kge_pull_index_build", tot_entity, tot_relation, triples, n_pairs * n_batches, s, perm, slice_lo)) return rc;
+        } else {
+            for (int64_t b = 0; b < n_batches; ++b)
+                if (int rc = debug_check_triples("kge_pull_index_build", tot_entity, tot_relation, triples, n_pairs, s, perm, slice_lo + b * batch_stride)) return rc;
+        }
+    }
     IxArgs a;
     a.triples = triples; a.perm = perm; a.batch_stride = batch_stride; a.slice_lo = slice_lo;
     a.n = (int)n_pairs; a.nb = (int)n_batches; a.E = (int)tot_entity; a.nrows = (int)(tot_entity + tot_relation);

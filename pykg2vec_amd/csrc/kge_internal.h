@@ -24,6 +24,22 @@ struct Geometry { int G, NCH; };
 bool pick_geometry(int max_row_dim, Geometry* out);
 DeviceModel to_device_model(const kge_model_desc* m);
 
+// kge_debug.hip -- the A/B and debugging switches of DESIGN.md section 5a, in ONE place with ONE meaning: the value set by
+// kge_set_switch(name, v) if any, else the integer in the environment variable KGE_<NAME> ("0" = off, "1" = on, other integers where
+// a switch takes them), else -1 = unset (the built-in rule decides).  A getenv per launch costs ~0.1 us; tests flip the variables
+// inside one process, so nothing is cached.
+int switch_value(const char* name /* without the KGE_ prefix, upper case */);
+
+// kge_debug.hip -- id-range scans of the debug mode (KGE_DEBUG_IDS=1 / kge_set_debug): 0 when the mode is off or every id is in
+// range, -3 (+ kge_last_error) on the first offender; they synchronise the stream and are skipped during graph capture
+bool debug_ids();
+int debug_check_ids(const char* who, const char* what, const int64_t* ids, int64_t n, int stride, int col, int64_t bound, hipStream_t s,
+                    const int64_t* perm = nullptr, int64_t start = 0);
+int debug_check_ids32(const char* who, const char* what, const int32_t* ids, int64_t n, int stride, int col, int64_t bound, hipStream_t s);
+int debug_check_hrt(const char* who, const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n, hipStream_t s);
+int debug_check_triples(const char* who, int64_t tot_entity, int64_t tot_relation, const int64_t* triples, int64_t n, hipStream_t s,
+                        const int64_t* perm = nullptr, int64_t start = 0);
+
 // kge_score.hip
 int launch_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                          int64_t n, float* scores, hipStream_t s);

@@ -761,8 +761,8 @@ static void launch_ntn_lin(const float* Ma, const float* Mb, float* out, int64_t
 // (8 blocks of 16)
 static bool ntn_big_ok(int64_t n, int d, int kr) {
     if (d > 128 || kr > 128) return false;
-    const char* force = getenv("KGE_NTN_BIG");   // A/B and tests: 0 / 1 (read per call, like KGE_EVAL_GEMM)
-    if (force) return force[0] == '1';
+    const int force = switch_value("NTN_BIG");   // A/B and tests: 0 / 1
+    if (force >= 0) return force == 1;
     return n >= 1024;   // profiles/r03_ntn_threshold.txt: 2 x 512 rows 590 -> 493 us per step, 2 x 128 rows 234 -> 373 us
 }
 static int ntn_slices_per_group(int64_t n, int kr) {

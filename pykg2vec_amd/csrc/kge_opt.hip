@@ -84,8 +84,8 @@ static int launch_kind(float* p, float* g, float* s1, float* s2, int64_t numel, 
     if (blocks > 256 * 16) blocks = 256 * 16;
     // parameters + gradient + state beyond the 256 MB Infinity Cache: stream them non-temporally (kge_opt_device.h)
     const int streams = KIND == KGE_OPT_SGD ? 2 : KIND == KGE_OPT_ADAM ? 4 : 3;
-    const char* force = getenv("KGE_OPT_NT");
-    const bool nt = force ? force[0] == '1' : (int64_t)streams * numel * 4 > ((int64_t)256 << 20);
+    const int force = switch_value("OPT_NT");
+    const bool nt = force >= 0 ? force == 1 : (int64_t)streams * numel * 4 > ((int64_t)256 << 20);
     if (zero && nt)
         hipLaunchKernelGGL((k_opt<KIND, true, true>), dim3((int)blocks), dim3(256), 0, s, p, g, s1, s2, numel, a, dh, adv);
     else if (zero)

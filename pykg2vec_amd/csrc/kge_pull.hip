@@ -610,8 +610,7 @@ static PullGeo pull_geo(int dim) {
     PullGeo g{0, 0};
     if (dim <= 0 || (dim & 3) || dim > 1024) return g;
     const int nvec = dim >> 2;
-    const char* force = getenv("KGE_PULL_G");
-    if (nvec <= 32 && force && force[0] == '1') {
+    if (nvec <= 32 && switch_value("PULL_G") == 16) {
         g.G = 16; g.NV = nvec <= 16 ? 1 : 2;
         return g;
     }

@@ -856,7 +856,8 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
     fs.triples = triples; fs.perm = perm; fs.start = start; fs.E = m->tot_entity; fs.bern = bern;
     fs.slots = (const unsigned long long*)slots; fs.mask = (unsigned long long)(slots ? n_slots - 1 : 0);
     fs.seed = seed; fs.offset = offset; fs.cursor = cursor;
-    static const int split = getenv("KGE_ROTATE_SPLIT") ? atoi(getenv("KGE_ROTATE_SPLIT")) : 2;   // A/B switch (0 / 2 / 4), read once; measured 83 / 73 / 79 us at C3
+    const int split_sw = switch_value("ROTATE_SPLIT");
+    const int split = split_sw >= 0 ? split_sw : 2;   // A/B switch (0 / 2 / 4); measured 83 / 73 / 79 us at C3
     if (sink && geo.G == 64 && (split == 2 || split == 4)) {   // rows of more than 512 floats: a bundle's rows over two or four waves
         int64_t b = (n_pos * split + 3) / 4;
         if (b > kMaxBlocks) b = kMaxBlocks;

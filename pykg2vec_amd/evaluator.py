@@ -161,6 +161,8 @@ class Evaluator:
         self.metric_calculator = MetricCalculator(config)
         self._cache = {}
         self._groups = {}
+        self._known_dev = None
+        self.setup_stats = {}
 
     # --- single-query hooks kept for Trainer.infer_* style callers (evaluator.py:249-273)
     def test_tail_rank(self, h, r, topk=-1):
@@ -244,9 +246,58 @@ class Evaluator:
                            torch.from_numpy(np.ascontiguousarray(qblocks)).to(dev)))
         return chunks
 
+    FILTER_SOURCE = None   # None: the rule of _filter_source; "triples" / "dicts": forced (tests compare the two)
+
+    @staticmethod
+    def _fingerprint(data, n):
+        """Cache key of (data, n) by CONTENT: an `id()` can be reused by a different array after the first one is freed.
+        Arrays: shape + per-column sums + an xor fold of the first n rows (tens of microseconds for 60 k rows); lists of Triple
+        objects: length + the first, middle and last triple (walking 60 k python objects per call would cost more than the sweep)."""
+        if isinstance(data, np.ndarray):
+            a = np.ascontiguousarray(data[:n], dtype=np.int64)
+            mix = a[:, 0] * 1000003 + a[:, 1] * 8191 + a[:, 2]
+            return ("a", a.shape, int(a[:, 0].sum()), int(a[:, 1].sum()), int(a[:, 2].sum()),
+                    int(np.bitwise_xor.reduce(mix)) if len(a) else 0)
+        m = len(data) if n is None else n
+        pick = [data[i] for i in sorted({0, m // 2, m - 1})] if m else []
+        return ("o", id(data), len(data), m, tuple((t.h, t.r, t.t) for t in pick))
+
+    def _known_triples(self):
+        """train + valid + test as ONE int64 [M, 3] device tensor (what hr_t / tr_h are built from, data/kgcontroller.py:410-428),
+        uploaded once per Evaluator; None when the cache does not carry the three splits."""
+        if getattr(self, "_known_dev", None) is None:
+            kg = self.config.knowledge_graph
+            try:
+                parts = [_as_array(kg.read_cache_data(k), None) for k in ('triplets_train', 'triplets_valid', 'triplets_test')]
+            except (KeyError, FileNotFoundError, AttributeError):
+                return None
+            dev = next(self.model.parameters()).device
+            self._known_dev = torch.from_numpy(np.concatenate(parts)).to(dev)
+        return self._known_dev
+
+    def _filter_source(self):
+        """Where the filter lists come from.  "triples": the three splits are numpy arrays in the cache -> sorted and searched on the
+        device (kge_filter_csr_*; 1-2 ms for the FB15k test set).  "dicts": the reference's own cache format -- splits as lists of
+        Triple objects next to the hr_t / tr_h dicts of sets: flattening the dicts for the evaluated queries on the host (a python
+        loop, ~2 us per query) is then cheaper than converting ~600 k python objects into an array first."""
+        if self.FILTER_SOURCE is not None:
+            return self.FILTER_SOURCE
+        if self.K is not K:
+            return "dicts" if self.metric_calculator.hr_t is not None else "triples_host"
+        kg = self.config.knowledge_graph
+        try:
+            flat = all(isinstance(kg.read_cache_data(k), np.ndarray) for k in ('triplets_train', 'triplets_valid', 'triplets_test'))
+        except (KeyError, FileNotFoundError, AttributeError):
+            flat = False
+        if flat or self.metric_calculator.hr_t is None:
+            return "triples"
+        return "dicts"
+
     def _device_inputs(self, data, n):
-        key = (id(data), n)
+        import time
+        key = self._fingerprint(data, n)
         if key not in self._cache:
+            t0 = time.perf_counter()
             trip = _as_array(data, n)
             dense = self._dense_relations(trip)
             if dense is not None:  # grouped triples first, sorted by relation; ranks are scattered back to the input order
@@ -256,27 +307,40 @@ class Evaluator:
                 cuts = np.concatenate([[0], np.flatnonzero(np.diff(trip[:nd, 1])) + 1, [nd]]).astype(np.int64)
                 self._groups[key] = (order, self._group_chunks(trip, cuts), nd)
             mc = self.metric_calculator
-            if mc.hr_t is not None:
-                csr = build_filter_csr(trip, mc.hr_t, mc.tr_h)
-            else:  # hr_t / tr_h = train + valid + test grouped by (h,r) / (t,r)  (data/kgcontroller.py:410-428)
+            dev = next(self.model.parameters()).device
+            source = self._filter_source()
+            trip_dev = torch.from_numpy(trip).to(dev)
+            t1 = time.perf_counter()
+            if source == "triples":   # sort + binary search on the device (csrc/kge_index.hip)
+                known = self._known_triples()
+                if known is None:
+                    raise K.L.KgeHipError("Evaluator: the knowledge-graph cache carries neither hr_t / tr_h nor the three splits")
+                csr = self.K.filter_csr_build(known, trip_dev, self.config.tot_entity, self.config.tot_relation)
+                if trip_dev.is_cuda:
+                    torch.cuda.synchronize(dev)
+            elif source == "dicts":
+                csr = tuple(torch.from_numpy(a).to(dev) for a in build_filter_csr(trip, mc.hr_t, mc.tr_h))
+            else:  # host arrays without a device backend (CPU tests of the plumbing)
                 kg = self.config.knowledge_graph
                 known = np.concatenate([_as_array(kg.read_cache_data(k), None) for k in
                                         ('triplets_train', 'triplets_valid', 'triplets_test')])
-                csr = build_filter_csr_from_triples(trip, known, self.config.tot_relation)
-            dev = next(self.model.parameters()).device
-            self._cache[key] = (torch.from_numpy(trip).to(dev),) + tuple(torch.from_numpy(a).to(dev) for a in csr)
-        return self._cache[key]
+                csr = tuple(torch.from_numpy(a).to(dev) for a in build_filter_csr_from_triples(trip, known, self.config.tot_relation))
+            t2 = time.perf_counter()
+            self.setup_stats = {"csr_ms": (t2 - t1) * 1e3, "csr_source": source, "queries": int(trip.shape[0]),
+                                "host_prepare_ms": (t1 - t0) * 1e3, "filter_ids": int(csr[1].numel() + csr[3].numel())}
+            self._cache[key] = (trip_dev,) + tuple(csr)
+        return self._cache[key], key
 
     def rank_all(self, data, n):
         """int32 [4, n] device tensor of ranks for the first n triples of `data`."""
-        trip, t_off, t_ids, h_off, h_ids = self._device_inputs(data, n)
+        (trip, t_off, t_ids, h_off, h_ids), key = self._device_inputs(data, n)
         if getattr(self.model, "kernel_name", None) == "rescal":
             # the reference's forward renormalises both tables during eval too (pairwise.py:843-844)
             self.K.rescal_normalize(self.model.ent_embeddings.weight.data, self.model.rel_matrices.weight.data,
                                     self.model.hidden_size)
         desc = self.K.model_desc(self.model)
-        if (id(data), n) in self._groups:
-            order, chunks, nd = self._groups[(id(data), n)]
+        if key in self._groups:
+            order, chunks, nd = self._groups[key]
             out = torch.empty((4, len(order)), dtype=torch.int32, device=trip.device)
             dst = torch.from_numpy(order).to(trip.device)
             if nd < len(order):  # rare relations: candidate transform inside the sweep

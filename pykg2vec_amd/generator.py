@@ -220,10 +220,17 @@ class PullIndex:
         return self._skips[b] if self._skips is not None else None
 
     @staticmethod
-    def bytes_estimate(n_batches, batch_size, tot_entity, tot_relation):
+    def footprint(backend, n_batches, batch_size, tot_entity, tot_relation, segment=None, groups_per_block=8, compact=None):
+        """(resident bytes, peak bytes while building) of the device-built index of `n_batches` batches plus the two per-step
+        sampler list sets every owner-computes path keeps: the exact strides of kge_pull_index_geometry (the device builder sizes
+        every batch's arrays for the worst case), not an estimate."""
+        seg = PullIndex._segment(segment, groups_per_block)
         nrows = int(tot_entity) + int(tot_relation)
-        listed = min(3 * batch_size, nrows) if 3 * batch_size * 2 <= nrows else nrows
-        return n_batches * (listed * 16 + 3 * batch_size * 4 + batch_size * 16 + nrows // 8)
+        if compact is None:
+            compact = PullIndex._compact_rule(batch_size, nrows)
+        resident, workspace = backend.pull_index_bytes(n_batches, batch_size, tot_entity, tot_relation, seg, groups_per_block, compact)
+        resident += 2 * backend.pull_list_set_bytes(batch_size, tot_entity)
+        return resident, resident + workspace
 
     def batch(self, b):
         """(pairs, inc, items, multi) views of batch b; incidence / pair indices inside are relative to the batch."""

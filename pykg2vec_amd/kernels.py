@@ -38,9 +38,89 @@ def _ids(t, what):
     return _dev(t, torch.int64, what)
 
 
+# Shape every table of a model must have for the ids the kernels index it with: (rows indexed by, columns).  "E" / "R": the
+# kernels read row `entity id` / `relation id`, so the table needs at least tot_entity / tot_relation rows; an int: exactly that
+# many rows.  d = dim, k = rel_dim.  (models/pairwise.py, models/pointwise.py constructors; include/kge_hip.h enum kge_model.)
+_TABLE_SHAPES = {
+    "transe": [("E", "d"), ("R", "d")],
+    "transm": [("E", "d"), ("R", "d"), ("R", None)],                      # theta [R]
+    "transh": [("E", "d"), ("R", "d"), ("R", "d")],
+    "transd": [("E", "d"), ("R", "k"), ("E", "d"), ("R", "k")],
+    "rotate": [("E", "d"), ("E", "d"), ("R", "d")],
+    "rescal": [("E", "d"), ("R", "d*d")],
+    "ntn": [("E", "d"), ("R", "k"), ("d", "k"), ("d", "k"), (1, "k"), ("k", "d*d")],
+    "transr": [("E", "d"), ("R", "k"), ("R", "d*k")],
+    "distmult": [("E", "d"), ("R", "d")],
+    "complex": [("E", "d"), ("E", "d"), ("R", "d"), ("R", "d")],
+    "complexn3": [("E", "d"), ("E", "d"), ("R", "d"), ("R", "d")],
+    "analogy": [("E", "d"), ("R", "d"), ("E", "d/2"), ("E", "d/2"), ("R", "d/2"), ("R", "d/2")],
+    "cp": [("E", "d"), ("R", "d"), ("E", "d")],
+    "simple": [("E", "d"), ("E", "d"), ("R", "d"), ("R", "d")],
+    "simple_ignr": [("E", "d"), ("E", "d"), ("R", "d"), ("R", "d")],
+    # QuatE's four relation tables are allocated with tot_entity rows (models/pointwise.py:622-631) but looked up by RELATION
+    # id: tot_relation > tot_entity is an IndexError in the reference and a refused descriptor here
+    "quate": [("E", "d")] * 4 + [("R", "d")] * 4,
+}
+
+
+def _check_table_shapes(model_name, tables, tot_entity, tot_relation, dim, rel_dim):
+    spec = _TABLE_SHAPES.get(model_name)
+    if spec is None:
+        return
+    if len(tables) < len(spec):
+        raise L.KgeHipError("%s: %d tables given, the model has %d" % (model_name, len(tables), len(spec)))
+    size = {"E": int(tot_entity), "R": int(tot_relation), "d": int(dim), "k": int(rel_dim)}
+    cols_of = {"d": size["d"], "k": size["k"], "d*d": size["d"] ** 2, "d*k": size["d"] * size["k"], "d/2": size["d"] // 2}
+    for i, ((by, cols), t) in enumerate(zip(spec, tables)):
+        rows = t.shape[0]
+        want_cols = cols_of.get(cols)
+        got_cols = t.numel() // rows if rows else 0
+        if by in ("E", "R"):
+            need = size[by]
+            if rows < need:
+                raise L.KgeHipError(
+                    "%s: table %d has %d rows but is indexed by %s ids up to %d (tot_%s = %d): an nn.Embedding lookup would raise "
+                    "IndexError (models/Domain.py:8-13)" % (model_name, i, rows, "entity" if by == "E" else "relation", need - 1,
+                                                             "entity" if by == "E" else "relation", need))
+        else:
+            need = by if isinstance(by, int) else size[by]
+            if rows != need:
+                raise L.KgeHipError("%s: table %d must have %d rows (got %d)" % (model_name, i, need, rows))
+        if want_cols is not None and (t.dim() != 2 or got_cols != want_cols):
+            raise L.KgeHipError("%s: table %d must be [rows, %d] (got %s)" % (model_name, i, want_cols, tuple(t.shape)))
+
+
+def set_debug(check_ids=True):
+    """Debug mode of the library (include/kge_hip.h: kge_set_debug; KGE_DEBUG_IDS=1 in the environment does the same): every id
+    handed to an entry point is range-checked against its table first and a bad one raises KgeHipError, as nn.Embedding raises
+    IndexError for the reference.  Synchronises the stream on every call: not for the hot loop."""
+    L.load().kge_set_debug(1 if check_ids else 0)
+
+
+def set_switch(name, value):
+    """Force (0 / 1 / an integer) or release (None) one of the library's A/B switches (kge_set_switch; e.g. "EVAL_GEMM")."""
+    L.check(L.load().kge_set_switch(name.encode(), -1 if value is None else int(value)), "kge_set_switch")
+
+
+def debug_enabled():
+    return bool(L.load().kge_get_debug())
+
+
+def check_ids(ids, bound, what="ids"):
+    """Raise KgeHipError if some id is outside [0, bound) (one scan kernel + a stream synchronisation)."""
+    L.check(L.load().kge_check_ids(_ids(ids, what), ids.numel(), int(bound), _stream()), "kge_check_ids(%s)" % what)
+
+
+def debug_marker(tag):
+    """An empty launch of `tag` workgroups ("kge::k_marker"): a cut point in a profiler's dispatch sequence (bench.py)."""
+    L.check(L.load().kge_debug_marker(int(tag), _stream()), "kge_debug_marker")
+
+
 def make_desc(model_name, tables, grads=None, *, tot_entity, tot_relation, dim, rel_dim=None, l1_flag=False,
               margin=0.0):
-    """Build a kge_model_desc.  `tables` / `grads`: lists of fp32 device tensors in parameter_list order."""
+    """Build a kge_model_desc.  `tables` / `grads`: lists of fp32 device tensors in parameter_list order.  Table shapes are
+    checked against (tot_entity, tot_relation, dim, rel_dim): the kernels index rows by id without a bounds test."""
+    _check_table_shapes(model_name, tables, tot_entity, tot_relation, dim, rel_dim if rel_dim is not None else dim)
     d = L.ModelDesc()
     d.model = MODEL_IDS[model_name]
     d.flags = L.FLAG_L1 if l1_flag else 0
@@ -520,6 +600,33 @@ def eval_ranks_via_forward(desc, triples, tail_off, tail_ids, head_off, head_ids
     return out
 
 
+def filter_csr_build(known, queries, tot_entity, tot_relation):
+    """Per-query filter lists (tail_off int64 [n+1], tail_ids int32, head_off, head_ids) of `queries` [n, 3] against the set of
+    `known` triples [M, 3] (train + valid + test), built on the device: kge_filter_csr_count / _fill.  One host read (the two list
+    totals) between the calls."""
+    n, M = int(queries.shape[0]), int(known.shape[0])
+    dev = queries.device
+    t_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    h_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    if n == 0 or M == 0:
+        empty = torch.empty(0, dtype=torch.int32, device=dev)
+        return t_off, empty, h_off, empty.clone()
+    lib = L.load()
+    ws = torch.empty(lib.kge_filter_csr_workspace_bytes(M, n), dtype=torch.uint8, device=dev)
+    totals = torch.empty(2, dtype=torch.int64, device=dev)
+    L.check(lib.kge_filter_csr_count(_ids(known, "known triples"), M, _ids(queries, "queries"), n, int(tot_entity), int(tot_relation),
+                                     _dev(ws, torch.uint8, "workspace"), ws.numel(), _dev(t_off, torch.int64, "tail_off"),
+                                     _dev(h_off, torch.int64, "head_off"), _dev(totals, torch.int64, "totals"), _stream()),
+            "kge_filter_csr_count")
+    nt, nh = (int(x) for x in totals.tolist())       # the one host read
+    t_ids = torch.empty(max(nt, 1), dtype=torch.int32, device=dev)[:nt]
+    h_ids = torch.empty(max(nh, 1), dtype=torch.int32, device=dev)[:nh]
+    L.check(lib.kge_filter_csr_fill(_ids(queries, "queries"), n, M, _dev(ws, torch.uint8, "workspace"), _dev(t_off, torch.int64, "tail_off"),
+                                    _dev(h_off, torch.int64, "head_off"), ctypes.c_void_p(t_ids.data_ptr()), ctypes.c_void_p(h_ids.data_ptr()),
+                                    _stream()), "kge_filter_csr_fill")
+    return t_off, t_ids, h_off, h_ids
+
+
 def triple_set_build(triples):
     """Open-addressing hash set of the train triples (uint64 slots, power of two >= 2n)."""
     n = triples.shape[0]
@@ -645,6 +752,9 @@ def pull_sample(pairs, inv, tot_entity, bern_prob, slots, seed, offset, lists, c
 
 
 def pull_lists_explicit(pairs, inv, nh, nt, lists):
+    if debug_enabled():   # (the entry point is not told the entity count; the list set is sized by it)
+        check_ids(nh, lists.count.numel(), "negative heads")
+        check_ids(nt, lists.count.numel(), "negative tails")
     L.check(L.load().kge_pull_lists_explicit(_i32(pairs, "pairs"), _i32(inv, "inv"), _ids(nh, "nh"), _ids(nt, "nt"), pairs.shape[0],
                                              ctypes.byref(lists.c), _stream()), "kge_pull_lists_explicit")
 
@@ -732,6 +842,24 @@ def pull_index_build(triples, perm, batch_stride, slice_lo, n_pairs, n_batches, 
                                      skip.data_ptr() if skip is not None else None, counts.data_ptr(), ws.data_ptr(), ws.numel(),
                                      _stream()), "kge_pull_index_build")
     return pairs, inc, inv, items, multi, skip, counts
+
+
+def pull_index_bytes(n_batches, n_pairs, tot_entity, tot_relation, segment, groups_per_block, compact):
+    """(resident bytes, transient workspace bytes) of kge_pull_index_build's output for these sizes -- the exact strides of
+    kge_pull_index_geometry, no device needed."""
+    item_cap, multi_cap, words = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    ws_bytes = ctypes.c_size_t()
+    L.check(L.load().kge_pull_index_geometry(int(n_batches), int(n_pairs), int(tot_entity), int(tot_relation), int(segment),
+                                             int(groups_per_block), 1 if compact else 0, ctypes.byref(item_cap), ctypes.byref(multi_cap),
+                                             ctypes.byref(words), ctypes.byref(ws_bytes)), "kge_pull_index_geometry")
+    nb, n = int(n_batches), int(n_pairs)
+    resident = nb * (n * 16 + 2 * 3 * n * 4 + item_cap.value * 16 + multi_cap.value * 16 + (words.value * 4 if compact else 0) + 16)
+    return resident, int(ws_bytes.value)
+
+
+def pull_list_set_bytes(batch_size, tot_entity):
+    """Bytes of ONE PullListSet (two are kept per owner-computes path)."""
+    return int(batch_size) * (4 + 4 + 3 * 16) + int(tot_entity) * (4 + 4 + L.PULL_BUCKET * 4 + L.PULL_BUCKET * 16)
 
 
 class PullPlan:

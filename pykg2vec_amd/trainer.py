@@ -9,8 +9,10 @@ flat parameter buffer (which also clears the gradients), and no host synchronisa
 Inference helpers, hyper-parameter tuning, early stopping, export and plotting are outside the hot path (SURVEY.md
 section 2) and stay with the reference: `pykg2vec_amd.integration.reference_trainer()` grafts this module's hot loop onto
 the reference's own Trainer class, which keeps all of those (tests/test_integration_graft.py).  The stand-alone Trainer
-keeps only the checkpoint pair in the reference's format (save_model / load_model: `model.vec.pt` state_dict) and accepts
-any object with `should_stop(metrics)` as `early_stopper` (the graft passes the reference's own EarlyStopper).
+keeps what `train_model` itself needs to honour the configuration: the patience rule of the reference's early stopping
+(`PatienceStopper`; any object with `should_stop(metrics)` can be injected -- the graft passes the reference's own
+EarlyStopper), best-metric checkpointing under `config.save_model`, and the checkpoint pair in the reference's format
+(save_model / load_model: `model.vec.pt` state_dict + `config.npy`).
 """
 import os
 
@@ -24,6 +26,34 @@ from .generator import Generator
 
 def _log(msg):
     print(msg, flush=True)
+
+
+class PatienceStopper:
+    """The early-stopping rule `train_model` applies after every mini-test (utils/trainer.py:22-68, 199-205): compare the monitored
+    metric with the PREVIOUS mini-test's; a worse value spends one unit of patience, or stops the training when none is left; any
+    other value refills the patience.  Lower is better for the (filtered) mean rank, higher for the reciprocal ranks.  A negative
+    patience never stops (there is never exactly zero left)."""
+
+    def __init__(self, patience, monitor):
+        self.patience, self.monitor = int(patience), monitor
+        self.left, self.previous = int(patience), None
+
+    def should_stop(self, metrics):
+        cur = metrics[self.monitor.value]
+        prev, self.previous = self.previous, cur
+        if prev is None:
+            return False
+        worse = cur > prev if self.monitor in (Monitor.MEAN_RANK, Monitor.FILTERED_MEAN_RANK) else cur < prev
+        if worse and self.left > 0:
+            self.left -= 1
+            _log("%d more chances before the trainer stops the training. (prev_%s, curr_%s): (%.4f, %.4f)"
+                 % (self.left, self.monitor.name, self.monitor.name, prev, cur))
+            return False
+        if worse and self.left == 0:
+            _log("Stop the training.")
+            return True
+        self.left = self.patience
+        return False
 
 
 class FlatState:
@@ -176,7 +206,10 @@ class Trainer:
     TRAINED_MODEL_CONFIG_NAME = "config.npy"
 
     GRAPH_MAX_ROWS = 16384  # steps scoring at most this many triples are launch-bound: replay them as one hipGraph
-    PULL_INDEX_BUDGET = 256 << 20   # bytes of per-batch incidence index the owner-computes path may build (see _pull_ok)
+    # bytes the per-batch incidence index of an owner-computes path (+ its sampler list sets, + the build's workspace) may occupy:
+    # at most this, and at most a quarter of the device memory free when the path is chosen (see _owner_index_fits).  Beyond it
+    # the step falls back to the atomic-scatter kernels (hipGraph-replayed when launch-bound), which need no index.
+    PULL_INDEX_BUDGET = 32 << 30
     GRAPH_UNROLL = 8        # steps per replayed multi-step graph (even; 0 = single-step graphs only)
     OWN_GENERIC_MODELS = ("analogy", "cp", "simple", "simple_ignr", "quate")
     PULL_TWO_PHASE_MIN_BATCH = 8192    # owner-computes step in two launches (each pair evaluated once) from this batch size on
@@ -234,6 +267,9 @@ class Trainer:
         self.evaluator = Evaluator(self.model, self.config, backend=self.K)
         self.loss_buf = self.K.new_loss_buffer(self.flat.param.device)
         self.monitor = monitor
+        if self.early_stopper is None:   # utils/trainer.py:143 (config.patience is hard-wired to 3 there, config.py:55)
+            self.early_stopper = PatienceStopper(getattr(self.config, "patience", -1), monitor)
+        self.best_metric = None
         self._desc = self.K.model_desc(self.model, [v for v in self.flat.views], self.flat.grad_views)
         self._selfadv_ws = None
         if self.distributed:  # replicas must start identical
@@ -356,12 +392,30 @@ class Trainer:
             return self.switches["pull"]
         # one launch per step, enqueued by a native loop: faster than the hipGraph-replayed atomic step at every batch size
         # measured (FB15k shape: B=128 13.1 vs 16.5 us, B=4096 17.2 vs 24.6 us, B=32768 34.5 vs 60 us).  The limit is the
-        # per-batch incidence index built once on the host (16 B per listed row; batches that touch a small part of the tables
-        # list only those rows and the kernel visits the rest implicitly).
+        # per-batch incidence index (batches that touch a small part of the tables list only those rows + a bitmap of all rows).
+        return self._owner_index_fits(K.pull_groups_per_block(self.model.hidden_size), getattr(self.generator, "pull_segment", None))
+
+    def _owner_index_fits(self, groups_per_block, segment=None, compact=None):
+        """Does the incidence index of every batch of the epoch (built once on the device, kept resident) fit the budget?  The
+        footprint is exact (kge_pull_index_geometry's strides: the builder sizes every batch for the worst case) and includes the
+        two sampler list sets and the build's transient workspace.  A graph of a million entities stepped at the reference's
+        default B = 128 would need tens of GB of per-batch row bitmaps: such runs take the index-free atomic step instead."""
         from .generator import PullIndex
-        n_batches = self.generator.n_train // int(self.config.batch_size)
-        index_bytes = PullIndex.bytes_estimate(n_batches, int(self.config.batch_size), self.config.tot_entity, self.config.tot_relation)
-        return index_bytes <= self.PULL_INDEX_BUDGET or self.config.batch_size * 2 > self.GRAPH_MAX_ROWS
+        key = (groups_per_block, segment, compact, int(self.config.batch_size), self.generator.n_train)
+        cache = self.__dict__.setdefault("_fit_cache", {})
+        if key not in cache:
+            B = int(self.config.batch_size)
+            per = B // self.world_size if self.distributed and B % self.world_size == 0 else B
+            n_batches = self.generator.n_train // B
+            resident, peak = PullIndex.footprint(K, n_batches, per, self.config.tot_entity, self.config.tot_relation, segment,
+                                                 groups_per_block, compact)
+            budget = self.PULL_INDEX_BUDGET
+            dev = self.flat.param.device if self.flat is not None else None
+            if dev is not None and dev.type == "cuda":
+                budget = min(budget, torch.cuda.mem_get_info(dev)[0] // 4)
+            cache[key] = peak <= budget
+            self._index_footprint = {"resident_bytes": resident, "peak_bytes": peak, "budget_bytes": budget, "fits": cache[key]}
+        return cache[key]
 
     def _pull_shape_ok(self):
         """Model / shape conditions of the owner-computes kernels: TransE / TransM hinge with neg_rate 1, rows of float4s, and
@@ -534,7 +588,8 @@ class Trainer:
         # Measured against the (hipGraph-replayed) atomic-scatter step with the staged form (profiles/r03_experiments.md section 14):
         # it wins at every batch size and optimiser tried -- DistMult FB15k B = 128 / 1024 / 4096 / 8192 / 32768: 16.8 / 19.7 / 32.4
         # / 50.2 / 70 -> 14.3 / 17.6 / 23.6 / 29.8 / 57.6 us; ComplEx WN18RR B = 128 Adagrad 39.9 -> 16.1, Adam 94.5 -> 70.3 us.
-        return True
+        # -- as long as the per-batch index fits (the same guard as the TransE path)
+        return self._owner_index_fits(K.own_groups_per_block(m.kernel_name, m.hidden_size), None, None if self._own_dense() else True)
 
     def _own_dense(self):
         return self.config.optimizer in ("adam", "rms")   # optimisers that move every row every step
@@ -657,7 +712,9 @@ class Trainer:
         # measured against the hipGraph-replayed atomic step at FB15k shape (profiles/r03_experiments.md section 14): TransH B = 128 /
         # 1024 / 4096 / 8192 / 32768: 27.3 / 29.0 / 31.2 / 36.8 / 80 -> 19.8 / 22.5 / 27.9 / 35.4 / 64 us; TransD 1024 / 4096 / 8192 /
         # 32768: 40.0 / 42.6 / 51.5 / 117 -> 30.1 / 35.7 / 43.4 / 84 us
-        return int(self.config.batch_size) >= self.TRANSX_OWN_MIN_BATCH
+        if int(self.config.batch_size) < self.TRANSX_OWN_MIN_BATCH:
+            return False
+        return self._owner_index_fits(K.transx_groups_per_block(m.parameter_list[0].weight.shape[1]), 32)
 
     def _transx_state(self):
         st = getattr(self, "_transx", None)
@@ -1051,26 +1108,58 @@ class Trainer:
             gen.pull_segment = 32    # two-phase step: a visit is a few bytes, so an item carries a whole row's incidences (32 / item)
         return gen
 
-    # ------------------------------------------------------------------ checkpoints (reference format, utils/trainer.py:388-409)
-    def save_model(self, path):
-        """state_dict under the reference's file name and key names (`ent_embeddings.weight`, ...): a checkpoint written
-        here loads into the reference's model classes and vice versa."""
-        self.sync_model()
-        os.makedirs(str(path), exist_ok=True)
-        torch.save(self.model.state_dict(), os.path.join(str(path), self.TRAINED_MODEL_FILE_NAME))
+    # ------------------------------------------------------------------ checkpoints (reference format, utils/trainer.py:388-419)
+    def _checkpoint_dir(self, path=None):
+        if path is not None:
+            return str(path)
+        root = getattr(self.config, "path_tmp", None)
+        if root is None:
+            raise ValueError("save_model / load_model: no path given and the configuration has no path_tmp")
+        return os.path.join(str(root), self.model.model_name)
 
-    def load_model(self, path):
-        state = torch.load(os.path.join(str(path), self.TRAINED_MODEL_FILE_NAME), map_location=self.config.device)
+    def save_model(self, path=None):
+        """state_dict under the reference's file name and key names (`ent_embeddings.weight`, ...) plus the pickled configuration
+        next to it (`config.npy`): the pair the reference's load_model requires.  Default directory as the reference's:
+        config.path_tmp / model_name."""
+        import numpy as np
+        self.sync_model()
+        d = self._checkpoint_dir(path)
+        os.makedirs(d, exist_ok=True)
+        torch.save(self.model.state_dict(), os.path.join(d, self.TRAINED_MODEL_FILE_NAME))
+        try:
+            np.save(os.path.join(d, self.TRAINED_MODEL_CONFIG_NAME), self.config)
+        except Exception as e:   # a configuration holding an unpicklable object (open handles, lambdas): the weights are still saved
+            _log("save_model: configuration not pickled (%s: %s)" % (type(e).__name__, e))
+
+    def load_model(self, path=None):
+        """Load a checkpoint written by save_model or by the reference.  Strict: every key the model's state_dict has must be in
+        the file with the same shape, and the file may hold nothing else -- a wrong or partial checkpoint raises instead of loading
+        silently.  (The reference additionally swaps in the pickled configuration; the tables' shapes are what this path checks.)"""
+        d = self._checkpoint_dir(path)
+        f = os.path.join(d, self.TRAINED_MODEL_FILE_NAME)
+        if not os.path.exists(f):
+            raise ValueError("Cannot load model from %s" % d)   # utils/trainer.py:418-419
+        state = torch.load(f, map_location=self.config.device)
+        own = self.model.state_dict()
+        missing, extra = sorted(set(own) - set(state)), sorted(set(state) - set(own))
+        wrong = sorted(k for k in set(own) & set(state) if tuple(own[k].shape) != tuple(state[k].shape))
+        if missing or extra or wrong:
+            raise ValueError("load_model: checkpoint does not match the model (missing %s, unexpected %s, shape mismatch %s)"
+                             % (missing, extra, [(k, tuple(state[k].shape), tuple(own[k].shape)) for k in wrong]))
         if self.flat is None:
-            self.model.load_state_dict(state)
+            self.model.load_state_dict(state, strict=True)
             return
-        named = dict(self.model.named_parameters())
         with torch.no_grad():   # in place: the parameters live in the flat buffer
-            for k, v in state.items():
-                if k in named:
-                    named[k].data.copy_(v)
+            for k, v in own.items():
+                v.copy_(state[k])
         if getattr(self, "_pull", None) is not None:
             self._pull.sync_in()
+
+    def _is_better(self, metrics):
+        key = self.monitor.value
+        if self.monitor in (Monitor.MEAN_RANK, Monitor.FILTERED_MEAN_RANK):
+            return metrics[key] < self.best_metric[key]
+        return metrics[key] > self.best_metric[key]
 
     def train_model(self):
         self.generator = self._new_generator()
@@ -1085,6 +1174,11 @@ class Trainer:
                     metrics = self.evaluator.mini_test(cur_epoch_idx)
                 if self.early_stopper is not None and self.early_stopper.should_stop(metrics):
                     break
+                if getattr(self.config, "save_model", False) and getattr(self.config, "path_tmp", None) is not None:
+                    # keep the best weights seen so far (utils/trainer.py:207-219)
+                    if self.best_metric is None or self._is_better(metrics):
+                        self.best_metric = metrics
+                        self.save_model()
         self.model.eval()
         with torch.no_grad():
             self.evaluator.full_test(cur_epoch_idx)

@@ -145,15 +145,13 @@ def test_product_never_imports_the_oracle():
                 assert "kge_oracle" not in text and "oracle_backend" not in text and "/root/reference" not in text, f
 
 
-def test_stand_alone_trainer_takes_any_early_stopper_and_keeps_reference_checkpoint_names(tmp_path):
-    """Early stopping is outside the hot path: the stand-alone Trainer carries no stopper of its own (the graft hands it
-    the reference's, tests/test_integration_graft.py) but calls whatever object is set; checkpoints keep the reference's
-    file name and state_dict keys (utils/trainer.py:86-87,388-409)."""
+def test_stand_alone_trainer_stops_early_checkpoints_the_best_and_keeps_reference_checkpoint_format(tmp_path):
+    """train_model honours config.patience with the reference's rule (a default PatienceStopper, any object with should_stop can be
+    injected instead), keeps the best weights under config.save_model, and save_model / load_model use the reference's file
+    names, key names and default directory (utils/trainer.py:86-87,199-219,388-419); a wrong checkpoint raises."""
     import oracle_backend
     import hip_util
-    from pykg2vec_amd.trainer import Trainer
-    import pykg2vec_amd.trainer as T
-    assert not hasattr(T, "EarlyStopper")
+    from pykg2vec_amd.trainer import Trainer, PatienceStopper
     c = Case("transe_l1")
     cfg = hip_util.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test, optimizer="sgd", lr=0.05, batch_size=64, device="cpu")
     cfg.epochs, cfg.test_step, cfg.test_num = 5, 1, 4
@@ -170,10 +168,11 @@ def test_stand_alone_trainer_takes_any_early_stopper_and_keeps_reference_checkpo
     m = hip_util.model_from_case(c, device="cpu")
     tr = Trainer(m, cfg, backend=oracle_backend)
     tr.build_model()
-    assert tr.early_stopper is None
+    assert isinstance(tr.early_stopper, PatienceStopper) and tr.early_stopper.patience == cfg.patience
     tr.early_stopper = StopAtSecond()
     assert tr.train_model() == 1 and tr.early_stopper.calls == 2
     tr.save_model(tmp_path)
+    assert os.path.exists(os.path.join(str(tmp_path), Trainer.TRAINED_MODEL_CONFIG_NAME))
     state = torch.load(os.path.join(str(tmp_path), Trainer.TRAINED_MODEL_FILE_NAME))
     assert set(state) == {"ent_embeddings.weight", "rel_embeddings.weight"}
     m2 = hip_util.model_from_case(c, device="cpu")
@@ -182,6 +181,48 @@ def test_stand_alone_trainer_takes_any_early_stopper_and_keeps_reference_checkpo
     tr2.load_model(tmp_path)
     for k, v in state.items():
         assert torch.equal(dict(m2.named_parameters())[k].detach(), v)
+    # strict: a checkpoint with a missing key, an unexpected key or a wrong shape raises
+    bad_dir = tmp_path / "bad"
+    bad_dir.mkdir()
+    for bad in ({"ent_embeddings.weight": state["ent_embeddings.weight"]},
+                dict(state, extra=torch.zeros(1)),
+                dict(state, **{"rel_embeddings.weight": state["rel_embeddings.weight"][:, :1].clone()})):
+        torch.save(bad, str(bad_dir / Trainer.TRAINED_MODEL_FILE_NAME))
+        with pytest.raises(ValueError, match="does not match the model"):
+            tr2.load_model(bad_dir)
+    with pytest.raises(ValueError, match="Cannot load model"):
+        tr2.load_model(tmp_path / "nowhere")
+    # default directory = config.path_tmp / model_name, and the best weights are kept while training under config.save_model
+    cfg.path_tmp, cfg.save_model, cfg.epochs = tmp_path / "tmp", True, 2
+    m3 = hip_util.model_from_case(c, device="cpu")
+    tr3 = Trainer(m3, cfg, backend=oracle_backend)
+    tr3.build_model()
+    tr3.train_model()
+    assert tr3.best_metric is not None
+    assert os.path.exists(os.path.join(str(cfg.path_tmp), "transe", Trainer.TRAINED_MODEL_FILE_NAME))
+    tr3.load_model()
+
+
+def test_patience_rule_equals_the_reference_early_stopper():
+    """PatienceStopper.should_stop == the reference's EarlyStopper.should_stop on the same metric sequences, for every monitor and
+    for zero / positive / negative patience (utils/trainer.py:22-68).  Needs the reference tree (build container only)."""
+    import ref_shim
+    if not ref_shim.reference_available():
+        pytest.skip("reference tree not present")
+    ref_shim.install()
+    from pykg2vec.utils.trainer import EarlyStopper
+    from pykg2vec.common import Monitor as RefMonitor
+    from pykg2vec_amd.trainer import PatienceStopper
+    from pykg2vec_amd.common import Monitor
+    rng = np.random.default_rng(0)
+    for mon in ("mr", "fmr", "mrr", "fmrr"):
+        for patience in (-1, 0, 1, 3):
+            for trial in range(20):
+                ours, ref = PatienceStopper(patience, Monitor(mon)), EarlyStopper(patience, RefMonitor(mon))
+                seq = rng.integers(0, 4, size=25).astype(float)          # plenty of equal and worse neighbours
+                for v in seq:
+                    metrics = {"mr": v, "fmr": v, "mrr": v, "fmrr": v}
+                    assert ours.should_stop(metrics) == ref.should_stop(metrics), (mon, patience, trial)
 
 
 def test_relation_property_matches_reference_rule():

@@ -1,0 +1,36 @@
+#!/bin/bash
+# One gpurun lease = the round's evidence set.  Usage (through gpurun):  bash tools/gpu_evidence.sh <tag> [parts]
+#   tag    prefix of everything written under gpurun_out/ (e.g. r04a); copy what is to be judged into profiles/
+#   parts  any of: tests smoke bench bench20 stats pmc   (default: all, in that order)
+#     tests    pytest -m gpu                                   -> <tag>_tests.log
+#     smoke    __graft_entry__.smoke()
+#     bench    python bench.py (default flags: 200 steps, live counter passes, extras, CPU baseline) -> <tag>_bench_line.json
+#     bench20  the driver's shape: --steps 20 --warmup 5        -> <tag>_bench_line_20steps.json
+#     stats    rocprofv3 --kernel-trace --stats of the bench command, split by launch geometry -> <tag>_kernel_stats.md
+#     pmc      FETCH_SIZE / WRITE_SIZE / SQ_* passes (separate passes, --kernel-trace only) of the bench command,
+#              per (kernel, grid)                               -> <tag>_pmc_traffic.json
+ulimit -c 0
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG=${1:?tag}; shift
+PARTS=${*:-tests smoke bench bench20 stats pmc}
+O=gpurun_out
+for part in $PARTS; do
+  case $part in
+    tests)   timeout 1500 python -m pytest tests -x -q -m gpu --timeout 300 > $O/${TAG}_tests.log 2>&1; tail -4 $O/${TAG}_tests.log ;;
+    smoke)   timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+    bench)   timeout 900 python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err; head -c 600 $O/${TAG}_bench_line.json; echo; tail -3 $O/${TAG}_bench.err ;;
+    bench20) timeout 900 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_line_20steps.json 2> $O/${TAG}_bench20.err; head -c 300 $O/${TAG}_bench_line_20steps.json; echo ;;
+    stats)   timeout 600 rocprofv3 --kernel-trace --stats -d $O/_p0 -o b -- python bench.py --no-cpu-baseline --no-live-pmc > $O/${TAG}_prof0.log 2>&1
+             python tools/rocpd_summary.py $(find $O/_p0 -name '*.db' | head -1) $O/${TAG}_kernel_stats.md > /dev/null; head -16 $O/${TAG}_kernel_stats.md | cut -c1-180
+             rm -rf $O/_p0 ;;
+    pmc)     B2="python bench.py --no-cpu-baseline --no-live-pmc"
+             timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/_p1 -o b -- $B2 > $O/${TAG}_prof1.log 2>&1
+             timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/_p2 -o b -- $B2 > $O/${TAG}_prof2.log 2>&1
+             timeout 500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU --kernel-trace -d $O/_p3 -o b -- $B2 > $O/${TAG}_prof3.log 2>&1
+             python tools/rocpd_pmc.py $O/${TAG}_pmc_traffic.json "$B2; one counter set per pass (FETCH_SIZE | WRITE_SIZE | SQ_*), --kernel-trace only" $(find $O/_p1 $O/_p2 $O/_p3 -name '*.db')
+             rm -rf $O/_p1 $O/_p2 $O/_p3 ;;
+    *) echo "unknown part $part" ;;
+  esac
+done
