@@ -11,7 +11,12 @@ d=200, FB15k-237 RotatE d=1000 neg 16, YAGO3-10 RESCAL k=200 -- on tables built 
   * Evaluator.test ranks / filtered ranks of n_rank test triples              (utils/evaluator.py:309-334)
     (none for RESCAL at YAGO3-10 size: the reference's sweep would gather E*k*k floats = 19.7 GB)
 
-Usage: python oracle/make_golden_fullsize.py [case ...]
+  * (`step` mode, files ref_full_step_<case>.npz) ONE optimiser step on the batch the bench's default path would draw first
+    (tests/golden_util.default_step_batch: the generator's permutation rule + the Philox sampler restated on the host): loss,
+    digests of every updated table and of the optimiser state (utils/trainer.py:147-180,296-299; torch.optim defaults :112-131)
+
+Usage: python oracle/make_golden_fullsize.py [case ...]            (scores / gradients / ranks)
+       python oracle/make_golden_fullsize.py step [case ...]       (the default-path step fixtures)
 """
 import os
 import sys
@@ -116,6 +121,63 @@ def run(name):
     print("wrote", name, "loss=%.6f" % rec["loss"], "ranks" if n_rank else "", rec.get("ranks", np.zeros(0))[:, :4] if n_rank else "")
 
 
+def run_step(name):
+    """One reference step (zero_grad, train_step_*, backward, optimizer.step) on the default path's first batch."""
+    spec, step, P, train, pos, (nh, nr, nt) = gu.default_step_batch(name)
+    E, R, hp, model_name = spec["E"], spec["R"], spec["hp"], spec["model"]
+    neg_rate = hp.get("neg_rate", 1)
+    cfg = types.SimpleNamespace(
+        tot_entity=E, tot_relation=R, device="cpu", optimizer=step["optimizer"], learning_rate=step["lr"], neg_rate=neg_rate,
+        alpha=hp.get("alpha", 0.1), margin=hp.get("margin", 1.0), batch_size=step["B"], tot_train_triples=len(train),
+        epochs=1000, test_num=0, debug=False, load_from_data=None, hits=[1, 3, 5, 10], patience=3,
+        dataset_name="synthetic", sampling="uniform",
+        knowledge_graph=_KG({"triplets_train": [], "triplets_valid": [], "triplets_test": [], "hr_t": {}, "tr_h": {}}))
+    for k, v in hp.items():
+        setattr(cfg, k, v)
+    cfg.summary = lambda: None
+    mod, cls = CLASS[model_name].split(".")
+    model_def = getattr(__import__("pykg2vec.models." + mod, fromlist=[cls]), cls)
+    torch.manual_seed(0)
+    model = model_def(**cfg.__dict__)
+    model.load_state_dict({k + ".weight": torch.from_numpy(v.copy()) for k, v in P.items()})
+    trainer = Trainer(model, cfg)
+    trainer.build_model()                                       # utils/trainer.py:103-144: model.to(device), torch.optim.<kind>(lr)
+    if model_name in gu.POINTWISE:
+        batch = ko.pointwise_layout(pos, nh, nr, nt, neg_rate)
+    else:
+        batch = (pos[:, 0], pos[:, 1], pos[:, 2], nh, nr, nt)
+    tens = [torch.LongTensor(np.ascontiguousarray(a)) for a in batch]
+    model.train()
+    trainer.optimizer.zero_grad()                               # utils/trainer.py:296-299
+    loss = trainer.train_step_pointwise(*tens) if model_name in gu.POINTWISE else trainer.train_step_pairwise(*tens)
+    loss.backward()
+    trainer.optimizer.step()
+    rec = {"name": name, "loss": np.float32(loss.item()), "B": np.int64(step["B"]),
+           "batch_checksum": np.int64(sum(int(np.asarray(a, np.int64).sum()) * (i + 1) for i, a in enumerate(batch)))}
+    touched_e = np.unique(np.concatenate([pos[:, 0], pos[:, 2], nh, nt]))
+    untouched_e = np.setdiff1d(np.arange(E), touched_e)[:32]
+    touched_r = np.unique(pos[:, 1])
+    untouched_r = np.setdiff1d(np.arange(R), touched_r)[:32]
+    state = trainer.optimizer.state
+    for k, p in model.named_parameters():
+        is_ent = p.shape[0] == E
+        rows = np.concatenate([touched_e[:64], untouched_e]) if is_ent else np.concatenate([touched_r[:64], untouched_r])
+        rec["rows.%s" % k] = rows
+        for label, tensor in (("post", p.detach()),) + tuple((kind, state[p][key]) for kind, key in
+                                                              (("state1", "exp_avg" if step["optimizer"] == "adam" else
+                                                                "sum" if step["optimizer"] == "adagrad" else "square_avg"),
+                                                               ("state2", "exp_avg_sq")) if key in state[p]):
+            s_, a_, full = gu.table_digest(tensor.numpy(), rows)
+            rec["%s.%s.rowsum" % (label, k)], rec["%s.%s.rowabs" % (label, k)], rec["%s.%s.rows" % (label, k)] = s_, a_, full
+    np.savez_compressed(os.path.join(OUT, "ref_full_step_%s.npz" % name), **rec)
+    print("wrote step", name, "B=%d %s loss=%.6f" % (step["B"], step["optimizer"], rec["loss"]))
+
+
 if __name__ == "__main__":
-    for name in (sys.argv[1:] or list(gu.FULLSIZE)):
-        run(name)
+    args = sys.argv[1:]
+    if args and args[0] == "step":
+        for name in (args[1:] or list(gu.DEFAULT_STEP)):
+            run_step(name)
+    else:
+        for name in (args or list(gu.FULLSIZE)):
+            run(name)

@@ -161,3 +161,45 @@ def tie_bracket(scores_row, true_id, known=()):
     if kn.size:
         keep[kn] = False
     return int(lower.sum()), int(tied.sum()), int((lower & keep).sum()), int((tied & keep).sum())
+
+
+# ---- ONE training step of every BASELINE config through the path the bench TIMES (Trainer.train_model_epoch with one batch of the
+# bench's size: the sampler-fused default kernels), pinned to the live reference: oracle/make_golden_fullsize.py restates the device
+# generator's first batch on the host (same permutation rule, Philox draws by oracle/sampler_oracle.py), runs the reference's
+# train_step + backward + optimizer.step on it and freezes digests of the updated tables and optimiser state.
+DEFAULT_STEP = {
+    "c1_transe_l1": dict(B=32768, optimizer="adam", lr=0.01),
+    "c1_transe_l2": dict(B=32768, optimizer="adam", lr=0.01),
+    "c2_complex": dict(B=5000, optimizer="adagrad", lr=0.01),
+    "c3_rotate": dict(B=1024, optimizer="adam", lr=0.01),
+    "c4_rescal": dict(B=1024, optimizer="adam", lr=0.01),
+}
+GENERATOR_SEED = 0
+
+
+def generator_first_batch(train, batch_size, seed=GENERATOR_SEED):
+    """Rows of the train split that form batch 0 of pykg2vec_amd.generator.Generator(seed): one permutation per run
+    (data/generator.py:23), the slice ordered by relation id (a batch is a set)."""
+    perm = np.random.default_rng(seed).permutation(len(train))
+    sl = perm[:batch_size]
+    return sl[np.argsort(train[sl, 1], kind="stable")]
+
+
+def default_step_batch(name):
+    """(spec, step, params, train, positives [B,3], (nh, nr, nt)) of the first default-path step of a FULLSIZE case: uniform corruption
+    drawn from the device sampler's Philox stream (seed GENERATOR_SEED, counter = slot), train-set rejection."""
+    import sampler_oracle as so
+    spec, P, train, valid, test, _ids, _batch = fullsize_inputs(name)
+    step = DEFAULT_STEP[name]
+    pos = train[generator_first_batch(train, step["B"])]
+    neg_rate = spec["hp"].get("neg_rate", 1)
+    train_set = set(map(tuple, train.tolist()))
+    neg = so.corrupt(pos[:, 0], pos[:, 1], pos[:, 2], neg_rate, spec["E"], None, train_set, GENERATOR_SEED, 0)
+    return spec, step, P, train, pos, neg
+
+
+def table_digest(w, rows):
+    """What a fixture keeps of an updated [rows, d] table: float64 row sums and row absolute sums of every row, and the listed
+    rows in full (first DIGEST_COLS columns)."""
+    w64 = np.asarray(w, dtype=np.float64)
+    return w64.sum(1).astype(np.float32), np.abs(w64).sum(1).astype(np.float32), np.asarray(w)[rows][:, :DIGEST_COLS].copy()

@@ -94,7 +94,8 @@ def test_entity_counts_around_the_sweep_tile(hip, E):
     test[0] = (0, 0, E - 1)          # extreme ids
     test[1] = (E - 1, R - 1, 0)
     hr_t, tr_h = ko.build_filters(test)
-    cfg.knowledge_graph.cache.update(hr_t=hr_t, tr_h=tr_h)
+    # the known triples are these nine: the splits (what the device builds its filter lists from) and the dicts must say the same
+    cfg.knowledge_graph.cache.update(hr_t=hr_t, tr_h=tr_h, triplets_train=test[:5], triplets_valid=test[5:7], triplets_test=test[7:])
     got = Evaluator(m, cfg).rank_all(test, 9).cpu().numpy()
     _, rk = ko.evaluate("transe", P, test, hr_t, tr_h, l1_flag=True)
     ref = np.stack([rk["head"], rk["tail"], rk["fhead"], rk["ftail"]])
