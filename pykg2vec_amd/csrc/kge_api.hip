@@ -411,7 +411,46 @@ int kge_optimizer_step_rows(int32_t kind, float* param, float* grad, float* stat
     if (rows == 0) return 0;
     if (touched_rows && touched_rows == touched_clear) { set_error("kge_optimizer_step_rows: the bitmap to clear must be the other parity's"); return -1; }
     return launch_optimizer_rows(kind, param, grad, state1, state2, rows, dim, lr, step < 1 ? 1 : step, zero_grad, normalize, dev_hyper,
-                                 touched_rows, touched_clear, (hipStream_t)stream);
+                                 touched_rows, touched_clear, nullptr, (hipStream_t)stream);
+}
+
+int kge_optimizer_step_rows_lazy(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
+                                 float lr, int64_t step, int32_t zero_grad, int32_t normalize, const uint32_t* touched_rows,
+                                 uint32_t* touched_clear, const kge_lazy_rows* lazy, void* stream) {
+    if (!param || !grad || rows < 0 || dim <= 0 || dim > 1024 || !lazy || (step < 1 && !lazy->dev_cursor)) {
+        set_error("kge_optimizer_step_rows_lazy: bad arguments (rows of at most 1024 floats, lazy state required)");
+        return -1;
+    }
+    if (rows == 0) return 0;
+    if (touched_rows && touched_rows == touched_clear) { set_error("kge_optimizer_step_rows_lazy: the bitmap to clear must be the other parity's"); return -1; }
+    return launch_optimizer_rows(kind, param, grad, state1, state2, rows, dim, lr, step < 1 ? 1 : step, zero_grad, normalize, nullptr,
+                                 touched_rows, touched_clear, lazy, (hipStream_t)stream);
+}
+
+int kge_lazy_hyper_fill(float lr, int64_t first_step, int64_t n, float* host_out) {
+    if (!host_out || n < 0 || first_step < 0) { set_error("kge_lazy_hyper_fill: bad arguments"); return -1; }
+    lazy_hyper_fill(lr, first_step, n, host_out);
+    return 0;
+}
+
+int kge_lazy_catchup(int32_t kind, float* param, float* state1, float* state2, int64_t rows, int32_t dim, float lr, int32_t normalize,
+                     const kge_lazy_rows* lazy, int64_t step, const int64_t* const* id_lists, int32_t n_lists, int64_t n_ids,
+                     void* stream) {
+    if (!param || rows <= 0 || dim <= 0 || n_lists < 1 || n_lists > 4 || !id_lists || n_ids < 0) { set_error("kge_lazy_catchup: bad arguments (1..4 id lists)"); return -1; }
+    if (n_ids == 0) return 0;
+    for (int i = 0; i < n_lists; ++i) {
+        if (!id_lists[i]) { set_error("kge_lazy_catchup: id list %d is null", i); return -1; }
+        if (int rc = debug_check_ids("kge_lazy_catchup", "row", id_lists[i], n_ids, 1, 0, rows, (hipStream_t)stream)) return rc;
+    }
+    return launch_lazy_rows(kind, 0, param, state1, state2, rows, dim, lr, normalize, lazy, step, id_lists, n_ids, n_lists, 1, (hipStream_t)stream);
+}
+
+int kge_lazy_flush(int32_t kind, float* param, float* state1, float* state2, int64_t rows, int32_t dim, float lr, int32_t normalize,
+                   int32_t normalize_last_step, const kge_lazy_rows* lazy, int64_t step, void* stream) {
+    if (!param || rows <= 0 || dim <= 0 || step < 0) { set_error("kge_lazy_flush: bad arguments"); return -1; }
+    if (lazy && lazy->dev_cursor) { set_error("kge_lazy_flush: the target step is a host argument (dev_cursor must be NULL)"); return -1; }
+    if (step == 0) return 0;
+    return launch_lazy_rows(kind, 1, param, state1, state2, rows, dim, lr, normalize, lazy, step, nullptr, 0, 0, normalize_last_step, (hipStream_t)stream);
 }
 
 int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,

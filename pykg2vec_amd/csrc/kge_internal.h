@@ -171,7 +171,11 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
 
 int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float lr, int64_t step,
                           int zero_grad, int normalize, const float* dev_hyper, const unsigned* touched, unsigned* touched_clear,
-                          hipStream_t s);
+                          const kge_lazy_rows* lazy, hipStream_t s);
+int launch_lazy_rows(int kind, int mode, float* p, float* s1, float* s2, int64_t rows, int dim, float lr, int normalize,
+                     const kge_lazy_rows* lazy, int64_t step, const int64_t* const* ids, int64_t n_ids, int n_lists, int norm_last,
+                     hipStream_t s);
+void lazy_hyper_fill(float lr, int64_t first_step, int64_t n, float* out);
 
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);

@@ -77,3 +77,16 @@ def dev(a, dtype=torch.int64):
 def params_of(model):
     return {p_name: getattr(model, p_name).weight.detach().cpu().numpy()
             for p_name in [n.split(".")[0] for n, _ in model.named_parameters()]}
+
+
+def record_max(report, key, value):
+    """Keep the largest `value` seen under `key` in gpurun_out/<report>.json (observed deviations from the reference, copied into
+    profiles/ by the builder: the tolerances of the deterministic paths are set to ~2x what is recorded there)."""
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    fn = os.path.join(out, report + ".json")
+    doc = json.load(open(fn)) if os.path.exists(fn) else {}
+    doc[key] = max(float(value), doc.get(key, 0.0))
+    json.dump(doc, open(fn, "w"), indent=1, sort_keys=True)

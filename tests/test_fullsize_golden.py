@@ -170,8 +170,11 @@ def test_hip_ranks_match_reference_at_full_size_inside_the_score_band(name):
 # ------------------------------------------------------------------ ONE optimiser step of every BASELINE config through the path the
 # bench times, against the live reference (tests/golden/ref_full_step_*.npz, oracle/make_golden_fullsize.py step)
 STEP_CASES = list(gu.DEFAULT_STEP)
-GRAD_FLOOR = 1e-6     # |gradient element| below which the first Adam / Adagrad step (p -= lr * g / (|g| + eps)) turns fp32 noise of
-                      # the gradient into a +-lr step: such elements are held to |delta p| <= 2 lr instead (and counted in the report)
+GRAD_FLOOR_REL = 1e-4  # the first Adam / Adagrad step is p -= lr * g / (|g| + eps) = lr * sign(g): an element whose gradient is fp32
+                       # noise (|g| below this fraction of the table's largest gradient element; implementations agree on g to ~1e-6
+                       # of that) may step the other way.  Such elements are held to |delta p| <= 2 lr and counted in the report.
+UPDATED_ROW_ATOL = {"c4_rescal": 5e-7}     # RESCAL's entity gradients are float atomics (order-dependent rounding); the other default
+UPDATED_ROW_ATOL_DET = 2e-7                # paths sum in a fixed order: 2x the largest deviation observed (profiles/r04_step_agreement_fullsize.json: 9e-8)
 
 
 def _step_golden(name):
@@ -182,7 +185,7 @@ def _grad_from_state1(optimizer, s1):
     return {"adam": lambda m: m / 0.1, "adagrad": np.sqrt, "rms": lambda s: np.sqrt(s / 0.01)}[optimizer](np.asarray(s1, np.float64))
 
 
-def check_step_against_reference(name, loss, tables, state1, state2, report, loss_rtol=3e-5, state_rtol=2e-3):
+def check_step_against_reference(name, loss, tables, state1, state2, report, loss_rtol=3e-5, state_rtol=2e-5, row_atol=None):
     """tables / state1 / state2: {state_dict key: array}.  Untouched rows must equal the reference's bit for bit (dense optimisers
     with zero gradient and zero state leave a row unchanged); gradient-carrying quantities (optimiser state) agree to fp32 noise over
     ALL rows (float64 row digests); the listed rows of the updated tables agree element-wise wherever the gradient is not noise."""
@@ -201,7 +204,7 @@ def check_step_against_reference(name, loss, tables, state1, state2, report, los
         d1 = np.abs(got_s1 - ref_s1)
         assert np.all(d1 <= state_rtol * np.abs(ref_s1) + 2e-6 * scale1), (key, "state1 rows", float(d1.max()), scale1)
         g = np.abs(_grad_from_state1(opt, ref_s1))
-        solid = g >= GRAD_FLOOR
+        solid = g >= GRAD_FLOOR_REL * max(float(g.max()), 1e-30)
         dp = np.abs(got_rows - ref_rows)
         untouched = ~np.any(ref_s1 != 0, axis=1)
         # rows nobody touched: bit-identical -- except RESCAL, whose forward renormalises every row (same value to rounding)
@@ -210,7 +213,7 @@ def check_step_against_reference(name, loss, tables, state1, state2, report, los
         else:
             assert np.array_equal(got_rows[untouched], ref_rows[untouched]), (key, "untouched rows moved")
         solid = solid | untouched[:, None]
-        tol_solid = 2e-6 + 2e-3 * lr          # the update is lr * (g / (|g| + eps)): relative error of g -> absolute error <= ~1e-3 lr
+        tol_solid = row_atol if row_atol is not None else UPDATED_ROW_ATOL.get(name, UPDATED_ROW_ATOL_DET)
         assert np.all(dp[solid] <= tol_solid), (key, "post rows", float(dp[solid].max()))
         assert np.all(dp[~solid] <= 2.0 * lr * 1.001 + 1e-6), (key, "noise-gradient elements", float(dp[~solid].max()))
         # digests over ALL rows of the gradient-carrying state
@@ -249,7 +252,9 @@ def test_oracle_default_step_matches_reference_at_full_size(name):
     ko.optimizer_step(step["optimizer"], Pn, G, st, step["lr"])
     s1 = st["m"] if step["optimizer"] == "adam" else st["sq"]
     wkey = lambda d: {k + ".weight": v for k, v in d.items()}
-    check_step_against_reference(name, loss, wkey(Pn), wkey(s1), wkey(st["v"]) if step["optimizer"] == "adam" else None, {})
+    # (numpy's reduction order differs from both ATen's and the kernels': a looser row tolerance than the GPU paths are held to)
+    check_step_against_reference(name, loss, wkey(Pn), wkey(s1), wkey(st["v"]) if step["optimizer"] == "adam" else None, {},
+                                 state_rtol=2e-4, row_atol=1e-5)
 
 
 @pytest.mark.gpu
