@@ -66,7 +66,9 @@ class FlatState:
     reduce-scatter(grad) -> optimiser on 1/N of the tables -> all-gather(param).  Same bytes on the wire as an
     all-reduce, 1/N of the optimiser sweep (the B-independent part of the step) and of its state memory."""
 
-    def __init__(self, model, optimizer, backend=K, world_size=1, rank=0, distributed=None):
+    def __init__(self, model, optimizer, backend=K, world_size=1, rank=0, distributed=None, replicate_optimizer=False):
+        """replicate_optimizer (data parallel with the sparse gradient exchange, Trainer._sparse_dp): every rank keeps the optimiser
+        state of ALL rows and steps all of them, so no parameter all-gather exists -- the shard is the whole buffer."""
         self.K = backend
         # distributed (default: world_size > 1): the step goes through the collectives and needs a reduce-scatter target that
         # is distinct from the local gradient buffer -- also at world size 1 when a process group was given explicitly
@@ -82,8 +84,9 @@ class FlatState:
         tot = (tot + quantum - 1) // quantum * quantum
         self.numel = tot
         self.world_size, self.rank = world_size, rank
-        self.shard_numel = tot // world_size
-        self.shard_lo = rank * self.shard_numel
+        self.replicate_optimizer = bool(replicate_optimizer)
+        self.shard_numel = tot if replicate_optimizer else tot // world_size
+        self.shard_lo = 0 if replicate_optimizer else rank * self.shard_numel
         self.param = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.views, self.grad_views = [], []
@@ -96,7 +99,7 @@ class FlatState:
         self.optimizer = optimizer
         self.param_shard = self.param[self.shard_lo:self.shard_lo + self.shard_numel]
         # reduced gradient of this rank's shard: the full buffer itself when there is nothing to reduce
-        self.grad_shard = self.grad if not distributed else torch.zeros(self.shard_numel, dtype=torch.float32, device=dev)
+        self.grad_shard = self.grad if (not distributed or replicate_optimizer) else torch.zeros(self.shard_numel, dtype=torch.float32, device=dev)
         self.state1 = torch.zeros_like(self.param_shard) if optimizer in ("adam", "adagrad", "rms") else None
         self.state2 = torch.zeros_like(self.param_shard) if optimizer == "adam" else None
         self.step = 0
@@ -239,7 +242,8 @@ class Trainer:
         return {"pull": flag("KGE_PULL"), "staged": flag("KGE_STAGED"), "graph_multi": flag("KGE_GRAPH_MULTI"),
                 "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED"),
                 "rescal_unfused": flag("KGE_RESCAL_UNFUSED"), "pull_dir": flag("KGE_PULL_DIR"),
-                "transx_own": flag("KGE_TRANSX_OWN"), "own_staged": flag("KGE_OWN_STAGED"), "lazy_opt": flag("KGE_LAZY_OPT")}
+                "transx_own": flag("KGE_TRANSX_OWN"), "own_staged": flag("KGE_OWN_STAGED"), "lazy_opt": flag("KGE_LAZY_OPT"),
+                "dp_sparse": flag("KGE_DP_SPARSE")}
 
     def _init_hot_path(self, process_group=None, backend=None, use_graph=None):
         # `backend` exists so that the multi-process plumbing (batch sharding, gradient collectives, replica
@@ -269,7 +273,9 @@ class Trainer:
         if self.config.optimizer not in K.OPTIMIZER_IDS:  # sgd / adam / adagrad / rms (utils/trainer.py:112-131)
             raise NotImplementedError("No support for %s optimizer" % self.config.optimizer)
         self.model.to(self.config.device)
-        self.flat = FlatState(self.model, self.config.optimizer, self.K, self.world_size, self.rank, self.distributed)
+        self._sparse_dp = self._sparse_dp_wanted()
+        self.flat = FlatState(self.model, self.config.optimizer, self.K, self.world_size, self.rank, self.distributed,
+                              replicate_optimizer=self._sparse_dp)
         self.evaluator = Evaluator(self.model, self.config, backend=self.K)
         self.loss_buf = self.K.new_loss_buffer(self.flat.param.device)
         self.monitor = monitor
@@ -389,8 +395,12 @@ class Trainer:
             data = next(gen)
         self._wait_gather()      # (the sampler launch above ran under the previous step's parameter all-gather)
         if self.model.training_strategy == TrainingStrategy.PAIRWISE_BASED:
+            if getattr(self, "_sparse_dp", False):       # the entity rows this rank's share of the batch can touch
+                self._batch_entity_ids = torch.cat([data[0], data[2], data[3], data[5]])
             self._accumulate_pairwise(*data, sampled=True)
         else:
+            if getattr(self, "_sparse_dp", False):
+                self._batch_entity_ids = torch.cat([data[0], data[2]])
             self._accumulate_pointwise(*data)
 
     def _accumulate_pointwise(self, h, r, t, y):
@@ -907,15 +917,24 @@ class Trainer:
     def _lazy_rows(self):
         """The exact lazy form of the entity table's dense optimiser (RESCAL inside an epoch, csrc/kge_opt.hip): only the rows a step
         touched are stepped, the rows a batch reads are first caught up by replaying their missed zero-gradient steps, everything
-        is flushed when the epoch ends.  Bit-identical to the dense sweep; it removes the sweep over the 97 % of C4's entity rows no
-        batch touched (111 of 185 us per step).  KGE_LAZY_OPT=0 keeps the dense sweep (A/B).  Decided once per epoch."""
+        is flushed when the epoch ends.  Bit-identical to the dense sweep.  Default: on for SGD / Adagrad / RMSprop, off for Adam
+        (see _lazy_begin_epoch); KGE_LAZY_OPT=0 / 1 overrides.  Decided once per epoch."""
         if not getattr(self, "_lazy_epoch", False):
             return None
         return self._lazy
 
     def _lazy_begin_epoch(self, num_batch):
         self._lazy_epoch = False
-        if self.switches.get("lazy_opt") is False or not self._rescal_fused():
+        want = self.switches.get("lazy_opt")
+        if want is None:
+            # Measured at the C4 shape (profiles/r04_c4_lazy_ab.txt, r04_experiments.md section 1): with Adam the replay loses --
+            # 301 vs 185 us per step.  Every row is touched every ~40 steps, so its moments never reach zero and each missed step
+            # costs the full update (IEEE sqrt + two divisions + the row renormalisation): the replays run at 0.28 T element-steps/s
+            # of VALU, no faster than the dense sweep streams (0.23 T/s at 5.5 TB/s), and the slowest chain of a batch sets the
+            # launch time.  With SGD / Adagrad / RMSprop a zero gradient leaves p alone: a replay is the renormalisation's fixed point
+            # (one or two passes) plus, for RMSprop, one multiply per missed step.
+            want = self.config.optimizer != "adam"
+        if not want or not self._rescal_fused():
             return
         ent = self.flat.views[0]
         if ent.shape[1] % 4 or ent.shape[1] > 1024 or not self.K.rescal_pair_step_ok(self._desc, int(self.config.batch_size)):
@@ -944,6 +963,62 @@ class Trainer:
         the hinge is a SUM (criterion.py:25-29)."""
         return (self.model.training_strategy != TrainingStrategy.PAIRWISE_BASED
                 or self.model.model_name.lower() == "rotate")
+
+    # ------------------------------------------------------------------ data parallel: exchange only the rows the global batch touched
+    # models whose step takes materialised batch ids (kge_sample_batch) and whose gradient is confined to the batch's rows (NTN's
+    # dense L2 regulariser touches every row of every table: it keeps the dense exchange)
+    SPARSE_DP_MODELS = ("rescal", "transr")
+
+    def _sparse_dp_wanted(self):
+        """Data parallel with a batch that touches a small part of the entity tables (C4: 4 x 1 024 of 123 182 rows): instead of
+        reduce-scattering and all-gathering the dense flat buffers (2 x 104 MB on the wire at C4), the ranks exchange the gradient
+        ROWS of the entities the global batch names -- all-gather of the id lists, one all-reduce of a [4 x global batch, d]
+        buffer per entity table -- plus one dense all-reduce of the (small) remaining tables, and every rank then runs the same
+        dense optimiser step over all rows (replicated; no parameter all-gather).  Replicas stay bit-identical (every rank sums
+        the same all-reduced rows); at world size 2 the result equals the dense exchange bit for bit (tests/test_dist_gloo.py).
+        Rule: the id lists' capacity (4 ids per pair of the GLOBAL batch) is at most a quarter of the entity rows.  KGE_DP_SPARSE=0/1."""
+        if not self.distributed or self.model.kernel_name not in self.SPARSE_DP_MODELS:
+            return False
+        if self.switches.get("dp_sparse") is not None:
+            return self.switches["dp_sparse"]
+        rows = 4 * int(self.config.batch_size) * (1 + int(self.config.neg_rate)) // 2
+        return 4 * rows <= int(self.config.tot_entity)
+
+    def _sparse_exchange(self, mean):
+        """Sum, over ranks, the gradient rows of the entity-indexed tables named by this step's batch ids, and the dense gradients of
+        every other table.  All index work is device-side torch indexing on small tensors (no host synchronisation)."""
+        dist = torch.distributed
+        flat, E = self.flat, int(self.config.tot_entity)
+        ids = self._batch_entity_ids.to(torch.int64)
+        n_local = ids.numel()
+        cap = n_local * self.world_size
+        st = self.__dict__.setdefault("_sparse_bufs", {})
+        if st.get("cap") != cap:
+            dev = flat.param.device
+            st.update(cap=cap, ids_all=torch.empty(cap, dtype=torch.int64, device=dev), mask=torch.zeros(E, dtype=torch.int32, device=dev),
+                      bufs={})
+        dist.all_gather_into_tensor(st["ids_all"], ids.contiguous(), group=self.process_group)
+        ids_all = st["ids_all"]
+        mask = st["mask"]
+        mask.zero_()
+        mask[ids_all] = 1
+        slot_of_row = torch.cumsum(mask, 0) - 1          # the same on every rank: position of a touched row in the exchange buffer
+        s_local, s_all = slot_of_row[ids], slot_of_row[ids_all]
+        for v, g in zip(flat.views, flat.grad_views):
+            if v.shape[0] == E and v.dim() == 2:
+                buf = st["bufs"].get(tuple(v.shape))
+                if buf is None:
+                    buf = st["bufs"][tuple(v.shape)] = torch.zeros(cap, v.shape[1], dtype=torch.float32, device=v.device)
+                buf.zero_()
+                buf[s_local] = g[ids]                    # (a row named twice is written twice with the same values)
+                dist.all_reduce(buf, group=self.process_group)
+                if mean:
+                    buf.div_(self.world_size)
+                g[ids_all] = buf[s_all]                  # every touched row, also those only other ranks touched
+            else:                                        # relation-indexed tables: small, dense
+                dist.all_reduce(g, group=self.process_group)
+                if mean:
+                    g.div_(self.world_size)
 
     def _collectives(self):
         """(reduce_scatter_ok, backend name) of the process group: RCCL ("nccl") has the fused primitives; gloo (CPU
@@ -993,6 +1068,14 @@ class Trainer:
         # byte-identical tables afterwards by construction (everyone receives the same shards).
         dist = torch.distributed
         mean = self._mean_type_loss()
+        if getattr(self, "_sparse_dp", False):
+            # sparse exchange: gradient rows of the touched entities + the small dense tables, then the full optimiser on every rank
+            self._mark("compute")
+            self._sparse_exchange(mean)
+            self._mark("reduce_scatter")
+            optimise()
+            self._mark("optimiser")
+            return
         fused, _ = self._collectives()
         self._wait_gather()
         self._mark("compute")

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, model_name, opt, out_dir):
+def _run(rank, world, port, model_name, opt, out_dir, sparse=None, tag=""):
     for p in (os.path.dirname(HERE), HERE, os.path.join(os.path.dirname(HERE), "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -42,14 +42,20 @@ def _run(rank, world, port, model_name, opt, out_dir):
     cfg.tot_train_triples = 64 * 3  # three steps per epoch
     m = hip_util.model_from_case(c, device="cpu")
     tr = Trainer(m, cfg, backend=oracle_backend)
+    if sparse is not None:
+        tr.switches["dp_sparse"] = sparse
     tr.build_model()
     tr.generator = tr._new_generator()
     losses = [tr.train_model_epoch(e) for e in range(2)]
     ranks = tr.evaluator.rank_all(c.test, 8).numpy()
-    assert tr.flat.numel % (4 * world) == 0 and tr.flat.param_shard.numel() * world == tr.flat.numel
-    if tr.flat.state1 is not None:  # optimiser state exists only for this rank's shard
-        assert tr.flat.state1.numel() * world == tr.flat.numel
-    np.savez(os.path.join(out_dir, "r%d_w%d.npz" % (rank, world)), losses=np.asarray(losses), ranks=ranks,
+    assert tr._sparse_dp == bool(sparse and world > 1)
+    if tr._sparse_dp:   # sparse exchange: the optimiser (and its state) is replicated, nothing is sharded
+        assert tr.flat.param_shard.numel() == tr.flat.numel and (tr.flat.state1 is None or tr.flat.state1.numel() == tr.flat.numel)
+    else:
+        assert tr.flat.numel % (4 * world) == 0 and tr.flat.param_shard.numel() * world == tr.flat.numel
+        if tr.flat.state1 is not None:  # optimiser state exists only for this rank's shard
+            assert tr.flat.state1.numel() * world == tr.flat.numel
+    np.savez(os.path.join(out_dir, "r%d_w%d%s.npz" % (rank, world, tag)), losses=np.asarray(losses), ranks=ranks,
              **{n: p.detach().numpy() for n, p in m.named_parameters()})
     if world > 1:
         dist.destroy_process_group()
@@ -73,3 +79,21 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path, model_name, opt)
     assert np.allclose(a["losses"], one["losses"], rtol=1e-4)
     assert np.array_equal(a["ranks"], b["ranks"])
     assert np.abs(a["ranks"] - one["ranks"]).max() <= 1
+
+
+@pytest.mark.parametrize("model_name,opt", [("rescal", "adam"), ("rescal", "sgd"), ("rescal", "rms")])
+def test_sparse_row_exchange_equals_the_dense_exchange_bit_for_bit(tmp_path, model_name, opt):
+    """Two ranks, gradient rows of the touched entities exchanged as lists (Trainer._sparse_exchange) instead of the dense
+    reduce-scatter / all-gather of the flat buffers: identical tables on both ranks, and identical -- np.array_equal -- to the dense
+    exchange's (at world size 2 a row's sum is one addition either way)."""
+    out = str(tmp_path)
+    port = _free_port()
+    mp.spawn(_run, args=(2, port, model_name, opt, out, False, "_dense"), nprocs=2, join=True)
+    port = _free_port()
+    mp.spawn(_run, args=(2, port, model_name, opt, out, True, "_sparse"), nprocs=2, join=True)
+    d0 = np.load(os.path.join(out, "r0_w2_dense.npz"))
+    s0 = np.load(os.path.join(out, "r0_w2_sparse.npz"))
+    s1 = np.load(os.path.join(out, "r1_w2_sparse.npz"))
+    for k in d0.files:
+        assert np.array_equal(s0[k], s1[k]), "replicas diverged on %s" % k
+        assert np.array_equal(s0[k], d0[k]), (k, np.abs(s0[k] - d0[k]).max())
