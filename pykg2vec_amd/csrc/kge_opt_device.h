@@ -18,6 +18,8 @@ __device__ __forceinline__ void opt_update(float& p, float g, float& s1, float& 
     } else if constexpr (KIND == KGE_OPT_ADAM) {  // torch/optim/adam.py _single_tensor_adam, defaults
         s1 = s1 + (1.0f - 0.9f) * (g - s1);          // exp_avg.lerp_(grad, 1 - beta1)
         s2 = s2 * 0.999f + (1.0f - 0.999f) * g * g;  // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+        // (the sweeps are memory-bound: a build with the 1-ulp hardware sqrt / rcp instead of these IEEE sequences streams no faster,
+        //  profiles/r04_experiments.md section 2)
         const float denom = sqrtf(s2) / a.bc2_sqrt + 1e-8f;
         p = p + (-a.step_size) * s1 / denom;         // param.addcdiv_(exp_avg, denom, value=-step_size)
     } else if constexpr (KIND == KGE_OPT_ADAGRAD) {  // lr_decay 0, eps 1e-10

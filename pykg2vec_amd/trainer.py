@@ -917,23 +917,22 @@ class Trainer:
     def _lazy_rows(self):
         """The exact lazy form of the entity table's dense optimiser (RESCAL inside an epoch, csrc/kge_opt.hip): only the rows a step
         touched are stepped, the rows a batch reads are first caught up by replaying their missed zero-gradient steps, everything
-        is flushed when the epoch ends.  Bit-identical to the dense sweep.  Default: on for SGD / Adagrad / RMSprop, off for Adam
-        (see _lazy_begin_epoch); KGE_LAZY_OPT=0 / 1 overrides.  Decided once per epoch."""
+        is flushed when the epoch ends.  Bit-identical to the dense sweep, and -- measured -- not faster than it (see
+        _lazy_begin_epoch): opt-in with KGE_LAZY_OPT=1.  Decided once per epoch."""
         if not getattr(self, "_lazy_epoch", False):
             return None
         return self._lazy
 
     def _lazy_begin_epoch(self, num_batch):
         self._lazy_epoch = False
-        want = self.switches.get("lazy_opt")
-        if want is None:
-            # Measured at the C4 shape (profiles/r04_c4_lazy_ab.txt, r04_experiments.md section 1): with Adam the replay loses --
-            # 301 vs 185 us per step.  Every row is touched every ~40 steps, so its moments never reach zero and each missed step
-            # costs the full update (IEEE sqrt + two divisions + the row renormalisation): the replays run at 0.28 T element-steps/s
-            # of VALU, no faster than the dense sweep streams (0.23 T/s at 5.5 TB/s), and the slowest chain of a batch sets the
-            # launch time.  With SGD / Adagrad / RMSprop a zero gradient leaves p alone: a replay is the renormalisation's fixed point
-            # (one or two passes) plus, for RMSprop, one multiply per missed step.
-            want = self.config.optimizer != "adam"
+        # Opt-in (KGE_LAZY_OPT=1).  Measured at the C4 shape, same box, us per step dense -> lazy (profiles/r04_c4_lazy_ab.txt,
+        # r04_experiments.md section 1): Adam 185 -> 301, RMSprop 158 -> 172, SGD 113 -> 134, Adagrad 154 -> 138.  Every row of C4 is
+        # touched every ~40 steps, so with Adam its moments never reach zero and each missed step costs the full update (IEEE sqrt,
+        # two divisions, the row renormalisation): the replays run at 0.28 T element-steps/s of VALU -- no faster than the dense sweep
+        # streams (0.23 T/s at 5.5 TB/s) -- and the longest chain of a batch (a row behind by hundreds of steps) sets the launch
+        # time.  Without Adam p is a fixed point of the optimiser, but fp32 renormalisation of a unit row need not settle (it can
+        # alternate between two neighbouring rows), so those replays run their full length too.  The dense sweep stays the default.
+        want = bool(self.switches.get("lazy_opt"))
         if not want or not self._rescal_fused():
             return
         ent = self.flat.views[0]

@@ -84,10 +84,12 @@ def _run_rccl_one_rank(rank, port, case, out_dir):
         if p not in sys.path:
             sys.path.insert(0, p)
     model, opt, mode = case
-    for k in ("KGE_PULL", "KGE_GRAPH_MULTI", "KGE_STAGED"):
+    for k in ("KGE_PULL", "KGE_GRAPH_MULTI", "KGE_STAGED", "KGE_DP_SPARSE"):
         os.environ.pop(k, None)
     if mode == "graph":
         os.environ["KGE_GRAPH_MULTI"] = "1"
+    if mode == "sparse":       # gradient rows of the batch's entities exchanged as lists, replicated optimiser (Trainer._sparse_exchange)
+        os.environ["KGE_DP_SPARSE"] = "1"
     os.environ["KGE_PULL"] = "1" if mode == "pull" else "0"
     import hip_util
     import kge_oracle as ko
@@ -116,7 +118,8 @@ def _run_rccl_one_rank(rank, port, case, out_dir):
         tr.generator = tr._new_generator()
         if pg is not None:
             assert tr.distributed and tr.world_size == 1 and tr._collectives() == (True, "nccl")
-            assert tr.flat.grad_shard.data_ptr() != tr.flat.grad.data_ptr()
+            assert tr._sparse_dp == (mode == "sparse")
+            assert (tr.flat.grad_shard.data_ptr() != tr.flat.grad.data_ptr()) == (mode != "sparse")
             assert tr._graph_wanted(4) == (mode == "graph")
             assert tr._pull_dp_ok() == (mode == "pull")
         losses = [tr.train_model_epoch(e) for e in range(2)]
@@ -140,7 +143,8 @@ def _run_rccl_one_rank(rank, port, case, out_dir):
 
 @pytest.mark.parametrize("case", [("transe", "adam", "eager"), ("transe", "adam", "graph"), ("transe", "sgd", "pull"),
                                   ("complex", "adagrad", "eager"), ("complex", "adagrad", "graph"),
-                                  ("rescal", "adam", "eager")],   # separate sampler launch: it runs under the async all-gather
+                                  ("rescal", "adam", "eager"),    # separate sampler launch: it runs under the async all-gather
+                                  ("rescal", "adam", "sparse")],
                          ids=lambda c: "-".join(c))
 def test_one_rank_rccl_group_runs_the_collective_step(tmp_path, case):
     out = str(tmp_path)
@@ -152,6 +156,8 @@ def test_one_rank_rccl_group_runs_the_collective_step(tmp_path, case):
         assert marks == ["begin", "compute", "reduce_scatter", "optimiser", "all_gather", "row_norms"] * 4, marks
     elif case[2] == "eager":
         assert marks == ["begin", "compute", "reduce_scatter", "optimiser", "all_gather"] * 4, marks
+    elif case[2] == "sparse":  # no parameter all-gather: every rank steps every row
+        assert marks == ["begin", "compute", "reduce_scatter", "optimiser"] * 4, marks
     for k in z.files:
         if not k.startswith("plain."):
             continue
