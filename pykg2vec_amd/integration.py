@@ -69,12 +69,16 @@ def reference_trainer(backend=None, process_group=None, use_graph=None):
         def tune_model(self):
             return self._with_hip_collaborators(lambda: ref_tr.Trainer.tune_model(self))
 
-    # the hot loop and its private helpers, taken from the class that owns them (no name list to keep in sync)
-    for name, fn in vars(Hip).items():
-        if isinstance(fn, types.FunctionType) and name not in vars(Trainer) and \
-                (name.startswith("_") and not name.startswith("__") or name in ("train_model_epoch", "train_step_pairwise",
-                                                                                 "train_step_pointwise", "step_next_batch",
-                                                                                 "step_next_batches", "pull_step_explicit",
-                                                                                 "sync_model")):
-            setattr(Trainer, name, fn)
+    # the hot loop, its private helpers and the constants they read, taken from the class that owns them (no name list of the
+    # private part to keep in sync); the reference keeps everything outside the hot path
+    public = ("train_model_epoch", "train_step_pairwise", "train_step_pointwise", "step_next_batch", "step_next_batches", "step_path",
+              "pull_step_explicit", "own_step_explicit", "transx_step_explicit", "sync_model")
+    for name, obj in vars(Hip).items():
+        if name in vars(Trainer) or name.startswith("__"):
+            continue
+        if isinstance(obj, types.FunctionType):
+            if name.startswith("_") or name in public:
+                setattr(Trainer, name, obj)
+        elif name.isupper() and name not in ("TRAINED_MODEL_FILE_NAME", "TRAINED_MODEL_CONFIG_NAME"):
+            setattr(Trainer, name, obj)        # STEP_PATHS, PULL_INDEX_BUDGET, OWN_GENERIC_MODELS, ...
     return Trainer

@@ -862,38 +862,59 @@ class Trainer:
         """One whole training step on the generator's next batch, whichever path serves it."""
         self.step_next_batches(1)
 
+    # The step paths, in order of precedence: the first whose predicate holds serves the next batches.  (name, predicate, needs
+    # FULL batches -- the owner-computes runs index only the whole batches of the permutation; a short last batch falls through).
+    #
+    #   path      models                                   when (defaults; DESIGN.md section 5a lists the overriding switches)           step
+    #   pull      TransE, TransM                           hinge, neg_rate 1, one GPU, d % 4 == 0 and <= 1024, index within budget       kge_pull_run: [k_pull_eval +] k_pull_step per step (two launches for L1 at B >= 8192)
+    #   own       DistMult, ComplEx(N3), ANALOGY, CP,      pointwise logistic, neg_rate 1, one GPU, index within budget                  kge_own_run: k_own_eval + k_own_step (+ k_own_apply)
+    #             SimplE(_ignr), QuatE
+    #   staged    RotatE (DistMult / ComplEx: KGE_STAGED)  one GPU, a step scores more than GRAPH_MAX_ROWS triples                       bundle kernel with staged gradient rows + k_opt_staged
+    #   transx    TransH, TransD                           hinge, neg_rate 1, one GPU, d % 4 == 0 and <= 512, index within budget        kge_transx_run: k_transx_eval + k_transx_own + k_opt
+    #   pull_dp   TransE, TransM at N > 1                  batch per rank beyond the graph regime                                        k_pull_step<gradient> -> reduce-scatter -> sharded k_opt -> all-gather -> k_row_norms
+    #   generic   everything else (RESCAL, NTN, TransR,    --                                                                            fused step kernel (atomic scatter) + k_opt / k_opt_rows4; replayed as a hipGraph
+    #             neg_rate > 1, short last batches, N > 1)                                                                               when a step scores <= GRAPH_MAX_ROWS triples (train_model_epoch); at N > 1 the dense or
+    #                                                                                                                                    the sparse-row gradient exchange (_reduce_and_step)
+    STEP_PATHS = (("pull", "_pull_ok", True), ("own", "_own_ok", True), ("staged", "_staged_ok", False), ("transx", "_transx_ok", True),
+                  ("pull_dp", "_pull_dp_ok", False), ("generic", None, False))
+
+    def step_path(self, n=1):
+        """Name of the path that serves the next n batches (STEP_PATHS)."""
+        full = n > 0 and self.generator is not None and \
+            self.generator._batch_idx + n <= self.generator.n_train // int(self.config.batch_size)
+        for name, pred, needs_full in self.STEP_PATHS:
+            if pred is None or ((full or not needs_full) and getattr(self, pred)()):
+                return name
+
     def step_next_batches(self, n):
-        """n consecutive steps of the current epoch.  On the owner-computes path they are enqueued by one native call."""
-        if n > 0 and self._pull_ok() and self.generator._batch_idx + n <= self.generator.n_train // self.config.batch_size:
-            self._pull_steps(n)
-            return
-        if n > 0 and self._own_ok() and self.generator._batch_idx + n <= self.generator.n_train // self.config.batch_size:
-            self._own_steps(n)
-            return
-        if getattr(self, "_pull", None) is not None and not self._pull.grad_only:
+        """n consecutive steps of the current epoch.  On the owner-computes paths they are enqueued by one native call."""
+        path = self.step_path(n)
+        if path not in ("pull", "own") and getattr(self, "_pull", None) is not None and not self._pull.grad_only:
             # leaving the single-GPU pull path (a short last batch): hand the tables back.  (The gradient-mode state of the
             # data-parallel step owns no tables and is kept: its prepared calls and ride-along sampler survive.)
             self.sync_model()
             self._pull = None
-        if self._staged_ok():
+        if path == "pull":
+            self._pull_steps(n)
+        elif path == "own":
+            self._own_steps(n)
+        elif path == "staged":
             for _ in range(n):
                 self._staged_step()
-            return
-        if n > 0 and self._transx_ok() and self.generator._batch_idx + n <= self.generator.n_train // self.config.batch_size:
+        elif path == "transx":
             self._transx_steps(n)
-            return
-        if self._pull_dp_ok():
+        elif path == "pull_dp":
             for _ in range(n):
                 self._pull_dp_step()
-            return
-        try:
-            for _ in range(n):
-                self._rescal_last = self.generator._pending == 1   # the epoch's last step leaves RESCAL's tables as the optimiser wrote them
-                self._mark("begin")
-                self._accumulate_next_batch()
-                self._reduce_and_step(overlap_gather=self.distributed)
-        finally:
-            self._wait_gather()
+        else:
+            try:
+                for _ in range(n):
+                    self._rescal_last = self.generator._pending == 1   # the epoch's last step leaves RESCAL's tables as the optimiser wrote them
+                    self._mark("begin")
+                    self._accumulate_next_batch()
+                    self._reduce_and_step(overlap_gather=self.distributed)
+            finally:
+                self._wait_gather()
 
     def _touched_bitmaps(self):
         if getattr(self, "_touched", None) is None:
@@ -1120,8 +1141,8 @@ class Trainer:
             return False
         if self.switches["staged"] and self._staged_ok():   # the staged step is an eager two-launch step
             return False
-        if self.use_graph is None and self.generator is not None and (self._pull_ok() or self._own_ok() or self._transx_ok()):   # one native call per epoch beats a replay per step
-            return False
+        if self.use_graph is None and self.generator is not None and self.step_path(1) in ("pull", "own", "transx"):
+            return False   # one native call per epoch beats a replay per step
         if self.distributed:
             # RCCL collectives are capturable (gloo is not); multi-rank capture is opt-in (use_graph=True or
             # KGE_GRAPH_MULTI=1): it has only ever run on one-rank process groups (tests/test_hip_dist.py)
