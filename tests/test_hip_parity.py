@@ -224,14 +224,14 @@ def test_eval_sweep_scores_and_ranks_match_reference(hip, name):
         ev5 = Evaluator(m, cfg)  # mixed: relations with >= 2 test triples grouped, the rest through the in-sweep transform
         ev5.GROUPED_MIN_TRIPLES_PER_RELATION = 2
         r5 = ev5.rank_all(c.test, n).cpu().numpy()
-        nd5 = ev5._groups[(id(c.test), n)][2]
+        nd5 = ev5._groups[ev5._fingerprint(c.test, n)][2]
         assert 0 < nd5 < n
         assert np.abs(r5 - ranks).max() <= 1 and (r5 != ranks).sum() <= 2
     if c.model == "transr":  # relation groups split over several grouped calls (tiny table budget) give the same ranks
         ev2 = Evaluator(m, cfg)
         ev2.TABLE_BUDGET_BYTES = 1
         assert np.array_equal(ev2.rank_all(c.test, n).cpu().numpy(), ranks)
-        assert len(ev2._groups[(id(c.test), n)][1]) > 1
+        assert len(ev2._groups[ev2._fingerprint(c.test, n)][1]) > 1
 
 
 def test_pretrained_fb15k_transe_slice(hip):
