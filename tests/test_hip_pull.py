@@ -19,7 +19,7 @@ def hip():
     return hip_util
 
 
-PULL_WEIGHT_ATOL = 1e-4   # provisional: tightened to 2x the recorded maximum once a GPU run has written it
+PULL_WEIGHT_ATOL = 8e-6   # 2x the largest deviation recorded over the 80 cases (3.6e-6, RMSprop / L2; profiles/r04_weight_agreement.json)
 
 
 @pytest.mark.parametrize("segment,compact", [(None, False), (2, False), (1, False), (None, True), (1, True)])
