@@ -826,19 +826,26 @@ def main():
     latency_model = None
     if pull and not pull_dp:
         ps_, idx_ = tr._pull_state()
-        n_groups = int(idx_.batch(0)[2].shape[0]) * K.pull_groups_per_block(DIM)
-        resident = 256 * 4 * 8 * 2     # CUs x SIMDs x 8 waves (36-62 VGPRs) x two 32-lane owner groups per wave
+        n_groups = int(idx_.batch(0)[2].shape[0])       # work items = owner groups of one launch (32 lanes each)
+        resident = 256 * 4 * 8 * 2     # CUs x SIMDs x 8 waves (32-62 VGPRs) x two 32-lane owner groups per wave
         load = min(1.0, max(0.0, (min(n_groups, resident) - 8192) / (32768 - 8192.0)))
         hop_us = HOP_US_AT_8K_GROUPS + load * (HOP_US_AT_32K_GROUPS - HOP_US_AT_8K_GROUPS)
         hops = 4 if two_phase else 5    # item -> {row, state, lists} -> {records + codes | three hat rows per visit -> ...} -> store drain
         rounds = max(1.0, n_groups / float(resident))
+        stride = K.pull_partial_stride(DIM)
+        row_bytes = (E + R) * (6 * DIM * 4 + stride * 4 + 4)        # p, m, v read and written; normalised copy + norm written
+        stream_us = row_bytes / 5.0e6                                # at the ~5 TB/s an L2 / Infinity-Cache resident sweep streams (k_opt over the same tables: 7-8 us)
+        visits_us = 4.3 if two_phase else None                       # measured with the visits compiled out (profiles/r03_experiments.md section 11)
         latency_model = {"owner_groups": n_groups, "resident_groups": resident, "residency_rounds": rounds,
                          "dependent_hops_per_owner": hops, "hop_latency_us": hop_us,
                          "hop_latency_source": "profiles/r03_gather_bench.txt (chain G=32: 21.53 us / 8 hops at 32768 groups, 9.23 us / 8 at 8192)",
-                         "predicted_owner_kernel_us": rounds * hops * hop_us,
-                         "note": "floor of the owner launch from latency alone: rounds x hops x loaded hop latency; the measured launch adds "
-                                 "the visits' arithmetic (4.3 us with the visits compiled out, profiles/r03_experiments.md section 11) and the "
-                                 "Adam finish (IEEE div / sqrt per element).  Compare with rocprofv3's k_pull_step average in profiles/r04_kernel_stats.md"}
+                         "hop_chain_us": rounds * hops * hop_us, "row_io_bytes": row_bytes, "row_io_stream_us": stream_us,
+                         "visits_us": visits_us,
+                         "predicted_owner_kernel_us": rounds * hops * hop_us + stream_us + (visits_us or 0.0),
+                         "note": "what bounds the owner launch: one residency round of owner groups, each a chain of dependent loads (rounds x "
+                                 "hops x loaded hop latency), the rows' own read-modify-write stream (parameters, both Adam moments, normalised "
+                                 "copy, norm) and the visits' arithmetic.  Compare with rocprofv3's k_pull_step average in "
+                                 "profiles/r04_kernel_stats.md (20.0 us); k_pull_eval (8.8 us) is one more launch of two dependent hops"}
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
