@@ -669,6 +669,11 @@ int kge_optimizer_step_staged(int32_t optimizer, const kge_staged_step* st, floa
  * bias may be NULL (TuckER).  fp32 on the matrix cores. */
 int kge_head_1n_forward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity,
                         const float* bias, float* preds, void* stream);
+/* The same forward with the operands rounded to bfloat16 (round to nearest even) on their way into LDS and the products
+ * accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (SURVEY 8(f) rank 4 names a bf16 option).  Inputs and outputs stay fp32.  Opt-in:
+ * the reference computes the head in fp32; a logit differs from the fp32 one by about 2^-8 relative per operand. */
+int kge_head_1n_forward_bf16(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
+                             float* preds, void* stream);
 
 /* Autograd backward of the head given d loss / d preds: dx[B,dim] is overwritten, g_ent[E,dim] and g_bias[E] are
  * accumulated into (any of the three may be NULL). */

@@ -597,6 +597,22 @@ def head_1n_forward(x, ent, bias=None, dtype=np.float32):
     return _sigmoid(z)
 
 
+def bf16_round(a):
+    """fp32 -> bfloat16 (round to nearest even) -> fp32, as the bf16 option of the head rounds its operands."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32)
+
+
+def head_1n_forward_bf16(x, ent, bias=None):
+    """The bf16 option of the head (kge_head_1n_forward_bf16): operands rounded to bfloat16, exact products, wide accumulation
+    (float64 here: the kernel accumulates in fp32 in the matrix core's own order), bias and sigmoid in fp32."""
+    z = (bf16_round(x).astype(np.float64) @ bf16_round(ent).astype(np.float64).T).astype(np.float32)
+    if bias is not None:
+        z = z + np.asarray(bias, np.float32).reshape(1, -1)
+    return _sigmoid(z)
+
+
 def multi_class_bce_dir(preds, labels, label_smoothing, tot_entity, dtype=np.float32):
     """One direction of Criterion.multi_class_bce (criterion.py:41-49): optional label smoothing
     y <- y (1 - ls) + 1/E, then torch.nn.BCEWithLogitsLoss (mean over all B*E elements) applied to the sigmoid OUTPUTS

@@ -770,7 +770,12 @@ int kge_own_run(const kge_own_plan* p, int64_t first_batch, int64_t n_steps, int
 
 int kge_head_1n_forward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
                         float* preds, void* stream) {
-    return launch_head_forward(x, batch, dim, ent, tot_entity, bias, preds, (hipStream_t)stream);
+    return launch_head_forward(x, batch, dim, ent, tot_entity, bias, preds, 0, (hipStream_t)stream);
+}
+
+int kge_head_1n_forward_bf16(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
+                             float* preds, void* stream) {
+    return launch_head_forward(x, batch, dim, ent, tot_entity, bias, preds, 1, (hipStream_t)stream);
 }
 
 int kge_head_1n_backward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* preds,

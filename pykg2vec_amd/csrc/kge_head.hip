@@ -199,6 +199,138 @@ __global__ __launch_bounds__(256, 3) void k_head_gemm128(HeadArgs a) {
     if constexpr (MODE == 1) block_accumulate_loss<1>(lsum * a.inv_count, 0, a.loss);
 }
 
+// ---- bf16 option of the forward ("bf16/f32 MFMA GEMM"): the operands are rounded to bfloat16 (round to
+// nearest even) while they are staged into LDS, products are exact in fp32 and accumulate in fp32 on
+// v_mfma_f32_32x32x16_bf16 (gfx950: 16 k per instruction, 16x the rate of the f32-input form).  Inputs and outputs stay fp32 in
+// HBM, so the [B, E] output write (not the matrix cores) bounds it.  NOT the default: the reference computes this head in fp32
+// (projection.py:100-102); a logit differs from the fp32 one by ~2^-8 relative per operand (tolerance in the tests).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int HSB = HK + 8;   // bf16 elements per LDS row: 80 bytes, 16-byte aligned operand reads
+
+// two floats -> two bfloat16 (round to nearest even) in one VALU instruction: v_cvt_pk_bf16_f32 (gfx950)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) { return (unsigned short)(pack_bf16x2(f, 0.f) & 0xFFFFu); }
+
+__device__ __forceinline__ float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }   // 1-2 ulp: bf16 option only
+
+__global__ __launch_bounds__(256) void k_head_gemm_bf16(HeadArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sA[HT * HSB], sB[HT * HSB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t e0 = (int64_t)blockIdx.x * HT, b0 = (int64_t)blockIdx.y * HT;
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x16 acc = {0};
+    const int nslabs = (a.d + HK - 1) / HK;
+    float ra[HPT], rb[HPT];
+    auto load = [&](int sl) {
+#pragma unroll
+        for (int j = 0; j < HPT; ++j) {
+            const int idx = threadIdx.x + 256 * j, r = idx / HK, k = idx - r * HK, kg = sl * HK + k;
+            ra[j] = (kg < a.d && b0 + r < a.B) ? a.x[(b0 + r) * a.d + kg] : 0.f;
+            rb[j] = (kg < a.d && e0 + r < a.E) ? a.ent[(e0 + r) * a.d + kg] : 0.f;
+        }
+    };
+    load(0);
+    for (int sl = 0; sl < nslabs; ++sl) {
+#pragma unroll
+        for (int j = 0; j < HPT; ++j) {
+            const int idx = threadIdx.x + 256 * j, r = idx / HK, k = idx - r * HK;
+            sA[r * HSB + k] = f32_to_bf16_rne(ra[j]);
+            sB[r * HSB + k] = f32_to_bf16_rne(rb[j]);
+        }
+        __syncthreads();
+        if (sl + 1 < nslabs) load(sl + 1);      // next slab's global loads in flight under the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < HK; kk += 16) {    // lane (li, lk): A row wr*32 + li / B column wc*32 + li, k = kk + 8 lk .. + 7
+            const s16x8 va = *reinterpret_cast<const s16x8*>(sA + (wr * 32 + li) * HSB + kk + 8 * lk);
+            const s16x8 vb = *reinterpret_cast<const s16x8*>(sB + (wc * 32 + li) * HSB + kk + 8 * lk);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, vb), acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int64_t e = e0 + wc * 32 + li;
+    const float bias = (a.bias && e < a.E) ? a.bias[e] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t b = b0 + wr * 32 + head_row(reg, lk);
+        if (b < a.B && e < a.E) a.preds[b * a.E + e] = sigmoid_fast(acc[reg] + bias);
+    }
+}
+
+// the bf16 forward at a 128 x 128 macro-tile: 4 waves x (2 x 2) accumulators of 32 x 32; operands fetched as float4 (8 threads
+// cover 128 contiguous bytes of a row), rounded to bf16 and stored 8 bytes at a time into a ROW-major LDS image ([row][k], 80-byte
+// rows) from which a lane reads its 8 consecutive k of an MFMA operand with one 16-byte read; slabs of 32 k double-buffered in LDS,
+// the next slab's global loads in flight during the current slab's 8 MFMAs per wave (one barrier per slab).
+constexpr int HKB = 32;
+// (a variant with the operand loads running TWO slabs ahead through two register sets -- 236 VGPRs, two waves per SIMD -- measured
+//  slower: 229 vs 162 us at B = 4096; what bounds this kernel is its epilogue, 61 M sigmoids and a [B, E] store, not its operands)
+__global__ __launch_bounds__(256, 2) void k_head_gemm128_bf16(HeadArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][HT2][HSB], sB[2][HT2][HSB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t e0 = (int64_t)blockIdx.x * HT2, b0 = (int64_t)blockIdx.y * HT2;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int srow = threadIdx.x >> 3, sk4 = (threadIdx.x & 7) * 4;   // float4 number t + 256 j of a slab: row srow + 32 j, k = sk4 .. + 3
+    const int nslab = (a.d + HKB - 1) / HKB;
+    float4 ra[4], rb[4];
+    auto load_slab = [&](int sl) {
+        const int k = sl * HKB + sk4;
+        const bool live = k < a.d;   // d % 4 == 0: a float4 is inside the row or past its end
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t b = b0 + srow + 32 * j, e = e0 + srow + 32 * j;
+            ra[j] = (live && b < a.B) ? *reinterpret_cast<const float4*>(a.x + b * a.d + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = (live && e < a.E) ? *reinterpret_cast<const float4*>(a.ent + e * a.d + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x16{0};
+    load_slab(0);
+    int buf = 0;
+    for (int sl = 0; sl < nslab; ++sl) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<uint2*>(&sA[buf][srow + 32 * j][sk4]) = make_uint2(pack_bf16x2(ra[j].x, ra[j].y), pack_bf16x2(ra[j].z, ra[j].w));
+            *reinterpret_cast<uint2*>(&sB[buf][srow + 32 * j][sk4]) = make_uint2(pack_bf16x2(rb[j].x, rb[j].y), pack_bf16x2(rb[j].z, rb[j].w));
+        }
+        __syncthreads();   // slab sl is in LDS; everybody finished reading the buffer that is written next
+        if (sl + 1 < nslab) load_slab(sl + 1);
+#pragma unroll
+        for (int kk = 0; kk < HKB; kk += 16) {
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(&sA[buf][wr * 64 + li][kk + 8 * lk]));
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(&sA[buf][wr * 64 + 32 + li][kk + 8 * lk]));
+            const bf16x8 c0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(&sB[buf][wc * 64 + li][kk + 8 * lk]));
+            const bf16x8 c1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(&sB[buf][wc * 64 + 32 + li][kk + 8 * lk]));
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, c0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, c1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c1, acc[1][1], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int64_t e = e0 + wc * 64 + ni * 32 + li;
+        const float bias = (a.bias && e < a.E) ? a.bias[e] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t b = b0 + wr * 64 + mi * 32 + head_row(reg, lk);
+                if (b < a.B && e < a.E) a.preds[b * a.E + e] = sigmoid_fast(acc[mi][ni][reg] + bias);
+            }
+    }
+}
+
 // the large tile pays once the grid fills the chip with it and the rows can be fetched 16 bytes at a time
 static bool head_use_128(const HeadArgs& a) {
     const int force = switch_value("HEAD_TILE");
@@ -328,10 +460,18 @@ static int head_check(const char* who, const float* x, const float* ent, int64_t
 
 
 int launch_head_forward(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* bias, float* preds,
-                        hipStream_t s) {
+                        int bf16, hipStream_t s) {
     if (head_check("kge_head_1n_forward", x, ent, B, E, d) || !preds) { if (!preds) set_error("kge_head_1n_forward: null output"); return -1; }
     HeadArgs a{};
     a.x = x; a.ent = ent; a.bias = bias; a.B = B; a.E = E; a.d = d; a.preds = preds;
+    if (bf16) {
+        // (the same accumulation order over k in both tile shapes: 16 k per MFMA, slabs in order -- identical logits)
+        if (head_use_128(a))
+            hipLaunchKernelGGL(k_head_gemm128_bf16, dim3((unsigned)((E + HT2 - 1) / HT2), (unsigned)((B + HT2 - 1) / HT2)), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_head_gemm_bf16, dim3((unsigned)((E + HT - 1) / HT), (unsigned)((B + HT - 1) / HT)), dim3(256), 0, s, a);
+        return check_launch("k_head_gemm_bf16");
+    }
     launch_head_gemm<0>(a, s);
     return check_launch("k_head_gemm<0>");
 }

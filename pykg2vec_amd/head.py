@@ -11,10 +11,10 @@ from . import kernels as K
 
 class _OneToN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ent, bias):
+    def forward(ctx, x, ent, bias, precision="f32"):
         x, ent = x.contiguous(), ent.contiguous()
         b = None if bias is None else bias.contiguous().view(-1)
-        preds = K.head_1n_forward(x, ent, b)
+        preds = K.head_1n_forward(x, ent, b, precision=precision)
         ctx.save_for_backward(x, ent, preds)
         ctx.has_bias = bias is not None
         ctx.bias_shape = None if bias is None else bias.shape
@@ -24,12 +24,15 @@ class _OneToN(torch.autograd.Function):
     def backward(ctx, dpreds):
         x, ent, preds = ctx.saved_tensors
         dx, g_ent, g_bias = K.head_1n_backward(x, ent, preds, dpreds.contiguous(), need_bias=ctx.has_bias)
-        return dx, g_ent, (g_bias.view(ctx.bias_shape) if ctx.has_bias else None)
+        return dx, g_ent, (g_bias.view(ctx.bias_shape) if ctx.has_bias else None), None
 
 
-def one_to_n_scores(x, ent_weight, bias=None):
-    """sigmoid(x @ ent_weight.T + bias) -> [B, E]; bias: [E] or [1, E] (ConvE's `b.weight`) or None (TuckER)."""
-    return _OneToN.apply(x, ent_weight, bias)
+def one_to_n_scores(x, ent_weight, bias=None, precision="f32"):
+    """sigmoid(x @ ent_weight.T + bias) -> [B, E]; bias: [E] or [1, E] (ConvE's `b.weight`) or None (TuckER).
+    precision="bf16": the forward GEMM with bfloat16-rounded operands and fp32 accumulation (v_mfma_f32_32x32x16_bf16; the [B, E]
+    output write then bounds it instead of the f32 matrix cores) -- for scoring all entities at evaluation time or where the
+    model tolerates it; the backward GEMMs stay fp32 and use the saved predictions.  Default "f32" = the reference's arithmetic."""
+    return _OneToN.apply(x, ent_weight, bias, precision)
 
 
 def multi_class_bce_step(x, ent_weight, bias, label_off, label_ids, label_smoothing, loss_buf, g_ent, g_bias=None):

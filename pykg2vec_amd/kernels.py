@@ -1168,14 +1168,17 @@ def _f32(t, what):
     return _dev(t, torch.float32, what)
 
 
-def head_1n_forward(x, ent, bias=None):
-    """sigmoid(x @ ent.T + bias): float32 [B, E]  (kge_head_1n_forward)."""
+def head_1n_forward(x, ent, bias=None, precision="f32"):
+    """sigmoid(x @ ent.T + bias): float32 [B, E]  (kge_head_1n_forward; precision="bf16": operands rounded to bfloat16 on their way
+    to the matrix cores, fp32 accumulation -- kge_head_1n_forward_bf16)."""
+    if precision not in ("f32", "bf16"):
+        raise ValueError("head_1n_forward: precision must be 'f32' or 'bf16'")
     B, d = x.shape
     E = ent.shape[0]
     preds = torch.empty((B, E), dtype=torch.float32, device=x.device)
-    L.check(L.load().kge_head_1n_forward(_f32(x, "x"), B, d, _f32(ent, "ent"), E,
-                                         _f32(bias, "bias") if bias is not None else None, _f32(preds, "preds"), _stream()),
-            "kge_head_1n_forward")
+    lib = L.load()
+    fn, name = (lib.kge_head_1n_forward, "kge_head_1n_forward") if precision == "f32" else (lib.kge_head_1n_forward_bf16, "kge_head_1n_forward_bf16")
+    L.check(fn(_f32(x, "x"), B, d, _f32(ent, "ent"), E, _f32(bias, "bias") if bias is not None else None, _f32(preds, "preds"), _stream()), name)
     return preds
 
 

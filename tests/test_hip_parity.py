@@ -715,6 +715,53 @@ def test_head_1n_vs_oracle_other_shapes(hip, B, E, d, with_bias):
     assert np.allclose(g_ent.cpu().numpy(), ge_ref, atol=1e-3 * scale, rtol=1e-3)
 
 
+@pytest.mark.parametrize("B,E,d,with_bias", [(128, 1000, 200, True), (70, 333, 50, False), (1, 64, 8, True), (257, 129, 97, True),
+                                             (512, 14951, 200, True)])
+def test_head_1n_bf16_option(hip, B, E, d, with_bias):
+    """kge_head_1n_forward_bf16: operands rounded to bfloat16 (RNE), exact products, fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+    (i) Against the restatement with bf16-rounded operands: the logits agree to fp32 summation noise -- this also pins the MFMA
+    operand layout (asymmetric random operands, ragged tile edges).  (ii) Against the fp32 head (what the reference computes,
+    projection.py:100-102): within the bf16 operand rounding, |delta logit| <= 2^-7 * sum_k |x_k e_k| (each operand carries a
+    relative rounding error of at most 2^-9).  The backward of one_to_n_scores(precision="bf16") is the fp32 backward on the saved
+    predictions."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.head import one_to_n_scores
+    rng = np.random.default_rng(B * 7 + E + d)
+    x = rng.normal(size=(B, d)).astype(np.float32)
+    ent = (rng.normal(size=(E, d)) * 0.3).astype(np.float32)
+    bias = (rng.normal(size=E) * 0.1).astype(np.float32) if with_bias else None
+    xd, ed = torch.from_numpy(x).cuda(), torch.from_numpy(ent).cuda()
+    bd = torch.from_numpy(bias).cuda() if with_bias else None
+    got = K.head_1n_forward(xd, ed, bd, precision="bf16").cpu().numpy()
+    ref_bf16 = ko.head_1n_forward_bf16(x, ent, bias)
+    logit = lambda p: np.log(p) - np.log1p(-p)
+    ok = (ref_bf16 > 1e-3) & (ref_bf16 < 1 - 1e-3)      # where a float32 probability still resolves its logit
+    scale = (np.abs(ko.bf16_round(x)) @ np.abs(ko.bf16_round(ent)).T)
+    assert np.all(np.abs(logit(got[ok]) - logit(ref_bf16[ok])) <= 3e-6 * scale[ok] + 3e-4), \
+        float(np.abs(logit(got[ok]) - logit(ref_bf16[ok])).max())
+    assert np.allclose(got, ref_bf16, atol=2e-6, rtol=2e-5)
+    ref_f32 = ko.head_1n_forward(x, ent, bias)
+    okf = ok & (ref_f32 > 1e-3) & (ref_f32 < 1 - 1e-3)
+    bound = 2.0 ** -7 * (np.abs(x) @ np.abs(ent).T) + 1e-4
+    assert np.all(np.abs(logit(got[okf]) - logit(ref_f32[okf])) <= bound[okf])
+    for tile in ("0", "1"):       # both tile shapes accumulate k in the same order: identical predictions
+        K.set_switch("HEAD_TILE", int(tile))
+        try:
+            assert torch.equal(K.head_1n_forward(xd, ed, bd, precision="bf16").cpu(), torch.from_numpy(got)) or d % 4
+        finally:
+            K.set_switch("HEAD_TILE", None)
+    # autograd form: forward in bf16, backward = the fp32 backward on the saved predictions
+    xt = xd.clone().requires_grad_(True)
+    et = ed.clone().requires_grad_(True)
+    p16 = one_to_n_scores(xt, et, bd, precision="bf16")
+    assert torch.equal(p16.detach().cpu(), torch.from_numpy(got))
+    dp = torch.from_numpy(rng.normal(size=(B, E)).astype(np.float32)).cuda()
+    p16.backward(dp)
+    dx, ge, _ = K.head_1n_backward(xd, ed, p16.detach(), dp, need_bias=False)
+    # (the backward GEMMs accumulate their split-K partial tiles with float atomics: equal to rounding, not bit for bit)
+    assert torch.allclose(xt.grad, dx, rtol=1e-4, atol=1e-5) and torch.allclose(et.grad, ge, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("B,E,d", [(300, 1000, 40), (129, 257, 4), (2048, 14951, 200)])
 def test_head_1n_large_tile_equals_small_tile(hip, monkeypatch, B, E, d):
     """The 128 x 128 macro-tile GEMM (large batches) keeps the k order of the 64 x 64 one: identical predictions, and the

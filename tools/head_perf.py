@@ -26,6 +26,7 @@ for B, E, d in ((128, 14951, 200), (1000, 14951, 200), (128, 40943, 200), (4096,
     ids = lab.nonzero()[:, 1].int().contiguous()
     loss_buf = K.new_loss_buffer("cuda"); g_ent = torch.zeros_like(ent); g_bias = torch.zeros(E, device="cuda")
     t_fwd = bench(lambda: K.head_1n_forward(x, ent, bias))
+    t_bf16 = bench(lambda: K.head_1n_forward(x, ent, bias, precision="bf16"))
     t_fused = bench(lambda: K.head_1n_bce(x, ent, bias, off, ids, 0.1, loss_buf, g_ent, g_bias))
     xr, er, br = x.clone().requires_grad_(), ent.clone().requires_grad_(), bias.clone().requires_grad_()
     bce = torch.nn.BCEWithLogitsLoss()
@@ -39,5 +40,6 @@ for B, E, d in ((128, 14951, 200), (1000, 14951, 200), (128, 40943, 200), (4096,
     t_aten = bench(aten)
     t_aten_fwd = bench(lambda: torch.sigmoid(torch.matmul(x, ent.T) + bias))
     flops = 2.0 * B * E * d
-    print(f"B={B} E={E} d={d}: forward {t_fwd:.1f} us ({flops/t_fwd/1e6:.1f} TFLOP/s; ATen {t_aten_fwd:.1f} us) | "
+    print(f"B={B} E={E} d={d}: forward {t_fwd:.1f} us ({flops/t_fwd/1e6:.1f} TFLOP/s; ATen {t_aten_fwd:.1f} us; bf16 option {t_bf16:.1f} us = "
+          f"{flops/t_bf16/1e6:.1f} TFLOP/s, output write {B*E*4/t_bf16/1e6:.2f} TB/s) | "
           f"fused head+bce+backward {t_fused:.1f} us ({3*flops/t_fused/1e6:.1f} TFLOP/s; ATen chain {t_aten:.1f} us)", flush=True)
