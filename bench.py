@@ -860,7 +860,7 @@ def main():
                        "model_state": "timed steps start from the freshly initialised tables (reset after warm-up)",
                        "step_path": "owner-computes (pull), two-phase: kge_pull_run, k_pull_eval + k_pull_step<two-phase> per step (the next batch's sampler rides in the second launch)" if two_phase else
                                     "owner-computes (pull): kge_pull_run, one k_pull_step launch per step (the next batch's sampler rides in its leading blocks)" if pull else
-                                    "owner-computes gradient (k_pull_step, KGE_OPT_GRADIENT: no atomics) + reduce-scatter + sharded kge_optimizer_step + all-gather + kge_row_norms" if pull_dp else
+                                    "owner-computes gradient (k_pull_step, KGE_OPT_GRADIENT: no atomics) + gradient exchange (see `collectives`) + kge_optimizer_step + kge_row_norms" if pull_dp else
                                     "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step"},
             "roofline": {"kernel": kernel_label, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -955,7 +955,9 @@ def main():
             out["phases_us"] = phases_us
             out["collectives"] = {"backend": dist.get_backend(), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "(unset: RCCL picks)"),
                                   "NCCL_PROTO": os.environ.get("NCCL_PROTO", "(unset)"),
-                                  "per_step": "reduce_scatter(flat grad, %d B) + all_gather(flat param)" % (tr.flat.numel * 4),
+                                  "per_step": ("all_reduce(flat grad, %d B); every rank steps every row (tables <= 32 MB)" % (tr.flat.numel * 4)
+                                               if getattr(tr, "_dp_allreduce", False) else
+                                               "reduce_scatter(flat grad, %d B) + all_gather(flat param)" % (tr.flat.numel * 4)),
                                   "optimizer_shard_floats": tr.flat.shard_numel}
         print(json.dumps(out), flush=True)
     if world > 1:

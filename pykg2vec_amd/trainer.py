@@ -243,7 +243,8 @@ class Trainer:
                 "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED"),
                 "rescal_unfused": flag("KGE_RESCAL_UNFUSED"), "pull_dir": flag("KGE_PULL_DIR"),
                 "transx_own": flag("KGE_TRANSX_OWN"), "own_staged": flag("KGE_OWN_STAGED"), "lazy_opt": flag("KGE_LAZY_OPT"),
-                "dp_sparse": flag("KGE_DP_SPARSE")}
+                "dp_sparse": flag("KGE_DP_SPARSE"),
+                "dp_allreduce": flag("KGE_DP_ALLREDUCE")}
 
     def _init_hot_path(self, process_group=None, backend=None, use_graph=None):
         # `backend` exists so that the multi-process plumbing (batch sharding, gradient collectives, replica
@@ -274,8 +275,9 @@ class Trainer:
             raise NotImplementedError("No support for %s optimizer" % self.config.optimizer)
         self.model.to(self.config.device)
         self._sparse_dp = self._sparse_dp_wanted()
+        self._dp_allreduce = (not self._sparse_dp) and self._dp_allreduce_wanted()
         self.flat = FlatState(self.model, self.config.optimizer, self.K, self.world_size, self.rank, self.distributed,
-                              replicate_optimizer=self._sparse_dp)
+                              replicate_optimizer=self._sparse_dp or self._dp_allreduce)
         self.evaluator = Evaluator(self.model, self.config, backend=self.K)
         self.loss_buf = self.K.new_loss_buffer(self.flat.param.device)
         self.monitor = monitor
@@ -984,6 +986,21 @@ class Trainer:
         return (self.model.training_strategy != TrainingStrategy.PAIRWISE_BASED
                 or self.model.model_name.lower() == "rotate")
 
+    # ------------------------------------------------------------------ data parallel: one all-reduce for small tables
+    DP_ALLREDUCE_MAX_BYTES = 32 << 20
+
+    def _dp_allreduce_wanted(self):
+        """Data parallel with tables small enough that the optimiser sweep is a few microseconds (C0 / C1: 6.5 MB): ONE all-reduce of the
+        flat gradient and the full dense optimiser on every rank, instead of reduce-scatter -> sharded optimiser -> all-gather.  The
+        same bytes cross the links, but a step pays one collective's launch + synchronisation latency instead of two -- and at
+        these sizes that latency, not the bytes, is the exchange.  Larger tables keep the sharded step, whose
+        optimiser sweep and state shrink N-fold.  KGE_DP_ALLREDUCE=0/1 overrides."""
+        if not self.distributed:
+            return False
+        if self.switches.get("dp_allreduce") is not None:
+            return self.switches["dp_allreduce"]
+        return sum(p.weight.numel() for p in self.model.parameter_list) * 4 <= self.DP_ALLREDUCE_MAX_BYTES
+
     # ------------------------------------------------------------------ data parallel: exchange only the rows the global batch touched
     # models whose step takes materialised batch ids (kge_sample_batch) and whose gradient is confined to the batch's rows (NTN's
     # dense L2 regulariser touches every row of every table: it keeps the dense exchange)
@@ -1097,6 +1114,19 @@ class Trainer:
             self._mark("optimiser")
             return
         fused, _ = self._collectives()
+        if getattr(self, "_dp_allreduce", False):
+            # small tables: one all-reduce, every rank steps every row (replicas identical: all ranks hold the same reduced buffer)
+            self._mark("compute")
+            if fused:
+                dist.all_reduce(flat.grad, op=dist.ReduceOp.AVG if mean else dist.ReduceOp.SUM, group=self.process_group)
+            else:
+                dist.all_reduce(flat.grad, group=self.process_group)
+                if mean:
+                    flat.grad.div_(self.world_size)
+            self._mark("reduce_scatter")
+            optimise()
+            self._mark("optimiser")
+            return
         self._wait_gather()
         self._mark("compute")
         if fused:

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, model_name, opt, out_dir, sparse=None, tag=""):
+def _run(rank, world, port, model_name, opt, out_dir, sparse=None, tag="", allreduce=None):
     for p in (os.path.dirname(HERE), HERE, os.path.join(os.path.dirname(HERE), "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -44,12 +44,16 @@ def _run(rank, world, port, model_name, opt, out_dir, sparse=None, tag=""):
     tr = Trainer(m, cfg, backend=oracle_backend)
     if sparse is not None:
         tr.switches["dp_sparse"] = sparse
+    if allreduce is not None:
+        tr.switches["dp_allreduce"] = allreduce
     tr.build_model()
     tr.generator = tr._new_generator()
     losses = [tr.train_model_epoch(e) for e in range(2)]
     ranks = tr.evaluator.rank_all(c.test, 8).numpy()
     assert tr._sparse_dp == bool(sparse and world > 1)
-    if tr._sparse_dp:   # sparse exchange: the optimiser (and its state) is replicated, nothing is sharded
+    if world > 1 and not tr._sparse_dp:
+        assert tr._dp_allreduce == (allreduce is not False)     # (default at these table sizes: one all-reduce)
+    if tr._sparse_dp or tr._dp_allreduce:   # the optimiser (and its state) is replicated, nothing is sharded
         assert tr.flat.param_shard.numel() == tr.flat.numel and (tr.flat.state1 is None or tr.flat.state1.numel() == tr.flat.numel)
     else:
         assert tr.flat.numel % (4 * world) == 0 and tr.flat.param_shard.numel() * world == tr.flat.numel
@@ -61,13 +65,16 @@ def _run(rank, world, port, model_name, opt, out_dir, sparse=None, tag=""):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("allreduce", [False, None], ids=["sharded", "allreduce"])
 @pytest.mark.parametrize("model_name,opt", [("transe_l1", "adam"), ("distmult", "adagrad"), ("rotate", "sgd"),
                                             ("complex", "adagrad"), ("rescal", "adam"), ("transh_l2", "rms")])
-def test_two_rank_data_parallel_equals_single_process(tmp_path, model_name, opt):
+def test_two_rank_data_parallel_equals_single_process(tmp_path, model_name, opt, allreduce):
     out = str(tmp_path)
     _run(0, 1, 0, model_name, opt, out)
     port = _free_port()
-    mp.spawn(_run, args=(2, port, model_name, opt, out), nprocs=2, join=True)
+    # sharded = reduce-scatter -> optimiser on the rank's shard -> all-gather (tables beyond 32 MB); the default at these sizes is
+    # one all-reduce with the optimiser replicated (Trainer._dp_allreduce_wanted)
+    mp.spawn(_run, args=(2, port, model_name, opt, out, None, "", allreduce), nprocs=2, join=True)
     one = np.load(os.path.join(out, "r0_w1.npz"))
     a = np.load(os.path.join(out, "r0_w2.npz"))
     b = np.load(os.path.join(out, "r1_w2.npz"))

@@ -90,6 +90,11 @@ def _run_rccl_one_rank(rank, port, case, out_dir):
         os.environ["KGE_GRAPH_MULTI"] = "1"
     if mode == "sparse":       # gradient rows of the batch's entities exchanged as lists, replicated optimiser (Trainer._sparse_exchange)
         os.environ["KGE_DP_SPARSE"] = "1"
+    # tables of this size take ONE all-reduce by default (Trainer._dp_allreduce_wanted); the other cases force the sharded
+    # reduce-scatter / all-gather step that larger tables use
+    allreduce = mode.endswith("allreduce")
+    os.environ["KGE_DP_ALLREDUCE"] = "1" if allreduce else "0"
+    mode = mode.replace("+allreduce", "").replace("allreduce", "eager")
     os.environ["KGE_PULL"] = "1" if mode == "pull" else "0"
     import hip_util
     import kge_oracle as ko
@@ -118,8 +123,8 @@ def _run_rccl_one_rank(rank, port, case, out_dir):
         tr.generator = tr._new_generator()
         if pg is not None:
             assert tr.distributed and tr.world_size == 1 and tr._collectives() == (True, "nccl")
-            assert tr._sparse_dp == (mode == "sparse")
-            assert (tr.flat.grad_shard.data_ptr() != tr.flat.grad.data_ptr()) == (mode != "sparse")
+            assert tr._sparse_dp == (mode == "sparse") and tr._dp_allreduce == allreduce
+            assert (tr.flat.grad_shard.data_ptr() != tr.flat.grad.data_ptr()) == (mode != "sparse" and not allreduce)
             assert tr._graph_wanted(4) == (mode == "graph")
             assert tr._pull_dp_ok() == (mode == "pull")
         losses = [tr.train_model_epoch(e) for e in range(2)]
@@ -144,7 +149,8 @@ def _run_rccl_one_rank(rank, port, case, out_dir):
 @pytest.mark.parametrize("case", [("transe", "adam", "eager"), ("transe", "adam", "graph"), ("transe", "sgd", "pull"),
                                   ("complex", "adagrad", "eager"), ("complex", "adagrad", "graph"),
                                   ("rescal", "adam", "eager"),    # separate sampler launch: it runs under the async all-gather
-                                  ("rescal", "adam", "sparse")],
+                                  ("rescal", "adam", "sparse"),
+                                  ("transe", "adam", "allreduce"), ("transe", "sgd", "pull+allreduce"), ("complex", "adagrad", "allreduce")],
                          ids=lambda c: "-".join(c))
 def test_one_rank_rccl_group_runs_the_collective_step(tmp_path, case):
     out = str(tmp_path)
@@ -152,7 +158,10 @@ def test_one_rank_rccl_group_runs_the_collective_step(tmp_path, case):
     z = np.load(os.path.join(out, "rccl1.npz"))
     assert np.allclose(z["plain_losses"], z["rccl_losses"], rtol=1e-4), (z["plain_losses"], z["rccl_losses"])
     marks = [str(x) for x in z["marks"]]
-    if case[2] == "pull":      # four full batches through the owner-computes gradient step
+    if case[2].endswith("allreduce"):   # one collective per step, no parameter all-gather
+        want = ["begin", "compute", "reduce_scatter", "optimiser"] + (["row_norms"] if "pull" in case[2] else [])
+        assert marks == want * 4, marks
+    elif case[2] == "pull":      # four full batches through the owner-computes gradient step
         assert marks == ["begin", "compute", "reduce_scatter", "optimiser", "all_gather", "row_norms"] * 4, marks
     elif case[2] == "eager":
         assert marks == ["begin", "compute", "reduce_scatter", "optimiser", "all_gather"] * 4, marks

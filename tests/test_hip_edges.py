@@ -149,7 +149,9 @@ def test_bench_two_ranks_owner_computes_gradient():
     assert d["n_gpus"] == 2 and "owner-computes gradient" in d["config"]["step_path"]
     assert d["value"] > 0 and "REPLICAS_IDENTICAL 1" in out.stdout
     ph = d["phases_us"]     # per-phase event times of the data-parallel step (max over ranks)
-    assert all(ph[k] > 0 for k in ("compute", "reduce_scatter", "optimiser", "all_gather", "row_norms")), ph
+    # (6.5 MB of tables: one all-reduce per step -- recorded under `reduce_scatter` -- and no parameter all-gather)
+    assert all(ph[k] > 0 for k in ("compute", "reduce_scatter", "optimiser", "row_norms")) and ph["all_gather"] == 0, ph
+    assert d["collectives"]["per_step"].startswith("all_reduce")
 
 
 def test_bench_two_ranks_share_one_gpu():
@@ -157,7 +159,8 @@ def test_bench_two_ranks_share_one_gpu():
     stream, all-reduce the flat gradient and must end with bit-identical tables; rank 0 prints the one JSON line."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, KGE_BENCH_SHARE_GPU="1", KGE_BENCH_CHECK_REPLICAS="1")
+    # KGE_DP_ALLREDUCE=0: the sharded step larger tables take (reduce-scatter, optimiser on the rank's shard, all-gather)
+    env = dict(os.environ, KGE_BENCH_SHARE_GPU="1", KGE_BENCH_CHECK_REPLICAS="1", KGE_DP_ALLREDUCE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
            "--batch", "4096", "--eval-triples", "256"]
