@@ -407,7 +407,7 @@ def pmc_child_units(batch, eval_triples):
     return units
 
 
-def live_pmc(args, timeout_s=240):
+def live_pmc(args, timeout_s=150):
     """Run the counter child under rocprofv3 once per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass) and return
     {leg: {"fetch_raw_bytes", "write_bytes", "bytes" (2 x fetch + write), "kernels": {...}}} per unit (step / pass), or
     (None, reason).  Everything is best effort: a missing rocprofv3, a timeout or an unreadable result only costs the live figure."""
