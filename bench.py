@@ -541,7 +541,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32768, help="positives per GPU per step (weak scaling)")
-    ap.add_argument("--eval-triples", type=int, default=8192, help="test triples ranked per GPU in the eval leg")
+    ap.add_argument("--eval-triples", type=int, default=N_TEST, help="test triples ranked per GPU in the eval leg (default: the whole FB15k-shape test split, 59 071 = a full_test(); capped at N_TEST // world)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the C2 / C3 / C4 `extra` records (N=1 only)")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 counter passes (use the committed ones)")
