@@ -300,6 +300,21 @@ int kge_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int6
                            const int64_t* head_off, const int32_t* head_ids,
                            void* workspace, size_t workspace_bytes, int32_t* ranks, void* stream);
 
+/* The same two entry points with a TIE report (round 4).  ranks are count-based, rank = #{e : s_e < s_true}: exact whenever no
+ * candidate ties the true one; on exact ties the reference lands somewhere inside the tie group (wherever torch.topk puts it,
+ * utils/evaluator.py:70-123) while this count is the OPTIMISTIC end of it.  ties: int32 [2, n] (row 0 head sweeps, row 1 tail
+ * sweeps) = the number of OTHER candidates whose energy equals the true candidate's bit for bit, counted in the same sweep:
+ * rank <= reference rank <= rank + ties.  0 everywhere for trained distance / dot-product models; large where a scorer saturates
+ * (SimplE's clamp, constant outputs).  -1 = not counted (NTN's sweep).  NULL: the plain entry points. */
+int kge_eval_ranks_ties(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
+                        const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* workspace,
+                        size_t workspace_bytes, int32_t* ranks, int32_t* ties, void* stream);
+int kge_eval_ranks_grouped_ties(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,
+                                const int64_t* group_rel, int64_t n_groups, const int32_t* qblocks, int64_t n_qblocks,
+                                const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
+                                const int32_t* head_ids, void* workspace, size_t workspace_bytes, int32_t* ranks, int32_t* ties,
+                                void* stream);
+
 /* Evaluator.test_tail_rank / test_head_rank score vectors (utils/evaluator.py:249-273) through the sweep
  * kernels: for each of the n triples, scores[2i][e] = energy of (h_i, r_i, e) and scores[2i+1][e] = energy of
  * (e, r_i, t_i) for every entity e.  scores: float [2n, E].  Used by the predict_tail_rank / predict_head_rank

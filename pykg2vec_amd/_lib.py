@@ -189,6 +189,10 @@ _SIGNATURES = {
                                    + [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 3 + [ctypes.c_void_p]),
     "kge_eval_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc), ctypes.c_int64]),
     "kge_eval_ranks": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_eval_ranks_ties": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_eval_ranks_grouped_ties": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+                                    + [ctypes.c_void_p] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_eval_grouped_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc), ctypes.c_int64, ctypes.c_int64]),
     "kge_eval_ranks_grouped": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                               ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]

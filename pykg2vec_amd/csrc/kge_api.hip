@@ -806,16 +806,22 @@ size_t kge_eval_workspace_bytes(const kge_model_desc* m, int64_t n) {
     return eval_workspace_bytes(m, n);
 }
 
-int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
-                   const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* workspace,
-                   size_t workspace_bytes, int32_t* ranks, void* stream) {
+int kge_eval_ranks_ties(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
+                        const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* workspace,
+                        size_t workspace_bytes, int32_t* ranks, int32_t* ties, void* stream) {
     if (validate(m, false, "kge_eval_ranks")) return -1;
     if (n == 0) return 0;
     if (n < 0 || !triples || !ranks) { set_error("kge_eval_ranks: bad arguments"); return -1; }
     if ((tail_off && !tail_ids) || (head_off && !head_ids)) { set_error("kge_eval_ranks: CSR offsets without ids"); return -1; }
     if (int rc = debug_check_triples("kge_eval_ranks", m->tot_entity, m->tot_relation, triples, n, (hipStream_t)stream)) return rc;
-    return launch_eval_ranks(m, triples, n, tail_off, tail_ids, head_off, head_ids, workspace, workspace_bytes, ranks,
+    return launch_eval_ranks(m, triples, n, tail_off, tail_ids, head_off, head_ids, workspace, workspace_bytes, ranks, ties,
                              (hipStream_t)stream);
+}
+
+int kge_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
+                   const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* workspace,
+                   size_t workspace_bytes, int32_t* ranks, void* stream) {
+    return kge_eval_ranks_ties(m, triples, n, tail_off, tail_ids, head_off, head_ids, workspace, workspace_bytes, ranks, nullptr, stream);
 }
 
 size_t kge_eval_grouped_workspace_bytes(const kge_model_desc* m, int64_t n, int64_t n_groups) {
@@ -823,10 +829,11 @@ size_t kge_eval_grouped_workspace_bytes(const kge_model_desc* m, int64_t n, int6
     return eval_workspace_bytes(m, n, n_groups == 1 ? 2 : n_groups);
 }
 
-int kge_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,
-                           const int64_t* group_rel, int64_t n_groups, const int32_t* qblocks, int64_t n_qblocks,
-                           const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
-                           const int32_t* head_ids, void* workspace, size_t workspace_bytes, int32_t* ranks, void* stream) {
+int kge_eval_ranks_grouped_ties(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,
+                                const int64_t* group_rel, int64_t n_groups, const int32_t* qblocks, int64_t n_qblocks,
+                                const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
+                                const int32_t* head_ids, void* workspace, size_t workspace_bytes, int32_t* ranks, int32_t* ties,
+                                void* stream) {
     if (validate(m, false, "kge_eval_ranks_grouped")) return -1;
     if (n == 0) return 0;
     if (n < 0 || !triples || !ranks || !group_of_triple || !group_rel || !qblocks || n_groups < 1 || n_qblocks < 1) {
@@ -836,7 +843,15 @@ int kge_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int6
     if ((tail_off && !tail_ids) || (head_off && !head_ids)) { set_error("kge_eval_ranks_grouped: CSR offsets without ids"); return -1; }
     if (int rc = debug_check_triples("kge_eval_ranks_grouped", m->tot_entity, m->tot_relation, triples, n, (hipStream_t)stream)) return rc;
     return launch_eval_ranks_grouped(m, triples, n, group_of_triple, group_rel, n_groups, qblocks, n_qblocks, tail_off, tail_ids,
-                                     head_off, head_ids, workspace, workspace_bytes, ranks, (hipStream_t)stream);
+                                     head_off, head_ids, workspace, workspace_bytes, ranks, ties, (hipStream_t)stream);
+}
+
+int kge_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,
+                           const int64_t* group_rel, int64_t n_groups, const int32_t* qblocks, int64_t n_qblocks,
+                           const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
+                           const int32_t* head_ids, void* workspace, size_t workspace_bytes, int32_t* ranks, void* stream) {
+    return kge_eval_ranks_grouped_ties(m, triples, n, group_of_triple, group_rel, n_groups, qblocks, n_qblocks, tail_off, tail_ids,
+                                       head_off, head_ids, workspace, workspace_bytes, ranks, nullptr, stream);
 }
 
 int kge_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* workspace,

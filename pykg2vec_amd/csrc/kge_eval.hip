@@ -46,7 +46,7 @@ struct EvalPlan {
     int64_t E, n, tables, table_stride;  // tables > 1: one projected candidate table per relation group (TransR)
     int K, Kpad, QV, form, xform, post;
     int64_t ntiles;
-    float* cand; float* aux; float* qvec; float* qscale; float* st; int32_t* fcount; int32_t* rcount;
+    float* cand; float* aux; float* qvec; float* qscale; float* st; int32_t* fcount; int32_t* rcount; int32_t* tcount;
     float* qT;   // dot-product forms: the queries as k-major 128-wide tiles (matrix-core sweep)
     size_t bytes;
 };
@@ -90,7 +90,8 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p,
     p->qscale = (float*)take((size_t)2 * n * sizeof(float));
     p->st = (float*)take((size_t)2 * n * sizeof(float));
     p->fcount = (int32_t*)take((size_t)2 * n * sizeof(int32_t));
-    p->rcount = (int32_t*)take((size_t)2 * n * sizeof(int32_t));
+    p->rcount = (int32_t*)take((size_t)4 * n * sizeof(int32_t));   // [2n] candidates strictly below the target, then
+    p->tcount = p->rcount ? p->rcount + 2 * n : nullptr;           // [2n] candidates whose energy EQUALS the target's (itself included)
     p->qT = nullptr;
     if ((p->form == F_NEGDOT || p->form == F_SQM) && p->xform == X_NONE)
         p->qT = (float*)take((size_t)((2 * n + 127) / 128) * p->Kpad * 128 * sizeof(float));
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                                                     const float* __restrict__ st,
                                                     int64_t nq, int64_t E, int64_t ntiles, int Kpad, int QV, float margin,
                                                     int S, int qblocks, int32_t* __restrict__ rcount,
-                                                    float* __restrict__ scores_out,
+                                                    int32_t* __restrict__ tcount, float* __restrict__ scores_out,
                                                     const int32_t* __restrict__ qdesc, int64_t table_stride) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -901,6 +902,7 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
     float sthr[QT];
     float qsc[QT];
     int cnt[QT];
+    int tie[QT];     // candidates whose energy equals the target's bit for bit (the target itself is one of them): wave-uniform, like cnt
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
         const int64_t qi = (q0 + q < nq) ? q0 + q : nq - 1;
@@ -908,6 +910,7 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
         sthr[q] = WRITE ? 0.f : st[qi];
         qsc[q] = POST == P_SCALE ? qscale[qi] : 1.0f;
         cnt[q] = 0;
+        tie[q] = 0;
     }
     if constexpr (XFORM == X_NONE) {
         // plain forms: TWO candidate tiles per wave pass -- every scalar query operand feeds two VALU streams
@@ -964,6 +967,7 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                     }
                 } else {
                     cnt[q] += __popcll(__ballot(valid_a && sa < sthr[q])) + __popcll(__ballot(valid_b && sb < sthr[q]));
+                    tie[q] += __popcll(__ballot(valid_a && sa == sthr[q])) + __popcll(__ballot(valid_b && sb == sthr[q]));
                 }
             }
         }
@@ -1035,6 +1039,7 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                 if (valid && q0 + q < nq) scores_out[(q0 + q) * E + e] = s;
             } else {
                 cnt[q] += __popcll(__ballot(valid && s < sthr[q]));
+                tie[q] += __popcll(__ballot(valid && s == sthr[q]));
             }
         }
     }
@@ -1042,8 +1047,10 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
     if constexpr (!WRITE) {
         if (lane == 0) {
 #pragma unroll
-            for (int q = 0; q < QT; ++q)
+            for (int q = 0; q < QT; ++q) {
                 if (q0 + q < nq && cnt[q] != 0) atomicAdd(rcount + q0 + q, cnt[q]);
+                if (tcount && q0 + q < nq && tie[q] != 0) atomicAdd(tcount + q0 + q, tie[q]);
+            }
         }
     }
 }
@@ -1105,7 +1112,7 @@ template <bool WRITE, int POST, bool SQM>
 __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __restrict__ cand, const float* __restrict__ qT,
                                                    const float* __restrict__ st, int64_t nq, int64_t E, int64_t ntiles64,
                                                    int Kpad, int qtiles, int S, int32_t* __restrict__ rcount,
-                                                   float* __restrict__ scores_out, const float* __restrict__ qn,
+                                                   int32_t* __restrict__ tcount, float* __restrict__ scores_out, const float* __restrict__ qn,
                                                    const float* __restrict__ cn, float margin) {
     __shared__ float sA[2][GKS][GLD], sB[2][GKS][GLD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1126,7 +1133,7 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
     const int lk4 = lane >> 4;       // k index of this lane's operands inside a 16x16x4 step
 #endif
     float thr[NB], qn2[NB];
-    int cnt[NB];
+    int cnt[NB], tcnt[NB];
     // query column (inside the workgroup's 128) that column block ni holds for this lane
 #ifdef KGE_GEMM_32X32
     auto qcol = [&](int ni) { return wc * 64 + ni * 32 + li; };
@@ -1137,6 +1144,7 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
     for (int ni = 0; ni < NB; ++ni) {
         const int64_t q = (int64_t)qt * GT + qcol(ni);
         cnt[ni] = 0;
+        tcnt[ni] = 0;
         thr[ni] = (!WRITE && q < nq) ? st[q] : 0.f;
         qn2[ni] = (SQM && q < nq) ? qn[q] : 0.f;
     }
@@ -1238,6 +1246,7 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
                         if (q < nq && e < e_lim) scores_out[q * E + e] = sc;
                     } else {
                         cnt[ni] += (sc < thr[ni] && (full || e < e_lim)) ? 1 : 0;
+                        tcnt[ni] += (sc == thr[ni] && (full || e < e_lim)) ? 1 : 0;
                     }
                 }
             }
@@ -1250,8 +1259,10 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int c2 = cnt[ni] + __shfl_xor(cnt[ni], 32, 64);   // the two lanes that own the same query column
+            const int t2 = tcnt[ni] + __shfl_xor(tcnt[ni], 32, 64);
             const int64_t q = (int64_t)qt * GT + wc * 64 + ni * 32 + li;
             if (lk == 0 && q < nq && c2 != 0) atomicAdd(rcount + q, c2);
+            if (tcount && lk == 0 && q < nq && t2 != 0) atomicAdd(tcount + q, t2);
         }
     }
 }
@@ -1323,6 +1334,7 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
                         if (q < nq && e < e_lim) scores_out[q * E + e] = sc;
                     } else {
                         cnt[ni] += (sc < thr[ni] && (full || e < e_lim)) ? 1 : 0;
+                        tcnt[ni] += (sc == thr[ni] && (full || e < e_lim)) ? 1 : 0;
                     }
                 }
             }
@@ -1336,8 +1348,11 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
         for (int ni = 0; ni < 4; ++ni) {
             int c2 = cnt[ni] + __shfl_xor(cnt[ni], 16, 64);   // the four lanes that own the same query column
             c2 += __shfl_xor(c2, 32, 64);
+            int t2 = tcnt[ni] + __shfl_xor(tcnt[ni], 16, 64);
+            t2 += __shfl_xor(t2, 32, 64);
             const int64_t q = (int64_t)qt * GT + qcol(ni);
             if (lk4 == 0 && q < nq && c2 != 0) atomicAdd(rcount + q, c2);
+            if (tcount && lk4 == 0 && q < nq && t2 != 0) atomicAdd(tcount + q, t2);
         }
     }
 }
@@ -1345,10 +1360,15 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
 
 #endif
 
+// ties (may be NULL): int32 [2, n] = per head sweep / tail sweep the number of OTHER candidates whose energy equals the true one's
 __global__ void k_eval_finalize(const int32_t* __restrict__ rcount, const int32_t* __restrict__ fcount, int64_t n,
-                                int32_t* __restrict__ ranks) {
+                                int32_t* __restrict__ ranks, const int32_t* __restrict__ tcount, int32_t* __restrict__ ties) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (ties) {
+        ties[i] = max(0, tcount[2 * i + 1] - 1);
+        ties[n + i] = max(0, tcount[2 * i] - 1);
+    }
     const int32_t rt = rcount[2 * i], rh = rcount[2 * i + 1];
     ranks[i] = rh;                               // rank_head
     ranks[n + i] = rt;                           // rank_tail
@@ -1460,10 +1480,10 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
                                    p.qvec, p.qscale, triples, p.n, p.Kpad, m->margin, tail_off, tail_ids, head_off, head_ids, p.st,
                                    p.fcount);
                 hipLaunchKernelGGL((k_eval_gemm<false, POST, SQM>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
-                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, nullptr, p.qscale, p.aux, m->margin);
+                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, p.tcount, nullptr, p.qscale, p.aux, m->margin);
             } else {
                 hipLaunchKernelGGL((k_eval_gemm<true, POST, SQM>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
-                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, scores_out, p.qscale, p.aux, m->margin);
+                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, nullptr, scores_out, p.qscale, p.aux, m->margin);
             }
             return;
         }
@@ -1474,18 +1494,18 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
                            p.st, p.fcount, group_of_triple, p.table_stride);
     if (scores_out == nullptr) {
         hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, false, POST>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec,
-                           p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, nullptr,
+                           p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, p.tcount, nullptr,
                            qdesc, p.table_stride);
     } else {
         hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, true, POST>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec,
-                           p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, scores_out,
+                           p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, nullptr, scores_out,
                            qdesc, p.table_stride);
     }
 }
 
 static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
                         const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
-                        size_t ws_bytes, int32_t* ranks, float* scores_out, hipStream_t s) {
+                        size_t ws_bytes, int32_t* ranks, int32_t* ties, float* scores_out, hipStream_t s) {
     EvalPlan p;
     if (!make_plan(m, n, ws, &p)) { set_error("kge_eval: model %d has no sweep form", m->model); return -1; }
     if (ws == nullptr || ws_bytes < p.bytes) {
@@ -1542,7 +1562,7 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     }
 #undef KGE_Q
     }
-    if (scores_out == nullptr) (void)hipMemsetAsync(p.rcount, 0, (size_t)2 * n * sizeof(int32_t), s);
+    if (scores_out == nullptr) (void)hipMemsetAsync(p.rcount, 0, (size_t)4 * n * sizeof(int32_t), s);   // rcount | tcount
 #define KGE_S(F, X) launch_tf_and_sweep<F, X>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s)
     if (p.post == P_SCALE) {
         if (p.form == F_L1) launch_tf_and_sweep<F_L1, X_NONE, P_SCALE>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s);
@@ -1563,16 +1583,18 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     }
 #undef KGE_S
     if (scores_out == nullptr)
-        hipLaunchKernelGGL(k_eval_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.rcount, p.fcount, n, ranks);
+        hipLaunchKernelGGL(k_eval_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.rcount, p.fcount, n, ranks, p.tcount, ties);
     return check_launch("kge_eval pipeline");
 }
 
 int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
                       const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
-                      size_t ws_bytes, int32_t* ranks, hipStream_t s) {
-    if (m->model == KGE_NTN)
+                      size_t ws_bytes, int32_t* ranks, int32_t* ties, hipStream_t s) {
+    if (m->model == KGE_NTN) {   // (the NTN sweep does not count ties: reported as unknown, -1)
+        if (ties) (void)hipMemsetAsync(ties, 0xFF, (size_t)2 * n * sizeof(int32_t), s);
         return launch_ntn_eval_ranks(m, triples, n, tail_off, tail_ids, head_off, head_ids, ws, ws_bytes, ranks, s);
-    return run_pipeline(m, triples, n, tail_off, tail_ids, head_off, head_ids, ws, ws_bytes, ranks, nullptr, s);
+    }
+    return run_pipeline(m, triples, n, tail_off, tail_ids, head_off, head_ids, ws, ws_bytes, ranks, ties, nullptr, s);
 }
 
 // TransR over several relation groups in one pass: one projected candidate table per group, every sweep workgroup
@@ -1580,7 +1602,7 @@ int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n
 int launch_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,
                               const int64_t* group_rel, int64_t n_groups, const int32_t* qblocks, int64_t n_qblocks,
                               const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
-                              const int32_t* head_ids, void* ws, size_t ws_bytes, int32_t* ranks, hipStream_t s) {
+                              const int32_t* head_ids, void* ws, size_t ws_bytes, int32_t* ranks, int32_t* ties, hipStream_t s) {
     if (m->model != KGE_TRANSR && m->model != KGE_TRANSH && m->model != KGE_TRANSD) {
         set_error("kge_eval_ranks_grouped: TransR / TransH / TransD only (the other models' candidates do not depend on the relation)");
         return -1;
@@ -1610,14 +1632,14 @@ int launch_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, i
         else
             hipLaunchKernelGGL((k_eval_queries<KGE_TRANSD>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale);
     }
-    (void)hipMemsetAsync(p.rcount, 0, (size_t)2 * n * sizeof(int32_t), s);
+    (void)hipMemsetAsync(p.rcount, 0, (size_t)4 * n * sizeof(int32_t), s);
     if (p.form == F_L1)
         launch_tf_and_sweep<F_L1, X_NONE>(p, m, triples, tail_off, tail_ids, head_off, head_ids, nullptr, s, group_of_triple,
                                           qblocks, n_qblocks);
     else
         launch_tf_and_sweep<F_L2, X_NONE>(p, m, triples, tail_off, tail_ids, head_off, head_ids, nullptr, s, group_of_triple,
                                           qblocks, n_qblocks);
-    hipLaunchKernelGGL(k_eval_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.rcount, p.fcount, n, ranks);
+    hipLaunchKernelGGL(k_eval_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.rcount, p.fcount, n, ranks, p.tcount, ties);
     return check_launch("kge_eval grouped pipeline");
 }
 
@@ -1625,7 +1647,7 @@ int launch_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, i
 int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
                              float* scores, hipStream_t s) {
     if (m->model == KGE_NTN) return launch_ntn_eval_scores(m, triples, n, ws, ws_bytes, scores, s);
-    return run_pipeline(m, triples, n, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, nullptr, scores, s);
+    return run_pipeline(m, triples, n, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, nullptr, nullptr, scores, s);
 }
 
 }  // namespace kge

@@ -238,10 +238,10 @@ size_t eval_workspace_bytes(const kge_model_desc* m, int64_t n, int64_t tables =
 int launch_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, int64_t n, const int32_t* group_of_triple,
                               const int64_t* group_rel, int64_t n_groups, const int32_t* qblocks, int64_t n_qblocks,
                               const int64_t* tail_off, const int32_t* tail_ids, const int64_t* head_off,
-                              const int32_t* head_ids, void* ws, size_t ws_bytes, int32_t* ranks, hipStream_t s);
+                              const int32_t* head_ids, void* ws, size_t ws_bytes, int32_t* ranks, int32_t* ties, hipStream_t s);
 int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
                       const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
-                      size_t ws_bytes, int32_t* ranks, hipStream_t s);
+                      size_t ws_bytes, int32_t* ranks, int32_t* ties /* [2, n] or NULL */, hipStream_t s);
 int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
                              float* scores, hipStream_t s);
 

@@ -163,6 +163,7 @@ class Evaluator:
         self._groups = {}
         self._known_dev = None
         self.setup_stats = {}
+        self.tie_counts = None     # [2, n] of the last test(): candidates tied with the true entity per head / tail sweep
 
     # --- single-query hooks kept for Trainer.infer_* style callers (evaluator.py:249-273)
     def test_tail_rank(self, h, r, topk=-1):
@@ -331,30 +332,54 @@ class Evaluator:
             self._cache[key] = (trip_dev,) + tuple(csr)
         return self._cache[key], key
 
-    def rank_all(self, data, n):
-        """int32 [4, n] device tensor of ranks for the first n triples of `data`."""
+    def rank_all(self, data, n, return_ties=False):
+        """int32 [4, n] device tensor of ranks for the first n triples of `data`.  return_ties: also an int32 [2, n] tensor (head
+        sweeps, tail sweeps) with the number of OTHER candidates whose energy equals the true entity's bit for bit (the ranks are
+        the optimistic end of such a tie group; -1 = not counted, None with a backend that does not count)."""
         (trip, t_off, t_ids, h_off, h_ids), key = self._device_inputs(data, n)
         if getattr(self.model, "kernel_name", None) == "rescal":
             # the reference's forward renormalises both tables during eval too (pairwise.py:843-844)
             self.K.rescal_normalize(self.model.ent_embeddings.weight.data, self.model.rel_matrices.weight.data,
                                     self.model.hidden_size)
         desc = self.K.model_desc(self.model)
+        count_ties = return_ties and self.K is K
+        new_ties = lambda m: torch.zeros((2, m), dtype=torch.int32, device=trip.device) if count_ties else None
+        kw = lambda t: {"ties": t} if count_ties else {}
         if key in self._groups:
             order, chunks, nd = self._groups[key]
             out = torch.empty((4, len(order)), dtype=torch.int32, device=trip.device)
+            ties = new_ties(len(order))
             dst = torch.from_numpy(order).to(trip.device)
             if nd < len(order):  # rare relations: candidate transform inside the sweep
-                out[:, dst[nd:]] = self.K.eval_ranks(desc, trip[nd:], t_off[nd:], t_ids, h_off[nd:], h_ids)
+                t = new_ties(len(order) - nd)
+                out[:, dst[nd:]] = self.K.eval_ranks(desc, trip[nd:], t_off[nd:], t_ids, h_off[nd:], h_ids, **kw(t))
+                if count_ties:
+                    ties[:, dst[nd:]] = t
             for a, b, got, grel, qb in chunks:  # many relation groups per launch, bounded by candidate-table memory
+                t = new_ties(b - a)
                 out[:, dst[a:b]] = self.K.eval_ranks_grouped(desc, trip[a:b], got, grel, qb, t_off[a:b + 1], t_ids,
-                                                             h_off[a:b + 1], h_ids)
-            return out
-        return self.K.eval_ranks(desc, trip, t_off, t_ids, h_off, h_ids)
+                                                             h_off[a:b + 1], h_ids, **kw(t))
+                if count_ties:
+                    ties[:, dst[a:b]] = t
+            return (out, ties) if return_ties else out
+        ties = new_ties(trip.shape[0])
+        out = self.K.eval_ranks(desc, trip, t_off, t_ids, h_off, h_ids, **kw(ties))
+        return (out, ties) if return_ties else out
 
     def test(self, data, num_of_test, epoch=None):
         mc = self.metric_calculator
         mc.reset()
-        ranks = self.rank_all(data, num_of_test).cpu().numpy()  # the one D2H copy: 4*n int32
+        ranks, ties = self.rank_all(data, num_of_test, return_ties=True)
+        ranks = ranks.cpu().numpy()  # the D2H copy: 4*n int32 (+ 2*n tie counts)
+        self.tie_counts = ties.cpu().numpy() if ties is not None else None
+        if self.tie_counts is not None and (self.tie_counts > 0).any():
+            # ranks are count-based (#candidates strictly below the true one): exact unless candidates TIE it, where the reference
+            # lands somewhere inside the tie group (torch.topk's order) and this count is the optimistic end of it
+            t = self.tie_counts
+            _log("WARNING: %d of %d rank sweeps have candidates whose energy equals the true entity's exactly (up to %d of them): the "
+                 "reported ranks are the optimistic end of each tie group -- rank <= reference rank <= rank + ties; a saturated or "
+                 "collapsed scorer (clamped energies, constant outputs) makes MR / MRR / Hits look better than they are"
+                 % (int((t > 0).sum()), t.size, int(t.max())))
         mc.append_ranks(ranks, epoch)
         mc.settle()
         mc.display_summary()

@@ -574,9 +574,10 @@ def eval_workspace(desc, n, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
-def eval_ranks(desc, triples, tail_off, tail_ids, head_off, head_ids, workspace=None):
+def eval_ranks(desc, triples, tail_off, tail_ids, head_off, head_ids, workspace=None, ties=None):
     """triples int64 [n,3]; CSR filter lists (int64 offsets [n+1], int32 ids) or None.  Returns int32 [4,n]:
-    rank_head, rank_tail, filtered_rank_head, filtered_rank_tail (0-based)."""
+    rank_head, rank_tail, filtered_rank_head, filtered_rank_tail (0-based).  ties: optional int32 [2, n] that receives, per head /
+    tail sweep, the number of other candidates whose energy equals the true one's (kge_eval_ranks_ties)."""
     n = triples.shape[0]
     if workspace is None:
         workspace = eval_workspace(desc, n, triples.device)
@@ -587,13 +588,14 @@ def eval_ranks(desc, triples, tail_off, tail_ids, head_off, head_ids, workspace=
             args += [None, None]
         else:
             args += [_dev(off, torch.int64, "csr offsets"), _dev(ids, torch.int32, "csr ids")]
-    L.check(L.load().kge_eval_ranks(ctypes.byref(desc), _ids(triples, "triples"), n, *args,
-                                    _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
-                                    _dev(ranks, torch.int32, "ranks"), _stream()), "kge_eval_ranks")
+    L.check(L.load().kge_eval_ranks_ties(ctypes.byref(desc), _ids(triples, "triples"), n, *args,
+                                         _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
+                                         _dev(ranks, torch.int32, "ranks"),
+                                         _dev(ties, torch.int32, "ties") if ties is not None else None, _stream()), "kge_eval_ranks")
     return ranks
 
 
-def eval_ranks_grouped(desc, triples, group_of_triple, group_rel, qblocks, tail_off, tail_ids, head_off, head_ids):
+def eval_ranks_grouped(desc, triples, group_of_triple, group_rel, qblocks, tail_off, tail_ids, head_off, head_ids, ties=None):
     """TransR: triples sorted by relation, several relation groups per call (kge_eval_ranks_grouped).  int32 [4,n]."""
     n, G = triples.shape[0], group_rel.shape[0]
     lib = L.load()
@@ -608,11 +610,12 @@ def eval_ranks_grouped(desc, triples, group_of_triple, group_rel, qblocks, tail_
             args += [None, None]
         else:
             args += [_dev(off, torch.int64, "csr offsets"), _dev(ids, torch.int32, "csr ids")]
-    L.check(lib.kge_eval_ranks_grouped(ctypes.byref(desc), _ids(triples, "triples"), n,
-                                       _dev(group_of_triple, torch.int32, "group_of_triple"), _ids(group_rel, "group_rel"), G,
-                                       _dev(qblocks, torch.int32, "qblocks"), qblocks.shape[0], *args,
-                                       _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
-                                       _dev(ranks, torch.int32, "ranks"), _stream()), "kge_eval_ranks_grouped")
+    L.check(lib.kge_eval_ranks_grouped_ties(ctypes.byref(desc), _ids(triples, "triples"), n,
+                                            _dev(group_of_triple, torch.int32, "group_of_triple"), _ids(group_rel, "group_rel"), G,
+                                            _dev(qblocks, torch.int32, "qblocks"), qblocks.shape[0], *args,
+                                            _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
+                                            _dev(ranks, torch.int32, "ranks"),
+                                            _dev(ties, torch.int32, "ties") if ties is not None else None, _stream()), "kge_eval_ranks_grouped")
     return ranks
 
 

@@ -155,7 +155,8 @@ def test_tie_policy_on_clamp_saturated_simple(hip):
     m = hip.model_from_case(c)
     cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test)
     n = len(c.z["eval.rank_head"])
-    ranks = Evaluator(m, cfg).rank_all(c.test, n).cpu().numpy()
+    ranks, tie_counts = Evaluator(m, cfg).rank_all(c.test, n, return_ties=True)
+    ranks, tie_counts = ranks.cpu().numpy(), tie_counts.cpu().numpy()        # tie_counts [2, n]: head sweeps, tail sweeps
     scores = K.eval_sweep_scores(m.make_desc(), hip.dev(c.test[:n])).cpu().numpy()
     ref_sw = c.z["eval.sweeps"]
     sat = np.abs(ref_sw) == 20.0
@@ -168,11 +169,33 @@ def test_tie_policy_on_clamp_saturated_simple(hip):
         for row, true, known, a, b in ((scores[2 * i], t, hr_t[(h, r)], 1, 3), (scores[2 * i + 1], h, tr_h[(t, r)], 0, 2)):
             less, ties, fless, fties = tie_bracket(row, true, known)
             assert (ranks[a, i], ranks[b, i]) == (less, fless)            # count-based, exact function of the GPU scores
+            assert tie_counts[a, i] == ties                                # ... and the sweep reports the size of the tie group
             near = int(np.sum((np.abs(row - row[true]) <= 6e-4) & (row != row[true])))
             assert less - near <= ref[a, i] <= less + ties + near and fless - near <= ref[b, i] <= fless + fties + near, \
                 (i, less, ties, fless, fties, ref[:, i], near)
             ties_total += ties
     assert ties_total > 100
+    # the same counts from the matrix-core sweep and from the VALU sweep (both count while they sweep); Evaluator.test() warns
+    for gemm in (0, 1):
+        K.set_switch("EVAL_GEMM", gemm)
+        try:
+            r2, t2 = Evaluator(m, cfg).rank_all(c.test, n, return_ties=True)
+        finally:
+            K.set_switch("EVAL_GEMM", None)
+        assert np.array_equal(r2.cpu().numpy(), ranks) and np.array_equal(t2.cpu().numpy(), tie_counts), gemm
+    ev = Evaluator(m, cfg)
+    ev.test(c.test, n, epoch=0)
+    assert ev.tie_counts is not None and int(ev.tie_counts.sum()) == int(tie_counts.sum())
+
+
+def test_no_ties_reported_for_an_unsaturated_model(hip):
+    """A distance model with generic weights has no exact ties: the tie report is all zeros (and costs nothing to ask for)."""
+    from pykg2vec_amd.evaluator import Evaluator
+    c = Case("transe_l1")
+    m = hip.model_from_case(c, "adam.final.")
+    cfg = hip.make_config(c.E, c.R, c.hp, c.train, c.valid, c.test)
+    ranks, ties = Evaluator(m, cfg).rank_all(c.test, 8, return_ties=True)
+    assert int(ties.abs().sum()) == 0 and torch.equal(ranks, Evaluator(m, cfg).rank_all(c.test, 8))
 
 
 @pytest.mark.parametrize("name", EVAL_CASES)
