@@ -148,6 +148,11 @@ int launch_ntn_forward(const kge_model_desc* m, const int64_t* h, const int64_t*
                        int64_t n, float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_ntn_backward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,
                         int64_t n, const float* dscore, void* ws, size_t ws_bytes, bool forward_in_ws, hipStream_t s);
+// kge_transr_rows.hip: the pairwise TransR step of large batches (negatives keep their positives' relations) in two launches
+size_t transr_rows_ws_bytes(const kge_model_desc* m, int64_t n);
+bool transr_rows_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes);
+int launch_transr_pair_step(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
+                            const int64_t* nt, int64_t n, float margin, float* loss, void* ws, size_t ws_bytes, hipStream_t s);
 // kge_transr.hip
 size_t transr_workspace_bytes(const kge_model_desc* m, int64_t n);
 int launch_transr_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t,

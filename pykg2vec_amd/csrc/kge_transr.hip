@@ -263,7 +263,12 @@ static size_t transr_lds_bytes(int mode, int de, int dr) {
     return f * sizeof(float) + (size_t)TILE * sizeof(int) + (size_t)2 * TILE * sizeof(long long) + 16;
 }
 
-size_t transr_workspace_bytes(const kge_model_desc* m, int64_t n) { return group_ws_bytes(m->tot_relation, n); }
+// per side (the pairwise step gets two of these): the grouping of the tile kernels, or half of what the two-launch large-batch
+// step keeps between its kernels (kge_transr_rows.hip), whichever is larger
+size_t transr_workspace_bytes(const kge_model_desc* m, int64_t n) {
+    const size_t a = group_ws_bytes(m->tot_relation, n), b = (transr_rows_ws_bytes(m, n) + 1) / 2;
+    return a > b ? a : b;
+}
 
 static int transr_check(const kge_model_desc* m, int64_t n) {
     if (m->dim > TR_MAXD || m->rel_dim > TR_MAXD || m->rel_dim <= 0) {

@@ -405,6 +405,46 @@ def test_rescal_pair_step_in_one_launch_matches_oracle(hip, monkeypatch, k, E, R
         assert np.allclose(a, c, atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("de,dr,E,R,B,l1,margin", [(100, 100, 300, 11, 160, True, 1.0), (50, 50, 300, 3, 333, False, 1.0),
+                                                     (128, 100, 50, 1, 40, False, 2.0), (33, 70, 300, 40, 160, True, 1.0),
+                                                     (100, 100, 3000, 400, 1500, True, 0.5), (64, 64, 300, 11, 160, True, 0.02),
+                                                     (20, 7, 9, 2, 1, True, 1.0), (16, 16, 300, 11, 700, False, 1.0),
+                                                     (70, 33, 40, 3, 70, False, 1.0), (128, 128, 30, 2, 33, True, 1.0),
+                                                     (48, 80, 2000, 5, 3000, True, 1.0), (100, 100, 5000, 700, 9000, False, 1.0)])
+def test_transr_pair_step_rows_matches_oracle(hip, monkeypatch, de, dr, E, R, B, l1, margin):
+    """nr IS pr (one buffer): the large-batch TransR step (csrc/kge_transr_rows.hip: k_transr_rows + k_transr_g, batch-as-M GEMMs on
+    v_mfma_f32_16x16x4_f32), forced on at oracle sizes -- every block-count class, d_e != d_r both ways, partial tiles and waves,
+    relations spanning several runs (atomic G) and single-run ones (plain read-modify-write), margin 0.02 (whole workgroups without
+    gradient).  Against the oracle and against the tile kernels (KGE_TRANSR_ROWS=0) on the same batch."""
+    from pykg2vec_amd.trainer import Trainer
+    rng = np.random.default_rng(de + 7 * dr + B)
+    P = ko.init_params("transr", rng, tot_entity=E, tot_relation=R, ent_hidden_size=de, rel_hidden_size=dr)
+    hp = dict(ent_hidden_size=de, rel_hidden_size=dr, l1_flag=l1, margin=margin, neg_rate=1)
+    pos = np.stack([rng.integers(E, size=B), rng.integers(R, size=B), rng.integers(E, size=B)], 1)
+    flip = rng.random(B) > 0.5
+    rnd = rng.integers(E, size=B)
+    nh = np.where(flip, pos[:, 0], rnd); nt = np.where(flip, rnd, pos[:, 2])
+    batch = (pos[:, 0], pos[:, 1], pos[:, 2], nh, pos[:, 1], nt)
+    loss_ref, G_ref, _, _ = ko.train_step_grads("transr", P, batch, **hp)
+    out = {}
+    for rows in (True, False):
+        monkeypatch.setenv("KGE_TRANSR_ROWS", "1" if rows else "0")
+        m = hip.model_from_params("transr", P, hp, E, R, train=pos)
+        cfg = hip.make_config(E, R, hp, pos, pos[:1], pos[:1])
+        tr = Trainer(m, cfg)
+        tr.build_model()
+        b = [hip.dev(x) for x in batch]
+        loss = tr.train_step_pairwise(b[0], b[1], b[2], b[3], b[1], b[5])
+        assert np.isclose(loss.item(), loss_ref, rtol=5e-5, atol=5e-5), (rows, loss.item(), loss_ref)
+        out[rows] = [g.cpu().numpy().copy() for g in tr.flat.grad_views]
+        names = [n.split(".")[0] for n, _ in hip.table_parameters(m)]
+        for nme, got in zip(names, out[rows]):
+            scale = max(1.0, np.abs(G_ref[nme]).max())
+            assert np.allclose(got, G_ref[nme], atol=5e-5 * scale, rtol=2e-4), (rows, nme, np.abs(got - G_ref[nme]).max())
+    for a, c in zip(out[True], out[False]):
+        assert np.allclose(a, c, atol=5e-5, rtol=2e-4)
+
+
 def test_missing_gpu_tensor_fails_loudly(hip):
     import pykg2vec_amd.pairwise as pw
     from pykg2vec_amd._lib import KgeHipError
