@@ -197,7 +197,7 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
         // nr == pr (one buffer) and a batch large enough to fill the chip with (relation, 32 pairs) workgroups: the two-launch
         // step of kge_transr_rows.hip (KGE_TRANSR_ROWS=0/1 overrides the size rule)
         const int rows_sw = switch_value("TRANSR_ROWS");
-        if (nr == pr && rows_sw != 0 && (rows_sw == 1 || n >= kTransRRowsMinPairs) && transr_rows_ok(m, n, 2 * gws))
+        if (nr == pr && rows_sw != 0 && (rows_sw >= 1 || n >= kTransRRowsMinPairs) && transr_rows_ok(m, n, 2 * gws))
             return launch_transr_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, wsp, 2 * gws, s);
         if ((rc = launch_transr_pair_forward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s))) return rc;
         if ((rc = launch_hinge_coeffs(sp, sn, n, margin, loss, s))) return rc;

@@ -427,8 +427,8 @@ def test_transr_pair_step_rows_matches_oracle(hip, monkeypatch, de, dr, E, R, B,
     batch = (pos[:, 0], pos[:, 1], pos[:, 2], nh, pos[:, 1], nt)
     loss_ref, G_ref, _, _ = ko.train_step_grads("transr", P, batch, **hp)
     out = {}
-    for rows in (True, False):
-        monkeypatch.setenv("KGE_TRANSR_ROWS", "1" if rows else "0")
+    for rows in (1, 2, 0):      # 1: M_r resident in LDS (the default form), 2: slab staging, 0: the tile kernels
+        monkeypatch.setenv("KGE_TRANSR_ROWS", str(rows))
         m = hip.model_from_params("transr", P, hp, E, R, train=pos)
         cfg = hip.make_config(E, R, hp, pos, pos[:1], pos[:1])
         tr = Trainer(m, cfg)
@@ -441,8 +441,9 @@ def test_transr_pair_step_rows_matches_oracle(hip, monkeypatch, de, dr, E, R, B,
         for nme, got in zip(names, out[rows]):
             scale = max(1.0, np.abs(G_ref[nme]).max())
             assert np.allclose(got, G_ref[nme], atol=5e-5 * scale, rtol=2e-4), (rows, nme, np.abs(got - G_ref[nme]).max())
-    for a, c in zip(out[True], out[False]):
-        assert np.allclose(a, c, atol=5e-5, rtol=2e-4)
+    for k in (1, 2):
+        for a, c in zip(out[k], out[0]):
+            assert np.allclose(a, c, atol=5e-5, rtol=2e-4)
 
 
 def test_missing_gpu_tensor_fails_loudly(hip):
