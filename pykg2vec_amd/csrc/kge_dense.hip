@@ -912,54 +912,71 @@ __global__ __launch_bounds__(1024) void k_rescal_pair_gm(const float* __restrict
 // consecutive 16-pair tiles of one relation) as M, the way kge_ntn.hip treats NTN's shared tensor.  A wave owns 8 pairs = one
 // 16-row block (rows 2 p and 2 p + 1: a pair's positive and its negative, so both energies of a pair meet in ONE lane of the
 // accumulator layout and the hinge is a few register operations); its rows' H (then T) operand lives in registers for the whole
-// pass, M_r streams through LDS in 16-deep slabs (transposed while staging for U), v_mfma_f32_16x16x4_f32 with NB accumulator
-// blocks per wave.  Entity gradients leave through float atomics as in k_rescal_pair (the uncorrupted side of a pair: one merged
-// atomic); dL/denergy goes to ds_out for k_rescal_pair_gm.  k <= 16 NB, any k.
-template <int NB>
+// pass (lane (l, lk) holds k = 16 kb + 4 lk + kk: 16 consecutive bytes of the row per slab), M_r streams through LDS in 16-deep
+// slabs (transposed while staging for U), v_mfma_f32_16x16x4_f32 with NB accumulator blocks per wave.  Entity gradients leave
+// through float atomics as in k_rescal_pair (the uncorrupted side of a pair: one merged atomic); dL/denergy goes to ds_out for the
+// relation-matrix gradient's launch.  k <= 16 NB, any k; VEC: k % 4 == 0 and a 16-byte aligned table.
+// Round 4: every global load sits on a clamped (always valid) address and is masked by a select where it is USED -- the first form
+// had its 507 loads inside 824 divergent branches, each join an s_waitcnt vmcnt(0) -- and blocks are numbered so that the live
+// (even) tiles of a relation are consecutive block ids (kge_mfma_blocks.h: strided_tile).
+template <int NB, bool VEC>
 __global__ __launch_bounds__(256, 2) void k_rescal_rows(const float* __restrict__ ent, const float* __restrict__ relm,
                                                         float* __restrict__ g_ent, const int64_t* __restrict__ ph,
                                                         const int64_t* __restrict__ pt, const int64_t* __restrict__ nh,
                                                         const int64_t* __restrict__ nt, const int* __restrict__ offsets,
                                                         const int* __restrict__ tile_off, const int* __restrict__ tile_rel,
                                                         const int* __restrict__ perm, int R, int k, float margin, float* __restrict__ loss,
-                                                        unsigned* __restrict__ touched, float* __restrict__ ds_out) {
+                                                        unsigned* __restrict__ touched, float* __restrict__ ds_out, int tiles) {
     constexpr int DP = 16 * NB, PITCH = DP + 4, NK = 4 * NB;
     __shared__ __attribute__((aligned(16))) float sW[2][16][PITCH];
     int rel, tin;
-    if (!locate_tile(tile_off, tile_rel, R, blockIdx.x, rel, tin)) return;
+    const int tile = strided_tile<2>(tiles);
+    if (tile >= tiles || !locate_tile(tile_off, tile_rel, R, tile, rel, tin)) return;
     if (tin & 1) return;                       // (the workgroup of an even tile takes the odd one after it as well)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 15, lk = lane >> 4;
     const int g_lo = offsets[rel] + tin * kPairTile, g_hi = min(offsets[rel + 1], g_lo + 2 * kPairTile);
     // A-operand row of this lane: row l of the wave = pair 8 wave + l / 2, side l & 1
-    int a_h, a_t;
-    bool a_on;
-    {
-        const int gp = g_lo + 8 * wave + (l >> 1);
-        a_on = gp < g_hi;
-        const int pair = a_on ? perm[gp] : 0;
-        a_h = a_on ? (int)((l & 1) ? nh[pair] : ph[pair]) : 0;
-        a_t = a_on ? (int)((l & 1) ? nt[pair] : pt[pair]) : 0;
-    }
+    const int a_g = g_lo + 8 * wave + (l >> 1);
+    const bool a_on = a_g < g_hi;
+    const int a_pair = perm[min(a_g, g_hi - 1)];
     // accumulator rows of this lane: 4 lk + q = pairs 2 lk (q = 0 positive, 1 negative) and 2 lk + 1 (q = 2, 3)
-    int c_h[4], c_t[4], c_pair[2];
+    int c_pair[2];
     bool c_on[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int gp = g_lo + 8 * wave + 2 * lk + j;
         c_on[j] = gp < g_hi;
-        c_pair[j] = c_on[j] ? perm[gp] : 0;
-        c_h[2 * j] = c_on[j] ? (int)ph[c_pair[j]] : 0; c_h[2 * j + 1] = c_on[j] ? (int)nh[c_pair[j]] : 0;
-        c_t[2 * j] = c_on[j] ? (int)pt[c_pair[j]] : 0; c_t[2 * j + 1] = c_on[j] ? (int)nt[c_pair[j]] : 0;
+        c_pair[j] = perm[min(gp, g_hi - 1)];
+    }
+    const int a_h = (int)((l & 1) ? nh[a_pair] : ph[a_pair]), a_t = (int)((l & 1) ? nt[a_pair] : pt[a_pair]);
+    int c_h[4], c_t[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        c_h[2 * j] = (int)ph[c_pair[j]]; c_h[2 * j + 1] = (int)nh[c_pair[j]];
+        c_t[2 * j] = (int)pt[c_pair[j]]; c_t[2 * j + 1] = (int)nt[c_pair[j]];
     }
     float a[NK];
-    unroll_seq([&](auto ksc) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ksc)::value;
-        const int kk = 4 * ks + lk;
-        a[ks] = (a_on && kk < k) ? ent[(int64_t)a_h * k + kk] : 0.f;
-    }, std::make_integer_sequence<int, NK>{});
-    f32x4v acc[NB];
+    auto load_a = [&](int id) __attribute__((always_inline)) {   // element 4 kb + kk = k index 16 kb + 4 lk + kk of the row
+        const float* __restrict__ row = ent + (int64_t)id * k;
+        if constexpr (VEC) {
+            unroll_seq([&](auto kbc) __attribute__((always_inline)) {
+                constexpr int kb = decltype(kbc)::value;
+                const float4 v = *reinterpret_cast<const float4*>(row + min(16 * kb + 4 * lk, k - 4));
+                a[4 * kb] = v.x; a[4 * kb + 1] = v.y; a[4 * kb + 2] = v.z; a[4 * kb + 3] = v.w;
+            }, std::make_integer_sequence<int, NB>{});
+        } else {
+            unroll_seq([&](auto ksc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(ksc)::value;
+                a[ks] = row[min(16 * (ks >> 2) + 4 * lk + (ks & 3), k - 1)];
+            }, std::make_integer_sequence<int, NK>{});
+        }
+    };
+    auto mask_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < NK; ++ks) a[ks] = (a_on && 16 * (ks >> 2) + 4 * lk + (ks & 3) < k) ? a[ks] : 0.f;
+    };
+    load_a(a_h);
+    f32x4v acc[NB];
     const float* __restrict__ M = relm + (int64_t)rel * k * k;
     float st[NB];
     int buf = 0;
@@ -967,24 +984,29 @@ __global__ __launch_bounds__(256, 2) void k_rescal_rows(const float* __restrict_
     auto pass = [&](auto tr_tag) __attribute__((always_inline)) {
         constexpr bool TR = decltype(tr_tag)::value;
         const int kq = TR ? (threadIdx.x & 15) : (threadIdx.x >> 4), c0 = TR ? (threadIdx.x >> 4) : (threadIdx.x & 15);
-        const int toff = TR ? c0 * k + kq : kq * k + c0;
-        auto fetch = [&](int kb) __attribute__((always_inline)) {
-            const float* __restrict__ Ms = M + (TR ? 16 * kb : 16 * kb * k);
+        auto fetch = [&](int kb) __attribute__((always_inline)) {   // raw values off clamped addresses; masked at the LDS store
+            const int kr = min(16 * kb + kq, k - 1);
 #pragma unroll
-            for (int u = 0; u < NB; ++u) st[u] = (16 * kb + kq < k && c0 + 16 * u < k) ? Ms[toff + (TR ? 16 * u * k : 16 * u)] : 0.f;
+            for (int u = 0; u < NB; ++u) {
+                const int c = min(c0 + 16 * u, k - 1);
+                st[u] = TR ? M[(int64_t)c * k + kr] : M[(int64_t)kr * k + c];
+            }
         };
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
         fetch(0);
         unroll_seq([&](auto kbc) __attribute__((always_inline)) {
             constexpr int kb = decltype(kbc)::value;
 #pragma unroll
-            for (int u = 0; u < NB; ++u) sW[buf][kq][BlkMapNat<NB>::pos(u, c0)] = st[u];   // (natural accumulator columns: coalesced atomics)
+            for (int u = 0; u < NB; ++u)   // (natural accumulator columns: coalesced atomics)
+                sW[buf][kq][BlkMapNat<NB>::pos(u, c0)] = (16 * kb + kq < k && c0 + 16 * u < k) ? st[u] : 0.f;
             __syncthreads();   // slab kb is in LDS; everybody finished reading the buffer that is written next
             if (kb + 1 < NB) fetch(kb + 1);
             float b[2][NB];
-            read_blocks<NB>(&sW[buf][lk][0], l, b[0]);
+            read_blocks<NB>(&sW[buf][4 * lk][0], l, b[0]);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                if (kk + 1 < 4) read_blocks<NB>(&sW[buf][4 * (kk + 1) + lk][0], l, b[(kk + 1) & 1]);
+                if (kk + 1 < 4) read_blocks<NB>(&sW[buf][4 * lk + kk + 1][0], l, b[(kk + 1) & 1]);
                 KGE_KEEP_READS_AHEAD();
 #pragma unroll
                 for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * kb + kk], b[kk & 1][cb], acc[cb], 0, 0, 0);
@@ -992,30 +1014,32 @@ __global__ __launch_bounds__(256, 2) void k_rescal_rows(const float* __restrict_
             buf ^= 1;
         }, std::make_integer_sequence<int, NB>{});
     };
+    mask_a();
     pass(std::false_type{});
     // ---- energies -s = -<V, T>, margin hinge of the lane's two pairs (as k_hinge_coeffs).  The T elements the accumulators meet are
     // fetched in accumulator layout only now: 4 NB registers that are not live during the MFMA passes (three waves per SIMD)
     float tq[NB][4];
     unroll_seq([&](auto cbc) __attribute__((always_inline)) {
         constexpr int cb = decltype(cbc)::value;
-        const int col = 16 * cb + l;
+        const int col = min(16 * cb + l, k - 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tq[cb][q] = (c_on[q >> 1] && col < k) ? ent[(int64_t)c_t[q] * k + col] : 0.f;
+        for (int q = 0; q < 4; ++q) tq[cb][q] = ent[(int64_t)c_t[q] * k + col];
     }, std::make_integer_sequence<int, NB>{});
     float p[4] = {0.f, 0.f, 0.f, 0.f};
     unroll_seq([&](auto cbc) __attribute__((always_inline)) {
         constexpr int cb = decltype(cbc)::value;
+        const bool in = 16 * cb + l < k;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) p[q] = fmaf(acc[cb][q], tq[cb][q], p[q]);
+        for (int q = 0; q < 4; ++q) p[q] = fmaf(acc[cb][q], (in && c_on[q >> 1]) ? tq[cb][q] : 0.f, p[q]);
     }, std::make_integer_sequence<int, NB>{});
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { p[q] += __shfl_xor(p[q], 1, 64); p[q] += __shfl_xor(p[q], 2, 64); p[q] += __shfl_xor(p[q], 4, 64); p[q] += __shfl_xor(p[q], 8, 64); }
+    for (int q = 0; q < 4; ++q) p[q] = gsum<16>(p[q]);
     float c[2], hl = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const float v = (-p[2 * j]) + margin - (-p[2 * j + 1]);
         c[j] = c_on[j] ? (v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f)) : 0.f;
-        if (c_on[j]) hl += fmaxf(v, 0.f);
+        hl += c_on[j] ? fmaxf(v, 0.f) : 0.f;
         if (l == 0 && c_on[j]) ds_out[c_pair[j]] = c[j];
     }
     {
@@ -1033,31 +1057,26 @@ __global__ __launch_bounds__(256, 2) void k_rescal_rows(const float* __restrict_
     }
     // rows of a pair leave as grad = -ds x: positive row -c x_pos, negative row +c x_neg; the same entity on both sides: one atomic
     auto scatter = [&](const int (&ids)[4]) __attribute__((always_inline)) {
-        unroll_seq([&](auto cbc) __attribute__((always_inline)) {
-            constexpr int cb = decltype(cbc)::value;
-            const int col = 16 * cb + l;
-            if (col < k) {
-                const float x0 = acc[cb][0], x1 = acc[cb][1], x2 = acc[cb][2], x3 = acc[cb][3];
-                if (c[0] != 0.f) {
-                    if (ids[0] == ids[1]) unsafeAtomicAdd(g_ent + (int64_t)ids[0] * k + col, -c[0] * (x0 - x1));
-                    else { unsafeAtomicAdd(g_ent + (int64_t)ids[0] * k + col, -c[0] * x0); unsafeAtomicAdd(g_ent + (int64_t)ids[1] * k + col, c[0] * x1); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (c[j] == 0.f) continue;
+            const bool same = ids[2 * j] == ids[2 * j + 1];
+            float* __restrict__ op = g_ent + (int64_t)ids[2 * j] * k + l;
+            float* __restrict__ on = g_ent + (int64_t)ids[2 * j + 1] * k + l;
+            unroll_seq([&](auto cbc) __attribute__((always_inline)) {
+                constexpr int cb = decltype(cbc)::value;
+                if (16 * cb + l < k) {
+                    const float xp = acc[cb][2 * j], xn = acc[cb][2 * j + 1];
+                    unsafeAtomicAdd(op + 16 * cb, same ? -c[j] * (xp - xn) : -c[j] * xp);
+                    if (!same) unsafeAtomicAdd(on + 16 * cb, c[j] * xn);
                 }
-                if (c[1] != 0.f) {
-                    if (ids[2] == ids[3]) unsafeAtomicAdd(g_ent + (int64_t)ids[2] * k + col, -c[1] * (x2 - x3));
-                    else { unsafeAtomicAdd(g_ent + (int64_t)ids[2] * k + col, -c[1] * x2); unsafeAtomicAdd(g_ent + (int64_t)ids[3] * k + col, c[1] * x3); }
-                }
-            }
-        }, std::make_integer_sequence<int, NB>{});
+            }, std::make_integer_sequence<int, NB>{});
+        }
     };
+    load_a(a_t);                               // (the U pass's A operand: requested under the atomics of the V pass)
     scatter(c_t);                              // grad_t = -ds V
     // ---- U = T M^T, grad_h = -ds U
-    unroll_seq([&](auto ksc) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ksc)::value;
-        const int kk = 4 * ks + lk;
-        a[ks] = (a_on && kk < k) ? ent[(int64_t)a_t * k + kk] : 0.f;
-    }, std::make_integer_sequence<int, NK>{});
-#pragma unroll
-    for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    mask_a();
     pass(std::true_type{});
     scatter(c_h);
 }
@@ -1174,10 +1193,181 @@ __global__ __launch_bounds__(256, 2) void k_rescal_g(const float* __restrict__ e
     }
 }
 
+// k_rescal_g, second form (k % 4 == 0, 16-byte aligned table): the same GEMM with rows fetched as 16-byte pieces (a thread: NVA
+// pieces of its row's head vector and NVB of the tail vector's column half per slab), a ring of D slabs in flight in registers, and
+// no load inside a branch: within an iteration every load depends only on values loaded in EARLIER iterations (pair of slab
+// sl + D + 2, then coefficient + ids of slab sl + D + 1, then the rows of slab sl + D), all on clamped addresses, masked where they
+// are stored to LDS.  The first form's 164 loads sat in 172 branches with 120 s_waitcnt vmcnt(0): one exposed round trip per slab
+// for the id chain and one for the rows.  Blocks are numbered so that the runs of a relation are consecutive block ids (strided_tile).
+template <int NBI, int NBJ, int D>
+__global__ __launch_bounds__(256, 2) void k_rescal_g2(const float* __restrict__ ent, float* __restrict__ g_rel,
+                                                      const int64_t* __restrict__ ph, const int64_t* __restrict__ pt,
+                                                      const int64_t* __restrict__ nh, const int64_t* __restrict__ nt,
+                                                      const int* __restrict__ offsets, const int* __restrict__ tile_off,
+                                                      const int* __restrict__ tile_rel, const int* __restrict__ perm, int R, int k,
+                                                      const float* __restrict__ ds, int tiles) {
+    constexpr int DPI = 16 * NBI, DPJ = 16 * NBJ, PA = DPI + 4, PB = DPJ + 4;
+    constexpr int RBW = (NBI + 3) / 4;   // row blocks per wave
+    constexpr int NVA = (NBI + 3) / 4, NVB = (NBJ + 3) / 4;   // 16-byte pieces per thread (16 threads per row: pieces f, f + 16, ...)
+    __shared__ __attribute__((aligned(16))) float sA[2][16][PA], sB[2][16][PB];
+    const int jbase = blockIdx.y * DPJ;   // the workgroup's half of the output columns
+    int rel, tin;
+    const int tile = strided_tile<kGRun>(tiles);
+    if (tile >= tiles || !locate_tile(tile_off, tile_rel, R, tile, rel, tin)) return;
+    if (tin % kGRun) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 15, lk = lane >> 4;
+    const int r0 = offsets[rel], r1 = offsets[rel + 1];
+    const int g_lo = r0 + tin * kPairTile, g_hi = min(r1, g_lo + kGRun * kPairTile);
+    const bool shared_rel = (r1 - r0) > kGRun * kPairTile;
+    const int nslab = (g_hi - g_lo + 7) / 8;   // 8 pairs = 16 rows per slab
+    f32x4v acc[RBW][NBJ];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NBJ; ++cb) acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // staging roles: slab row kq = tid / 16 = pair kq / 2, side kq & 1; pieces f + 16 v of the row
+    const int kq = threadIdx.x >> 4, f = threadIdx.x & 15;
+    const bool neg = kq & 1;
+    const int64_t* __restrict__ hcol = neg ? nh : ph;
+    const int64_t* __restrict__ tcol = neg ? nt : pt;
+    float4 ra[D][NVA], rb_[D][NVB];
+    float rs[D];
+    auto resolve1 = [&](int sl) __attribute__((always_inline)) -> int { return perm[min(g_lo + 8 * sl + (kq >> 1), g_hi - 1)]; };
+    auto fetch = [&](auto slot, int64_t idh, int64_t idt, float coef) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot)::value;
+        rs[S] = coef;
+        const float* __restrict__ hr = ent + idh * k;
+        const float* __restrict__ tr = ent + idt * k + jbase;
+#pragma unroll
+        for (int v = 0; v < NVA; ++v) ra[S][v] = *reinterpret_cast<const float4*>(hr + min(4 * (f + 16 * v), k - 4));
+#pragma unroll
+        for (int v = 0; v < NVB; ++v) rb_[S][v] = *reinterpret_cast<const float4*>(tr + min(4 * (f + 16 * v), k - 4 - jbase));
+    };
+    auto coef_of = [&](int sl, float c) __attribute__((always_inline)) -> float {
+        return g_lo + 8 * sl + (kq >> 1) < g_hi ? (neg ? -c : c) : 0.f;
+    };
+    // prologue: the chains of the first D slabs side by side, ids of slab D, pair of slab D + 1
+    int p_pair[D + 2];
+    int64_t p_h[D + 1], p_t[D + 1];
+    float p_c[D + 1];
+#pragma unroll
+    for (int s2 = 0; s2 <= D + 1; ++s2) p_pair[s2] = resolve1(s2);
+#pragma unroll
+    for (int s2 = 0; s2 <= D; ++s2) { p_c[s2] = ds[p_pair[s2]]; p_h[s2] = hcol[p_pair[s2]]; p_t[s2] = tcol[p_pair[s2]]; }
+    unroll_seq([&](auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        fetch(sc, p_h[S], p_t[S], coef_of(S, p_c[S]));
+    }, std::make_integer_sequence<int, D>{});
+    int64_t n_h = p_h[D], n_t = p_t[D];      // slab sl + D: ids and coefficient known
+    float n_c = p_c[D];
+    int m_pair = p_pair[D + 1];              // slab sl + D + 1: pair known
+    int buf = 0;
+    auto step = [&](auto slot, int sl) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot)::value;
+        const float sc = rs[S];
+#pragma unroll
+        for (int v = 0; v < NVA; ++v) {
+            const int c = 4 * (f + 16 * v);
+            if (c < DPI) {
+                const float w = c < k ? sc : 0.f;
+                *reinterpret_cast<float4*>(&sA[buf][kq][c]) = float4{ra[S][v].x * w, ra[S][v].y * w, ra[S][v].z * w, ra[S][v].w * w};
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NVB; ++v) {
+            const int c = 4 * (f + 16 * v);
+            if (c < DPJ) {
+                const bool lb = sc != 0.f && jbase + c < k;
+                const int u = c >> 4, c0 = c & 15;   // columns c .. c + 3 of block u: positions 4 apart
+                sB[buf][kq][BlkMapNat<NBJ>::pos(u, c0)] = lb ? rb_[S][v].x : 0.f;
+                sB[buf][kq][BlkMapNat<NBJ>::pos(u, c0 + 1)] = lb ? rb_[S][v].y : 0.f;
+                sB[buf][kq][BlkMapNat<NBJ>::pos(u, c0 + 2)] = lb ? rb_[S][v].z : 0.f;
+                sB[buf][kq][BlkMapNat<NBJ>::pos(u, c0 + 3)] = lb ? rb_[S][v].w : 0.f;
+            }
+        }
+        __syncthreads();
+        {
+            const float c1 = ds[m_pair];
+            const int64_t h1 = hcol[m_pair], t1 = tcol[m_pair];
+            const int pair2 = resolve1(sl + D + 2);
+            fetch(slot, n_h, n_t, coef_of(sl + D, n_c));   // rows of slab sl + D into the registers just emptied (past the run: dead)
+            n_h = h1; n_t = t1; n_c = c1;
+            m_pair = pair2;
+        }
+        float b[2][NBJ], av[2][RBW];
+        auto operands = [&](int kk, int s2) __attribute__((always_inline)) {
+            read_blocks<NBJ>(&sB[buf][4 * kk + lk][0], l, b[s2]);
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) av[s2][rb] = wave + 4 * rb < NBI ? sA[buf][4 * kk + lk][16 * (wave + 4 * rb) + l] : 0.f;
+        };
+        operands(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk + 1 < 4) operands(kk + 1, (kk + 1) & 1);
+            KGE_KEEP_READS_AHEAD();
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) {
+                if (wave + 4 * rb < NBI) {   // wave-uniform
+#pragma unroll
+                    for (int cb = 0; cb < NBJ; ++cb)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk & 1][rb], b[kk & 1][cb], acc[rb][cb], 0, 0, 0);
+                }
+            }
+        }
+        buf ^= 1;
+    };
+    int sl = 0;
+    for (; sl + D <= nslab; sl += D)   // whole groups of D steps without a branch between them: the memory counter waits stay partial
+        unroll_seq([&](auto sc) __attribute__((always_inline)) { step(sc, sl + decltype(sc)::value); }, std::make_integer_sequence<int, D>{});
+    unroll_seq([&](auto sc) __attribute__((always_inline)) {
+        if (sl + decltype(sc)::value < nslab) step(sc, sl + decltype(sc)::value);   // workgroup-uniform
+    }, std::make_integer_sequence<int, D>{});
+    float* __restrict__ gM = g_rel + (int64_t)rel * k * k;
+    if (!shared_rel) {   // sole writer: the old values of a row block are requested together, on clamped addresses, before the first store
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) {
+            float old[NBJ][4];
+#pragma unroll
+            for (int cb = 0; cb < NBJ; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = min(16 * (wave + 4 * rb) + 4 * lk + q, k - 1), j = min(jbase + 16 * cb + l, k - 1);
+                    old[cb][q] = gM[(int64_t)i * k + j];
+                }
+#pragma unroll
+            for (int cb = 0; cb < NBJ; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rb][cb][q] = old[cb][q] - acc[rb][cb][q];
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+        if (wave + 4 * rb >= NBI) continue;
+#pragma unroll
+        for (int cb = 0; cb < NBJ; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * (wave + 4 * rb) + 4 * lk + q, j = jbase + 16 * cb + l;
+                const float v = acc[rb][cb][q];
+                if (i < k && j < k) {
+                    float* o = gM + (int64_t)i * k + j;
+                    if (shared_rel) { if (v != 0.f) unsafeAtomicAdd(o, -v); } else *o = v;
+                }
+            }
+    }
+}
+
 template <int NBI>
 static void launch_rescal_g(const kge_model_desc* m, const int64_t* ph, const int64_t* pt, const int64_t* nh, const int64_t* nt,
                             const GroupWs& g, unsigned tiles, int R, int k, const float* ds, hipStream_t s) {
     constexpr int JA = (NBI + 1) / 2;   // column blocks per half (an odd NBI leaves one masked block in the second half)
+    const bool vec = (k & 3) == 0 && (reinterpret_cast<uintptr_t>(m->tables[0]) & 15) == 0 && k >= 16 * JA + 4;
+    if (vec && switch_value("RESCAL_G2") != 0) {   // (KGE_RESCAL_G2=0: the dword-gather form, A/B)
+        const unsigned grid = (tiles + kGRun - 1) / kGRun * kGRun;
+        hipLaunchKernelGGL((k_rescal_g2<NBI, JA, (NBI > 8 ? 2 : 3)>), dim3(grid, NBI > 1 ? 2 : 1), dim3(256), 0, s, m->tables[0], m->grads[1], ph, pt, nh, nt,
+                           g.offsets, g.tile_off, g.tile_rel, g.perm, R, k, ds, (int)tiles);
+        return;
+    }
     hipLaunchKernelGGL((k_rescal_g<NBI, JA>), dim3(tiles, NBI > 1 ? 2 : 1), dim3(256), 0, s, m->tables[0], m->grads[1], ph, pt, nh, nt,
                        g.offsets, g.tile_off, g.tile_rel, g.perm, R, k, ds);
 }
@@ -1221,14 +1411,21 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
     const bool rows = ds != nullptr && k <= 208 && switch_value("RESCAL_ROWS") != 0;
     if (rows) {
         const int nb = (k + 15) / 16;
-#define KGE_RR(J) case J: hipLaunchKernelGGL(k_rescal_rows<J>, dim3(tiles), dim3(256), 0, s, m->tables[0], m->tables[1], m->grads[0], ph, pt, nh, \
-                                             nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched, ds); break;
+        const bool vec = (k & 3) == 0 && ((reinterpret_cast<uintptr_t>(m->tables[0])) & 15) == 0;
+        const unsigned grid2 = (tiles + 1) / 2 * 2;
+#define KGE_RR(J) case J: if (vec) hipLaunchKernelGGL((k_rescal_rows<J, true>), dim3(grid2), dim3(256), 0, s, m->tables[0], m->tables[1], m->grads[0], ph, pt, nh, \
+                                             nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched, ds, (int)tiles); \
+                  else hipLaunchKernelGGL((k_rescal_rows<J, false>), dim3(grid2), dim3(256), 0, s, m->tables[0], m->tables[1], m->grads[0], ph, pt, nh, \
+                                             nt, g.offsets, g.tile_off, g.tile_rel, g.perm, (int)R, k, margin, loss, touched, ds, (int)tiles); break;
         switch (nb) { KGE_RR(1) KGE_RR(2) KGE_RR(3) KGE_RR(4) KGE_RR(5) KGE_RR(6) KGE_RR(7) KGE_RR(8) KGE_RR(9) KGE_RR(10) KGE_RR(11) KGE_RR(12) KGE_RR(13) }
 #undef KGE_RR
     }
     const int g_sw = switch_value("RESCAL_G");
     // the relation-matrix gradient as a GEMM over gathered rows (k_rescal_g) where relations span several 128-pair runs
-    const bool gemm_g = rows && (g_sw >= 0 ? g_sw == 1 : n >= 128 * R);
+    // (the 16-byte-gather form k_rescal_g2 wins at every relation count measured -- FB15k shape, 24 pairs per relation: 345 -> 175 us
+    // against k_rescal_pair_gm; the dword form only where relations span several runs)
+    const bool g2_ok = (k & 3) == 0 && (reinterpret_cast<uintptr_t>(m->tables[0]) & 15) == 0 && switch_value("RESCAL_G2") != 0;
+    const bool gemm_g = rows && (g_sw >= 0 ? g_sw == 1 : (g2_ok || n >= 128 * R));
 #define KGE_RP(VK_)                                                                                                              \
     {                                                                                                                            \
         if (!rows)                                                                                                               \

@@ -56,4 +56,14 @@ static_assert(blk_maps_agree<1>() && blk_maps_agree<2>() && blk_maps_agree<3>() 
 template <class F, int... I>
 __device__ __forceinline__ void unroll_seq(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 
+// Only every S-th tile of a relation starts a workgroup's work (S = 2: pairs of tiles; S = run length); launched in tile order the
+// live workgroups of a relation would all sit on block ids that are S apart, i.e. on 8 / gcd(S, 8) of the 8 XCDs (blocks go to
+// XCDs round robin) -- with S = 8 a whole relation on ONE XCD.  Blocks are therefore numbered class by class: block v works on tile
+// (v mod Q) S + v / Q, Q = ceil(tiles / S), so that the live tiles of a relation are CONSECUTIVE block ids.  The grid has Q S blocks.
+template <int S>
+__device__ __forceinline__ int strided_tile(int tiles) {
+    const int Q = (tiles + S - 1) / S;
+    return ((int)blockIdx.x % Q) * S + (int)blockIdx.x / Q;
+}
+
 }  // namespace kge

@@ -42,15 +42,6 @@ struct TransRRowsArgs {
     float* gws;    // [4 n][dr]  grouped pair g: GA of the positive, GA of the negative, GC of the positive, GC of the negative
 };
 
-// Only every S-th tile of a relation starts a workgroup's work (S = 2: pairs of tiles; S = run length); launched in tile order the
-// live workgroups of a relation would all sit on block ids that are S apart, i.e. on 8 / gcd(S, 8) of the 8 XCDs (blocks go to
-// XCDs round robin) -- with S = 8 a whole relation on ONE XCD.  Blocks are therefore numbered class by class: block v works on tile
-// (v mod Q) S + v / Q, Q = ceil(tiles / S), so that the live tiles of a relation are CONSECUTIVE block ids.  The grid has Q S blocks.
-template <int S>
-__device__ __forceinline__ int strided_tile(int tiles) {
-    const int Q = (tiles + S - 1) / S;
-    return ((int)blockIdx.x % Q) * S + (int)blockIdx.x / Q;
-}
 __device__ __forceinline__ float grp16_sum(float v) { return gsum<16>(v); }   // DPP steps inside a 16-lane row: no LDS crossbar
 
 // k_transr_rows: M_r is RESIDENT in LDS for the workgroup's lifetime (d_e x d_r floats: 40 KB at 100 / 100, two workgroups per CU), so
