@@ -85,8 +85,8 @@ const char* kge_last_error(void);
  * kge_triple_set_build, kge_pull_index_build (all listed batches: which covers the owner-computes runs built on that index),
  * kge_eval_ranks / _grouped / kge_eval_sweep_scores, kge_rank_from_scores. */
 int kge_set_debug(int32_t check_ids);
-/* A/B switches of the dispatch rules: RESCAL_UNFUSED, RESCAL_ROWS, RESCAL_G, EVAL_GEMM, HEAD_TILE, NTN_BIG,
- * OPT_NT, PULL_G, ROTATE_SPLIT.  value >= 0 forces it, -1 hands the decision back to the environment variable KGE_<name> (an
+/* A/B switches of the dispatch rules: RESCAL_UNFUSED, RESCAL_ROWS, RESCAL_G, RESCAL_G2, TRANSR_ROWS, TRANSR_G,
+ * EVAL_GEMM, HEAD_TILE, NTN_BIG, OPT_NT, PULL_G, ROTATE_SPLIT.  value >= 0 forces it, -1 hands the decision back to the environment variable KGE_<name> (an
  * integer; "0" off, "1" on) or, if that is unset, to the built-in rule.  Same meaning on both sides of the boundary. */
 int kge_set_switch(const char* name, int32_t value);
 int kge_get_debug(void);
@@ -113,6 +113,8 @@ int kge_debug_marker(int32_t tag, void* stream);
 
 /* Scratch bytes the score / train entry points need for a call on n rows (n pairs for the pairwise step).
  * 0 for the gather-type models; RESCAL and TransR group the batch by relation on the device (about 5R + n + n/32 ints per side),
+ * TransR's large-batch pairwise step (negatives that keep their positives' relations: nr == pr, from 1 024 pairs on) keeps
+ * 2n*(rel_dim + 1) floats per side between its two launches (dL/d(h^ M), dL/d(t^ M) and the rows' inverse norms),
  * NTN keeps n*(4d + 3k_r + 6) floats of intermediates per side; the hinge step adds 2n floats. */
 size_t kge_workspace_bytes(const kge_model_desc* m, int64_t n);
 

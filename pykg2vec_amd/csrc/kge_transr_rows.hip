@@ -38,7 +38,6 @@ struct TransRRowsArgs {
     float* loss;
     float* invs;   // [4 n]  grouped pair g: 1 / max(|row|, eps) of (pos h, neg h, pos t, neg t); 0 = the pair has no gradient
     int tiles;     // tiles of the grouping (the grid is rounded up to a multiple of the kernel's tile stride)
-    int dbg;       // timing experiments only (KGE_TRANSR_DBG bit mask: parts compiled out at run time, results wrong)
     float* gws;    // [4 n][dr]  grouped pair g: GA of the positive, GA of the negative, GC of the positive, GC of the negative
 };
 
@@ -396,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void k_transr_rows(TransRRowsArgs A) {
             }
         }
     };
-    if (wave_live && !(A.dbg & 1)) {
+    if (wave_live) {
         scatter(acc0, c_h, 0);
         scatter(acc1, c_t, 1);
     }
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_transr_g(TransRRowsArgs A) {
     const int r0 = A.offsets[rel], r1 = A.offsets[rel + 1];
     const int g_lo = r0 + tin * kTrPairTile, g_hi = min(r1, g_lo + kTrGRun * kTrPairTile);
     const bool shared_rel = (r1 - r0) > kTrGRun * kTrPairTile;
-    const int nslab = (A.dbg & 32) ? 0 : (g_hi - g_lo + 3) / 4;   // 4 pairs = 16 rows per slab
+    const int nslab = (g_hi - g_lo + 3) / 4;   // 4 pairs = 16 rows per slab
     f32x4v acc[RBW][NBJ];
 #pragma unroll
     for (int rb = 0; rb < RBW; ++rb)
@@ -509,7 +508,6 @@ __global__ __launch_bounds__(256, 2) void k_transr_g(TransRRowsArgs A) {
         buf ^= 1;
     }
     float* __restrict__ gM = A.g_mat + (int64_t)rel * de * dr;
-    if (A.dbg & 16) return;
     if (!shared_rel) {   // sole writer of these elements: the old values are requested together, on clamped addresses, before the first store
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) {
@@ -563,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void k_transr_g2(TransRRowsArgs A) {
     const int r0 = A.offsets[rel], r1 = A.offsets[rel + 1];
     const int g_lo = r0 + tin * kTrPairTile, g_hi = min(r1, g_lo + kTrGRun * kTrPairTile);
     const bool shared_rel = (r1 - r0) > kTrGRun * kTrPairTile;
-    const int nslab = (A.dbg & 32) ? 0 : (g_hi - g_lo + 3) / 4;   // 4 pairs = 16 rows per slab
+    const int nslab = (g_hi - g_lo + 3) / 4;   // 4 pairs = 16 rows per slab
     f32x4v acc[RBW][NB];
 #pragma unroll
     for (int rb = 0; rb < RBW; ++rb)
@@ -670,7 +668,6 @@ __global__ __launch_bounds__(256, 2) void k_transr_g2(TransRRowsArgs A) {
         if (sl + decltype(sc)::value < nslab) step(sc, sl + decltype(sc)::value);   // workgroup-uniform
     }, std::make_integer_sequence<int, D>{});
     float* __restrict__ gM = A.g_mat + (int64_t)rel * de * dr;
-    if (A.dbg & 16) return;
     if (!shared_rel) {   // sole writer of these elements: the old values of a row block are requested together, on clamped addresses
 #pragma unroll      //   (a load inside a divergent branch would be waited for one by one), before the first store
         for (int rb = 0; rb < RBW; ++rb) {
@@ -753,7 +750,6 @@ int launch_transr_pair_step(const kge_model_desc* m, const int64_t* ph, const in
     a.offsets = g.offsets; a.tile_off = g.tile_off; a.tile_rel = g.tile_rel; a.perm = g.perm;
     a.R = (int)R; a.de = m->dim; a.dr = m->rel_dim; a.l1 = (m->flags & KGE_FLAG_L1) ? 1 : 0;
     a.margin = margin; a.loss = loss;
-    a.dbg = switch_value("TRANSR_DBG") > 0 ? switch_value("TRANSR_DBG") : 0;
     a.invs = (float*)((char*)ws + gi);
     a.gws = a.invs + 4 * n;
     const unsigned tiles = (unsigned)(n / kTrPairTile + R + 1);

@@ -1,6 +1,8 @@
 """Dev tool: randomised A/B of the large-batch forms of the relation-matrix models against the tile kernels they replace, on one
 MI355X: NTN (KGE_NTN_BIG=0/1, random d, k_r <= 128, batch) and RESCAL (KGE_RESCAL_ROWS / KGE_RESCAL_G = 0/1, random even k <= 208,
-relations, >= 8 192 pairs).  Same batch, same tables: loss and every gradient table must agree within fp32 summation-order noise."""
+relations, >= 8 192 pairs; the 16-byte-gather form of the relation-matrix gradient on and off: KGE_RESCAL_G2) and TransR
+(KGE_TRANSR_ROWS = 0/1, KGE_TRANSR_G = 0/1, random d_e, d_r <= 128, L1 / L2, any batch).  Same batch, same tables: loss and every
+gradient table must agree within fp32 summation-order noise."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
@@ -25,21 +27,46 @@ def step(model, P, hp, E, R, pos, batch, env, share_nr=False):
     return loss, [g.cpu().numpy().copy() for g in tr.flat.grad_views]
 
 
-def compare(tag, info, ref, got):
-    global bad
+flips = 0
+
+
+def compare(tag, info, ref, got, l1=False):
+    """l1: the gradient of |x| is discontinuous at 0 -- a residual element that two summation orders put on either side of 0 moves the
+    gradient rows of ONE pair (<= 3 entity rows, 1 relation row, 1 matrix) by O(1) with the loss unchanged: counted, not a failure."""
+    global bad, flips
     ok = np.isclose(ref[0], got[0], rtol=2e-5, atol=1e-4)
-    worst = 0.0
+    worst, rows_off = 0.0, []
     for a, b in zip(ref[1], got[1]):
         scale = max(1.0, float(np.abs(a).max()))
-        worst = max(worst, float(np.abs(a - b).max()) / scale)
+        err = np.abs(a - b) / scale
+        worst = max(worst, float(err.max()))
+        rows_off.append(int((err.reshape(err.shape[0], -1).max(axis=1) > 2e-4).sum()))
     if not ok or worst > 2e-4:
+        if ok and l1 and len(rows_off) == 3 and rows_off[0] <= 6 and rows_off[1] <= 2 and rows_off[2] <= 2:
+            flips += 1
+            print("sign flip", tag, info, "rows off (ent, rel, mat)", rows_off, "grad err", worst, flush=True)
+            return
         bad += 1
-        print("FAIL", tag, info, "loss", ref[0], got[0], "grad err", worst, flush=True)
+        print("FAIL", tag, info, "loss", ref[0], got[0], "grad err", worst, "rows off", rows_off, flush=True)
 
 
 for it in range(N):
     try:
-        if it % 2 == 0:
+        if it % 3 == 2:
+            de, dr = int(rng.integers(1, 129)), int(rng.integers(2, 129))   # (d_r = 1: a normalised scalar is +-1, its gradient 0 * 1 / |x|: noise)
+            if rng.random() < 0.5:
+                de, dr = max(4, de // 4 * 4), max(4, dr // 4 * 4)      # the 16-byte forms
+            E, R, B = int(rng.integers(20, 3000)), int(rng.integers(1, 300)), int(rng.integers(1, 6000))
+            hp = dict(ent_hidden_size=de, rel_hidden_size=dr, l1_flag=bool(rng.random() < 0.5), margin=float(rng.choice([0.02, 0.5, 1.0, 2.0])))
+            P = ko.init_params("transr", rng, tot_entity=E, tot_relation=R, ent_hidden_size=de, rel_hidden_size=dr)
+            pos = np.stack([rng.integers(E, size=B), rng.integers(R, size=B), rng.integers(E, size=B)], 1)
+            flip = rng.random(B) > 0.5; rnd = rng.integers(E, size=B)
+            batch = (pos[:, 0], pos[:, 1], pos[:, 2], np.where(flip, pos[:, 0], rnd), pos[:, 1].copy(), np.where(flip, rnd, pos[:, 2]))
+            ref = step("transr", P, hp, E, R, pos, batch, {"KGE_TRANSR_ROWS": "0"}, share_nr=True)
+            for g_ in ("0", "1"):
+                got = step("transr", P, hp, E, R, pos, batch, {"KGE_TRANSR_ROWS": "1", "KGE_TRANSR_G": g_}, share_nr=True)
+                compare("transr g=" + g_, dict(de=de, dr=dr, E=E, R=R, B=B, l1=hp["l1_flag"], margin=hp["margin"]), ref, got, l1=hp["l1_flag"])
+        elif it % 3 == 0:
             d, kr = int(rng.integers(2, 129)), int(rng.integers(1, 129))
             E, R, B = int(rng.integers(20, 500)), int(rng.integers(1, 20)), int(rng.integers(40, 900))
             hp = dict(ent_hidden_size=d, rel_hidden_size=kr, lmbda=1e-3, margin=float(rng.uniform(0.5, 3)))
@@ -59,11 +86,11 @@ for it in range(N):
             flip = rng.random(B) > 0.5; rnd = rng.integers(E, size=B)
             batch = (pos[:, 0], pos[:, 1], pos[:, 2], np.where(flip, pos[:, 0], rnd), pos[:, 1].copy(), np.where(flip, rnd, pos[:, 2]))
             ref = step("rescal", P, hp, E, R, pos, batch, {"KGE_RESCAL_ROWS": "0", "KGE_RESCAL_G": "0"}, share_nr=True)
-            for g_ in ("0", "1"):
-                got = step("rescal", P, hp, E, R, pos, batch, {"KGE_RESCAL_ROWS": "1", "KGE_RESCAL_G": g_}, share_nr=True)
-                compare("rescal g=" + g_, dict(k=k, E=E, R=R, B=B, margin=hp["margin"]), ref, got)
+            for g_, g2_ in (("0", "1"), ("1", "1"), ("1", "0")):
+                got = step("rescal", P, hp, E, R, pos, batch, {"KGE_RESCAL_ROWS": "1", "KGE_RESCAL_G": g_, "KGE_RESCAL_G2": g2_}, share_nr=True)
+                compare("rescal g=%s g2=%s" % (g_, g2_), dict(k=k, E=E, R=R, B=B, margin=hp["margin"]), ref, got)
     except Exception as ex:  # noqa
         bad += 1
         print("ERROR", it, repr(ex)[:300], flush=True)
-print("fuzz done: %d cases, %d bad" % (N, bad))
+print("fuzz done: %d cases, %d bad, %d L1 sign flips (see compare)" % (N, bad, flips))
 sys.exit(1 if bad else 0)
