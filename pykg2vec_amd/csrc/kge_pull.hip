@@ -154,38 +154,57 @@ struct PullRows {
 // same arithmetic in the same order as a visit of k_pull_step -- and leaves a record: the hinge coefficient, and the signed
 // direction of both residuals (L1: two bits per element; L2: the residual rows and their norms).  No sampling here: the draw was
 // registered by the sampler riding in the previous step's launch.
+// kEvalPP pairs per lane group, their descriptors and then their four rows requested together (independent chains): half the
+// workgroups -- 2 048 at B = 32 768, ONE residency round of 8 x 256 workgroups instead of two -- and half the workgroup launches
+// (per-workgroup timestamps: the dispatcher needs 1.8 us to start 2 048 workgroups; profiles/r04_experiments.md section 7).
+constexpr int kEvalPP = 2;
 template <bool L1, int G, int NV>
 __global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restrict__ loss) {
-    constexpr int GPB = kBlock / G;
+    constexpr int GPB = kBlock / G, PP = kEvalPP;
     const int gl = threadIdx.x % G;
-    const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
     float acc = 0.f;
-    if (i < a.n_pairs) {
-        const int4 p = a.pairs[i];
-        const int w = a.lists.pc[i];
-        const bool tail = ((w >> 24) & 1) != 0;
-        const char* __restrict__ hat_e = reinterpret_cast<const char*>(a.hat_in[0]);
-        const char* __restrict__ hat_r = reinterpret_cast<const char*>(a.hat_in[1]);
-        constexpr unsigned kRowBytes = 16u * G * NV;
-        const unsigned lane_off = 16u * gl;
-        const unsigned oh = (unsigned)p.x * kRowBytes + lane_off, orr = (unsigned)p.y * kRowBytes + lane_off;
-        const unsigned ot = (unsigned)p.z * kRowBytes + lane_off, oc = (unsigned)(w & 0xFFFFFF) * kRowBytes + lane_off;
-        float4 hh[NV], rr[NV], tt[NV], cc[NV];
+    const char* __restrict__ hat_e = reinterpret_cast<const char*>(a.hat_in[0]);
+    const char* __restrict__ hat_r = reinterpret_cast<const char*>(a.hat_in[1]);
+    constexpr unsigned kRowBytes = 16u * G * NV;
+    const unsigned lane_off = 16u * gl;
+    int64_t idx[PP];
+    bool on[PP];
+    int4 p[PP];
+    int w[PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q) {   // (clamped: the loads stay unconditional, a dead pair is masked at its stores)
+        idx[q] = ((int64_t)blockIdx.x * PP + q) * GPB + threadIdx.x / G;
+        on[q] = idx[q] < a.n_pairs;
+        const int64_t ic = on[q] ? idx[q] : a.n_pairs - 1;
+        p[q] = a.pairs[ic];
+        w[q] = a.lists.pc[ic];
+    }
+    float4 hh[PP][NV], rr[PP][NV], tt[PP][NV], cc[PP][NV];
+    float th[PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q) {
+        const unsigned oh = (unsigned)p[q].x * kRowBytes + lane_off, orr = (unsigned)p[q].y * kRowBytes + lane_off;
+        const unsigned ot = (unsigned)p[q].z * kRowBytes + lane_off, oc = (unsigned)(w[q] & 0xFFFFFF) * kRowBytes + lane_off;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            hh[v] = *reinterpret_cast<const float4*>(hat_e + (oh + 16u * G * v));
-            rr[v] = *reinterpret_cast<const float4*>(hat_r + (orr + 16u * G * v));
-            tt[v] = *reinterpret_cast<const float4*>(hat_e + (ot + 16u * G * v));
-            cc[v] = *reinterpret_cast<const float4*>(hat_e + (oc + 16u * G * v));
+            hh[q][v] = *reinterpret_cast<const float4*>(hat_e + (oh + 16u * G * v));
+            rr[q][v] = *reinterpret_cast<const float4*>(hat_r + (orr + 16u * G * v));
+            tt[q][v] = *reinterpret_cast<const float4*>(hat_e + (ot + 16u * G * v));
+            cc[q][v] = *reinterpret_cast<const float4*>(hat_e + (oc + 16u * G * v));
         }
-        const float th = a.theta ? a.theta[p.y] : 1.0f;
+        th[q] = a.theta ? a.theta[p[q].y] : 1.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < PP; ++q) {
+        const int64_t i = idx[q];
+        const bool tail = ((w[q] >> 24) & 1) != 0;
         float4 up[NV], un[NV];
         float sp = 0.f, sn = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
 #define KGE_FWD(c)                                                                                            \
-            up[v].c = hh[v].c + rr[v].c - tt[v].c;                                                            \
-            un[v].c = (tail ? hh[v].c : cc[v].c) + rr[v].c - (tail ? cc[v].c : tt[v].c);                      \
+            up[v].c = hh[q][v].c + rr[q][v].c - tt[q][v].c;                                                   \
+            un[v].c = (tail ? hh[q][v].c : cc[q][v].c) + rr[q][v].c - (tail ? cc[q][v].c : tt[q][v].c);       \
             sp = L1 ? sp + fabsf(up[v].c) : fmaf(up[v].c, up[v].c, sp);                                       \
             sn = L1 ? sn + fabsf(un[v].c) : fmaf(un[v].c, un[v].c, sn);
             KGE_FWD(x) KGE_FWD(y) KGE_FWD(z) KGE_FWD(w)
@@ -193,9 +212,10 @@ __global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restr
         }
         gsum2<G>(sp, sn);
         if constexpr (!L1) { sp = sqrtf(sp); sn = sqrtf(sn); }
-        const float vv = th * sp + a.margin - th * sn;
-        acc = fmaxf(vv, 0.f);
-        const float coef = (vv > 0.f ? 1.f : (vv == 0.f ? 0.5f : 0.f)) * th;
+        const float vv = th[q] * sp + a.margin - th[q] * sn;
+        if (!on[q]) continue;   // (group-uniform)
+        acc += fmaxf(vv, 0.f);
+        const float coef = (vv > 0.f ? 1.f : (vv == 0.f ? 0.5f : 0.f)) * th[q];
         if (gl == 0) a.recs[i] = make_float4(tail ? -coef : coef, sp, sn, 0.f);   // (coef >= 0: its sign carries `tail`)
         if (coef != 0.f) {
             if constexpr (L1) {
@@ -235,13 +255,13 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
     const int gl = threadIdx.x % G;
     const int gbase = (threadIdx.x & 63) / G * G;   // first lane of this group inside its wave
     const int d = a.d, nvec = a.d >> 2;
-    const int64_t item = (int64_t)((int)blockIdx.x - a.sample_blocks) * GPB + threadIdx.x / G;
     // partial sums of rows cut into 2..GPB items: their owners sit in consecutive groups of this workgroup
     __shared__ float4 s_part[GPB][NV * G];
     // visit descriptors (h, r, t, c | tail << 24 | role << 25) of each owner group, in visit order: one broadcast
     // ds_read_b128 per visit instead of four cross-lane shuffles
     __shared__ int4 s_desc[GPB][G];
     float acc = 0.f;
+    const int64_t item = (int64_t)((int)blockIdx.x - a.sample_blocks) * GPB + threadIdx.x / G;
     int4 it = make_int4(-1, 0, 0, 0);
     if (item < a.n_items) it = a.items[item];
     else if (a.dense_skip != nullptr && item - a.n_items < a.n_rows) {   // implicit part: a row without static incidences
@@ -627,7 +647,7 @@ static int launch_pull_geo(PullArgs& a, const PullSampleArgs& sa, float* loss, h
     const int item_blocks = (int)((a.n_items + (a.dense_skip ? a.n_rows : 0) + GPB - 1) / GPB);
     a.sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
     if (a.recs) {   // two-phase form: evaluate every pair once, then let the owners sum the records
-        const unsigned eb = (unsigned)((a.n_pairs + GPB - 1) / GPB);
+        const unsigned eb = (unsigned)((a.n_pairs + GPB * kEvalPP - 1) / (GPB * kEvalPP));
         if (a.l1) {
             hipLaunchKernelGGL((k_pull_eval<true, G, NV>), dim3(eb), dim3(kBlock), 0, s, a, loss);
             hipLaunchKernelGGL((k_pull_step<OPT, true, G, NV, true>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);

@@ -1300,7 +1300,8 @@ class Trainer:
     def _new_generator(self):
         gen = Generator(self.model, self.config, rank=self.rank, world_size=self.world_size, backend=self.K)
         if self.K is K and not self.distributed and self.model.kernel_name in ("transe", "transm") and self._pull_two_phase():
-            gen.pull_segment = 32    # two-phase step: a visit is a few bytes, so an item carries a whole row's incidences (32 / item)
+            # two-phase step: a visit is a few bytes, so an item carries as many incidences as its lane group is wide (32; 16 with KGE_PULL_G=16)
+            gen.pull_segment = min(32, 256 // max(1, self.K.pull_groups_per_block(self.model.hidden_size)))
         return gen
 
     # ------------------------------------------------------------------ checkpoints (reference format, utils/trainer.py:388-419)
