@@ -720,8 +720,10 @@ static void launch_transr_rows_nb(const TransRRowsArgs& a, unsigned tiles, hipSt
                      ((reinterpret_cast<uintptr_t>(a.ent) | reinterpret_cast<uintptr_t>(a.mat) | reinterpret_cast<uintptr_t>(a.gws)) & 15) == 0;
     const size_t lds = transr_rows2_lds_bytes(NB, a.de);
     const bool l1 = a.l1 != 0;
+    static bool attr_set[4] = {false, false, false, false};   // (per block-count instantiation: once per (VEC, L1) kernel)
     auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        bool& done = attr_set[(vec ? 2 : 0) + (l1 ? 1 : 0)];
+        if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); done = true; }
         hipLaunchKernelGGL(kern, dim3((tiles + 1) / 2 * 2), dim3(256), lds, s, a);
     };
     if (vec) { if (l1) go(k_transr_rows<NB, true, true>); else go(k_transr_rows<NB, true, false>); }
