@@ -222,13 +222,14 @@ __global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restr
                 unsigned char* cp = reinterpret_cast<unsigned char*>(a.codes) + i * (int64_t)(2 * G * NV);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    // the sign k_pull_step uses: clamp(x * 2^100, -1, 1); code 0 = zero, 1 = positive, 2 = negative
+                    // the sign k_pull_step uses: clamp(x * 2^100, -1, 1); code 0 = zero, 1 = positive, 3 = negative: the two bits ARE the
+                    // sign as a two's-complement number (the owner decodes with one v_bfe_i32 + one v_cvt_f32_i32 per element)
                     unsigned bp = 0, bn = 0;
 #define KGE_CODE(c, sh)                                                                                       \
                     { const float s1 = __builtin_amdgcn_fmed3f(up[v].c * 0x1p100f, -1.f, 1.f);                 \
                       const float s2 = __builtin_amdgcn_fmed3f(un[v].c * 0x1p100f, -1.f, 1.f);                 \
-                      bp |= (s1 > 0.f ? 1u : (s1 < 0.f ? 2u : 0u)) << sh;                                      \
-                      bn |= (s2 > 0.f ? 1u : (s2 < 0.f ? 2u : 0u)) << sh; }
+                      bp |= (s1 > 0.f ? 1u : (s1 < 0.f ? 3u : 0u)) << sh;                                      \
+                      bn |= (s2 > 0.f ? 1u : (s2 < 0.f ? 3u : 0u)) << sh; }
                     KGE_CODE(x, 0) KGE_CODE(y, 2) KGE_CODE(z, 4) KGE_CODE(w, 6)
 #undef KGE_CODE
                     cp[v * G + gl] = (unsigned char)bp;
@@ -304,18 +305,44 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
             const int* __restrict__ vis = reinterpret_cast<const int*>(s_desc[threadIdx.x / G]);
             using RecT = typename std::conditional<L1, float, float4>::type;   // L1 needs only the signed coefficient
             auto rec_x = [](const RecT& r) { if constexpr (L1) return r; else return r.x; };
+            // The owner kernel is VALU-bound (SQ_ACTIVE_INST_VALU: 0.75 of its SIMD cycles, ~1 000 VALU instructions per wave, most of
+            // them in the visits), so a visit is kept short: the own row's coefficients in up / un come out of two 16-bit tables of
+            // 2-bit two's-complement entries indexed by (role, tail), the direction codes decode with one v_bfe_i32 each, and TransE
+            // (theta == NULL: every coefficient is 1 or 1/2) sums in INTEGER half units -- v_mad_i32_i24 instead of v_cvt + v_fma;
+            // those float sums were exact, so the result is bit-identical (profiles/r04_experiments.md section 7).
+            //   su: H +1, T -1, R +1, C 0;   sv: H (tail ? -1 : 0), T (tail ? 0 : +1), R -1, C (tail ? +1 : -1);   index 2 role + tail
+            const bool unit = L1 && a.theta == nullptr;   // kernel-uniform
+            int4 gi[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) gi[v] = make_int4(0, 0, 0, 0);
             auto visit_dir = [&](int e, const RecT rec, const auto& cpv, const auto& cnv) {
                 const int role = e & 3;
-                const bool tail = __float_as_uint(rec_x(rec)) >> 31;
+                const unsigned rbits = __float_as_uint(rec_x(rec));
                 const float coef = fabsf(rec_x(rec));
                 if (coef == 0.f) return;
-                float su = role == kRoleT ? -coef : (role == kRoleC ? 0.f : coef);
-                float sv = role == kRoleR ? -coef : (role == kRoleH ? (tail ? -coef : 0.f) : role == kRoleT ? (tail ? 0.f : coef) : (tail ? coef : -coef));
+                const unsigned sh2 = (unsigned)(((role << 1) | (int)(rbits >> 31)) << 1);
+                const int lu = __builtin_amdgcn_sbfe(0x05F5, sh2, 2u), lv = __builtin_amdgcn_sbfe(0x7F1C, sh2, 2u);
+                float su = (float)lu * coef, sv = (float)lv * coef;
                 if constexpr (L1) {
+                    if (unit) {
+                        const int c2 = coef == 1.f ? 2 : 1;
+                        const int iu = __mul24(lu, c2), iv = __mul24(lv, c2);
+#pragma unroll
+                        for (int v2 = 0; v2 < NV; ++v2) {
+                            const int bp = (int)cpv[v2], bn = (int)cnv[v2];
+#define KGE_DECI(b, sh) (((int)((unsigned)(b) << (30 - (sh)))) >> 30)
+                            gi[v2].x += __mul24(iv, KGE_DECI(bn, 0)) + __mul24(iu, KGE_DECI(bp, 0));
+                            gi[v2].y += __mul24(iv, KGE_DECI(bn, 2)) + __mul24(iu, KGE_DECI(bp, 2));
+                            gi[v2].z += __mul24(iv, KGE_DECI(bn, 4)) + __mul24(iu, KGE_DECI(bp, 4));
+                            gi[v2].w += __mul24(iv, KGE_DECI(bn, 6)) + __mul24(iu, KGE_DECI(bp, 6));
+#undef KGE_DECI
+                        }
+                        return;
+                    }
 #pragma unroll
                     for (int v2 = 0; v2 < NV; ++v2) {
                         const unsigned bp = cpv[v2], bn = cnv[v2];
-#define KGE_DEC(b, sh) ((((b) >> (sh)) & 3u) == 1u ? 1.f : ((((b) >> (sh)) & 3u) == 2u ? -1.f : 0.f))
+#define KGE_DEC(b, sh) ((float)(((int)((b) << (30 - (sh)))) >> 30))   /* 2-bit two's complement: 01 -> +1, 11 -> -1, 00 -> 0 */
                         gs[v2].x = fmaf(sv, KGE_DEC(bn, 0), fmaf(su, KGE_DEC(bp, 0), gs[v2].x));
                         gs[v2].y = fmaf(sv, KGE_DEC(bn, 2), fmaf(su, KGE_DEC(bp, 2), gs[v2].y));
                         gs[v2].z = fmaf(sv, KGE_DEC(bn, 4), fmaf(su, KGE_DEC(bp, 4), gs[v2].z));
@@ -384,6 +411,12 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                     else rb = a.recs[best];
                     visit_dir((best << 2) | kRoleC, rb, c1, c2);
                     last = best;
+                }
+            }
+            if (unit) {   // integer half units -> float (exact)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    gs[v].x = (float)gi[v].x * 0.5f; gs[v].y = (float)gi[v].y * 0.5f; gs[v].z = (float)gi[v].z * 0.5f; gs[v].w = (float)gi[v].w * 0.5f;
                 }
             }
         } else {
