@@ -64,6 +64,13 @@ struct PullArgs {
 
 #define KGE_F4_EACH(expr_x, expr_y, expr_z, expr_w) expr_x; expr_y; expr_z; expr_w;
 
+// a * b + c on 24-bit signed operands as ONE VALU instruction (the compiler turns __mul24(a, b) + c into v_mul_i32_i24 + v_add3_u32)
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // gradient wrt the NORMALISED own row, summed over incidences -> normalisation backward -> optimiser -> new row, its
 // normalised copy and its norm
 template <int OPT, int G, int NV, bool PRE = false>
@@ -329,12 +336,12 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                         const int iu = __mul24(lu, c2), iv = __mul24(lv, c2);
 #pragma unroll
                         for (int v2 = 0; v2 < NV; ++v2) {
-                            const int bp = (int)cpv[v2], bn = (int)cnv[v2];
+                            const unsigned bp = cpv[v2], bn = cnv[v2];
 #define KGE_DECI(b, sh) (((int)((unsigned)(b) << (30 - (sh)))) >> 30)
-                            gi[v2].x += __mul24(iv, KGE_DECI(bn, 0)) + __mul24(iu, KGE_DECI(bp, 0));
-                            gi[v2].y += __mul24(iv, KGE_DECI(bn, 2)) + __mul24(iu, KGE_DECI(bp, 2));
-                            gi[v2].z += __mul24(iv, KGE_DECI(bn, 4)) + __mul24(iu, KGE_DECI(bp, 4));
-                            gi[v2].w += __mul24(iv, KGE_DECI(bn, 6)) + __mul24(iu, KGE_DECI(bp, 6));
+                            gi[v2].x = mad_i24(iv, KGE_DECI(bn, 0), mad_i24(iu, KGE_DECI(bp, 0), gi[v2].x));
+                            gi[v2].y = mad_i24(iv, KGE_DECI(bn, 2), mad_i24(iu, KGE_DECI(bp, 2), gi[v2].y));
+                            gi[v2].z = mad_i24(iv, KGE_DECI(bn, 4), mad_i24(iu, KGE_DECI(bp, 4), gi[v2].z));
+                            gi[v2].w = mad_i24(iv, KGE_DECI(bn, 6), mad_i24(iu, KGE_DECI(bp, 6), gi[v2].w));
 #undef KGE_DECI
                         }
                         return;
@@ -364,9 +371,12 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
             using CodeT = typename std::conditional<L1, unsigned, float4>::type;
             auto load_codes = [&](int pair, CodeT (&cpv)[NV], CodeT (&cnv)[NV]) {
                 if constexpr (L1) {
-                    const unsigned char* cp = reinterpret_cast<const unsigned char*>(a.codes) + pair * (int64_t)(2 * G * NV);
+                    // (32-bit byte offsets from the uniform base: one shift-add per visit instead of 64-bit address arithmetic per load;
+                    //  n_pairs * 2 G NV bytes < 4 GiB is checked where the buffers are sized)
+                    const unsigned char* __restrict__ cbase = reinterpret_cast<const unsigned char*>(a.codes);
+                    const unsigned off = (unsigned)pair * (unsigned)(2 * G * NV) + (unsigned)gl;
 #pragma unroll
-                    for (int v2 = 0; v2 < NV; ++v2) { cpv[v2] = cp[v2 * G + gl]; cnv[v2] = cp[G * NV + v2 * G + gl]; }
+                    for (int v2 = 0; v2 < NV; ++v2) { cpv[v2] = cbase[off + (unsigned)(v2 * G)]; cnv[v2] = cbase[off + (unsigned)(G * NV + v2 * G)]; }
                 } else {
                     const float4* cp = reinterpret_cast<const float4*>(a.codes) + pair * (int64_t)(2 * G * NV);
 #pragma unroll
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                 for (int q = 0; q < kDirBatch; ++q) {
                     e[q] = v0 + q < nvis ? vis[v0 + q] : -1;
                     const int pair = e[q] >= 0 ? (e[q] >> 2) : 0;
-                    if constexpr (L1) rec[q] = reinterpret_cast<const float*>(a.recs)[4 * (int64_t)pair];
+                    if constexpr (L1) rec[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.recs) + (unsigned)pair * 16u);
                     else rec[q] = a.recs[pair];
                     load_codes(pair, cpv[q], cnv[q]);
                 }
@@ -732,6 +742,10 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
                       (unsigned long long)rows, (unsigned long long)row_bytes);
             return -1;
         }
+    }
+    if (dir && dir->codes && (uint64_t)dir->n_pairs * (uint64_t)(2 * geo.G * geo.NV) > 0xFFFFFFFFull) {   // (L1 codes: 32-bit byte offsets)
+        set_error("kge_pull_step: %lld pairs exceed the 4 GiB the 32-bit offsets into the direction codes address", (long long)dir->n_pairs);
+        return -1;
     }
     PullArgs a;
     for (int i = 0; i < 2; ++i) {
