@@ -842,10 +842,19 @@ def main():
                          "hop_chain_us": rounds * hops * hop_us, "row_io_bytes": row_bytes, "row_io_stream_us": stream_us,
                          "visits_us": visits_us,
                          "predicted_owner_kernel_us": rounds * hops * hop_us + stream_us + (visits_us or 0.0),
-                         "note": "what bounds the owner launch: one residency round of owner groups, each a chain of dependent loads (rounds x "
-                                 "hops x loaded hop latency), the rows' own read-modify-write stream (parameters, both Adam moments, normalised "
-                                 "copy, norm) and the visits' arithmetic.  Compare with rocprofv3's k_pull_step average in "
-                                 "profiles/r04_kernel_stats.md (20.0 us); k_pull_eval (8.8 us) is one more launch of two dependent hops"}
+                         "note": "the round-3 model of the owner launch (a chain of dependent loads per owner group + the rows' read-modify-write "
+                                 "stream + the visits): kept for comparison -- it matched the 20.0 us of the round-3 kernel, but the round-4 "
+                                 "measurements below say the kernel is bound by VALU issue, not by this sum",
+                         "superseded_by": {
+                             "source": "profiles/r04_experiments.md section 7 (per-workgroup wall_clock64 timestamps + HW_REG_HW_ID of an experiment "
+                                       "build; SQ counter passes of this command in profiles/r04_pmc_traffic.json)",
+                             "resident_workgroups_per_cu": 7, "resident_limit": "SGPR file (81 SGPRs per wave)",
+                             "workgroups_per_launch": 2173, "resident_slots": 1792,
+                             "workgroup_lifetime_us": {"mean": 11.8, "p10": 6.9, "p90": 15.5, "max": 17.5},
+                             "valu_busy_frac_round3_kernel": 0.75, "valu_wave_instructions_per_wave_round3_kernel": 1005,
+                             "valu_wave_instructions_per_wave_after_first_cut": 804,
+                             "what_helped": "fewer VALU instructions per visit (2-bit two's-complement codes, coefficient tables, integer half-unit "
+                                            "sums): 29.8 -> 27.7 us per step; residency, prefetch depth and layering changes did not"}}
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
