@@ -113,7 +113,7 @@ int kge_debug_marker(int32_t tag, void* stream);
 
 /* Scratch bytes the score / train entry points need for a call on n rows (n pairs for the pairwise step).
  * 0 for the gather-type models; RESCAL and TransR group the batch by relation on the device (about 5R + n + n/32 ints per side),
- * TransR's large-batch pairwise step (negatives that keep their positives' relations: nr == pr, from 1 024 pairs on) keeps
+ * TransR's large-batch pairwise step (negatives that keep their positives' relations: nr == pr) keeps
  * 2n*(rel_dim + 1) floats per side between its two launches (dL/d(h^ M), dL/d(t^ M) and the rows' inverse norms),
  * NTN keeps n*(4d + 3k_r + 6) floats of intermediates per side; the hinge step adds 2n floats. */
 size_t kge_workspace_bytes(const kge_model_desc* m, int64_t n);

@@ -105,7 +105,7 @@ int kge_abi_version(void) { return KGE_ABI_VERSION; }
 const char* kge_last_error(void) { return g_err; }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-static const int64_t kTransRRowsMinPairs = 1024;   // measured crossover: profiles/r04_experiments.md
+static const int64_t kTransRRowsMinPairs = 1;      // the two-launch step wins at every batch size measured (128 ... 32 768 pairs: profiles/r04_transr_threshold.txt)
 
 size_t kge_workspace_bytes(const kge_model_desc* m, int64_t n) {
     if (validate(m, false, "kge_workspace_bytes") || n < 0) return 0;
@@ -194,8 +194,7 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
         return launch_ntn_pair_backward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s);
     }
     if (m->model == KGE_TRANSR) {
-        // nr == pr (one buffer) and a batch large enough to fill the chip with (relation, 32 pairs) workgroups: the two-launch
-        // step of kge_transr_rows.hip (KGE_TRANSR_ROWS=0/1 overrides the size rule)
+        // nr == pr (one buffer): the two-launch step of kge_transr_rows.hip (KGE_TRANSR_ROWS=0: the tile kernels)
         const int rows_sw = switch_value("TRANSR_ROWS");
         if (nr == pr && rows_sw != 0 && (rows_sw >= 1 || n >= kTransRRowsMinPairs) && transr_rows_ok(m, n, 2 * gws))
             return launch_transr_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, wsp, 2 * gws, s);

@@ -313,7 +313,7 @@ class Trainer:
             # previous step's optimiser already stored them renormalised (_reduce_and_step): then this pass is skipped.
             self.K.rescal_normalize(self.flat.views[0], self.flat.views[1], self.model.hidden_size)
         if sampled and self.model.kernel_name == "transr" and nr.numel() == pr.numel():
-            nr = pr      # (as for RESCAL below: pairs grouped by relation, the two-launch step of csrc/kge_transr_rows.hip from 1 024 pairs on)
+            nr = pr      # (as for RESCAL below: pairs grouped by relation, the two-launch step of csrc/kge_transr_rows.hip)
         if sampled and name == "rescal" and nr.numel() == pr.numel():
             nr = pr      # our sampler corrupts heads and tails only: passing the SAME buffer lets kge_train_pairwise_hinge group
                          # pairs by relation and run the whole step in one launch (k_rescal_pair)
