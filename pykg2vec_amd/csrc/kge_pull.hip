@@ -25,6 +25,8 @@
 #include "kge_opt_device.h"
 #include "kge_sampler_device.h"
 #include "kge_pull_device.h"
+#define KGE_TS_UNIT pull
+#include "kge_ts_debug.h"   // (slots: 0 = k_pull_step, 1 = k_pull_eval; no-ops in the product build)
 #include <stdlib.h>
 #include <type_traits>
 
@@ -168,6 +170,7 @@ constexpr int kEvalPP = 2;
 template <bool L1, int G, int NV>
 __global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restrict__ loss) {
     constexpr int GPB = kBlock / G, PP = kEvalPP;
+    KGE_TS_BEGIN(1)
     const int gl = threadIdx.x % G;
     float acc = 0.f;
     const char* __restrict__ hat_e = reinterpret_cast<const char*>(a.hat_in[0]);
@@ -250,14 +253,17 @@ __global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restr
         }
     }
     block_accumulate_loss<G>(acc, gl, loss);
+    KGE_TS_END(1, 1)
 }
 
 template <int OPT, bool L1, int G, int NV, bool DIR = false>
 __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs sa, float* __restrict__ loss) {
     constexpr int GPB = kBlock / G;
+    KGE_TS_BEGIN(0)
     if ((int)blockIdx.x < a.sample_blocks) {   // leading blocks: the sampler of the NEXT batch rides along (writes the other list set)
         const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
         if (i < sa.n) pull_sample_one(sa, i);
+        KGE_TS_END(0, 2)
         return;
     }
     const int gl = threadIdx.x % G;
@@ -585,6 +591,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
         pull_finish_row<OPT, G, NV, DIR && OPT != KGE_OPT_GRADIENT>(a, g, X, nX, gs, gl, S1, S2);
     }
     block_accumulate_loss<G>(acc, gl, loss);
+    KGE_TS_END(0, 1)
 }
 
 // rows cut into several segments: add the segments' partial sums in segment order, then finish the row

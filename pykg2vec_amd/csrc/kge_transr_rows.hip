@@ -22,6 +22,8 @@
 #include "kge_internal.h"
 #include "kge_relgroup.h"
 #include "kge_mfma_blocks.h"
+#define KGE_TS_UNIT transr
+#include "kge_ts_debug.h"   // (slot 0 = k_transr_g2; no-ops in the product build)
 
 namespace kge {
 
@@ -552,6 +554,7 @@ __global__ __launch_bounds__(256, 2) void k_transr_g2(TransRRowsArgs A) {
     constexpr int RBW = (NB + 3) / 4;   // row blocks per wave
     constexpr int NV = (NB + 3) / 4;    // 16-byte pieces per thread and row half (16 threads per row: pieces f, f + 16)
     __shared__ __attribute__((aligned(16))) float sA[2][16][PA], sB[2][16][PB];
+    KGE_TS_BEGIN(0)
     int rel, tin;
     const int tile = strided_tile<kTrGRun>(A.tiles);
     if (tile >= A.tiles || !locate_tile(A.tile_off, A.tile_rel, A.R, tile, rel, tin)) return;
@@ -700,6 +703,7 @@ __global__ __launch_bounds__(256, 2) void k_transr_g2(TransRRowsArgs A) {
                 }
             }
     }
+    KGE_TS_END(0, 1 + nslab)
 }
 
 // workspace of the two-launch step: the grouping of n pairs in 16-pair tiles, then invs [4 n] and gws [4 n][dr]
