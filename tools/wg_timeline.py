@@ -39,7 +39,14 @@ def analyse(name, t, live_tags=None):
     t0 = t[:, 0].astype(np.int64); t1 = t[:, 1].astype(np.int64); tag = t[:, 3].astype(np.int64)
     xcc = t[:, 2].astype(np.int64) & 15; hw = t[:, 2].astype(np.int64) >> 8
     # a record of an older launch geometry can survive at a block id the last launch did not have: keep the last cluster of entry times
-    keep = t0 >= np.median(t0) - 100 * 30     # entry times more than 30 us before the median entry belong to an older launch
+    # a block id the last launch did not have keeps the record of an older launch: entry times separated from the rest by a gap of
+    # more than 5 us (workgroups of one launch start densely) are dropped
+    order = np.argsort(t0)
+    gaps = np.diff(t0[order])
+    big = np.where(gaps > 500)[0]
+    keep = np.ones(len(t0), dtype=bool)
+    if len(big):
+        keep[order[:big[-1] + 1]] = False
     t0, t1, tag, xcc, hw = t0[keep], t1[keep], tag[keep], xcc[keep], hw[keep]
     base = t0.min()
     us = lambda x: x / 100.0
