@@ -39,14 +39,14 @@ def analyse(name, t, live_tags=None):
     t0 = t[:, 0].astype(np.int64); t1 = t[:, 1].astype(np.int64); tag = t[:, 3].astype(np.int64)
     xcc = t[:, 2].astype(np.int64) & 15; hw = t[:, 2].astype(np.int64) >> 8
     # a record of an older launch geometry can survive at a block id the last launch did not have: keep the last cluster of entry times
-    # a block id the last launch did not have keeps the record of an older launch: entry times separated from the rest by a gap of
-    # more than 5 us (workgroups of one launch start densely) are dropped
+    # a block id the last launch did not have keeps the record of an older launch: a handful of entry times, separated from the
+    # launch's own by a gap of more than 5 us (a later residency round is a gap too, but behind at least 1 % of the records)
     order = np.argsort(t0)
     gaps = np.diff(t0[order])
-    big = np.where(gaps > 500)[0]
     keep = np.ones(len(t0), dtype=bool)
-    if len(big):
-        keep[order[:big[-1] + 1]] = False
+    for gi in np.where(gaps > 500)[0]:
+        if gi + 1 < 0.01 * len(t0):
+            keep[order[:gi + 1]] = False
     t0, t1, tag, xcc, hw = t0[keep], t1[keep], tag[keep], xcc[keep], hw[keep]
     base = t0.min()
     us = lambda x: x / 100.0
