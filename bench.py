@@ -425,16 +425,17 @@ def live_pmc(args, timeout_s=150):
     tmp = tempfile.mkdtemp(prefix="kge_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out_dir = os.path.join(tmp, ctr)
-            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", out_dir, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
+        # third pass: VALU issue counters (the owner kernel of the train leg is VALU-bound, profiles/r04_experiments.md section 7)
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES"):
+            out_dir = os.path.join(tmp, ctr.split()[0])
+            cmd = [exe, "--pmc"] + ctr.split() + ["--kernel-trace", "-d", out_dir, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", "--batch", str(args.batch), "--eval-triples", str(args.eval_triples)]
             t0 = time.perf_counter()
             try:
                 res = subprocess.run(cmd, env=env, cwd="/tmp", timeout=timeout_s, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
             except subprocess.TimeoutExpired:
                 return None, "rocprofv3 --pmc %s pass exceeded %d s" % (ctr, timeout_s)
-            meta[ctr + "_pass_s"] = time.perf_counter() - t0
+            meta[ctr.split()[0] + "_pass_s"] = time.perf_counter() - t0
             dbs = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
             if res.returncode != 0 or not dbs:
                 return None, "rocprofv3 --pmc %s pass failed (rc %d, %d result files): %s" % (
@@ -447,6 +448,14 @@ def live_pmc(args, timeout_s=150):
                 if tag not in units:
                     continue
                 leg = legs.setdefault(name_of[tag], {"units": units[tag], "kernels": {}})
+                if ctr.startswith("SQ_"):    # several counters in one pass: one row per (dispatch, counter)
+                    ncs = len(ctr.split())
+                    for kname, k in rec["kernels"].items():
+                        kk = leg["kernels"].setdefault(kname, {})
+                        for c in ctr.split():
+                            kk[c + "_per_unit"] = k.get(c, 0.0) / units[tag]
+                        kk["us_per_unit_in_sq_pass"] = k["duration_us"] / ncs / units[tag]
+                    continue
                 total_kb = rec["counters"].get(ctr, 0.0)
                 leg["fetch_raw_bytes" if ctr == "FETCH_SIZE" else "write_bytes"] = total_kb * 1024.0 / units[tag]
                 for kname, k in rec["kernels"].items():
@@ -462,6 +471,32 @@ def live_pmc(args, timeout_s=150):
             # doubled, as the guide prescribes for 16-byte-per-lane reads, which is how these kernels read rows and streams
             leg["bytes"] = 2.0 * leg["fetch_raw_bytes"] + leg["write_bytes"]
     return legs, meta
+
+
+def valu_record(kernels):
+    """VALU issue load of the train leg's kernels from the third live counter pass: per kernel the VALU wave-instructions per step and
+    a LOWER bound of the busy fraction of the SIMDs' VALU issue -- SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1 024
+    SIMDs (MI355X_MICROARCH.md), divided here by the kernel's duration at the 2.4 GHz peak clock (the chip runs slower under load, so the
+    true fraction is higher: SQ_BUSY_CYCLES over the 32 shader engines puts the clock of the owner launch near 1.8-1.9 GHz)."""
+    if not kernels:
+        return None
+    out = {}
+    for name, k in kernels.items():
+        if "SQ_ACTIVE_INST_VALU_per_unit" not in k or not k.get("us_per_unit_in_sq_pass"):
+            continue
+        act, dur = k["SQ_ACTIVE_INST_VALU_per_unit"], k["us_per_unit_in_sq_pass"]
+        rec = {"valu_wave_instructions_per_step": k.get("SQ_INSTS_VALU_per_unit"), "waves_per_step": k.get("SQ_WAVES_per_unit"),
+               "active_quad_cycles_per_step": act, "us_per_step_in_this_pass": dur,
+               "busy_frac_lower_bound": 4.0 * act / (dur * 1e-6 * 2.4e9 * 1024)}
+        busy = k.get("SQ_BUSY_CYCLES_per_unit")
+        if busy:
+            rec["busy_frac_by_sq_busy_cycles"] = act / (8.0 * busy)   # 4 x quad-cycles / 1 024 SIMDs over cycles / 32 shader engines
+        out[name] = rec
+    if not out:
+        return None
+    out["note"] = ("observed in this run (third rocprofv3 pass of the counter child).  k_pull_step is bound by VALU issue, not by HBM: "
+                   "roofline.frac above is the HBM fraction SURVEY 8(d) asks for; this record is what actually limits the launch")
+    return out
 
 
 def setup_headline(batch, eval_triples, device, world=1, rank=0):
@@ -881,6 +916,7 @@ def main():
                          "traffic_note": ("2 x FETCH_SIZE (gfx950: 16-byte-per-lane reads are tallied at half, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; "
                                           "the counters sit on the fabric side of the per-XCD L2s and include Infinity-Cache hits" if pull else "FETCH_SIZE + WRITE_SIZE, raw"),
                          "traffic_kernels": traffic_kernels,
+                         "valu": valu_record(traffic_kernels),
                          "nominal_achieved": nominal, "nominal_frac": nominal / HBM_PEAK_GBS,
                          "nominal_note": ("ALGORITHMIC bytes of SURVEY section 8(d) (forward gathers + gradient read-modify-write + ids per scored "
                                           "triple: 3628 B) / avg_launch_ms.  The owner-computes step performs no gradient read-modify-write and "
