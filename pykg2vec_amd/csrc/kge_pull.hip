@@ -308,7 +308,8 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
         // the row's corrupting-entity draws are walked by its first (or only) item
         const bool walks_c = !is_rel && (kind == 0 || kind == 1 || (kind == 3 && ((it.w >> 2) & 15) == 0));
         int nvis;
-        if constexpr (DIR) nvis = own_visit_list_dir<G>(a.lists, a.inc, it, g, walks_c, gl, gbase, reinterpret_cast<int*>(s_desc[threadIdx.x / G]), &cnt, &fast_c);
+        if constexpr (DIR) nvis = own_visit_list_dir<G>(a.lists, a.inc, it, g, walks_c, gl, gbase, reinterpret_cast<int*>(s_desc[threadIdx.x / G]), &cnt, &fast_c,
+                                                        /* ranked = */ !(L1 && a.theta == nullptr));
         else nvis = own_visit_list<G>(a.lists, it, g, walks_c, gl, gbase, s_desc[threadIdx.x / G], &cnt, &fast_c);
 #pragma unroll
         for (int v = 0; v < NV; ++v) gs[v] = make_float4(0.f, 0.f, 0.f, 0.f);

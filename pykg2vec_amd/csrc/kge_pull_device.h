@@ -96,10 +96,12 @@ __device__ __forceinline__ int own_visit_list(const PullLists& lists, const int4
 // The same list for the two-phase ("staged direction") step: a visit is (pair << 2 | role) -- static incidences straight from
 // `inc`, drawers from the entity's bucket of pair indices, ranked by pair index -- because the owner needs nothing but the pair's
 // evaluation record, which phase 1 left behind.
+// ranked == false: the drawers are visited in arrival order (the caller's sums are exact in any order -- TransE's integer half units --,
+// so the 47-instruction ranking loop per bucket entry is skipped: it was a quarter of the owner kernel's VALU instructions)
 template <int G>
 __device__ __forceinline__ int own_visit_list_dir(const PullLists& lists, const int32_t* __restrict__ inc, const int4 it, int g,
                                                   bool walks_c, int gl, int gbase, int* __restrict__ s_vis_row, int* cnt_out,
-                                                  bool* fast) {
+                                                  bool* fast, bool ranked = true) {
     const int n_static = it.z - it.y;
     const int q = gl - n_static;
     int e = -1;
@@ -115,7 +117,7 @@ __device__ __forceinline__ int own_visit_list_dir(const PullLists& lists, const 
     if (cnt > 0 && fast_c) {
         const bool mine = q >= 0 && q < cnt;
         const int key = mine ? dd : 0x7FFFFFFF;
-        if (cnt > 1) {
+        if (cnt > 1 && ranked) {
             int rank = 0;
             for (int m = 0; m < cnt; ++m) rank += __shfl(key, gbase + n_static + m, 64) < key ? 1 : 0;
             if (mine) slot = n_static + rank;
