@@ -1372,14 +1372,23 @@ static void launch_rescal_g(const kge_model_desc* m, const int64_t* ph, const in
                        g.offsets, g.tile_off, g.tile_rel, g.perm, R, k, ds);
 }
 
-constexpr int64_t kPairSplitG = 8192;      // pairs from which the relation-matrix gradient gets its own launch
+// Pairs from which dL/denergy is left behind and the relation-matrix gradient gets its own launch (with k_rescal_rows for V / U where
+// k <= 208): 8 192 -- or 512 on graphs with many relations, where most 16-pair tiles of k_rescal_pair are partial and each still pays
+// its k^2 atomics (profiles/r04_rescal_threshold.txt: FB15k shape k = 200, B = 512 ... 4 096: 130 / 195 / 319 / 383 -> 104 / 176 / 251 /
+// 298 us; YAGO3-10 shape, 37 relations: k_rescal_pair wins up to ~6 000 pairs).  KGE_RESCAL_SPLIT_MIN=<pairs> overrides (A/B).
+constexpr int64_t kPairSplitG = 8192, kPairSplitManyRel = 512, kManyRelations = 512;
+static bool pair_split(int64_t R, int64_t n) {
+    const int v = switch_value("RESCAL_SPLIT_MIN");
+    if (v > 0) return n >= (int64_t)v;
+    return n >= kPairSplitG || (R >= kManyRelations && n >= kPairSplitManyRel);
+}
 
 static size_t rescal_pair_lds_bytes(int k) {
     const int S = (k + 1) | 1;
     return (size_t)(2 * TILE * S + 8 * 16 * 64 + 8 * TILE + TILE) * sizeof(float) + (size_t)2 * TILE * sizeof(long long) + 16;
 }
 static size_t rescal_pair_ws_bytes(int64_t R, int64_t n) {
-    return (size_t)(4 * (R + 1) + n + (n / kPairTile + R + 1) + 8 + (n >= kPairSplitG ? n : 0)) * sizeof(int);
+    return (size_t)(4 * (R + 1) + n + (n / kPairTile + R + 1) + 8 + n) * sizeof(int);   // (+ n floats of dL/denergy: used from pair_split_min() pairs on)
 }
 
 bool rescal_pair_step_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
@@ -1404,7 +1413,7 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
         attr_set = true;
     }
     const unsigned tiles = (unsigned)(n / kPairTile + R + 1);
-    float* ds = n >= kPairSplitG ? (float*)(g.tile_rel + tiles) : nullptr;
+    float* ds = pair_split(R, n) ? (float*)(g.tile_rel + tiles) : nullptr;
     const int S = (k + 1) | 1;
     const size_t lds_gm = (size_t)(2 * TILE * S + TILE) * sizeof(float) + (size_t)2 * TILE * sizeof(long long);
     // large batches: V / U as batch-as-M GEMMs (k_rescal_rows), dL/denergy to the relation-owner launch below (KGE_RESCAL_ROWS=0/1: A/B)

@@ -370,7 +370,9 @@ def _check_step_vs_oracle(hip, model, hp, neg_rate, E, R, B, grad_atol=5e-5):
                                               (50, 3000, 400, 9000, 1.0),
                                               # >= 8192 pairs: dL/denergy left behind, relation-matrix gradient by the relation-owner
                                               # launch (k_rescal_pair_gm); > 16384: the block-aggregated grouping kernels
-                                              (64, 3000, 5, 9000, 1.0), (32, 5000, 7, 20000, 1.0), (32, 5000, 700, 20000, 1.0)])
+                                              (64, 3000, 5, 9000, 1.0), (32, 5000, 7, 20000, 1.0), (32, 5000, 700, 20000, 1.0),
+                                              # many relations: the split form (k_rescal_rows + k_rescal_g2) from 512 pairs on
+                                              (64, 3000, 600, 2000, 1.0), (50, 2000, 900, 700, 1.0)])
 def test_rescal_pair_step_in_one_launch_matches_oracle(hip, monkeypatch, k, E, R, B, margin):
     """nr IS pr (one buffer): kge_train_pairwise_hinge groups PAIRS by relation and runs scores, hinge and the three gradients in
     one launch (k_rescal_pair).  Against the oracle, and against the three-launch path on the same batch (margin 0.02: most
