@@ -1,0 +1,163 @@
+"""The reference's C1 hot path restated ATen-op for ATen-op -- TEST / MEASUREMENT INFRASTRUCTURE, never the product path.
+
+Why this exists: `bench.py`'s `cpu_baseline` leg has to time the reference's arithmetic on the GPU box's host cores, and the
+reference tree (/root/reference) does not travel there.  The numpy oracle (oracle/kge_oracle.py) and its C/OpenMP form
+(oracle/kge_oracle_c.c) restate the ALGORITHM; they are not what the reference executes (the C form is ~24x faster than the
+reference).  This file restates the EXECUTION: the same torch calls, in the same order, on the same library (the container's
+torch CPU build, which is also the GPU box's), so that its wall clock is the reference's wall clock for this path:
+
+  train step  models/pairwise.py:56-93   TransE.forward/embed: nn.Embedding x3 -> F.normalize(p=2, dim=-1) x3 -> torch.norm(p=1|2)
+              utils/criterion.py:25-29   pairwise_hinge: pos + margin - neg -> torch.max(., zeros_like) -> sum
+              utils/trainer.py:147-157   two forwards (positives, negatives), `loss += get_reg()` (0.0 for TransE, models/KGMeta.py:36-38)
+              utils/trainer.py:266,298-299  optimizer.zero_grad() ... loss.backward(); optimizer.step()  (optim.Adam defaults, :112-116)
+  eval        utils/evaluator.py:249-273 test_tail_rank / test_head_rank: LongTensor([x]).repeat([E]), LongTensor(list(range(E))),
+                                         model.forward over all E candidates, torch.topk(k=E)
+              utils/evaluator.py:309-334 Evaluator.test: per triple head sweep then tail sweep, .detach().cpu().numpy()
+              utils/evaluator.py:70-123  MetricCalculator.get_tail_rank / get_head_rank: python scan of the ordering from its END
+
+tests/test_aten_restatement.py proves it BIT-EQUAL to the live reference in the build container (loss, gradients, post-step
+weights over several Adam steps, raw and filtered ranks) -- with that pinned, `cpu_baseline.kind` = "aten-restatement" on the
+GPU box is the reference's arithmetic library doing the reference's op sequence on the same host as the GPU number.
+Nothing here is imported by pykg2vec_amd/.
+"""
+import os
+import platform
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+class AtenTransE(torch.nn.Module):
+    """models/pairwise.py:37-93.  Construction order matters for the RNG stream: both nn.Embedding constructors draw their
+    default normal init first, then xavier_uniform_ overwrites entity then relation table (pairwise.py:43-47)."""
+
+    def __init__(self, tot_entity, tot_relation, hidden_size, l1_flag=True):
+        super().__init__()
+        self.l1_flag = l1_flag
+        self.ent_embeddings = torch.nn.Embedding(tot_entity, hidden_size)
+        self.rel_embeddings = torch.nn.Embedding(tot_relation, hidden_size)
+        torch.nn.init.xavier_uniform_(self.ent_embeddings.weight)
+        torch.nn.init.xavier_uniform_(self.rel_embeddings.weight)
+
+    def forward(self, h, r, t):
+        rows = (self.ent_embeddings(h), self.rel_embeddings(r), self.ent_embeddings(t))
+        hh, rr, tt = (F.normalize(x, p=2, dim=-1) for x in rows)
+        return torch.norm(hh + rr - tt, p=1 if self.l1_flag else 2, dim=-1)
+
+
+def hinge(pos, neg, margin):
+    """utils/criterion.py:25-29."""
+    x = pos + margin - neg
+    return torch.max(x, torch.zeros_like(x)).sum()
+
+
+def make_optimizer(model, name="adam", lr=0.01):
+    """utils/trainer.py:112-131: torch.optim defaults, dense."""
+    cls = {"adam": torch.optim.Adam, "sgd": torch.optim.SGD, "adagrad": torch.optim.Adagrad, "rms": torch.optim.RMSprop}[name]
+    return cls(model.parameters(), lr=lr)
+
+
+def train_step(model, opt, batch, margin):
+    """Body of the epoch loop, utils/trainer.py:266-299, for a pairwise batch of six id tensors.  Returns the loss tensor."""
+    model.train()
+    opt.zero_grad()
+    ph, pr, pt, nh, nr, nt = batch
+    loss = hinge(model(ph, pr, pt), model(nh, nr, nt), margin)
+    loss += 0.0          # `loss += self.model.get_reg(None, None, None)` with KGMeta's default 0.0
+    loss.backward()
+    opt.step()
+    return loss
+
+
+def _sweep(model, E, fixed_a, fixed_b, tail):
+    """utils/evaluator.py:249-273 without the predict_*_rank hook: every call rebuilds the E-long id tensors from python
+    lists, as the reference does, scores all candidates and asks topk for the complete ordering (descending energy)."""
+    a = torch.LongTensor([fixed_a]).repeat([E])
+    b = torch.LongTensor([fixed_b]).repeat([E])
+    ents = torch.LongTensor(list(range(E)))
+    preds = model.forward(a, b, ents) if tail else model.forward(ents, a, b)
+    return torch.topk(preds, k=E)[1]
+
+
+def _scan(order, true_id, known):
+    """utils/evaluator.py:70-123: walk the ordering from its end (lowest energy) to the true id; filtered rank discounts
+    candidates that are known answers."""
+    raw = filt = 0
+    for j in range(len(order)):
+        v = order[-j - 1]
+        if v == true_id:
+            break
+        raw += 1
+        filt += 1
+        if v in known:
+            filt -= 1
+    return raw, filt
+
+
+def rank_pass(model, triples, hr_t, tr_h, E):
+    """utils/evaluator.py:309-334 over `triples` (int rows h, r, t): returns int64 [4, n] = head, tail, filtered head, filtered tail
+    (0-based ranks, MetricCalculator's lists before settle())."""
+    model.eval()
+    out = np.zeros((4, len(triples)), dtype=np.int64)
+    with torch.no_grad():
+        for i, (h, r, t) in enumerate(triples):
+            h, r, t = int(h), int(r), int(t)
+            # head sweep first: test_head_rank(r, t) = forward(all, r, t); then the tail sweep
+            ho = _sweep(model, E, r, t, tail=False).detach().cpu().numpy()
+            to = _sweep(model, E, h, r, tail=True).detach().cpu().numpy()
+            out[1, i], out[3, i] = _scan(to, t, hr_t[(h, r)])
+            out[0, i], out[2, i] = _scan(ho, h, tr_h[(t, r)])
+    return out
+
+
+def corrupt_batches(train, E, batch, n_batches, seed=0):
+    """Pre-generated pairwise batches (uniform corruption of head or tail), as LongTensors -- the same recipe as
+    oracle/ref_cpu_baseline.py so both baselines see identical inputs."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n_batches):
+        pos = train[k * batch:(k + 1) * batch]
+        neg = pos.copy()
+        flip = rng.random(batch) > 0.5
+        rnd = rng.integers(E, size=batch)
+        neg[:, 2] = np.where(flip, rnd, neg[:, 2])
+        neg[:, 0] = np.where(flip, neg[:, 0], rnd)
+        out.append([torch.LongTensor(np.ascontiguousarray(a)) for a in (pos[:, 0], pos[:, 1], pos[:, 2], neg[:, 0], neg[:, 1], neg[:, 2])])
+    return out
+
+
+def measure(E, R, dim, train, test, hr_t, tr_h, batch=32768, n_eval=200, margin=1.0, lr=0.01, train_budget_s=10.0,
+            eval_budget_s=8.0, min_timed=5, max_timed=30):
+    """Same protocol as oracle/ref_cpu_baseline.py:measure (SURVEY.md 8(d) "CPU baseline timing"): 10 warm-up steps, median of
+    the timed dense-Adam steps on pre-generated batches; Evaluator.test-equivalent loop over (up to) n_eval test triples,
+    bounded by eval_budget_s.  hr_t / tr_h: the filter dicts for test[:n_eval]."""
+    torch.manual_seed(0)
+    model = AtenTransE(E, R, dim, True)
+    opt = make_optimizer(model, "adam", lr)
+    batches = corrupt_batches(train, E, batch, min(8, len(train) // batch))
+    for k in range(10):
+        train_step(model, opt, batches[k % len(batches)], margin)
+    times, t_begin = [], time.perf_counter()
+    while len(times) < max_timed and (len(times) < min_timed or time.perf_counter() - t_begin < train_budget_s):
+        t0 = time.perf_counter()
+        train_step(model, opt, batches[len(times) % len(batches)], margin)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    rank_pass(model, test[:4], hr_t, tr_h, E)   # warm
+    t0, done = time.perf_counter(), 0
+    while done < n_eval and time.perf_counter() - t0 < eval_budget_s:
+        m = min(20, n_eval - done)
+        rank_pass(model, test[done:done + m], hr_t, tr_h, E)
+        done += m
+    edt = time.perf_counter() - t0
+    return {"what": "ATen-op-for-op restatement of the reference's TransE step and Evaluator.test loop (oracle/aten_step.py, bit-equal "
+                    "to the live reference in the build container: tests/test_aten_restatement.py) on torch %s CPU" % torch.__version__,
+            "host": "%s, %d logical cores" % (platform.processor() or platform.machine(), os.cpu_count()),
+            "cores": torch.get_num_threads(),
+            "train": {"value": 2 * batch / med, "unit": "scored triples/s", "median_ms_per_step": med * 1e3,
+                      "sample": "%d timed dense-Adam steps of B=%d positives + %d negatives after 10 warm-up steps, median"
+                                % (len(times), batch, batch)},
+            "eval": {"value": done / edt, "unit": "test triples ranked/s",
+                     "sample": "%d test triples, two topk(k=E) sweeps over E=%d each + python rank scan" % (done, E)}}

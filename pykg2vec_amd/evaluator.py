@@ -247,6 +247,7 @@ class Evaluator:
                            torch.from_numpy(np.ascontiguousarray(qblocks)).to(dev)))
         return chunks
 
+    DEVICE_CSR_MAX_ENTITY, DEVICE_CSR_MAX_RELATION = 1 << 24, 1 << 16   # packed key of kge_filter_csr_* (csrc/kge_index.hip)
     FILTER_SOURCE = None   # None: the rule of _filter_source; "triples" / "dicts": forced (tests compare the two)
 
     @staticmethod
@@ -260,7 +261,9 @@ class Evaluator:
             return ("a", a.shape, int(a[:, 0].sum()), int(a[:, 1].sum()), int(a[:, 2].sum()),
                     int(np.bitwise_xor.reduce(mix)) if len(a) else 0)
         m = len(data) if n is None else n
-        pick = [data[i] for i in sorted({0, m // 2, m - 1})] if m else []
+        # 64 evenly spaced triples + the ends (a few microseconds): `id(data)` alone can be reused by a NEW list after the old one is
+        # freed, and three samples would miss most edits; the id stays in the key only to keep distinct live lists apart cheaply
+        pick = [data[i] for i in sorted({0, m - 1} | {(j * m) // 64 for j in range(64)})] if m else []
         return ("o", id(data), len(data), m, tuple((t.h, t.r, t.t) for t in pick))
 
     def _known_triples(self):
@@ -290,6 +293,9 @@ class Evaluator:
             flat = all(isinstance(kg.read_cache_data(k), np.ndarray) for k in ('triplets_train', 'triplets_valid', 'triplets_test'))
         except (KeyError, FileNotFoundError, AttributeError):
             flat = False
+        if int(self.config.tot_entity) > self.DEVICE_CSR_MAX_ENTITY or int(self.config.tot_relation) > self.DEVICE_CSR_MAX_RELATION:
+            # beyond the device builder's packed 24 / 16 / 24-bit key (csrc/kge_index.hip): the host builders have no such limit
+            return "dicts" if self.metric_calculator.hr_t is not None else "triples_host"
         if flat or self.metric_calculator.hr_t is None:
             return "triples"
         return "dicts"

@@ -1043,8 +1043,13 @@ class Trainer:
         mask[ids_all] = 1
         slot_of_row = torch.cumsum(mask, 0) - 1          # the same on every rank: position of a touched row in the exchange buffer
         s_local, s_all = slot_of_row[ids], slot_of_row[ids_all]
-        for v, g in zip(flat.views, flat.grad_views):
-            if v.shape[0] == E and v.dim() == 2:
+        # which tables are looked up by ENTITY id is a property of the model (kernels._TABLE_SHAPES), not of a row count: with
+        # tot_relation == tot_entity a relation table has E rows too, and reducing only its rows named by entity ids would let the
+        # replicas drift apart silently
+        roles = K._TABLE_SHAPES.get(self.model.model_name)
+        by_entity = [i < len(roles) and roles[i][0] == "E" for i in range(len(flat.views))] if roles else [False] * len(flat.views)
+        for (v, g), sparse in zip(zip(flat.views, flat.grad_views), by_entity):
+            if sparse and v.dim() == 2:
                 buf = st["bufs"].get(tuple(v.shape))
                 if buf is None:
                     buf = st["bufs"][tuple(v.shape)] = torch.zeros(cap, v.shape[1], dtype=torch.float32, device=v.device)
@@ -1322,10 +1327,21 @@ class Trainer:
         d = self._checkpoint_dir(path)
         os.makedirs(d, exist_ok=True)
         torch.save(self.model.state_dict(), os.path.join(d, self.TRAINED_MODEL_FILE_NAME))
+        # the configuration is pickled to a temporary file and renamed on success: a configuration holding an unpicklable object (open
+        # handles, lambdas) must not leave a truncated config.npy next to the weights -- the reference's load_model needs both files
+        # (utils/trainer.py:408) and would fail on a partial one with an unrelated error
+        final = os.path.join(d, self.TRAINED_MODEL_CONFIG_NAME)
+        tmp = final + ".tmp%d" % os.getpid()
         try:
-            np.save(os.path.join(d, self.TRAINED_MODEL_CONFIG_NAME), self.config)
-        except Exception as e:   # a configuration holding an unpicklable object (open handles, lambdas): the weights are still saved
-            _log("save_model: configuration not pickled (%s: %s)" % (type(e).__name__, e))
+            with open(tmp, "wb") as f:
+                np.save(f, self.config, allow_pickle=True)
+            os.replace(tmp, final)
+        except Exception as e:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            if os.path.exists(final):   # a stale configuration from an earlier save no longer describes these weights
+                os.remove(final)
+            _log("save_model: configuration not pickled, checkpoint is weights only (%s: %s)" % (type(e).__name__, e))
 
     def load_model(self, path=None):
         """Load a checkpoint written by save_model or by the reference.  Strict: every key the model's state_dict has must be in
@@ -1374,7 +1390,10 @@ class Trainer:
                     # keep the best weights seen so far (utils/trainer.py:207-219)
                     if self.best_metric is None or self._is_better(metrics):
                         self.best_metric = metrics
-                        self.save_model()
+                        if self.rank == 0:      # replicas are identical: one writer (N truncating writers would race on the same files)
+                            self.save_model()
+                        if self.distributed:
+                            torch.distributed.barrier(group=self.process_group)
         self.model.eval()
         with torch.no_grad():
             self.evaluator.full_test(cur_epoch_idx)

@@ -104,3 +104,46 @@ def test_sparse_row_exchange_equals_the_dense_exchange_bit_for_bit(tmp_path, mod
     for k in d0.files:
         assert np.array_equal(s0[k], s1[k]), "replicas diverged on %s" % k
         assert np.array_equal(s0[k], d0[k]), (k, np.abs(s0[k] - d0[k]).max())
+
+
+def _run_square(rank, world, port, model_name, out_dir, sparse, tag):
+    """tot_relation == tot_entity: the relation tables have as many rows as the entity table (the sparse-row exchange
+    used to pick its tables by row count and would have reduced the relation tables only at the rows named by ENTITY ids)."""
+    for p in (os.path.dirname(HERE), HERE, os.path.join(os.path.dirname(HERE), "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_backend
+    import hip_util
+    import kge_oracle as ko
+    from pykg2vec_amd.trainer import Trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N = 40                                       # entities == relations
+    rng = np.random.default_rng(17)
+    hp = dict(hidden_size=6, margin=1.0) if model_name == "rescal" else dict(ent_hidden_size=6, rel_hidden_size=5, margin=1.0, l1_flag=True)
+    trip = np.stack([rng.integers(N, size=160), rng.integers(N, size=160), rng.integers(N, size=160)], 1).astype(np.int64)
+    P = ko.init_params(model_name, rng, tot_entity=N, tot_relation=N, **{k: v for k, v in hp.items() if k.endswith("hidden_size")})
+    cfg = hip_util.make_config(N, N, hp, trip[:128], trip[128:144], trip[144:], optimizer="adam", lr=0.05, batch_size=8, device="cpu")
+    cfg.tot_train_triples = 8 * 4
+    m = hip_util.model_from_params(model_name, P, hp, N, N, device="cpu")
+    tr = Trainer(m, cfg, backend=oracle_backend)
+    tr.switches["dp_sparse"] = sparse
+    tr.build_model()
+    tr.generator = tr._new_generator()
+    for e in range(2):
+        tr.train_model_epoch(e)
+    assert tr._sparse_dp == sparse
+    np.savez(os.path.join(out_dir, "sq_r%d%s.npz" % (rank, tag)), **{n: p.detach().numpy() for n, p in m.named_parameters()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model_name", ["rescal", "transr"])
+def test_sparse_row_exchange_with_as_many_relations_as_entities(tmp_path, model_name):
+    out = str(tmp_path)
+    mp.spawn(_run_square, args=(2, _free_port(), model_name, out, False, "_dense"), nprocs=2, join=True)
+    mp.spawn(_run_square, args=(2, _free_port(), model_name, out, True, "_sparse"), nprocs=2, join=True)
+    d0, s0, s1 = (np.load(os.path.join(out, "sq_r%d_%s.npz" % (r, t))) for r, t in ((0, "dense"), (0, "sparse"), (1, "sparse")))
+    for k in d0.files:
+        assert np.array_equal(s0[k], s1[k]), "replicas diverged on %s" % k
+        assert np.array_equal(s0[k], d0[k]), (k, np.abs(s0[k] - d0[k]).max())
