@@ -216,6 +216,8 @@ def cpu_baseline(H):
             out = {"value": doc["train"]["value"], "unit": "scored triples/s", "cores": doc["cores"], "kind": "aten-restatement",
                    "sample": doc["train"]["sample"], "what": doc["what"], "host": doc["host"], "same_run": True, "same_host": True,
                    "kind_note": "the reference's exact ATen op sequence on this host's torch CPU build (%s)" % tried,
+                   "torch_default_threads": doc.get("torch_default_threads"),
+                   "value_at_torch_default_threads": doc["train"].get("value_at_torch_default_threads"),
                    "eval": {"value": doc["eval"]["value"], "unit": "test triples ranked/s", "sample": doc["eval"]["sample"]}}
         except Exception as e:
             tried = "%s; ATen restatement failed: %s: %s" % (tried, type(e).__name__, e)
@@ -671,6 +673,8 @@ def compact_line(out, detail_path=None):
              "same_run": cb.get("same_run", True), "same_host": cb.get("same_host", True), "sample": _short(cb.get("sample"), 120)}
         if cb.get("eval"):
             c["eval"] = {"value": _r(cb["eval"].get("value"), 5), "unit": cb["eval"].get("unit")}
+        if cb.get("value_at_torch_default_threads"):
+            c["at_torch_default_threads"] = {"value": _r(cb["value_at_torch_default_threads"], 5), "threads": cb.get("torch_default_threads")}
         if cb.get("port"):
             c["port"] = {"value": _r(cb["port"].get("value"), 5), "cores": cb["port"].get("cores"),
                          "eval": _r((cb["port"].get("eval") or {}).get("value"), 5)}

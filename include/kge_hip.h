@@ -220,38 +220,6 @@ int kge_optimizer_step_rows(int32_t kind, float* param, float* grad, float* stat
                             float lr, int64_t step, int32_t zero_grad, int32_t normalize, const float* dev_hyper,
                             const uint32_t* touched_rows, uint32_t* touched_clear, void* stream);
 
-/* ---- The exact LAZY form of the dense optimisers for row tables (kge_opt.hip).
- * torch.optim on dense nn.Embedding gradients (models/Domain.py:8-13, utils/trainer.py:112-131) moves every row every step; a
- * row whose gradient is zero for steps L+1 .. t-1 follows a trajectory fixed by its own (p, m, v) -- Adam: m <- m + 0.1 (0 - m),
- * v <- 0.999 v, p <- p - step_size_i m / (sqrt(v) / bc2_i + eps); RMSprop: only its accumulator decays; SGD / Adagrad: nothing --
- * plus, for RESCAL, the row renormalisation of every forward (pairwise.py:843-844).  `last[row]` = the last step applied to the row.
- * kge_optimizer_step_rows_lazy steps ONLY the rows of the touched-row bitmap (and sets last[row] = step); kge_lazy_catchup replays
- * the missed zero-gradient steps of the rows a batch is about to read (call it before the forward: rows named several times are
- * replayed once); kge_lazy_flush does the same for every row before the tables are observed (evaluation, checkpoints, the end of
- * an epoch).  The replay runs the sweep's own fp32 operation sequence in registers: results are bit-identical to the dense sweep.
- * hyper: device float [hyper_cap][2] = {lr / (1 - 0.9^i), sqrt(1 - 0.999^i)} of step i, as kge_lazy_hyper_fill writes them on the
- * host (torch computes these scalars in double on the host too); every step index used must be < hyper_cap.
- * dev_cursor (hipGraph replays; may be NULL): device int64[8] whose element 2 is the current step index (kge_step_advance). */
-typedef struct kge_lazy_rows {
-    int32_t* last;
-    const float* hyper;
-    int64_t hyper_cap;
-    const int64_t* dev_cursor;
-} kge_lazy_rows;
-int kge_lazy_hyper_fill(float lr, int64_t first_step, int64_t n, float* host_out /* [n][2], HOST memory */);
-int kge_optimizer_step_rows_lazy(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
-                                 float lr, int64_t step, int32_t zero_grad, int32_t normalize, const uint32_t* touched_rows,
-                                 uint32_t* touched_clear, const kge_lazy_rows* lazy, void* stream);
-/* id_lists: 1..4 device int64 arrays of n_ids row ids each (RESCAL: heads, tails, corrupted heads, corrupted tails of the batch).
- * Rows are brought to step - 1, every replayed step followed by the renormalisation when normalize != 0. */
-int kge_lazy_catchup(int32_t kind, float* param, float* state1, float* state2, int64_t rows, int32_t dim, float lr, int32_t normalize,
-                     const kge_lazy_rows* lazy, int64_t step, const int64_t* const* id_lists, int32_t n_lists, int64_t n_ids,
-                     void* stream);
-/* Every row to `step`.  normalize_last_step = 0: the final replayed step is left un-normalised (what the reference's tables hold
- * after the last optimiser step of an epoch: the renormalisation belongs to the NEXT forward). */
-int kge_lazy_flush(int32_t kind, float* param, float* state1, float* state2, int64_t rows, int32_t dim, float lr, int32_t normalize,
-                   int32_t normalize_last_step, const kge_lazy_rows* lazy, int64_t step, void* stream);
-
 /* The pairwise RESCAL train step of kge_train_pairwise_hinge (Trainer.train_model_epoch -> model.forward on both sides ->
  * Criterion.pairwise_hinge -> backward, utils/trainer.py:262-276 with pairwise.py:838-870) for batches whose negatives keep
  * their positives' relation ids (every sampler of the reference: data/generator.py:143-196 corrupts heads and tails only):

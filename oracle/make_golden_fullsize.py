@@ -15,8 +15,17 @@ d=200, FB15k-237 RotatE d=1000 neg 16, YAGO3-10 RESCAL k=200 -- on tables built 
     (tests/golden_util.default_step_batch: the generator's permutation rule + the Philox sampler restated on the host): loss,
     digests of every updated table and of the optimiser state (utils/trainer.py:147-180,296-299; torch.optim defaults :112-131)
 
+  * (`ranks` mode, files ref_full_ranks_<case>.npz; round 5) a WIDE rank sample: Evaluator.test over the first 512 test triples
+    of C1 (L1, L2), C2, C3 -- and, for C4 at its full E = 123 182, 16 triples whose sweeps are STITCHED from the reference's own
+    Rescal.forward over 4 096-candidate chunks (each chunk's forward starts from the same pre-sweep tables, so all chunks see the
+    one renormalisation a single E-candidate forward would have applied, models/pairwise.py:843-865), ranked by the reference's
+    own topk + MetricCalculator scan (utils/evaluator.py:70-123,249-273).  Next to the reference's fp32 ranks the file keeps the
+    FLOAT64 ranks of the same queries (numpy restatement in double): the arbiter for every query on which two fp32
+    implementations disagree.
+
 Usage: python oracle/make_golden_fullsize.py [case ...]            (scores / gradients / ranks)
        python oracle/make_golden_fullsize.py step [case ...]       (the default-path step fixtures)
+       python oracle/make_golden_fullsize.py ranks [case ...]      (the wide rank samples)
 """
 import os
 import sys
@@ -173,9 +182,125 @@ def run_step(name):
     print("wrote step", name, "B=%d %s loss=%.6f" % (step["B"], step["optimizer"], rec["loss"]))
 
 
+WIDE_RANKS = {"c1_transe_l1": 512, "c1_transe_l2": 512, "c2_complex": 512, "c3_rotate": 512, "c4_rescal": 16}
+RESCAL_CHUNK = 4096
+
+
+def _ranks64(spec, P, queries, hr_t, tr_h):
+    """Float64 ranks of the same queries: rank = #{e : s_e < s_true} in double (ties in double do not occur on these tables)."""
+    model_name, hp = spec["model"], dict(spec["hp"])
+    hp.setdefault("margin", 1.0)
+    out = np.zeros((4, len(queries)), np.int64)
+    if model_name == "rescal":      # h' M_r t over all entities without materialising E x k x k
+        k = hp["hidden_size"]
+        P64 = {n: v.astype(np.float64) for n, v in P.items()}
+        ent = P64["ent_embeddings"] / np.linalg.norm(P64["ent_embeddings"], axis=1, keepdims=True)
+        rel = P64["rel_matrices"] / np.linalg.norm(P64["rel_matrices"], axis=1, keepdims=True)
+        for i, (h, r, t) in enumerate(queries):
+            M = rel[r].reshape(k, k)
+            sh = -(ent @ (M @ ent[t]))          # (e, r, t) for every e
+            st = -(ent @ (ent[h] @ M))          # (h, r, e)
+            out[0, i], out[2, i] = ko.rank_from_scores(sh, int(h), tr_h[(int(t), int(r))])
+            out[1, i], out[3, i] = ko.rank_from_scores(st, int(t), hr_t[(int(h), int(r))])
+        return out
+    for i, (h, r, t) in enumerate(queries):
+        h, r, t = int(h), int(r), int(t)
+        sh = ko.sweep_scores(model_name, P, h, r, t, "head", dtype=np.float64, **hp)
+        st = ko.sweep_scores(model_name, P, h, r, t, "tail", dtype=np.float64, **hp)
+        out[0, i], out[2, i] = ko.rank_from_scores(sh, h, tr_h[(t, r)])
+        out[1, i], out[3, i] = ko.rank_from_scores(st, t, hr_t[(h, r)])
+    return out
+
+
+def _stitched_rescal(model, E, queries, hr_t, tr_h):
+    """Evaluator.test for a model whose single E-candidate forward does not fit memory: the same sweeps, chunk by chunk, through the
+    reference's own forward; the ordering and the rank scan are the reference's (torch.topk(k=E), MetricCalculator)."""
+    from pykg2vec.utils.evaluator import MetricCalculator
+    cfg = types.SimpleNamespace(knowledge_graph=_KG({"hr_t": hr_t, "tr_h": tr_h}), hits=[1, 3, 5, 10])
+    mc = MetricCalculator(cfg)
+    true_scores = []
+
+    def sweep(fixed_a, fixed_b, tail):
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        parts, after = [], None
+        for lo in range(0, E, RESCAL_CHUNK):
+            if after is not None:                       # every chunk starts from the pre-sweep tables
+                model.ent_embeddings.weight.data = before["ent_embeddings.weight"].clone()
+                model.rel_matrices.weight.data = before["rel_matrices.weight"].clone()
+            ents = torch.arange(lo, min(E, lo + RESCAL_CHUNK))
+            a = torch.LongTensor([fixed_a]).repeat([len(ents)])
+            b = torch.LongTensor([fixed_b]).repeat([len(ents)])
+            parts.append(model.forward(a, b, ents) if tail else model.forward(ents, a, b))
+            after = True
+        preds = torch.cat(parts)
+        return preds, torch.topk(preds, k=E)[1]
+
+    with torch.no_grad():
+        for i, (h, r, t) in enumerate(queries):
+            h, r, t = int(h), int(r), int(t)
+            ph, hrank = sweep(r, t, tail=False)         # utils/evaluator.py:321-322: head sweep first
+            pt, trank = sweep(h, r, tail=True)
+            true_scores.append((ph[h].item(), pt[t].item()))
+            mc.append_result([trank.numpy(), hrank.numpy(), h, r, t, 0])
+            print("  stitched query %d/%d" % (i + 1, len(queries)), flush=True)
+    return mc, np.asarray(true_scores, np.float32)
+
+
+def run_ranks(name):
+    spec, P, train, valid, test, ids, batch = gu.fullsize_inputs(name)
+    E, R, hp, model_name = spec["E"], spec["R"], spec["hp"], spec["model"]
+    n = WIDE_RANKS[name]
+    queries = test[:n]
+    hr_t, tr_h = gu.query_filters(np.concatenate([train, valid, test]), queries, R)
+    mk = lambda arr: [Triple(int(a), int(b), int(c)) for a, b, c in arr]
+    cfg = types.SimpleNamespace(
+        tot_entity=E, tot_relation=R, device="cpu", optimizer="sgd", learning_rate=0.01, neg_rate=hp.get("neg_rate", 1),
+        alpha=hp.get("alpha", 0.1), margin=hp.get("margin", 1.0), batch_size=spec["step_B"], tot_train_triples=len(train),
+        epochs=1000, test_num=n, debug=False, load_from_data=None, hits=[1, 3, 5, 10], patience=3,
+        dataset_name="synthetic", sampling="uniform",
+        knowledge_graph=_KG({"triplets_train": [], "triplets_valid": mk(valid[:4]), "triplets_test": mk(queries),
+                             "hr_t": hr_t, "tr_h": tr_h}))
+    for k, v in hp.items():
+        setattr(cfg, k, v)
+    cfg.summary = lambda: None
+    mod, cls = CLASS[model_name].split(".")
+    model_def = getattr(__import__("pykg2vec.models." + mod, fromlist=[cls]), cls)
+    model = model_def(**cfg.__dict__)
+    model.load_state_dict({k + ".weight": torch.from_numpy(v.copy()) for k, v in P.items()})
+    model.eval()
+    rec = {"name": name, "n": np.int64(n)}
+    if model_name == "rescal":
+        mc, rec["true_scores"] = _stitched_rescal(model, E, queries, hr_t, tr_h)
+        rec["chunk"] = np.int64(RESCAL_CHUNK)
+    else:
+        import contextlib
+        import io
+        ev = Evaluator(model, cfg)
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            ev.test(ev.test_data, n, epoch=0)
+        mc = ev.metric_calculator
+        with torch.no_grad():
+            ents = torch.arange(E)
+            st = []
+            for h, r, t in queries:
+                sh = model(ents, torch.full((E,), int(r)), torch.full((E,), int(t)))
+                stl = model(torch.full((E,), int(h)), torch.full((E,), int(r)), ents)
+                st.append((sh[int(h)].item(), stl[int(t)].item()))
+        rec["true_scores"] = np.asarray(st, np.float32)
+    rec["ranks"] = np.stack([np.asarray(x, np.int64) for x in (mc.rank_head, mc.rank_tail, mc.f_rank_head, mc.f_rank_tail)])
+    print("reference ranks done:", name, flush=True)
+    rec["ranks64"] = _ranks64(spec, P, queries, hr_t, tr_h)
+    np.savez_compressed(os.path.join(OUT, "ref_full_ranks_%s.npz" % name), **rec)
+    diff = int((rec["ranks"] != rec["ranks64"]).any(0).sum())
+    print("wrote ranks", name, "n=%d" % n, "queries where the reference's fp32 ranks differ from float64: %d" % diff, flush=True)
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
-    if args and args[0] == "step":
+    if args and args[0] == "ranks":
+        for name in (args[1:] or list(WIDE_RANKS)):
+            run_ranks(name)
+    elif args and args[0] == "step":
         for name in (args[1:] or list(gu.DEFAULT_STEP)):
             run_step(name)
     else:

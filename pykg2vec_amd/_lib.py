@@ -90,11 +90,6 @@ class OwnPlanC(ctypes.Structure):
                 ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p), ("stage", ctypes.c_void_p)]
 
 
-class LazyRows(ctypes.Structure):
-    """struct kge_lazy_rows"""
-    _fields_ = [("last", ctypes.c_void_p), ("hyper", ctypes.c_void_p), ("hyper_cap", ctypes.c_int64), ("dev_cursor", ctypes.c_void_p)]
-
-
 class StagedTable(ctypes.Structure):
     """struct kge_staged_table"""
     _fields_ = [("cls", ctypes.c_int32), ("site_a", ctypes.c_int32), ("site_b", ctypes.c_int32), ("dsite", ctypes.c_int32),
@@ -173,14 +168,6 @@ _SIGNATURES = {
     "kge_optimizer_step": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_float, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_optimizer_step_rows": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
                                                ctypes.c_int64, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 4),
-    "kge_optimizer_step_rows_lazy": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
-                                                    ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
-                                                    ctypes.POINTER(LazyRows), ctypes.c_void_p]),
-    "kge_lazy_hyper_fill": (ctypes.c_int, [ctypes.c_float, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
-    "kge_lazy_catchup": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_int32,
-                                        ctypes.POINTER(LazyRows), ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]),
-    "kge_lazy_flush": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_int32,
-                                      ctypes.c_int32, ctypes.POINTER(LazyRows), ctypes.c_int64, ctypes.c_void_p]),
     "kge_rescal_pair_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_rescal_pair_step_ok": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_int64]),

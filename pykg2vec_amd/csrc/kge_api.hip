@@ -111,7 +111,9 @@ size_t kge_workspace_bytes(const kge_model_desc* m, int64_t n) {
     if (validate(m, false, "kge_workspace_bytes") || n < 0) return 0;
     if (is_vector_model(m->model)) return 0;
     // the pairwise step keeps one scorer workspace per side (positive / negative) plus the two score vectors
-    return 2 * align256(dense_workspace_bytes(m, n)) + align256((size_t)2 * n * sizeof(float));
+    size_t b = 2 * align256(dense_workspace_bytes(m, n)) + align256((size_t)2 * n * sizeof(float));
+    if (m->model == KGE_RESCAL) b += rescal_slab_extra_bytes(m, n);   // V rows + energy shares of the slab form of the pairwise step
+    return b;
 }
 
 int kge_score_forward(const kge_model_desc* m, const int64_t* h, const int64_t* r, const int64_t* t, int64_t n,
@@ -181,7 +183,7 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
         // of the reference does): scores, hinge and gradients of a (relation, 16 pairs) tile in one launch
         const bool unfused = switch_value("RESCAL_UNFUSED") == 1;   // A/B switch (same 0 / 1 meaning as Trainer.switches)
         if (nr == pr && rescal_pair_step_ok(m, n, 2 * gws) && !unfused)
-            return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, wsp, 2 * gws, nullptr, s);
+            return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, wsp, workspace_bytes, nullptr, s);
         // positives and negatives as ONE grouped batch of 2n triples (scores / coefficients contiguous: sp | sn); the
         // region of the two per-side workspaces holds the grouping of 2n triples (group_ws_bytes(R, 2n) <= 2 gws)
         if ((rc = launch_rescal_pair_forward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s))) return rc;
@@ -416,46 +418,7 @@ int kge_optimizer_step_rows(int32_t kind, float* param, float* grad, float* stat
     if (rows == 0) return 0;
     if (touched_rows && touched_rows == touched_clear) { set_error("kge_optimizer_step_rows: the bitmap to clear must be the other parity's"); return -1; }
     return launch_optimizer_rows(kind, param, grad, state1, state2, rows, dim, lr, step < 1 ? 1 : step, zero_grad, normalize, dev_hyper,
-                                 touched_rows, touched_clear, nullptr, (hipStream_t)stream);
-}
-
-int kge_optimizer_step_rows_lazy(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
-                                 float lr, int64_t step, int32_t zero_grad, int32_t normalize, const uint32_t* touched_rows,
-                                 uint32_t* touched_clear, const kge_lazy_rows* lazy, void* stream) {
-    if (!param || !grad || rows < 0 || dim <= 0 || dim > 1024 || !lazy || (step < 1 && !lazy->dev_cursor)) {
-        set_error("kge_optimizer_step_rows_lazy: bad arguments (rows of at most 1024 floats, lazy state required)");
-        return -1;
-    }
-    if (rows == 0) return 0;
-    if (touched_rows && touched_rows == touched_clear) { set_error("kge_optimizer_step_rows_lazy: the bitmap to clear must be the other parity's"); return -1; }
-    return launch_optimizer_rows(kind, param, grad, state1, state2, rows, dim, lr, step < 1 ? 1 : step, zero_grad, normalize, nullptr,
-                                 touched_rows, touched_clear, lazy, (hipStream_t)stream);
-}
-
-int kge_lazy_hyper_fill(float lr, int64_t first_step, int64_t n, float* host_out) {
-    if (!host_out || n < 0 || first_step < 0) { set_error("kge_lazy_hyper_fill: bad arguments"); return -1; }
-    lazy_hyper_fill(lr, first_step, n, host_out);
-    return 0;
-}
-
-int kge_lazy_catchup(int32_t kind, float* param, float* state1, float* state2, int64_t rows, int32_t dim, float lr, int32_t normalize,
-                     const kge_lazy_rows* lazy, int64_t step, const int64_t* const* id_lists, int32_t n_lists, int64_t n_ids,
-                     void* stream) {
-    if (!param || rows <= 0 || dim <= 0 || n_lists < 1 || n_lists > 4 || !id_lists || n_ids < 0) { set_error("kge_lazy_catchup: bad arguments (1..4 id lists)"); return -1; }
-    if (n_ids == 0) return 0;
-    for (int i = 0; i < n_lists; ++i) {
-        if (!id_lists[i]) { set_error("kge_lazy_catchup: id list %d is null", i); return -1; }
-        if (int rc = debug_check_ids("kge_lazy_catchup", "row", id_lists[i], n_ids, 1, 0, rows, (hipStream_t)stream)) return rc;
-    }
-    return launch_lazy_rows(kind, 0, param, state1, state2, rows, dim, lr, normalize, lazy, step, id_lists, n_ids, n_lists, 1, (hipStream_t)stream);
-}
-
-int kge_lazy_flush(int32_t kind, float* param, float* state1, float* state2, int64_t rows, int32_t dim, float lr, int32_t normalize,
-                   int32_t normalize_last_step, const kge_lazy_rows* lazy, int64_t step, void* stream) {
-    if (!param || rows <= 0 || dim <= 0 || step < 0) { set_error("kge_lazy_flush: bad arguments"); return -1; }
-    if (lazy && lazy->dev_cursor) { set_error("kge_lazy_flush: the target step is a host argument (dev_cursor must be NULL)"); return -1; }
-    if (step == 0) return 0;
-    return launch_lazy_rows(kind, 1, param, state1, state2, rows, dim, lr, normalize, lazy, step, nullptr, 0, 0, normalize_last_step, (hipStream_t)stream);
+                                 touched_rows, touched_clear, (hipStream_t)stream);
 }
 
 int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,

@@ -117,7 +117,7 @@ constexpr int kSmallGroupMaxR = 4096;      // relations whose three int arrays f
 constexpr int kSmallGroupMaxN = 16384;
 __global__ __launch_bounds__(1024) void k_rel_group_small(IdSplit r, int n, int R, int* __restrict__ offsets, int* __restrict__ tile_off,
                                                           int* __restrict__ perm, int* __restrict__ tile_rel,
-                                                          float* __restrict__ zero_buf, int zero_n, int tile) {
+                                                          float* __restrict__ zero_buf, int zero_n, int tile, PairGather pg) {
     for (int i = threadIdx.x; i < zero_n; i += 1024) zero_buf[i] = 0.f;   // (the scorer's accumulation target: saves a memset launch)
     extern __shared__ int s_grp[];
     int* s_cnt = s_grp;            // [R]   counts, then scatter cursors
@@ -162,16 +162,28 @@ __global__ __launch_bounds__(1024) void k_rel_group_small(IdSplit r, int n, int 
         const int rel = (int)r.at(i);
         const int local = atomicAdd(&s_cnt[rel], 1);
         perm[s_off[rel] + local] = i;
-        if (local % tile == 0) tile_rel[s_toff[rel] + local / tile] = rel;
+        if (local % tile == 0) {
+            tile_rel[s_toff[rel] + local / tile] = rel;
+            // one descriptor per tile: its relation, first grouped position, pairs, and the number of tiles of its relation -- what
+            // a (tile, slab) workgroup of kge_rescal_slab.hip would otherwise collect over three dependent round trips
+            if (pg.tdesc) pg.tdesc[s_toff[rel] + local / tile] =
+                make_int4(rel, s_off[rel] + local, min(tile, s_off[rel + 1] - s_off[rel] - local), s_toff[rel + 1] - s_toff[rel]);
+        }
+        // the pair's four entity ids in GROUPED order (one 16-byte load instead of perm -> four id loads)
+        if (pg.gids) pg.gids[s_off[rel] + local] = make_int4((int)pg.ph[i], (int)pg.pt[i], (int)pg.nh[i], (int)pg.nt[i]);
     }
 }
 
-int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s, float* zero_buf, int64_t zero_n, int tile) {
+bool group_small_ok(int64_t n, int64_t R) { return n <= kSmallGroupMaxN && R <= kSmallGroupMaxR; }
+
+int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s, float* zero_buf, int64_t zero_n, int tile,
+                            const PairGather* pg) {
     if (n <= kSmallGroupMaxN && R <= kSmallGroupMaxR && zero_n <= kSmallGroupMaxN) {
         hipLaunchKernelGGL(k_rel_group_small, dim3(1), dim3(1024), (size_t)(3 * R + 2) * sizeof(int), s, r, (int)n, (int)R, g.offsets,
-                           g.tile_off, g.perm, g.tile_rel, zero_buf, (int)(zero_buf ? zero_n : 0), tile);
+                           g.tile_off, g.perm, g.tile_rel, zero_buf, (int)(zero_buf ? zero_n : 0), tile, pg ? *pg : PairGather{});
         return check_launch("k_rel_group_small");
     }
+    if (pg) { set_error("grouping: the pair gather needs the one-launch grouping (n <= %d, R <= %d)", kSmallGroupMaxN, kSmallGroupMaxR); return -1; }
     if (zero_buf && zero_n > 0) {
         hipError_t ez = hipMemsetAsync(zero_buf, 0, (size_t)zero_n * sizeof(float), s);
         if (ez != hipSuccess) { set_error("grouping: memset: %s", hipGetErrorString(ez)); return -2; }
@@ -576,7 +588,6 @@ __device__ __forceinline__ void ldv(float (&o)[VK], const float* __restrict__ p)
     if constexpr (VK == 4) { const float4 q = *reinterpret_cast<const float4*>(p); o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; }
     else { const float2 q = *reinterpret_cast<const float2*>(p); o[0] = q.x; o[1] = q.y; }
 }
-constexpr int kPairTile = 16;      // pairs per workgroup
 constexpr int kPairSteps = 52;     // V: MFMA steps (two k each) of operand loads in flight per wave
 constexpr int kPairUK = 104;       // U: k covered by the operand loads one wave keeps in flight (13 float4 or 26 float2 per lane)
 
@@ -1391,6 +1402,19 @@ static size_t rescal_pair_ws_bytes(int64_t R, int64_t n) {
     return (size_t)(4 * (R + 1) + n + (n / kPairTile + R + 1) + 8 + n) * sizeof(int);   // (+ n floats of dL/denergy: used from pair_split_min() pairs on)
 }
 
+// Below the split thresholds the step runs as (relation chunk, 32-column slab) workgroups (kge_rescal_slab.hip) when the caller's
+// workspace has room for the V rows and the slabs' energy shares BEHIND the pairwise step's standard layout (two grouping
+// workspaces + 2 n scores, kge_workspace_bytes); KGE_RESCAL_SLAB=0: the one-launch tile kernel k_rescal_pair (A/B).
+static size_t align256d(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t rescal_slab_offset(int64_t R, int64_t n) {
+    return 2 * align256d(group_ws_bytes(R, n)) + align256d((size_t)2 * n * sizeof(float));
+}
+size_t rescal_slab_extra_bytes(const kge_model_desc* m, int64_t n) {
+    if (m->dim % 2 != 0 || m->dim > 256 || n >= kPairSplitG) return 0;
+    if (!group_small_ok(n, m->tot_relation)) return 0;
+    return align256d(rescal_slab_ws_bytes(m->dim, m->tot_relation, n));
+}
+
 bool rescal_pair_step_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
     return m->dim % 2 == 0 && m->dim <= 256 && n < (1ll << 31) && ws_bytes >= rescal_pair_ws_bytes(m->tot_relation, n);
 }
@@ -1403,6 +1427,16 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
     const int64_t R = m->tot_relation;
     if (!rescal_pair_step_ok(m, n, ws_bytes)) { set_error("RESCAL pair step: unsupported shape or workspace"); return -1; }
     const GroupWs g = carve_group_ws(ws, R, n);       // (tile_rel, the last array, holds n / 16 + R + 1 entries here)
+    const size_t slab_off = rescal_slab_offset(R, n), slab_bytes = rescal_slab_extra_bytes(m, n);
+    if (!pair_split(R, n) && slab_bytes != 0 && ws_bytes != (size_t)-1 && ws_bytes >= slab_off + slab_bytes && switch_value("RESCAL_SLAB") != 0) {
+        void* ws_slab = (char*)ws + slab_off;
+        PairGather pg;
+        pg.ph = ph; pg.pt = pt; pg.nh = nh; pg.nt = nt;
+        rescal_slab_gather(ws_slab, k, R, n, &pg);
+        int rcs = group_by_relation_split(id_whole(pr, n), n, R, g, s, nullptr, 0, kSlabChunk, &pg);
+        if (rcs) return rcs;
+        return launch_rescal_slab_step(m, n, g, margin, loss, touched, ws_slab, s);
+    }
     int rc = group_by_relation_split(id_whole(pr, n), n, R, g, s, nullptr, 0, kPairTile);
     if (rc) return rc;
     const size_t lds = rescal_pair_lds_bytes(k);

@@ -165,6 +165,7 @@ int launch_transr_eval_prepare(const kge_model_desc* m, const int64_t* triples, 
 int launch_hinge_coeffs(float* pos, float* neg, int64_t n, float margin, float* loss, hipStream_t s);
 // the whole pairwise RESCAL step in one launch after the grouping (negatives share the positives' relation ids)
 bool rescal_pair_step_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes);
+size_t rescal_slab_extra_bytes(const kge_model_desc* m, int64_t n);   // workspace behind the standard pairwise layout (kge_rescal_slab.hip)
 int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
                             const int64_t* nt, int64_t n, float margin, float* loss, void* ws, size_t ws_bytes, unsigned* touched,
                             hipStream_t s);
@@ -176,11 +177,7 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
 
 int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float lr, int64_t step,
                           int zero_grad, int normalize, const float* dev_hyper, const unsigned* touched, unsigned* touched_clear,
-                          const kge_lazy_rows* lazy, hipStream_t s);
-int launch_lazy_rows(int kind, int mode, float* p, float* s1, float* s2, int64_t rows, int dim, float lr, int normalize,
-                     const kge_lazy_rows* lazy, int64_t step, const int64_t* const* ids, int64_t n_ids, int n_lists, int norm_last,
-                     hipStream_t s);
-void lazy_hyper_fill(float lr, int64_t first_step, int64_t n, float* out);
+                          hipStream_t s);
 
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);

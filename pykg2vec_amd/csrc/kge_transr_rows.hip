@@ -714,30 +714,49 @@ size_t transr_rows_ws_bytes(const kge_model_desc* m, int64_t n) {
 }
 
 bool transr_rows_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
-    return m->dim >= 1 && m->rel_dim >= 1 && m->dim <= 128 && m->rel_dim <= 128 && n >= 1 && n < (1ll << 29) &&
-           ws_bytes >= transr_rows_ws_bytes(m, n);
+    if (!(m->dim >= 1 && m->rel_dim >= 1 && m->dim <= 128 && m->rel_dim <= 128 && n >= 1 && n < (1ll << 29) &&
+          ws_bytes >= transr_rows_ws_bytes(m, n)))
+        return false;
+    // the tile's dynamic LDS (about 101 KB at d = 128) must fit what THIS device grants a workgroup on opt-in; a shape that does
+    // not fit falls back to the tile kernels of kge_transr.hip instead of failing at launch
+    const int nb = (max(m->dim, m->rel_dim) + 15) / 16;
+    int dev = 0, optin = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return transr_rows2_lds_bytes(nb, m->dim) <= (size_t)optin;
 }
 
 template <int NB>
-static void launch_transr_rows_nb(const TransRRowsArgs& a, unsigned tiles, hipStream_t s) {
+static bool launch_transr_rows_nb(const TransRRowsArgs& a, unsigned tiles, hipStream_t s) {
     const bool vec = ((a.de | a.dr) & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(a.ent) | reinterpret_cast<uintptr_t>(a.mat) | reinterpret_cast<uintptr_t>(a.gws)) & 15) == 0;
     const size_t lds = transr_rows2_lds_bytes(NB, a.de);
     const bool l1 = a.l1 != 0;
-    static bool attr_set[4] = {false, false, false, false};   // (per block-count instantiation: once per (VEC, L1) kernel)
-    auto go = [&](auto kern) {
-        bool& done = attr_set[(vec ? 2 : 0) + (l1 ? 1 : 0)];
-        if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); done = true; }
+    // set on every launch (a host-side table write, ~0.1 us): a process-wide "done" flag would leave the attribute unset on a second
+    // device or under a concurrent first launch, and the > 64 KB dynamic-LDS launch would then fail instead of running
+    auto go = [&](auto kern) -> bool {
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("TransR pair step: the device refused %zu bytes of dynamic LDS", lds);
+            return false;
+        }
         hipLaunchKernelGGL(kern, dim3((tiles + 1) / 2 * 2), dim3(256), lds, s, a);
+        return true;
     };
-    if (vec) { if (l1) go(k_transr_rows<NB, true, true>); else go(k_transr_rows<NB, true, false>); }
-    else { if (l1) go(k_transr_rows<NB, false, true>); else go(k_transr_rows<NB, false, false>); }
+    const bool launched = vec ? (l1 ? go(k_transr_rows<NB, true, true>) : go(k_transr_rows<NB, true, false>))
+                              : (l1 ? go(k_transr_rows<NB, false, true>) : go(k_transr_rows<NB, false, false>));
+    if (!launched) return false;
     if (vec && switch_value("TRANSR_G") != 0) {   // (KGE_TRANSR_G=0: the dword-gather form, A/B)
         hipLaunchKernelGGL((k_transr_g2<NB, 3>), dim3((tiles + kTrGRun - 1) / kTrGRun * kTrGRun), dim3(256), 0, s, a);
-        return;
+        return true;
     }
     constexpr int JA = (NB + 1) / 2;   // column blocks per half (an odd NB leaves one masked block in the second half)
     hipLaunchKernelGGL((k_transr_g<NB, JA>), dim3((tiles + kTrGRun - 1) / kTrGRun * kTrGRun, NB > 1 ? 2 : 1), dim3(256), 0, s, a);
+    return true;
 }
 
 // negatives share pr (the caller passed nr == pr); ws: the pairwise step's scorer workspace
@@ -761,16 +780,18 @@ int launch_transr_pair_step(const kge_model_desc* m, const int64_t* ph, const in
     const unsigned tiles = (unsigned)(n / kTrPairTile + R + 1);
     a.tiles = (int)tiles;
     const int nb = (max(m->dim, m->rel_dim) + 15) / 16;
+    bool ok;
     switch (nb) {
-        case 1: launch_transr_rows_nb<1>(a, tiles, s); break;
-        case 2: launch_transr_rows_nb<2>(a, tiles, s); break;
-        case 3: launch_transr_rows_nb<3>(a, tiles, s); break;
-        case 4: launch_transr_rows_nb<4>(a, tiles, s); break;
-        case 5: launch_transr_rows_nb<5>(a, tiles, s); break;
-        case 6: launch_transr_rows_nb<6>(a, tiles, s); break;
-        case 7: launch_transr_rows_nb<7>(a, tiles, s); break;
-        default: launch_transr_rows_nb<8>(a, tiles, s); break;
+        case 1: ok = launch_transr_rows_nb<1>(a, tiles, s); break;
+        case 2: ok = launch_transr_rows_nb<2>(a, tiles, s); break;
+        case 3: ok = launch_transr_rows_nb<3>(a, tiles, s); break;
+        case 4: ok = launch_transr_rows_nb<4>(a, tiles, s); break;
+        case 5: ok = launch_transr_rows_nb<5>(a, tiles, s); break;
+        case 6: ok = launch_transr_rows_nb<6>(a, tiles, s); break;
+        case 7: ok = launch_transr_rows_nb<7>(a, tiles, s); break;
+        default: ok = launch_transr_rows_nb<8>(a, tiles, s); break;
     }
+    if (!ok) return -1;
     return check_launch("k_transr_rows / k_transr_g");
 }
 

@@ -451,74 +451,6 @@ def optimizer_step_rows(kind, param, grad, state1, state2, rows, dim, lr, step, 
                                              _stream()), "kge_optimizer_step_rows")
 
 
-class LazyRows:
-    """State of the exact lazy row optimiser for ONE [rows, dim] table (struct kge_lazy_rows, csrc/kge_opt.hip): `last[row]` = the
-    last optimiser step applied to the row, and the per-step bias-correction table every replay reads (built on the host by
-    kge_lazy_hyper_fill -- the same double-precision scalars torch.optim computes -- and uploaded; grown by doubling)."""
-
-    MIN_CAP = 1 << 16
-
-    def __init__(self, rows, lr, device, steps=0):
-        self.lr, self.device = float(lr), device
-        self.last = torch.zeros(int(rows), dtype=torch.int32, device=device)
-        self.cap, self.hyper = 0, None
-        self.ensure(steps)
-
-    def ensure(self, upto):
-        """Make the table cover step indices <= upto.  Returns True when it was reallocated (captured graphs hold the old pointer)."""
-        import numpy as np
-        if upto < self.cap:
-            return False
-        cap = max(self.MIN_CAP, 2 * (int(upto) + 1))
-        host = np.empty((cap, 2), dtype=np.float32)
-        L.check(L.load().kge_lazy_hyper_fill(self.lr, 0, cap, host.ctypes.data_as(ctypes.c_void_p)), "kge_lazy_hyper_fill")
-        self.hyper, self.cap = torch.from_numpy(host).to(self.device), cap
-        return True
-
-    def c(self, cursor=None):
-        return L.LazyRows(self.last.data_ptr(), self.hyper.data_ptr(), self.cap,
-                          _dev(cursor, torch.int64, "cursor").value if cursor is not None else None)
-
-
-def optimizer_step_rows_lazy(kind, param, grad, state1, state2, rows, dim, lr, step, lazy, touched, touched_clear=None, zero_grad=True,
-                             normalize=False, cursor=None):
-    """kge_optimizer_step_rows_lazy: step only the rows of the touched-row bitmap (they were caught up by lazy_catchup)."""
-    p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
-    p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
-    z = lazy.c(cursor)
-    L.check(L.load().kge_optimizer_step_rows_lazy(OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"), _dev(grad, torch.float32, "grad"),
-                                                  p1, p2, int(rows), int(dim), float(lr), int(step), 1 if zero_grad else 0,
-                                                  1 if normalize else 0, _dev(touched, torch.int32, "touched"),
-                                                  _dev(touched_clear, torch.int32, "touched_clear") if touched_clear is not None else None,
-                                                  ctypes.byref(z), _stream()), "kge_optimizer_step_rows_lazy")
-
-
-def lazy_catchup(kind, param, state1, state2, rows, dim, lr, lazy, step, id_lists, normalize=False, cursor=None):
-    """kge_lazy_catchup: replay the missed zero-gradient steps of the rows named by `id_lists` (1..4 int64 tensors of equal length)
-    up to step - 1, before a forward reads them."""
-    p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
-    p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
-    n = id_lists[0].numel()
-    arr = (ctypes.c_void_p * 4)()
-    for i, t in enumerate(id_lists):
-        if t.numel() != n:
-            raise ValueError("lazy_catchup: id lists must have equal lengths")
-        arr[i] = _ids(t, "id list %d" % i).value
-    z = lazy.c(cursor)
-    L.check(L.load().kge_lazy_catchup(OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"), p1, p2, int(rows), int(dim), float(lr),
-                                      1 if normalize else 0, ctypes.byref(z), int(step), ctypes.addressof(arr), len(id_lists), int(n),
-                                      _stream()), "kge_lazy_catchup")
-
-
-def lazy_flush(kind, param, state1, state2, rows, dim, lr, lazy, step, normalize=False, normalize_last=True):
-    """kge_lazy_flush: every row to `step` (before the tables are observed)."""
-    p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
-    p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
-    z = lazy.c(None)
-    L.check(L.load().kge_lazy_flush(OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"), p1, p2, int(rows), int(dim), float(lr),
-                                    1 if normalize else 0, 1 if normalize_last else 0, ctypes.byref(z), int(step), _stream()), "kge_lazy_flush")
-
-
 def rescal_pair_step_ok(desc, n):
     return bool(L.load().kge_rescal_pair_step_ok(ctypes.byref(desc), int(n)))
 

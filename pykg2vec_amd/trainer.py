@@ -109,24 +109,18 @@ class FlatState:
         self.K.optimizer_step_advance(self.optimizer, self.param_shard, self.grad_shard, self.state1, self.state2, lr, hyper,
                                       cursor, next_cursor, next_hyper, batch_stride, n_batches, draws, zero_grad=True)
 
-    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None, touched=None, touched_clear=None, lazy=None):
+    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None, touched=None, touched_clear=None):
         """The optimiser step with the FIRST table ([rows, dim], at offset 0 of the flat buffers) handled by the row-owner kernel
         (which can store the rows renormalised: RESCAL) and the remaining tables by the flat sweep.  advance: as
-        optimizer_step_advance (device-resident step state of hipGraph-replayed steps); single GPU only.
-        lazy (kernels.LazyRows): step only the rows of `touched`; every other row stays behind until somebody needs it."""
+        optimizer_step_advance (device-resident step state of hipGraph-replayed steps); single GPU only."""
         self.step += 1
         n0 = rows * dim
         cut = self.offsets[1] if len(self.offsets) > 1 else self.numel
         sl = lambda buf, a, b: buf[a:b] if buf is not None else None
         hyper = advance[0] if advance is not None else None
-        if lazy is not None:
-            self.K.optimizer_step_rows_lazy(self.optimizer, self.param[:n0], self.grad[:n0], sl(self.state1, 0, n0), sl(self.state2, 0, n0),
-                                            rows, dim, lr, self.step, lazy, touched, touched_clear, zero_grad=True, normalize=normalize,
-                                            cursor=advance[1] if advance is not None else None)
-        else:
-            self.K.optimizer_step_rows(self.optimizer, self.param[:n0], self.grad[:n0], sl(self.state1, 0, n0), sl(self.state2, 0, n0),
-                                       rows, dim, lr, self.step, zero_grad=True, normalize=normalize, dev_hyper=hyper,
-                                       touched=touched, touched_clear=touched_clear)
+        self.K.optimizer_step_rows(self.optimizer, self.param[:n0], self.grad[:n0], sl(self.state1, 0, n0), sl(self.state2, 0, n0),
+                                   rows, dim, lr, self.step, zero_grad=True, normalize=normalize, dev_hyper=hyper,
+                                   touched=touched, touched_clear=touched_clear)
         rest = (self.param[cut:], self.grad[cut:], sl(self.state1, cut, self.numel), sl(self.state2, cut, self.numel))
         if advance is not None:
             self.K.optimizer_step_advance(self.optimizer, *rest, lr, *advance, zero_grad=True)
@@ -242,7 +236,7 @@ class Trainer:
         return {"pull": flag("KGE_PULL"), "staged": flag("KGE_STAGED"), "graph_multi": flag("KGE_GRAPH_MULTI"),
                 "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED"),
                 "rescal_unfused": flag("KGE_RESCAL_UNFUSED"), "pull_dir": flag("KGE_PULL_DIR"),
-                "transx_own": flag("KGE_TRANSX_OWN"), "own_staged": flag("KGE_OWN_STAGED"), "lazy_opt": flag("KGE_LAZY_OPT"),
+                "transx_own": flag("KGE_TRANSX_OWN"), "own_staged": flag("KGE_OWN_STAGED"),
                 "dp_sparse": flag("KGE_DP_SPARSE"),
                 "dp_allreduce": flag("KGE_DP_ALLREDUCE")}
 
@@ -323,17 +317,6 @@ class Trainer:
                 # step's optimiser resets the other one.  (A parity that repeats after an epoch boundary only leaves stale
                 # bits behind: rows read needlessly, never a gradient missed.)
                 par = self._touch_parity
-                lz = self._lazy_rows()
-                if lz is not None:
-                    # exact lazy optimiser: rows that were not touched for a while are behind by zero-gradient steps; replay those of
-                    # the rows this batch reads (up to the previous step) before the forward gathers them (csrc/kge_opt.hip)
-                    ent, flat = self.flat.views[0], self.flat
-                    n0 = ent.numel()
-                    cur = getattr(self, "_step_cursor", None)
-                    self.K.lazy_catchup(self.config.optimizer, flat.param[:n0], flat.state1[:n0] if flat.state1 is not None else None,
-                                        flat.state2[:n0] if flat.state2 is not None else None, ent.shape[0], ent.shape[1],
-                                        self.config.learning_rate, lz, flat.step + 1, (ph, pt, nh, nt), normalize=True, cursor=cur)
-                    self._lazy_dirty = True
                 self.K.rescal_pair_step(self._desc, ph, pr, pt, nh, nt, self.config.margin, self.loss_buf, touched=self._touched_bitmaps()[par])
                 self._touched_step = par
                 return
@@ -939,49 +922,6 @@ class Trainer:
         # launch costs more than the pass it saves (FB15k preset, 3 MB: 64.5 -> 68.6 us)
         return self.flat.views[0].numel() * 4 >= (32 << 20)
 
-    def _lazy_rows(self):
-        """The exact lazy form of the entity table's dense optimiser (RESCAL inside an epoch, csrc/kge_opt.hip): only the rows a step
-        touched are stepped, the rows a batch reads are first caught up by replaying their missed zero-gradient steps, everything
-        is flushed when the epoch ends.  Bit-identical to the dense sweep, and -- measured -- not faster than it (see
-        _lazy_begin_epoch): opt-in with KGE_LAZY_OPT=1.  Decided once per epoch."""
-        if not getattr(self, "_lazy_epoch", False):
-            return None
-        return self._lazy
-
-    def _lazy_begin_epoch(self, num_batch):
-        self._lazy_epoch = False
-        # Opt-in (KGE_LAZY_OPT=1).  Measured at the C4 shape, same box, us per step dense -> lazy (profiles/r04_c4_lazy_ab.txt,
-        # r04_experiments.md section 1): Adam 185 -> 301, RMSprop 158 -> 172, SGD 113 -> 134, Adagrad 154 -> 138.  Every row of C4 is
-        # touched every ~40 steps, so with Adam its moments never reach zero and each missed step costs the full update (IEEE sqrt,
-        # two divisions, the row renormalisation): the replays run at 0.28 T element-steps/s of VALU -- no faster than the dense sweep
-        # streams (0.23 T/s at 5.5 TB/s) -- and the longest chain of a batch (a row behind by hundreds of steps) sets the launch
-        # time.  Without Adam p is a fixed point of the optimiser, but fp32 renormalisation of a unit row need not settle (it can
-        # alternate between two neighbouring rows), so those replays run their full length too.  The dense sweep stays the default.
-        want = bool(self.switches.get("lazy_opt"))
-        if not want or not self._rescal_fused():
-            return
-        ent = self.flat.views[0]
-        if ent.shape[1] % 4 or ent.shape[1] > 1024 or not self.K.rescal_pair_step_ok(self._desc, int(self.config.batch_size)):
-            return
-        if int(self.config.batch_size) * 8 > ent.shape[0]:
-            return   # a batch that touches a large part of the table: the dense sweep is the cheaper way to move every row
-        if getattr(self, "_lazy", None) is None:
-            self._lazy = K.LazyRows(ent.shape[0], self.config.learning_rate, ent.device)
-        self._lazy.last.fill_(self.flat.step)           # between epochs every row is current (flushed, or stepped densely)
-        if self._lazy.ensure(self.flat.step + num_batch + 1):
-            self._graph = None                          # captured steps hold the old table's address: capture again
-        self._lazy_epoch, self._lazy_dirty = True, False
-
-    def _lazy_flush(self):
-        """Bring every row to the current step (the epoch's last step leaves the tables un-normalised, as the reference's are)."""
-        if getattr(self, "_lazy_epoch", False) and getattr(self, "_lazy_dirty", False):
-            ent, flat = self.flat.views[0], self.flat
-            n0 = ent.numel()
-            self.K.lazy_flush(self.config.optimizer, flat.param[:n0], flat.state1[:n0] if flat.state1 is not None else None,
-                              flat.state2[:n0] if flat.state2 is not None else None, ent.shape[0], ent.shape[1],
-                              self.config.learning_rate, self._lazy, flat.step, normalize=True, normalize_last=False)
-            self._lazy_dirty = False
-
     def _mean_type_loss(self):
         """pointwise_logistic and the self-adversarial loss are MEANS over the batch (criterion.py:13-23,31-34);
         the hinge is a SUM (criterion.py:25-29)."""
@@ -1085,13 +1025,9 @@ class Trainer:
                 ent = flat.views[0]
                 par, self._touched_step = self._touched_step, None
                 bm = self._touched_bitmaps() if par is not None else (None, None)
-                lz = self._lazy_rows()
-                if lz is not None and par is None:
-                    raise K.L.KgeHipError("lazy RESCAL optimiser: a step without the pair kernel's touched-row bitmap (dense and lazy steps "
-                                          "cannot be mixed inside an epoch)")
                 flat.optimizer_step_rows_first(self.config.learning_rate, ent.shape[0], ent.shape[1], keep, advance,
                                                touched=bm[par] if par is not None else None,
-                                               touched_clear=bm[1 - par] if par is not None else None, lazy=lz)
+                                               touched_clear=bm[1 - par] if par is not None else None)
                 self._touch_parity ^= 1
                 if keep:
                     self.K.rescal_normalize_relations(flat.views[1], self.model.hidden_size)
@@ -1248,12 +1184,10 @@ class Trainer:
         self.model.train()
         # RESCAL (see _reduce_and_step): inside the epoch the optimiser hands the tables to the next step already renormalised
         self._in_epoch, self._rescal_normalised, self._rescal_last = True, False, num_batch == 1
-        self._lazy_begin_epoch(num_batch)
         try:
             return self._train_epoch_body(epoch_idx, num_batch)
         finally:
             self._in_epoch, self._rescal_normalised, self._rescal_last = False, False, False
-            self._lazy_epoch = False
 
     def _train_epoch_body(self, epoch_idx, num_batch):
         if num_batch > 0 and self._graph_wanted(num_batch):
@@ -1292,7 +1226,6 @@ class Trainer:
                 self._pull_state()[0].sync_in()   # the tables may have been changed from outside since the last epoch
             self.step_next_batches(num_batch)
             self.sync_model()
-        self._lazy_flush()      # rows the lazy optimiser left behind: current before anybody looks at the tables
         acc = self.K.read_loss(self.loss_buf)
         if self.distributed:
             torch.distributed.all_reduce(acc, group=self.process_group)

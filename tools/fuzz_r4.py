@@ -1,8 +1,6 @@
 #!/usr/bin/env python
 """Randomised sweeps of the round-4 entry points on one MI355X:
   csr    kge_filter_csr_* against the dict-of-sets form (random E / R / split sizes / duplicates / absent keys)
-  lazy   kge_lazy_catchup + kge_optimizer_step_rows_lazy + kge_lazy_flush against the dense kge_optimizer_step_rows sweep, bit for bit
-         (random table shapes, optimisers, renormalisation on / off, touch patterns, flush points)
   ids    debug mode: one bad id at a random position of a random id-taking entry point must be reported at exactly that position
 Usage: ITERS=60 SEED=1 python tools/fuzz_r4.py      (exit code 1 on any violation)"""
 import os, sys
@@ -42,57 +40,6 @@ for it in range(ITERS):
             break
     n_q += n
 print("csr: %d cases, %d queries, bad so far %d" % (ITERS, n_q, bad), flush=True)
-
-# ---------------------------------------------------------------- lazy vs dense
-def bitmap(rows, n_rows):
-    w = np.zeros((n_rows + 31) // 32, dtype=np.uint32)
-    r = np.unique(np.asarray(rows, dtype=np.int64))
-    np.bitwise_or.at(w, r >> 5, (np.uint32(1) << (r & 31).astype(np.uint32)))
-    return torch.from_numpy(w.view(np.int32)).to(dev)
-
-steps_total = 0
-for it in range(ITERS):
-    kind = str(rng.choice(["adam", "rms", "adagrad", "sgd"]))
-    norm = bool(rng.random() < 0.5)
-    rows = int(rng.integers(8, 700))
-    dim = int(rng.choice([4, 8, 36, 100, 128, 200, 260, 512, 1024]))
-    T = int(rng.integers(5, 90))
-    lr = float(rng.choice([0.001, 0.01, 0.1]))
-    p0 = (rng.normal(size=(rows, dim)) * rng.choice([0.01, 0.3, 2.0])).astype(np.float32)
-    if norm:
-        p0 /= np.maximum(np.linalg.norm(p0, axis=1, keepdims=True), 1e-12)
-    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
-    state = lambda: (torch.zeros(rows, dim, device=dev) if kind != "sgd" else None, torch.zeros(rows, dim, device=dev) if kind == "adam" else None)
-    pd, (md, vd) = f32(p0), state()
-    pl, (ml, vl) = f32(p0), state()
-    gd, gl = torch.zeros(rows, dim, device=dev), torch.zeros(rows, dim, device=dev)
-    lazy = K.LazyRows(rows, lr, dev)
-    bm = [torch.zeros((rows + 31) // 32, dtype=torch.int32, device=dev) for _ in range(2)]
-    v = lambda t: t.view(-1) if t is not None else None
-    flush_at = set(rng.integers(1, T + 1, size=2).tolist())
-    for t in range(1, T + 1):
-        k = int(rng.integers(0, max(1, rows // 6)))
-        S = rng.choice(rows, size=k, replace=False) if k else np.zeros(0, np.int64)
-        extra = rng.integers(rows, size=3)
-        if k:
-            g = (rng.normal(size=(k, dim)) * rng.choice([1e-4, 1.0])).astype(np.float32)
-            gd[mk(S)] = f32(g); gl[mk(S)] = f32(g)
-        K.optimizer_step_rows(kind, v(pd), v(gd), v(md), v(vd), rows, dim, lr, t, zero_grad=True, normalize=norm)
-        ids = np.concatenate([S, extra, extra[:1]])
-        pad = np.resize(ids, ((len(ids) + 1) // 2) * 2).reshape(2, -1)
-        K.lazy_catchup(kind, v(pl), v(ml), v(vl), rows, dim, lr, lazy, t, [mk(pad[0]), mk(pad[1])], normalize=norm)
-        par = t & 1
-        bm[par].copy_(bitmap(S, rows)) if k else bm[par].zero_()
-        K.optimizer_step_rows_lazy(kind, v(pl), v(gl), v(ml), v(vl), rows, dim, lr, t, lazy, bm[par], bm[1 - par], normalize=norm)
-        if t in flush_at or t == T:
-            K.lazy_flush(kind, v(pl), v(ml), v(vl), rows, dim, lr, lazy, t, normalize=norm, normalize_last=True)
-            ok = torch.equal(pl, pd) and (md is None or torch.equal(ml, md)) and (vd is None or torch.equal(vl, vd))
-            if not ok:
-                bad += 1
-                print("lazy mismatch", it, kind, norm, rows, dim, "at step", t)
-                break
-    steps_total += T
-print("lazy: %d cases, %d steps, bad so far %d" % (ITERS, steps_total, bad), flush=True)
 
 # ---------------------------------------------------------------- debug ids
 K.set_debug(True)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B inside ONE gpurun lease (box-to-box spread is +-8 %, so accept / reject decisions need both arms on one box).
 # Usage (through gpurun):  bash tools/gpu_ab.sh <tag> <rounds> "<arm A: env assignments>" "<arm B: env assignments>" -- <command ...>
-#   an arm is a (possibly empty) list of VAR=value words, e.g. "KGE_LAZY_OPT=0" or "KGE_HIP_LIB=tools/_libs/variant.so";
+#   an arm is a (possibly empty) list of VAR=value words, e.g. "KGE_RESCAL_SLAB=0" or "KGE_HIP_LIB=tools/_libs/variant.so";
 #   the command's stdout of every run is appended to gpurun_out/<tag>_ab.log under a header naming the arm.
 ulimit -c 0
 cd "$GRAFT_REPO_ROOT" || exit 1
