@@ -387,7 +387,8 @@ typedef struct kge_pull_lists {
 /* Two-phase ("staged direction") form of the step, selected by passing a kge_pull_direction with non-NULL buffers: phase 1
  * (k_pull_eval) evaluates every pair of the batch ONCE -- same gathers and arithmetic as an owner's visit -- and leaves a
  * 16-byte record (hinge coefficient, both energies, which side was corrupted) plus the signed direction of both residuals
- * (L1: 2 bits per element; L2: the residual rows); phase 2 is the owner-computes kernel with visits that read those records
+ * (2 bits per element; L1 models only -- a direction passed with an L2 model is ignored: both evaluate-once forms of L2 measured
+ * slower than its one-phase step and were removed); phase 2 is the owner-computes kernel with visits that read those records
  * instead of re-evaluating the pair (3.25 evaluations per pair -> 1).  Same gradients bit for bit (same coefficients, same fused
  * multiply-adds in the same order); the loss is accumulated by phase 1.  lists_without_descriptors != 0: the sampler riding in
  * this launch skips sdesc / dbucket (the NEXT step must then also be two-phase). */

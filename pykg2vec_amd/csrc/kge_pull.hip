@@ -59,8 +59,7 @@ struct PullArgs {
     const float* theta;        // TransM (pairwise.py:341-347): fixed per-relation weight of both energies; NULL = TransE
     // two-phase ("staged direction") form: k_pull_eval leaves one record per pair, the owners of k_pull_step<..., DIR> sum them
     float4* recs;              // [n_pairs] (coef * theta, energy(+), energy(-), tail as 0 / 1)
-    void* codes;               // [n_pairs][2][G * NV] L1: one byte per lane = the signs of its four residual elements (2 bits each);
-                               //                       L2: float4 per lane = the residuals themselves
+    void* codes;               // [n_pairs][2][G * NV] one byte per lane = the signs of its four residual elements (2 bits each)
     int64_t n_pairs;
 };
 
@@ -161,7 +160,7 @@ struct PullRows {
 
 // ---- phase 1 of the two-phase form: every pair of the batch is evaluated ONCE by one lane group -- the same four gathers, the
 // same arithmetic in the same order as a visit of k_pull_step -- and leaves a record: the hinge coefficient, and the signed
-// direction of both residuals (L1: two bits per element; L2: the residual rows and their norms).  No sampling here: the draw was
+// direction of both residuals (two bits per element).  L1 only (see launch_pull_step).  No sampling here: the draw was
 // registered by the sampler riding in the previous step's launch.
 // kEvalPP pairs per lane group, their descriptors and then their four rows requested together (independent chains): half the
 // workgroups -- 2 048 at B = 32 768, ONE residency round of 8 x 256 workgroups instead of two -- and half the workgroup launches
@@ -245,10 +244,6 @@ __global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restr
                     cp[v * G + gl] = (unsigned char)bp;
                     cp[G * NV + v * G + gl] = (unsigned char)bn;
                 }
-            } else {
-                float4* cp = reinterpret_cast<float4*>(a.codes) + i * (int64_t)(2 * G * NV);
-#pragma unroll
-                for (int v = 0; v < NV; ++v) { cp[v * G + gl] = up[v]; cp[G * NV + v * G + gl] = un[v]; }
             }
         }
     }
@@ -258,6 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restr
 
 template <int OPT, bool L1, int G, int NV, bool DIR = false>
 __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs sa, float* __restrict__ loss) {
+    static_assert(!DIR || L1, "the two-phase form exists for L1 only");
     constexpr int GPB = kBlock / G;
     KGE_TS_BEGIN(0)
     if ((int)blockIdx.x < a.sample_blocks) {   // leading blocks: the sampler of the NEXT batch rides along (writes the other list set)
@@ -317,8 +313,8 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
             // two-phase form: a visit is the pair's record + this lane's share of its two direction codes -- no row gathers,
             // no reductions.  Same coefficients, same fused multiply-adds in the same order as the one-phase visit below.
             const int* __restrict__ vis = reinterpret_cast<const int*>(s_desc[threadIdx.x / G]);
-            using RecT = typename std::conditional<L1, float, float4>::type;   // L1 needs only the signed coefficient
-            auto rec_x = [](const RecT& r) { if constexpr (L1) return r; else return r.x; };
+            using RecT = float;                                 // a visit needs only the signed coefficient of the pair's record
+            auto rec_x = [](const RecT& r) { return r; };
             // The owner kernel is VALU-bound (SQ_ACTIVE_INST_VALU: 0.75 of its SIMD cycles, ~1 000 VALU instructions per wave, most of
             // them in the visits), so a visit is kept short: the own row's coefficients in up / un come out of two 16-bit tables of
             // 2-bit two's-complement entries indexed by (role, tail), the direction codes decode with one v_bfe_i32 each, and TransE
@@ -363,19 +359,9 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                         gs[v2].w = fmaf(sv, KGE_DEC(bn, 6), fmaf(su, KGE_DEC(bp, 6), gs[v2].w));
 #undef KGE_DEC
                     }
-                } else {
-                    if constexpr (!L1) {
-                        su = rec.y > 0.f ? su / rec.y : 0.f;
-                        sv = rec.z > 0.f ? sv / rec.z : 0.f;
-                    }
-#pragma unroll
-                    for (int v2 = 0; v2 < NV; ++v2) {
-                        gs[v2].x = fmaf(sv, cnv[v2].x, fmaf(su, cpv[v2].x, gs[v2].x)); gs[v2].y = fmaf(sv, cnv[v2].y, fmaf(su, cpv[v2].y, gs[v2].y));
-                        gs[v2].z = fmaf(sv, cnv[v2].z, fmaf(su, cpv[v2].z, gs[v2].z)); gs[v2].w = fmaf(sv, cnv[v2].w, fmaf(su, cpv[v2].w, gs[v2].w));
-                    }
                 }
             };
-            using CodeT = typename std::conditional<L1, unsigned, float4>::type;
+            using CodeT = unsigned;
             auto load_codes = [&](int pair, CodeT (&cpv)[NV], CodeT (&cnv)[NV]) {
                 if constexpr (L1) {
                     // (32-bit byte offsets from the uniform base: one shift-add per visit instead of 64-bit address arithmetic per load;
@@ -384,16 +370,12 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                     const unsigned off = (unsigned)pair * (unsigned)(2 * G * NV) + (unsigned)gl;
 #pragma unroll
                     for (int v2 = 0; v2 < NV; ++v2) { cpv[v2] = cbase[off + (unsigned)(v2 * G)]; cnv[v2] = cbase[off + (unsigned)(G * NV + v2 * G)]; }
-                } else {
-                    const float4* cp = reinterpret_cast<const float4*>(a.codes) + pair * (int64_t)(2 * G * NV);
-#pragma unroll
-                    for (int v2 = 0; v2 < NV; ++v2) { cpv[v2] = cp[v2 * G + gl]; cnv[v2] = cp[G * NV + v2 * G + gl]; }
                 }
             };
 #ifndef KGE_DIR_BATCH
 #define KGE_DIR_BATCH 4
 #endif
-            constexpr int kDirBatch = L1 ? KGE_DIR_BATCH : 2;     // visits whose records and codes are requested before the first is summed
+            constexpr int kDirBatch = KGE_DIR_BATCH;     // visits whose records and codes are requested before the first is summed
 #ifdef KGE_DIR_NOVISIT   /* timing experiment only: how long is phase 2 without its visits? */
             nvis = 0;
 #endif
@@ -405,8 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                 for (int q = 0; q < kDirBatch; ++q) {
                     e[q] = v0 + q < nvis ? vis[v0 + q] : -1;
                     const int pair = e[q] >= 0 ? (e[q] >> 2) : 0;
-                    if constexpr (L1) rec[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.recs) + (unsigned)pair * 16u);
-                    else rec[q] = a.recs[pair];
+                    rec[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.recs) + (unsigned)pair * 16u);
                     load_codes(pair, cpv[q], cnv[q]);
                 }
 #pragma unroll
@@ -424,8 +405,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
                     CodeT c1[NV], c2[NV];
                     load_codes(best, c1, c2);
                     RecT rb;
-                    if constexpr (L1) rb = reinterpret_cast<const float*>(a.recs)[4 * (int64_t)best];
-                    else rb = a.recs[best];
+                    rb = reinterpret_cast<const float*>(a.recs)[4 * (int64_t)best];
                     visit_dir((best << 2) | kRoleC, rb, c1, c2);
                     last = best;
                 }
@@ -697,15 +677,10 @@ static int launch_pull_geo(PullArgs& a, const PullSampleArgs& sa, float* loss, h
     constexpr int GPB = kBlock / G;
     const int item_blocks = (int)((a.n_items + (a.dense_skip ? a.n_rows : 0) + GPB - 1) / GPB);
     a.sample_blocks = sa.n > 0 ? (int)((sa.n + kBlock - 1) / kBlock) : 0;
-    if (a.recs) {   // two-phase form: evaluate every pair once, then let the owners sum the records
+    if (a.recs) {   // two-phase form (L1 only): evaluate every pair once, then let the owners sum the records
         const unsigned eb = (unsigned)((a.n_pairs + GPB * kEvalPP - 1) / (GPB * kEvalPP));
-        if (a.l1) {
-            hipLaunchKernelGGL((k_pull_eval<true, G, NV>), dim3(eb), dim3(kBlock), 0, s, a, loss);
-            hipLaunchKernelGGL((k_pull_step<OPT, true, G, NV, true>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
-        } else {
-            hipLaunchKernelGGL((k_pull_eval<false, G, NV>), dim3(eb), dim3(kBlock), 0, s, a, loss);
-            hipLaunchKernelGGL((k_pull_step<OPT, false, G, NV, true>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
-        }
+        hipLaunchKernelGGL((k_pull_eval<true, G, NV>), dim3(eb), dim3(kBlock), 0, s, a, loss);
+        hipLaunchKernelGGL((k_pull_step<OPT, true, G, NV, true>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
     } else if (a.l1)
         hipLaunchKernelGGL((k_pull_step<OPT, true, G, NV>), dim3((unsigned)(item_blocks + a.sample_blocks)), dim3(kBlock), 0, s, a, sa, loss);
     else
@@ -727,7 +702,7 @@ static int launch_pull_opt(PullArgs& a, const PullSampleArgs& sa, PullGeo g, flo
 // bytes of the two-phase form's scratch for n pairs: direction codes (L1: one byte per lane and residual; L2: a float4) and records
 void pull_direction_bytes(int dim, int l1, int64_t n, size_t* codes, size_t* recs) {
     const PullGeo g = pull_geo(dim);
-    *codes = g.G ? (size_t)n * 2 * g.G * g.NV * (l1 ? 1 : 16) : 0;
+    *codes = g.G ? (l1 ? (size_t)n * 2 * g.G * g.NV : (size_t)16) : 0;   // (L2 has no two-phase form: the buffers only have to exist)
     *recs = (size_t)n * 16;
 }
 int pull_partial_stride(int dim) { const PullGeo g = pull_geo(dim); return 4 * g.G * g.NV; }
@@ -771,12 +746,17 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
     a.theta = m->model == KGE_TRANSM ? m->tables[2] : nullptr;
     a.opt = make_opt_args(lr, step < 1 ? 1 : step);
     a.dev_hyper = dev_hyper;
-    a.recs = dir && dir->recs ? reinterpret_cast<float4*>(dir->recs) : nullptr;
-    a.codes = dir ? dir->codes : nullptr;
-    a.n_pairs = dir ? dir->n_pairs : 0;
+    // The two-phase form exists for L1 only.  For L2 both evaluate-once forms lost to the one-phase step on the same box and were
+    // removed: residual rows staged by phase 1 (1 KB per pair: 46.3 -> 53.6 us, round 3) and records of the two scalars with the owners
+    // recomputing the residuals from their four gathers (45.9 -> 51.3 us, profiles/r05_l2_mid_ab.txt) -- an L2 visit is bound by its
+    // row gathers, not by the reductions an evaluate-once form saves.  A direction passed with an L2 model is ignored.
+    const bool two_phase = dir && dir->recs && (m->flags & KGE_FLAG_L1);
+    a.recs = two_phase ? reinterpret_cast<float4*>(dir->recs) : nullptr;
+    a.codes = two_phase ? dir->codes : nullptr;
+    a.n_pairs = two_phase ? dir->n_pairs : 0;
     PullSampleArgs sa = make_sample_args(next_pairs, next_inv, next_pairs && next_lists ? next_n : 0, m->tot_entity, bern, slots,
                                          n_slots, seed, next_offset, nullptr, next_lists);
-    sa.no_desc = a.recs && dir->lists_without_descriptors ? 1 : 0;
+    sa.no_desc = two_phase && dir->lists_without_descriptors ? 1 : 0;
     switch (optimizer) {
         case KGE_OPT_SGD: return launch_pull_opt<KGE_OPT_SGD>(a, sa, geo, loss, s);
         case KGE_OPT_ADAM: return launch_pull_opt<KGE_OPT_ADAM>(a, sa, geo, loss, s);

@@ -503,12 +503,15 @@ class Trainer:
     def _pull_two_phase(self):
         """The owner-computes step in two launches: every pair evaluated once, the owners sum the pairs' records
         (csrc/kge_pull.hip: k_pull_eval + k_pull_step<..., DIR>).  KGE_PULL_DIR=0 / 1 overrides."""
+        if not bool(getattr(self.model, "l1_flag", False)):
+            return False
         if self.switches.get("pull_dir") is not None:
             return self.switches["pull_dir"]
         # measured (profiles/r03_experiments.md section 11): L1, B = 32768: 35.0 -> 30.3 us per step (TransM 47.4 -> 44.9);
         # B = 16384: 31.5 -> 30.8, B = 8192: 27.3 -> 23.7, B = 4096: 19.1 -> 20.4, B = 128: 13.0 -> 15.6 (a second launch costs
         # more than the re-evaluations it saves);
-        # L2: 46.3 -> 53.6 (the direction of an L2 residual is a float row, 1 KB per pair, not 2 bits per element)
+        # L2 has no two-phase form: staged residual rows (46.3 -> 53.6 us) and the scalar-record form whose owners recompute the
+        # residuals from their gathers (45.9 -> 51.3 us, profiles/r05_l2_mid_ab.txt) both lost to the one-phase step and were removed
         return bool(getattr(self.model, "l1_flag", False)) and int(self.config.batch_size) >= self.PULL_TWO_PHASE_MIN_BATCH
 
     def _pull_state(self):

@@ -203,3 +203,33 @@ def table_digest(w, rows):
     rows in full (first DIGEST_COLS columns)."""
     w64 = np.asarray(w, dtype=np.float64)
     return w64.sum(1).astype(np.float32), np.abs(w64).sum(1).astype(np.float32), np.asarray(w)[rows][:, :DIGEST_COLS].copy()
+
+
+# ---- a learnable synthetic graph for trajectory-level parity (oracle/make_golden_trajectory.py, tests/test_hip_trajectory.py):
+# triples (h, r, t) with t the entity nearest (L1) to ent[h] + rel[r] in a planted 8-dimensional translation model
+TRAJECTORY = {
+    "transe_l1_adam": dict(model="transe", ref="pairwise.TransE", hp=dict(hidden_size=32, l1_flag=True, margin=1.0), optimizer="adam", lr=0.01,
+                           batch=256, neg=1, epochs=30),
+    "complex_adagrad": dict(model="complex", ref="pointwise.Complex", hp=dict(hidden_size=32, lmbda=1e-5), optimizer="adagrad", lr=0.1,
+                            batch=256, neg=1, epochs=30),
+    "rotate_adam": dict(model="rotate", ref="pairwise.RotatE", hp=dict(hidden_size=32, margin=6.0, alpha=1.0), optimizer="adam", lr=0.01,
+                        batch=256, neg=4, epochs=30),
+}
+TRAJECTORY_SEEDS = 5
+TRAJECTORY_TEST = 200
+
+
+def planted_graph(seed=7, E=400, R=6, dp=8):
+    """(E, R, train, valid, test) int64 triples of the planted translation graph."""
+    rng = np.random.default_rng(seed)
+    ent = rng.normal(size=(E, dp))
+    rel = rng.normal(size=(R, dp)) * 1.5
+    trip = set()
+    for h in range(E):
+        for r in range(R):
+            t = int(np.argmin(np.abs(ent[h] + rel[r] - ent).sum(1) + 1e9 * (np.arange(E) == h)))
+            trip.add((h, r, t))
+    trip = np.asarray(sorted(trip), dtype=np.int64)
+    trip = trip[rng.permutation(len(trip))]
+    n = TRAJECTORY_TEST
+    return E, R, trip[2 * n:], trip[:n], trip[n:2 * n]

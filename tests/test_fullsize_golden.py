@@ -303,3 +303,78 @@ def test_hip_default_path_step_matches_reference_at_full_size(name):
     rep = check_step_against_reference(name, loss, tables, s1, s2, doc)
     rep["path"] = path + (", two-phase" if path == "pull" and tr._pull.direction is not None else "")
     json.dump(doc, open(fn, "w"), indent=1)
+
+
+# ------------------------------------------------------------------ WIDE rank samples (round 5): 512 test triples per config -- and 16 at
+# C4's full E = 123 182, stitched from the reference's own Rescal.forward over 4 096-candidate chunks -- with the float64 ranks of the same
+# queries as arbiter (tests/golden/ref_full_ranks_*.npz, oracle/make_golden_fullsize.py ranks)
+WIDE = {"c1_transe_l1": 512, "c1_transe_l2": 512, "c2_complex": 512, "c3_rotate": 512, "c4_rescal": 16}
+
+
+def _wide_golden(name):
+    path = os.path.join(GOLDEN, "ref_full_ranks_%s.npz" % name)
+    if not os.path.exists(path):
+        pytest.skip("fixture %s not generated" % os.path.basename(path))
+    return np.load(path)
+
+
+@pytest.mark.parametrize("name", list(WIDE))
+def test_wide_rank_fixture_is_consistent_with_float64(name):
+    """The reference's fp32 ranks and the float64 ranks of the same queries differ only by near-ties: a handful of queries, small steps."""
+    z = _wide_golden(name)
+    ref, r64 = z["ranks"], z["ranks64"]
+    assert ref.shape == (4, WIDE[name]) and r64.shape == ref.shape
+    differ = (ref != r64).any(0)
+    # RotatE at d = 1000 sums 2 000 squares per energy on near-uniform random tables: 30 % of the triples have a candidate within fp32
+    # noise of the true one (the reference's own fp32 ranks move by 1-2 there); the other configs a few per cent
+    assert differ.mean() <= (0.4 if name == "c3_rotate" else 0.06), differ.mean()
+    assert np.abs(ref - r64).max() <= 4
+    assert (ref[2] <= ref[0]).all() and (ref[3] <= ref[1]).all()      # filtered <= raw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(WIDE))
+def test_hip_ranks_on_the_wide_sample_with_float64_arbitration(name):
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd.evaluator import Evaluator
+    import hip_util
+    z = _wide_golden(name)
+    n = WIDE[name]
+    spec, P, train, valid, test, ids, batch = _inputs(name)
+    hp = _hp(spec)
+    q = test[:n]
+    hr_t, tr_h = gu.query_filters(np.concatenate([train, valid, test]), q, spec["R"])
+    cfg = hip_util.make_config(spec["E"], spec["R"], hp, train[:1], valid[:4], q, optimizer="sgd", lr=0.01, batch_size=spec["step_B"])
+    cfg.knowledge_graph.cache.update(triplets_train=train, triplets_valid=valid, triplets_test=test, hr_t=hr_t, tr_h=tr_h)
+    m = hip_util.model_from_params(spec["model"], P, spec["hp"], spec["E"], spec["R"], train=train)
+    ranks = Evaluator(m, cfg).rank_all(q, n).cpu().numpy()
+    ref, r64 = z["ranks"], z["ranks64"]
+    differ = np.flatnonzero((ranks != ref).any(0))
+    report = {"case": name, "test_triples": n, "queries": 2 * n, "triples_with_a_differing_rank": int(len(differ)),
+              "hip_equals_float64": 0, "reference_equals_float64": 0, "neither": 0, "max_abs_rank_diff": 0, "flips": []}
+    if len(differ):
+        scores = K.eval_sweep_scores(m.make_desc(), hip_util.dev(q[differ])).cpu().numpy()   # [2 d, E]: tail sweep, head sweep per triple
+    for j, i in enumerate(differ):
+        h, r, t = (int(x) for x in q[i])
+        for side, row, true, (a, b) in (("tail", scores[2 * j], t, (1, 3)), ("head", scores[2 * j + 1], h, (0, 2))):
+            assert close(row[true], z["true_scores"][i, 0 if side == "head" else 1], atol=2e-5, rtol=2e-5)
+            for which in (a, b):
+                g_, r_, d_ = int(ranks[which, i]), int(ref[which, i]), int(r64[which, i])
+                if g_ == r_:
+                    continue
+                ok, near = gu.rank_band_ok(row, true, g_, r_)
+                assert ok, (name, int(i), side, which, g_, r_, near)
+                report["max_abs_rank_diff"] = max(report["max_abs_rank_diff"], abs(g_ - r_))
+                verdict = "hip" if g_ == d_ else ("reference" if r_ == d_ else "neither")
+                report["hip_equals_float64" if verdict == "hip" else "reference_equals_float64" if verdict == "reference" else "neither"] += 1
+                report["flips"].append({"triple": int(i), "side": side, "filtered": which >= 2, "hip": g_, "reference": r_, "float64": d_,
+                                        "float64_sides_with": verdict, "candidates_inside_band": near})
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "rank_agreement_fullsize_wide.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc[name] = report
+    json.dump(doc, open(path, "w"), indent=1)
+    # near-ties are rare on these tables except RotatE d = 1000 (see the fixture's own fp32-vs-float64 count); a systematic deviation
+    # would flip many more
+    assert len(differ) <= (0.5 if name == "c3_rotate" else 0.2) * n

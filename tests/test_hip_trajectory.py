@@ -1,0 +1,78 @@
+"""Trajectory-level parity: the drop-in Trainer on a planted (learnable) graph must follow the LIVE reference's learning curves.
+
+tests/golden/ref_trajectory.npz (oracle/make_golden_trajectory.py) holds, for TransE L1 / Adam, ComplEx / Adagrad and RotatE / Adam with
+self-adversarial negatives, the reference's own Trainer + Generator + Evaluator run for 30 epochs x 5 seeds on
+golden_util.planted_graph: per epoch the filtered mean rank, filtered MRR and filtered Hits@10 of the 200 held-out test triples.
+The samplers draw from different generators by design, so the comparison is distributional: every checked epoch of every seed trained
+here must lie inside  mean +- (3 sigma + floor)  of the reference's seeds (the floor -- 8 % of the mean plus a small absolute term --
+covers a sigma estimated from five runs).  Observed curves go to gpurun_out/trajectory_agreement.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+CHECK_EPOCHS = (2, 4, 9, 14, 19, 29)
+FLOOR = {"fmr": lambda m: 0.08 * m + 2.0, "fmrr": lambda m: 0.08 * m + 0.01, "fhit10": lambda m: 0.08 * m + 0.04}
+
+
+def _golden():
+    path = os.path.join(gu.GOLDEN, "ref_trajectory.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/ref_trajectory.npz not generated")
+    return np.load(path)
+
+
+@pytest.mark.parametrize("name", list(gu.TRAJECTORY))
+def test_reference_curves_show_learning(name):
+    """Sanity of the fixture itself: the reference learns the planted graph (filtered MR falls, MRR rises) on every seed."""
+    z = _golden()
+    fmr, fmrr = z[name + ".fmr"], z[name + ".fmrr"]
+    assert fmr.shape == (gu.TRAJECTORY_SEEDS, gu.TRAJECTORY[name]["epochs"])
+    assert (fmr[:, -1] < 0.8 * fmr[:, 0]).all() and (fmrr[:, -1] > 1.2 * fmrr[:, 0]).all(), (fmr[:, [0, -1]], fmrr[:, [0, -1]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(gu.TRAJECTORY))
+def test_learning_curve_follows_the_reference(name):
+    import hip_util as hip
+    from pykg2vec_amd.trainer import Trainer
+    z = _golden()
+    c = gu.TRAJECTORY[name]
+    E, R, train, valid, test = gu.planted_graph()
+    ref = {k: z["%s.%s" % (name, k)] for k in ("fmr", "fmrr", "fhit10")}
+    report = {"config": {k: v for k, v in c.items() if k != "hp"}, "hp": c["hp"], "epochs": list(CHECK_EPOCHS), "seeds": []}
+    for seed in range(3):
+        hp = dict(c["hp"], neg_rate=c["neg"])
+        cfg = hip.make_config(E, R, hp, train, valid, test, optimizer=c["optimizer"], lr=c["lr"], batch_size=c["batch"])
+        cfg.seed, cfg.epochs = seed, 10 ** 6
+        torch.manual_seed(seed)
+        m = hip.model_from_params(c["model"], {}, c["hp"], E, R, train=train)
+        tr = Trainer(m, cfg)
+        tr.build_model()
+        tr.generator = tr._new_generator()
+        curve = {k: [] for k in ref}
+        for e in range(c["epochs"]):
+            tr.train_model_epoch(e)
+            m.eval()
+            with torch.no_grad():
+                got = tr.evaluator.test(test, len(test), epoch=e)
+            mc = tr.evaluator.metric_calculator
+            curve["fmr"].append(float(got["fmr"])); curve["fmrr"].append(float(got["fmrr"])); curve["fhit10"].append(float(mc.fhit[(e, 10)]))
+        report["seeds"].append({k: [curve[k][e] for e in CHECK_EPOCHS] for k in curve})
+        for k, vals in curve.items():
+            for e in CHECK_EPOCHS:
+                mean, sd = float(ref[k][:, e].mean()), float(ref[k][:, e].std())
+                half = 3.0 * sd + FLOOR[k](abs(mean))
+                assert abs(vals[e] - mean) <= half, (name, "seed %d epoch %d %s" % (seed, e, k), vals[e], "reference %.4f +- %.4f" % (mean, half))
+    report["reference_mean"] = {k: [float(ref[k][:, e].mean()) for e in CHECK_EPOCHS] for k in ref}
+    report["reference_sigma"] = {k: [float(ref[k][:, e].std()) for e in CHECK_EPOCHS] for k in ref}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "trajectory_agreement.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc[name] = report
+    json.dump(doc, open(path, "w"), indent=1)

@@ -17,6 +17,9 @@ CONFIGS = [
     ("C1 TransE FB15k d=100 B=16384 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 16384, 1, 0),
     ("C1 TransE FB15k d=100 B=32768 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 32768, 1, 8192),
     ("C1 TransE-L2 FB15k d=100 B=32768 sgd", "transe", "fb15k", dict(hidden_size=100, l1_flag=False, margin=1.0), "sgd", 32768, 1, 8192),
+    ("C1 TransE-L2 FB15k d=100 B=32768 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=False, margin=1.0), "adam", 32768, 1, 0),
+    ("C1 TransE-L2 FB15k d=100 B=8192 adam", "transe", "fb15k", dict(hidden_size=100, l1_flag=False, margin=1.0), "adam", 8192, 1, 0),
+    ("TransM-L2 FB15k d=100 B=32768 adam", "transm", "fb15k", dict(hidden_size=100, l1_flag=False, margin=1.0), "adam", 32768, 1, 0),
     ("TransH FB15k d=100 B=8192 adam", "transh", "fb15k", dict(hidden_size=100, l1_flag=True, margin=1.0), "adam", 8192, 1, 0),
     ("TransD FB15k d=100 B=8192 adam", "transd", "fb15k", dict(ent_hidden_size=100, rel_hidden_size=100, l1_flag=True, margin=1.0), "adam", 8192, 1, 0),
     ("DistMult FB15k d=100 B=128 adam", "distmult", "fb15k", dict(hidden_size=100, lmbda=1e-4), "adam", 128, 1, 0),
