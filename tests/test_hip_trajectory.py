@@ -2,10 +2,11 @@
 
 tests/golden/ref_trajectory.npz (oracle/make_golden_trajectory.py) holds, for TransE L1 / Adam, ComplEx / Adagrad and RotatE / Adam with
 self-adversarial negatives, the reference's own Trainer + Generator + Evaluator run for 30 epochs x 5 seeds on
-golden_util.planted_graph: per epoch the filtered mean rank, filtered MRR and filtered Hits@10 of the 200 held-out test triples.
+golden_util.planted_graph: per epoch the accumulated training loss and the filtered mean rank, filtered MRR and filtered Hits@10 of the 200 held-out test triples.
 The samplers draw from different generators by design, so the comparison is distributional: every checked epoch of every seed trained
-here must lie inside  mean +- (3 sigma + floor)  of the reference's seeds (the floor -- 8 % of the mean plus a small absolute term --
-covers a sigma estimated from five runs).  Observed curves go to gpurun_out/trajectory_agreement.json."""
+here must lie inside  mean +- (3 sigma + floor)  of the reference's seeds at that epoch or at one within three epochs of it (the floor
+-- 8 % of the mean plus a small absolute term -- covers a sigma estimated from five runs; the time slack covers seed-dependent
+transition times).  Observed curves go to gpurun_out/trajectory_agreement.json."""
 import json
 import os
 
@@ -16,7 +17,9 @@ import torch
 import golden_util as gu
 
 CHECK_EPOCHS = (2, 4, 9, 14, 19, 29)
-FLOOR = {"fmr": lambda m: 0.08 * m + 2.0, "fmrr": lambda m: 0.08 * m + 0.01, "fhit10": lambda m: 0.08 * m + 0.04}
+TIME_SLACK = 3          # epochs
+FLOOR = {"fmr": lambda m: 0.08 * m + 2.0, "fmrr": lambda m: 0.08 * m + 0.01, "fhit10": lambda m: 0.08 * m + 0.04,
+         "loss": lambda m: 0.08 * m + 0.05}
 
 
 def _golden():
@@ -28,11 +31,16 @@ def _golden():
 
 @pytest.mark.parametrize("name", list(gu.TRAJECTORY))
 def test_reference_curves_show_learning(name):
-    """Sanity of the fixture itself: the reference learns the planted graph (filtered MR falls, MRR rises) on every seed."""
+    """Sanity of the fixture itself: on every seed the reference's training loss falls by more than half, and the translation-type
+    models (TransE, RotatE) generalise to the held-out triples of the planted translation graph -- filtered MR falls, MRR rises.
+    (ComplEx fits the training set -- loss 4.85 -> 0.94 -- but a near-symmetric bilinear form barely transfers to a translation
+    graph: its test curve is flat around filtered MR 175-180, and that flat curve is what the drop-in has to reproduce.)"""
     z = _golden()
-    fmr, fmrr = z[name + ".fmr"], z[name + ".fmrr"]
+    fmr, fmrr, loss = z[name + ".fmr"], z[name + ".fmrr"], z[name + ".loss"]
     assert fmr.shape == (gu.TRAJECTORY_SEEDS, gu.TRAJECTORY[name]["epochs"])
-    assert (fmr[:, -1] < 0.8 * fmr[:, 0]).all() and (fmrr[:, -1] > 1.2 * fmrr[:, 0]).all(), (fmr[:, [0, -1]], fmrr[:, [0, -1]])
+    assert (loss[:, -1] < 0.5 * loss[:, 0]).all(), loss[:, [0, -1]]
+    if name != "complex_adagrad":
+        assert (fmr[:, -1] < 0.8 * fmr[:, 0]).all() and (fmrr[:, -1] > 1.2 * fmrr[:, 0]).all(), (fmr[:, [0, -1]], fmrr[:, [0, -1]])
 
 
 @pytest.mark.gpu
@@ -43,7 +51,7 @@ def test_learning_curve_follows_the_reference(name):
     z = _golden()
     c = gu.TRAJECTORY[name]
     E, R, train, valid, test = gu.planted_graph()
-    ref = {k: z["%s.%s" % (name, k)] for k in ("fmr", "fmrr", "fhit10")}
+    ref = {k: z["%s.%s" % (name, k)] for k in ("fmr", "fmrr", "fhit10", "loss")}
     report = {"config": {k: v for k, v in c.items() if k != "hp"}, "hp": c["hp"], "epochs": list(CHECK_EPOCHS), "seeds": []}
     for seed in range(3):
         hp = dict(c["hp"], neg_rate=c["neg"])
@@ -56,7 +64,7 @@ def test_learning_curve_follows_the_reference(name):
         tr.generator = tr._new_generator()
         curve = {k: [] for k in ref}
         for e in range(c["epochs"]):
-            tr.train_model_epoch(e)
+            curve["loss"].append(float(tr.train_model_epoch(e)))
             m.eval()
             with torch.no_grad():
                 got = tr.evaluator.test(test, len(test), epoch=e)
@@ -65,9 +73,15 @@ def test_learning_curve_follows_the_reference(name):
         report["seeds"].append({k: [curve[k][e] for e in CHECK_EPOCHS] for k in curve})
         for k, vals in curve.items():
             for e in CHECK_EPOCHS:
-                mean, sd = float(ref[k][:, e].mean()), float(ref[k][:, e].std())
-                half = 3.0 * sd + FLOOR[k](abs(mean))
-                assert abs(vals[e] - mean) <= half, (name, "seed %d epoch %d %s" % (seed, e, k), vals[e], "reference %.4f +- %.4f" % (mean, half))
+                # inside the reference's tube at epoch e, or at an epoch within TIME_SLACK of it: where a curve has a fast transition
+                # (ComplEx's loss falls from 2.8 to 0.9 somewhere between epochs 10 and 30, at a seed-dependent time) a five-seed
+                # sigma at ONE epoch says little, and a run that makes the same transition two epochs earlier is the same behaviour
+                bands = []
+                for e2 in range(max(0, e - TIME_SLACK), min(c["epochs"], e + TIME_SLACK + 1)):
+                    mean, sd = float(ref[k][:, e2].mean()), float(ref[k][:, e2].std())
+                    bands.append((abs(vals[e] - mean), 3.0 * sd + FLOOR[k](abs(mean)), e2, mean))
+                assert any(d <= h for d, h, _, _ in bands), (name, "seed %d epoch %d %s" % (seed, e, k), vals[e],
+                                                             ["epoch %d: %.4f +- %.4f" % (e2, m_, h) for _, h, e2, m_ in bands])
     report["reference_mean"] = {k: [float(ref[k][:, e].mean()) for e in CHECK_EPOCHS] for k in ref}
     report["reference_sigma"] = {k: [float(ref[k][:, e].std()) for e in CHECK_EPOCHS] for k in ref}
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
