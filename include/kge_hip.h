@@ -232,6 +232,35 @@ int kge_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64
                          uint32_t* touched_rows, void* stream);
 int kge_rescal_pair_step_ok(const kge_model_desc* m, int64_t n);
 
+/* ---- Entity gradients of the pairwise RESCAL step WITHOUT float atomics (round 5; the relation-matrix gradient of the slab form has
+ * none already).  The grouping launch orders the pairs of every relation of at most 64 pairs by pair index; the forward launch registers
+ * slot 4 g + j of grouped pair g (j: 0 positive head, 1 positive tail, 2 negative head, 3 negative tail) with its entity (count / bucket /
+ * overflow chain) while marking the entity in touched_rows; the backward launch stores every side's gradient row to gstage[slot] with plain
+ * stores and the pair's hinge coefficient to dsv[g]; kge_optimizer_step_rows_staged -- the row-owner optimiser of
+ * kge_optimizer_step_rows -- sums the rows registered with a touched entity in ascending slot order (skipping pairs with a zero
+ * coefficient), applies the optimiser, and resets the entity's list.  Results are bit-reproducible run to run as long as no relation has
+ * more than 64 pairs in the batch (a longer relation spans several chunks, whose shares of the relation-matrix gradient add atomically).
+ * Replaces: loss.backward() into dense nn.Embedding gradients + optimizer.step() (utils/trainer.py:298-299) for RESCAL.
+ * count / head: int32 [tot_entity], all zero between steps (the optimiser resets what it consumed); bucket: int32 [tot_entity * cap];
+ * next: int32 [4 n]; gstage: float [4 n][dim]; dsv: float [n]; 1 <= cap <= 32.  kge_rescal_stage_ok: 1 when the step of n pairs takes
+ * the slab form with the workspace kge_workspace_bytes reports, the hidden size is a multiple of 4 and n <= 4096. */
+typedef struct kge_rescal_stage {
+    float* gstage;
+    float* dsv;
+    int32_t* count;
+    int32_t* bucket;
+    int32_t* head;
+    int32_t* next;
+    int32_t cap;
+} kge_rescal_stage;
+int kge_rescal_stage_ok(const kge_model_desc* m, int64_t n);
+int kge_rescal_pair_step_staged(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
+                                const int64_t* nt, int64_t n, float margin, void* workspace, size_t workspace_bytes, float* loss,
+                                uint32_t* touched_rows, const kge_rescal_stage* stage, void* stream);
+int kge_optimizer_step_rows_staged(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
+                                   float lr, int64_t step, int32_t normalize, const float* dev_hyper, const uint32_t* touched_rows,
+                                   uint32_t* touched_clear, const kge_rescal_stage* stage, void* stream);
+
 /* NTN.get_reg (pairwise.py:962-963): loss += lmbda * sqrt(sum_i param[i]^2), grad += lmbda * param / that root, over
  * ONE flat buffer holding every table of the model (pad with zeros).  scratch: 1 float. */
 int kge_l2norm_reg(const float* param, float* grad, int64_t numel, float lmbda, float* scratch, float* loss,

@@ -90,6 +90,12 @@ class OwnPlanC(ctypes.Structure):
                 ("seed", ctypes.c_uint64), ("draws_per_batch", ctypes.c_int64), ("loss", ctypes.c_void_p), ("stage", ctypes.c_void_p)]
 
 
+class RescalStage(ctypes.Structure):
+    """struct kge_rescal_stage"""
+    _fields_ = [("gstage", ctypes.c_void_p), ("dsv", ctypes.c_void_p), ("count", ctypes.c_void_p), ("bucket", ctypes.c_void_p),
+                ("head", ctypes.c_void_p), ("next", ctypes.c_void_p), ("cap", ctypes.c_int32)]
+
+
 class StagedTable(ctypes.Structure):
     """struct kge_staged_table"""
     _fields_ = [("cls", ctypes.c_int32), ("site_a", ctypes.c_int32), ("site_b", ctypes.c_int32), ("dsite", ctypes.c_int32),
@@ -171,6 +177,11 @@ _SIGNATURES = {
     "kge_rescal_pair_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_rescal_pair_step_ok": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_int64]),
+    "kge_rescal_stage_ok": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_int64]),
+    "kge_rescal_pair_step_staged": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p,
+                                                   ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(RescalStage), ctypes.c_void_p]),
+    "kge_optimizer_step_rows_staged": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
+                                                      ctypes.c_int64, ctypes.c_int32] + [ctypes.c_void_p] * 3 + [ctypes.POINTER(RescalStage), ctypes.c_void_p]),
     "kge_step_advance": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]),
     "kge_optimizer_step_advance": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_float, ctypes.c_int32]
                                    + [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 3 + [ctypes.c_void_p]),

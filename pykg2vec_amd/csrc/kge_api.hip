@@ -183,7 +183,7 @@ int kge_train_pairwise_hinge(const kge_model_desc* m, const int64_t* ph, const i
         // of the reference does): scores, hinge and gradients of a (relation, 16 pairs) tile in one launch
         const bool unfused = switch_value("RESCAL_UNFUSED") == 1;   // A/B switch (same 0 / 1 meaning as Trainer.switches)
         if (nr == pr && rescal_pair_step_ok(m, n, 2 * gws) && !unfused)
-            return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, wsp, workspace_bytes, nullptr, s);
+            return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, wsp, workspace_bytes, nullptr, nullptr, s);
         // positives and negatives as ONE grouped batch of 2n triples (scores / coefficients contiguous: sp | sn); the
         // region of the two per-side workspaces holds the grouping of 2n triples (group_ws_bytes(R, 2n) <= 2 gws)
         if ((rc = launch_rescal_pair_forward(m, ph, pr, pt, nh, nr, nt, n, sp, wsp, 2 * gws, s))) return rc;
@@ -404,7 +404,28 @@ int kge_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64
     }
     if (int rc = debug_check_hrt("kge_rescal_pair_step (positives)", m, ph, pr, pt, n, (hipStream_t)stream)) return rc;
     if (int rc = debug_check_hrt("kge_rescal_pair_step (negatives)", m, nh, pr, nt, n, (hipStream_t)stream)) return rc;
-    return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, workspace, workspace_bytes, touched_rows, (hipStream_t)stream);
+    return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, workspace, workspace_bytes, touched_rows, nullptr, (hipStream_t)stream);
+}
+
+int kge_rescal_stage_ok(const kge_model_desc* m, int64_t n) {
+    return m && m->model == KGE_RESCAL && n >= 0 && rescal_pair_step_ok(m, n, (size_t)-1) && rescal_stage_ok(m, n, kge_workspace_bytes(m, n)) ? 1 : 0;
+}
+
+int kge_rescal_pair_step_staged(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
+                                const int64_t* nt, int64_t n, float margin, void* workspace, size_t workspace_bytes, float* loss,
+                                uint32_t* touched_rows, const kge_rescal_stage* stage, void* stream) {
+    if (validate(m, true, "kge_rescal_pair_step_staged")) return -1;
+    if (m->model != KGE_RESCAL) { set_error("kge_rescal_pair_step_staged: not a RESCAL model"); return -1; }
+    if (n == 0) return 0;
+    if (n < 0 || !ph || !pr || !pt || !nh || !nt || !loss || !workspace || !touched_rows || !stage || !stage->gstage || !stage->dsv ||
+        !stage->count || !stage->bucket || !stage->head || !stage->next || stage->cap < 1 || stage->cap > 32) {
+        set_error("kge_rescal_pair_step_staged: bad arguments (every buffer of the stage, 1 <= cap <= 32, and the touched-row bitmap are required)");
+        return -1;
+    }
+    if (!rescal_pair_step_ok(m, n, workspace_bytes)) { set_error("kge_rescal_pair_step_staged: hidden size or workspace (kge_workspace_bytes)"); return -1; }
+    if (int rc = debug_check_hrt("kge_rescal_pair_step_staged (positives)", m, ph, pr, pt, n, (hipStream_t)stream)) return rc;
+    if (int rc = debug_check_hrt("kge_rescal_pair_step_staged (negatives)", m, nh, pr, nt, n, (hipStream_t)stream)) return rc;
+    return launch_rescal_pair_step(m, ph, pr, pt, nh, nt, n, margin, loss, workspace, workspace_bytes, touched_rows, stage, (hipStream_t)stream);
 }
 
 int kge_rescal_pair_step_ok(const kge_model_desc* m, int64_t n) {
@@ -418,7 +439,20 @@ int kge_optimizer_step_rows(int32_t kind, float* param, float* grad, float* stat
     if (rows == 0) return 0;
     if (touched_rows && touched_rows == touched_clear) { set_error("kge_optimizer_step_rows: the bitmap to clear must be the other parity's"); return -1; }
     return launch_optimizer_rows(kind, param, grad, state1, state2, rows, dim, lr, step < 1 ? 1 : step, zero_grad, normalize, dev_hyper,
-                                 touched_rows, touched_clear, (hipStream_t)stream);
+                                 touched_rows, touched_clear, nullptr, (hipStream_t)stream);
+}
+
+int kge_optimizer_step_rows_staged(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
+                                   float lr, int64_t step, int32_t normalize, const float* dev_hyper, const uint32_t* touched_rows,
+                                   uint32_t* touched_clear, const kge_rescal_stage* stage, void* stream) {
+    if (!param || !grad || rows < 0 || dim <= 0 || dim > 1024 || (step < 1 && !dev_hyper) || !stage || !touched_rows) {
+        set_error("kge_optimizer_step_rows_staged: bad arguments (rows of at most 1024 floats, the stage and the touched-row bitmap are required)");
+        return -1;
+    }
+    if (rows == 0) return 0;
+    if (touched_rows == touched_clear) { set_error("kge_optimizer_step_rows_staged: the bitmap to clear must be the other parity's"); return -1; }
+    return launch_optimizer_rows(kind, param, grad, state1, state2, rows, dim, lr, step < 1 ? 1 : step, 0, normalize, dev_hyper,
+                                 touched_rows, touched_clear, stage, (hipStream_t)stream);
 }
 
 int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,

@@ -115,6 +115,7 @@ int group_by_relation(const int64_t* r, int64_t n, int64_t R, const GroupWs& g, 
 // hit the same few dozen global counters (measured 10.6 + 4.7 + 10.6 us at the C4 shape, plus the gaps between them).
 constexpr int kSmallGroupMaxR = 4096;      // relations whose three int arrays fit the workgroup's LDS (48 KB)
 constexpr int kSmallGroupMaxN = 16384;
+constexpr int kStageMaxN = 4096;           // pairs of a batch whose grouped order also fits the LDS (deterministic form)
 __global__ __launch_bounds__(1024) void k_rel_group_small(IdSplit r, int n, int R, int* __restrict__ offsets, int* __restrict__ tile_off,
                                                           int* __restrict__ perm, int* __restrict__ tile_rel,
                                                           float* __restrict__ zero_buf, int zero_n, int tile, PairGather pg) {
@@ -158,6 +159,63 @@ __global__ __launch_bounds__(1024) void k_rel_group_small(IdSplit r, int n, int 
     if (tid == 0) { s_off[R] = s_carry[0]; s_toff[R] = s_carry[1]; offsets[R] = s_carry[0]; tile_off[R] = s_carry[1]; }
     for (int i = tid; i < R; i += 1024) s_cnt[i] = 0;   // now the scatter cursors
     __syncthreads();
+    if (pg.sorted) {
+        // ---- deterministic form (staged entity gradients): the grouped order goes through LDS, relations of 2 .. 64 pairs are sorted by
+        // pair index (one wave per relation, bitonic over the lanes), then ids and descriptors are written from the final order.  (n <= kStageMaxN: s_perm fits behind the three relation arrays.)
+        int* s_perm = s_toff + R + 1;      // [n] grouped position -> pair
+        int* s_inv = s_perm + n;           // [n] pair -> grouped position
+        constexpr int kPer = kStageMaxN / 1024;
+        int4 ids[kPer];                    // this thread's pairs' entity ids, requested now (they depend on nothing computed here)
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            ids[u] = make_int4(0, 0, 0, 0);
+            if (1024 * u < n) {   // (uniform)
+                const int i = min(tid + 1024 * u, n - 1);
+                ids[u] = make_int4((int)pg.ph[i], (int)pg.pt[i], (int)pg.nh[i], (int)pg.nt[i]);
+            }
+        }
+        for (int i = tid; i < n; i += 1024) {
+            const int rel = (int)r.at(i);
+            s_perm[s_off[rel] + atomicAdd(&s_cnt[rel], 1)] = i;
+        }
+        __syncthreads();
+        for (int rel = wave; rel < R; rel += 16) {
+            const int lo = s_off[rel], c = s_off[rel + 1] - lo;
+            if (c < 2 || c > 64) continue;            // (longer relations span several chunks: their share of G adds atomically anyway)
+            int v = lane < c ? s_perm[lo + lane] : 0x7FFFFFFF;
+#pragma unroll
+            for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+                for (int j = k >> 1; j >= 1; j >>= 1) {
+                    const int o = __shfl_xor(v, j, 64);
+                    const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+                    v = (lower == up) ? min(v, o) : max(v, o);
+                }
+            if (lane < c) s_perm[lo + lane] = v;
+        }
+        __syncthreads();
+        for (int g = tid; g < n; g += 1024) {
+            const int i = s_perm[g];
+            perm[g] = i;
+            s_inv[i] = g;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int i = tid + 1024 * u;
+            if (i < n) pg.gids[s_inv[i]] = ids[u];
+            // (the entity registrations of slot 4 g + j are made by the forward launch of the slab step, spread over its workgroups
+            //  and under its operand loads: 4 n returning atomics from this one workgroup cost 20 us at n = 1 024)
+        }
+        for (int rel = tid; rel < R; rel += 1024) {   // tile descriptors (and tile_rel) of every relation, from the counts
+            const int lo = s_off[rel], c = s_off[rel + 1] - lo, t0 = s_toff[rel], nt_ = s_toff[rel + 1] - t0;
+            for (int t = 0; t < nt_; ++t) {
+                tile_rel[t0 + t] = rel;
+                pg.tdesc[t0 + t] = make_int4(rel, lo + t * tile, min(tile, c - t * tile), nt_);
+            }
+        }
+        return;
+    }
     for (int i = tid; i < n; i += 1024) {
         const int rel = (int)r.at(i);
         const int local = atomicAdd(&s_cnt[rel], 1);
@@ -179,7 +237,9 @@ bool group_small_ok(int64_t n, int64_t R) { return n <= kSmallGroupMaxN && R <= 
 int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, hipStream_t s, float* zero_buf, int64_t zero_n, int tile,
                             const PairGather* pg) {
     if (n <= kSmallGroupMaxN && R <= kSmallGroupMaxR && zero_n <= kSmallGroupMaxN) {
-        hipLaunchKernelGGL(k_rel_group_small, dim3(1), dim3(1024), (size_t)(3 * R + 2) * sizeof(int), s, r, (int)n, (int)R, g.offsets,
+        if (pg && pg->sorted && n > kStageMaxN) { set_error("grouping: staged entity gradients take at most %d pairs", kStageMaxN); return -1; }
+        const size_t lds = (size_t)(3 * R + 2 + (pg && pg->sorted ? 2 * n : 0)) * sizeof(int);
+        hipLaunchKernelGGL(k_rel_group_small, dim3(1), dim3(1024), lds, s, r, (int)n, (int)R, g.offsets,
                            g.tile_off, g.perm, g.tile_rel, zero_buf, (int)(zero_buf ? zero_n : 0), tile, pg ? *pg : PairGather{});
         return check_launch("k_rel_group_small");
     }
@@ -1420,22 +1480,39 @@ bool rescal_pair_step_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
 }
 
 // negatives share pr (the caller passed nr == pr); ws: the pairwise step's scorer workspace
+static bool rescal_slab_taken(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
+    const int64_t R = m->tot_relation;
+    const size_t slab_bytes = rescal_slab_extra_bytes(m, n);
+    return !pair_split(R, n) && slab_bytes != 0 && ws_bytes != (size_t)-1 && ws_bytes >= rescal_slab_offset(R, n) + slab_bytes &&
+           switch_value("RESCAL_SLAB") != 0;
+}
+bool rescal_stage_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
+    // (the deterministic grouping keeps 3 R + 2 n + 2 ints in the 64 KB of LDS a launch gets without opting in)
+    return m->dim % 4 == 0 && n <= kStageMaxN && (3 * m->tot_relation + 2 * n + 2) * (int64_t)sizeof(int) <= 64 * 1024 &&
+           m->tot_entity < (1ll << 31) && rescal_slab_taken(m, n, ws_bytes);
+}
+
 int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
                             const int64_t* nt, int64_t n, float margin, float* loss, void* ws, size_t ws_bytes, unsigned* touched,
-                            hipStream_t s) {
+                            const kge_rescal_stage* stage, hipStream_t s) {
     const int k = m->dim;
     const int64_t R = m->tot_relation;
     if (!rescal_pair_step_ok(m, n, ws_bytes)) { set_error("RESCAL pair step: unsupported shape or workspace"); return -1; }
     const GroupWs g = carve_group_ws(ws, R, n);       // (tile_rel, the last array, holds n / 16 + R + 1 entries here)
-    const size_t slab_off = rescal_slab_offset(R, n), slab_bytes = rescal_slab_extra_bytes(m, n);
-    if (!pair_split(R, n) && slab_bytes != 0 && ws_bytes != (size_t)-1 && ws_bytes >= slab_off + slab_bytes && switch_value("RESCAL_SLAB") != 0) {
-        void* ws_slab = (char*)ws + slab_off;
+    if (stage && (!rescal_stage_ok(m, n, ws_bytes) || !touched)) {
+        set_error("kge_rescal_pair_step_staged: the staged form takes hidden sizes that are multiples of 4, at most %d pairs, the slab form's "
+                  "workspace (kge_workspace_bytes) and the touched-row bitmap (kge_rescal_stage_ok)", kStageMaxN);
+        return -1;
+    }
+    if (rescal_slab_taken(m, n, ws_bytes)) {
+        void* ws_slab = (char*)ws + rescal_slab_offset(R, n);
         PairGather pg;
         pg.ph = ph; pg.pt = pt; pg.nh = nh; pg.nt = nt;
         rescal_slab_gather(ws_slab, k, R, n, &pg);
+        if (stage) pg.sorted = 1;
         int rcs = group_by_relation_split(id_whole(pr, n), n, R, g, s, nullptr, 0, kSlabChunk, &pg);
         if (rcs) return rcs;
-        return launch_rescal_slab_step(m, n, g, margin, loss, touched, ws_slab, s);
+        return launch_rescal_slab_step(m, n, g, margin, loss, touched, ws_slab, stage, s);
     }
     int rc = group_by_relation_split(id_whole(pr, n), n, R, g, s, nullptr, 0, kPairTile);
     if (rc) return rc;

@@ -166,9 +166,10 @@ int launch_hinge_coeffs(float* pos, float* neg, int64_t n, float margin, float* 
 // the whole pairwise RESCAL step in one launch after the grouping (negatives share the positives' relation ids)
 bool rescal_pair_step_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes);
 size_t rescal_slab_extra_bytes(const kge_model_desc* m, int64_t n);   // workspace behind the standard pairwise layout (kge_rescal_slab.hip)
+bool rescal_stage_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes);   // the staged (atomic-free) form can take this shape
 int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const int64_t* pr, const int64_t* pt, const int64_t* nh,
                             const int64_t* nt, int64_t n, float margin, float* loss, void* ws, size_t ws_bytes, unsigned* touched,
-                            hipStream_t s);
+                            const kge_rescal_stage* stage /* NULL: entity gradients through float atomics */, hipStream_t s);
 
 // kge_opt.hip
 int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t numel, float lr, int64_t step,
@@ -177,7 +178,7 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
 
 int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float lr, int64_t step,
                           int zero_grad, int normalize, const float* dev_hyper, const unsigned* touched, unsigned* touched_clear,
-                          hipStream_t s);
+                          const kge_rescal_stage* stage /* NULL: the gradient rows of `g` */, hipStream_t s);
 
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);

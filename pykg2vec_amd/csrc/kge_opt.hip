@@ -141,11 +141,20 @@ __global__ __launch_bounds__(256) void k_opt_rows(float* __restrict__ p, float* 
 
 // the same for rows of float4s (dim % 4 == 0): a 32-lane group per row, NV float4 per lane, two rows per wave, 16-byte accesses,
 // optimiser state streamed non-temporally when the tables exceed the Infinity Cache (as k_opt does)
+// Staged gradients (kge_rescal_stage, include/kge_hip.h): the gradient of a touched row is not a row of `g` but the sum of the
+// rows of `gstage` registered with it (count / bucket / overflow chain, filled by the grouping launch of the pairwise step), added
+// in ascending slot order -- a fixed order, whatever order the registrations arrived in -- and skipped where the slot's pair has a
+// zero hinge coefficient.  The owner resets the row's list: the lists are all-zero again when the sweep ends.
+struct RowStage {
+    const float* gstage; const float* dsv;
+    int* count; const int* bucket; int* head; const int* next; int cap;
+};
+
 template <int KIND, int NV, bool NORM, bool NT>
 __global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                    float* __restrict__ s2, int64_t rows, int dim, OptArgs a,
                                                    const float* __restrict__ dev_hyper, int zero,
-                                                   const unsigned* __restrict__ touched, unsigned* __restrict__ touched_clear) {
+                                                   const unsigned* __restrict__ touched, unsigned* __restrict__ touched_clear, RowStage stage) {
     if (dev_hyper) { a.lr = dev_hyper[0]; a.step_size = dev_hyper[1]; a.bc2_sqrt = dev_hyper[2]; }
     const int gl = threadIdx.x & 31;
     const int nvec = dim >> 2;
@@ -165,9 +174,36 @@ __global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float*
             const bool on = i < nvec;
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             pv[v] = on ? pr[i] : z;
-            gv[v] = (on && has_g) ? stream_load<NT>(gr + i) : z;
+            gv[v] = (on && has_g && !stage.gstage) ? stream_load<NT>(gr + i) : z;
             av[v] = (KIND != KGE_OPT_SGD && on) ? stream_load<NT>(ar + i) : z;
             bv[v] = (KIND == KGE_OPT_ADAM && on) ? stream_load<NT>(br + i) : z;
+        }
+        if (stage.gstage && has_g) {
+            const int cnt = stage.count[row];
+            if (cnt > 0) {
+                const int nb = cnt < stage.cap ? cnt : stage.cap;
+                const int mine = gl < nb ? stage.bucket[row * stage.cap + gl] : 0x7FFFFFFF;   // (cap <= 32: one bucket entry per lane)
+                const int chain = cnt > stage.cap ? stage.head[row] - 1 : -1;
+                int last = -1;
+                for (int it = 0; it < cnt; ++it) {      // ascending slot order: the smallest slot above the last one taken
+                    int best = mine > last ? mine : 0x7FFFFFFF;
+#pragma unroll
+                    for (int o = 16; o >= 1; o >>= 1) best = min(best, __shfl_xor(best, o, 64));   // over the row's 32 lanes
+                    for (int j = chain; j >= 0; j = stage.next[j])
+                        if (j > last && j < best) best = j;
+                    if (best == 0x7FFFFFFF) break;
+                    last = best;
+                    if (stage.dsv[best >> 2] != 0.f) {
+                        const float4* sr = reinterpret_cast<const float4*>(stage.gstage + (int64_t)best * dim);
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+                            const int i = v * 32 + gl;
+                            if (i < nvec) { const float4 x = sr[i]; gv[v].x += x.x; gv[v].y += x.y; gv[v].z += x.z; gv[v].w += x.w; }
+                        }
+                    }
+                }
+                if (gl == 0) { stage.count[row] = 0; if (cnt > stage.cap) stage.head[row] = 0; }
+            }
         }
         float n2 = 0.f;
 #pragma unroll
@@ -186,7 +222,7 @@ __global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float*
                 pr[i] = pv[v];   // (the next step gathers parameter rows: plain store)
                 if constexpr (KIND != KGE_OPT_SGD) stream_store<NT>(ar + i, av[v]);
                 if constexpr (KIND == KGE_OPT_ADAM) stream_store<NT>(br + i, bv[v]);
-                if (zero && (gv[v].x != 0.f || gv[v].y != 0.f || gv[v].z != 0.f || gv[v].w != 0.f)) gr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (zero && !stage.gstage && (gv[v].x != 0.f || gv[v].y != 0.f || gv[v].z != 0.f || gv[v].w != 0.f)) gr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -198,7 +234,7 @@ static bool rows4_ok(const float* p, const float* g, const float* s1, const floa
 
 template <int KIND>
 static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t rows, int dim, OptArgs a, int zero, int normalize,
-                            const float* dh, const unsigned* touched, unsigned* tclear, hipStream_t s) {
+                            const float* dh, const unsigned* touched, unsigned* tclear, const RowStage& stage, hipStream_t s) {
     if (rows4_ok(p, g, s1, s2, dim)) {
         int64_t blocks4 = (rows + 7) / 8;
         if (blocks4 > 256 * 32) blocks4 = 256 * 32;
@@ -206,15 +242,16 @@ static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t ro
         const bool nt = (int64_t)streams * rows * dim * 4 > ((int64_t)256 << 20);
 #define KGE_ROWS4(NV_)                                                                                                    \
         if (dim <= 128 * NV_) {                                                                                            \
-            if (normalize && nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear); \
-            else if (normalize) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear); \
-            else if (nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear); \
-            else hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear); \
+            if (normalize && nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage); \
+            else if (normalize) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage); \
+            else if (nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage); \
+            else hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage); \
             return check_launch("k_opt_rows4");                                                                            \
         }
         KGE_ROWS4(1) KGE_ROWS4(2) KGE_ROWS4(4) KGE_ROWS4(8)
 #undef KGE_ROWS4
     }
+    if (stage.gstage) { set_error("kge_optimizer_step_rows_staged: rows of float4s only (dim %% 4 == 0, dim <= 1024, 16-byte aligned buffers)"); return -1; }
     if (tclear) {   // (the dword kernel reads every gradient row: a superset of the touched ones)
         hipError_t e = hipMemsetAsync(tclear, 0, (size_t)((rows + 31) / 32) * sizeof(unsigned), s);
         if (e != hipSuccess) { set_error("optimizer rows: memset: %s", hipGetErrorString(e)); return -2; }
@@ -234,19 +271,27 @@ static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t ro
 
 int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float lr, int64_t step,
                           int zero_grad, int normalize, const float* dev_hyper, const unsigned* touched, unsigned* touched_clear,
-                          hipStream_t s) {
+                          const kge_rescal_stage* st, hipStream_t s) {
     const OptArgs a = make_opt_args(lr, step);
+    RowStage stage{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (st) {
+        if (!st->gstage || !st->dsv || !st->count || !st->bucket || !st->head || !st->next || st->cap < 1 || st->cap > 32 || !touched) {
+            set_error("kge_optimizer_step_rows_staged: incomplete stage (all buffers, 1 <= cap <= 32, and the touched-row bitmap are required)");
+            return -1;
+        }
+        stage = RowStage{st->gstage, st->dsv, st->count, st->bucket, st->head, st->next, st->cap};
+    }
     switch (kind) {
-        case KGE_OPT_SGD: return launch_rows_kind<KGE_OPT_SGD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, s);
+        case KGE_OPT_SGD: return launch_rows_kind<KGE_OPT_SGD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s);
         case KGE_OPT_ADAM:
             if (!s1 || !s2) { set_error("adam needs two state buffers"); return -1; }
-            return launch_rows_kind<KGE_OPT_ADAM>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, s);
+            return launch_rows_kind<KGE_OPT_ADAM>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s);
         case KGE_OPT_ADAGRAD:
             if (!s1) { set_error("adagrad needs a state buffer"); return -1; }
-            return launch_rows_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, s);
+            return launch_rows_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s);
         case KGE_OPT_RMSPROP:
             if (!s1) { set_error("rmsprop needs a state buffer"); return -1; }
-            return launch_rows_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, s);
+            return launch_rows_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s);
     }
     set_error("kge_optimizer_step_rows: unknown optimizer %d", kind);
     return -1;

@@ -42,6 +42,10 @@ struct PairGather {
     const int64_t* ph = nullptr; const int64_t* pt = nullptr; const int64_t* nh = nullptr; const int64_t* nt = nullptr;
     int4* tdesc = nullptr;     // [n / tile + R + 1]
     int4* gids = nullptr;      // [n]  (ph, pt, nh, nt) of grouped position g
+    // staged entity gradients (kge_rescal_stage, include/kge_hip.h): with `sorted` set the grouping orders the pairs of every relation
+    // of at most 64 pairs by pair index -- a deterministic grouped order (the scatter's own order is arrival order), which fixes the slot
+    // numbers 4 g + j of the staged gradient rows and the summation order of the relation-matrix gradient
+    int sorted = 0;
 };
 bool group_small_ok(int64_t n, int64_t R);   // the grouping runs as one launch (the only form that fills a PairGather)
 
@@ -54,7 +58,7 @@ int group_by_relation_split(IdSplit r, int64_t n, int64_t R, const GroupWs& g, h
 size_t rescal_slab_ws_bytes(int k, int64_t R, int64_t n);
 void rescal_slab_gather(void* ws_slab, int k, int64_t R, int64_t n, PairGather* pg);   // where the grouping leaves tdesc / gids
 int launch_rescal_slab_step(const kge_model_desc* m, int64_t n, const GroupWs& g, float margin, float* loss, unsigned* touched,
-                            void* ws_slab, hipStream_t s);
+                            void* ws_slab, const kge_rescal_stage* stage, hipStream_t s);
 
 // which (relation, tile-in-relation) is block `b`?  (tile_rel is written by the grouping's scatter pass)
 __device__ __forceinline__ bool locate_tile(const int* __restrict__ tile_off, const int* __restrict__ tile_rel, int R, int b,

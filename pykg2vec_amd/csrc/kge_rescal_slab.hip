@@ -54,6 +54,12 @@ struct SlabArgs {
     unsigned* touched;
     float* wsV;      // [2 n][k]      V rows in grouped order: slot 2 g + side
     float* wsP;      // [n_slab][2 n] the slabs' shares of every h^T M t
+    // staged entity gradients (NULL: float atomics into g_ent): row 4 g + j of gstage = the gradient pair g contributes to its positive
+    // head (j = 0), positive tail (1), negative head (2), negative tail (3), written with plain stores where the pair's hinge
+    // coefficient dsv[g] is not 0; the row owners of the optimiser sum them in slot order (kge_opt.hip: k_opt_rows4<..., STAGED>)
+    float* gstage;
+    float* dsv;      // [n] hinge coefficient of grouped pair g
+    int32_t* st_count; int32_t* st_bucket; int32_t* st_head; int32_t* st_next; int st_cap;   // per-entity lists of staged rows
 };
 
 template <int VK>
@@ -104,6 +110,19 @@ __global__ __launch_bounds__(256) void k_rescal_slab_fwd(SlabArgs a) {
     }
     const bool neg = li >= kPairTile;
     const int hid = neg ? id4.z : id4.x, tid = neg ? id4.w : id4.y;
+    if (a.gstage && slab == 0 && lk == 0 && p < cnt) {
+        // staged entity gradients: this triple's two gradient rows (slot 4 g + 2 side for its head, + 1 for its tail) register with
+        // their entities -- count / bucket / overflow chain, all zero between steps -- and mark them for the optimiser.  Done here, by
+        // the first slab's workgroup of every chunk, so that the returning atomics sit under the operand loads below.
+        const int slot_h = 4 * (g_lo + p) + (neg ? 2 : 0);
+        const int ph_ = atomicAdd(a.st_count + hid, 1), pt_ = atomicAdd(a.st_count + tid, 1);
+        if (ph_ < a.st_cap) a.st_bucket[(int64_t)hid * a.st_cap + ph_] = slot_h;
+        else a.st_next[slot_h] = atomicExch(a.st_head + hid, slot_h + 1) - 1;      // head holds slot + 1: all-zero = empty
+        if (pt_ < a.st_cap) a.st_bucket[(int64_t)tid * a.st_cap + pt_] = slot_h + 1;
+        else a.st_next[slot_h + 1] = atomicExch(a.st_head + tid, slot_h + 2) - 1;
+        atomicOr(a.touched + (hid >> 5), 1u << (hid & 31));
+        atomicOr(a.touched + (tid >> 5), 1u << (tid & 31));
+    }
     const bool active = wave * kPairTile < cnt;      // (uniform) this wave's row block exists
     float av[NJ][VK];
     float tv[16];
@@ -220,7 +239,10 @@ __global__ __launch_bounds__(256, 2) void k_rescal_slab_bwd(SlabArgs a) {
         v = (-sp) + a.margin - (-sn);
         c = v > 0.f ? 1.f : (v == 0.f ? 0.5f : 0.f);
     }
-    if (lane < kPairTile) { sDs[wave * 32 + lane] = c; sDs[wave * 32 + kPairTile + lane] = -c; }
+    if (lane < kPairTile) {
+        sDs[wave * 32 + lane] = c; sDs[wave * 32 + kPairTile + lane] = -c;
+        if (a.dsv && slab == 0 && on) a.dsv[gp] = c;
+    }
     const float tot = wave_sum(fmaxf(v, 0.f));
     const unsigned long long any = __ballot(c != 0.f);
     __syncthreads();
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void k_rescal_slab_bwd(SlabArgs a) {
     if (!sAny) return;        // every pair of the chunk inside the margin: no gradient
     SLAB_TS(1, 3)
     const bool active = any != 0ull;              // (wave-uniform) this wave's row block carries a gradient
-    if (a.touched && slab == 0 && lk == 0 && sDs[wave * 32 + li] != 0.f) {   // entity rows this chunk writes a gradient into
+    if (a.touched && !a.gstage && slab == 0 && lk == 0 && sDs[wave * 32 + li] != 0.f) {   // entity rows this chunk writes a gradient into
         atomicOr(a.touched + (hid >> 5), 1u << (hid & 31));
         atomicOr(a.touched + (tid >> 5), 1u << (tid & 31));
     }
@@ -289,7 +311,29 @@ __global__ __launch_bounds__(256, 2) void k_rescal_slab_bwd(SlabArgs a) {
         asm volatile("s_nop 0" :: "v"(ua[0]));
 #endif
         SLAB_TS(1, 5)
-        if (col < k) {   // rows i and i + 16 are the two sides of one pair (registers reg, reg + 8): the side the sampler did not
+        if (col < k && a.gstage) {
+            // staged: every side of every active pair owns a row of gstage (slot 4 g + j), plain stores, no atomics
+#pragma unroll
+            for (int reg = 0; reg < 8; ++reg) {
+                const int i = acc_row(reg, lk);
+                const float ds = sDs[wave * 32 + i];
+                if (ds != 0.f) {
+                    const int64_t slot = 4 * (int64_t)(g_lo + wave * kPairTile + i);
+                    a.gstage[slot * k + col] = -ds * ua[reg];                 // positive head
+                    a.gstage[(slot + 2) * k + col] = ds * ua[reg + 8];        // negative head
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = r + 8 * lk;
+                const float ds = sDs[wave * 32 + i];
+                if (ds != 0.f) {
+                    const int64_t slot = 4 * (int64_t)(g_lo + wave * kPairTile + i);
+                    a.gstage[(slot + 1) * k + col] = -ds * vp[r];             // positive tail
+                    a.gstage[(slot + 3) * k + col] = ds * vn[r];              // negative tail
+                }
+            }
+        } else if (col < k) {   // rows i and i + 16 are the two sides of one pair (registers reg, reg + 8): the side the sampler did not
                          // corrupt is the SAME entity row and leaves as one atomic
 #pragma unroll
             for (int reg = 0; reg < 8; ++reg) {
@@ -384,7 +428,7 @@ void rescal_slab_gather(void* ws_slab, int k, int64_t R, int64_t n, PairGather* 
 
 // the grouping (kSlabChunk pairs per tile, with the PairGather of rescal_slab_gather) has been enqueued on s before this call
 int launch_rescal_slab_step(const kge_model_desc* m, int64_t n, const GroupWs& g, float margin, float* loss, unsigned* touched,
-                            void* ws_slab, hipStream_t s) {
+                            void* ws_slab, const kge_rescal_stage* stage, hipStream_t s) {
     const int k = m->dim;
     const int64_t R = m->tot_relation;
     PairGather pg;
@@ -394,6 +438,9 @@ int launch_rescal_slab_step(const kge_model_desc* m, int64_t n, const GroupWs& g
     a.tile_off = g.tile_off; a.tdesc = pg.tdesc; a.gids = pg.gids;
     a.R = (int)R; a.k = k; a.n_slab = (k + 31) / 32; a.n = n;
     a.margin = margin; a.loss = loss; a.touched = touched;
+    a.gstage = stage ? stage->gstage : nullptr; a.dsv = stage ? stage->dsv : nullptr;
+    a.st_count = stage ? stage->count : nullptr; a.st_bucket = stage ? stage->bucket : nullptr;
+    a.st_head = stage ? stage->head : nullptr; a.st_next = stage ? stage->next : nullptr; a.st_cap = stage ? stage->cap : 0;
     a.wsV = (float*)((char*)pg.gids + align256s((size_t)n * sizeof(int4)));
     a.wsP = a.wsV + (size_t)2 * n * k;
     const unsigned grid = (unsigned)((slab_tiles(R, n) + 7) / 8 * 8 * a.n_slab);

@@ -451,6 +451,53 @@ def optimizer_step_rows(kind, param, grad, state1, state2, rows, dim, lr, step, 
                                              _stream()), "kge_optimizer_step_rows")
 
 
+class RescalStage:
+    """Buffers of the atomic-free entity gradients of the pairwise RESCAL step (struct kge_rescal_stage): gradient rows staged per
+    (pair, side), the pairs' hinge coefficients, and per entity the list of staged rows registered with it (all zero between steps)."""
+    CAP = 8
+
+    def __init__(self, tot_entity, n_pairs, dim, device):
+        self.n_pairs = int(n_pairs)
+        self.gstage = torch.zeros(4 * self.n_pairs * int(dim), dtype=torch.float32, device=device)
+        self.dsv = torch.zeros(self.n_pairs, dtype=torch.float32, device=device)
+        self.count = torch.zeros(int(tot_entity), dtype=torch.int32, device=device)
+        self.bucket = torch.zeros(int(tot_entity) * self.CAP, dtype=torch.int32, device=device)
+        self.head = torch.zeros(int(tot_entity), dtype=torch.int32, device=device)
+        self.next = torch.zeros(4 * self.n_pairs, dtype=torch.int32, device=device)
+        self.c = L.RescalStage(self.gstage.data_ptr(), self.dsv.data_ptr(), self.count.data_ptr(), self.bucket.data_ptr(),
+                               self.head.data_ptr(), self.next.data_ptr(), self.CAP)
+
+
+def rescal_stage_ok(desc, n):
+    """kge_rescal_stage_ok: the pairwise RESCAL step of n pairs can stage its entity gradients (slab form, d % 4 == 0, n <= 4096)."""
+    return bool(L.load().kge_rescal_stage_ok(ctypes.byref(desc), int(n)))
+
+
+def rescal_pair_step_staged(desc, ph, pr, pt, nh, nt, margin, loss_buf, touched, stage):
+    """kge_rescal_pair_step_staged: the pairwise RESCAL step with every entity gradient row staged instead of added atomically."""
+    n = ph.numel()
+    if nh.numel() != n or n > stage.n_pairs:
+        raise ValueError("rescal_pair_step_staged: %d pairs (stage sized for %d; neg_rate must be 1)" % (n, stage.n_pairs))
+    wp, wb, _keep = _workspace(desc, n, ph.device)
+    L.check(L.load().kge_rescal_pair_step_staged(ctypes.byref(desc), _ids(ph, "ph"), _ids(pr, "pr"), _ids(pt, "pt"), _ids(nh, "nh"),
+                                                 _ids(nt, "nt"), n, float(margin), wp, wb, _dev(loss_buf, torch.float32, "loss"),
+                                                 _dev(touched, torch.int32, "touched"), ctypes.byref(stage.c), _stream()),
+            "kge_rescal_pair_step_staged")
+
+
+def optimizer_step_rows_staged(kind, param, grad, state1, state2, rows, dim, lr, step, stage, touched, touched_clear=None, normalize=False,
+                               dev_hyper=None):
+    """kge_optimizer_step_rows_staged: kge_optimizer_step_rows with the gradient of a touched row summed from the stage."""
+    p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
+    p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
+    ph = _dev(dev_hyper, torch.float32, "dev_hyper") if dev_hyper is not None else None
+    L.check(L.load().kge_optimizer_step_rows_staged(OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"), _dev(grad, torch.float32, "grad"),
+                                                    p1, p2, int(rows), int(dim), float(lr), int(step), 1 if normalize else 0, ph,
+                                                    _dev(touched, torch.int32, "touched"),
+                                                    _dev(touched_clear, torch.int32, "touched_clear") if touched_clear is not None else None,
+                                                    ctypes.byref(stage.c), _stream()), "kge_optimizer_step_rows_staged")
+
+
 def rescal_pair_step_ok(desc, n):
     return bool(L.load().kge_rescal_pair_step_ok(ctypes.byref(desc), int(n)))
 

@@ -109,7 +109,7 @@ class FlatState:
         self.K.optimizer_step_advance(self.optimizer, self.param_shard, self.grad_shard, self.state1, self.state2, lr, hyper,
                                       cursor, next_cursor, next_hyper, batch_stride, n_batches, draws, zero_grad=True)
 
-    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None, touched=None, touched_clear=None):
+    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None, touched=None, touched_clear=None, stage=None):
         """The optimiser step with the FIRST table ([rows, dim], at offset 0 of the flat buffers) handled by the row-owner kernel
         (which can store the rows renormalised: RESCAL) and the remaining tables by the flat sweep.  advance: as
         optimizer_step_advance (device-resident step state of hipGraph-replayed steps); single GPU only."""
@@ -118,9 +118,13 @@ class FlatState:
         cut = self.offsets[1] if len(self.offsets) > 1 else self.numel
         sl = lambda buf, a, b: buf[a:b] if buf is not None else None
         hyper = advance[0] if advance is not None else None
-        self.K.optimizer_step_rows(self.optimizer, self.param[:n0], self.grad[:n0], sl(self.state1, 0, n0), sl(self.state2, 0, n0),
-                                   rows, dim, lr, self.step, zero_grad=True, normalize=normalize, dev_hyper=hyper,
-                                   touched=touched, touched_clear=touched_clear)
+        if stage is not None:   # entity gradients staged by the pair step (kernels.RescalStage): summed per row in a fixed order, no atomics
+            self.K.optimizer_step_rows_staged(self.optimizer, self.param[:n0], self.grad[:n0], sl(self.state1, 0, n0), sl(self.state2, 0, n0),
+                                              rows, dim, lr, self.step, stage, touched, touched_clear, normalize=normalize, dev_hyper=hyper)
+        else:
+            self.K.optimizer_step_rows(self.optimizer, self.param[:n0], self.grad[:n0], sl(self.state1, 0, n0), sl(self.state2, 0, n0),
+                                       rows, dim, lr, self.step, zero_grad=True, normalize=normalize, dev_hyper=hyper,
+                                       touched=touched, touched_clear=touched_clear)
         rest = (self.param[cut:], self.grad[cut:], sl(self.state1, cut, self.numel), sl(self.state2, cut, self.numel))
         if advance is not None:
             self.K.optimizer_step_advance(self.optimizer, *rest, lr, *advance, zero_grad=True)
@@ -236,7 +240,7 @@ class Trainer:
         return {"pull": flag("KGE_PULL"), "staged": flag("KGE_STAGED"), "graph_multi": flag("KGE_GRAPH_MULTI"),
                 "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED"),
                 "rescal_unfused": flag("KGE_RESCAL_UNFUSED"), "pull_dir": flag("KGE_PULL_DIR"),
-                "transx_own": flag("KGE_TRANSX_OWN"), "own_staged": flag("KGE_OWN_STAGED"),
+                "transx_own": flag("KGE_TRANSX_OWN"), "own_staged": flag("KGE_OWN_STAGED"), "rescal_staged": flag("KGE_RESCAL_STAGED"),
                 "dp_sparse": flag("KGE_DP_SPARSE"),
                 "dp_allreduce": flag("KGE_DP_ALLREDUCE")}
 
@@ -317,8 +321,12 @@ class Trainer:
                 # step's optimiser resets the other one.  (A parity that repeats after an epoch boundary only leaves stale
                 # bits behind: rows read needlessly, never a gradient missed.)
                 par = self._touch_parity
-                self.K.rescal_pair_step(self._desc, ph, pr, pt, nh, nt, self.config.margin, self.loss_buf, touched=self._touched_bitmaps()[par])
-                self._touched_step = par
+                st = self._rescal_stage_for(ph.numel())
+                if st is not None:   # entity gradient rows staged per (pair, side) and summed by the row owners: no float atomics
+                    self.K.rescal_pair_step_staged(self._desc, ph, pr, pt, nh, nt, self.config.margin, self.loss_buf, self._touched_bitmaps()[par], st)
+                else:
+                    self.K.rescal_pair_step(self._desc, ph, pr, pt, nh, nt, self.config.margin, self.loss_buf, touched=self._touched_bitmaps()[par])
+                self._touched_step, self._stage_step = par, st
                 return
         if name == "rotate":
             self._selfadv_ws = self.K.train_pairwise_selfadv(self._desc, ph, pr, pt, nh, nr, nt, self.config.neg_rate,
@@ -925,6 +933,20 @@ class Trainer:
         # launch costs more than the pass it saves (FB15k preset, 3 MB: 64.5 -> 68.6 us)
         return self.flat.views[0].numel() * 4 >= (32 << 20)
 
+    def _rescal_stage_for(self, n_pairs):
+        """The staging buffers of the atomic-free entity gradients (kernels.RescalStage), or None when the step of n_pairs pairs cannot
+        stage (large batches take the split kernels; hidden sizes that are not multiples of 4; KGE_RESCAL_STAGED=0; a test backend)."""
+        if self.K is not K or self.switches.get("rescal_staged") is False or not hasattr(self.K, "rescal_stage_ok"):
+            return None
+        if not self.K.rescal_stage_ok(self._desc, n_pairs):
+            return None
+        st = getattr(self, "_rescal_stage", None)
+        if st is None or st.n_pairs < n_pairs:
+            ent = self.flat.views[0]
+            st = self._rescal_stage = K.RescalStage(ent.shape[0], max(n_pairs, int(self.config.batch_size)), ent.shape[1], ent.device)
+            self._graph = None     # (captured steps hold the old buffers' addresses)
+        return st
+
     def _mean_type_loss(self):
         """pointwise_logistic and the self-adversarial loss are MEANS over the batch (criterion.py:13-23,31-34);
         the hinge is a SUM (criterion.py:25-29)."""
@@ -1028,9 +1050,11 @@ class Trainer:
                 ent = flat.views[0]
                 par, self._touched_step = self._touched_step, None
                 bm = self._touched_bitmaps() if par is not None else (None, None)
+                st, self._stage_step = getattr(self, "_stage_step", None), None
                 flat.optimizer_step_rows_first(self.config.learning_rate, ent.shape[0], ent.shape[1], keep, advance,
                                                touched=bm[par] if par is not None else None,
-                                               touched_clear=bm[1 - par] if par is not None else None)
+                                               touched_clear=bm[1 - par] if par is not None else None,
+                                               stage=st if par is not None else None)
                 self._touch_parity ^= 1
                 if keep:
                     self.K.rescal_normalize_relations(flat.views[1], self.model.hidden_size)
