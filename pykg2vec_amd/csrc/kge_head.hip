@@ -326,6 +326,8 @@ __global__ __launch_bounds__(256, 2) void k_head_gemm128_bf16(HeadArgs a) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int64_t b = b0 + wr * 64 + mi * 32 + head_row(reg, lk);
+                // (plain stores: non-temporal ones measured slower, 149.6 -> 204.4 us at B = 4 096 -- the 128-byte row segments of an
+                //  odd-E output are partial lines that need the L2 to merge them; profiles/r05_experiments.md section 8)
                 if (b < a.B && e < a.E) a.preds[b * a.E + e] = sigmoid_fast(acc[mi][ni][reg] + bias);
             }
     }

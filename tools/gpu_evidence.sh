@@ -22,8 +22,10 @@ for part in $PARTS; do
   case $part in
     tests)   timeout 1500 python -m pytest tests -x -q -m gpu --timeout 300 > $O/${TAG}_tests.log 2>&1; tail -4 $O/${TAG}_tests.log ;;
     smoke)   timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
-    bench)   timeout 900 python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err; head -c 600 $O/${TAG}_bench_line.json; echo; tail -3 $O/${TAG}_bench.err ;;
-    bench20) timeout 900 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_line_20steps.json 2> $O/${TAG}_bench20.err; head -c 300 $O/${TAG}_bench_line_20steps.json; echo ;;
+    bench)   timeout 900 python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err; cp $O/bench_detail.json $O/${TAG}_bench_detail.json 2>/dev/null
+             tail -n 1 $O/${TAG}_bench_line.json | head -c 600; echo; tail -3 $O/${TAG}_bench.err ;;
+    bench20) timeout 900 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_line_20steps.json 2> $O/${TAG}_bench20.err; cp $O/bench_detail.json $O/${TAG}_bench_detail_20steps.json 2>/dev/null
+             tail -n 1 $O/${TAG}_bench_line_20steps.json | head -c 300; echo ;;
     stats)   timeout 600 rocprofv3 --kernel-trace --stats -d $O/_p0 -o b -- python bench.py --no-cpu-baseline --no-live-pmc > $O/${TAG}_prof0.log 2>&1
              python tools/rocpd_summary.py $(find $O/_p0 -name '*.db' | head -1) $O/${TAG}_kernel_stats.md > /dev/null; head -16 $O/${TAG}_kernel_stats.md | cut -c1-180
              rm -rf $O/_p0 ;;
