@@ -358,6 +358,19 @@ int kge_sample_batch(const int64_t* triples, const int64_t* perm, int64_t start,
 int kge_step_advance(int64_t* dev_cursor, float* dev_hyper, int64_t batch_stride, int64_t n_batches,
                      int64_t draws_per_batch, float lr, void* stream);
 
+/* Dense optimiser over a [rows, dim] table of WIDE rows followed by the in-place row renormalisation W <- W / ||row||_2 that
+ * Rescal.embed applies to rel_matrices at the next forward (models/pairwise.py:843-844): the optimiser launch leaves the sums of
+ * squares of 4 096-float chunks in `scratch`, one rescale launch follows -- two launches and one pass less than kge_optimizer_step +
+ * kge_rescal_normalize_ws, bit-identical rows.  rows < 1 024, dim >= 16 384 (kge_optimizer_step_rownorm_ok); scratch: rows *
+ * ceil(dim / 4096) floats (kge_rescal_normalize_scratch_bytes).  dev_cursor / next_cursor / next_hyper: all NULL, or the step-state
+ * transition of kge_optimizer_step_advance folded into the launch (hipGraph-replayed steps).  Replaces: optimizer.step() +
+ * zero_grad() on rel_matrices (utils/trainer.py:272,299) + the rel_matrices half of Rescal.embed's renormalisation. */
+int kge_optimizer_step_rownorm_ok(int64_t rows, int64_t dim);
+int kge_optimizer_step_rownorm(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int64_t dim, float lr,
+                               int64_t step, int32_t zero_grad, const float* dev_hyper, void* scratch, size_t scratch_bytes,
+                               const int64_t* dev_cursor, int64_t* next_cursor, float* next_hyper, int64_t batch_stride,
+                               int64_t n_batches, int64_t draws_per_batch, void* stream);
+
 /* kge_optimizer_step for hipGraph-replayed steps, with kge_step_advance for the FOLLOWING step folded into the same
  * launch: the sweep reads its scalars from dev_hyper (this step's set) and thread 0 derives the next step's state
  * next_cursor / next_hyper from dev_cursor.  The two sets must be distinct buffers (the replayed graphs alternate

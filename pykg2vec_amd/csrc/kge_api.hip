@@ -455,6 +455,24 @@ int kge_optimizer_step_rows_staged(int32_t kind, float* param, float* grad, floa
                                  touched_rows, touched_clear, stage, (hipStream_t)stream);
 }
 
+int kge_optimizer_step_rownorm_ok(int64_t rows, int64_t dim) {
+    return optimizer_rownorm_ok(rows, dim, (size_t)-1) ? 1 : 0;
+}
+
+int kge_optimizer_step_rownorm(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int64_t dim, float lr,
+                               int64_t step, int32_t zero_grad, const float* dev_hyper, void* scratch, size_t scratch_bytes,
+                               const int64_t* dev_cursor, int64_t* next_cursor, float* next_hyper, int64_t batch_stride,
+                               int64_t n_batches, int64_t draws_per_batch, void* stream) {
+    if (!param || !grad || rows <= 0 || dim <= 0 || !scratch || (step < 1 && !dev_hyper)) { set_error("kge_optimizer_step_rownorm: bad arguments"); return -1; }
+    if ((dev_cursor || next_cursor || next_hyper) && (!dev_cursor || !next_cursor || !next_hyper || !dev_hyper || dev_cursor == next_cursor || dev_hyper == next_hyper || n_batches < 1)) {
+        set_error("kge_optimizer_step_rownorm: the step-state transition needs dev_hyper, dev_cursor and a different next set");
+        return -1;
+    }
+    return launch_optimizer_rownorm(kind, param, grad, state1, state2, rows, dim, lr, step, zero_grad, dev_hyper, (float*)scratch,
+                                    scratch_bytes / sizeof(float), dev_cursor, next_cursor, next_hyper, batch_stride, n_batches, draws_per_batch,
+                                    (hipStream_t)stream);
+}
+
 int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,
                                int32_t zero_grad, const float* dev_hyper, const int64_t* dev_cursor, int64_t* next_cursor,
                                float* next_hyper, int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch,

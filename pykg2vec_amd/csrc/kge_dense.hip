@@ -129,8 +129,29 @@ __global__ __launch_bounds__(1024) void k_rel_group_small(IdSplit r, int n, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < R; i += 1024) s_cnt[i] = 0;
     if (tid < 2) s_carry[tid] = 0;
+    // sorted form (n <= kStageMaxN): this thread's pairs -- their entity ids and relation -- are requested now and live in registers
+    constexpr int kPer = kStageMaxN / 1024;
+    int4 ids[kPer];
+    int rel_of[kPer];
+    if (pg.sorted) {
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            ids[u] = make_int4(0, 0, 0, 0); rel_of[u] = 0;
+            if (1024 * u < n) {   // (uniform)
+                const int i = min(tid + 1024 * u, n - 1);
+                ids[u] = make_int4((int)pg.ph[i], (int)pg.pt[i], (int)pg.nh[i], (int)pg.nt[i]);
+                rel_of[u] = (int)r.at(i);
+            }
+        }
+    }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) atomicAdd(&s_cnt[(int)r.at(i)], 1);
+    if (pg.sorted) {
+#pragma unroll
+        for (int u = 0; u < kPer; ++u)
+            if (tid + 1024 * u < n) atomicAdd(&s_cnt[rel_of[u]], 1);
+    } else {
+        for (int i = tid; i < n; i += 1024) atomicAdd(&s_cnt[(int)r.at(i)], 1);
+    }
     __syncthreads();
     for (int base = 0; base < R; base += 1024) {   // exclusive scans of counts and of ceil(counts / TILE), 1024 relations per pass
         const int idx = base + tid;
@@ -164,19 +185,10 @@ __global__ __launch_bounds__(1024) void k_rel_group_small(IdSplit r, int n, int 
         // pair index (one wave per relation, bitonic over the lanes), then ids and descriptors are written from the final order.  (n <= kStageMaxN: s_perm fits behind the three relation arrays.)
         int* s_perm = s_toff + R + 1;      // [n] grouped position -> pair
         int* s_inv = s_perm + n;           // [n] pair -> grouped position
-        constexpr int kPer = kStageMaxN / 1024;
-        int4 ids[kPer];                    // this thread's pairs' entity ids, requested now (they depend on nothing computed here)
 #pragma unroll
         for (int u = 0; u < kPer; ++u) {
-            ids[u] = make_int4(0, 0, 0, 0);
-            if (1024 * u < n) {   // (uniform)
-                const int i = min(tid + 1024 * u, n - 1);
-                ids[u] = make_int4((int)pg.ph[i], (int)pg.pt[i], (int)pg.nh[i], (int)pg.nt[i]);
-            }
-        }
-        for (int i = tid; i < n; i += 1024) {
-            const int rel = (int)r.at(i);
-            s_perm[s_off[rel] + atomicAdd(&s_cnt[rel], 1)] = i;
+            const int i = tid + 1024 * u;
+            if (i < n) s_perm[s_off[rel_of[u]] + atomicAdd(&s_cnt[rel_of[u]], 1)] = i;
         }
         __syncthreads();
         for (int rel = wave; rel < R; rel += 16) {
@@ -1487,7 +1499,7 @@ static bool rescal_slab_taken(const kge_model_desc* m, int64_t n, size_t ws_byte
            switch_value("RESCAL_SLAB") != 0;
 }
 bool rescal_stage_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
-    // (the deterministic grouping keeps 3 R + 2 n + 2 ints in the 64 KB of LDS a launch gets without opting in)
+    // (the sorted grouping keeps 3 R + 2 n + 2 ints in the 64 KB of LDS a launch gets without opting in)
     return m->dim % 4 == 0 && n <= kStageMaxN && (3 * m->tot_relation + 2 * n + 2) * (int64_t)sizeof(int) <= 64 * 1024 &&
            m->tot_entity < (1ll << 31) && rescal_slab_taken(m, n, ws_bytes);
 }

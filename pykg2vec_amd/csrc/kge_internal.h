@@ -180,6 +180,12 @@ int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, in
                           int zero_grad, int normalize, const float* dev_hyper, const unsigned* touched, unsigned* touched_clear,
                           const kge_rescal_stage* stage /* NULL: the gradient rows of `g` */, hipStream_t s);
 
+bool optimizer_rownorm_ok(int64_t rows, int64_t dim, size_t scratch_floats);
+int launch_optimizer_rownorm(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int64_t dim, float lr, int64_t step,
+                             int zero_grad, const float* dev_hyper, float* scratch, size_t scratch_floats, const int64_t* cursor_in,
+                             int64_t* cursor_out, float* hyper_out, int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch,
+                             hipStream_t s);
+
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);
 // the staged owner-computes step of the remaining pointwise gather models (kge_ownx.hip)

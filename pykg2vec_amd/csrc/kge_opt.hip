@@ -325,4 +325,90 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
     return -1;
 }
 
+// ---- dense optimiser over a [rows, dim] table of WIDE rows (RESCAL's relation matrices: 37 x 40 000) followed by the in-place row
+// renormalisation Rescal.embed applies at the next forward (models/pairwise.py:843-844, get_normalized_data).  Separately that is
+// k_opt (all streams) + k_row_sumsq_chunks (re-reads the table) + k_row_scale_chunks: here the optimiser launch itself leaves the
+// chunks' sums of squares -- same chunking (4 096 floats), same element-to-thread map and summation order as k_row_sumsq_chunks, so the
+// stored rows are bit-identical to the three-launch form -- and only the rescale pass follows.
+constexpr int kOptNormChunk = 4096;     // = kNormChunk of kge_dense.hip (the separate normalisation pass)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_opt_sumsq_chunks(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
+                                                          float* __restrict__ s2, int64_t dim, int nchunk, OptArgs a,
+                                                          const float* __restrict__ dev_hyper, int zero, float* __restrict__ part,
+                                                          AdvanceArgs adv) {
+    if (dev_hyper) { a.lr = dev_hyper[0]; a.step_size = dev_hyper[1]; a.bc2_sqrt = dev_hyper[2]; }
+    if (adv.cin != nullptr && blockIdx.x == 0 && threadIdx.x == 0) advance_state(adv);
+    __shared__ float sw[4];
+    const int64_t row = blockIdx.x / nchunk;
+    const int ch = blockIdx.x % nchunk;
+    const int64_t base = row * dim;
+    const int64_t lo = (int64_t)ch * kOptNormChunk, hi = min(dim, lo + kOptNormChunk);
+    constexpr int PER = kOptNormChunk / 256;
+    float pv[PER], gv[PER], av[PER], bv[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {      // every stream of the chunk requested before the first update (clamped addresses)
+        const int64_t c = base + min(lo + threadIdx.x + 256 * u, hi - 1);
+        pv[u] = p[c]; gv[u] = g[c];
+        av[u] = KIND != KGE_OPT_SGD ? s1[c] : 0.f;
+        bv[u] = KIND == KGE_OPT_ADAM ? s2[c] : 0.f;
+    }
+    float n2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t cc = lo + threadIdx.x + 256 * u;
+        if (cc < hi) {
+            const int64_t c = base + cc;
+            opt_update<KIND>(pv[u], gv[u], av[u], bv[u], a);
+            p[c] = pv[u];
+            if constexpr (KIND != KGE_OPT_SGD) s1[c] = av[u];
+            if constexpr (KIND == KGE_OPT_ADAM) s2[c] = bv[u];
+            if (zero && gv[u] != 0.f) g[c] = 0.f;
+            n2 = fmaf(pv[u], pv[u], n2);
+        }
+    }
+    n2 = wave_sum(n2);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = n2;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ __launch_bounds__(256) void k_opt_scale_chunks(float* __restrict__ w, int64_t dim, int nchunk, const float* __restrict__ part) {
+    const int64_t row = blockIdx.x / nchunk;
+    const int ch = blockIdx.x % nchunk;
+    float t = 0.f;
+    for (int i = 0; i < nchunk; ++i) t += part[row * nchunk + i];
+    const float nrm = sqrtf(t);
+    float* p = w + row * dim;
+    const int64_t lo = (int64_t)ch * kOptNormChunk, hi = min(dim, lo + kOptNormChunk);
+    for (int64_t c = lo + threadIdx.x; c < hi; c += 256) p[c] = p[c] / nrm;
+}
+
+bool optimizer_rownorm_ok(int64_t rows, int64_t dim, size_t scratch_floats) {
+    const int64_t nchunk = (dim + kOptNormChunk - 1) / kOptNormChunk;
+    return dim >= 4 * kOptNormChunk && rows >= 1 && rows < 1024 && scratch_floats >= (size_t)(rows * nchunk);
+}
+
+int launch_optimizer_rownorm(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int64_t dim, float lr, int64_t step,
+                             int zero_grad, const float* dev_hyper, float* scratch, size_t scratch_floats, const int64_t* cursor_in,
+                             int64_t* cursor_out, float* hyper_out, int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch,
+                             hipStream_t s) {
+    if (!optimizer_rownorm_ok(rows, dim, scratch_floats)) { set_error("kge_optimizer_step_rownorm: rows of at least 16 384 floats, fewer than 1 024 rows, scratch of rows * ceil(dim / 4096) floats"); return -1; }
+    if ((kind != KGE_OPT_SGD && !s1) || (kind == KGE_OPT_ADAM && !s2)) { set_error("kge_optimizer_step_rownorm: optimiser state missing"); return -1; }
+    AdvanceArgs adv;
+    adv.cin = cursor_in; adv.cout = cursor_out; adv.hout = hyper_out;
+    adv.batch_stride = batch_stride; adv.n_batches = n_batches > 0 ? n_batches : 1; adv.draws_per_batch = draws_per_batch;
+    adv.lr = lr;
+    const OptArgs a = make_opt_args(lr, step < 1 ? 1 : step);
+    const int nchunk = (int)((dim + kOptNormChunk - 1) / kOptNormChunk);
+    const dim3 grid((unsigned)(rows * nchunk));
+    switch (kind) {
+        case KGE_OPT_SGD: hipLaunchKernelGGL((k_opt_sumsq_chunks<KGE_OPT_SGD>), grid, dim3(256), 0, s, p, g, s1, s2, dim, nchunk, a, dev_hyper, zero_grad, scratch, adv); break;
+        case KGE_OPT_ADAM: hipLaunchKernelGGL((k_opt_sumsq_chunks<KGE_OPT_ADAM>), grid, dim3(256), 0, s, p, g, s1, s2, dim, nchunk, a, dev_hyper, zero_grad, scratch, adv); break;
+        case KGE_OPT_ADAGRAD: hipLaunchKernelGGL((k_opt_sumsq_chunks<KGE_OPT_ADAGRAD>), grid, dim3(256), 0, s, p, g, s1, s2, dim, nchunk, a, dev_hyper, zero_grad, scratch, adv); break;
+        case KGE_OPT_RMSPROP: hipLaunchKernelGGL((k_opt_sumsq_chunks<KGE_OPT_RMSPROP>), grid, dim3(256), 0, s, p, g, s1, s2, dim, nchunk, a, dev_hyper, zero_grad, scratch, adv); break;
+        default: set_error("kge_optimizer_step_rownorm: unknown optimizer %d", kind); return -1;
+    }
+    hipLaunchKernelGGL(k_opt_scale_chunks, grid, dim3(256), 0, s, p, dim, nchunk, scratch);
+    return check_launch("k_opt_sumsq_chunks / k_opt_scale_chunks");
+}
+
 }  // namespace kge

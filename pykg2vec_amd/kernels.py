@@ -527,6 +527,34 @@ def rescal_normalize_relations(rel, k):
                                         _stream()), "kge_rescal_normalize_ws")
 
 
+def optimizer_step_rownorm_ok(rows, dim):
+    return bool(L.load().kge_optimizer_step_rownorm_ok(int(rows), int(dim)))
+
+
+def optimizer_step_rownorm(kind, param, grad, state1, state2, rows, dim, lr, step, zero_grad=True, advance=None):
+    """kge_optimizer_step_rownorm: dense optimiser over a [rows, dim] table of wide rows + the in-place row renormalisation, with the
+    rows' sums of squares left by the optimiser launch itself.  advance: None, or (hyper, cursor, next_cursor, next_hyper, batch_stride,
+    n_batches, draws_per_batch) -- the step-state transition of optimizer_step_advance folded in."""
+    lib = L.load()
+    need = lib.kge_rescal_normalize_scratch_bytes(int(rows), int(round(dim ** 0.5))) if int(round(dim ** 0.5)) ** 2 == dim else 4 * int(rows) * ((int(dim) + 4095) // 4096)
+    need = max(need, 4 * int(rows) * ((int(dim) + 4095) // 4096))
+    key = (param.device, need)
+    if key not in _rescal_scratch:
+        _rescal_scratch[key] = torch.empty(max(1, need // 4), dtype=torch.float32, device=param.device)
+    sc = _rescal_scratch[key]
+    p1 = _dev(state1, torch.float32, "state1") if state1 is not None else None
+    p2 = _dev(state2, torch.float32, "state2") if state2 is not None else None
+    if advance is not None:
+        hyper, cursor, next_cursor, next_hyper, batch_stride, n_batches, draws = advance
+        adv = (_dev(hyper, torch.float32, "hyper"), _dev(cursor, torch.int64, "cursor"), _dev(next_cursor, torch.int64, "next_cursor"),
+               _dev(next_hyper, torch.float32, "next_hyper"), int(batch_stride), int(n_batches), int(draws))
+    else:
+        adv = (None, None, None, None, 0, 1, 0)
+    L.check(lib.kge_optimizer_step_rownorm(OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"), _dev(grad, torch.float32, "grad"), p1, p2,
+                                           int(rows), int(dim), float(lr), int(step), 1 if zero_grad else 0, adv[0], sc.data_ptr(), sc.numel() * 4,
+                                           adv[1], adv[2], adv[3], adv[4], adv[5], adv[6], _stream()), "kge_optimizer_step_rownorm")
+
+
 def optimizer_step_advance(kind, param, grad, state1, state2, lr, hyper, cursor, next_cursor, next_hyper, batch_stride,
                            n_batches, draws_per_batch, zero_grad=True):
     """Dense optimiser sweep of a graph-replayed step + the next step's device-resident state (kge_optimizer_step_advance)."""

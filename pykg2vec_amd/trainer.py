@@ -109,7 +109,7 @@ class FlatState:
         self.K.optimizer_step_advance(self.optimizer, self.param_shard, self.grad_shard, self.state1, self.state2, lr, hyper,
                                       cursor, next_cursor, next_hyper, batch_stride, n_batches, draws, zero_grad=True)
 
-    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None, touched=None, touched_clear=None, stage=None):
+    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None, touched=None, touched_clear=None, stage=None, rest_rownorm=None):
         """The optimiser step with the FIRST table ([rows, dim], at offset 0 of the flat buffers) handled by the row-owner kernel
         (which can store the rows renormalised: RESCAL) and the remaining tables by the flat sweep.  advance: as
         optimizer_step_advance (device-resident step state of hipGraph-replayed steps); single GPU only."""
@@ -126,10 +126,19 @@ class FlatState:
                                        rows, dim, lr, self.step, zero_grad=True, normalize=normalize, dev_hyper=hyper,
                                        touched=touched, touched_clear=touched_clear)
         rest = (self.param[cut:], self.grad[cut:], sl(self.state1, cut, self.numel), sl(self.state2, cut, self.numel))
+        if rest_rownorm is not None:
+            # the remaining table is [rows, dim] of wide rows to be renormalised behind its sweep (RESCAL's relation matrices): the
+            # optimiser launch leaves the rows' sums of squares, one rescale launch follows (kge_optimizer_step_rownorm)
+            r_rows, r_dim = rest_rownorm
+            n1 = r_rows * r_dim
+            self.K.optimizer_step_rownorm(self.optimizer, rest[0][:n1], rest[1][:n1], sl(rest[2], 0, n1), sl(rest[3], 0, n1), r_rows, r_dim,
+                                          lr, self.step, zero_grad=True, advance=advance)
+            return True
         if advance is not None:
             self.K.optimizer_step_advance(self.optimizer, *rest, lr, *advance, zero_grad=True)
         else:
             self.K.optimizer_step(self.optimizer, *rest, lr, self.step, zero_grad=True)
+        return False
 
     def optimizer_step(self, lr, dev_hyper=None):
         """Dense optimiser sweep over this rank's shard (the whole buffer when world_size == 1); clears the reduced
@@ -1051,12 +1060,17 @@ class Trainer:
                 par, self._touched_step = self._touched_step, None
                 bm = self._touched_bitmaps() if par is not None else (None, None)
                 st, self._stage_step = getattr(self, "_stage_step", None), None
-                flat.optimizer_step_rows_first(self.config.learning_rate, ent.shape[0], ent.shape[1], keep, advance,
-                                               touched=bm[par] if par is not None else None,
-                                               touched_clear=bm[1 - par] if par is not None else None,
-                                               stage=st if par is not None else None)
+                rel = flat.views[1]
+                rownorm = None
+                if (keep and self.K is K and len(flat.views) == 2 and flat.offsets[1] + rel.numel() == flat.numel
+                        and K.optimizer_step_rownorm_ok(rel.shape[0], rel.shape[1])):
+                    rownorm = (rel.shape[0], rel.shape[1])
+                done = flat.optimizer_step_rows_first(self.config.learning_rate, ent.shape[0], ent.shape[1], keep, advance,
+                                                      touched=bm[par] if par is not None else None,
+                                                      touched_clear=bm[1 - par] if par is not None else None,
+                                                      stage=st if par is not None else None, rest_rownorm=rownorm)
                 self._touch_parity ^= 1
-                if keep:
+                if keep and not done:
                     self.K.rescal_normalize_relations(flat.views[1], self.model.hidden_size)
                 self._rescal_normalised = keep
                 return

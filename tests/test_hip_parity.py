@@ -1057,3 +1057,33 @@ def test_rescal_staged_entity_gradients_are_reproducible_and_equal_the_atomic_st
     # isolated entries may differ by a few lr (as in the pull-vs-push tests); the atomic path itself differs run to run by as much
     off = float((~torch.isclose(pa, pc, atol=2e-4, rtol=1e-3)).float().mean())
     assert off <= 2e-3, (off, float((pa - pc).abs().max()))
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd", "adagrad", "rms"])
+@pytest.mark.parametrize("rows,k", [(7, 136), (37, 200), (3, 128)])
+def test_optimizer_rownorm_equals_sweep_plus_normalisation_bit_for_bit(hip, opt, rows, k):
+    """kge_optimizer_step_rownorm (round 5): the dense optimiser over RESCAL's relation matrices with the rows' sums of squares left by
+    the optimiser launch itself + one rescale launch must store exactly what kge_optimizer_step + kge_rescal_normalize_ws store (same
+    chunking, same element-to-thread map and summation order), for several steps, with and without gradients."""
+    from pykg2vec_amd import kernels as K
+    dim = k * k
+    assert K.optimizer_step_rownorm_ok(rows, dim)
+    g0 = torch.Generator(device="cpu").manual_seed(rows * 1000 + k)
+    p = torch.randn(rows * dim, generator=g0).cuda()
+    runs = []
+    for fused in (False, True):
+        pa = p.clone()
+        s1 = None if opt == "sgd" else torch.zeros_like(pa)
+        s2 = torch.zeros_like(pa) if opt == "adam" else None
+        for step in range(1, 5):
+            g = (torch.randn(rows * dim, generator=torch.Generator(device="cpu").manual_seed(step)) * (step % 2)).cuda()   # zero on even steps
+            if fused:
+                K.optimizer_step_rownorm(opt, pa, g, s1, s2, rows, dim, 0.01, step)
+            else:
+                K.optimizer_step(opt, pa, g, s1, s2, 0.01, step)
+                K.rescal_normalize_relations(pa.view(rows, dim), k)
+            assert bool((g == 0).all())
+        runs.append((pa, s1, s2))
+    for a, b in zip(*runs):
+        assert (a is None and b is None) or torch.equal(a, b)
+    assert torch.allclose(runs[1][0].view(rows, dim).norm(dim=1), torch.ones(rows, device="cuda"), atol=1e-5)
