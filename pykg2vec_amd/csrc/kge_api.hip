@@ -34,6 +34,7 @@ bool pick_geometry(int d, Geometry* out) {
     else if (d <= 256) *out = {32, 8};
     else if (d <= 512) *out = {64, 8};
     else if (d <= 1024) *out = {64, 16};
+    else if (d <= 2048) *out = {64, 32};   // (32 floats of every row per lane: functional -- the wide rows spill for the many-row models)
     else return false;
     return true;
 }

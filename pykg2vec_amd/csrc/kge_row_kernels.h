@@ -496,6 +496,7 @@ struct Launch {
         KGE_FOR_GEOMETRY(MID, 32, 8, BODY)                      \
         KGE_FOR_GEOMETRY(MID, 64, 8, BODY)                      \
         KGE_FOR_GEOMETRY(MID, 64, 16, BODY)                     \
+        KGE_FOR_GEOMETRY(MID, 64, 32, BODY)                     \
         break;                                                  \
     }
 

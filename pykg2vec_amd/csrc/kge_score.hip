@@ -797,7 +797,7 @@ __global__ __launch_bounds__(kBlock) void k_selfadv_coeffs(float* __restrict__ p
 
 static bool geometry_for(const kge_model_desc* m, Geometry* geo) {
     if (!pick_geometry(m->dim, geo)) {
-        set_error("hidden size %d exceeds the register-resident row kernels (max 1024)", m->dim);
+        set_error("hidden size %d exceeds the register-resident row kernels (max 2048)", m->dim);
         return false;
     }
     return true;

@@ -14,7 +14,7 @@ namespace kge {
 
 static bool geometry_for(const kge_model_desc* m, Geometry* geo) {
     if (!pick_geometry(m->dim, geo)) {
-        set_error("hidden size %d exceeds the register-resident row kernels (max 1024)", m->dim);
+        set_error("hidden size %d exceeds the register-resident row kernels (max 2048)", m->dim);
         return false;
     }
     return true;

@@ -10,7 +10,7 @@ int launch_pointwise_logistic_sampled_staged(const kge_model_desc* m, const int6
                                              int64_t n_slots, uint64_t seed, uint64_t offset, float lmbda, int reg_type,
                                              float* loss, const StageSink& sink, hipStream_t s) {
     Geometry geo;
-    if (!pick_geometry(m->dim, &geo)) { set_error("hidden size %d exceeds the register-resident row kernels (max 1024)", m->dim); return -1; }
+    if (!pick_geometry(m->dim, &geo)) { set_error("hidden size %d exceeds the register-resident row kernels (max 2048)", m->dim); return -1; }
     if (neg_rate > geo.G) { set_error("fused pointwise sampler: neg_rate %d exceeds the lane group (%d)", neg_rate, geo.G); return -1; }
     FusedSampler fs;
     fs.triples = triples; fs.perm = perm; fs.start = start; fs.E = m->tot_entity; fs.bern = bern;
