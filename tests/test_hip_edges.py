@@ -52,7 +52,7 @@ def test_every_row_length_boundary(hip, d):
 def test_hidden_size_beyond_register_kernels_fails_loudly(hip):
     from pykg2vec_amd._lib import KgeHipError
     rng = np.random.default_rng(0)
-    hp = dict(hidden_size=1025, l1_flag=True, margin=1.0)
+    hp = dict(hidden_size=2049, l1_flag=True, margin=1.0)
     P, m, tr, cfg, trip = _setup(hip, "transe", hp, 8, 2, rng)
     with pytest.raises(KgeHipError, match="exceeds"):
         m(hip.dev(trip[:4, 0] % 8), hip.dev(trip[:4, 1] % 2), hip.dev(trip[:4, 2] % 8))
