@@ -1227,6 +1227,15 @@ class Trainer:
         self._in_epoch, self._rescal_normalised, self._rescal_last = True, False, num_batch == 1
         try:
             return self._train_epoch_body(epoch_idx, num_batch)
+        except BaseException:
+            # a step that died between the pair step's registrations and the optimiser that consumes (and resets) them would leave
+            # entries in the per-entity lists of the staged RESCAL gradients: start the next epoch from empty lists
+            st = getattr(self, "_rescal_stage", None)
+            if st is not None:
+                st.count.zero_(); st.head.zero_()
+                for b in (self._touched or ()):
+                    b.zero_()
+            raise
         finally:
             self._in_epoch, self._rescal_normalised, self._rescal_last = False, False, False
 
