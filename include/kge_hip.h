@@ -704,9 +704,13 @@ int kge_head_1n_forward_bf16(const float* x, int64_t batch, int32_t dim, const f
                              float* preds, void* stream);
 
 /* Autograd backward of the head given d loss / d preds: dx[B,dim] is overwritten, g_ent[E,dim] and g_bias[E] are
- * accumulated into (any of the three may be NULL). */
+ * accumulated into (any of the three may be NULL).  workspace (kge_head_1n_backward_workspace_bytes(), a constant; may be NULL):
+ * room for the partial tiles of the split-K products, which are then added in split order -- bit-reproducible gradients; without it
+ * the partial tiles are combined with float atomics. */
+size_t kge_head_1n_backward_workspace_bytes(void);
 int kge_head_1n_backward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity,
-                         const float* preds, const float* dpreds, float* dx, float* g_ent, float* g_bias, void* stream);
+                         const float* preds, const float* dpreds, float* dx, float* g_ent, float* g_bias,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* One direction of Criterion.multi_class_bce (utils/criterion.py:41-49) fused with the head and its backward:
  * loss += mean_{B*E} BCEWithLogits(preds, y)  -- the reference applies the logits loss to the SIGMOID OUTPUTS, kept --

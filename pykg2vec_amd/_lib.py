@@ -165,8 +165,9 @@ _SIGNATURES = {
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_head_1n_forward_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "kge_head_1n_backward_workspace_bytes": (ctypes.c_size_t, []),
     "kge_head_1n_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64]
-                             + [ctypes.c_void_p] * 6),
+                             + [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
     "kge_head_1n_bce_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
     "kge_head_1n_bce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,

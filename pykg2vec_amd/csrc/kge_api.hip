@@ -799,9 +799,13 @@ int kge_head_1n_forward_bf16(const float* x, int64_t batch, int32_t dim, const f
     return launch_head_forward(x, batch, dim, ent, tot_entity, bias, preds, 1, (hipStream_t)stream);
 }
 
+size_t kge_head_1n_backward_workspace_bytes(void) { return head_backward_workspace_bytes(); }
+
 int kge_head_1n_backward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* preds,
-                         const float* dpreds, float* dx, float* g_ent, float* g_bias, void* stream) {
-    return launch_head_backward(x, batch, dim, ent, tot_entity, preds, dpreds, dx, g_ent, g_bias, (hipStream_t)stream);
+                         const float* dpreds, float* dx, float* g_ent, float* g_bias, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    return launch_head_backward(x, batch, dim, ent, tot_entity, preds, dpreds, dx, g_ent, g_bias, workspace, workspace_bytes,
+                                (hipStream_t)stream);
 }
 
 size_t kge_head_1n_bce_workspace_bytes(int64_t batch, int64_t tot_entity, int64_t n_pos) {

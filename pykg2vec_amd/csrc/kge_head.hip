@@ -16,6 +16,7 @@
 //   k_head_dent       g_ent += dZ^T X        [E,B]x[B,d] ;  g_bias += column sums of dZ
 // For the autograd form dZ = dpreds * p * (1 - p) is formed while the operand tile is staged.
 #include "kge_internal.h"
+#include <type_traits>
 
 namespace kge {
 
@@ -27,7 +28,15 @@ constexpr int HS = HK + 1;
 
 __device__ __forceinline__ int head_row(int reg, int lk) { return (reg & 3) + 8 * (reg >> 2) + 4 * lk; }
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
-__device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+// Criterion.multi_class_bce on a NEGATIVE label y0 (utils/criterion.py:41-49: BCEWithLogitsLoss applied to the sigmoid OUTPUT p):
+// loss term softplus(p) - p y0 and its derivative through the sigmoid, (sigmoid(p) - y0) p (1 - p).  With t = exp(-p), p in (0, 1):
+// softplus(p) = p + log(1 + t), sigmoid(p) = 1 / (1 + t), and 1 + t is in (1.36, 2] -- no cancellation, so the hardware exp / log /
+// rcp (1-2 ulp each) serve: these terms enter sums over B E elements.  p itself, the model output, keeps the exact sigmoidf_.
+__device__ __forceinline__ float bce_neg_terms(float p, float y0, float& loss_term) {
+    const float u = 1.0f + __expf(-p);
+    loss_term = p + __logf(u) - p * y0;
+    return (__builtin_amdgcn_rcpf(u) - y0) * p * (1.f - p);
+}
 
 // one 32-wide K slab: acc += A[32 x 32] B[32 x 32] with A rows / B columns taken from LDS tiles stored [row][k]
 __device__ __forceinline__ void slab_mfma(const float* __restrict__ sa, const float* __restrict__ sb, int li, int lk, f32x16& acc) {
@@ -68,10 +77,28 @@ struct HeadArgs {
     const float* x; const float* ent; const float* bias;
     int64_t B, E; int d;
     float* preds;                 // fwd: sigmoid outputs [B,E]
-    float* dz;                    // bce: gradient wrt the logits [B,E]
+    float* dz;                    // bce: gradient wrt the logits [B, ldz]: rows padded to a multiple of four floats, so that the
+    int64_t ldz;                  //      backward products fetch them with aligned 16-byte loads (E is odd in every dataset)
     float y0, inv_count;          // bce: negative label, 1/(B*E)
     float* loss;                  // striped accumulators
+    int xcd_runs;                 // tile numbering: 1 = one contiguous run of tiles per XCD (head_tile)
 };
+
+// Workgroup -> output tile.  Consecutive workgroup ids go round robin over the 8 XCDs, each with its own L2.  E is odd in every
+// dataset of the reference (14 951, 40 943), so the 128-byte row segments a wave stores straddle cache lines and the tiles either
+// side of a column boundary share a line: with the plain (x = entity tile, y = batch tile) grid those two tiles sit on DIFFERENT
+// XCDs and the line leaves both L2s as a partial write.  Tiles are therefore numbered so that every XCD owns one contiguous run of
+// tiles (entity tile fastest): neighbours along a row are written from one L2, which merges them, and share the x rows.
+__device__ __forceinline__ void head_tile(const HeadArgs& a, int tile, int64_t& e0, int64_t& b0) {
+    const int64_t nte = (a.E + tile - 1) / tile, ntb = (a.B + tile - 1) / tile, T = nte * ntb;
+    int64_t t = blockIdx.x;
+    if (a.xcd_runs) {
+        const int64_t x = t & 7, slot = t >> 3, lo = T >> 3, rem = T & 7;
+        t = x * lo + (x < rem ? x : rem) + slot;
+    }
+    const int64_t bt = t / nte;
+    e0 = (t - bt * nte) * tile; b0 = bt * tile;
+}
 
 // MODE 0: preds.  MODE 1: fused multi_class_bce with every label = y0 (positives are corrected by k_head_bce_pos).
 template <int MODE>
@@ -79,7 +106,8 @@ __global__ __launch_bounds__(256) void k_head_gemm(HeadArgs a) {
     __shared__ float sA[HT * HS], sB[HT * HS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lk = lane >> 5;
-    const int64_t e0 = (int64_t)blockIdx.x * HT, b0 = (int64_t)blockIdx.y * HT;
+    int64_t e0, b0;
+    head_tile(a, HT, e0, b0);
     const int wr = wave >> 1, wc = wave & 1;  // wave's 32x32 sub-tile: rows (batch) wr, columns (entities) wc
     f32x16 acc = {0};
     auto fa = [&](int sl, int j, int& pos) -> float {  // x tile [b][k], coalesced along k
@@ -104,98 +132,189 @@ __global__ __launch_bounds__(256) void k_head_gemm(HeadArgs a) {
             if constexpr (MODE == 0) {
                 a.preds[b * a.E + e] = p;
             } else {
-                lsum += softplusf_(p) - p * a.y0;                                   // BCEWithLogits(p, y0)
-                a.dz[b * a.E + e] = (sigmoidf_(p) - a.y0) * p * (1.f - p) * a.inv_count;
+                float lt;
+                a.dz[b * a.ldz + e] = bce_neg_terms(p, a.y0, lt) * a.inv_count;
+                lsum += lt;
             }
         }
     }
     if constexpr (MODE == 1) block_accumulate_loss<1>(lsum * a.inv_count, 0, a.loss);
 }
 
-// ---- the same GEMM at a 128 x 128 macro-tile (large batches): 4 waves x (2 x 2) accumulators of 32 x 32, i.e. 64 FMAs per
-// operand float fetched from LDS instead of 16; both operand tiles are row-major in memory (k contiguous), fetched with one
-// 16-byte load per thread and 16-deep K slab and written k-major into LDS ([k][128 + pad]: conflict-free MFMA operand reads);
-// slabs double-buffered in LDS with the next slab's global loads in flight during the current slab's 32 MFMAs per wave (one
-// barrier per slab).  The accumulation order over k is the old kernel's (one MFMA chain), so the logits are bit-identical.
-constexpr int HT2 = 128, HK2 = 16, HLD2 = HT2 + 4;
+constexpr int HT2 = 128, HK2 = 16;   // the large tile: 128 x 128 outputs per workgroup, K slabs of 16
 
-template <int MODE>
-__global__ __launch_bounds__(256, 3) void k_head_gemm128(HeadArgs a) {
-    __shared__ float sA[2][HK2][HLD2], sB[2][HK2][HLD2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 31, lk = lane >> 5;
-    const int64_t e0 = (int64_t)blockIdx.x * HT2, b0 = (int64_t)blockIdx.y * HT2;
-    const int wr = wave >> 1, wc = wave & 1;   // wave's 64 x 64 sub-tile: batch rows wr, entity columns wc
-    // staging role: float4 number t + 256 j of a slab = (row = idx / 4, k = 4 * (idx % 4) .. + 3)
-    const int srow = threadIdx.x >> 2, sk4 = (threadIdx.x & 3) * 4;
-    const int nslab = (a.d + HK2 - 1) / HK2;
-    float4 ra[2], rb[2];
-    auto load_slab = [&](int sl) {
-        const int k = sl * HK2 + sk4;
+// ---- the 128 x 128 macro-tile on v_mfma_f32_16x16x4_f32 (the form kge_eval.hip::k_eval_gemm settled on: 40-cycle dependent latency
+// instead of 64, holds its issue rate with four waves per SIMD -- tools/mfma_bench.hip 154 vs 129 TF -- and 64 accumulator registers
+// as 4 x 4 blocks of 16 x 16 leave room for four workgroups per CU).  Row block mi of a wave holds batch rows 4 r + mi, column block
+// ni entity columns 4 c + ni (r, c = row / column inside the MFMA block): a lane's four A operands (and four B operands) of a k-step
+// are 16 consecutive bytes of the k-major slab, and its four results of one batch row are four CONSECUTIVE entities -- one 16-byte
+// store (4-byte aligned: E is odd, global_store_dwordx4 takes it), 256 contiguous bytes of a row per 16 lanes.  One MFMA chain over
+// k per element, like the other forms: bit-identical logits.
+#ifndef HEAD_OCC
+#define HEAD_OCC 4
+#endif
+#ifndef HEAD_BWD_OCC
+#define HEAD_BWD_OCC 3
+#endif
+constexpr int HLD3 = HT2 + 16;   // 16 lanes read 16 consecutive floats of row k, the next 16 lanes row k + 1: rows 16 banks apart
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) float4u { float x, y, z, w; };
+
+// Loads of the 128-wide kernels are UNCONDITIONAL on clamped addresses, and what they fetched is masked one slab LATER, where it is
+// stored into LDS (the "fix" functions of gemm128x_core): a load under a lane mask, inside a branch, or with a select on its result
+// makes the compiler wait for it on the spot, and the point of the K loop is that a slab's loads stay in flight for a whole slab
+// of matrix work.
+__device__ __forceinline__ float4 load4_clamped(const float* __restrict__ p, int64_t i, bool ok) {
+    return *reinterpret_cast<const float4*>(p + (ok ? i : 0));
+}
+__device__ __forceinline__ float4 keep_if(float4 v, bool ok) {
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+}
+__device__ __forceinline__ float4 first_n(float4 v, int nv) {
+    v.x = nv > 0 ? v.x : 0.f; v.y = nv > 1 ? v.y : 0.f; v.z = nv > 2 ? v.z : 0.f; v.w = nv > 3 ? v.w : 0.f;
+    return v;
+}
+// One operand float4 of a 16-deep slab goes to the k-major LDS image [k][128 + pad].  Two memory layouts feed it:
+//   RK  "row-major, k contiguous" (x[b][k], ent[e][k], dz[b][e] as the A operand of dX): thread t stages float4 number t + 256 j =
+//       (row t / 4 + 64 j, k = 4 (t % 4) .. + 3) -- four scalar LDS stores (the transposition);
+//   KM  "k-major" (ent[e][k] as the B operand of dX, dz[b][e] and x[b][k] in the entity-gradient product): float4 number t + 256 j =
+//       (k = idx / 32, rows 4 (idx % 32) .. + 3) -- one 16-byte LDS store.
+template <bool KM>
+__device__ __forceinline__ void stage_store(float (*sX)[HLD3], int j, const float4& v) {
+    if constexpr (KM) {
+        const int idx = threadIdx.x + 256 * j;
+        *reinterpret_cast<float4*>(&sX[idx >> 5][(idx & 31) * 4]) = v;
+    } else {
+        const int r = (threadIdx.x >> 2) + 64 * j, k = (threadIdx.x & 3) * 4;
+        sX[k + 0][r] = v.x; sX[k + 1][r] = v.y; sX[k + 2][r] = v.z; sX[k + 3][r] = v.w;
+    }
+}
+struct NoSlabHookX { __device__ __forceinline__ void operator()(float (*)[HLD3]) const {} };
+
+// K loop of a 128 x 128 tile: la / lb(slab, j) return the j-th float4 this thread stages of the A / B operand (zeros outside the
+// operand); slabs double-buffered in LDS, the next slab's global loads in flight during the current slab's 64 MFMAs per wave (one
+// barrier per slab), LDS operands of k-step kk + 4 read before the MFMAs of k-step kk are issued.  acc[mi][ni][reg] = element
+// (row 64 wr + 4 (4 lk4 + reg) + mi, column 64 wc + 4 lcol + ni) of the tile.
+template <bool A_KM, bool B_KM, class LA, class FA, class LB, class FB, class HOOK = NoSlabHookX>
+__device__ __forceinline__ void gemm128x_core(int nslab, LA la, FA fa, LB lb, FB fb, float (&sA)[2][HK2][HLD3],
+                                              float (&sB)[2][HK2][HLD3], int wr, int wc, int lcol, int lk4, f32x4 (&acc)[4][4],
+                                              HOOK hook = HOOK()) {
+    // la / lb(slab, j): the raw fetch of the j-th float4 this thread stages; fa / fb(slab, j, raw): its value (see load4_clamped)
+    decltype(la(0, 0)) ra[2];
+    decltype(lb(0, 0)) rb[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t b = b0 + srow + 64 * j, e = e0 + srow + 64 * j;
-            const bool live = k < a.d;   // d % 4 == 0: a float4 is inside the row or past its end
-            ra[j] = (live && b < a.B) ? *reinterpret_cast<const float4*>(a.x + b * a.d + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[j] = (live && e < a.E) ? *reinterpret_cast<const float4*>(a.ent + e * a.d + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    f32x16 acc[2][2];
+    for (int j = 0; j < 2; ++j) { ra[j] = la(0, j); rb[j] = lb(0, j); }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int j = 0; j < 2; ++j) { stage_store<A_KM>(sA[0], j, fa(0, j, ra[j])); stage_store<B_KM>(sB[0], j, fb(0, j, rb[j])); }
+    if (1 < nslab) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x16{0};
-    load_slab(0);
+        for (int j = 0; j < 2; ++j) { ra[j] = la(1, j); rb[j] = lb(1, j); }
+    }
+    __syncthreads();
     int buf = 0;
     for (int sl = 0; sl < nslab; ++sl) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = srow + 64 * j;
-            sA[buf][sk4 + 0][r] = ra[j].x; sA[buf][sk4 + 1][r] = ra[j].y; sA[buf][sk4 + 2][r] = ra[j].z; sA[buf][sk4 + 3][r] = ra[j].w;
-            sB[buf][sk4 + 0][r] = rb[j].x; sB[buf][sk4 + 1][r] = rb[j].y; sB[buf][sk4 + 2][r] = rb[j].z; sB[buf][sk4 + 3][r] = rb[j].w;
-        }
-        __syncthreads();   // slab sl is in LDS; everybody finished reading the buffer that is written next
-        if (sl + 1 < nslab) load_slab(sl + 1);
-        // operands of step kk + 2 are read from LDS before the MFMAs of step kk are issued (register double buffer): the LDS
-        // latency hides under 4 x 64 cycles of matrix work instead of stalling the wave in front of every quadruple
-        float na0 = sA[buf][lk][wr * 64 + li], na1 = sA[buf][lk][wr * 64 + 32 + li];
-        float nc0 = sB[buf][lk][wc * 64 + li], nc1 = sB[buf][lk][wc * 64 + 32 + li];
-#pragma unroll
-        for (int kk = 0; kk < HK2; kk += 2) {
-            const float a0 = na0, a1 = na1, c0 = nc0, c1 = nc1;
-            if (kk + 2 < HK2) {
-                na0 = sA[buf][kk + 2 + lk][wr * 64 + li]; na1 = sA[buf][kk + 2 + lk][wr * 64 + 32 + li];
-                nc0 = sB[buf][kk + 2 + lk][wc * 64 + li]; nc1 = sB[buf][kk + 2 + lk][wc * 64 + 32 + li];
-            }
-            KGE_KEEP_READS_AHEAD();
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c1, acc[1][1], 0, 0, 0);
-        }
-        buf ^= 1;
+        // LDS buffer `buf` holds slab sl; the registers hold slab sl + 1 (requested one slab ago)
+        hook(sA[buf]);
+        float na[4], nb[4];
+#define KGE_HEAD_READ(K)                                                                                                   \
+    {                                                                                                                      \
+        const float4 va = *reinterpret_cast<const float4*>(&sA[buf][(K) + lk4][wr * 64 + 4 * lcol]);                       \
+        const float4 vb = *reinterpret_cast<const float4*>(&sB[buf][(K) + lk4][wc * 64 + 4 * lcol]);                       \
+        na[0] = va.x; na[1] = va.y; na[2] = va.z; na[3] = va.w;                                                            \
+        nb[0] = vb.x; nb[1] = vb.y; nb[2] = vb.z; nb[3] = vb.w;                                                            \
     }
-    float lsum = 0.f;
+        KGE_HEAD_READ(0)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int64_t e = e0 + wc * 64 + ni * 32 + li;
-        const float bias = (a.bias && e < a.E) ? a.bias[e] : 0.f;
+        for (int kk = 0; kk < HK2; kk += 4) {
+            float a4[4], b4[4];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int i = 0; i < 4; ++i) { a4[i] = na[i]; b4[i] = nb[i]; }
+            if (kk + 4 < HK2) KGE_HEAD_READ(kk + 4)
+            KGE_KEEP_READS_AHEAD();
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int64_t b = b0 + wr * 64 + mi * 32 + head_row(reg, lk);
-                if (b < a.B && e < a.E) {
-                    const float p = sigmoidf_(acc[mi][ni][reg] + bias);
-                    if constexpr (MODE == 0) {
-                        a.preds[b * a.E + e] = p;
-                    } else {
-                        lsum += softplusf_(p) - p * a.y0;
-                        a.dz[b * a.E + e] = (sigmoidf_(p) - a.y0) * p * (1.f - p) * a.inv_count;
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi], b4[ni], acc[mi][ni], 0, 0, 0);
+            if (kk == 0) {
+                // behind the first quarter of this slab's MFMAs (so that the matrix pipe has work queued while this wave stores):
+                // slab sl + 1 goes from the registers into the OTHER buffer -- free since the barrier that ended slab sl - 1 -- and
+                // slab sl + 2 is requested.  Workgroups of one CU run in step; a store phase in front of the barrier (the round-4
+                // form of this loop) left the matrix pipe idle in all of them at once.
+                KGE_KEEP_READS_AHEAD();
+                if (sl + 1 < nslab) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { stage_store<A_KM>(sA[buf ^ 1], j, fa(sl + 1, j, ra[j])); stage_store<B_KM>(sB[buf ^ 1], j, fb(sl + 1, j, rb[j])); }
+                    if (sl + 2 < nslab) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) { ra[j] = la(sl + 2, j); rb[j] = lb(sl + 2, j); }
                     }
                 }
+                KGE_KEEP_READS_AHEAD();
             }
+        }
+#undef KGE_HEAD_READ
+        __syncthreads();   // slab sl + 1 is in LDS; everybody finished reading slab sl
+        buf ^= 1;
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, HEAD_OCC) void k_head_gemm128x(HeadArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[2][HK2][HLD3], sB[2][HK2][HLD3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lcol = lane & 15, lk4 = lane >> 4;
+    int64_t e0, b0;
+    head_tile(a, HT2, e0, b0);
+    const int wr = wave >> 1, wc = wave & 1;   // wave's 64 x 64 sub-tile: batch rows wr, entity columns wc
+    const int srow = threadIdx.x >> 2, sk4 = (threadIdx.x & 3) * 4;
+    // (d % 4 == 0: a float4 is inside the row or past its end)
+    auto oka = [&](int sl, int j) { return sl * HK2 + sk4 < a.d && b0 + srow + 64 * j < a.B; };
+    auto okb = [&](int sl, int j) { return sl * HK2 + sk4 < a.d && e0 + srow + 64 * j < a.E; };
+    auto la = [&](int sl, int j) { return load4_clamped(a.x, (b0 + srow + 64 * j) * a.d + sl * HK2 + sk4, oka(sl, j)); };
+    auto lb = [&](int sl, int j) { return load4_clamped(a.ent, (e0 + srow + 64 * j) * a.d + sl * HK2 + sk4, okb(sl, j)); };
+    auto fa = [&](int sl, int j, const float4& v) { return keep_if(v, oka(sl, j)); };
+    auto fb = [&](int sl, int j, const float4& v) { return keep_if(v, okb(sl, j)); };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm128x_core<false, false>((a.d + HK2 - 1) / HK2, la, fa, lb, fb, sA, sB, wr, wc, lcol, lk4, acc);
+    // the lane owns entity columns e .. e + 3 (column blocks ni = 0 .. 3) of batch rows 4 (4 lk4 + reg) + mi
+    const int64_t e = e0 + wc * 64 + 4 * lcol;
+    float bias[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bias[ni] = (a.bias && e + ni < a.E) ? a.bias[e + ni] : 0.f;
+    const bool whole = e + 3 < a.E;
+    float lsum = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t b = b0 + wr * 64 + 4 * (4 * lk4 + reg) + mi;
+            if (b >= a.B || e >= a.E) continue;
+            float o[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const float p = sigmoidf_(acc[mi][ni][reg] + bias[ni]);
+                if constexpr (MODE == 0) {
+                    o[ni] = p;
+                } else {
+                    float lt;
+                    o[ni] = bce_neg_terms(p, a.y0, lt) * a.inv_count;
+                    if (e + ni < a.E) lsum += lt;
+                }
+            }
+            float* const dst = MODE == 0 ? a.preds + b * a.E + e : a.dz + b * a.ldz + e;
+            if (whole) {
+                *reinterpret_cast<float4u*>(dst) = float4u{o[0], o[1], o[2], o[3]};
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    if (e + ni < a.E) dst[ni] = o[ni];
+            }
+        }
     if constexpr (MODE == 1) block_accumulate_loss<1>(lsum * a.inv_count, 0, a.loss);
 }
 
@@ -223,7 +342,8 @@ __global__ __launch_bounds__(256) void k_head_gemm_bf16(HeadArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sA[HT * HSB], sB[HT * HSB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lk = lane >> 5;
-    const int64_t e0 = (int64_t)blockIdx.x * HT, b0 = (int64_t)blockIdx.y * HT;
+    int64_t e0, b0;
+    head_tile(a, HT, e0, b0);
     const int wr = wave >> 1, wc = wave & 1;
     f32x16 acc = {0};
     const int nslabs = (a.d + HK - 1) / HK;
@@ -274,7 +394,8 @@ __global__ __launch_bounds__(256, 2) void k_head_gemm128_bf16(HeadArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][HT2][HSB], sB[2][HT2][HSB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lk = lane >> 5;
-    const int64_t e0 = (int64_t)blockIdx.x * HT2, b0 = (int64_t)blockIdx.y * HT2;
+    int64_t e0, b0;
+    head_tile(a, HT2, e0, b0);
     const int wr = wave >> 1, wc = wave & 1;
     const int srow = threadIdx.x >> 3, sk4 = (threadIdx.x & 7) * 4;   // float4 number t + 256 j of a slab: row srow + 32 j, k = sk4 .. + 3
     const int nslab = (a.d + HKB - 1) / HKB;
@@ -333,20 +454,24 @@ __global__ __launch_bounds__(256, 2) void k_head_gemm128_bf16(HeadArgs a) {
     }
 }
 
-// the large tile pays once the grid fills the chip with it and the rows can be fetched 16 bytes at a time
+static dim3 head_grid(const HeadArgs& a, int tile) { return dim3((unsigned)(((a.E + tile - 1) / tile) * ((a.B + tile - 1) / tile))); }
+
+// the large tile pays once its grid covers most of the chip (measured from B = 256 at E = 14 951: 234 tiles) and the rows can be
+// fetched 16 bytes at a time
 static bool head_use_128(const HeadArgs& a) {
     const int force = switch_value("HEAD_TILE");
     if (force >= 0) return force == 1 && a.d % 4 == 0;
     const int64_t tiles = ((a.E + HT2 - 1) / HT2) * ((a.B + HT2 - 1) / HT2);
-    return a.d % 4 == 0 && (((uintptr_t)a.x | (uintptr_t)a.ent) & 15) == 0 && tiles >= 512;
+    return a.d % 4 == 0 && (((uintptr_t)a.x | (uintptr_t)a.ent) & 15) == 0 && tiles >= 200;
 }
 
 template <int MODE>
 static void launch_head_gemm(const HeadArgs& a, hipStream_t s) {
-    if (head_use_128(a))
-        hipLaunchKernelGGL(k_head_gemm128<MODE>, dim3((unsigned)((a.E + HT2 - 1) / HT2), (unsigned)((a.B + HT2 - 1) / HT2)), dim3(256), 0, s, a);
+    if (head_use_128(a)) {
+        hipLaunchKernelGGL(k_head_gemm128x<MODE>, head_grid(a, HT2), dim3(256), 0, s, a);
+    }
     else
-        hipLaunchKernelGGL(k_head_gemm<MODE>, dim3((unsigned)((a.E + HT - 1) / HT), (unsigned)((a.B + HT - 1) / HT)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_head_gemm<MODE>, head_grid(a, HT), dim3(256), 0, s, a);
 }
 
 // positives: group of 32 lanes per (b, e) entry of the CSR label lists
@@ -360,7 +485,7 @@ __global__ __launch_bounds__(256) void k_head_bce_pos(HeadArgs a, const int64_t*
         for (int k = gl; k < a.d; k += 32) z = fmaf(a.x[b * a.d + k], a.ent[e * a.d + k], z);
         z = gsum<32>(z) + (a.bias ? a.bias[e] : 0.f);
         const float p = sigmoidf_(z);
-        if (gl == 0) a.dz[b * a.E + e] -= dy * p * (1.f - p) * a.inv_count;  // label y1 instead of y0: d(-p*y)/dp
+        if (gl == 0) a.dz[b * a.ldz + e] -= dy * p * (1.f - p) * a.inv_count;  // label y1 instead of y0: d(-p*y)/dp
         acc -= p * dy * a.inv_count;
     }
     (void)lab_off;
@@ -370,12 +495,57 @@ __global__ __launch_bounds__(256) void k_head_bce_pos(HeadArgs a, const int64_t*
 // per-element gradient wrt the logits: dz[b,e] (fused form) or dpreds[b,e] * p (1 - p) (autograd form)
 struct DzSrc {
     const float* dz; const float* dpreds; const float* preds;
+    int64_t ld;   // row stride of whichever source is set (dz: padded workspace rows; preds / dpreds: E)
     __device__ __forceinline__ float at(int64_t i) const {
         if (dz) return dz[i];
         const float p = preds[i];
         return dpreds[i] * p * (1.f - p);
     }
 };
+
+// four consecutive elements of a gradient row for the 128-wide products.  FUSED (the workspace of kge_head_1n_bce): rows are padded
+// to a multiple of four floats and i is a multiple of four, so this is ONE aligned 16-byte load with no control flow around it (the
+// load stays in flight across the slab it is issued in); elements past the operand -- pad columns are never written -- are masked.
+// four consecutive elements of a gradient row, the first nv of them inside the operand, in two steps: the raw fetch (dz_fetch4)
+// and, at the LDS store, the value (dz_value4).  FUSED (the workspace of kge_head_1n_bce): rows are padded to a multiple of four
+// floats and i is a multiple of four -- one aligned 16-byte load; pad columns are never written, hence the mask.  Otherwise
+// (autograd form) dpreds * p (1 - p) from two 4-byte aligned loads.
+struct DzRaw { float4 a, b; };
+template <bool FUSED>
+__device__ __forceinline__ DzRaw dz_fetch4(const DzSrc& g, int64_t i, int nv, int64_t total) {
+    DzRaw r;
+    const int64_t ii = nv > 0 ? i : 0;
+    if constexpr (FUSED) {
+        r.a = *reinterpret_cast<const float4*>(g.dz + ii);
+        r.b = r.a;
+    } else {
+        const int64_t ic = ii < total - 4 ? ii : total - 4;   // (the tail of the last row: fetched from the last in-bounds position)
+        const float4u p = *reinterpret_cast<const float4u*>(g.preds + ic), q = *reinterpret_cast<const float4u*>(g.dpreds + ic);
+        r.a = make_float4(p.x, p.y, p.z, p.w); r.b = make_float4(q.x, q.y, q.z, q.w);
+    }
+    return r;
+}
+__device__ __forceinline__ float4 shift4(float4 v, int sh) {
+    float4 r;
+    r.x = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : v.w));
+    r.y = sh == 0 ? v.y : (sh == 1 ? v.z : v.w);
+    r.z = sh == 0 ? v.z : v.w;
+    r.w = v.w;
+    return r;
+}
+template <bool FUSED>
+__device__ __forceinline__ float4 dz_value4(const DzRaw& w, int64_t i, int nv, int64_t total) {
+    if constexpr (FUSED) {
+        return first_n(w.a, nv);
+    } else {
+        const int64_t ii = nv > 0 ? i : 0;
+        const int sh = ii < total - 4 ? 0 : (int)(ii - (total - 4));
+        const float4 p = shift4(w.a, sh), q = shift4(w.b, sh);
+        float4 r;
+        r.x = q.x * p.x * (1.f - p.x); r.y = q.y * p.y * (1.f - p.y); r.z = q.z * p.z * (1.f - p.z); r.w = q.w * p.w * (1.f - p.w);
+        return first_n(r, nv);
+    }
+}
 
 // dX[b, k] += sum_{e in this split} dz[b, e] ent[e, k]     grid: (d tiles, B tiles, E splits)
 __global__ __launch_bounds__(256) void k_head_dx(DzSrc g, const float* __restrict__ ent, int64_t B, int64_t E, int d,
@@ -391,7 +561,7 @@ __global__ __launch_bounds__(256) void k_head_dx(DzSrc g, const float* __restric
         const int idx = threadIdx.x + 256 * j, r = idx / HK, c = idx - r * HK;
         const int64_t e = es + (int64_t)sl * HK + c;
         pos = r * HS + c;
-        return (e < ee && b0 + r < B) ? g.at((b0 + r) * E + e) : 0.f;
+        return (e < ee && b0 + r < B) ? g.at((b0 + r) * g.ld + e) : 0.f;
     };
     auto fb = [&](int sl, int j, int& pos) -> float {  // entity tile stored [k][e-slab], read coalesced along k
         const int idx = threadIdx.x + 256 * j, c = idx / HT, r = idx - c * HT;
@@ -424,7 +594,7 @@ __global__ __launch_bounds__(256) void k_head_dent(DzSrc g, const float* __restr
         const int idx = threadIdx.x + 256 * j, c = idx / HT, r = idx - c * HT;
         const int64_t b = bs + (int64_t)sl * HK + c;
         pos = r * HS + c;
-        return (b < be && e0 + r < E) ? g.at(b * E + e0 + r) : 0.f;
+        return (b < be && e0 + r < E) ? g.at(b * g.ld + e0 + r) : 0.f;
     };
     auto fb = [&](int sl, int j, int& pos) -> float {  // x tile stored [k][b-slab], read coalesced along k
         const int idx = threadIdx.x + 256 * j, c = idx / HT, r = idx - c * HT;
@@ -448,6 +618,170 @@ __global__ __launch_bounds__(256) void k_head_dent(DzSrc g, const float* __restr
     if (do_bias && e0 + threadIdx.x < E && colsum != 0.f) unsafeAtomicAdd(g_bias + e0 + threadIdx.x, colsum);
 }
 
+// What a split-K workgroup of the backward products does with its 128 x 128 tile:
+//   kOutDirect  the product is not split: the tile IS the result -- plain 16-byte stores (dX) or read-modify-writes (g_ent +=);
+//   kOutParts   the tile goes to its slot of the partials buffer (workgroup number x 64 KB) and k_head_sum_parts adds the splits in
+//               split order: no atomics, bit-reproducible gradients (the fused entry point, which owns a workspace);
+//   kOutAtomic  float atomics into the result (kge_head_1n_backward, the autograd form: no workspace in its signature).
+constexpr int kOutDirect = 0, kOutParts = 1, kOutAtomic = 2;
+constexpr int64_t kHeadPartSlots = 768;   // split-K workgroups per product (three per CU)
+
+__device__ __forceinline__ void tile_out(const f32x4 (&acc)[4][4], int emode, float* __restrict__ part, float* __restrict__ out,
+                                         int64_t m0, int64_t M, int64_t n0, int N, int wr, int wc, int lcol, int lk4, bool accumulate) {
+    const int col = wc * 64 + 4 * lcol;
+    const int64_t n = n0 + col;
+    if (emode == kOutParts) {
+        float* const pt = part + ((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) << 14);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = wr * 64 + 4 * (4 * lk4 + reg) + mi;
+                *reinterpret_cast<float4*>(pt + row * HT2 + col) = make_float4(acc[mi][0][reg], acc[mi][1][reg], acc[mi][2][reg], acc[mi][3][reg]);
+            }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t m = m0 + wr * 64 + 4 * (4 * lk4 + reg) + mi;
+            if (m >= M || n >= N) continue;   // (N % 4 == 0: the lane's four columns are inside the row or past its end)
+            float* const o = out + m * N + n;
+            if (emode == kOutDirect) {
+                float4 v = make_float4(acc[mi][0][reg], acc[mi][1][reg], acc[mi][2][reg], acc[mi][3][reg]);
+                if (accumulate) { const float4 w = *reinterpret_cast<const float4*>(o); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+                *reinterpret_cast<float4*>(o) = v;
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    if (acc[mi][ni][reg] != 0.f) unsafeAtomicAdd(o + ni, acc[mi][ni][reg]);
+            }
+        }
+}
+
+// ---- the two backward products at the 128 x 128 tile of k_head_gemm128x (large batches; d % 4 == 0)
+// dX[b, k] += sum_{e in this split} dz[b, e] ent[e, k]     grid: (d tiles, B tiles, E splits); A = dz rows (RK), B = ent (KM)
+template <bool FUSED>
+__global__ __launch_bounds__(256, HEAD_BWD_OCC) void k_head_dx128(DzSrc g, const float* __restrict__ ent, int64_t B, int64_t E, int d,
+                                                       int64_t e_per_split, float* __restrict__ dx, int emode, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float sA[2][HK2][HLD3], sB[2][HK2][HLD3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lcol = lane & 15, lk4 = lane >> 4;
+    const int64_t k0 = (int64_t)blockIdx.x * HT2, b0 = (int64_t)blockIdx.y * HT2;
+    const int64_t es = (int64_t)blockIdx.z * e_per_split, ee = min(E, es + e_per_split);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int srow = threadIdx.x >> 2, sk4 = (threadIdx.x & 3) * 4;
+    const int64_t total = B * E;
+    auto ia = [&](int sl, int j, int& nv) {   // element index of this thread's dz float4 and how many of its elements count
+        const int64_t b = b0 + srow + 64 * j, e = es + (int64_t)sl * HK2 + sk4;
+        const int64_t n = b < B ? ee - e : 0;
+        nv = n > 4 ? 4 : (int)n;
+        return b * g.ld + e;
+    };
+    auto ib = [&](int sl, int j, bool& ok) {
+        const int idx = threadIdx.x + 256 * j;
+        const int64_t e = es + (int64_t)sl * HK2 + (idx >> 5), k = k0 + (idx & 31) * 4;
+        ok = e < ee && k < d;
+        return e * d + k;
+    };
+    auto la = [&](int sl, int j) { int nv; const int64_t i = ia(sl, j, nv); return dz_fetch4<FUSED>(g, i, nv, total); };
+    auto fa = [&](int sl, int j, const DzRaw& w) { int nv; const int64_t i = ia(sl, j, nv); return dz_value4<FUSED>(w, i, nv, total); };
+    auto lb = [&](int sl, int j) { bool ok; const int64_t i = ib(sl, j, ok); return load4_clamped(ent, i, ok); };
+    auto fb = [&](int sl, int j, const float4& v) { bool ok; ib(sl, j, ok); return keep_if(v, ok); };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm128x_core<false, true>((int)((ee - es + HK2 - 1) / HK2), la, fa, lb, fb, sA, sB, wr, wc, lcol, lk4, acc);
+    tile_out(acc, emode, part, dx, b0, B, k0, d, wr, wc, lcol, lk4, /* accumulate = */ false);
+}
+
+// g_ent[e, k] += sum_{b in this split} dz[b, e] x[b, k] ;  g_bias[e] += sum_b dz[b, e]    grid: (d tiles, E tiles, B splits);
+// both operands are k-major in memory (k = the batch row): no transposition on the way into LDS
+template <bool FUSED>
+__global__ __launch_bounds__(256, HEAD_BWD_OCC) void k_head_dent128(DzSrc g, const float* __restrict__ x, int64_t B, int64_t E, int d,
+                                                         int64_t b_per_split, float* __restrict__ g_ent, float* __restrict__ g_bias,
+                                                         int emode, float* __restrict__ part, float* __restrict__ bpart) {
+    __shared__ __attribute__((aligned(16))) float sA[2][HK2][HLD3], sB[2][HK2][HLD3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lcol = lane & 15, lk4 = lane >> 4;
+    const int64_t k0 = (int64_t)blockIdx.x * HT2, e0 = (int64_t)blockIdx.y * HT2;
+    const int64_t bs = (int64_t)blockIdx.z * b_per_split, be = min(B, bs + b_per_split);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t total = B * E;
+    auto ia = [&](int sl, int j, int& nv) {
+        const int idx = threadIdx.x + 256 * j;
+        const int64_t b = bs + (int64_t)sl * HK2 + (idx >> 5), e = e0 + (idx & 31) * 4;
+        const int64_t n = b < be ? E - e : 0;
+        nv = n > 4 ? 4 : (int)n;
+        return b * g.ld + e;
+    };
+    auto ib = [&](int sl, int j, bool& ok) {
+        const int idx = threadIdx.x + 256 * j;
+        const int64_t b = bs + (int64_t)sl * HK2 + (idx >> 5), k = k0 + (idx & 31) * 4;
+        ok = b < be && k < d;
+        return b * d + k;
+    };
+    auto la = [&](int sl, int j) { int nv; const int64_t i = ia(sl, j, nv); return dz_fetch4<FUSED>(g, i, nv, total); };
+    auto fa = [&](int sl, int j, const DzRaw& w) { int nv; const int64_t i = ia(sl, j, nv); return dz_value4<FUSED>(w, i, nv, total); };
+    auto lb = [&](int sl, int j) { bool ok; const int64_t i = ib(sl, j, ok); return load4_clamped(x, i, ok); };
+    auto fb = [&](int sl, int j, const float4& v) { bool ok; ib(sl, j, ok); return keep_if(v, ok); };
+    float colsum = 0.f;   // threads 0 .. 127 of the k-tile-0 workgroups: bias gradient of entity e0 + threadIdx.x
+    const bool do_bias = g_bias != nullptr && blockIdx.x == 0 && threadIdx.x < HT2;
+    auto hook = [&](float (*sa)[HLD3]) {
+        if (do_bias) {
+#pragma unroll
+            for (int c = 0; c < HK2; ++c) colsum += sa[c][threadIdx.x];
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm128x_core<true, true>((int)((be - bs + HK2 - 1) / HK2), la, fa, lb, fb, sA, sB, wr, wc, lcol, lk4, acc, hook);
+    tile_out(acc, emode, part, g_ent, e0, E, k0, d, wr, wc, lcol, lk4, /* accumulate = */ true);
+    if (do_bias) {
+        if (emode == kOutParts) bpart[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * HT2 + threadIdx.x] = colsum;
+        else if (e0 + threadIdx.x < E && colsum != 0.f) {
+            if (emode == kOutDirect) g_bias[e0 + threadIdx.x] += colsum;
+            else unsafeAtomicAdd(g_bias + e0 + threadIdx.x, colsum);
+        }
+    }
+}
+
+// out[m, n] (+)= sum over the splits, in split order, of the partial tiles the workgroups of a split-K product left (kOutParts);
+// one thread per float4 of the tile space.  bpart: the bias-gradient partials of the entity-gradient product (column tile 0).
+__global__ __launch_bounds__(256) void k_head_sum_parts(const float* __restrict__ part, int splits, int MT, int NT, int64_t M, int N,
+                                                        float* __restrict__ out, int accumulate, const float* __restrict__ bpart,
+                                                        float* __restrict__ g_bias) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = (int)(i & 31), r = (int)((i >> 5) & 127);
+    const int64_t t = i >> 12;
+    if (t >= (int64_t)MT * NT) return;
+    const int nt = (int)(t % NT), mt = (int)(t / NT);
+    const int64_t m = (int64_t)mt * HT2 + r;
+    const int n = nt * HT2 + 4 * c4;
+    if (m >= M) return;
+    if (n < N) {
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < splits; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(part + ((((int64_t)z * MT + mt) * NT + nt) << 14) + r * HT2 + 4 * c4);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        float4* const o = reinterpret_cast<float4*>(out + m * N + n);
+        if (accumulate) { const float4 w = *o; sum.x += w.x; sum.y += w.y; sum.z += w.z; sum.w += w.w; }
+        *o = sum;
+    }
+    if (bpart != nullptr && nt == 0 && c4 == 0) {
+        float bs = 0.f;
+        for (int z = 0; z < splits; ++z) bs += bpart[((int64_t)z * MT + mt) * HT2 + r];
+        g_bias[m] += bs;
+    }
+}
+
 __global__ void k_head_rows_of(const int64_t* __restrict__ lab_off, int64_t B, int32_t* __restrict__ row_of) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -465,59 +799,93 @@ int launch_head_forward(const float* x, int64_t B, int d, const float* ent, int6
                         int bf16, hipStream_t s) {
     if (head_check("kge_head_1n_forward", x, ent, B, E, d) || !preds) { if (!preds) set_error("kge_head_1n_forward: null output"); return -1; }
     HeadArgs a{};
+    a.xcd_runs = switch_value("HEAD_XCD") != 0;   // KGE_HEAD_XCD=0: plain tile numbering (A/B)
     a.x = x; a.ent = ent; a.bias = bias; a.B = B; a.E = E; a.d = d; a.preds = preds;
     if (bf16) {
         // (the same accumulation order over k in both tile shapes: 16 k per MFMA, slabs in order -- identical logits)
         if (head_use_128(a))
-            hipLaunchKernelGGL(k_head_gemm128_bf16, dim3((unsigned)((E + HT2 - 1) / HT2), (unsigned)((B + HT2 - 1) / HT2)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_head_gemm128_bf16, head_grid(a, HT2), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL(k_head_gemm_bf16, dim3((unsigned)((E + HT - 1) / HT), (unsigned)((B + HT - 1) / HT)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_head_gemm_bf16, head_grid(a, HT), dim3(256), 0, s, a);
         return check_launch("k_head_gemm_bf16");
     }
     launch_head_gemm<0>(a, s);
     return check_launch("k_head_gemm<0>");
 }
 
+// parts (may be NULL): head_parts_bytes() of workspace for the split-K partial tiles of the wide products
+static size_t head_parts_bytes() { return (size_t)kHeadPartSlots * HT2 * HT2 * sizeof(float) + (size_t)kHeadPartSlots * HT2 * sizeof(float); }
+
 static int head_backward_gemms(const DzSrc& g, const float* x, int64_t B, int d, const float* ent, int64_t E, float* dx,
-                               float* g_ent, float* g_bias, hipStream_t s) {
-    if (dx) {
-        hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * d * sizeof(float), s);
-        if (e != hipSuccess) { set_error("kge_head: memset: %s", hipGetErrorString(e)); return -2; }
-        // split the long E reduction so that ~8 workgroups per CU exist; every split a multiple of the slab
-        const int64_t tiles = ((B + HT - 1) / HT) * ((d + HT - 1) / HT);
-        int64_t splits = (2048 + tiles - 1) / tiles;
-        const int64_t max_splits = (E + HK - 1) / HK;
+                               float* g_ent, float* g_bias, float* parts, hipStream_t s) {
+    // the 128-wide forms pay once the batch fills their tiles (the same switch as the forward: KGE_HEAD_TILE = 0 / 1 forces)
+    const int force = switch_value("HEAD_TILE");
+    const bool aligned = d % 4 == 0 && (((uintptr_t)x | (uintptr_t)ent | (uintptr_t)dx | (uintptr_t)g_ent) & 15) == 0;
+    const int min_b = switch_value("HEAD_WIDE_B") > 0 ? switch_value("HEAD_WIDE_B") : (parts ? 512 : 2560);
+    const bool wide = aligned && (force >= 0 ? force == 1 : B >= min_b);
+    const int T = wide ? HT2 : HT, SK = wide ? HK2 : HK;
+    // split-K: ~8 small-tile workgroups per CU; wide: three per CU, all resident in ONE round (rounding the split count up left a
+    // second, mostly empty round) and never more than the partials buffer has slots.  Every split a multiple of the slab.
+    auto split = [&](int64_t tiles, int64_t K, int64_t* per) {
+        int64_t splits = wide ? kHeadPartSlots / tiles : (2048 + tiles - 1) / tiles;
+        const int64_t max_splits = wide ? (K + 127) / 128 : (K + SK - 1) / SK;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
-        int64_t per = ((E + splits - 1) / splits + HK - 1) / HK * HK;
-        splits = (E + per - 1) / per;
-        hipLaunchKernelGGL(k_head_dx, dim3((unsigned)((d + HT - 1) / HT), (unsigned)((B + HT - 1) / HT), (unsigned)splits),
-                           dim3(256), 0, s, g, ent, B, E, d, per, dx);
+        *per = ((K + splits - 1) / splits + SK - 1) / SK * SK;
+        return (K + *per - 1) / *per;
+    };
+    float* const bparts = parts ? parts + kHeadPartSlots * HT2 * HT2 : nullptr;
+    if (dx) {
+        int64_t per;
+        const int64_t MT = (B + T - 1) / T, NT = (d + T - 1) / T;
+        const int64_t splits = split(MT * NT, E, &per);
+        const int emode = !wide ? kOutAtomic : (splits == 1 ? kOutDirect : (parts ? kOutParts : kOutAtomic));
+        if (emode == kOutAtomic) {
+            hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * d * sizeof(float), s);
+            if (e != hipSuccess) { set_error("kge_head: memset: %s", hipGetErrorString(e)); return -2; }
+        }
+        const dim3 grid((unsigned)NT, (unsigned)MT, (unsigned)splits);
+        if (wide && g.dz) hipLaunchKernelGGL(k_head_dx128<true>, grid, dim3(256), 0, s, g, ent, B, E, d, per, dx, emode, parts);
+        else if (wide) hipLaunchKernelGGL(k_head_dx128<false>, grid, dim3(256), 0, s, g, ent, B, E, d, per, dx, emode, parts);
+        else hipLaunchKernelGGL(k_head_dx, grid, dim3(256), 0, s, g, ent, B, E, d, per, dx);
+        if (emode == kOutParts)
+            hipLaunchKernelGGL(k_head_sum_parts, dim3((unsigned)(MT * NT * 16)), dim3(256), 0, s, parts, (int)splits, (int)MT, (int)NT, B, d,
+                               dx, 0, (const float*)nullptr, (float*)nullptr);
     }
     if (g_ent) {
-        const int64_t tiles = ((E + HT - 1) / HT) * ((d + HT - 1) / HT);
-        int64_t splits = (2048 + tiles - 1) / tiles;
-        const int64_t max_splits = (B + HK - 1) / HK;
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
-        int64_t per = ((B + splits - 1) / splits + HK - 1) / HK * HK;
-        splits = (B + per - 1) / per;
-        hipLaunchKernelGGL(k_head_dent, dim3((unsigned)((d + HT - 1) / HT), (unsigned)((E + HT - 1) / HT), (unsigned)splits),
-                           dim3(256), 0, s, g, x, B, E, d, per, g_ent, g_bias);
+        int64_t per;
+        const int64_t MT = (E + T - 1) / T, NT = (d + T - 1) / T;
+        const int64_t splits = split(MT * NT, B, &per);
+        const int emode = !wide ? kOutAtomic : (splits == 1 ? kOutDirect : (parts ? kOutParts : kOutAtomic));
+        const dim3 grid((unsigned)NT, (unsigned)MT, (unsigned)splits);
+        if (wide && g.dz) hipLaunchKernelGGL(k_head_dent128<true>, grid, dim3(256), 0, s, g, x, B, E, d, per, g_ent, g_bias, emode, parts, bparts);
+        else if (wide) hipLaunchKernelGGL(k_head_dent128<false>, grid, dim3(256), 0, s, g, x, B, E, d, per, g_ent, g_bias, emode, parts, bparts);
+        else hipLaunchKernelGGL(k_head_dent, grid, dim3(256), 0, s, g, x, B, E, d, per, g_ent, g_bias);
+        if (emode == kOutParts)
+            hipLaunchKernelGGL(k_head_sum_parts, dim3((unsigned)(MT * NT * 16)), dim3(256), 0, s, parts, (int)splits, (int)MT, (int)NT, E, d,
+                               g_ent, 1, g_bias ? (const float*)bparts : (const float*)nullptr, g_bias);
     }
     return check_launch("k_head_dx / k_head_dent");
 }
 
+size_t head_backward_workspace_bytes() { return head_parts_bytes(); }
+
 int launch_head_backward(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* preds,
-                         const float* dpreds, float* dx, float* g_ent, float* g_bias, hipStream_t s) {
+                         const float* dpreds, float* dx, float* g_ent, float* g_bias, void* ws, size_t ws_bytes, hipStream_t s) {
     if (head_check("kge_head_1n_backward", x, ent, B, E, d)) return -1;
     if (!preds || !dpreds) { set_error("kge_head_1n_backward: preds / dpreds are null"); return -1; }
-    DzSrc g{nullptr, dpreds, preds};
-    return head_backward_gemms(g, x, B, d, ent, E, dx, g_ent, g_bias, s);
+    if (ws && (ws_bytes < head_parts_bytes() || ((uintptr_t)ws & 15))) {
+        set_error("kge_head_1n_backward: workspace too small or misaligned (need kge_head_1n_backward_workspace_bytes, 16-byte aligned)");
+        return -1;
+    }
+    DzSrc g{nullptr, dpreds, preds, E};
+    return head_backward_gemms(g, x, B, d, ent, E, dx, g_ent, g_bias, (float*)ws, s);
 }
 
+static int64_t head_ldz(int64_t E) { return (E + 3) / 4 * 4; }
+
 size_t head_bce_workspace_bytes(int64_t B, int64_t E, int64_t n_pos) {
-    return ((size_t)B * E * sizeof(float) + 255) / 256 * 256 + ((size_t)n_pos * sizeof(int32_t) + 255) / 256 * 256;
+    return ((size_t)B * head_ldz(E) * sizeof(float) + 255) / 256 * 256 + ((size_t)n_pos * sizeof(int32_t) + 255) / 256 * 256 + head_parts_bytes();
 }
 
 int launch_head_bce(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* bias,
@@ -530,13 +898,14 @@ int launch_head_bce(const float* x, int64_t B, int d, const float* ent, int64_t 
         return -1;
     }
     float* dz = (float*)ws;
-    int32_t* row_of = (int32_t*)((char*)ws + ((size_t)B * E * sizeof(float) + 255) / 256 * 256);
+    int32_t* row_of = (int32_t*)((char*)ws + ((size_t)B * head_ldz(E) * sizeof(float) + 255) / 256 * 256);
     // Criterion.multi_class_bce (utils/criterion.py:42-45): y <- y (1 - ls) + 1/E when label smoothing is given
     const bool smooth = label_smoothing >= 0.f;
     const float y0 = smooth ? 1.0f / (float)E : 0.f;
     const float y1 = smooth ? (1.0f - label_smoothing) + 1.0f / (float)E : 1.f;
     HeadArgs a{};
-    a.x = x; a.ent = ent; a.bias = bias; a.B = B; a.E = E; a.d = d; a.dz = dz; a.loss = loss;
+    a.xcd_runs = switch_value("HEAD_XCD") != 0;   // KGE_HEAD_XCD=0: plain tile numbering (A/B)
+    a.x = x; a.ent = ent; a.bias = bias; a.B = B; a.E = E; a.d = d; a.dz = dz; a.ldz = head_ldz(E); a.loss = loss;
     a.y0 = y0; a.inv_count = 1.0f / ((float)B * (float)E);
     launch_head_gemm<1>(a, s);
     if (n_pos > 0) {
@@ -545,8 +914,9 @@ int launch_head_bce(const float* x, int64_t B, int d, const float* ent, int64_t 
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(k_head_bce_pos, dim3((unsigned)blocks), dim3(256), 0, s, a, lab_off, lab_ids, row_of, n_pos, y1 - y0);
     }
-    DzSrc g{dz, nullptr, nullptr};
-    return head_backward_gemms(g, x, B, d, ent, E, dx, g_ent, g_bias, s);
+    DzSrc g{dz, nullptr, nullptr, a.ldz};
+    float* const parts = (float*)((char*)row_of + ((size_t)n_pos * sizeof(int32_t) + 255) / 256 * 256);
+    return head_backward_gemms(g, x, B, d, ent, E, dx, g_ent, g_bias, parts, s);
 }
 
 }  // namespace kge

@@ -268,8 +268,9 @@ int launch_ntn_eval_scores(const kge_model_desc* m, const int64_t* triples, int6
 // kge_head.hip (1-N scoring head of the projection models)
 int launch_head_forward(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* bias, float* preds,
                         int bf16, hipStream_t s);
+size_t head_backward_workspace_bytes();
 int launch_head_backward(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* preds,
-                         const float* dpreds, float* dx, float* g_ent, float* g_bias, hipStream_t s);
+                         const float* dpreds, float* dx, float* g_ent, float* g_bias, void* ws, size_t ws_bytes, hipStream_t s);
 size_t head_bce_workspace_bytes(int64_t B, int64_t E, int64_t n_pos);
 int launch_head_bce(const float* x, int64_t B, int d, const float* ent, int64_t E, const float* bias,
                     const int64_t* lab_off, const int32_t* lab_ids, int64_t n_pos, float label_smoothing, void* ws,

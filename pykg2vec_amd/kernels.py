@@ -1199,9 +1199,13 @@ def head_1n_backward(x, ent, preds, dpreds, need_bias=True):
     dx = torch.empty_like(x)
     g_ent = torch.zeros_like(ent)
     g_bias = torch.zeros(E, dtype=torch.float32, device=x.device) if need_bias else None
-    L.check(L.load().kge_head_1n_backward(_f32(x, "x"), B, d, _f32(ent, "ent"), E, _f32(preds, "preds"),
-                                          _f32(dpreds, "dpreds"), _f32(dx, "dx"), _f32(g_ent, "g_ent"),
-                                          _f32(g_bias, "g_bias") if need_bias else None, _stream()), "kge_head_1n_backward")
+    lib = L.load()
+    # (room for the split-K partial tiles: summed in split order instead of with float atomics -- reproducible gradients)
+    ws = torch.empty(lib.kge_head_1n_backward_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    L.check(lib.kge_head_1n_backward(_f32(x, "x"), B, d, _f32(ent, "ent"), E, _f32(preds, "preds"),
+                                     _f32(dpreds, "dpreds"), _f32(dx, "dx"), _f32(g_ent, "g_ent"),
+                                     _f32(g_bias, "g_bias") if need_bias else None, _dev(ws, torch.uint8, "workspace"), ws.numel(),
+                                     _stream()), "kge_head_1n_backward")
     return dx, g_ent, g_bias
 
 

@@ -858,6 +858,43 @@ def test_head_1n_large_tile_equals_small_tile(hip, monkeypatch, B, E, d):
     assert np.allclose(g_ent.cpu().numpy(), ge_ref, atol=1e-3 * scale, rtol=1e-3)
 
 
+@pytest.mark.parametrize("B,E,d", [(130, 259, 8), (257, 129, 12), (64, 1001, 200), (700, 14951, 200)])
+def test_head_1n_wide_backward_products(hip, B, E, d):
+    """The 128 x 128 forms of the two backward products (dX = dZ Ent, g_ent += dZ^T X, g_bias += column sums), forced on at ragged
+    shapes: the autograd form reads dpreds * p (1 - p) through 4-byte aligned 16-byte loads (E odd: rows are not 16-byte aligned, the
+    tail of the last row is fetched from the last in-bounds position), the fused form reads the padded workspace rows.  Both against
+    the oracle, and both bit-reproducible run to run (split-K partial tiles are summed in split order, no float atomics)."""
+    from pykg2vec_amd import kernels as K
+    rng = np.random.default_rng(B * 3 + E + d)
+    x = rng.normal(size=(B, d)).astype(np.float32)
+    ent = (rng.normal(size=(E, d)) * 0.2).astype(np.float32)
+    bias = (rng.normal(size=E) * 0.1).astype(np.float32)
+    lab = (rng.random((B, E)) < 0.01).astype(np.float32)
+    p_ref = ko.head_1n_forward(x, ent, bias)
+    loss_ref, dp = ko.multi_class_bce_dir(p_ref, lab, 0.1, E)
+    dx_ref, ge_ref, gb_ref = ko.head_1n_backward(x, ent, p_ref, dp)
+    xd, ed, bd = torch.from_numpy(x).cuda(), torch.from_numpy(ent).cuda(), torch.from_numpy(bias).cuda()
+    off, ids = _csr_of(lab)
+    offd, idsd = torch.from_numpy(off).cuda(), torch.from_numpy(ids).cuda()
+    scale = 1.0 / (B * E)
+    K.set_switch("HEAD_TILE", 1)
+    try:
+        p = K.head_1n_forward(xd, ed, bd)
+        runs = []
+        for _ in range(2):
+            dx, ge, gb = K.head_1n_backward(xd, ed, p, torch.from_numpy(dp).cuda())
+            loss_buf = K.new_loss_buffer("cuda")
+            g_ent, g_bias = torch.zeros_like(ed), torch.zeros(E, device="cuda")
+            dx2 = K.head_1n_bce(xd, ed, bd, offd, idsd, 0.1, loss_buf, g_ent, g_bias)
+            runs.append((dx, ge, gb, dx2, g_ent, g_bias))
+    finally:
+        K.set_switch("HEAD_TILE", None)
+    for got, ref in zip(runs[0], (dx_ref, ge_ref, gb_ref, dx_ref, ge_ref, gb_ref)):
+        assert np.allclose(got.cpu().numpy(), ref, atol=1e-3 * scale, rtol=1e-3)
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("name,neg", [("distmult", 1), ("complex", 3), ("analogy", 1), ("cp", 2), ("simple", 1), ("quate", 4)])
 def test_fused_pointwise_sampler_step_equals_sample_then_step(hip, name, neg):
     """kge_train_pointwise_logistic_sampled (corruption fused into the pointwise kernel) must see exactly the rows

@@ -18,7 +18,10 @@ def bench(fn, n=50):
     return (time.perf_counter() - t0) / n * 1e6
 
 
-for B, E, d in ((128, 14951, 200), (1000, 14951, 200), (128, 40943, 200), (4096, 14951, 200), (16384, 14951, 200)):
+SHAPES = ((128, 14951, 200), (1000, 14951, 200), (128, 40943, 200), (4096, 14951, 200), (16384, 14951, 200))
+if os.environ.get("HEAD_B"):   # one batch size only, no ATen legs: the form to run under rocprofv3
+    SHAPES = ((int(os.environ["HEAD_B"]), 14951, 200),)
+for B, E, d in SHAPES:
     rng = np.random.default_rng(0)
     x = torch.randn(B, d, device="cuda"); ent = torch.randn(E, d, device="cuda") * 0.2; bias = torch.randn(E, device="cuda") * 0.1
     lab = (torch.rand(B, E, device="cuda") < 0.002).float()
@@ -28,6 +31,9 @@ for B, E, d in ((128, 14951, 200), (1000, 14951, 200), (128, 40943, 200), (4096,
     t_fwd = bench(lambda: K.head_1n_forward(x, ent, bias))
     t_bf16 = bench(lambda: K.head_1n_forward(x, ent, bias, precision="bf16"))
     t_fused = bench(lambda: K.head_1n_bce(x, ent, bias, off, ids, 0.1, loss_buf, g_ent, g_bias))
+    if os.environ.get("HEAD_B"):
+        print(f"B={B} E={E} d={d}: forward {t_fwd:.1f} us, bf16 {t_bf16:.1f} us, fused head+bce+backward {t_fused:.1f} us", flush=True)
+        continue
     xr, er, br = x.clone().requires_grad_(), ent.clone().requires_grad_(), bias.clone().requires_grad_()
     bce = torch.nn.BCEWithLogitsLoss()
 
