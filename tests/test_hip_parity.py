@@ -1096,6 +1096,47 @@ def test_rescal_staged_entity_gradients_are_reproducible_and_equal_the_atomic_st
     assert off <= 2e-3, (off, float((pa - pc).abs().max()))
 
 
+def test_rescal_staged_lists_are_emptied_when_an_epoch_dies_between_pair_step_and_optimiser(hip, monkeypatch):
+    """The staged RESCAL gradients live in per-entity lists that the pair step fills and the row-owner optimiser consumes and resets.
+    An exception between the two (here: the optimiser call of the second batch raises) must not leave registrations behind:
+    Trainer.train_model_epoch empties the lists and the touched-row bitmaps before re-raising, and the next epoch trains normally."""
+    from pykg2vec_amd.trainer import Trainer
+    E, R, k, B = 2000, 20, 64, 128
+    rng = np.random.default_rng(5)
+    n = 6 * B
+    train = np.stack([rng.integers(E, size=n), rng.integers(R, size=n), rng.integers(E, size=n)], 1)
+    P = ko.init_params("rescal", rng, tot_entity=E, tot_relation=R, hidden_size=k)
+    hp = dict(hidden_size=k, margin=1.0, neg_rate=1)
+    monkeypatch.setenv("KGE_RESCAL_FUSED", "1")
+    monkeypatch.setenv("KGE_RESCAL_STAGED", "1")
+    cfg = hip.make_config(E, R, hp, train, train[:4], train[:4], optimizer="adam", lr=0.01, batch_size=B)
+    tr = Trainer(hip.model_from_params("rescal", P, hp, E, R, train=train), cfg, use_graph=False)
+    tr.build_model()
+    tr.generator = tr._new_generator()
+    first = tr.train_model_epoch(0)
+    st = tr._rescal_stage
+    assert st is not None and np.isfinite(first)
+    real, calls = tr.flat.optimizer_step_rows_first, []
+
+    def dies_on_second_call(*a, **kw):
+        calls.append(1)
+        if len(calls) == 2:
+            raise RuntimeError("injected")
+        return real(*a, **kw)
+    monkeypatch.setattr(tr.flat, "optimizer_step_rows_first", dies_on_second_call)
+    with pytest.raises(RuntimeError, match="injected"):
+        tr.train_model_epoch(1)
+    torch.cuda.synchronize()
+    assert int(st.count.abs().sum()) == 0 and int(st.head.abs().sum()) == 0
+    assert all(int(b.abs().sum()) == 0 for b in tr._touched)
+    monkeypatch.setattr(tr.flat, "optimizer_step_rows_first", real)
+    tr.flat.grad.zero_()      # (the half-finished step's relation gradient; entity gradients never reached the buffer)
+    after = tr.train_model_epoch(2)
+    assert np.isfinite(after) and after < first
+    assert int(st.count.abs().sum()) == 0 and int(st.head.abs().sum()) == 0
+    assert bool(torch.isfinite(tr.flat.param).all())
+
+
 @pytest.mark.parametrize("opt", ["adam", "sgd", "adagrad", "rms"])
 @pytest.mark.parametrize("rows,k", [(7, 136), (37, 200), (3, 128)])
 def test_optimizer_rownorm_equals_sweep_plus_normalisation_bit_for_bit(hip, opt, rows, k):
