@@ -5,16 +5,21 @@
 // Criterion.multi_class_bce (utils/criterion.py:41-49): BCEWithLogitsLoss applied to the SIGMOID OUTPUTS against the
 // (label-smoothed) multi-hot rows hr_t / tr_h, mean over B*E.
 //
-// GEMM-shaped, so it runs on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak), 64x64 output tile per
-// workgroup (4 waves x one 32x32 tile), K staged through LDS in 32-wide slabs.  Operand maps as in kge_dense.hip.
-//   k_head_fwd        Z = X Ent^T (+bias) -> sigmoid            [B,d]x[d,E]
-//   k_head_bce        the same GEMM with the loss fused into the epilogue: every element is first treated as a negative
-//                     (label y0); loss += sum softplus(p) - p*y0 and dz = (sigmoid(p) - y0) p (1-p) / (B*E) is written
+// GEMM-shaped, so it runs on the f32 matrix cores (exact fp32 products, 157 TF peak), in two tile shapes:
+//   small batches (the reference's B = 128)   64 x 64 outputs per workgroup on v_mfma_f32_32x32x2_f32, K in 32-wide LDS slabs
+//       k_head_gemm<MODE>, k_head_dx, k_head_dent (split-K partial tiles combined with float atomics)
+//   large batches                             128 x 128 per workgroup on v_mfma_f32_16x16x4_f32, one K loop (gemm128x_core)
+//       k_head_gemm128x<MODE>, k_head_dx128, k_head_dent128 (+ k_head_sum_parts: split-K partial tiles added in split order --
+//       no atomics, reproducible gradients)
+// MODE 0  Z = X Ent^T (+bias) -> sigmoid                        [B,d]x[d,E]
+// MODE 1  the same GEMM with the loss fused into the epilogue: every element is first treated as a negative (label y0);
+//         loss += sum softplus(p) - p*y0 and dz = (sigmoid(p) - y0) p (1-p) / (B*E) is written (never the predictions)
 //   k_head_bce_pos    one 32-lane group per positive (b, e) of the CSR label lists: recomputes p and applies the
 //                     (y1 - y0) correction to the loss and to dz[b, e]  (a positive is touched by exactly one group)
-//   k_head_dx         dX = dZ Ent            [B,E]x[E,d]   split over E, atomics into dX
-//   k_head_dent       g_ent += dZ^T X        [E,B]x[B,d] ;  g_bias += column sums of dZ
+//   dX = dZ Ent            [B,E]x[E,d]   split over E
+//   g_ent += dZ^T X        [E,B]x[B,d]   split over B;  g_bias += column sums of dZ
 // For the autograd form dZ = dpreds * p * (1 - p) is formed while the operand tile is staged.
+// bf16 option of the forward: k_head_gemm_bf16 / k_head_gemm128_bf16 (v_mfma_f32_32x32x16_bf16).
 #include "kge_internal.h"
 #include <type_traits>
 
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(256) void k_head_dent(DzSrc g, const float* __restr
 //   kOutDirect  the product is not split: the tile IS the result -- plain 16-byte stores (dX) or read-modify-writes (g_ent +=);
 //   kOutParts   the tile goes to its slot of the partials buffer (workgroup number x 64 KB) and k_head_sum_parts adds the splits in
 //               split order: no atomics, bit-reproducible gradients (the fused entry point, which owns a workspace);
-//   kOutAtomic  float atomics into the result (kge_head_1n_backward, the autograd form: no workspace in its signature).
+//   kOutAtomic  float atomics into the result (kge_head_1n_backward called without its optional workspace).
 constexpr int kOutDirect = 0, kOutParts = 1, kOutAtomic = 2;
 constexpr int64_t kHeadPartSlots = 768;   // split-K workgroups per product (three per CU)
 
