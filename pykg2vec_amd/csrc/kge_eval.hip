@@ -875,6 +875,39 @@ __device__ __forceinline__ void pair_step2(float& acc, f32x2 c, f32x2 q) {
     }
 }
 
+// One KC-chunk of every query of the block, in query order: body(q, v) sees v[s][j] = qrow[q][off[s] + j] (scalar loads: the rows are
+// wave-uniform).  The chunk of query q + 1 is requested BEFORE the arithmetic of query q.  Scalar loads return out of order, so the only
+// wait there is waits for all of them: requested right in front of its use -- what the compiler does by itself -- that wait stands
+// between every two queries with nothing to hide it (36 VALU instructions per query and chunk in the L1 sweep).  The empty asm is a
+// use of the current chunk in front of the next request: it pins the wait THERE (profiles/r05_experiments.md section 11).
+template <int QT, int NS, class F>
+__device__ __forceinline__ void for_query_chunks(const float* const (&qrow)[QT], const int (&off)[NS], F body) {
+    float nx[NS][KC];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < KC; ++j) nx[s][j] = qrow[0][off[s] + j];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        float cur[NS][KC];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < KC; ++j) cur[s][j] = nx[s][j];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) asm volatile("" ::"s"(cur[s][0]), "s"(cur[s][KC - 1]));
+        if (q + 1 < QT) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int j = 0; j < KC; ++j) nx[s][j] = qrow[q + 1][off[s] + j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        body(q, cur);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int FORM, int XFORM, int QT, bool WRITE, int POST>
 __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ cand, const float* __restrict__ aux,
                                                     const float* __restrict__ qvec, const float* __restrict__ qscale,
@@ -929,13 +962,13 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                     va[j].x = ca[(int64_t)(k0 + 2 * j) * 64]; va[j].y = ca[(int64_t)(k0 + 2 * j + 1) * 64];
                     vb[j].x = cb[(int64_t)(k0 + 2 * j) * 64]; vb[j].y = cb[(int64_t)(k0 + 2 * j + 1) * 64];
                 }
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
+                const int off1[1] = {k0};
+                for_query_chunks<QT, 1>(qrow, off1, [&](int q, const float (&qv)[1][KC]) {
 #pragma unroll
                     for (int j = 0; j < KC / 2; ++j) {
                         f32x2 qq;
-                        qq.x = qrow[q][k0 + 2 * j];
-                        qq.y = qrow[q][k0 + 2 * j + 1];
+                        qq.x = qv[0][2 * j];
+                        qq.y = qv[0][2 * j + 1];
                         if constexpr (FORM == F_NEGDOT) {  // one v_pk_fma_f32 per k-pair: SGPR pair x VGPR pair
                             pa[q] = __builtin_elementwise_fma(va[j], qq, pa[q]);
                             pb[q] = __builtin_elementwise_fma(vb[j], qq, pb[q]);
@@ -948,7 +981,7 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                             pair_step2<FORM>(accb[q], vb[j], qq);
                         }
                     }
-                }
+                });
             }
             if constexpr (FORM != F_L1) {
 #pragma unroll
@@ -986,11 +1019,11 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                     float cv[KC];
 #pragma unroll
                     for (int j = 0; j < KC; ++j) cv[j] = c[(int64_t)(k0 + j) * 64];
+                    const int off1[1] = {Kpad + k0};
+                    for_query_chunks<QT, 1>(qrow, off1, [&](int q, const float (&qv)[1][KC]) {
 #pragma unroll
-                    for (int q = 0; q < QT; ++q) {
-#pragma unroll
-                        for (int j = 0; j < KC; ++j) p[q] = fmaf(cv[j], qrow[q][Kpad + k0 + j], p[q]);
-                    }
+                        for (int j = 0; j < KC; ++j) p[q] = fmaf(cv[j], qv[0][j], p[q]);
+                    });
                 }
 #pragma unroll
                 for (int q = 0; q < QT; ++q) p[q] = -p[q];
@@ -1005,14 +1038,14 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                 float cv[KC];
 #pragma unroll
                 for (int j = 0; j < KC; ++j) cv[j] = c[(int64_t)(k0 + j) * 64];
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
+                const int off1[1] = {Kpad + k0};
+                for_query_chunks<QT, 1>(qrow, off1, [&](int q, const float (&qv)[1][KC]) {
 #pragma unroll
                     for (int j = 0; j < KC; ++j) {
-                        const float v = fmaf(p[q], qrow[q][Kpad + k0 + j], cv[j]);
+                        const float v = fmaf(p[q], qv[0][j], cv[j]);
                         inv[q] = fmaf(v, v, inv[q]);
                     }
-                }
+                });
             }
 #pragma unroll
             for (int q = 0; q < QT; ++q) inv[q] = 1.0f / fmaxf(sqrtf(inv[q]), kEpsNormalize);
@@ -1020,14 +1053,14 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
                 float cv[KC];
 #pragma unroll
                 for (int j = 0; j < KC; ++j) cv[j] = c[(int64_t)(k0 + j) * 64];
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
+                const int off2[2] = {Kpad + k0, k0};
+                for_query_chunks<QT, 2>(qrow, off2, [&](int q, const float (&qv)[2][KC]) {
 #pragma unroll
                     for (int j = 0; j < KC; ++j) {
-                        const float v = fmaf(p[q], qrow[q][Kpad + k0 + j], cv[j]) * inv[q];
-                        acc[q] = pair_step<FORM>(acc[q], v, qrow[q][k0 + j]);
+                        const float v = fmaf(p[q], qv[0][j], cv[j]) * inv[q];
+                        acc[q] = pair_step<FORM>(acc[q], v, qv[1][j]);
                     }
-                }
+                });
             }
         }
         const int64_t e = tile * 64 + lane;
