@@ -7,7 +7,7 @@
 #     bench    python bench.py (default flags: 200 steps, live counter passes, extras, CPU baseline) -> <tag>_bench_line.json
 #     bench20  the driver's shape: --steps 20 --warmup 5        -> <tag>_bench_line_20steps.json
 #     stats    rocprofv3 --kernel-trace --stats of the bench command, split by launch geometry -> <tag>_kernel_stats.md
-#     fuzz     the randomised sweeps tools/fuzz_*.py (parity, graph, pull, staged, own, eval gemm, big paths, round-4 entry points)
+#     fuzz     the randomised sweeps tools/fuzz_*.py (parity, graph, pull, staged, own, eval gemm, big paths, round-4 entry points, 1-N head)
 #                                                                -> <tag>_fuzz.txt
 #     pmc      FETCH_SIZE / WRITE_SIZE / SQ_* passes (separate passes, --kernel-trace only) of the bench command,
 #              per (kernel, grid)                               -> <tag>_pmc_traffic.json
@@ -35,7 +35,7 @@ for part in $PARTS; do
              timeout 500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU --kernel-trace -d $O/_p3 -o b -- $B2 > $O/${TAG}_prof3.log 2>&1
              python tools/rocpd_pmc.py $O/${TAG}_pmc_traffic.json "$B2; one counter set per pass (FETCH_SIZE | WRITE_SIZE | SQ_*), --kernel-trace only" $(find $O/_p1 $O/_p2 $O/_p3 -name '*.db')
              rm -rf $O/_p1 $O/_p2 $O/_p3 ;;
-    fuzz)    for spec in "fuzz_parity 120 77" "fuzz_graph 60 9" "fuzz_pull 48 3" "fuzz_staged 40 21" "fuzz_own 64 5" "fuzz_eval_gemm 60 31" "fuzz_big_paths 40 41" "fuzz_r4 60 1"; do
+    fuzz)    for spec in "fuzz_parity 120 77" "fuzz_graph 60 9" "fuzz_pull 48 3" "fuzz_staged 40 21" "fuzz_own 64 5" "fuzz_eval_gemm 60 31" "fuzz_big_paths 40 41" "fuzz_r4 60 1" "fuzz_head 60 3"; do
                set -- $spec
                ITERS=$2 SEED=$3 timeout 900 python tools/$1.py > $O/_fuzz_$1.log 2>&1; echo "== $1 ITERS=$2 SEED=$3 rc=$?" | tee -a $O/${TAG}_fuzz.txt; tail -4 $O/_fuzz_$1.log | tee -a $O/${TAG}_fuzz.txt
              done ;;
