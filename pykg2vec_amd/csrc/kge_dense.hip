@@ -1529,11 +1529,13 @@ int launch_rescal_pair_step(const kge_model_desc* m, const int64_t* ph, const in
     int rc = group_by_relation_split(id_whole(pr, n), n, R, g, s, nullptr, 0, kPairTile);
     if (rc) return rc;
     const size_t lds = rescal_pair_lds_bytes(k);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_rescal_pair<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        (void)hipFuncSetAttribute((const void*)k_rescal_pair<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        attr_set = true;
+    // (per call, not once per process: the attribute is per device, and a process may drive several)
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((k & 3) == 0 ? (const void*)k_rescal_pair<4> : (const void*)k_rescal_pair<2>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("RESCAL pair step: the device refuses %zu bytes of dynamic LDS", lds);
+        return -1;
     }
     const unsigned tiles = (unsigned)(n / kPairTile + R + 1);
     float* ds = pair_split(R, n) ? (float*)(g.tile_rel + tiles) : nullptr;
