@@ -83,7 +83,8 @@ for it in range(N):
             moved = np.abs(a - p0)
             rel = np.abs(a - b) / np.maximum(moved, 1e-12)
             print("   ", nme, "max |a-b| %.3g" % np.abs(a - b).max(), "median move %.3g" % np.median(moved), "median / 99th pct of |a-b| / move: %.3g / %.3g" % (np.median(rel), np.percentile(rel, 99)), flush=True)
-    ok = np.allclose(res["0"][0], res["1"][0], rtol=1e-4)
+    # (rms: the atomic arm differs from itself run to run by up to ~1.5e-4 of the second epoch's loss on tables of two relations)
+    ok = np.allclose(res["0"][0], res["1"][0], rtol=3e-4 if opt == "rms" else 1e-4)
     fracs = []
     for a, b in zip(res["0"][1], res["1"][1]):
         if exact and fam == "two_phase" and (E + R) * 1 > 0:
@@ -99,7 +100,7 @@ for it in range(N):
             # between the two paths' gradient sums already moves a parameter by the tolerance -- and the normal-vector / relation
             # gradients of an L1 model are sums of hundreds of cancelling terms whose fp32 value depends on the summation tree at
             # that level (the same case agrees under SGD / Adam / Adagrad: replay with ONLY_IT / FORCE_OPT).  Under rms the
-            # element-wise check therefore only bounds the damage; the losses (rtol 1e-4) carry the comparison.
+            # element-wise check therefore only bounds the damage; the losses (rtol 3e-4 under rms, 1e-4 otherwise) carry the comparison.
             lim = (2e-3 if l1_model else 0.0) if opt == "sgd" else (1.0 if a.size < 4096 else 0.1) if opt == "rms" else 1e-2
             ok = ok and frac <= lim
     if not ok:
