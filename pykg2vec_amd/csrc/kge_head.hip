@@ -323,6 +323,130 @@ __global__ __launch_bounds__(256, HEAD_OCC) void k_head_gemm128x(HeadArgs a) {
     if constexpr (MODE == 1) block_accumulate_loss<1>(lsum * a.inv_count, 0, a.loss);
 }
 
+// ---- the same loop at a 64 x 64 tile for small batches (the reference's B = 128 at E = 14 951: 2 x 234 tiles): 4 waves x (2 x 2
+// blocks of 16 x 16), K slabs of 32 (two float4 per thread and operand), rows 2 r + mi / columns 2 c + ni per block so that a lane's
+// two A (two B) operands of a k-step are one 8-byte LDS read and its two results of a row are consecutive entities.  The 32x32x2
+// kernel it replaces (k_head_gemm, kept for hidden sizes that are no multiple of 4) fetched its slabs with scalar loads under a
+// select: synchronous, 21.5 us at B = 128 against 11 us here.
+constexpr int HK4 = 32, HLD4 = HT + 32;   // 96-float rows: the four k rows a wave reads per k-step sit 32 banks apart
+struct __attribute__((packed, aligned(4))) float2u { float x, y; };
+
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void k_head_gemm64x(HeadArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[2][HK4][HLD4], sB[2][HK4][HLD4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lcol = lane & 15, lk4 = lane >> 4;
+    int64_t e0, b0;
+    head_tile(a, HT, e0, b0);
+    const int wr = wave >> 1, wc = wave & 1;   // wave's 32 x 32 sub-tile: batch rows wr, entity columns wc
+    const int srow = threadIdx.x >> 2, sk4 = (threadIdx.x & 3) * 4;   // float4 j of a slab: row srow, k = sk4 + 16 j .. + 3
+    const int nslab = (a.d + HK4 - 1) / HK4;
+    const bool rowa = b0 + srow < a.B, rowb = e0 + srow < a.E;
+    const float* const pa = a.x + (rowa ? (b0 + srow) * a.d : 0);
+    const float* const pb = a.ent + (rowb ? (e0 + srow) * a.d : 0);
+    // THREE slabs of operands in registers (slab s in set s % 3): one being stored, two in flight -- the matrix work of a slab (32
+    // MFMAs per wave) is far shorter than a round trip, and this tile leaves the registers for it (64 VGPRs)
+    float4 ra[3][2], rb[3][2];
+    // (d % 4 == 0: a float4 is inside the row or past its end; past it the row's first float4 is fetched and dropped at the store)
+    auto load_slab = [&](int sl, auto set) {
+        constexpr int P = decltype(set)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = sl * HK4 + sk4 + 16 * j;
+            ra[P][j] = *reinterpret_cast<const float4*>(pa + (k < a.d ? k : 0));
+            rb[P][j] = *reinterpret_cast<const float4*>(pb + (k < a.d ? k : 0));
+        }
+    };
+    auto store_slab = [&](int sl, int buf, auto set) {
+        constexpr int P = decltype(set)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = sk4 + 16 * j;
+            const bool live = sl * HK4 + kk < a.d;
+            const float4 va = keep_if(ra[P][j], live && rowa), vb = keep_if(rb[P][j], live && rowb);
+            sA[buf][kk + 0][srow] = va.x; sA[buf][kk + 1][srow] = va.y; sA[buf][kk + 2][srow] = va.z; sA[buf][kk + 3][srow] = va.w;
+            sB[buf][kk + 0][srow] = vb.x; sB[buf][kk + 1][srow] = vb.y; sB[buf][kk + 2][srow] = vb.z; sB[buf][kk + 3][srow] = vb.w;
+        }
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_slab(0, S0());
+    if (1 < nslab) load_slab(1, S1());
+    if (2 < nslab) load_slab(2, S2());
+    store_slab(0, 0, S0());
+    __syncthreads();
+    int buf = 0;
+    auto step = [&](int sl, auto set, auto next) {   // set = sl % 3, next = (sl + 1) % 3
+        float2 na, nb;
+#define KGE_HEAD_READ2(K)                                                                                                  \
+    {                                                                                                                      \
+        na = *reinterpret_cast<const float2*>(&sA[buf][(K) + lk4][wr * 32 + 2 * lcol]);                                    \
+        nb = *reinterpret_cast<const float2*>(&sB[buf][(K) + lk4][wc * 32 + 2 * lcol]);                                    \
+    }
+        KGE_HEAD_READ2(0)
+#pragma unroll
+        for (int kk = 0; kk < HK4; kk += 4) {
+            const float2 a2 = na, b2 = nb;
+            if (kk + 4 < HK4) KGE_HEAD_READ2(kk + 4)
+            KGE_KEEP_READS_AHEAD();
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, acc[1][1], 0, 0, 0);
+            if (kk == 0) {   // (as in gemm128x_core: the next slab is stored behind the first MFMAs of this one)
+                KGE_KEEP_READS_AHEAD();
+                if (sl + 1 < nslab) {
+                    store_slab(sl + 1, buf ^ 1, next);
+                    if (sl + 3 < nslab) load_slab(sl + 3, set);   // (this set's slab went to LDS one step ago)
+                }
+                KGE_KEEP_READS_AHEAD();
+            }
+        }
+#undef KGE_HEAD_READ2
+        __syncthreads();
+        buf ^= 1;
+    };
+    for (int sl = 0; sl < nslab; sl += 3) {
+        step(sl, S0(), S1());
+        if (sl + 1 < nslab) step(sl + 1, S1(), S2());
+        if (sl + 2 < nslab) step(sl + 2, S2(), S0());
+    }
+    // the lane owns entity columns e, e + 1 (column blocks ni = 0, 1) of batch rows 2 (4 lk4 + reg) + mi
+    const int64_t e = e0 + wc * 32 + 2 * lcol;
+    float bias[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) bias[ni] = (a.bias && e + ni < a.E) ? a.bias[e + ni] : 0.f;
+    const bool whole = e + 1 < a.E;
+    float lsum = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t b = b0 + wr * 32 + 2 * (4 * lk4 + reg) + mi;
+            if (b >= a.B || e >= a.E) continue;
+            float o[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const float p = sigmoidf_(acc[mi][ni][reg] + bias[ni]);
+                if constexpr (MODE == 0) {
+                    o[ni] = p;
+                } else {
+                    float lt;
+                    o[ni] = bce_neg_terms(p, a.y0, lt) * a.inv_count;
+                    if (e + ni < a.E) lsum += lt;
+                }
+            }
+            float* const dst = MODE == 0 ? a.preds + b * a.E + e : a.dz + b * a.ldz + e;
+            if (whole) *reinterpret_cast<float2u*>(dst) = float2u{o[0], o[1]};
+            else dst[0] = o[0];
+        }
+    if constexpr (MODE == 1) block_accumulate_loss<1>(lsum * a.inv_count, 0, a.loss);
+}
+
 // ---- bf16 option of the forward ("bf16/f32 MFMA GEMM"): the operands are rounded to bfloat16 (round to
 // nearest even) while they are staged into LDS, products are exact in fp32 and accumulate in fp32 on
 // v_mfma_f32_32x32x16_bf16 (gfx950: 16 k per instruction, 16x the rate of the f32-input form).  Inputs and outputs stay fp32 in
@@ -475,6 +599,8 @@ static void launch_head_gemm(const HeadArgs& a, hipStream_t s) {
     if (head_use_128(a)) {
         hipLaunchKernelGGL(k_head_gemm128x<MODE>, head_grid(a, HT2), dim3(256), 0, s, a);
     }
+    else if (a.d % 4 == 0 && (((uintptr_t)a.x | (uintptr_t)a.ent) & 15) == 0 && switch_value("HEAD_SMALL_X") != 0)
+        hipLaunchKernelGGL(k_head_gemm64x<MODE>, head_grid(a, HT), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(k_head_gemm<MODE>, head_grid(a, HT), dim3(256), 0, s, a);
 }
@@ -757,12 +883,15 @@ __global__ __launch_bounds__(256, HEAD_BWD_OCC) void k_head_dent128(DzSrc g, con
     }
 }
 
-// out[m, n] (+)= sum over the splits, in split order, of the partial tiles the workgroups of a split-K product left (kOutParts);
-// one thread per float4 of the tile space.  bpart: the bias-gradient partials of the entity-gradient product (column tile 0).
+// out[m, n] (+)= the sum over the splits of the partial tiles the workgroups of a split-K product left (kOutParts), in a FIXED
+// order: L lanes per float4 of the tile space, lane j adds splits j, j + L, ... in ascending order, then the L lane sums are added
+// by a butterfly (L = 1: plain split order).  bpart: the bias-gradient partials of the entity-gradient product (column tile 0).
+template <int L>
 __global__ __launch_bounds__(256) void k_head_sum_parts(const float* __restrict__ part, int splits, int MT, int NT, int64_t M, int N,
                                                         float* __restrict__ out, int accumulate, const float* __restrict__ bpart,
                                                         float* __restrict__ g_bias) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / L;
+    const int lane = threadIdx.x % L;
     const int c4 = (int)(i & 31), r = (int)((i >> 5) & 127);
     const int64_t t = i >> 12;
     if (t >= (int64_t)MT * NT) return;
@@ -770,21 +899,40 @@ __global__ __launch_bounds__(256) void k_head_sum_parts(const float* __restrict_
     const int64_t m = (int64_t)mt * HT2 + r;
     const int n = nt * HT2 + 4 * c4;
     if (m >= M) return;
-    if (n < N) {
+    if (n < N) {   // (uniform over the L lanes of a group)
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < splits; ++z) {
+        for (int z = lane; z < splits; z += L) {
             const float4 v = *reinterpret_cast<const float4*>(part + ((((int64_t)z * MT + mt) * NT + nt) << 14) + r * HT2 + 4 * c4);
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
-        float4* const o = reinterpret_cast<float4*>(out + m * N + n);
-        if (accumulate) { const float4 w = *o; sum.x += w.x; sum.y += w.y; sum.z += w.z; sum.w += w.w; }
-        *o = sum;
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) {
+            sum.x += __shfl_xor(sum.x, o, 64); sum.y += __shfl_xor(sum.y, o, 64);
+            sum.z += __shfl_xor(sum.z, o, 64); sum.w += __shfl_xor(sum.w, o, 64);
+        }
+        if (lane == 0) {
+            float4* const o4 = reinterpret_cast<float4*>(out + m * N + n);
+            if (accumulate) { const float4 w = *o4; sum.x += w.x; sum.y += w.y; sum.z += w.z; sum.w += w.w; }
+            *o4 = sum;
+        }
     }
     if (bpart != nullptr && nt == 0 && c4 == 0) {
         float bs = 0.f;
-        for (int z = 0; z < splits; ++z) bs += bpart[((int64_t)z * MT + mt) * HT2 + r];
-        g_bias[m] += bs;
+        for (int z = lane; z < splits; z += L) bs += bpart[((int64_t)z * MT + mt) * HT2 + r];
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) bs += __shfl_xor(bs, o, 64);
+        if (lane == 0) g_bias[m] += bs;
     }
+}
+
+static void launch_head_sum_parts(const float* part, int64_t splits, int64_t MT, int64_t NT, int64_t M, int N, float* out, int accumulate,
+                                  const float* bpart, float* g_bias, hipStream_t s) {
+    if (splits >= 16)
+        hipLaunchKernelGGL(k_head_sum_parts<8>, dim3((unsigned)(MT * NT * 16 * 8)), dim3(256), 0, s, part, (int)splits, (int)MT, (int)NT, M, N,
+                           out, accumulate, bpart, g_bias);
+    else
+        hipLaunchKernelGGL(k_head_sum_parts<1>, dim3((unsigned)(MT * NT * 16)), dim3(256), 0, s, part, (int)splits, (int)MT, (int)NT, M, N, out,
+                           accumulate, bpart, g_bias);
 }
 
 __global__ void k_head_rows_of(const int64_t* __restrict__ lab_off, int64_t B, int32_t* __restrict__ row_of) {
@@ -826,14 +974,18 @@ static int head_backward_gemms(const DzSrc& g, const float* x, int64_t B, int d,
     // the 128-wide forms pay once the batch fills their tiles (the same switch as the forward: KGE_HEAD_TILE = 0 / 1 forces)
     const int force = switch_value("HEAD_TILE");
     const bool aligned = d % 4 == 0 && (((uintptr_t)x | (uintptr_t)ent | (uintptr_t)dx | (uintptr_t)g_ent) & 15) == 0;
-    const int min_b = switch_value("HEAD_WIDE_B") > 0 ? switch_value("HEAD_WIDE_B") : (parts ? 512 : 2560);
+    // with a partials buffer the wide forms win from the reference's own batch (B = 128: dX 40 -> 12 us, g_ent 31 -> 17 us); without
+    // one their split-K tiles meet in float atomics, which only pays from B ~ 2 560
+    const int min_b = switch_value("HEAD_WIDE_B") > 0 ? switch_value("HEAD_WIDE_B") : (parts ? 1 : 2560);
     const bool wide = aligned && (force >= 0 ? force == 1 : B >= min_b);
     const int T = wide ? HT2 : HT, SK = wide ? HK2 : HK;
-    // split-K: ~8 small-tile workgroups per CU; wide: three per CU, all resident in ONE round (rounding the split count up left a
-    // second, mostly empty round) and never more than the partials buffer has slots.  Every split a multiple of the slab.
+    // split-K: ~8 small-tile workgroups per CU; wide: at most three per CU, all resident in ONE round (rounding the split count up
+    // left a second, mostly empty round), never more than the partials buffer has slots, and no split shorter than kMinK of K
+    // (every split pays a prologue, an epilogue and a partial tile that somebody has to add).  Every split a multiple of the slab.
+    const int min_k = switch_value("HEAD_MINK") > 0 ? switch_value("HEAD_MINK") : 128;
     auto split = [&](int64_t tiles, int64_t K, int64_t* per) {
         int64_t splits = wide ? kHeadPartSlots / tiles : (2048 + tiles - 1) / tiles;
-        const int64_t max_splits = wide ? (K + 127) / 128 : (K + SK - 1) / SK;
+        const int64_t max_splits = wide ? (K + min_k - 1) / min_k : (K + SK - 1) / SK;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
         *per = ((K + splits - 1) / splits + SK - 1) / SK * SK;
@@ -853,9 +1005,7 @@ static int head_backward_gemms(const DzSrc& g, const float* x, int64_t B, int d,
         if (wide && g.dz) hipLaunchKernelGGL(k_head_dx128<true>, grid, dim3(256), 0, s, g, ent, B, E, d, per, dx, emode, parts);
         else if (wide) hipLaunchKernelGGL(k_head_dx128<false>, grid, dim3(256), 0, s, g, ent, B, E, d, per, dx, emode, parts);
         else hipLaunchKernelGGL(k_head_dx, grid, dim3(256), 0, s, g, ent, B, E, d, per, dx);
-        if (emode == kOutParts)
-            hipLaunchKernelGGL(k_head_sum_parts, dim3((unsigned)(MT * NT * 16)), dim3(256), 0, s, parts, (int)splits, (int)MT, (int)NT, B, d,
-                               dx, 0, (const float*)nullptr, (float*)nullptr);
+        if (emode == kOutParts) launch_head_sum_parts(parts, splits, MT, NT, B, d, dx, 0, nullptr, nullptr, s);
     }
     if (g_ent) {
         int64_t per;
@@ -866,9 +1016,7 @@ static int head_backward_gemms(const DzSrc& g, const float* x, int64_t B, int d,
         if (wide && g.dz) hipLaunchKernelGGL(k_head_dent128<true>, grid, dim3(256), 0, s, g, x, B, E, d, per, g_ent, g_bias, emode, parts, bparts);
         else if (wide) hipLaunchKernelGGL(k_head_dent128<false>, grid, dim3(256), 0, s, g, x, B, E, d, per, g_ent, g_bias, emode, parts, bparts);
         else hipLaunchKernelGGL(k_head_dent, grid, dim3(256), 0, s, g, x, B, E, d, per, g_ent, g_bias);
-        if (emode == kOutParts)
-            hipLaunchKernelGGL(k_head_sum_parts, dim3((unsigned)(MT * NT * 16)), dim3(256), 0, s, parts, (int)splits, (int)MT, (int)NT, E, d,
-                               g_ent, 1, g_bias ? (const float*)bparts : (const float*)nullptr, g_bias);
+        if (emode == kOutParts) launch_head_sum_parts(parts, splits, MT, NT, E, d, g_ent, 1, g_bias ? bparts : nullptr, g_bias, s);
     }
     return check_launch("k_head_dx / k_head_dent");
 }
