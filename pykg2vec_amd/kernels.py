@@ -1192,8 +1192,9 @@ def head_1n_forward(x, ent, bias=None, precision="f32"):
     return preds
 
 
-def head_1n_backward(x, ent, preds, dpreds, need_bias=True):
-    """(dx, g_ent, g_bias) of the head given d loss / d preds (kge_head_1n_backward)."""
+def head_1n_backward(x, ent, preds, dpreds, need_bias=True, workspace=True):
+    """(dx, g_ent, g_bias) of the head given d loss / d preds (kge_head_1n_backward).  workspace=False: the entry point's
+    workspace-free form (split-K partial tiles meet in float atomics instead of being added in a fixed order)."""
     B, d = x.shape
     E = ent.shape[0]
     dx = torch.empty_like(x)
@@ -1201,10 +1202,11 @@ def head_1n_backward(x, ent, preds, dpreds, need_bias=True):
     g_bias = torch.zeros(E, dtype=torch.float32, device=x.device) if need_bias else None
     lib = L.load()
     # (room for the split-K partial tiles: summed in split order instead of with float atomics -- reproducible gradients)
-    ws = torch.empty(lib.kge_head_1n_backward_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    ws = torch.empty(lib.kge_head_1n_backward_workspace_bytes(), dtype=torch.uint8, device=x.device) if workspace else None
     L.check(lib.kge_head_1n_backward(_f32(x, "x"), B, d, _f32(ent, "ent"), E, _f32(preds, "preds"),
                                      _f32(dpreds, "dpreds"), _f32(dx, "dx"), _f32(g_ent, "g_ent"),
-                                     _f32(g_bias, "g_bias") if need_bias else None, _dev(ws, torch.uint8, "workspace"), ws.numel(),
+                                     _f32(g_bias, "g_bias") if need_bias else None,
+                                     _dev(ws, torch.uint8, "workspace") if workspace else None, ws.numel() if workspace else 0,
                                      _stream()), "kge_head_1n_backward")
     return dx, g_ent, g_bias
 

@@ -893,6 +893,15 @@ def test_head_1n_wide_backward_products(hip, B, E, d):
         assert np.allclose(got.cpu().numpy(), ref, atol=1e-3 * scale, rtol=1e-3)
     for a, b in zip(runs[0], runs[1]):
         assert torch.equal(a, b)
+    # the workspace-free form of the entry point (partial tiles meet in float atomics), both tile shapes
+    for tile in (0, 1):
+        K.set_switch("HEAD_TILE", tile)
+        try:
+            got = K.head_1n_backward(xd, ed, p, torch.from_numpy(dp).cuda(), workspace=False)
+        finally:
+            K.set_switch("HEAD_TILE", None)
+        for g, ref in zip(got, (dx_ref, ge_ref, gb_ref)):
+            assert np.allclose(g.cpu().numpy(), ref, atol=1e-3 * scale, rtol=1e-3)
 
 
 @pytest.mark.parametrize("name,neg", [("distmult", 1), ("complex", 3), ("analogy", 1), ("cp", 2), ("simple", 1), ("quate", 4)])
