@@ -114,7 +114,7 @@ def build_filters(all_triples, queries, R_):
     return hr_t, tr_h
 
 
-def cpu_baseline_train(train, budget_s=2.5, batch=32768):
+def cpu_baseline_train(train, budget_s=1.2, batch=32768):
     """C/OpenMP restatement of one reference train step (utils/trainer.py:147-157,298-299 + criterion.py:25-29 + dense
     Adam) on all host cores -- oracle/kge_oracle_c.c, a *port* held to the numpy oracle by tests/test_oracle_c.py."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -155,7 +155,7 @@ def cpu_baseline_train(train, budget_s=2.5, batch=32768):
             "%d dense-Adam steps of B=%d positives + %d negatives (FB15k-shape TransE d=100 L1), C/OpenMP fp32" % (n, batch, batch))
 
 
-def cpu_baseline_eval(P_np, test, csr, budget_s=2.5):
+def cpu_baseline_eval(P_np, test, csr, budget_s=1.2):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import kge_oracle_c as kc
     t_off, t_ids, h_off, h_ids = csr
@@ -212,7 +212,7 @@ def cpu_baseline(H):
             import aten_step
             hr_t, tr_h = build_filters(np.concatenate([H.train, H.valid, H.test]), H.test[:n_ref], R)
             doc = aten_step.measure(E, R, DIM, H.train, H.test, hr_t, tr_h, batch=H.cfg.batch_size, n_eval=n_ref, margin=H.cfg.margin,
-                                    lr=H.cfg.learning_rate, train_budget_s=4.0, eval_budget_s=4.0, max_timed=20)
+                                    lr=H.cfg.learning_rate, train_budget_s=3.0, eval_budget_s=3.0, max_timed=20)
             out = {"value": doc["train"]["value"], "unit": "scored triples/s", "cores": doc["cores"], "kind": "aten-restatement",
                    "sample": doc["train"]["sample"], "what": doc["what"], "host": doc["host"], "same_run": True, "same_host": True,
                    "kind_note": "the reference's exact ATen op sequence on this host's torch CPU build (%s)" % tried,
