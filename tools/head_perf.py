@@ -31,8 +31,12 @@ for B, E, d in SHAPES:
     t_fwd = bench(lambda: K.head_1n_forward(x, ent, bias))
     t_bf16 = bench(lambda: K.head_1n_forward(x, ent, bias, precision="bf16"))
     t_fused = bench(lambda: K.head_1n_bce(x, ent, bias, off, ids, 0.1, loss_buf, g_ent, g_bias))
+    preds = K.head_1n_forward(x, ent, bias)
+    dpr = torch.randn_like(preds)
+    t_bwd = bench(lambda: K.head_1n_backward(x, ent, preds, dpr))      # autograd form: (dx, g_ent, g_bias) from d loss / d preds
     if os.environ.get("HEAD_B"):
-        print(f"B={B} E={E} d={d}: forward {t_fwd:.1f} us, bf16 {t_bf16:.1f} us, fused head+bce+backward {t_fused:.1f} us", flush=True)
+        print(f"B={B} E={E} d={d}: forward {t_fwd:.1f} us, bf16 {t_bf16:.1f} us, backward (autograd form) {t_bwd:.1f} us, "
+              f"fused head+bce+backward {t_fused:.1f} us", flush=True)
         continue
     xr, er, br = x.clone().requires_grad_(), ent.clone().requires_grad_(), bias.clone().requires_grad_()
     bce = torch.nn.BCEWithLogitsLoss()
@@ -48,4 +52,5 @@ for B, E, d in SHAPES:
     flops = 2.0 * B * E * d
     print(f"B={B} E={E} d={d}: forward {t_fwd:.1f} us ({flops/t_fwd/1e6:.1f} TFLOP/s; ATen {t_aten_fwd:.1f} us; bf16 option {t_bf16:.1f} us = "
           f"{flops/t_bf16/1e6:.1f} TFLOP/s, output write {B*E*4/t_bf16/1e6:.2f} TB/s) | "
-          f"fused head+bce+backward {t_fused:.1f} us ({3*flops/t_fused/1e6:.1f} TFLOP/s; ATen chain {t_aten:.1f} us)", flush=True)
+          f"fused head+bce+backward {t_fused:.1f} us ({3*flops/t_fused/1e6:.1f} TFLOP/s; ATen chain {t_aten:.1f} us) | "
+          f"backward of the autograd form {t_bwd:.1f} us ({2*flops/t_bwd/1e6:.1f} TFLOP/s)", flush=True)
