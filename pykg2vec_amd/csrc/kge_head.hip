@@ -155,12 +155,10 @@ constexpr int HT2 = 128, HK2 = 16;   // the large tile: 128 x 128 outputs per wo
 // are 16 consecutive bytes of the k-major slab, and its four results of one batch row are four CONSECUTIVE entities -- one 16-byte
 // store (4-byte aligned: E is odd, global_store_dwordx4 takes it), 256 contiguous bytes of a row per 16 lanes.  One MFMA chain over
 // k per element, like the other forms: bit-identical logits.
-#ifndef HEAD_OCC
+// workgroups per CU the register allocation must allow: four for the forward, three for the backward products (168 VGPRs: at four
+// the loaders' 64-bit indices spill, and a spill reload inside the K loop waits for every load in flight)
 #define HEAD_OCC 4
-#endif
-#ifndef HEAD_BWD_OCC
 #define HEAD_BWD_OCC 3
-#endif
 constexpr int HLD3 = HT2 + 16;   // 16 lanes read 16 consecutive floats of row k, the next 16 lanes row k + 1: rows 16 banks apart
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) float4u { float x, y, z, w; };
