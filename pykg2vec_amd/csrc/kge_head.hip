@@ -975,7 +975,8 @@ static int head_backward_gemms(const DzSrc& g, const float* x, int64_t B, int d,
     // with a partials buffer the wide forms win from the reference's own batch (B = 128: dX 40 -> 12 us, g_ent 31 -> 17 us); without
     // one their split-K tiles meet in float atomics, which only pays from B ~ 2 560
     const int min_b = switch_value("HEAD_WIDE_B") > 0 ? switch_value("HEAD_WIDE_B") : (parts ? 1 : 2560);
-    const bool wide = aligned && (force >= 0 ? force == 1 : B >= min_b);
+    // (the autograd form's 16-byte fetches are clamped to the last in-bounds position of the [B, E] arrays: they need four elements)
+    const bool wide = aligned && (g.dz != nullptr || B * E >= 4) && (force >= 0 ? force == 1 : B >= min_b);
     const int T = wide ? HT2 : HT, SK = wide ? HK2 : HK;
     // split-K: ~8 small-tile workgroups per CU; wide: at most three per CU, all resident in ONE round (rounding the split count up
     // left a second, mostly empty round), never more than the partials buffer has slots, and no split shorter than kMinK of K

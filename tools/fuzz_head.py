@@ -13,6 +13,8 @@ for it in range(int(os.environ.get("ITERS", 40))):
     B = int(rng.choice([1, 3, 64, 127, 128, 129, 300, 513, 700]))
     E = int(rng.choice([1, 2, 3, 4, 5, 63, 64, 65, 127, 129, 257, 1000, 1001, 1002, 1003, 2500]))
     d = int(rng.choice([4, 8, 12, 64, 100, 128, 132, 200, 260])) if rng.random() < 0.85 else int(rng.choice([1, 7, 33]))
+    if it < 4:      # the corner the wide backward products must refuse: fewer than four elements in the whole [B, E] array
+        B, E, d = 1, it % 3 + 1, 4
     with_bias = bool(rng.random() < 0.7)
     dens = float(rng.choice([0.0, 0.01, 0.2]))
     ls = None if rng.random() < 0.3 else 0.1
