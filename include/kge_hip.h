@@ -321,6 +321,14 @@ int kge_eval_ranks_grouped_ties(const kge_model_desc* m, const int64_t* triples,
 int kge_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n,
                           void* workspace, size_t workspace_bytes, float* scores, void* stream);
 
+/* One side of the same sweep: side 0 = Evaluator.test_tail_rank's score vector (utils/evaluator.py:249-260: energies of
+ * (h_i, r_i, e) over all e; column 2 of `triples` is not read), side 1 = test_head_rank's (:262-273: energies of (e, r_i, t_i);
+ * column 0 not read).  scores: float [n, E].  What the predict_tail_rank / predict_head_rank hooks call (n = 1): the other
+ * side's query row is never swept.  TransR (candidates projected per call) and NTN compute both sides anyway: refused here,
+ * use kge_eval_sweep_scores.  Same workspace as kge_eval_ranks. */
+int kge_eval_sweep_scores_side(const kge_model_desc* m, const int64_t* triples, int64_t n, int side,
+                               void* workspace, size_t workspace_bytes, float* scores, void* stream);
+
 /* MetricCalculator.get_tail_rank / get_head_rank (utils/evaluator.py:70-123) from materialised score rows, for models
  * whose sweep is served by kge_score_forward over all candidates (NTN): scores float [nq, E], truth int64 [nq] (the true
  * entity of each row), CSR of known entities per row (may be NULL) -> rank, filtered rank (int32 [nq], 0-based). */

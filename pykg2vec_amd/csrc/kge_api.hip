@@ -888,6 +888,16 @@ int kge_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64
     return launch_eval_sweep_scores(m, triples, n, workspace, workspace_bytes, scores, (hipStream_t)stream);
 }
 
+int kge_eval_sweep_scores_side(const kge_model_desc* m, const int64_t* triples, int64_t n, int side, void* workspace,
+                               size_t workspace_bytes, float* scores, void* stream) {
+    if (validate(m, false, "kge_eval_sweep_scores_side")) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || !triples || !scores || (side != 0 && side != 1)) { set_error("kge_eval_sweep_scores_side: bad arguments (side is 0 = tail sweep or 1 = head sweep)"); return -1; }
+    // (the unused column still passes through the id check: callers put any valid id there)
+    if (int rc = debug_check_triples("kge_eval_sweep_scores_side", m->tot_entity, m->tot_relation, triples, n, (hipStream_t)stream)) return rc;
+    return launch_eval_sweep_scores(m, triples, n, workspace, workspace_bytes, scores, (hipStream_t)stream, side);
+}
+
 int kge_rank_from_scores(const float* scores, int64_t nq, int64_t tot_entity, const int64_t* truth, const int64_t* off,
                          const int32_t* ids, int32_t* rank, int32_t* frank, void* stream) {
     if (nq == 0) return 0;

@@ -43,6 +43,7 @@ enum XForm { X_NONE = 0, X_TRANSH = 1, X_TRANSD = 2 };
 enum Post { P_NONE = 0, P_SCALE = 1, P_CLAMP = 2 };
 
 struct EvalPlan {
+    int64_t nq;   // query rows the sweep walks: 2n (tail + head sweep per triple), n for a one-sided score sweep
     int64_t E, n, tables, table_stride;  // tables > 1: one projected candidate table per relation group (TransR)
     int K, Kpad, QV, form, xform, post;
     int64_t ntiles;
@@ -64,7 +65,7 @@ static int sweep_K(const kge_model_desc* m) {
 }
 
 static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p, int64_t tables = 1) {
-    p->E = m->tot_entity; p->n = n; p->tables = tables;
+    p->E = m->tot_entity; p->n = n; p->nq = 2 * n; p->tables = tables;
     const bool per_group_tables = tables > 1 || m->model == KGE_TRANSR;  // candidates already transformed per relation group
     p->K = sweep_K(m);
     p->Kpad = (p->K + KC - 1) / KC * KC;
@@ -403,11 +404,13 @@ __global__ __launch_bounds__(256) void k_eval_prepare_xf(XfPrepArgs a, float* __
 }
 
 // ------------------------------------------------------------------ 2. query vectors
-// one wave (translation family) or one workgroup per test triple; writes qvec[(2i+side)*QV*Kpad ...], side 0 = tail sweep (h,r,?), 1 = head sweep (?,r,t)
+// one wave (translation family) or one workgroup per test triple; writes qvec[(2i+side)*QV*Kpad ...], side 0 = tail sweep (h,r,?), 1 = head sweep (?,r,t).
+// `only` = 0 / 1 (one-sided score sweeps, kge_eval_sweep_scores_side): the wanted side's vector of triple i is row i, the other
+// side's goes to row n + i, which nothing reads (the sweep then walks n query rows).  `only` = 2: both, interleaved.
 template <int M>
 __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64_t* __restrict__ triples, int64_t n,
                                                       int K, int Kpad, int QV, float* __restrict__ qvec,
-                                                      float* __restrict__ qscale) {
+                                                      float* __restrict__ qscale, int only) {
     // the translation family needs wave-wide row reductions: one wave per triple; everything else is element-wise over k
     // (or independent per output column, RESCAL): the whole workgroup takes one triple, four times the loads in flight per row
     constexpr int TPT = (M == KGE_TRANSE || M == KGE_TRANSH || M == KGE_TRANSD || M == KGE_TRANSM) ? 64 : 256;
@@ -415,12 +418,14 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
     const int64_t i = (int64_t)blockIdx.x * (256 / TPT) + threadIdx.x / TPT;
     if (i >= n) return;
     const int64_t h = triples[3 * i], r = triples[3 * i + 1], t = triples[3 * i + 2];
+    const int64_t row_t = only == 2 ? 2 * i : only == 0 ? i : n + i;
+    const int64_t row_h = only == 2 ? 2 * i + 1 : only == 1 ? i : n + i;
     if (lane == 0) {
         const float sc = (M == KGE_TRANSM) ? m.tab[2][r] : 1.0f;
-        qscale[2 * i] = sc; qscale[2 * i + 1] = sc;
+        qscale[row_t] = sc; qscale[row_h] = sc;
     }
-    float* qt = qvec + (2 * i) * (int64_t)QV * Kpad;
-    float* qh = qvec + (2 * i + 1) * (int64_t)QV * Kpad;
+    float* qt = qvec + row_t * (int64_t)QV * Kpad;
+    float* qh = qvec + row_h * (int64_t)QV * Kpad;
     const int d = m.dim;
     for (int k = K + lane; k < Kpad; k += TPT) {
         qt[k] = 0.f; qh[k] = 0.f;
@@ -1482,7 +1487,7 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
                                 const int32_t* group_of_triple = nullptr, const int32_t* qdesc = nullptr,
                                 int64_t n_qblocks = 0) {
     constexpr int QT = XFORM == X_NONE ? QT_PLAIN : QT_XF;
-    const int64_t nq = 2 * p.n;
+    const int64_t nq = p.nq;
     const int qblocks = qdesc ? (int)n_qblocks : (int)((nq + QT - 1) / QT);
     // tile splits S: every wave gets >= 1 tile; aim at >= ~8 waves of workgroups per CU so the last round is cheap
     const int64_t tiles_per_wave_pass = XFORM == X_NONE ? 2 : 1;
@@ -1538,9 +1543,16 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
 
 static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t n, const int64_t* tail_off,
                         const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
-                        size_t ws_bytes, int32_t* ranks, int32_t* ties, float* scores_out, hipStream_t s) {
+                        size_t ws_bytes, int32_t* ranks, int32_t* ties, float* scores_out, hipStream_t s, int side = 2) {
     EvalPlan p;
     if (!make_plan(m, n, ws, &p)) { set_error("kge_eval: model %d has no sweep form", m->model); return -1; }
+    if (side != 2) {
+        if (scores_out == nullptr || (side != 0 && side != 1) || m->model == KGE_TRANSR) {
+            set_error("kge_eval: one-sided sweeps write scores only (side 0 = tail, 1 = head; TransR projects per call: use both sides)");
+            return -1;
+        }
+        p.nq = n;
+    }
     if (ws == nullptr || ws_bytes < p.bytes) {
         set_error("kge_eval: workspace too small (%zu < %zu)", ws_bytes, p.bytes);
         return -1;
@@ -1552,7 +1564,7 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     } else {
     PrepArgs pa;
     fill_prep(m, p, &pa);
-    pa.want_n2 = (p.form == F_SQM && p.xform == X_NONE && p.qT != nullptr && use_gemm_sweep(p, 2 * n)) ? 1 : 0;
+    pa.want_n2 = (p.form == F_SQM && p.xform == X_NONE && p.qT != nullptr && use_gemm_sweep(p, p.nq)) ? 1 : 0;
     bool vec = !pa.normalize && !pa.dot_tab;
     for (int sg = 0; sg < pa.nseg; ++sg) vec = vec && pa.seg_dim[sg] % 4 == 0 && (uintptr_t)pa.seg[sg] % 16 == 0;
     if (vec) {   // 16-byte re-layout, K split over grid.y
@@ -1586,7 +1598,7 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     }
     const DeviceModel dm = to_device_model(m);
     const unsigned qb = (unsigned)((n + 3) / 4);
-#define KGE_Q(MID) case MID: hipLaunchKernelGGL((k_eval_queries<MID>), dim3((MID == KGE_TRANSE || MID == KGE_TRANSH || MID == KGE_TRANSD || MID == KGE_TRANSM) ? qb : (unsigned)n), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale); break;
+#define KGE_Q(MID) case MID: hipLaunchKernelGGL((k_eval_queries<MID>), dim3((MID == KGE_TRANSE || MID == KGE_TRANSH || MID == KGE_TRANSD || MID == KGE_TRANSM) ? qb : (unsigned)n), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale, side); break;
     switch (m->model) {
         KGE_Q(KGE_TRANSE) KGE_Q(KGE_TRANSH) KGE_Q(KGE_TRANSD) KGE_Q(KGE_ROTATE) KGE_Q(KGE_DISTMULT)
         KGE_Q(KGE_COMPLEX) KGE_Q(KGE_ANALOGY) KGE_Q(KGE_RESCAL)
@@ -1661,9 +1673,9 @@ int launch_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, i
         const DeviceModel dm = to_device_model(m);
         const unsigned qb = (unsigned)((n + 3) / 4);
         if (m->model == KGE_TRANSH)
-            hipLaunchKernelGGL((k_eval_queries<KGE_TRANSH>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale);
+            hipLaunchKernelGGL((k_eval_queries<KGE_TRANSH>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale, 2);
         else
-            hipLaunchKernelGGL((k_eval_queries<KGE_TRANSD>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale);
+            hipLaunchKernelGGL((k_eval_queries<KGE_TRANSD>), dim3(qb), dim3(256), 0, s, dm, triples, n, p.K, p.Kpad, p.QV, p.qvec, p.qscale, 2);
     }
     (void)hipMemsetAsync(p.rcount, 0, (size_t)4 * n * sizeof(int32_t), s);
     if (p.form == F_L1)
@@ -1676,11 +1688,15 @@ int launch_eval_ranks_grouped(const kge_model_desc* m, const int64_t* triples, i
     return check_launch("kge_eval grouped pipeline");
 }
 
-// scores: float [2n, E]: row 2i = tail-sweep energies of triple i, row 2i+1 = head-sweep energies
+// scores: float [2n, E]: row 2i = tail-sweep energies of triple i, row 2i+1 = head-sweep energies (side 2);
+// side 0 / 1: float [n, E], the tail / head sweep only
 int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
-                             float* scores, hipStream_t s) {
-    if (m->model == KGE_NTN) return launch_ntn_eval_scores(m, triples, n, ws, ws_bytes, scores, s);
-    return run_pipeline(m, triples, n, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, nullptr, nullptr, scores, s);
+                             float* scores, hipStream_t s, int side) {
+    if (m->model == KGE_NTN) {
+        if (side != 2) { set_error("kge_eval_sweep_scores_side: the NTN sweep computes both sides per call"); return -1; }
+        return launch_ntn_eval_scores(m, triples, n, ws, ws_bytes, scores, s);
+    }
+    return run_pipeline(m, triples, n, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, nullptr, nullptr, scores, s, side);
 }
 
 }  // namespace kge

@@ -252,7 +252,7 @@ int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n
                       const int32_t* tail_ids, const int64_t* head_off, const int32_t* head_ids, void* ws,
                       size_t ws_bytes, int32_t* ranks, int32_t* ties /* [2, n] or NULL */, hipStream_t s);
 int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
-                             float* scores, hipStream_t s);
+                             float* scores, hipStream_t s, int side = 2);
 
 int launch_rank_from_scores(const float* scores, int64_t nq, int64_t E, const int64_t* truth, const int64_t* off,
                             const int32_t* ids, int32_t* rank, int32_t* frank, hipStream_t s);

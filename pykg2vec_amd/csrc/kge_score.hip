@@ -616,8 +616,9 @@ __global__ __launch_bounds__(kBlock) void k_rotate_bundle_staged(DeviceModel m, 
 // buffered).  Everything derived from the energy (softmax state, weights) is computed redundantly by both waves.  Same
 // mathematics; the energy is the sum of two half-row sums instead of one 64-lane butterfly over the whole row.
 // (Splitting the NEGATIVES over two waves instead keeps all eleven rows per wave: 626 spilled registers at two waves per SIMD.)
+// (waves per SIMD the register budget is sized for: a wave owning 8 chunks of every row needs ~256 registers whatever the split)
 template <int NCH, int SPLIT>
-__global__ __launch_bounds__(kBlock, SPLIT) void k_rotate_bundle_staged_split(DeviceModel m, int64_t n_pos, int neg_rate, float alpha,
+__global__ __launch_bounds__(kBlock, NCH >= 8 ? 2 : SPLIT) void k_rotate_bundle_staged_split(DeviceModel m, int64_t n_pos, int neg_rate, float alpha,
                                                                           float* __restrict__ loss, FusedSampler fs, StageSink sink,
                                                                           float* __restrict__ pair_scale) {
     constexpr int G = 64;
@@ -858,11 +859,21 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
     fs.seed = seed; fs.offset = offset; fs.cursor = cursor;
     const int split_sw = switch_value("ROTATE_SPLIT");
     const int split = split_sw >= 0 ? split_sw : 2;   // A/B switch (0 / 2 / 4); measured 83 / 73 / 79 us at C3
-    if (sink && geo.G == 64 && (split == 2 || split == 4)) {   // rows of more than 512 floats: a bundle's rows over two or four waves
-        int64_t b = (n_pos * split + 3) / 4;
+    // rows of 1025..2048 floats (geometry {64, 32}) exist only as four waves of 512 floats each: every other form would hold
+    // 1024 floats of eleven rows per wave (spills) or, worse, cover only the first 1024 floats of a row
+    const bool wide = geo.G == 64 && geo.NCH == 32;
+    if (wide && !sink) {
+        set_error("kge_train_pairwise_selfadv_sampled: hidden size %d > 1024 needs the staged form (a stage sink); "
+                  "use the explicit-id step (kge_train_pairwise_selfadv)", m->dim);
+        return -1;
+    }
+    if (sink && geo.G == 64 && (wide || split == 2 || split == 4)) {   // rows of more than 512 floats: a bundle's rows over two or four waves
+        const int sp = wide ? 4 : split;
+        int64_t b = (n_pos * sp + 3) / 4;
         if (b > kMaxBlocks) b = kMaxBlocks;
 #define KGE_RS(NCH_, SP_) k_rotate_bundle_staged_split<NCH_, SP_><<<dim3((unsigned)b), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs, *sink, pair_scale)
-        if (geo.NCH == 8 && split == 2) KGE_RS(4, 2);
+        if (wide) KGE_RS(8, 4);
+        else if (geo.NCH == 8 && split == 2) KGE_RS(4, 2);
         else if (geo.NCH == 8) KGE_RS(2, 4);
         else if (split == 2) KGE_RS(8, 2);
         else KGE_RS(4, 4);
@@ -879,6 +890,7 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
     }
     KGE_RB(32, 1) KGE_RB(32, 2) KGE_RB(32, 4) KGE_RB(32, 8) KGE_RB(64, 8) KGE_RB(64, 16)
 #undef KGE_RB
+    set_error("kge_train_pairwise_selfadv_sampled: no kernel for the row geometry {%d, %d} (hidden size %d)", geo.G, geo.NCH, m->dim);
     return -1;
 }
 

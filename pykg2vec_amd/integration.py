@@ -14,14 +14,40 @@ PAIRWISE = ("TransE", "TransH", "TransD", "TransM", "TransR", "RotatE", "Rescal"
 POINTWISE = ("DistMult", "Complex", "ComplexN3", "ANALOGY", "CP", "SimplE", "SimplE_ignr", "QuatE")
 
 
+class _Installed:
+    """Undo handle of `install_models()`: `.restore()` puts the reference's own classes back (idempotent); also a context
+    manager (`with install_models(): ...`)."""
+
+    def __init__(self, saved):
+        self._saved = saved
+
+    def restore(self):
+        for module, name, cls in self._saved:
+            setattr(module, name, cls)
+        self._saved = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.restore()
+        return False
+
+
 def install_models():
+    """Patch the drop-in classes into `pykg2vec.models.pairwise / .pointwise`; returns the undo handle.  A process that only
+    ever wants the HIP models can ignore it; anything that also uses the reference's own classes (the parity tests) restores."""
     import pykg2vec.models.pairwise as ref_pw
     import pykg2vec.models.pointwise as ref_pt
     from . import pairwise as pw, pointwise as pt
-    for name in PAIRWISE:
-        setattr(ref_pw, name, getattr(pw, name))
-    for name in POINTWISE:
-        setattr(ref_pt, name, getattr(pt, name))
+    saved = []
+    for ref_mod, mod, names in ((ref_pw, pw, PAIRWISE), (ref_pt, pt, POINTWISE)):
+        for name in names:
+            ours = getattr(mod, name)
+            if getattr(ref_mod, name) is not ours:     # (a second install must not record our own class as "the original")
+                saved.append((ref_mod, name, getattr(ref_mod, name)))
+            setattr(ref_mod, name, ours)
+    return _Installed(saved)
 
 
 def reference_trainer(backend=None, process_group=None, use_graph=None):

@@ -638,6 +638,21 @@ def eval_sweep_scores(desc, triples, workspace=None):
     return out
 
 
+def eval_sweep_scores_side(desc, triples, side, workspace=None):
+    """float32 [n, E]: side 0 = energies of (h_i, r_i, e) for all e, side 1 = energies of (e, r_i, t_i); the other side's query
+    is never swept (kge_eval_sweep_scores_side).  TransR / NTN compute both sides per call: the full sweep, sliced."""
+    if desc.model in (MODEL_IDS["transr"], MODEL_IDS["ntn"]):
+        return eval_sweep_scores(desc, triples, workspace)[int(side)::2]
+    n = triples.shape[0]
+    if workspace is None:
+        workspace = eval_workspace(desc, n, triples.device)
+    out = torch.empty((n, desc.tot_entity), dtype=torch.float32, device=triples.device)
+    L.check(L.load().kge_eval_sweep_scores_side(ctypes.byref(desc), _ids(triples, "triples"), n, int(side),
+                                                _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
+                                                _dev(out, torch.float32, "scores"), _stream()), "kge_eval_sweep_scores_side")
+    return out
+
+
 def rank_from_scores(scores, truth, off, ids):
     """scores float32 [nq, E] -> (rank, filtered rank) int32 [nq] given the true entity per row and a CSR of knowns."""
     nq, E = scores.shape

@@ -69,20 +69,19 @@ class Model:
 
     # ---- the reference Evaluator's optional hooks (utils/evaluator.py:250-252,263-265): candidate ids by
     # descending energy, shape [1, topk]; served by the sweep kernels instead of forward() over E id tensors.
-    def _sweep(self, h, r, t):
-        """float32 [2, E]: energies of (h, r, e) and of (e, r, t) for every entity e."""
+    def _sweep(self, h, r, t, side):
+        """float32 [E]: energies of (h, r, e) (side 0) or of (e, r, t) (side 1) for every entity e -- ONE sweep (round 5 ran both
+        and threw one away); the id of the swept position is a placeholder the kernel never reads."""
         h0, r0, t0 = h.view(-1)[0], r.view(-1)[0], t.view(-1)[0]
         trip = torch.stack([h0, r0, t0]).view(1, 3).contiguous()
-        return K.eval_sweep_scores(self.make_desc(), trip)
+        return K.eval_sweep_scores_side(self.make_desc(), trip, side)[0]
 
     def predict_tail_rank(self, h, r, topk=-1):
-        scores = self._sweep(h, r, torch.zeros_like(h))[0]
-        _, rank = torch.topk(scores, k=topk)
+        _, rank = torch.topk(self._sweep(h, r, torch.zeros_like(h), 0), k=topk)
         return rank.view(1, -1)
 
     def predict_head_rank(self, t, r, topk=-1):
-        scores = self._sweep(torch.zeros_like(t), r, t)[1]
-        _, rank = torch.topk(scores, k=topk)
+        _, rank = torch.topk(self._sweep(torch.zeros_like(t), r, t, 1), k=topk)
         return rank.view(1, -1)
 
 

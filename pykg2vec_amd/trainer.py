@@ -170,9 +170,13 @@ class Trainer:
         group = 32 if self.model.hidden_size <= 256 else 64
         return 1 <= int(self.config.neg_rate) <= group
 
-    def _fused_rotate_ok(self):
-        """RotatE self-adversarial step with the sampler fused in (negatives of a positive must fit one lane group)."""
+    def _fused_rotate_ok(self, staged=False):
+        """RotatE self-adversarial step with the sampler fused in (negatives of a positive must fit one lane group).  Rows of
+        more than 1024 floats exist only in the staged form (four waves per bundle, csrc/kge_score.hip); the atomic form of
+        such a model takes the stand-alone sampler + the explicit-id bundle kernel."""
         if not (self.K is K and self.model.model_name.lower() == "rotate" and self.model.kernel_name == "rotate"):
+            return False
+        if self.model.hidden_size > 1024 and not staged:
             return False
         group = 32 if self.model.hidden_size <= 256 else 64
         return int(self.config.neg_rate) <= group
@@ -625,7 +629,7 @@ class Trainer:
         from .generator import StagedIndex
         if not (self.K is K and not self.distributed and self.generator is not None):
             return False
-        if not (self._fused_rotate_ok() or (self._fused_pointwise_ok() and self.model.kernel_name in ("distmult", "complex"))):
+        if not (self._fused_rotate_ok(staged=True) or (self._fused_pointwise_ok() and self.model.kernel_name in ("distmult", "complex"))):
             return False
         dims = {p.weight.shape[1] for p in self.model.parameter_list}
         if len(dims) != 1 or self.model.hidden_size % 4 or self.model.hidden_size > 2048:

@@ -199,6 +199,46 @@ def test_no_ties_reported_for_an_unsaturated_model(hip):
 
 
 @pytest.mark.parametrize("name", EVAL_CASES)
+def test_one_sided_sweeps_and_rank_hooks(hip, name):
+    """kge_eval_sweep_scores_side (what the predict_tail_rank / predict_head_rank hooks of utils/evaluator.py:250-252,263-265 call):
+    bit-identical to the corresponding rows of the two-sided sweep, whatever sits in the column the side does not read; the hooks
+    return the ids in ascending-energy order of that row."""
+    from pykg2vec_amd import kernels as K
+    c = Case(name)
+    m = hip.model_from_case(c, "adam.final.")
+    if c.model == "rescal":
+        m.normalize_tables()
+    trips = c.test[:5] if c.model != "transr" else c.test[:1]
+    both = K.eval_sweep_scores(m.make_desc(), hip.dev(trips))
+    junk = trips.copy()
+    junk[:, 2] = (junk[:, 2] + 7) % c.E
+    tail = K.eval_sweep_scores_side(m.make_desc(), hip.dev(junk if c.model not in ("transr", "ntn") else trips), 0)
+    junk = trips.copy()
+    junk[:, 0] = (junk[:, 0] + 3) % c.E
+    head = K.eval_sweep_scores_side(m.make_desc(), hip.dev(junk if c.model not in ("transr", "ntn") else trips), 1)
+    assert torch.equal(tail, both[0::2]) and torch.equal(head, both[1::2])
+    h, r, t = (hip.dev(trips[:1, i]) for i in range(3))
+    ids = m.predict_tail_rank(h, r, topk=c.E)
+    assert ids.shape == (1, c.E)
+    # torch.topk = largest first, exactly what the reference's hook convention returns (models/projection.py:119-125)
+    assert torch.equal(both[0][ids[0]], torch.sort(both[0], descending=True).values)
+    ids = m.predict_head_rank(t, r, topk=c.E)
+    assert torch.equal(both[1][ids[0]], torch.sort(both[1], descending=True).values)
+
+
+def test_one_sided_sweep_on_the_matrix_core_path(hip):
+    """>= 512 query rows: the dot-product forms sweep on k_eval_gemm; one-sided, the 600 wanted rows alone fill the tiles."""
+    from pykg2vec_amd import kernels as K
+    c = Case("complex")
+    m = hip.model_from_case(c, "adam.final.")
+    rng = np.random.default_rng(0)
+    trips = np.stack([rng.integers(c.E, size=600), rng.integers(c.R, size=600), rng.integers(c.E, size=600)], 1)
+    both = K.eval_sweep_scores(m.make_desc(), hip.dev(trips))
+    for side in (0, 1):
+        assert torch.equal(K.eval_sweep_scores_side(m.make_desc(), hip.dev(trips), side), both[side::2])
+
+
+@pytest.mark.parametrize("name", EVAL_CASES)
 def test_eval_sweep_scores_and_ranks_match_reference(hip, name):
     from pykg2vec_amd import kernels as K
     from pykg2vec_amd.evaluator import Evaluator

@@ -83,13 +83,18 @@ def test_staged_training_is_bit_reproducible(hip, monkeypatch):
         assert torch.equal(out[0][1][k], out[1][1][k]), k
 
 
-def test_staged_gradient_matches_oracle(hip, monkeypatch):
-    """One SGD step with lr = 1 turns the staged path into its own gradient: p_before - p_after must be the oracle's dense
-    gradient of the batch the sampler drew (kge_sample_batch with the same counters)."""
+@pytest.mark.parametrize("D,staged", [(64, True), (1200, True), (2048, True), (1028, True),
+                                      (1200, False)])   # rows beyond 1 024 floats: the staged form over four waves per bundle; without the
+                                                        # stage sink the epoch takes the stand-alone sampler + the explicit-id bundle kernel
+def test_staged_gradient_matches_oracle(hip, monkeypatch, D, staged):
+    """One SGD step with lr = 1 turns the epoch's step path into its own gradient: p_before - p_after must be the oracle's dense
+    gradient of the batch the sampler drew (kge_sample_batch with the same counters).  D > 1 024 is the round-5 advisor case:
+    Trainer.step_next_batches (what train_model_epoch runs) on the sampled and the staged path, every element of a row covered."""
     from pykg2vec_amd import kernels as K
-    E, R, D, B, neg = 300, 11, 64, 128, 8
+    E, R, B, neg = 300, 11, 128, 8
     world = _world(E, R, D, B)
-    tr, m = _trainer(hip, world, E, R, D, B, neg, "sgd", True, monkeypatch, lr=1.0)
+    tr, m = _trainer(hip, world, E, R, D, B, neg, "sgd", staged, monkeypatch, lr=1.0)
+    assert tr._fused_rotate_ok() == (D <= 1024)
     before = {k[:-len(".weight")]: p.detach().cpu().numpy().copy() for k, p in hip.table_parameters(m)}
     gen = tr.generator
     ph, pr, pt, nh, nr, nt = [x.cpu().numpy() for x in
@@ -101,6 +106,20 @@ def test_staged_gradient_matches_oracle(hip, monkeypatch):
     for k in before:
         got = before[k] - after[k + ".weight"].cpu().numpy()
         assert np.allclose(got, grads[k], atol=2e-6, rtol=2e-4), (k, np.abs(got - grads[k]).max())
+        if D > 1024:     # the columns past 1 024 carry gradient too (they were silently dropped before round 6)
+            assert np.abs(grads[k][:, 1024:]).max() > 0 and np.abs(got[:, 1024:]).max() > 0, k
+
+
+def test_sampled_rotate_refuses_wide_rows_without_a_sink(hip, monkeypatch):
+    """The fused-sampler entry point without a stage sink has no kernel for rows of more than 1 024 floats: loud, not partial."""
+    from pykg2vec_amd import kernels as K
+    from pykg2vec_amd._lib import KgeHipError
+    E, R, D, B, neg = 300, 11, 1200, 64, 4
+    tr, m = _trainer(hip, _world(E, R, D, B), E, R, D, B, neg, "sgd", False, monkeypatch)
+    gen = tr.generator
+    with pytest.raises(KgeHipError, match="1024"):
+        K.train_pairwise_selfadv_sampled(tr._desc, gen.triples, gen.perm, 0, B, neg, 0.5, gen.bern, gen.slots, gen.seed, 0,
+                                         tr.loss_buf)
 
 
 def _pw_trainer(hip, model, world, E, R, D, B, neg, opt, staged, monkeypatch, lr=0.01):

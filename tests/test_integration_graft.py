@@ -51,8 +51,39 @@ def _config(tmp, c, model_name, **extra):
     return Config(**kw)
 
 
+@pytest.fixture
+def installed_models():
+    """The drop-in classes patched into the reference's model modules for ONE test: the reference's own classes are put back
+    whatever the test does (round 5 left them patched: tests importing the reference after this file then built HIP models)."""
+    ref_shim.install()
+    from pykg2vec_amd import integration
+    import pykg2vec.models.pairwise as ref_pw
+    original = ref_pw.TransE
+    handle = integration.install_models()
+    try:
+        yield handle
+    finally:
+        handle.restore()
+        assert ref_pw.TransE is original and ref_pw.TransE.__module__ == "pykg2vec.models.pairwise"
+
+
+def test_install_models_is_undone_by_its_handle():
+    ref_shim.install()
+    from pykg2vec_amd import integration
+    import pykg2vec.models.pairwise as ref_pw
+    import pykg2vec.models.pointwise as ref_pt
+    before = {(m, n): getattr(m, n) for m, names in ((ref_pw, integration.PAIRWISE), (ref_pt, integration.POINTWISE)) for n in names}
+    with integration.install_models():
+        assert ref_pw.TransE.__module__ == "pykg2vec_amd.pairwise" and ref_pt.Complex.__module__ == "pykg2vec_amd.pointwise"
+        with integration.install_models():          # nested / repeated installs keep the ORIGINAL classes on record
+            pass
+        assert ref_pw.TransE.__module__ == "pykg2vec_amd.pairwise"
+    for (m, n), cls in before.items():
+        assert getattr(m, n) is cls, n
+
+
 @pytest.mark.parametrize("case,model_name", [("transe_l1", "TransE"), ("distmult", "DistMult")])
-def test_reference_trainer_drives_the_drop_in_path(tmp_path, case, model_name):
+def test_reference_trainer_drives_the_drop_in_path(tmp_path, case, model_name, installed_models):
     ref_shim.install()
     import oracle_backend
     from golden_util import Case
@@ -62,7 +93,6 @@ def test_reference_trainer_drives_the_drop_in_path(tmp_path, case, model_name):
     import pykg2vec_amd.evaluator as hip_ev
     import pykg2vec_amd.generator as hip_gen
 
-    integration.install_models()
     c = Case(case)
     cfg = _config(tmp_path, c, model_name)
     _, model_def = Importer().import_model_config(model_name.lower())   # the reference's own discovery finds OUR class
