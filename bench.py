@@ -56,6 +56,7 @@ VALU_PEAK_CLOCK_HZ = 2.4e9
 L1_SWEEP_CYCLES_PER_ELEMENT_PER_WAVE = 4.0              # 2 plain VALU issues x 2 cycles each per element per wave64
 L1_SWEEP_ISSUES_PER_ELEMENT = 2.0
 L1_SWEEP_MICROBENCH_TELEMS = 32.9                       # register-resident ceiling of the same mix (tools/valu_bench.hip)
+REPEATS = 7                                             # timed regions per run (train) / timed passes (eval): the MEDIAN is reported
 MIN_WARM_SECONDS = 0.05                                 # warm until >= 50 ms of GPU work has run, whatever --warmup says
 # marker tags of the counter child (kge_debug_marker: grid.x = 64 x tag); a segment runs from its tag to the next marker
 PMC_TAGS = {"C1_train": 101, "C1_eval": 102, "C1_small": 103, "C2_train": 111, "C2_eval": 112, "C3_train": 121, "C3_eval": 122,
@@ -613,6 +614,35 @@ def run_headline_steps(H, n, events=None):
         n -= k
 
 
+def rccl_setup_summary():
+    """What RCCL reported when it built this process's communicator (the NCCL_DEBUG=INFO / INIT file main() asked for): channel
+    count, transports, connected topologies, and -- only with KGE_BENCH_RCCL_TUNING=1 -- the algorithm / protocol it chose per
+    collective size.  Best effort: None when there is no log (gloo, user-set NCCL_DEBUG) or nothing recognisable in it."""
+    import re
+    try:
+        path = "/tmp/kge_rccl_%d.log" % os.getpid()
+        if not os.path.exists(path):
+            return None
+        txt = open(path, errors="replace").read()
+        chans = [int(m) for m in re.findall(r"Channel (\d+)/\d+ :", txt)]
+        nchan = re.findall(r"(\d+) coll channels", txt)
+        out = {"version": (re.findall(r"(?:RCCL|NCCL) version ([^\s]+)", txt) or [None])[0],
+               "channels": (int(nchan[-1]) if nchan else (max(chans) + 1 if chans else None)),
+               "transports": sorted(set(re.findall(r"via (P2P/[A-Za-z/]+|SHM[A-Za-z/]*|NET/[A-Za-z]+|direct)", txt))) or None,
+               "connected": sorted(set(m.lower() for m in re.findall(r"Connected all (rings|trees)", txt))) or None}
+        choice = re.findall(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)", txt)
+        if choice:
+            algo = {"0": "tree", "1": "ring", "2": "collnet_direct", "3": "collnet_chain", "4": "nvls", "5": "nvls_tree"}
+            proto = {"0": "LL", "1": "LL128", "2": "simple"}
+            seen = {}
+            for coll, nbytes, a, pr in choice:
+                seen["%s %s B" % (coll, nbytes)] = "%s/%s" % (algo.get(a, a), proto.get(pr, pr))
+            out["chosen"] = dict(list(seen.items())[:8])
+        return out if any(v is not None for v in out.values()) else None
+    except Exception as e:   # never let log parsing take the line down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def predicted_step_us(world, allreduce):
     """DESIGN.md section 5b/5d's arithmetic for the C1 step at N ranks (nothing measured: 61 GB/s per xGMI link and direction, one link per
     peer, collective latency 10 / 15 / 25 us at N = 2 / 4 / 8), so that the first real `phases_us` is judged against a stated model."""
@@ -652,17 +682,22 @@ def compact_line(out, detail_path=None):
     line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                     "scaling", "vs_baseline", "dtype", "data")}
     line["value"], line["ms_per_step"] = _r(line["value"], 7), _r(line["ms_per_step"], 6)
+    line["repeats"] = out.get("repeats")
+    line["ms_per_step_min"], line["ms_per_step_max"] = _r(out.get("ms_per_step_min"), 5), _r(out.get("ms_per_step_max"), 5)
+    line["timed_region_s"] = None if out.get("timed_region_s") is None else round(out["timed_region_s"], 7)
     line["config"] = {"workload": _short(cfgd.get("workload"), 150), "batch_per_gpu": cfgd.get("batch_per_gpu"),
                       "global_batch": cfgd.get("global_batch"), "parallelism": cfgd.get("parallelism"),
                       "step_path": _short(cfgd.get("step_path_short") or cfgd.get("step_path"), 110)}
     line["roofline"] = {"kernel": _short(ro.get("kernel_short") or ro.get("kernel"), 90), "bound": ro.get("bound"),
                         "achieved": _r(ro.get("achieved")), "peak": ro.get("peak"), "unit": ro.get("unit"), "frac": _r(ro.get("frac"), 4),
                         "traffic": _r(ro.get("traffic"), 6), "traffic_src": ro.get("traffic_src_short"),
+                        "frac_roof": _short(ro.get("frac_roof"), 60), "algorithmic_frac": _r(ro.get("algorithmic_frac"), 4),
                         "avg_launch_ms": _r(ro.get("avg_launch_ms")), "nominal_frac": _r(ro.get("nominal_frac"), 4),
                         "hbm_frac": _r(ro.get("hbm_frac"), 4), "valu_frac": _r(ro.get("valu_frac"), 4),
                         "bound_note": _short(ro.get("bound_note"), 160)}
     er = ev.get("roofline") or {}
     line["eval"] = {"value": _r(ev.get("value"), 7), "unit": ev.get("unit"), "ms_per_pass": _r(ev.get("ms_per_pass")),
+                    "ms_per_pass_min": _r(ev.get("ms_per_pass_min"), 4), "ms_per_pass_max": _r(ev.get("ms_per_pass_max"), 4),
                     "test_triples": ev.get("test_triples_per_gpu"), "setup_ms": _r(ev.get("setup_ms"), 4),
                     "roofline": {"kernel": _short(er.get("kernel_short") or er.get("kernel"), 60), "bound": er.get("bound"),
                                  "achieved": _r(er.get("achieved")), "peak": _r(er.get("peak")), "unit": _short(er.get("unit"), 40),
@@ -715,7 +750,8 @@ def compact_line(out, detail_path=None):
     if out.get("collectives"):
         co = out["collectives"]
         line["collectives"] = {"backend": co.get("backend"), "world_size": co.get("world_size"), "per_step": _short(co.get("per_step"), 120),
-                               "captured": co.get("captured")}
+                               "captured": co.get("captured"), "NCCL_ALGO": co.get("NCCL_ALGO"), "NCCL_PROTO": co.get("NCCL_PROTO"),
+                               "rccl": co.get("rccl")}
     line["detail"] = detail_path
     txt = json.dumps(line, separators=(",", ":"))
     # never exceed the limit: shed optional parts, most expendable first
@@ -781,6 +817,13 @@ def main():
         if share:
             dist.init_process_group("gloo")
         else:
+            # what RCCL set up (channels, transports, rings / trees) is logged once at communicator creation: INIT-only debug
+            # output into a per-process file costs nothing inside the timed region (KGE_BENCH_RCCL_TUNING=1 adds the per-call
+            # algorithm / protocol choice -- a line per collective, which DOES perturb the timing: diagnosis only)
+            if "NCCL_DEBUG" not in os.environ:
+                os.environ["NCCL_DEBUG"] = "INFO"
+                os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,TUNING" if os.environ.get("KGE_BENCH_RCCL_TUNING") == "1" else "INIT"
+                os.environ["NCCL_DEBUG_FILE"] = "/tmp/kge_rccl_%p.log"
             dist.init_process_group("nccl", device_id=torch.device(device))
 
     import pykg2vec_amd.pairwise as pw
@@ -840,22 +883,29 @@ def main():
         warm_extra += 16
         torch.cuda.synchronize()
 
-    # ---- the timed region: EXACTLY --steps steps between barrier + synchronize on both sides
-    reset_model()
+    # ---- the timed region: EXACTLY --steps steps between barrier + synchronize on both sides.  A region of 20 steps is 0.6 ms: one
+    # sample of it moves by 5-9 % with the box's clock state, so the region is run REPEATS times (tables reset in between, each one
+    # bracketed and MAX-reduced over ranks on its own) and the MEDIAN region is what the line reports; min / max go next to it
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    ev_t0, ev_t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev_t0.record()
-    run_steps(args.steps, events)
-    ev_t1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    region_ms_per_step = ev_t0.elapsed_time(ev_t1) / args.steps   # HIP events on the launch stream around the timed steps
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    regions = []
+    for _rep in range(REPEATS):
+        reset_model()
+        barrier()
+        ev_t0, ev_t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev_t0.record()
+        run_steps(args.steps, events)
+        ev_t1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regions.append((float(t.item()), ev_t0.elapsed_time(ev_t1) / args.steps))
+    by_wall = sorted(regions)
+    dt, region_ms_per_step = by_wall[len(by_wall) // 2]   # the median region: its wall clock and its HIP-event time per step
+    region_spread = {"repeats": REPEATS, "ms_per_step_min": by_wall[0][0] / args.steps * 1e3, "ms_per_step_max": by_wall[-1][0] / args.steps * 1e3,
+                     "ms_per_step_all": [r[0] / args.steps * 1e3 for r in regions]}
     # ---- N > 1: where a step's time goes.  A separate, untimed pass of 16 steps with an event at every phase boundary of the
     # data-parallel step (Trainer._mark): compute (the owner-computes kernel writing this rank's dense gradient rows, next batch's
     # sampler riding along) / reduce-scatter / optimiser on the rank's shard / all-gather of the updated tables / row norms of the
@@ -962,22 +1012,23 @@ def main():
         eval_setup[label] = ev_w.setup_stats["csr_ms"]
         eval_setup[label + "_queries"] = len(qs)
     del ev_w
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    reps = 3
-    for _ in range(reps):
+    passes = []
+    for _rep in range(REPEATS):      # one pass per timed region, as for the train leg: median over REPEATS
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
         ranks = ev.rank_all(my_test, n_eval)
-    e1.record()
-    barrier()
-    edt = (time.perf_counter() - t0) / reps
-    te = torch.tensor([edt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-    edt = float(te.item())
+        e1.record()
+        barrier()
+        te = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        passes.append((float(te.item()), e0.elapsed_time(e1)))
+    by_wall_e = sorted(passes)
+    edt, eval_kern_ms = by_wall_e[len(by_wall_e) // 2]
+    eval_spread = {"repeats": REPEATS, "ms_per_pass_min": by_wall_e[0][0] * 1e3, "ms_per_pass_max": by_wall_e[-1][0] * 1e3}
     eval_value = n_eval * world / edt
-    eval_kern_ms = e0.elapsed_time(e1) / reps
     eval_elements = 2.0 * n_eval * E * DIM                       # (query, candidate, k) elements per pass
     eval_elem_rate = eval_elements / (eval_kern_ms * 1e-3)
     valu_peak_elems = VALU_SIMDS * 64.0 / L1_SWEEP_CYCLES_PER_ELEMENT_PER_WAVE * VALU_PEAK_CLOCK_HZ
@@ -1074,7 +1125,11 @@ def main():
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
             "value": value, "unit": "scored triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "repeats": REPEATS, "ms_per_step_min": region_spread["ms_per_step_min"],
+            "ms_per_step_max": region_spread["ms_per_step_max"], "timed_region_s": dt, "ms_per_step_all": region_spread["ms_per_step_all"],
+            "timing_note": "the timed region (--steps steps between barrier + synchronize) is run %d times, tables reset in between; "
+                           "value / ms_per_step / timed_region_s are the MEDIAN region's" % REPEATS,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "FB15k-shape TransE d=100 L1 margin=1.0 hinge, neg_rate=1, dense Adam lr=0.01, "
                                    "on-device uniform corruption; E=14951 R=1345 train=483142",
@@ -1110,6 +1165,11 @@ def main():
                          "valu_frac": valu_frac,
                          "bound_note": ("neither roof is reached: counter bytes / time = hbm_frac of 8 TB/s, VALU issue = valu_frac of 1024 SIMDs x 1.2 G "
                                         "wave-instr/s; the launch is bound by the dependent-load chains of its owner groups (DESIGN.md section 4)"),
+                         "frac_roof": ("hbm-counter: bytes at the L2 <-> fabric boundary per launch / avg_launch_ms / 8 TB/s" if traffic
+                                       else "hbm-algorithmic (no counter pass in this run)"),
+                         "algorithmic_frac": nominal / HBM_PEAK_GBS,
+                         "algorithmic_roof": "SURVEY 8(d): 3628 B per scored triple x scored triples per launch / avg_launch_ms / 8 TB/s (can exceed 1: "
+                                             "the owner-computes step does no gradient read-modify-write and its 6.5 MB of tables stay in L2 / Infinity Cache)",
                          "nominal_achieved": nominal, "nominal_frac": nominal / HBM_PEAK_GBS,
                          "nominal_note": ("ALGORITHMIC bytes of SURVEY section 8(d) (forward gathers + gradient read-modify-write + ids per scored "
                                           "triple: 3628 B) / avg_launch_ms.  The owner-computes step performs no gradient read-modify-write and "
@@ -1128,7 +1188,8 @@ def main():
                          "timed_region_event_ms_note": "HIP events around each launch inside the timed region: includes "
                                                        "the dispatch gap in front of the kernel"},
             "eval": {"value": eval_value, "unit": "test triples ranked/s", "test_triples_per_gpu": n_eval,
-                     "ms_per_pass": edt * 1e3, "mean_rank_check": mean_rank,
+                     "ms_per_pass": edt * 1e3, "repeats": REPEATS, "ms_per_pass_min": eval_spread["ms_per_pass_min"],
+                     "ms_per_pass_max": eval_spread["ms_per_pass_max"], "mean_rank_check": mean_rank,
                      "setup_ms": eval_setup.get("csr_ms", max(0.0, eval_first_ms - edt * 1e3)),
                      "setup": dict(eval_setup, first_pass_ms=eval_first_ms,
                                    what="per-query filter lists (hr_t / tr_h of train + valid + test, data/kgcontroller.py:410-428) as CSR on the "
@@ -1203,6 +1264,7 @@ def main():
             out["collectives"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                   "NCCL_ALGO": os.environ.get("NCCL_ALGO", "(unset: RCCL picks)"),
                                   "NCCL_PROTO": os.environ.get("NCCL_PROTO", "(unset)"),
+                                  "rccl": rccl_setup_summary(),
                                   "per_step": ("all_reduce(flat grad, %d B); every rank steps every row (tables <= 32 MB)" % (tr.flat.numel * 4)
                                                if allred else
                                                "reduce_scatter(flat grad, %d B) + all_gather(flat param)" % (tr.flat.numel * 4)),

@@ -32,6 +32,17 @@
 
 namespace kge {
 
+// Summation order of the matrix-core sweep's energies (round 6).  An energy used to be ONE in-order fmaf chain over all of k (what
+// back-to-back MFMAs on one accumulator compute): its rounding error grows like K u sigma / sqrt(2), ~15x the error of ATen's blocked
+// reduction at K = 400, and on the 512-triple C2 fixture float64 sided with the reference on every rank the HIP path differed in.
+// With KGE_GEMM_CHUNK = C > 0 the chain restarts every C elements of k and the finished chunk is added to a running total
+// (`tot += acc; acc = 0`: two accumulator sets on the matrix cores whatever the chunk count).  Emulated on the host
+// (tools/rank_chain_study.py -> profiles/r06_rank_chain_study.json): 6 -> 0..1 differing ranks of 1 024 at C2, energy error 3x
+// smaller.  k_eval_target_filter_chain follows the same chunk boundaries, so ranks stay exact functions of bit-identical energies.
+#ifndef KGE_GEMM_CHUNK
+#define KGE_GEMM_CHUNK 64
+#endif
+constexpr int kGemmChunk = KGE_GEMM_CHUNK;   // 0 = one chain over all of k (rounds 2-5); else a multiple of the K slab
 constexpr int KC = 8;        // k-chunk held in VGPRs
 constexpr int QT_PLAIN = 16; // queries per wave pass, plain forms
 constexpr int QT_XF = 8;     // ... candidate-transform forms (TransH / TransD)
@@ -777,7 +788,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_target_filter_chain(PrepArgs a,
         const int idx = base + lane;
         int e = truth;
         if (lane < pg && idx > 0) e = ids[b + idx - 1];
-        float acc = 0.f;
+        float acc = 0.f, tot = 0.f;   // tot: the finished chunks of kGemmChunk elements (see KGE_GEMM_CHUNK)
         const int total = pg << lc;
         // a chunk's operands travel global -> registers -> LDS; the NEXT chunk's loads are issued before this chunk's chains
         // run, so their round trip hides behind the (sequential) arithmetic
@@ -835,16 +846,21 @@ __global__ __launch_bounds__(256, 4) void k_eval_target_filter_chain(PrepArgs a,
                         acc = fmaf(c4[u].x, q4[u].x, acc); acc = fmaf(c4[u].y, q4[u].y, acc);
                         acc = fmaf(c4[u].z, q4[u].z, acc); acc = fmaf(c4[u].w, q4[u].w, acc);
                     }
+                    if (kGemmChunk && ((k0 + kk + 16) % (kGemmChunk ? kGemmChunk : 1)) == 0) { tot += acc; acc = 0.f; }
                 }
                 for (; kk < nk; kk += 8) {
                     const float4 c0 = *reinterpret_cast<const float4*>(cr + kk), c1 = *reinterpret_cast<const float4*>(cr + kk + 4);
                     const float4 q0 = *reinterpret_cast<const float4*>(sq + kk), q1 = *reinterpret_cast<const float4*>(sq + kk + 4);
                     acc = fmaf(c0.x, q0.x, acc); acc = fmaf(c0.y, q0.y, acc); acc = fmaf(c0.z, q0.z, acc); acc = fmaf(c0.w, q0.w, acc);
                     acc = fmaf(c1.x, q1.x, acc); acc = fmaf(c1.y, q1.y, acc); acc = fmaf(c1.z, q1.z, acc); acc = fmaf(c1.w, q1.w, acc);
+                    if (kGemmChunk && ((k0 + kk + 8) % (kGemmChunk ? kGemmChunk : 1)) == 0) { tot += acc; acc = 0.f; }
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
+        // the last chunk (k_eval_gemm folds after its last K slab whatever the slab count; elements past Kpad are zeros there: the
+        // chain passes them unchanged).  A chunk that ended exactly at Kpad left acc = +0: tot + 0 = tot.
+        if (kGemmChunk) acc = tot + acc;
         // squared distance through the expansion |q|^2 + |c|^2 - 2 <q, c> the matrix-core sweep uses (aux[e] = |c|^2): same
         // stored norms, same operation order => same bits as k_eval_gemm
         if constexpr (FORM == F_SQM) acc = sqm_from_dot(acc, qn, lane < pg ? aux[e] : 0.f);
@@ -1107,6 +1123,10 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GT = 128;      // tile edge (queries and candidates) per workgroup
 constexpr int GKS = 16;      // K slab
+static_assert(kGemmChunk % GKS == 0, "the running total is folded at K slab boundaries");
+#if defined(KGE_GEMM_32X32) && KGE_GEMM_CHUNK
+#error "the 32x32x2 experiment form of k_eval_gemm keeps the single chain: build it with -DKGE_GEMM_CHUNK=0"
+#endif
 // MFMA form of the sweep: v_mfma_f32_16x16x4_f32 (default) or v_mfma_f32_32x32x2_f32 (-DKGE_GEMM_32X32, the round-2 form).  Both run
 // at the same peak; the 16x16x4 form has a 40-cycle dependent latency instead of 64 and holds its issue rate with four waves per
 // SIMD (tools/mfma_bench.hip: 154 vs 129 TF), which is how this kernel runs (3-4 workgroups per CU).
@@ -1146,8 +1166,12 @@ __global__ __launch_bounds__(256) void k_eval_qnorm(const float* __restrict__ qv
 }
 
 // (four workgroups per CU for the dot form; the squared-distance epilogue needs ~20 more registers: three per CU, no spills)
+// (with the running totals of KGE_GEMM_CHUNK: 64 more registers per lane, two workgroups per CU)
 template <bool WRITE, int POST, bool SQM>
-__global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __restrict__ cand, const float* __restrict__ qT,
+#ifndef KGE_GEMM_OCC
+#define KGE_GEMM_OCC (kGemmChunk > 0 ? 2 : SQM ? 3 : 4)
+#endif
+__global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __restrict__ cand, const float* __restrict__ qT,
                                                    const float* __restrict__ st, int64_t nq, int64_t E, int64_t ntiles64,
                                                    int Kpad, int qtiles, int S, int32_t* __restrict__ rcount,
                                                    int32_t* __restrict__ tcount, float* __restrict__ scores_out, const float* __restrict__ qn,
@@ -1307,10 +1331,11 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
 #else
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 acc[4][4];   // 64 x 64 sub-tile of the wave as 4 x 4 blocks of 16 x 16: candidate rows mi, query columns ni
+    f32x4 tot[4][4];   // KGE_GEMM_CHUNK: the finished chunks of every energy
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < 4; ++ni) { acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     if (nsteps > 0) load_step();
     int buf = 0;
     for (int64_t g = 0; g < nsteps; ++g) {
@@ -1333,6 +1358,10 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
         nb[0] = vb.x; nb[1] = vb.y; nb[2] = vb.z; nb[3] = vb.w;                                                            \
     }
         KGE_GEMM_READ(0)
+        // KGE_GEMM_CHUNK: does this slab begin / complete a chunk of k (the last slab of a tile completes one whatever its index)?
+        constexpr int SPC = kGemmChunk > 0 ? kGemmChunk / GKS : 1;   // slabs per chunk
+        const bool c_first = kGemmChunk > 0 && cu_sl % SPC == 0;
+        const bool c_last = kGemmChunk > 0 && ((cu_sl + 1) % SPC == 0 || cu_sl + 1 == nslab);
 #pragma unroll
         for (int kk = 0; kk < GKS; kk += 4) {
             float a4[4], b4[4];
@@ -1340,12 +1369,27 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
             for (int i = 0; i < 4; ++i) { a4[i] = na[i]; b4[i] = nb[i]; }
             if (kk + 4 < GKS) KGE_GEMM_READ(kk + 4)
             KGE_KEEP_READS_AHEAD();
+            if (kGemmChunk > 0 && kk == 0 && c_first) {
+                // a chunk's chain starts from the constant 0 (the C operand of the MFMA): the accumulators are never cleared
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi], b4[ni], zero, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi], b4[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+        if (c_last) {   // the chunk is complete: its chains join the running totals (32 packed adds per lane)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi], b4[ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < 4; ++ni) tot[mi][ni] += acc[mi][ni];
         }
-        buf ^= 1;
         if (++cu_sl != nslab) continue;
         cu_sl = 0;
         // ---- last slab of a candidate tile: epilogue.  energy = -dot (+ post-op); the lane owns query column (ni, lcol), its 4
@@ -1366,7 +1410,7 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
                 if constexpr (SQM) cn2 = e < e_pad ? cn[e] : 0.f;
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    const float sc = energy(acc[mi][ni][reg], ni, cn2);
+                    const float sc = energy(kGemmChunk > 0 ? tot[mi][ni][reg] : acc[mi][ni][reg], ni, cn2);
                     if constexpr (WRITE) {
                         const int64_t q = (int64_t)qt * GT + qcol(ni);
                         if (q < nq && e < e_lim) scores_out[q * E + e] = sc;
@@ -1379,7 +1423,10 @@ __global__ __launch_bounds__(256, SQM ? 3 : 4) void k_eval_gemm(const float* __r
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ni = 0; ni < 4; ++ni) {
+                if constexpr (kGemmChunk > 0) tot[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};   // (acc restarts from the constant 0)
+                else acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
     }
     if constexpr (!WRITE) {
 #pragma unroll
@@ -1504,7 +1551,7 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
             const int64_t ctiles = (p.ntiles + 1) / 2;
             // candidate-tile splits: fill the 4 x 256 resident workgroup slots WITHOUT spilling into a second, mostly empty
             // generation (1029 workgroups on 1024 slots cost 25 % more than 980)
-            int64_t S2 = ((SQM ? 3 : 4) * 256) / qtiles;
+            int64_t S2 = ((KGE_GEMM_OCC) * 256) / qtiles;
             if (S2 > ctiles) S2 = ctiles;
             if (S2 < 1) S2 = 1;
             hipLaunchKernelGGL(k_eval_qt, dim3((unsigned)(qtiles * 2), (unsigned)((p.Kpad + 63) / 64)), dim3(256), 0, s, p.qvec, nq,

@@ -7,24 +7,7 @@ training form: head + one direction of Criterion.multi_class_bce + backward with
 import torch
 
 from . import kernels as K
-
-
-class _OneToN(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, ent, bias, precision="f32"):
-        x, ent = x.contiguous(), ent.contiguous()
-        b = None if bias is None else bias.contiguous().view(-1)
-        preds = K.head_1n_forward(x, ent, b, precision=precision)
-        ctx.save_for_backward(x, ent, preds)
-        ctx.has_bias = bias is not None
-        ctx.bias_shape = None if bias is None else bias.shape
-        return preds
-
-    @staticmethod
-    def backward(ctx, dpreds):
-        x, ent, preds = ctx.saved_tensors
-        dx, g_ent, g_bias = K.head_1n_backward(x, ent, preds, dpreds.contiguous(), need_bias=ctx.has_bias)
-        return dx, g_ent, (g_bias.view(ctx.bias_shape) if ctx.has_bias else None), None
+from . import ops  # noqa: F401  (registers torch.ops.kge.*)
 
 
 def one_to_n_scores(x, ent_weight, bias=None, precision="f32"):
@@ -32,7 +15,9 @@ def one_to_n_scores(x, ent_weight, bias=None, precision="f32"):
     precision="bf16": the forward GEMM with bfloat16-rounded operands and fp32 accumulation (v_mfma_f32_32x32x16_bf16; the [B, E]
     output write then bounds it instead of the f32 matrix cores) -- for scoring all entities at evaluation time or where the
     model tolerates it; the backward GEMMs stay fp32 and use the saved predictions.  Default "f32" = the reference's arithmetic."""
-    return _OneToN.apply(x, ent_weight, bias, precision)
+    if precision not in ("f32", "bf16"):
+        raise ValueError("precision must be 'f32' or 'bf16'")
+    return torch.ops.kge.one_to_n_scores(x, ent_weight, bias, precision == "bf16")
 
 
 def multi_class_bce_step(x, ent_weight, bias, label_off, label_ids, label_smoothing, loss_buf, g_ent, g_bias=None):

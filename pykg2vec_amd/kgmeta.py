@@ -1,9 +1,10 @@
 """Model base classes mirroring pykg2vec/models/KGMeta.py:14-80 and models/Domain.py:8-17, with `forward`
-routed to the HIP scorer through a torch.autograd.Function (dense gradients, like nn.Embedding(sparse=False))."""
+routed to the HIP scorer through the custom op `kge::score` (ops.py; dense gradients, like nn.Embedding(sparse=False))."""
 import torch
 import torch.nn as nn
 
 from . import kernels as K
+from . import ops
 from .common import TrainingStrategy
 
 
@@ -17,26 +18,6 @@ class NamedEmbedding(nn.Embedding):
     @property
     def name(self):
         return self._name
-
-
-class _HipScore(torch.autograd.Function):
-    """scores = Model.forward(h, r, t) on the HIP scorer; backward scatters dense table gradients."""
-
-    @staticmethod
-    def forward(ctx, model, h, r, t, *weights):
-        h, r, t = h.contiguous(), r.contiguous(), t.contiguous()
-        desc = model.make_desc(weights)
-        ctx.model = model
-        ctx.save_for_backward(h, r, t, *weights)
-        return K.score_forward(desc, h, r, t)
-
-    @staticmethod
-    def backward(ctx, dscore):
-        h, r, t, *weights = ctx.saved_tensors
-        grads = [torch.zeros_like(w) for w in weights]
-        desc = ctx.model.make_desc(weights, grads)
-        K.score_backward(desc, h, r, t, dscore.contiguous())
-        return (None, None, None, None) + tuple(grads)
 
 
 class Model:
@@ -65,7 +46,9 @@ class Model:
                            tot_entity=self.tot_entity, tot_relation=self.tot_relation, **self.desc_kwargs())
 
     def forward(self, h, r, t):
-        return _HipScore.apply(self, h, r, t, *[p.weight for p in self.parameter_list])
+        """Energies of the triples (h, r, t) through the dispatcher-registered op `kge::score` (ops.py): differentiable w.r.t. the
+        tables (dense gradients, like nn.Embedding(sparse=False)), visible to torch.ops / torch.compile."""
+        return torch.ops.kge.score(ops.register_model(self), h, r, t, [p.weight for p in self.parameter_list])
 
     # ---- the reference Evaluator's optional hooks (utils/evaluator.py:250-252,263-265): candidate ids by
     # descending energy, shape [1, topk]; served by the sweep kernels instead of forward() over E id tensors.

@@ -177,6 +177,37 @@ DEFAULT_STEP = {
 GENERATOR_SEED = 0
 
 
+# ---- TRAINED tables at the BASELINE sizes (round 6).  Every full-size rank fixture of rounds 4-5 sits on freshly initialised tables,
+# where near-ties are densest.  Tables that have been trained cannot be committed (65 / 116 MB at C2 / C3) and the reference cannot
+# train on the GPU box, so they are DEFINED as what the drop-in Trainer's default step path -- bit-reproducible on every one of these
+# configs -- leaves after `epochs` epochs over the whole synthetic train split from the seeded initial tables: produced once on the GPU
+# (tools/make_trained_tables.py), ranked by the live reference in the build container (oracle/make_golden_trained.py), re-produced by
+# the GPU test and recognised by their SHA-256 (tests/test_trained_ranks.py).
+TRAINED = {
+    "c1_transe_l1": dict(B=32768, optimizer="adam", lr=0.01, epochs=30, n_rank=512),
+    "c2_complex": dict(B=5000, optimizer="adagrad", lr=0.1, epochs=60, n_rank=512),
+    "c3_rotate": dict(B=1024, optimizer="adam", lr=0.001, epochs=4, n_rank=512),
+}
+
+
+def trained_queries(name, train, test):
+    """Queries of a TRAINED case: half held-out test triples (ranks spread over the entity set), half TRAINING triples (ranks near the
+    top, where a trained model's real test triples live)."""
+    n = TRAINED[name]["n_rank"]
+    pick = np.random.default_rng(4242).permutation(len(train))[:n // 2]
+    return np.concatenate([test[:n - n // 2], train[pick]])
+
+
+def tables_sha256(tables):
+    """SHA-256 over the float32 bytes of the tables in key order."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(tables):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(tables[k], dtype=np.float32).tobytes())
+    return h.hexdigest()
+
+
 def generator_first_batch(train, batch_size, seed=GENERATOR_SEED):
     """Rows of the train split that form batch 0 of pykg2vec_amd.generator.Generator(seed): one permutation per run
     (data/generator.py:23), the slice ordered by relation id (a batch is a set)."""

@@ -90,3 +90,30 @@ def record_max(report, key, value):
     doc = json.load(open(fn)) if os.path.exists(fn) else {}
     doc[key] = max(float(value), doc.get(key, 0.0))
     json.dump(doc, open(fn, "w"), indent=1, sort_keys=True)
+
+
+def train_fullsize(name):
+    """golden_util.TRAINED[name]: the seeded full-size tables after `epochs` epochs of the drop-in Trainer's default step path over
+    the whole synthetic train split -> (tables {name: float32 array}, model, spec, (train, valid, test)).  Bit-reproducible: the
+    owner-computes / two-phase own / staged steps involve no float atomics and the generator's permutation and Philox counters are
+    functions of (seed, epoch, batch)."""
+    import golden_util as gu
+    from pykg2vec_amd.trainer import Trainer
+    spec, P, train, valid, test, _ids, _batch = gu.fullsize_inputs(name)
+    t = gu.TRAINED[name]
+    hp = dict(spec["hp"])
+    hp.setdefault("margin", 1.0)
+    cfg = make_config(spec["E"], spec["R"], hp, train[:1], valid[:4], test[:4], optimizer=t["optimizer"], lr=t["lr"], batch_size=t["B"])
+    cfg.knowledge_graph.cache.update(triplets_train=train)
+    cfg.seed, cfg.tot_train_triples, cfg.sampling, cfg.epochs = gu.GENERATOR_SEED, len(train), "uniform", t["epochs"]
+    m = model_from_params(spec["model"], P, spec["hp"], spec["E"], spec["R"], train=train)
+    tr = Trainer(m, cfg)
+    tr.build_model()
+    tr.generator = tr._new_generator()
+    losses = [float(tr.train_model_epoch(e)) for e in range(t["epochs"])]
+    tr.sync_model()
+    torch.cuda.synchronize()
+    path = ("hipGraph" if tr._graph is not None else "staged" if getattr(tr, "_staged", None) is not None else
+            "own" if getattr(tr, "_own", None) is not None else "pull" if getattr(tr, "_pull", None) is not None else "eager")
+    tables = {k[:-len(".weight")]: p.detach().cpu().numpy().copy() for k, p in table_parameters(m)}
+    return tables, m, spec, (train, valid, test), dict(path=path, losses=losses)

@@ -69,3 +69,33 @@ def test_multi_gpu_fields_ride_in_the_compact_line():
     d = json.loads(bench.compact_line(full, None))
     assert d["phases_us"]["compute"] == 33.0 and d["replicas_identical"] is True and d["collectives"]["world_size"] == 8
     assert d["predicted_step_us"]["step"] == pytest.approx(33 + 25 + 2 * 6518400 / 8 / 61e3 + 8 + 5, rel=1e-3)
+
+
+def test_rccl_setup_summary_reads_an_init_log(tmp_path, monkeypatch):
+    """bench.rccl_setup_summary on the shape of log RCCL writes at communicator creation (NCCL_DEBUG=INFO, INIT [+ TUNING]); a
+    missing or unrecognisable log gives None, never an exception."""
+    import os
+    log = "/tmp/kge_rccl_%d.log" % os.getpid()
+    if os.path.exists(log):
+        os.remove(log)
+    assert bench.rccl_setup_summary() is None
+    with open(log, "w") as f:
+        f.write("box:1:1 [0] NCCL INFO RCCL version 2.22.3+hip7.0 HEAD:abc\n"
+                "box:1:2 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7\n"
+                "box:1:2 [0] NCCL INFO Channel 15/16 :    0   7   6   5   4   3   2   1\n"
+                "box:1:2 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC\n"
+                "box:1:2 [0] NCCL INFO Connected all rings\nbox:1:2 [0] NCCL INFO Connected all trees\n"
+                "box:1:2 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer\n"
+                "box:1:2 [0] NCCL INFO AllReduce: 6518400 Bytes -> Algo 1 proto 2 time 45.1\n")
+    try:
+        got = bench.rccl_setup_summary()
+    finally:
+        os.remove(log)
+    assert got["version"].startswith("2.22.3") and got["channels"] == 16 and got["transports"] == ["P2P/IPC"]
+    assert got["connected"] == ["rings", "trees"] and got["chosen"] == {"AllReduce 6518400 B": "ring/simple"}
+    with open(log, "w") as f:
+        f.write("nothing recognisable\n")
+    try:
+        assert bench.rccl_setup_summary() is None
+    finally:
+        os.remove(log)

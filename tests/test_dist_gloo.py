@@ -88,6 +88,26 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path, model_name, opt,
     assert np.abs(a["ranks"] - one["ranks"]).max() <= 1
 
 
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("model_name,opt,allreduce", [("transe_l1", "adam", False), ("transe_l1", "adam", None), ("rotate", "sgd", None),
+                                                      ("rescal", "adam", False), ("complex", "adagrad", None)])
+def test_four_and_eight_rank_data_parallel_equals_single_process(tmp_path, world, model_name, opt, allreduce):
+    """The node the north star names has 8 GPUs: the same sharding / exchange / replica-consistency logic at world sizes 4 and 8
+    (a batch of 64 positives leaves 16 / 8 per rank; the flat buffers are padded to a multiple of 4 * world floats)."""
+    out = str(tmp_path)
+    _run(0, 1, 0, model_name, opt, out)
+    mp.spawn(_run, args=(world, _free_port(), model_name, opt, out, None, "", allreduce), nprocs=world, join=True)
+    one = np.load(os.path.join(out, "r0_w1.npz"))
+    reps = [np.load(os.path.join(out, "r%d_w%d.npz" % (r, world))) for r in range(world)]
+    for k in one.files:
+        for b in reps[1:]:
+            assert np.array_equal(reps[0][k], b[k]), "replicas diverged on %s" % k
+        if k not in ("losses", "ranks"):
+            assert np.allclose(reps[0][k], one[k], atol=2e-5, rtol=1e-4), (k, np.abs(reps[0][k] - one[k]).max())
+    assert np.allclose(reps[0]["losses"], one["losses"], rtol=1e-4)
+    assert np.abs(reps[0]["ranks"] - one["ranks"]).max() <= 1
+
+
 @pytest.mark.parametrize("model_name,opt", [("rescal", "adam"), ("rescal", "sgd"), ("rescal", "rms")])
 def test_sparse_row_exchange_equals_the_dense_exchange_bit_for_bit(tmp_path, model_name, opt):
     """Two ranks, gradient rows of the touched entities exchanged as lists (Trainer._sparse_exchange) instead of the dense

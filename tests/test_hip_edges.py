@@ -176,6 +176,35 @@ def test_bench_two_ranks_share_one_gpu():
     assert all(ph[k] > 0 for k in ("compute", "reduce_scatter", "optimiser", "all_gather")), ph
 
 
+@pytest.mark.parametrize("env_extra,label", [({}, "all-reduce"), ({"KGE_DP_ALLREDUCE": "0"}, "sharded"), ({"KGE_PULL": "1"}, "owner-computes")])
+def test_bench_eight_ranks_share_one_gpu(env_extra, label):
+    """The launch the driver makes on an 8-GPU node (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`), rehearsed on ONE
+    GPU: eight processes (gloo, all on device 0) shard the batch and the Philox stream eight ways, exchange the flat gradient, and must
+    end with bit-identical tables; the test split (59 071 triples, not a multiple of 8) is sharded over the ranks for the eval leg; rank
+    0 prints the one JSON line with the per-phase times and the collective description.  Nothing here needs RCCL: what is rehearsed
+    is every line of bench.py's and the Trainer's N = 8 path except the transport."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KGE_BENCH_SHARE_GPU="1", KGE_BENCH_CHECK_REPLICAS="1", **env_extra)
+    port = {"all-reduce": "29531", "sharded": "29533", "owner-computes": "29535"}[label]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--batch", "4096"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8 * 4096 and d["config"]["parallelism"] == "dp8"
+    assert d["value"] > 0 and d["repeats"] >= 7 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert "REPLICAS_IDENTICAL 1" in out.stdout and d["replicas_identical"] is True
+    assert d["collectives"]["world_size"] == 8 and d["collectives"]["backend"] == "gloo"
+    ph = d["phases_us"]
+    assert set(ph) >= {"compute", "reduce_scatter", "optimiser", "all_gather", "row_norms"}, ph
+    assert ph["compute"] > 0 and ph["reduce_scatter"] > 0 and ph["optimiser"] > 0
+    assert (ph["all_gather"] > 0) == (label == "sharded"), ph      # 6.5 MB of tables: one all-reduce unless the sharded step is forced
+    assert d["eval"]["test_triples"] == 59071 // 8 and d["eval"]["value"] > 0 and "cpu_baseline" not in d
+
+
 @pytest.mark.parametrize("model,hp,opt,lr,fmr_drop,mrr_gain", [
     ("transe", dict(hidden_size=32, l1_flag=True, margin=1.0), "adam", 0.01, 0.5, 3.0),
     # a symmetric bilinear model can only partly fit a translation graph: it must still clearly beat chance
