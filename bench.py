@@ -1098,7 +1098,7 @@ def main():
         hop_us = HOP_US_AT_8K_GROUPS + load * (HOP_US_AT_32K_GROUPS - HOP_US_AT_8K_GROUPS)
         hops = 4 if two_phase else 5    # item -> {row, state, lists} -> {records + codes | three hat rows per visit -> ...} -> store drain
         rounds = max(1.0, n_groups / float(resident))
-        stride = K.pull_partial_stride(DIM)
+        stride = K.pull_hat_stride(DIM)
         row_bytes = (E + R) * (6 * DIM * 4 + stride * 4 + 4)        # p, m, v read and written; normalised copy + norm written
         stream_us = row_bytes / 5.0e6                                # at the ~5 TB/s an L2 / Infinity-Cache resident sweep streams (k_opt over the same tables: 7-8 us)
         visits_us = 4.3 if two_phase else None                       # measured with the visits compiled out (profiles/r03_experiments.md section 11)

@@ -409,8 +409,9 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
  * step.  next_pairs != NULL: the sampler of the NEXT batch rides in this step's launch and fills next_lists (a second
  * set), so a steady-state step is one launch (+ a small finishing launch when rows are cut into several items).
  * m->tables = the tables read; tables_out = the other half of the double buffer; hat_in / hat_out: the row-normalised
- * copies x / max(||x||, 1e-12) of the tables read / written (what other owners gather), rows padded with zeros to
- * kge_pull_partial_stride(dim) floats; norm_in / norm_out [E + R]: their
+ * copies x / max(||x||, 1e-12) of the tables read / written (what other owners gather), rows of kge_pull_hat_stride(dim)
+ * floats (round 6: compact, = dim; the padded layout of rounds 2-5, zeros up to kge_pull_partial_stride(dim), behind
+ * KGE_HAT_COMPACT=0); norm_in / norm_out [E + R]: their
  * L2 row norms (kge_row_norms fills both before the first step); state1 / state2: optimiser state per table.
  * dim must be a multiple of 4 (rows move as float4) and at most 1024.  TransM: m->tables[2] = the per-relation weights.
  * partials: kge_pull_partial_stride(dim) floats per slot.
@@ -450,6 +451,7 @@ typedef struct kge_pull_direction {
 } kge_pull_direction;
 int kge_pull_direction_bytes(int32_t dim, int32_t l1, int64_t n_pairs, size_t* codes_bytes, size_t* recs_bytes);
 int kge_pull_partial_stride(int32_t dim);
+int kge_pull_hat_stride(int32_t dim);         /* floats between consecutive rows of the hat tables (kge_row_norms writes, kge_pull_step reads / writes) */
 int kge_pull_groups_per_block(int32_t dim);   /* owner groups per 256-thread workgroup: items are laid out in workgroup slots */
 int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, float* normalised, void* stream);
 int kge_pull_sample(const int32_t* pairs, const int32_t* inv, int64_t n, int64_t tot_entity, const float* bern_prob,

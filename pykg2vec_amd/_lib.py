@@ -207,6 +207,7 @@ _SIGNATURES = {
     "kge_corrupt": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64] + [ctypes.c_void_p] * 3 + [ctypes.c_void_p]),
     "kge_sample_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32] + [ctypes.c_void_p] * 6 + [ctypes.c_void_p, ctypes.c_void_p]),
     "kge_pull_partial_stride": (ctypes.c_int, [ctypes.c_int32]),
+    "kge_pull_hat_stride": (ctypes.c_int, [ctypes.c_int32]),
     "kge_pull_groups_per_block": (ctypes.c_int, [ctypes.c_int32]),
     "kge_row_norms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_pull_sample": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

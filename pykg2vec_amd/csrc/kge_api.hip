@@ -489,6 +489,7 @@ int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* s
 
 /* ---- owner-computes ("pull") training step, kge_pull.hip */
 int kge_pull_partial_stride(int32_t dim) { return pull_partial_stride(dim); }
+int kge_pull_hat_stride(int32_t dim) { return pull_hat_stride(dim); }
 int kge_pull_groups_per_block(int32_t dim) { return pull_groups_per_block(dim); }
 
 int kge_row_norms(const float* table, int64_t rows, int32_t dim, float* norms, float* normalised, void* stream) {

@@ -1499,8 +1499,9 @@ static bool rescal_slab_taken(const kge_model_desc* m, int64_t n, size_t ws_byte
            switch_value("RESCAL_SLAB") != 0;
 }
 bool rescal_stage_ok(const kge_model_desc* m, int64_t n, size_t ws_bytes) {
-    // (the sorted grouping keeps 3 R + 2 n + 2 ints in the 64 KB of LDS a launch gets without opting in)
-    return m->dim % 4 == 0 && n <= kStageMaxN && (3 * m->tot_relation + 2 * n + 2) * (int64_t)sizeof(int) <= 64 * 1024 &&
+    // (the sorted grouping keeps 3 R + 2 n + 2 ints in the 64 KB of LDS a launch gets without opting in -- next to the 8 bytes of
+    // static LDS k_rel_group_small declares (s_carry): at the boundary the launch would fail instead of the step falling back)
+    return m->dim % 4 == 0 && n <= kStageMaxN && (3 * m->tot_relation + 2 * n + 2) * (int64_t)sizeof(int) <= 64 * 1024 - 64 &&
            m->tot_entity < (1ll << 31) && rescal_slab_taken(m, n, ws_bytes);
 }
 

@@ -188,6 +188,7 @@ int launch_optimizer_rownorm(int kind, float* p, float* g, float* s1, float* s2,
 
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);
+int pull_hat_stride(int dim);
 // the staged owner-computes step of the remaining pointwise gather models (kge_ownx.hip)
 bool ownx_model(int model);
 int ownx_groups_per_block(int model, int dim);

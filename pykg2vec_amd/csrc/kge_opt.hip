@@ -150,11 +150,13 @@ struct RowStage {
     int* count; const int* bucket; int* head; const int* next; int cap;
 };
 
+constexpr int kStageChainLds = 256;   // overflow-chain entries of one row kept in LDS (8 row groups per workgroup: 8 KB)
 template <int KIND, int NV, bool NORM, bool NT>
 __global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                    float* __restrict__ s2, int64_t rows, int dim, OptArgs a,
                                                    const float* __restrict__ dev_hyper, int zero,
                                                    const unsigned* __restrict__ touched, unsigned* __restrict__ touched_clear, RowStage stage) {
+    __shared__ int s_chain[8][kStageChainLds];
     if (dev_hyper) { a.lr = dev_hyper[0]; a.step_size = dev_hyper[1]; a.bc2_sqrt = dev_hyper[2]; }
     const int gl = threadIdx.x & 31;
     const int nvec = dim >> 2;
@@ -184,12 +186,26 @@ __global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float*
                 const int nb = cnt < stage.cap ? cnt : stage.cap;
                 const int mine = gl < nb ? stage.bucket[row * stage.cap + gl] : 0x7FFFFFFF;   // (cap <= 32: one bucket entry per lane)
                 const int chain = cnt > stage.cap ? stage.head[row] - 1 : -1;
+                // The overflow chain (registrations beyond the bucket: hub entities of real graphs -- tens per 1 024-pair batch on
+                // YAGO3-10 / FB15k) is walked ONCE into LDS; rounds 5's selection re-walked it -- dependent global loads -- for every
+                // one of the cnt slots (O(cnt * chain) round trips, milliseconds for one hub row).  Entries beyond the
+                // LDS window (kStageChainLds per row group) keep the walk: correct for any length, fast for every realistic one.
+                int* const sc = s_chain[threadIdx.x >> 5];
+                int nlds = 0, rest = -1;
+                for (int j = chain; j >= 0; j = stage.next[j]) {     // (group-uniform: every lane walks, lane 0 files)
+                    if (nlds == kStageChainLds) { rest = j; break; }
+                    if (gl == 0) sc[nlds] = j;
+                    ++nlds;
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): lane 0's LDS writes have landed (same wave reads them below)
+                __builtin_amdgcn_wave_barrier();
                 int last = -1;
                 for (int it = 0; it < cnt; ++it) {      // ascending slot order: the smallest slot above the last one taken
                     int best = mine > last ? mine : 0x7FFFFFFF;
+                    for (int k = gl; k < nlds; k += 32) { const int j = sc[k]; if (j > last && j < best) best = j; }
 #pragma unroll
                     for (int o = 16; o >= 1; o >>= 1) best = min(best, __shfl_xor(best, o, 64));   // over the row's 32 lanes
-                    for (int j = chain; j >= 0; j = stage.next[j])
+                    for (int j = rest; j >= 0; j = stage.next[j])
                         if (j > last && j < best) best = j;
                     if (best == 0x7FFFFFFF) break;
                     last = best;

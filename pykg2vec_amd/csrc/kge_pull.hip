@@ -38,6 +38,8 @@ struct PullArgs {
     const float* hat_in[2];    // row-normalised copies x / max(||x||, eps) of tab_in: what the other owners gather.  Rows
                                // are padded with zeros to 4 * G * NV floats, so a gather is one unconditional 16-byte load
     float* hat_out[2];         // the same for tab_out, written by each row's owner
+    unsigned hat_row_bytes;    // bytes between consecutive hat rows: 16 * G * NV (padded: every lane loads) or 4 * d (compact, round 6:
+                               // lanes beyond the row skip their load; 6.5 instead of 8.3 MB of normalised rows for the L2s to hold at C1)
     const float* norm_in;      // [E + R] L2 norms of the rows of tab_in (entities first)
     float* norm_out;           // norms of the rows of tab_out
     float* s1[2];              // optimiser state, same row layout as the tables (NULL where the optimiser has none)
@@ -141,11 +143,12 @@ __device__ __forceinline__ void pull_finish_row(const PullArgs& a, int g, const 
     store_row4<G, NV>(t_out + off, P, nvec, gl);
     if constexpr (OPT != KGE_OPT_SGD) store_row4<G, NV>(st1 + off, M1, nvec, gl);
     if constexpr (OPT == KGE_OPT_ADAM) store_row4<G, NV>(st2 + off, M2, nvec, gl);
-    float4* const hrow = reinterpret_cast<float4*>(h_out) + (int64_t)(is_rel ? g - a.E : g) * (G * NV);
+    float4* const hrow = reinterpret_cast<float4*>(reinterpret_cast<char*>(h_out) + (int64_t)(is_rel ? g - a.E : g) * a.hat_row_bytes);
+    const int hvec = (int)(a.hat_row_bytes >> 4);   // float4 slots of a hat row: G * NV (padded: lanes beyond the row store their zeros) or d / 4
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {   // padded row: lanes beyond the row store their zeros
+    for (int v = 0; v < NV; ++v) {
         P[v].x *= inn; P[v].y *= inn; P[v].z *= inn; P[v].w *= inn;
-        hrow[v * G + gl] = P[v];
+        if (v * G + gl < hvec) hrow[v * G + gl] = P[v];
     }
     if (gl == 0) a.norm_out[g] = nn;
 }
@@ -166,6 +169,7 @@ struct PullRows {
 // workgroups -- 2 048 at B = 32 768, ONE residency round of 8 x 256 workgroups instead of two -- and half the workgroup launches
 // (per-workgroup timestamps: the dispatcher needs 1.8 us to start 2 048 workgroups; profiles/r04_experiments.md section 7).
 constexpr int kEvalPP = 2;
+constexpr bool kHatCompactDefault = true;   // hat rows: padded to 4 * G * NV floats (rounds 2-5) or compact (KGE_HAT_COMPACT=1)
 template <bool L1, int G, int NV>
 __global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restrict__ loss) {
     constexpr int GPB = kBlock / G, PP = kEvalPP;
@@ -174,8 +178,9 @@ __global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restr
     float acc = 0.f;
     const char* __restrict__ hat_e = reinterpret_cast<const char*>(a.hat_in[0]);
     const char* __restrict__ hat_r = reinterpret_cast<const char*>(a.hat_in[1]);
-    constexpr unsigned kRowBytes = 16u * G * NV;
+    const unsigned kRowBytes = a.hat_row_bytes;
     const unsigned lane_off = 16u * gl;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int64_t idx[PP];
     bool on[PP];
     int4 p[PP];
@@ -190,18 +195,26 @@ __global__ __launch_bounds__(kBlock) void k_pull_eval(PullArgs a, float* __restr
     }
     float4 hh[PP][NV], rr[PP][NV], tt[PP][NV], cc[PP][NV];
     float th[PP];
+    unsigned oh[PP], orr[PP], ot[PP], oc[PP];
 #pragma unroll
     for (int q = 0; q < PP; ++q) {
-        const unsigned oh = (unsigned)p[q].x * kRowBytes + lane_off, orr = (unsigned)p[q].y * kRowBytes + lane_off;
-        const unsigned ot = (unsigned)p[q].z * kRowBytes + lane_off, oc = (unsigned)(w[q] & 0xFFFFFF) * kRowBytes + lane_off;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            hh[q][v] = *reinterpret_cast<const float4*>(hat_e + (oh + 16u * G * v));
-            rr[q][v] = *reinterpret_cast<const float4*>(hat_r + (orr + 16u * G * v));
-            tt[q][v] = *reinterpret_cast<const float4*>(hat_e + (ot + 16u * G * v));
-            cc[q][v] = *reinterpret_cast<const float4*>(hat_e + (oc + 16u * G * v));
-        }
+        oh[q] = (unsigned)p[q].x * kRowBytes + lane_off; orr[q] = (unsigned)p[q].y * kRowBytes + lane_off;
+        ot[q] = (unsigned)p[q].z * kRowBytes + lane_off; oc[q] = (unsigned)(w[q] & 0xFFFFFF) * kRowBytes + lane_off;
         th[q] = a.theta ? a.theta[p[q].y] : 1.0f;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {   // ONE predicated region per chunk for all PP x 4 row gathers (padded rows: every lane is inside)
+#pragma unroll
+        for (int q = 0; q < PP; ++q) { hh[q][v] = zero4; rr[q][v] = zero4; tt[q][v] = zero4; cc[q][v] = zero4; }
+        if (lane_off + 16u * G * v < kRowBytes) {
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                hh[q][v] = *reinterpret_cast<const float4*>(hat_e + (oh[q] + 16u * G * v));
+                rr[q][v] = *reinterpret_cast<const float4*>(hat_r + (orr[q] + 16u * G * v));
+                tt[q][v] = *reinterpret_cast<const float4*>(hat_e + (ot[q] + 16u * G * v));
+                cc[q][v] = *reinterpret_cast<const float4*>(hat_e + (oc[q] + 16u * G * v));
+            }
+        }
     }
 #pragma unroll
     for (int q = 0; q < PP; ++q) {
@@ -423,19 +436,23 @@ __global__ __launch_bounds__(kBlock) void k_pull_step(PullArgs a, PullSampleArgs
         // (32-bit byte offsets from the uniform table bases: one shift-or per row instead of 64-bit address arithmetic)
         const char* __restrict__ hat_e = reinterpret_cast<const char*>(a.hat_in[0]);
         const char* __restrict__ hat_r = reinterpret_cast<const char*>(a.hat_in[1]);
-        constexpr unsigned kRowBytes = 16u * G * NV;
+        const unsigned kRowBytes = a.hat_row_bytes;
         const unsigned lane_off = 16u * gl;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         auto fetch = [&](int h, int r, int t, int w, PullRows<NV>& b) {
             b.w = w;
             b.th = a.theta ? a.theta[r] : 1.0f;
             const unsigned oh = (unsigned)h * kRowBytes + lane_off, orr = (unsigned)r * kRowBytes + lane_off;
             const unsigned ot = (unsigned)t * kRowBytes + lane_off, oc = (unsigned)(w & 0xFFFFFF) * kRowBytes + lane_off;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {   // padded rows: no bounds checks
-                b.hh[v] = *reinterpret_cast<const float4*>(hat_e + (oh + 16u * G * v));
-                b.rr[v] = *reinterpret_cast<const float4*>(hat_r + (orr + 16u * G * v));
-                b.tt[v] = *reinterpret_cast<const float4*>(hat_e + (ot + 16u * G * v));
-                b.cc[v] = *reinterpret_cast<const float4*>(hat_e + (oc + 16u * G * v));
+            for (int v = 0; v < NV; ++v) {   // (padded rows: every lane is inside)
+                b.hh[v] = zero4; b.rr[v] = zero4; b.tt[v] = zero4; b.cc[v] = zero4;
+                if (lane_off + 16u * G * v < kRowBytes) {
+                    b.hh[v] = *reinterpret_cast<const float4*>(hat_e + (oh + 16u * G * v));
+                    b.rr[v] = *reinterpret_cast<const float4*>(hat_r + (orr + 16u * G * v));
+                    b.tt[v] = *reinterpret_cast<const float4*>(hat_e + (ot + 16u * G * v));
+                    b.cc[v] = *reinterpret_cast<const float4*>(hat_e + (oc + 16u * G * v));
+                }
             }
         };
         auto fetch_visit = [&](int v, PullRows<NV>& b) {
@@ -603,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_finish(PullArgs a) {
 // L2 norms and normalised copies of the rows of a table, in the lane layout / operation order pull_finish_row uses
 template <int G, int NV>
 __global__ __launch_bounds__(kBlock) void k_row_norms(const float* __restrict__ tab, int64_t rows, int d, float* __restrict__ out,
-                                                      float* __restrict__ hat) {
+                                                      float* __restrict__ hat, unsigned hat_row_bytes) {
     constexpr int GPB = kBlock / G;
     const int gl = threadIdx.x % G;
     const int64_t r = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
@@ -616,13 +633,14 @@ __global__ __launch_bounds__(kBlock) void k_row_norms(const float* __restrict__ 
     n2 = gsum<G>(n2);
     const float nn = sqrtf(n2);
     if (gl == 0) out[r] = nn;
-    if (hat) {   // padded rows of 4 * G * NV floats
+    if (hat) {   // rows of hat_row_bytes: padded to 4 * G * NV floats, or compact (d floats)
         const float inn = 1.0f / fmaxf(nn, kEpsNormalize);
-        float4* const hrow = reinterpret_cast<float4*>(hat) + r * (G * NV);
+        float4* const hrow = reinterpret_cast<float4*>(reinterpret_cast<char*>(hat) + r * (int64_t)hat_row_bytes);
+        const int hvec = (int)(hat_row_bytes >> 4);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             X[v].x *= inn; X[v].y *= inn; X[v].z *= inn; X[v].w *= inn;
-            hrow[v * G + gl] = X[v];
+            if (v * G + gl < hvec) hrow[v * G + gl] = X[v];
         }
     }
 }
@@ -706,6 +724,13 @@ void pull_direction_bytes(int dim, int l1, int64_t n, size_t* codes, size_t* rec
     *recs = (size_t)n * 16;
 }
 int pull_partial_stride(int dim) { const PullGeo g = pull_geo(dim); return 4 * g.G * g.NV; }
+// Bytes between hat rows (kge_pull_hat_stride floats: callers size and slice their hat buffers with it).  Read per launch: every kernel of
+// a run -- and the caller's slicing -- must see the same value of the switch.
+static unsigned hat_row_bytes(const PullGeo& g, int dim) {
+    const int sw = switch_value("HAT_COMPACT");
+    return (sw >= 0 ? sw == 1 : kHatCompactDefault) ? 4u * (unsigned)dim : 16u * (unsigned)g.G * (unsigned)g.NV;
+}
+int pull_hat_stride(int dim) { const PullGeo g = pull_geo(dim); return g.G ? (int)(hat_row_bytes(g, dim) / 4) : 0; }
 int pull_groups_per_block(int dim) { const PullGeo g = pull_geo(dim); return g.G ? kBlock / g.G : 0; }
 
 int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const float* const hat_in[2], float* const hat_out[2],
@@ -736,6 +761,7 @@ int launch_pull_step(const kge_model_desc* m, float* const tables_out[2], const 
         a.hat_in[i] = hat_in[i]; a.hat_out[i] = hat_out[i];
         a.s1[i] = state1 ? state1[i] : nullptr; a.s2[i] = state2 ? state2[i] : nullptr;
     }
+    a.hat_row_bytes = hat_row_bytes(geo, m->dim);
     a.norm_in = norm_in; a.norm_out = norm_out;
     a.pairs = (const int4*)pairs; a.lists = to_lists(lists);
     a.items = (const int4*)items; a.inc = inc; a.partials = partials; a.multi = (const int4*)multi;
@@ -775,7 +801,7 @@ int launch_row_norms(const float* table, int64_t rows, int dim, float* out, floa
 #define KGE_RN(G_, NV_)                                                                                               \
     if (g.G == G_ && g.NV == NV_) {                                                                                    \
         hipLaunchKernelGGL((k_row_norms<G_, NV_>), dim3((unsigned)((rows + kBlock / G_ - 1) / (kBlock / G_))), dim3(kBlock), 0, s, \
-                           table, rows, dim, out, hat);                                                                \
+                           table, rows, dim, out, hat, hat_row_bytes(g, dim));                                         \
         return check_launch("k_row_norms");                                                                            \
     }
     KGE_RN(16, 1) KGE_RN(16, 2) KGE_RN(32, 1) KGE_RN(32, 2) KGE_RN(32, 4) KGE_RN(32, 8)

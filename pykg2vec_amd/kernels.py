@@ -809,6 +809,11 @@ def pull_partial_stride(dim):
     return int(L.load().kge_pull_partial_stride(int(dim)))
 
 
+def pull_hat_stride(dim):
+    """Floats between consecutive rows of the owner-computes step's normalised ("hat") tables."""
+    return int(L.load().kge_pull_hat_stride(int(dim)))
+
+
 def pull_groups_per_block(dim):
     return int(L.load().kge_pull_groups_per_block(int(dim)))
 

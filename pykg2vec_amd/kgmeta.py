@@ -48,7 +48,17 @@ class Model:
     def forward(self, h, r, t):
         """Energies of the triples (h, r, t) through the dispatcher-registered op `kge::score` (ops.py): differentiable w.r.t. the
         tables (dense gradients, like nn.Embedding(sparse=False)), visible to torch.ops / torch.compile."""
-        return torch.ops.kge.score(ops.register_model(self), h, r, t, [p.weight for p in self.parameter_list])
+        return torch.ops.kge.score(self._kge_op_key, h, r, t, [p.weight for p in self.parameter_list])
+
+    def _register_op_handle(self):
+        """The integer handle torch.ops.kge.score finds this model by: taken once per object (construction, unpickling, deepcopy),
+        so that forward() reads a plain attribute -- a constant for torch.compile -- instead of touching the weak registry."""
+        self.__dict__.pop("_kge_op_key", None)
+        ops.register_model(self)
+
+    def _restore(self, state):   # unpickling / deepcopy: the copy is a new object and needs its own handle
+        nn.Module.__setstate__(self, state)
+        self._register_op_handle()
 
     # ---- the reference Evaluator's optional hooks (utils/evaluator.py:250-252,263-265): candidate ids by
     # descending energy, shape [1, topk]; served by the sweep kernels instead of forward() over E id tensors.
@@ -70,19 +80,23 @@ class Model:
 
 class PairwiseModel(nn.Module, Model):
     forward = Model.forward  # nn.Module.forward precedes Model.forward in the MRO
+    __setstate__ = Model._restore
 
     def __init__(self, model_name):
         super().__init__()
         self.model_name = model_name
         self.training_strategy = TrainingStrategy.PAIRWISE_BASED
         self.database = {}
+        self._register_op_handle()
 
 
 class PointwiseModel(nn.Module, Model):
     forward = Model.forward
+    __setstate__ = Model._restore
 
     def __init__(self, model_name):
         super().__init__()
         self.model_name = model_name
         self.training_strategy = TrainingStrategy.POINTWISE_BASED
         self.database = {}
+        self._register_op_handle()

@@ -147,8 +147,8 @@ class PullState:
         offs = [v.data_ptr() - flat.param.data_ptr() for v in flat.views[:2]]
         view = lambda buf: [buf[o // 4:o // 4 + r * d].view(r, d) for o, (r, d) in zip(offs, shapes)]
         self.tables = [view(flat.param), view(self.alt)]
-        # row-normalised copies of both halves, rows padded to the kernels' float4 lane layout (kge_pull_partial_stride)
-        stride = K.pull_partial_stride(shapes[0][1])
+        # row-normalised copies of both halves, rows of kge_pull_hat_stride floats (compact since round 6: 6.5 instead of 8.3 MB at C1)
+        stride = K.pull_hat_stride(shapes[0][1])
         # (entity rows, then relation rows, in ONE buffer per half: a single kge_row_norms call refreshes both tables when they
         # are adjacent in the flat parameter buffer)
         self.hat_all = [torch.zeros(sum(r for r, _ in shapes), stride, dtype=torch.float32, device=dev) for _ in range(2)]

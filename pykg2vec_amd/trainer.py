@@ -1044,11 +1044,16 @@ class Trainer:
         except BaseException:
             # a step that died between the pair step's registrations and the optimiser that consumes (and resets) them would leave
             # entries in the per-entity lists of the staged RESCAL gradients: start the next epoch from empty lists
+            # (after a HIP fault these device ops raise themselves: the ORIGINAL error is the one to surface)
+            self._touched_step, self._stage_step = None, None
             st = getattr(self, "_rescal_stage", None)
             if st is not None:
-                st.count.zero_(); st.head.zero_()
-                for b in (self._touched or ()):
-                    b.zero_()
+                try:
+                    st.count.zero_(); st.head.zero_()
+                    for b in (self._touched or ()):
+                        b.zero_()
+                except Exception as cleanup_error:   # noqa: BLE001
+                    _log("train_model_epoch: resetting the staged-gradient lists after a failed step also failed: %r" % (cleanup_error,))
             raise
         finally:
             self._in_epoch, self._rescal_normalised, self._rescal_last = False, False, False
@@ -1187,10 +1192,14 @@ class Trainer:
                     # keep the best weights seen so far (utils/trainer.py:207-219)
                     if self.best_metric is None or self._is_better(metrics):
                         self.best_metric = metrics
-                        if self.rank == 0:      # replicas are identical: one writer (N truncating writers would race on the same files)
-                            self.save_model()
-                        if self.distributed:
-                            torch.distributed.barrier(group=self.process_group)
+                        # replicas are identical: one writer (N truncating writers would race on the same files).  The barrier is reached
+                        # whatever the save does: a rank-0 exception must not leave the other ranks waiting in it
+                        try:
+                            if self.rank == 0:
+                                self.save_model()
+                        finally:
+                            if self.distributed:
+                                torch.distributed.barrier(group=self.process_group)
         self.model.eval()
         with torch.no_grad():
             self.evaluator.full_test(cur_epoch_idx)

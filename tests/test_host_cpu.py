@@ -416,3 +416,16 @@ def test_pull_index_structure(E, R, B, seg, gpb):
             assert len(row) == 1 and row[0, 1] == ps[0] and row[0, 2] == len(its)
             n_partial += len(its)
     assert n_partial == nglob
+
+
+def test_copies_of_a_model_get_their_own_op_handle():
+    """torch.ops.kge.score finds its model through an integer handle (pykg2vec_amd/ops.py): deepcopy / pickle must not share it."""
+    import copy
+    import pickle
+    import pykg2vec_amd.pointwise as pt
+    from pykg2vec_amd import ops
+    m = pt.Complex(tot_entity=10, tot_relation=3, hidden_size=8, lmbda=0.1)
+    clones = [copy.deepcopy(m), pickle.loads(pickle.dumps(m))]
+    keys = {m._kge_op_key} | {c._kge_op_key for c in clones}
+    assert len(keys) == 3 and all(ops._model(c._kge_op_key) is c for c in clones + [m])
+    assert str(torch.ops.kge.score.default._schema).startswith("kge::score(SymInt key, Tensor h, Tensor r, Tensor t, Tensor[] weights)")
