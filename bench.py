@@ -1,29 +1,20 @@
 #!/usr/bin/env python
-"""bench.py -- BASELINE.json metric on MI355X: scored triples/sec (train) + test triples ranked/sec,
-FB15k-shape TransE d=100 (configs[1]).
+"""bench.py -- BASELINE.json's metric on MI355X: scored triples/sec (train) + test triples ranked/sec, FB15k-shape TransE d=100
+(configs[1]), synthetic data of that shape, random-init tables, fp32.
 
-A *step* is one pass of the training hot path over one batch of the HBM-resident train set: ONE kernel does the
-negative corruption, score(+), score(-), hinge and the backward scatter (kge_train_pairwise_hinge_sampled)
--> [N>1: RCCL reduce-scatter of the flat dense gradient] -> fused dense Adam sweep over the rank's 1/N shard
-(kge_optimizer_step) -> [N>1: RCCL all-gather of the updated tables].  Nothing is skipped or cached inside the timed
-region.  After the timed training steps the same process times the filtered-rank evaluation sweep (kge_eval_ranks),
-the other BASELINE configs (C2 ComplEx-WN18RR, C3 RotatE-FB15k-237, C4 RESCAL-YAGO3-10; N=1 only, `extra`) and, on
-rank 0 at N=1, the CPU baseline: the UNMODIFIED reference's CPU-PyTorch path when its tree can be imported
-(oracle/ref_cpu_baseline.py, `kind: "reference"`; the tree does not exist on the GPU box), else a multi-threaded C *port* of the
-reference algorithm (oracle/kge_oracle_c.c, pinned to the numpy oracle and the reference's golden vectors, `kind: "port"`) --
-on a bounded sample of the same workload, all host cores.
+A *step* is one pass of the training hot path over one batch of the HBM-resident train split.  N = 1: the owner-computes step
+(csrc/kge_pull.hip) -- k_pull_eval (every pair once: four row gathers, hinge, direction codes) + k_pull_step (one owner per table
+row: sums its incidences, normalisation backward, dense Adam; the NEXT batch's negative sampler rides in its leading blocks), all
+steps of the region enqueued by one native call (kge_pull_run).  N > 1: each rank computes the gradient of its share of the batch
+with the same kernel, one RCCL exchange of the flat gradient, the optimiser, row norms.  Nothing is skipped or cached inside the
+timed region, which is run REPEATS times (median reported).  Then, untimed for `value`: the filtered-rank sweep of the whole test
+split (`eval`), the other BASELINE configs (`extra`, tools/bench_extra.py), the reference's CPU path on the same host (`cpu_baseline`,
+tools/bench_cpu.py) and the hardware-counter passes that give `roofline.traffic` (tools/bench_pmc.py: a child run under rocprofv3
+--pmc FETCH_SIZE / WRITE_SIZE, separate passes, segmented by marker launches; `--no-live-pmc` uses the committed passes).
 
-HBM traffic (`roofline.traffic`, `eval.roofline.traffic`, `extra.C*.traffic`) is OBSERVED IN THIS RUN when rocprofv3 is on the
-box: rank 0 at N=1 re-runs a short version of every leg as a child process under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and
-again under `--pmc WRITE_SIZE` (separate passes, MI355X_MICROARCH.md), each leg's timed steps bracketed by marker launches
-(kge_debug_marker), and sums the counters of all kernels between the markers.  `--no-live-pmc` (or a missing / failing
-rocprofv3) falls back to the committed passes under profiles/ and says so in `traffic_source`.
-
-Launch:  python bench.py [--gpus N --steps K --warmup W]
-         N>1 without a torch.distributed environment: bench.py re-executes itself under torch.distributed.run
-         (one rank per GPU); an existing RANK/WORLD_SIZE environment (torchrun) is used as is.
-Rank 0 writes the complete record to gpurun_out/bench_detail.json and prints ONE compact JSON line (< 4 KB: the driver parses the
-last line of an 8 KB stdout tail) as its LAST stdout line; --full-line also prints the complete record as an earlier line.
+Launch:  python bench.py [--gpus N --steps K --warmup W]      (N > 1 without a torch.distributed environment re-executes itself under
+         torch.distributed.run, one rank per GPU; an existing torchrun environment is used as is)
+Rank 0 writes the complete record to gpurun_out/bench_detail.json and prints ONE compact JSON line (< 4 KB) as its LAST stdout line.
 """
 import argparse
 import json
@@ -58,16 +49,6 @@ L1_SWEEP_ISSUES_PER_ELEMENT = 2.0
 L1_SWEEP_MICROBENCH_TELEMS = 32.9                       # register-resident ceiling of the same mix (tools/valu_bench.hip)
 REPEATS = 7                                             # timed regions per run (train) / timed passes (eval): the MEDIAN is reported
 MIN_WARM_SECONDS = 0.05                                 # warm until >= 50 ms of GPU work has run, whatever --warmup says
-# marker tags of the counter child (kge_debug_marker: grid.x = 64 x tag); a segment runs from its tag to the next marker
-PMC_TAGS = {"C1_train": 101, "C1_eval": 102, "C1_small": 103, "C2_train": 111, "C2_eval": 112, "C3_train": 121, "C3_eval": 122,
-            "C4_train": 131, "C4_eval": 132, "end": 99}
-PMC_C1_STEPS, PMC_EVAL_REPS, PMC_EXTRA_STEPS, PMC_SMALL_STEPS = 28, 1, 20, 400
-# third (optional) pass of the counter child: what the SQ sees -- VALU / VMEM / SALU wave-instructions, and where a wave's time goes
-# (parked on s_waitcnt / issue-stalled / issuing).  Eight SQ counters fit one pass (MI355X_MICROARCH.md, counter table).
-SQ_PASS = "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"
-# dependent-load latency under load, from the committed random-row microbenchmark (profiles/r03_gather_bench.txt, 16 296-row table,
-# "chain G=32 8 hops": 21.53 us at 32 768 groups, 9.23 us at 8 192 groups -> us per hop)
-HOP_US_AT_32K_GROUPS, HOP_US_AT_8K_GROUPS = 21.53 / 8, 9.23 / 8
 
 
 class _KG:
@@ -115,163 +96,6 @@ def build_filters(all_triples, queries, R_):
     return hr_t, tr_h
 
 
-def cpu_baseline_train(train, budget_s=1.2, batch=32768):
-    """C/OpenMP restatement of one reference train step (utils/trainer.py:147-157,298-299 + criterion.py:25-29 + dense
-    Adam) on all host cores -- oracle/kge_oracle_c.c, a *port* held to the numpy oracle by tests/test_oracle_c.py."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import kge_oracle as ko
-    import kge_oracle_c as kc
-    rng = np.random.default_rng(0)
-    P = ko.init_params("transe", rng, tot_entity=E, tot_relation=R, hidden_size=DIM)
-    st = kc.TransEAdam(P["ent_embeddings"], P["rel_embeddings"], True, 1.0, 0.01)
-    batches = []
-    for k in range(N_TRAIN // batch):  # one epoch of distinct batches, like the GPU leg walks the permutation
-        pos = train[k * batch:(k + 1) * batch]
-        neg = pos.copy()
-        flip = rng.random(batch) > 0.5
-        rnd = rng.integers(E, size=batch)
-        neg[:, 2] = np.where(flip, rnd, neg[:, 2])
-        neg[:, 0] = np.where(flip, neg[:, 0], rnd)
-        batches.append([np.ascontiguousarray(a) for a in (pos[:, 0], pos[:, 1], pos[:, 2], neg[:, 0], neg[:, 1], neg[:, 2])])
-    st.train_step(*batches[0])  # warm
-    # thread count: the container may expose more logical cores than it can run; probe a few counts briefly, keep the best
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else kc.threads()
-    best, best_rate = avail, 0.0
-    for nt in sorted({min(avail, c) for c in (8, 16, 32, avail)}):
-        kc.set_threads(nt)
-        t0, k = time.perf_counter(), 0
-        while time.perf_counter() - t0 < 0.3:
-            st.train_step(*batches[k % len(batches)])
-            k += 1
-        rate = k / (time.perf_counter() - t0)
-        if rate > best_rate:
-            best, best_rate = nt, rate
-    kc.set_threads(best)
-    t0, n = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s:
-        st.train_step(*batches[n % len(batches)])
-        n += 1
-    dt = time.perf_counter() - t0
-    return (2 * batch * n / dt, kc.threads(),
-            "%d dense-Adam steps of B=%d positives + %d negatives (FB15k-shape TransE d=100 L1), C/OpenMP fp32" % (n, batch, batch))
-
-
-def cpu_baseline_eval(P_np, test, csr, budget_s=1.2):
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import kge_oracle_c as kc
-    t_off, t_ids, h_off, h_ids = csr
-    t0, n, chunk = time.perf_counter(), 0, 4 * kc.threads()
-    while time.perf_counter() - t0 < budget_s and n < len(test):
-        m = min(chunk, len(test) - n)
-        to = t_off[n:n + m + 1] - t_off[n]
-        ho = h_off[n:n + m + 1] - h_off[n]
-        kc.transe_eval(P_np["ent_embeddings"], P_np["rel_embeddings"], True, test[n:n + m], to,
-                       t_ids[t_off[n]:t_off[n + m]], ho, h_ids[h_off[n]:h_off[n + m]])
-        n += m
-    return n / (time.perf_counter() - t0), n
-
-
-def reference_cpu_numbers():
-    """The UNMODIFIED reference's CPU-PyTorch throughput on this workload as measured in the build container
-    (profiles/r04_reference_cpu_baseline.json, tools/ref_cpu_baseline.py; the round-2 file when that is absent).  Quoted next to
-    the in-run port wherever the reference tree cannot be imported (the GPU box); never used as `value`."""
-    for name in ("r04_reference_cpu_baseline.json", "r02_reference_cpu_baseline.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            doc = json.load(open(path))
-            return {"train_scored_triples_per_s": doc["train"]["value"], "eval_test_triples_per_s": doc["eval"]["value"],
-                    "cores": doc["cores"], "host": doc["host"], "source": "profiles/" + name, "same_run": False, "same_host": False}
-    return None
-
-
-def cpu_baseline(H):
-    """`cpu_baseline` of the JSON line, measured on THIS host in THIS run.  First choice: the reference itself (SURVEY 8(d):
-    Trainer.train_step_pairwise + backward + optimizer.step, utils/trainer.py:147-157,298-299; Evaluator.test on 200 triples,
-    utils/evaluator.py:309-334) -- possible wherever its tree is importable (PYKG2VEC_REFERENCE, default /root/reference; NOT on the GPU
-    box).  Otherwise oracle/aten_step.py: the same ATen call sequence on the same torch CPU build, proven bit-equal to the live reference
-    in the build container (tests/test_aten_restatement.py) -> `kind: "aten-restatement"`.  The C/OpenMP port of the algorithm (what a
-    tuned CPU implementation reaches, ~24x the reference) rides beside either as `port`."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from pykg2vec_amd.evaluator import build_filter_csr
-    n_ref = 100
-    out, tried = None, None
-    try:
-        import ref_cpu_baseline
-        if ref_cpu_baseline.available():
-            hr_t, tr_h = build_filters(np.concatenate([H.train, H.valid, H.test]), H.test[:n_ref], R)
-            doc = ref_cpu_baseline.measure(E, R, DIM, H.train, H.valid, H.test, hr_t, tr_h, batch=H.cfg.batch_size, n_eval=n_ref,
-                                           train_budget_s=4.0, max_timed=20)
-            out = {"value": doc["train"]["value"], "unit": "scored triples/s", "cores": doc["cores"], "kind": "reference",
-                   "sample": doc["train"]["sample"], "what": doc["what"], "host": doc["host"], "same_run": True, "same_host": True,
-                   "eval": {"value": doc["eval"]["value"], "unit": "test triples ranked/s", "sample": doc["eval"]["sample"]}}
-        else:
-            tried = "reference tree not present at %s" % ref_cpu_baseline.ref_shim.REFERENCE_ROOT
-    except Exception as e:   # the baseline leg must never take the line down
-        tried = "reference import / run failed: %s: %s" % (type(e).__name__, e)
-    if out is None:
-        try:
-            import aten_step
-            hr_t, tr_h = build_filters(np.concatenate([H.train, H.valid, H.test]), H.test[:n_ref], R)
-            doc = aten_step.measure(E, R, DIM, H.train, H.test, hr_t, tr_h, batch=H.cfg.batch_size, n_eval=n_ref, margin=H.cfg.margin,
-                                    lr=H.cfg.learning_rate, train_budget_s=3.0, eval_budget_s=3.0, max_timed=20)
-            out = {"value": doc["train"]["value"], "unit": "scored triples/s", "cores": doc["cores"], "kind": "aten-restatement",
-                   "sample": doc["train"]["sample"], "what": doc["what"], "host": doc["host"], "same_run": True, "same_host": True,
-                   "kind_note": "the reference's exact ATen op sequence on this host's torch CPU build (%s)" % tried,
-                   "torch_default_threads": doc.get("torch_default_threads"),
-                   "value_at_torch_default_threads": doc["train"].get("value_at_torch_default_threads"),
-                   "eval": {"value": doc["eval"]["value"], "unit": "test triples ranked/s", "sample": doc["eval"]["sample"]}}
-        except Exception as e:
-            tried = "%s; ATen restatement failed: %s: %s" % (tried, type(e).__name__, e)
-    v, cores, sample = cpu_baseline_train(H.train)
-    P_np = {"ent_embeddings": H.model.ent_embeddings.weight.detach().cpu().numpy(),
-            "rel_embeddings": H.model.rel_embeddings.weight.detach().cpu().numpy()}
-    ve, ne = cpu_baseline_eval(P_np, H.my_test, build_filter_csr(H.my_test, H.hr_t, H.tr_h))
-    port = {"value": v, "unit": "scored triples/s", "cores": cores, "kind": "port", "sample": sample,
-            "kind_note": "C/OpenMP restatement of the reference ALGORITHM (oracle/kge_oracle_c.c), all host cores: an upper estimate of what "
-                         "a tuned CPU implementation reaches, not the reference's CPU-PyTorch path",
-            "eval": {"value": ve, "unit": "test triples ranked/s", "sample": "%d test triples, two full-entity sweeps each, C/OpenMP fp32" % ne}}
-    if out is None:   # neither the reference nor its ATen restatement ran: the port is all there is
-        out = dict(port, same_run=True, same_host=True, kind_note=port["kind_note"] + " (%s)" % tried)
-    else:
-        out["port"] = port
-    ref = reference_cpu_numbers()
-    if ref is not None and out["kind"] != "reference":
-        out["reference_in_build_container"] = ref
-    return out
-
-
-def pmc_traffic(kernel_prefix, batch, fetch_scale=1.0):
-    """HBM bytes per launch of the dominant train kernel from the committed rocprofv3 PMC passes
-    (profiles/*pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, separate passes, same bench command and batch size).
-    The same kernel name is launched at several geometries inside one bench run (B=32768 headline steps, the B=128
-    reference-default-batch leg), so the entry is selected by GRID: tools/rocpd_pmc.py keys its rows "<kernel> @grid=<threads>"
-    and the headline launches are the largest grid of that kernel.  (Files written before the per-grid keys carry one mixed
-    row per kernel: its max_KB -- the big launches -- is used, never the mixed average.)
-    fetch_scale: the gfx950 correction of MI355X_MICROARCH.md (HBM section) -- FETCH_SIZE reports half the bytes of wide
-    (16 B per lane) coalesced reads, which is how the owner-computes kernel fetches every row; the round-1 push kernel
-    reads one dword per lane (uncalibrated width: left raw).  Returns (bytes or None, source)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files or batch != 32768:
-        return None, None
-    for f in reversed(files):   # newest round first
-        doc = json.load(open(f))
-        best = None
-        for name, ctr in doc["kernels"].items():
-            if not (name.startswith(kernel_prefix) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr):
-                continue
-            if "@grid=" in name:
-                grid = int(name.split("@grid=")[1].split("x")[0])
-                cand = (grid, fetch_scale * ctr["FETCH_SIZE"]["avg_KB"] + ctr["WRITE_SIZE"]["avg_KB"], name)
-            else:
-                cand = (0, fetch_scale * ctr["FETCH_SIZE"]["max_KB"] + ctr["WRITE_SIZE"]["max_KB"], name + " (max rows)")
-            if best is None or cand[0] > best[0]:
-                best = cand
-        if best is not None:
-            return best[1] * 1024.0, "%s :: %s" % (os.path.basename(f), best[2])
-    return None, None
-
-
 def self_launch(args):
     """`python bench.py --gpus N` with no torch.distributed environment: re-execute under torch.distributed.run, one
     rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
@@ -285,262 +109,6 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     return subprocess.run(cmd, env=env).returncode
-
-
-def timed_epochs(tr, steps_per_epoch, n_epochs=1):
-    """One warm-up epoch (captures the hipGraph when the step is launch-bound), then n_epochs timed ones."""
-    import torch
-    tr.train_model_epoch(0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for e in range(n_epochs):
-        tr.train_model_epoch(1 + e)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / (n_epochs * steps_per_epoch)
-
-
-# the other BASELINE.json configs (SURVEY.md 8d): shapes, presets, algorithmic bytes / flops per unit
-EXTRA_CONFIGS = {
-    "C2": dict(name="ComplEx WN18RR-shape d=200, pointwise logistic + F2 reg, Adagrad, B=5000 (+5000 negatives)",
-               model="complex", E=40943, R=11, splits=(86835, 3034, 3134), hp=dict(hidden_size=200, lmbda=1e-4),
-               optimizer="adagrad", batch=5000, neg=1, n_eval=3134, train_bytes=14428, eval_bytes=1600),
-    "C3": dict(name="RotatE FB15k-237-shape d=1000, self-adversarial neg 16, Adam, B=1024",
-               model="rotate", E=14541, R=237, splits=(272115, 17535, 20466),
-               hp=dict(hidden_size=1000, margin=24.0, alpha=1.0), optimizer="adam", batch=1024, neg=16, n_eval=2048,
-               train_bytes=60028, eval_bytes=8000),
-    "C4": dict(name="RESCAL YAGO3-10-shape k=200, hinge, Adam, B=1024 (f32 MFMA path)",
-               model="rescal", E=123182, R=37, splits=(1079040, 5000, 5000), hp=dict(hidden_size=200, margin=1.0),
-               optimizer="adam", batch=1024, neg=1, n_eval=1024, train_bytes=4828, eval_bytes=800, train_flops=80400),
-}
-
-
-def build_extra_config(key, device, steps_cap=200):
-    import torch
-    import pykg2vec_amd as pa
-    from pykg2vec_amd.trainer import Trainer
-    c = EXTRA_CONFIGS[key]
-    E_, R_ = c["E"], c["R"]
-    train, valid, test = synthetic_split(E_, R_, c["splits"], seed=1234)
-    q = test[:c["n_eval"]]
-    hr_t, tr_h = build_filters(np.concatenate([train, valid, test]), q, R_)
-    hp = dict(c["hp"])
-    cfg = make_config(E_, R_, len(train), c["batch"], device, optimizer=c["optimizer"], neg_rate=c["neg"], **hp)
-    cfg.knowledge_graph = _KG({"triplets_train": train, "triplets_valid": valid, "triplets_test": test, "hr_t": hr_t,
-                               "tr_h": tr_h}, key)
-    torch.manual_seed(0)
-    model = pa.import_model(c["model"])(**cfg.__dict__)
-    tr = Trainer(model, cfg)
-    tr.build_model()
-    tr.generator = tr._new_generator()
-    steps = min(steps_cap, len(train) // c["batch"])
-    cfg.tot_train_triples = steps * c["batch"]
-    return c, cfg, model, tr, q, steps
-
-
-def run_extra_config(key, device):
-    import torch
-    from pykg2vec_amd.evaluator import Evaluator
-    c, cfg, model, tr, q, steps = build_extra_config(key, device)
-    E_ = c["E"]
-    dt = timed_epochs(tr, steps)
-    rows = c["batch"] * (1 + c["neg"])
-    ev = Evaluator(model, cfg)
-    t0 = time.perf_counter()
-    ev.rank_all(q, len(q))   # first pass: builds the per-query filter CSR (host) and uploads it
-    torch.cuda.synchronize()
-    first_ms = (time.perf_counter() - t0) * 1e3
-    t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        ev.rank_all(q, len(q))
-    torch.cuda.synchronize()
-    edt = (time.perf_counter() - t0) / reps
-    out = {"workload": c["name"],
-           "mode": step_mode(tr),
-           "step_us": dt * 1e6, "scored_triples_per_s": rows / dt,
-           "train_algorithmic_GBps_whole_step": rows * c["train_bytes"] / dt / 1e9,
-           "train_nominal_hbm_frac_whole_step": rows * c["train_bytes"] / dt / 1e9 / HBM_PEAK_GBS,
-           "eval_test_triples_per_s": len(q) / edt, "eval_ms_per_pass": edt * 1e3, "eval_test_triples": len(q),
-           "eval_setup_ms": max(0.0, first_ms - edt * 1e3),
-           "eval_algorithmic_GBps": 2.0 * len(q) * E_ * c["eval_bytes"] / edt / 1e9,
-           "eval_sweep": ("matrix cores (k_eval_gemm, f32 MFMA)" if c["model"] in ("complex", "rotate", "rescal") and 2 * len(q) >= 512
-                          else "VALU (k_eval_sweep)"),
-           "eval_TFLOPs": 2.0 * 2 * len(q) * E_ * (c["eval_bytes"] / 4) / edt / 1e12}
-    if "train_flops" in c:
-        out["train_TFLOPs_whole_step"] = rows * c["train_flops"] / dt / 1e12
-        out["train_mfma_frac_whole_step"] = out["train_TFLOPs_whole_step"] / MFMA_F32_PEAK_TFLOPS
-    del tr, ev, model
-    torch.cuda.empty_cache()
-    return out
-
-
-def step_mode(tr):
-    return ("hipGraph replay" if tr._graph is not None else
-            "eager, staged gradients (no atomics, kge_optimizer_step_staged)" if getattr(tr, "_staged", None) is not None else
-            "owner-computes, staged (kge_own_run: k_own_eval + k_own_step per step, no atomics, one native call per epoch)"
-            if getattr(tr, "_own", None) is not None else
-            "owner-computes (kge_pull_run)" if getattr(tr, "_pull", None) is not None else "eager")
-
-
-# ---------------------------------------------------------------------------- HBM counters observed in this run
-def pmc_child(args):
-    """The process rocprofv3 wraps (one pass per counter): a short version of every leg, each timed part bracketed by
-    kge_debug_marker launches so that the parent can cut the dispatch sequence into per-leg segments.  Prints nothing."""
-    import torch
-    from pykg2vec_amd import kernels as K
-    from pykg2vec_amd.evaluator import Evaluator
-    torch.cuda.set_device(0)
-    device = "cuda:0"
-    mark = lambda name: K.debug_marker(PMC_TAGS[name])
-    H = setup_headline(args.batch, args.eval_triples, device)
-    run_headline_steps(H, 2 * H.steps_per_epoch)        # warm: index build, code objects, list sets
-    reset_headline(H)
-    torch.cuda.synchronize()
-    mark("C1_train")
-    run_headline_steps(H, PMC_C1_STEPS)
-    mark("end")
-    H.tr.sync_model()
-    ev = Evaluator(H.model, H.cfg)
-    ev.rank_all(H.my_test, H.n_eval)
-    mark("C1_eval")
-    for _ in range(PMC_EVAL_REPS):
-        ev.rank_all(H.my_test, H.n_eval)
-    mark("end")
-    torch.cuda.synchronize()
-    for key in EXTRA_CONFIGS:
-        c, cfg, model, tr, q, steps = build_extra_config(key, device, steps_cap=PMC_EXTRA_STEPS)
-        tr.train_model_epoch(0)                           # warm (captures the hipGraph where the step is launch-bound)
-        torch.cuda.synchronize()
-        mark(key + "_train")
-        tr.train_model_epoch(1)
-        mark("end")
-        ev = Evaluator(model, cfg)
-        ev.rank_all(q, len(q))
-        mark(key + "_eval")
-        for _ in range(PMC_EVAL_REPS):
-            ev.rank_all(q, len(q))
-        mark("end")
-        torch.cuda.synchronize()
-        del tr, ev, model
-        torch.cuda.empty_cache()
-
-
-def pmc_child_units(batch, eval_triples):
-    """Units (train steps / eval passes) the child runs inside each marker segment -- what a segment's counter sum is divided by."""
-    units = {PMC_TAGS["C1_train"]: PMC_C1_STEPS, PMC_TAGS["C1_eval"]: PMC_EVAL_REPS}
-    for key, c in EXTRA_CONFIGS.items():
-        units[PMC_TAGS[key + "_train"]] = min(PMC_EXTRA_STEPS, c["splits"][0] // c["batch"])
-        units[PMC_TAGS[key + "_eval"]] = PMC_EVAL_REPS
-    return units
-
-
-def live_pmc(args, timeout_s=150):
-    """Run the counter child under rocprofv3 once per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass) and return
-    {leg: {"fetch_raw_bytes", "write_bytes", "bytes" (2 x fetch + write), "kernels": {...}}} per unit (step / pass), or
-    (None, reason).  Everything is best effort: a missing rocprofv3, a timeout or an unreadable result only costs the live figure."""
-    import glob
-    import shutil
-    import tempfile
-    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if exe is None:
-        return None, "rocprofv3 not found"
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import rocpd_pmc
-    units = pmc_child_units(args.batch, args.eval_triples)
-    name_of = {v: k for k, v in PMC_TAGS.items()}
-    legs, meta = {}, {}
-    tmp = tempfile.mkdtemp(prefix="kge_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
-    try:
-        # third pass: VALU issue counters (the owner kernel of the train leg is VALU-bound, profiles/r04_experiments.md section 7)
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE", SQ_PASS):
-            out_dir = os.path.join(tmp, ctr.split()[0])
-            cmd = [exe, "--pmc"] + ctr.split() + ["--kernel-trace", "-d", out_dir, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
-                   "--pmc-child", "--batch", str(args.batch), "--eval-triples", str(args.eval_triples)]
-            t0 = time.perf_counter()
-            optional = ctr.startswith("SQ_")     # the issue-counter pass is extra evidence: its failure must not cost the traffic figure
-            try:
-                res = subprocess.run(cmd, env=env, cwd="/tmp", timeout=timeout_s, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-            except subprocess.TimeoutExpired:
-                if optional:
-                    meta["sq_pass_error"] = "exceeded %d s" % timeout_s
-                    continue
-                return None, "rocprofv3 --pmc %s pass exceeded %d s" % (ctr, timeout_s)
-            meta[ctr.split()[0] + "_pass_s"] = time.perf_counter() - t0
-            dbs = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
-            if res.returncode != 0 or not dbs:
-                msg = "rocprofv3 --pmc %s pass failed (rc %d, %d result files): %s" % (
-                    ctr, res.returncode, len(dbs), res.stdout.decode(errors="replace")[-300:])
-                if optional:
-                    meta["sq_pass_error"] = msg
-                    continue
-                return None, msg
-            seg = rocpd_pmc.segments(dbs[0])
-            if "error" in seg:
-                if optional:
-                    meta["sq_pass_error"] = seg["error"]
-                    continue
-                return None, "%s (columns: %s)" % (seg["error"], seg.get("columns"))
-            meta["order_by"] = seg["order_by"]
-            for tag, rec in seg["segments"].items():
-                if tag not in units:
-                    continue
-                leg = legs.setdefault(name_of[tag], {"units": units[tag], "kernels": {}})
-                if ctr.startswith("SQ_"):    # several counters in one pass: one row per (dispatch, counter)
-                    ncs = len(ctr.split())
-                    for kname, k in rec["kernels"].items():
-                        kk = leg["kernels"].setdefault(kname, {})
-                        for c in ctr.split():
-                            kk[c + "_per_unit"] = k.get(c, 0.0) / units[tag]
-                        kk["us_per_unit_in_sq_pass"] = k["duration_us"] / ncs / units[tag]
-                    continue
-                total_kb = rec["counters"].get(ctr, 0.0)
-                leg["fetch_raw_bytes" if ctr == "FETCH_SIZE" else "write_bytes"] = total_kb * 1024.0 / units[tag]
-                for kname, k in rec["kernels"].items():
-                    kk = leg["kernels"].setdefault(kname, {})
-                    kk[ctr + "_KB_per_unit"] = k.get(ctr, 0.0) / units[tag]
-                    kk["launches_per_unit"] = k["rows"] / units[tag]
-                    kk["us_per_unit_in_counter_pass"] = k["duration_us"] / units[tag]
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    for leg in legs.values():
-        if "fetch_raw_bytes" in leg and "write_bytes" in leg:
-            # gfx950: FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 B (MI355X_MICROARCH.md, HBM section):
-            # doubled, as the guide prescribes for 16-byte-per-lane reads, which is how these kernels read rows and streams
-            leg["bytes"] = 2.0 * leg["fetch_raw_bytes"] + leg["write_bytes"]
-    return legs, meta
-
-
-def valu_record(kernels):
-    """VALU issue load of the train leg's kernels from the third live counter pass, in the ONE convention both legs of the line use
-    (MI355X_MICROARCH.md, "Wave scheduling" + the per-instruction table): a wave64 VALU instruction occupies its SIMD-32 for 2 cycles, the
-    roof is 1 024 SIMDs x 2.4 GHz / 2 = 1.2288 T wave-instructions/s.  `issue_frac` = SQ_INSTS_VALU / duration / that roof.
-    (SQ_ACTIVE_INST_VALU, in quad-cycles, is kept raw: rounds 3-4 divided it by a busy-cycle clock and read 0.73 "VALU-bound" off it;
-    by the guide's own issue rate the same launch sits near 0.3 -- see DESIGN.md section 4 for what does bound it.)"""
-    if not kernels:
-        return None
-    out = {}
-    roof = VALU_SIMDS * VALU_PEAK_CLOCK_HZ / 2.0
-    for name, k in kernels.items():
-        if "SQ_INSTS_VALU_per_unit" not in k or not k.get("us_per_unit_in_sq_pass"):
-            continue
-        dur = k["us_per_unit_in_sq_pass"] * 1e-6
-        rec = {"valu_wave_instructions_per_step": k.get("SQ_INSTS_VALU_per_unit"), "waves_per_step": k.get("SQ_WAVES_per_unit"),
-               "active_quad_cycles_per_step": k.get("SQ_ACTIVE_INST_VALU_per_unit"), "us_per_step_in_this_pass": dur * 1e6,
-               "issue_frac": k["SQ_INSTS_VALU_per_unit"] / dur / roof}
-        for c in ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_WAIT_INST_ANY", "SQ_INST_CYCLES_VMEM", "SQ_WAVE_CYCLES",
-                  "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
-            if c + "_per_unit" in k:
-                rec[c] = k[c + "_per_unit"]
-        if rec.get("SQ_WAVE_CYCLES"):
-            wc = rec["SQ_WAVE_CYCLES"]
-            rec["wave_time_split"] = {n: rec[c] / wc for n, c in (("parked_waitcnt", "SQ_WAIT_ANY"), ("issue_stall", "SQ_WAIT_INST_ANY"),
-                                                                   ("issuing", "SQ_ACTIVE_INST_ANY")) if rec.get(c) is not None}
-        out[name] = rec
-    if not out:
-        return None
-    out["convention"] = "issue_frac = wave64 VALU instructions / s over 1024 SIMDs x 2.4 GHz / 2 cycles per instruction"
-    return out
 
 
 def setup_headline(batch, eval_triples, device, world=1, rank=0):
@@ -795,12 +363,14 @@ def main():
     args = ap.parse_args()
 
     if args.pmc_child:
-        return pmc_child(args)
+        from tools import bench_pmc
+        return bench_pmc.pmc_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
+    from tools import bench_extra, bench_pmc   # the C2-C4 `extra` records; the rocprofv3 counter-pass harness
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1045,7 +615,7 @@ def main():
         tr_s = Trainer(pw.TransE(**cfg_s.__dict__), cfg_s)
         tr_s.build_model()
         tr_s.generator = tr_s._new_generator()
-        dts = timed_epochs(tr_s, 400)
+        dts = bench_extra.timed_epochs(tr_s, 400)
         small = {"batch": 128, "value": 256 / dts, "unit": "scored triples/s", "ms_per_step": dts * 1e3,
                  "mode": ("hipGraph replay, 8 steps per graph, of fused step + Adam (next step's state derived inside the Adam launch)" if tr_s._graph is not None
                           else "owner-computes step, one launch per step, the epoch enqueued by one native call (kge_pull_run); compact incidence index" if getattr(tr_s, "_pull", None) is not None
@@ -1053,17 +623,9 @@ def main():
         del tr_s
 
     # ---- HBM traffic of every leg, observed in THIS run by two rocprofv3 counter passes over a short child run (N=1, rank 0)
-    live, live_meta = (None, "disabled (--no-live-pmc)") if (args.no_live_pmc or world > 1) else live_pmc(args)
+    live, live_meta = (None, "disabled (--no-live-pmc)") if (args.no_live_pmc or world > 1) else bench_pmc.live_pmc(args)
 
     out = None
-    kernel_label = ("k_pull_eval<L1,G=32> + k_pull_step<Adam,L1,G=32,two-phase> (owner-computes step in two launches: every pair evaluated "
-                    "once -- 4 row gathers, hinge, 2-bit direction codes --, then one owner per row sums the records of its incidences, "
-                    "normalisation backward, dense Adam; no atomics.  Durations and traffic are the SUM of the two kernels)" if two_phase else
-                    "k_pull_step<Adam,G=32,NCH=4> (owner-computes step: per-row re-evaluation of incident pairs, hinge, backward, "
-                    "normalisation backward, dense Adam; no atomics)" if pull else
-                    "k_pull_step<gradient,G=32,NCH=4> (owner-computes gradient of the rank's share of the batch: per-row re-evaluation of "
-                    "incident pairs, hinge, backward, normalisation backward; dense gradient rows written once, no atomics)" if pull_dp else
-                    "k_transe_pair_sampled<G=32,NCH=4,CH=4> (sampler + score(+) + score(-) + hinge + backward)")
     traffic_kernels = None
     if live is not None and "bytes" in live.get("C1_train", {}):
         leg = live["C1_train"]
@@ -1071,56 +633,21 @@ def main():
                                              "over %d steps of the same step path in a child process, all kernels between the marker launches" % leg["units"])
         traffic_kernels = leg["kernels"]
     elif two_phase:
-        t1, s1 = pmc_traffic("kge::k_pull_step<1, true, 32, 1, true>", per_rank_batch, fetch_scale=2.0)
-        t2, s2 = pmc_traffic("kge::k_pull_eval<true, 32", per_rank_batch, fetch_scale=2.0)
+        t1, s1 = bench_pmc.pmc_traffic("kge::k_pull_step<1, true, 32, 1, true>", per_rank_batch, fetch_scale=2.0)
+        t2, s2 = bench_pmc.pmc_traffic("kge::k_pull_eval<true, 32", per_rank_batch, fetch_scale=2.0)
         traffic, traffic_src = (t1 + t2, "committed passes (not observed in this run: %s): %s + %s" % (live_meta, s1, s2)) if (t1 is not None and t2 is not None) else (None, None)
     else:
-        traffic, traffic_src = (None, None) if pull_dp else pmc_traffic(
+        traffic, traffic_src = (None, None) if pull_dp else bench_pmc.pmc_traffic(
             "kge::k_pull_step<1, true, 32, 1, false>" if pull else "kge::k_transe_pair_sampled<32, 4, 4", per_rank_batch, fetch_scale=2.0 if pull else 1.0)
         if traffic is not None:
             traffic_src = "committed passes (not observed in this run: %s): %s" % (live_meta, traffic_src)
     nominal = alg_bytes / (kern_ms * 1e-3) / 1e9
     achieved = traffic / (kern_ms * 1e-3) / 1e9 if traffic else nominal
-    valu = valu_record(traffic_kernels)
+    valu = bench_pmc.valu_record(traffic_kernels)
     valu_frac = None
     if valu:   # all VALU wave-instructions of a step over the step's launch time, same convention as the eval leg's roof
         insts = sum(v["valu_wave_instructions_per_step"] for v in valu.values() if isinstance(v, dict) and v.get("valu_wave_instructions_per_step"))
         valu_frac = insts / (kern_ms * 1e-3) / (VALU_SIMDS * VALU_PEAK_CLOCK_HZ / 2.0)
-    # what bounds the owner kernel when it is not bandwidth: one residency round of owner groups, each a chain of dependent loads
-    # (item -> row + optimiser state + visit lists -> records / direction codes -> stores).  Hop latency under load from the committed
-    # random-row microbenchmark, interpolated in the number of concurrently resident groups.
-    latency_model = None
-    if pull and not pull_dp:
-        ps_, idx_ = tr._pull_state()
-        n_groups = int(idx_.batch(0)[2].shape[0])       # work items = owner groups of one launch (32 lanes each)
-        resident = 256 * 4 * 8 * 2     # CUs x SIMDs x 8 waves (32-62 VGPRs) x two 32-lane owner groups per wave
-        load = min(1.0, max(0.0, (min(n_groups, resident) - 8192) / (32768 - 8192.0)))
-        hop_us = HOP_US_AT_8K_GROUPS + load * (HOP_US_AT_32K_GROUPS - HOP_US_AT_8K_GROUPS)
-        hops = 4 if two_phase else 5    # item -> {row, state, lists} -> {records + codes | three hat rows per visit -> ...} -> store drain
-        rounds = max(1.0, n_groups / float(resident))
-        stride = K.pull_hat_stride(DIM)
-        row_bytes = (E + R) * (6 * DIM * 4 + stride * 4 + 4)        # p, m, v read and written; normalised copy + norm written
-        stream_us = row_bytes / 5.0e6                                # at the ~5 TB/s an L2 / Infinity-Cache resident sweep streams (k_opt over the same tables: 7-8 us)
-        visits_us = 4.3 if two_phase else None                       # measured with the visits compiled out (profiles/r03_experiments.md section 11)
-        latency_model = {"owner_groups": n_groups, "resident_groups": resident, "residency_rounds": rounds,
-                         "dependent_hops_per_owner": hops, "hop_latency_us": hop_us,
-                         "hop_latency_source": "profiles/r03_gather_bench.txt (chain G=32: 21.53 us / 8 hops at 32768 groups, 9.23 us / 8 at 8192)",
-                         "hop_chain_us": rounds * hops * hop_us, "row_io_bytes": row_bytes, "row_io_stream_us": stream_us,
-                         "visits_us": visits_us,
-                         "predicted_owner_kernel_us": rounds * hops * hop_us + stream_us + (visits_us or 0.0),
-                         "note": "the round-3 model of the owner launch (a chain of dependent loads per owner group + the rows' read-modify-write "
-                                 "stream + the visits): kept for comparison -- it matched the 20.0 us of the round-3 kernel, but the round-4 "
-                                 "measurements below say the kernel is bound by VALU issue, not by this sum",
-                         "superseded_by": {
-                             "source": "profiles/r04_experiments.md section 7 (per-workgroup wall_clock64 timestamps + HW_REG_HW_ID of an experiment "
-                                       "build; SQ counter passes of this command in profiles/r04_pmc_traffic.json)",
-                             "resident_workgroups_per_cu": 7, "resident_limit": "SGPR file (81 SGPRs per wave)",
-                             "workgroups_per_launch": 2173, "resident_slots": 1792,
-                             "workgroup_lifetime_us": {"mean": 11.8, "p10": 6.9, "p90": 15.5, "max": 17.5},
-                             "valu_busy_frac_round3_kernel": 0.75, "valu_wave_instructions_per_wave_round3_kernel": 1005,
-                             "valu_wave_instructions_per_wave_after_first_cut": 804,
-                             "what_helped": "fewer VALU instructions per visit (2-bit two's-complement codes, coefficient tables, integer half-unit "
-                                            "sums): 29.8 -> 27.7 us per step; residency, prefetch depth and layering changes did not"}}
     if rank == 0:
         out = {
             "metric": "scored triples/sec (train) + test-triples ranked/sec, FB15k TransE d=100",
@@ -1140,21 +667,13 @@ def main():
                        "step_path_short": ("owner-computes two-phase: k_pull_eval + k_pull_step per step (kge_pull_run), no atomics" if two_phase else
                                            "owner-computes: one k_pull_step per step (kge_pull_run), no atomics" if pull else
                                            "owner-computes gradient (k_pull_step, no atomics) + exchange + kge_optimizer_step + kge_row_norms" if pull_dp else
-                                           "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step"),
-                       "step_path": "owner-computes (pull), two-phase: kge_pull_run, k_pull_eval + k_pull_step<two-phase> per step (the next batch's sampler rides in the second launch)" if two_phase else
-                                    "owner-computes (pull): kge_pull_run, one k_pull_step launch per step (the next batch's sampler rides in its leading blocks)" if pull else
-                                    "owner-computes gradient (k_pull_step, KGE_OPT_GRADIENT: no atomics) + gradient exchange (see `collectives`) + kge_optimizer_step + kge_row_norms" if pull_dp else
-                                    "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step"},
-            "roofline": {"kernel": kernel_label,
-                         "kernel_short": ("k_pull_eval<L1,32> + k_pull_step<Adam,L1,32,two-phase> (sum of both launches)" if two_phase else
+                                           "push: kge_train_pairwise_hinge_sampled (atomic scatter) + kge_optimizer_step")},
+            "roofline": {"kernel": ("k_pull_eval<L1,32> + k_pull_step<Adam,L1,32,two-phase> (sum of both launches)" if two_phase else
                                           "k_pull_step<Adam,G=32>" if pull else "k_pull_step<gradient,G=32>" if pull_dp else "k_transe_pair_sampled<32,4,4>"),
                          "traffic_src_short": (None if not traffic else "live rocprofv3 --pmc passes in this run" if traffic_kernels is not None
                                                else "committed profiles/ passes"),
                          "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "frac_basis": ("bytes that crossed the L2 <-> fabric boundary per step (PMC: 2 x FETCH_SIZE + WRITE_SIZE, `traffic`) / "
-                                        "avg_launch_ms / peak: a physical fraction, <= 1 by construction" if traffic else
-                                        "NO counter figure available (%s): algorithmic bytes / avg_launch_ms / peak -- nominal, see nominal_note" % (live_meta,)),
                          "traffic": traffic,
                          "traffic_source": traffic_src,
                          "traffic_note": ("2 x FETCH_SIZE (gfx950: 16-byte-per-lane reads are tallied at half, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; "
@@ -1170,13 +689,8 @@ def main():
                          "algorithmic_frac": nominal / HBM_PEAK_GBS,
                          "algorithmic_roof": "SURVEY 8(d): 3628 B per scored triple x scored triples per launch / avg_launch_ms / 8 TB/s (can exceed 1: "
                                              "the owner-computes step does no gradient read-modify-write and its 6.5 MB of tables stay in L2 / Infinity Cache)",
-                         "nominal_achieved": nominal, "nominal_frac": nominal / HBM_PEAK_GBS,
-                         "nominal_note": ("ALGORITHMIC bytes of SURVEY section 8(d) (forward gathers + gradient read-modify-write + ids per scored "
-                                          "triple: 3628 B) / avg_launch_ms.  The owner-computes step performs no gradient read-modify-write and "
-                                          "gathers from 6.5 MB tables that stay in L2 / Infinity Cache, so this figure can exceed 1: it is kept "
-                                          "for continuity with SURVEY 8(d), it is not a fraction of a roof the kernel can hit"),
+                         "nominal_frac": nominal / HBM_PEAK_GBS,   # (the same figure under its pre-round-6 name)
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "latency_model": latency_model,
                          "avg_launch_ms": kern_ms,
                          "avg_launch_ms_method": ("HIP events on the launch stream around the timed region / steps (%s per step; "
                                                   "includes the dispatch gaps between consecutive launches)" % ("two launches" if two_phase else "one launch") if pull else
@@ -1184,9 +698,7 @@ def main():
                                                   "the timed region (= rocprofv3 kernel duration)" % burst),
                          "burst_launch_ms": burst_ms,
                          "burst_launch_ms_note": "%d back-to-back launches of ONE batch on the initial tables (index slice hot in L2): lower bound" % burst,
-                         "timed_region_event_ms": event_ms,
-                         "timed_region_event_ms_note": "HIP events around each launch inside the timed region: includes "
-                                                       "the dispatch gap in front of the kernel"},
+                         "timed_region_event_ms": event_ms},   # (HIP events around each launch inside the timed region, dispatch gap included)
             "eval": {"value": eval_value, "unit": "test triples ranked/s", "test_triples_per_gpu": n_eval,
                      "ms_per_pass": edt * 1e3, "repeats": REPEATS, "ms_per_pass_min": eval_spread["ms_per_pass_min"],
                      "ms_per_pass_max": eval_spread["ms_per_pass_max"], "mean_rank_check": mean_rank,
@@ -1216,7 +728,7 @@ def main():
             er["traffic"], er["traffic_source"] = leg["bytes"], "observed in this run (rocprofv3 counter passes, %d passes, all kernels of a pass)" % leg["units"]
             er["traffic_kernels"] = leg["kernels"]
         else:
-            tsw, ssw = pmc_traffic("kge::k_eval_sweep<0, 0, 16", 32768, fetch_scale=2.0)
+            tsw, ssw = bench_pmc.pmc_traffic("kge::k_eval_sweep<0, 0, 16", 32768, fetch_scale=2.0)
             if tsw is not None:
                 er["traffic"], er["traffic_source"] = tsw, "committed passes, k_eval_sweep only (not observed in this run: %s): %s" % (live_meta, ssw)
         if er["traffic"]:
@@ -1231,9 +743,9 @@ def main():
         out["live_pmc"] = live_meta if not isinstance(live_meta, str) else {"unavailable": live_meta}
     if world == 1 and not args.no_extra_configs:
         extra = {}
-        for key in EXTRA_CONFIGS:
+        for key in bench_extra.EXTRA_CONFIGS:
             try:
-                extra[key] = run_extra_config(key, device)
+                extra[key] = bench_extra.run_extra_config(key, device)
                 for legname, field in ((key + "_train", "train"), (key + "_eval", "eval")):
                     leg = (live or {}).get(legname)
                     if leg and "bytes" in leg:
@@ -1257,7 +769,8 @@ def main():
         del ref_p
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H)
+            from tools import bench_cpu
+            out["cpu_baseline"] = bench_cpu.cpu_baseline(H)
         if world > 1:
             out["phases_us"] = phases_us
             allred = bool(getattr(tr, "_dp_allreduce", False))

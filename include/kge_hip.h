@@ -713,6 +713,21 @@ int kge_head_1n_forward(const float* x, int64_t batch, int32_t dim, const float*
 int kge_head_1n_forward_bf16(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
                              float* preds, void* stream);
 
+/* Filtered rank of the head WITHOUT the [B, E] prediction tensor: what the projection models' evaluation does with the head's output
+ * (projection.py:119-125: predict_tail_rank / predict_head_rank = topk(-forward(...)), consumed by MetricCalculator.get_tail_rank /
+ * get_head_rank, utils/evaluator.py:70-123): for row i, rank = #{e : p_ie > p_i,truth_i} over all E entities and the filtered rank
+ * subtracts the entities of the row's known list (CSR off int64 [B+1] / ids int32; NULL = no filter) that outrank the true one.
+ * Runs the rank sweep of kge_eval_ranks (candidate tiles x query tiles, count epilogue, matrix cores from 512 rows on) over the
+ * candidate rows [ent row | bias] and the query rows [x row | 1]; energy = -sigmoid(logit), the sigmoid being the head's own
+ * expression, so ties of saturated predictions are ties here too (ties[i] = candidates whose prediction equals the true one's bit
+ * for bit, the true one excluded; may be NULL).  triples: int64 [B, 3], column 2 = the true entity of row i (columns 0 / 1: any
+ * valid ids, not read).  ranks: int32 [2, B] = rank, filtered rank (0-based).  energies (optional, tests): float [B, E], the
+ * sweep's -p values instead of ranks (ranks / ties are then not written).  workspace: kge_head_1n_rank_workspace_bytes. */
+size_t kge_head_1n_rank_workspace_bytes(int64_t batch, int32_t dim, int64_t tot_entity, int32_t has_bias);
+int kge_head_1n_rank(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
+                     const int64_t* triples, const int64_t* off, const int32_t* ids, void* workspace, size_t workspace_bytes,
+                     int32_t* ranks, int32_t* ties, float* energies, void* stream);
+
 /* Autograd backward of the head given d loss / d preds: dx[B,dim] is overwritten, g_ent[E,dim] and g_bias[E] are
  * accumulated into (any of the three may be NULL).  workspace (kge_head_1n_backward_workspace_bytes(), a constant; may be NULL):
  * room for the partial tiles of the split-K products, which are then added in split order -- bit-reproducible gradients; without it

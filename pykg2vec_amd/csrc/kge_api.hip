@@ -800,6 +800,25 @@ int kge_head_1n_forward_bf16(const float* x, int64_t batch, int32_t dim, const f
     return launch_head_forward(x, batch, dim, ent, tot_entity, bias, preds, 1, (hipStream_t)stream);
 }
 
+size_t kge_head_1n_rank_workspace_bytes(int64_t batch, int32_t dim, int64_t tot_entity, int32_t has_bias) {
+    if (batch < 0 || dim <= 0 || tot_entity <= 0) return 0;
+    return head_rank_workspace_bytes(batch, dim, tot_entity, has_bias != 0);
+}
+
+int kge_head_1n_rank(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* bias,
+                     const int64_t* triples, const int64_t* off, const int32_t* ids, void* workspace, size_t workspace_bytes,
+                     int32_t* ranks, int32_t* ties, float* energies, void* stream) {
+    if (batch == 0) return 0;
+    if (batch < 0 || dim <= 0 || tot_entity <= 0 || !x || !ent || !triples || (!ranks && !energies) || ((off == nullptr) != (ids == nullptr))) {
+        set_error("kge_head_1n_rank: bad arguments");
+        return -1;
+    }
+    if (tot_entity >= (1ll << 31)) { set_error("kge_head_1n_rank: entity ids must fit 31 bits"); return -1; }
+    if (int rc = debug_check_ids("kge_head_1n_rank", "true entity", triples, batch, 3, 2, tot_entity, (hipStream_t)stream)) return rc;
+    return launch_head_rank(x, batch, dim, ent, tot_entity, bias, triples, off, ids, workspace, workspace_bytes, ranks, ties, energies,
+                            (hipStream_t)stream);
+}
+
 size_t kge_head_1n_backward_workspace_bytes(void) { return head_backward_workspace_bytes(); }
 
 int kge_head_1n_backward(const float* x, int64_t batch, int32_t dim, const float* ent, int64_t tot_entity, const float* preds,

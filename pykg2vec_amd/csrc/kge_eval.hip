@@ -29,6 +29,7 @@
 // reuse the kernel is VALU-bound (2 lane-ops per element per pair for L1), not HBM-bound.
 #include "kge_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace kge {
 
@@ -51,10 +52,11 @@ enum Form { F_L1 = 0, F_L2 = 1, F_SQM = 2, F_NEGDOT = 3 };
 enum XForm { X_NONE = 0, X_TRANSH = 1, X_TRANSD = 2 };
 // per-query post-op on the finished energy: TransM multiplies by theta_r (pairwise.py:341-347), SimplE clamps to
 // [-20, 20] (pointwise.py:525-526)
-enum Post { P_NONE = 0, P_SCALE = 1, P_CLAMP = 2 };
+enum Post { P_NONE = 0, P_SCALE = 1, P_CLAMP = 2, P_SIGMOID = 3 };   // P_SIGMOID: the 1-N head (energy = -sigmoid(logit), kge_head_1n_rank)
 
 struct EvalPlan {
-    int64_t nq;   // query rows the sweep walks: 2n (tail + head sweep per triple), n for a one-sided score sweep
+    int64_t nq;   // query rows the sweep walks: 2n (tail + head sweep per triple), n for a one-sided sweep
+    int only;     // 2 = both sides (query row 2i + side); 0 / 1 = one-sided (query row i = triple i's tail / head sweep)
     int64_t E, n, tables, table_stride;  // tables > 1: one projected candidate table per relation group (TransR)
     int K, Kpad, QV, form, xform, post;
     int64_t ntiles;
@@ -71,12 +73,13 @@ static int sweep_K(const kge_model_desc* m) {
         case KGE_CP: case KGE_SIMPLE: case KGE_SIMPLE_IGNR: return 2 * m->dim;  // both entity tables side by side
         case KGE_QUATE: return 4 * m->dim;
         case KGE_TRANSR: return m->rel_dim;  // candidates live in the relation space of the call's relation
+        case KGE_HEAD_1N_INTERNAL: return m->dim + (m->tables[1] ? 1 : 0);   // [ent row | bias] . [x | 1]
         default: return m->dim;
     }
 }
 
 static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p, int64_t tables = 1) {
-    p->E = m->tot_entity; p->n = n; p->nq = 2 * n; p->tables = tables;
+    p->E = m->tot_entity; p->n = n; p->nq = 2 * n; p->only = 2; p->tables = tables;
     const bool per_group_tables = tables > 1 || m->model == KGE_TRANSR;  // candidates already transformed per relation group
     p->K = sweep_K(m);
     p->Kpad = (p->K + KC - 1) / KC * KC;
@@ -87,10 +90,11 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p,
             p->form = (m->flags & KGE_FLAG_L1) ? F_L1 : F_L2; break;
         case KGE_ROTATE: p->form = F_SQM; break;
         case KGE_DISTMULT: case KGE_COMPLEX: case KGE_ANALOGY: case KGE_RESCAL:
-        case KGE_CP: case KGE_SIMPLE: case KGE_SIMPLE_IGNR: case KGE_QUATE: p->form = F_NEGDOT; break;
+        case KGE_CP: case KGE_SIMPLE: case KGE_SIMPLE_IGNR: case KGE_QUATE: case KGE_HEAD_1N_INTERNAL: p->form = F_NEGDOT; break;
         default: return false;
     }
-    p->post = m->model == KGE_TRANSM ? P_SCALE : (m->model == KGE_SIMPLE || m->model == KGE_SIMPLE_IGNR) ? P_CLAMP : P_NONE;
+    p->post = m->model == KGE_TRANSM ? P_SCALE : (m->model == KGE_SIMPLE || m->model == KGE_SIMPLE_IGNR) ? P_CLAMP
+              : m->model == KGE_HEAD_1N_INTERNAL ? P_SIGMOID : P_NONE;
     p->ntiles = (p->E + 63) / 64;
     size_t off = 0;
     char* base = (char*)ws;
@@ -486,6 +490,11 @@ __global__ __launch_bounds__(256) void k_eval_queries(DeviceModel m, const int64
                 if constexpr (M == KGE_TRANSD) { qt[Kpad + k] = rm[k]; qh[Kpad + k] = rm[k]; }
             }
         }
+    } else if constexpr (M == KGE_HEAD_1N_INTERNAL) {
+        // the 1-N head: the query IS the caller's activation row (one-sided: row i of x), extended by the 1 that multiplies the bias
+        const float* x = m.tab[2] + i * d;
+        for (int k = lane; k < d; k += TPT) { qt[k] = x[k]; qh[k] = 0.f; }
+        if (lane == 0 && m.tab[1] != nullptr) { qt[d] = 1.0f; qh[d] = 0.f; }
     } else if constexpr (M == KGE_DISTMULT) {
         const float* eh = m.tab[0] + h * d; const float* er = m.tab[1] + r * d; const float* et = m.tab[0] + t * d;
         for (int k = lane; k < d; k += TPT) { qt[k] = eh[k] * er[k]; qh[k] = er[k] * et[k]; }
@@ -614,6 +623,7 @@ template <int POST>
 __device__ __forceinline__ float pair_post(float s, float scale) {
     if constexpr (POST == P_SCALE) return scale * s;
     else if constexpr (POST == P_CLAMP) return fminf(fmaxf(s, -20.f), 20.f);
+    else if constexpr (POST == P_SIGMOID) return -(1.0f / (1.0f + expf(s)));   // s = -logit: the head's own sigmoid expression (kge_head.hip)
     else return s;
 }
 
@@ -716,13 +726,13 @@ __global__ __launch_bounds__(256) void k_eval_target_filter(const float* __restr
                                                             const int64_t* __restrict__ tail_off, const int32_t* __restrict__ tail_ids,
                                                             const int64_t* __restrict__ head_off, const int32_t* __restrict__ head_ids,
                                                             float* __restrict__ st, int32_t* __restrict__ fcount,
-                                                            const int32_t* __restrict__ group_of_triple, int64_t table_stride) {
+                                                            const int32_t* __restrict__ group_of_triple, int64_t table_stride, int only) {
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= 2 * n) return;
-    const int64_t i = qi >> 1;
+    if (qi >= (only == 2 ? 2 * n : n)) return;
+    const int64_t i = only == 2 ? qi >> 1 : qi;        // one-sided sweeps (only = 0 / 1): query row i IS triple i's tail / head sweep
     if (group_of_triple) cand += group_of_triple[i] * table_stride;  // grouped evaluation: this query's candidate table
-    const int side = (int)(qi & 1);
+    const int side = only == 2 ? (int)(qi & 1) : only;
     const int64_t truth = side == 0 ? triples[3 * i + 2] : triples[3 * i];
     const float* q = qvec + qi * (int64_t)QV * Kpad;
     const float scale = POST == P_SCALE ? qscale[qi] : 1.0f;
@@ -759,15 +769,15 @@ __global__ __launch_bounds__(256, 4) void k_eval_target_filter_chain(PrepArgs a,
                                                                   const int64_t* __restrict__ triples, int64_t n, int Kpad, float margin,
                                                                   const int64_t* __restrict__ tail_off, const int32_t* __restrict__ tail_ids,
                                                                   const int64_t* __restrict__ head_off, const int32_t* __restrict__ head_ids,
-                                                                  float* __restrict__ st, int32_t* __restrict__ fcount) {
+                                                                  float* __restrict__ st, int32_t* __restrict__ fcount, int only) {
     static_assert(FORM == F_NEGDOT || FORM == F_SQM, "chain order: plain dot-product based forms");
     __shared__ __attribute__((aligned(16))) float s_c[4][kChainElems + 4 * 64];   // [pair][chunk + 4]: rows 4 banks apart
     __shared__ __attribute__((aligned(16))) float s_q[4][kChainElems / 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wv;
-    if (qi >= 2 * n) return;
-    const int64_t i = qi >> 1;
-    const int side = (int)(qi & 1);
+    if (qi >= (only == 2 ? 2 * n : n)) return;
+    const int64_t i = only == 2 ? qi >> 1 : qi;
+    const int side = only == 2 ? (int)(qi & 1) : only;
     const int truth = (int)(side == 0 ? triples[3 * i + 2] : triples[3 * i]);
     const float* q = qvec + qi * (int64_t)Kpad;
     const float qn = FORM == F_SQM ? qnorm[qi] : 0.f;   // |q|^2
@@ -1461,6 +1471,16 @@ __global__ void k_eval_finalize(const int32_t* __restrict__ rcount, const int32_
     ranks[3 * n + i] = rt - fcount[2 * i];       // filtered tail
 }
 
+// one-sided sweeps: query row i = triple i; ranks [2, n] = rank, filtered rank; ties [n]
+__global__ void k_eval_finalize_side(const int32_t* __restrict__ rcount, const int32_t* __restrict__ fcount, int64_t n,
+                                     int32_t* __restrict__ ranks, const int32_t* __restrict__ tcount, int32_t* __restrict__ ties) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (ties) ties[i] = max(0, tcount[i] - 1);
+    ranks[i] = rcount[i];
+    ranks[n + i] = rcount[i] - fcount[i];
+}
+
 // ------------------------------------------------------------------ ranks from materialised score rows
 // (models without a pre-contracted sweep form, i.e. NTN: scores come from kge_score_forward over all candidates)
 __global__ __launch_bounds__(256) void k_rank_from_scores(const float* __restrict__ scores, int64_t nq, int64_t E,
@@ -1515,6 +1535,9 @@ static void fill_prep(const kge_model_desc* m, const EvalPlan& p, PrepArgs* a) {
         case KGE_ANALOGY:
             a->nseg = 3; a->seg[1] = m->tables[2]; a->seg_dim[1] = m->dim / 2;
             a->seg[2] = m->tables[3]; a->seg_dim[2] = m->dim / 2; break;
+        case KGE_HEAD_1N_INTERNAL:   // candidate row = [ent row | bias]: the bias joins the logit as the chain's last term, bias * 1
+            if (m->tables[1]) { a->nseg = 2; a->seg[1] = m->tables[1]; a->seg_dim[1] = 1; }
+            break;
         default: break;
     }
 }
@@ -1563,7 +1586,7 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
                 fill_prep(m, p, &pa);
                 hipLaunchKernelGGL((k_eval_target_filter_chain<FORM, POST>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, pa, p.aux,
                                    p.qvec, p.qscale, triples, p.n, p.Kpad, m->margin, tail_off, tail_ids, head_off, head_ids, p.st,
-                                   p.fcount);
+                                   p.fcount, p.only);
                 hipLaunchKernelGGL((k_eval_gemm<false, POST, SQM>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
                                    nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, p.tcount, nullptr, p.qscale, p.aux, m->margin);
             } else {
@@ -1576,7 +1599,7 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
     if (scores_out == nullptr)
         hipLaunchKernelGGL((k_eval_target_filter<FORM, XFORM, POST>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p.cand,
                            p.aux, p.qvec, p.qscale, triples, p.n, p.Kpad, p.QV, m->margin, tail_off, tail_ids, head_off, head_ids,
-                           p.st, p.fcount, group_of_triple, p.table_stride);
+                           p.st, p.fcount, group_of_triple, p.table_stride, p.only);
     if (scores_out == nullptr) {
         hipLaunchKernelGGL((k_eval_sweep<FORM, XFORM, QT, false, POST>), dim3(grid), dim3(256), 0, s, p.cand, p.aux, p.qvec,
                            p.qscale, p.st, nq, p.E, p.ntiles, p.Kpad, p.QV, m->margin, (int)S, qblocks, p.rcount, p.tcount, nullptr,
@@ -1593,12 +1616,13 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
                         size_t ws_bytes, int32_t* ranks, int32_t* ties, float* scores_out, hipStream_t s, int side = 2) {
     EvalPlan p;
     if (!make_plan(m, n, ws, &p)) { set_error("kge_eval: model %d has no sweep form", m->model); return -1; }
-    if (side != 2) {
-        if (scores_out == nullptr || (side != 0 && side != 1) || m->model == KGE_TRANSR) {
-            set_error("kge_eval: one-sided sweeps write scores only (side 0 = tail, 1 = head; TransR projects per call: use both sides)");
+    if (side != 2) {   // one-sided: scores [n, E], or ranks [2, n] = (rank, filtered rank) of that side (ties [n])
+        if ((side != 0 && side != 1) || m->model == KGE_TRANSR) {
+            set_error("kge_eval: one-sided sweeps take side 0 = tail or 1 = head (TransR projects per call: use both sides)");
             return -1;
         }
         p.nq = n;
+        p.only = side;
     }
     if (ws == nullptr || ws_bytes < p.bytes) {
         set_error("kge_eval: workspace too small (%zu < %zu)", ws_bytes, p.bytes);
@@ -1649,7 +1673,7 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
     switch (m->model) {
         KGE_Q(KGE_TRANSE) KGE_Q(KGE_TRANSH) KGE_Q(KGE_TRANSD) KGE_Q(KGE_ROTATE) KGE_Q(KGE_DISTMULT)
         KGE_Q(KGE_COMPLEX) KGE_Q(KGE_ANALOGY) KGE_Q(KGE_RESCAL)
-        KGE_Q(KGE_TRANSM) KGE_Q(KGE_CP) KGE_Q(KGE_SIMPLE) KGE_Q(KGE_SIMPLE_IGNR) KGE_Q(KGE_QUATE)
+        KGE_Q(KGE_TRANSM) KGE_Q(KGE_CP) KGE_Q(KGE_SIMPLE) KGE_Q(KGE_SIMPLE_IGNR) KGE_Q(KGE_QUATE) KGE_Q(KGE_HEAD_1N_INTERNAL)
         default: set_error("kge_eval: unsupported model %d", m->model); return -1;
     }
 #undef KGE_Q
@@ -1661,6 +1685,8 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
         else launch_tf_and_sweep<F_L2, X_NONE, P_SCALE>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s);
     } else if (p.post == P_CLAMP) {
         launch_tf_and_sweep<F_NEGDOT, X_NONE, P_CLAMP>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s);
+    } else if (p.post == P_SIGMOID) {
+        launch_tf_and_sweep<F_NEGDOT, X_NONE, P_SIGMOID>(p, m, triples, tail_off, tail_ids, head_off, head_ids, scores_out, s);
     } else if (p.xform == X_NONE) {
         switch (p.form) {
             case F_L1: KGE_S(F_L1, X_NONE); break;
@@ -1674,8 +1700,10 @@ static int run_pipeline(const kge_model_desc* m, const int64_t* triples, int64_t
         if (p.form == F_L1) KGE_S(F_L1, X_TRANSD); else KGE_S(F_L2, X_TRANSD);
     }
 #undef KGE_S
-    if (scores_out == nullptr)
-        hipLaunchKernelGGL(k_eval_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.rcount, p.fcount, n, ranks, p.tcount, ties);
+    if (scores_out == nullptr) {
+        if (side == 2) hipLaunchKernelGGL(k_eval_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.rcount, p.fcount, n, ranks, p.tcount, ties);
+        else hipLaunchKernelGGL(k_eval_finalize_side, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.rcount, p.fcount, n, ranks, p.tcount, ties);
+    }
     return check_launch("kge_eval pipeline");
 }
 
@@ -1744,6 +1772,30 @@ int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, in
         return launch_ntn_eval_scores(m, triples, n, ws, ws_bytes, scores, s);
     }
     return run_pipeline(m, triples, n, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, nullptr, nullptr, scores, s, side);
+}
+
+static kge_model_desc head_rank_desc(const float* x, int dim, const float* ent, int64_t E, const float* bias) {
+    kge_model_desc m;
+    memset(&m, 0, sizeof(m));
+    m.model = KGE_HEAD_1N_INTERNAL;
+    m.tot_entity = E; m.tot_relation = 1; m.dim = dim; m.rel_dim = dim;
+    m.tables[0] = const_cast<float*>(ent); m.tables[1] = const_cast<float*>(bias); m.tables[2] = const_cast<float*>(x);
+    return m;
+}
+
+size_t head_rank_workspace_bytes(int64_t n, int dim, int64_t E, bool has_bias) {
+    static const float one = 1.0f;   // (only its non-NULLness is read: the plan adds the bias column)
+    const kge_model_desc m = head_rank_desc(nullptr, dim, nullptr, E, has_bias ? &one : nullptr);
+    EvalPlan p;
+    return make_plan(&m, n, nullptr, &p) ? p.bytes : 0;
+}
+
+// triples: int64 [n, 3] whose column 2 holds the true entity of row i (columns 0 / 1 are not read beyond the id check)
+int launch_head_rank(const float* x, int64_t n, int dim, const float* ent, int64_t E, const float* bias, const int64_t* triples,
+                     const int64_t* off, const int32_t* ids, void* ws, size_t ws_bytes, int32_t* ranks, int32_t* ties, float* energies,
+                     hipStream_t s) {
+    const kge_model_desc m = head_rank_desc(x, dim, ent, E, bias);
+    return run_pipeline(&m, triples, n, off, ids, nullptr, nullptr, ws, ws_bytes, ranks, ties, energies, s, 0);
 }
 
 }  // namespace kge

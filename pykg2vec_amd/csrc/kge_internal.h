@@ -254,6 +254,14 @@ int launch_eval_ranks(const kge_model_desc* m, const int64_t* triples, int64_t n
                       size_t ws_bytes, int32_t* ranks, int32_t* ties /* [2, n] or NULL */, hipStream_t s);
 int launch_eval_sweep_scores(const kge_model_desc* m, const int64_t* triples, int64_t n, void* ws, size_t ws_bytes,
                              float* scores, hipStream_t s, int side = 2);
+// The 1-N head's filtered rank through the same sweep pipeline (kge_head_1n_rank): a pseudo-model, internal to the library, whose
+// "candidate table" is [ent row | bias] and whose query vectors are the caller's activation rows [x | 1]; energy = -sigmoid(logit).
+// tables[0] = ent [E, dim], tables[1] = bias [E] or NULL, tables[2] = x [n, dim].
+constexpr int KGE_HEAD_1N_INTERNAL = 100;
+size_t head_rank_workspace_bytes(int64_t n, int dim, int64_t E, bool has_bias);
+int launch_head_rank(const float* x, int64_t n, int dim, const float* ent, int64_t E, const float* bias, const int64_t* triples,
+                     const int64_t* off, const int32_t* ids, void* ws, size_t ws_bytes, int32_t* ranks, int32_t* ties, float* energies,
+                     hipStream_t s);
 
 int launch_rank_from_scores(const float* scores, int64_t nq, int64_t E, const int64_t* truth, const int64_t* off,
                             const int32_t* ids, int32_t* rank, int32_t* frank, hipStream_t s);

@@ -26,3 +26,11 @@ def multi_class_bce_step(x, ent_weight, bias, label_off, label_ids, label_smooth
     b = None if bias is None else bias.contiguous().view(-1)
     gb = None if g_bias is None else g_bias.view(-1)
     return K.head_1n_bce(x.contiguous(), ent_weight.contiguous(), b, label_off, label_ids, label_smoothing, loss_buf, g_ent, gb)
+
+
+def one_to_n_rank(x, ent_weight, bias, truth, known_off=None, known_ids=None, return_ties=False):
+    """Evaluation form of the head (models/projection.py:119-125 + utils/evaluator.py:70-123): int32 [2, B] = for every row the number
+    of entities predicted strictly above the true one, and the same count without the row's known entities (CSR known_off int64
+    [B+1] / known_ids int32).  No [B, E] tensor is formed: the rank sweep's tiles count against the true entity's prediction."""
+    b = None if bias is None else bias.contiguous().view(-1)
+    return K.head_1n_rank(x.contiguous(), ent_weight.contiguous(), b, truth.contiguous(), known_off, known_ids, return_ties=return_ties)

@@ -1212,6 +1212,31 @@ def head_1n_forward(x, ent, bias=None, precision="f32"):
     return preds
 
 
+def head_1n_rank(x, ent, bias, truth, off=None, ids=None, return_ties=False, energies=False):
+    """(rank, filtered rank) int32 [2, B] of the true entity of every row under sigmoid(x @ ent.T + bias), without the [B, E] tensor
+    (kge_head_1n_rank).  truth int64 [B]; off int64 [B+1] / ids int32: CSR of the entities known for each row (None = unfiltered).
+    energies=True (tests): the sweep's float32 [B, E] energies -p instead."""
+    B, d = x.shape
+    E = ent.shape[0]
+    dev = x.device
+    trip = torch.zeros((B, 3), dtype=torch.int64, device=dev)
+    trip[:, 2] = truth
+    lib = L.load()
+    ws = torch.empty(max(1, lib.kge_head_1n_rank_workspace_bytes(B, d, E, int(bias is not None))), dtype=torch.uint8, device=dev)
+    ranks = torch.empty((2, B), dtype=torch.int32, device=dev)
+    ties = torch.empty(B, dtype=torch.int32, device=dev) if return_ties else None
+    out = torch.empty((B, E), dtype=torch.float32, device=dev) if energies else None
+    L.check(lib.kge_head_1n_rank(_f32(x, "x"), B, d, _f32(ent, "ent"), E, _f32(bias.view(-1), "bias") if bias is not None else None,
+                                 _ids(trip, "triples"), _dev(off, torch.int64, "csr offsets") if off is not None else None,
+                                 _dev(ids, torch.int32, "csr ids") if ids is not None else None,
+                                 _dev(ws, torch.uint8, "workspace"), ws.numel(), _dev(ranks, torch.int32, "ranks"),
+                                 _dev(ties, torch.int32, "ties") if ties is not None else None,
+                                 _f32(out, "energies") if out is not None else None, _stream()), "kge_head_1n_rank")
+    if energies:
+        return out
+    return (ranks, ties) if return_ties else ranks
+
+
 def head_1n_backward(x, ent, preds, dpreds, need_bias=True, workspace=True):
     """(dx, g_ent, g_bias) of the head given d loss / d preds (kge_head_1n_backward).  workspace=False: the entry point's
     workspace-free form (split-K partial tiles meet in float atomics instead of being added in a fixed order)."""

@@ -186,7 +186,8 @@ def _grad_from_state1(optimizer, s1):
     return {"adam": lambda m: m / 0.1, "adagrad": np.sqrt, "rms": lambda s: np.sqrt(s / 0.01)}[optimizer](np.asarray(s1, np.float64))
 
 
-def check_step_against_reference(name, loss, tables, state1, state2, report, loss_rtol=3e-5, state_rtol=1e-4, row_atol=None):
+def check_step_against_reference(name, loss, tables, state1, state2, report, loss_rtol=3e-5, state_rtol=1e-4, row_atol=None,
+                                 state_floor=5e-5, state2_rtol=None):
     """tables / state1 / state2: {state_dict key: array}.  Untouched rows must equal the reference's bit for bit (dense optimisers
     with zero gradient and zero state leave a row unchanged); gradient-carrying quantities (optimiser state) agree to fp32 noise over
     ALL rows (float64 row digests); the listed rows of the updated tables agree element-wise wherever the gradient is not noise."""
@@ -204,7 +205,7 @@ def check_step_against_reference(name, loss, tables, state1, state2, report, los
         scale1 = max(float(np.abs(ref_s1).max()), 1e-12)
         d1 = np.abs(got_s1 - ref_s1)
         # (Adagrad / RMSprop keep SQUARED gradients: twice the relative error; relation rows sum thousands of cancelling terms)
-        assert np.all(d1 <= state_rtol * np.abs(ref_s1) + 5e-5 * scale1), (key, "state1 rows", float(d1.max()), scale1)
+        assert np.all(d1 <= state_rtol * np.abs(ref_s1) + state_floor * scale1), (key, "state1 rows", float(d1.max()), scale1)
         g = np.abs(_grad_from_state1(opt, ref_s1))
         solid = g >= GRAD_FLOOR_REL * max(float(g.max()), 1e-30)
         dp = np.abs(got_rows - ref_rows)
@@ -236,7 +237,7 @@ def check_step_against_reference(name, loss, tables, state1, state2, report, los
             got_s2 = np.asarray(state2[key])[rows][:, :gu.DIGEST_COLS]
             scale2 = max(float(np.abs(ref_s2).max()), 1e-30)
             d2 = np.abs(got_s2 - ref_s2)
-            assert np.all(d2 <= 2 * state_rtol * np.abs(ref_s2) + 4e-6 * scale2), (key, "state2 rows", float(d2.max()), scale2)
+            assert np.all(d2 <= 2 * (state2_rtol or state_rtol) * np.abs(ref_s2) + 4e-6 * scale2), (key, "state2 rows", float(d2.max()), scale2)
             entry["max_abs_diff_state2_rows"] = float(d2.max())
         rep["tables"][key] = entry
     report[name] = rep
@@ -301,7 +302,10 @@ def test_hip_default_path_step_matches_reference_at_full_size(name):
     os.makedirs(out, exist_ok=True)
     fn = os.path.join(out, "step_agreement_fullsize.json")
     doc = json.load(open(fn)) if os.path.exists(fn) else {}
-    rep = check_step_against_reference(name, loss, tables, s1, s2, doc)
+    # round 6 ratchet: ~3x the largest deviations on record (profiles/r05_step_agreement_fullsize.json,
+    # r06_step_agreement_fullsize.json) -- loss 1.2e-7 relative, row digests of the optimiser state 3.2e-6 relative; the element-wise
+    # floor stays at 5e-5 of the state's scale: C2's relation rows (Adagrad: SQUARED sums of ~900 cancelling terms) sit at 2.4e-5
+    rep = check_step_against_reference(name, loss, tables, s1, s2, doc, loss_rtol=5e-7, state_rtol=1e-5, state_floor=5e-5, state2_rtol=1e-4)
     rep["path"] = path + (", two-phase" if path == "pull" and tr._pull.direction is not None else "")
     json.dump(doc, open(fn, "w"), indent=1)
 
@@ -377,5 +381,9 @@ def test_hip_ranks_on_the_wide_sample_with_float64_arbitration(name):
     doc[name] = report
     json.dump(doc, open(path, "w"), indent=1)
     # near-ties are rare on these tables except RotatE d = 1000 (see the fixture's own fp32-vs-float64 count); a systematic deviation
-    # would flip many more
-    assert len(differ) <= (0.5 if name == "c3_rotate" else 0.2) * n
+    # would flip many more.  Round 6 ratchet: ~2x the observed share of triples with a differing rank (profiles/r06_rank_agreement_wide.json:
+    # C1 1.6 % / 0.8 %, C2 0.2 % -- 1.0 % before the chunked k chain --, C3 31 %, C4 0 of 16)
+    limit = {"c1_transe_l1": 0.03, "c1_transe_l2": 0.03, "c2_complex": 0.02, "c3_rotate": 0.40, "c4_rescal": 1.0 / 16}[name]
+    assert len(differ) <= limit * n, (len(differ), n)
+    if name == "c2_complex":   # no longer one-sided against the HIP path by a margin (round 5: float64 sided with the reference 10 : 0)
+        assert report["reference_equals_float64"] <= 4, report

@@ -821,6 +821,83 @@ def test_head_1n_vs_oracle_other_shapes(hip, B, E, d, with_bias):
     assert np.allclose(g_ent.cpu().numpy(), ge_ref, atol=1e-3 * scale, rtol=1e-3)
 
 
+def _head_csr(labels):
+    """CSR (int64 offsets, int32 ids) of the positive columns of a multi-hot [B, E] array."""
+    off = np.zeros(labels.shape[0] + 1, np.int64)
+    off[1:] = np.cumsum((labels > 0).sum(1))
+    ids = np.concatenate([np.flatnonzero(row > 0) for row in labels]).astype(np.int32) if off[-1] else np.zeros(0, np.int32)
+    return off, ids
+
+
+def test_head_1n_rank_matches_reference_golden(hip):
+    """kge_head_1n_rank against the LIVE REFERENCE's head outputs (tests/golden/ref_head_1n.npz: sigmoid(x @ ent.T + b) of
+    projection.py:100-102): what the reference's evaluation makes of such a row -- topk(-preds) scanned from the best end by
+    MetricCalculator.get_tail_rank (projection.py:119-125, utils/evaluator.py:70-123) -- is the number of entities predicted strictly
+    above the true one, filtered by the row's known entities (the fixture's multi-hot hr_t / tr_h rows)."""
+    import os
+    from golden_util import GOLDEN
+    from pykg2vec_amd.head import one_to_n_rank
+    z = np.load(os.path.join(GOLDEN, "ref_head_1n.npz"))
+    rng = np.random.default_rng(5)
+    B, E = int(z["B"]), int(z["E"])
+    for xs, preds, labels in ((z["x_t"], z["plain.pred_t"], z["hr_t"]), (z["x_h"], z["plain.pred_h"], z["tr_h"])):
+        truth = rng.integers(E, size=B)
+        off, ids = _head_csr(labels)
+        got = one_to_n_rank(hip.dev(xs, torch.float32), hip.dev(z["ent"], torch.float32), hip.dev(z["bias"], torch.float32),
+                            hip.dev(truth), hip.dev(off), hip.dev(ids, torch.int32)).cpu().numpy()
+        for i in range(B):
+            known = set(np.flatnonzero(labels[i] > 0).tolist())
+            want = ko.rank_from_scores(-preds[i], int(truth[i]), known)
+            if (int(got[0, i]), int(got[1, i])) != want:        # only a candidate within fp32 noise of the true one may move a rank
+                near = int((np.abs(preds[i] - preds[i, truth[i]]) <= 2e-6).sum()) - 1
+                assert abs(int(got[0, i]) - want[0]) <= near and abs(int(got[1, i]) - want[1]) <= near, (i, got[:, i].tolist(), want, near)
+
+
+@pytest.mark.parametrize("B,E,d,with_bias", [(37, 203, 45, True), (5, 64, 8, False), (600, 5003, 200, True), (1030, 777, 33, False)])
+def test_head_1n_rank_is_the_rank_of_its_own_energies(hip, B, E, d, with_bias):
+    """Ranks are exact functions of the sweep's fp32 energies (the materialised form of the same call), the energies are the head's
+    predictions negated, and nothing [B, E]-sized is needed for the ranks.  B >= 512 takes the matrix-core sweep."""
+    from pykg2vec_amd import kernels as K
+    rng = np.random.default_rng(B + E)
+    x = rng.normal(size=(B, d)).astype(np.float32)
+    ent = (rng.normal(size=(E, d)) * 0.3).astype(np.float32)
+    bias = (rng.normal(size=E) * 0.1).astype(np.float32) if with_bias else None
+    truth = rng.integers(E, size=B)
+    labels = (rng.random((B, E)) < 0.02).astype(np.float32)
+    labels[np.arange(B), truth] = 1.0
+    labels[0] = 0.0                                   # a row without known entities
+    off, ids = _head_csr(labels)
+    xd, ed = hip.dev(x, torch.float32), hip.dev(ent, torch.float32)
+    bd = hip.dev(bias, torch.float32) if with_bias else None
+    ranks, ties = K.head_1n_rank(xd, ed, bd, hip.dev(truth), hip.dev(off), hip.dev(ids, torch.int32), return_ties=True)
+    ranks, ties = ranks.cpu().numpy(), ties.cpu().numpy()
+    en = K.head_1n_rank(xd, ed, bd, hip.dev(truth), energies=True).cpu().numpy()
+    preds = K.head_1n_forward(xd, ed, bd).cpu().numpy()
+    # (the rank sweep restarts its k chain every 64 elements from 512 rows on, the head's forward GEMM does not: logits differ by ~1e-6)
+    assert np.allclose(-en, preds, atol=4e-6, rtol=1e-5), np.abs(en + preds).max()
+    for i in range(B):
+        known = set(np.flatnonzero(labels[i] > 0).tolist())
+        assert (int(ranks[0, i]), int(ranks[1, i])) == ko.rank_from_scores(en[i], int(truth[i]), known), i
+        assert ties[i] == int((en[i] == en[i, truth[i]]).sum()) - 1
+    unf = K.head_1n_rank(xd, ed, bd, hip.dev(truth)).cpu().numpy()
+    assert np.array_equal(unf[0], ranks[0]) and np.array_equal(unf[1], unf[0])       # no filter lists: filtered == raw
+
+
+def test_head_1n_rank_reports_saturated_ties(hip):
+    """sigmoid saturates to exactly 1.0f for logits beyond ~17: such candidates tie with a saturated true entity (the reference's
+    order among them is torch.topk's, unspecified); the strict count leaves them out and the tie report names them."""
+    from pykg2vec_amd import kernels as K
+    E, d = 300, 16
+    ent = np.zeros((E, d), np.float32)
+    ent[:40, 0] = 30.0                                 # 40 saturated candidates for a query pointing along axis 0
+    ent[40:, 0] = np.linspace(-3, 3, E - 40)
+    x = np.zeros((2, d), np.float32)
+    x[:, 0] = 1.0
+    truth = np.asarray([3, 100])
+    ranks, ties = K.head_1n_rank(hip.dev(x, torch.float32), hip.dev(ent, torch.float32), None, hip.dev(truth), return_ties=True)
+    assert ranks[0].tolist() == [0, 40 + (E - 40 - 1 - 60)] and ties.tolist() == [39, 0]
+
+
 @pytest.mark.parametrize("B,E,d,with_bias", [(128, 1000, 200, True), (70, 333, 50, False), (1, 64, 8, True), (257, 129, 97, True),
                                              (512, 14951, 200, True)])
 def test_head_1n_bf16_option(hip, B, E, d, with_bias):

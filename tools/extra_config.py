@@ -7,11 +7,12 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+from tools import bench_extra
 
 key = sys.argv[1]
 for a in sys.argv[2:]:
     if a.startswith("--optimizer="):      # A/B of the optimiser kinds on a config's shape (the bench itself keeps the preset's)
-        bench.EXTRA_CONFIGS[key]["optimizer"] = a.split("=", 1)[1]
-out = bench.run_extra_config(key, "cuda:0")
+        bench_extra.EXTRA_CONFIGS[key]["optimizer"] = a.split("=", 1)[1]
+out = bench_extra.run_extra_config(key, "cuda:0")
 keep = ("mode", "step_us", "scored_triples_per_s") + (("eval_ms_per_pass", "eval_test_triples_per_s", "eval_setup_ms") if "--eval" in sys.argv else ())
 print(json.dumps({k: out[k] for k in keep}))

@@ -6,10 +6,11 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
+from tools import bench_extra
 from pykg2vec_amd import kernels as K
 
 dev = "cuda:0"
-c, cfg, model, tr, q, steps = bench.build_extra_config("C4", dev, steps_cap=20)
+c, cfg, model, tr, q, steps = bench_extra.build_extra_config("C4", dev, steps_cap=20)
 tr.train_model_epoch(0)
 flat, ent = tr.flat, tr.flat.views[0]
 n0, E, k = ent.numel(), ent.shape[0], ent.shape[1]

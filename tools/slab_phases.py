@@ -6,9 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench
+from tools import bench_extra
 from pykg2vec_amd import _lib as L
 
-c, cfg, model, tr, q, steps = bench.build_extra_config("C4", "cuda:0", steps_cap=8)
+c, cfg, model, tr, q, steps = bench_extra.build_extra_config("C4", "cuda:0", steps_cap=8)
 tr.train_model_epoch(0)
 torch.cuda.synchronize()
 lib = L.load()
