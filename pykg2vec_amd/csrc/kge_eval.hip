@@ -1132,7 +1132,11 @@ __global__ __launch_bounds__(256) void k_eval_sweep(const float* __restrict__ ca
 // ranks stay exact functions of the fp32 energies.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GT = 128;      // tile edge (queries and candidates) per workgroup
-constexpr int GKS = 16;      // K slab
+#ifndef KGE_GEMM_KS
+#define KGE_GEMM_KS 16
+#endif
+constexpr int GKS = KGE_GEMM_KS;   // K slab (16; 32 = experiment: half the barriers, twice the LDS -- free at two workgroups per CU)
+constexpr int GNJ = GKS / 8;        // float4s of each operand slab a thread stages
 static_assert(kGemmChunk % GKS == 0, "the running total is folded at K slab boundaries");
 #if defined(KGE_GEMM_32X32) && KGE_GEMM_CHUNK
 #error "the 32x32x2 experiment form of k_eval_gemm keeps the single chain: build it with -DKGE_GEMM_CHUNK=0"
@@ -1192,9 +1196,9 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
     const int qt = blockIdx.x % qtiles, sp = blockIdx.x / qtiles;
     const int64_t ctiles = (ntiles64 + 1) / 2;   // 128-candidate tiles
     // staging role: float4 number t + 256 j of a slab = (k = idx / 32, 4 columns at 4 * (idx % 32))
-    int sk[2], sc4[2];
+    int sk[GNJ], sc4[GNJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { const int idx = threadIdx.x + 256 * j; sk[j] = idx >> 5; sc4[j] = idx & 31; }
+    for (int j = 0; j < GNJ; ++j) { const int idx = threadIdx.x + 256 * j; sk[j] = idx >> 5; sc4[j] = idx & 31; }
     const float* qsrc = qT + (int64_t)qt * Kpad * GT;
 #ifdef KGE_GEMM_32X32
     constexpr int NB = 2;            // column blocks per wave (32 wide)
@@ -1231,14 +1235,14 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
     // fill / drain bubble at tile boundaries; LDS buffers alternate across the whole sequence (one barrier per step)
     const int64_t my_tiles = sp < ctiles ? (ctiles - sp + S - 1) / S : 0;
     const int64_t nsteps = my_tiles * nslab;
-    float4 ra[2], rb[2];
+    float4 ra[GNJ], rb[GNJ];
     int64_t ld_ct = sp, cu_ct = sp;   // candidate tile / slab of the next load step and of the current compute step (steps are
     int ld_sl = 0, cu_sl = 0;         // visited in order: counters instead of a 64-bit division per step)
     // a lane's two float4 of a slab sit at FIXED offsets from a base that is the same for the whole workgroup: scalar base
     // (advanced by one slab, or re-pointed at the next candidate tile pair) + 32-bit lane offset, no per-step address arithmetic
-    int la[2], la0[2], lq[2];
+    int la[GNJ], la0[GNJ], lq[GNJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < GNJ; ++j) {
         la0[j] = sk[j] * 64 + (sc4[j] & 15) * 4;                 // inside the first 64-candidate tile of the pair
         la[j] = (sc4[j] >> 4) * Kpad * 64 + la0[j];              // two 64-candidate tiles of the sweep layout side by side
         lq[j] = sk[j] * GT + sc4[j] * 4;
@@ -1249,7 +1253,7 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
         const bool pair = ld_ct * 2 + 1 < ntiles64;   // odd tile count: the last pair repeats its first tile (masked in the epilogue)
         const int krem = Kpad - ld_sl * GKS;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < GNJ; ++j) {
             const bool live = sk[j] < krem;
             ra[j] = live ? *reinterpret_cast<const float4*>(ld_c + (pair ? la[j] : la0[j])) : make_float4(0.f, 0.f, 0.f, 0.f);
             rb[j] = live ? *reinterpret_cast<const float4*>(ld_q + lq[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1267,7 +1271,7 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
     int buf = 0;
     for (int64_t g = 0; g < nsteps; ++g) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < GNJ; ++j) {
             *reinterpret_cast<float4*>(&sA[buf][sk[j]][sc4[j] * 4]) = ra[j];
             *reinterpret_cast<float4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
         }
@@ -1350,7 +1354,7 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
     int buf = 0;
     for (int64_t g = 0; g < nsteps; ++g) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < GNJ; ++j) {
             *reinterpret_cast<float4*>(&sA[buf][sk[j]][sc4[j] * 4]) = ra[j];
             *reinterpret_cast<float4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
         }

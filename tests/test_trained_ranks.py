@@ -23,6 +23,7 @@ import golden_util as gu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAINED = list(gu.TRAINED)
 MIN_IDENTICAL = 0.995
+FLAT_BAR = ("pretrained_fb15k_l1", "pretrained_fb15k_l2", "trained_c1_transe_l1", "trained_c2_complex")
 
 
 def _fixture(fname):
@@ -95,7 +96,10 @@ def _compare(tag, m, cfg, queries, ref, r64, true_scores):
     json.dump(doc, open(path, "w"), indent=1)
     ref_noise = report["reference_entries_differing_from_float64"] / ranks.size
     hip_noise = report["hip_entries_differing_from_float64"] / ranks.size
-    report["required_identical_fraction"] = min(MIN_IDENTICAL, 1.0 - 2.5 * ref_noise)
+    # measured (profiles/r06_rank_agreement_trained.json): 99.51 / 99.71 % (pretrained L1 / L2), 99.51 % (C1), 99.80 % (C2) -- every
+    # path involved is deterministic, so the flat 99.5 % bar holds exactly; a case whose reference is noisier than 0.2 % against
+    # float64 AND has not been measured yet falls back to 2.5x that noise
+    report["required_identical_fraction"] = MIN_IDENTICAL if tag in FLAT_BAR else min(MIN_IDENTICAL, 1.0 - 2.5 * ref_noise)
     json.dump(doc, open(path, "w"), indent=1)
     assert report["identical_fraction"] >= report["required_identical_fraction"], report
     assert hip_noise <= 1.5 * ref_noise + 0.002, report       # as close to the exact ranks as the reference is
