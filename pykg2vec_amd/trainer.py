@@ -768,7 +768,34 @@ class Trainer:
             ent = self.flat.views[0]
             st = self._rescal_stage = K.RescalStage(ent.shape[0], max(n_pairs, int(self.config.batch_size)), ent.shape[1], ent.device)
             self._graph = None     # (captured steps hold the old buffers' addresses)
+            self._report_rescal_reproducibility()
         return st
+
+    RESCAL_CHUNK_PAIRS = 64      # pairs of one relation a slab workgroup takes (csrc/kge_relgroup.h: kSlabChunk)
+
+    def _report_rescal_reproducibility(self):
+        """The staged RESCAL step is bit-reproducible while no relation has more than 64 pairs in a batch: a longer relation spans
+        several chunks, whose shares of the relation-matrix gradient meet in float atomics (and its pairs keep their arrival order in
+        the grouping).  Batches are fixed slices of one permutation, so which side of that line a run is on is known up front: computed
+        once (one bincount over the epoch order), exposed as `rescal_reproducible`, and said out loud when False (hub
+        relations of YAGO3-10 / FB15k put most real batches beyond 64 pairs)."""
+        gen = self.generator
+        self.rescal_reproducible = None
+        if gen is None or getattr(gen, "perm", None) is None or getattr(gen, "triples", None) is None:
+            return
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():   # (the answer needs a device -> host read)
+            return
+        B, n, R = int(gen.batch_size), int(gen.n_train), int(self.config.tot_relation)
+        nb = (n + B - 1) // B
+        if nb * R > (1 << 27):       # (a 512 MB histogram is not worth the answer)
+            return
+        rel = gen.triples[gen.perm[:n], 1]
+        key = (torch.arange(n, device=rel.device) // B) * R + rel
+        worst = int(torch.bincount(key, minlength=nb * R).max().item())
+        self.rescal_reproducible = worst <= self.RESCAL_CHUNK_PAIRS
+        if not self.rescal_reproducible:
+            _log("RESCAL staged step: a relation occurs %d times in one batch of %d (> %d): its share of the relation-matrix gradient is "
+                 "summed with float atomics -- results are equal to rounding, not bit-reproducible, on this graph" % (worst, B, self.RESCAL_CHUNK_PAIRS))
 
     def _mean_type_loss(self):
         """pointwise_logistic and the self-adversarial loss are MEANS over the batch (criterion.py:13-23,31-34);

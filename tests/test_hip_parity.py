@@ -1208,6 +1208,9 @@ def test_rescal_staged_entity_gradients_are_reproducible_and_equal_the_atomic_st
         losses = [tr.train_model_epoch(e) for e in range(3)]
         took = getattr(tr, "_rescal_stage", None) is not None
         assert took == (staged == "1" and k % 4 == 0), (took, staged)
+        if took:   # which side of the 64-pairs-per-relation line the run is on is computed up front and reported
+            worst = max(int(np.bincount(train[tr.generator.perm.cpu().numpy()[lo:lo + B], 1], minlength=R).max()) for lo in range(0, n, B))
+            assert tr.rescal_reproducible == (worst <= 64), (tr.rescal_reproducible, worst)
         if took:   # every list the optimiser consumed was reset
             assert int(tr._rescal_stage.count.abs().sum()) == 0 and int(tr._rescal_stage.head.abs().sum()) == 0
             assert bool((tr.flat.grad[: E * k] == 0).all())
