@@ -309,7 +309,8 @@ def compact_line(out, detail_path=None):
         line["extra_units"] = "train: scored triples/s; eval: test triples ranked/s"
     if out.get("train_reference_default_batch"):
         sm = out["train_reference_default_batch"]
-        line["default_batch_128"] = {"value": _r(sm.get("value")), "ms_per_step": _r(sm.get("ms_per_step"), 4)}
+        line["default_batch_128"] = {"value": _r(sm.get("value")), "ms_per_step": _r(sm.get("ms_per_step"), 4),
+                                     "adam_floor_frac": _r((sm.get("floor") or {}).get("frac_of_hbm_peak"), 3)}
     if out.get("setup_ms") is not None:
         line["setup_ms"] = _r(out["setup_ms"], 4)
     for k in ("phases_us", "predicted_step_us", "replicas_identical"):
@@ -562,7 +563,6 @@ def main():
     kern_ms = region_ms_per_step if pull else burst_ms
     reset_model()
     alg_bytes = 2 * per_rank_batch * TRAIN_BYTES_PER_SCORED_TRIPLE
-
     tr.sync_model()
     # ---- eval leg: filtered ranks of n_eval test triples per rank
     ev = Evaluator(model, cfg)
@@ -616,12 +616,13 @@ def main():
         tr_s.build_model()
         tr_s.generator = tr_s._new_generator()
         dts = bench_extra.timed_epochs(tr_s, 400)
+        adam_bytes = (E + R) * DIM * 4 * 7     # dense Adam moves every row every step: p, m, v read and written + the gradient
         small = {"batch": 128, "value": 256 / dts, "unit": "scored triples/s", "ms_per_step": dts * 1e3,
-                 "mode": ("hipGraph replay, 8 steps per graph, of fused step + Adam (next step's state derived inside the Adam launch)" if tr_s._graph is not None
-                          else "owner-computes step, one launch per step, the epoch enqueued by one native call (kge_pull_run); compact incidence index" if getattr(tr_s, "_pull", None) is not None
-                          else "eager")}
+                 "floor": {"what": "the B-independent dense Adam sweep: %.1f MB per step" % (adam_bytes / 1e6), "us_at_hbm_peak": adam_bytes / HBM_PEAK_GBS / 1e3,
+                           "achieved_GBps": adam_bytes / dts / 1e9, "frac_of_hbm_peak": adam_bytes / dts / 1e9 / HBM_PEAK_GBS},
+                 "mode": ("hipGraph replay of fused step + Adam" if tr_s._graph is not None else
+                          "owner-computes step, one launch per step (kge_pull_run)" if getattr(tr_s, "_pull", None) is not None else "eager")}
         del tr_s
-
     # ---- HBM traffic of every leg, observed in THIS run by two rocprofv3 counter passes over a short child run (N=1, rank 0)
     live, live_meta = (None, "disabled (--no-live-pmc)") if (args.no_live_pmc or world > 1) else bench_pmc.live_pmc(args)
 

@@ -253,7 +253,10 @@ static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t ro
                             const float* dh, const unsigned* touched, unsigned* tclear, const RowStage& stage, hipStream_t s) {
     if (rows4_ok(p, g, s1, s2, dim)) {
         int64_t blocks4 = (rows + 7) / 8;
-        if (blocks4 > 256 * 32) blocks4 = 256 * 32;
+#ifndef KGE_ROWS4_CAP
+#define KGE_ROWS4_CAP (256 * 32)
+#endif
+        if (blocks4 > KGE_ROWS4_CAP) blocks4 = KGE_ROWS4_CAP;   // (A/B: profiles/r06_opt_rows4_ab.txt)
         const int streams = KIND == KGE_OPT_SGD ? 2 : KIND == KGE_OPT_ADAM ? 4 : 3;
         const bool nt = (int64_t)streams * rows * dim * 4 > ((int64_t)256 << 20);
 #define KGE_ROWS4(NV_)                                                                                                    \
