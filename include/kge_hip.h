@@ -379,6 +379,20 @@ int kge_optimizer_step_rownorm(int32_t kind, float* param, float* grad, float* s
                                const int64_t* dev_cursor, int64_t* next_cursor, float* next_hyper, int64_t batch_stride,
                                int64_t n_batches, int64_t draws_per_batch, void* stream);
 
+/* RESCAL's whole optimiser step in two launches (round 6): kge_optimizer_step_rows / _rows_staged on the table of SHORT rows
+ * (ent_embeddings: param .. dim, touched_rows / touched_clear / stage as there; normalize must be 1) with the optimiser of the table of
+ * WIDE rows (rel_matrices: wparam .. wdim, as kge_optimizer_step_rownorm) riding in the first wrows * ceil(wdim / 4096) workgroups of the
+ * same launch, then the rescale launch of the wide rows.  Stored values are bit-identical to the two separate calls; the launch-bound
+ * chunk kernel (11.6 us at the YAGO3-10 shape) disappears under the entity table's sweep.  zero_grad applies to the wide-row table and,
+ * when stage is NULL, to the short-row table.  Replaces: optimizer.step() + zero_grad() (utils/trainer.py:272,299) + Rescal.embed's
+ * renormalisation of both tables (models/pairwise.py:843-844). */
+int kge_optimizer_step_rows_rownorm(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
+                                    float* wparam, float* wgrad, float* wstate1, float* wstate2, int64_t wrows, int64_t wdim,
+                                    float lr, int64_t step, int32_t zero_grad, int32_t normalize, const float* dev_hyper,
+                                    const uint32_t* touched_rows, uint32_t* touched_clear, const kge_rescal_stage* stage,
+                                    void* scratch, size_t scratch_bytes, const int64_t* dev_cursor, int64_t* next_cursor,
+                                    float* next_hyper, int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, void* stream);
+
 /* kge_optimizer_step for hipGraph-replayed steps, with kge_step_advance for the FOLLOWING step folded into the same
  * launch: the sweep reads its scalars from dev_hyper (this step's set) and thread 0 derives the next step's state
  * next_cursor / next_hyper from dev_cursor.  The two sets must be distinct buffers (the replayed graphs alternate

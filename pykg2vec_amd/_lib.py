@@ -183,6 +183,10 @@ _SIGNATURES = {
     "kge_optimizer_step_rownorm": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int64,
                                                   ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "kge_optimizer_step_rows_rownorm": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int32] + [ctypes.c_void_p] * 4
+                                        + [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+                                        + [ctypes.c_void_p] * 3 + [ctypes.POINTER(RescalStage), ctypes.c_void_p, ctypes.c_size_t]
+                                        + [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_void_p]),
     "kge_rescal_pair_step": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kge_rescal_pair_step_ok": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_int64]),

@@ -474,6 +474,29 @@ int kge_optimizer_step_rownorm(int32_t kind, float* param, float* grad, float* s
                                     (hipStream_t)stream);
 }
 
+int kge_optimizer_step_rows_rownorm(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t rows, int32_t dim,
+                                    float* wparam, float* wgrad, float* wstate1, float* wstate2, int64_t wrows, int64_t wdim,
+                                    float lr, int64_t step, int32_t zero_grad, int32_t normalize, const float* dev_hyper,
+                                    const uint32_t* touched_rows, uint32_t* touched_clear, const kge_rescal_stage* stage,
+                                    void* scratch, size_t scratch_bytes, const int64_t* dev_cursor, int64_t* next_cursor,
+                                    float* next_hyper, int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, void* stream) {
+    if (!param || !grad || rows <= 0 || dim <= 0 || dim > 1024 || !wparam || !wgrad || wrows <= 0 || wdim <= 0 || !scratch ||
+        (step < 1 && !dev_hyper)) {
+        set_error("kge_optimizer_step_rows_rownorm: bad arguments (short rows of at most 1024 floats, both tables and the scratch are required)");
+        return -1;
+    }
+    if (stage && !touched_rows) { set_error("kge_optimizer_step_rows_rownorm: the staged form needs the touched-row bitmap"); return -1; }
+    if (touched_rows && touched_rows == touched_clear) { set_error("kge_optimizer_step_rows_rownorm: the bitmap to clear must be the other parity's"); return -1; }
+    if ((dev_cursor || next_cursor || next_hyper) && (!dev_cursor || !next_cursor || !next_hyper || !dev_hyper || dev_cursor == next_cursor || dev_hyper == next_hyper || n_batches < 1)) {
+        set_error("kge_optimizer_step_rows_rownorm: the step-state transition needs dev_hyper, dev_cursor and a different next set");
+        return -1;
+    }
+    return launch_optimizer_rows_rownorm(kind, param, grad, state1, state2, rows, dim, wparam, wgrad, wstate1, wstate2, wrows, wdim, lr, step,
+                                         zero_grad, normalize, dev_hyper, touched_rows, touched_clear, stage, (float*)scratch,
+                                         scratch_bytes / sizeof(float), dev_cursor, next_cursor, next_hyper, batch_stride, n_batches,
+                                         draws_per_batch, (hipStream_t)stream);
+}
+
 int kge_optimizer_step_advance(int32_t kind, float* param, float* grad, float* state1, float* state2, int64_t numel, float lr,
                                int32_t zero_grad, const float* dev_hyper, const int64_t* dev_cursor, int64_t* next_cursor,
                                float* next_hyper, int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch,

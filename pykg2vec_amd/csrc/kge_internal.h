@@ -186,6 +186,12 @@ int launch_optimizer_rownorm(int kind, float* p, float* g, float* s1, float* s2,
                              int64_t* cursor_out, float* hyper_out, int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch,
                              hipStream_t s);
 
+int launch_optimizer_rows_rownorm(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float* wp, float* wg,
+                                  float* ws1, float* ws2, int64_t wrows, int64_t wdim, float lr, int64_t step, int zero_grad, int normalize,
+                                  const float* dev_hyper, const unsigned* touched, unsigned* touched_clear, const kge_rescal_stage* st,
+                                  float* scratch, size_t scratch_floats, const int64_t* cursor_in, int64_t* cursor_out, float* hyper_out,
+                                  int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, hipStream_t s);
+
 // kge_pull.hip (owner-computes training step: no atomics, optimiser fused, deterministic)
 int pull_partial_stride(int dim);
 int pull_hat_stride(int dim);

@@ -150,17 +150,83 @@ struct RowStage {
     int* count; const int* bucket; int* head; const int* next; int cap;
 };
 
+constexpr int kOptNormChunk = 4096;     // = kNormChunk of kge_dense.hip (the separate normalisation pass)
+// one workgroup = one chunk of one wide row: every stream of the chunk requested before the first update, the optimiser, the chunk's sum
+// of squares (per-thread fmaf chain in element order, wave butterflies, the four waves as (0 + 1) + (2 + 3)) to part[blk]
+template <int KIND>
+__device__ __forceinline__ void opt_sumsq_chunk(int blk, float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
+                                                float* __restrict__ s2, int64_t dim, int nchunk, const OptArgs& a, int zero,
+                                                float* __restrict__ part, float* sw) {
+    const int64_t row = blk / nchunk;
+    const int ch = blk % nchunk;
+    const int64_t base = row * dim;
+    const int64_t lo = (int64_t)ch * kOptNormChunk, hi = min(dim, lo + kOptNormChunk);
+    constexpr int PER = kOptNormChunk / 256, SUB = 4;   // SUB elements of every stream in flight per thread (registers: the rider form
+                                                        // must not cost the row owners of k_opt_rows4 their occupancy)
+    float n2 = 0.f;
+#pragma unroll
+    for (int u0 = 0; u0 < PER; u0 += SUB) {
+        float pv[SUB], gv[SUB], av[SUB], bv[SUB];
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {      // (clamped addresses)
+            const int64_t c = base + min(lo + threadIdx.x + 256 * (u0 + u), hi - 1);
+            pv[u] = p[c]; gv[u] = g[c];
+            av[u] = KIND != KGE_OPT_SGD ? s1[c] : 0.f;
+            bv[u] = KIND == KGE_OPT_ADAM ? s2[c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+            const int64_t cc = lo + threadIdx.x + 256 * (u0 + u);
+            if (cc < hi) {
+                const int64_t c = base + cc;
+                opt_update<KIND>(pv[u], gv[u], av[u], bv[u], a);
+                p[c] = pv[u];
+                if constexpr (KIND != KGE_OPT_SGD) s1[c] = av[u];
+                if constexpr (KIND == KGE_OPT_ADAM) s2[c] = bv[u];
+                if (zero && gv[u] != 0.f) g[c] = 0.f;
+                n2 = fmaf(pv[u], pv[u], n2);
+            }
+        }
+    }
+    n2 = wave_sum(n2);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = n2;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blk] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+// The wide-row table's optimiser as a RIDER of the row-owner sweep below (round 6): the first `nblocks` workgroups of k_opt_rows4<...,
+// RIDER> each take one chunk (opt_sumsq_chunk: the arithmetic of k_opt_sumsq_chunks, bit for bit) instead of rows, so RESCAL's step has
+// one optimiser launch + the rescale launch instead of three launches -- the 11.6 us of the launch-bound chunk kernel disappear under
+// the 100 us sweep of the entity table.
+struct RelRider {
+    float* p; float* g; float* s1; float* s2;
+    int64_t dim; int nchunk; int nblocks; int zero;
+    float* part;
+    AdvanceArgs adv;
+};
+
 constexpr int kStageChainLds = 256;   // overflow-chain entries of one row kept in LDS (8 row groups per workgroup: 8 KB)
-template <int KIND, int NV, bool NORM, bool NT>
+template <int KIND, int NV, bool NORM, bool NT, bool RIDER = false>
 __global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                    float* __restrict__ s2, int64_t rows, int dim, OptArgs a,
                                                    const float* __restrict__ dev_hyper, int zero,
-                                                   const unsigned* __restrict__ touched, unsigned* __restrict__ touched_clear, RowStage stage) {
+                                                   const unsigned* __restrict__ touched, unsigned* __restrict__ touched_clear, RowStage stage,
+                                                   RelRider rider) {
     __shared__ int s_chain[8][kStageChainLds];
     if (dev_hyper) { a.lr = dev_hyper[0]; a.step_size = dev_hyper[1]; a.bc2_sqrt = dev_hyper[2]; }
+    int first = 0;      // workgroups in front of the row owners
+    if constexpr (RIDER) {
+        first = rider.nblocks;
+        if ((int)blockIdx.x < first) {     // (workgroup-uniform) a chunk of the wide-row table instead of rows
+            if (rider.adv.cin != nullptr && blockIdx.x == 0 && threadIdx.x == 0) advance_state(rider.adv);
+            opt_sumsq_chunk<KIND>((int)blockIdx.x, rider.p, rider.g, rider.s1, rider.s2, rider.dim, rider.nchunk, a, rider.zero, rider.part,
+                                  reinterpret_cast<float*>(&s_chain[0][0]));
+            return;
+        }
+    }
     const int gl = threadIdx.x & 31;
     const int nvec = dim >> 2;
-    for (int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); row < rows; row += (int64_t)gridDim.x * 8) {
+    for (int64_t row = (int64_t)((int)blockIdx.x - first) * 8 + (threadIdx.x >> 5); row < rows; row += (int64_t)((int)gridDim.x - first) * 8) {
         // touched: one bit per row, set by the step that wrote a gradient into it; a clear bit means the row of `g` is zero
         // and is not read (one of the seven streams of a dense Adam sweep).  touched_clear: the OTHER step parity's bitmap, reset here.
         const bool has_g = !touched || ((touched[row >> 5] >> (row & 31)) & 1u);
@@ -169,16 +235,27 @@ __global__ __launch_bounds__(256) void k_opt_rows4(float* __restrict__ p, float*
         float4* gr = reinterpret_cast<float4*>(g + row * dim);
         float4* ar = reinterpret_cast<float4*>(s1 + row * dim);
         float4* br = reinterpret_cast<float4*>(s2 + row * dim);
+        // every stream of the row requested before anything is used: the addresses are CLAMPED into the row and a lane beyond it drops
+        // what it fetched (a select between two addresses -- `on ? pr[i] : z` -- made the compiler keep a zero in scratch and fetch
+        // through 8-byte FLAT loads behind a wait per stream: round 6, profiles/r06_experiments.md section 7)
         float4 pv[NV], gv[NV], av[NV], bv[NV];
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool read_g = has_g && !stage.gstage;      // (uniform over the row's 32 lanes)
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int i = v * 32 + gl;
-            const bool on = i < nvec;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            pv[v] = on ? pr[i] : z;
-            gv[v] = (on && has_g && !stage.gstage) ? stream_load<NT>(gr + i) : z;
-            av[v] = (KIND != KGE_OPT_SGD && on) ? stream_load<NT>(ar + i) : z;
-            bv[v] = (KIND == KGE_OPT_ADAM && on) ? stream_load<NT>(br + i) : z;
+            const int ic = min(v * 32 + gl, nvec - 1);
+            pv[v] = pr[ic];
+            if constexpr (KIND != KGE_OPT_SGD) av[v] = stream_load<NT>(ar + ic); else av[v] = z;
+            if constexpr (KIND == KGE_OPT_ADAM) bv[v] = stream_load<NT>(br + ic); else bv[v] = z;
+            gv[v] = z;
+        }
+        if (read_g) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) gv[v] = stream_load<NT>(gr + min(v * 32 + gl, nvec - 1));
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v * 32 + gl >= nvec) { pv[v] = z; gv[v] = z; av[v] = z; bv[v] = z; }
         }
         if (stage.gstage && has_g) {
             const int cnt = stage.count[row];
@@ -250,7 +327,8 @@ static bool rows4_ok(const float* p, const float* g, const float* s1, const floa
 
 template <int KIND>
 static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t rows, int dim, OptArgs a, int zero, int normalize,
-                            const float* dh, const unsigned* touched, unsigned* tclear, const RowStage& stage, hipStream_t s) {
+                            const float* dh, const unsigned* touched, unsigned* tclear, const RowStage& stage, hipStream_t s,
+                            const RelRider* rider = nullptr) {
     if (rows4_ok(p, g, s1, s2, dim)) {
         int64_t blocks4 = (rows + 7) / 8;
 #ifndef KGE_ROWS4_CAP
@@ -259,17 +337,31 @@ static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t ro
         if (blocks4 > KGE_ROWS4_CAP) blocks4 = KGE_ROWS4_CAP;   // (A/B: profiles/r06_opt_rows4_ab.txt)
         const int streams = KIND == KGE_OPT_SGD ? 2 : KIND == KGE_OPT_ADAM ? 4 : 3;
         const bool nt = (int64_t)streams * rows * dim * 4 > ((int64_t)256 << 20);
+        const RelRider none{};
+        if (rider) {     // the wide-row table's chunks ride in front of the row owners (RESCAL: always the renormalising form)
+            if (!normalize) { set_error("kge_optimizer_step_rows_rownorm: the rider form is the renormalising one"); return -1; }
+            const dim3 grid((unsigned)(blocks4 + rider->nblocks));
+#define KGE_ROWS4R(NV_)                                                                                                   \
+            if (dim <= 128 * NV_) {                                                                                        \
+                if (nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, true, true>), grid, dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage, *rider); \
+                else hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, false, true>), grid, dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage, *rider); \
+                return check_launch("k_opt_rows4 (+ rider)");                                                              \
+            }
+            KGE_ROWS4R(1) KGE_ROWS4R(2) KGE_ROWS4R(4) KGE_ROWS4R(8)
+#undef KGE_ROWS4R
+        }
 #define KGE_ROWS4(NV_)                                                                                                    \
         if (dim <= 128 * NV_) {                                                                                            \
-            if (normalize && nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage); \
-            else if (normalize) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage); \
-            else if (nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage); \
-            else hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage); \
+            if (normalize && nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage, none); \
+            else if (normalize) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, true, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage, none); \
+            else if (nt) hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, true>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage, none); \
+            else hipLaunchKernelGGL((k_opt_rows4<KIND, NV_, false, false>), dim3((int)blocks4), dim3(256), 0, s, p, g, s1, s2, rows, dim, a, dh, zero, touched, tclear, stage, none); \
             return check_launch("k_opt_rows4");                                                                            \
         }
         KGE_ROWS4(1) KGE_ROWS4(2) KGE_ROWS4(4) KGE_ROWS4(8)
 #undef KGE_ROWS4
     }
+    if (rider) { set_error("kge_optimizer_step_rows_rownorm: rows of float4s only (dim %% 4 == 0, dim <= 1024, 16-byte aligned buffers)"); return -1; }
     if (stage.gstage) { set_error("kge_optimizer_step_rows_staged: rows of float4s only (dim %% 4 == 0, dim <= 1024, 16-byte aligned buffers)"); return -1; }
     if (tclear) {   // (the dword kernel reads every gradient row: a superset of the touched ones)
         hipError_t e = hipMemsetAsync(tclear, 0, (size_t)((rows + 31) / 32) * sizeof(unsigned), s);
@@ -288,9 +380,9 @@ static int launch_rows_kind(float* p, float* g, float* s1, float* s2, int64_t ro
     return -1;
 }
 
-int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float lr, int64_t step,
-                          int zero_grad, int normalize, const float* dev_hyper, const unsigned* touched, unsigned* touched_clear,
-                          const kge_rescal_stage* st, hipStream_t s) {
+static int launch_optimizer_rows_impl(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float lr, int64_t step,
+                                      int zero_grad, int normalize, const float* dev_hyper, const unsigned* touched, unsigned* touched_clear,
+                                      const kge_rescal_stage* st, hipStream_t s, const RelRider* rider) {
     const OptArgs a = make_opt_args(lr, step);
     RowStage stage{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (st) {
@@ -301,19 +393,25 @@ int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, in
         stage = RowStage{st->gstage, st->dsv, st->count, st->bucket, st->head, st->next, st->cap};
     }
     switch (kind) {
-        case KGE_OPT_SGD: return launch_rows_kind<KGE_OPT_SGD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s);
+        case KGE_OPT_SGD: return launch_rows_kind<KGE_OPT_SGD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s, rider);
         case KGE_OPT_ADAM:
             if (!s1 || !s2) { set_error("adam needs two state buffers"); return -1; }
-            return launch_rows_kind<KGE_OPT_ADAM>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s);
+            return launch_rows_kind<KGE_OPT_ADAM>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s, rider);
         case KGE_OPT_ADAGRAD:
             if (!s1) { set_error("adagrad needs a state buffer"); return -1; }
-            return launch_rows_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s);
+            return launch_rows_kind<KGE_OPT_ADAGRAD>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s, rider);
         case KGE_OPT_RMSPROP:
             if (!s1) { set_error("rmsprop needs a state buffer"); return -1; }
-            return launch_rows_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s);
+            return launch_rows_kind<KGE_OPT_RMSPROP>(p, g, s1, s2, rows, dim, a, zero_grad, normalize, dev_hyper, touched, touched_clear, stage, s, rider);
     }
     set_error("kge_optimizer_step_rows: unknown optimizer %d", kind);
     return -1;
+}
+
+int launch_optimizer_rows(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float lr, int64_t step,
+                          int zero_grad, int normalize, const float* dev_hyper, const unsigned* touched, unsigned* touched_clear,
+                          const kge_rescal_stage* st, hipStream_t s) {
+    return launch_optimizer_rows_impl(kind, p, g, s1, s2, rows, dim, lr, step, zero_grad, normalize, dev_hyper, touched, touched_clear, st, s, nullptr);
 }
 
 int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t numel, float lr, int64_t step,
@@ -349,7 +447,6 @@ int launch_optimizer(int kind, float* p, float* g, float* s1, float* s2, int64_t
 // k_opt (all streams) + k_row_sumsq_chunks (re-reads the table) + k_row_scale_chunks: here the optimiser launch itself leaves the
 // chunks' sums of squares -- same chunking (4 096 floats), same element-to-thread map and summation order as k_row_sumsq_chunks, so the
 // stored rows are bit-identical to the three-launch form -- and only the rescale pass follows.
-constexpr int kOptNormChunk = 4096;     // = kNormChunk of kge_dense.hip (the separate normalisation pass)
 template <int KIND>
 __global__ __launch_bounds__(256) void k_opt_sumsq_chunks(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                           float* __restrict__ s2, int64_t dim, int nchunk, OptArgs a,
@@ -358,37 +455,7 @@ __global__ __launch_bounds__(256) void k_opt_sumsq_chunks(float* __restrict__ p,
     if (dev_hyper) { a.lr = dev_hyper[0]; a.step_size = dev_hyper[1]; a.bc2_sqrt = dev_hyper[2]; }
     if (adv.cin != nullptr && blockIdx.x == 0 && threadIdx.x == 0) advance_state(adv);
     __shared__ float sw[4];
-    const int64_t row = blockIdx.x / nchunk;
-    const int ch = blockIdx.x % nchunk;
-    const int64_t base = row * dim;
-    const int64_t lo = (int64_t)ch * kOptNormChunk, hi = min(dim, lo + kOptNormChunk);
-    constexpr int PER = kOptNormChunk / 256;
-    float pv[PER], gv[PER], av[PER], bv[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {      // every stream of the chunk requested before the first update (clamped addresses)
-        const int64_t c = base + min(lo + threadIdx.x + 256 * u, hi - 1);
-        pv[u] = p[c]; gv[u] = g[c];
-        av[u] = KIND != KGE_OPT_SGD ? s1[c] : 0.f;
-        bv[u] = KIND == KGE_OPT_ADAM ? s2[c] : 0.f;
-    }
-    float n2 = 0.f;
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int64_t cc = lo + threadIdx.x + 256 * u;
-        if (cc < hi) {
-            const int64_t c = base + cc;
-            opt_update<KIND>(pv[u], gv[u], av[u], bv[u], a);
-            p[c] = pv[u];
-            if constexpr (KIND != KGE_OPT_SGD) s1[c] = av[u];
-            if constexpr (KIND == KGE_OPT_ADAM) s2[c] = bv[u];
-            if (zero && gv[u] != 0.f) g[c] = 0.f;
-            n2 = fmaf(pv[u], pv[u], n2);
-        }
-    }
-    n2 = wave_sum(n2);
-    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = n2;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+    opt_sumsq_chunk<KIND>((int)blockIdx.x, p, g, s1, s2, dim, nchunk, a, zero, part, sw);
 }
 __global__ __launch_bounds__(256) void k_opt_scale_chunks(float* __restrict__ w, int64_t dim, int nchunk, const float* __restrict__ part) {
     const int64_t row = blockIdx.x / nchunk;
@@ -428,6 +495,31 @@ int launch_optimizer_rownorm(int kind, float* p, float* g, float* s1, float* s2,
     }
     hipLaunchKernelGGL(k_opt_scale_chunks, grid, dim3(256), 0, s, p, dim, nchunk, scratch);
     return check_launch("k_opt_sumsq_chunks / k_opt_scale_chunks");
+}
+
+// RESCAL's whole optimiser step as TWO launches: the row-owner sweep of the entity table with the relation matrices' chunks riding
+// in front (k_opt_rows4<..., RIDER>), then the rescale of the relation matrices.  Stored values are bit-identical to
+// launch_optimizer_rows + launch_optimizer_rownorm (same device functions, same operation order).
+int launch_optimizer_rows_rownorm(int kind, float* p, float* g, float* s1, float* s2, int64_t rows, int dim, float* wp, float* wg,
+                                  float* ws1, float* ws2, int64_t wrows, int64_t wdim, float lr, int64_t step, int zero_grad, int normalize,
+                                  const float* dev_hyper, const unsigned* touched, unsigned* touched_clear, const kge_rescal_stage* st,
+                                  float* scratch, size_t scratch_floats, const int64_t* cursor_in, int64_t* cursor_out, float* hyper_out,
+                                  int64_t batch_stride, int64_t n_batches, int64_t draws_per_batch, hipStream_t s) {
+    if (!optimizer_rownorm_ok(wrows, wdim, scratch_floats)) { set_error("kge_optimizer_step_rows_rownorm: wide rows of at least 16 384 floats, fewer than 1 024 of them, scratch of rows * ceil(dim / 4096) floats"); return -1; }
+    if ((kind != KGE_OPT_SGD && !ws1) || (kind == KGE_OPT_ADAM && !ws2)) { set_error("kge_optimizer_step_rows_rownorm: optimiser state of the wide-row table missing"); return -1; }
+    RelRider r;
+    r.p = wp; r.g = wg; r.s1 = ws1; r.s2 = ws2; r.dim = wdim;
+    r.nchunk = (int)((wdim + kOptNormChunk - 1) / kOptNormChunk);
+    r.nblocks = (int)(wrows * r.nchunk);
+    r.zero = zero_grad; r.part = scratch;
+    r.adv.cin = cursor_in; r.adv.cout = cursor_out; r.adv.hout = hyper_out;
+    r.adv.batch_stride = batch_stride; r.adv.n_batches = n_batches > 0 ? n_batches : 1; r.adv.draws_per_batch = draws_per_batch;
+    r.adv.lr = lr;
+    int rc = launch_optimizer_rows_impl(kind, p, g, s1, s2, rows, dim, lr, step < 1 ? 1 : step, st ? 0 : zero_grad, normalize, dev_hyper, touched,
+                                        touched_clear, st, s, &r);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_opt_scale_chunks, dim3((unsigned)r.nblocks), dim3(256), 0, s, wp, wdim, r.nchunk, scratch);
+    return check_launch("k_opt_scale_chunks");
 }
 
 }  // namespace kge

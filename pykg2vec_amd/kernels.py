@@ -555,6 +555,35 @@ def optimizer_step_rownorm(kind, param, grad, state1, state2, rows, dim, lr, ste
                                            adv[1], adv[2], adv[3], adv[4], adv[5], adv[6], _stream()), "kge_optimizer_step_rownorm")
 
 
+def optimizer_step_rows_rownorm(kind, param, grad, state1, state2, rows, dim, wparam, wgrad, wstate1, wstate2, wrows, wdim, lr, step,
+                                normalize=True, dev_hyper=None, touched=None, touched_clear=None, stage=None, advance=None, zero_grad=True):
+    """kge_optimizer_step_rows_rownorm: RESCAL's optimiser step in two launches -- the row-owner sweep of the short-row table with the
+    wide-row table's optimiser riding in its first workgroups, then the wide rows' rescale.  Arguments as optimizer_step_rows(_staged) and
+    optimizer_step_rownorm; bit-identical to calling those two."""
+    lib = L.load()
+    need = 4 * int(wrows) * ((int(wdim) + 4095) // 4096)
+    key = (param.device, "rider", need)
+    if key not in _rescal_scratch:
+        _rescal_scratch[key] = torch.empty(max(1, need // 4), dtype=torch.float32, device=param.device)
+    sc = _rescal_scratch[key]
+    f = lambda t, what: _dev(t, torch.float32, what) if t is not None else None
+    if advance is not None:
+        hyper, cursor, next_cursor, next_hyper, batch_stride, n_batches, draws = advance
+        adv = (_dev(cursor, torch.int64, "cursor"), _dev(next_cursor, torch.int64, "next_cursor"), _dev(next_hyper, torch.float32, "next_hyper"),
+               int(batch_stride), int(n_batches), int(draws))
+        dev_hyper = hyper
+    else:
+        adv = (None, None, None, 0, 1, 0)
+    L.check(lib.kge_optimizer_step_rows_rownorm(
+        OPTIMIZER_IDS[kind], _dev(param, torch.float32, "param"), _dev(grad, torch.float32, "grad"), f(state1, "state1"), f(state2, "state2"),
+        int(rows), int(dim), _dev(wparam, torch.float32, "wparam"), _dev(wgrad, torch.float32, "wgrad"), f(wstate1, "wstate1"),
+        f(wstate2, "wstate2"), int(wrows), int(wdim), float(lr), int(step), 1 if zero_grad else 0, 1 if normalize else 0, f(dev_hyper, "dev_hyper"),
+        _dev(touched, torch.int32, "touched") if touched is not None else None,
+        _dev(touched_clear, torch.int32, "touched_clear") if touched_clear is not None else None,
+        ctypes.byref(stage.c) if stage is not None else None, sc.data_ptr(), sc.numel() * 4, adv[0], adv[1], adv[2], adv[3], adv[4], adv[5],
+        _stream()), "kge_optimizer_step_rows_rownorm")
+
+
 def optimizer_step_advance(kind, param, grad, state1, state2, lr, hyper, cursor, next_cursor, next_hyper, batch_stride,
                            n_batches, draws_per_batch, zero_grad=True):
     """Dense optimiser sweep of a graph-replayed step + the next step's device-resident state (kge_optimizer_step_advance)."""

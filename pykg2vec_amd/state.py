@@ -92,7 +92,8 @@ class FlatState:
         self.K.optimizer_step_advance(self.optimizer, self.param_shard, self.grad_shard, self.state1, self.state2, lr, hyper,
                                       cursor, next_cursor, next_hyper, batch_stride, n_batches, draws, zero_grad=True)
 
-    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None, touched=None, touched_clear=None, stage=None, rest_rownorm=None):
+    def optimizer_step_rows_first(self, lr, rows, dim, normalize, advance=None, touched=None, touched_clear=None, stage=None, rest_rownorm=None,
+                                  rider=True):
         """The optimiser step with the FIRST table ([rows, dim], at offset 0 of the flat buffers) handled by the row-owner kernel
         (which can store the rows renormalised: RESCAL) and the remaining tables by the flat sweep.  advance: as
         optimizer_step_advance (device-resident step state of hipGraph-replayed steps); single GPU only."""
@@ -101,6 +102,16 @@ class FlatState:
         cut = self.offsets[1] if len(self.offsets) > 1 else self.numel
         sl = lambda buf, a, b: buf[a:b] if buf is not None else None
         hyper = advance[0] if advance is not None else None
+        if rest_rownorm is not None and normalize and rider and hasattr(self.K, "optimizer_step_rows_rownorm"):
+            # RESCAL: the relation matrices' optimiser rides in the first workgroups of the entity table's sweep, one rescale launch
+            # follows (kge_optimizer_step_rows_rownorm, round 6: two launches instead of three, bit-identical tables)
+            r_rows, r_dim = rest_rownorm
+            n1 = r_rows * r_dim
+            self.K.optimizer_step_rows_rownorm(self.optimizer, self.param[:n0], self.grad[:n0], sl(self.state1, 0, n0), sl(self.state2, 0, n0),
+                                               rows, dim, self.param[cut:cut + n1], self.grad[cut:cut + n1], sl(self.state1, cut, cut + n1),
+                                               sl(self.state2, cut, cut + n1), r_rows, r_dim, lr, self.step, normalize=True, dev_hyper=hyper,
+                                               touched=touched, touched_clear=touched_clear, stage=stage, advance=advance)
+            return True
         if stage is not None:   # entity gradients staged by the pair step (kernels.RescalStage): summed per row in a fixed order, no atomics
             self.K.optimizer_step_rows_staged(self.optimizer, self.param[:n0], self.grad[:n0], sl(self.state1, 0, n0), sl(self.state2, 0, n0),
                                               rows, dim, lr, self.step, stage, touched, touched_clear, normalize=normalize, dev_hyper=hyper)

@@ -60,7 +60,7 @@ class Trainer:
                 "pw_pull": flag("KGE_PW_PULL"), "rescal_fused": flag("KGE_RESCAL_FUSED"),
                 "rescal_unfused": flag("KGE_RESCAL_UNFUSED"), "pull_dir": flag("KGE_PULL_DIR"),
                 "transx_own": flag("KGE_TRANSX_OWN"), "own_staged": flag("KGE_OWN_STAGED"), "rescal_staged": flag("KGE_RESCAL_STAGED"),
-                "dp_sparse": flag("KGE_DP_SPARSE"),
+                "dp_sparse": flag("KGE_DP_SPARSE"), "opt_rider": flag("KGE_OPT_RIDER"),
                 "dp_allreduce": flag("KGE_DP_ALLREDUCE")}
 
     def _init_hot_path(self, process_group=None, backend=None, use_graph=None):
@@ -909,7 +909,8 @@ class Trainer:
                 done = flat.optimizer_step_rows_first(self.config.learning_rate, ent.shape[0], ent.shape[1], keep, advance,
                                                       touched=bm[par] if par is not None else None,
                                                       touched_clear=bm[1 - par] if par is not None else None,
-                                                      stage=st if par is not None else None, rest_rownorm=rownorm)
+                                                      stage=st if par is not None else None, rest_rownorm=rownorm,
+                                                      rider=self.switches.get("opt_rider") is not False)
                 self._touch_parity ^= 1
                 if keep and not done:
                     self.K.rescal_normalize_relations(flat.views[1], self.model.hidden_size)
