@@ -96,11 +96,15 @@ static bool make_plan(const kge_model_desc* m, int64_t n, void* ws, EvalPlan* p,
     p->post = m->model == KGE_TRANSM ? P_SCALE : (m->model == KGE_SIMPLE || m->model == KGE_SIMPLE_IGNR) ? P_CLAMP
               : m->model == KGE_HEAD_1N_INTERNAL ? P_SIGMOID : P_NONE;
     p->ntiles = (p->E + 63) / 64;
+    // the dot-product forms (matrix-core sweep): k padded to whole 16-deep slabs (zeros add nothing to a chain) and one spare 64-candidate
+    // tile behind the tables, so that k_eval_gemm's operand loads need neither a k predicate nor an odd-tile-count select (round 6)
+    const bool dot_form = (p->form == F_NEGDOT || p->form == F_SQM) && p->xform == X_NONE;
+    if (dot_form) p->Kpad = (p->K + 15) / 16 * 16;
     size_t off = 0;
     char* base = (char*)ws;
     auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += align256(bytes); return q; };
     p->table_stride = p->ntiles * p->Kpad * 64;
-    p->cand = (float*)take((size_t)tables * p->table_stride * sizeof(float));
+    p->cand = (float*)take(((size_t)tables * p->table_stride + (dot_form ? (size_t)p->Kpad * 64 : 0)) * sizeof(float));
     p->aux = (float*)take((size_t)p->ntiles * 64 * sizeof(float));
     p->qvec = (float*)take((size_t)2 * n * p->QV * p->Kpad * sizeof(float));
     p->qscale = (float*)take((size_t)2 * n * sizeof(float));
@@ -1179,6 +1183,31 @@ __global__ __launch_bounds__(256) void k_eval_qnorm(const float* __restrict__ qv
     if (lane == 0) qn[q] = n2;
 }
 
+// XCD-aware split of the (query tile, candidate tile) grid of k_eval_gemm: per XCD `a` whole query tiles x S candidate splits, plus
+// the left-over query tiles in m parts per XCD; xcd = 0: the flat numbering of rounds 2-5 (query tile = block % qtiles)
+struct GemmSplit { int xcd, a, S, m; };
+static GemmSplit gemm_split(int qtiles, int64_t ctiles, int slots_per_xcd, unsigned* grid, int S_flat) {
+    GemmSplit g{0, 0, 0, 0};
+    const int sw = switch_value("EVAL_GEMM_XCD");
+    if (sw == 0) { *grid = (unsigned)(qtiles * S_flat); return g; }
+    const int a = qtiles / 8, r = qtiles % 8;
+    const int smax = (int)(ctiles < slots_per_xcd ? ctiles : slots_per_xcd);
+    for (int S = smax; S >= 1; --S) {
+        int m = 0;
+        if (r) {
+            m = a ? (S + 7) / 8 : (int)((ctiles + 7) / 8 < slots_per_xcd / r ? (ctiles + 7) / 8 : slots_per_xcd / r);
+            if (m < 1) m = 1;
+        }
+        if (a * S + r * m <= slots_per_xcd || S == 1) {
+            g.xcd = 1; g.a = a; g.S = a ? S : 0; g.m = m;
+            *grid = (unsigned)(8 * (g.a * g.S + r * m));
+            return g;
+        }
+    }
+    *grid = (unsigned)(qtiles * S_flat);
+    return g;
+}
+
 // (four workgroups per CU for the dot form; the squared-distance epilogue needs ~20 more registers: three per CU, no spills)
 // (with the running totals of KGE_GEMM_CHUNK: 64 more registers per lane, two workgroups per CU)
 template <bool WRITE, int POST, bool SQM>
@@ -1187,14 +1216,24 @@ template <bool WRITE, int POST, bool SQM>
 #endif
 __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __restrict__ cand, const float* __restrict__ qT,
                                                    const float* __restrict__ st, int64_t nq, int64_t E, int64_t ntiles64,
-                                                   int Kpad, int qtiles, int S, int32_t* __restrict__ rcount,
+                                                   int Kpad, int qtiles, int S, GemmSplit gs, int32_t* __restrict__ rcount,
                                                    int32_t* __restrict__ tcount, float* __restrict__ scores_out, const float* __restrict__ qn,
                                                    const float* __restrict__ cn, float margin) {
     __shared__ float sA[2][GKS][GLD], sB[2][GKS][GLD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;   // wave's 64 x 64 sub-tile: candidate rows wr, query columns wc
-    const int qt = blockIdx.x % qtiles, sp = blockIdx.x / qtiles;
     const int64_t ctiles = (ntiles64 + 1) / 2;   // 128-candidate tiles
+    // workgroup -> (query tile, candidate tiles ct0, ct0 + cstride, ...).  Round 6: XCD-aware (GemmSplit): consecutive block ids go round
+    // the 8 XCDs, each with its own 4 MB L2, so XCD x takes the query tiles x, x + 8, ... -- a handful of tiles that STAY in its L2 --
+    // and its workgroups of one candidate split sweep the same candidate tile at the same time: a candidate tile is fetched once per
+    // XCD instead of once per (XCD, few query tiles).  The qtiles % 8 left-over query tiles are cut across all XCDs by candidate range.
+    int qt, ct0, cstride;
+    if (gs.xcd) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        if (j < gs.a * gs.S) { qt = x + 8 * (j % gs.a); ct0 = j / gs.a; cstride = gs.S; }
+        else { const int j2 = j - gs.a * gs.S; qt = 8 * gs.a + j2 / gs.m; ct0 = x * gs.m + j2 % gs.m; cstride = 8 * gs.m; }
+    } else { qt = blockIdx.x % qtiles; ct0 = blockIdx.x / qtiles; cstride = S; }
+    const int sp = ct0;
     // staging role: float4 number t + 256 j of a slab = (k = idx / 32, 4 columns at 4 * (idx % 32))
     int sk[GNJ], sc4[GNJ];
 #pragma unroll
@@ -1233,32 +1272,33 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
     // ONE software pipeline over all (candidate tile, K slab) steps of this workgroup: the loads of step g + 1 -- which may
     // be the first slab of the NEXT candidate tile -- are in flight while step g runs on the matrix cores, so there is no
     // fill / drain bubble at tile boundaries; LDS buffers alternate across the whole sequence (one barrier per step)
-    const int64_t my_tiles = sp < ctiles ? (ctiles - sp + S - 1) / S : 0;
+    const int64_t my_tiles = sp < ctiles ? (ctiles - sp + cstride - 1) / cstride : 0;
     const int64_t nsteps = my_tiles * nslab;
-    float4 ra[GNJ], rb[GNJ];
+    typedef float gvec4 __attribute__((ext_vector_type(4)));   // (a native vector: a float4 STRUCT copy from global memory is a memcpy the
+    gvec4 ra[GNJ], rb[GNJ];                                      //  optimiser kept in scratch once the loads became unconditional)
     int64_t ld_ct = sp, cu_ct = sp;   // candidate tile / slab of the next load step and of the current compute step (steps are
     int ld_sl = 0, cu_sl = 0;         // visited in order: counters instead of a 64-bit division per step)
     // a lane's two float4 of a slab sit at FIXED offsets from a base that is the same for the whole workgroup: scalar base
     // (advanced by one slab, or re-pointed at the next candidate tile pair) + 32-bit lane offset, no per-step address arithmetic
-    int la[GNJ], la0[GNJ], lq[GNJ];
+    int la[GNJ], lq[GNJ];
 #pragma unroll
     for (int j = 0; j < GNJ; ++j) {
-        la0[j] = sk[j] * 64 + (sc4[j] & 15) * 4;                 // inside the first 64-candidate tile of the pair
-        la[j] = (sc4[j] >> 4) * Kpad * 64 + la0[j];              // two 64-candidate tiles of the sweep layout side by side
+        la[j] = (sc4[j] >> 4) * Kpad * 64 + sk[j] * 64 + (sc4[j] & 15) * 4;   // two 64-candidate tiles of the sweep layout side by side
         lq[j] = sk[j] * GT + sc4[j] * 4;
     }
     const float* ld_c = cand + ld_ct * 2 * Kpad * 64;
     const float* ld_q = qsrc;
-    auto load_step = [&]() {
-        const bool pair = ld_ct * 2 + 1 < ntiles64;   // odd tile count: the last pair repeats its first tile (masked in the epilogue)
-        const int krem = Kpad - ld_sl * GKS;
+    // (round 6: the counters put as many plain VALU instructions as MFMAs into this loop -- zero fills, selects and 64-bit address
+    //  arithmetic of predicated loads -- and every one of them costs the in-order wave issue slots between its MFMAs.  Kpad is a whole
+    //  number of slabs and a spare tile follows the tables (make_plan), so a step's loads are unconditional: scalar base + fixed lane
+    //  offset.  An odd tile count leaves garbage in the rows of the last pair's second half: rows e >= E, masked in the epilogue.)
+    auto load_step = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < GNJ; ++j) {
-            const bool live = sk[j] < krem;
-            ra[j] = live ? *reinterpret_cast<const float4*>(ld_c + (pair ? la[j] : la0[j])) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[j] = live ? *reinterpret_cast<const float4*>(ld_q + lq[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[j] = *reinterpret_cast<const gvec4*>(ld_c + (unsigned)la[j]);
+            rb[j] = *reinterpret_cast<const gvec4*>(ld_q + (unsigned)lq[j]);
         }
-        if (++ld_sl == nslab) { ld_sl = 0; ld_ct += S; ld_c = cand + ld_ct * 2 * Kpad * 64; ld_q = qsrc; }
+        if (++ld_sl == nslab) { ld_sl = 0; ld_ct += cstride; ld_c = cand + ld_ct * 2 * Kpad * 64; ld_q = qsrc; }
         else { ld_c += GKS * 64; ld_q += GKS * GT; }
     };
 #ifdef KGE_GEMM_32X32
@@ -1272,8 +1312,8 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
     for (int64_t g = 0; g < nsteps; ++g) {
 #pragma unroll
         for (int j = 0; j < GNJ; ++j) {
-            *reinterpret_cast<float4*>(&sA[buf][sk[j]][sc4[j] * 4]) = ra[j];
-            *reinterpret_cast<float4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
+            *reinterpret_cast<gvec4*>(&sA[buf][sk[j]][sc4[j] * 4]) = ra[j];
+            *reinterpret_cast<gvec4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
         }
         __syncthreads();   // step g is in LDS; everybody finished reading the buffer that is written next
         if (g + 1 < nsteps) load_step();
@@ -1300,7 +1340,7 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
         // ---- last slab of a candidate tile: epilogue.  energy = -dot (+ post-op); the lane owns query column (ni, li),
         // its 16 registers per block are candidate rows
         const int64_t ct = cu_ct;
-        cu_ct += S;
+        cu_ct += cstride;
         const int e_base = (int)(ct * GT) + wr * 64 + 4 * lk;   // candidate ids fit 31 bits (packed keys: < 2^24)
         const int e_lim = (int)E;
         const bool full = ct * GT + GT <= E && (ct * 2 + 1 < ntiles64);
@@ -1351,12 +1391,14 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) { acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     if (nsteps > 0) load_step();
-    int buf = 0;
-    for (int64_t g = 0; g < nsteps; ++g) {
+    // (the LDS buffer of a step is a compile-time constant: its addresses are one lane base + immediates.  A register ring of two slabs
+    //  in flight was measured on the way -- no gain, profiles/r06_experiments.md section 9)
+    auto body = [&](auto buf_, int64_t g) __attribute__((always_inline)) {
+        constexpr int buf = decltype(buf_)::value;
 #pragma unroll
         for (int j = 0; j < GNJ; ++j) {
-            *reinterpret_cast<float4*>(&sA[buf][sk[j]][sc4[j] * 4]) = ra[j];
-            *reinterpret_cast<float4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
+            *reinterpret_cast<gvec4*>(&sA[buf][sk[j]][sc4[j] * 4]) = ra[j];
+            *reinterpret_cast<gvec4*>(&sB[buf][sk[j]][sc4[j] * 4]) = rb[j];
         }
         __syncthreads();   // step g is in LDS; everybody finished reading the buffer that is written next
         if (g + 1 < nsteps) load_step();
@@ -1397,19 +1439,18 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
                     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi], b4[ni], acc[mi][ni], 0, 0, 0);
             }
         }
-        buf ^= 1;
         if (c_last) {   // the chunk is complete: its chains join the running totals (32 packed adds per lane)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) tot[mi][ni] += acc[mi][ni];
         }
-        if (++cu_sl != nslab) continue;
+        if (++cu_sl != nslab) return;
         cu_sl = 0;
         // ---- last slab of a candidate tile: epilogue.  energy = -dot (+ post-op); the lane owns query column (ni, lcol), its 4
         // registers per block are candidate rows 4 * lk4 + reg of block mi
         const int64_t ct = cu_ct;
-        cu_ct += S;
+        cu_ct += cstride;
         // candidate ids fit 31 bits (packed keys: < 2^24); MFMA block row 4 lk4 + reg of block mi = candidate row 4 (4 lk4 + reg) + mi
         const int e_base = (int)(ct * GT) + wr * 64 + 16 * lk4;
         const int e_lim = (int)E;
@@ -1441,6 +1482,10 @@ __global__ __launch_bounds__(256, KGE_GEMM_OCC) void k_eval_gemm(const float* __
                 if constexpr (kGemmChunk > 0) tot[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};   // (acc restarts from the constant 0)
                 else acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+    };
+    for (int64_t g = 0; g < nsteps; g += 2) {
+        body(std::integral_constant<int, 0>{}, g);
+        if (g + 1 < nsteps) body(std::integral_constant<int, 1>{}, g + 1);
     }
     if constexpr (!WRITE) {
 #pragma unroll
@@ -1572,7 +1617,7 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
     if (S < 1) S = 1;
     const unsigned grid = (unsigned)(qgroups * 256 * S);
     if constexpr ((FORM == F_NEGDOT || FORM == F_SQM) && XFORM == X_NONE && POST != P_SCALE) {
-        if (qdesc == nullptr && p.qT != nullptr && use_gemm_sweep(p, nq)) {   // the dot-product based sweeps on the matrix cores
+        if (qdesc == nullptr && p.qT != nullptr && p.Kpad % GKS == 0 && use_gemm_sweep(p, nq)) {   // the dot-product based sweeps on the matrix cores
             constexpr bool SQM = FORM == F_SQM;
             const int qtiles = (int)((nq + GT - 1) / GT);
             const int64_t ctiles = (p.ntiles + 1) / 2;
@@ -1581,6 +1626,8 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
             int64_t S2 = ((KGE_GEMM_OCC) * 256) / qtiles;
             if (S2 > ctiles) S2 = ctiles;
             if (S2 < 1) S2 = 1;
+            unsigned ggrid = 0;
+            const GemmSplit gs = gemm_split(qtiles, ctiles, (KGE_GEMM_OCC) * 32, &ggrid, (int)S2);
             hipLaunchKernelGGL(k_eval_qt, dim3((unsigned)(qtiles * 2), (unsigned)((p.Kpad + 63) / 64)), dim3(256), 0, s, p.qvec, nq,
                                p.Kpad, p.qT);
             if (SQM)   // |q|^2 per query (p.qscale is free in this form); |c|^2 per candidate was left in p.aux by k_eval_prepare
@@ -1591,11 +1638,11 @@ static void launch_tf_and_sweep(const EvalPlan& p, const kge_model_desc* m, cons
                 hipLaunchKernelGGL((k_eval_target_filter_chain<FORM, POST>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, pa, p.aux,
                                    p.qvec, p.qscale, triples, p.n, p.Kpad, m->margin, tail_off, tail_ids, head_off, head_ids, p.st,
                                    p.fcount, p.only);
-                hipLaunchKernelGGL((k_eval_gemm<false, POST, SQM>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
-                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, p.tcount, nullptr, p.qscale, p.aux, m->margin);
+                hipLaunchKernelGGL((k_eval_gemm<false, POST, SQM>), dim3(ggrid), dim3(256), 0, s, p.cand, p.qT, p.st,
+                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, gs, p.rcount, p.tcount, nullptr, p.qscale, p.aux, m->margin);
             } else {
-                hipLaunchKernelGGL((k_eval_gemm<true, POST, SQM>), dim3((unsigned)(qtiles * S2)), dim3(256), 0, s, p.cand, p.qT, p.st,
-                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, p.rcount, nullptr, scores_out, p.qscale, p.aux, m->margin);
+                hipLaunchKernelGGL((k_eval_gemm<true, POST, SQM>), dim3(ggrid), dim3(256), 0, s, p.cand, p.qT, p.st,
+                                   nq, p.E, p.ntiles, p.Kpad, qtiles, (int)S2, gs, p.rcount, nullptr, scores_out, p.qscale, p.aux, m->margin);
             }
             return;
         }
