@@ -1225,6 +1225,39 @@ def test_rescal_staged_entity_gradients_are_reproducible_and_equal_the_atomic_st
     assert off <= 2e-3, (off, float((pa - pc).abs().max()))
 
 
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipGraph"])
+@pytest.mark.parametrize("opt", ["adam", "sgd", "adagrad", "rms"])
+def test_rescal_optimizer_rider_is_bit_identical_to_the_separate_launches(hip, monkeypatch, opt, use_graph):
+    """Round 6: kge_optimizer_step_rows_rownorm -- the relation matrices' optimiser riding in the first workgroups of the entity table's
+    row-owner sweep (k_opt_rows4<..., RIDER>) + the rescale launch -- must leave BYTE-IDENTICAL tables and optimiser state to
+    kge_optimizer_step_rows(_staged) followed by kge_optimizer_step_rownorm (KGE_OPT_RIDER=0): same device functions, same order."""
+    from pykg2vec_amd.trainer import Trainer
+    E, R, k, B = 1500, 6, 128, 96          # rel_matrices rows of 16 384 floats: the wide-row form's minimum
+    rng = np.random.default_rng(23)
+    n = 7 * B
+    train = np.stack([rng.integers(E, size=n), rng.integers(R, size=n), rng.integers(E, size=n)], 1)
+    P = ko.init_params("rescal", rng, tot_entity=E, tot_relation=R, hidden_size=k)
+    hp = dict(hidden_size=k, margin=1.0, neg_rate=1)
+    monkeypatch.setenv("KGE_RESCAL_FUSED", "1")
+    out = []
+    for rider in ("1", "0"):
+        monkeypatch.setenv("KGE_OPT_RIDER", rider)
+        cfg = hip.make_config(E, R, hp, train, train[:4], train[:4], optimizer=opt, lr=0.01, batch_size=B)
+        tr = Trainer(hip.model_from_params("rescal", P, hp, E, R, train=train), cfg, use_graph=use_graph)
+        tr.build_model()
+        tr.generator = tr._new_generator()
+        losses = [tr.train_model_epoch(e) for e in range(2)]
+        assert tr.rescal_reproducible in (True, None) or getattr(tr, "_rescal_stage", None) is None
+        out.append((losses, tr.flat.param.clone(), None if tr.flat.state1 is None else tr.flat.state1.clone(),
+                    None if tr.flat.state2 is None else tr.flat.state2.clone()))
+    (la, pa, sa, ta), (lb, pb, sb, tb) = out
+    if getattr(tr, "rescal_reproducible", None):      # (the pair step itself is run-to-run reproducible on this graph: then so is the whole)
+        assert np.allclose(la, lb, rtol=1e-6)      # (the epoch loss is summed over slots with float atomics: equal to rounding)
+        assert torch.equal(pa, pb) and (sa is None or torch.equal(sa, sb)) and (ta is None or torch.equal(ta, tb))
+    else:
+        assert np.allclose(la, lb, rtol=1e-5) and torch.allclose(pa, pb, atol=1e-5)
+
+
 def test_rescal_staged_lists_are_emptied_when_an_epoch_dies_between_pair_step_and_optimiser(hip, monkeypatch):
     """The staged RESCAL gradients live in per-entity lists that the pair step fills and the row-owner optimiser consumes and resets.
     An exception between the two (here: the optimiser call of the second batch raises) must not leave registrations behind:
