@@ -696,6 +696,11 @@ typedef struct kge_staged_step {
     int32_t static_slots, dynamic_slots;
     int64_t n_pos, n_neg;                               /* positives / negative pairs of the batch */
     int64_t tot_entity, tot_relation;
+    int32_t stage_spare;                                /* round 6.  != 0: the caller padded stage_stride to the width the bundle's waves
+                                                           cover (1 024 floats for rows of 513..1 024, 2 048 beyond) AND left static_slots +
+                                                           dynamic_slots spare rows behind the n_pos * static_slots + n_neg * dynamic_slots
+                                                           used ones: the RotatE bundle kernel then stores without predicates (lanes beyond
+                                                           a row write its padding, a missing last bundle the spare rows).  0: tight rows */
 } kge_staged_step;
 size_t kge_staged_step_bytes(void);
 

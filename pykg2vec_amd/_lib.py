@@ -118,7 +118,7 @@ class StagedStep(ctypes.Structure):
                 ("stage", ctypes.c_void_p), ("stage_stride", ctypes.c_int64),
                 ("static_slots", ctypes.c_int32), ("dynamic_slots", ctypes.c_int32),
                 ("n_pos", ctypes.c_int64), ("n_neg", ctypes.c_int64),
-                ("tot_entity", ctypes.c_int64), ("tot_relation", ctypes.c_int64)]
+                ("tot_entity", ctypes.c_int64), ("tot_relation", ctypes.c_int64), ("stage_spare", ctypes.c_int32)]
 
 
 _SIGNATURES = {

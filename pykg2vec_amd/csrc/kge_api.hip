@@ -302,6 +302,7 @@ static int staged_sink(const kge_model_desc* m, const kge_staged_step* st, int64
     sink->count = st->dyn_count; sink->bucket = st->dyn_bucket; sink->head = st->dyn_head; sink->next = st->dyn_next;
     sink->cap = st->dyn_cap; sink->ns = st->static_slots; sink->nd = st->dynamic_slots;
     sink->dyn_list = st->dyn_list;
+    sink->spare = st->stage_spare;
     return 0;
 }
 

@@ -79,6 +79,7 @@ struct StageSink {
     int32_t* count; int32_t* bucket; int32_t* head; int32_t* next; int32_t cap;
     int32_t ns, nd;
     int32_t* dyn_list;   // optional [n_neg]: entry p = the entity pair p drew if p was that entity's FIRST registrant, else -1
+    int32_t spare;       // != 0: ns + nd spare rows follow the used ones (rows padded to the bundle's width: unconditional stores)
 };
 __device__ __forceinline__ void stage_register(const StageSink& k, int c, int pair) {
     const int pos = atomicAdd(k.count + c, 1);

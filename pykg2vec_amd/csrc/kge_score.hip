@@ -617,7 +617,7 @@ __global__ __launch_bounds__(kBlock) void k_rotate_bundle_staged(DeviceModel m, 
 // mathematics; the energy is the sum of two half-row sums instead of one 64-lane butterfly over the whole row.
 // (Splitting the NEGATIVES over two waves instead keeps all eleven rows per wave: 626 spilled registers at two waves per SIMD.)
 // (waves per SIMD the register budget is sized for: a wave owning 8 chunks of every row needs ~256 registers whatever the split)
-template <int NCH, int SPLIT>
+template <int NCH, int SPLIT, bool PAD>
 __global__ __launch_bounds__(kBlock, NCH >= 8 ? 2 : SPLIT) void k_rotate_bundle_staged_split(DeviceModel m, int64_t n_pos, int neg_rate, float alpha,
                                                                           float* __restrict__ loss, FusedSampler fs, StageSink sink,
                                                                           float* __restrict__ pair_scale) {
@@ -633,6 +633,9 @@ __global__ __launch_bounds__(kBlock, NCH >= 8 ? 2 : SPLIT) void k_rotate_bundle_
     const float inv_b = 1.0f / (float)n_pos;
     float acc = 0.f;
     int par = 0;
+    // stage rows as wide as the SPLIT waves cover, ns + nd spare rows behind the n_pos * (ns + nd * neg_rate) used ones (StagedPlan)
+    constexpr bool padded = PAD;     // (chosen at launch: sink.stride >= SPLIT * HALF and sink.spare)
+    float* const spare = sink.stage + (n_pos * sink.ns + n_pos * (int64_t)neg_rate * sink.nd) * sink.stride + ho;
     for (int64_t i0 = (int64_t)blockIdx.x * BPB; i0 < n_pos; i0 += (int64_t)gridDim.x * BPB) {
         const int64_t i = i0 + slot_b;
         const bool valid = i < n_pos;
@@ -649,14 +652,29 @@ __global__ __launch_bounds__(kBlock, NCH >= 8 ? 2 : SPLIT) void k_rotate_bundle_
             }
         }
         const int dv = valid ? dh : 0;         // (an invalid bundle loads and stores nothing but keeps the barriers)
+        // Round 6: where the stage rows are padded to the width the bundle's waves cover (`padded`) every gradient store is
+        // UNCONDITIONAL (lanes beyond the row write the row's padding; an invalid bundle writes the spare rows behind the stage) and the
+        // negatives register behind the loop.  With every store in its own predicated region (store_row) the loop's memory operations
+        // could not be counted, and the wait in front of the prefetched negative was an s_waitcnt vmcnt(0): it drained the previous
+        // iteration's 16 stores as well.  Same lanes, same elements, same arithmetic: bit-identical results.  (Unconditional clamped
+        // LOADS as well were measured: 256 VGPRs + spills, C3 step 217 -> 275 us.)
+        auto ld = [&](float (&x)[NCH], const float* __restrict__ row) __attribute__((always_inline)) { load_row<G, NCH>(x, row, dv, gl); };
+        auto st = [&](float* __restrict__ row, const float (&g)[NCH]) __attribute__((always_inline)) {
+            if constexpr (padded) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) row[c * G + gl] = g[c];
+            } else {
+                store_row<G, NCH>(row, g, dv, gl);
+            }
+        };
         float HR[NCH], HI[NCH], TR[NCH], TI[NCH], CS[NCH], SN[NCH];
         {
             float RL[NCH];
-            load_row<G, NCH>(HR, m.tab[0] + h * (int64_t)d + ho, dv, gl);
-            load_row<G, NCH>(HI, m.tab[1] + h * (int64_t)d + ho, dv, gl);
-            load_row<G, NCH>(RL, m.tab[2] + r * (int64_t)d + ho, dv, gl);
-            load_row<G, NCH>(TR, m.tab[0] + t * (int64_t)d + ho, dv, gl);
-            load_row<G, NCH>(TI, m.tab[1] + t * (int64_t)d + ho, dv, gl);
+            ld(HR, m.tab[0] + h * (int64_t)d + ho);
+            ld(HI, m.tab[1] + h * (int64_t)d + ho);
+            ld(RL, m.tab[2] + r * (int64_t)d + ho);
+            ld(TR, m.tab[0] + t * (int64_t)d + ho);
+            ld(TI, m.tab[1] + t * (int64_t)d + ho);
 #pragma unroll
             for (int k = 0; k < NCH; ++k) sincosf(RL[k] / m.phase_div, &SN[k], &CS[k]);
         }
@@ -667,8 +685,8 @@ __global__ __launch_bounds__(kBlock, NCH >= 8 ? 2 : SPLIT) void k_rotate_bundle_
         float NR[NCH], NI[NCH];
         {
             const int64_t c0 = __shfl(my_c, 0, 64);
-            load_row<G, NCH>(NR, m.tab[0] + c0 * (int64_t)d + ho, dv, gl);
-            load_row<G, NCH>(NI, m.tab[1] + c0 * (int64_t)d + ho, dv, gl);
+            ld(NR, m.tab[0] + c0 * (int64_t)d + ho);
+            ld(NI, m.tab[1] + c0 * (int64_t)d + ho);
         }
         for (int j = 0; j < neg_rate; ++j) {
             const int64_t c = __shfl(my_c, j, 64);
@@ -678,8 +696,8 @@ __global__ __launch_bounds__(kBlock, NCH >= 8 ? 2 : SPLIT) void k_rotate_bundle_
             for (int k = 0; k < NCH; ++k) { CR[k] = NR[k]; CI[k] = NI[k]; }
             if (j + 1 < neg_rate) {
                 const int64_t cn1 = __shfl(my_c, j + 1, 64);
-                load_row<G, NCH>(NR, m.tab[0] + cn1 * (int64_t)d + ho, dv, gl);
-                load_row<G, NCH>(NI, m.tab[1] + cn1 * (int64_t)d + ho, dv, gl);
+                ld(NR, m.tab[0] + cn1 * (int64_t)d + ho);
+                ld(NI, m.tab[1] + cn1 * (int64_t)d + ho);
             }
             __builtin_amdgcn_sched_barrier(0);
             float re[NCH], im[NCH], p = 0.f;
@@ -726,11 +744,15 @@ __global__ __launch_bounds__(kBlock, NCH >= 8 ? 2 : SPLIT) void k_rotate_bundle_
                 }
             }
             const int64_t pair = i * neg_rate + j;
-            float* slot = sink.stage + (n_pos * sink.ns + pair * sink.nd) * sink.stride + ho;
-            store_row<G, NCH>(slot, gCR, dv, gl);
-            store_row<G, NCH>(slot + sink.stride, gCI, dv, gl);
-            if (valid && half == 0 && gl == 0) stage_register(sink, (int)c, (int)pair);
+            float* slot = (valid || !padded) ? sink.stage + (n_pos * sink.ns + pair * sink.nd) * sink.stride + ho : spare + sink.ns * sink.stride;
+            st(slot, gCR);
+            st(slot + sink.stride, gCI);
+            if constexpr (!padded) { if (valid && half == 0 && gl == 0) stage_register(sink, (int)c, (int)pair); }
         }
+        // padded form: the negatives' rows register with their entities behind the loop, one lane per negative (inside it the returning
+        // atomics made the loop's memory-operation count path dependent; the owners sum in ascending slot order whatever order these
+        // arrive in).  The tight-row form keeps the registration where it was: there it measured faster (217 vs 245 us per C3 step).
+        if constexpr (padded) { if (valid && half == 0 && gl < neg_rate) stage_register(sink, my_c, (int)(i * neg_rate + gl)); }
         const float cn = -inv_b / D;
         if (valid && half == 0 && gl < neg_rate) pair_scale[i * neg_rate + gl] = expf(m_mine - M) * cn;
         float p0 = 0.f, re0[NCH], im0[NCH];
@@ -760,12 +782,12 @@ __global__ __launch_bounds__(kBlock, NCH >= 8 ? 2 : SPLIT) void k_rotate_bundle_
             gTI[k] = -Ii + cn * aTI[k];
             GP[k] = (Rr * (-HR[k] * SN[k] - HI[k] * CS[k]) + Ii * (HR[k] * CS[k] - HI[k] * SN[k]) + cn * aP[k]) / m.phase_div;
         }
-        float* slot = sink.stage + i * sink.ns * sink.stride + ho;
-        store_row<G, NCH>(slot, gHR, dv, gl);
-        store_row<G, NCH>(slot + sink.stride, gHI, dv, gl);
-        store_row<G, NCH>(slot + 2 * sink.stride, GP, dv, gl);
-        store_row<G, NCH>(slot + 3 * sink.stride, gTR, dv, gl);
-        store_row<G, NCH>(slot + 4 * sink.stride, gTI, dv, gl);
+        float* slot = (valid || !padded) ? sink.stage + i * sink.ns * sink.stride + ho : spare;
+        st(slot, gHR);
+        st(slot + sink.stride, gHI);
+        st(slot + 2 * sink.stride, GP);
+        st(slot + 3 * sink.stride, gTR);
+        st(slot + 4 * sink.stride, gTI);
     }
     block_accumulate_loss<G>(acc, gl, loss);
 }
@@ -871,12 +893,18 @@ int launch_rotate_bundle_sampled(const kge_model_desc* m, const int64_t* triples
         const int sp = wide ? 4 : split;
         int64_t b = (n_pos * sp + 3) / 4;
         if (b > kMaxBlocks) b = kMaxBlocks;
-#define KGE_RS(NCH_, SP_) k_rotate_bundle_staged_split<NCH_, SP_><<<dim3((unsigned)b), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs, *sink, pair_scale)
-        if (wide) KGE_RS(8, 4);
-        else if (geo.NCH == 8 && split == 2) KGE_RS(4, 2);
-        else if (geo.NCH == 8) KGE_RS(2, 4);
-        else if (split == 2) KGE_RS(8, 2);
-        else KGE_RS(4, 4);
+#define KGE_RS(NCH_, SP_)                                                                                                                  \
+        {                                                                                                                                  \
+            if (sink->spare && sink->stride >= (int64_t)64 * NCH_ * SP_)                                                                   \
+                k_rotate_bundle_staged_split<NCH_, SP_, true><<<dim3((unsigned)b), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs, *sink, pair_scale);  \
+            else                                                                                                                           \
+                k_rotate_bundle_staged_split<NCH_, SP_, false><<<dim3((unsigned)b), dim3(kBlock), 0, s>>>(dm, n_pos, neg_rate, alpha, loss, fs, *sink, pair_scale); \
+        }
+        if (wide) KGE_RS(8, 4)
+        else if (geo.NCH == 8 && split == 2) KGE_RS(4, 2)
+        else if (geo.NCH == 8) KGE_RS(2, 4)
+        else if (split == 2) KGE_RS(8, 2)
+        else KGE_RS(4, 4)
 #undef KGE_RS
         return check_launch("k_rotate_bundle_staged_split");
     }

@@ -4,6 +4,7 @@ PyTorch is used here only for device memory and the current HIP stream; all arit
 libkge_hip.so.  Every function raises if a tensor is not a contiguous tensor on a HIP device.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -274,6 +275,13 @@ class StagedPlan:
         self.ns, self.nd, self.neg_rate, self.max_pos = ns, nd, int(neg_rate), int(max_pos)
         self.stride = (int(dim) + 3) // 4 * 4
         n_slots = self.max_pos * (ns + nd * self.neg_rate)
+        # RotatE rows of more than 512 floats (a bundle's rows over 2 or 4 waves, csrc/kge_score.hip: k_rotate_bundle_staged_split): rows
+        # padded to the width the waves cover + one spare slot set behind the used ones -> the kernel's stores carry no predicates
+        # (kge_staged_step.stage_spare, round 6)
+        self.spare = kernel_name == "rotate" and int(dim) > 512 and os.environ.get("KGE_STAGE_SPARE") != "0"   # (=0: tight rows, A/B)
+        if self.spare:
+            self.stride = 1024 if int(dim) <= 1024 else 2048
+            n_slots += ns + nd
         self.stage = torch.empty(n_slots * self.stride, dtype=torch.float32, device=dev)
         # sparse (SGD / Adagrad with touched-row lists): ONE registration set, count | head back to back so that
         # the train entry point clears it with one memset; the sweep then visits only rows that have a slot.
@@ -301,6 +309,7 @@ class StagedPlan:
         c.n_tables, c.dim = len(sites), int(dim)
         c.dyn_bucket, c.dyn_next, c.dyn_cap = self.bucket.data_ptr(), self.next.data_ptr(), STAGED_CAP
         c.stage, c.stage_stride = self.stage.data_ptr(), self.stride
+        c.stage_spare = 1 if self.spare else 0
         self.dyn_scale = torch.ones(self.max_pos * self.neg_rate, dtype=torch.float32, device=dev) if kernel_name == "rotate" else None
         c.dyn_scale = self.dyn_scale.data_ptr() if self.dyn_scale is not None else None
         c.static_slots, c.dynamic_slots = ns, nd
