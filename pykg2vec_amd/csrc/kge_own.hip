@@ -345,7 +345,10 @@ __global__ __launch_bounds__(kBlock, KGE_OWN_WAVES) void k_own_step(OwnArgs a, P
 #pragma unroll
                 for (int t = 0; t < NT; ++t) load_row_e<VEC, G, NV>(r[t], st + t * RSE, d, gl);
             };
-            constexpr int kBatch = 4;     // visits whose rows are requested before the first is added
+#ifndef KGE_OWN_BATCH
+#define KGE_OWN_BATCH 4
+#endif
+            constexpr int kBatch = KGE_OWN_BATCH;     // visits whose rows are requested before the first is added
             for (int v0 = 0; v0 < nvis; v0 += kBatch) {
                 float r[kBatch][NT][NE];
 #pragma unroll
