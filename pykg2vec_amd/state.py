@@ -102,7 +102,8 @@ class FlatState:
         cut = self.offsets[1] if len(self.offsets) > 1 else self.numel
         sl = lambda buf, a, b: buf[a:b] if buf is not None else None
         hyper = advance[0] if advance is not None else None
-        if rest_rownorm is not None and normalize and rider and hasattr(self.K, "optimizer_step_rows_rownorm"):
+        if (rest_rownorm is not None and normalize and rider and hasattr(self.K, "optimizer_step_rows_rownorm")
+                and dim % 4 == 0 and dim <= 1024):     # (the rider form exists for rows of float4s only: k_opt_rows4)
             # RESCAL: the relation matrices' optimiser rides in the first workgroups of the entity table's sweep, one rescale launch
             # follows (kge_optimizer_step_rows_rownorm, round 6: two launches instead of three, bit-identical tables)
             r_rows, r_dim = rest_rownorm
