@@ -1256,7 +1256,11 @@ def test_rescal_optimizer_rider_is_bit_identical_to_the_separate_launches(hip, m
         assert np.allclose(la, lb, rtol=1e-6)      # (the epoch loss is summed over slots with float atomics: equal to rounding)
         assert torch.equal(pa, pb) and (sa is None or torch.equal(sa, sb)) and (ta is None or torch.equal(ta, tb))
     else:
-        assert np.allclose(la, lb, rtol=1e-5) and torch.allclose(pa, pb, atol=1e-5)
+        # (the atomic pair step differs run to run by rounding, and Adam / RMSprop turn a rounding-residue gradient into a full lr step:
+        #  isolated entries -- the same bar as the staged-vs-atomic test above)
+        assert np.allclose(la, lb, rtol=5e-4), (la, lb)
+        off = float((~torch.isclose(pa, pb, atol=2e-4, rtol=1e-3)).float().mean())
+        assert off <= 2e-3, (off, float((pa - pb).abs().max()))
 
 
 def test_rescal_staged_lists_are_emptied_when_an_epoch_dies_between_pair_step_and_optimiser(hip, monkeypatch):
